@@ -1,0 +1,1231 @@
+/* go1_oracle.c — CPU ORACLE (test infrastructure, NOT a product path).
+ *
+ * fp64 restatement of the Go1 vectorised step behind `LeggedRobot.step`
+ * (reference: go1_gym/envs/base/legged_robot.py:60-136).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may call it; the shipped path is the HIP library and it
+ * fails loudly when that library is missing.
+ *
+ * PARITY STATUS
+ *   - tensor maps (torque model, derived state, gait clock, termination, rewards, observations):
+ *     PINNED against the reference's own Python executed by method borrowing
+ *     (tests/golden/make_golden.py -> tests/golden/ .npz files, tests/test_oracle_golden.py).
+ *   - physics substep: PARITY UNPINNED.  The reference delegates it to the closed Isaac Gym /
+ *     PhysX binary (legged_robot.py:76-80), which is absent from /root/reference and cannot be
+ *     executed; no golden trajectories exist upstream.  The algorithm below is a
+ *     restatement of the *contract* (same model, dt, limits, contact/friction semantics) and is
+ *     validated by physical invariants (tests/test_oracle_physics.py).
+ *
+ * The physics is deliberately formulated differently from the HIP kernel so that agreement
+ * between the two checks the mathematics, not a shared implementation:
+ *   oracle: classical 3-vector recursive Newton-Euler, dense 18x18 mass matrix from 18 RNEA
+ *           columns, Cholesky solves, dense M^-1 J^T.
+ *   kernel: spatial-algebra articulated-body algorithm (Featherstone ABA), O(n) impulse
+ *           propagation with the ABA factors.
+ * Both then run the identical projected Gauss-Seidel sweep order, so results agree to fp32
+ * round-off.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/go1sim.h"
+#include "../walk-these-ways_amd/csrc/go1_model_data.h"
+#include "../walk-these-ways_amd/csrc/go1_actuator_data.h"
+
+typedef double real;
+#define NV 18
+#define PI 3.14159265358979323846
+
+/* ------------------------------------------------------------------ small vector helpers */
+static inline void v3set(real* a, real x, real y, real z) { a[0] = x; a[1] = y; a[2] = z; }
+static inline void v3cpy(real* a, const real* b) { a[0] = b[0]; a[1] = b[1]; a[2] = b[2]; }
+static inline void v3add(real* o, const real* a, const real* b) { o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2]; }
+static inline void v3sub(real* o, const real* a, const real* b) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+static inline void v3axpy(real* o, real s, const real* a) { o[0] += s * a[0]; o[1] += s * a[1]; o[2] += s * a[2]; }
+static inline real v3dot(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void v3cross(real* o, const real* a, const real* b) {
+  real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static inline real v3norm(const real* a) { return sqrt(v3dot(a, a)); }
+/* o = R (row-major 3x3) * v */
+static inline void m3v(real* o, const real* R, const real* v) {
+  real x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+  real y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+  real z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void m3tv(real* o, const real* R, const real* v) {
+  real x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2];
+  real y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2];
+  real z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void m3m(real* o, const real* A, const real* B) {
+  real t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+  memcpy(o, t, sizeof t);
+}
+/* quaternion xyzw -> rotation matrix (body -> world) */
+static void quat_to_mat(real* R, const real* q) {
+  real x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+/* isaacgym.torch_utils semantics restated from the maths */
+static void quat_rotate(real* o, const real* q, const real* v) {   /* R(q) v */
+  real u[3] = {q[0], q[1], q[2]}, t[3], t2[3];
+  v3cross(t, u, v);
+  v3cross(t2, u, t);
+  for (int i = 0; i < 3; i++) o[i] = v[i] + 2 * q[3] * t[i] + 2 * t2[i];
+}
+static void quat_rotate_inverse(real* o, const real* q, const real* v) {   /* R(q)^T v */
+  real qc[4] = {-q[0], -q[1], -q[2], q[3]};
+  quat_rotate(o, qc, v);
+}
+static void quat_mul(real* o, const real* a, const real* b) {   /* Hamilton product, xyzw */
+  real x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  real y = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+  real z = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+  real w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10 (Salmon et al., SC'11) */
+static inline void mulhilo(uint32_t a, uint32_t b, uint32_t* hi, uint32_t* lo) {
+  uint64_t p = (uint64_t)a * b;
+  *hi = (uint32_t)(p >> 32);
+  *lo = (uint32_t)p;
+}
+void go1_oracle_philox(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4]) {
+  uint32_t c[4] = {ctr_in[0], ctr_in[1], ctr_in[2], ctr_in[3]};
+  uint32_t k0 = key_in[0], k1 = key_in[1];
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0, lo0, hi1, lo1;
+    mulhilo(0xD2511F53u, c[0], &hi0, &lo0);
+    mulhilo(0xCD9E8D57u, c[2], &hi1, &lo1);
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  memcpy(out, c, sizeof c);
+}
+enum { P_NOISE = 1, P_RESET = 2, P_DOFPROPS_CB = 3, P_DOFPROPS_RESET = 4, P_CMD_CB = 5, P_CMD_RESET = 6,
+       P_PUSH = 7, P_GRAVITY = 8 };
+/* uniform [0,1) number `idx` of stream (env, step, purpose) */
+static float rng_uniform(const Go1SimConfig* cfg, uint32_t env_global, int64_t step, uint32_t purpose, uint32_t idx) {
+  uint32_t ctr[4] = {env_global, (uint32_t)step, purpose, idx >> 2};
+  uint32_t key[2] = {(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
+  uint32_t out[4];
+  go1_oracle_philox(ctr, key, out);
+  return (float)(out[idx & 3] >> 8) * (1.0f / 16777216.0f);
+}
+
+/* ------------------------------------------------------------------ per-env working state */
+typedef struct {
+  real pos[3], quat[4], vlin[3], vang[3];  /* root, world */
+  real q[12], qd[12];
+  real mass0;                              /* base mass incl. payload */
+  real com0[3];                            /* base com (= com_displacement, legged_robot.py:671) */
+  real mu, rest;                           /* robot material */
+} Phys;
+
+typedef struct {
+  real R[13][9];       /* body -> world */
+  real p[13][3];       /* body frame origin, world, RELATIVE to base origin */
+  real axis[12][3];    /* joint axis, world */
+  real com[13][3];     /* body com, world, relative to base origin */
+  real Iw[13][9];      /* inertia about com, world axes */
+  real mass[13];
+} Kin;
+
+static void rot_axis(real* R, int axis, real a) {
+  real c = cos(a), s = sin(a);
+  if (axis == 0) { real t[9] = {1, 0, 0, 0, c, -s, 0, s, c}; memcpy(R, t, sizeof t); }
+  else           { real t[9] = {c, 0, s, 0, 1, 0, -s, 0, c}; memcpy(R, t, sizeof t); }
+}
+
+static void kinematics(const Phys* s, Kin* k) {
+  quat_to_mat(k->R[0], s->quat);
+  v3set(k->p[0], 0, 0, 0);
+  for (int leg = 0; leg < 4; leg++) {
+    for (int j = 0; j < 3; j++) {
+      int b = 1 + 3 * leg + j, par = (j == 0) ? 0 : b - 1, ji = b - 1;
+      real r[3] = {GO1_JOINT_ORIGIN[ji][0], GO1_JOINT_ORIGIN[ji][1], GO1_JOINT_ORIGIN[ji][2]};
+      real off[3];
+      m3v(off, k->R[par], r);
+      v3add(k->p[b], k->p[par], off);
+      real ax[3] = {0, 0, 0};
+      ax[GO1_JOINT_AXIS[ji]] = 1;
+      m3v(k->axis[ji], k->R[par], ax);
+      real Rj[9];
+      rot_axis(Rj, GO1_JOINT_AXIS[ji], s->q[ji]);
+      m3m(k->R[b], k->R[par], Rj);
+    }
+  }
+  for (int b = 0; b < 13; b++) {
+    real c[3], I[9];
+    real scale = 1;
+    if (b == 0) {
+      v3cpy(c, s->com0);
+      k->mass[0] = s->mass0;
+      scale = s->mass0 / GO1_BODY_MASS[0];   /* recomputeInertia=True restated as mass-proportional scaling */
+    } else {
+      v3set(c, GO1_BODY_COM[b][0], GO1_BODY_COM[b][1], GO1_BODY_COM[b][2]);
+      k->mass[b] = GO1_BODY_MASS[b];
+    }
+    real cw[3];
+    m3v(cw, k->R[b], c);
+    v3add(k->com[b], k->p[b], cw);
+    const double* i6 = GO1_BODY_INERTIA[b];
+    real Il[9] = {i6[0], i6[1], i6[2], i6[1], i6[3], i6[4], i6[2], i6[4], i6[5]};
+    for (int i = 0; i < 9; i++) Il[i] *= scale;
+    real Rt[9] = {k->R[b][0], k->R[b][3], k->R[b][6], k->R[b][1], k->R[b][4], k->R[b][7], k->R[b][2], k->R[b][5], k->R[b][8]};
+    m3m(I, k->R[b], Il);
+    m3m(k->Iw[b], I, Rt);
+  }
+}
+
+/* Classical recursive Newton-Euler.  Generalised coordinates: [omega(3), v_O(3), qd(12)] with
+ * omega, v_O the base angular velocity / base-origin velocity in WORLD axes; generalised
+ * accelerations are their classical time derivatives.  Output f = M(q) acc + bias(q, vel) - gravity terms,
+ * conjugate to those coordinates (moment about the base origin, force, joint torques). */
+static void rnea(const Kin* k, const real* vel, const real* acc, const real* grav, real* f) {
+  real w[13][3], wd[13][3], a[13][3];   /* angular vel, angular acc, linear acc of body origin */
+  real F[13][3], Nm[13][3];
+  v3set(w[0], 0, 0, 0); v3set(wd[0], acc[0], acc[1], acc[2]);
+  if (vel) v3set(w[0], vel[0], vel[1], vel[2]);
+  for (int i = 0; i < 3; i++) a[0][i] = acc[3 + i] - (grav ? grav[i] : 0);
+  for (int b = 1; b < 13; b++) {
+    int ji = b - 1, par = ((b - 1) % 3 == 0) ? 0 : b - 1;
+    real qd = vel ? vel[6 + ji] : 0, qdd = acc[6 + ji];
+    real d[3], t[3], t2[3];
+    v3sub(d, k->p[b], k->p[par]);
+    /* origin of b is fixed in the parent */
+    v3cross(t, wd[par], d);
+    v3cross(t2, w[par], d);
+    v3cross(t2, w[par], t2);
+    for (int i = 0; i < 3; i++) a[b][i] = a[par][i] + t[i] + t2[i];
+    for (int i = 0; i < 3; i++) w[b][i] = w[par][i] + k->axis[ji][i] * qd;
+    v3cross(t, w[par], k->axis[ji]);
+    for (int i = 0; i < 3; i++) wd[b][i] = wd[par][i] + k->axis[ji][i] * qdd + t[i] * qd;
+  }
+  for (int b = 0; b < 13; b++) {
+    real d[3], t[3], t2[3], ac[3], Iw[3];
+    v3sub(d, k->com[b], k->p[b]);
+    v3cross(t, wd[b], d);
+    v3cross(t2, w[b], d);
+    v3cross(t2, w[b], t2);
+    for (int i = 0; i < 3; i++) ac[i] = a[b][i] + t[i] + t2[i];
+    for (int i = 0; i < 3; i++) F[b][i] = k->mass[b] * ac[i];
+    m3v(Nm[b], k->Iw[b], wd[b]);
+    m3v(Iw, k->Iw[b], w[b]);
+    v3cross(t, w[b], Iw);
+    v3add(Nm[b], Nm[b], t);
+  }
+  /* backward: accumulate force and moment about each body's origin */
+  real fa[13][3], na[13][3];
+  for (int b = 12; b >= 0; b--) {
+    real d[3], t[3];
+    v3cpy(fa[b], F[b]);
+    v3sub(d, k->com[b], k->p[b]);
+    v3cross(t, d, F[b]);
+    v3add(na[b], Nm[b], t);
+    /* children */
+    for (int c = 1; c < 13; c++) {
+      int par = ((c - 1) % 3 == 0) ? 0 : c - 1;
+      if (par != b) continue;
+      v3add(fa[b], fa[b], fa[c]);
+      v3sub(d, k->p[c], k->p[b]);
+      v3cross(t, d, fa[c]);
+      v3add(na[b], na[b], na[c]);
+      v3add(na[b], na[b], t);
+    }
+    if (b == 0) break;
+  }
+  /* the child loop above needs children processed before parents: bodies are numbered so that
+   * children have larger indices, and fa/na of a child are final when its parent is visited. */
+  for (int i = 0; i < 3; i++) { f[i] = na[0][i]; f[3 + i] = fa[0][i]; }
+  for (int ji = 0; ji < 12; ji++) f[6 + ji] = v3dot(k->axis[ji], na[ji + 1]);
+}
+
+/* dense symmetric positive definite solve, in place Cholesky (lower) */
+static int cholesky(real* A, int n) {
+  for (int j = 0; j < n; j++) {
+    real d = A[j * n + j];
+    for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k];
+    if (d <= 0) return -1;
+    d = sqrt(d);
+    A[j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      real s = A[i * n + j];
+      for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = s / d;
+    }
+  }
+  return 0;
+}
+static void chol_solve(const real* L, int n, real* b) {
+  for (int i = 0; i < n; i++) {
+    real s = b[i];
+    for (int k = 0; k < i; k++) s -= L[i * n + k] * b[k];
+    b[i] = s / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    real s = b[i];
+    for (int k = i + 1; k < n; k++) s -= L[k * n + i] * b[k];
+    b[i] = s / L[i * n + i];
+  }
+}
+
+/* ------------------------------------------------------------------ terrain */
+typedef struct { const Go1SimConfig* cfg; const int16_t* hs; } Terrain;
+/* height and unit normal at world (x, y).  Height field: bilinear interpolation of the int16 samples
+ * (same sample convention as _get_heights, legged_robot.py:1793-1806: index = (x + border) / hscale). */
+static void terrain_sample(const Terrain* t, real x, real y, real* h, real* n) {
+  const Go1SimConfig* c = t->cfg;
+  if (c->terrain_type == 0 || !t->hs) { *h = 0; v3set(n, 0, 0, 1); return; }
+  real fx = (x + c->hf_border) / c->hf_hscale, fy = (y + c->hf_border) / c->hf_hscale;
+  if (fx < 0) fx = 0; if (fy < 0) fy = 0;
+  if (fx > c->hf_rows - 1.000001) fx = c->hf_rows - 1.000001;
+  if (fy > c->hf_cols - 1.000001) fy = c->hf_cols - 1.000001;
+  int ix = (int)fx, iy = (int)fy;
+  real ax = fx - ix, ay = fy - iy;
+  real h00 = t->hs[ix * c->hf_cols + iy] * (real)c->hf_vscale, h10 = t->hs[(ix + 1) * c->hf_cols + iy] * (real)c->hf_vscale;
+  real h01 = t->hs[ix * c->hf_cols + iy + 1] * (real)c->hf_vscale, h11 = t->hs[(ix + 1) * c->hf_cols + iy + 1] * (real)c->hf_vscale;
+  *h = h00 * (1 - ax) * (1 - ay) + h10 * ax * (1 - ay) + h01 * (1 - ax) * ay + h11 * ax * ay;
+  real dhdx = ((h10 - h00) * (1 - ay) + (h11 - h01) * ay) / c->hf_hscale;
+  real dhdy = ((h01 - h00) * (1 - ax) + (h11 - h10) * ax) / c->hf_hscale;
+  real nn[3] = {-dhdx, -dhdy, 1};
+  real l = v3norm(nn);
+  v3set(n, nn[0] / l, nn[1] / l, nn[2] / l);
+}
+
+/* ------------------------------------------------------------------ contacts
+ * One contact per reported body (17): the deepest candidate point of its collision shape
+ * (box corners, capsule end spheres, foot sphere) against the terrain.  Candidate lists follow the
+ * URDF collision shapes with replace_cylinder_with_capsule (legged_robot_config.py:232). */
+typedef struct {
+  int active;
+  real x[3];      /* contact point, world, relative to base origin */
+  real n[3], t1[3], t2[3];
+  real phi;       /* signed separation */
+  int dyn_body;   /* dynamic body (0..12) carrying the point */
+} Contact;
+
+static void candidate(const Terrain* ter, const Kin* k, const real* base_pos, int dynb, const real* local, real radius,
+                      Contact* best) {
+  real w[3], x[3];
+  m3v(w, k->R[dynb], local);
+  v3add(x, k->p[dynb], w);
+  real h, n[3];
+  terrain_sample(ter, base_pos[0] + x[0], base_pos[1] + x[1], &h, n);
+  real phi = (base_pos[2] + x[2]) - radius - h;
+  if (!best->active || phi < best->phi) {
+    best->active = 1;
+    best->phi = phi;
+    best->dyn_body = dynb;
+    for (int i = 0; i < 3; i++) best->x[i] = x[i] - radius * n[i];
+    v3cpy(best->n, n);
+  }
+}
+
+static void detect_contacts(const Go1SimConfig* cfg, const Terrain* ter, const Kin* k, const real* base_pos, Contact* C) {
+  for (int b = 0; b < 17; b++) C[b].active = 0;
+  /* trunk box */
+  for (int m = 0; m < 8; m++) {
+    real l[3] = {(m & 1 ? 1 : -1) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1 : -1) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1 : -1) * GO1_TRUNK_BOX_HALF[2]};
+    candidate(ter, k, base_pos, 0, l, 0, &C[0]);
+  }
+  for (int leg = 0; leg < 4; leg++) {
+    int hipb = 1 + 3 * leg, rep = 1 + 4 * leg;
+    for (int m = 0; m < 2; m++) {
+      real l[3] = {GO1_HIP_CAPSULE_CENTER[leg][0], GO1_HIP_CAPSULE_CENTER[leg][1] + (m ? 1 : -1) * GO1_HIP_CAPSULE_HALF, GO1_HIP_CAPSULE_CENTER[leg][2]};
+      candidate(ter, k, base_pos, hipb, l, GO1_HIP_CAPSULE_RADIUS, &C[rep]);
+    }
+    for (int m = 0; m < 8; m++) {
+      real l[3] = {GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1 : -1) * GO1_THIGH_BOX_HALF[0],
+                   GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1 : -1) * GO1_THIGH_BOX_HALF[1],
+                   GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1 : -1) * GO1_THIGH_BOX_HALF[2]};
+      candidate(ter, k, base_pos, hipb + 1, l, 0, &C[rep + 1]);
+    }
+    for (int m = 0; m < 8; m++) {
+      real l[3] = {GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1 : -1) * GO1_CALF_BOX_HALF[0],
+                   GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1 : -1) * GO1_CALF_BOX_HALF[1],
+                   GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1 : -1) * GO1_CALF_BOX_HALF[2]};
+      candidate(ter, k, base_pos, hipb + 2, l, 0, &C[rep + 2]);
+    }
+    real fo[3] = {GO1_FOOT_OFFSET[leg][0], GO1_FOOT_OFFSET[leg][1], GO1_FOOT_OFFSET[leg][2]};
+    candidate(ter, k, base_pos, hipb + 2, fo, GO1_FOOT_RADIUS, &C[rep + 3]);
+  }
+  for (int b = 0; b < 17; b++) {
+    Contact* c = &C[b];
+    c->active = c->active && (c->phi < cfg->contact_distance);
+    if (!c->active) continue;
+    real ex[3] = {1, 0, 0};
+    real d = v3dot(ex, c->n);
+    for (int i = 0; i < 3; i++) c->t1[i] = ex[i] - d * c->n[i];
+    real l = v3norm(c->t1);
+    for (int i = 0; i < 3; i++) c->t1[i] /= l;
+    v3cross(c->t2, c->n, c->t1);
+  }
+}
+
+/* Jacobian row for world direction d at point x (relative to base origin) on dynamic body dynb */
+static void jac_row(const Kin* k, int dynb, const real* x, const real* d, real* J) {
+  memset(J, 0, NV * sizeof(real));
+  real t[3];
+  v3cross(t, x, d);
+  for (int i = 0; i < 3; i++) { J[i] = t[i]; J[3 + i] = d[i]; }
+  if (dynb == 0) return;
+  int leg = (dynb - 1) / 3, depth = (dynb - 1) % 3;
+  for (int j = 0; j <= depth; j++) {
+    int ji = 3 * leg + j, b = ji + 1;
+    real r[3];
+    v3sub(r, x, k->p[b]);
+    v3cross(t, r, d);
+    J[6 + ji] = v3dot(k->axis[ji], t);
+  }
+}
+
+/* ------------------------------------------------------------------ one physics substep (replaces gym.simulate) */
+typedef struct { real force[17][3]; } ContactOut;
+
+static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s, const real* tau, const real* grav,
+                            real lam[17][3], int use_warm, ContactOut* out) {
+  const real h = (real)cfg->sim_dt;
+  Kin k;
+  kinematics(s, &k);
+  real vel[NV], zero[NV] = {0}, bias[NV];
+  for (int i = 0; i < 3; i++) { vel[i] = s->vang[i]; vel[3 + i] = s->vlin[i]; }
+  for (int j = 0; j < 12; j++) vel[6 + j] = s->qd[j];
+  rnea(&k, vel, zero, grav, bias);
+  real M[NV * NV];
+  for (int c = 0; c < NV; c++) {
+    real e[NV] = {0}, col[NV];
+    e[c] = 1;
+    rnea(&k, NULL, e, NULL, col);
+    for (int r = 0; r < NV; r++) M[r * NV + c] = col[r];
+  }
+  for (int r = 0; r < NV; r++)
+    for (int c = r + 1; c < NV; c++) { real m = 0.5 * (M[r * NV + c] + M[c * NV + r]); M[r * NV + c] = M[c * NV + r] = m; }
+  real L[NV * NV];
+  memcpy(L, M, sizeof M);
+  cholesky(L, NV);
+  real acc[NV];
+  for (int i = 0; i < 6; i++) acc[i] = -bias[i];
+  for (int j = 0; j < 12; j++) acc[6 + j] = tau[j] - bias[6 + j];
+  chol_solve(L, NV, acc);
+  real v[NV];
+  for (int i = 0; i < NV; i++) v[i] = vel[i] + h * acc[i];
+
+  /* contacts at the start-of-step configuration */
+  Contact C[17];
+  detect_contacts(cfg, ter, &k, s->pos, C);
+  real J[17][3][NV], T[17][3][NV], A[17][3], vstar[17];
+  real mu = 0.5 * (s->mu + (real)cfg->terrain_friction);        /* PhysX default combine mode: average */
+  real e_c = 0.5 * (s->rest + (real)cfg->terrain_restitution);
+  for (int b = 0; b < 17; b++) {
+    if (!C[b].active) { lam[b][0] = lam[b][1] = lam[b][2] = 0; continue; }
+    const real* dirs[3] = {C[b].n, C[b].t1, C[b].t2};
+    for (int r = 0; r < 3; r++) {
+      jac_row(&k, C[b].dyn_body, C[b].x, dirs[r], J[b][r]);
+      memcpy(T[b][r], J[b][r], sizeof(real) * NV);
+      chol_solve(L, NV, T[b][r]);
+      real a = 0;
+      for (int i = 0; i < NV; i++) a += J[b][r][i] * T[b][r][i];
+      A[b][r] = a;
+    }
+    real vs = -C[b].phi / h;
+    if (vs > cfg->max_depenetration_velocity) vs = cfg->max_depenetration_velocity;
+    real un_pre = 0;
+    for (int i = 0; i < NV; i++) un_pre += J[b][0][i] * vel[i];
+    if (un_pre < -(real)cfg->bounce_threshold_velocity && -e_c * un_pre > vs) vs = -e_c * un_pre;
+    vstar[b] = vs;
+    if (!use_warm) lam[b][0] = lam[b][1] = lam[b][2] = 0;
+    for (int r = 0; r < 3; r++)
+      for (int i = 0; i < NV; i++) v[i] += T[b][r][i] * lam[b][r];
+  }
+  for (int it = 0; it < cfg->solver_iterations; it++) {
+    for (int b = 0; b < 17; b++) {
+      if (!C[b].active) continue;
+      real un = 0;
+      for (int i = 0; i < NV; i++) un += J[b][0][i] * v[i];
+      real ln = lam[b][0] - (un - vstar[b]) / A[b][0];
+      if (ln < 0) ln = 0;
+      real dl = ln - lam[b][0];
+      lam[b][0] = ln;
+      for (int i = 0; i < NV; i++) v[i] += T[b][0][i] * dl;
+      real u1 = 0, u2 = 0;
+      for (int i = 0; i < NV; i++) { u1 += J[b][1][i] * v[i]; u2 += J[b][2][i] * v[i]; }
+      real l1 = lam[b][1] - u1 / A[b][1], l2 = lam[b][2] - u2 / A[b][2];
+      real lim = mu * ln, nrm = sqrt(l1 * l1 + l2 * l2);
+      if (nrm > lim) { real sc = (nrm > 0) ? lim / nrm : 0; l1 *= sc; l2 *= sc; }
+      real d1 = l1 - lam[b][1], d2 = l2 - lam[b][2];
+      lam[b][1] = l1; lam[b][2] = l2;
+      for (int i = 0; i < NV; i++) v[i] += T[b][1][i] * d1 + T[b][2][i] * d2;
+    }
+  }
+  for (int b = 0; b < 17; b++) {
+    for (int i = 0; i < 3; i++)
+      out->force[b][i] = C[b].active ? (C[b].n[i] * lam[b][0] + C[b].t1[i] * lam[b][1] + C[b].t2[i] * lam[b][2]) / h : 0;
+  }
+  /* joint velocity limits, then semi-implicit Euler */
+  for (int j = 0; j < 12; j++) {
+    real vl = GO1_JOINT_VEL_LIMIT[j];
+    if (v[6 + j] > vl) v[6 + j] = vl;
+    if (v[6 + j] < -vl) v[6 + j] = -vl;
+  }
+  for (int i = 0; i < 3; i++) { s->vang[i] = v[i]; s->vlin[i] = v[3 + i]; s->pos[i] += h * v[3 + i]; }
+  real wn = v3norm(s->vang);
+  if (wn > 1e-12) {
+    real half = 0.5 * wn * h, sn = sin(half) / wn;
+    real dq[4] = {s->vang[0] * sn, s->vang[1] * sn, s->vang[2] * sn, cos(half)}, qn[4];
+    quat_mul(qn, dq, s->quat);
+    real l = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    for (int i = 0; i < 4; i++) s->quat[i] = qn[i] / l;
+  }
+  for (int j = 0; j < 12; j++) {
+    s->qd[j] = v[6 + j];
+    s->q[j] += h * s->qd[j];
+    if (s->q[j] < GO1_JOINT_LOWER[j]) { s->q[j] = GO1_JOINT_LOWER[j]; if (s->qd[j] < 0) s->qd[j] = 0; }
+    if (s->q[j] > GO1_JOINT_UPPER[j]) { s->q[j] = GO1_JOINT_UPPER[j]; if (s->qd[j] > 0) s->qd[j] = 0; }
+  }
+}
+
+/* exported for the invariant tests: mass matrix, bias and free acceleration at a state */
+void go1_oracle_dynamics(const double* root13, const double* q, const double* qd, const double* tau, const double* grav,
+                         double payload, const double* com_disp, double* M_out, double* bias_out, double* acc_out) {
+  Phys s;
+  memcpy(s.pos, root13, 3 * sizeof(double)); memcpy(s.quat, root13 + 3, 4 * sizeof(double));
+  memcpy(s.vlin, root13 + 7, 3 * sizeof(double)); memcpy(s.vang, root13 + 10, 3 * sizeof(double));
+  memcpy(s.q, q, 12 * sizeof(double)); memcpy(s.qd, qd, 12 * sizeof(double));
+  s.mass0 = GO1_BODY_MASS[0] + payload;
+  v3set(s.com0, com_disp[0], com_disp[1], com_disp[2]);
+  s.mu = 1; s.rest = 0;
+  Kin k;
+  kinematics(&s, &k);
+  real vel[NV], zero[NV] = {0}, bias[NV], M[NV * NV];
+  for (int i = 0; i < 3; i++) { vel[i] = s.vang[i]; vel[3 + i] = s.vlin[i]; }
+  for (int j = 0; j < 12; j++) vel[6 + j] = s.qd[j];
+  rnea(&k, vel, zero, grav, bias);
+  for (int c = 0; c < NV; c++) {
+    real e[NV] = {0}, col[NV];
+    e[c] = 1;
+    rnea(&k, NULL, e, NULL, col);
+    for (int r = 0; r < NV; r++) M[r * NV + c] = col[r];
+  }
+  memcpy(M_out, M, sizeof M);
+  memcpy(bias_out, bias, sizeof bias);
+  real L[NV * NV], acc[NV];
+  memcpy(L, M, sizeof M);
+  cholesky(L, NV);
+  for (int i = 0; i < 6; i++) acc[i] = -bias[i];
+  for (int j = 0; j < 12; j++) acc[6 + j] = tau[j] - bias[6 + j];
+  chol_solve(L, NV, acc);
+  memcpy(acc_out, acc, sizeof acc);
+}
+
+/* ------------------------------------------------------------------ torque model (legged_robot.py:907-946) */
+static real softsign(real x) { return x / (1 + fabs(x)); }
+static real actuator_net(const real* in6) {
+  real h0[32], h1[32];
+  for (int i = 0; i < 32; i++) {
+    real a = GO1_ACT_B0[i];
+    for (int k = 0; k < 6; k++) a += (real)GO1_ACT_W0[i][k] * in6[k];
+    h0[i] = softsign(a);
+  }
+  for (int i = 0; i < 32; i++) {
+    real a = GO1_ACT_B1[i];
+    for (int k = 0; k < 32; k++) a += (real)GO1_ACT_W1[i][k] * h0[k];
+    h1[i] = softsign(a);
+  }
+  real o = GO1_ACT_B2;
+  for (int k = 0; k < 32; k++) o += (real)GO1_ACT_W2[k] * h1[k];
+  return o;
+}
+void go1_oracle_actuator_net(const double* in6, int n, double* out) {
+  for (int i = 0; i < n; i++) out[i] = actuator_net(in6 + 6 * i);
+}
+
+#define AT(buf, c, e) ((buf)[(size_t)(c) * N + (e)])
+
+static void compute_torques(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int* lag_head, int advance_head,
+                            const real* q, const real* qd, real* tau) {
+  const int N = cfg->num_envs;
+  const int nl = cfg->lag_timesteps + 1;
+  int head = *lag_head;
+  for (int j = 0; j < 12; j++) {
+    real a = (real)AT(B->actions, j, e) * (real)cfg->action_scale;
+    if (j % 3 == 0) a *= (real)cfg->hip_scale_reduction;
+    real target;
+    if (cfg->use_lag) {
+      B->lag_buffer[((size_t)head * 12 + j) * N + e] = (float)a;          /* overwrite the oldest entry */
+      int h2 = (head + 1) % nl;
+      target = (real)B->lag_buffer[((size_t)h2 * 12 + j) * N + e] + (real)cfg->default_dof_pos[j];
+    } else {
+      target = a + (real)cfg->default_dof_pos[j];
+    }
+    AT(B->joint_pos_target, j, e) = (float)target;
+    target = (real)(float)target;
+    real t;
+    if (cfg->control_type == 1) {
+      real err = q[j] - target + (real)AT(B->motor_offsets, j, e);
+      real in6[6] = {err, AT(B->joint_pos_err_last, j, e), AT(B->joint_pos_err_last_last, j, e),
+                     qd[j], AT(B->joint_vel_last, j, e), AT(B->joint_vel_last_last, j, e)};
+      t = actuator_net(in6);
+      AT(B->joint_pos_err_last_last, j, e) = AT(B->joint_pos_err_last, j, e);
+      AT(B->joint_pos_err_last, j, e) = (float)err;
+      AT(B->joint_vel_last_last, j, e) = AT(B->joint_vel_last, j, e);
+      AT(B->joint_vel_last, j, e) = (float)qd[j];
+    } else {
+      t = (real)cfg->kp * (real)AT(B->Kp_factors, j, e) * (target - q[j] + (real)AT(B->motor_offsets, j, e))
+          - (real)cfg->kd * (real)AT(B->Kd_factors, j, e) * qd[j];
+    }
+    t *= (real)AT(B->motor_strengths, j, e);
+    real lim = cfg->torque_limits[j];
+    if (t > lim) t = lim;
+    if (t < -lim) t = -lim;
+    tau[j] = t;
+    AT(B->torques, j, e) = (float)t;
+  }
+  if (advance_head) *lag_head = (head + 1) % nl;
+}
+
+/* ------------------------------------------------------------------ state <-> buffers */
+static void load_phys(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, Phys* s) {
+  const int N = cfg->num_envs;
+  for (int i = 0; i < 3; i++) { s->pos[i] = AT(B->root_states, i, e); s->vlin[i] = AT(B->root_states, 7 + i, e); s->vang[i] = AT(B->root_states, 10 + i, e); }
+  for (int i = 0; i < 4; i++) s->quat[i] = AT(B->root_states, 3 + i, e);
+  for (int j = 0; j < 12; j++) { s->q[j] = AT(B->dof_pos, j, e); s->qd[j] = AT(B->dof_vel, j, e); }
+  s->mass0 = GO1_BODY_MASS[0] + (real)B->payloads[e];
+  for (int i = 0; i < 3; i++) s->com0[i] = AT(B->com_displacements, i, e);
+  s->mu = B->friction_coeffs[e];
+  s->rest = B->restitutions[e];
+}
+static void store_phys(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, const Phys* s) {
+  const int N = cfg->num_envs;
+  for (int i = 0; i < 3; i++) { AT(B->root_states, i, e) = (float)s->pos[i]; AT(B->root_states, 7 + i, e) = (float)s->vlin[i]; AT(B->root_states, 10 + i, e) = (float)s->vang[i]; }
+  for (int i = 0; i < 4; i++) AT(B->root_states, 3 + i, e) = (float)s->quat[i];
+  for (int j = 0; j < 12; j++) { AT(B->dof_pos, j, e) = (float)s->q[j]; AT(B->dof_vel, j, e) = (float)s->qd[j]; }
+}
+
+/* gravity acting during the policy step whose pre-increment common_step_counter is t
+ * (legged_robot.py:546-561,701-705): a random offset drawn every gravity_rand_interval steps is
+ * active for gravity_rand_duration steps, then zero.  Global (one draw for all envs, quirk D11). */
+static void gravity_at(const Go1SimConfig* cfg, int64_t t, real* g) {
+  for (int i = 0; i < 3; i++) g[i] = cfg->gravity[i];
+  if (!cfg->randomize_gravity) return;
+  int64_t epoch = t / cfg->gravity_rand_interval, ph = t % cfg->gravity_rand_interval;
+  if (ph >= cfg->gravity_rand_duration) return;
+  for (int i = 0; i < 3; i++) {
+    real u = rng_uniform(cfg, 0xFFFFFFFFu, epoch, P_GRAVITY, i);
+    g[i] += u * ((real)cfg->gravity_range[1] - (real)cfg->gravity_range[0]) + (real)cfg->gravity_range[0];
+  }
+}
+
+static void feet_state(const Phys* s, real fp[4][3], real fv[4][3]) {
+  Kin k;
+  kinematics(s, &k);
+  for (int leg = 0; leg < 4; leg++) {
+    int b = 3 + 3 * leg;
+    real fo[3] = {GO1_FOOT_OFFSET[leg][0], GO1_FOOT_OFFSET[leg][1], GO1_FOOT_OFFSET[leg][2]}, w[3], x[3];
+    m3v(w, k.R[b], fo);
+    v3add(x, k.p[b], w);
+    for (int i = 0; i < 3; i++) fp[leg][i] = s->pos[i] + x[i];
+    /* velocity: v_O + omega x r + sum_j (axis_j x (x - p_j)) qd_j */
+    real v[3], t[3];
+    v3cross(t, s->vang, x);
+    v3add(v, s->vlin, t);
+    for (int j = 0; j < 3; j++) {
+      int ji = 3 * leg + j;
+      real r[3];
+      v3sub(r, x, k.p[ji + 1]);
+      v3cross(t, k.axis[ji], r);
+      v3axpy(v, s->qd[ji], t);
+    }
+    v3cpy(fv[leg], v);
+  }
+}
+
+/* ------------------------------------------------------------------ commands (device-curriculum semantics) */
+static real fmod1(real x) { real r = fmod(x, 1.0); if (r < 0) r += 1.0; return r; }   /* torch `%` / remainder */
+
+static void resample_commands(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int64_t step, uint32_t purpose) {
+  const int N = cfg->num_envs;
+  if (!cfg->device_curriculum) { B->resample_flags[e] |= (purpose == P_CMD_CB) ? 1 : 2; goto clear; }
+  {
+    uint32_t eg = (uint32_t)(cfg->env_id_offset + e);
+    int ep_len = cfg->max_episode_length < cfg->resample_interval ? cfg->max_episode_length : cfg->resample_interval;
+    /* curriculum success bookkeeping (curriculum.py:135-154, legged_robot.py:718-739) */
+    int ok = cfg->curriculum_keys != 0;
+    for (int kx = 0; kx < 4; kx++) {
+      if (!(cfg->curriculum_keys & (1 << kx))) continue;
+      float val = AT(B->command_sums, cfg->curriculum_sum_index[kx], e) / (float)ep_len;
+      if (!(val > cfg->curriculum_threshold[kx])) ok = 0;
+    }
+    int cat_old = B->env_command_categories[e], bin_old = B->env_command_bins[e];
+    if (ok) B->curriculum_success[cat_old * cfg->num_bins + bin_old] += 1;
+    /* new category and bin */
+    float u0 = rng_uniform(cfg, eg, step, purpose, 0), u1 = rng_uniform(cfg, eg, step, purpose, 1);
+    int cat = (int)(u0 * cfg->num_categories);
+    if (cat >= cfg->num_categories) cat = cfg->num_categories - 1;
+    const float* cdf = B->curriculum_cdf + (size_t)cat * cfg->num_bins;
+    int bin = 0;
+    while (bin < cfg->num_bins - 1 && !(u1 < cdf[bin])) bin++;
+    B->env_command_bins[e] = bin;
+    B->env_command_categories[e] = cat;
+    int rem = bin;
+    float cmd[GO1_MAX_COMMANDS];
+    for (int kx = GO1_MAX_COMMANDS - 1; kx >= 0; kx--) {
+      int nb = cfg->grid_bins[kx], idx = rem % nb;
+      rem /= nb;
+      float bs = (cfg->grid_high[kx] - cfg->grid_low[kx]) / nb;
+      float centroid = cfg->grid_low[kx] + bs * (idx + 0.5f);
+      float u = rng_uniform(cfg, eg, step, purpose, 2 + kx);
+      cmd[kx] = centroid + (u - 0.5f) * bs;
+    }
+    if (cfg->num_commands > 5) {
+      if (cfg->gaitwise_curricula) {   /* legged_robot.py:764-781 */
+        if (cat == 0) { for (int kx = 5; kx < 8; kx++) cmd[kx] = (float)fmod1(cmd[kx] / 2 - 0.25f); }
+        else if (cat == 1) { cmd[5] = cmd[5] / 2 + 0.25f; cmd[6] = 0; cmd[7] = 0; }
+        else if (cat == 2) { cmd[5] = 0; cmd[6] = cmd[6] / 2 + 0.25f; cmd[7] = 0; }
+        else { cmd[5] = 0; cmd[6] = 0; cmd[7] = cmd[7] / 2 + 0.25f; }
+      }
+      if (cfg->binary_phases)          /* :814-817; torch.round = round-half-even = rint */
+        for (int kx = 5; kx < 8; kx++) cmd[kx] = (float)fmod1(rintf(2 * cmd[kx]) / 2.0f);
+    }
+    float nrm = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);   /* :820 */
+    if (!(nrm > 0.2f)) { cmd[0] = 0; cmd[1] = 0; }
+    for (int kx = 0; kx < cfg->num_commands; kx++) AT(B->commands, kx, e) = cmd[kx];
+  }
+clear:
+  for (int kx = 0; kx < cfg->num_rewards + 5; kx++) AT(B->command_sums, kx, e) = 0;   /* :823-824 */
+}
+
+void go1_oracle_curriculum_update(const Go1SimConfig* cfg, const Go1SimBuffers* B) {
+  for (int c = 0; c < cfg->num_categories; c++) {
+    float* w = B->curriculum_weights + (size_t)c * cfg->num_bins;
+    int32_t* s = B->curriculum_success + (size_t)c * cfg->num_bins;
+    float* cdf = B->curriculum_cdf + (size_t)c * cfg->num_bins;
+    float* add = (float*)calloc(cfg->num_bins, sizeof(float));
+    for (int b = 0; b < cfg->num_bins; b++) {
+      int cnt = s[b] > 0 ? 1 : 0;
+      for (int p = B->curriculum_nbr_ptr[b]; p < B->curriculum_nbr_ptr[b + 1]; p++) cnt += s[B->curriculum_nbr_idx[p]];
+      add[b] = 0.2f * cnt;
+    }
+    double tot = 0;
+    for (int b = 0; b < cfg->num_bins; b++) { w[b] = fminf(1.0f, w[b] + add[b]); s[b] = 0; tot += w[b]; }
+    double run = 0;
+    for (int b = 0; b < cfg->num_bins; b++) { run += w[b]; cdf[b] = (float)(run / tot); }
+    free(add);
+  }
+}
+
+static void randomize_dof_props(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int64_t step, uint32_t purpose) {
+  const int N = cfg->num_envs;
+  uint32_t eg = (uint32_t)(cfg->env_id_offset + e);
+  if (cfg->randomize_motor_strength) {   /* one value per env, broadcast (legged_robot.py:646-650) */
+    float u = rng_uniform(cfg, eg, step, purpose, 0);
+    float v = u * (cfg->motor_strength_range[1] - cfg->motor_strength_range[0]) + cfg->motor_strength_range[0];
+    for (int j = 0; j < 12; j++) AT(B->motor_strengths, j, e) = v;
+  }
+  if (cfg->randomize_motor_offset)
+    for (int j = 0; j < 12; j++) {
+      float u = rng_uniform(cfg, eg, step, purpose, 1 + j);
+      AT(B->motor_offsets, j, e) = u * (cfg->motor_offset_range[1] - cfg->motor_offset_range[0]) + cfg->motor_offset_range[0];
+    }
+  if (cfg->randomize_Kp_factor) {
+    float u = rng_uniform(cfg, eg, step, purpose, 13);
+    float v = u * (cfg->Kp_factor_range[1] - cfg->Kp_factor_range[0]) + cfg->Kp_factor_range[0];
+    for (int j = 0; j < 12; j++) AT(B->Kp_factors, j, e) = v;
+  }
+  if (cfg->randomize_Kd_factor) {
+    float u = rng_uniform(cfg, eg, step, purpose, 14);
+    float v = u * (cfg->Kd_factor_range[1] - cfg->Kd_factor_range[0]) + cfg->Kd_factor_range[0];
+    for (int j = 0; j < 12; j++) AT(B->Kd_factors, j, e) = v;
+  }
+}
+
+/* reset_idx for one env (legged_robot.py:150-239,948-1001) */
+static void reset_env(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int64_t step, int lag_slots) {
+  const int N = cfg->num_envs;
+  uint32_t eg = (uint32_t)(cfg->env_id_offset + e);
+  resample_commands(cfg, B, e, step, P_CMD_RESET);
+  randomize_dof_props(cfg, B, e, step, P_DOFPROPS_RESET);
+  for (int j = 0; j < 12; j++) {   /* _reset_dofs :956-958 */
+    float u = rng_uniform(cfg, eg, step, P_RESET, j);
+    AT(B->dof_pos, j, e) = cfg->default_dof_pos[j] * (0.5f + u);
+    AT(B->dof_vel, j, e) = 0;
+  }
+  float root[13];
+  for (int i = 0; i < 13; i++) root[i] = cfg->base_init_state[i];   /* _reset_root_states :973-997 */
+  for (int i = 0; i < 3; i++) root[i] += AT(B->env_origins, i, e);
+  if (cfg->custom_origins) {
+    root[0] += (2 * rng_uniform(cfg, eg, step, P_RESET, 12) - 1) * cfg->x_init_range + cfg->x_init_offset;
+    root[1] += (2 * rng_uniform(cfg, eg, step, P_RESET, 13) - 1) * cfg->y_init_range + cfg->y_init_offset;
+  }
+  float yaw = (2 * rng_uniform(cfg, eg, step, P_RESET, 14) - 1) * cfg->yaw_init_range;
+  root[3] = 0; root[4] = 0; root[5] = sinf(0.5f * yaw); root[6] = cosf(0.5f * yaw);
+  for (int i = 0; i < 6; i++) root[7 + i] = rng_uniform(cfg, eg, step, P_RESET, 15 + i) - 0.5f;
+  for (int i = 0; i < 13; i++) AT(B->root_states, i, e) = root[i];
+  for (int j = 0; j < 12; j++) { AT(B->last_actions, j, e) = 0; AT(B->last_last_actions, j, e) = 0; AT(B->last_dof_vel, j, e) = 0; }
+  B->episode_length_buf[e] = 0;
+  B->reset_buf[e] = 1;
+  for (int kx = 0; kx <= cfg->num_rewards; kx++) {   /* :181-187 logged mean is formed by the host from episode_log */
+    B->episode_log[kx] += AT(B->episode_sums, kx, e);
+    AT(B->episode_sums, kx, e) = 0;
+  }
+  B->episode_log[cfg->num_rewards + 1] += 1;
+  B->gait_indices[e] = 0;
+  for (int sl = 0; sl < lag_slots; sl++)
+    for (int j = 0; j < 12; j++) B->lag_buffer[((size_t)sl * 12 + j) * N + e] = 0;
+}
+
+void go1_oracle_reset_idx(const Go1SimConfig* cfg, const Go1SimBuffers* B, const int32_t* ids, int n, int64_t step) {
+  for (int kx = 0; kx <= cfg->num_rewards + 1; kx++) B->episode_log[kx] = 0;
+  for (int i = 0; i < (ids ? n : cfg->num_envs); i++) reset_env(cfg, B, ids ? ids[i] : i, step, cfg->lag_timesteps + 1);
+}
+
+/* ------------------------------------------------------------------ rewards (corl_rewards.py) */
+static real normal_cdf(real x, real sigma) { return 0.5 * (1 + erf(x / (sigma * sqrt(2.0)))); }
+
+typedef struct {
+  real base_pos[3], base_quat[4], base_lin_vel[3], base_ang_vel[3], proj_g[3], gvec[3];
+  real q[12], qd[12];
+  real fpos[4][3], fvel[4][3], cf[17][3];
+} Derived;
+
+static real reward_term(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int id, const Derived* d) {
+  const int N = cfg->num_envs;
+  real r = 0;
+  switch (id) {
+    case GO1_REW_TRACKING_LIN_VEL: {
+      real ex = (real)AT(B->commands, 0, e) - d->base_lin_vel[0], ey = (real)AT(B->commands, 1, e) - d->base_lin_vel[1];
+      return exp(-(ex * ex + ey * ey) / (real)cfg->tracking_sigma);
+    }
+    case GO1_REW_TRACKING_ANG_VEL: {
+      real ez = (real)AT(B->commands, 2, e) - d->base_ang_vel[2];
+      return exp(-(ez * ez) / (real)cfg->tracking_sigma_yaw);
+    }
+    case GO1_REW_LIN_VEL_Z: return d->base_lin_vel[2] * d->base_lin_vel[2];
+    case GO1_REW_ANG_VEL_XY: return d->base_ang_vel[0] * d->base_ang_vel[0] + d->base_ang_vel[1] * d->base_ang_vel[1];
+    case GO1_REW_ORIENTATION: return d->proj_g[0] * d->proj_g[0] + d->proj_g[1] * d->proj_g[1];
+    case GO1_REW_TORQUES: for (int j = 0; j < 12; j++) r += (real)AT(B->torques, j, e) * (real)AT(B->torques, j, e); return r;
+    case GO1_REW_DOF_ACC: for (int j = 0; j < 12; j++) { real a = ((real)AT(B->last_dof_vel, j, e) - d->qd[j]) / (real)cfg->dt; r += a * a; } return r;
+    case GO1_REW_ACTION_RATE: for (int j = 0; j < 12; j++) { real a = (real)AT(B->last_actions, j, e) - (real)AT(B->actions, j, e); r += a * a; } return r;
+    case GO1_REW_COLLISION:
+      for (int b = 0; b < 17; b++) if (cfg->penalised_body_mask & (1u << b)) r += (v3norm(d->cf[b]) > 0.1) ? 1 : 0;
+      return r;
+    case GO1_REW_DOF_POS_LIMITS:
+      for (int j = 0; j < 12; j++) {
+        real lo = d->q[j] - (real)cfg->dof_pos_soft_lower[j], hi = d->q[j] - (real)cfg->dof_pos_soft_upper[j];
+        r += -(lo < 0 ? lo : 0) + (hi > 0 ? hi : 0);
+      }
+      return r;
+    case GO1_REW_JUMP: {
+      real t = d->base_pos[2] - ((real)AT(B->commands, 3, e) + (real)cfg->base_height_target);
+      return -t * t;
+    }
+    case GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE:
+      for (int f = 0; f < 4; f++) {
+        real fn = v3norm(d->cf[4 + 4 * f]);
+        r += -(1 - (real)AT(B->desired_contact_states, f, e)) * (1 - exp(-fn * fn / (real)cfg->gait_force_sigma));
+      }
+      return r / 4;
+    case GO1_REW_TRACKING_CONTACTS_SHAPED_VEL:
+      for (int f = 0; f < 4; f++) {
+        real vn = v3norm(d->fvel[f]);
+        r += -((real)AT(B->desired_contact_states, f, e) * (1 - exp(-vn * vn / (real)cfg->gait_vel_sigma)));
+      }
+      return r / 4;
+    case GO1_REW_DOF_POS: for (int j = 0; j < 12; j++) { real a = d->q[j] - (real)cfg->default_dof_pos[j]; r += a * a; } return r;
+    case GO1_REW_DOF_VEL: for (int j = 0; j < 12; j++) r += d->qd[j] * d->qd[j]; return r;
+    case GO1_REW_ACTION_SMOOTHNESS_1:
+      for (int j = 0; j < 12; j++) {
+        real a = (real)AT(B->joint_pos_target, j, e) - (real)AT(B->last_joint_pos_target, j, e);
+        r += a * a * (AT(B->last_actions, j, e) != 0 ? 1 : 0);
+      }
+      return r;
+    case GO1_REW_ACTION_SMOOTHNESS_2:
+      for (int j = 0; j < 12; j++) {
+        real a = (real)AT(B->joint_pos_target, j, e) - 2 * (real)AT(B->last_joint_pos_target, j, e) + (real)AT(B->last_last_joint_pos_target, j, e);
+        r += a * a * (AT(B->last_actions, j, e) != 0 ? 1 : 0) * (AT(B->last_last_actions, j, e) != 0 ? 1 : 0);
+      }
+      return r;
+    case GO1_REW_FEET_SLIP:
+      for (int f = 0; f < 4; f++) {
+        int contact = d->cf[4 + 4 * f][2] > 1.0;
+        int filt = contact || AT(B->last_contacts, f, e);
+        AT(B->last_contacts, f, e) = (uint8_t)contact;
+        r += filt * (d->fvel[f][0] * d->fvel[f][0] + d->fvel[f][1] * d->fvel[f][1]);
+      }
+      return r;
+    case GO1_REW_FEET_CONTACT_VEL:
+      for (int f = 0; f < 4; f++) r += (d->fpos[f][2] < 0.03 ? 1 : 0) * v3dot(d->fvel[f], d->fvel[f]);
+      return r;
+    case GO1_REW_FEET_CONTACT_FORCES:
+      for (int f = 0; f < 4; f++) { real x = v3norm(d->cf[4 + 4 * f]) - (real)cfg->max_contact_force; r += x > 0 ? x : 0; }
+      return r;
+    case GO1_REW_FEET_CLEARANCE_CMD_LINEAR:
+      for (int f = 0; f < 4; f++) {
+        real fi = AT(B->foot_indices, f, e);
+        real cl = fi * 2.0 - 1.0; cl = cl < 0 ? 0 : (cl > 1 ? 1 : cl);
+        real ph = 1 - fabs(1.0 - cl * 2.0);
+        real target = (real)AT(B->commands, 9, e) * ph + 0.02;
+        real df = target - d->fpos[f][2];
+        r += df * df * (1 - (real)AT(B->desired_contact_states, f, e));
+      }
+      return r;
+    case GO1_REW_FEET_IMPACT_VEL:
+      for (int f = 0; f < 4; f++) {
+        real pv = AT(B->prev_foot_velocities, 3 * f + 2, e);
+        pv = pv > 0 ? 0 : (pv < -100 ? -100 : pv);
+        r += (v3norm(d->cf[4 + 4 * f]) > 1.0 ? 1 : 0) * pv * pv;
+      }
+      return r;
+    case GO1_REW_ORIENTATION_CONTROL: {
+      real pitch = AT(B->commands, 10, e), roll = AT(B->commands, 11, e);
+      real qr[4] = {sin(-roll / 2), 0, 0, cos(-roll / 2)}, qp[4] = {0, sin(-pitch / 2), 0, cos(-pitch / 2)}, qd_[4], g[3];
+      quat_mul(qd_, qr, qp);
+      quat_rotate_inverse(g, qd_, d->gvec);
+      real a = d->proj_g[0] - g[0], b = d->proj_g[1] - g[1];
+      return a * a + b * b;
+    }
+    case GO1_REW_RAIBERT_HEURISTIC: {
+      /* quat_apply_yaw(quat_conjugate(base_quat), foot - base) (math_utils.py:12-17) */
+      real qy[4] = {0, 0, -d->base_quat[2], d->base_quat[3]};
+      real l = sqrt(qy[2] * qy[2] + qy[3] * qy[3]);
+      qy[2] /= l; qy[3] /= l;
+      real width = cfg->num_commands >= 13 ? (real)AT(B->commands, 12, e) : 0.3;
+      real length = cfg->num_commands >= 14 ? (real)AT(B->commands, 13, e) : 0.45;
+      real freq = AT(B->commands, 4, e), xv = AT(B->commands, 0, e), yawv = AT(B->commands, 2, e);
+      real yv = yawv * length / 2;
+      for (int f = 0; f < 4; f++) {
+        real rel[3], fb[3];
+        v3sub(rel, d->fpos[f], d->base_pos);
+        quat_rotate(fb, qy, rel);
+        real ys = (f % 2 == 0 ? 1 : -1) * width / 2, xs = (f < 2 ? 1 : -1) * length / 2;
+        real ph = fabs(1.0 - (real)AT(B->foot_indices, f, e) * 2.0) * 1.0 - 0.5;
+        real yo = ph * yv * (0.5 / freq), xo = ph * xv * (0.5 / freq);
+        if (f >= 2) yo *= -1;
+        real ex = fabs((xs + xo) - fb[0]), ey = fabs((ys + yo) - fb[1]);
+        r += ex * ex + ey * ey;
+      }
+      return r;
+    }
+  }
+  return 0;
+}
+/* sign class of each raw term: +1 raw >= 0, -1 raw <= 0 (DESIGN.md "batch-sum sign") */
+static int reward_raw_sign(int id) {
+  return (id == GO1_REW_JUMP || id == GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE || id == GO1_REW_TRACKING_CONTACTS_SHAPED_VEL) ? -1 : 1;
+}
+
+/* ------------------------------------------------------------------ post-physics for one env */
+static void post_physics(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int64_t counter_post,
+                         const real* grav_used, int lag_slots) {
+  const int N = cfg->num_envs;
+  uint32_t eg = (uint32_t)(cfg->env_id_offset + e);
+  Derived d;
+  B->episode_length_buf[e] += 1;
+  Phys s;
+  load_phys(cfg, B, e, &s);
+  v3cpy(d.base_pos, s.pos);
+  memcpy(d.base_quat, s.quat, sizeof d.base_quat);
+  quat_rotate_inverse(d.base_lin_vel, s.quat, s.vlin);
+  quat_rotate_inverse(d.base_ang_vel, s.quat, s.vang);
+  real gn = v3norm(grav_used);
+  for (int i = 0; i < 3; i++) d.gvec[i] = grav_used[i] / gn;
+  quat_rotate_inverse(d.proj_g, s.quat, d.gvec);
+  for (int i = 0; i < 3; i++) {
+    AT(B->base_lin_vel, i, e) = (float)d.base_lin_vel[i];
+    AT(B->base_ang_vel, i, e) = (float)d.base_ang_vel[i];
+    AT(B->projected_gravity, i, e) = (float)d.proj_g[i];
+  }
+  for (int j = 0; j < 12; j++) { d.q[j] = s.q[j]; d.qd[j] = s.qd[j]; }
+  for (int f = 0; f < 4; f++)
+    for (int i = 0; i < 3; i++) { d.fpos[f][i] = AT(B->foot_positions, 3 * f + i, e); d.fvel[f][i] = AT(B->foot_velocities, 3 * f + i, e); }
+  for (int b = 0; b < 17; b++)
+    for (int i = 0; i < 3; i++) d.cf[b][i] = AT(B->contact_forces, 3 * b + i, e);
+
+  /* ---- _post_physics_step_callback (legged_robot.py:675-708) ---- */
+  if (cfg->teleport_robots) {   /* :1028-1051 */
+    float x = AT(B->root_states, 0, e), y = AT(B->root_states, 1, e), th = cfg->teleport_thresh, xo = cfg->teleport_x_offset;
+    if (x < th + xo) x += cfg->terrain_length * (cfg->terrain_num_rows - 1);
+    if (x > cfg->terrain_length * cfg->terrain_num_rows - th + xo) x -= cfg->terrain_length * (cfg->terrain_num_rows - 1);
+    if (y < th) y += cfg->terrain_width * (cfg->terrain_num_cols - 1);
+    if (y > cfg->terrain_width * cfg->terrain_num_cols - th) y -= cfg->terrain_width * (cfg->terrain_num_cols - 1);
+    AT(B->root_states, 0, e) = x; AT(B->root_states, 1, e) = y;
+  }
+  if (B->episode_length_buf[e] % cfg->resample_interval == 0) resample_commands(cfg, B, e, counter_post, P_CMD_CB);
+  if (cfg->observe_gait_commands) {   /* _step_contact_targets :826-905 (float32 arithmetic order preserved where it matters) */
+    float freq = AT(B->commands, 4, e), phase = AT(B->commands, 5, e), offset = AT(B->commands, 6, e), bound = AT(B->commands, 7, e), dur = AT(B->commands, 8, e);
+    float gi = (float)fmod1((real)(float)(B->gait_indices[e] + cfg->dt * freq));
+    B->gait_indices[e] = gi;
+    float fi[4];
+    if (cfg->pacing_offset) { fi[0] = gi + phase + offset + bound; fi[1] = gi + bound; fi[2] = gi + offset; fi[3] = gi + phase; }
+    else                    { fi[0] = gi + phase + offset + bound; fi[1] = gi + offset; fi[2] = gi + bound; fi[3] = gi + phase; }
+    for (int f = 0; f < 4; f++) {
+      real rem = fmod1(fi[f]);
+      AT(B->foot_indices, f, e) = (float)rem;
+      real idx = fi[f];
+      if (rem < dur) idx = rem * (0.5 / dur);
+      else if (rem > dur) idx = 0.5 + (rem - dur) * (0.5 / (1 - dur));
+      AT(B->clock_inputs, f, e) = (float)sin(2 * PI * idx);
+      real kap = cfg->kappa_gait_probs, x = fmod1(idx);
+      real sm = normal_cdf(x, kap) * (1 - normal_cdf(x - 0.5, kap)) + normal_cdf(x - 1, kap) * (1 - normal_cdf(x - 0.5 - 1, kap));
+      AT(B->desired_contact_states, f, e) = (float)sm;
+    }
+  }
+  if (cfg->push_robots && B->episode_length_buf[e] % cfg->push_interval == 0) {   /* :1017-1026 */
+    for (int i = 0; i < 2; i++)
+      AT(B->root_states, 7 + i, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, i) - 1) * cfg->max_push_vel_xy;
+  }
+  if (B->episode_length_buf[e] % cfg->rand_interval == 0) randomize_dof_props(cfg, B, e, counter_post, P_DOFPROPS_CB);
+
+  /* ---- check_termination (:138-148) ---- */
+  int reset = 0;
+  for (int b = 0; b < 17; b++) if ((cfg->termination_body_mask & (1u << b)) && v3norm(d.cf[b]) > 1.0) reset = 1;
+  int time_out = B->episode_length_buf[e] > cfg->max_episode_length;
+  reset |= time_out;
+  if (cfg->use_terminal_body_height && (real)AT(B->root_states, 2, e) < (real)cfg->terminal_body_height) reset = 1;
+  B->time_out_buf[e] = (uint8_t)time_out;
+  B->reset_buf[e] = (uint8_t)reset;
+
+  /* ---- compute_reward (:263-300) ---- */
+  real rew = 0, pos = 0, neg = 0;
+  for (int kx = 0; kx < cfg->num_rewards; kx++) {
+    int id = cfg->reward_ids[kx];
+    real r = reward_term(cfg, B, e, id, &d) * (real)cfg->reward_scales[kx];
+    rew += r;
+    if (reward_raw_sign(id) * cfg->reward_scales[kx] >= 0) pos += r; else neg += r;
+    AT(B->episode_sums, kx, e) += (float)r;
+    if (id == GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE || id == GO1_REW_TRACKING_CONTACTS_SHAPED_VEL)
+      AT(B->command_sums, kx, e) += (float)((real)cfg->reward_scales[kx] + r);
+    else
+      AT(B->command_sums, kx, e) += (float)r;
+  }
+  if (cfg->only_positive_rewards) rew = rew < 0 ? 0 : rew;
+  else if (cfg->only_positive_rewards_ji22_style) rew = pos * exp(neg / (real)cfg->sigma_rew_neg);
+  B->rew_buf[e] = (float)rew;
+  AT(B->episode_sums, cfg->num_rewards, e) += (float)rew;
+  {
+    int k0 = cfg->num_rewards;
+    real vx = d.base_lin_vel[0], wz = d.base_ang_vel[2], c0 = AT(B->commands, 0, e), c2 = AT(B->commands, 2, e);
+    AT(B->command_sums, k0 + 0, e) += (float)vx;
+    AT(B->command_sums, k0 + 1, e) += (float)wz;
+    AT(B->command_sums, k0 + 2, e) += (float)((vx - c0) * (vx - c0));
+    AT(B->command_sums, k0 + 3, e) += (float)((wz - c2) * (wz - c2));
+    AT(B->command_sums, k0 + 4, e) += 1;
+  }
+
+  /* ---- reset (:122-123) ---- */
+  if (reset) reset_env(cfg, B, e, counter_post, lag_slots);
+
+  /* ---- compute_observations (:302-491) ---- */
+  {
+    float obs[GO1_MAX_OBS];
+    int n = 0;
+    float core[GO1_MAX_OBS];
+    int nc = 0;
+    for (int i = 0; i < 3; i++) core[nc++] = AT(B->projected_gravity, i, e);
+    if (cfg->observe_command)
+      for (int kx = 0; kx < cfg->num_commands; kx++) core[nc++] = AT(B->commands, kx, e) * cfg->commands_scale[kx];
+    for (int j = 0; j < 12; j++) core[nc++] = (AT(B->dof_pos, j, e) - cfg->default_dof_pos[j]) * cfg->obs_scale_dof_pos;
+    for (int j = 0; j < 12; j++) core[nc++] = AT(B->dof_vel, j, e) * cfg->obs_scale_dof_vel;
+    for (int j = 0; j < 12; j++) core[nc++] = AT(B->actions, j, e);
+    if (cfg->observe_two_prev_actions) for (int j = 0; j < 12; j++) core[nc++] = AT(B->last_actions, j, e);
+    if (cfg->observe_timing_parameter) core[nc++] = B->gait_indices[e];
+    if (cfg->observe_clock_inputs) for (int f = 0; f < 4; f++) core[nc++] = AT(B->clock_inputs, f, e);
+    /* prefixes are prepended in this order: vel block first, then only_ang_vel, then only_lin_vel in front */
+    if (cfg->observe_only_lin_vel) for (int i = 0; i < 3; i++) obs[n++] = AT(B->base_lin_vel, i, e) * cfg->obs_scale_lin_vel;
+    if (cfg->observe_only_ang_vel) for (int i = 0; i < 3; i++) obs[n++] = AT(B->base_ang_vel, i, e) * cfg->obs_scale_ang_vel;
+    if (cfg->observe_vel) {
+      for (int i = 0; i < 3; i++)
+        obs[n++] = (cfg->global_reference ? AT(B->root_states, 7 + i, e) : AT(B->base_lin_vel, i, e)) * cfg->obs_scale_lin_vel;
+      for (int i = 0; i < 3; i++) obs[n++] = AT(B->base_ang_vel, i, e) * cfg->obs_scale_ang_vel;
+    }
+    for (int i = 0; i < nc; i++) obs[n++] = core[i];
+    if (cfg->observe_yaw) {
+      real q[4] = {AT(B->root_states, 3, e), AT(B->root_states, 4, e), AT(B->root_states, 5, e), AT(B->root_states, 6, e)};
+      real fw[3] = {1, 0, 0}, o[3];
+      quat_rotate(o, q, fw);
+      obs[n++] = (float)atan2(o[1], o[0]);
+    }
+    if (cfg->observe_contact_states) for (int f = 0; f < 4; f++) obs[n++] = AT(B->contact_forces, 3 * (4 + 4 * f) + 2, e) > 1.0f ? 1.0f : 0.0f;
+    for (int i = 0; i < n; i++) {
+      float v = obs[i];
+      if (cfg->add_noise && cfg->noise_scale_vec[i] != 0)
+        v += (2 * rng_uniform(cfg, eg, counter_post, P_NOISE, i) - 1) * cfg->noise_scale_vec[i];
+      if (v > cfg->clip_observations) v = cfg->clip_observations;
+      if (v < -cfg->clip_observations) v = -cfg->clip_observations;
+      B->obs_buf[(size_t)e * cfg->num_obs + i] = v;
+    }
+    /* privileged observations */
+    float pv[GO1_MAX_PRIV_OBS];
+    int np = 0;
+#define PRIV(idx, val) pv[np++] = ((val) - cfg->priv_shift[idx]) * cfg->priv_scale[idx]
+    if (cfg->priv_enabled[GO1_PRIV_FRICTION]) PRIV(GO1_PRIV_FRICTION, B->friction_coeffs[e]);
+    if (cfg->priv_enabled[GO1_PRIV_RESTITUTION]) PRIV(GO1_PRIV_RESTITUTION, B->restitutions[e]);
+    if (cfg->priv_enabled[GO1_PRIV_BASE_MASS]) PRIV(GO1_PRIV_BASE_MASS, B->payloads[e]);
+    if (cfg->priv_enabled[GO1_PRIV_COM_DISPLACEMENT]) for (int i = 0; i < 3; i++) PRIV(GO1_PRIV_COM_DISPLACEMENT, AT(B->com_displacements, i, e));
+    if (cfg->priv_enabled[GO1_PRIV_MOTOR_STRENGTH]) for (int j = 0; j < 12; j++) PRIV(GO1_PRIV_MOTOR_STRENGTH, AT(B->motor_strengths, j, e));
+    if (cfg->priv_enabled[GO1_PRIV_MOTOR_OFFSET]) for (int j = 0; j < 12; j++) PRIV(GO1_PRIV_MOTOR_OFFSET, AT(B->motor_offsets, j, e));
+    if (cfg->priv_enabled[GO1_PRIV_BODY_HEIGHT]) PRIV(GO1_PRIV_BODY_HEIGHT, AT(B->root_states, 2, e));
+    if (cfg->priv_enabled[GO1_PRIV_BODY_VELOCITY]) for (int i = 0; i < 3; i++) PRIV(GO1_PRIV_BODY_VELOCITY, AT(B->base_lin_vel, i, e));
+    if (cfg->priv_enabled[GO1_PRIV_GRAVITY])   /* (gravities - shift) / scale: division, legged_robot.py:477 */
+      for (int i = 0; i < 3; i++) pv[np++] = ((float)(grav_used[i] - cfg->gravity[i]) - cfg->priv_shift[GO1_PRIV_GRAVITY]) / cfg->priv_scale[GO1_PRIV_GRAVITY];
+    if (cfg->priv_enabled[GO1_PRIV_CLOCK_INPUTS]) for (int f = 0; f < 4; f++) pv[np++] = AT(B->clock_inputs, f, e);
+    if (cfg->priv_enabled[GO1_PRIV_DESIRED_CONTACT]) for (int f = 0; f < 4; f++) pv[np++] = AT(B->desired_contact_states, f, e);
+    for (int i = 0; i < np; i++) {
+      float v = pv[i];
+      if (v > cfg->clip_observations) v = cfg->clip_observations;
+      if (v < -cfg->clip_observations) v = -cfg->clip_observations;
+      B->privileged_obs_buf[(size_t)e * cfg->num_privileged_obs + i] = v;
+    }
+  }
+  /* ---- roll (:126-131) ---- */
+  for (int j = 0; j < 12; j++) {
+    AT(B->last_last_actions, j, e) = AT(B->last_actions, j, e);
+    AT(B->last_actions, j, e) = AT(B->actions, j, e);
+    AT(B->last_last_joint_pos_target, j, e) = AT(B->last_joint_pos_target, j, e);
+    AT(B->last_joint_pos_target, j, e) = AT(B->joint_pos_target, j, e);
+    AT(B->last_dof_vel, j, e) = AT(B->dof_vel, j, e);
+  }
+}
+
+/* history append (history_wrapper.py:23): double-length ring, slot k = step index mod H written at k and k+H;
+ * the window of the reference's obs_history after this step is columns [(k+1)*num_obs, (k+1+H)*num_obs). */
+static void history_append(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int slot) {
+  const int no = cfg->num_obs, H = cfg->num_obs_history;
+  float* row = B->obs_history + (size_t)e * 2 * H * no;
+  const float* obs = B->obs_buf + (size_t)e * no;
+  memcpy(row + (size_t)slot * no, obs, no * sizeof(float));
+  memcpy(row + (size_t)(slot + H) * no, obs, no * sizeof(float));
+}
+
+/* ------------------------------------------------------------------ public step */
+typedef struct { int64_t common_step_counter; int32_t lag_head; int32_t history_slot; } Go1OracleCounters;
+
+/* actions: row-major (N,12).  Advances the counters. */
+void go1_oracle_step(const Go1SimConfig* cfg, const Go1SimBuffers* B, const float* actions, Go1OracleCounters* ctr) {
+  const int N = cfg->num_envs;
+  const int nl = cfg->lag_timesteps + 1;
+  Terrain ter = {cfg, B->height_samples};
+  real grav[3];
+  gravity_at(cfg, ctr->common_step_counter, grav);
+  int64_t counter_post = ctr->common_step_counter + 1;
+  for (int kx = 0; kx <= cfg->num_rewards + 1; kx++) B->episode_log[kx] = 0;
+  int head_end = ctr->lag_head;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < N; e++) {
+    for (int j = 0; j < 12; j++) {
+      float a = actions[(size_t)e * 12 + j];
+      if (a > cfg->clip_actions) a = cfg->clip_actions;
+      if (a < -cfg->clip_actions) a = -cfg->clip_actions;
+      AT(B->actions, j, e) = a;
+    }
+    for (int i = 0; i < 12; i++) AT(B->prev_foot_velocities, i, e) = AT(B->foot_velocities, i, e);
+    Phys s;
+    load_phys(cfg, B, e, &s);
+    real lam[17][3];
+    int warm = cfg->warm_start && B->episode_length_buf[e] > 0;
+    for (int b = 0; b < 17; b++)
+      for (int i = 0; i < 3; i++) lam[b][i] = 0;
+    if (warm) {
+      /* impulses of the previous substep: stored as world forces; the contact frame on the plane is
+       * (n, t1, t2) = (z, x, y); for height fields the frame is re-projected in the solver order */
+      for (int b = 0; b < 17; b++) {
+        lam[b][0] = (real)AT(B->contact_forces, 3 * b + 2, e) * (real)cfg->sim_dt;
+        lam[b][1] = (real)AT(B->contact_forces, 3 * b + 0, e) * (real)cfg->sim_dt;
+        lam[b][2] = (real)AT(B->contact_forces, 3 * b + 1, e) * (real)cfg->sim_dt;
+      }
+    }
+    ContactOut co;
+    int head = ctr->lag_head;
+    for (int sub = 0; sub < cfg->decimation; sub++) {
+      real tau[12];
+      compute_torques(cfg, B, e, &head, 1, s.q, s.qd, tau);
+      physics_substep(cfg, &ter, &s, tau, grav, lam, warm || (cfg->warm_start && sub > 0), &co);
+    }
+    store_phys(cfg, B, e, &s);
+    real fp[4][3], fv[4][3];
+    feet_state(&s, fp, fv);
+    for (int f = 0; f < 4; f++)
+      for (int i = 0; i < 3; i++) { AT(B->foot_positions, 3 * f + i, e) = (float)fp[f][i]; AT(B->foot_velocities, 3 * f + i, e) = (float)fv[f][i]; }
+    for (int b = 0; b < 17; b++)
+      for (int i = 0; i < 3; i++) AT(B->contact_forces, 3 * b + i, e) = (float)co.force[b][i];
+    if (e == 0) head_end = head;
+  }
+  if (N > 0) ctr->lag_head = (ctr->lag_head + cfg->decimation) % nl;
+  (void)head_end;
+  /* post-physics touches shared curriculum/episode_log accumulators: serial for determinism */
+  for (int e = 0; e < N; e++) {
+    post_physics(cfg, B, e, counter_post, grav, nl);
+    if (B->obs_history) history_append(cfg, B, e, ctr->history_slot);
+  }
+  ctr->common_step_counter = counter_post;
+  ctr->history_slot = (ctr->history_slot + 1) % cfg->num_obs_history;
+  if (cfg->device_curriculum && B->curriculum_weights) go1_oracle_curriculum_update(cfg, B);
+}
+
+/* piecewise entry points mirroring go1sim_compute_torques / go1sim_physics_substep */
+void go1_oracle_compute_torques(const Go1SimConfig* cfg, const Go1SimBuffers* B, const float* actions_soa, Go1OracleCounters* ctr) {
+  const int N = cfg->num_envs;
+  for (int e = 0; e < N; e++) {
+    for (int j = 0; j < 12; j++) AT(B->actions, j, e) = AT(actions_soa, j, e);
+    real q[12], qd[12], tau[12];
+    for (int j = 0; j < 12; j++) { q[j] = AT(B->dof_pos, j, e); qd[j] = AT(B->dof_vel, j, e); }
+    int head = ctr->lag_head;
+    compute_torques(cfg, B, e, &head, 1, q, qd, tau);
+  }
+  ctr->lag_head = (ctr->lag_head + 1) % (cfg->lag_timesteps + 1);
+}
+void go1_oracle_physics_substep(const Go1SimConfig* cfg, const Go1SimBuffers* B, Go1OracleCounters* ctr) {
+  const int N = cfg->num_envs;
+  Terrain ter = {cfg, B->height_samples};
+  real grav[3];
+  gravity_at(cfg, ctr->common_step_counter, grav);
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < N; e++) {
+    Phys s;
+    load_phys(cfg, B, e, &s);
+    real lam[17][3], tau[12];
+    for (int b = 0; b < 17; b++) {
+      lam[b][0] = (real)AT(B->contact_forces, 3 * b + 2, e) * (real)cfg->sim_dt;
+      lam[b][1] = (real)AT(B->contact_forces, 3 * b + 0, e) * (real)cfg->sim_dt;
+      lam[b][2] = (real)AT(B->contact_forces, 3 * b + 1, e) * (real)cfg->sim_dt;
+    }
+    for (int j = 0; j < 12; j++) tau[j] = AT(B->torques, j, e);
+    ContactOut co;
+    physics_substep(cfg, &ter, &s, tau, grav, lam, cfg->warm_start, &co);
+    store_phys(cfg, B, e, &s);
+    real fp[4][3], fv[4][3];
+    feet_state(&s, fp, fv);
+    for (int f = 0; f < 4; f++)
+      for (int i = 0; i < 3; i++) { AT(B->foot_positions, 3 * f + i, e) = (float)fp[f][i]; AT(B->foot_velocities, 3 * f + i, e) = (float)fv[f][i]; }
+    for (int b = 0; b < 17; b++)
+      for (int i = 0; i < 3; i++) AT(B->contact_forces, 3 * b + i, e) = (float)co.force[b][i];
+  }
+}
+
+/* post-physics only (tensor maps) on whatever is in the buffers: used to pin the maps against the
+ * reference's Python (tests/test_oracle_golden.py).  grav_used: gravity vector of the step. */
+void go1_oracle_post_physics(const Go1SimConfig* cfg, const Go1SimBuffers* B, const double* grav_used, Go1OracleCounters* ctr) {
+  int64_t counter_post = ctr->common_step_counter + 1;
+  for (int kx = 0; kx <= cfg->num_rewards + 1; kx++) B->episode_log[kx] = 0;
+  for (int e = 0; e < cfg->num_envs; e++) post_physics(cfg, B, e, counter_post, grav_used, cfg->lag_timesteps + 1);
+  ctr->common_step_counter = counter_post;
+}
+
+void go1_oracle_gravity_at(const Go1SimConfig* cfg, int64_t t, double* g) { gravity_at(cfg, t, g); }
+float go1_oracle_uniform(const Go1SimConfig* cfg, uint32_t env, int64_t step, uint32_t purpose, uint32_t idx) {
+  return rng_uniform(cfg, env, step, purpose, idx);
+}
+int go1_oracle_sizeof_config(void) { return (int)sizeof(Go1SimConfig); }
+int go1_oracle_sizeof_buffers(void) { return (int)sizeof(Go1SimBuffers); }

@@ -1,0 +1,133 @@
+"""ctypes access to the CPU oracle (oracle/go1_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Allowed importers: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.  The product
+path (walk-these-ways_amd/) never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.join(_HERE, "..", "walk-these-ways_amd")
+for p in (_PKG, os.path.join(_PKG, "shims")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import go1sim_abi as abi  # noqa: E402
+
+LIB = os.path.join(_HERE, "_build", "libgo1oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "go1_oracle.c")
+    stale = (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(
+        os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "..", "include", "go1sim.h")))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+    return LIB
+
+
+class Counters(ctypes.Structure):
+    _fields_ = [("common_step_counter", ctypes.c_int64), ("lag_head", ctypes.c_int32), ("history_slot", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(LIB)
+        cfgp, bufp, ctrp = ctypes.POINTER(abi.Go1SimConfig), ctypes.POINTER(abi.Go1SimBuffers), ctypes.POINTER(Counters)
+        vp = ctypes.c_void_p
+        L.go1_oracle_step.argtypes = [cfgp, bufp, vp, ctrp]
+        L.go1_oracle_compute_torques.argtypes = [cfgp, bufp, vp, ctrp]
+        L.go1_oracle_physics_substep.argtypes = [cfgp, bufp, ctrp]
+        L.go1_oracle_post_physics.argtypes = [cfgp, bufp, vp, ctrp]
+        L.go1_oracle_reset_idx.argtypes = [cfgp, bufp, vp, ctypes.c_int, ctypes.c_int64]
+        L.go1_oracle_curriculum_update.argtypes = [cfgp, bufp]
+        L.go1_oracle_dynamics.argtypes = [vp] * 5 + [ctypes.c_double] + [vp] * 4
+        L.go1_oracle_actuator_net.argtypes = [vp, ctypes.c_int, vp]
+        L.go1_oracle_philox.argtypes = [vp, vp, vp]
+        L.go1_oracle_gravity_at.argtypes = [cfgp, ctypes.c_int64, vp]
+        L.go1_oracle_uniform.argtypes = [cfgp, ctypes.c_uint32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint32]
+        L.go1_oracle_uniform.restype = ctypes.c_float
+        assert L.go1_oracle_sizeof_config() == ctypes.sizeof(abi.Go1SimConfig)
+        assert L.go1_oracle_sizeof_buffers() == ctypes.sizeof(abi.Go1SimBuffers)
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class Oracle:
+    """Steps CPU `SimBuffers` (go1sim_host.SimBuffers on device 'cpu') with the oracle."""
+
+    def __init__(self, S, buffers):
+        assert buffers.device.type == "cpu"
+        self.S, self.buffers = S, buffers
+        self.ctr = Counters(0, 0, 0)
+        self.L = lib()
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        assert a.shape == (self.S.num_envs, 12)
+        self.L.go1_oracle_step(ctypes.byref(self.S), ctypes.byref(self.buffers.struct), _ptr(a), ctypes.byref(self.ctr))
+
+    def compute_torques(self, actions_soa):
+        a = np.ascontiguousarray(actions_soa, dtype=np.float32)
+        assert a.shape == (12, self.S.num_envs)
+        self.L.go1_oracle_compute_torques(ctypes.byref(self.S), ctypes.byref(self.buffers.struct), _ptr(a), ctypes.byref(self.ctr))
+
+    def physics_substep(self):
+        self.L.go1_oracle_physics_substep(ctypes.byref(self.S), ctypes.byref(self.buffers.struct), ctypes.byref(self.ctr))
+
+    def post_physics(self, gravity):
+        g = np.ascontiguousarray(gravity, dtype=np.float64)
+        self.L.go1_oracle_post_physics(ctypes.byref(self.S), ctypes.byref(self.buffers.struct), _ptr(g), ctypes.byref(self.ctr))
+
+    def reset_idx(self, ids=None):
+        if ids is None:
+            self.L.go1_oracle_reset_idx(ctypes.byref(self.S), ctypes.byref(self.buffers.struct), None, 0, self.ctr.common_step_counter)
+        else:
+            i = np.ascontiguousarray(ids, dtype=np.int32)
+            self.L.go1_oracle_reset_idx(ctypes.byref(self.S), ctypes.byref(self.buffers.struct), _ptr(i), len(i), self.ctr.common_step_counter)
+
+    def curriculum_update(self):
+        self.L.go1_oracle_curriculum_update(ctypes.byref(self.S), ctypes.byref(self.buffers.struct))
+
+    def gravity_at(self, t):
+        g = np.zeros(3)
+        self.L.go1_oracle_gravity_at(ctypes.byref(self.S), int(t), _ptr(g))
+        return g
+
+
+def dynamics(root13, q, qd, tau, grav, payload=0.0, com_disp=(0, 0, 0)):
+    """(M, bias, acc) of the floating-base model at a state (fp64)."""
+    L = lib()
+    arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (root13, q, qd, tau, grav)]
+    cd = np.ascontiguousarray(com_disp, dtype=np.float64)
+    M, b, a = np.zeros((18, 18)), np.zeros(18), np.zeros(18)
+    L.go1_oracle_dynamics(*[_ptr(x) for x in arrs], float(payload), _ptr(cd), _ptr(M), _ptr(b), _ptr(a))
+    return M, b, a
+
+
+def actuator_net(x):
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 6)
+    out = np.zeros(len(x))
+    lib().go1_oracle_actuator_net(_ptr(x), len(x), _ptr(out))
+    return out
+
+
+def philox(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    o = np.zeros(4, dtype=np.uint32)
+    lib().go1_oracle_philox(_ptr(c), _ptr(k), _ptr(o))
+    return o

@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by executing the REFERENCE's own Python on CPU.
+
+Runs only in the authoring container (needs /root/reference).  Technique: inject
+test-only stub modules for the packages the reference imports but that are absent here
+(`isaacgym`, `params_proto`, `ml_logger`, `gym`), import go1_gym.envs.base.legged_robot and
+go1_gym.envs.rewards.corl_rewards FROM /root/reference, and call the unbound methods
+(`LeggedRobot._compute_torques`, `_step_contact_targets`, `check_termination`, `compute_reward`,
+`compute_observations`, `_get_noise_scale_vec`, `_prepare_reward_function`) on a mock object that
+carries synthetic state tensors.  No reference code is copied; its functions are executed.
+The `isaacgym.torch_utils` helpers the reference calls are plain quaternion algebra and come from
+walk-these-ways_amd/go1_gym/utils/math_utils.py (loaded under a private name).
+
+Output: tests/golden/maps_<variant>.npz, torques_<variant>.npz, curriculum.npz
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+PKG = os.path.join(REPO, "walk-these-ways_amd")
+
+
+def load_private(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def install_stubs():
+    sys.path.insert(0, os.path.join(PKG, "shims"))          # params_proto stand-in
+    mu = load_private("_wtw_math_utils", os.path.join(PKG, "go1_gym", "utils", "math_utils.py"))
+    isaacgym = types.ModuleType("isaacgym")
+    tu = types.ModuleType("isaacgym.torch_utils")
+    for n in ("quat_rotate_inverse", "quat_apply", "quat_from_angle_axis", "quat_mul", "quat_conjugate", "normalize",
+              "torch_rand_float", "to_torch", "get_axis_params", "quat_rotate"):
+        setattr(tu, n, getattr(mu, n))
+    tu.torch = torch
+    tu.np = np
+    for n in ("gymtorch", "gymapi", "gymutil", "terrain_utils"):
+        m = types.ModuleType(f"isaacgym.{n}")
+        setattr(isaacgym, n, m)
+        sys.modules[f"isaacgym.{n}"] = m
+    isaacgym.torch_utils = tu
+    sys.modules["isaacgym"] = isaacgym
+    sys.modules["isaacgym.torch_utils"] = tu
+    gym = types.ModuleType("gym")
+    gym.Env = object
+    gym.Wrapper = object
+    gym.spaces = types.ModuleType("gym.spaces")
+    sys.modules["gym"] = gym
+    sys.modules["gym.spaces"] = gym.spaces
+    sys.path.insert(0, REF)
+
+
+class Mock:
+    pass
+
+
+def rand_quat(rng, n, tilt=0.5):
+    ax = rng.standard_normal((n, 3))
+    ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang = rng.uniform(-tilt, tilt, n)
+    yaw = rng.uniform(-3.14, 3.14, n)
+    q1 = np.concatenate([ax * np.sin(ang / 2)[:, None], np.cos(ang / 2)[:, None]], 1)
+    q2 = np.stack([0 * yaw, 0 * yaw, np.sin(yaw / 2), np.cos(yaw / 2)], 1)
+    from _wtw_math_utils import quat_mul
+    return quat_mul(torch.tensor(q2), torch.tensor(q1)).float()
+
+
+def make_env(variant, N, seed, mild=False):
+    """A mock LeggedRobot carrying a random but plausible post-physics state."""
+    from go1_gym.envs.base.legged_robot import LeggedRobot       # the REFERENCE module
+    from go1_gym.envs.base.legged_robot_config import Cfg
+    from _wtw_math_utils import quat_rotate_inverse
+    tc = load_private("_wtw_train_config", os.path.join(PKG, "scripts", "train_config.py"))
+    var = load_private("_wtw_variants", os.path.join(HERE, "variants.py"))
+    tc.apply_train_config(Cfg)
+    var.apply_variant(Cfg, variant)
+    rng = np.random.default_rng(seed)
+    f = lambda *s, lo=-1.0, hi=1.0: torch.tensor(rng.uniform(lo, hi, s), dtype=torch.float)
+    k = 0.08 if mild else 1.0        # "mild" states sit near nominal standing so the total reward is not ~0
+
+    e = Mock()
+    e.cfg = Cfg
+    e.device = "cpu"
+    e.num_envs = e.num_train_envs = N
+    e.num_actions = e.num_dof = e.num_dofs = e.num_actuated_dof = 12
+    e.num_bodies = 17
+    e.sim_params = Mock()
+    e.sim_params.dt = float(np.float32(Cfg.sim.dt))
+    LeggedRobot._parse_cfg(e, Cfg)
+    legs = ["FL", "FR", "RL", "RR"]
+    e.dof_names = [f"{l}_{p}_joint" for l in legs for p in ("hip", "thigh", "calf")]
+    e.default_dof_pos = torch.tensor([Cfg.init_state.default_joint_angles[n] for n in e.dof_names]).unsqueeze(0)
+    e.feet_indices = torch.tensor([4, 8, 12, 16])
+    e.penalised_contact_indices = torch.tensor([2, 6, 10, 14, 3, 7, 11, 15])
+    e.termination_contact_indices = torch.tensor([0])
+    lo = torch.tensor([-0.802851455917, -1.0471975512, -2.69653369433] * 4)
+    hi = torch.tensor([0.802851455917, 4.18879020479, -0.916297857297] * 4)
+    m, r = (lo + hi) / 2, hi - lo
+    e.dof_pos_limits = torch.stack([m - 0.5 * r * Cfg.rewards.soft_dof_pos_limit, m + 0.5 * r * Cfg.rewards.soft_dof_pos_limit], 1)
+    e.torque_limits = torch.full((12,), 33.5)
+    e.p_gains = torch.full((12,), 20.0)
+    e.d_gains = torch.full((12,), 0.5)
+
+    # --- state
+    e.root_states = torch.zeros(N, 13)
+    e.root_states[:, 0:2] = f(N, 2, lo=-3, hi=3)
+    e.root_states[:, 2] = f(N, lo=0.25, hi=0.34) if mild else f(N, lo=0.03, hi=0.40)
+    e.root_states[:, 3:7] = rand_quat(rng, N, tilt=0.5 * k)
+    e.root_states[:, 7:13] = f(N, 6, lo=-1.5, hi=1.5) * (0.3 if mild else 1.0)
+    e.base_pos = e.root_states[:, 0:3]
+    e.base_quat = e.root_states[:, 3:7]
+    e.dof_pos = e.default_dof_pos + f(N, 12, lo=-0.9, hi=0.9) * k
+    e.dof_vel = f(N, 12, lo=-8, hi=8) * k
+    e.gravity_vec = torch.tensor([0.3, -0.2, -9.8]).div(torch.tensor([0.3, -0.2, -9.8]).norm()).repeat(N, 1)
+    e.gravities = torch.tensor([0.3, -0.2, 0.0]).repeat(N, 1)
+    e.base_lin_vel = quat_rotate_inverse(e.base_quat, e.root_states[:, 7:10])
+    e.base_ang_vel = quat_rotate_inverse(e.base_quat, e.root_states[:, 10:13])
+    e.projected_gravity = quat_rotate_inverse(e.base_quat, e.gravity_vec)
+    e.foot_positions = e.base_pos.unsqueeze(1) + f(N, 4, 3, lo=-0.4, hi=0.4)
+    if mild:
+        from _wtw_math_utils import quat_apply_yaw
+        nominal = torch.tensor([[0.2, 0.14, 0.], [0.2, -0.14, 0.], [-0.2, 0.14, 0.], [-0.2, -0.14, 0.]]).repeat(N, 1, 1)
+        nominal = nominal + f(N, 4, 3, lo=-0.03, hi=0.03)
+        for i in range(4):
+            e.foot_positions[:, i] = e.base_pos + quat_apply_yaw(e.base_quat.clone(), nominal[:, i])
+    e.foot_positions[:, :, 2] = f(N, 4, lo=0.0, hi=0.15) * (0.5 if mild else 1.0) + (0.02 if mild else 0.0)
+    e.foot_velocities = f(N, 4, 3, lo=-2, hi=2) * k
+    e.prev_foot_velocities = f(N, 4, 3, lo=-2, hi=2)
+    cf = f(N, 17, 3, lo=-1, hi=1) * torch.tensor(rng.choice([0.0, 0.05, 2.0, 60.0, 200.0], (N, 17, 1)), dtype=torch.float)
+    cf[:, :, 2] = cf[:, :, 2].abs()
+    if mild:
+        cf[:, [0, 1, 2, 3, 5, 6, 7, 9, 10, 11, 13, 14, 15]] = 0.0
+        cf[:, [4, 8, 12, 16]] = cf[:, [4, 8, 12, 16]].clamp(-40, 40)
+    cf[: N // 2, 0] *= 0.0                                     # half the envs: no base contact -> no termination
+    e.contact_forces = cf
+    e.actions = f(N, 12, lo=-3, hi=3) * k
+    e.last_actions = k * f(N, 12, lo=-3, hi=3) * torch.tensor(rng.choice([0.0, 1.0], (N, 12), p=[0.2, 0.8]), dtype=torch.float)
+    e.last_last_actions = k * f(N, 12, lo=-3, hi=3) * torch.tensor(rng.choice([0.0, 1.0], (N, 12), p=[0.2, 0.8]), dtype=torch.float)
+    e.joint_pos_target = e.default_dof_pos + f(N, 12, lo=-0.7, hi=0.7) * k
+    e.last_joint_pos_target = e.default_dof_pos + f(N, 12, lo=-0.7, hi=0.7) * k
+    e.last_last_joint_pos_target = e.default_dof_pos + f(N, 12, lo=-0.7, hi=0.7) * k
+    e.last_dof_vel = e.dof_vel + f(N, 12, lo=-8, hi=8) * k * 0.1 if mild else f(N, 12, lo=-8, hi=8)
+    e.torques = f(N, 12, lo=-33.5, hi=33.5) * (0.2 if mild else 1.0)
+    e.last_contacts = torch.tensor(rng.choice([False, True], (N, 4)))
+    c = Cfg.commands
+    rngs = [c.lin_vel_x, c.lin_vel_y, c.ang_vel_yaw, c.body_height_cmd, c.gait_frequency_cmd_range, [0, 1], [0, 1], [0, 1],
+            c.gait_duration_cmd_range, c.footswing_height_range, c.body_pitch_range, [-0.2, 0.2], c.stance_width_range,
+            c.stance_length_range, c.aux_reward_coef_range]
+    e.commands = torch.stack([f(N, lo=a, hi=b) if b > a else torch.full((N,), float(a)) for a, b in rngs], 1)
+    e.commands[:, 5:8] = torch.round(2 * e.commands[:, 5:8]) / 2.0 % 1
+    e.commands[N // 4: N // 2, 8] = f(N // 2 - N // 4, lo=0.3, hi=0.7)     # non-default stance durations too
+    e.gait_indices = f(N, lo=0, hi=1)
+    e.clock_inputs = torch.zeros(N, 4)
+    e.doubletime_clock_inputs = torch.zeros(N, 4)
+    e.halftime_clock_inputs = torch.zeros(N, 4)
+    e.desired_contact_states = torch.zeros(N, 4)
+    e.episode_length_buf = torch.tensor(rng.integers(2, 480, N), dtype=torch.long)
+    e.episode_length_buf[-3:] = int(e.cfg.env.max_episode_length) + torch.tensor([0, 1, 2])
+    e.measured_heights = 0
+    # domain randomisation
+    e.friction_coeffs = f(N, 1, lo=0.1, hi=3.0).repeat(1, 4)
+    e.restitutions = f(N, 1, lo=0.0, hi=0.4).repeat(1, 4)
+    e.payloads = f(N, lo=-1, hi=3)
+    e.com_displacements = f(N, 3, lo=-0.1, hi=0.1)
+    e.motor_strengths = f(N, 1, lo=0.9, hi=1.1).repeat(1, 12)
+    e.motor_offsets = f(N, 12, lo=-0.02, hi=0.02)
+    e.Kp_factors = f(N, 1, lo=0.8, hi=1.3).repeat(1, 12)
+    e.Kd_factors = f(N, 1, lo=0.5, hi=1.5).repeat(1, 12)
+    os_ = e.obs_scales
+    e.commands_scale = torch.tensor([os_.lin_vel, os_.lin_vel, os_.ang_vel, os_.body_height_cmd, os_.gait_freq_cmd,
+                                     os_.gait_phase_cmd, os_.gait_phase_cmd, os_.gait_phase_cmd, os_.gait_phase_cmd,
+                                     os_.footswing_height_cmd, os_.body_pitch_cmd, os_.body_roll_cmd, os_.stance_width_cmd,
+                                     os_.stance_length_cmd, os_.aux_reward_cmd])[:Cfg.commands.num_commands]
+    e.forward_vec = torch.tensor([1., 0., 0.]).repeat(N, 1)
+    e.obs_buf = torch.zeros(N, Cfg.env.num_observations)
+    e.noise_scale_vec = LeggedRobot._get_noise_scale_vec(e, Cfg)
+    e.rew_buf = torch.zeros(N)
+    e.rew_buf_pos = torch.zeros(N)
+    e.rew_buf_neg = torch.zeros(N)
+    LeggedRobot._prepare_reward_function(e)
+    for k in e.episode_sums:
+        e.episode_sums[k] = f(N, lo=-2, hi=2)
+    for k in e.command_sums:
+        e.command_sums[k] = f(N, lo=-2, hi=2)
+    return e, LeggedRobot
+
+
+def flat(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def gen_maps(variant, N=48, seed=11, mild=False):
+    e, LR = make_env(variant, N, seed, mild)
+    inp = dict(root_states=e.root_states.clone(), dof_pos=e.dof_pos.clone(), dof_vel=e.dof_vel.clone(),
+               gravity=torch.tensor([0.3, -0.2, -9.8]), foot_positions=e.foot_positions.clone(),
+               foot_velocities=e.foot_velocities.clone(), prev_foot_velocities=e.prev_foot_velocities.clone(),
+               contact_forces=e.contact_forces.clone(), actions=e.actions.clone(), last_actions=e.last_actions.clone(),
+               last_last_actions=e.last_last_actions.clone(), joint_pos_target=e.joint_pos_target.clone(),
+               last_joint_pos_target=e.last_joint_pos_target.clone(),
+               last_last_joint_pos_target=e.last_last_joint_pos_target.clone(), last_dof_vel=e.last_dof_vel.clone(),
+               torques=e.torques.clone(), last_contacts=e.last_contacts.clone(), commands=e.commands.clone(),
+               gait_indices=e.gait_indices.clone(), episode_length_buf=e.episode_length_buf.clone(),
+               friction_coeffs=e.friction_coeffs[:, 0].clone(), restitutions=e.restitutions[:, 0].clone(),
+               payloads=e.payloads.clone(), com_displacements=e.com_displacements.clone(),
+               motor_strengths=e.motor_strengths.clone(), motor_offsets=e.motor_offsets.clone(),
+               episode_sums=torch.stack([e.episode_sums[k] for k in e.episode_sums]).clone(),
+               command_sums=torch.stack([e.command_sums[k] for k in e.command_sums]).clone())
+    names = dict(episode_sum_names=np.array(list(e.episode_sums)), command_sum_names=np.array(list(e.command_sums)),
+                 reward_names=np.array(e.reward_names),
+                 reward_scales=np.array([e.reward_scales[n] for n in e.reward_names]))
+    # the reference's post_physics_step order (legged_robot.py:117-124), physics-free parts
+    LR._step_contact_targets(e)
+    LR.check_termination(e)
+    LR.compute_reward(e)
+    LR.compute_observations(e)
+    clip = e.cfg.normalization.clip_observations
+    out = dict(out_gait_indices=e.gait_indices, out_foot_indices=e.foot_indices, out_clock_inputs=e.clock_inputs,
+               out_desired_contact_states=e.desired_contact_states, out_reset_buf=e.reset_buf, out_time_out_buf=e.time_out_buf,
+               out_rew_buf=e.rew_buf, out_last_contacts=e.last_contacts,
+               out_episode_sums=torch.stack([e.episode_sums[k] for k in e.episode_sums]),
+               out_command_sums=torch.stack([e.command_sums[k] for k in e.command_sums]),
+               out_obs=torch.clip(e.obs_buf, -clip, clip), out_priv=torch.clip(e.privileged_obs_buf, -clip, clip),
+               out_noise_scale_vec=e.noise_scale_vec, out_base_lin_vel=e.base_lin_vel, out_base_ang_vel=e.base_ang_vel,
+               out_projected_gravity=e.projected_gravity,
+               out_max_episode_length=np.array(int(e.cfg.env.max_episode_length)),
+               out_dof_pos_soft_limits=e.dof_pos_limits)
+    np.savez_compressed(os.path.join(HERE, f"maps_{variant}{'_mild' if mild else ''}.npz"), **flat(inp), **flat(out), **names)
+    print("maps", variant, "rew mean", float(e.rew_buf.mean()), "resets", int(e.reset_buf.sum()))
+
+
+def gen_torques(variant, N=16, steps=12, seed=5):
+    e, LR = make_env(variant, N, seed)
+    net = torch.jit.load(os.path.join(REF, "resources/actuator_nets/unitree_go1.pt"), map_location="cpu")
+
+    def eval_net(p, pl, pll, v, vl, vll):     # same packing as legged_robot.py:1242-1251 (closure not importable)
+        xs = torch.stack((p, pl, pll, v, vl, vll), dim=-1)
+        return net(xs.view(N * 12, 6)).view(N, 12)
+    e.actuator_network = eval_net
+    rng = np.random.default_rng(seed + 1)
+    e.lag_buffer = [torch.zeros(N, 12) for _ in range(e.cfg.domain_rand.lag_timesteps + 1)]
+    for n in ("joint_pos_err_last_last", "joint_pos_err_last", "joint_vel_last_last", "joint_vel_last"):
+        setattr(e, n, torch.zeros(N, 12))
+    rec = dict(motor_strengths=e.motor_strengths, motor_offsets=e.motor_offsets, Kp_factors=e.Kp_factors, Kd_factors=e.Kd_factors)
+    acts, qs, qds, taus, tgts = [], [], [], [], []
+    for s in range(steps):
+        a = torch.tensor(rng.uniform(-4, 4, (N, 12)), dtype=torch.float)
+        e.dof_pos = e.default_dof_pos + torch.tensor(rng.uniform(-0.8, 0.8, (N, 12)), dtype=torch.float)
+        e.dof_vel = torch.tensor(rng.uniform(-10, 10, (N, 12)), dtype=torch.float)
+        with torch.no_grad():
+            tau = LR._compute_torques(e, a)
+        acts.append(a); qs.append(e.dof_pos.clone()); qds.append(e.dof_vel.clone()); taus.append(tau.clone()); tgts.append(e.joint_pos_target.clone())
+    rec.update(actions=torch.stack(acts), dof_pos=torch.stack(qs), dof_vel=torch.stack(qds), torques=torch.stack(taus),
+               joint_pos_target=torch.stack(tgts))
+    np.savez_compressed(os.path.join(HERE, f"torques_{variant}.npz"), **flat(rec))
+    print("torques", variant, "mean |tau|", float(torch.stack(taus).abs().mean()))
+
+
+def gen_curriculum():
+    """reference curriculum.py (importable standalone): grid, set_to, get_local_bins, update."""
+    from go1_gym.envs.base.curriculum import RewardThresholdCurriculum as Ref
+    kw = dict(x_vel=(-5.0, 5.0, 21), y_vel=(-0.6, 0.6, 1), yaw_vel=(-5.0, 5.0, 21), body_height=(-0.25, 0.15, 2),
+              gait_frequency=(2.0, 4.0, 3))
+    r = Ref(seed=100, **kw)
+    low, high = np.array([-1.0, -0.6, -1.0, -0.25, 2.0]), np.array([1.0, 0.6, 1.0, 0.15, 4.0])
+    r.set_to(low=low, high=high)
+    w0 = r.weights.copy()
+    bins = np.array([5, 300, 301, 300, 900, 17])
+    rew = [torch.tensor([1.0, 0.9, 0.2, 0.95, 0.99, 0.1]), torch.tensor([0.8, 0.9, 0.9, 0.1, 0.9, 0.9])]
+    lr = np.array([0.55, 0.55, 0.55, 0.55, 0.35])
+    r.update(bins, rew, [0.5, 0.5], local_range=lr)
+    local = r.get_local_bins(np.array([0, 300, 1322]), ranges=lr)
+    samples, inds = r.sample(64)
+    np.savez_compressed(os.path.join(HERE, "curriculum.npz"), grid=r.grid, weights0=w0, weights1=r.weights, bins=bins,
+                        rew0=rew[0].numpy(), rew1=rew[1].numpy(), local=local, samples=samples, inds=inds, low=low, high=high,
+                        local_range=lr)
+    print("curriculum weights", w0.sum(), r.weights.sum())
+
+
+if __name__ == "__main__":
+    install_stubs()
+    torch.manual_seed(0)
+    gen_curriculum()
+    for v in ("train", "alt"):
+        # the reference mutates the global Cfg: one process state per variant
+        for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+            del sys.modules[m]
+        gen_maps(v)
+        for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+            del sys.modules[m]
+        gen_maps(v, seed=23, mild=True)
+        for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+            del sys.modules[m]
+        gen_torques(v)

@@ -1,0 +1,75 @@
+"""Shared helpers for the tests: build configs/buffers, load golden fixtures into SoA buffers."""
+import os
+
+import numpy as np
+import torch
+
+import go1sim_host as H
+from go1_gym.envs.base.legged_robot_config import make_cfg
+from scripts.train_config import apply_train_config
+from golden.variants import apply_variant
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def make_cfg_variant(variant="train", num_envs=16, extra=None):
+    cfg = apply_train_config(make_cfg(), num_envs=num_envs)
+    if variant != "train_noise":
+        apply_variant(cfg, variant)
+    for section, values in (extra or {}).items():
+        for k, v in values.items():
+            setattr(getattr(cfg, section), k, v)
+    return cfg
+
+
+def make_sim(variant="train", num_envs=16, seed=3, extra=None, **kw):
+    cfg = make_cfg_variant(variant, num_envs, extra)
+    S, meta = H.build_sim_config(cfg, seed=seed, **kw)
+    B = H.SimBuffers(S, meta, "cpu")
+    return cfg, S, meta, B
+
+
+def standing_state(S, B, z=0.30):
+    B.root_states.zero_()
+    B.root_states[2] = z
+    B.root_states[6] = 1.0
+    B.dof_pos[:] = torch.tensor(list(S.default_dof_pos)).unsqueeze(1)
+    B.dof_vel.zero_()
+
+
+def randomize_dr(B, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    B.friction_coeffs.uniform_(0.1, 3.0, generator=g)
+    B.restitutions.uniform_(0.0, 0.4, generator=g)
+    B.payloads.uniform_(-1.0, 3.0, generator=g)
+
+
+def load_maps_fixture(name, S, meta, B):
+    """Fill SoA buffers from a tests/golden/maps_*.npz fixture (reference layouts are (N, ...))."""
+    d = np.load(os.path.join(GOLDEN, name))
+    t = lambda k: torch.from_numpy(np.ascontiguousarray(d[k]))
+    N = S.num_envs
+    B.root_states[:] = t("root_states").t()
+    B.dof_pos[:] = t("dof_pos").t()
+    B.dof_vel[:] = t("dof_vel").t()
+    B.foot_positions[:] = t("foot_positions").reshape(N, 12).t()
+    B.foot_velocities[:] = t("foot_velocities").reshape(N, 12).t()
+    B.prev_foot_velocities[:] = t("prev_foot_velocities").reshape(N, 12).t()
+    B.contact_forces[:] = t("contact_forces").reshape(N, 51).t()
+    for k in ("actions", "last_actions", "last_last_actions", "joint_pos_target", "last_joint_pos_target",
+              "last_last_joint_pos_target", "last_dof_vel", "torques", "motor_strengths", "motor_offsets"):
+        getattr(B, k)[:] = t(k).t()
+    B.last_contacts[:] = t("last_contacts").t().to(torch.uint8)
+    B.commands[:] = t("commands").t()
+    B.gait_indices[:] = t("gait_indices")
+    B.episode_length_buf[:] = (t("episode_length_buf") - 1).to(torch.int32)     # the oracle increments first
+    for k in ("friction_coeffs", "restitutions", "payloads"):
+        getattr(B, k)[:] = t(k)
+    B.com_displacements[:] = t("com_displacements").t()
+    es_names = [str(x) for x in d["episode_sum_names"]]
+    cs_names = [str(x) for x in d["command_sum_names"]]
+    assert es_names == meta["episode_sum_names"], (es_names, meta["episode_sum_names"])
+    assert cs_names == meta["command_sum_names"]
+    B.episode_sums[:] = t("episode_sums")
+    B.command_sums[:] = t("command_sums")
+    return d
