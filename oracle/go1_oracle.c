@@ -392,6 +392,11 @@ static void jac_row(const Kin* k, int dynb, const real* x, const real* d, real* 
   }
 }
 
+/* Solver contact list: at most GO1_MAX_CONTACTS of the 17 per-body contacts are handed to the solver, taken in
+ * this priority order (feet, trunk, calves, thighs, hips); the PGS sweeps follow the same order. */
+#define GO1_MAX_CONTACTS 6
+static const int CONTACT_ORDER[17] = {4, 8, 12, 16, 0, 3, 7, 11, 15, 2, 6, 10, 14, 1, 5, 9, 13};
+
 /* ------------------------------------------------------------------ one physics substep (replaces gym.simulate) */
 typedef struct { real force[17][3]; } ContactOut;
 
@@ -426,6 +431,14 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
   /* contacts at the start-of-step configuration */
   Contact C[17];
   detect_contacts(cfg, ter, &k, s->pos, C);
+  {
+    int kept = 0;
+    for (int o = 0; o < 17; o++) {
+      Contact* c = &C[CONTACT_ORDER[o]];
+      if (c->active && kept >= GO1_MAX_CONTACTS) c->active = 0;
+      kept += c->active;
+    }
+  }
   real J[17][3][NV], T[17][3][NV], A[17][3], vstar[17];
   real mu = 0.5 * (s->mu + (real)cfg->terrain_friction);        /* PhysX default combine mode: average */
   real e_c = 0.5 * (s->rest + (real)cfg->terrain_restitution);
@@ -451,7 +464,8 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
       for (int i = 0; i < NV; i++) v[i] += T[b][r][i] * lam[b][r];
   }
   for (int it = 0; it < cfg->solver_iterations; it++) {
-    for (int b = 0; b < 17; b++) {
+    for (int o = 0; o < 17; o++) {
+      const int b = CONTACT_ORDER[o];
       if (!C[b].active) continue;
       real un = 0;
       for (int i = 0; i < NV; i++) un += J[b][0][i] * v[i];

