@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec (sim+PPO) at 4096 Go1 envs per GPU (BASELINE.json metric), MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One *step* = one PPO iteration of the hot path over a fresh batch: 24 policy steps x 4096 envs through the fused
+HIP step kernel (torque model + 4 physics substeps + tensor maps each), policy inference for every step
+(`alg.act`), storage, GAE, then the full update (5 epochs x 4 mini-batches x {PPO step, adaptation step}).
+Workload = BASELINE.json configs[1]: Go1 flat terrain, 4096 envs, train.py configuration (actuator net, lag 6,
+domain randomisation, device command curriculum), bf16 policy.  Synthetic: random-init policy acting in closed
+loop, initial states from the reset distribution.  N > 1: every rank owns 4096 envs (weak scaling), gradients are
+all-reduced over RCCL; value = total env-steps of all ranks / max-over-ranks time.
+
+Extra JSON objects: `roofline` (step kernel's algorithmic HBM bytes / per-launch HIP-event duration, DESIGN.md
+"Measurement") and, on rank 0 at N=1, `cpu_baseline` (the fp64 oracle restatement of the same env step on the
+host cores — the reference's own CPU path, Isaac Gym CPU-PhysX, is a closed binary that cannot run here).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "walk-these-ways_amd")
+for p in (os.path.join(PKG, "shims"), PKG, REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+ALGORITHMIC_BYTES_PER_ENV_STEP = 3444      # 1,332 B read + 1,832 B written + 280 B history append
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def build_env(num_envs, rank, seed):
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+    from go1_gym.envs.wrappers.history_wrapper import HistoryWrapper
+    from scripts.train_config import apply_train_config
+    cfg = apply_train_config(make_cfg(), num_envs=num_envs)
+    cfg.seed = seed
+    cfg.env.env_id_offset = rank * num_envs
+    env = VelocityTrackingEasyEnv(sim_device=f"cuda:{torch.cuda.current_device()}", headless=True, cfg=cfg)
+    return HistoryWrapper(env), cfg
+
+
+def cpu_baseline(num_envs, policy_steps=24):
+    """Oracle (fp64 port of the same step, OpenMP over envs) on the host cores: bounded sample."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import numpy as np
+    import pyoracle
+    import go1sim_host as H
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from scripts.train_config import apply_train_config
+    cfg = apply_train_config(make_cfg(), num_envs=num_envs)
+    S, meta = H.build_sim_config(cfg, seed=0)
+    B = H.SimBuffers(S, meta, "cpu")
+    B.friction_coeffs.uniform_(0.1, 3.0)
+    B.payloads.uniform_(-1.0, 3.0)
+    orc = pyoracle.Oracle(S, B)
+    orc.reset_idx()
+    rng = np.random.default_rng(0)
+    acts = rng.standard_normal((policy_steps, num_envs, 12)).astype(np.float32)
+    orc.step(acts[0])
+    t0 = time.perf_counter()
+    for a in acts:
+        orc.step(a)
+    dt = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    return {"value": num_envs * policy_steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{num_envs} envs x {policy_steps} policy steps of the sim step only (no policy/PPO), fp64 oracle "
+                      f"(oracle/go1_oracle.c, OpenMP over envs), N(0,1) actions, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10, help="timed PPO iterations")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--fp32", action="store_true", help="fp32 policy instead of bf16 autocast")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sim-only", action="store_true", help="diagnostic: time env.step alone with pre-generated actions")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from go1_gym_learn.ppo_cse import Runner, RunnerArgs
+    from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    PPO_Args.autocast_bf16 = not args.fp32
+    RunnerArgs.save_video_interval = 0
+    torch.manual_seed(args.seed + rank)
+    env, cfg = build_env(args.envs, rank, args.seed)
+    device = f"cuda:{local_rank}"
+    runner = Runner(env, device=device)
+    sim = env.env.sim
+    T = runner.num_steps_per_env
+    sim.enable_timing(T * args.steps)
+
+    buf = env.episode_length_buf
+    buf.copy_(torch.randint_like(buf, high=int(env.max_episode_length)))
+    obs_dict = env.get_observations()
+    runner.alg.actor_critic.train()
+
+    def iteration(obs_dict):
+        with torch.inference_mode():
+            for _ in range(T):
+                obs_dict, _ = runner._rollout_step(obs_dict)
+            n = env.num_train_envs
+            runner.alg.compute_returns(obs_dict["obs_history"][:n], obs_dict["privileged_obs"][:n])
+        runner.alg.update()
+        return obs_dict
+
+    def sim_iteration(obs_dict, acts):
+        for t in range(T):
+            obs_dict, _, _, _ = env.step(acts[t])
+        return obs_dict
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    acts = torch.randn(T, args.envs, 12, device=device) if args.sim_only else None
+    for _ in range(args.warmup):
+        obs_dict = sim_iteration(obs_dict, acts) if args.sim_only else iteration(obs_dict)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        obs_dict = sim_iteration(obs_dict, acts) if args.sim_only else iteration(obs_dict)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    kernel_ms = sim.read_timings()
+    if rank == 0:
+        total_env_steps = args.envs * T * args.steps * world
+        avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * args.envs
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec (sim+PPO)" if not args.sim_only else "env-steps/sec (sim only, diagnostic)",
+            "value": total_env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Go1 flat terrain, 4096 envs/GPU, train.py config (actuator_net, lag 6, DR, gait "
+                                   "curriculum), HIP sim + ppo_cse, 24 steps/iter, 5 epochs x 4 minibatches",
+                       "envs_per_gpu": args.envs, "policy_dtype": "fp32" if args.fp32 else "bf16 autocast (fp32 master)",
+                       "physics_dtype": "f32", "step": "one PPO iteration = 24 x envs env-steps + update",
+                       "parallelism": f"dp{world} (envs sharded, RCCL gradient all-reduce)" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "go1_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launch_ms": avg_ms, "launches": len(kernel_ms), "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "latency/issue-bound O(n_dof) recursion: the HBM fraction is reported as north_star requires, "
+                                 "it is not the limiter (DESIGN.md Measurement)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.envs)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

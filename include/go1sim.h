@@ -225,7 +225,8 @@ typedef struct Go1SimBuffers {
   float* rew_buf;                  /* [N] */
   float* episode_sums;             /* [num_rewards+1][N], last row = "total" */
   float* command_sums;             /* [num_rewards+5][N]: +lin_vel_raw, ang_vel_raw, lin_vel_residual, ang_vel_residual, ep_timesteps */
-  float* episode_log;              /* [num_rewards+1 +1]: per-call sum over reset envs of episode_sums, last = count */
+  float* episode_log;              /* [num_rewards+1 +1]: running sum over reset envs of episode_sums, last = count;
+                                      accumulated atomically by step/reset_idx, zeroed by the caller when consumed */
   /* domain randomisation parameters — legged_robot.py:1260-1288 */
   float* friction_coeffs;          /* [N] */
   float* restitutions;             /* [N] */
@@ -247,7 +248,7 @@ typedef struct Go1SimBuffers {
   /* outputs consumed by the policy */
   float* obs_buf;                  /* (N, num_obs) */
   float* privileged_obs_buf;       /* (N, num_privileged_obs) */
-  float* obs_history;              /* (N, 2*H*num_obs) double-length ring; window documented in DESIGN.md */
+  float* obs_history;              /* (N, 2*(H+1)*num_obs): ring of H+1 slots stored twice; window via go1sim_history_window_offset */
   /* terrain */
   const int16_t* height_samples;   /* (hf_rows, hf_cols) or NULL for plane */
 } Go1SimBuffers;
@@ -279,14 +280,23 @@ int go1sim_reset_idx(Go1Sim* sim, const int32_t* ids, int32_t n, void* stream);
 int go1sim_compute_torques(Go1Sim* sim, const float* actions_soa, void* stream);   /* legged_robot.py:907-946 */
 int go1sim_physics_substep(Go1Sim* sim, void* stream);                             /* one gym.simulate, :76-80 */
 int go1sim_curriculum_update(Go1Sim* sim, void* stream);                           /* curriculum.py:135-154 */
+/* tensor maps of post_physics_step only (legged_robot.py:90-136) on the state in the buffers; `gravity` = host
+ * pointer to the 3 floats of the gravity vector in force during the step.  Advances common_step_counter. */
+int go1sim_post_physics(Go1Sim* sim, const float* gravity, void* stream);
+/* HistoryWrapper.get_observations' side effect (history_wrapper.py:26-30): append obs_buf to the history once more. */
+int go1sim_append_history(Go1Sim* sim, void* stream);
+/* Column (in floats) where the reference-ordered (oldest first) obs-history window starts inside each obs_history row. */
+int go1sim_history_window_offset(Go1Sim* sim, int32_t* offset_floats);
 
 /* Step counter (legged_robot.py:103 common_step_counter) and lag ring head live in the handle. */
 int go1sim_get_counters(Go1Sim* sim, int64_t* common_step_counter, int32_t* lag_head);
 int go1sim_set_counters(Go1Sim* sim, int64_t common_step_counter, int32_t lag_head);
 
-/* Duration in ms of the last go1sim_step's dominant kernel when timing is enabled (HIP events on `stream`). */
-int go1sim_enable_timing(Go1Sim* sim, int enable);
-int go1sim_last_step_kernel_ms(Go1Sim* sim, float* ms);
+/* Per-launch timing of the step kernel with HIP events recorded on the launch stream (bench.py roofline leg).
+ * enable_timing(capacity): keep event pairs for the last `capacity` go1sim_step launches (0 disables).
+ * read_timings: synchronises on the recorded events and returns up to `max` durations in ms (oldest first). */
+int go1sim_enable_timing(Go1Sim* sim, int capacity);
+int go1sim_read_timings(Go1Sim* sim, float* ms, int32_t max, int32_t* count);
 
 const char* go1sim_version(void);
 

@@ -1113,14 +1113,15 @@ static void post_physics(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e,
   }
 }
 
-/* history append (history_wrapper.py:23): double-length ring, slot k = step index mod H written at k and k+H;
- * the window of the reference's obs_history after this step is columns [(k+1)*num_obs, (k+1+H)*num_obs). */
+/* history append (history_wrapper.py:23): ring of R = H+1 slots stored twice back to back; the observation of
+ * this step goes to slot w and w+R.  The reference's obs_history (oldest first) after the append is the H-slot
+ * window starting at slot (w+2) mod R of the doubled row; the previous step's window is still intact. */
 static void history_append(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int slot) {
-  const int no = cfg->num_obs, H = cfg->num_obs_history;
-  float* row = B->obs_history + (size_t)e * 2 * H * no;
+  const int no = cfg->num_obs, R = cfg->num_obs_history + 1;
+  float* row = B->obs_history + (size_t)e * 2 * R * no;
   const float* obs = B->obs_buf + (size_t)e * no;
   memcpy(row + (size_t)slot * no, obs, no * sizeof(float));
-  memcpy(row + (size_t)(slot + H) * no, obs, no * sizeof(float));
+  memcpy(row + (size_t)(slot + R) * no, obs, no * sizeof(float));
 }
 
 /* ------------------------------------------------------------------ public step */
@@ -1184,7 +1185,7 @@ void go1_oracle_step(const Go1SimConfig* cfg, const Go1SimBuffers* B, const floa
     if (B->obs_history) history_append(cfg, B, e, ctr->history_slot);
   }
   ctr->common_step_counter = counter_post;
-  ctr->history_slot = (ctr->history_slot + 1) % cfg->num_obs_history;
+  ctr->history_slot = (ctr->history_slot + 1) % (cfg->num_obs_history + 1);
   if (cfg->device_curriculum && B->curriculum_weights) go1_oracle_curriculum_update(cfg, B);
 }
 

@@ -189,7 +189,7 @@ def test_determinism_and_shard_independence():
 def test_full_size_invariants_4096():
     """BASELINE config 2 size: 4096 envs, 50 steps of N(0,1) actions: finite, limits, cone, weight support at rest."""
     N = 4096
-    cfg, S, meta, Bc, orc = gpu_pair("train_noise", N, seed=9)
+    cfg, S, meta, Bc, orc = gpu_pair("train_noise", N, seed=9, extra={"domain_rand": dict(randomize_gravity=False)})
     Bg, sim = to_gpu(S, Bc)
     g = torch.Generator(device="cuda").manual_seed(0)
     for t in range(50):
@@ -222,6 +222,7 @@ def test_full_size_invariants_4096():
     # history ring: the reference window equals the last H observations, newest last
     H_, no = S.num_obs_history, S.num_obs
     c, _ = sim.counters()
-    k = (c - 1) % H_
-    win = Bg.obs_history[:, (k + 1) * no:(k + 1 + H_) * no]
+    off = sim.history_window_offset()
+    assert off == ((c % (H_ + 1)) + 1) % (H_ + 1) * no
+    win = Bg.obs_history[:, off:off + H_ * no]
     assert torch.equal(win[:, -no:], Bg.obs_buf)

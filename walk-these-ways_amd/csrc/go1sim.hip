@@ -64,7 +64,8 @@ struct StepArgs {
   int64_t counter;           // common_step_counter before this step
   int32_t lag_head;
   int32_t history_slot;
-  int32_t mode;              // 0 full step, 1 torques only, 2 one physics substep, 3 reset ids
+  int32_t mode;              // 0 full step, 1 torques only, 2 one physics substep, 3 reset ids, 4 post-physics only
+  float gravity_override[3];
   const int32_t* ids;
   int32_t n_ids;
 };
@@ -952,8 +953,9 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, in
   // ---- compute_observations ----------------------------------------------------------------------
   {
     float* obs_row = B.obs_buf + (size_t)e * cfg.num_obs;
-    float* h0 = B.obs_history ? B.obs_history + (size_t)e * 2 * cfg.num_obs_history * cfg.num_obs + (size_t)history_slot * cfg.num_obs : nullptr;
-    float* h1 = h0 ? h0 + (size_t)cfg.num_obs_history * cfg.num_obs : nullptr;
+    const int R = cfg.num_obs_history + 1;     // ring slots (one spare keeps the previous window intact)
+    float* h0 = B.obs_history ? B.obs_history + (size_t)e * 2 * R * cfg.num_obs + (size_t)history_slot * cfg.num_obs : nullptr;
+    float* h1 = h0 ? h0 + (size_t)R * cfg.num_obs : nullptr;
     int n = 0;
     auto emit = [&](float v) {
       if (cfg.add_noise && cfg.noise_scale_vec[n] != 0.f) v += (2 * rng_uniform(cfg, eg, counter_post, P_NOISE, n) - 1) * cfg.noise_scale_vec[n];
@@ -1082,6 +1084,10 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
     if (e < A.n_ids) reset_env(cfg, B, A.ids ? A.ids[e] : e, N, A.counter);
     return;
   }
+  if (A.mode == 4) {       // tensor maps only
+    post_physics(cfg, B, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot);
+    return;
+  }
   Base s;
   load_state(B, lds, lane, e, N, s);
   if (A.mode == 1) {       // torques only (actions given as SoA)
@@ -1127,6 +1133,18 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
   feet_state(lds, lane, s, B, e, N);
   store_forces(cfg, B, lds, lane, e, N);
   post_physics(cfg, B, e, N, A.counter + 1, grav, A.history_slot);
+}
+
+// HistoryWrapper.get_observations: append the current obs_buf to the double-length ring
+extern "C" __global__ void __launch_bounds__(256) go1_history_kernel(const Go1SimConfig cfg, const Go1SimBuffers B, int slot) {
+  const int no = cfg.num_obs, R = cfg.num_obs_history + 1;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)cfg.num_envs * no) return;
+  const size_t e = i / no, c = i % no;
+  float v = B.obs_buf[i];
+  float* row = B.obs_history + e * 2 * R * no;
+  row[(size_t)slot * no + c] = v;
+  row[(size_t)(slot + R) * no + c] = v;
 }
 
 // curriculum weight update + CDF rebuild (reference curriculum.py:135-154): one workgroup per category
@@ -1181,9 +1199,9 @@ struct Go1Sim {
   int64_t counter;
   int32_t lag_head;
   int32_t history_slot;
-  int timing;
-  hipEvent_t ev0, ev1;
-  bool ev_valid;
+  int timing_cap;
+  int64_t timing_n;
+  hipEvent_t* ev;      // 2 * timing_cap
 };
 
 static int check_cfg(const Go1SimConfig* cfg) {
@@ -1201,20 +1219,18 @@ extern "C" int go1sim_create(const Go1SimConfig* cfg, const Go1SimBuffers* buffe
   if (hipSetDevice(device) != hipSuccess) return -10;
   Go1Sim* s = new Go1Sim();
   s->cfg = *cfg; s->buf = *buffers; s->device = device;
-  s->counter = 0; s->lag_head = 0; s->history_slot = 0; s->timing = 0; s->ev_valid = false;
+  s->counter = 0; s->lag_head = 0; s->history_slot = 0; s->timing_cap = 0; s->timing_n = 0; s->ev = nullptr;
   if (hipFuncSetAttribute((const void*)go1_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_END * WAVE * 4) != hipSuccess) {
     delete s;
     return -11;
   }
-  (void)hipEventCreate(&s->ev0);
-  (void)hipEventCreate(&s->ev1);
   *out = s;
   return 0;
 }
 extern "C" int go1sim_destroy(Go1Sim* s) {
   if (!s) return -1;
-  (void)hipEventDestroy(s->ev0);
-  (void)hipEventDestroy(s->ev1);
+  for (int i = 0; i < 2 * s->timing_cap; i++) (void)hipEventDestroy(s->ev[i]);
+  delete[] s->ev;
   delete s;
   return 0;
 }
@@ -1227,27 +1243,29 @@ extern "C" int go1sim_set_config(Go1Sim* s, const Go1SimConfig* cfg) {
   return 0;
 }
 
-static int launch(Go1Sim* s, int mode, const float* actions, const int32_t* ids, int n_ids, hipStream_t st, bool timed) {
+static int launch(Go1Sim* s, int mode, const float* actions, const int32_t* ids, int n_ids, hipStream_t st, bool timed,
+                  const float* grav = nullptr) {
   StepArgs A;
+  for (int i = 0; i < 3; i++) A.gravity_override[i] = grav ? grav[i] : 0.f;
   A.cfg = s->cfg; A.buf = s->buf; A.actions = actions; A.counter = s->counter; A.lag_head = s->lag_head;
   A.history_slot = s->history_slot; A.mode = mode; A.ids = ids; A.n_ids = n_ids;
   const int n = (mode == 3) ? n_ids : s->cfg.num_envs;
   dim3 grid((n + WAVE - 1) / WAVE), block(WAVE);
-  if (timed) (void)hipEventRecord(s->ev0, st);
+  const int slot = timed ? (int)(s->timing_n % s->timing_cap) : 0;
+  if (timed) (void)hipEventRecord(s->ev[2 * slot], st);
   hipLaunchKernelGGL(go1_step_kernel, grid, block, L_END * WAVE * 4, st, A);
-  if (timed) { (void)hipEventRecord(s->ev1, st); s->ev_valid = true; }
+  if (timed) { (void)hipEventRecord(s->ev[2 * slot + 1], st); s->timing_n++; }
   return hipGetLastError() == hipSuccess ? 0 : -20;
 }
 
 extern "C" int go1sim_step(Go1Sim* s, const float* actions, void* stream) {
   if (!s || !actions) return -1;
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(s->buf.episode_log, 0, sizeof(float) * (s->cfg.num_rewards + 2), st);
-  int rc = launch(s, 0, actions, nullptr, 0, st, s->timing != 0);
+  int rc = launch(s, 0, actions, nullptr, 0, st, s->timing_cap > 0);
   if (rc) return rc;
   s->counter += 1;
   s->lag_head = (s->lag_head + s->cfg.decimation) % (s->cfg.lag_timesteps + 1);
-  s->history_slot = (s->history_slot + 1) % s->cfg.num_obs_history;
+  s->history_slot = (s->history_slot + 1) % (s->cfg.num_obs_history + 1);
   if (s->cfg.device_curriculum && s->buf.curriculum_weights) {
     hipLaunchKernelGGL(go1_curriculum_kernel, dim3(s->cfg.num_categories), dim3(256), 0, st, s->cfg, s->buf);
     if (hipGetLastError() != hipSuccess) return -21;
@@ -1257,7 +1275,6 @@ extern "C" int go1sim_step(Go1Sim* s, const float* actions, void* stream) {
 extern "C" int go1sim_reset_idx(Go1Sim* s, const int32_t* ids, int32_t n, void* stream) {
   if (!s) return -1;
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(s->buf.episode_log, 0, sizeof(float) * (s->cfg.num_rewards + 2), st);
   int cnt = ids ? n : s->cfg.num_envs;
   if (cnt <= 0) return 0;
   return launch(s, 3, nullptr, ids, cnt, st, false);
@@ -1277,6 +1294,25 @@ extern "C" int go1sim_curriculum_update(Go1Sim* s, void* stream) {
   hipLaunchKernelGGL(go1_curriculum_kernel, dim3(s->cfg.num_categories), dim3(256), 0, (hipStream_t)stream, s->cfg, s->buf);
   return hipGetLastError() == hipSuccess ? 0 : -21;
 }
+extern "C" int go1sim_post_physics(Go1Sim* s, const float* gravity, void* stream) {
+  if (!s || !gravity) return -1;
+  int rc = launch(s, 4, nullptr, nullptr, 0, (hipStream_t)stream, false, gravity);
+  s->counter += 1;
+  s->history_slot = (s->history_slot + 1) % (s->cfg.num_obs_history + 1);
+  return rc;
+}
+extern "C" int go1sim_append_history(Go1Sim* s, void* stream) {
+  if (!s || !s->buf.obs_history) return -1;
+  size_t total = (size_t)s->cfg.num_envs * s->cfg.num_obs;
+  hipLaunchKernelGGL(go1_history_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s->cfg, s->buf, s->history_slot);
+  s->history_slot = (s->history_slot + 1) % (s->cfg.num_obs_history + 1);
+  return hipGetLastError() == hipSuccess ? 0 : -22;
+}
+extern "C" int go1sim_history_window_offset(Go1Sim* s, int32_t* off) {
+  if (!s || !off) return -1;
+  *off = ((s->history_slot + 1) % (s->cfg.num_obs_history + 1)) * s->cfg.num_obs;   // skip the spare (next-write) slot
+  return 0;
+}
 extern "C" int go1sim_get_counters(Go1Sim* s, int64_t* c, int32_t* h) {
   if (!s) return -1;
   if (c) *c = s->counter;
@@ -1288,14 +1324,29 @@ extern "C" int go1sim_set_counters(Go1Sim* s, int64_t c, int32_t h) {
   s->counter = c; s->lag_head = h;
   return 0;
 }
-extern "C" int go1sim_enable_timing(Go1Sim* s, int enable) {
-  if (!s) return -1;
-  s->timing = enable;
+extern "C" int go1sim_enable_timing(Go1Sim* s, int capacity) {
+  if (!s || capacity < 0) return -1;
+  for (int i = 0; i < 2 * s->timing_cap; i++) (void)hipEventDestroy(s->ev[i]);
+  delete[] s->ev;
+  s->ev = nullptr; s->timing_cap = 0; s->timing_n = 0;
+  if (capacity > 0) {
+    s->ev = new hipEvent_t[2 * capacity];
+    for (int i = 0; i < 2 * capacity; i++)
+      if (hipEventCreate(&s->ev[i]) != hipSuccess) return -30;
+    s->timing_cap = capacity;
+  }
   return 0;
 }
-extern "C" int go1sim_last_step_kernel_ms(Go1Sim* s, float* ms) {
-  if (!s || !ms || !s->ev_valid) return -1;
-  if (hipEventSynchronize(s->ev1) != hipSuccess) return -30;
-  return hipEventElapsedTime(ms, s->ev0, s->ev1) == hipSuccess ? 0 : -31;
+extern "C" int go1sim_read_timings(Go1Sim* s, float* ms, int32_t max, int32_t* count) {
+  if (!s || !ms || !count) return -1;
+  int64_t have = s->timing_n < s->timing_cap ? s->timing_n : s->timing_cap;
+  if (have > max) have = max;
+  for (int64_t k = 0; k < have; k++) {
+    int slot = (int)((s->timing_n - have + k) % s->timing_cap);
+    if (hipEventSynchronize(s->ev[2 * slot + 1]) != hipSuccess) return -31;
+    if (hipEventElapsedTime(&ms[k], s->ev[2 * slot], s->ev[2 * slot + 1]) != hipSuccess) return -32;
+  }
+  *count = (int32_t)have;
+  return 0;
 }
 extern "C" const char* go1sim_version(void) { return "go1sim 0.1 (gfx950, abi 1)"; }

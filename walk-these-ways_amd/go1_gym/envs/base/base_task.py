@@ -1,0 +1,60 @@
+"""Base class of the vectorised task: device selection, VecEnv attribute surface, reset()
+(mirror of reference go1_gym/envs/base/base_task.py:14-137; no viewer on this stack)."""
+import gym
+import torch
+
+
+def parse_device_str(device_str):
+    parts = str(device_str).split(":")
+    return parts[0], int(parts[1]) if len(parts) > 1 else 0
+
+
+class BaseTask(gym.Env):
+    def __init__(self, cfg, sim_params, physics_engine, sim_device, headless, eval_cfg=None):
+        if eval_cfg is not None:
+            raise NotImplementedError("train/eval env split (SURVEY.md §8f rank 4)")
+        self.sim_params = sim_params
+        self.physics_engine = physics_engine
+        self.sim_device = sim_device
+        sim_device_type, self.sim_device_id = parse_device_str(sim_device)
+        self.headless = headless          # accepted and ignored: no viewer
+        if sim_device_type != "cuda":
+            raise RuntimeError(
+                f"sim_device={sim_device!r}: the Go1 step runs only as HIP kernels on an MI355X ('cuda:N' under "
+                f"PyTorch-ROCm); there is no CPU simulation path in the product")
+        self.device = f"cuda:{self.sim_device_id}"
+        self.graphics_device_id = -1
+        self.num_obs = cfg.env.num_observations
+        self.num_privileged_obs = cfg.env.num_privileged_obs
+        self.num_actions = cfg.env.num_actions
+        self.num_eval_envs = 0
+        self.num_train_envs = cfg.env.num_envs
+        self.num_envs = cfg.env.num_envs
+        self.extras = {}
+        self.viewer = None
+        self.enable_viewer_sync = True
+        self.create_sim()
+
+    def get_observations(self):
+        return self.obs_buf
+
+    def get_privileged_observations(self):
+        return self.privileged_obs_buf
+
+    def reset_idx(self, env_ids):
+        raise NotImplementedError
+
+    def reset(self):
+        self.reset_idx(torch.arange(self.num_envs, device=self.device))
+        obs, privileged_obs, _, _, _ = self.step(
+            torch.zeros(self.num_envs, self.num_actions, device=self.device, requires_grad=False))
+        return obs, privileged_obs
+
+    def step(self, actions):
+        raise NotImplementedError
+
+    def render_gui(self, sync_frame_time=True):
+        pass
+
+    def close(self):
+        pass

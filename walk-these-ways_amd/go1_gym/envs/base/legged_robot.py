@@ -1,0 +1,367 @@
+"""`LeggedRobot`: the vectorised Go1 environment on MI355X.
+
+Same step / reset / get_observations surface, constructor and attribute names as the reference's
+go1_gym/envs/base/legged_robot.py (`LeggedRobot` :19-58, `step` :60-88, `reset_idx` :150-239, buffers
+:1123-1297), but nothing here computes per-environment arithmetic in Python: `step()` is one call into
+libgo1sim (HIP, include/go1sim.h `go1sim_step`), which runs the torque model, the 4 physics substeps and
+every tensor map of `post_physics_step` in a single kernel launch on the current torch stream, with no
+host synchronisation.  This class owns the device buffers (torch tensors, SoA layout) and exposes them
+under the reference's attribute names as (N, ...) views.
+"""
+from collections.abc import Mapping
+
+import numpy as np
+import torch
+
+import go1sim_host as H
+from go1_gym.envs.base.base_task import BaseTask
+from go1_gym.utils.terrain import Terrain
+
+
+class _EpisodeStats(Mapping):
+    """`extras["train/episode"]` (reference legged_robot.py:181-227): means of the per-term episode sums over the
+    environments that were reset, plus command-range statistics.  Evaluated lazily on access (device reductions,
+    no work and no sync inside step()); the running sums are kept by the kernel in `episode_log`."""
+
+    def __init__(self, env):
+        self.env = env
+
+    def _keys(self):
+        e = self.env
+        keys = ["rew_" + n for n in e.episode_sum_names]
+        if e.cfg.commands.command_curriculum:
+            for n in ("duration", "bound", "offset", "phase", "freq", "x_vel", "y_vel", "yaw_vel"):
+                keys += [f"min_command_{n}", f"max_command_{n}"]
+            if e.cfg.commands.num_commands > 9:
+                keys += ["min_command_swing_height", "max_command_swing_height"]
+            keys += [f"command_area_{c}" for c in e.category_names] + ["min_action", "max_action"]
+        return keys
+
+    def __iter__(self):
+        return iter(self._keys())
+
+    def __len__(self):
+        return len(self._keys())
+
+    def __getitem__(self, key):
+        e = self.env
+        log = e.buffers.episode_log
+        if key.startswith("rew_"):
+            i = e.episode_sum_names.index(key[4:])
+            return log[i] / log[-1].clamp(min=1.0)
+        col = {"duration": 8, "bound": 7, "offset": 6, "phase": 5, "freq": 4, "x_vel": 0, "y_vel": 1, "yaw_vel": 2,
+               "swing_height": 9}
+        if key.startswith("min_command_"):
+            return e.buffers.commands[col[key[12:]]].min()
+        if key.startswith("max_command_"):
+            return e.buffers.commands[col[key[12:]]].max()
+        if key.startswith("command_area_"):
+            w = e.buffers.curriculum_weights[e.category_names.index(key[13:])]
+            return w.sum() / w.numel()
+        if key == "min_action":
+            return e.buffers.actions.min()
+        if key == "max_action":
+            return e.buffers.actions.max()
+        raise KeyError(key)
+
+    def consume(self):
+        """Snapshot the running means as floats and restart the accumulation (one host sync, used at log time)."""
+        out = {k: float(v) for k, v in self.items()}
+        self.env.buffers.episode_log.zero_()
+        return out
+
+
+class _CurriculumDistribution(Mapping):
+    """`extras["curriculum/distribution"]` (reference legged_robot.py:229-232)."""
+
+    def __init__(self, env):
+        self.env = env
+
+    def __iter__(self):
+        for c in self.env.category_names:
+            yield f"weights_{c}"
+            yield f"grid_{c}"
+
+    def __len__(self):
+        return 2 * len(self.env.category_names)
+
+    def __getitem__(self, key):
+        kind, cat = key.split("_", 1)
+        i = self.env.category_names.index(cat)
+        self.env.sync_curricula_from_device()
+        return self.env.curricula[i].weights if kind == "weights" else self.env.curricula[i].grid
+
+
+class LeggedRobot(BaseTask):
+    def __init__(self, cfg, sim_params, physics_engine, sim_device, headless, eval_cfg=None,
+                 initial_dynamics_dict=None):
+        self.cfg = cfg
+        self.eval_cfg = eval_cfg
+        self.sim_params = sim_params
+        self.height_samples = None
+        self.debug_viz = False
+        self.init_done = False
+        self.initial_dynamics_dict = initial_dynamics_dict
+        self._parse_cfg(cfg)
+        super().__init__(cfg, sim_params, physics_engine, sim_device, headless, eval_cfg)
+        self._init_buffers()
+        self.init_done = True
+        self.record_now = False
+        self.record_eval_now = False
+        self.collecting_evaluation = False
+        self.num_still_evaluating = 0
+
+    # ------------------------------------------------------------------------------------------------
+    def _parse_cfg(self, cfg):
+        """reference legged_robot.py:1716-1732 (derived step counts are written back into cfg, as there)."""
+        self.dt = H.policy_dt(cfg)
+        self.obs_scales = cfg.obs_scales
+        self.curriculum_thresholds = vars(cfg.curriculum_thresholds)
+        cfg.command_ranges = vars(cfg.commands)
+        if cfg.terrain.mesh_type not in ('heightfield', 'trimesh'):
+            cfg.terrain.curriculum = False
+        cfg.env.max_episode_length = np.ceil(cfg.env.episode_length_s / self.dt)
+        self.max_episode_length = cfg.env.max_episode_length
+        dr = cfg.domain_rand
+        dr.push_interval = np.ceil(dr.push_interval_s / self.dt)
+        dr.rand_interval = np.ceil(dr.rand_interval_s / self.dt)
+        dr.gravity_rand_interval = np.ceil(dr.gravity_rand_interval_s / self.dt)
+        dr.gravity_rand_duration = np.ceil(dr.gravity_rand_interval * dr.gravity_impulse_duration)
+
+    def create_sim(self):
+        """reference legged_robot.py:493-515 + _create_envs :1481-1609: terrain, origins, per-env dynamics
+        parameters, then the simulator instance (go1sim_create replaces gym.create_sim / prepare_sim)."""
+        cfg = self.cfg
+        mesh_type = cfg.terrain.mesh_type
+        if mesh_type not in (None, 'plane', 'heightfield', 'trimesh'):
+            raise ValueError("Terrain mesh type not recognised. Allowed types are [None, plane, heightfield, trimesh]")
+        self.up_axis_idx = 2
+        if mesh_type in ('heightfield', 'trimesh'):
+            self.terrain = Terrain(cfg.terrain, self.num_train_envs)
+            hs = self.terrain.heightsamples
+            if np.any(hs != hs.flat[0]):
+                raise NotImplementedError("height-field contact is the next scope row (BASELINE config 3)")
+            self.height_samples = torch.tensor(hs).view(self.terrain.tot_rows, self.terrain.tot_cols).to(self.device)
+        seed = int(getattr(cfg, "seed", getattr(cfg.env, "seed", 0)))
+        offset = int(getattr(cfg.env, "env_id_offset", 0))
+        self.sim_config, self.sim_meta = H.build_sim_config(
+            cfg, num_envs=self.num_envs, seed=seed, env_id_offset=offset,
+            solver_iterations=int(getattr(cfg.sim.physx, "num_solver_sweeps", 8)))
+        self.buffers = B = H.SimBuffers(self.sim_config, self.sim_meta, self.device)
+        self.num_dof = self.num_dofs = self.num_actuated_dof = 12
+        self.num_bodies = 17
+        self.dof_names = list(H.DOF_NAMES)
+        self.body_names = list(H.BODY_NAMES)
+        self.feet_indices = torch.tensor([4, 8, 12, 16], device=self.device)
+        self.penalised_contact_indices = torch.tensor(
+            [i for i in range(17) if self.sim_config.penalised_body_mask >> i & 1], device=self.device)
+        self.termination_contact_indices = torch.tensor(
+            [i for i in range(17) if self.sim_config.termination_body_mask >> i & 1], device=self.device)
+        self._get_env_origins()
+        self._init_custom_buffers__()
+        self._randomize_rigid_body_props(torch.arange(self.num_envs, device=self.device), cfg)
+        self.category_names = self.sim_meta["category_names"]
+        self.curricula = self.sim_meta["curricula"]
+        self.sim = H.Go1Sim(self.sim_config, B, self.sim_device_id)
+
+    def _get_env_origins(self):
+        """reference legged_robot.py:1675-1714."""
+        cfg, B, N = self.cfg, self.buffers, self.num_envs
+        ter = cfg.terrain
+        if ter.mesh_type in ("heightfield", "trimesh"):
+            self.custom_origins = True
+            lo, hi = (ter.min_init_terrain_level, ter.max_init_terrain_level) if ter.curriculum else (0, ter.num_rows - 1)
+            if ter.center_robots:
+                lo, hi = ter.num_rows // 2 - ter.center_span, ter.num_rows // 2 + ter.center_span - 1
+                tlo, thi = ter.num_cols // 2 - ter.center_span, ter.num_cols // 2 + ter.center_span - 1
+                self.terrain_levels = torch.randint(lo, hi + 1, (N,), device=self.device)
+                self.terrain_types = torch.randint(tlo, thi + 1, (N,), device=self.device)
+            else:
+                self.terrain_levels = torch.randint(lo, hi + 1, (N,), device=self.device)
+                self.terrain_types = torch.div(torch.arange(N, device=self.device), (N / ter.num_cols),
+                                               rounding_mode='floor').to(torch.long)
+            ter.max_terrain_level = ter.num_rows
+            ter.terrain_origins = torch.from_numpy(ter.env_origins).to(self.device).to(torch.float)
+            origins = ter.terrain_origins[self.terrain_levels, self.terrain_types]
+        else:
+            self.custom_origins = False
+            cols = np.floor(np.sqrt(N))
+            rows = np.ceil(N / cols)
+            xx, yy = torch.meshgrid(torch.arange(rows), torch.arange(cols), indexing="ij")
+            origins = torch.zeros(N, 3, device=self.device)
+            origins[:, 0] = cfg.env.env_spacing * xx.flatten()[:N].to(self.device)
+            origins[:, 1] = cfg.env.env_spacing * yy.flatten()[:N].to(self.device)
+            self.terrain_levels = torch.zeros(N, dtype=torch.long, device=self.device)
+            self.terrain_types = torch.zeros(N, dtype=torch.long, device=self.device)
+        B.env_origins.copy_(origins.t())
+        self.env_origins = B.env_origins.t()
+
+    def _init_custom_buffers__(self):
+        """reference legged_robot.py:1260-1297: views of the per-env dynamics parameters (+ optional presets)."""
+        B = self.buffers
+        B.friction_coeffs.fill_(1.0)          # rigid_shape_props_asset[1].friction: Isaac Gym default material
+        B.restitutions.fill_(0.0)
+        self.default_friction, self.default_restitution = 1.0, 0.0
+        self.friction_coeffs = B.friction_coeffs.unsqueeze(1).expand(-1, 4)
+        self.restitutions = B.restitutions.unsqueeze(1).expand(-1, 4)
+        self.payloads = B.payloads
+        self.com_displacements = B.com_displacements.t()
+        self.motor_strengths = B.motor_strengths.t()
+        self.motor_offsets = B.motor_offsets.t()
+        self.Kp_factors = B.Kp_factors.t()
+        self.Kd_factors = B.Kd_factors.t()
+        if self.initial_dynamics_dict is not None:
+            for k, v in self.initial_dynamics_dict.items():
+                v = v.to(self.device)
+                if k in ("friction_coeffs", "restitutions"):
+                    getattr(B, k).copy_(v.reshape(self.num_envs, -1)[:, 0])
+                elif k == "payloads":
+                    B.payloads.copy_(v)
+                elif k in ("com_displacements", "motor_strengths", "Kp_factors", "Kd_factors"):
+                    getattr(B, k).copy_(v.t())
+
+    def _randomize_rigid_body_props(self, env_ids, cfg):
+        """reference legged_robot.py:611-633 (set-up time; the step kernel re-draws nothing here unless
+        randomize_rigids_after_start, which is not on the train.py path)."""
+        B, dr, n = self.buffers, cfg.domain_rand, len(env_ids)
+        u = lambda rng, *shape: torch.rand(*shape, device=self.device) * (rng[1] - rng[0]) + rng[0]
+        if self.initial_dynamics_dict is not None:
+            return
+        if dr.randomize_base_mass:
+            B.payloads[env_ids] = u(dr.added_mass_range, n)
+        if dr.randomize_com_displacement:
+            B.com_displacements[:, env_ids] = u(dr.com_displacement_range, 3, n)
+        if dr.randomize_friction:
+            B.friction_coeffs[env_ids] = u(dr.friction_range, n)
+        if dr.randomize_restitution:
+            B.restitutions[env_ids] = u(dr.restitution_range, n)
+
+    def _init_buffers(self):
+        """Expose the simulator's SoA buffers under the reference's attribute names (legged_robot.py:1123-1258).
+        `.t()` views keep the reference's (N, ...) shapes and in-place write semantics."""
+        B, N = self.buffers, self.num_envs
+        S = self.sim_config
+        self.root_states = B.root_states.t()
+        self.base_pos = self.root_states[:, 0:3]
+        self.base_quat = self.root_states[:, 3:7]
+        self.dof_pos = B.dof_pos.t()
+        self.dof_vel = B.dof_vel.t()
+        self.contact_forces = B.contact_forces.view(17, 3, N).permute(2, 0, 1)
+        self.foot_positions = B.foot_positions.view(4, 3, N).permute(2, 0, 1)
+        self.foot_velocities = B.foot_velocities.view(4, 3, N).permute(2, 0, 1)
+        self.prev_foot_velocities = B.prev_foot_velocities.view(4, 3, N).permute(2, 0, 1)
+        self.base_lin_vel = B.base_lin_vel.t()
+        self.base_ang_vel = B.base_ang_vel.t()
+        self.projected_gravity = B.projected_gravity.t()
+        self.torques = B.torques.t()
+        self.actions = B.actions.t()
+        self.last_actions = B.last_actions.t()
+        self.last_last_actions = B.last_last_actions.t()
+        self.joint_pos_target = B.joint_pos_target.t()
+        self.last_joint_pos_target = B.last_joint_pos_target.t()
+        self.last_last_joint_pos_target = B.last_last_joint_pos_target.t()
+        self.last_dof_vel = B.last_dof_vel.t()
+        self.commands = B.commands.t()[:, :self.cfg.commands.num_commands]
+        self.gait_indices = B.gait_indices
+        self.clock_inputs = B.clock_inputs.t()
+        self.desired_contact_states = B.desired_contact_states.t()
+        self.foot_indices = B.foot_indices.t()
+        self.episode_length_buf = B.episode_length_buf
+        self.reset_buf = B.reset_buf
+        self.time_out_buf = B.time_out_buf.view(torch.bool)
+        self.last_contacts = B.last_contacts.t().view(torch.bool)
+        self.rew_buf = B.rew_buf
+        self.obs_buf = B.obs_buf
+        self.privileged_obs_buf = B.privileged_obs_buf[:, :self.num_privileged_obs]
+        self.default_dof_pos = torch.tensor(list(S.default_dof_pos), device=self.device).unsqueeze(0)
+        self.torque_limits = torch.tensor(list(S.torque_limits), device=self.device)
+        self.dof_pos_limits = torch.tensor([list(S.dof_pos_soft_lower), list(S.dof_pos_soft_upper)], device=self.device).t()
+        self.noise_scale_vec = torch.tensor(list(S.noise_scale_vec)[:self.num_obs], device=self.device)
+        self.commands_scale = torch.tensor(list(S.commands_scale)[:self.cfg.commands.num_commands], device=self.device)
+        self.reward_names = list(self.sim_meta["reward_names"])
+        self.reward_scales = dict(self.sim_meta["reward_scales"])
+        self.episode_sum_names = list(self.sim_meta["episode_sum_names"])
+        self.episode_sums = {n: B.episode_sums[i] for i, n in enumerate(self.episode_sum_names)}
+        self.command_sums = {n: B.command_sums[i] for i, n in enumerate(self.sim_meta["command_sum_names"])}
+        self.common_step_counter = 0
+        self.measured_heights = 0
+        self.add_noise = self.cfg.noise.add_noise
+        self.extras = {"env_bins": B.env_command_bins, "train/episode": _EpisodeStats(self)}
+        if self.cfg.env.send_timeouts:
+            self.extras["time_outs"] = self.time_out_buf
+        if self.cfg.commands.command_curriculum:
+            self.extras["curriculum/distribution"] = _CurriculumDistribution(self)
+
+    # ------------------------------------------------------------------------------------------------
+    def step(self, actions):
+        """reference legged_robot.py:60-88 — one kernel launch, no host sync."""
+        actions = actions.to(device=self.device, dtype=torch.float32)
+        if not actions.is_contiguous():
+            actions = actions.contiguous()
+        self.sim.step(actions)
+        self.common_step_counter += 1
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def reset_idx(self, env_ids):
+        """reference legged_robot.py:150-239."""
+        if len(env_ids) == 0:
+            return
+        if len(env_ids) == self.num_envs:
+            self.sim.reset_idx(None)
+        else:
+            self.sim.reset_idx(torch.as_tensor(env_ids, device=self.device))
+
+    def set_idx_pose(self, env_ids, dof_pos, base_state):
+        """reference legged_robot.py:241-261: the buffers ARE the simulator state, so writing them is the push."""
+        if len(env_ids) == 0:
+            return
+        if dof_pos is not None:
+            self.dof_pos[env_ids] = dof_pos.to(self.device)
+            self.dof_vel[env_ids] = 0.
+        self.root_states[env_ids] = base_state.to(self.device)
+
+    def set_main_agent_pose(self, loc, quat):
+        self.root_states[0, 0:3] = torch.tensor(loc, device=self.device, dtype=torch.float)
+        self.root_states[0, 3:7] = torch.tensor(quat, device=self.device, dtype=torch.float)
+
+    @property
+    def env_command_bins(self):
+        return self.buffers.env_command_bins.cpu().numpy()
+
+    @property
+    def env_command_categories(self):
+        return self.buffers.env_command_categories.cpu().numpy()
+
+    def sync_curricula_from_device(self):
+        w = self.buffers.curriculum_weights.double().cpu().numpy()
+        for cur, row in zip(self.curricula, w):
+            cur.weights = row
+
+    def sync_curricula_to_device(self):
+        """After a host-side edit of `curricula[i].weights` (e.g. Runner resume, ppo_cse/__init__.py:83-91)."""
+        w = np.stack([c.weights for c in self.curricula]).astype(np.float32)
+        self.buffers.curriculum_weights.copy_(torch.from_numpy(w))
+        cdf = np.cumsum(w.astype(np.float64), axis=1)
+        self.buffers.curriculum_cdf.copy_(torch.from_numpy((cdf / cdf[:, -1:]).astype(np.float32)))
+
+    # ---- recording: no renderer on this stack; the Runner calls these every iteration ------------------
+    def start_recording(self):
+        self.record_now = True
+
+    def start_recording_eval(self):
+        self.record_eval_now = True
+
+    def pause_recording(self):
+        self.record_now = False
+
+    def pause_recording_eval(self):
+        self.record_eval_now = False
+
+    def get_complete_frames(self):
+        return []
+
+    def get_complete_frames_eval(self):
+        return []
+
+    def render(self, mode="rgb_array"):
+        raise NotImplementedError("no renderer on the MI355X stack (SURVEY.md §5 video: out of scope)")

@@ -1,0 +1,124 @@
+"""Actor-critic with a learned adaptation module (mirror of reference go1_gym_learn/ppo_cse/actor_critic.py:7-166).
+
+Same module names and layer layout, so state_dict keys (`adaptation_module.N.*`, `actor_body.N.*`,
+`critic_body.N.*`, `std`) and the exported TorchScript files load interchangeably with the reference
+(SURVEY.md §8f rank 2).  The three MLPs run under bf16 autocast on MI355X when `PPO_Args.autocast_bf16` is set;
+master weights and the Normal distribution stay fp32."""
+import torch
+import torch.nn as nn
+from params_proto import PrefixProto
+from torch.distributions import Normal
+
+
+class AC_Args(PrefixProto, cli=False):
+    init_noise_std = 1.0
+    actor_hidden_dims = [512, 256, 128]
+    critic_hidden_dims = [512, 256, 128]
+    activation = 'elu'
+    adaptation_module_branch_hidden_dims = [256, 128]
+    use_decoder = False
+
+
+_ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "crelu": nn.ReLU, "lrelu": nn.LeakyReLU,
+                "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
+
+
+def get_activation(act_name):
+    if act_name not in _ACTIVATIONS:
+        print("invalid activation function!")
+        return None
+    return _ACTIVATIONS[act_name]()
+
+
+def _mlp(sizes, act):
+    layers = []
+    for i in range(len(sizes) - 1):
+        layers.append(nn.Linear(sizes[i], sizes[i + 1]))
+        if i < len(sizes) - 2:
+            layers.append(act)
+    return nn.Sequential(*layers)
+
+
+class ActorCritic(nn.Module):
+    is_recurrent = False
+
+    def __init__(self, num_obs, num_privileged_obs, num_obs_history, num_actions, **kwargs):
+        if kwargs:
+            print("ActorCritic.__init__ got unexpected arguments, which will be ignored: " + str(list(kwargs)))
+        self.decoder = AC_Args.use_decoder
+        super().__init__()
+        self.num_obs_history = num_obs_history
+        self.num_privileged_obs = num_privileged_obs
+        act = get_activation(AC_Args.activation)
+        self.adaptation_module = _mlp([num_obs_history] + list(AC_Args.adaptation_module_branch_hidden_dims) + [num_privileged_obs], act)
+        self.actor_body = _mlp([num_privileged_obs + num_obs_history] + list(AC_Args.actor_hidden_dims) + [num_actions], act)
+        self.critic_body = _mlp([num_privileged_obs + num_obs_history] + list(AC_Args.critic_hidden_dims) + [1], act)
+        self.std = nn.Parameter(AC_Args.init_noise_std * torch.ones(num_actions))
+        self.distribution = None
+        self.autocast_dtype = None           # set by PPO from PPO_Args.autocast_bf16
+        Normal.set_default_validate_args = False
+
+    # -- precision policy ------------------------------------------------------------------------
+    def _amp(self, x):
+        on = self.autocast_dtype is not None and x.is_cuda
+        return torch.autocast(device_type="cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=on)
+
+    def _latent(self, observation_history):
+        with self._amp(observation_history):
+            return self.adaptation_module(observation_history).float()
+
+    def _actor(self, observation_history, latent):
+        with self._amp(observation_history):
+            return self.actor_body(torch.cat((observation_history, latent), dim=-1)).float()
+
+    # -- reference surface -----------------------------------------------------------------------------
+    def reset(self, dones=None):
+        pass
+
+    def forward(self):
+        raise NotImplementedError
+
+    @property
+    def action_mean(self):
+        return self.distribution.mean
+
+    @property
+    def action_std(self):
+        return self.distribution.stddev
+
+    @property
+    def entropy(self):
+        return self.distribution.entropy().sum(dim=-1)
+
+    def update_distribution(self, observation_history):
+        mean = self._actor(observation_history, self._latent(observation_history))
+        self.distribution = Normal(mean, mean * 0. + self.std)
+
+    def act(self, observation_history, **kwargs):
+        self.update_distribution(observation_history)
+        return self.distribution.sample()
+
+    def get_actions_log_prob(self, actions):
+        return self.distribution.log_prob(actions).sum(dim=-1)
+
+    def act_expert(self, ob, policy_info={}):
+        return self.act_teacher(ob["obs_history"], ob["privileged_obs"])
+
+    def act_inference(self, ob, policy_info={}):
+        return self.act_student(ob["obs_history"], policy_info=policy_info)
+
+    def act_student(self, observation_history, policy_info={}):
+        latent = self._latent(observation_history)
+        policy_info["latents"] = latent.detach().cpu().numpy()
+        return self._actor(observation_history, latent)
+
+    def act_teacher(self, observation_history, privileged_info, policy_info={}):
+        policy_info["latents"] = privileged_info
+        return self._actor(observation_history, privileged_info)
+
+    def evaluate(self, observation_history, privileged_observations, **kwargs):
+        with self._amp(observation_history):
+            return self.critic_body(torch.cat((observation_history, privileged_observations), dim=-1)).float()
+
+    def get_student_latent(self, observation_history):
+        return self._latent(observation_history)

@@ -1,0 +1,107 @@
+"""(T, N, .) rollout buffers, GAE return scan and shuffled mini-batches (mirror of reference
+go1_gym_learn/ppo_cse/rollout_storage.py:7-139).  The advantage normalisation becomes a global statistic when
+the environments are sharded over ranks (one small all-reduce)."""
+import torch
+import torch.distributed as dist
+
+
+class RolloutStorage:
+    class Transition:
+        _FIELDS = ("observations", "privileged_observations", "observation_histories", "critic_observations", "actions",
+                   "rewards", "dones", "values", "actions_log_prob", "action_mean", "action_sigma", "env_bins")
+
+        def __init__(self):
+            for f in self._FIELDS:
+                setattr(self, f, None)
+
+        def clear(self):
+            self.__init__()
+
+    def __init__(self, num_envs, num_transitions_per_env, obs_shape, privileged_obs_shape, obs_history_shape,
+                 actions_shape, device='cpu'):
+        self.device = device
+        self.obs_shape, self.privileged_obs_shape = obs_shape, privileged_obs_shape
+        self.obs_history_shape, self.actions_shape = obs_history_shape, actions_shape
+        T, N = num_transitions_per_env, num_envs
+        z = lambda *s, **kw: torch.zeros(T, N, *s, device=self.device, **kw)
+        self.observations = z(*obs_shape)
+        self.privileged_observations = z(*privileged_obs_shape)
+        self.observation_histories = z(*obs_history_shape)
+        self.rewards = z(1)
+        self.actions = z(*actions_shape)
+        self.dones = z(1).byte()
+        self.actions_log_prob = z(1)
+        self.values = z(1)
+        self.returns = z(1)
+        self.advantages = z(1)
+        self.mu = z(*actions_shape)
+        self.sigma = z(*actions_shape)
+        self.env_bins = z(1)
+        self.num_transitions_per_env, self.num_envs = T, N
+        self.step = 0
+
+    def add_transitions(self, transition):
+        if self.step >= self.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        s = self.step
+        self.observations[s].copy_(transition.observations)
+        self.privileged_observations[s].copy_(transition.privileged_observations)
+        self.observation_histories[s].copy_(transition.observation_histories)
+        self.actions[s].copy_(transition.actions)
+        self.rewards[s].copy_(transition.rewards.view(-1, 1))
+        self.dones[s].copy_(transition.dones.view(-1, 1))
+        self.values[s].copy_(transition.values)
+        self.actions_log_prob[s].copy_(transition.actions_log_prob.view(-1, 1))
+        self.mu[s].copy_(transition.action_mean)
+        self.sigma[s].copy_(transition.action_sigma)
+        self.env_bins[s].copy_(transition.env_bins.view(-1, 1))
+        self.step += 1
+
+    def clear(self):
+        self.step = 0
+
+    def compute_returns(self, last_values, gamma, lam):
+        advantage = 0
+        for step in reversed(range(self.num_transitions_per_env)):
+            next_values = last_values if step == self.num_transitions_per_env - 1 else self.values[step + 1]
+            alive = 1.0 - self.dones[step].float()
+            delta = self.rewards[step] + alive * gamma * next_values - self.values[step]
+            advantage = delta + alive * gamma * lam * advantage
+            self.returns[step] = advantage + self.values[step]
+        self.advantages = self.returns - self.values
+        mean, std = self._global_mean_std(self.advantages)
+        self.advantages = (self.advantages - mean) / (std + 1e-8)
+
+    @staticmethod
+    def _global_mean_std(x):
+        """mean / unbiased std over every rank's samples (equals x.mean(), x.std() on one rank)."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return x.mean(), x.std()
+        stats = torch.stack((x.sum(), (x * x).sum(), torch.tensor(float(x.numel()), device=x.device))).double()
+        dist.all_reduce(stats)
+        n = stats[2]
+        mean = stats[0] / n
+        var = (stats[1] - n * mean * mean) / (n - 1)
+        return mean.to(x.dtype), var.clamp(min=0).sqrt().to(x.dtype)
+
+    def get_statistics(self):
+        done = self.dones
+        done[-1] = 1
+        flat = done.permute(1, 0, 2).reshape(-1, 1)
+        idx = torch.cat((flat.new_tensor([-1], dtype=torch.int64), flat.nonzero(as_tuple=False)[:, 0]))
+        return (idx[1:] - idx[:-1]).float().mean(), self.rewards.mean()
+
+    def mini_batch_generator(self, num_mini_batches, num_epochs=8):
+        batch_size = self.num_envs * self.num_transitions_per_env
+        mini_batch_size = batch_size // num_mini_batches
+        indices = torch.randperm(num_mini_batches * mini_batch_size, requires_grad=False, device=self.device)
+        flat = lambda t: t.flatten(0, 1)
+        observations, privileged_obs, obs_history = flat(self.observations), flat(self.privileged_observations), flat(self.observation_histories)
+        actions, values, returns = flat(self.actions), flat(self.values), flat(self.returns)
+        old_log_prob, advantages = flat(self.actions_log_prob), flat(self.advantages)
+        old_mu, old_sigma, old_bins = flat(self.mu), flat(self.sigma), flat(self.env_bins)
+        for _ in range(num_epochs):
+            for i in range(num_mini_batches):
+                idx = indices[i * mini_batch_size:(i + 1) * mini_batch_size]
+                yield (observations[idx], observations[idx], privileged_obs[idx], obs_history[idx], actions[idx], values[idx],
+                       advantages[idx], returns[idx], old_log_prob[idx], old_mu[idx], old_sigma[idx], None, old_bins[idx])

@@ -329,7 +329,7 @@ def _buffer_specs(S):
         "env_command_bins": (i32, (N,)), "env_command_categories": (i32, (N,)),
         "curriculum_weights": (f, (nc, nb)), "curriculum_cdf": (f, (nc, nb)), "curriculum_success": (i32, (nc, nb)),
         "obs_buf": (f, (N, S.num_obs)), "privileged_obs_buf": (f, (N, max(S.num_privileged_obs, 1))),
-        "obs_history": (f, (N, 2 * S.num_obs_history * S.num_obs)),
+        "obs_history": (f, (N, 2 * (S.num_obs_history + 1) * S.num_obs)),
     }
 
 
@@ -407,14 +407,18 @@ def load_library():
     lib.go1sim_compute_torques.argtypes = [vp, vp, vp]
     lib.go1sim_physics_substep.argtypes = [vp, vp]
     lib.go1sim_curriculum_update.argtypes = [vp, vp]
+    lib.go1sim_post_physics.argtypes = [vp, vp, vp]
+    lib.go1sim_append_history.argtypes = [vp, vp]
+    lib.go1sim_history_window_offset.argtypes = [vp, ctypes.POINTER(i32)]
     lib.go1sim_get_counters.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i32)]
     lib.go1sim_set_counters.argtypes = [vp, i64, i32]
     lib.go1sim_enable_timing.argtypes = [vp, ctypes.c_int]
-    lib.go1sim_last_step_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.go1sim_read_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float), i32, ctypes.POINTER(i32)]
     lib.go1sim_version.restype = ctypes.c_char_p
     for fn in ("go1sim_create", "go1sim_destroy", "go1sim_set_config", "go1sim_step", "go1sim_reset_idx",
-               "go1sim_compute_torques", "go1sim_physics_substep", "go1sim_curriculum_update",
-               "go1sim_get_counters", "go1sim_set_counters", "go1sim_enable_timing", "go1sim_last_step_kernel_ms"):
+               "go1sim_compute_torques", "go1sim_physics_substep", "go1sim_curriculum_update", "go1sim_post_physics",
+               "go1sim_append_history", "go1sim_history_window_offset",
+               "go1sim_get_counters", "go1sim_set_counters", "go1sim_enable_timing", "go1sim_read_timings"):
         getattr(lib, fn).restype = ctypes.c_int
     _lib = lib
     return lib
@@ -422,8 +426,9 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["go1sim_create", "go1sim_destroy", "go1sim_set_config", "go1sim_step", "go1sim_reset_idx",
                     "go1sim_compute_torques", "go1sim_physics_substep", "go1sim_curriculum_update",
+                    "go1sim_post_physics", "go1sim_append_history", "go1sim_history_window_offset",
                     "go1sim_get_counters", "go1sim_set_counters", "go1sim_enable_timing",
-                    "go1sim_last_step_kernel_ms", "go1sim_version"]
+                    "go1sim_read_timings", "go1sim_version"]
 
 
 class Go1Sim:
@@ -466,6 +471,18 @@ class Go1Sim:
     def curriculum_update(self):
         self._check(self.lib.go1sim_curriculum_update(self.handle, self._stream()), "go1sim_curriculum_update")
 
+    def post_physics(self, gravity):
+        g = (ctypes.c_float * 3)(*[float(x) for x in gravity])
+        self._check(self.lib.go1sim_post_physics(self.handle, ctypes.cast(g, ctypes.c_void_p), self._stream()), "go1sim_post_physics")
+
+    def append_history(self):
+        self._check(self.lib.go1sim_append_history(self.handle, self._stream()), "go1sim_append_history")
+
+    def history_window_offset(self):
+        off = ctypes.c_int32()
+        self.lib.go1sim_history_window_offset(self.handle, ctypes.byref(off))
+        return off.value
+
     def set_config(self, S):
         self.S = S
         self._check(self.lib.go1sim_set_config(self.handle, ctypes.byref(S)), "go1sim_set_config")
@@ -478,13 +495,14 @@ class Go1Sim:
     def set_counters(self, counter, lag_head):
         self.lib.go1sim_set_counters(self.handle, int(counter), int(lag_head))
 
-    def enable_timing(self, on=True):
-        self.lib.go1sim_enable_timing(self.handle, int(on))
+    def enable_timing(self, capacity):
+        self._check(self.lib.go1sim_enable_timing(self.handle, int(capacity)), "go1sim_enable_timing")
 
-    def last_step_kernel_ms(self):
-        ms = ctypes.c_float()
-        self.lib.go1sim_last_step_kernel_ms(self.handle, ctypes.byref(ms))
-        return ms.value
+    def read_timings(self, max_n=65536):
+        buf = (ctypes.c_float * max_n)()
+        n = ctypes.c_int32()
+        self._check(self.lib.go1sim_read_timings(self.handle, buf, max_n, ctypes.byref(n)), "go1sim_read_timings")
+        return list(buf[:n.value])
 
     def __del__(self):
         try:
