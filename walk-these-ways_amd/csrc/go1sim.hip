@@ -57,9 +57,12 @@ __device__ __constant__ const int CONTACT_ORDER[17] = {4, 8, 12, 16, 0, 3, 7, 11
 
 enum { P_NOISE = 1, P_RESET = 2, P_DOFPROPS_CB = 3, P_DOFPROPS_RESET = 4, P_CMD_CB = 5, P_CMD_RESET = 6, P_PUSH = 7, P_GRAVITY = 8 };
 
-struct StepArgs {
+struct SimConst {            // lives in device memory (one per handle): indexable with scalar loads
   Go1SimConfig cfg;
   Go1SimBuffers buf;
+};
+struct StepArgs {
+  const SimConst* __restrict__ sc;
   const float* actions;      // (N,12) row-major, or SoA for the piecewise entry points
   int64_t counter;           // common_step_counter before this step
   int32_t lag_head;
@@ -72,7 +75,7 @@ struct StepArgs {
 
 #define AT(ptr, c, e) ((ptr)[(size_t)(c) * N + (e)])
 
-DEV float rng_uniform(const Go1SimConfig& cfg, uint32_t env_global, int64_t step, uint32_t purpose, uint32_t idx) {
+__device__ __noinline__ float rng_uniform(const Go1SimConfig& cfg, uint32_t env_global, int64_t step, uint32_t purpose, uint32_t idx) {
   uint32_t out[4];
   philox4x32_10(env_global, (uint32_t)step, purpose, idx >> 2, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), out);
   uint32_t sel = idx & 3;
@@ -83,63 +86,91 @@ DEV float rng_uniform(const Go1SimConfig& cfg, uint32_t env_global, int64_t step
 // ================================================================================================
 // torque model (reference legged_robot.py:907-946): lag ring, actuator net / PD, strength, clip
 // ================================================================================================
-DEV float softsign(float x) { return x / (1.f + fabsf(x)); }
+DEV float softsign(float x) { return x * __builtin_amdgcn_rcpf(1.f + fabsf(x)); }   // v_rcp_f32: <= 1 ulp
 
-DEV float actuator_net(const float in[6]) {
-  float h0[32];
+// The 6->32->32->1 actuator network for the three joints of one leg at once: every weight (wave-uniform, fetched
+// with scalar loads from constant memory) is used for 3 independent accumulation chains, which hides the
+// 4-cycle dependent-FMA latency that a single chain would expose at one wave per SIMD.
+DEV void actuator_net3(const float in[3][6], float out[3]) {
+  float h0[3][32];
 #pragma unroll
   for (int i = 0; i < 32; i++) {
-    float a = GO1_ACT_B0[i];
+    float a0 = GO1_ACT_B0[i], a1 = a0, a2 = a0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) a = fmaf(GO1_ACT_W0[i][k], in[k], a);
-    h0[i] = softsign(a);
+    for (int k = 0; k < 6; k++) {
+      const float w = GO1_ACT_W0[i][k];
+      a0 = fmaf(w, in[0][k], a0); a1 = fmaf(w, in[1][k], a1); a2 = fmaf(w, in[2][k], a2);
+    }
+    h0[0][i] = softsign(a0); h0[1][i] = softsign(a1); h0[2][i] = softsign(a2);
   }
-  float o = GO1_ACT_B2;
-#pragma unroll 1
+  float o0 = GO1_ACT_B2, o1 = o0, o2 = o0;
+#pragma unroll 2
   for (int i = 0; i < 32; i++) {
-    float a = GO1_ACT_B1[i];
+    float a0 = GO1_ACT_B1[i], a1 = a0, a2 = a0;
 #pragma unroll
-    for (int k = 0; k < 32; k++) a = fmaf(GO1_ACT_W1[i][k], h0[k], a);
-    o = fmaf(GO1_ACT_W2[i], softsign(a), o);
+    for (int k = 0; k < 32; k++) {
+      const float w = GO1_ACT_W1[i][k];
+      a0 = fmaf(w, h0[0][k], a0); a1 = fmaf(w, h0[1][k], a1); a2 = fmaf(w, h0[2][k], a2);
+    }
+    const float w2 = GO1_ACT_W2[i];
+    o0 = fmaf(w2, softsign(a0), o0); o1 = fmaf(w2, softsign(a1), o1); o2 = fmaf(w2, softsign(a2), o2);
   }
-  return o;
+  out[0] = o0; out[1] = o1; out[2] = o2;
 }
 
 DEV void compute_torques(const Go1SimConfig& cfg, const Go1SimBuffers& B, float* lds, int lane, int e, int N, int head) {
   const int nl = cfg.lag_timesteps + 1;
   const int h2 = (head + 1) % nl;
 #pragma unroll 1
-  for (int j = 0; j < 12; j++) {
-    float a = AT(B.actions, j, e) * cfg.action_scale;
-    if (j % 3 == 0) a *= cfg.hip_scale_reduction;
-    float target;
-    if (cfg.use_lag) {
-      B.lag_buffer[((size_t)head * 12 + j) * N + e] = a;
-      target = B.lag_buffer[((size_t)h2 * 12 + j) * N + e] + cfg.default_dof_pos[j];
-    } else {
-      target = a + cfg.default_dof_pos[j];
+  for (int leg = 0; leg < 4; leg++) {
+    float in[3][6], tq[3], tgt[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      float a = AT(B.actions, j, e) * cfg.action_scale;
+      if (jj == 0) a *= cfg.hip_scale_reduction;
+      float target;
+      if (cfg.use_lag) {
+        B.lag_buffer[((size_t)head * 12 + j) * N + e] = a;
+        target = B.lag_buffer[((size_t)h2 * 12 + j) * N + e] + cfg.default_dof_pos[j];
+      } else {
+        target = a + cfg.default_dof_pos[j];
+      }
+      AT(B.joint_pos_target, j, e) = target;
+      tgt[jj] = target;
     }
-    AT(B.joint_pos_target, j, e) = target;
-    const float q = LDS(L_Q + j), qd = LDS(L_QD + j);
-    float t;
     if (cfg.control_type == 1) {
-      float err = q - target + AT(B.motor_offsets, j, e);
-      float el = AT(B.joint_pos_err_last, j, e), ell = AT(B.joint_pos_err_last_last, j, e);
-      float vl = AT(B.joint_vel_last, j, e), vll = AT(B.joint_vel_last_last, j, e);
-      float in6[6] = {err, el, ell, qd, vl, vll};
-      t = actuator_net(in6);
-      AT(B.joint_pos_err_last_last, j, e) = el;
-      AT(B.joint_pos_err_last, j, e) = err;
-      AT(B.joint_vel_last_last, j, e) = vl;
-      AT(B.joint_vel_last, j, e) = qd;
+#pragma unroll
+      for (int jj = 0; jj < 3; jj++) {
+        const int j = 3 * leg + jj;
+        const float q = LDS(L_Q + j), qd = LDS(L_QD + j);
+        float err = q - tgt[jj] + AT(B.motor_offsets, j, e);
+        float el = AT(B.joint_pos_err_last, j, e), ell = AT(B.joint_pos_err_last_last, j, e);
+        float vl = AT(B.joint_vel_last, j, e), vll = AT(B.joint_vel_last_last, j, e);
+        in[jj][0] = err; in[jj][1] = el; in[jj][2] = ell; in[jj][3] = qd; in[jj][4] = vl; in[jj][5] = vll;
+        AT(B.joint_pos_err_last_last, j, e) = el;
+        AT(B.joint_pos_err_last, j, e) = err;
+        AT(B.joint_vel_last_last, j, e) = vl;
+        AT(B.joint_vel_last, j, e) = qd;
+      }
+      actuator_net3(in, tq);
     } else {
-      t = cfg.kp * AT(B.Kp_factors, j, e) * (target - q + AT(B.motor_offsets, j, e)) - cfg.kd * AT(B.Kd_factors, j, e) * qd;
+#pragma unroll
+      for (int jj = 0; jj < 3; jj++) {
+        const int j = 3 * leg + jj;
+        const float q = LDS(L_Q + j), qd = LDS(L_QD + j);
+        tq[jj] = cfg.kp * AT(B.Kp_factors, j, e) * (tgt[jj] - q + AT(B.motor_offsets, j, e)) - cfg.kd * AT(B.Kd_factors, j, e) * qd;
+      }
     }
-    t *= AT(B.motor_strengths, j, e);
-    float lim = cfg.torque_limits[j];
-    t = fminf(fmaxf(t, -lim), lim);
-    LDS(L_TAU + j) = t;
-    AT(B.torques, j, e) = t;
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      float t = tq[jj] * AT(B.motor_strengths, j, e);
+      const float lim = cfg.torque_limits[j];
+      t = fminf(fmaxf(t, -lim), lim);
+      LDS(L_TAU + j) = t;
+      AT(B.torques, j, e) = t;
+    }
   }
 }
 
@@ -1072,42 +1103,16 @@ DEV void store_forces(const Go1SimConfig& cfg, const Go1SimBuffers& B, const flo
 
 extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const Go1SimConfig& cfg = A.cfg;
-  const Go1SimBuffers& B = A.buf;
+  const Go1SimConfig& cfg = A.sc->cfg;
+  const Go1SimBuffers& B = A.sc->buf;
   const int N = cfg.num_envs;
   const int lane = threadIdx.x;
   const int e = blockIdx.x * WAVE + lane;
   if (e >= N) return;
   const float h = cfg.sim_dt;
-
-  if (A.mode == 3) {       // reset_idx
-    if (e < A.n_ids) reset_env(cfg, B, A.ids ? A.ids[e] : e, N, A.counter);
-    return;
-  }
-  if (A.mode == 4) {       // tensor maps only
-    post_physics(cfg, B, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot);
-    return;
-  }
   Base s;
   load_state(B, lds, lane, e, N, s);
-  if (A.mode == 1) {       // torques only (actions given as SoA)
-#pragma unroll 1
-    for (int j = 0; j < 12; j++) AT(B.actions, j, e) = AT(A.actions, j, e);
-    compute_torques(cfg, B, lds, lane, e, N, A.lag_head);
-    return;
-  }
   const V3 grav = gravity_at(cfg, A.counter);
-  if (A.mode == 2) {       // one physics substep with the torques in the buffer
-#pragma unroll 1
-    for (int j = 0; j < 12; j++) LDS(L_TAU + j) = AT(B.torques, j, e);
-    load_lambda(cfg, B, lds, lane, e, N);
-    physics_substep(cfg, lds, lane, s, grav, cfg.warm_start != 0, h);
-    store_state(B, lds, lane, e, N, s);
-    feet_state(lds, lane, s, B, e, N);
-    store_forces(cfg, B, lds, lane, e, N);
-    return;
-  }
-  // ---- full policy step ------------------------------------------------------------------------------
 #pragma unroll 1
   for (int j = 0; j < 12; j++) {
     float a = A.actions[(size_t)e * 12 + j];
@@ -1135,8 +1140,46 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
   post_physics(cfg, B, e, N, A.counter + 1, grav, A.history_slot);
 }
 
+// piecewise entry points (parity tests, reset_idx): same device functions, kept out of the hot kernel
+extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const Go1SimConfig& cfg = A.sc->cfg;
+  const Go1SimBuffers& B = A.sc->buf;
+  const int N = cfg.num_envs;
+  const int lane = threadIdx.x;
+  const int e = blockIdx.x * WAVE + lane;
+  if (e >= N) return;
+  if (A.mode == 3) {       // reset_idx
+    if (e < A.n_ids) reset_env(cfg, B, A.ids ? A.ids[e] : e, N, A.counter);
+    return;
+  }
+  if (A.mode == 4) {       // tensor maps only
+    post_physics(cfg, B, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot);
+    return;
+  }
+  Base s;
+  load_state(B, lds, lane, e, N, s);
+  if (A.mode == 1) {       // torques only (actions given as SoA)
+#pragma unroll 1
+    for (int j = 0; j < 12; j++) AT(B.actions, j, e) = AT(A.actions, j, e);
+    compute_torques(cfg, B, lds, lane, e, N, A.lag_head);
+    return;
+  }
+  // mode 2: one physics substep with the torques in the buffer
+  const V3 grav = gravity_at(cfg, A.counter);
+#pragma unroll 1
+  for (int j = 0; j < 12; j++) LDS(L_TAU + j) = AT(B.torques, j, e);
+  load_lambda(cfg, B, lds, lane, e, N);
+  physics_substep(cfg, lds, lane, s, grav, cfg.warm_start != 0, cfg.sim_dt);
+  store_state(B, lds, lane, e, N, s);
+  feet_state(lds, lane, s, B, e, N);
+  store_forces(cfg, B, lds, lane, e, N);
+}
+
 // HistoryWrapper.get_observations: append the current obs_buf to the double-length ring
-extern "C" __global__ void __launch_bounds__(256) go1_history_kernel(const Go1SimConfig cfg, const Go1SimBuffers B, int slot) {
+extern "C" __global__ void __launch_bounds__(256) go1_history_kernel(const SimConst* __restrict__ sc, int slot) {
+  const Go1SimConfig& cfg = sc->cfg;
+  const Go1SimBuffers& B = sc->buf;
   const int no = cfg.num_obs, R = cfg.num_obs_history + 1;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)cfg.num_envs * no) return;
@@ -1148,7 +1191,9 @@ extern "C" __global__ void __launch_bounds__(256) go1_history_kernel(const Go1Si
 }
 
 // curriculum weight update + CDF rebuild (reference curriculum.py:135-154): one workgroup per category
-extern "C" __global__ void __launch_bounds__(256) go1_curriculum_kernel(const Go1SimConfig cfg, const Go1SimBuffers B) {
+extern "C" __global__ void __launch_bounds__(256) go1_curriculum_kernel(const SimConst* __restrict__ sc) {
+  const Go1SimConfig& cfg = sc->cfg;
+  const Go1SimBuffers& B = sc->buf;
   __shared__ float part[256];
   const int c = blockIdx.x, nb = cfg.num_bins, t = threadIdx.x;
   float* w = B.curriculum_weights + (size_t)c * nb;
@@ -1199,6 +1244,7 @@ struct Go1Sim {
   int64_t counter;
   int32_t lag_head;
   int32_t history_slot;
+  SimConst* dconst;    // device copy of {cfg, buf}
   int timing_cap;
   int64_t timing_n;
   hipEvent_t* ev;      // 2 * timing_cap
@@ -1212,6 +1258,12 @@ static int check_cfg(const Go1SimConfig* cfg) {
   return 0;
 }
 
+static int upload_const(Go1Sim* s) {
+  SimConst h;
+  h.cfg = s->cfg; h.buf = s->buf;
+  return hipMemcpy(s->dconst, &h, sizeof(SimConst), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+
 extern "C" int go1sim_create(const Go1SimConfig* cfg, const Go1SimBuffers* buffers, int device, Go1Sim** out) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
@@ -1220,10 +1272,14 @@ extern "C" int go1sim_create(const Go1SimConfig* cfg, const Go1SimBuffers* buffe
   Go1Sim* s = new Go1Sim();
   s->cfg = *cfg; s->buf = *buffers; s->device = device;
   s->counter = 0; s->lag_head = 0; s->history_slot = 0; s->timing_cap = 0; s->timing_n = 0; s->ev = nullptr;
-  if (hipFuncSetAttribute((const void*)go1_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_END * WAVE * 4) != hipSuccess) {
+  if (hipFuncSetAttribute((const void*)go1_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_END * WAVE * 4) != hipSuccess ||
+      hipFuncSetAttribute((const void*)go1_aux_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_END * WAVE * 4) != hipSuccess) {
     delete s;
     return -11;
   }
+  s->dconst = nullptr;
+  if (hipMalloc((void**)&s->dconst, sizeof(SimConst)) != hipSuccess) { delete s; return -12; }
+  if (upload_const(s) != 0) { (void)hipFree(s->dconst); delete s; return -13; }
   *out = s;
   return 0;
 }
@@ -1231,6 +1287,7 @@ extern "C" int go1sim_destroy(Go1Sim* s) {
   if (!s) return -1;
   for (int i = 0; i < 2 * s->timing_cap; i++) (void)hipEventDestroy(s->ev[i]);
   delete[] s->ev;
+  (void)hipFree(s->dconst);
   delete s;
   return 0;
 }
@@ -1240,20 +1297,21 @@ extern "C" int go1sim_set_config(Go1Sim* s, const Go1SimConfig* cfg) {
   if (rc) return rc;
   if (cfg->num_envs != s->cfg.num_envs) return -6;
   s->cfg = *cfg;
-  return 0;
+  return upload_const(s);      // blocking copy: configuration changes are rare and never on the step path
 }
 
 static int launch(Go1Sim* s, int mode, const float* actions, const int32_t* ids, int n_ids, hipStream_t st, bool timed,
                   const float* grav = nullptr) {
   StepArgs A;
   for (int i = 0; i < 3; i++) A.gravity_override[i] = grav ? grav[i] : 0.f;
-  A.cfg = s->cfg; A.buf = s->buf; A.actions = actions; A.counter = s->counter; A.lag_head = s->lag_head;
+  A.sc = s->dconst; A.actions = actions; A.counter = s->counter; A.lag_head = s->lag_head;
   A.history_slot = s->history_slot; A.mode = mode; A.ids = ids; A.n_ids = n_ids;
   const int n = (mode == 3) ? n_ids : s->cfg.num_envs;
   dim3 grid((n + WAVE - 1) / WAVE), block(WAVE);
   const int slot = timed ? (int)(s->timing_n % s->timing_cap) : 0;
   if (timed) (void)hipEventRecord(s->ev[2 * slot], st);
-  hipLaunchKernelGGL(go1_step_kernel, grid, block, L_END * WAVE * 4, st, A);
+  if (mode == 0) hipLaunchKernelGGL(go1_step_kernel, grid, block, L_END * WAVE * 4, st, A);
+  else hipLaunchKernelGGL(go1_aux_kernel, grid, block, L_END * WAVE * 4, st, A);
   if (timed) { (void)hipEventRecord(s->ev[2 * slot + 1], st); s->timing_n++; }
   return hipGetLastError() == hipSuccess ? 0 : -20;
 }
@@ -1267,7 +1325,7 @@ extern "C" int go1sim_step(Go1Sim* s, const float* actions, void* stream) {
   s->lag_head = (s->lag_head + s->cfg.decimation) % (s->cfg.lag_timesteps + 1);
   s->history_slot = (s->history_slot + 1) % (s->cfg.num_obs_history + 1);
   if (s->cfg.device_curriculum && s->buf.curriculum_weights) {
-    hipLaunchKernelGGL(go1_curriculum_kernel, dim3(s->cfg.num_categories), dim3(256), 0, st, s->cfg, s->buf);
+    hipLaunchKernelGGL(go1_curriculum_kernel, dim3(s->cfg.num_categories), dim3(256), 0, st, (const SimConst*)s->dconst);
     if (hipGetLastError() != hipSuccess) return -21;
   }
   return 0;
@@ -1291,7 +1349,7 @@ extern "C" int go1sim_physics_substep(Go1Sim* s, void* stream) {
 }
 extern "C" int go1sim_curriculum_update(Go1Sim* s, void* stream) {
   if (!s) return -1;
-  hipLaunchKernelGGL(go1_curriculum_kernel, dim3(s->cfg.num_categories), dim3(256), 0, (hipStream_t)stream, s->cfg, s->buf);
+  hipLaunchKernelGGL(go1_curriculum_kernel, dim3(s->cfg.num_categories), dim3(256), 0, (hipStream_t)stream, (const SimConst*)s->dconst);
   return hipGetLastError() == hipSuccess ? 0 : -21;
 }
 extern "C" int go1sim_post_physics(Go1Sim* s, const float* gravity, void* stream) {
@@ -1304,7 +1362,7 @@ extern "C" int go1sim_post_physics(Go1Sim* s, const float* gravity, void* stream
 extern "C" int go1sim_append_history(Go1Sim* s, void* stream) {
   if (!s || !s->buf.obs_history) return -1;
   size_t total = (size_t)s->cfg.num_envs * s->cfg.num_obs;
-  hipLaunchKernelGGL(go1_history_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s->cfg, s->buf, s->history_slot);
+  hipLaunchKernelGGL(go1_history_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const SimConst*)s->dconst, s->history_slot);
   s->history_slot = (s->history_slot + 1) % (s->cfg.num_obs_history + 1);
   return hipGetLastError() == hipSuccess ? 0 : -22;
 }

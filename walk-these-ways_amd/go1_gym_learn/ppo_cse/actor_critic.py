@@ -6,6 +6,7 @@ Same module names and layer layout, so state_dict keys (`adaptation_module.N.*`,
 master weights and the Normal distribution stay fp32."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from params_proto import PrefixProto
 from torch.distributions import Normal
 
@@ -65,11 +66,49 @@ class ActorCritic(nn.Module):
 
     def _latent(self, observation_history):
         with self._amp(observation_history):
-            return self.adaptation_module(observation_history).float()
+            return self.adaptation_module(observation_history).to(self.std.dtype)
 
     def _actor(self, observation_history, latent):
         with self._amp(observation_history):
-            return self.actor_body(torch.cat((observation_history, latent), dim=-1)).float()
+            return self.actor_body(torch.cat((observation_history, latent), dim=-1)).to(self.std.dtype)
+
+    # -- fused path used by PPO on MI355X ------------------------------------------------------------
+    def fused_forward(self, observation_history, privileged_observations=None, want_value=True):
+        """(action mean, value, latent) with ONE GEMM over the 2100-wide history for the first layers of the
+        adaptation module, the actor and the critic (they share the input: N = 256 + 512 + 512 output columns),
+        instead of three GEMMs plus two (M, 2102) concatenations.  Mathematically identical to
+        act()/evaluate(): W [h ; z] = W_h h + W_z z.  `observation_history` may be the storage's zero-padded bf16
+        copy (row length a multiple of 8 elements so that every GEMM operand is 16-byte aligned)."""
+        K = self.num_obs_history
+        la, lc, ld = self.actor_body[0], self.critic_body[0], self.adaptation_module[0]
+        with self._amp(observation_history):
+            parts = [ld.weight, la.weight[:, :K]] + ([lc.weight[:, :K]] if want_value else [])
+            Wh = torch.cat(parts, dim=0)
+            pad = observation_history.shape[-1] - K
+            if pad:
+                Wh = F.pad(Wh, (0, pad))
+            y = F.linear(observation_history, Wh)
+            nd, na = ld.weight.shape[0], la.weight.shape[0]
+            latent = self.adaptation_module[1:](y[:, :nd] + ld.bias).to(self.std.dtype)
+            a1 = y[:, nd:nd + na] + F.linear(latent, la.weight[:, K:]) + la.bias
+            mean = self.actor_body[1:](a1).to(self.std.dtype)
+            value = None
+            if want_value:
+                c1 = y[:, nd + na:] + F.linear(privileged_observations, lc.weight[:, K:]) + lc.bias
+                value = self.critic_body[1:](c1).to(self.std.dtype)
+        return mean, value, latent
+
+    def latent_padded(self, observation_history):
+        """adaptation module on a (possibly zero-padded) history batch."""
+        K = self.num_obs_history
+        ld = self.adaptation_module[0]
+        with self._amp(observation_history):
+            pad = observation_history.shape[-1] - K
+            W = F.pad(ld.weight, (0, pad)) if pad else ld.weight
+            return self.adaptation_module[1:](F.linear(observation_history, W, ld.bias)).to(self.std.dtype)
+
+    def set_distribution(self, mean):
+        self.distribution = Normal(mean, mean * 0. + self.std)
 
     # -- reference surface -----------------------------------------------------------------------------
     def reset(self, dones=None):
@@ -118,7 +157,7 @@ class ActorCritic(nn.Module):
 
     def evaluate(self, observation_history, privileged_observations, **kwargs):
         with self._amp(observation_history):
-            return self.critic_body(torch.cat((observation_history, privileged_observations), dim=-1)).float()
+            return self.critic_body(torch.cat((observation_history, privileged_observations), dim=-1)).to(self.std.dtype)
 
     def get_student_latent(self, observation_history):
         return self._latent(observation_history)

@@ -75,8 +75,11 @@ class PPO:
 
     def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, privileged_obs_shape, obs_history_shape,
                      action_shape):
+        bf16 = PPO_Args.autocast_bf16 and self.on_gpu
         self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, privileged_obs_shape,
-                                      obs_history_shape, action_shape, self.device)
+                                      obs_history_shape, action_shape, self.device,
+                                      history_dtype=torch.bfloat16 if bf16 else torch.float32,
+                                      history_pad_to=8 if bf16 else 1)
 
     def test_mode(self):
         self.actor_critic.test()
@@ -86,18 +89,22 @@ class PPO:
 
     def act(self, obs, privileged_obs, obs_history):
         t = self.transition
-        t.actions = self.actor_critic.act(obs_history).detach()
-        t.values = self.actor_critic.evaluate(obs_history, privileged_obs).detach()
-        t.actions_log_prob = self.actor_critic.get_actions_log_prob(t.actions).detach()
-        t.action_mean = self.actor_critic.action_mean.detach()
-        t.action_sigma = self.actor_critic.action_std.detach()
+        # the env's obs_history is a live view of its ring buffer: take the storage copy now, before env.step
+        # (it is also the dtype / padding the policy GEMMs want)
+        slot = self.storage.observation_histories[self.storage.step]
+        slot[:, :obs_history.shape[-1]].copy_(obs_history)
+        t.observation_histories = slot
+        ac = self.actor_critic
+        mean, value, _ = ac.fused_forward(slot, privileged_obs)
+        ac.set_distribution(mean.detach())
+        t.actions = ac.distribution.sample()
+        t.values = value.detach()
+        t.actions_log_prob = ac.get_actions_log_prob(t.actions).detach()
+        t.action_mean = ac.action_mean.detach()
+        t.action_sigma = ac.action_std.detach()
         t.observations = obs
         t.critic_observations = obs
         t.privileged_observations = privileged_obs
-        # the env's obs_history is a live view of its ring buffer: take the storage copy now, before env.step
-        slot = self.storage.observation_histories[self.storage.step]
-        slot.copy_(obs_history)
-        t.observation_histories = slot
         return t.actions
 
     def process_env_step(self, rewards, dones, infos):
@@ -113,6 +120,8 @@ class PPO:
 
     def compute_returns(self, last_critic_obs, last_critic_privileged_obs):
         last_values = self.actor_critic.evaluate(last_critic_obs, last_critic_privileged_obs).detach()
+        if last_values.is_inference():
+            last_values = last_values.clone()
         self.storage.compute_returns(last_values, PPO_Args.gamma, PPO_Args.lam)
 
     # ---- data parallel helpers ---------------------------------------------------------------------
@@ -154,9 +163,9 @@ class PPO:
         for (obs_batch, critic_obs_batch, privileged_obs_batch, obs_history_batch, actions_batch, target_values_batch,
              advantages_batch, returns_batch, old_actions_log_prob_batch, old_mu_batch, old_sigma_batch, masks_batch,
              env_bins_batch) in generator:
-            self.actor_critic.act(obs_history_batch, masks=masks_batch)
+            mean, value_batch, _ = self.actor_critic.fused_forward(obs_history_batch, privileged_obs_batch)
+            self.actor_critic.set_distribution(mean)
             actions_log_prob_batch = self.actor_critic.get_actions_log_prob(actions_batch)
-            value_batch = self.actor_critic.evaluate(obs_history_batch, privileged_obs_batch, masks=masks_batch)
             mu_batch = self.actor_critic.action_mean
             sigma_batch = self.actor_critic.action_std
             entropy_batch = self.actor_critic.entropy
@@ -189,7 +198,7 @@ class PPO:
 
             num_train = int(privileged_obs_batch.shape[0] // 5 * 4)
             for _ in range(A.num_adaptation_module_substeps):
-                adaptation_pred = self.actor_critic.get_student_latent(obs_history_batch)
+                adaptation_pred = self.actor_critic.latent_padded(obs_history_batch)
                 adaptation_target = privileged_obs_batch.detach()
                 sel = 0 if A.selective_adaptation_module_loss else slice(None)
                 adaptation_loss = F.mse_loss(adaptation_pred[:num_train, sel], adaptation_target[:num_train, sel])

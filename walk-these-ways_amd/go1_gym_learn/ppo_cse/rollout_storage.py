@@ -18,7 +18,10 @@ class RolloutStorage:
             self.__init__()
 
     def __init__(self, num_envs, num_transitions_per_env, obs_shape, privileged_obs_shape, obs_history_shape,
-                 actions_shape, device='cpu'):
+                 actions_shape, device='cpu', history_dtype=torch.float32, history_pad_to=1):
+        """`history_dtype` / `history_pad_to`: the (T, N, H*num_obs) history block is the dominant storage
+        (826 MB in fp32 at N=4096); under the bf16 policy it is kept in bf16 with rows zero-padded to a multiple
+        of `history_pad_to` elements, which is exactly what the policy GEMMs consume."""
         self.device = device
         self.obs_shape, self.privileged_obs_shape = obs_shape, privileged_obs_shape
         self.obs_history_shape, self.actions_shape = obs_history_shape, actions_shape
@@ -26,7 +29,9 @@ class RolloutStorage:
         z = lambda *s, **kw: torch.zeros(T, N, *s, device=self.device, **kw)
         self.observations = z(*obs_shape)
         self.privileged_observations = z(*privileged_obs_shape)
-        self.observation_histories = z(*obs_history_shape)
+        self.history_width = int(obs_history_shape[0])
+        padded = -(-self.history_width // history_pad_to) * history_pad_to
+        self.observation_histories = z(padded, dtype=history_dtype)
         self.rewards = z(1)
         self.actions = z(*actions_shape)
         self.dones = z(1).byte()
@@ -46,7 +51,9 @@ class RolloutStorage:
         s = self.step
         self.observations[s].copy_(transition.observations)
         self.privileged_observations[s].copy_(transition.privileged_observations)
-        self.observation_histories[s].copy_(transition.observation_histories)
+        if transition.observation_histories is not self.observation_histories[s]:
+            src = transition.observation_histories
+            self.observation_histories[s][:, :src.shape[-1]].copy_(src)
         self.actions[s].copy_(transition.actions)
         self.rewards[s].copy_(transition.rewards.view(-1, 1))
         self.dones[s].copy_(transition.dones.view(-1, 1))
