@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="fp32 policy instead of bf16 autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sim-only", action="store_true", help="diagnostic: time env.step alone with pre-generated actions")
+    ap.add_argument("--breakdown", action="store_true", help="diagnostic: print rollout/update split to stderr (adds syncs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,13 +114,25 @@ def main():
     obs_dict = env.get_observations()
     runner.alg.actor_critic.train()
 
+    split = {"rollout": 0.0, "update": 0.0}
+
     def iteration(obs_dict):
+        if args.breakdown:
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
         with torch.inference_mode():
             for _ in range(T):
                 obs_dict, _ = runner._rollout_step(obs_dict)
             n = env.num_train_envs
             runner.alg.compute_returns(obs_dict["obs_history"][:n], obs_dict["privileged_obs"][:n])
+        if args.breakdown:
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
         runner.alg.update()
+        if args.breakdown:
+            torch.cuda.synchronize()
+            split["rollout"] += tb - ta
+            split["update"] += time.perf_counter() - tb
         return obs_dict
 
     def sim_iteration(obs_dict, acts):
@@ -136,6 +149,7 @@ def main():
     for _ in range(args.warmup):
         obs_dict = sim_iteration(obs_dict, acts) if args.sim_only else iteration(obs_dict)
     barrier()
+    split["rollout"] = split["update"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         obs_dict = sim_iteration(obs_dict, acts) if args.sim_only else iteration(obs_dict)
@@ -147,6 +161,9 @@ def main():
         elapsed = float(t)
 
     kernel_ms = sim.read_timings()
+    if args.breakdown and rank == 0:
+        n_it = args.steps
+        print(f"[breakdown] rollout {1e3 * split['rollout'] / n_it:.1f} ms/iter, update {1e3 * split['update'] / n_it:.1f} ms/iter", file=sys.stderr)
     if rank == 0:
         total_env_steps = args.envs * T * args.steps * world
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)

@@ -1,0 +1,76 @@
+"""PPO side (PyTorch-ROCm) vs the reference classes: the golden rollout in tests/golden/ppo.npz was pushed through
+the REFERENCE go1_gym_learn.ppo_cse (RolloutStorage.compute_returns + PPO.update, fp32, CPU) by make_golden.py;
+our restructured implementation (fused first layer, flat gradient buffer, device-side adaptive LR, explicit
+Gaussian algebra) must reproduce returns, advantages, losses, final learning rate and final weights."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import GOLDEN
+
+
+@pytest.fixture()
+def small_ac_args():
+    from go1_gym_learn.ppo_cse.actor_critic import AC_Args
+    old = (AC_Args.actor_hidden_dims, AC_Args.critic_hidden_dims, AC_Args.adaptation_module_branch_hidden_dims)
+    AC_Args.actor_hidden_dims, AC_Args.critic_hidden_dims, AC_Args.adaptation_module_branch_hidden_dims = [32, 16], [24, 16], [16, 8]
+    yield
+    AC_Args.actor_hidden_dims, AC_Args.critic_hidden_dims, AC_Args.adaptation_module_branch_hidden_dims = old
+
+
+def test_update_matches_reference(small_ac_args):
+    from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
+    from go1_gym_learn.ppo_cse.ppo import PPO, PPO_Args
+    d = np.load(os.path.join(GOLDEN, "ppo.npz"))
+    N, T, no, npv, H, na = [int(x) for x in d["dims"]]
+    ac = ActorCritic(no, npv, no * H, na)
+    ac.load_state_dict({k[5:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("init_")})
+    alg = PPO(ac, device="cpu")
+    alg.init_storage(N, T, [no], [npv], [no * H], [na])
+    st = alg.storage
+    for k in ("observations", "privileged_observations", "observation_histories", "actions", "rewards", "dones", "values",
+              "mu", "sigma", "actions_log_prob"):
+        getattr(st, k).copy_(torch.from_numpy(d["in_" + k]))
+    st.step = T
+    st.compute_returns(torch.from_numpy(d["last_values"]), PPO_Args.gamma, PPO_Args.lam)
+    np.testing.assert_allclose(st.returns.numpy(), d["out_returns"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st.advantages.numpy(), d["out_advantages"], rtol=1e-5, atol=1e-5)
+    torch.manual_seed(int(d["seed"]) + 2)          # same randperm as the reference run
+    losses = alg.update()
+    np.testing.assert_allclose(losses, d["losses"], rtol=2e-4, atol=1e-6)
+    assert alg.learning_rate == pytest.approx(float(d["final_lr"]), rel=1e-6)
+    for k, v in ac.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), d["final_" + k], rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+def test_fused_forward_equals_reference_surface():
+    from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
+    from go1_gym_learn.ppo_cse.ppo import gaussian_entropy, gaussian_log_prob
+    torch.manual_seed(0)
+    ac = ActorCritic(70, 2, 2100, 12).double()
+    hist, priv = torch.randn(16, 2100).double(), torch.randn(16, 2).double()
+    mean, value, latent = ac.fused_forward(hist, priv)
+    ac.update_distribution(hist)
+    assert (mean - ac.action_mean).abs().max() < 1e-12
+    assert (value - ac.evaluate(hist, priv)).abs().max() < 1e-12
+    assert (latent - ac.get_student_latent(hist)).abs().max() < 1e-12
+    padded = torch.nn.functional.pad(hist, (0, 4))
+    assert (ac.fused_forward(padded, priv)[0] - mean).abs().max() < 1e-12
+    assert (ac.latent_padded(padded) - latent).abs().max() < 1e-12
+    a = ac.distribution.sample()
+    assert (gaussian_log_prob(a, mean, ac.std) - ac.get_actions_log_prob(a)).abs().max() < 1e-10
+    assert (gaussian_entropy(ac.std) - ac.entropy).abs().max() < 1e-10
+    assert sum(p.numel() for p in ActorCritic(70, 2, 2100, 12).parameters()) == 3054619
+
+
+def test_state_dict_keys_match_reference_layout():
+    from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
+    keys = set(ActorCritic(70, 2, 2100, 12).state_dict())
+    expect = {"std"} | {f"{m}.{i}.{w}" for m, idx in (("adaptation_module", (0, 2, 4)), ("actor_body", (0, 2, 4, 6)),
+                                                         ("critic_body", (0, 2, 4, 6))) for i in idx for w in ("weight", "bias")}
+    assert keys == expect
+    ac = ActorCritic(70, 2, 2100, 12)
+    torch.jit.script(ac.adaptation_module)      # export path of Runner.save
+    torch.jit.script(ac.actor_body)

@@ -2,8 +2,8 @@
 
 Same module names and layer layout, so state_dict keys (`adaptation_module.N.*`, `actor_body.N.*`,
 `critic_body.N.*`, `std`) and the exported TorchScript files load interchangeably with the reference
-(SURVEY.md §8f rank 2).  The three MLPs run under bf16 autocast on MI355X when `PPO_Args.autocast_bf16` is set;
-master weights and the Normal distribution stay fp32."""
+(SURVEY.md §8f rank 2).  `fused_forward` is the path PPO uses on MI355X (one GEMM over the shared 2100-wide
+history input); the reference-surface methods below it keep their original semantics."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -56,59 +56,63 @@ class ActorCritic(nn.Module):
         self.critic_body = _mlp([num_privileged_obs + num_obs_history] + list(AC_Args.critic_hidden_dims) + [1], act)
         self.std = nn.Parameter(AC_Args.init_noise_std * torch.ones(num_actions))
         self.distribution = None
-        self.autocast_dtype = None           # set by PPO from PPO_Args.autocast_bf16
         Normal.set_default_validate_args = False
 
-    # -- precision policy ------------------------------------------------------------------------
-    def _amp(self, x):
-        on = self.autocast_dtype is not None and x.is_cuda
-        return torch.autocast(device_type="cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=on)
-
-    def _latent(self, observation_history):
-        with self._amp(observation_history):
-            return self.adaptation_module(observation_history).to(self.std.dtype)
-
-    def _actor(self, observation_history, latent):
-        with self._amp(observation_history):
-            return self.actor_body(torch.cat((observation_history, latent), dim=-1)).to(self.std.dtype)
-
     # -- fused path used by PPO on MI355X ------------------------------------------------------------
+    @staticmethod
+    def _side(y, z, Wz, b):
+        """y + z @ Wz^T + b for a side input with a tiny inner dimension (2 latent / privileged columns):
+        broadcast multiply-adds instead of a K=2 GEMM, which GEMM libraries handle poorly."""
+        if z.shape[-1] <= 4:
+            out = y + b
+            for i in range(z.shape[-1]):
+                out = torch.addcmul(out, z[:, i:i + 1], Wz[:, i])
+            return out
+        return y + F.linear(z, Wz, b)
+
     def fused_forward(self, observation_history, privileged_observations=None, want_value=True):
         """(action mean, value, latent) with ONE GEMM over the 2100-wide history for the first layers of the
-        adaptation module, the actor and the critic (they share the input: N = 256 + 512 + 512 output columns),
+        adaptation module, the actor and the critic (they share the input: 256 + 512 + 512 output columns),
         instead of three GEMMs plus two (M, 2102) concatenations.  Mathematically identical to
-        act()/evaluate(): W [h ; z] = W_h h + W_z z.  `observation_history` may be the storage's zero-padded bf16
-        copy (row length a multiple of 8 elements so that every GEMM operand is 16-byte aligned)."""
+        act()/evaluate(): W [h ; z] = W_h h + W_z z.  Runs in the dtype of the module's weights (the bf16 compute
+        replica or the fp32 master); `observation_history` may be the storage's zero-padded copy (row length a
+        multiple of 8 elements so that every GEMM operand is 16-byte aligned)."""
         K = self.num_obs_history
         la, lc, ld = self.actor_body[0], self.critic_body[0], self.adaptation_module[0]
-        with self._amp(observation_history):
-            parts = [ld.weight, la.weight[:, :K]] + ([lc.weight[:, :K]] if want_value else [])
-            Wh = torch.cat(parts, dim=0)
-            pad = observation_history.shape[-1] - K
-            if pad:
-                Wh = F.pad(Wh, (0, pad))
-            y = F.linear(observation_history, Wh)
-            nd, na = ld.weight.shape[0], la.weight.shape[0]
-            latent = self.adaptation_module[1:](y[:, :nd] + ld.bias).to(self.std.dtype)
-            a1 = y[:, nd:nd + na] + F.linear(latent, la.weight[:, K:]) + la.bias
-            mean = self.actor_body[1:](a1).to(self.std.dtype)
-            value = None
-            if want_value:
-                c1 = y[:, nd + na:] + F.linear(privileged_observations, lc.weight[:, K:]) + lc.bias
-                value = self.critic_body[1:](c1).to(self.std.dtype)
-        return mean, value, latent
+        wdt, odt = ld.weight.dtype, self.std.dtype
+        x = observation_history if observation_history.dtype == wdt else observation_history.to(wdt)
+        parts = [ld.weight, la.weight[:, :K]] + ([lc.weight[:, :K]] if want_value else [])
+        Wh = torch.cat(parts, dim=0)
+        pad = x.shape[-1] - K
+        if pad:
+            Wh = F.pad(Wh, (0, pad))
+        y = F.linear(x, Wh)
+        nd, na = ld.weight.shape[0], la.weight.shape[0]
+        latent = self.adaptation_module[1:](y[:, :nd] + ld.bias)
+        mean = self.actor_body[1:](self._side(y[:, nd:nd + na], latent, la.weight[:, K:], la.bias)).to(odt)
+        value = None
+        if want_value:
+            p = privileged_observations.to(wdt)
+            value = self.critic_body[1:](self._side(y[:, nd + na:], p, lc.weight[:, K:], lc.bias)).to(odt)
+        return mean, value, latent.to(odt)
 
     def latent_padded(self, observation_history):
         """adaptation module on a (possibly zero-padded) history batch."""
         K = self.num_obs_history
         ld = self.adaptation_module[0]
-        with self._amp(observation_history):
-            pad = observation_history.shape[-1] - K
-            W = F.pad(ld.weight, (0, pad)) if pad else ld.weight
-            return self.adaptation_module[1:](F.linear(observation_history, W, ld.bias)).to(self.std.dtype)
+        x = observation_history if observation_history.dtype == ld.weight.dtype else observation_history.to(ld.weight.dtype)
+        pad = x.shape[-1] - K
+        W = F.pad(ld.weight, (0, pad)) if pad else ld.weight
+        return self.adaptation_module[1:](F.linear(x, W, ld.bias)).to(self.std.dtype)
 
     def set_distribution(self, mean):
         self.distribution = Normal(mean, mean * 0. + self.std)
+
+    def _latent(self, observation_history):
+        return self.adaptation_module(observation_history)
+
+    def _actor(self, observation_history, latent):
+        return self.actor_body(torch.cat((observation_history, latent), dim=-1))
 
     # -- reference surface -----------------------------------------------------------------------------
     def reset(self, dones=None):
@@ -156,8 +160,7 @@ class ActorCritic(nn.Module):
         return self._actor(observation_history, privileged_info)
 
     def evaluate(self, observation_history, privileged_observations, **kwargs):
-        with self._amp(observation_history):
-            return self.critic_body(torch.cat((observation_history, privileged_observations), dim=-1)).to(self.std.dtype)
+        return self.critic_body(torch.cat((observation_history, privileged_observations), dim=-1))
 
     def get_student_latent(self, observation_history):
         return self._latent(observation_history)

@@ -1,16 +1,25 @@
 """PPO with adaptive-KL learning rate, clipped value loss and an adaptation-module regression step
 (mirror of reference go1_gym_learn/ppo_cse/ppo.py:13-205), PyTorch-ROCm.
 
-MI355X-first changes that do not alter the algorithm:
-  * no host synchronisation inside `update()`: the KL-adaptive learning rate lives in a device tensor (Adam with a
-    tensor `lr`), loss statistics are accumulated on device and read once per update;
-  * bf16 autocast for the three MLPs when `PPO_Args.autocast_bf16` (fp32 master weights / Adam state);
-  * data-parallel mode (only when the environments are partitioned per GPU): the flat gradient is all-reduced
-    over RCCL before clipping, the KL mean is all-reduced so every rank takes the same LR branch.
+Same algorithm, hyper-parameters (`PPO_Args`) and public methods (`act`, `process_env_step`,
+`compute_returns`, `update`).  What is organised differently for the MI355X:
+
+  * mixed precision the classic way instead of per-op autocast: fp32 master weights (the exported / checkpointed
+    `actor_critic`) + a bf16 compute replica; one multi-tensor copy per optimiser step in each direction, no cast
+    kernels around every Linear;
+  * one flat fp32 gradient buffer: master `.grad`s are views into it, so global-norm clipping is one norm over one
+    tensor and the data-parallel all-reduce (RCCL over xGMI, only when envs are partitioned per GPU) is one
+    collective on that buffer per optimiser step — no bucketing, no DDP hooks;
+  * the Gaussian policy algebra (log-prob, entropy, KL, surrogate, clipped value loss) is written out on (M, 12)
+    tensors instead of going through torch.distributions (which validates `std >= 0` with a host sync per sample);
+  * no host synchronisation inside `update()`: the KL-adaptive learning rate is a device tensor handed to Adam,
+    loss statistics are accumulated on device and read once at the end.
 """
+import copy
+import math
+
 import torch
 import torch.distributed as dist
-import torch.nn as nn
 import torch.nn.functional as F
 import torch.optim as optim
 from params_proto import PrefixProto
@@ -37,12 +46,26 @@ class PPO_Args(PrefixProto):
     max_grad_norm = 1.
     selective_adaptation_module_loss = False
     # MI355X additions
-    autocast_bf16 = False           # BASELINE config 2: "bf16 policy"
+    autocast_bf16 = False           # BASELINE config 2: "bf16 policy" (fp32 master weights + bf16 compute replica)
     data_parallel = True            # all-reduce gradients when torch.distributed is initialised with world_size > 1
+
+
+_HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
 
 
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def gaussian_log_prob(actions, mean, std):
+    """sum_j log N(a_j; mu_j, sigma_j) — what Normal(mean, std).log_prob(a).sum(-1) evaluates."""
+    z = (actions - mean) / std
+    return -0.5 * (z * z).sum(dim=-1) - (torch.log(std).sum() + actions.shape[-1] * _HALF_LOG_2PI)
+
+
+def gaussian_entropy(std):
+    """sum_j H[N(., sigma_j)]; identical for every sample because sigma does not depend on the observation."""
+    return (0.5 + _HALF_LOG_2PI) * std.numel() + torch.log(std).sum()
 
 
 class PPO:
@@ -52,22 +75,72 @@ class PPO:
         self.device = device
         self.actor_critic = actor_critic
         self.actor_critic.to(device)
-        self.actor_critic.autocast_dtype = torch.bfloat16 if PPO_Args.autocast_bf16 else None
-        self.storage = None
         self.on_gpu = torch.device(device).type == "cuda"
+        self.bf16 = bool(PPO_Args.autocast_bf16 and self.on_gpu)
+        self.storage = None
+        self.master_params = list(self.actor_critic.parameters())
+        # flat fp32 gradient buffer; every master .grad is a view into it
+        self.flat_grad = torch.zeros(sum(p.numel() for p in self.master_params), device=device)
+        off = 0
+        for p in self.master_params:
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        adapt = list(self.actor_critic.adaptation_module.parameters())
+        first = next(i for i, p in enumerate(self.master_params) if p is adapt[0])
+        a0 = sum(p.numel() for p in self.master_params[:first])
+        self.adapt_params = adapt
+        self.adapt_flat_grad = self.flat_grad[a0:a0 + sum(p.numel() for p in adapt)]
+        if self.bf16:
+            self.compute_ac = copy.deepcopy(self.actor_critic)
+            for m in (self.compute_ac.adaptation_module, self.compute_ac.actor_body, self.compute_ac.critic_body):
+                m.to(torch.bfloat16)
+            self.compute_params = list(self.compute_ac.parameters())
+            self.compute_adapt_params = list(self.compute_ac.adaptation_module.parameters())
+        else:
+            self.compute_ac = self.actor_critic
+            self.compute_params = self.master_params
+            self.compute_adapt_params = adapt
         kw = dict(fused=True) if self.on_gpu else {}
         lr = torch.tensor(PPO_Args.learning_rate, device=device) if self.on_gpu else PPO_Args.learning_rate
-        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=lr, **kw)
-        self.adaptation_module_optimizer = optim.Adam(self.actor_critic.parameters(),
-                                                      lr=PPO_Args.adaptation_module_learning_rate, **kw)
-        if self.actor_critic.decoder:
-            self.decoder_optimizer = optim.Adam(self.actor_critic.parameters(), lr=PPO_Args.adaptation_module_learning_rate)
+        self.optimizer = optim.Adam(self.master_params, lr=lr, **kw)
+        # the reference builds this optimiser over all parameters (ppo.py:45-46) but only the adaptation module ever
+        # receives a non-zero gradient from the adaptation loss, so only those parameters move
+        self.adaptation_module_optimizer = optim.Adam(adapt, lr=PPO_Args.adaptation_module_learning_rate, **kw)
         self.transition = RolloutStorage.Transition()
         self._lr = torch.tensor(PPO_Args.learning_rate, device=device)
         self.dp = PPO_Args.data_parallel and _world() > 1
         if self.dp:                              # identical initial weights on every rank
-            for p in self.actor_critic.parameters():
+            for p in self.master_params:
                 dist.broadcast(p.data, src=0)
+        self._push_weights()
+
+    # ---- precision plumbing --------------------------------------------------------------------------
+    def _push_weights(self, adapt_only=False):
+        if self.bf16:
+            with torch.no_grad():
+                if adapt_only:
+                    torch._foreach_copy_(self.compute_adapt_params, self.adapt_params)
+                else:
+                    torch._foreach_copy_(self.compute_params, self.master_params)
+
+    def _pull_grads(self, adapt_only=False):
+        """compute-replica gradients -> flat fp32 master gradient buffer (no-op in fp32 mode: they are the same)."""
+        if not self.bf16:
+            return
+        src_params = self.compute_adapt_params if adapt_only else self.compute_params
+        dst_params = self.adapt_params if adapt_only else self.master_params
+        dst, src = [], []
+        for m, c in zip(dst_params, src_params):
+            if c.grad is not None:
+                dst.append(m.grad)
+                src.append(c.grad)
+        torch._foreach_copy_(dst, src)
+
+    def _zero_grads(self, adapt_only=False):
+        (self.adapt_flat_grad if adapt_only else self.flat_grad).zero_()
+        if self.bf16:
+            for p in (self.compute_adapt_params if adapt_only else self.compute_params):
+                p.grad = None
 
     @property
     def learning_rate(self):
@@ -75,11 +148,11 @@ class PPO:
 
     def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, privileged_obs_shape, obs_history_shape,
                      action_shape):
-        bf16 = PPO_Args.autocast_bf16 and self.on_gpu
         self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, privileged_obs_shape,
                                       obs_history_shape, action_shape, self.device,
-                                      history_dtype=torch.bfloat16 if bf16 else torch.float32,
-                                      history_pad_to=8 if bf16 else 1)
+                                      history_dtype=torch.bfloat16 if self.bf16 else torch.float32,
+                                      history_pad_to=8 if self.bf16 else 1)
+        self._last_hist = torch.zeros_like(self.storage.observation_histories[0])
 
     def test_mode(self):
         self.actor_critic.test()
@@ -87,6 +160,7 @@ class PPO:
     def train_mode(self):
         self.actor_critic.train()
 
+    # ---- rollout -----------------------------------------------------------------------------------------
     def act(self, obs, privileged_obs, obs_history):
         t = self.transition
         # the env's obs_history is a live view of its ring buffer: take the storage copy now, before env.step
@@ -94,14 +168,14 @@ class PPO:
         slot = self.storage.observation_histories[self.storage.step]
         slot[:, :obs_history.shape[-1]].copy_(obs_history)
         t.observation_histories = slot
-        ac = self.actor_critic
+        ac = self.compute_ac
         mean, value, _ = ac.fused_forward(slot, privileged_obs)
-        ac.set_distribution(mean.detach())
-        t.actions = ac.distribution.sample()
+        mean, std = mean.detach(), ac.std.detach()
+        t.actions = mean + std * torch.randn_like(mean)
         t.values = value.detach()
-        t.actions_log_prob = ac.get_actions_log_prob(t.actions).detach()
-        t.action_mean = ac.action_mean.detach()
-        t.action_sigma = ac.action_std.detach()
+        t.actions_log_prob = gaussian_log_prob(t.actions, mean, std)
+        t.action_mean = mean
+        t.action_sigma = std.expand_as(mean)
         t.observations = obs
         t.critic_observations = obs
         t.privileged_observations = privileged_obs
@@ -119,25 +193,12 @@ class PPO:
         self.actor_critic.reset(dones)
 
     def compute_returns(self, last_critic_obs, last_critic_privileged_obs):
-        last_values = self.actor_critic.evaluate(last_critic_obs, last_critic_privileged_obs).detach()
-        if last_values.is_inference():
-            last_values = last_values.clone()
-        self.storage.compute_returns(last_values, PPO_Args.gamma, PPO_Args.lam)
+        self._last_hist[:, :last_critic_obs.shape[-1]].copy_(last_critic_obs)
+        with torch.no_grad():
+            _, last_values, _ = self.compute_ac.fused_forward(self._last_hist, last_critic_privileged_obs)
+        self.storage.compute_returns(last_values.detach().clone(), PPO_Args.gamma, PPO_Args.lam)
 
-    # ---- data parallel helpers ---------------------------------------------------------------------
-    def _allreduce_grads(self, params):
-        grads = [p.grad for p in params if p.grad is not None]
-        if not grads:
-            return
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat)
-        flat.div_(_world())
-        off = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
-
+    # ---- update ------------------------------------------------------------------------------------------
     def _adapt_lr(self, kl_mean):
         if self.dp:
             dist.all_reduce(kl_mean)
@@ -154,27 +215,33 @@ class PPO:
             else:
                 group['lr'] = float(new)
 
+    def _clip_and_step(self, optimizer, flat, max_norm=None):
+        if self.dp:
+            dist.all_reduce(flat)
+            flat.div_(_world())
+        if max_norm is not None:     # nn.utils.clip_grad_norm_ on the flat buffer
+            flat.mul_(torch.clamp(max_norm / (torch.linalg.vector_norm(flat) + 1e-6), max=1.0))
+        optimizer.step()
+
     def update(self):
         A = PPO_Args
-        dev = self.device
-        acc = torch.zeros(4, device=dev)        # value, surrogate, adaptation, adaptation-test
-        params = [p for p in self.actor_critic.parameters()]
+        ac = self.compute_ac
+        acc = torch.zeros(4, device=self.device)        # value, surrogate, adaptation, adaptation-test
         generator = self.storage.mini_batch_generator(A.num_mini_batches, A.num_learning_epochs)
         for (obs_batch, critic_obs_batch, privileged_obs_batch, obs_history_batch, actions_batch, target_values_batch,
              advantages_batch, returns_batch, old_actions_log_prob_batch, old_mu_batch, old_sigma_batch, masks_batch,
              env_bins_batch) in generator:
-            mean, value_batch, _ = self.actor_critic.fused_forward(obs_history_batch, privileged_obs_batch)
-            self.actor_critic.set_distribution(mean)
-            actions_log_prob_batch = self.actor_critic.get_actions_log_prob(actions_batch)
-            mu_batch = self.actor_critic.action_mean
-            sigma_batch = self.actor_critic.action_std
-            entropy_batch = self.actor_critic.entropy
+            self._zero_grads()
+            mu_batch, value_batch, _ = ac.fused_forward(obs_history_batch, privileged_obs_batch)
+            std = ac.std
+            actions_log_prob_batch = gaussian_log_prob(actions_batch, mu_batch, std)
+            entropy = gaussian_entropy(std)
 
             if A.desired_kl is not None and A.schedule == 'adaptive':
-                with torch.no_grad():
-                    kl = torch.sum(torch.log(sigma_batch / old_sigma_batch + 1.e-5)
+                with torch.no_grad():     # reference ppo.py:120-124
+                    kl = torch.sum(torch.log(std / old_sigma_batch + 1.e-5)
                                    + (torch.square(old_sigma_batch) + torch.square(old_mu_batch - mu_batch))
-                                   / (2.0 * torch.square(sigma_batch)) - 0.5, axis=-1)
+                                   / (2.0 * torch.square(std)) - 0.5, axis=-1)
                     self._adapt_lr(torch.mean(kl))
 
             ratio = torch.exp(actions_log_prob_batch - torch.squeeze(old_actions_log_prob_batch))
@@ -185,30 +252,28 @@ class PPO:
                 value_loss = torch.max((value_batch - returns_batch).pow(2), (value_clipped - returns_batch).pow(2)).mean()
             else:
                 value_loss = (returns_batch - value_batch).pow(2).mean()
-            loss = surrogate_loss + A.value_loss_coef * value_loss - A.entropy_coef * entropy_batch.mean()
+            loss = surrogate_loss + A.value_loss_coef * value_loss - A.entropy_coef * entropy
 
-            self.optimizer.zero_grad()
             loss.backward()
-            if self.dp:
-                self._allreduce_grads(params)
-            nn.utils.clip_grad_norm_(self.actor_critic.parameters(), A.max_grad_norm)
-            self.optimizer.step()
+            self._pull_grads()
+            self._clip_and_step(self.optimizer, self.flat_grad, A.max_grad_norm)
+            self._push_weights()
             acc[0] += value_loss.detach()
             acc[1] += surrogate_loss.detach()
 
             num_train = int(privileged_obs_batch.shape[0] // 5 * 4)
             for _ in range(A.num_adaptation_module_substeps):
-                adaptation_pred = self.actor_critic.latent_padded(obs_history_batch)
+                self._zero_grads(adapt_only=True)
+                adaptation_pred = ac.latent_padded(obs_history_batch)
                 adaptation_target = privileged_obs_batch.detach()
                 sel = 0 if A.selective_adaptation_module_loss else slice(None)
                 adaptation_loss = F.mse_loss(adaptation_pred[:num_train, sel], adaptation_target[:num_train, sel])
                 with torch.no_grad():
                     adaptation_test_loss = F.mse_loss(adaptation_pred[num_train:, sel], adaptation_target[num_train:, sel])
-                self.adaptation_module_optimizer.zero_grad()
                 adaptation_loss.backward()
-                if self.dp:
-                    self._allreduce_grads(params)
-                self.adaptation_module_optimizer.step()
+                self._pull_grads(adapt_only=True)
+                self._clip_and_step(self.adaptation_module_optimizer, self.adapt_flat_grad)
+                self._push_weights(adapt_only=True)
                 acc[2] += adaptation_loss.detach()
                 acc[3] += adaptation_test_loss.detach()
 
