@@ -78,69 +78,92 @@ class PPO:
         self.on_gpu = torch.device(device).type == "cuda"
         self.bf16 = bool(PPO_Args.autocast_bf16 and self.on_gpu)
         self.storage = None
-        self.master_params = list(self.actor_critic.parameters())
-        # flat fp32 gradient buffer; every master .grad is a view into it
-        self.flat_grad = torch.zeros(sum(p.numel() for p in self.master_params), device=device)
-        off = 0
-        for p in self.master_params:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-            off += p.numel()
-        adapt = list(self.actor_critic.adaptation_module.parameters())
-        first = next(i for i, p in enumerate(self.master_params) if p is adapt[0])
-        a0 = sum(p.numel() for p in self.master_params[:first])
-        self.adapt_params = adapt
-        self.adapt_flat_grad = self.flat_grad[a0:a0 + sum(p.numel() for p in adapt)]
+        ac = self.actor_critic
+        modules = (ac.adaptation_module, ac.actor_body, ac.critic_body)
+        # parameter order of the flat buffers: [std | adaptation module | actor | critic]
+        self.master_params = [ac.std] + [p for m in modules for p in m.parameters()]
+        assert len(self.master_params) == len(list(ac.parameters()))
+        self.flat_param = self._flatten([p.data for p in self.master_params], torch.float32)
+        self.flat_grad = torch.zeros_like(self.flat_param)      # every master .grad is a view into it
+        self._bind(self.master_params, self.flat_param, self.flat_grad)
+        self.adapt_params = list(ac.adaptation_module.parameters())
+        offs, total = self._offsets(self.master_params)
+        n_std = offs[1]                                       # padded length of the std block
+        self.adapt_slice = slice(n_std, offs[1 + len(self.adapt_params)])
+        self.body_slice = slice(n_std, total)
         if self.bf16:
-            self.compute_ac = copy.deepcopy(self.actor_critic)
-            for m in (self.compute_ac.adaptation_module, self.compute_ac.actor_body, self.compute_ac.critic_body):
-                m.to(torch.bfloat16)
-            self.compute_params = list(self.compute_ac.parameters())
-            self.compute_adapt_params = list(self.compute_ac.adaptation_module.parameters())
+            # bf16 compute replica of the three MLPs; `std` stays the shared fp32 parameter
+            self.compute_ac = copy.deepcopy(ac)
+            self.compute_ac.std = ac.std
+            cmods = (self.compute_ac.adaptation_module, self.compute_ac.actor_body, self.compute_ac.critic_body)
+            cparams = [p for m in cmods for p in m.parameters()]
+            self.cflat_param = self._flatten([p.data for p in cparams], torch.bfloat16)
+            self.cflat_grad = torch.zeros_like(self.cflat_param)
+            self._bind(cparams, self.cflat_param, self.cflat_grad)
         else:
-            self.compute_ac = self.actor_critic
-            self.compute_params = self.master_params
-            self.compute_adapt_params = adapt
+            self.compute_ac = ac
         kw = dict(fused=True) if self.on_gpu else {}
         lr = torch.tensor(PPO_Args.learning_rate, device=device) if self.on_gpu else PPO_Args.learning_rate
         self.optimizer = optim.Adam(self.master_params, lr=lr, **kw)
         # the reference builds this optimiser over all parameters (ppo.py:45-46) but only the adaptation module ever
         # receives a non-zero gradient from the adaptation loss, so only those parameters move
-        self.adaptation_module_optimizer = optim.Adam(adapt, lr=PPO_Args.adaptation_module_learning_rate, **kw)
+        self.adaptation_module_optimizer = optim.Adam(self.adapt_params, lr=PPO_Args.adaptation_module_learning_rate, **kw)
         self.transition = RolloutStorage.Transition()
         self._lr = torch.tensor(PPO_Args.learning_rate, device=device)
         self.dp = PPO_Args.data_parallel and _world() > 1
         if self.dp:                              # identical initial weights on every rank
-            for p in self.master_params:
-                dist.broadcast(p.data, src=0)
+            dist.broadcast(self.flat_param, src=0)
         self._push_weights()
 
     # ---- precision plumbing --------------------------------------------------------------------------
+    ALIGN = 16          # elements: every parameter starts on a 32-byte (bf16) / 64-byte (fp32) boundary
+
+    @classmethod
+    def _offsets(cls, tensors):
+        offs, off = [], 0
+        for t in tensors:
+            offs.append(off)
+            off += -(-t.numel() // cls.ALIGN) * cls.ALIGN
+        return offs, off
+
+    @classmethod
+    def _flatten(cls, tensors, dtype):
+        offs, total = cls._offsets(tensors)
+        flat = torch.zeros(total, dtype=dtype, device=tensors[0].device)
+        for t, o in zip(tensors, offs):
+            flat[o:o + t.numel()].copy_(t.detach().reshape(-1))
+        return flat
+
+    @classmethod
+    def _bind(cls, params, flat_param, flat_grad):
+        """Re-seat every parameter (and its .grad) as a view into the flat buffers."""
+        offs, _ = cls._offsets(params)
+        for p, off in zip(params, offs):
+            n = p.numel()
+            p.data = flat_param[off:off + n].view_as(p)
+            p.grad = flat_grad[off:off + n].view_as(p)
+
     def _push_weights(self, adapt_only=False):
+        """fp32 master -> bf16 compute replica: one cast kernel."""
         if self.bf16:
-            with torch.no_grad():
-                if adapt_only:
-                    torch._foreach_copy_(self.compute_adapt_params, self.adapt_params)
-                else:
-                    torch._foreach_copy_(self.compute_params, self.master_params)
+            sl = self.adapt_slice if adapt_only else self.body_slice
+            n0 = self.body_slice.start
+            self.cflat_param[sl.start - n0:sl.stop - n0].copy_(self.flat_param[sl])
 
     def _pull_grads(self, adapt_only=False):
-        """compute-replica gradients -> flat fp32 master gradient buffer (no-op in fp32 mode: they are the same)."""
-        if not self.bf16:
-            return
-        src_params = self.compute_adapt_params if adapt_only else self.compute_params
-        dst_params = self.adapt_params if adapt_only else self.master_params
-        dst, src = [], []
-        for m, c in zip(dst_params, src_params):
-            if c.grad is not None:
-                dst.append(m.grad)
-                src.append(c.grad)
-        torch._foreach_copy_(dst, src)
+        """bf16 replica gradients -> flat fp32 master gradient buffer: one cast kernel (no-op in fp32 mode)."""
+        if self.bf16:
+            sl = self.adapt_slice if adapt_only else self.body_slice
+            n0 = self.body_slice.start
+            self.flat_grad[sl].copy_(self.cflat_grad[sl.start - n0:sl.stop - n0])
 
     def _zero_grads(self, adapt_only=False):
-        (self.adapt_flat_grad if adapt_only else self.flat_grad).zero_()
+        sl = self.adapt_slice if adapt_only else slice(0, self.flat_grad.numel())
+        self.flat_grad[sl].zero_()
         if self.bf16:
-            for p in (self.compute_adapt_params if adapt_only else self.compute_params):
-                p.grad = None
+            n0 = self.body_slice.start
+            lo, hi = (sl.start - n0, sl.stop - n0) if adapt_only else (0, self.cflat_grad.numel())
+            self.cflat_grad[lo:hi].zero_()
 
     @property
     def learning_rate(self):
@@ -272,7 +295,7 @@ class PPO:
                     adaptation_test_loss = F.mse_loss(adaptation_pred[num_train:, sel], adaptation_target[num_train:, sel])
                 adaptation_loss.backward()
                 self._pull_grads(adapt_only=True)
-                self._clip_and_step(self.adaptation_module_optimizer, self.adapt_flat_grad)
+                self._clip_and_step(self.adaptation_module_optimizer, self.flat_grad[self.adapt_slice])
                 self._push_weights(adapt_only=True)
                 acc[2] += adaptation_loss.detach()
                 acc[3] += adaptation_test_loss.detach()
