@@ -1,0 +1,65 @@
+"""Data-parallel PPO path on CPU: 2 processes, gloo backend (the GPU path is the same code over RCCL).
+Environments are partitioned per rank, the policy is replicated: after an update every rank must hold the same
+weights and learning rate, advantage statistics must be global, and the all-reduced gradient must be the mean of
+the per-rank gradients."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, out):
+    sys.path[:0] = [os.path.join(HERE, "..", "walk-these-ways_amd", "shims"), os.path.join(HERE, "..", "walk-these-ways_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from go1_gym_learn.ppo_cse.actor_critic import AC_Args, ActorCritic
+    from go1_gym_learn.ppo_cse.ppo import PPO, PPO_Args
+    from go1_gym_learn.ppo_cse.rollout_storage import RolloutStorage
+    AC_Args.actor_hidden_dims, AC_Args.critic_hidden_dims, AC_Args.adaptation_module_branch_hidden_dims = [32, 16], [24, 16], [16, 8]
+    N, T, no, npv, H, na = 12, 5, 10, 2, 3, 12
+    torch.manual_seed(100 + rank)                     # different initial weights: rank 0's must win
+    alg = PPO(ActorCritic(no, npv, no * H, na), device="cpu")
+    w0 = alg.flat_param.clone()
+    alg.init_storage(N, T, [no], [npv], [no * H], [na])
+    g = torch.Generator().manual_seed(7 + rank)       # different data per rank (env shard)
+    for t in range(T):
+        obs, priv, hist = torch.randn(N, no, generator=g), torch.randn(N, npv, generator=g), torch.randn(N, no * H, generator=g)
+        alg.act(obs, priv, hist)
+        alg.process_env_step(torch.randn(N, generator=g), (torch.rand(N, generator=g) < 0.1).to(torch.uint8),
+                             {"env_bins": torch.zeros(N), "time_outs": torch.zeros(N, dtype=torch.bool)})
+    alg.compute_returns(hist, priv)
+    adv_local = (alg.storage.returns - alg.storage.values).clone()
+    gathered = [torch.zeros_like(adv_local) for _ in range(world)]
+    dist.all_gather(gathered, adv_local)
+    allv = torch.cat(gathered)
+    expect = (adv_local - allv.mean()) / (allv.std() + 1e-8)
+    adv_ok = torch.allclose(alg.storage.advantages, expect, atol=1e-5)
+    # gradient all-reduce == mean of per-rank gradients
+    alg.flat_grad.copy_(torch.full_like(alg.flat_grad, float(rank + 1)))
+    alg._clip_and_step(type("O", (), {"step": lambda self: None})(), alg.flat_grad, None)
+    grad_ok = torch.allclose(alg.flat_grad, torch.full_like(alg.flat_grad, (1 + world) / 2))
+    torch.manual_seed(5)
+    alg.update()
+    out[rank] = dict(w0=w0, w=alg.flat_param.clone(), lr=alg.learning_rate, adv_ok=adv_ok, grad_ok=grad_ok, dp=alg.dp)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_update_keeps_replicas_identical():
+    world = 2
+    port = 29500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["dp"] and r1["dp"]
+    assert torch.equal(r0["w0"], r1["w0"])                 # broadcast of rank 0's initial weights
+    assert torch.equal(r0["w"], r1["w"])                   # identical after 20 + 20 optimiser steps
+    assert not torch.equal(r0["w"], r0["w0"])
+    assert r0["lr"] == r1["lr"]
+    assert r0["adv_ok"] and r1["adv_ok"]
+    assert r0["grad_ok"] and r1["grad_ok"]

@@ -1,0 +1,118 @@
+"""GPU tests of the env surface (LeggedRobot / VelocityTrackingEasyEnv / HistoryWrapper / Runner) and of the HIP
+tensor maps against the REFERENCE golden vectors (tests/golden/maps_*.npz, produced by the reference Python)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import go1sim_host as H
+from util import load_maps_fixture, make_sim
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("variant,fname", [("train", "maps_train.npz"), ("train", "maps_train_mild.npz"),
+                                           ("alt", "maps_alt.npz"), ("alt", "maps_alt_mild.npz")])
+def test_hip_post_physics_maps_match_reference_golden(variant, fname):
+    """fp32 HIP kernel vs the reference's fp32 PyTorch: 1e-5 relative on sums, 2e-5 absolute on elementwise maps."""
+    N = 48
+    cfg, S, meta, Bc = make_sim(variant, N)
+    d = load_maps_fixture(fname, S, meta, Bc)
+    Bg = Bc.clone_to("cuda:0")
+    sim = H.Go1Sim(S, Bg, 0)
+    sim.set_counters(7, 0)
+    sim.post_physics(d["gravity"])
+    torch.cuda.synchronize()
+    g = lambda k: Bg.tensors[k].cpu()
+    reset = d["out_reset_buf"].astype(bool)
+    keep = ~reset
+    np.testing.assert_array_equal(g("reset_buf").numpy().astype(bool), reset)
+    np.testing.assert_array_equal(g("time_out_buf").numpy().astype(bool), d["out_time_out_buf"].astype(bool))
+    tol = dict(rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(g("base_lin_vel").t().numpy(), d["out_base_lin_vel"], **tol)
+    np.testing.assert_allclose(g("projected_gravity").t().numpy(), d["out_projected_gravity"], **tol)
+    np.testing.assert_allclose(g("foot_indices").t().numpy(), d["out_foot_indices"], **tol)
+    np.testing.assert_allclose(g("clock_inputs").t().numpy(), d["out_clock_inputs"], rtol=1e-5, atol=3e-5)
+    np.testing.assert_allclose(g("desired_contact_states").t().numpy(), d["out_desired_contact_states"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(g("rew_buf").numpy(), d["out_rew_buf"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_array_equal(g("last_contacts").t().numpy().astype(bool), d["out_last_contacts"].astype(bool))
+    np.testing.assert_allclose(g("episode_sums").numpy()[:, keep], d["out_episode_sums"][:, keep], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(g("command_sums").numpy()[:, keep], d["out_command_sums"][:, keep], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(g("obs_buf").numpy()[keep], d["out_obs"][keep], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(g("privileged_obs_buf").numpy()[keep][:, :S.num_privileged_obs], d["out_priv"][keep], rtol=1e-5, atol=2e-5)
+
+
+def build_env(N=64):
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+    from go1_gym.envs.wrappers.history_wrapper import HistoryWrapper
+    from scripts.train_config import apply_train_config
+    cfg = apply_train_config(make_cfg(), num_envs=N)
+    env = VelocityTrackingEasyEnv(sim_device="cuda:0", headless=False, cfg=cfg)
+    return HistoryWrapper(env), cfg
+
+
+def test_env_surface_and_history_semantics():
+    N = 64
+    env, cfg = build_env(N)
+    assert (env.num_envs, env.num_obs, env.num_privileged_obs, env.num_obs_history, env.num_actions) == (N, 70, 2, 2100, 12)
+    assert env.dt == pytest.approx(0.02, abs=1e-8) and int(env.max_episode_length) == 1001
+    od = env.reset()
+    assert set(od) == {"obs", "privileged_obs", "obs_history"}
+    assert od["obs"].shape == (N, 70) and od["privileged_obs"].shape == (N, 2) and od["obs_history"].shape == (N, 2100)
+    assert float(od["obs_history"].abs().max()) == 0.0                       # reset() zeroes the history
+    od = env.get_observations()                                            # ... and get_observations appends obs once
+    assert torch.equal(od["obs_history"][:, -70:], od["obs"]) and float(od["obs_history"][:, :-70].abs().max()) == 0.0
+    prev = od["obs"].clone()
+    held = od["obs_history"]                                               # a caller may hold the view across one step
+    held_copy = held.clone()
+    a = 0.1 * torch.randn(N, 12, device="cuda")
+    od, rew, done, info = env.step(a)
+    assert torch.equal(held, held_copy)                                    # previous window not clobbered by the step
+    assert rew.shape == (N,) and done.shape == (N,) and od["obs"].dtype == torch.float32
+    h = od["obs_history"]
+    assert torch.equal(h[:, -70:], od["obs"]) and torch.equal(h[:, -140:-70], prev)
+    assert {"privileged_obs", "env_bins", "time_outs", "train/episode", "joint_pos", "contact_states", "torques"} <= set(info)
+    assert isinstance(info["joint_pos"], np.ndarray) and info["joint_pos"].shape == (N, 12)
+    assert info["foot_positions"].shape == (N, 4, 3)
+    # views write through to the simulator state (reference legged_robot.py:1138-1150 semantics)
+    base = env.env
+    base.dof_pos[3] = base.default_dof_pos[0]
+    assert torch.equal(base.buffers.dof_pos[:, 3], base.default_dof_pos[0])
+    base.commands[:, 0] = 0.7
+    assert float(base.buffers.commands[0].min()) == pytest.approx(0.7)
+    stats = info["train/episode"]
+    assert "rew_total" in stats and "command_area_trot" in stats and float(stats["command_area_trot"]) == pytest.approx(25 / 441)
+    for _ in range(30):
+        od, rew, done, info = env.step(a)
+    assert torch.isfinite(od["obs_history"]).all() and torch.isfinite(rew).all()
+    assert base.start_recording() is None and base.get_complete_frames() == []
+
+
+def test_runner_learns_and_exports(tmp_path):
+    from go1_gym_learn.ppo_cse import Runner, RunnerArgs
+    from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    from ml_logger import logger
+    logger.configure("run", root=str(tmp_path))
+    logger.print_summary = False
+    PPO_Args.autocast_bf16 = True
+    RunnerArgs.save_interval = 1
+    RunnerArgs.log_freq = 1
+    env, cfg = build_env(256)
+    os.chdir(tmp_path)
+    runner = Runner(env, device="cuda:0")
+    w0 = runner.alg.flat_param.clone()
+    runner.learn(num_learning_iterations=2, init_at_random_ep_len=True, eval_freq=100)
+    assert not torch.equal(w0, runner.alg.flat_param) and torch.isfinite(runner.alg.flat_param).all()
+    ck = tmp_path / "run" / "checkpoints"
+    assert (ck / "ac_weights_last.pt").exists() and (ck / "ac_weights_000001.pt").exists()
+    sd = torch.load(ck / "ac_weights_last.pt")
+    assert sd["actor_body.0.weight"].shape == (512, 2102) and sd["std"].shape == (12,)
+    body = torch.jit.load(str(ck / "body_latest.jit"))
+    adapt = torch.jit.load(str(ck / "adaptation_module_latest.jit"))
+    hist = torch.randn(3, 2100)
+    assert body(torch.cat((hist, adapt(hist)), dim=-1)).shape == (3, 12)       # scripts/play.py:20-29 usage
+    metrics = logger.load_pkl("metrics.pkl")
+    assert "train/episode/rew_total/mean" in metrics[-1] and metrics[-1]["timesteps"] == 2 * 24 * 256
+    PPO_Args.autocast_bf16 = False

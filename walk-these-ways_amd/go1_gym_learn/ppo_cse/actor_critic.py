@@ -70,6 +70,20 @@ class ActorCritic(nn.Module):
             return out
         return y + F.linear(z, Wz, b)
 
+    @staticmethod
+    def _head(seq, x, min_cols=64):
+        """seq[1:] applied to first-layer pre-activations x, with the final Linear's output width padded to
+        `min_cols` zero rows: GEMMs with 1 / 2 / 12 output columns (value, latent, action mean) are served by very
+        slow kernels, a 64-column GEMM is not; the extra columns are dropped."""
+        body, last = seq[1:-1], seq[-1]
+        h = body(x)
+        n = last.weight.shape[0]
+        if n >= min_cols or not h.is_cuda:
+            return last(h)
+        W = F.pad(last.weight, (0, 0, 0, min_cols - n))
+        b = F.pad(last.bias, (0, min_cols - n))
+        return F.linear(h, W, b)[:, :n]
+
     def fused_forward(self, observation_history, privileged_observations=None, want_value=True):
         """(action mean, value, latent) with ONE GEMM over the 2100-wide history for the first layers of the
         adaptation module, the actor and the critic (they share the input: 256 + 512 + 512 output columns),
@@ -88,12 +102,12 @@ class ActorCritic(nn.Module):
             Wh = F.pad(Wh, (0, pad))
         y = F.linear(x, Wh)
         nd, na = ld.weight.shape[0], la.weight.shape[0]
-        latent = self.adaptation_module[1:](y[:, :nd] + ld.bias)
-        mean = self.actor_body[1:](self._side(y[:, nd:nd + na], latent, la.weight[:, K:], la.bias)).to(odt)
+        latent = self._head(self.adaptation_module, y[:, :nd] + ld.bias)
+        mean = self._head(self.actor_body, self._side(y[:, nd:nd + na], latent, la.weight[:, K:], la.bias)).to(odt)
         value = None
         if want_value:
             p = privileged_observations.to(wdt)
-            value = self.critic_body[1:](self._side(y[:, nd + na:], p, lc.weight[:, K:], lc.bias)).to(odt)
+            value = self._head(self.critic_body, self._side(y[:, nd + na:], p, lc.weight[:, K:], lc.bias)).to(odt)
         return mean, value, latent.to(odt)
 
     def latent_padded(self, observation_history):
@@ -103,7 +117,7 @@ class ActorCritic(nn.Module):
         x = observation_history if observation_history.dtype == ld.weight.dtype else observation_history.to(ld.weight.dtype)
         pad = x.shape[-1] - K
         W = F.pad(ld.weight, (0, pad)) if pad else ld.weight
-        return self.adaptation_module[1:](F.linear(x, W, ld.bias)).to(self.std.dtype)
+        return self._head(self.adaptation_module, F.linear(x, W, ld.bias)).to(self.std.dtype)
 
     def set_distribution(self, mean):
         self.distribution = Normal(mean, mean * 0. + self.std)
