@@ -1,0 +1,502 @@
+// go1_maps.h — tensor maps of post_physics_step, commands/curriculum sampling, domain randomisation, reset
+// (reference legged_robot.py:90-136,138-239,263-491,675-905; corl_rewards.py:15-202).  One environment per calling lane.
+#pragma once
+#include "go1_math.h"
+#include "../../include/go1sim.h"
+
+#define PI_F 3.14159265358979323846f
+enum { P_NOISE = 1, P_RESET = 2, P_DOFPROPS_CB = 3, P_DOFPROPS_RESET = 4, P_CMD_CB = 5, P_CMD_RESET = 6, P_PUSH = 7, P_GRAVITY = 8 };
+
+#define AT(ptr, c, e) ((ptr)[(size_t)(c) * N + (e)])
+
+__device__ __noinline__ float rng_uniform(const Go1SimConfig& cfg, uint32_t env_global, int64_t step, uint32_t purpose, uint32_t idx) {
+  uint32_t out[4];
+  philox4x32_10(env_global, (uint32_t)step, purpose, idx >> 2, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), out);
+  uint32_t sel = idx & 3;
+  uint32_t v = sel == 0 ? out[0] : sel == 1 ? out[1] : sel == 2 ? out[2] : out[3];
+  return u32_to_unit(v);
+}
+
+DEV V3 gravity_at(const Go1SimConfig& cfg, int64_t t) {
+  V3 g = v3(cfg.gravity[0], cfg.gravity[1], cfg.gravity[2]);
+  if (!cfg.randomize_gravity) return g;
+  int64_t epoch = t / cfg.gravity_rand_interval, ph = t % cfg.gravity_rand_interval;
+  if (ph >= cfg.gravity_rand_duration) return g;
+  float span = cfg.gravity_range[1] - cfg.gravity_range[0];
+  g.x += rng_uniform(cfg, 0xFFFFFFFFu, epoch, P_GRAVITY, 0) * span + cfg.gravity_range[0];
+  g.y += rng_uniform(cfg, 0xFFFFFFFFu, epoch, P_GRAVITY, 1) * span + cfg.gravity_range[0];
+  g.z += rng_uniform(cfg, 0xFFFFFFFFu, epoch, P_GRAVITY, 2) * span + cfg.gravity_range[0];
+  return g;
+}
+
+// ================================================================================================
+// commands, domain randomisation, reset
+// ================================================================================================
+DEV float fmod1(float x) { float r = fmodf(x, 1.0f); return r < 0.f ? r + 1.0f : r; }
+
+DEV void resample_commands(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int64_t step, uint32_t purpose) {
+  if (cfg.device_curriculum) {
+    const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
+    const int ep_len = cfg.max_episode_length < cfg.resample_interval ? cfg.max_episode_length : cfg.resample_interval;
+    bool ok = cfg.curriculum_keys != 0;
+#pragma unroll 1
+    for (int kx = 0; kx < 4; kx++) {
+      if (!(cfg.curriculum_keys & (1 << kx))) continue;
+      float val = AT(B.command_sums, cfg.curriculum_sum_index[kx], e) / (float)ep_len;
+      if (!(val > cfg.curriculum_threshold[kx])) ok = false;
+    }
+    int cat_old = B.env_command_categories[e], bin_old = B.env_command_bins[e];
+    if (ok) atomicAdd(&B.curriculum_success[cat_old * cfg.num_bins + bin_old], 1);
+    float u0 = rng_uniform(cfg, eg, step, purpose, 0), u1 = rng_uniform(cfg, eg, step, purpose, 1);
+    int cat = (int)(u0 * cfg.num_categories);
+    if (cat >= cfg.num_categories) cat = cfg.num_categories - 1;
+    const float* cdf = B.curriculum_cdf + (size_t)cat * cfg.num_bins;
+    int bin = 0;
+    while (bin < cfg.num_bins - 1 && !(u1 < cdf[bin])) bin++;
+    B.env_command_bins[e] = bin;
+    B.env_command_categories[e] = cat;
+    int rem = bin;
+    float cmd[GO1_MAX_COMMANDS];
+#pragma unroll
+    for (int kx = GO1_MAX_COMMANDS - 1; kx >= 0; kx--) {
+      int nb = cfg.grid_bins[kx], idx = rem % nb;
+      rem /= nb;
+      float bs = (cfg.grid_high[kx] - cfg.grid_low[kx]) / nb;
+      float centroid = cfg.grid_low[kx] + bs * (idx + 0.5f);
+      float u = rng_uniform(cfg, eg, step, purpose, 2 + kx);
+      cmd[kx] = centroid + (u - 0.5f) * bs;
+    }
+    if (cfg.num_commands > 5) {
+      if (cfg.gaitwise_curricula) {
+        if (cat == 0) { cmd[5] = fmod1(cmd[5] / 2 - 0.25f); cmd[6] = fmod1(cmd[6] / 2 - 0.25f); cmd[7] = fmod1(cmd[7] / 2 - 0.25f); }
+        else if (cat == 1) { cmd[5] = cmd[5] / 2 + 0.25f; cmd[6] = 0.f; cmd[7] = 0.f; }
+        else if (cat == 2) { cmd[5] = 0.f; cmd[6] = cmd[6] / 2 + 0.25f; cmd[7] = 0.f; }
+        else { cmd[5] = 0.f; cmd[6] = 0.f; cmd[7] = cmd[7] / 2 + 0.25f; }
+      }
+      if (cfg.binary_phases) {
+        cmd[5] = fmod1(rintf(2 * cmd[5]) / 2.0f); cmd[6] = fmod1(rintf(2 * cmd[6]) / 2.0f); cmd[7] = fmod1(rintf(2 * cmd[7]) / 2.0f);
+      }
+    }
+    float nrm = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
+    if (!(nrm > 0.2f)) { cmd[0] = 0.f; cmd[1] = 0.f; }
+#pragma unroll
+    for (int kx = 0; kx < GO1_MAX_COMMANDS; kx++)
+      if (kx < cfg.num_commands) AT(B.commands, kx, e) = cmd[kx];
+  } else {
+    B.resample_flags[e] |= (purpose == P_CMD_CB) ? 1 : 2;
+  }
+#pragma unroll 1
+  for (int kx = 0; kx < cfg.num_rewards + 5; kx++) AT(B.command_sums, kx, e) = 0.f;
+}
+
+DEV void randomize_dof_props(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int64_t step, uint32_t purpose) {
+  const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
+  if (cfg.randomize_motor_strength) {
+    float v = rng_uniform(cfg, eg, step, purpose, 0) * (cfg.motor_strength_range[1] - cfg.motor_strength_range[0]) + cfg.motor_strength_range[0];
+#pragma unroll 1
+    for (int j = 0; j < 12; j++) AT(B.motor_strengths, j, e) = v;
+  }
+  if (cfg.randomize_motor_offset) {
+#pragma unroll 1
+    for (int j = 0; j < 12; j++)
+      AT(B.motor_offsets, j, e) = rng_uniform(cfg, eg, step, purpose, 1 + j) * (cfg.motor_offset_range[1] - cfg.motor_offset_range[0]) + cfg.motor_offset_range[0];
+  }
+  if (cfg.randomize_Kp_factor) {
+    float v = rng_uniform(cfg, eg, step, purpose, 13) * (cfg.Kp_factor_range[1] - cfg.Kp_factor_range[0]) + cfg.Kp_factor_range[0];
+#pragma unroll 1
+    for (int j = 0; j < 12; j++) AT(B.Kp_factors, j, e) = v;
+  }
+  if (cfg.randomize_Kd_factor) {
+    float v = rng_uniform(cfg, eg, step, purpose, 14) * (cfg.Kd_factor_range[1] - cfg.Kd_factor_range[0]) + cfg.Kd_factor_range[0];
+#pragma unroll 1
+    for (int j = 0; j < 12; j++) AT(B.Kd_factors, j, e) = v;
+  }
+}
+
+DEV void reset_env(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int64_t step) {
+  const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
+  resample_commands(cfg, B, e, N, step, P_CMD_RESET);
+  randomize_dof_props(cfg, B, e, N, step, P_DOFPROPS_RESET);
+#pragma unroll 1
+  for (int j = 0; j < 12; j++) {
+    AT(B.dof_pos, j, e) = cfg.default_dof_pos[j] * (0.5f + rng_uniform(cfg, eg, step, P_RESET, j));
+    AT(B.dof_vel, j, e) = 0.f;
+  }
+  float root[13];
+#pragma unroll
+  for (int i = 0; i < 13; i++) root[i] = cfg.base_init_state[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) root[i] += AT(B.env_origins, i, e);
+  if (cfg.custom_origins) {
+    root[0] += (2 * rng_uniform(cfg, eg, step, P_RESET, 12) - 1) * cfg.x_init_range + cfg.x_init_offset;
+    root[1] += (2 * rng_uniform(cfg, eg, step, P_RESET, 13) - 1) * cfg.y_init_range + cfg.y_init_offset;
+  }
+  float yaw = (2 * rng_uniform(cfg, eg, step, P_RESET, 14) - 1) * cfg.yaw_init_range;
+  root[3] = 0.f; root[4] = 0.f; root[5] = sinf(0.5f * yaw); root[6] = cosf(0.5f * yaw);
+#pragma unroll
+  for (int i = 0; i < 6; i++) root[7 + i] = rng_uniform(cfg, eg, step, P_RESET, 15 + i) - 0.5f;
+#pragma unroll
+  for (int i = 0; i < 13; i++) AT(B.root_states, i, e) = root[i];
+#pragma unroll 1
+  for (int j = 0; j < 12; j++) { AT(B.last_actions, j, e) = 0.f; AT(B.last_last_actions, j, e) = 0.f; AT(B.last_dof_vel, j, e) = 0.f; }
+  B.episode_length_buf[e] = 0;
+  B.reset_buf[e] = 1;
+#pragma unroll 1
+  for (int kx = 0; kx <= cfg.num_rewards; kx++) {
+    atomicAdd(&B.episode_log[kx], AT(B.episode_sums, kx, e));
+    AT(B.episode_sums, kx, e) = 0.f;
+  }
+  atomicAdd(&B.episode_log[cfg.num_rewards + 1], 1.0f);
+  B.gait_indices[e] = 0.f;
+  const int nl = cfg.lag_timesteps + 1;
+#pragma unroll 1
+  for (int sl = 0; sl < nl; sl++)
+#pragma unroll 1
+    for (int j = 0; j < 12; j++) B.lag_buffer[((size_t)sl * 12 + j) * N + e] = 0.f;
+}
+
+// ================================================================================================
+// rewards (reference corl_rewards.py:15-202), one raw term per id
+// ================================================================================================
+struct Derived {
+  V3 base_pos, blv, bav, pg, gvec;
+  float qx, qy, qz, qw;
+};
+
+DEV float cf_norm(const Go1SimBuffers& B, int b, int e, int N) {
+  float x = AT(B.contact_forces, 3 * b, e), y = AT(B.contact_forces, 3 * b + 1, e), z = AT(B.contact_forces, 3 * b + 2, e);
+  return sqrtf(x * x + y * y + z * z);
+}
+DEV float normal_cdf(float x, float sigma) { return 0.5f * (1.f + erff(x / (sigma * 1.41421356237309504880f))); }
+
+DEV float reward_term(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int id, const Derived& d) {
+  float r = 0.f;
+  switch (id) {
+    case GO1_REW_TRACKING_LIN_VEL: {
+      float ex = AT(B.commands, 0, e) - d.blv.x, ey = AT(B.commands, 1, e) - d.blv.y;
+      return expf(-(ex * ex + ey * ey) / cfg.tracking_sigma);
+    }
+    case GO1_REW_TRACKING_ANG_VEL: {
+      float ez = AT(B.commands, 2, e) - d.bav.z;
+      return expf(-(ez * ez) / cfg.tracking_sigma_yaw);
+    }
+    case GO1_REW_LIN_VEL_Z: return d.blv.z * d.blv.z;
+    case GO1_REW_ANG_VEL_XY: return d.bav.x * d.bav.x + d.bav.y * d.bav.y;
+    case GO1_REW_ORIENTATION: return d.pg.x * d.pg.x + d.pg.y * d.pg.y;
+    case GO1_REW_TORQUES:
+#pragma unroll 1
+      for (int j = 0; j < 12; j++) { float t = AT(B.torques, j, e); r = fmaf(t, t, r); }
+      return r;
+    case GO1_REW_DOF_ACC:
+#pragma unroll 1
+      for (int j = 0; j < 12; j++) { float a = (AT(B.last_dof_vel, j, e) - AT(B.dof_vel, j, e)) / cfg.dt; r = fmaf(a, a, r); }
+      return r;
+    case GO1_REW_ACTION_RATE:
+#pragma unroll 1
+      for (int j = 0; j < 12; j++) { float a = AT(B.last_actions, j, e) - AT(B.actions, j, e); r = fmaf(a, a, r); }
+      return r;
+    case GO1_REW_COLLISION:
+#pragma unroll 1
+      for (int b = 0; b < 17; b++) if (cfg.penalised_body_mask & (1u << b)) r += (cf_norm(B, b, e, N) > 0.1f) ? 1.f : 0.f;
+      return r;
+    case GO1_REW_DOF_POS_LIMITS:
+#pragma unroll 1
+      for (int j = 0; j < 12; j++) {
+        float q = AT(B.dof_pos, j, e);
+        float lo = q - cfg.dof_pos_soft_lower[j], hi = q - cfg.dof_pos_soft_upper[j];
+        r += -fminf(lo, 0.f) + fmaxf(hi, 0.f);
+      }
+      return r;
+    case GO1_REW_JUMP: {
+      float t = d.base_pos.z - (AT(B.commands, 3, e) + cfg.base_height_target);
+      return -t * t;
+    }
+    case GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE:
+#pragma unroll 1
+      for (int f = 0; f < 4; f++) {
+        float fn = cf_norm(B, 4 + 4 * f, e, N);
+        r += -(1.f - AT(B.desired_contact_states, f, e)) * (1.f - expf(-fn * fn / cfg.gait_force_sigma));
+      }
+      return r / 4;
+    case GO1_REW_TRACKING_CONTACTS_SHAPED_VEL:
+#pragma unroll 1
+      for (int f = 0; f < 4; f++) {
+        float vx = AT(B.foot_velocities, 3 * f, e), vy = AT(B.foot_velocities, 3 * f + 1, e), vz = AT(B.foot_velocities, 3 * f + 2, e);
+        float vv = vx * vx + vy * vy + vz * vz;
+        r += -(AT(B.desired_contact_states, f, e) * (1.f - expf(-vv / cfg.gait_vel_sigma)));
+      }
+      return r / 4;
+    case GO1_REW_DOF_POS:
+#pragma unroll 1
+      for (int j = 0; j < 12; j++) { float a = AT(B.dof_pos, j, e) - cfg.default_dof_pos[j]; r = fmaf(a, a, r); }
+      return r;
+    case GO1_REW_DOF_VEL:
+#pragma unroll 1
+      for (int j = 0; j < 12; j++) { float a = AT(B.dof_vel, j, e); r = fmaf(a, a, r); }
+      return r;
+    case GO1_REW_ACTION_SMOOTHNESS_1:
+#pragma unroll 1
+      for (int j = 0; j < 12; j++) {
+        float a = AT(B.joint_pos_target, j, e) - AT(B.last_joint_pos_target, j, e);
+        r += a * a * (AT(B.last_actions, j, e) != 0.f ? 1.f : 0.f);
+      }
+      return r;
+    case GO1_REW_ACTION_SMOOTHNESS_2:
+#pragma unroll 1
+      for (int j = 0; j < 12; j++) {
+        float a = AT(B.joint_pos_target, j, e) - 2.f * AT(B.last_joint_pos_target, j, e) + AT(B.last_last_joint_pos_target, j, e);
+        r += a * a * (AT(B.last_actions, j, e) != 0.f ? 1.f : 0.f) * (AT(B.last_last_actions, j, e) != 0.f ? 1.f : 0.f);
+      }
+      return r;
+    case GO1_REW_FEET_SLIP:
+#pragma unroll 1
+      for (int f = 0; f < 4; f++) {
+        bool contact = AT(B.contact_forces, 3 * (4 + 4 * f) + 2, e) > 1.0f;
+        bool filt = contact || AT(B.last_contacts, f, e);
+        AT(B.last_contacts, f, e) = (uint8_t)contact;
+        float vx = AT(B.foot_velocities, 3 * f, e), vy = AT(B.foot_velocities, 3 * f + 1, e);
+        r += filt ? (vx * vx + vy * vy) : 0.f;
+      }
+      return r;
+    case GO1_REW_FEET_CONTACT_VEL:
+#pragma unroll 1
+      for (int f = 0; f < 4; f++) {
+        float vx = AT(B.foot_velocities, 3 * f, e), vy = AT(B.foot_velocities, 3 * f + 1, e), vz = AT(B.foot_velocities, 3 * f + 2, e);
+        r += (AT(B.foot_positions, 3 * f + 2, e) < 0.03f) ? (vx * vx + vy * vy + vz * vz) : 0.f;
+      }
+      return r;
+    case GO1_REW_FEET_CONTACT_FORCES:
+#pragma unroll 1
+      for (int f = 0; f < 4; f++) r += fmaxf(cf_norm(B, 4 + 4 * f, e, N) - cfg.max_contact_force, 0.f);
+      return r;
+    case GO1_REW_FEET_CLEARANCE_CMD_LINEAR:
+#pragma unroll 1
+      for (int f = 0; f < 4; f++) {
+        float cl = fminf(fmaxf(AT(B.foot_indices, f, e) * 2.0f - 1.0f, 0.f), 1.f);
+        float ph = 1.f - fabsf(1.0f - cl * 2.0f);
+        float target = AT(B.commands, 9, e) * ph + 0.02f;
+        float df = target - AT(B.foot_positions, 3 * f + 2, e);
+        r += df * df * (1.f - AT(B.desired_contact_states, f, e));
+      }
+      return r;
+    case GO1_REW_FEET_IMPACT_VEL:
+#pragma unroll 1
+      for (int f = 0; f < 4; f++) {
+        float pv = fminf(fmaxf(AT(B.prev_foot_velocities, 3 * f + 2, e), -100.f), 0.f);
+        r += (cf_norm(B, 4 + 4 * f, e, N) > 1.0f) ? pv * pv : 0.f;
+      }
+      return r;
+    case GO1_REW_ORIENTATION_CONTROL: {
+      float pitch = AT(B.commands, 10, e), roll = AT(B.commands, 11, e);
+      float sr, cr, sp, cp;
+      sincosf(-0.5f * roll, &sr, &cr);
+      sincosf(-0.5f * pitch, &sp, &cp);
+      // quat_mul((sr,0,0,cr), (0,sp,0,cp))
+      float x = sr * cp, y = cr * sp, z = sr * sp, w = cr * cp;
+      V3 g = quat_rotate_inverse(x, y, z, w, d.gvec);
+      float a = d.pg.x - g.x, b = d.pg.y - g.y;
+      return a * a + b * b;
+    }
+    case GO1_REW_RAIBERT_HEURISTIC: {
+      float l = rsqrtf(d.qz * d.qz + d.qw * d.qw);
+      float yz = -d.qz * l, yw = d.qw * l;
+      float width = cfg.num_commands >= 13 ? AT(B.commands, 12, e) : 0.3f;
+      float length = cfg.num_commands >= 14 ? AT(B.commands, 13, e) : 0.45f;
+      float freq = AT(B.commands, 4, e), xv = AT(B.commands, 0, e), yawv = AT(B.commands, 2, e);
+      float yv = yawv * length / 2;
+#pragma unroll 1
+      for (int f = 0; f < 4; f++) {
+        V3 rel = v3(AT(B.foot_positions, 3 * f, e) - d.base_pos.x, AT(B.foot_positions, 3 * f + 1, e) - d.base_pos.y,
+                    AT(B.foot_positions, 3 * f + 2, e) - d.base_pos.z);
+        V3 fb = quat_rotate(0.f, 0.f, yz, yw, rel);
+        float ys = (f % 2 == 0 ? 1.f : -1.f) * width / 2, xs = (f < 2 ? 1.f : -1.f) * length / 2;
+        float ph = fabsf(1.0f - AT(B.foot_indices, f, e) * 2.0f) * 1.0f - 0.5f;
+        float yo = ph * yv * (0.5f / freq), xo = ph * xv * (0.5f / freq);
+        if (f >= 2) yo = -yo;
+        float ex = fabsf((xs + xo) - fb.x), ey = fabsf((ys + yo) - fb.y);
+        r += ex * ex + ey * ey;
+      }
+      return r;
+    }
+    default: return 0.f;
+  }
+}
+DEV int reward_raw_sign(int id) {
+  return (id == GO1_REW_JUMP || id == GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE || id == GO1_REW_TRACKING_CONTACTS_SHAPED_VEL) ? -1 : 1;
+}
+
+// ================================================================================================
+// post-physics maps (reference legged_robot.py:90-136)
+// ================================================================================================
+DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int64_t counter_post, V3 grav, int history_slot) {
+  const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
+  Derived d;
+  int ep_len = B.episode_length_buf[e] + 1;
+  B.episode_length_buf[e] = ep_len;
+  d.base_pos = v3(AT(B.root_states, 0, e), AT(B.root_states, 1, e), AT(B.root_states, 2, e));
+  d.qx = AT(B.root_states, 3, e); d.qy = AT(B.root_states, 4, e); d.qz = AT(B.root_states, 5, e); d.qw = AT(B.root_states, 6, e);
+  V3 vl = v3(AT(B.root_states, 7, e), AT(B.root_states, 8, e), AT(B.root_states, 9, e));
+  V3 va = v3(AT(B.root_states, 10, e), AT(B.root_states, 11, e), AT(B.root_states, 12, e));
+  d.blv = quat_rotate_inverse(d.qx, d.qy, d.qz, d.qw, vl);
+  d.bav = quat_rotate_inverse(d.qx, d.qy, d.qz, d.qw, va);
+  d.gvec = (1.f / norm(grav)) * grav;
+  d.pg = quat_rotate_inverse(d.qx, d.qy, d.qz, d.qw, d.gvec);
+  AT(B.base_lin_vel, 0, e) = d.blv.x; AT(B.base_lin_vel, 1, e) = d.blv.y; AT(B.base_lin_vel, 2, e) = d.blv.z;
+  AT(B.base_ang_vel, 0, e) = d.bav.x; AT(B.base_ang_vel, 1, e) = d.bav.y; AT(B.base_ang_vel, 2, e) = d.bav.z;
+  AT(B.projected_gravity, 0, e) = d.pg.x; AT(B.projected_gravity, 1, e) = d.pg.y; AT(B.projected_gravity, 2, e) = d.pg.z;
+
+  // ---- _post_physics_step_callback -----------------------------------------------------------
+  if (cfg.teleport_robots) {
+    float x = AT(B.root_states, 0, e), y = AT(B.root_states, 1, e), th = cfg.teleport_thresh, xo = cfg.teleport_x_offset;
+    if (x < th + xo) x += cfg.terrain_length * (cfg.terrain_num_rows - 1);
+    if (x > cfg.terrain_length * cfg.terrain_num_rows - th + xo) x -= cfg.terrain_length * (cfg.terrain_num_rows - 1);
+    if (y < th) y += cfg.terrain_width * (cfg.terrain_num_cols - 1);
+    if (y > cfg.terrain_width * cfg.terrain_num_cols - th) y -= cfg.terrain_width * (cfg.terrain_num_cols - 1);
+    AT(B.root_states, 0, e) = x; AT(B.root_states, 1, e) = y;
+  }
+  if (ep_len % cfg.resample_interval == 0) resample_commands(cfg, B, e, N, counter_post, P_CMD_CB);
+  if (cfg.observe_gait_commands) {
+    float freq = AT(B.commands, 4, e), phase = AT(B.commands, 5, e), offset = AT(B.commands, 6, e), bound = AT(B.commands, 7, e), dur = AT(B.commands, 8, e);
+    float gi = fmod1(B.gait_indices[e] + cfg.dt * freq);
+    B.gait_indices[e] = gi;
+    float fi[4];
+    if (cfg.pacing_offset) { fi[0] = gi + phase + offset + bound; fi[1] = gi + bound; fi[2] = gi + offset; fi[3] = gi + phase; }
+    else                   { fi[0] = gi + phase + offset + bound; fi[1] = gi + offset; fi[2] = gi + bound; fi[3] = gi + phase; }
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+      float rem = fmod1(fi[f]);
+      AT(B.foot_indices, f, e) = rem;
+      float idx = fi[f];
+      if (rem < dur) idx = rem * (0.5f / dur);
+      else if (rem > dur) idx = 0.5f + (rem - dur) * (0.5f / (1.f - dur));
+      AT(B.clock_inputs, f, e) = sinf(2.f * PI_F * idx);
+      float kap = cfg.kappa_gait_probs, x = fmod1(idx);
+      float sm = normal_cdf(x, kap) * (1.f - normal_cdf(x - 0.5f, kap)) + normal_cdf(x - 1.f, kap) * (1.f - normal_cdf(x - 0.5f - 1.f, kap));
+      AT(B.desired_contact_states, f, e) = sm;
+    }
+  }
+  if (cfg.push_robots && ep_len % cfg.push_interval == 0) {
+    AT(B.root_states, 7, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, 0) - 1) * cfg.max_push_vel_xy;
+    AT(B.root_states, 8, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, 1) - 1) * cfg.max_push_vel_xy;
+  }
+  if (ep_len % cfg.rand_interval == 0) randomize_dof_props(cfg, B, e, N, counter_post, P_DOFPROPS_CB);
+
+  // ---- check_termination -----------------------------------------------------------------------
+  bool reset = false;
+#pragma unroll 1
+  for (int b = 0; b < 17; b++) if ((cfg.termination_body_mask & (1u << b)) && cf_norm(B, b, e, N) > 1.0f) reset = true;
+  bool time_out = ep_len > cfg.max_episode_length;
+  reset = reset || time_out;
+  if (cfg.use_terminal_body_height && AT(B.root_states, 2, e) < cfg.terminal_body_height) reset = true;
+  B.time_out_buf[e] = (uint8_t)time_out;
+  B.reset_buf[e] = (uint8_t)reset;
+
+  // ---- compute_reward --------------------------------------------------------------------------
+  float rew = 0.f, pos = 0.f, neg = 0.f;
+#pragma unroll 1
+  for (int kx = 0; kx < cfg.num_rewards; kx++) {
+    int id = cfg.reward_ids[kx];
+    float sc = cfg.reward_scales[kx];
+    float r = reward_term(cfg, B, e, N, id, d) * sc;
+    rew += r;
+    if (reward_raw_sign(id) * sc >= 0) pos += r; else neg += r;
+    AT(B.episode_sums, kx, e) += r;
+    if (id == GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE || id == GO1_REW_TRACKING_CONTACTS_SHAPED_VEL) AT(B.command_sums, kx, e) += sc + r;
+    else AT(B.command_sums, kx, e) += r;
+  }
+  if (cfg.only_positive_rewards) rew = fmaxf(rew, 0.f);
+  else if (cfg.only_positive_rewards_ji22_style) rew = pos * expf(neg / cfg.sigma_rew_neg);
+  B.rew_buf[e] = rew;
+  AT(B.episode_sums, cfg.num_rewards, e) += rew;
+  {
+    int k0 = cfg.num_rewards;
+    float c0 = AT(B.commands, 0, e), c2 = AT(B.commands, 2, e);
+    AT(B.command_sums, k0 + 0, e) += d.blv.x;
+    AT(B.command_sums, k0 + 1, e) += d.bav.z;
+    AT(B.command_sums, k0 + 2, e) += (d.blv.x - c0) * (d.blv.x - c0);
+    AT(B.command_sums, k0 + 3, e) += (d.bav.z - c2) * (d.bav.z - c2);
+    AT(B.command_sums, k0 + 4, e) += 1.f;
+  }
+
+  // ---- reset -----------------------------------------------------------------------------------
+  if (reset) reset_env(cfg, B, e, N, counter_post);
+
+  // ---- compute_observations ----------------------------------------------------------------------
+  {
+    float* obs_row = B.obs_buf + (size_t)e * cfg.num_obs;
+    const int R = cfg.num_obs_history + 1;     // ring slots (one spare keeps the previous window intact)
+    float* h0 = B.obs_history ? B.obs_history + (size_t)e * 2 * R * cfg.num_obs + (size_t)history_slot * cfg.num_obs : nullptr;
+    float* h1 = h0 ? h0 + (size_t)R * cfg.num_obs : nullptr;
+    int n = 0;
+    auto emit = [&](float v) {
+      if (cfg.add_noise && cfg.noise_scale_vec[n] != 0.f) v += (2 * rng_uniform(cfg, eg, counter_post, P_NOISE, n) - 1) * cfg.noise_scale_vec[n];
+      v = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations);
+      obs_row[n] = v;
+      if (h0) { h0[n] = v; h1[n] = v; }
+      n++;
+    };
+    if (cfg.observe_only_lin_vel) for (int i = 0; i < 3; i++) emit(AT(B.base_lin_vel, i, e) * cfg.obs_scale_lin_vel);
+    if (cfg.observe_only_ang_vel) for (int i = 0; i < 3; i++) emit(AT(B.base_ang_vel, i, e) * cfg.obs_scale_ang_vel);
+    if (cfg.observe_vel) {
+      for (int i = 0; i < 3; i++) emit((cfg.global_reference ? AT(B.root_states, 7 + i, e) : AT(B.base_lin_vel, i, e)) * cfg.obs_scale_lin_vel);
+      for (int i = 0; i < 3; i++) emit(AT(B.base_ang_vel, i, e) * cfg.obs_scale_ang_vel);
+    }
+    for (int i = 0; i < 3; i++) emit(AT(B.projected_gravity, i, e));
+    if (cfg.observe_command)
+#pragma unroll 1
+      for (int kx = 0; kx < cfg.num_commands; kx++) emit(AT(B.commands, kx, e) * cfg.commands_scale[kx]);
+#pragma unroll 1
+    for (int j = 0; j < 12; j++) emit((AT(B.dof_pos, j, e) - cfg.default_dof_pos[j]) * cfg.obs_scale_dof_pos);
+#pragma unroll 1
+    for (int j = 0; j < 12; j++) emit(AT(B.dof_vel, j, e) * cfg.obs_scale_dof_vel);
+#pragma unroll 1
+    for (int j = 0; j < 12; j++) emit(AT(B.actions, j, e));
+    if (cfg.observe_two_prev_actions)
+#pragma unroll 1
+      for (int j = 0; j < 12; j++) emit(AT(B.last_actions, j, e));
+    if (cfg.observe_timing_parameter) emit(B.gait_indices[e]);
+    if (cfg.observe_clock_inputs) for (int f = 0; f < 4; f++) emit(AT(B.clock_inputs, f, e));
+    if (cfg.observe_yaw) {
+      V3 fw = quat_rotate(AT(B.root_states, 3, e), AT(B.root_states, 4, e), AT(B.root_states, 5, e), AT(B.root_states, 6, e), v3(1.f, 0.f, 0.f));
+      emit(atan2f(fw.y, fw.x));
+    }
+    if (cfg.observe_contact_states) for (int f = 0; f < 4; f++) emit(AT(B.contact_forces, 3 * (4 + 4 * f) + 2, e) > 1.0f ? 1.0f : 0.0f);
+
+    float* pv = B.privileged_obs_buf + (size_t)e * cfg.num_privileged_obs;
+    int np = 0;
+    auto priv = [&](int idx, float val) {
+      float v = (val - cfg.priv_shift[idx]) * cfg.priv_scale[idx];
+      pv[np++] = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations);
+    };
+    auto privraw = [&](float v) { pv[np++] = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations); };
+    if (cfg.priv_enabled[GO1_PRIV_FRICTION]) priv(GO1_PRIV_FRICTION, B.friction_coeffs[e]);
+    if (cfg.priv_enabled[GO1_PRIV_RESTITUTION]) priv(GO1_PRIV_RESTITUTION, B.restitutions[e]);
+    if (cfg.priv_enabled[GO1_PRIV_BASE_MASS]) priv(GO1_PRIV_BASE_MASS, B.payloads[e]);
+    if (cfg.priv_enabled[GO1_PRIV_COM_DISPLACEMENT]) for (int i = 0; i < 3; i++) priv(GO1_PRIV_COM_DISPLACEMENT, AT(B.com_displacements, i, e));
+    if (cfg.priv_enabled[GO1_PRIV_MOTOR_STRENGTH])
+#pragma unroll 1
+      for (int j = 0; j < 12; j++) priv(GO1_PRIV_MOTOR_STRENGTH, AT(B.motor_strengths, j, e));
+    if (cfg.priv_enabled[GO1_PRIV_MOTOR_OFFSET])
+#pragma unroll 1
+      for (int j = 0; j < 12; j++) priv(GO1_PRIV_MOTOR_OFFSET, AT(B.motor_offsets, j, e));
+    if (cfg.priv_enabled[GO1_PRIV_BODY_HEIGHT]) priv(GO1_PRIV_BODY_HEIGHT, AT(B.root_states, 2, e));
+    if (cfg.priv_enabled[GO1_PRIV_BODY_VELOCITY]) for (int i = 0; i < 3; i++) priv(GO1_PRIV_BODY_VELOCITY, AT(B.base_lin_vel, i, e));
+    if (cfg.priv_enabled[GO1_PRIV_GRAVITY]) {
+      privraw(((grav.x - cfg.gravity[0]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
+      privraw(((grav.y - cfg.gravity[1]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
+      privraw(((grav.z - cfg.gravity[2]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
+    }
+    if (cfg.priv_enabled[GO1_PRIV_CLOCK_INPUTS]) for (int f = 0; f < 4; f++) privraw(AT(B.clock_inputs, f, e));
+    if (cfg.priv_enabled[GO1_PRIV_DESIRED_CONTACT]) for (int f = 0; f < 4; f++) privraw(AT(B.desired_contact_states, f, e));
+  }
+  // ---- roll ------------------------------------------------------------------------------------------
+#pragma unroll 1
+  for (int j = 0; j < 12; j++) {
+    AT(B.last_last_actions, j, e) = AT(B.last_actions, j, e);
+    AT(B.last_actions, j, e) = AT(B.actions, j, e);
+    AT(B.last_last_joint_pos_target, j, e) = AT(B.last_joint_pos_target, j, e);
+    AT(B.last_joint_pos_target, j, e) = AT(B.joint_pos_target, j, e);
+    AT(B.last_dof_vel, j, e) = AT(B.dof_vel, j, e);
+  }
+}
+

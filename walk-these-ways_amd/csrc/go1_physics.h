@@ -1,0 +1,623 @@
+// go1_physics.h — torque model + one physics substep, FOUR LANES PER ENVIRONMENT (one lane per leg).
+//
+// Wavefront = 16 environments x 4 legs (lane = 4*env_local + leg).  The four legs of the Go1 are independent
+// sub-trees hanging off the floating base, so every O(n_dof) recursion splits four ways:
+//   * each lane keeps ITS leg's chain in registers: joint state, motion subspaces S_j, ABA factors U_j, 1/D_j, u_j
+//     (static indexing, no LDS / scratch traffic for the chain);
+//   * the base (6x6 articulated inertia, its inverse, twist, pose) is replicated in the four lanes; the only
+//     cross-lane traffic is quad reductions done with DPP quad_perm moves (no LDS, no barriers):
+//     27 floats after ABA pass 2, 6 floats per Delassus column / impulse application, 3 per PGS row;
+//   * what is genuinely shared per environment — the <= 6-contact list, the 18x18 Delassus matrix, impulses —
+//     lives in LDS as [field][env_local] (a quad reads one address: broadcast; 16 envs -> 16 banks).
+// Replaces gym.simulate (reference legged_robot.py:76-80) and _compute_torques (:907-946).  Same contract and
+// solver order as oracle/go1_oracle.c.
+#pragma once
+#include "go1_maps.h"
+
+#define GO1_CONST static __device__ __constant__ const
+#define GO1_REAL float
+#include "go1_model_data.h"
+#include "go1_actuator_data.h"
+
+#define WAVE 64
+#define EPW 16                       // environments per wavefront
+#define MAXC 6                       // solver contacts per env (oracle: GO1_MAX_CONTACTS)
+#define NR (3 * MAXC)
+
+// ---- LDS map (floats), index = field * EPW + env_local ---------------------------------------------
+enum {
+  L_LAM = 0,            // 17 x (n, t1, t2) impulses per reported body
+  L_CX = 51,            // MAXC x 3 contact points (rel. base origin)
+  L_VSTAR = 69,         // MAXC
+  L_BV = 75,            // MAXC x 3  b = J v_free
+  L_LS = 93,            // MAXC x 3  slot impulses
+  L_W = 111,            // NR x NR Delassus matrix
+  L_END = 111 + NR * NR
+};
+#define LDS(f) lds[(f) * EPW + el]
+
+// ---- quad (4-lane) collectives on DPP -----------------------------------------------------------------
+DEV float dpp_xor1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false)); }   // quad_perm [1,0,3,2]
+DEV float dpp_xor2(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, false)); }   // quad_perm [2,3,0,1]
+DEV float quad_sum(float x) { x += dpp_xor1(x); x += dpp_xor2(x); return x; }
+DEV SV quad_sum(SV s) {
+  return sv(v3(quad_sum(s.a.x), quad_sum(s.a.y), quad_sum(s.a.z)), v3(quad_sum(s.l.x), quad_sum(s.l.y), quad_sum(s.l.z)));
+}
+DEV unsigned quad_ballot(bool p, int lane) { return (unsigned)((__ballot(p) >> (lane & ~3)) & 0xFull); }
+
+// ================================================================================================
+// torque model (reference legged_robot.py:907-946): the calling lane handles the 3 joints of its leg
+// ================================================================================================
+DEV float softsign(float x) { return x * __builtin_amdgcn_rcpf(1.f + fabsf(x)); }   // v_rcp_f32: <= 1 ulp
+
+// 6->32->32->1 actuator network for the three joints of one leg: every weight (wave-uniform, scalar loads from
+// constant memory) feeds 3 independent accumulation chains, hiding the dependent-FMA latency of a single chain.
+DEV void actuator_net3(const float in[3][6], float out[3]) {
+  float h0[3][32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    float a0 = GO1_ACT_B0[i], a1 = a0, a2 = a0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const float w = GO1_ACT_W0[i][k];
+      a0 = fmaf(w, in[0][k], a0); a1 = fmaf(w, in[1][k], a1); a2 = fmaf(w, in[2][k], a2);
+    }
+    h0[0][i] = softsign(a0); h0[1][i] = softsign(a1); h0[2][i] = softsign(a2);
+  }
+  float o0 = GO1_ACT_B2, o1 = o0, o2 = o0;
+#pragma unroll 2
+  for (int i = 0; i < 32; i++) {
+    float a0 = GO1_ACT_B1[i], a1 = a0, a2 = a0;
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+      const float w = GO1_ACT_W1[i][k];
+      a0 = fmaf(w, h0[0][k], a0); a1 = fmaf(w, h0[1][k], a1); a2 = fmaf(w, h0[2][k], a2);
+    }
+    const float w2 = GO1_ACT_W2[i];
+    o0 = fmaf(w2, softsign(a0), o0); o1 = fmaf(w2, softsign(a1), o1); o2 = fmaf(w2, softsign(a2), o2);
+  }
+  out[0] = o0; out[1] = o1; out[2] = o2;
+}
+
+struct Leg {             // the calling lane's leg
+  float q[3], qd[3], tau[3];
+};
+
+DEV void compute_torques(const Go1SimConfig& cfg, const Go1SimBuffers& B, Leg& L, int leg, int e, int N, int head) {
+  const int nl = cfg.lag_timesteps + 1;
+  const int h2 = (head + 1) % nl;
+  float in[3][6], tq[3], tgt[3];
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+    const int j = 3 * leg + jj;
+    float a = AT(B.actions, j, e) * cfg.action_scale;
+    if (jj == 0) a *= cfg.hip_scale_reduction;
+    float target;
+    if (cfg.use_lag) {
+      B.lag_buffer[((size_t)head * 12 + j) * N + e] = a;
+      target = B.lag_buffer[((size_t)h2 * 12 + j) * N + e] + cfg.default_dof_pos[j];
+    } else {
+      target = a + cfg.default_dof_pos[j];
+    }
+    AT(B.joint_pos_target, j, e) = target;
+    tgt[jj] = target;
+  }
+  if (cfg.control_type == 1) {
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      float err = L.q[jj] - tgt[jj] + AT(B.motor_offsets, j, e);
+      float elast = AT(B.joint_pos_err_last, j, e), ell = AT(B.joint_pos_err_last_last, j, e);
+      float vl = AT(B.joint_vel_last, j, e), vll = AT(B.joint_vel_last_last, j, e);
+      in[jj][0] = err; in[jj][1] = elast; in[jj][2] = ell; in[jj][3] = L.qd[jj]; in[jj][4] = vl; in[jj][5] = vll;
+      AT(B.joint_pos_err_last_last, j, e) = elast;
+      AT(B.joint_pos_err_last, j, e) = err;
+      AT(B.joint_vel_last_last, j, e) = vl;
+      AT(B.joint_vel_last, j, e) = L.qd[jj];
+    }
+    actuator_net3(in, tq);
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      tq[jj] = cfg.kp * AT(B.Kp_factors, j, e) * (tgt[jj] - L.q[jj] + AT(B.motor_offsets, j, e)) - cfg.kd * AT(B.Kd_factors, j, e) * L.qd[jj];
+    }
+  }
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+    const int j = 3 * leg + jj;
+    float t = tq[jj] * AT(B.motor_strengths, j, e);
+    const float lim = cfg.torque_limits[j];
+    t = fminf(fmaxf(t, -lim), lim);
+    L.tau[jj] = t;
+    AT(B.torques, j, e) = t;
+  }
+}
+
+// ================================================================================================
+// physics substep
+// ================================================================================================
+struct Base {             // replicated in the 4 lanes of the environment
+  V3 pos;                 // world position of the base origin
+  float qx, qy, qz, qw;
+  V3 w, v;                // angular velocity, velocity of the base origin (world axes)
+  float mass0;            // trunk mass + payload
+  V3 com0;                // base com in body axes (= com_displacement, reference legged_robot.py:671)
+  float mu, rest;
+};
+
+DEV V3 model_v3(const float (*tab)[3], int i) { return v3(tab[i][0], tab[i][1], tab[i][2]); }
+
+struct Cand { float phi, x, y, z, un; };     // deepest contact candidate of one reported body
+DEV void cand_init(Cand& c) { c.phi = 1e30f; c.x = c.y = c.z = c.un = 0.f; }
+// x: candidate point relative to the base origin (world axes); plane terrain: height 0, normal +z
+DEV void cand_try(Cand& c, V3 x, float base_z, float radius, SV vb) {
+  float phi = (base_z + x.z) - radius;
+  if (phi < c.phi) {
+    V3 xs = v3(x.x, x.y, x.z - radius);
+    V3 vp = vb.l + cross(vb.a, xs);
+    c.phi = phi; c.x = xs.x; c.y = xs.y; c.z = xs.z; c.un = vp.z;
+  }
+}
+DEV void cand_min_dpp(Cand& c, int lane) {      // quad-wide deepest candidate (ties: lower leg index, as the serial scan)
+#pragma unroll
+  for (int step = 0; step < 2; step++) {
+    Cand o;
+    if (step == 0) { o.phi = dpp_xor1(c.phi); o.x = dpp_xor1(c.x); o.y = dpp_xor1(c.y); o.z = dpp_xor1(c.z); o.un = dpp_xor1(c.un); }
+    else           { o.phi = dpp_xor2(c.phi); o.x = dpp_xor2(c.x); o.y = dpp_xor2(c.y); o.z = dpp_xor2(c.z); o.un = dpp_xor2(c.un); }
+    const int bit = step == 0 ? 1 : 2;
+    const bool other_is_lower = ((lane & bit) != 0);
+    bool take = (o.phi < c.phi) || (o.phi == c.phi && other_is_lower);
+    if (take) c = o;
+  }
+}
+
+// velocity change of the lane's own leg body at `depth` for the current impulse-propagation state
+DEV SV leg_response(const SV S[3], const SV U[3], const float Dinv[3], SV a0, int depth, bool on_path, int path_depth, const float pu[3]) {
+  SV a = a0;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    if (j <= depth) {
+      float uu = (on_path && j <= path_depth) ? pu[j] : 0.f;
+      float qdd = Dinv[j] * (uu - dot(U[j], a));
+      a = a + qdd * S[j];
+    }
+  }
+  return a;
+}
+
+DEV void physics_substep(const Go1SimConfig& cfg, float* lds, int lane, Base& s, Leg& L, V3 grav, bool use_warm, float h) {
+  const int leg = lane & 3, el = lane >> 2;
+  const M3 R0 = quat_to_mat(s.qx, s.qy, s.qz, s.qw);
+  const SV v0 = sv(s.w, s.v);
+  // ---- base body (replicated) ----------------------------------------------------------------------
+  Sym6 IA0;
+  SV pA0;
+  {
+    float Il[6], Iw[6];
+    float scale = s.mass0 / GO1_BODY_MASS[0];          // recomputeInertia=True: mass-proportional (oracle kinematics())
+#pragma unroll
+    for (int i = 0; i < 6; i++) Il[i] = GO1_BODY_INERTIA[0][i] * scale;
+    rotate_inertia(R0, Il, Iw);
+    V3 c = mul(R0, s.com0);
+    IA0 = rigid_inertia(s.mass0, c, Iw);
+    SV hv = sym6_mul(IA0, v0);
+    V3 fg = s.mass0 * grav;
+    pA0 = cross_force(v0, hv) - sv(cross(c, fg), fg);
+  }
+  // trunk box: two corners per lane, quad-wide minimum
+  Cand cbase;
+  cand_init(cbase);
+#pragma unroll
+  for (int mm = 0; mm < 2; mm++) {
+    const int m = 2 * leg + mm;
+    V3 l = v3((m & 1 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[2]);
+    cand_try(cbase, mul(R0, l), s.pos.z, 0.f, v0);
+  }
+  cand_min_dpp(cbase, lane);
+
+  // ---- own leg: kinematics, contact candidates, ABA passes 1+2 ---------------------------------------
+  SV S[3], U[3];
+  float Dinv[3], uu[3];
+  SV cj[3];
+  Cand cand[4];            // hip, thigh, calf, foot of this leg
+  {
+    M3 R[3];
+    V3 p[3];
+    SV v[3], pA[3];
+    Sym6 IA[3];
+    M3 Rpar = R0;
+    V3 ppar = v3(0.f, 0.f, 0.f);
+    SV vpar = v0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int ji = 3 * leg + j, b = ji + 1;
+      p[j] = ppar + mul(Rpar, model_v3(GO1_JOINT_ORIGIN, ji));
+      V3 ax = (j == 0) ? Rpar.c0 : Rpar.c1;
+      float sn, cs;
+      sincosf(L.q[j], &sn, &cs);
+      R[j] = (j == 0) ? rot_x(Rpar, sn, cs) : rot_y(Rpar, sn, cs);
+      S[j] = sv(ax, cross(p[j], ax));
+      SV vj = L.qd[j] * S[j];
+      v[j] = vpar + vj;
+      cj[j] = cross_motion(v[j], vj);
+      float Il[6], Iw[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) Il[i] = GO1_BODY_INERTIA[b][i];
+      rotate_inertia(R[j], Il, Iw);
+      V3 com = p[j] + mul(R[j], model_v3(GO1_BODY_COM, b));
+      float m = GO1_BODY_MASS[b];
+      IA[j] = rigid_inertia(m, com, Iw);
+      SV hv = sym6_mul(IA[j], v[j]);
+      V3 fg = m * grav;
+      pA[j] = cross_force(v[j], hv) - sv(cross(com, fg), fg);
+      Rpar = R[j]; ppar = p[j]; vpar = v[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) cand_init(cand[i]);
+    {
+      V3 hc = model_v3(GO1_HIP_CAPSULE_CENTER, leg);
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        V3 l = v3(hc.x, hc.y + (m ? 1.f : -1.f) * (float)GO1_HIP_CAPSULE_HALF, hc.z);
+        cand_try(cand[0], p[0] + mul(R[0], l), s.pos.z, (float)GO1_HIP_CAPSULE_RADIUS, v[0]);
+      }
+#pragma unroll 1
+      for (int m = 0; m < 8; m++) {
+        V3 l = v3(GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[0],
+                  GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[1],
+                  GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[2]);
+        cand_try(cand[1], p[1] + mul(R[1], l), s.pos.z, 0.f, v[1]);
+      }
+#pragma unroll 1
+      for (int m = 0; m < 8; m++) {
+        V3 l = v3(GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[0],
+                  GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[1],
+                  GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[2]);
+        cand_try(cand[2], p[2] + mul(R[2], l), s.pos.z, 0.f, v[2]);
+      }
+      cand_try(cand[3], p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos.z, (float)GO1_FOOT_RADIUS, v[2]);
+    }
+    // ABA pass 2: calf -> thigh -> hip, then quad-sum into the base
+    SV pa_hip;
+#pragma unroll
+    for (int j = 2; j >= 0; j--) {
+      U[j] = sym6_mul(IA[j], S[j]);
+      float D = dot(S[j], U[j]);
+      Dinv[j] = 1.f / D;
+      uu[j] = L.tau[j] - dot(S[j], pA[j]);
+      sym6_rank1_sub(IA[j], U[j], Dinv[j]);
+      SV pa = pA[j] + sym6_mul(IA[j], cj[j]) + (uu[j] * Dinv[j]) * U[j];
+      if (j > 0) { sym6_add(IA[j - 1], IA[j]); pA[j - 1] = pA[j - 1] + pa; }
+      else pa_hip = pa;
+    }
+#pragma unroll
+    for (int i = 0; i < 21; i++) IA0.m[i] += quad_sum(IA[0].m[i]);
+    pA0 = pA0 + quad_sum(pa_hip);
+  }
+
+  // ---- ABA pass 3 ------------------------------------------------------------------------------------
+  const Sym6 I0inv = sym6_inverse(IA0);
+  SV a0 = -sym6_mul(I0inv, pA0);
+  V3 w_free = s.w + h * a0.a;
+  V3 v_free = s.v + h * (a0.l + cross(s.w, s.v));
+  float qd_free[3];
+  {
+    SV a = a0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      SV ap = a + cj[j];
+      float qdd = Dinv[j] * (uu[j] - dot(U[j], ap));
+      a = ap + qdd * S[j];
+      qd_free[j] = L.qd[j] + h * qdd;
+    }
+  }
+
+  // ---- solver contact list: priority feet, trunk, calves, thighs, hips; at most MAXC -----------------
+  const float cd = cfg.contact_distance;
+  const bool act_h = cand[0].phi < cd, act_t = cand[1].phi < cd, act_c = cand[2].phi < cd, act_f = cand[3].phi < cd;
+  const bool act_b = cbase.phi < cd;
+  const unsigned below = (1u << leg) - 1u;
+  const unsigned mf = quad_ballot(act_f, lane), mc = quad_ballot(act_c, lane), mt = quad_ballot(act_t, lane), mh = quad_ballot(act_h, lane);
+  const int nf = __popc(mf), nb = act_b ? 1 : 0, nc = __popc(mc), nt = __popc(mt), nh = __popc(mh);
+  int slot[4];             // own hip, thigh, calf, foot -> solver slot or -1
+  slot[3] = act_f ? __popc(mf & below) : -1;
+  const int slot_base = act_b ? nf : -1;
+  slot[2] = act_c ? nf + nb + __popc(mc & below) : -1;
+  slot[1] = act_t ? nf + nb + nc + __popc(mt & below) : -1;
+  slot[0] = act_h ? nf + nb + nc + nt + __popc(mh & below) : -1;
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (slot[i] >= MAXC) slot[i] = -1;
+  const int sbase = (slot_base >= 0 && slot_base < MAXC) ? slot_base : -1;
+  int K = nf + nb + nc + nt + nh;
+  K = K > MAXC ? MAXC : K;
+  const float e_c = 0.5f * (s.rest + cfg.terrain_restitution);
+
+  // impulses: listed bodies start from the warm value or zero, all others are dropped
+  float lam0[4][3], lamb[3];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int b = 1 + 4 * leg + i;
+#pragma unroll
+    for (int r = 0; r < 3; r++) lam0[i][r] = (slot[i] >= 0 && use_warm) ? LDS(L_LAM + 3 * b + r) : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++) lamb[r] = (sbase >= 0 && use_warm) ? LDS(L_LAM + r) : 0.f;
+
+  // publish own contacts: point, target normal velocity, b = J v_free, start impulse
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (slot[i] >= 0) {
+      const int k = slot[i];
+      const int depth = i > 2 ? 2 : i;
+      const Cand& c = cand[i];
+      LDS(L_CX + 3 * k) = c.x; LDS(L_CX + 3 * k + 1) = c.y; LDS(L_CX + 3 * k + 2) = c.z;
+      float vs = fminf(-c.phi / h, cfg.max_depenetration_velocity);
+      if (c.un < -cfg.bounce_threshold_velocity && -e_c * c.un > vs) vs = -e_c * c.un;
+      LDS(L_VSTAR + k) = vs;
+      SV vb = sv(w_free, v_free);
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        if (j <= depth) vb = vb + qd_free[j] * S[j];
+      V3 xk = v3(c.x, c.y, c.z);
+      V3 vp = vb.l + cross(vb.a, xk);
+      LDS(L_BV + 3 * k) = vp.z; LDS(L_BV + 3 * k + 1) = vp.x; LDS(L_BV + 3 * k + 2) = vp.y;       // (n, t1, t2) = (z, x, y)
+      LDS(L_LS + 3 * k) = lam0[i][0]; LDS(L_LS + 3 * k + 1) = lam0[i][1]; LDS(L_LS + 3 * k + 2) = lam0[i][2];
+    }
+  }
+  if (sbase >= 0 && leg == 0) {
+    const int k = sbase;
+    LDS(L_CX + 3 * k) = cbase.x; LDS(L_CX + 3 * k + 1) = cbase.y; LDS(L_CX + 3 * k + 2) = cbase.z;
+    float vs = fminf(-cbase.phi / h, cfg.max_depenetration_velocity);
+    if (cbase.un < -cfg.bounce_threshold_velocity && -e_c * cbase.un > vs) vs = -e_c * cbase.un;
+    LDS(L_VSTAR + k) = vs;
+    V3 xk = v3(cbase.x, cbase.y, cbase.z);
+    V3 vp = v_free + cross(w_free, xk);
+    LDS(L_BV + 3 * k) = vp.z; LDS(L_BV + 3 * k + 1) = vp.x; LDS(L_BV + 3 * k + 2) = vp.y;
+    LDS(L_LS + 3 * k) = lamb[0]; LDS(L_LS + 3 * k + 1) = lamb[1]; LDS(L_LS + 3 * k + 2) = lamb[2];
+  }
+  // clear the per-body impulses (re-filled for the listed bodies after the solve)
+  if (leg == 0) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) LDS(L_LAM + r) = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) LDS(L_LAM + 3 * (1 + 4 * leg) + i) = 0.f;
+
+  __syncthreads();      // one-wave workgroup: orders this wave's LDS traffic between phases
+  // ---- Delassus matrix by impulse propagation through the ABA factors ---------------------------------
+#pragma unroll 1
+  for (int k = 0; k < K; k++) {
+    const V3 x = v3(LDS(L_CX + 3 * k), LDS(L_CX + 3 * k + 1), LDS(L_CX + 3 * k + 2));
+    // is slot k one of mine?  (at most one of the four can match)
+    int mydepth = -1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (slot[i] == k) mydepth = i > 2 ? 2 : i;
+    const bool mine = mydepth >= 0;
+    const bool base_col = (sbase == k);
+#pragma unroll 1
+    for (int r = 0; r < 3; r++) {
+      V3 d = r == 0 ? v3(0.f, 0.f, 1.f) : r == 1 ? v3(1.f, 0.f, 0.f) : v3(0.f, 1.f, 0.f);
+      SV f = sv(cross(x, d), d);
+      float pu[3] = {0.f, 0.f, 0.f};
+      SV contrib = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
+      if (mine) {
+        SV pA = -f;
+#pragma unroll
+        for (int j = 2; j >= 0; j--) {
+          if (j <= mydepth) {
+            float u = -dot(S[j], pA);
+            pu[j] = u;
+            pA = pA + (u * Dinv[j]) * U[j];
+          }
+        }
+        contrib = pA;
+      } else if (base_col && leg == 0) {
+        contrib = -f;
+      }
+      SV p0 = quad_sum(contrib);
+      SV a0c = -sym6_mul(I0inv, p0);
+      // rows of W for my own contacts (and lane 0: the trunk contact)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (slot[i] >= 0) {
+          const int k2 = slot[i];
+          const int depth = i > 2 ? 2 : i;
+          SV ab = leg_response(S, U, Dinv, a0c, depth, mine, mydepth, pu);
+          V3 x2 = v3(cand[i].x, cand[i].y, cand[i].z);
+          V3 vp = ab.l + cross(ab.a, x2);
+          LDS(L_W + (3 * k2 + 0) * NR + 3 * k + r) = vp.z;
+          LDS(L_W + (3 * k2 + 1) * NR + 3 * k + r) = vp.x;
+          LDS(L_W + (3 * k2 + 2) * NR + 3 * k + r) = vp.y;
+        }
+      }
+      if (sbase >= 0 && leg == 0) {
+        V3 x2 = v3(cbase.x, cbase.y, cbase.z);
+        V3 vp = a0c.l + cross(a0c.a, x2);
+        LDS(L_W + (3 * sbase + 0) * NR + 3 * k + r) = vp.z;
+        LDS(L_W + (3 * sbase + 1) * NR + 3 * k + r) = vp.x;
+        LDS(L_W + (3 * sbase + 2) * NR + 3 * k + r) = vp.y;
+      }
+    }
+  }
+
+  __syncthreads();
+  // ---- projected Gauss-Seidel on the impulses: row dot-products split over the quad -------------------
+  const float mu = 0.5f * (s.mu + cfg.terrain_friction);       // PhysX default combine mode: average
+#pragma unroll 1
+  for (int it = 0; it < cfg.solver_iterations; it++) {
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+      const int r0 = 3 * k;
+      float pn = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll 1
+      for (int c = leg; c < 3 * K; c += 4) {
+        float l = LDS(L_LS + c);
+        pn = fmaf(LDS(L_W + r0 * NR + c), l, pn);
+        p1 = fmaf(LDS(L_W + (r0 + 1) * NR + c), l, p1);
+        p2 = fmaf(LDS(L_W + (r0 + 2) * NR + c), l, p2);
+      }
+      float un = LDS(L_BV + r0) + quad_sum(pn);
+      float u1 = LDS(L_BV + r0 + 1) + quad_sum(p1);
+      float u2 = LDS(L_BV + r0 + 2) + quad_sum(p2);
+      const float ln_old = LDS(L_LS + r0);
+      const float ln = fmaxf(0.f, ln_old - (un - LDS(L_VSTAR + k)) / LDS(L_W + r0 * NR + r0));
+      const float dln = ln - ln_old;
+      u1 = fmaf(LDS(L_W + (r0 + 1) * NR + r0), dln, u1);     // the tangential rows see the updated normal impulse
+      u2 = fmaf(LDS(L_W + (r0 + 2) * NR + r0), dln, u2);
+      float l1 = LDS(L_LS + r0 + 1) - u1 / LDS(L_W + (r0 + 1) * NR + r0 + 1);
+      float l2 = LDS(L_LS + r0 + 2) - u2 / LDS(L_W + (r0 + 2) * NR + r0 + 2);
+      float lim = mu * ln, nrm = sqrtf(l1 * l1 + l2 * l2);
+      if (nrm > lim) { float sc = (nrm > 0.f) ? lim / nrm : 0.f; l1 *= sc; l2 *= sc; }
+      if (leg == 0) { LDS(L_LS + r0) = ln; LDS(L_LS + r0 + 1) = l1; LDS(L_LS + r0 + 2) = l2; }
+    }
+  }
+
+  __syncthreads();
+  // ---- apply all contact impulses with one propagation ------------------------------------------------
+  SV pA[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) pA[j] = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (slot[i] >= 0) {
+      const int k = slot[i], b = 1 + 4 * leg + i;
+      const float ln = LDS(L_LS + 3 * k), l1 = LDS(L_LS + 3 * k + 1), l2 = LDS(L_LS + 3 * k + 2);
+      LDS(L_LAM + 3 * b) = ln; LDS(L_LAM + 3 * b + 1) = l1; LDS(L_LAM + 3 * b + 2) = l2;
+      V3 x = v3(cand[i].x, cand[i].y, cand[i].z);
+      V3 f = v3(l1, l2, ln);
+      SV ff = sv(cross(x, f), f);
+      const int depth = i > 2 ? 2 : i;
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        if (j == depth) pA[j] = pA[j] - ff;
+    }
+  }
+  SV contrib = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
+  float du[3];
+#pragma unroll
+  for (int j = 2; j >= 0; j--) {
+    float u = -dot(S[j], pA[j]);
+    du[j] = u;
+    SV pa = pA[j] + (u * Dinv[j]) * U[j];
+    if (j > 0) pA[j - 1] = pA[j - 1] + pa; else contrib = pa;
+  }
+  if (sbase >= 0 && leg == 0) {
+    const float ln = LDS(L_LS + 3 * sbase), l1 = LDS(L_LS + 3 * sbase + 1), l2 = LDS(L_LS + 3 * sbase + 2);
+    LDS(L_LAM) = ln; LDS(L_LAM + 1) = l1; LDS(L_LAM + 2) = l2;
+    V3 x = v3(cbase.x, cbase.y, cbase.z);
+    V3 f = v3(l1, l2, ln);
+    contrib = contrib - sv(cross(x, f), f);
+  }
+  SV dv0 = -sym6_mul(I0inv, quad_sum(contrib));
+  s.w = w_free + dv0.a;
+  s.v = v_free + dv0.l;
+  {
+    SV a = dv0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int ji = 3 * leg + j;
+      float dqd = Dinv[j] * (du[j] - dot(U[j], a));
+      a = a + dqd * S[j];
+      float qd = qd_free[j] + dqd;
+      // joint velocity limit, semi-implicit Euler, hard position limits
+      float vl = GO1_JOINT_VEL_LIMIT[ji];
+      qd = fminf(fmaxf(qd, -vl), vl);
+      float q = L.q[j] + h * qd;
+      float lo = GO1_JOINT_LOWER[ji], hi = GO1_JOINT_UPPER[ji];
+      if (q < lo) { q = lo; qd = fmaxf(qd, 0.f); }
+      if (q > hi) { q = hi; qd = fminf(qd, 0.f); }
+      L.q[j] = q;
+      L.qd[j] = qd;
+    }
+  }
+  // base pose
+  s.pos = s.pos + h * s.v;
+  float wn = norm(s.w);
+  if (wn > 1e-12f) {
+    float half = 0.5f * wn * h, sn, cs;
+    sincosf(half, &sn, &cs);
+    sn /= wn;
+    float dx = s.w.x * sn, dy = s.w.y * sn, dz = s.w.z * sn, dw = cs;
+    float nx = dw * s.qx + dx * s.qw + dy * s.qz - dz * s.qy;
+    float ny = dw * s.qy - dx * s.qz + dy * s.qw + dz * s.qx;
+    float nz = dw * s.qz + dx * s.qy - dy * s.qx + dz * s.qw;
+    float nw = dw * s.qw - dx * s.qx - dy * s.qy - dz * s.qz;
+    float inv = rsqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
+    s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv; s.qw = nw * inv;
+  }
+}
+
+// own foot position / velocity at the current state (reference legged_robot.py:112-115)
+DEV void foot_state(const Base& s, const Leg& L, int leg, const Go1SimBuffers& B, int e, int N) {
+  M3 Rpar = quat_to_mat(s.qx, s.qy, s.qz, s.qw);
+  V3 ppar = v3(0.f, 0.f, 0.f);
+  SV vb = sv(s.w, s.v);
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int ji = 3 * leg + j;
+    V3 p = ppar + mul(Rpar, model_v3(GO1_JOINT_ORIGIN, ji));
+    V3 ax = (j == 0) ? Rpar.c0 : Rpar.c1;
+    float sn, cs;
+    sincosf(L.q[j], &sn, &cs);
+    Rpar = (j == 0) ? rot_x(Rpar, sn, cs) : rot_y(Rpar, sn, cs);
+    vb = vb + L.qd[j] * sv(ax, cross(p, ax));
+    ppar = p;
+  }
+  V3 x = ppar + mul(Rpar, model_v3(GO1_FOOT_OFFSET, leg));
+  V3 vp = vb.l + cross(vb.a, x);
+  AT(B.foot_positions, 3 * leg + 0, e) = s.pos.x + x.x;
+  AT(B.foot_positions, 3 * leg + 1, e) = s.pos.y + x.y;
+  AT(B.foot_positions, 3 * leg + 2, e) = s.pos.z + x.z;
+  AT(B.foot_velocities, 3 * leg + 0, e) = vp.x;
+  AT(B.foot_velocities, 3 * leg + 1, e) = vp.y;
+  AT(B.foot_velocities, 3 * leg + 2, e) = vp.z;
+}
+
+// ---- state <-> HBM ----------------------------------------------------------------------------------------
+DEV void load_state(const Go1SimBuffers& B, int leg, int e, int N, Base& s, Leg& L) {
+  s.pos = v3(AT(B.root_states, 0, e), AT(B.root_states, 1, e), AT(B.root_states, 2, e));
+  s.qx = AT(B.root_states, 3, e); s.qy = AT(B.root_states, 4, e); s.qz = AT(B.root_states, 5, e); s.qw = AT(B.root_states, 6, e);
+  s.v = v3(AT(B.root_states, 7, e), AT(B.root_states, 8, e), AT(B.root_states, 9, e));
+  s.w = v3(AT(B.root_states, 10, e), AT(B.root_states, 11, e), AT(B.root_states, 12, e));
+#pragma unroll
+  for (int j = 0; j < 3; j++) { L.q[j] = AT(B.dof_pos, 3 * leg + j, e); L.qd[j] = AT(B.dof_vel, 3 * leg + j, e); L.tau[j] = 0.f; }
+  s.mass0 = GO1_BODY_MASS[0] + B.payloads[e];
+  s.com0 = v3(AT(B.com_displacements, 0, e), AT(B.com_displacements, 1, e), AT(B.com_displacements, 2, e));
+  s.mu = B.friction_coeffs[e];
+  s.rest = B.restitutions[e];
+}
+DEV void store_state(const Go1SimBuffers& B, int leg, int e, int N, const Base& s, const Leg& L) {
+  if (leg == 0) {
+    AT(B.root_states, 0, e) = s.pos.x; AT(B.root_states, 1, e) = s.pos.y; AT(B.root_states, 2, e) = s.pos.z;
+    AT(B.root_states, 3, e) = s.qx; AT(B.root_states, 4, e) = s.qy; AT(B.root_states, 5, e) = s.qz; AT(B.root_states, 6, e) = s.qw;
+    AT(B.root_states, 7, e) = s.v.x; AT(B.root_states, 8, e) = s.v.y; AT(B.root_states, 9, e) = s.v.z;
+    AT(B.root_states, 10, e) = s.w.x; AT(B.root_states, 11, e) = s.w.y; AT(B.root_states, 12, e) = s.w.z;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) { AT(B.dof_pos, 3 * leg + j, e) = L.q[j]; AT(B.dof_vel, 3 * leg + j, e) = L.qd[j]; }
+}
+// per-body impulses <-> contact force buffer; each lane moves its leg's 4 bodies, lane 0 also the trunk
+DEV void load_lambda(const Go1SimConfig& cfg, const Go1SimBuffers& B, float* lds, int lane, int e, int N, bool zero) {
+  const int leg = lane & 3, el = lane >> 2;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    if (i == 4 && leg != 0) continue;
+    const int b = (i == 4) ? 0 : 1 + 4 * leg + i;       // world force -> (n, t1, t2) = (z, x, y) impulses
+    LDS(L_LAM + 3 * b) = zero ? 0.f : AT(B.contact_forces, 3 * b + 2, e) * cfg.sim_dt;
+    LDS(L_LAM + 3 * b + 1) = zero ? 0.f : AT(B.contact_forces, 3 * b, e) * cfg.sim_dt;
+    LDS(L_LAM + 3 * b + 2) = zero ? 0.f : AT(B.contact_forces, 3 * b + 1, e) * cfg.sim_dt;
+  }
+}
+DEV void store_forces(const Go1SimConfig& cfg, const Go1SimBuffers& B, const float* lds, int lane, int e, int N) {
+  const int leg = lane & 3, el = lane >> 2;
+  const float inv = 1.f / cfg.sim_dt;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    if (i == 4 && leg != 0) continue;
+    const int b = (i == 4) ? 0 : 1 + 4 * leg + i;
+    AT(B.contact_forces, 3 * b, e) = LDS(L_LAM + 3 * b + 1) * inv;
+    AT(B.contact_forces, 3 * b + 1, e) = LDS(L_LAM + 3 * b + 2) * inv;
+    AT(B.contact_forces, 3 * b + 2, e) = LDS(L_LAM + 3 * b) * inv;
+  }
+}
