@@ -84,24 +84,45 @@ class ActorCritic(nn.Module):
         b = F.pad(last.bias, (0, min_cols - n))
         return F.linear(h, W, b)[:, :n]
 
-    def fused_forward(self, observation_history, privileged_observations=None, want_value=True):
+    def fused_forward(self, observation_history, privileged_observations=None, want_value=True, augmented=False):
         """(action mean, value, latent) with ONE GEMM over the 2100-wide history for the first layers of the
         adaptation module, the actor and the critic (they share the input: 256 + 512 + 512 output columns),
         instead of three GEMMs plus two (M, 2102) concatenations.  Mathematically identical to
         act()/evaluate(): W [h ; z] = W_h h + W_z z.  Runs in the dtype of the module's weights (the bf16 compute
-        replica or the fp32 master); `observation_history` may be the storage's zero-padded copy (row length a
-        multiple of 8 elements so that every GEMM operand is 16-byte aligned)."""
+        replica or the fp32 master).
+
+        `observation_history` may be the storage's padded copy (row length a multiple of 8 elements so that every
+        GEMM operand is 16-byte aligned).  With `augmented=True` the padding carries [1, privileged_obs...] in
+        columns K, K+1.. (written by the storage), so the first-layer biases and the critic's privileged-input
+        weights ride inside the same GEMM: x' = [h, 1, p, 0], W' = [W_h, b, W_p, 0]."""
         K = self.num_obs_history
         la, lc, ld = self.actor_body[0], self.critic_body[0], self.adaptation_module[0]
         wdt, odt = ld.weight.dtype, self.std.dtype
         x = observation_history if observation_history.dtype == wdt else observation_history.to(wdt)
+        pad = x.shape[-1] - K
+        nd, na = ld.weight.shape[0], la.weight.shape[0]
+        npv = self.num_privileged_obs
+        if augmented:
+            assert pad >= 1 + npv
+            zc = lambda n, c: ld.weight.new_zeros(n, c)
+            rows = [torch.cat((ld.weight, ld.bias.unsqueeze(1), zc(nd, pad - 1)), dim=1),
+                    torch.cat((la.weight[:, :K], la.bias.unsqueeze(1), zc(na, pad - 1)), dim=1)]
+            if want_value:
+                nc = lc.weight.shape[0]
+                rows.append(torch.cat((lc.weight[:, :K], lc.bias.unsqueeze(1), lc.weight[:, K:], zc(nc, pad - 1 - npv)), dim=1))
+            y = F.linear(x, torch.cat(rows, dim=0))
+            latent = self._head(self.adaptation_module, y[:, :nd])
+            a1 = y[:, nd:nd + na]
+            for i in range(npv):
+                a1 = torch.addcmul(a1, latent[:, i:i + 1], la.weight[:, K + i])
+            mean = self._head(self.actor_body, a1).to(odt)
+            value = self._head(self.critic_body, y[:, nd + na:]).to(odt) if want_value else None
+            return mean, value, latent.to(odt)
         parts = [ld.weight, la.weight[:, :K]] + ([lc.weight[:, :K]] if want_value else [])
         Wh = torch.cat(parts, dim=0)
-        pad = x.shape[-1] - K
         if pad:
             Wh = F.pad(Wh, (0, pad))
         y = F.linear(x, Wh)
-        nd, na = ld.weight.shape[0], la.weight.shape[0]
         latent = self._head(self.adaptation_module, y[:, :nd] + ld.bias)
         mean = self._head(self.actor_body, self._side(y[:, nd:nd + na], latent, la.weight[:, K:], la.bias)).to(odt)
         value = None
@@ -110,12 +131,15 @@ class ActorCritic(nn.Module):
             value = self._head(self.critic_body, self._side(y[:, nd + na:], p, lc.weight[:, K:], lc.bias)).to(odt)
         return mean, value, latent.to(odt)
 
-    def latent_padded(self, observation_history):
-        """adaptation module on a (possibly zero-padded) history batch."""
+    def latent_padded(self, observation_history, augmented=False):
+        """adaptation module on a (possibly padded / augmented) history batch."""
         K = self.num_obs_history
         ld = self.adaptation_module[0]
         x = observation_history if observation_history.dtype == ld.weight.dtype else observation_history.to(ld.weight.dtype)
         pad = x.shape[-1] - K
+        if augmented:
+            W = torch.cat((ld.weight, ld.bias.unsqueeze(1), ld.weight.new_zeros(ld.weight.shape[0], pad - 1)), dim=1)
+            return self._head(self.adaptation_module, F.linear(x, W)).to(self.std.dtype)
         W = F.pad(ld.weight, (0, pad)) if pad else ld.weight
         return self._head(self.adaptation_module, F.linear(x, W, ld.bias)).to(self.std.dtype)
 

@@ -174,8 +174,9 @@ class PPO:
         self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, privileged_obs_shape,
                                       obs_history_shape, action_shape, self.device,
                                       history_dtype=torch.bfloat16 if self.bf16 else torch.float32,
-                                      history_pad_to=8 if self.bf16 else 1)
-        self._last_hist = torch.zeros_like(self.storage.observation_histories[0])
+                                      history_pad_to=8 if self.bf16 else 1, augment=self.bf16)
+        self.augmented = self.storage.augment
+        self._last_hist = self.storage.observation_histories[0].clone()
 
     def test_mode(self):
         self.actor_critic.test()
@@ -189,10 +190,10 @@ class PPO:
         # the env's obs_history is a live view of its ring buffer: take the storage copy now, before env.step
         # (it is also the dtype / padding the policy GEMMs want)
         slot = self.storage.observation_histories[self.storage.step]
-        slot[:, :obs_history.shape[-1]].copy_(obs_history)
+        self.storage.write_history(slot, obs_history, privileged_obs)
         t.observation_histories = slot
         ac = self.compute_ac
-        mean, value, _ = ac.fused_forward(slot, privileged_obs)
+        mean, value, _ = ac.fused_forward(slot, privileged_obs, augmented=self.augmented)
         mean, std = mean.detach(), ac.std.detach()
         t.actions = mean + std * torch.randn_like(mean)
         t.values = value.detach()
@@ -216,9 +217,9 @@ class PPO:
         self.actor_critic.reset(dones)
 
     def compute_returns(self, last_critic_obs, last_critic_privileged_obs):
-        self._last_hist[:, :last_critic_obs.shape[-1]].copy_(last_critic_obs)
+        self.storage.write_history(self._last_hist, last_critic_obs, last_critic_privileged_obs)
         with torch.no_grad():
-            _, last_values, _ = self.compute_ac.fused_forward(self._last_hist, last_critic_privileged_obs)
+            _, last_values, _ = self.compute_ac.fused_forward(self._last_hist, last_critic_privileged_obs, augmented=self.augmented)
         self.storage.compute_returns(last_values.detach().clone(), PPO_Args.gamma, PPO_Args.lam)
 
     # ---- update ------------------------------------------------------------------------------------------
@@ -255,7 +256,7 @@ class PPO:
              advantages_batch, returns_batch, old_actions_log_prob_batch, old_mu_batch, old_sigma_batch, masks_batch,
              env_bins_batch) in generator:
             self._zero_grads()
-            mu_batch, value_batch, _ = ac.fused_forward(obs_history_batch, privileged_obs_batch)
+            mu_batch, value_batch, _ = ac.fused_forward(obs_history_batch, privileged_obs_batch, augmented=self.augmented)
             std = ac.std
             actions_log_prob_batch = gaussian_log_prob(actions_batch, mu_batch, std)
             entropy = gaussian_entropy(std)
@@ -287,7 +288,7 @@ class PPO:
             num_train = int(privileged_obs_batch.shape[0] // 5 * 4)
             for _ in range(A.num_adaptation_module_substeps):
                 self._zero_grads(adapt_only=True)
-                adaptation_pred = ac.latent_padded(obs_history_batch)
+                adaptation_pred = ac.latent_padded(obs_history_batch, augmented=self.augmented)
                 adaptation_target = privileged_obs_batch.detach()
                 sel = 0 if A.selective_adaptation_module_loss else slice(None)
                 adaptation_loss = F.mse_loss(adaptation_pred[:num_train, sel], adaptation_target[:num_train, sel])

@@ -18,10 +18,11 @@ class RolloutStorage:
             self.__init__()
 
     def __init__(self, num_envs, num_transitions_per_env, obs_shape, privileged_obs_shape, obs_history_shape,
-                 actions_shape, device='cpu', history_dtype=torch.float32, history_pad_to=1):
+                 actions_shape, device='cpu', history_dtype=torch.float32, history_pad_to=1, augment=False):
         """`history_dtype` / `history_pad_to`: the (T, N, H*num_obs) history block is the dominant storage
         (826 MB in fp32 at N=4096); under the bf16 policy it is kept in bf16 with rows zero-padded to a multiple
-        of `history_pad_to` elements, which is exactly what the policy GEMMs consume."""
+        of `history_pad_to` elements, which is exactly what the policy GEMMs consume.  `augment`: the padding
+        columns carry [1, privileged_obs] so that biases and the critic's privileged inputs ride in the GEMM."""
         self.device = device
         self.obs_shape, self.privileged_obs_shape = obs_shape, privileged_obs_shape
         self.obs_history_shape, self.actions_shape = obs_history_shape, actions_shape
@@ -30,8 +31,12 @@ class RolloutStorage:
         self.observations = z(*obs_shape)
         self.privileged_observations = z(*privileged_obs_shape)
         self.history_width = int(obs_history_shape[0])
-        padded = -(-self.history_width // history_pad_to) * history_pad_to
+        self.augment = bool(augment)
+        extra = (1 + int(privileged_obs_shape[0])) if augment else 0
+        padded = -(-(self.history_width + extra) // history_pad_to) * history_pad_to
         self.observation_histories = z(padded, dtype=history_dtype)
+        if augment:
+            self.observation_histories[..., self.history_width] = 1.0
         self.rewards = z(1)
         self.actions = z(*actions_shape)
         self.dones = z(1).byte()
@@ -44,6 +49,13 @@ class RolloutStorage:
         self.env_bins = z(1)
         self.num_transitions_per_env, self.num_envs = T, N
         self.step = 0
+
+    def write_history(self, slot, obs_history, privileged_obs):
+        """copy (and cast/pad/augment) a history batch into `slot` (a (N, padded) row block of this layout)."""
+        K = self.history_width
+        slot[:, :K].copy_(obs_history)
+        if self.augment:
+            slot[:, K + 1:K + 1 + privileged_obs.shape[-1]].copy_(privileged_obs)
 
     def add_transitions(self, transition):
         if self.step >= self.num_transitions_per_env:
