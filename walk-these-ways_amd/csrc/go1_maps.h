@@ -156,11 +156,19 @@ DEV void reset_env(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N
 }
 
 // ================================================================================================
-// rewards (reference corl_rewards.py:15-202), one raw term per id
+// rewards (reference corl_rewards.py:15-202) — four lanes per environment
+// Each lane evaluates the part of a term that belongs to ITS leg (3 joints, 1 foot, its thigh/calf/hip bodies);
+// base-only terms are evaluated on the leg-0 lane.  The caller quad-sums the partials, so every lane ends up with
+// the reference's per-environment value.  One case per reference `_reward_*`.
 // ================================================================================================
 struct Derived {
   V3 base_pos, blv, bav, pg, gvec;
   float qx, qy, qz, qw;
+};
+struct FootCtx {            // the calling lane's foot
+  V3 pos, vel, force;
+  float fnorm;
+  float foot_index, desired_contact;
 };
 
 DEV float cf_norm(const Go1SimBuffers& B, int b, int e, int N) {
@@ -169,39 +177,46 @@ DEV float cf_norm(const Go1SimBuffers& B, int b, int e, int N) {
 }
 DEV float normal_cdf(float x, float sigma) { return 0.5f * (1.f + erff(x / (sigma * 1.41421356237309504880f))); }
 
-DEV float reward_term(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int id, const Derived& d) {
+DEV float reward_partial(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int id, const Derived& d,
+                         const FootCtx& F, int leg) {
+  const bool is0 = leg == 0;
+  const int j0 = 3 * leg;
   float r = 0.f;
   switch (id) {
     case GO1_REW_TRACKING_LIN_VEL: {
       float ex = AT(B.commands, 0, e) - d.blv.x, ey = AT(B.commands, 1, e) - d.blv.y;
-      return expf(-(ex * ex + ey * ey) / cfg.tracking_sigma);
+      return is0 ? expf(-(ex * ex + ey * ey) / cfg.tracking_sigma) : 0.f;
     }
     case GO1_REW_TRACKING_ANG_VEL: {
       float ez = AT(B.commands, 2, e) - d.bav.z;
-      return expf(-(ez * ez) / cfg.tracking_sigma_yaw);
+      return is0 ? expf(-(ez * ez) / cfg.tracking_sigma_yaw) : 0.f;
     }
-    case GO1_REW_LIN_VEL_Z: return d.blv.z * d.blv.z;
-    case GO1_REW_ANG_VEL_XY: return d.bav.x * d.bav.x + d.bav.y * d.bav.y;
-    case GO1_REW_ORIENTATION: return d.pg.x * d.pg.x + d.pg.y * d.pg.y;
+    case GO1_REW_LIN_VEL_Z: return is0 ? d.blv.z * d.blv.z : 0.f;
+    case GO1_REW_ANG_VEL_XY: return is0 ? d.bav.x * d.bav.x + d.bav.y * d.bav.y : 0.f;
+    case GO1_REW_ORIENTATION: return is0 ? d.pg.x * d.pg.x + d.pg.y * d.pg.y : 0.f;
     case GO1_REW_TORQUES:
-#pragma unroll 1
-      for (int j = 0; j < 12; j++) { float t = AT(B.torques, j, e); r = fmaf(t, t, r); }
+#pragma unroll
+      for (int j = j0; j < j0 + 3; j++) { float t = AT(B.torques, j, e); r = fmaf(t, t, r); }
       return r;
     case GO1_REW_DOF_ACC:
-#pragma unroll 1
-      for (int j = 0; j < 12; j++) { float a = (AT(B.last_dof_vel, j, e) - AT(B.dof_vel, j, e)) / cfg.dt; r = fmaf(a, a, r); }
+#pragma unroll
+      for (int j = j0; j < j0 + 3; j++) { float a = (AT(B.last_dof_vel, j, e) - AT(B.dof_vel, j, e)) / cfg.dt; r = fmaf(a, a, r); }
       return r;
     case GO1_REW_ACTION_RATE:
-#pragma unroll 1
-      for (int j = 0; j < 12; j++) { float a = AT(B.last_actions, j, e) - AT(B.actions, j, e); r = fmaf(a, a, r); }
+#pragma unroll
+      for (int j = j0; j < j0 + 3; j++) { float a = AT(B.last_actions, j, e) - AT(B.actions, j, e); r = fmaf(a, a, r); }
       return r;
     case GO1_REW_COLLISION:
-#pragma unroll 1
-      for (int b = 0; b < 17; b++) if (cfg.penalised_body_mask & (1u << b)) r += (cf_norm(B, b, e, N) > 0.1f) ? 1.f : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int b = 1 + 4 * leg + i;
+        if (cfg.penalised_body_mask & (1u << b)) r += (cf_norm(B, b, e, N) > 0.1f) ? 1.f : 0.f;
+      }
+      if (is0 && (cfg.penalised_body_mask & 1u)) r += (cf_norm(B, 0, e, N) > 0.1f) ? 1.f : 0.f;
       return r;
     case GO1_REW_DOF_POS_LIMITS:
-#pragma unroll 1
-      for (int j = 0; j < 12; j++) {
+#pragma unroll
+      for (int j = j0; j < j0 + 3; j++) {
         float q = AT(B.dof_pos, j, e);
         float lo = q - cfg.dof_pos_soft_lower[j], hi = q - cfg.dof_pos_soft_upper[j];
         r += -fminf(lo, 0.f) + fmaxf(hi, 0.f);
@@ -209,93 +224,62 @@ DEV float reward_term(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, in
       return r;
     case GO1_REW_JUMP: {
       float t = d.base_pos.z - (AT(B.commands, 3, e) + cfg.base_height_target);
-      return -t * t;
+      return is0 ? -t * t : 0.f;
     }
     case GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE:
-#pragma unroll 1
-      for (int f = 0; f < 4; f++) {
-        float fn = cf_norm(B, 4 + 4 * f, e, N);
-        r += -(1.f - AT(B.desired_contact_states, f, e)) * (1.f - expf(-fn * fn / cfg.gait_force_sigma));
-      }
-      return r / 4;
+      return -(1.f - F.desired_contact) * (1.f - expf(-F.fnorm * F.fnorm / cfg.gait_force_sigma)) * 0.25f;
     case GO1_REW_TRACKING_CONTACTS_SHAPED_VEL:
-#pragma unroll 1
-      for (int f = 0; f < 4; f++) {
-        float vx = AT(B.foot_velocities, 3 * f, e), vy = AT(B.foot_velocities, 3 * f + 1, e), vz = AT(B.foot_velocities, 3 * f + 2, e);
-        float vv = vx * vx + vy * vy + vz * vz;
-        r += -(AT(B.desired_contact_states, f, e) * (1.f - expf(-vv / cfg.gait_vel_sigma)));
-      }
-      return r / 4;
+      return -(F.desired_contact * (1.f - expf(-dot(F.vel, F.vel) / cfg.gait_vel_sigma))) * 0.25f;
     case GO1_REW_DOF_POS:
-#pragma unroll 1
-      for (int j = 0; j < 12; j++) { float a = AT(B.dof_pos, j, e) - cfg.default_dof_pos[j]; r = fmaf(a, a, r); }
+#pragma unroll
+      for (int j = j0; j < j0 + 3; j++) { float a = AT(B.dof_pos, j, e) - cfg.default_dof_pos[j]; r = fmaf(a, a, r); }
       return r;
     case GO1_REW_DOF_VEL:
-#pragma unroll 1
-      for (int j = 0; j < 12; j++) { float a = AT(B.dof_vel, j, e); r = fmaf(a, a, r); }
+#pragma unroll
+      for (int j = j0; j < j0 + 3; j++) { float a = AT(B.dof_vel, j, e); r = fmaf(a, a, r); }
       return r;
     case GO1_REW_ACTION_SMOOTHNESS_1:
-#pragma unroll 1
-      for (int j = 0; j < 12; j++) {
+#pragma unroll
+      for (int j = j0; j < j0 + 3; j++) {
         float a = AT(B.joint_pos_target, j, e) - AT(B.last_joint_pos_target, j, e);
         r += a * a * (AT(B.last_actions, j, e) != 0.f ? 1.f : 0.f);
       }
       return r;
     case GO1_REW_ACTION_SMOOTHNESS_2:
-#pragma unroll 1
-      for (int j = 0; j < 12; j++) {
+#pragma unroll
+      for (int j = j0; j < j0 + 3; j++) {
         float a = AT(B.joint_pos_target, j, e) - 2.f * AT(B.last_joint_pos_target, j, e) + AT(B.last_last_joint_pos_target, j, e);
         r += a * a * (AT(B.last_actions, j, e) != 0.f ? 1.f : 0.f) * (AT(B.last_last_actions, j, e) != 0.f ? 1.f : 0.f);
       }
       return r;
-    case GO1_REW_FEET_SLIP:
-#pragma unroll 1
-      for (int f = 0; f < 4; f++) {
-        bool contact = AT(B.contact_forces, 3 * (4 + 4 * f) + 2, e) > 1.0f;
-        bool filt = contact || AT(B.last_contacts, f, e);
-        AT(B.last_contacts, f, e) = (uint8_t)contact;
-        float vx = AT(B.foot_velocities, 3 * f, e), vy = AT(B.foot_velocities, 3 * f + 1, e);
-        r += filt ? (vx * vx + vy * vy) : 0.f;
-      }
-      return r;
-    case GO1_REW_FEET_CONTACT_VEL:
-#pragma unroll 1
-      for (int f = 0; f < 4; f++) {
-        float vx = AT(B.foot_velocities, 3 * f, e), vy = AT(B.foot_velocities, 3 * f + 1, e), vz = AT(B.foot_velocities, 3 * f + 2, e);
-        r += (AT(B.foot_positions, 3 * f + 2, e) < 0.03f) ? (vx * vx + vy * vy + vz * vz) : 0.f;
-      }
-      return r;
-    case GO1_REW_FEET_CONTACT_FORCES:
-#pragma unroll 1
-      for (int f = 0; f < 4; f++) r += fmaxf(cf_norm(B, 4 + 4 * f, e, N) - cfg.max_contact_force, 0.f);
-      return r;
-    case GO1_REW_FEET_CLEARANCE_CMD_LINEAR:
-#pragma unroll 1
-      for (int f = 0; f < 4; f++) {
-        float cl = fminf(fmaxf(AT(B.foot_indices, f, e) * 2.0f - 1.0f, 0.f), 1.f);
-        float ph = 1.f - fabsf(1.0f - cl * 2.0f);
-        float target = AT(B.commands, 9, e) * ph + 0.02f;
-        float df = target - AT(B.foot_positions, 3 * f + 2, e);
-        r += df * df * (1.f - AT(B.desired_contact_states, f, e));
-      }
-      return r;
-    case GO1_REW_FEET_IMPACT_VEL:
-#pragma unroll 1
-      for (int f = 0; f < 4; f++) {
-        float pv = fminf(fmaxf(AT(B.prev_foot_velocities, 3 * f + 2, e), -100.f), 0.f);
-        r += (cf_norm(B, 4 + 4 * f, e, N) > 1.0f) ? pv * pv : 0.f;
-      }
-      return r;
+    case GO1_REW_FEET_SLIP: {
+      bool contact = F.force.z > 1.0f;
+      bool filt = contact || AT(B.last_contacts, leg, e);
+      AT(B.last_contacts, leg, e) = (uint8_t)contact;
+      return filt ? (F.vel.x * F.vel.x + F.vel.y * F.vel.y) : 0.f;
+    }
+    case GO1_REW_FEET_CONTACT_VEL: return (F.pos.z < 0.03f) ? dot(F.vel, F.vel) : 0.f;
+    case GO1_REW_FEET_CONTACT_FORCES: return fmaxf(F.fnorm - cfg.max_contact_force, 0.f);
+    case GO1_REW_FEET_CLEARANCE_CMD_LINEAR: {
+      float cl = fminf(fmaxf(F.foot_index * 2.0f - 1.0f, 0.f), 1.f);
+      float ph = 1.f - fabsf(1.0f - cl * 2.0f);
+      float target = AT(B.commands, 9, e) * ph + 0.02f;
+      float df = target - F.pos.z;
+      return df * df * (1.f - F.desired_contact);
+    }
+    case GO1_REW_FEET_IMPACT_VEL: {
+      float pv = fminf(fmaxf(AT(B.prev_foot_velocities, 3 * leg + 2, e), -100.f), 0.f);
+      return (F.fnorm > 1.0f) ? pv * pv : 0.f;
+    }
     case GO1_REW_ORIENTATION_CONTROL: {
       float pitch = AT(B.commands, 10, e), roll = AT(B.commands, 11, e);
       float sr, cr, sp, cp;
       sincosf(-0.5f * roll, &sr, &cr);
       sincosf(-0.5f * pitch, &sp, &cp);
-      // quat_mul((sr,0,0,cr), (0,sp,0,cp))
-      float x = sr * cp, y = cr * sp, z = sr * sp, w = cr * cp;
+      float x = sr * cp, y = cr * sp, z = sr * sp, w = cr * cp;       // quat_mul((sr,0,0,cr), (0,sp,0,cp))
       V3 g = quat_rotate_inverse(x, y, z, w, d.gvec);
       float a = d.pg.x - g.x, b = d.pg.y - g.y;
-      return a * a + b * b;
+      return is0 ? a * a + b * b : 0.f;
     }
     case GO1_REW_RAIBERT_HEURISTIC: {
       float l = rsqrtf(d.qz * d.qz + d.qw * d.qw);
@@ -304,19 +288,13 @@ DEV float reward_term(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, in
       float length = cfg.num_commands >= 14 ? AT(B.commands, 13, e) : 0.45f;
       float freq = AT(B.commands, 4, e), xv = AT(B.commands, 0, e), yawv = AT(B.commands, 2, e);
       float yv = yawv * length / 2;
-#pragma unroll 1
-      for (int f = 0; f < 4; f++) {
-        V3 rel = v3(AT(B.foot_positions, 3 * f, e) - d.base_pos.x, AT(B.foot_positions, 3 * f + 1, e) - d.base_pos.y,
-                    AT(B.foot_positions, 3 * f + 2, e) - d.base_pos.z);
-        V3 fb = quat_rotate(0.f, 0.f, yz, yw, rel);
-        float ys = (f % 2 == 0 ? 1.f : -1.f) * width / 2, xs = (f < 2 ? 1.f : -1.f) * length / 2;
-        float ph = fabsf(1.0f - AT(B.foot_indices, f, e) * 2.0f) * 1.0f - 0.5f;
-        float yo = ph * yv * (0.5f / freq), xo = ph * xv * (0.5f / freq);
-        if (f >= 2) yo = -yo;
-        float ex = fabsf((xs + xo) - fb.x), ey = fabsf((ys + yo) - fb.y);
-        r += ex * ex + ey * ey;
-      }
-      return r;
+      V3 fb = quat_rotate(0.f, 0.f, yz, yw, F.pos - d.base_pos);
+      float ys = (leg % 2 == 0 ? 1.f : -1.f) * width / 2, xs = (leg < 2 ? 1.f : -1.f) * length / 2;
+      float ph = fabsf(1.0f - F.foot_index * 2.0f) * 1.0f - 0.5f;
+      float yo = ph * yv * (0.5f / freq), xo = ph * xv * (0.5f / freq);
+      if (leg >= 2) yo = -yo;
+      float ex = fabsf((xs + xo) - fb.x), ey = fabsf((ys + yo) - fb.y);
+      return ex * ex + ey * ey;
     }
     default: return 0.f;
   }
@@ -326,13 +304,19 @@ DEV int reward_raw_sign(int id) {
 }
 
 // ================================================================================================
-// post-physics maps (reference legged_robot.py:90-136)
+// post-physics maps (reference legged_robot.py:90-136), FOUR lanes per environment (lane = leg).
+// Per-leg work (gait clock of the own foot, reward partials, own joints' observation columns, history roll) runs
+// on every lane; per-environment scalar work on the leg-0 lane; `__syncthreads()` (one-wave workgroup) orders the
+// hand-overs through HBM/L2.  Must be called by all four lanes of the environment.
 // ================================================================================================
-DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int64_t counter_post, V3 grav, int history_slot) {
+#define QUAD_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)
+
+DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane, int e, int N, int64_t counter_post, V3 grav, int history_slot) {
+  const int leg = lane & 3;
+  const bool is0 = leg == 0;
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
   Derived d;
-  int ep_len = B.episode_length_buf[e] + 1;
-  B.episode_length_buf[e] = ep_len;
+  const int ep_len = B.episode_length_buf[e] + 1;
   d.base_pos = v3(AT(B.root_states, 0, e), AT(B.root_states, 1, e), AT(B.root_states, 2, e));
   d.qx = AT(B.root_states, 3, e); d.qy = AT(B.root_states, 4, e); d.qz = AT(B.root_states, 5, e); d.qw = AT(B.root_states, 6, e);
   V3 vl = v3(AT(B.root_states, 7, e), AT(B.root_states, 8, e), AT(B.root_states, 9, e));
@@ -341,157 +325,197 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, in
   d.bav = quat_rotate_inverse(d.qx, d.qy, d.qz, d.qw, va);
   d.gvec = (1.f / norm(grav)) * grav;
   d.pg = quat_rotate_inverse(d.qx, d.qy, d.qz, d.qw, d.gvec);
-  AT(B.base_lin_vel, 0, e) = d.blv.x; AT(B.base_lin_vel, 1, e) = d.blv.y; AT(B.base_lin_vel, 2, e) = d.blv.z;
-  AT(B.base_ang_vel, 0, e) = d.bav.x; AT(B.base_ang_vel, 1, e) = d.bav.y; AT(B.base_ang_vel, 2, e) = d.bav.z;
-  AT(B.projected_gravity, 0, e) = d.pg.x; AT(B.projected_gravity, 1, e) = d.pg.y; AT(B.projected_gravity, 2, e) = d.pg.z;
-
-  // ---- _post_physics_step_callback -----------------------------------------------------------
-  if (cfg.teleport_robots) {
-    float x = AT(B.root_states, 0, e), y = AT(B.root_states, 1, e), th = cfg.teleport_thresh, xo = cfg.teleport_x_offset;
-    if (x < th + xo) x += cfg.terrain_length * (cfg.terrain_num_rows - 1);
-    if (x > cfg.terrain_length * cfg.terrain_num_rows - th + xo) x -= cfg.terrain_length * (cfg.terrain_num_rows - 1);
-    if (y < th) y += cfg.terrain_width * (cfg.terrain_num_cols - 1);
-    if (y > cfg.terrain_width * cfg.terrain_num_cols - th) y -= cfg.terrain_width * (cfg.terrain_num_cols - 1);
-    AT(B.root_states, 0, e) = x; AT(B.root_states, 1, e) = y;
+  const float root_z = AT(B.root_states, 2, e);
+  QUAD_SYNC();                // every lane has read the pre-callback state
+  if (is0) {
+    B.episode_length_buf[e] = ep_len;
+    AT(B.base_lin_vel, 0, e) = d.blv.x; AT(B.base_lin_vel, 1, e) = d.blv.y; AT(B.base_lin_vel, 2, e) = d.blv.z;
+    AT(B.base_ang_vel, 0, e) = d.bav.x; AT(B.base_ang_vel, 1, e) = d.bav.y; AT(B.base_ang_vel, 2, e) = d.bav.z;
+    AT(B.projected_gravity, 0, e) = d.pg.x; AT(B.projected_gravity, 1, e) = d.pg.y; AT(B.projected_gravity, 2, e) = d.pg.z;
+    // ---- _post_physics_step_callback: teleport, interval command resampling ----------------------
+    if (cfg.teleport_robots) {
+      float x = AT(B.root_states, 0, e), y = AT(B.root_states, 1, e), th = cfg.teleport_thresh, xo = cfg.teleport_x_offset;
+      if (x < th + xo) x += cfg.terrain_length * (cfg.terrain_num_rows - 1);
+      if (x > cfg.terrain_length * cfg.terrain_num_rows - th + xo) x -= cfg.terrain_length * (cfg.terrain_num_rows - 1);
+      if (y < th) y += cfg.terrain_width * (cfg.terrain_num_cols - 1);
+      if (y > cfg.terrain_width * cfg.terrain_num_cols - th) y -= cfg.terrain_width * (cfg.terrain_num_cols - 1);
+      AT(B.root_states, 0, e) = x; AT(B.root_states, 1, e) = y;
+    }
+    if (ep_len % cfg.resample_interval == 0) resample_commands(cfg, B, e, N, counter_post, P_CMD_CB);
   }
-  if (ep_len % cfg.resample_interval == 0) resample_commands(cfg, B, e, N, counter_post, P_CMD_CB);
+  QUAD_SYNC();                // commands / command_sums of this step are final
+  // ---- gait clock of the own foot (_step_contact_targets) -----------------------------------------
+  FootCtx F;
+  F.foot_index = AT(B.foot_indices, leg, e);
+  F.desired_contact = AT(B.desired_contact_states, leg, e);
+  float clock_own = AT(B.clock_inputs, leg, e);
   if (cfg.observe_gait_commands) {
     float freq = AT(B.commands, 4, e), phase = AT(B.commands, 5, e), offset = AT(B.commands, 6, e), bound = AT(B.commands, 7, e), dur = AT(B.commands, 8, e);
     float gi = fmod1(B.gait_indices[e] + cfg.dt * freq);
-    B.gait_indices[e] = gi;
-    float fi[4];
-    if (cfg.pacing_offset) { fi[0] = gi + phase + offset + bound; fi[1] = gi + bound; fi[2] = gi + offset; fi[3] = gi + phase; }
-    else                   { fi[0] = gi + phase + offset + bound; fi[1] = gi + offset; fi[2] = gi + bound; fi[3] = gi + phase; }
-#pragma unroll
-    for (int f = 0; f < 4; f++) {
-      float rem = fmod1(fi[f]);
-      AT(B.foot_indices, f, e) = rem;
-      float idx = fi[f];
-      if (rem < dur) idx = rem * (0.5f / dur);
-      else if (rem > dur) idx = 0.5f + (rem - dur) * (0.5f / (1.f - dur));
-      AT(B.clock_inputs, f, e) = sinf(2.f * PI_F * idx);
-      float kap = cfg.kappa_gait_probs, x = fmod1(idx);
-      float sm = normal_cdf(x, kap) * (1.f - normal_cdf(x - 0.5f, kap)) + normal_cdf(x - 1.f, kap) * (1.f - normal_cdf(x - 0.5f - 1.f, kap));
-      AT(B.desired_contact_states, f, e) = sm;
+    float f0 = gi + phase + offset + bound, f3 = gi + phase;
+    float f1 = cfg.pacing_offset ? gi + bound : gi + offset;
+    float f2 = cfg.pacing_offset ? gi + offset : gi + bound;
+    float fi = leg == 0 ? f0 : leg == 1 ? f1 : leg == 2 ? f2 : f3;
+    float rem = fmod1(fi);
+    float idx = fi;
+    if (rem < dur) idx = rem * (0.5f / dur);
+    else if (rem > dur) idx = 0.5f + (rem - dur) * (0.5f / (1.f - dur));
+    clock_own = sinf(2.f * PI_F * idx);
+    float kap = cfg.kappa_gait_probs, x = fmod1(idx);
+    float sm = normal_cdf(x, kap) * (1.f - normal_cdf(x - 0.5f, kap)) + normal_cdf(x - 1.f, kap) * (1.f - normal_cdf(x - 0.5f - 1.f, kap));
+    F.foot_index = rem;
+    F.desired_contact = sm;
+    QUAD_SYNC();              // all lanes have read the old gait index
+    if (is0) B.gait_indices[e] = gi;
+    AT(B.foot_indices, leg, e) = rem;
+    AT(B.clock_inputs, leg, e) = clock_own;
+    AT(B.desired_contact_states, leg, e) = sm;
+  }
+  if (is0) {
+    if (cfg.push_robots && ep_len % cfg.push_interval == 0) {
+      AT(B.root_states, 7, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, 0) - 1) * cfg.max_push_vel_xy;
+      AT(B.root_states, 8, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, 1) - 1) * cfg.max_push_vel_xy;
     }
+    if (ep_len % cfg.rand_interval == 0) randomize_dof_props(cfg, B, e, N, counter_post, P_DOFPROPS_CB);
   }
-  if (cfg.push_robots && ep_len % cfg.push_interval == 0) {
-    AT(B.root_states, 7, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, 0) - 1) * cfg.max_push_vel_xy;
-    AT(B.root_states, 8, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, 1) - 1) * cfg.max_push_vel_xy;
+  // ---- own foot / bodies -------------------------------------------------------------------------
+  F.pos = v3(AT(B.foot_positions, 3 * leg, e), AT(B.foot_positions, 3 * leg + 1, e), AT(B.foot_positions, 3 * leg + 2, e));
+  F.vel = v3(AT(B.foot_velocities, 3 * leg, e), AT(B.foot_velocities, 3 * leg + 1, e), AT(B.foot_velocities, 3 * leg + 2, e));
+  {
+    const int b = 4 + 4 * leg;
+    F.force = v3(AT(B.contact_forces, 3 * b, e), AT(B.contact_forces, 3 * b + 1, e), AT(B.contact_forces, 3 * b + 2, e));
+    F.fnorm = norm(F.force);
   }
-  if (ep_len % cfg.rand_interval == 0) randomize_dof_props(cfg, B, e, N, counter_post, P_DOFPROPS_CB);
-
-  // ---- check_termination -----------------------------------------------------------------------
-  bool reset = false;
-#pragma unroll 1
-  for (int b = 0; b < 17; b++) if ((cfg.termination_body_mask & (1u << b)) && cf_norm(B, b, e, N) > 1.0f) reset = true;
-  bool time_out = ep_len > cfg.max_episode_length;
+  // ---- check_termination ---------------------------------------------------------------------------
+  float term = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int b = 1 + 4 * leg + i;
+    if ((cfg.termination_body_mask & (1u << b)) && cf_norm(B, b, e, N) > 1.0f) term = 1.f;
+  }
+  if (is0 && (cfg.termination_body_mask & 1u) && cf_norm(B, 0, e, N) > 1.0f) term = 1.f;
+  bool reset = quad_sum(term) > 0.f;
+  const bool time_out = ep_len > cfg.max_episode_length;
   reset = reset || time_out;
-  if (cfg.use_terminal_body_height && AT(B.root_states, 2, e) < cfg.terminal_body_height) reset = true;
-  B.time_out_buf[e] = (uint8_t)time_out;
-  B.reset_buf[e] = (uint8_t)reset;
+  if (cfg.use_terminal_body_height && root_z < cfg.terminal_body_height) reset = true;
+  if (is0) { B.time_out_buf[e] = (uint8_t)time_out; B.reset_buf[e] = (uint8_t)reset; }
 
-  // ---- compute_reward --------------------------------------------------------------------------
+  // ---- compute_reward ----------------------------------------------------------------------------------
   float rew = 0.f, pos = 0.f, neg = 0.f;
 #pragma unroll 1
   for (int kx = 0; kx < cfg.num_rewards; kx++) {
-    int id = cfg.reward_ids[kx];
-    float sc = cfg.reward_scales[kx];
-    float r = reward_term(cfg, B, e, N, id, d) * sc;
+    const int id = cfg.reward_ids[kx];
+    const float sc = cfg.reward_scales[kx];
+    const float r = quad_sum(reward_partial(cfg, B, e, N, id, d, F, leg)) * sc;
     rew += r;
     if (reward_raw_sign(id) * sc >= 0) pos += r; else neg += r;
-    AT(B.episode_sums, kx, e) += r;
-    if (id == GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE || id == GO1_REW_TRACKING_CONTACTS_SHAPED_VEL) AT(B.command_sums, kx, e) += sc + r;
-    else AT(B.command_sums, kx, e) += r;
+    if ((kx & 3) == leg) {      // the four lanes share the read-modify-write traffic of the running sums
+      AT(B.episode_sums, kx, e) += r;
+      const bool shaped = id == GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE || id == GO1_REW_TRACKING_CONTACTS_SHAPED_VEL;
+      AT(B.command_sums, kx, e) += shaped ? sc + r : r;
+    }
   }
   if (cfg.only_positive_rewards) rew = fmaxf(rew, 0.f);
   else if (cfg.only_positive_rewards_ji22_style) rew = pos * expf(neg / cfg.sigma_rew_neg);
-  B.rew_buf[e] = rew;
-  AT(B.episode_sums, cfg.num_rewards, e) += rew;
-  {
-    int k0 = cfg.num_rewards;
-    float c0 = AT(B.commands, 0, e), c2 = AT(B.commands, 2, e);
+  if (is0) {
+    B.rew_buf[e] = rew;
+    AT(B.episode_sums, cfg.num_rewards, e) += rew;
+    const int k0 = cfg.num_rewards;
+    const float c0 = AT(B.commands, 0, e), c2 = AT(B.commands, 2, e);
     AT(B.command_sums, k0 + 0, e) += d.blv.x;
     AT(B.command_sums, k0 + 1, e) += d.bav.z;
     AT(B.command_sums, k0 + 2, e) += (d.blv.x - c0) * (d.blv.x - c0);
     AT(B.command_sums, k0 + 3, e) += (d.bav.z - c2) * (d.bav.z - c2);
     AT(B.command_sums, k0 + 4, e) += 1.f;
   }
+  QUAD_SYNC();                // running sums complete before a reset logs / clears them
+  // ---- reset ----------------------------------------------------------------------------------------
+  if (reset && is0) reset_env(cfg, B, e, N, counter_post);
+  QUAD_SYNC();                // the observation sees the post-reset state, as in the reference
 
-  // ---- reset -----------------------------------------------------------------------------------
-  if (reset) reset_env(cfg, B, e, N, counter_post);
-
-  // ---- compute_observations ----------------------------------------------------------------------
+  // ---- compute_observations ---------------------------------------------------------------------------
   {
     float* obs_row = B.obs_buf + (size_t)e * cfg.num_obs;
     const int R = cfg.num_obs_history + 1;     // ring slots (one spare keeps the previous window intact)
     float* h0 = B.obs_history ? B.obs_history + (size_t)e * 2 * R * cfg.num_obs + (size_t)history_slot * cfg.num_obs : nullptr;
     float* h1 = h0 ? h0 + (size_t)R * cfg.num_obs : nullptr;
-    int n = 0;
-    auto emit = [&](float v) {
+    auto emit = [&](int n, float v) {
       if (cfg.add_noise && cfg.noise_scale_vec[n] != 0.f) v += (2 * rng_uniform(cfg, eg, counter_post, P_NOISE, n) - 1) * cfg.noise_scale_vec[n];
       v = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations);
       obs_row[n] = v;
       if (h0) { h0[n] = v; h1[n] = v; }
-      n++;
     };
-    if (cfg.observe_only_lin_vel) for (int i = 0; i < 3; i++) emit(AT(B.base_lin_vel, i, e) * cfg.obs_scale_lin_vel);
-    if (cfg.observe_only_ang_vel) for (int i = 0; i < 3; i++) emit(AT(B.base_ang_vel, i, e) * cfg.obs_scale_ang_vel);
+    int n = 0;                // running column (identical on all lanes)
+    if (cfg.observe_only_lin_vel) { if (is0) for (int i = 0; i < 3; i++) emit(n + i, AT(B.base_lin_vel, i, e) * cfg.obs_scale_lin_vel); n += 3; }
+    if (cfg.observe_only_ang_vel) { if (is0) for (int i = 0; i < 3; i++) emit(n + i, AT(B.base_ang_vel, i, e) * cfg.obs_scale_ang_vel); n += 3; }
     if (cfg.observe_vel) {
-      for (int i = 0; i < 3; i++) emit((cfg.global_reference ? AT(B.root_states, 7 + i, e) : AT(B.base_lin_vel, i, e)) * cfg.obs_scale_lin_vel);
-      for (int i = 0; i < 3; i++) emit(AT(B.base_ang_vel, i, e) * cfg.obs_scale_ang_vel);
+      if (is0) {
+        for (int i = 0; i < 3; i++) emit(n + i, (cfg.global_reference ? AT(B.root_states, 7 + i, e) : AT(B.base_lin_vel, i, e)) * cfg.obs_scale_lin_vel);
+        for (int i = 0; i < 3; i++) emit(n + 3 + i, AT(B.base_ang_vel, i, e) * cfg.obs_scale_ang_vel);
+      }
+      n += 6;
     }
-    for (int i = 0; i < 3; i++) emit(AT(B.projected_gravity, i, e));
-    if (cfg.observe_command)
+    if (is0) { emit(n, d.pg.x); emit(n + 1, d.pg.y); emit(n + 2, d.pg.z); }
+    n += 3;
+    if (cfg.observe_command) {
+      // 15 command columns: spread over the quad
 #pragma unroll 1
-      for (int kx = 0; kx < cfg.num_commands; kx++) emit(AT(B.commands, kx, e) * cfg.commands_scale[kx]);
-#pragma unroll 1
-    for (int j = 0; j < 12; j++) emit((AT(B.dof_pos, j, e) - cfg.default_dof_pos[j]) * cfg.obs_scale_dof_pos);
-#pragma unroll 1
-    for (int j = 0; j < 12; j++) emit(AT(B.dof_vel, j, e) * cfg.obs_scale_dof_vel);
-#pragma unroll 1
-    for (int j = 0; j < 12; j++) emit(AT(B.actions, j, e));
-    if (cfg.observe_two_prev_actions)
-#pragma unroll 1
-      for (int j = 0; j < 12; j++) emit(AT(B.last_actions, j, e));
-    if (cfg.observe_timing_parameter) emit(B.gait_indices[e]);
-    if (cfg.observe_clock_inputs) for (int f = 0; f < 4; f++) emit(AT(B.clock_inputs, f, e));
+      for (int kx = leg; kx < cfg.num_commands; kx += 4) emit(n + kx, AT(B.commands, kx, e) * cfg.commands_scale[kx]);
+      n += cfg.num_commands;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      emit(n + j, (AT(B.dof_pos, j, e) - cfg.default_dof_pos[j]) * cfg.obs_scale_dof_pos);
+      emit(n + 12 + j, AT(B.dof_vel, j, e) * cfg.obs_scale_dof_vel);
+      emit(n + 24 + j, AT(B.actions, j, e));
+      if (cfg.observe_two_prev_actions) emit(n + 36 + j, AT(B.last_actions, j, e));
+    }
+    n += cfg.observe_two_prev_actions ? 48 : 36;
+    if (cfg.observe_timing_parameter) { if (is0) emit(n, B.gait_indices[e]); n += 1; }
+    if (cfg.observe_clock_inputs) { emit(n + leg, clock_own); n += 4; }
     if (cfg.observe_yaw) {
-      V3 fw = quat_rotate(AT(B.root_states, 3, e), AT(B.root_states, 4, e), AT(B.root_states, 5, e), AT(B.root_states, 6, e), v3(1.f, 0.f, 0.f));
-      emit(atan2f(fw.y, fw.x));
+      if (is0) {
+        V3 fw = quat_rotate(AT(B.root_states, 3, e), AT(B.root_states, 4, e), AT(B.root_states, 5, e), AT(B.root_states, 6, e), v3(1.f, 0.f, 0.f));
+        emit(n, atan2f(fw.y, fw.x));
+      }
+      n += 1;
     }
-    if (cfg.observe_contact_states) for (int f = 0; f < 4; f++) emit(AT(B.contact_forces, 3 * (4 + 4 * f) + 2, e) > 1.0f ? 1.0f : 0.0f);
+    if (cfg.observe_contact_states) { emit(n + leg, F.force.z > 1.0f ? 1.0f : 0.0f); n += 4; }
 
-    float* pv = B.privileged_obs_buf + (size_t)e * cfg.num_privileged_obs;
-    int np = 0;
-    auto priv = [&](int idx, float val) {
-      float v = (val - cfg.priv_shift[idx]) * cfg.priv_scale[idx];
-      pv[np++] = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations);
-    };
-    auto privraw = [&](float v) { pv[np++] = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations); };
-    if (cfg.priv_enabled[GO1_PRIV_FRICTION]) priv(GO1_PRIV_FRICTION, B.friction_coeffs[e]);
-    if (cfg.priv_enabled[GO1_PRIV_RESTITUTION]) priv(GO1_PRIV_RESTITUTION, B.restitutions[e]);
-    if (cfg.priv_enabled[GO1_PRIV_BASE_MASS]) priv(GO1_PRIV_BASE_MASS, B.payloads[e]);
-    if (cfg.priv_enabled[GO1_PRIV_COM_DISPLACEMENT]) for (int i = 0; i < 3; i++) priv(GO1_PRIV_COM_DISPLACEMENT, AT(B.com_displacements, i, e));
-    if (cfg.priv_enabled[GO1_PRIV_MOTOR_STRENGTH])
+    if (is0) {
+      float* pv = B.privileged_obs_buf + (size_t)e * cfg.num_privileged_obs;
+      int np = 0;
+      auto priv = [&](int idx, float val) {
+        float v = (val - cfg.priv_shift[idx]) * cfg.priv_scale[idx];
+        pv[np++] = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations);
+      };
+      auto privraw = [&](float v) { pv[np++] = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations); };
+      if (cfg.priv_enabled[GO1_PRIV_FRICTION]) priv(GO1_PRIV_FRICTION, B.friction_coeffs[e]);
+      if (cfg.priv_enabled[GO1_PRIV_RESTITUTION]) priv(GO1_PRIV_RESTITUTION, B.restitutions[e]);
+      if (cfg.priv_enabled[GO1_PRIV_BASE_MASS]) priv(GO1_PRIV_BASE_MASS, B.payloads[e]);
+      if (cfg.priv_enabled[GO1_PRIV_COM_DISPLACEMENT]) for (int i = 0; i < 3; i++) priv(GO1_PRIV_COM_DISPLACEMENT, AT(B.com_displacements, i, e));
+      if (cfg.priv_enabled[GO1_PRIV_MOTOR_STRENGTH])
 #pragma unroll 1
-      for (int j = 0; j < 12; j++) priv(GO1_PRIV_MOTOR_STRENGTH, AT(B.motor_strengths, j, e));
-    if (cfg.priv_enabled[GO1_PRIV_MOTOR_OFFSET])
+        for (int j = 0; j < 12; j++) priv(GO1_PRIV_MOTOR_STRENGTH, AT(B.motor_strengths, j, e));
+      if (cfg.priv_enabled[GO1_PRIV_MOTOR_OFFSET])
 #pragma unroll 1
-      for (int j = 0; j < 12; j++) priv(GO1_PRIV_MOTOR_OFFSET, AT(B.motor_offsets, j, e));
-    if (cfg.priv_enabled[GO1_PRIV_BODY_HEIGHT]) priv(GO1_PRIV_BODY_HEIGHT, AT(B.root_states, 2, e));
-    if (cfg.priv_enabled[GO1_PRIV_BODY_VELOCITY]) for (int i = 0; i < 3; i++) priv(GO1_PRIV_BODY_VELOCITY, AT(B.base_lin_vel, i, e));
-    if (cfg.priv_enabled[GO1_PRIV_GRAVITY]) {
-      privraw(((grav.x - cfg.gravity[0]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
-      privraw(((grav.y - cfg.gravity[1]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
-      privraw(((grav.z - cfg.gravity[2]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
+        for (int j = 0; j < 12; j++) priv(GO1_PRIV_MOTOR_OFFSET, AT(B.motor_offsets, j, e));
+      if (cfg.priv_enabled[GO1_PRIV_BODY_HEIGHT]) priv(GO1_PRIV_BODY_HEIGHT, AT(B.root_states, 2, e));
+      if (cfg.priv_enabled[GO1_PRIV_BODY_VELOCITY]) for (int i = 0; i < 3; i++) priv(GO1_PRIV_BODY_VELOCITY, AT(B.base_lin_vel, i, e));
+      if (cfg.priv_enabled[GO1_PRIV_GRAVITY]) {
+        privraw(((grav.x - cfg.gravity[0]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
+        privraw(((grav.y - cfg.gravity[1]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
+        privraw(((grav.z - cfg.gravity[2]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
+      }
+      if (cfg.priv_enabled[GO1_PRIV_CLOCK_INPUTS]) for (int f = 0; f < 4; f++) privraw(AT(B.clock_inputs, f, e));
+      if (cfg.priv_enabled[GO1_PRIV_DESIRED_CONTACT]) for (int f = 0; f < 4; f++) privraw(AT(B.desired_contact_states, f, e));
     }
-    if (cfg.priv_enabled[GO1_PRIV_CLOCK_INPUTS]) for (int f = 0; f < 4; f++) privraw(AT(B.clock_inputs, f, e));
-    if (cfg.priv_enabled[GO1_PRIV_DESIRED_CONTACT]) for (int f = 0; f < 4; f++) privraw(AT(B.desired_contact_states, f, e));
   }
-  // ---- roll ------------------------------------------------------------------------------------------
-#pragma unroll 1
-  for (int j = 0; j < 12; j++) {
+  // ---- roll (own joints) --------------------------------------------------------------------------------
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+    const int j = 3 * leg + jj;
     AT(B.last_last_actions, j, e) = AT(B.last_actions, j, e);
     AT(B.last_actions, j, e) = AT(B.actions, j, e);
     AT(B.last_last_joint_pos_target, j, e) = AT(B.last_joint_pos_target, j, e);
@@ -499,4 +523,3 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, in
     AT(B.last_dof_vel, j, e) = AT(B.dof_vel, j, e);
   }
 }
-

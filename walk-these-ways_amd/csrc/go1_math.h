@@ -172,3 +172,12 @@ DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 DEV float u32_to_unit(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// ---- quad (4-lane) collectives on DPP: the four lanes of a quad hold the four legs of one environment -----------
+DEV float dpp_xor1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false)); }   // quad_perm [1,0,3,2]
+DEV float dpp_xor2(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, false)); }   // quad_perm [2,3,0,1]
+DEV float quad_sum(float x) { x += dpp_xor1(x); x += dpp_xor2(x); return x; }
+DEV SV quad_sum(SV s) {
+  return sv(v3(quad_sum(s.a.x), quad_sum(s.a.y), quad_sum(s.a.z)), v3(quad_sum(s.l.x), quad_sum(s.l.y), quad_sum(s.l.z)));
+}
+DEV unsigned quad_ballot(bool p, int lane) { return (unsigned)((__ballot(p) >> (lane & ~3)) & 0xFull); }

@@ -67,19 +67,25 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
   int head = A.lag_head;
 #pragma unroll 1
   for (int sub = 0; sub < cfg.decimation; sub++) {
+#ifndef GO1_ABLATE_TORQUE
     compute_torques(cfg, B, L, leg, e, N, head);
+#endif
     head = (head + 1) % nl;
+#ifndef GO1_ABLATE_PHYSICS
     physics_substep(cfg, lds, lane, s, L, grav, warm || (cfg.warm_start && sub > 0), h);
+#endif
   }
   store_state(B, leg, e, N, s, L);
   foot_state(s, L, leg, B, e, N);
   store_forces(cfg, B, lds, lane, e, N);
   __threadfence_block();
   __syncthreads();
-  if (leg == 0) post_physics(cfg, B, e, N, A.counter + 1, grav, A.history_slot);
+#ifndef GO1_ABLATE_POST
+  post_physics(cfg, B, lane, e, N, A.counter + 1, grav, A.history_slot);
+#endif
 }
 
-// piecewise entry points with the physics mapping (parity tests): torques only / one physics substep
+// piecewise entry points with the 4-lane mapping (parity tests): torques only / one physics substep / tensor maps only
 extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs A) {
   __shared__ float lds[L_END * EPW];
   const Go1SimConfig& cfg = A.sc->cfg;
@@ -88,6 +94,10 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   const int lane = threadIdx.x, leg = lane & 3;
   const int e = blockIdx.x * EPW + (lane >> 2);
   if (e >= N) return;
+  if (A.mode == 4) {       // tensor maps only
+    post_physics(cfg, B, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot);
+    return;
+  }
   Base s;
   Leg L;
   load_state(B, leg, e, N, s, L);
@@ -108,17 +118,13 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   store_forces(cfg, B, lds, lane, e, N);
 }
 
-// one environment per lane: reset_idx and the tensor maps alone
+// one environment per lane: reset_idx
 extern "C" __global__ void __launch_bounds__(WAVE) go1_env_kernel(const StepArgs A) {
   const Go1SimConfig& cfg = A.sc->cfg;
   const Go1SimBuffers& B = A.sc->buf;
   const int N = cfg.num_envs;
   const int e = blockIdx.x * WAVE + threadIdx.x;
-  if (A.mode == 3) {
-    if (e < A.n_ids) reset_env(cfg, B, A.ids ? A.ids[e] : e, N, A.counter);
-    return;
-  }
-  if (e < N) post_physics(cfg, B, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot);
+  if (e < A.n_ids) reset_env(cfg, B, A.ids ? A.ids[e] : e, N, A.counter);
 }
 
 // HistoryWrapper.get_observations: append the current obs_buf to the double-length ring
@@ -247,13 +253,13 @@ static int launch(Go1Sim* s, int mode, const float* actions, const int32_t* ids,
   A.sc = s->dconst; A.actions = actions; A.counter = s->counter; A.lag_head = s->lag_head;
   A.history_slot = s->history_slot; A.mode = mode; A.ids = ids; A.n_ids = n_ids;
   const int n = (mode == 3) ? n_ids : s->cfg.num_envs;
-  const int per_block = (mode >= 3) ? WAVE : EPW;
+  const int per_block = (mode == 3) ? WAVE : EPW;
   dim3 grid((n + per_block - 1) / per_block), block(WAVE);
   const int slot = timed ? (int)(s->timing_n % s->timing_cap) : 0;
   if (timed) (void)hipEventRecord(s->ev[2 * slot], st);
   if (mode == 0) hipLaunchKernelGGL(go1_step_kernel, grid, block, 0, st, A);
-  else if (mode <= 2) hipLaunchKernelGGL(go1_aux_kernel, grid, block, 0, st, A);
-  else hipLaunchKernelGGL(go1_env_kernel, grid, block, 0, st, A);
+  else if (mode == 3) hipLaunchKernelGGL(go1_env_kernel, grid, block, 0, st, A);
+  else hipLaunchKernelGGL(go1_aux_kernel, grid, block, 0, st, A);
   if (timed) { (void)hipEventRecord(s->ev[2 * slot + 1], st); s->timing_n++; }
   return hipGetLastError() == hipSuccess ? 0 : -20;
 }
