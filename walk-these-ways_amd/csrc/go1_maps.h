@@ -51,8 +51,13 @@ DEV void resample_commands(const Go1SimConfig& cfg, const Go1SimBuffers& B, int 
     int cat = (int)(u0 * cfg.num_categories);
     if (cat >= cfg.num_categories) cat = cfg.num_categories - 1;
     const float* cdf = B.curriculum_cdf + (size_t)cat * cfg.num_bins;
-    int bin = 0;
-    while (bin < cfg.num_bins - 1 && !(u1 < cdf[bin])) bin++;
+    // first bin with u1 < cdf[bin] (cdf is non-decreasing): binary search instead of the oracle's linear scan
+    int lo = 0, hi = cfg.num_bins - 1;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (u1 < cdf[mid]) hi = mid; else lo = mid + 1;
+    }
+    const int bin = lo;
     B.env_command_bins[e] = bin;
     B.env_command_categories[e] = cat;
     int rem = bin;
