@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="fp32 policy instead of bf16 autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sim-only", action="store_true", help="diagnostic: time env.step alone with pre-generated actions")
+    ap.add_argument("--zero-actions", action="store_true", help="diagnostic with --sim-only: standing robots (few resets)")
     ap.add_argument("--breakdown", action="store_true", help="diagnostic: print rollout/update split to stderr (adds syncs)")
     args = ap.parse_args()
 
@@ -154,7 +155,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    acts = torch.randn(T, args.envs, 12, device=device) if args.sim_only else None
+    acts = (torch.zeros if args.zero_actions else torch.randn)(T, args.envs, 12, device=device) if args.sim_only else None
     for _ in range(args.warmup):
         obs_dict = sim_iteration(obs_dict, acts) if args.sim_only else iteration(obs_dict)
     barrier()
@@ -176,6 +177,14 @@ def main():
     if rank == 0:
         total_env_steps = args.envs * T * args.steps * world
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same N)
+        try:
+            with open(os.path.join(REPO, "profiles", "r01_step_kernel_pmc.json")) as f:
+                pmc = json.load(f)
+            if args.envs == 4096:
+                traffic = pmc["hbm_traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * args.envs
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
@@ -189,7 +198,7 @@ def main():
                        "physics_dtype": "f32", "step": "one PPO iteration = 24 x envs env-steps + update",
                        "parallelism": f"dp{world} (envs sharded, RCCL gradient all-reduce)" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "go1_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": avg_ms, "launches": len(kernel_ms), "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "latency/issue-bound O(n_dof) recursion: the HBM fraction is reported as north_star requires, "
                                  "it is not the limiter (DESIGN.md Measurement)"},
