@@ -59,6 +59,11 @@ def test_fused_forward_equals_reference_surface():
     padded = torch.nn.functional.pad(hist, (0, 4))
     assert (ac.fused_forward(padded, priv)[0] - mean).abs().max() < 1e-12
     assert (ac.latent_padded(padded) - latent).abs().max() < 1e-12
+    # augmented layout used with the bf16 storage: [h, 1, privileged, 0] -> biases and critic privileged weights in the GEMM
+    aug = torch.cat((hist, torch.ones(16, 1).double(), priv, torch.zeros(16, 1).double()), dim=1)
+    m2, v2, l2 = ac.fused_forward(aug, None, augmented=True)
+    assert (m2 - mean).abs().max() < 1e-12 and (v2 - value).abs().max() < 1e-12 and (l2 - latent).abs().max() < 1e-12
+    assert (ac.latent_padded(aug, augmented=True) - latent).abs().max() < 1e-12
     a = ac.distribution.sample()
     assert (gaussian_log_prob(a, mean, ac.std) - ac.get_actions_log_prob(a)).abs().max() < 1e-10
     assert (gaussian_entropy(ac.std) - ac.entropy).abs().max() < 1e-10

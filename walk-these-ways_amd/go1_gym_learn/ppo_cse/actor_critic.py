@@ -82,7 +82,7 @@ class ActorCritic(nn.Module):
             return last(h)
         W = F.pad(last.weight, (0, 0, 0, min_cols - n))
         b = F.pad(last.bias, (0, min_cols - n))
-        return F.linear(h, W, b)[:, :n]
+        return F.linear(h, W, b).split([n, min_cols - n], dim=1)[0]
 
     def fused_forward(self, observation_history, privileged_observations=None, want_value=True, augmented=False):
         """(action mean, value, latent) with ONE GEMM over the 2100-wide history for the first layers of the
@@ -104,19 +104,22 @@ class ActorCritic(nn.Module):
         npv = self.num_privileged_obs
         if augmented:
             assert pad >= 1 + npv
-            zc = lambda n, c: ld.weight.new_zeros(n, c)
-            rows = [torch.cat((ld.weight, ld.bias.unsqueeze(1), zc(nd, pad - 1)), dim=1),
-                    torch.cat((la.weight[:, :K], la.bias.unsqueeze(1), zc(na, pad - 1)), dim=1)]
+            z = self._zeros(max(nd, na), pad, wdt, x.device)          # cached constant block of zeros
+            rows = [torch.cat((ld.weight, ld.bias.unsqueeze(1), z[:nd, :pad - 1]), dim=1),
+                    torch.cat((la.weight[:, :K], la.bias.unsqueeze(1), z[:na, :pad - 1]), dim=1)]
+            sizes = [nd, na]
             if want_value:
                 nc = lc.weight.shape[0]
-                rows.append(torch.cat((lc.weight[:, :K], lc.bias.unsqueeze(1), lc.weight[:, K:], zc(nc, pad - 1 - npv)), dim=1))
-            y = F.linear(x, torch.cat(rows, dim=0))
-            latent = self._head(self.adaptation_module, y[:, :nd])
-            a1 = y[:, nd:nd + na]
+                rows.append(torch.cat((lc.weight[:, :K], lc.bias.unsqueeze(1), lc.weight[:, K:], z[:nc, :pad - 1 - npv]), dim=1))
+                sizes.append(nc)
+            # split (not slicing): its backward is one concatenation instead of a zero-fill + add per slice
+            ys = F.linear(x, torch.cat(rows, dim=0)).split(sizes, dim=1)
+            latent = self._head(self.adaptation_module, ys[0])
+            a1 = ys[1]
             for i in range(npv):
                 a1 = torch.addcmul(a1, latent[:, i:i + 1], la.weight[:, K + i])
             mean = self._head(self.actor_body, a1).to(odt)
-            value = self._head(self.critic_body, y[:, nd + na:]).to(odt) if want_value else None
+            value = self._head(self.critic_body, ys[2]).to(odt) if want_value else None
             return mean, value, latent.to(odt)
         parts = [ld.weight, la.weight[:, :K]] + ([lc.weight[:, :K]] if want_value else [])
         Wh = torch.cat(parts, dim=0)
@@ -131,6 +134,13 @@ class ActorCritic(nn.Module):
             value = self._head(self.critic_body, self._side(y[:, nd + na:], p, lc.weight[:, K:], lc.bias)).to(odt)
         return mean, value, latent.to(odt)
 
+    def _zeros(self, rows, cols, dtype, device):
+        key = (rows, cols, dtype, str(device))
+        cache = self.__dict__.setdefault("_zero_cache", {})
+        if key not in cache:
+            cache[key] = torch.zeros(rows, cols, dtype=dtype, device=device)
+        return cache[key]
+
     def latent_padded(self, observation_history, augmented=False):
         """adaptation module on a (possibly padded / augmented) history batch."""
         K = self.num_obs_history
@@ -138,7 +148,8 @@ class ActorCritic(nn.Module):
         x = observation_history if observation_history.dtype == ld.weight.dtype else observation_history.to(ld.weight.dtype)
         pad = x.shape[-1] - K
         if augmented:
-            W = torch.cat((ld.weight, ld.bias.unsqueeze(1), ld.weight.new_zeros(ld.weight.shape[0], pad - 1)), dim=1)
+            z = self._zeros(ld.weight.shape[0], pad, ld.weight.dtype, x.device)
+            W = torch.cat((ld.weight, ld.bias.unsqueeze(1), z[:, :pad - 1]), dim=1)
             return self._head(self.adaptation_module, F.linear(x, W)).to(self.std.dtype)
         W = F.pad(ld.weight, (0, pad)) if pad else ld.weight
         return self._head(self.adaptation_module, F.linear(x, W, ld.bias)).to(self.std.dtype)
