@@ -30,9 +30,11 @@ def test_update_matches_reference(small_ac_args):
     alg = PPO(ac, device="cpu")
     alg.init_storage(N, T, [no], [npv], [no * H], [na])
     st = alg.storage
-    for k in ("observations", "privileged_observations", "observation_histories", "actions", "rewards", "dones", "values",
-              "mu", "sigma", "actions_log_prob"):
+    for k in ("observations", "privileged_observations", "actions", "rewards", "dones", "values", "mu", "sigma", "actions_log_prob"):
         getattr(st, k).copy_(torch.from_numpy(d["in_" + k]))
+    for t in range(T):       # our storage keeps the history rows augmented: [h, 1, privileged, 0]
+        st.write_history(st.observation_histories[t], torch.from_numpy(d["in_observation_histories"][t]),
+                         torch.from_numpy(d["in_privileged_observations"][t]))
     st.step = T
     st.compute_returns(torch.from_numpy(d["last_values"]), PPO_Args.gamma, PPO_Args.lam)
     np.testing.assert_allclose(st.returns.numpy(), d["out_returns"], rtol=1e-5, atol=1e-6)
@@ -41,7 +43,7 @@ def test_update_matches_reference(small_ac_args):
     losses = alg.update()
     np.testing.assert_allclose(losses, d["losses"], rtol=2e-4, atol=1e-6)
     assert alg.learning_rate == pytest.approx(float(d["final_lr"]), rel=1e-6)
-    for k, v in ac.state_dict().items():
+    for k, v in alg.sync_module().state_dict().items():
         np.testing.assert_allclose(v.numpy(), d["final_" + k], rtol=2e-3, atol=2e-5, err_msg=k)
 
 

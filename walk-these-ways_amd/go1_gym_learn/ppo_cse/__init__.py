@@ -135,6 +135,7 @@ class Runner:
 
     def save(self, it):
         """reference :231-251 / :255-274."""
+        self.alg.sync_module()
         with logger.Sync():
             logger.torch_save(self.alg.actor_critic.state_dict(), f"checkpoints/ac_weights_{it:06d}.pt")
             logger.duplicate(f"checkpoints/ac_weights_{it:06d}.pt", "checkpoints/ac_weights_last.pt")
@@ -158,12 +159,14 @@ class Runner:
             logger.save_video(frames, f"videos/{it:05d}.mp4", fps=1 / self.env.dt)
 
     def get_inference_policy(self, device=None):
+        self.alg.sync_module()
         self.alg.actor_critic.eval()
         if device is not None:
             self.alg.actor_critic.to(device)
         return self.alg.actor_critic.act_inference
 
     def get_expert_policy(self, device=None):
+        self.alg.sync_module()
         self.alg.actor_critic.eval()
         if device is not None:
             self.alg.actor_critic.to(device)

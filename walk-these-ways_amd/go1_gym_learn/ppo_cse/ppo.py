@@ -15,7 +15,6 @@ Same algorithm, hyper-parameters (`PPO_Args`) and public methods (`act`, `proces
   * no host synchronisation inside `update()`: the KL-adaptive learning rate is a device tensor handed to Adam,
     loss statistics are accumulated on device and read once at the end.
 """
-import copy
 import math
 
 import torch
@@ -27,6 +26,7 @@ from params_proto import PrefixProto
 from go1_gym_learn.ppo_cse import ActorCritic
 from go1_gym_learn.ppo_cse import RolloutStorage
 from go1_gym_learn.ppo_cse import caches  # noqa: F401
+from go1_gym_learn.ppo_cse.flat_policy import FlatPolicy
 
 
 class PPO_Args(PrefixProto):
@@ -73,97 +73,84 @@ class PPO:
 
     def __init__(self, actor_critic, device='cpu'):
         self.device = device
-        self.actor_critic = actor_critic
+        self.actor_critic = actor_critic          # public / checkpoint format; refreshed by sync_module()
         self.actor_critic.to(device)
         self.on_gpu = torch.device(device).type == "cuda"
         self.bf16 = bool(PPO_Args.autocast_bf16 and self.on_gpu)
         self.storage = None
         ac = self.actor_critic
-        modules = (ac.adaptation_module, ac.actor_body, ac.critic_body)
-        # parameter order of the flat buffers: [std | adaptation module | actor | critic]
-        self.master_params = [ac.std] + [p for m in modules for p in m.parameters()]
-        assert len(self.master_params) == len(list(ac.parameters()))
-        self.flat_param = self._flatten([p.data for p in self.master_params], torch.float32)
-        self.flat_grad = torch.zeros_like(self.flat_param)      # every master .grad is a view into it
-        self._bind(self.master_params, self.flat_param, self.flat_grad)
-        self.adapt_params = list(ac.adaptation_module.parameters())
-        offs, total = self._offsets(self.master_params)
-        n_std = offs[1]                                       # padded length of the std block
-        self.adapt_slice = slice(n_std, offs[1 + len(self.adapt_params)])
-        self.body_slice = slice(n_std, total)
-        if self.bf16:
-            # bf16 compute replica of the three MLPs; `std` stays the shared fp32 parameter
-            self.compute_ac = copy.deepcopy(ac)
-            self.compute_ac.std = ac.std
-            cmods = (self.compute_ac.adaptation_module, self.compute_ac.actor_body, self.compute_ac.critic_body)
-            cparams = [p for m in cmods for p in m.parameters()]
-            self.cflat_param = self._flatten([p.data for p in cparams], torch.bfloat16)
-            self.cflat_grad = torch.zeros_like(self.cflat_param)
-            self._bind(cparams, self.cflat_param, self.cflat_grad)
-        else:
-            self.compute_ac = ac
+        self.policy = FlatPolicy(ac)
+        n = self.policy.numel
+        self.n_body, self.n_std = n, ac.std.numel()
+        # fp32 master: [flat policy | std | pad]; the single tensor both optimisers step
+        self.master = torch.zeros(n + 16, device=device)
+        self.policy.pack(ac, self.master[:n])
+        self.master[n:n + self.n_std].copy_(ac.std.detach())
+        self.master.grad = torch.zeros_like(self.master)
+        pol = self.policy
+        self._priv_cols_grad = pol._block(self.master.grad[:n], "W1")[:pol.first[0] + pol.first[1], pol.K + 1:pol.K + 1 + pol.npv]
+        # compute copies (leaves of the autograd graph): policy body in bf16 or fp32, std always fp32
+        self.body = torch.zeros(n, device=device, dtype=torch.bfloat16 if self.bf16 else torch.float32).requires_grad_()
+        self.std = torch.zeros(self.n_std, device=device).requires_grad_()
         kw = dict(fused=True) if self.on_gpu else {}
         lr = torch.tensor(PPO_Args.learning_rate, device=device) if self.on_gpu else PPO_Args.learning_rate
-        self.optimizer = optim.Adam(self.master_params, lr=lr, **kw)
+        self.optimizer = optim.Adam([self.master], lr=lr, **kw)
         # the reference builds this optimiser over all parameters (ppo.py:45-46) but only the adaptation module ever
-        # receives a non-zero gradient from the adaptation loss, so only those parameters move
-        self.adaptation_module_optimizer = optim.Adam(self.adapt_params, lr=PPO_Args.adaptation_module_learning_rate, **kw)
+        # receives a non-zero gradient from the adaptation loss; with exactly-zero gradients Adam's moments stay zero
+        # and the other parameters do not move, so stepping the whole flat buffer is equivalent
+        self.adaptation_module_optimizer = optim.Adam([self.master], lr=PPO_Args.adaptation_module_learning_rate, **kw)
         self.transition = RolloutStorage.Transition()
         self._lr = torch.tensor(PPO_Args.learning_rate, device=device)
         self.dp = PPO_Args.data_parallel and _world() > 1
         if self.dp:                              # identical initial weights on every rank
-            dist.broadcast(self.flat_param, src=0)
+            dist.broadcast(self.master, src=0)
         self._push_weights()
 
     # ---- precision plumbing --------------------------------------------------------------------------
-    ALIGN = 16          # elements: every parameter starts on a 32-byte (bf16) / 64-byte (fp32) boundary
+    @property
+    def flat_param(self):
+        return self.master
 
-    @classmethod
-    def _offsets(cls, tensors):
-        offs, off = [], 0
-        for t in tensors:
-            offs.append(off)
-            off += -(-t.numel() // cls.ALIGN) * cls.ALIGN
-        return offs, off
+    @property
+    def flat_grad(self):
+        return self.master.grad
 
-    @classmethod
-    def _flatten(cls, tensors, dtype):
-        offs, total = cls._offsets(tensors)
-        flat = torch.zeros(total, dtype=dtype, device=tensors[0].device)
-        for t, o in zip(tensors, offs):
-            flat[o:o + t.numel()].copy_(t.detach().reshape(-1))
-        return flat
+    def _push_weights(self):
+        """fp32 master -> compute copies: one cast kernel + one tiny copy."""
+        with torch.no_grad():
+            self.body.copy_(self.master[:self.n_body])
+            self.std.copy_(self.master[self.n_body:self.n_body + self.n_std])
 
-    @classmethod
-    def _bind(cls, params, flat_param, flat_grad):
-        """Re-seat every parameter (and its .grad) as a view into the flat buffers."""
-        offs, _ = cls._offsets(params)
-        for p, off in zip(params, offs):
-            n = p.numel()
-            p.data = flat_param[off:off + n].view_as(p)
-            p.grad = flat_grad[off:off + n].view_as(p)
+    def _pull_grads(self):
+        """compute-copy gradients -> fp32 master gradient."""
+        g = self.master.grad
+        if self.body.grad is not None:
+            g[:self.n_body].copy_(self.body.grad)
+        else:
+            g[:self.n_body].zero_()
+        if self.std.grad is not None:
+            g[self.n_body:self.n_body + self.n_std].copy_(self.std.grad)
+        else:
+            g[self.n_body:].zero_()
+        self.body.grad = None
+        self.std.grad = None
+        # the augmented rows carry the privileged observations for the critic only: the adaptation module and the
+        # actor must not see them, so their (structurally zero) weights on those columns receive no gradient
+        self._priv_cols_grad.zero_()
 
-    def _push_weights(self, adapt_only=False):
-        """fp32 master -> bf16 compute replica: one cast kernel."""
-        if self.bf16:
-            sl = self.adapt_slice if adapt_only else self.body_slice
-            n0 = self.body_slice.start
-            self.cflat_param[sl.start - n0:sl.stop - n0].copy_(self.flat_param[sl])
+    def sync_module(self):
+        """Refresh the nn.Module (state_dict / TorchScript export format) from the master weights."""
+        self.policy.unpack(self.master[:self.n_body], self.actor_critic)
+        with torch.no_grad():
+            self.actor_critic.std.copy_(self.master[self.n_body:self.n_body + self.n_std])
+        return self.actor_critic
 
-    def _pull_grads(self, adapt_only=False):
-        """bf16 replica gradients -> flat fp32 master gradient buffer: one cast kernel (no-op in fp32 mode)."""
-        if self.bf16:
-            sl = self.adapt_slice if adapt_only else self.body_slice
-            n0 = self.body_slice.start
-            self.flat_grad[sl].copy_(self.cflat_grad[sl.start - n0:sl.stop - n0])
-
-    def _zero_grads(self, adapt_only=False):
-        sl = self.adapt_slice if adapt_only else slice(0, self.flat_grad.numel())
-        self.flat_grad[sl].zero_()
-        if self.bf16:
-            n0 = self.body_slice.start
-            lo, hi = (sl.start - n0, sl.stop - n0) if adapt_only else (0, self.cflat_grad.numel())
-            self.cflat_grad[lo:hi].zero_()
+    def load_module(self):
+        """Adopt weights that were loaded into the nn.Module (resume)."""
+        self.policy.pack(self.actor_critic, self.master[:self.n_body])
+        with torch.no_grad():
+            self.master[self.n_body:self.n_body + self.n_std].copy_(self.actor_critic.std)
+        self._push_weights()
 
     @property
     def learning_rate(self):
@@ -173,9 +160,8 @@ class PPO:
                      action_shape):
         self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, privileged_obs_shape,
                                       obs_history_shape, action_shape, self.device,
-                                      history_dtype=torch.bfloat16 if self.bf16 else torch.float32,
-                                      history_pad_to=8 if self.bf16 else 1, augment=self.bf16)
-        self.augmented = self.storage.augment
+                                      history_dtype=self.body.dtype, history_pad_to=8, augment=True)
+        assert self.storage.observation_histories.shape[-1] == self.policy.Kp
         self._last_hist = self.storage.observation_histories[0].clone()
 
     def test_mode(self):
@@ -192,9 +178,9 @@ class PPO:
         slot = self.storage.observation_histories[self.storage.step]
         self.storage.write_history(slot, obs_history, privileged_obs)
         t.observation_histories = slot
-        ac = self.compute_ac
-        mean, value, _ = ac.fused_forward(slot, privileged_obs, augmented=self.augmented)
-        mean, std = mean.detach(), ac.std.detach()
+        with torch.no_grad():
+            mean, value, _ = self.policy.forward(self.body, slot)
+        mean, value, std = mean.float(), value.float(), self.std.detach()
         t.actions = mean + std * torch.randn_like(mean)
         t.values = value.detach()
         t.actions_log_prob = gaussian_log_prob(t.actions, mean, std)
@@ -219,8 +205,8 @@ class PPO:
     def compute_returns(self, last_critic_obs, last_critic_privileged_obs):
         self.storage.write_history(self._last_hist, last_critic_obs, last_critic_privileged_obs)
         with torch.no_grad():
-            _, last_values, _ = self.compute_ac.fused_forward(self._last_hist, last_critic_privileged_obs, augmented=self.augmented)
-        self.storage.compute_returns(last_values.detach().clone(), PPO_Args.gamma, PPO_Args.lam)
+            _, last_values, _ = self.policy.forward(self.body, self._last_hist)
+        self.storage.compute_returns(last_values.float().clone(), PPO_Args.gamma, PPO_Args.lam)
 
     # ---- update ------------------------------------------------------------------------------------------
     def _adapt_lr(self, kl_mean):
@@ -249,15 +235,14 @@ class PPO:
 
     def update(self):
         A = PPO_Args
-        ac = self.compute_ac
         acc = torch.zeros(4, device=self.device)        # value, surrogate, adaptation, adaptation-test
         generator = self.storage.mini_batch_generator(A.num_mini_batches, A.num_learning_epochs)
         for (obs_batch, critic_obs_batch, privileged_obs_batch, obs_history_batch, actions_batch, target_values_batch,
              advantages_batch, returns_batch, old_actions_log_prob_batch, old_mu_batch, old_sigma_batch, masks_batch,
              env_bins_batch) in generator:
-            self._zero_grads()
-            mu_batch, value_batch, _ = ac.fused_forward(obs_history_batch, privileged_obs_batch, augmented=self.augmented)
-            std = ac.std
+            mu_batch, value_batch, _ = self.policy.forward(self.body, obs_history_batch)
+            mu_batch, value_batch = mu_batch.float(), value_batch.float()
+            std = self.std
             actions_log_prob_batch = gaussian_log_prob(actions_batch, mu_batch, std)
             entropy = gaussian_entropy(std)
 
@@ -280,24 +265,23 @@ class PPO:
 
             loss.backward()
             self._pull_grads()
-            self._clip_and_step(self.optimizer, self.flat_grad, A.max_grad_norm)
+            self._clip_and_step(self.optimizer, self.master.grad, A.max_grad_norm)
             self._push_weights()
             acc[0] += value_loss.detach()
             acc[1] += surrogate_loss.detach()
 
             num_train = int(privileged_obs_batch.shape[0] // 5 * 4)
             for _ in range(A.num_adaptation_module_substeps):
-                self._zero_grads(adapt_only=True)
-                adaptation_pred = ac.latent_padded(obs_history_batch, augmented=self.augmented)
+                adaptation_pred = self.policy.forward(self.body, obs_history_batch, want_actor=False)[2].float()
                 adaptation_target = privileged_obs_batch.detach()
                 sel = 0 if A.selective_adaptation_module_loss else slice(None)
                 adaptation_loss = F.mse_loss(adaptation_pred[:num_train, sel], adaptation_target[:num_train, sel])
                 with torch.no_grad():
                     adaptation_test_loss = F.mse_loss(adaptation_pred[num_train:, sel], adaptation_target[num_train:, sel])
                 adaptation_loss.backward()
-                self._pull_grads(adapt_only=True)
-                self._clip_and_step(self.adaptation_module_optimizer, self.flat_grad[self.adapt_slice])
-                self._push_weights(adapt_only=True)
+                self._pull_grads()
+                self._clip_and_step(self.adaptation_module_optimizer, self.master.grad)
+                self._push_weights()
                 acc[2] += adaptation_loss.detach()
                 acc[3] += adaptation_test_loss.detach()
 
