@@ -39,10 +39,15 @@ def _worker(rank, world, port, out):
     allv = torch.cat(gathered)
     expect = (adv_local - allv.mean()) / (allv.std() + 1e-8)
     adv_ok = torch.allclose(alg.storage.advantages, expect, atol=1e-5)
-    # gradient all-reduce == mean of per-rank gradients
-    alg.flat_grad.copy_(torch.full_like(alg.flat_grad, float(rank + 1)))
-    alg._clip_and_step(type("O", (), {"step": lambda self: None})(), alg.flat_grad, None)
-    grad_ok = torch.allclose(alg.flat_grad, torch.full_like(alg.flat_grad, (1 + world) / 2))
+    # gradient all-reduce == mean of per-rank gradients (adaptation stage: all-reduce, then divide by world size)
+    alg.master.grad.copy_(torch.full_like(alg.master.grad, float(rank + 1)))
+    dist.all_reduce(alg.master.grad)
+    lr_save = alg.adaptation_module_optimizer.param_groups[0]["lr"]
+    alg.adaptation_module_optimizer.param_groups[0]["lr"] = 0.0
+    alg._stage_adapt_step()
+    alg.adaptation_module_optimizer.param_groups[0]["lr"] = lr_save
+    alg.adaptation_module_optimizer.state.clear()
+    grad_ok = torch.allclose(alg.master.grad, torch.full_like(alg.master.grad, (1 + world) / 2))
     torch.manual_seed(5)
     alg.update()
     out[rank] = dict(w0=w0, w=alg.flat_param.clone(), lr=alg.learning_rate, adv_ok=adv_ok, grad_ok=grad_ok, dp=alg.dp)

@@ -48,6 +48,7 @@ class PPO_Args(PrefixProto):
     # MI355X additions
     autocast_bf16 = False           # BASELINE config 2: "bf16 policy" (fp32 master weights + bf16 compute replica)
     data_parallel = True            # all-reduce gradients when torch.distributed is initialised with world_size > 1
+    use_hip_graphs = True           # replay the mini-batch step as a HIP graph from the second update() on
 
 
 _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
@@ -92,7 +93,10 @@ class PPO:
         # compute copies (leaves of the autograd graph): policy body in bf16 or fp32, std always fp32
         self.body = torch.zeros(n, device=device, dtype=torch.bfloat16 if self.bf16 else torch.float32).requires_grad_()
         self.std = torch.zeros(self.n_std, device=device).requires_grad_()
-        kw = dict(fused=True) if self.on_gpu else {}
+        kw = dict(fused=True, capturable=True) if self.on_gpu else {}
+        self._kl = torch.zeros((), device=device)
+        self._acc = torch.zeros(4, device=device)        # value, surrogate, adaptation, adaptation-test losses
+        self._idx, self._graphs, self._updates_done = None, None, 0
         lr = torch.tensor(PPO_Args.learning_rate, device=device) if self.on_gpu else PPO_Args.learning_rate
         self.optimizer = optim.Adam([self.master], lr=lr, **kw)
         # the reference builds this optimiser over all parameters (ppo.py:45-46) but only the adaptation module ever
@@ -210,9 +214,6 @@ class PPO:
 
     # ---- update ------------------------------------------------------------------------------------------
     def _adapt_lr(self, kl_mean):
-        if self.dp:
-            dist.all_reduce(kl_mean)
-            kl_mean = kl_mean / _world()
         lr = self._lr
         dk = PPO_Args.desired_kl
         down = torch.clamp(lr / 1.5, min=1e-5)
@@ -225,68 +226,155 @@ class PPO:
             else:
                 group['lr'] = float(new)
 
-    def _clip_and_step(self, optimizer, flat, max_norm=None):
+    # ---- one mini-batch = four stages; each stage is capture-safe (static buffers, no host reads) ------------
+    def _gather(self, idx):
+        st = self.storage
+        f = lambda t: t.flatten(0, 1)[idx]
+        return dict(hist=f(st.observation_histories), priv=f(st.privileged_observations), actions=f(st.actions),
+                    values=f(st.values), adv=f(st.advantages), returns=f(st.returns), logp=f(st.actions_log_prob),
+                    mu=f(st.mu), sigma=f(st.sigma))
+
+    def _stage_ppo_backward(self, idx):
+        """PPO loss forward + backward into the fp32 master gradient (reference ppo.py:112-155)."""
+        A = PPO_Args
+        b = self._gather(idx)
+        mu_batch, value_batch, _ = self.policy.forward(self.body, b["hist"])
+        mu_batch, value_batch = mu_batch.float(), value_batch.float()
+        std = self.std
+        logp = gaussian_log_prob(b["actions"], mu_batch, std)
+        entropy = gaussian_entropy(std)
+        with torch.no_grad():     # KL(old || new), reference ppo.py:120-124
+            kl = torch.sum(torch.log(std / b["sigma"] + 1.e-5)
+                           + (torch.square(b["sigma"]) + torch.square(b["mu"] - mu_batch)) / (2.0 * torch.square(std)) - 0.5, axis=-1)
+            self._kl.copy_(torch.mean(kl))
+        ratio = torch.exp(logp - torch.squeeze(b["logp"]))
+        adv = torch.squeeze(b["adv"])
+        surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - A.clip_param, 1.0 + A.clip_param)).mean()
+        if A.use_clipped_value_loss:
+            value_clipped = b["values"] + (value_batch - b["values"]).clamp(-A.clip_param, A.clip_param)
+            value_loss = torch.max((value_batch - b["returns"]).pow(2), (value_clipped - b["returns"]).pow(2)).mean()
+        else:
+            value_loss = (b["returns"] - value_batch).pow(2).mean()
+        loss = surrogate_loss + A.value_loss_coef * value_loss - A.entropy_coef * entropy
+        loss.backward()
+        self._pull_grads()
+        self._acc[0] += value_loss.detach()
+        self._acc[1] += surrogate_loss.detach()
+
+    def _stage_ppo_step(self):
+        """adaptive-KL learning rate, global-norm clip, Adam, refresh the compute copies."""
+        A = PPO_Args
+        g = self.master.grad
         if self.dp:
-            dist.all_reduce(flat)
-            flat.div_(_world())
-        if max_norm is not None:     # nn.utils.clip_grad_norm_ on the flat buffer
-            flat.mul_(torch.clamp(max_norm / (torch.linalg.vector_norm(flat) + 1e-6), max=1.0))
-        optimizer.step()
+            g.div_(_world())
+        if A.desired_kl is not None and A.schedule == 'adaptive':
+            self._adapt_lr(self._kl / _world() if self.dp else self._kl)
+        g.mul_(torch.clamp(A.max_grad_norm / (torch.linalg.vector_norm(g) + 1e-6), max=1.0))
+        self.optimizer.step()
+        self._push_weights()
+
+    def _stage_adapt_backward(self, idx):
+        """adaptation-module regression on the same mini-batch (reference ppo.py:163-190)."""
+        A = PPO_Args
+        st = self.storage
+        hist = st.observation_histories.flatten(0, 1)[idx]
+        target = st.privileged_observations.flatten(0, 1)[idx]
+        num_train = int(target.shape[0] // 5 * 4)
+        pred = self.policy.forward(self.body, hist, want_actor=False)[2].float()
+        sel = 0 if A.selective_adaptation_module_loss else slice(None)
+        adaptation_loss = F.mse_loss(pred[:num_train, sel], target[:num_train, sel])
+        with torch.no_grad():
+            adaptation_test_loss = F.mse_loss(pred[num_train:, sel], target[num_train:, sel])
+        adaptation_loss.backward()
+        self._pull_grads()
+        self._acc[2] += adaptation_loss.detach()
+        self._acc[3] += adaptation_test_loss.detach()
+
+    def _stage_adapt_step(self):
+        if self.dp:
+            self.master.grad.div_(_world())
+        self.adaptation_module_optimizer.step()
+        self._push_weights()
+
+    def _minibatch_eager(self, idx):
+        self._stage_ppo_backward(idx)
+        if self.dp:
+            dist.all_reduce(self.master.grad)
+            dist.all_reduce(self._kl)
+        self._stage_ppo_step()
+        for _ in range(PPO_Args.num_adaptation_module_substeps):
+            self._stage_adapt_backward(idx)
+            if self.dp:
+                dist.all_reduce(self.master.grad)
+            self._stage_adapt_step()
+
+    def _capture(self):
+        """Record the mini-batch stages as HIP graphs (launch-bound: ~350 small kernels per mini-batch).
+        Single GPU: one graph for the whole mini-batch.  Data parallel: three graphs with the RCCL all-reduces
+        issued eagerly between them."""
+        idx = self._idx
+        single = not self.dp and PPO_Args.num_adaptation_module_substeps == 1
+        pool = None
+        graphs = []
+
+        def rec(fn):
+            nonlocal pool
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                fn()
+            pool = pool or g.pool()
+            graphs.append(g)
+        if single:
+            rec(lambda: self._minibatch_eager(idx))
+        else:
+            rec(lambda: self._stage_ppo_backward(idx))
+            rec(lambda: (self._stage_ppo_step(), self._stage_adapt_backward(idx)))
+            rec(self._stage_adapt_step)
+        return graphs
+
+    def _minibatch_replay(self):
+        g = self._graphs
+        if len(g) == 1:
+            g[0].replay()
+            return
+        g[0].replay()
+        dist.all_reduce(self.master.grad)
+        dist.all_reduce(self._kl)
+        g[1].replay()
+        dist.all_reduce(self.master.grad)
+        g[2].replay()
 
     def update(self):
         A = PPO_Args
-        acc = torch.zeros(4, device=self.device)        # value, surrogate, adaptation, adaptation-test
-        generator = self.storage.mini_batch_generator(A.num_mini_batches, A.num_learning_epochs)
-        for (obs_batch, critic_obs_batch, privileged_obs_batch, obs_history_batch, actions_batch, target_values_batch,
-             advantages_batch, returns_batch, old_actions_log_prob_batch, old_mu_batch, old_sigma_batch, masks_batch,
-             env_bins_batch) in generator:
-            mu_batch, value_batch, _ = self.policy.forward(self.body, obs_history_batch)
-            mu_batch, value_batch = mu_batch.float(), value_batch.float()
-            std = self.std
-            actions_log_prob_batch = gaussian_log_prob(actions_batch, mu_batch, std)
-            entropy = gaussian_entropy(std)
-
-            if A.desired_kl is not None and A.schedule == 'adaptive':
-                with torch.no_grad():     # reference ppo.py:120-124
-                    kl = torch.sum(torch.log(std / old_sigma_batch + 1.e-5)
-                                   + (torch.square(old_sigma_batch) + torch.square(old_mu_batch - mu_batch))
-                                   / (2.0 * torch.square(std)) - 0.5, axis=-1)
-                    self._adapt_lr(torch.mean(kl))
-
-            ratio = torch.exp(actions_log_prob_batch - torch.squeeze(old_actions_log_prob_batch))
-            adv = torch.squeeze(advantages_batch)
-            surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - A.clip_param, 1.0 + A.clip_param)).mean()
-            if A.use_clipped_value_loss:
-                value_clipped = target_values_batch + (value_batch - target_values_batch).clamp(-A.clip_param, A.clip_param)
-                value_loss = torch.max((value_batch - returns_batch).pow(2), (value_clipped - returns_batch).pow(2)).mean()
-            else:
-                value_loss = (returns_batch - value_batch).pow(2).mean()
-            loss = surrogate_loss + A.value_loss_coef * value_loss - A.entropy_coef * entropy
-
-            loss.backward()
-            self._pull_grads()
-            self._clip_and_step(self.optimizer, self.master.grad, A.max_grad_norm)
-            self._push_weights()
-            acc[0] += value_loss.detach()
-            acc[1] += surrogate_loss.detach()
-
-            num_train = int(privileged_obs_batch.shape[0] // 5 * 4)
-            for _ in range(A.num_adaptation_module_substeps):
-                adaptation_pred = self.policy.forward(self.body, obs_history_batch, want_actor=False)[2].float()
-                adaptation_target = privileged_obs_batch.detach()
-                sel = 0 if A.selective_adaptation_module_loss else slice(None)
-                adaptation_loss = F.mse_loss(adaptation_pred[:num_train, sel], adaptation_target[:num_train, sel])
-                with torch.no_grad():
-                    adaptation_test_loss = F.mse_loss(adaptation_pred[num_train:, sel], adaptation_target[num_train:, sel])
-                adaptation_loss.backward()
-                self._pull_grads()
-                self._clip_and_step(self.adaptation_module_optimizer, self.master.grad)
-                self._push_weights()
-                acc[2] += adaptation_loss.detach()
-                acc[3] += adaptation_test_loss.detach()
-
+        st = self.storage
+        batch_size = st.num_envs * st.num_transitions_per_env
+        mb = batch_size // A.num_mini_batches
+        if self._idx is None or self._idx.numel() != mb:
+            self._idx = torch.zeros(mb, dtype=torch.long, device=self.device)
+            self._graphs = None
+        self._acc.zero_()
+        indices = torch.randperm(A.num_mini_batches * mb, requires_grad=False, device=self.device)   # rollout_storage.py:103
+        use_graphs = (self.on_gpu and A.use_hip_graphs and A.num_adaptation_module_substeps == 1)
+        for epoch in range(A.num_learning_epochs):
+            for i in range(A.num_mini_batches):
+                self._idx.copy_(indices[i * mb:(i + 1) * mb])
+                if use_graphs and self._updates_done >= 1:
+                    if self._graphs is None:
+                        try:
+                            self._graphs = self._capture()
+                        except Exception as err:      # capture is an optimisation: fall back to eager launches
+                            print(f"[ppo] HIP graph capture failed ({type(err).__name__}: {err}); running eagerly")
+                            PPO_Args.use_hip_graphs = False
+                            use_graphs = False
+                            torch.cuda.synchronize()
+                            self._minibatch_eager(self._idx)
+                            continue
+                    self._minibatch_replay()
+                else:
+                    self._minibatch_eager(self._idx)
+        self._updates_done += 1
         num_updates = A.num_learning_epochs * A.num_mini_batches
-        v, s, a, at = (acc / num_updates).tolist()         # the only host read of the update
+        v, s, a, at = (self._acc / num_updates).tolist()         # the only host read of the update
         a /= A.num_adaptation_module_substeps
         at /= A.num_adaptation_module_substeps
         self.storage.clear()
