@@ -116,3 +116,36 @@ def test_runner_learns_and_exports(tmp_path):
     metrics = logger.load_pkl("metrics.pkl")
     assert "train/episode/rew_total/mean" in metrics[-1] and metrics[-1]["timesteps"] == 2 * 24 * 256
     PPO_Args.autocast_bf16 = False
+
+
+def test_graph_replay_update_equals_eager_update():
+    """The HIP-graph replay of the mini-batch step must produce exactly what the eager launches produce."""
+    from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
+    from go1_gym_learn.ppo_cse.ppo import PPO, PPO_Args
+    N, T = 512, 8
+    results = []
+    for use_graphs in (False, True):
+        PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs = True, use_graphs
+        torch.manual_seed(0)
+        alg = PPO(ActorCritic(70, 2, 2100, 12), device="cuda:0")
+        alg.init_storage(N, T, [70], [2], [2100], [12])
+        g = torch.Generator(device="cuda").manual_seed(1)
+        for it in range(2):
+            for t in range(T):
+                obs = torch.randn(N, 70, device="cuda", generator=g)
+                priv = torch.randn(N, 2, device="cuda", generator=g)
+                hist = torch.randn(N, 2100, device="cuda", generator=g)
+                torch.manual_seed(10 * it + t)
+                alg.act(obs, priv, hist)
+                alg.process_env_step(torch.randn(N, device="cuda", generator=g), torch.zeros(N, dtype=torch.uint8, device="cuda"),
+                                     {"env_bins": torch.zeros(N, device="cuda"), "time_outs": torch.zeros(N, dtype=torch.bool, device="cuda")})
+            alg.compute_returns(hist, priv)
+            torch.manual_seed(100 + it)
+            losses = alg.update()
+        assert (alg._graphs is not None) == use_graphs
+        results.append((alg.master.clone(), losses, alg.learning_rate))
+    PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs = False, True
+    (w0, l0, lr0), (w1, l1, lr1) = results
+    assert lr0 == lr1
+    np.testing.assert_allclose(l0, l1, rtol=1e-5)
+    assert torch.equal(w0, w1)
