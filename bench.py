@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sim-only", action="store_true", help="diagnostic: time env.step alone with pre-generated actions")
     ap.add_argument("--zero-actions", action="store_true", help="diagnostic with --sim-only: standing robots (few resets)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
+    ap.add_argument("--same-device", action="store_true", help="dry run: all ranks share GPU 0 (with --backend gloo)")
     ap.add_argument("--breakdown", action="store_true", help="diagnostic: print rollout/update split to stderr (adds syncs)")
     args = ap.parse_args()
 
@@ -102,10 +104,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from go1_gym_learn.ppo_cse import Runner, RunnerArgs
     from go1_gym_learn.ppo_cse.ppo import PPO_Args
