@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GO1SIM_ABI_VERSION 1
+#define GO1SIM_ABI_VERSION 2
 
 #define GO1_NUM_DOF 12
 #define GO1_NUM_BODIES 17        /* base, then FL,FR,RL,RR x (hip, thigh, calf, foot) */
@@ -36,6 +36,7 @@ extern "C" {
 #define GO1_MAX_PRIV_OBS 64
 #define GO1_MAX_LAG 8            /* lag_timesteps + 1 <= 8 */
 #define GO1_MAX_CATEGORIES 4
+#define GO1_MAX_HEIGHT_AXIS 32   /* measured_points_x / _y entries */
 
 /* canonical reward ids: one per `_reward_*` in go1_gym/envs/rewards/corl_rewards.py:15-202 */
 enum Go1RewardId {
@@ -117,6 +118,12 @@ typedef struct Go1SimConfig {
   int32_t terrain_type;            /* 0 plane, 1 height field */
   int32_t hf_rows, hf_cols;        /* height_samples shape */
   float hf_hscale, hf_vscale, hf_border;
+  /* height scan: legged_robot.py:1756-1806 (_init_height_points, _get_heights) */
+  int32_t measure_heights;         /* Cfg.terrain.measure_heights */
+  int32_t num_height_x, num_height_y;
+  float height_points_x[GO1_MAX_HEIGHT_AXIS], height_points_y[GO1_MAX_HEIGHT_AXIS];
+  int32_t observe_heights;         /* append clip(z_base - 0.5 - h, -1, 1) * scale to the observation (BASELINE config 3) */
+  float obs_scale_height, height_noise_scale;
 
   /* --- episode / domain randomisation cadence: legged_robot.py:675-708,1716-1732 --- */
   int32_t max_episode_length;
@@ -188,7 +195,7 @@ typedef struct Go1SimBuffers {
   float* root_states;              /* [13][N] pos3 quat4 linvel3 angvel3, world frame */
   float* dof_pos;                  /* [12][N] */
   float* dof_vel;                  /* [12][N] */
-  float* contact_forces;           /* [17*3][N] net contact force per body, last substep, world */
+  float* contact_forces;           /* [17*3][N] net contact force per body (x,y,z), last substep, world; also the solver's warm start */
   float* foot_positions;           /* [4*3][N] */
   float* foot_velocities;          /* [4*3][N] */
   float* prev_foot_velocities;     /* [4*3][N] legged_robot.py:72 */
@@ -251,6 +258,7 @@ typedef struct Go1SimBuffers {
   float* obs_history;              /* (N, 2*(H+1)*num_obs): ring of H+1 slots stored twice; window via go1sim_history_window_offset */
   /* terrain */
   const int16_t* height_samples;   /* (hf_rows, hf_cols) or NULL for plane */
+  float* measured_heights;         /* [num_height_x*num_height_y][N] or NULL */
 } Go1SimBuffers;
 
 typedef struct Go1Sim Go1Sim;      /* opaque handle */

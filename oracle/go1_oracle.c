@@ -400,8 +400,10 @@ static const int CONTACT_ORDER[17] = {4, 8, 12, 16, 0, 3, 7, 11, 15, 2, 6, 10, 1
 /* ------------------------------------------------------------------ one physics substep (replaces gym.simulate) */
 typedef struct { real force[17][3]; } ContactOut;
 
+/* wl[b]: world impulse vector (x,y,z) of body b's contact in the previous substep (warm start), updated in place */
 static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s, const real* tau, const real* grav,
-                            real lam[17][3], int use_warm, ContactOut* out) {
+                            real wl[17][3], int use_warm, ContactOut* out) {
+  real lam[17][3];
   const real h = (real)cfg->sim_dt;
   Kin k;
   kinematics(s, &k);
@@ -459,7 +461,9 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
     for (int i = 0; i < NV; i++) un_pre += J[b][0][i] * vel[i];
     if (un_pre < -(real)cfg->bounce_threshold_velocity && -e_c * un_pre > vs) vs = -e_c * un_pre;
     vstar[b] = vs;
-    if (!use_warm) lam[b][0] = lam[b][1] = lam[b][2] = 0;
+    lam[b][0] = use_warm ? v3dot(wl[b], C[b].n) : 0;      /* project last substep's impulse on the current contact frame */
+    lam[b][1] = use_warm ? v3dot(wl[b], C[b].t1) : 0;
+    lam[b][2] = use_warm ? v3dot(wl[b], C[b].t2) : 0;
     for (int r = 0; r < 3; r++)
       for (int i = 0; i < NV; i++) v[i] += T[b][r][i] * lam[b][r];
   }
@@ -485,8 +489,10 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
     }
   }
   for (int b = 0; b < 17; b++) {
-    for (int i = 0; i < 3; i++)
-      out->force[b][i] = C[b].active ? (C[b].n[i] * lam[b][0] + C[b].t1[i] * lam[b][1] + C[b].t2[i] * lam[b][2]) / h : 0;
+    for (int i = 0; i < 3; i++) {
+      wl[b][i] = C[b].active ? (C[b].n[i] * lam[b][0] + C[b].t1[i] * lam[b][1] + C[b].t2[i] * lam[b][2]) : 0;
+      out->force[b][i] = wl[b][i] / h;
+    }
   }
   /* joint velocity limits, then semi-implicit Euler */
   for (int j = 0; j < 12; j++) {
@@ -1002,12 +1008,43 @@ static void post_physics(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e,
   }
   if (B->episode_length_buf[e] % cfg->rand_interval == 0) randomize_dof_props(cfg, B, e, counter_post, P_DOFPROPS_CB);
 
+  /* ---- measured terrain heights (:689-691, _get_heights :1772-1806) ---- */
+  real mean_height = 0;
+  if (cfg->measure_heights && B->measured_heights) {
+    const int np = cfg->num_height_x * cfg->num_height_y;
+    real qy[4] = {0, 0, AT(B->root_states, 5, e), AT(B->root_states, 6, e)};     /* quat_apply_yaw (math_utils.py:12-17) */
+    real l = sqrt(qy[2] * qy[2] + qy[3] * qy[3]);
+    qy[2] /= l; qy[3] /= l;
+    for (int p = 0; p < np; p++) {
+      real loc[3] = {cfg->height_points_x[p / cfg->num_height_y], cfg->height_points_y[p % cfg->num_height_y], 0}, w[3];
+      quat_rotate(w, qy, loc);
+      float hgt = 0;
+      if (cfg->terrain_type != 0 && B->height_samples) {
+        /* float32 arithmetic and truncation toward zero as `(points / horizontal_scale).long()` */
+        float fx = ((float)w[0] + AT(B->root_states, 0, e) + cfg->hf_border) / cfg->hf_hscale;
+        float fy = ((float)w[1] + AT(B->root_states, 1, e) + cfg->hf_border) / cfg->hf_hscale;
+        long px = (long)fx, py = (long)fy;
+        if (px < 0) px = 0; if (py < 0) py = 0;
+        if (px > cfg->hf_rows - 2) px = cfg->hf_rows - 2;
+        if (py > cfg->hf_cols - 2) py = cfg->hf_cols - 2;
+        int16_t h1 = B->height_samples[px * cfg->hf_cols + py], h2 = B->height_samples[(px + 1) * cfg->hf_cols + py],
+                h3 = B->height_samples[px * cfg->hf_cols + py + 1];
+        int16_t hm = h1 < h2 ? h1 : h2;
+        hm = hm < h3 ? hm : h3;
+        hgt = hm * cfg->hf_vscale;
+      }
+      AT(B->measured_heights, p, e) = hgt;
+      mean_height += hgt;
+    }
+    mean_height /= np;
+  }
+
   /* ---- check_termination (:138-148) ---- */
   int reset = 0;
   for (int b = 0; b < 17; b++) if ((cfg->termination_body_mask & (1u << b)) && v3norm(d.cf[b]) > 1.0) reset = 1;
   int time_out = B->episode_length_buf[e] > cfg->max_episode_length;
   reset |= time_out;
-  if (cfg->use_terminal_body_height && (real)AT(B->root_states, 2, e) < (real)cfg->terminal_body_height) reset = 1;
+  if (cfg->use_terminal_body_height && (real)AT(B->root_states, 2, e) - mean_height < (real)cfg->terminal_body_height) reset = 1;
   B->time_out_buf[e] = (uint8_t)time_out;
   B->reset_buf[e] = (uint8_t)reset;
 
@@ -1079,6 +1116,18 @@ static void post_physics(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e,
       if (v > cfg->clip_observations) v = cfg->clip_observations;
       if (v < -cfg->clip_observations) v = -cfg->clip_observations;
       B->obs_buf[(size_t)e * cfg->num_obs + i] = v;
+    }
+    if (cfg->observe_heights && cfg->measure_heights && B->measured_heights) {     /* legacy legged_gym block, BASELINE config 3 */
+      const int np = cfg->num_height_x * cfg->num_height_y;
+      for (int p = 0; p < np; p++) {
+        float v = AT(B->root_states, 2, e) - 0.5f - AT(B->measured_heights, p, e);
+        v = (v < -1.f ? -1.f : (v > 1.f ? 1.f : v)) * cfg->obs_scale_height;
+        if (cfg->add_noise && cfg->height_noise_scale != 0)
+          v += (2 * rng_uniform(cfg, eg, counter_post, P_NOISE, n + p) - 1) * cfg->height_noise_scale;
+        if (v > cfg->clip_observations) v = cfg->clip_observations;
+        if (v < -cfg->clip_observations) v = -cfg->clip_observations;
+        B->obs_buf[(size_t)e * cfg->num_obs + n + p] = v;
+      }
     }
     /* privileged observations */
     float pv[GO1_MAX_PRIV_OBS];
@@ -1153,13 +1202,8 @@ void go1_oracle_step(const Go1SimConfig* cfg, const Go1SimBuffers* B, const floa
     for (int b = 0; b < 17; b++)
       for (int i = 0; i < 3; i++) lam[b][i] = 0;
     if (warm) {
-      /* impulses of the previous substep: stored as world forces; the contact frame on the plane is
-       * (n, t1, t2) = (z, x, y); for height fields the frame is re-projected in the solver order */
-      for (int b = 0; b < 17; b++) {
-        lam[b][0] = (real)AT(B->contact_forces, 3 * b + 2, e) * (real)cfg->sim_dt;
-        lam[b][1] = (real)AT(B->contact_forces, 3 * b + 0, e) * (real)cfg->sim_dt;
-        lam[b][2] = (real)AT(B->contact_forces, 3 * b + 1, e) * (real)cfg->sim_dt;
-      }
+      for (int b = 0; b < 17; b++)       /* world impulse of the previous step's last substep */
+        for (int i = 0; i < 3; i++) lam[b][i] = (real)AT(B->contact_forces, 3 * b + i, e) * (real)cfg->sim_dt;
     }
     ContactOut co;
     int head = ctr->lag_head;
@@ -1211,11 +1255,8 @@ void go1_oracle_physics_substep(const Go1SimConfig* cfg, const Go1SimBuffers* B,
     Phys s;
     load_phys(cfg, B, e, &s);
     real lam[17][3], tau[12];
-    for (int b = 0; b < 17; b++) {
-      lam[b][0] = (real)AT(B->contact_forces, 3 * b + 2, e) * (real)cfg->sim_dt;
-      lam[b][1] = (real)AT(B->contact_forces, 3 * b + 0, e) * (real)cfg->sim_dt;
-      lam[b][2] = (real)AT(B->contact_forces, 3 * b + 1, e) * (real)cfg->sim_dt;
-    }
+    for (int b = 0; b < 17; b++)
+      for (int i = 0; i < 3; i++) lam[b][i] = (real)AT(B->contact_forces, 3 * b + i, e) * (real)cfg->sim_dt;
     for (int j = 0; j < 12; j++) tau[j] = AT(B->torques, j, e);
     ContactOut co;
     physics_substep(cfg, &ter, &s, tau, grav, lam, cfg->warm_start, &co);

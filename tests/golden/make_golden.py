@@ -287,6 +287,37 @@ def gen_curriculum():
     print("curriculum weights", w0.sum(), r.weights.sum())
 
 
+def gen_heights(seed=9, N=24):
+    """reference LeggedRobot._init_height_points / _get_heights on a random height field."""
+    from go1_gym.envs.base.legged_robot import LeggedRobot
+    from go1_gym.envs.base.legged_robot_config import Cfg
+    rng = np.random.default_rng(seed)
+    e = Mock()
+    e.device = "cpu"
+    e.num_envs = N
+    Cfg.terrain.mesh_type = "heightfield"
+    Cfg.terrain.border_size = 2.0
+    Cfg.terrain.horizontal_scale = 0.1
+    Cfg.terrain.vertical_scale = 0.005
+    e.terrain = Mock()
+    e.terrain.cfg = Cfg.terrain
+    rows, cols = 120, 90
+    e.height_samples = torch.tensor(rng.integers(-60, 60, (rows, cols)), dtype=torch.int16)
+    e.root_states = torch.zeros(N, 13)
+    e.root_states[:, 0] = torch.tensor(rng.uniform(-3.0, rows * 0.1 - 1.0, N), dtype=torch.float)     # some scans leave the map
+    e.root_states[:, 1] = torch.tensor(rng.uniform(-3.0, cols * 0.1 - 1.0, N), dtype=torch.float)
+    e.root_states[:, 2] = 0.4
+    e.root_states[:, 3:7] = rand_quat(rng, N, tilt=0.3)
+    e.base_quat = e.root_states[:, 3:7]
+    ids = torch.arange(N)
+    e.height_points = LeggedRobot._init_height_points(e, ids, Cfg)
+    h = LeggedRobot._get_heights(e, ids, Cfg)
+    np.savez_compressed(os.path.join(HERE, "heights.npz"), height_samples=e.height_samples.numpy(), root_states=e.root_states.numpy(),
+                        heights=h.numpy(), points_x=np.array(Cfg.terrain.measured_points_x), points_y=np.array(Cfg.terrain.measured_points_y),
+                        border=np.array(2.0), hscale=np.array(0.1), vscale=np.array(0.005))
+    print("heights", h.shape, float(h.min()), float(h.max()))
+
+
 def gen_ppo(seed=3):
     """reference go1_gym_learn.ppo_cse: RolloutStorage.compute_returns + PPO.update on a fixed rollout."""
     ml = types.ModuleType("ml_logger")
@@ -334,6 +365,9 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     gen_curriculum()
     gen_ppo()
+    for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+        del sys.modules[m]
+    gen_heights()
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     for v in ("train", "alt"):

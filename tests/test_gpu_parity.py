@@ -153,6 +153,116 @@ def test_full_step_matches_oracle(variant):
     assert worst <= 0.02, worst
 
 
+def rough_field(rows=240, cols=240, amp=0.08, seed=0, hscale=0.1, vscale=0.005):
+    """Low-passed random relief plus a staircase strip: slopes, creases and 0.1 m risers under the robots."""
+    rng = np.random.default_rng(seed)
+    z = rng.uniform(-1, 1, (rows // 4 + 2, cols // 4 + 2))
+    z = np.kron(z, np.ones((4, 4)))[:rows, :cols]
+    for _ in range(3):
+        z = 0.25 * (np.roll(z, 1, 0) + np.roll(z, -1, 0) + np.roll(z, 1, 1) + np.roll(z, -1, 1))
+    z = amp * z / np.abs(z).max()
+    z[:, 100:140] += 0.1 * (np.arange(40) // 4)[None, :] % 0.5
+    return np.rint(z / vscale).astype(np.int16), hscale, vscale
+
+
+def scatter_on_field(S, B, g, hs, hscale, vscale, clearance):
+    N = B.root_states.shape[1]
+    B.root_states[0].uniform_(3.0, 20.0, generator=g)
+    B.root_states[1].uniform_(3.0, 20.0, generator=g)
+    ix = (B.root_states[0] / hscale).long()
+    iy = (B.root_states[1] / hscale).long()
+    ground = torch.from_numpy(hs.astype(np.float32))[ix, iy] * vscale
+    B.root_states[2] = ground + clearance
+
+
+@pytest.mark.parametrize("scenario", ["standing", "tumbling"])
+def test_physics_substep_on_height_field(scenario):
+    """Same comparison as above on a rough int16 height field (BASELINE config 3): bilinear height + tilted contact
+    frames + world-impulse warm start."""
+    N = 256
+    cfg, S, meta, Bc, orc = gpu_pair("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
+    hs, hscale, vscale = rough_field()
+    H.bind_height_field(S, Bc, hs, hscale, vscale, 0.0)
+    assert S.terrain_type == 1
+    g = torch.Generator().manual_seed(4)
+    if scenario == "standing":
+        standing_state(S, Bc, z=0.28)
+        scatter_on_field(S, Bc, g, hs, hscale, vscale, 0.29)
+    else:
+        q = torch.randn(4, N, generator=g)
+        Bc.root_states[3:7] = q / q.norm(dim=0, keepdim=True)
+        scatter_on_field(S, Bc, g, hs, hscale, vscale, 0.0)
+        Bc.root_states[2] += torch.empty(N).uniform_(0.08, 0.35, generator=g)
+        Bc.root_states[7:13].uniform_(-2, 2, generator=g)
+        Bc.dof_vel.uniform_(-5, 5, generator=g)
+    Bc.torques.uniform_(-20, 20, generator=g)
+    orc = __import__("pyoracle").Oracle(S, Bc)
+    Bg, sim = to_gpu(S, Bc)
+    worst = 0.0
+    for it in range(8):
+        orc.physics_substep()
+        sim.physics_substep()
+        torch.cuda.synchronize()
+        assert torch.isfinite(Bg.root_states).all() and torch.isfinite(Bg.dof_vel).all()
+        bad_env = torch.zeros(N, dtype=torch.bool)
+        for k, tol in (("root_states", 2e-4), ("dof_pos", 2e-4), ("dof_vel", 3e-3)):
+            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], tol, 1e-4)
+            bad_env |= bad.any(0)
+        bad, _ = frac_bad(Bg.contact_forces, Bc.contact_forces, 5e-2, 2e-3)
+        bad_env |= bad.any(0)
+        worst = max(worst, float(bad_env.float().mean()))
+        sync_from(Bc, Bg, sim, orc)
+    assert worst <= 0.02, worst
+    cf = Bc.contact_forces.view(17, 3, N)
+    assert float(cf[:, 2].abs().max()) > 1.0 and float(cf[:, :2].abs().max()) > 0.5       # tilted normals / friction at work
+
+
+def test_full_step_on_height_field():
+    """40 full steps with the 187-point height scan in the observation, resets onto the field and the
+    height-relative termination test (legged_robot.py:160-178, 1793-1806)."""
+    N = 256
+    pts_x = [round(-0.8 + 0.1 * i, 1) for i in range(17)]
+    pts_y = [round(-0.5 + 0.1 * i, 1) for i in range(11)]
+    ex = {"terrain": dict(measure_heights=True, measured_points_x=pts_x, measured_points_y=pts_y),
+          "env": dict(observe_heights=True, num_observations=70 + 187),
+          "domain_rand": dict(randomize_gravity=False)}
+    import pyoracle
+    cfg, S, meta, Bc = make_sim("train_noise", N, seed=13, extra=ex)
+    hs, hscale, vscale = rough_field(seed=2)
+    H.bind_height_field(S, Bc, hs, hscale, vscale, 0.0)
+    randomize_dr(Bc, 13)
+    Bc.env_origins[0].uniform_(4.0, 19.0, generator=torch.Generator().manual_seed(1))
+    Bc.env_origins[1].uniform_(4.0, 19.0, generator=torch.Generator().manual_seed(2))
+    ix = (Bc.env_origins[0] / hscale).long()
+    iy = (Bc.env_origins[1] / hscale).long()
+    Bc.env_origins[2] = torch.from_numpy(hs.astype(np.float32))[ix, iy] * vscale + 0.05
+    orc = pyoracle.Oracle(S, Bc)
+    orc.reset_idx()
+    Bg, sim = to_gpu(S, Bc)
+    sync_from(Bc, Bg, sim, orc)
+    rng = np.random.default_rng(0)
+    worst, resets = 0.0, 0
+    for step in range(40):
+        a = (rng.standard_normal((N, 12)) * (1.0 if step % 2 else 0.3)).astype(np.float32)
+        orc.step(a)
+        sim.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        cpu_reset = Bc.reset_buf.bool()
+        bad_env = (Bg.reset_buf.cpu().bool() != cpu_reset)
+        for k, tol, rt in (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
+                           ("torques", 5e-3, 1e-3), ("foot_positions", 1e-3, 0), ("measured_heights", 1e-3, 0)):
+            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], tol, rt)
+            bad_env |= bad.reshape(-1, N).any(0)
+        bad, _ = frac_bad(Bg.obs_buf, Bc.obs_buf, 5e-3, 1e-3)
+        bad_env |= bad.any(1)
+        worst = max(worst, float(bad_env.float().mean()))
+        resets += int(cpu_reset.sum())
+        sync_from(Bc, Bg, sim, orc)
+    assert Bc.obs_buf.shape[1] == 257 and float(Bc.obs_buf[:, 70:].abs().max()) > 0.1
+    assert resets > 5
+    assert worst <= 0.03, worst
+
+
 def test_determinism_and_shard_independence():
     """Same seed -> bit-identical results; envs [256,512) of a 512-env run == a 256-env run with env_id_offset 256."""
     N = 512

@@ -391,6 +391,32 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
     F.force = v3(AT(B.contact_forces, 3 * b, e), AT(B.contact_forces, 3 * b + 1, e), AT(B.contact_forces, 3 * b + 2, e));
     F.fnorm = norm(F.force);
   }
+  // ---- measured terrain heights (_get_heights, reference legged_robot.py:1772-1806): 187 points over the quad ----
+  float mean_height = 0.f;
+  if (cfg.measure_heights && B.measured_heights) {
+    const int np = cfg.num_height_x * cfg.num_height_y;
+    const float l = rsqrtf(d.qz * d.qz + d.qw * d.qw);       // quat_apply_yaw: yaw-only rotation of the scan pattern
+    const float yz = d.qz * l, yw = d.qw * l;
+    const float bx = AT(B.root_states, 0, e), by = AT(B.root_states, 1, e);
+    float sum = 0.f;
+#pragma unroll 1
+    for (int p = leg; p < np; p += 4) {
+      V3 w = quat_rotate(0.f, 0.f, yz, yw, v3(cfg.height_points_x[p / cfg.num_height_y], cfg.height_points_y[p % cfg.num_height_y], 0.f));
+      float hgt = 0.f;
+      if (cfg.terrain_type != 0 && B.height_samples) {
+        long px = (long)((w.x + bx + cfg.hf_border) / cfg.hf_hscale), py = (long)((w.y + by + cfg.hf_border) / cfg.hf_hscale);
+        px = px < 0 ? 0 : (px > cfg.hf_rows - 2 ? cfg.hf_rows - 2 : px);
+        py = py < 0 ? 0 : (py > cfg.hf_cols - 2 ? cfg.hf_cols - 2 : py);
+        const int16_t* q = B.height_samples + px * cfg.hf_cols + py;
+        int16_t hm = q[0] < q[cfg.hf_cols] ? q[0] : q[cfg.hf_cols];
+        hm = hm < q[1] ? hm : q[1];
+        hgt = hm * cfg.hf_vscale;
+      }
+      AT(B.measured_heights, p, e) = hgt;
+      sum += hgt;
+    }
+    mean_height = quad_sum(sum) / np;
+  }
   // ---- check_termination ---------------------------------------------------------------------------
   float term = 0.f;
 #pragma unroll
@@ -402,7 +428,7 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
   bool reset = quad_sum(term) > 0.f;
   const bool time_out = ep_len > cfg.max_episode_length;
   reset = reset || time_out;
-  if (cfg.use_terminal_body_height && root_z < cfg.terminal_body_height) reset = true;
+  if (cfg.use_terminal_body_height && root_z - mean_height < cfg.terminal_body_height) reset = true;
   if (is0) { B.time_out_buf[e] = (uint8_t)time_out; B.reset_buf[e] = (uint8_t)reset; }
 
   // ---- compute_reward ----------------------------------------------------------------------------------
@@ -487,6 +513,19 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
       n += 1;
     }
     if (cfg.observe_contact_states) { emit(n + leg, F.force.z > 1.0f ? 1.0f : 0.0f); n += 4; }
+    if (cfg.observe_heights && cfg.measure_heights && B.measured_heights) {      // legacy legged_gym height block (BASELINE config 3)
+      const int np = cfg.num_height_x * cfg.num_height_y;
+      const float z = AT(B.root_states, 2, e);
+#pragma unroll 1
+      for (int p = leg; p < np; p += 4) {
+        float v = fminf(fmaxf(z - 0.5f - AT(B.measured_heights, p, e), -1.f), 1.f) * cfg.obs_scale_height;
+        if (cfg.add_noise && cfg.height_noise_scale != 0.f) v += (2 * rng_uniform(cfg, eg, counter_post, P_NOISE, n + p) - 1) * cfg.height_noise_scale;
+        v = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations);
+        obs_row[n + p] = v;
+        if (h0) { h0[n + p] = v; h1[n + p] = v; }
+      }
+      n += np;
+    }
 
     if (is0) {
       float* pv = B.privileged_obs_buf + (size_t)e * cfg.num_privileged_obs;

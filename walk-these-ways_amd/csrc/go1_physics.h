@@ -26,13 +26,14 @@
 
 // ---- LDS map (floats), index = field * EPW + env_local ---------------------------------------------
 enum {
-  L_LAM = 0,            // 17 x (n, t1, t2) impulses per reported body
+  L_LAM = 0,            // 17 x world impulse (x, y, z) per reported body: solver output / warm start
   L_CX = 51,            // MAXC x 3 contact points (rel. base origin)
-  L_VSTAR = 69,         // MAXC
-  L_BV = 75,            // MAXC x 3  b = J v_free
-  L_LS = 93,            // MAXC x 3  slot impulses
-  L_W = 111,            // NR x NR Delassus matrix
-  L_END = 111 + NR * NR
+  L_CN = 69,            // MAXC x 3 contact normals
+  L_VSTAR = 87,         // MAXC
+  L_BV = 93,            // MAXC x 3  b = J v_free
+  L_LS = 111,           // MAXC x 3  slot impulses (n, t1, t2)
+  L_W = 129,            // NR x NR Delassus matrix
+  L_END = 129 + NR * NR
 };
 #define LDS(f) lds[(f) * EPW + el]
 
@@ -139,28 +140,59 @@ struct Base {             // replicated in the 4 lanes of the environment
 
 DEV V3 model_v3(const float (*tab)[3], int i) { return v3(tab[i][0], tab[i][1], tab[i][2]); }
 
-struct Cand { float phi, x, y, z, un; };     // deepest contact candidate of one reported body
-DEV void cand_init(Cand& c) { c.phi = 1e30f; c.x = c.y = c.z = c.un = 0.f; }
-// x: candidate point relative to the base origin (world axes); plane terrain: height 0, normal +z
-DEV void cand_try(Cand& c, V3 x, float base_z, float radius, SV vb) {
-  float phi = (base_z + x.z) - radius;
+struct Cand { float phi, x, y, z, un, nx, ny, nz; };     // deepest contact candidate of one reported body
+DEV void cand_init(Cand& c) { c.phi = 1e30f; c.x = c.y = c.z = c.un = 0.f; c.nx = c.ny = 0.f; c.nz = 1.f; }
+
+// terrain height and unit normal at world (x, y): plane, or bilinear interpolation of the int16 height field
+// (same sample convention as _get_heights, reference legged_robot.py:1793-1806; oracle terrain_sample())
+DEV void terrain_sample(const Go1SimConfig& cfg, const int16_t* __restrict__ hs, float x, float y, float& h, V3& n) {
+  if (cfg.terrain_type == 0 || hs == nullptr) { h = 0.f; n = v3(0.f, 0.f, 1.f); return; }
+  float fx = (x + cfg.hf_border) / cfg.hf_hscale, fy = (y + cfg.hf_border) / cfg.hf_hscale;
+  fx = fminf(fmaxf(fx, 0.f), (float)cfg.hf_rows - 1.000001f);
+  fy = fminf(fmaxf(fy, 0.f), (float)cfg.hf_cols - 1.000001f);
+  const int ix = (int)fx, iy = (int)fy;
+  const float ax = fx - ix, ay = fy - iy;
+  const int16_t* p = hs + (size_t)ix * cfg.hf_cols + iy;
+  const float h00 = p[0] * cfg.hf_vscale, h01 = p[1] * cfg.hf_vscale, h10 = p[cfg.hf_cols] * cfg.hf_vscale, h11 = p[cfg.hf_cols + 1] * cfg.hf_vscale;
+  h = h00 * (1.f - ax) * (1.f - ay) + h10 * ax * (1.f - ay) + h01 * (1.f - ax) * ay + h11 * ax * ay;
+  const float dhdx = ((h10 - h00) * (1.f - ay) + (h11 - h01) * ay) / cfg.hf_hscale;
+  const float dhdy = ((h01 - h00) * (1.f - ax) + (h11 - h10) * ax) / cfg.hf_hscale;
+  const float inv = rsqrtf(dhdx * dhdx + dhdy * dhdy + 1.f);
+  n = v3(-dhdx * inv, -dhdy * inv, inv);
+}
+
+// x: candidate point relative to the base origin (world axes); bpos: world position of the base origin
+DEV void cand_try(const Go1SimConfig& cfg, const int16_t* __restrict__ hs, Cand& c, V3 x, V3 bpos, float radius, SV vb) {
+  float h;
+  V3 n;
+  terrain_sample(cfg, hs, bpos.x + x.x, bpos.y + x.y, h, n);
+  float phi = (bpos.z + x.z) - radius - h;
   if (phi < c.phi) {
-    V3 xs = v3(x.x, x.y, x.z - radius);
+    V3 xs = x - radius * n;               // contact point on the shape surface
     V3 vp = vb.l + cross(vb.a, xs);
-    c.phi = phi; c.x = xs.x; c.y = xs.y; c.z = xs.z; c.un = vp.z;
+    c.phi = phi; c.x = xs.x; c.y = xs.y; c.z = xs.z; c.un = dot(n, vp);
+    c.nx = n.x; c.ny = n.y; c.nz = n.z;
   }
 }
 DEV void cand_min_dpp(Cand& c, int lane) {      // quad-wide deepest candidate (ties: lower leg index, as the serial scan)
 #pragma unroll
   for (int step = 0; step < 2; step++) {
     Cand o;
-    if (step == 0) { o.phi = dpp_xor1(c.phi); o.x = dpp_xor1(c.x); o.y = dpp_xor1(c.y); o.z = dpp_xor1(c.z); o.un = dpp_xor1(c.un); }
-    else           { o.phi = dpp_xor2(c.phi); o.x = dpp_xor2(c.x); o.y = dpp_xor2(c.y); o.z = dpp_xor2(c.z); o.un = dpp_xor2(c.un); }
+    if (step == 0) { o.phi = dpp_xor1(c.phi); o.x = dpp_xor1(c.x); o.y = dpp_xor1(c.y); o.z = dpp_xor1(c.z); o.un = dpp_xor1(c.un);
+                     o.nx = dpp_xor1(c.nx); o.ny = dpp_xor1(c.ny); o.nz = dpp_xor1(c.nz); }
+    else           { o.phi = dpp_xor2(c.phi); o.x = dpp_xor2(c.x); o.y = dpp_xor2(c.y); o.z = dpp_xor2(c.z); o.un = dpp_xor2(c.un);
+                     o.nx = dpp_xor2(c.nx); o.ny = dpp_xor2(c.ny); o.nz = dpp_xor2(c.nz); }
     const int bit = step == 0 ? 1 : 2;
     const bool other_is_lower = ((lane & bit) != 0);
     bool take = (o.phi < c.phi) || (o.phi == c.phi && other_is_lower);
     if (take) c = o;
   }
+}
+// contact frame: normal n, t1 = x-axis projected on the tangent plane, t2 = n x t1 (oracle detect_contacts())
+DEV void contact_frame(V3 n, V3& t1, V3& t2) {
+  V3 t = v3(1.f - n.x * n.x, -n.x * n.y, -n.x * n.z);
+  t1 = rsqrtf(dot(t, t)) * t;
+  t2 = cross(n, t1);
 }
 
 // velocity change of the lane's own leg body at `depth` for the current impulse-propagation state
@@ -177,7 +209,7 @@ DEV SV leg_response(const SV S[3], const SV U[3], const float Dinv[3], SV a0, in
   return a;
 }
 
-DEV void physics_substep(const Go1SimConfig& cfg, float* lds, int lane, Base& s, Leg& L, V3 grav, bool use_warm, float h) {
+DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs, float* lds, int lane, Base& s, Leg& L, V3 grav, bool use_warm, float h) {
   const int leg = lane & 3, el = lane >> 2;
   const M3 R0 = quat_to_mat(s.qx, s.qy, s.qz, s.qw);
   const SV v0 = sv(s.w, s.v);
@@ -203,7 +235,7 @@ DEV void physics_substep(const Go1SimConfig& cfg, float* lds, int lane, Base& s,
   for (int mm = 0; mm < 2; mm++) {
     const int m = 2 * leg + mm;
     V3 l = v3((m & 1 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[2]);
-    cand_try(cbase, mul(R0, l), s.pos.z, 0.f, v0);
+    cand_try(cfg, hs, cbase, mul(R0, l), s.pos, 0.f, v0);
   }
   cand_min_dpp(cbase, lane);
 
@@ -251,23 +283,23 @@ DEV void physics_substep(const Go1SimConfig& cfg, float* lds, int lane, Base& s,
 #pragma unroll
       for (int m = 0; m < 2; m++) {
         V3 l = v3(hc.x, hc.y + (m ? 1.f : -1.f) * (float)GO1_HIP_CAPSULE_HALF, hc.z);
-        cand_try(cand[0], p[0] + mul(R[0], l), s.pos.z, (float)GO1_HIP_CAPSULE_RADIUS, v[0]);
+        cand_try(cfg, hs, cand[0], p[0] + mul(R[0], l), s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0]);
       }
 #pragma unroll 1
       for (int m = 0; m < 8; m++) {
         V3 l = v3(GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[0],
                   GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[1],
                   GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[2]);
-        cand_try(cand[1], p[1] + mul(R[1], l), s.pos.z, 0.f, v[1]);
+        cand_try(cfg, hs, cand[1], p[1] + mul(R[1], l), s.pos, 0.f, v[1]);
       }
 #pragma unroll 1
       for (int m = 0; m < 8; m++) {
         V3 l = v3(GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[0],
                   GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[1],
                   GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[2]);
-        cand_try(cand[2], p[2] + mul(R[2], l), s.pos.z, 0.f, v[2]);
+        cand_try(cfg, hs, cand[2], p[2] + mul(R[2], l), s.pos, 0.f, v[2]);
       }
-      cand_try(cand[3], p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos.z, (float)GO1_FOOT_RADIUS, v[2]);
+      cand_try(cfg, hs, cand[3], p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2]);
     }
     // ABA pass 2: calf -> thigh -> hip, then quad-sum into the base
     SV pa_hip;
@@ -329,11 +361,19 @@ DEV void physics_substep(const Go1SimConfig& cfg, float* lds, int lane, Base& s,
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int b = 1 + 4 * leg + i;
-#pragma unroll
-    for (int r = 0; r < 3; r++) lam0[i][r] = (slot[i] >= 0 && use_warm) ? LDS(L_LAM + 3 * b + r) : 0.f;
+    V3 wl = v3(LDS(L_LAM + 3 * b), LDS(L_LAM + 3 * b + 1), LDS(L_LAM + 3 * b + 2));
+    V3 n = v3(cand[i].nx, cand[i].ny, cand[i].nz), t1, t2;
+    contact_frame(n, t1, t2);
+    const bool w = slot[i] >= 0 && use_warm;
+    lam0[i][0] = w ? dot(wl, n) : 0.f; lam0[i][1] = w ? dot(wl, t1) : 0.f; lam0[i][2] = w ? dot(wl, t2) : 0.f;
   }
-#pragma unroll
-  for (int r = 0; r < 3; r++) lamb[r] = (sbase >= 0 && use_warm) ? LDS(L_LAM + r) : 0.f;
+  {
+    V3 wl = v3(LDS(L_LAM), LDS(L_LAM + 1), LDS(L_LAM + 2));
+    V3 n = v3(cbase.nx, cbase.ny, cbase.nz), t1, t2;
+    contact_frame(n, t1, t2);
+    const bool w = sbase >= 0 && use_warm;
+    lamb[0] = w ? dot(wl, n) : 0.f; lamb[1] = w ? dot(wl, t1) : 0.f; lamb[2] = w ? dot(wl, t2) : 0.f;
+  }
 
   // publish own contacts: point, target normal velocity, b = J v_free, start impulse
 #pragma unroll
@@ -352,7 +392,10 @@ DEV void physics_substep(const Go1SimConfig& cfg, float* lds, int lane, Base& s,
         if (j <= depth) vb = vb + qd_free[j] * S[j];
       V3 xk = v3(c.x, c.y, c.z);
       V3 vp = vb.l + cross(vb.a, xk);
-      LDS(L_BV + 3 * k) = vp.z; LDS(L_BV + 3 * k + 1) = vp.x; LDS(L_BV + 3 * k + 2) = vp.y;       // (n, t1, t2) = (z, x, y)
+      V3 n = v3(c.nx, c.ny, c.nz), t1, t2;
+      contact_frame(n, t1, t2);
+      LDS(L_CN + 3 * k) = n.x; LDS(L_CN + 3 * k + 1) = n.y; LDS(L_CN + 3 * k + 2) = n.z;
+      LDS(L_BV + 3 * k) = dot(n, vp); LDS(L_BV + 3 * k + 1) = dot(t1, vp); LDS(L_BV + 3 * k + 2) = dot(t2, vp);
       LDS(L_LS + 3 * k) = lam0[i][0]; LDS(L_LS + 3 * k + 1) = lam0[i][1]; LDS(L_LS + 3 * k + 2) = lam0[i][2];
     }
   }
@@ -364,7 +407,10 @@ DEV void physics_substep(const Go1SimConfig& cfg, float* lds, int lane, Base& s,
     LDS(L_VSTAR + k) = vs;
     V3 xk = v3(cbase.x, cbase.y, cbase.z);
     V3 vp = v_free + cross(w_free, xk);
-    LDS(L_BV + 3 * k) = vp.z; LDS(L_BV + 3 * k + 1) = vp.x; LDS(L_BV + 3 * k + 2) = vp.y;
+    V3 n = v3(cbase.nx, cbase.ny, cbase.nz), t1, t2;
+    contact_frame(n, t1, t2);
+    LDS(L_CN + 3 * k) = n.x; LDS(L_CN + 3 * k + 1) = n.y; LDS(L_CN + 3 * k + 2) = n.z;
+    LDS(L_BV + 3 * k) = dot(n, vp); LDS(L_BV + 3 * k + 1) = dot(t1, vp); LDS(L_BV + 3 * k + 2) = dot(t2, vp);
     LDS(L_LS + 3 * k) = lamb[0]; LDS(L_LS + 3 * k + 1) = lamb[1]; LDS(L_LS + 3 * k + 2) = lamb[2];
   }
   // clear the per-body impulses (re-filled for the listed bodies after the solve)
@@ -386,9 +432,11 @@ DEV void physics_substep(const Go1SimConfig& cfg, float* lds, int lane, Base& s,
     for (int i = 0; i < 4; i++) if (slot[i] == k) mydepth = i > 2 ? 2 : i;
     const bool mine = mydepth >= 0;
     const bool base_col = (sbase == k);
+    V3 nk = v3(LDS(L_CN + 3 * k), LDS(L_CN + 3 * k + 1), LDS(L_CN + 3 * k + 2)), t1k, t2k;
+    contact_frame(nk, t1k, t2k);
 #pragma unroll 1
     for (int r = 0; r < 3; r++) {
-      V3 d = r == 0 ? v3(0.f, 0.f, 1.f) : r == 1 ? v3(1.f, 0.f, 0.f) : v3(0.f, 1.f, 0.f);
+      V3 d = r == 0 ? nk : r == 1 ? t1k : t2k;
       SV f = sv(cross(x, d), d);
       float pu[3] = {0.f, 0.f, 0.f};
       SV contrib = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
@@ -417,17 +465,21 @@ DEV void physics_substep(const Go1SimConfig& cfg, float* lds, int lane, Base& s,
           SV ab = leg_response(S, U, Dinv, a0c, depth, mine, mydepth, pu);
           V3 x2 = v3(cand[i].x, cand[i].y, cand[i].z);
           V3 vp = ab.l + cross(ab.a, x2);
-          LDS(L_W + (3 * k2 + 0) * NR + 3 * k + r) = vp.z;
-          LDS(L_W + (3 * k2 + 1) * NR + 3 * k + r) = vp.x;
-          LDS(L_W + (3 * k2 + 2) * NR + 3 * k + r) = vp.y;
+          V3 n2 = v3(cand[i].nx, cand[i].ny, cand[i].nz), t12, t22;
+          contact_frame(n2, t12, t22);
+          LDS(L_W + (3 * k2 + 0) * NR + 3 * k + r) = dot(n2, vp);
+          LDS(L_W + (3 * k2 + 1) * NR + 3 * k + r) = dot(t12, vp);
+          LDS(L_W + (3 * k2 + 2) * NR + 3 * k + r) = dot(t22, vp);
         }
       }
       if (sbase >= 0 && leg == 0) {
         V3 x2 = v3(cbase.x, cbase.y, cbase.z);
         V3 vp = a0c.l + cross(a0c.a, x2);
-        LDS(L_W + (3 * sbase + 0) * NR + 3 * k + r) = vp.z;
-        LDS(L_W + (3 * sbase + 1) * NR + 3 * k + r) = vp.x;
-        LDS(L_W + (3 * sbase + 2) * NR + 3 * k + r) = vp.y;
+        V3 n2 = v3(cbase.nx, cbase.ny, cbase.nz), t12, t22;
+        contact_frame(n2, t12, t22);
+        LDS(L_W + (3 * sbase + 0) * NR + 3 * k + r) = dot(n2, vp);
+        LDS(L_W + (3 * sbase + 1) * NR + 3 * k + r) = dot(t12, vp);
+        LDS(L_W + (3 * sbase + 2) * NR + 3 * k + r) = dot(t22, vp);
       }
     }
   }
@@ -474,9 +526,11 @@ DEV void physics_substep(const Go1SimConfig& cfg, float* lds, int lane, Base& s,
     if (slot[i] >= 0) {
       const int k = slot[i], b = 1 + 4 * leg + i;
       const float ln = LDS(L_LS + 3 * k), l1 = LDS(L_LS + 3 * k + 1), l2 = LDS(L_LS + 3 * k + 2);
-      LDS(L_LAM + 3 * b) = ln; LDS(L_LAM + 3 * b + 1) = l1; LDS(L_LAM + 3 * b + 2) = l2;
+      V3 n = v3(cand[i].nx, cand[i].ny, cand[i].nz), t1, t2;
+      contact_frame(n, t1, t2);
+      V3 f = ln * n + l1 * t1 + l2 * t2;           // world impulse
+      LDS(L_LAM + 3 * b) = f.x; LDS(L_LAM + 3 * b + 1) = f.y; LDS(L_LAM + 3 * b + 2) = f.z;
       V3 x = v3(cand[i].x, cand[i].y, cand[i].z);
-      V3 f = v3(l1, l2, ln);
       SV ff = sv(cross(x, f), f);
       const int depth = i > 2 ? 2 : i;
 #pragma unroll
@@ -495,9 +549,11 @@ DEV void physics_substep(const Go1SimConfig& cfg, float* lds, int lane, Base& s,
   }
   if (sbase >= 0 && leg == 0) {
     const float ln = LDS(L_LS + 3 * sbase), l1 = LDS(L_LS + 3 * sbase + 1), l2 = LDS(L_LS + 3 * sbase + 2);
-    LDS(L_LAM) = ln; LDS(L_LAM + 1) = l1; LDS(L_LAM + 2) = l2;
+    V3 n = v3(cbase.nx, cbase.ny, cbase.nz), t1, t2;
+    contact_frame(n, t1, t2);
+    V3 f = ln * n + l1 * t1 + l2 * t2;
+    LDS(L_LAM) = f.x; LDS(L_LAM + 1) = f.y; LDS(L_LAM + 2) = f.z;
     V3 x = v3(cbase.x, cbase.y, cbase.z);
-    V3 f = v3(l1, l2, ln);
     contrib = contrib - sv(cross(x, f), f);
   }
   SV dv0 = -sym6_mul(I0inv, quad_sum(contrib));
@@ -594,10 +650,9 @@ DEV void load_lambda(const Go1SimConfig& cfg, const Go1SimBuffers& B, float* lds
 #pragma unroll
   for (int i = 0; i < 5; i++) {
     if (i == 4 && leg != 0) continue;
-    const int b = (i == 4) ? 0 : 1 + 4 * leg + i;       // world force -> (n, t1, t2) = (z, x, y) impulses
-    LDS(L_LAM + 3 * b) = zero ? 0.f : AT(B.contact_forces, 3 * b + 2, e) * cfg.sim_dt;
-    LDS(L_LAM + 3 * b + 1) = zero ? 0.f : AT(B.contact_forces, 3 * b, e) * cfg.sim_dt;
-    LDS(L_LAM + 3 * b + 2) = zero ? 0.f : AT(B.contact_forces, 3 * b + 1, e) * cfg.sim_dt;
+    const int b = (i == 4) ? 0 : 1 + 4 * leg + i;       // world force -> world impulse
+#pragma unroll
+    for (int c = 0; c < 3; c++) LDS(L_LAM + 3 * b + c) = zero ? 0.f : AT(B.contact_forces, 3 * b + c, e) * cfg.sim_dt;
   }
 }
 DEV void store_forces(const Go1SimConfig& cfg, const Go1SimBuffers& B, const float* lds, int lane, int e, int N) {
@@ -607,8 +662,7 @@ DEV void store_forces(const Go1SimConfig& cfg, const Go1SimBuffers& B, const flo
   for (int i = 0; i < 5; i++) {
     if (i == 4 && leg != 0) continue;
     const int b = (i == 4) ? 0 : 1 + 4 * leg + i;
-    AT(B.contact_forces, 3 * b, e) = LDS(L_LAM + 3 * b + 1) * inv;
-    AT(B.contact_forces, 3 * b + 1, e) = LDS(L_LAM + 3 * b + 2) * inv;
-    AT(B.contact_forces, 3 * b + 2, e) = LDS(L_LAM + 3 * b) * inv;
+#pragma unroll
+    for (int c = 0; c < 3; c++) AT(B.contact_forces, 3 * b + c, e) = LDS(L_LAM + 3 * b + c) * inv;
   }
 }

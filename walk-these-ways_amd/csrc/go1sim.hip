@@ -72,7 +72,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
 #endif
     head = (head + 1) % nl;
 #ifndef GO1_ABLATE_PHYSICS
-    physics_substep(cfg, lds, lane, s, L, grav, warm || (cfg.warm_start && sub > 0), h);
+    physics_substep(cfg, B.height_samples, lds, lane, s, L, grav, warm || (cfg.warm_start && sub > 0), h);
 #endif
   }
   store_state(B, leg, e, N, s, L);
@@ -112,7 +112,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) L.tau[jj] = AT(B.torques, 3 * leg + jj, e);
   load_lambda(cfg, B, lds, lane, e, N, false);
-  physics_substep(cfg, lds, lane, s, L, grav, cfg.warm_start != 0, cfg.sim_dt);
+  physics_substep(cfg, B.height_samples, lds, lane, s, L, grav, cfg.warm_start != 0, cfg.sim_dt);
   store_state(B, leg, e, N, s, L);
   foot_state(s, L, leg, B, e, N);
   store_forces(cfg, B, lds, lane, e, N);
@@ -204,8 +204,10 @@ struct Go1Sim {
 static int check_cfg(const Go1SimConfig* cfg) {
   if (!cfg || cfg->abi_version != GO1SIM_ABI_VERSION) return -2;
   if (cfg->num_envs <= 0 || cfg->lag_timesteps + 1 > GO1_MAX_LAG) return -3;
-  if (cfg->num_obs > GO1_MAX_OBS || cfg->num_privileged_obs > GO1_MAX_PRIV_OBS || cfg->num_rewards > GO1_MAX_REWARDS) return -4;
-  if (cfg->terrain_type != 0) return -5;       // height-field contact: SURVEY.md §8 config 3, next row
+  const int scan = cfg->observe_heights ? cfg->num_height_x * cfg->num_height_y : 0;
+  if (cfg->num_obs - scan > GO1_MAX_OBS || cfg->num_privileged_obs > GO1_MAX_PRIV_OBS || cfg->num_rewards > GO1_MAX_REWARDS) return -4;
+  if (cfg->terrain_type != 0 && (cfg->hf_rows < 2 || cfg->hf_cols < 2)) return -5;
+  if (cfg->num_height_x > GO1_MAX_HEIGHT_AXIS || cfg->num_height_y > GO1_MAX_HEIGHT_AXIS) return -4;
   return 0;
 }
 
@@ -355,4 +357,4 @@ extern "C" int go1sim_read_timings(Go1Sim* s, float* ms, int32_t max, int32_t* c
   *count = (int32_t)have;
   return 0;
 }
-extern "C" const char* go1sim_version(void) { return "go1sim 0.2 (gfx950, abi 1, 4 lanes/env)"; }
+extern "C" const char* go1sim_version(void) { return "go1sim 0.3 (gfx950, abi 2, 4 lanes/env)"; }

@@ -139,8 +139,6 @@ class LeggedRobot(BaseTask):
         if mesh_type in ('heightfield', 'trimesh'):
             self.terrain = Terrain(cfg.terrain, self.num_train_envs)
             hs = self.terrain.heightsamples
-            if np.any(hs != hs.flat[0]):
-                raise NotImplementedError("height-field contact is the next scope row (BASELINE config 3)")
             self.height_samples = torch.tensor(hs).view(self.terrain.tot_rows, self.terrain.tot_cols).to(self.device)
         seed = int(getattr(cfg, "seed", getattr(cfg.env, "seed", 0)))
         offset = int(getattr(cfg.env, "env_id_offset", 0))
@@ -148,6 +146,10 @@ class LeggedRobot(BaseTask):
             cfg, num_envs=self.num_envs, seed=seed, env_id_offset=offset,
             solver_iterations=int(getattr(cfg.sim.physx, "num_solver_sweeps", 8)))
         self.buffers = B = H.SimBuffers(self.sim_config, self.sim_meta, self.device)
+        if mesh_type in ('heightfield', 'trimesh'):
+            # both mesh types are simulated on the height field's bilinear surface (utils/terrain.py docstring)
+            H.bind_height_field(self.sim_config, B, self.terrain.heightsamples, cfg.terrain.horizontal_scale,
+                                cfg.terrain.vertical_scale, cfg.terrain.border_size)
         self.num_dof = self.num_dofs = self.num_actuated_dof = 12
         self.num_bodies = 17
         self.dof_names = list(H.DOF_NAMES)
@@ -284,7 +286,7 @@ class LeggedRobot(BaseTask):
         self.episode_sums = {n: B.episode_sums[i] for i, n in enumerate(self.episode_sum_names)}
         self.command_sums = {n: B.command_sums[i] for i, n in enumerate(self.sim_meta["command_sum_names"])}
         self.common_step_counter = 0
-        self.measured_heights = 0
+        self.measured_heights = B.measured_heights.t() if S.measure_heights else 0
         self.add_noise = self.cfg.noise.add_noise
         self.extras = {"env_bins": B.env_command_bins, "train/episode": _EpisodeStats(self)}
         if self.cfg.env.send_timeouts:

@@ -135,7 +135,16 @@ def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curricu
     S.terrain_restitution = cfg.terrain.restitution
     S.solver_iterations = int(solver_iterations)
     S.warm_start = int(warm_start)
-    S.terrain_type = 0                                          # set by the env when a height field is bound
+    S.terrain_type = 0                                          # set by bind_height_field() when a height field is bound
+    S.measure_heights = int(ter_measure(cfg))
+    xs, ys = list(cfg.terrain.measured_points_x), list(cfg.terrain.measured_points_y)
+    assert len(xs) <= abi.GO1_MAX_HEIGHT_AXIS and len(ys) <= abi.GO1_MAX_HEIGHT_AXIS
+    S.num_height_x, S.num_height_y = len(xs), len(ys)
+    _fill(S.height_points_x, xs)
+    _fill(S.height_points_y, ys)
+    S.observe_heights = int(getattr(cfg.env, "observe_heights", False) and S.measure_heights)
+    S.obs_scale_height = cfg.obs_scales.height_measurements
+    S.height_noise_scale = cfg.noise_scales.height_measurements * cfg.noise.noise_level * cfg.obs_scales.height_measurements
 
     S.max_episode_length = int(math.ceil(cfg.env.episode_length_s / dt))
     S.resample_interval = int(cfg.commands.resampling_time / dt)
@@ -200,8 +209,11 @@ def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curricu
     _fill(S.commands_scale, cs)
     S.add_noise = int(cfg.noise.add_noise)
     nv = noise_scale_vec(cfg)
-    if env.num_observations > abi.GO1_MAX_OBS:
-        raise ValueError("num_observations exceeds GO1_MAX_OBS")
+    scan = S.num_height_x * S.num_height_y if S.observe_heights else 0
+    if len(nv) > abi.GO1_MAX_OBS:
+        raise ValueError("scalar observations exceed GO1_MAX_OBS")
+    if len(nv) + scan != env.num_observations:
+        raise ValueError(f"num_observations ({env.num_observations}) != assembled observation width ({len(nv) + scan})")
     _fill(S.noise_scale_vec, nv)
     S.clip_observations = cfg.normalization.clip_observations
     nz = cfg.normalization
@@ -275,6 +287,23 @@ def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curricu
     return S, meta
 
 
+def ter_measure(cfg):
+    return bool(cfg.terrain.measure_heights)
+
+
+def bind_height_field(S, buffers, heights_int16, hscale, vscale, border):
+    """`_create_heightfield` / `_create_trimesh` (legged_robot.py:1441-1479): hand the int16 height samples to the
+    simulator.  A constant field is served by the plane fast path (same physics, no gathers)."""
+    hs = torch.as_tensor(np.ascontiguousarray(heights_int16), dtype=torch.int16)
+    S.hf_rows, S.hf_cols = int(hs.shape[0]), int(hs.shape[1])
+    S.hf_hscale, S.hf_vscale, S.hf_border = float(hscale), float(vscale), float(border)
+    flat = bool((hs == hs.flatten()[0]).all()) and int(hs.flatten()[0]) == 0
+    S.terrain_type = 0 if flat else 1
+    buffers.tensors["height_samples"] = hs.to(buffers.device)
+    buffers.refresh_struct()
+    return S
+
+
 def noise_scale_vec(cfg):
     """`_get_noise_scale_vec` (legged_robot.py:1053-1120)."""
     env, ns, lvl, os_ = cfg.env, cfg.noise_scales, cfg.noise.noise_level, cfg.obs_scales
@@ -330,6 +359,7 @@ def _buffer_specs(S):
         "curriculum_weights": (f, (nc, nb)), "curriculum_cdf": (f, (nc, nb)), "curriculum_success": (i32, (nc, nb)),
         "obs_buf": (f, (N, S.num_obs)), "privileged_obs_buf": (f, (N, max(S.num_privileged_obs, 1))),
         "obs_history": (f, (N, 2 * (S.num_obs_history + 1) * S.num_obs)),
+        "measured_heights": (f, (max(S.num_height_x * S.num_height_y, 1), N)),
     }
 
 
