@@ -54,3 +54,44 @@ def test_bad_config_is_rejected_without_gpu():
     handle = ctypes.c_void_p()
     lib.go1sim_create.restype = ctypes.c_int
     assert lib.go1sim_create(ctypes.byref(cfg), ctypes.byref(abi.Go1SimBuffers()), 0, ctypes.byref(handle)) == -2
+
+
+# ---- libgo1ppo.so (include/go1ppo.h): fused PPO-update kernels ------------------------------------------------
+PPO_HEADER = os.path.join(os.path.dirname(__file__), "..", "include", "go1ppo.h")
+
+
+def ppo_declared_functions():
+    src = re.sub(r"/\*.*?\*/", "", open(PPO_HEADER).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(go1ppo_\w+)\s*\(", src)))
+
+
+def test_ppo_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    from go1_gym_learn.ppo_cse import fused
+    assert ppo_declared_functions() == sorted(fused.EXPORTED_SYMBOLS)
+    lib = fused.load_library(g.build_ppo_hip())
+    for name in ppo_declared_functions():
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.go1ppo_version()
+    # argument validation happens before any launch: callable without a GPU
+    assert lib.go1ppo_wgrad(None, 0, None, 0, 0, 0, 0, None, 0, None) == -1
+    assert lib.go1ppo_elu_fwd(None, 0, 0, 0, None, 0, 0, None, 0, 0, None) == -1
+
+
+def test_ppo_loss_args_mirror_matches_header():
+    """field order of the ctypes mirror == the C struct (names in declaration order)."""
+    from go1_gym_learn.ppo_cse import fused
+    src = re.sub(r"/\*.*?\*/", "", open(PPO_HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct \{(.*?)\} Go1PpoLossArgs;", src, flags=re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            names += [n.strip().lstrip("*") for n in re.sub(r"^(const\s+)?\w+\s*\*?", "", decl, count=1).split(",")]
+    assert names == [f[0] for f in fused.LossArgs._fields_]
+
+
+def test_fused_update_fails_loudly_without_library(tmp_path):
+    from go1_gym_learn.ppo_cse import fused
+    with pytest.raises(fused.Go1PpoLibraryMissing):
+        fused.load_library(str(tmp_path / "missing.so"))

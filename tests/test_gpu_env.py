@@ -119,13 +119,15 @@ def test_runner_learns_and_exports(tmp_path):
 
 
 def test_graph_replay_update_equals_eager_update():
-    """The HIP-graph replay of the mini-batch step must produce exactly what the eager launches produce."""
+    """The HIP-graph replay of the mini-batch step must produce exactly what the eager launches produce
+    (autograd path: deterministic kernels; the fused path accumulates with atomics and is compared with a
+    tolerance in test_gpu_ppo_fused.py)."""
     from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
     from go1_gym_learn.ppo_cse.ppo import PPO, PPO_Args
     N, T = 512, 8
     results = []
     for use_graphs in (False, True):
-        PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs = True, use_graphs
+        PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs, PPO_Args.use_fused_kernels = True, use_graphs, False
         torch.manual_seed(0)
         alg = PPO(ActorCritic(70, 2, 2100, 12), device="cuda:0")
         alg.init_storage(N, T, [70], [2], [2100], [12])
@@ -144,7 +146,7 @@ def test_graph_replay_update_equals_eager_update():
             losses = alg.update()
         assert (alg._graphs is not None) == use_graphs
         results.append((alg.master.clone(), losses, alg.learning_rate))
-    PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs = False, True
+    PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs, PPO_Args.use_fused_kernels = False, True, True
     (w0, l0, lr0), (w1, l1, lr1) = results
     assert lr0 == lr1
     np.testing.assert_allclose(l0, l1, rtol=1e-5)

@@ -1,0 +1,383 @@
+// go1ppo.hip — fused kernels of the PPO update for gfx950 (C-ABI in include/go1ppo.h).
+//
+// The update of go1_gym_learn/ppo_cse/ppo.py:99-205 is a chain of small-MLP GEMMs (hipBLASLt, through torch.mm on
+// static buffers) glued by element-wise maps and reductions.  Those maps are the kernels of this file:
+//   elu_fwd   ELU (+ the actor's latent columns) in place on a column block of the fused first-layer output
+//   elu_bwd   dZ = dH * elu'(H) in place, with the bias gradient (column sums) accumulated on the way
+//   loss      surrogate / clipped value / entropy loss + KL, forward AND the analytic gradient w.r.t. mean, value,
+//             std and the head biases, gathering the rollout-storage rows through the mini-batch index
+//   mse       adaptation-module regression loss and gradient
+//   wgrad     dW = dZ^T H for the small layers (n, k <= 512, 24576-row reduction): bf16 MFMA 16x16x32 with the
+//             operands transposed through LDS, split over row chunks, fp32 atomic accumulation.  hipBLASLt serves
+//             these shapes with 16x16 macro-tiles at ~50-70 us; this kernel fills the chip with (n/64)(k/64)S blocks.
+// bf16 activations, fp32 math, fp32 parameter gradients.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/go1ppo.h"
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {          // round to nearest even (inputs are finite)
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+struct alignas(16) Bf8 { bf16_t v[8]; };
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+
+// ---------------------------------------------------------------------------------------------- elu_fwd
+__global__ __launch_bounds__(256) void elu_fwd_kernel(bf16_t* y, int64_t rows, int cols, int ld, const bf16_t* lat,
+                                                      int lat_ld, int npv, const bf16_t* wz, int wz_ld, int lat_cols) {
+  int cgs = cols >> 3;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cgs) return;
+  int64_t r = i / cgs;
+  int c0 = (int)(i - r * cgs) << 3;
+  Bf8* p = reinterpret_cast<Bf8*>(y + r * ld + c0);
+  Bf8 v = *p;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) x[e] = bf2f(v.v[e]);
+  if (lat && c0 < lat_cols) {
+    for (int q = 0; q < npv; q++) {
+      float l = bf2f(lat[r * lat_ld + q]);
+#pragma unroll
+      for (int e = 0; e < 8; e++) x[e] = fmaf(l, bf2f(wz[(int64_t)(c0 + e) * wz_ld + q]), x[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) v.v[e] = f2bf(elu1(x[e]));
+  *p = v;
+}
+
+// ---------------------------------------------------------------------------------------------- elu_bwd (+ column sums)
+// block = 256 threads = CG column groups (8 columns each) x 256/CG row lanes; one block covers RCHUNK rows.
+#define EB_RCHUNK 256
+__global__ __launch_bounds__(256) void elu_bwd_kernel(bf16_t* d, int ld_d, const bf16_t* h, int ld_h, int64_t rows, int cols,
+                                                      float* bias_grad, int cg_per_block) {
+  __shared__ float red[256 * 8];
+  int cgi = threadIdx.x % cg_per_block, rl = threadIdx.x / cg_per_block, rlanes = 256 / cg_per_block;
+  int c0 = (blockIdx.x * cg_per_block + cgi) << 3;
+  int64_t r0 = (int64_t)blockIdx.y * EB_RCHUNK;
+  int64_t r1 = r0 + EB_RCHUNK < rows ? r0 + EB_RCHUNK : rows;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < cols) {
+    for (int64_t r = r0 + rl; r < r1; r += rlanes) {
+      Bf8* pd = reinterpret_cast<Bf8*>(d + r * ld_d + c0);
+      Bf8 g = *pd;
+      if (h) {
+        Bf8 a = *reinterpret_cast<const Bf8*>(h + r * ld_h + c0);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          float hv = bf2f(a.v[e]);
+          float dz = bf2f(g.v[e]) * (hv > 0.f ? 1.f : hv + 1.f);
+          g.v[e] = f2bf(dz);
+          s[e] += bf2f(g.v[e]);
+        }
+        *pd = g;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) s[e] += bf2f(g.v[e]);
+      }
+    }
+  }
+  if (!bias_grad) return;
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[(rl * cg_per_block + cgi) * 8 + e] = s[e];
+  __syncthreads();
+  for (int o = threadIdx.x; o < cg_per_block * 8; o += 256) {
+    int c = (blockIdx.x * cg_per_block << 3) + o;
+    if (c >= cols) continue;
+    float t = 0.f;
+    for (int q = 0; q < rlanes; q++) t += red[q * cg_per_block * 8 + o];
+    atomicAdd(bias_grad + c, t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- block reduction helper
+template <int NV>
+__device__ __forceinline__ void block_reduce_atomic(float (&v)[NV], float* const (&dst)[NV], float* lds /* [4][NV] */) {
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    float x = v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    v[i] = x;
+  }
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0)
+    for (int i = 0; i < NV; i++) lds[wave * NV + i] = v[i];
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += lds[w * NV + threadIdx.x];
+    if (dst[threadIdx.x]) atomicAdd(dst[threadIdx.x], t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- PPO loss
+// One thread per sample.  Everything the autograd graph of ppo.py:112-150 computes, in closed form:
+//   logp = -1/2 sum z^2 - sum log sigma - A c,  z = (a - mu)/sigma;   ratio = exp(logp - logp_old)
+//   surrogate = mean max(-adv ratio, -adv clamp(ratio, 1-eps, 1+eps))
+//   d surrogate / d logp = -adv ratio / M where the un-clamped branch is active (inside the clip range both
+//   branches coincide and torch.max splits the gradient half/half onto two identical paths), else 0
+//   value loss: max((v-R)^2, (v_old + clamp(v - v_old, -eps, eps) - R)^2), same tie rule
+//   entropy = sum log sigma + const (independent of the sample)
+__global__ __launch_bounds__(256) void loss_kernel(Go1PpoLossArgs a) {
+  __shared__ float lds[4 * (4 + 2 * GO1PPO_MAX_ACTIONS)];
+  const int A = a.num_actions;
+  int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool on = r < a.rows;
+  float invM = 1.f / (float)a.rows;
+  float sur = 0.f, vl = 0.f, kl = 0.f, dvb = 0.f;
+  float dstd[GO1PPO_MAX_ACTIONS], dmb[GO1PPO_MAX_ACTIONS];
+#pragma unroll
+  for (int j = 0; j < GO1PPO_MAX_ACTIONS; j++) dstd[j] = dmb[j] = 0.f;
+  if (on) {
+    int64_t s = a.idx[r];
+    const bf16_t* mrow = reinterpret_cast<const bf16_t*>(a.mean) + r * a.head_ld;
+    float mu[GO1PPO_MAX_ACTIONS], z[GO1PPO_MAX_ACTIONS], isg[GO1PPO_MAX_ACTIONS];
+    float logp = 0.f;
+    const float HALF_LOG_2PI = 0.9189385332046727f;
+#pragma unroll
+    for (int j = 0; j < GO1PPO_MAX_ACTIONS; j++) {
+      if (j < A) {
+        float sg = a.std[j];
+        mu[j] = bf2f(mrow[j]);
+        isg[j] = 1.f / sg;
+        z[j] = (a.actions[s * A + j] - mu[j]) * isg[j];
+        logp += -0.5f * z[j] * z[j] - logf(sg) - HALF_LOG_2PI;
+        float so = a.old_sigma[s * A + j], dm = a.old_mu[s * A + j] - mu[j];
+        kl += logf(sg / so + 1.e-5f) + (so * so + dm * dm) / (2.f * sg * sg) - 0.5f;
+      }
+    }
+    float adv = a.advantages[s];
+    float ratio = expf(logp - a.old_logp[s]);
+    float lo = 1.f - a.clip_param, hi = 1.f + a.clip_param;
+    float rc = fminf(fmaxf(ratio, lo), hi);
+    float s1 = -adv * ratio, s2 = -adv * rc;
+    sur = fmaxf(s1, s2) * invM;
+    float dratio = (ratio >= lo && ratio <= hi) ? -adv : (s1 > s2 ? -adv : 0.f);
+    float dlogp = dratio * ratio * invM;
+    bf16_t* drow = reinterpret_cast<bf16_t*>(a.d_mean) + r * a.head_ld;
+#pragma unroll
+    for (int j = 0; j < GO1PPO_MAX_ACTIONS; j++) {
+      if (j < A) {
+        bf16_t g = f2bf(dlogp * z[j] * isg[j]);
+        drow[j] = g;
+        dmb[j] = bf2f(g);
+        dstd[j] = dlogp * (z[j] * z[j] - 1.f) * isg[j];
+      }
+    }
+    float v = bf2f(reinterpret_cast<const bf16_t*>(a.value)[r * a.head_ld]);
+    float R = a.returns[s], dv;
+    if (a.use_clipped_value_loss) {
+      float vo = a.old_values[s];
+      float dlt = v - vo;
+      float vc = vo + fminf(fmaxf(dlt, -a.clip_param), a.clip_param);
+      float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+      vl = fmaxf(l1, l2) * invM;
+      bool inside = dlt >= -a.clip_param && dlt <= a.clip_param;
+      dv = inside ? 2.f * (v - R) : (l1 > l2 ? 2.f * (v - R) : 0.f);
+    } else {
+      vl = (R - v) * (R - v) * invM;
+      dv = 2.f * (v - R);
+    }
+    bf16_t g = f2bf(a.value_loss_coef * dv * invM);
+    reinterpret_cast<bf16_t*>(a.d_value)[r * a.head_ld] = g;
+    dvb = bf2f(g);
+    kl *= invM;
+  }
+  // reductions: [sur, vl, kl, dvb] then dstd[A], dmb[A]
+  {
+    float v4[4] = {sur, vl, kl, dvb};
+    float* const d4[4] = {a.surrogate_loss, a.value_loss, a.kl, a.d_value_bias};
+    block_reduce_atomic<4>(v4, d4, lds);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j0 = 0; j0 < GO1PPO_MAX_ACTIONS; j0 += 4) {
+    if (j0 < A) {      // uniform
+      float v8[8];
+      float* d8[8];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        bool ok = j0 + q < A;
+        v8[q] = ok ? dstd[j0 + q] : 0.f;
+        v8[4 + q] = ok ? dmb[j0 + q] : 0.f;
+        d8[q] = ok ? a.d_std + j0 + q : nullptr;
+        d8[4 + q] = ok ? a.d_mean_bias + j0 + q : nullptr;
+      }
+      float* const d8c[8] = {d8[0], d8[1], d8[2], d8[3], d8[4], d8[5], d8[6], d8[7]};
+      block_reduce_atomic<8>(v8, d8c, lds);
+      __syncthreads();
+    }
+  }
+  // entropy term: loss -= entropy_coef * (sum log sigma + const)  ->  d/d sigma_j = -entropy_coef / sigma_j  (once)
+  if (blockIdx.x == 0 && threadIdx.x < A) atomicAdd(a.d_std + threadIdx.x, -a.entropy_coef / a.std[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------- adaptation MSE
+__global__ __launch_bounds__(256) void mse_kernel(const bf16_t* pred, int pred_ld, const float* target, int npv, const int64_t* idx,
+                                                  int64_t rows, int64_t num_train, int selective, bf16_t* d_pred,
+                                                  float* d_pred_bias, float* train_loss, float* test_loss) {
+  __shared__ float lds[4 * 8];
+  int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int ncol = selective ? 1 : npv;
+  float ltrain = 0.f, ltest = 0.f;
+  float inv_train = 1.f / ((float)num_train * ncol), inv_test = 1.f / ((float)(rows - num_train) * ncol);
+  for (int j0 = 0; j0 < ncol; j0 += 6) {        // 6 columns of bias gradient per reduction round
+    float v8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < rows) {
+      int64_t s = idx[r];
+      for (int q = 0; q < 6 && j0 + q < ncol; q++) {
+        int j = j0 + q;
+        float e = bf2f(pred[r * pred_ld + j]) - target[s * npv + j];
+        if (r < num_train) {
+          ltrain += e * e * inv_train;
+          bf16_t g = f2bf(2.f * e * inv_train);
+          d_pred[r * pred_ld + j] = g;
+          v8[q] = bf2f(g);
+        } else {
+          ltest += e * e * inv_test;
+          d_pred[r * pred_ld + j] = 0;
+        }
+      }
+    }
+    bool last = j0 + 6 >= ncol;
+    v8[6] = last ? ltrain : 0.f;
+    v8[7] = last ? ltest : 0.f;
+    float* d8[8];
+    for (int q = 0; q < 6; q++) d8[q] = (j0 + q < ncol) ? d_pred_bias + j0 + q : nullptr;
+    d8[6] = last ? train_loss : nullptr;
+    d8[7] = last ? test_loss : nullptr;
+    float* const d8c[8] = {d8[0], d8[1], d8[2], d8[3], d8[4], d8[5], d8[6], d8[7]};
+    block_reduce_atomic<8>(v8, d8c, lds);
+    __syncthreads();
+  }
+  if (selective && r < rows)      // columns the selective loss ignores carry no gradient
+    for (int j = 1; j < npv; j++) d_pred[r * pred_ld + j] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------- wgrad (MFMA, split rows)
+// dW[n0+i][k0+j] += sum_m dz[m][n0+i] h[m][k0+j] for a 64x64 output tile and one row chunk per workgroup.
+// MFMA 16x16x32 bf16 wants, per lane, 8 consecutive reduction indices (m) for one output row/column, but both
+// operands are m-major in memory; the 32-row step is therefore transposed on its way into LDS
+// (At[n][m], Bt[k][m], rows padded to 40 elements = 80 B: 16-byte aligned b128 reads that tile all 64 banks).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+#define WG_LDM 40
+__global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* dz, int ld_dz, const bf16_t* h, int ld_h, int64_t rows,
+                                                    int chunk_rows, float* dW, int ldw) {
+  __shared__ __attribute__((aligned(16))) bf16_t At[2][64][WG_LDM];
+  __shared__ __attribute__((aligned(16))) bf16_t Bt[2][64][WG_LDM];
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int64_t m_begin = (int64_t)blockIdx.z * chunk_rows;
+  const int64_t m_end = m_begin + chunk_rows < rows ? m_begin + chunk_rows : rows;
+  const int t = threadIdx.x, lrow = t >> 3, cg = t & 7, wave = t >> 6, lane = t & 63;
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  Bf8 ra, rb;
+  auto gload = [&](int64_t m) {
+    int64_t r = m + lrow;
+    if (r < m_end) {
+      ra = *reinterpret_cast<const Bf8*>(dz + r * ld_dz + n0 + 8 * cg);
+      rb = *reinterpret_cast<const Bf8*>(h + r * ld_h + k0 + 8 * cg);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) ra.v[e] = rb.v[e] = 0;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      At[buf][8 * cg + e][lrow] = ra.v[e];
+      Bt[buf][8 * cg + e][lrow] = rb.v[e];
+    }
+  };
+  if (m_begin >= m_end) return;
+  gload(m_begin);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t m = m_begin; m < m_end; m += 32) {
+    bool more = m + 32 < m_end;
+    if (more) gload(m + 32);
+    bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(&At[buf][16 * wave + (lane & 15)][(lane >> 4) * 8]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      bf16x8_t bv = *reinterpret_cast<const bf16x8_t*>(&Bt[buf][16 * j + (lane & 15)][(lane >> 4) * 8]);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[j], 0, 0, 0);
+    }
+    if (more) sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int row = n0 + 16 * wave + (lane >> 4) * 4 + q, col = k0 + 16 * j + (lane & 15);
+      atomicAdd(dW + (int64_t)row * ldw + col, acc[j][q]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- C-ABI
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int go1ppo_elu_fwd(void* y, int64_t rows, int cols, int ld, const void* lat, int lat_ld, int npv, const void* wz,
+                              int wz_ld, int lat_cols, void* stream) {
+  if (!y || rows <= 0 || cols <= 0 || (cols & 7) || (ld & 7) || !aligned16(y)) return -1;
+  if (lat && (!wz || npv <= 0 || (lat_cols & 7))) return -2;
+  int64_t n = rows * (cols >> 3);
+  elu_fwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      (bf16_t*)y, rows, cols, ld, (const bf16_t*)lat, lat_ld, npv, (const bf16_t*)wz, wz_ld, lat_cols);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_elu_bwd(void* d, int ld_d, const void* h, int ld_h, int64_t rows, int cols, float* bias_grad, void* stream) {
+  if (!d || rows <= 0 || cols <= 0 || (cols & 7) || (ld_d & 7) || (h && (ld_h & 7)) || !aligned16(d) || (h && !aligned16(h))) return -1;
+  int cgs = cols >> 3;
+  int cgb = cgs >= 32 ? 32 : (cgs >= 16 ? 16 : 8);
+  dim3 grid((cgs + cgb - 1) / cgb, (unsigned)((rows + EB_RCHUNK - 1) / EB_RCHUNK));
+  elu_bwd_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>((bf16_t*)d, ld_d, (const bf16_t*)h, ld_h, rows, cols, bias_grad, cgb);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_loss(const Go1PpoLossArgs* a, void* stream) {
+  if (!a || a->rows <= 0 || a->num_actions <= 0 || a->num_actions > GO1PPO_MAX_ACTIONS || a->head_ld < a->num_actions) return -1;
+  loss_kernel<<<dim3((unsigned)((a->rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(*a);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_mse(const void* pred, int pred_ld, const float* target, int npv, const int64_t* idx, int64_t rows,
+                          int64_t num_train, int selective, void* d_pred, float* d_pred_bias, float* train_loss,
+                          float* test_loss, void* stream) {
+  if (!pred || !target || !idx || rows <= 0 || num_train <= 0 || num_train >= rows || npv <= 0 || npv > pred_ld) return -1;
+  mse_kernel<<<dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      (const bf16_t*)pred, pred_ld, target, npv, idx, rows, num_train, selective, (bf16_t*)d_pred, d_pred_bias, train_loss, test_loss);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_wgrad(const void* dz, int ld_dz, const void* h, int ld_h, int64_t rows, int n, int k, float* dW, int ldw,
+                            void* stream) {
+  if (!dz || !h || !dW || rows <= 0 || n <= 0 || k <= 0 || (n & 63) || (k & 63) || (ld_dz & 7) || (ld_h & 7) || !aligned16(dz) || !aligned16(h))
+    return -1;
+  int tiles = (n / 64) * (k / 64);
+  int64_t steps = (rows + 31) / 32;
+  int64_t S = 2048 / tiles;                 // ~8 workgroups per CU
+  if (S < 1) S = 1;
+  if (S > steps) S = steps;
+  if (S > 1024) S = 1024;
+  int64_t chunk_steps = (steps + S - 1) / S;
+  S = (steps + chunk_steps - 1) / chunk_steps;
+  wgrad_kernel<<<dim3(n / 64, k / 64, (unsigned)S), dim3(256), 0, (hipStream_t)stream>>>(
+      (const bf16_t*)dz, ld_dz, (const bf16_t*)h, ld_h, rows, (int)(chunk_steps * 32), dW, ldw);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" const char* go1ppo_version(void) { return "go1ppo 0.1 (gfx950, abi 1)"; }

@@ -41,7 +41,8 @@ class FlatPolicy:
         # ---- layout -------------------------------------------------------------------------------------
         self.blocks = []         # (name, shape)
         self.blocks.append(("W1", (sum(self.first), self.Kp)))
-        self.blocks.append(("Wz", (self.first[1], self.npv)))
+        assert self.npv <= HEAD_COLS
+        self.blocks.append(("Wz", (self.first[1], HEAD_COLS)))      # columns >= npv stay exactly zero
         for n, lins in self.nets.items():
             for li, lin in enumerate(lins[1:], start=1):
                 last = li == len(lins) - 1
@@ -84,7 +85,7 @@ class FlatPolicy:
             if n == "critic":
                 W1[r:r + rows, K + 1:K + 1 + npv].copy_(lin.weight[:, K:])
             elif n == "actor":
-                self._block(flat, "Wz").copy_(lin.weight[:, K:])
+                self._block(flat, "Wz")[:, :npv].copy_(lin.weight[:, K:])
             r += rows
         for n, lins in self.nets.items():
             for li, lin in enumerate(lins[1:], start=1):
@@ -105,7 +106,7 @@ class FlatPolicy:
             if n == "critic":
                 lin.weight[:, K:].copy_(W1[r:r + rows, K + 1:K + 1 + npv])
             elif n == "actor":
-                lin.weight[:, K:].copy_(self._block(flat, "Wz"))
+                lin.weight[:, K:].copy_(self._block(flat, "Wz")[:, :npv])
             r += rows
         for n, lins in self.nets.items():
             for li, lin in enumerate(lins[1:], start=1):

@@ -1,0 +1,247 @@
+"""Hand-scheduled forward / backward of the ActorCritic for the MI355X (no reference analogue: the reference lets
+autograd run go1_gym_learn/ppo_cse/ppo.py:99-205 as ~350 small kernels per mini-batch).
+
+Same mathematics as `FlatPolicy.forward` + autograd, organised as
+  * hipBLASLt GEMMs (torch.mm / torch.addmm with `out=`) on buffers allocated once per batch size,
+  * the fused element-wise / reduction / small-wgrad kernels of csrc/go1ppo.hip (C-ABI include/go1ppo.h) in between,
+  * parameter gradients written straight into the fp32 flat gradient the optimiser and the RCCL all-reduce use.
+The whole thing is capture-safe (static addresses, no host reads), so `PPO._capture` records it as a HIP graph.
+
+bf16 compute only (BASELINE config 2's "bf16 policy"); the fp32 / CPU path stays on autograd (`ppo.py`), which is
+also the checker for this one (tests/test_gpu_env.py).
+"""
+import ctypes
+import os
+
+import torch
+
+HEAD = 64
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libgo1ppo.so"))
+_lib = None
+
+
+class Go1PpoLibraryMissing(RuntimeError):
+    pass
+
+
+class LossArgs(ctypes.Structure):
+    _fields_ = [("mean", ctypes.c_void_p), ("value", ctypes.c_void_p), ("std", ctypes.c_void_p),
+                ("head_ld", ctypes.c_int32), ("num_actions", ctypes.c_int32), ("rows", ctypes.c_int64),
+                ("idx", ctypes.c_void_p), ("actions", ctypes.c_void_p), ("old_mu", ctypes.c_void_p),
+                ("old_sigma", ctypes.c_void_p), ("old_logp", ctypes.c_void_p), ("advantages", ctypes.c_void_p),
+                ("returns", ctypes.c_void_p), ("old_values", ctypes.c_void_p),
+                ("clip_param", ctypes.c_float), ("value_loss_coef", ctypes.c_float), ("entropy_coef", ctypes.c_float),
+                ("use_clipped_value_loss", ctypes.c_int32),
+                ("d_mean", ctypes.c_void_p), ("d_value", ctypes.c_void_p), ("d_std", ctypes.c_void_p),
+                ("d_mean_bias", ctypes.c_void_p), ("d_value_bias", ctypes.c_void_p), ("kl", ctypes.c_void_p),
+                ("value_loss", ctypes.c_void_p), ("surrogate_loss", ctypes.c_void_p)]
+
+
+EXPORTED_SYMBOLS = ["go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_version"]
+
+
+def load_library(path=None):
+    """dlopen libgo1ppo.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        raise Go1PpoLibraryMissing(f"{p} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                   "(hipcc --offload-arch=gfx950); the fused PPO update has no CPU fallback")
+    L = ctypes.CDLL(p)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    L.go1ppo_elu_fwd.argtypes = [vp, i64, i32, i32, vp, i32, i32, vp, i32, i32, vp]
+    L.go1ppo_elu_bwd.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp]
+    L.go1ppo_loss.argtypes = [ctypes.POINTER(LossArgs), vp]
+    L.go1ppo_mse.argtypes = [vp, i32, vp, i32, vp, i64, i64, i32, vp, vp, vp, vp, vp]
+    L.go1ppo_wgrad.argtypes = [vp, i32, vp, i32, i64, i32, i32, vp, i32, vp]
+    for name in EXPORTED_SYMBOLS[:-1]:
+        getattr(L, name).restype = ctypes.c_int
+    L.go1ppo_version.restype = ctypes.c_char_p
+    if path is None:
+        _lib = L
+    return L
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1
+    return t.stride(0)
+
+
+class FusedNet:
+    """Static-buffer forward (and optionally backward) of the three MLPs for a fixed row count M.
+
+    `body` is the bf16 flat parameter buffer (FlatPolicy layout), `grad` the fp32 flat gradient (or None for
+    inference-only engines)."""
+
+    def __init__(self, policy, body, grad, M, lib, with_grad):
+        assert body.dtype == torch.bfloat16 and body.is_cuda
+        self.pol, self.M, self.lib = policy, M, lib
+        dev = body.device
+        self.P = {name: policy._block(body, name) for name, _ in policy.blocks}
+        self.G = {name: policy._block(grad, name) for name, _ in policy.blocks} if grad is not None else None
+        self.nd, self.na, self.nc = policy.first
+        self.n1 = self.nd + self.na + self.nc
+        self.depth = {n: len(l) for n, l in policy.nets.items()}
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        self.Y1 = torch.zeros(M, self.n1, **bf)
+        self.Y1d = torch.zeros(M, self.nd, **bf)                # adaptation-only pass
+        self.Z = {n: {li: torch.zeros(M, self.P[f"{n}.{li}.W"].shape[0], **bf) for li in range(1, d)}
+                  for n, d in self.depth.items()}
+        assert policy.npv <= HEAD and self.P["Wz"].shape == (self.na, HEAD)
+        if with_grad:
+            self.X = torch.zeros(M, policy.Kp, **bf)
+            self.dY1 = torch.zeros(M, self.n1, **bf)
+            self.dY1d = torch.zeros(M, self.nd, **bf)
+            self.dZ = {n: {li: torch.zeros_like(z) for li, z in zs.items()} for n, zs in self.Z.items()}
+            self._w1_tmp = torch.zeros(self.n1, policy.Kp, **bf)
+            self._mm_f32 = self._probe_mm_out_dtype(dev)
+
+    @staticmethod
+    def _probe_mm_out_dtype(dev):
+        try:
+            a = torch.ones(64, 32, device=dev, dtype=torch.bfloat16)
+            o = torch.zeros(32, 32, device=dev)
+            torch.mm(a.t(), a, out_dtype=torch.float32, out=o)
+            return bool((o == 64).all())
+        except Exception:
+            return False
+
+    # ---- kernels -----------------------------------------------------------------------------------------
+    def _elu(self, y, lat=None, lat_cols=0):
+        wz = self.P["Wz"] if lat is not None else None
+        _chk(self.lib.go1ppo_elu_fwd(y.data_ptr(), y.shape[0], y.shape[1], _ld(y), _ptr(lat), _ld(lat) if lat is not None else 0,
+                                     self.pol.npv if lat is not None else 0, _ptr(wz), HEAD, lat_cols, _stream()), "go1ppo_elu_fwd")
+
+    def _elu_bwd(self, d, h, bias_grad):
+        _chk(self.lib.go1ppo_elu_bwd(d.data_ptr(), _ld(d), _ptr(h), _ld(h) if h is not None else 0, d.shape[0], d.shape[1],
+                                     _ptr(bias_grad), _stream()), "go1ppo_elu_bwd")
+
+    def _wgrad(self, dz, h, gW):
+        n, k = dz.shape[1], h.shape[1]
+        assert gW.shape == (n, k) and gW.is_contiguous()
+        _chk(self.lib.go1ppo_wgrad(dz.data_ptr(), _ld(dz), h.data_ptr(), _ld(h), dz.shape[0], n, k, gW.data_ptr(), k, _stream()),
+             "go1ppo_wgrad")
+
+    # ---- forward -------------------------------------------------------------------------------------------
+    def _tail(self, net, h):
+        P, d = self.P, self.depth[net]
+        for li in range(1, d):
+            z = self.Z[net][li]
+            torch.addmm(P[f"{net}.{li}.b"], h, P[f"{net}.{li}.W"].t(), out=z)
+            if li < d - 1:
+                self._elu(z)
+            h = z
+        return h
+
+    def forward(self, x):
+        """x: (M, Kp) augmented rows.  Returns (mean (M, HEAD), value (M, HEAD), latent (M, HEAD)) padded head
+        outputs (valid columns: num_actions / 1 / num_privileged_obs); views of static buffers."""
+        nd, na = self.nd, self.na
+        torch.mm(x, self.P["W1"].t(), out=self.Y1)
+        self._elu(self.Y1[:, :nd])
+        latent = self._tail("adaptation", self.Y1[:, :nd])
+        self._elu(self.Y1[:, nd:], latent, na)
+        mean = self._tail("actor", self.Y1[:, nd:nd + na])
+        value = self._tail("critic", self.Y1[:, nd + na:])
+        return mean, value, latent
+
+    def forward_adaptation(self, x):
+        torch.mm(x, self.P["W1"][:self.nd].t(), out=self.Y1d)
+        self._elu(self.Y1d)
+        return self._tail("adaptation", self.Y1d)
+
+    # ---- backward ------------------------------------------------------------------------------------------
+    def _tail_bwd(self, net, h0, dh0):
+        """Given dZ[net][last], accumulate the tail's parameter gradients and write d(loss)/d(h0) into dh0."""
+        P, G, d = self.P, self.G, self.depth[net]
+        for li in range(d - 1, 0, -1):
+            dz = self.dZ[net][li]
+            h_in = self.Z[net][li - 1] if li > 1 else h0
+            self._wgrad(dz, h_in, G[f"{net}.{li}.W"])
+            out = self.dZ[net][li - 1] if li > 1 else dh0
+            torch.mm(dz, P[f"{net}.{li}.W"], out=out)
+            if li > 1:
+                self._elu_bwd(out, h_in, G[f"{net}.{li - 1}.b"])
+
+    def _big_wgrad(self, dY, x, gW, tmp):
+        if self._mm_f32:
+            torch.mm(dY.t(), x, out_dtype=torch.float32, out=gW)
+        else:
+            torch.mm(dY.t(), x, out=tmp)
+            gW.copy_(tmp)
+
+    def backward(self, x):
+        """After forward(x) and a loss kernel that filled dZ[actor][last], dZ[critic][last] (+ their bias / std
+        gradients): everything else.  Gradients are ACCUMULATED into the (pre-zeroed) flat gradient."""
+        nd, na = self.nd, self.na
+        G = self.G
+        Y1, dY1 = self.Y1, self.dY1
+        self._tail_bwd("actor", Y1[:, nd:nd + na], dY1[:, nd:nd + na])
+        self._tail_bwd("critic", Y1[:, nd + na:], dY1[:, nd + na:])
+        self._elu_bwd(dY1[:, nd:], Y1[:, nd:], None)
+        # actor first layer's latent columns: a1 += latent Wz^T
+        last = self.depth["adaptation"] - 1
+        latent, dlat = self.Z["adaptation"][last], self.dZ["adaptation"][last]
+        dA1 = dY1[:, nd:nd + na]
+        self._wgrad(dA1, latent, G["Wz"])
+        torch.mm(dA1, self.P["Wz"], out=dlat)
+        self._elu_bwd(dlat, None, G[f"adaptation.{last}.b"])
+        self._tail_bwd("adaptation", Y1[:, :nd], dY1[:, :nd])
+        self._elu_bwd(dY1[:, :nd], Y1[:, :nd], None)
+        self._big_wgrad(dY1, x, G["W1"], self._w1_tmp)
+
+    def backward_adaptation(self, x):
+        nd = self.nd
+        self._tail_bwd("adaptation", self.Y1d, self.dY1d)
+        self._elu_bwd(self.dY1d, self.Y1d, None)
+        self._big_wgrad(self.dY1d, x, self.G["W1"][:nd], self._w1_tmp[:nd])
+
+    # ---- losses ----------------------------------------------------------------------------------------------
+    def ppo_loss(self, st, idx, std, g_std, A, kl, acc):
+        """st: RolloutStorage; acc: fp32 [value_loss, surrogate, ...] accumulators; kl: fp32 scalar (pre-zeroed)."""
+        la, lc = self.depth["actor"] - 1, self.depth["critic"] - 1
+        flat = lambda t: t.flatten(0, 1)
+        a = LossArgs()
+        a.mean, a.value, a.std = self.Z["actor"][la].data_ptr(), self.Z["critic"][lc].data_ptr(), std.data_ptr()
+        a.head_ld, a.num_actions, a.rows = HEAD, std.numel(), self.M
+        a.idx = idx.data_ptr()
+        for field, t in (("actions", st.actions), ("old_mu", st.mu), ("old_sigma", st.sigma), ("old_logp", st.actions_log_prob),
+                         ("advantages", st.advantages), ("returns", st.returns), ("old_values", st.values)):
+            t = flat(t)
+            assert t.is_contiguous() and t.dtype == torch.float32
+            setattr(a, field, t.data_ptr())
+        a.clip_param, a.value_loss_coef, a.entropy_coef = A.clip_param, A.value_loss_coef, A.entropy_coef
+        a.use_clipped_value_loss = int(A.use_clipped_value_loss)
+        a.d_mean, a.d_value = self.dZ["actor"][la].data_ptr(), self.dZ["critic"][lc].data_ptr()
+        a.d_std = g_std.data_ptr()
+        a.d_mean_bias = self.G[f"actor.{la}.b"].data_ptr()
+        a.d_value_bias = self.G[f"critic.{lc}.b"].data_ptr()
+        a.kl = kl.data_ptr()
+        a.value_loss = acc[0:].data_ptr()
+        a.surrogate_loss = acc[1:].data_ptr()
+        _chk(self.lib.go1ppo_loss(ctypes.byref(a), _stream()), "go1ppo_loss")
+
+    def adaptation_loss(self, st, idx, num_train, selective, acc):
+        last = self.depth["adaptation"] - 1
+        pred, dpred = self.Z["adaptation"][last], self.dZ["adaptation"][last]
+        target = st.privileged_observations.flatten(0, 1)
+        assert target.is_contiguous() and target.dtype == torch.float32 and target.shape[1] == self.pol.npv
+        _chk(self.lib.go1ppo_mse(pred.data_ptr(), HEAD, target.data_ptr(), self.pol.npv, idx.data_ptr(), self.M, num_train,
+                                 int(selective), dpred.data_ptr(), self.G[f"adaptation.{last}.b"].data_ptr(),
+                                 acc[2:].data_ptr(), acc[3:].data_ptr(), _stream()), "go1ppo_mse")

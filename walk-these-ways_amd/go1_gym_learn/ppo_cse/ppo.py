@@ -49,6 +49,7 @@ class PPO_Args(PrefixProto):
     autocast_bf16 = False           # BASELINE config 2: "bf16 policy" (fp32 master weights + bf16 compute replica)
     data_parallel = True            # all-reduce gradients when torch.distributed is initialised with world_size > 1
     use_hip_graphs = True           # replay the mini-batch step as a HIP graph from the second update() on
+    use_fused_kernels = True        # bf16 policy on a GPU: hand-scheduled forward/backward with csrc/go1ppo.hip (fused.py)
 
 
 _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
@@ -106,6 +107,13 @@ class PPO:
         self.transition = RolloutStorage.Transition()
         self._lr = torch.tensor(PPO_Args.learning_rate, device=device)
         self.dp = PPO_Args.data_parallel and _world() > 1
+        # hand-scheduled forward/backward (fused.py): bf16 policy with ELU activations on a GPU.  No silent fallback:
+        # when it applies and libgo1ppo.so is missing, load_library() raises.
+        self.fused = bool(self.bf16 and PPO_Args.use_fused_kernels and self.policy.act is torch.nn.ELU)
+        self._roll_net = self._train_net = None
+        if self.fused:
+            from go1_gym_learn.ppo_cse import fused
+            self._fused_lib = fused.load_library()
         if self.dp:                              # identical initial weights on every rank
             dist.broadcast(self.master, src=0)
         self._push_weights()
@@ -167,6 +175,9 @@ class PPO:
                                       history_dtype=self.body.dtype, history_pad_to=8, augment=True)
         assert self.storage.observation_histories.shape[-1] == self.policy.Kp
         self._last_hist = self.storage.observation_histories[0].clone()
+        if self.fused:
+            from go1_gym_learn.ppo_cse.fused import FusedNet
+            self._roll_net = FusedNet(self.policy, self.body, None, num_envs, self._fused_lib, with_grad=False)
 
     def test_mode(self):
         self.actor_critic.test()
@@ -182,9 +193,8 @@ class PPO:
         slot = self.storage.observation_histories[self.storage.step]
         self.storage.write_history(slot, obs_history, privileged_obs)
         t.observation_histories = slot
-        with torch.no_grad():
-            mean, value, _ = self.policy.forward(self.body, slot)
-        mean, value, std = mean.float(), value.float(), self.std.detach()
+        mean, value = self._infer(slot)
+        std = self.std.detach()
         t.actions = mean + std * torch.randn_like(mean)
         t.values = value.detach()
         t.actions_log_prob = gaussian_log_prob(t.actions, mean, std)
@@ -194,6 +204,15 @@ class PPO:
         t.critic_observations = obs
         t.privileged_observations = privileged_obs
         return t.actions
+
+    def _infer(self, rows):
+        """fp32 (mean, value) of a batch of augmented history rows, no autograd."""
+        with torch.no_grad():
+            if self._roll_net is not None and rows.shape[0] == self._roll_net.M:
+                mean, value, _ = self._roll_net.forward(rows)
+                return mean[:, :self.n_std].float(), value[:, :1].float()
+            mean, value, _ = self.policy.forward(self.body, rows)
+            return mean.float(), value.float()
 
     def process_env_step(self, rewards, dones, infos):
         t = self.transition
@@ -208,9 +227,8 @@ class PPO:
 
     def compute_returns(self, last_critic_obs, last_critic_privileged_obs):
         self.storage.write_history(self._last_hist, last_critic_obs, last_critic_privileged_obs)
-        with torch.no_grad():
-            _, last_values, _ = self.policy.forward(self.body, self._last_hist)
-        self.storage.compute_returns(last_values.float().clone(), PPO_Args.gamma, PPO_Args.lam)
+        _, last_values = self._infer(self._last_hist)
+        self.storage.compute_returns(last_values.clone(), PPO_Args.gamma, PPO_Args.lam)
 
     # ---- update ------------------------------------------------------------------------------------------
     def _adapt_lr(self, kl_mean):
@@ -234,8 +252,31 @@ class PPO:
                     values=f(st.values), adv=f(st.advantages), returns=f(st.returns), logp=f(st.actions_log_prob),
                     mu=f(st.mu), sigma=f(st.sigma))
 
+    def _stage_ppo_backward_fused(self, idx):
+        net, n = self._train_net, self.n_body
+        with torch.no_grad():
+            torch.index_select(self.storage.observation_histories.flatten(0, 1), 0, idx, out=net.X)
+            self.master.grad.zero_()
+            self._kl.zero_()
+            net.forward(net.X)
+            net.ppo_loss(self.storage, idx, self.std, self.master.grad[n:n + self.n_std], PPO_Args, self._kl, self._acc)
+            net.backward(net.X)
+            self._priv_cols_grad.zero_()
+
+    def _stage_adapt_backward_fused(self, idx):
+        net = self._train_net          # net.X still holds this mini-batch's rows (gathered by the PPO stage)
+        num_train = int(idx.numel() // 5 * 4)
+        with torch.no_grad():
+            self.master.grad.zero_()
+            net.forward_adaptation(net.X)
+            net.adaptation_loss(self.storage, idx, num_train, PPO_Args.selective_adaptation_module_loss, self._acc)
+            net.backward_adaptation(net.X)
+            self._priv_cols_grad.zero_()
+
     def _stage_ppo_backward(self, idx):
         """PPO loss forward + backward into the fp32 master gradient (reference ppo.py:112-155)."""
+        if self._train_net is not None:
+            return self._stage_ppo_backward_fused(idx)
         A = PPO_Args
         b = self._gather(idx)
         mu_batch, value_batch, _ = self.policy.forward(self.body, b["hist"])
@@ -275,6 +316,8 @@ class PPO:
 
     def _stage_adapt_backward(self, idx):
         """adaptation-module regression on the same mini-batch (reference ppo.py:163-190)."""
+        if self._train_net is not None:
+            return self._stage_adapt_backward_fused(idx)
         A = PPO_Args
         st = self.storage
         hist = st.observation_histories.flatten(0, 1)[idx]
@@ -352,6 +395,9 @@ class PPO:
         if self._idx is None or self._idx.numel() != mb:
             self._idx = torch.zeros(mb, dtype=torch.long, device=self.device)
             self._graphs = None
+            if self.fused:
+                from go1_gym_learn.ppo_cse.fused import FusedNet
+                self._train_net = FusedNet(self.policy, self.body, self.master.grad[:self.n_body], mb, self._fused_lib, with_grad=True)
         self._acc.zero_()
         indices = torch.randperm(A.num_mini_batches * mb, requires_grad=False, device=self.device)   # rollout_storage.py:103
         use_graphs = (self.on_gpu and A.use_hip_graphs and A.num_adaptation_module_substeps == 1)
