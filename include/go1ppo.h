@@ -25,9 +25,11 @@ extern "C" {
 int go1ppo_elu_fwd(void* y, int64_t rows, int cols, int ld, const void* lat, int lat_ld, int npv, const void* wz,
                    int wz_ld, int lat_cols, void* stream);
 
-/* d[r, c] *= elu'(.) evaluated from the activation output h (h > 0 ? 1 : h + 1), in place; h == NULL: identity.
- * bias_grad[c] += sum_r d[r, c] (after the multiplication) when bias_grad != NULL. */
-int go1ppo_elu_bwd(void* d, int ld_d, const void* h, int ld_h, int64_t rows, int cols, float* bias_grad, void* stream);
+/* out[r, c] = d[r, c] * elu'(.) evaluated from the activation output h (h > 0 ? 1 : h + 1); out may alias d (in
+ * place) or be a column block of a wider matrix; h == NULL: identity.
+ * bias_grad[c] += sum_r out[r, c] when bias_grad != NULL. */
+int go1ppo_elu_bwd(const void* d, int ld_d, const void* h, int ld_h, int64_t rows, int cols, float* bias_grad, void* out,
+                   int ld_out, void* stream);
 
 typedef struct {
   /* network outputs of this mini-batch (bf16, heads padded to `head_ld` columns) */
@@ -70,9 +72,10 @@ int go1ppo_mse(const void* pred, int pred_ld, const float* target, int npv, cons
                float* test_loss, void* stream);
 
 /* dW[n, k] (fp32, ld ldw) += sum_r dz[r, n] * h[r, k]; bf16 MFMA, split over row chunks with atomic accumulation.
- * n and k multiples of 16. */
+ * bias_grad[n] += sum_r dz[r, n] when bias_grad != NULL (the layer's bias gradient rides along: the dz tile is in
+ * LDS anyway).  n and k multiples of 64. */
 int go1ppo_wgrad(const void* dz, int ld_dz, const void* h, int ld_h, int64_t rows, int n, int k, float* dW, int ldw,
-                 void* stream);
+                 float* bias_grad, void* stream);
 
 const char* go1ppo_version(void);
 

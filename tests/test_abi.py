@@ -74,7 +74,7 @@ def test_ppo_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert b"gfx950" in lib.go1ppo_version()
     # argument validation happens before any launch: callable without a GPU
-    assert lib.go1ppo_wgrad(None, 0, None, 0, 0, 0, 0, None, 0, None) == -1
+    assert lib.go1ppo_wgrad(None, 0, None, 0, 0, 0, 0, None, 0, None, None) == -1
     assert lib.go1ppo_elu_fwd(None, 0, 0, 0, None, 0, 0, None, 0, 0, None) == -1
 
 

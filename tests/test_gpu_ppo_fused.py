@@ -58,7 +58,7 @@ def test_elu_backward_and_bias_gradient(lib, cols, ld):
     ref = bf(df * torch.where(hf > 0, torch.ones_like(hf), hf + 1.0))
     bias = torch.zeros(cols, device="cuda")
     d0 = d.clone()
-    assert lib.go1ppo_elu_bwd(d.data_ptr(), ld, h.data_ptr(), ld, M, cols, bias.data_ptr(), stream()) == 0
+    assert lib.go1ppo_elu_bwd(d.data_ptr(), ld, h.data_ptr(), ld, M, cols, bias.data_ptr(), d.data_ptr(), ld, stream()) == 0
     torch.cuda.synchronize()
     torch.testing.assert_close(d[:, :cols].float(), ref.float(), rtol=8e-3, atol=1e-6)
     assert torch.equal(d[:, cols:], d0[:, cols:])
@@ -66,10 +66,16 @@ def test_elu_backward_and_bias_gradient(lib, cols, ld):
     # identity mode = column sums only
     bias.zero_()
     d1 = d.clone()
-    assert lib.go1ppo_elu_bwd(d.data_ptr(), ld, None, 0, M, cols, bias.data_ptr(), stream()) == 0
+    assert lib.go1ppo_elu_bwd(d.data_ptr(), ld, None, 0, M, cols, bias.data_ptr(), d.data_ptr(), ld, stream()) == 0
     torch.cuda.synchronize()
     assert torch.equal(d, d1)
     torch.testing.assert_close(bias, d[:, :cols].float().sum(0), rtol=1e-4, atol=1e-3)
+    # out of place into a column block of a wider matrix
+    wide = torch.zeros(M, cols + 64, device="cuda", dtype=torch.bfloat16)
+    assert lib.go1ppo_elu_bwd(d0.data_ptr(), ld, h.data_ptr(), ld, M, cols, None, wide[:, 64:].data_ptr(), cols + 64, stream()) == 0
+    torch.cuda.synchronize()
+    torch.testing.assert_close(wide[:, 64:].float(), ref.float(), rtol=8e-3, atol=1e-6)
+    assert not wide[:, :64].any()
 
 
 @pytest.mark.parametrize("M,n,k,ld_dz,ld_h", [(24576, 256, 512, 256, 1280), (24576, 64, 128, 64, 128), (5000, 512, 64, 1280, 64),
@@ -79,11 +85,17 @@ def test_wgrad_matches_fp32_matmul(lib, M, n, k, ld_dz, ld_h):
     dz = bf(torch.randn(M, ld_dz, device="cuda", generator=g))
     h = bf(torch.randn(M, ld_h, device="cuda", generator=g))
     out = torch.full((n, k), 1.0, device="cuda")                   # accumulates on top of what is there
-    assert lib.go1ppo_wgrad(dz.data_ptr(), ld_dz, h.data_ptr(), ld_h, M, n, k, out.data_ptr(), k, stream()) == 0
+    bias = torch.full((n,), -2.0, device="cuda")
+    assert lib.go1ppo_wgrad(dz.data_ptr(), ld_dz, h.data_ptr(), ld_h, M, n, k, out.data_ptr(), k, bias.data_ptr(), stream()) == 0
     torch.cuda.synchronize()
     ref = dz[:, :n].float().t() @ h[:, :k].float() + 1.0
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-3 * M ** 0.5)      # exact bf16 products, fp32 sums
-    assert lib.go1ppo_wgrad(dz.data_ptr(), ld_dz, h.data_ptr(), ld_h, M, 48, k, out.data_ptr(), k, stream()) == -1
+    torch.testing.assert_close(bias, dz[:, :n].float().sum(0) - 2.0, rtol=1e-4, atol=2e-3 * M ** 0.5)
+    out2 = torch.zeros(n, k, device="cuda")
+    assert lib.go1ppo_wgrad(dz.data_ptr(), ld_dz, h.data_ptr(), ld_h, M, n, k, out2.data_ptr(), k, None, stream()) == 0
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out2, ref - 1.0, rtol=1e-4, atol=2e-3 * M ** 0.5)
+    assert lib.go1ppo_wgrad(dz.data_ptr(), ld_dz, h.data_ptr(), ld_h, M, 48, k, out.data_ptr(), k, None, stream()) == -1
 
 
 def autograd_losses(mean, value, std, b, A):

@@ -13,6 +13,7 @@
 // bf16 activations, fp32 math, fp32 parameter gradients.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/go1ppo.h"
 
 typedef uint16_t bf16_t;
@@ -54,20 +55,19 @@ __global__ __launch_bounds__(256) void elu_fwd_kernel(bf16_t* y, int64_t rows, i
 }
 
 // ---------------------------------------------------------------------------------------------- elu_bwd (+ column sums)
-// block = 256 threads = CG column groups (8 columns each) x 256/CG row lanes; one block covers RCHUNK rows.
-#define EB_RCHUNK 256
-__global__ __launch_bounds__(256) void elu_bwd_kernel(bf16_t* d, int ld_d, const bf16_t* h, int ld_h, int64_t rows, int cols,
-                                                      float* bias_grad, int cg_per_block) {
+// block = 256 threads = CG column groups (8 columns each) x 256/CG row lanes; one block covers `rchunk` rows.
+__global__ __launch_bounds__(256) void elu_bwd_kernel(const bf16_t* d, int ld_d, const bf16_t* h, int ld_h, int64_t rows, int cols,
+                                                      float* bias_grad, bf16_t* out, int ld_out, int cg_per_block, int rchunk) {
   __shared__ float red[256 * 8];
   int cgi = threadIdx.x % cg_per_block, rl = threadIdx.x / cg_per_block, rlanes = 256 / cg_per_block;
   int c0 = (blockIdx.x * cg_per_block + cgi) << 3;
-  int64_t r0 = (int64_t)blockIdx.y * EB_RCHUNK;
-  int64_t r1 = r0 + EB_RCHUNK < rows ? r0 + EB_RCHUNK : rows;
+  int64_t r0 = (int64_t)blockIdx.y * rchunk;
+  int64_t r1 = r0 + rchunk < rows ? r0 + rchunk : rows;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c0 < cols) {
     for (int64_t r = r0 + rl; r < r1; r += rlanes) {
-      Bf8* pd = reinterpret_cast<Bf8*>(d + r * ld_d + c0);
-      Bf8 g = *pd;
+      Bf8 g = *reinterpret_cast<const Bf8*>(d + r * ld_d + c0);
+      Bf8* po = reinterpret_cast<Bf8*>(out + r * ld_out + c0);
       if (h) {
         Bf8 a = *reinterpret_cast<const Bf8*>(h + r * ld_h + c0);
 #pragma unroll
@@ -77,10 +77,11 @@ __global__ __launch_bounds__(256) void elu_bwd_kernel(bf16_t* d, int ld_d, const
           g.v[e] = f2bf(dz);
           s[e] += bf2f(g.v[e]);
         }
-        *pd = g;
+        *po = g;
       } else {
 #pragma unroll
         for (int e = 0; e < 8; e++) s[e] += bf2f(g.v[e]);
+        if (out != d) *po = g;
       }
     }
   }
@@ -326,6 +327,88 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* dz, int ld_dz,
     }
 }
 
+// v2: 64-row steps; every thread loads a 4-row x 8-column patch of one operand and stores its transpose with eight
+// 8-byte LDS writes (4 consecutive reduction indices each) instead of 32 two-byte ones.
+#define WG2_LDM 72
+__global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* dz, int ld_dz, const bf16_t* h, int ld_h, int64_t rows,
+                                                     int chunk_rows, float* dW, int ldw, float* bias_grad) {
+  __shared__ __attribute__((aligned(16))) bf16_t T[2][2][64][WG2_LDM];      // [buffer][operand][n or k][m]
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int64_t m_begin = (int64_t)blockIdx.z * chunk_rows;
+  const int64_t m_end = m_begin + chunk_rows < rows ? m_begin + chunk_rows : rows;
+  const int t = threadIdx.x, op = t >> 7, rq = (t & 127) >> 3, cg = t & 7, wave = t >> 6, lane = t & 63;
+  const bf16_t* src = op ? h + k0 + 8 * cg : dz + n0 + 8 * cg;
+  const int ld = op ? ld_h : ld_dz;
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 r[4];
+  auto gload = [&](int64_t m) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int64_t row = m + 4 * rq + q;
+      r[q] = row < m_end ? *reinterpret_cast<const uint4*>(src + row * ld) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto sstore = [&](int buf) {
+    const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&r[0]);
+    const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&r[1]);
+    const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&r[2]);
+    const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&r[3]);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {        // dword p holds columns 2p, 2p+1 of each of the 4 rows
+      uint2 even, odd;
+      even.x = (w0[p] & 0xffffu) | (w1[p] << 16);
+      even.y = (w2[p] & 0xffffu) | (w3[p] << 16);
+      odd.x = (w0[p] >> 16) | (w1[p] & 0xffff0000u);
+      odd.y = (w2[p] >> 16) | (w3[p] & 0xffff0000u);
+      *reinterpret_cast<uint2*>(&T[buf][op][8 * cg + 2 * p][4 * rq]) = even;
+      *reinterpret_cast<uint2*>(&T[buf][op][8 * cg + 2 * p + 1][4 * rq]) = odd;
+    }
+  };
+  if (m_begin >= m_end) return;
+  const bool do_bias = bias_grad && blockIdx.y == 0;      // the k-tile-0 workgroups also own the column sums of dz
+  float bsum = 0.f;
+  gload(m_begin);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t m = m_begin; m < m_end; m += 64) {
+    bool more = m + 64 < m_end;
+    if (more) gload(m + 64);
+    if (do_bias) {                                           // thread t: row n = t/4 of the tile, 16 of the 64 m's
+      const Bf8* q = reinterpret_cast<const Bf8*>(&T[buf][0][t >> 2][16 * (t & 3)]);
+      Bf8 u0 = q[0], u1 = q[1];
+#pragma unroll
+      for (int e = 0; e < 8; e++) bsum += bf2f(u0.v[e]) + bf2f(u1.v[e]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(&T[buf][0][16 * wave + (lane & 15)][ks * 32 + (lane >> 4) * 8]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        bf16x8_t bv = *reinterpret_cast<const bf16x8_t*>(&T[buf][1][16 * j + (lane & 15)][ks * 32 + (lane >> 4) * 8]);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[j], 0, 0, 0);
+      }
+    }
+    if (more) sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int row = n0 + 16 * wave + (lane >> 4) * 4 + q, col = k0 + 16 * j + (lane & 15);
+      atomicAdd(dW + (int64_t)row * ldw + col, acc[j][q]);
+    }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 1, 64);
+    bsum += __shfl_xor(bsum, 2, 64);
+    if ((t & 3) == 0) atomicAdd(bias_grad + n0 + (t >> 2), bsum);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- C-ABI
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -339,12 +422,19 @@ extern "C" int go1ppo_elu_fwd(void* y, int64_t rows, int cols, int ld, const voi
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
-extern "C" int go1ppo_elu_bwd(void* d, int ld_d, const void* h, int ld_h, int64_t rows, int cols, float* bias_grad, void* stream) {
-  if (!d || rows <= 0 || cols <= 0 || (cols & 7) || (ld_d & 7) || (h && (ld_h & 7)) || !aligned16(d) || (h && !aligned16(h))) return -1;
+extern "C" int go1ppo_elu_bwd(const void* d, int ld_d, const void* h, int ld_h, int64_t rows, int cols, float* bias_grad, void* out,
+                              int ld_out, void* stream) {
+  if (!d || !out || rows <= 0 || cols <= 0 || (cols & 7) || (ld_d & 7) || (ld_out & 7) || (h && (ld_h & 7)) || !aligned16(d) ||
+      !aligned16(out) || (h && !aligned16(h)))
+    return -1;
   int cgs = cols >> 3;
   int cgb = cgs >= 32 ? 32 : (cgs >= 16 ? 16 : 8);
-  dim3 grid((cgs + cgb - 1) / cgb, (unsigned)((rows + EB_RCHUNK - 1) / EB_RCHUNK));
-  elu_bwd_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>((bf16_t*)d, ld_d, (const bf16_t*)h, ld_h, rows, cols, bias_grad, cgb);
+  int xblocks = (cgs + cgb - 1) / cgb;
+  int rchunk = 256;                    // rows per block: aim for >= ~1500 blocks, at least 4 rows per thread-row
+  while (rchunk > 32 && xblocks * ((rows + rchunk - 1) / rchunk) < 1536) rchunk >>= 1;
+  dim3 grid(xblocks, (unsigned)((rows + rchunk - 1) / rchunk));
+  elu_bwd_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)d, ld_d, (const bf16_t*)h, ld_h, rows, cols, bias_grad,
+                                                              (bf16_t*)out, ld_out, cgb, rchunk);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
@@ -364,19 +454,34 @@ extern "C" int go1ppo_mse(const void* pred, int pred_ld, const float* target, in
 }
 
 extern "C" int go1ppo_wgrad(const void* dz, int ld_dz, const void* h, int ld_h, int64_t rows, int n, int k, float* dW, int ldw,
-                            void* stream) {
+                            float* bias_grad, void* stream) {
   if (!dz || !h || !dW || rows <= 0 || n <= 0 || k <= 0 || (n & 63) || (k & 63) || (ld_dz & 7) || (ld_h & 7) || !aligned16(dz) || !aligned16(h))
     return -1;
+  static int variant = -1, wg_per_cu = 8;
+  if (variant < 0) {
+    const char* e = getenv("GO1PPO_WGRAD_VARIANT");
+    variant = e ? atoi(e) : 2;
+    const char* w0 = getenv("GO1PPO_WGRAD_WGS");
+    if (!w0) wg_per_cu = 4;
+    const char* w = getenv("GO1PPO_WGRAD_WGS");
+    if (w) wg_per_cu = atoi(w);
+  }
+  const int step = variant == 1 ? 32 : 64;
   int tiles = (n / 64) * (k / 64);
-  int64_t steps = (rows + 31) / 32;
-  int64_t S = 2048 / tiles;                 // ~8 workgroups per CU
+  int64_t steps = (rows + step - 1) / step;
+  int64_t S = (256 * wg_per_cu) / tiles;
   if (S < 1) S = 1;
   if (S > steps) S = steps;
-  if (S > 1024) S = 1024;
+  if (S > 128) S = 128;                      // same-address atomics serialise in L2: keep the fan-in per output moderate
   int64_t chunk_steps = (steps + S - 1) / S;
   S = (steps + chunk_steps - 1) / chunk_steps;
-  wgrad_kernel<<<dim3(n / 64, k / 64, (unsigned)S), dim3(256), 0, (hipStream_t)stream>>>(
-      (const bf16_t*)dz, ld_dz, (const bf16_t*)h, ld_h, rows, (int)(chunk_steps * 32), dW, ldw);
+  dim3 grid(n / 64, k / 64, (unsigned)S);
+  if (variant == 1 && !bias_grad)
+    wgrad_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dz, ld_dz, (const bf16_t*)h, ld_h, rows,
+                                                              (int)(chunk_steps * step), dW, ldw);
+  else
+    wgrad2_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dz, ld_dz, (const bf16_t*)h, ld_h, rows,
+                                                               (int)(chunk_steps * step), dW, ldw, bias_grad);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 

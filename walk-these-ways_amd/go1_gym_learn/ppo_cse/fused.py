@@ -53,10 +53,10 @@ def load_library(path=None):
     L = ctypes.CDLL(p)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
     L.go1ppo_elu_fwd.argtypes = [vp, i64, i32, i32, vp, i32, i32, vp, i32, i32, vp]
-    L.go1ppo_elu_bwd.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp]
+    L.go1ppo_elu_bwd.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp, i32, vp]
     L.go1ppo_loss.argtypes = [ctypes.POINTER(LossArgs), vp]
     L.go1ppo_mse.argtypes = [vp, i32, vp, i32, vp, i64, i64, i32, vp, vp, vp, vp, vp]
-    L.go1ppo_wgrad.argtypes = [vp, i32, vp, i32, i64, i32, i32, vp, i32, vp]
+    L.go1ppo_wgrad.argtypes = [vp, i32, vp, i32, i64, i32, i32, vp, i32, vp, vp]
     for name in EXPORTED_SYMBOLS[:-1]:
         getattr(L, name).restype = ctypes.c_int
     L.go1ppo_version.restype = ctypes.c_char_p
@@ -106,21 +106,13 @@ class FusedNet:
         assert policy.npv <= HEAD and self.P["Wz"].shape == (self.na, HEAD)
         if with_grad:
             self.X = torch.zeros(M, policy.Kp, **bf)
+            # GEMM outputs are never strided views: the tails' input gradients land in one contiguous buffer per net
+            # (dH1), the ELU-backward kernel writes them into the column blocks of dY1 for the single W1 wgrad GEMM
+            self.dH1 = {"adaptation": torch.zeros(M, self.nd, **bf), "actor": torch.zeros(M, self.na, **bf),
+                        "critic": torch.zeros(M, self.nc, **bf)}
             self.dY1 = torch.zeros(M, self.n1, **bf)
-            self.dY1d = torch.zeros(M, self.nd, **bf)
             self.dZ = {n: {li: torch.zeros_like(z) for li, z in zs.items()} for n, zs in self.Z.items()}
             self._w1_tmp = torch.zeros(self.n1, policy.Kp, **bf)
-            self._mm_f32 = self._probe_mm_out_dtype(dev)
-
-    @staticmethod
-    def _probe_mm_out_dtype(dev):
-        try:
-            a = torch.ones(64, 32, device=dev, dtype=torch.bfloat16)
-            o = torch.zeros(32, 32, device=dev)
-            torch.mm(a.t(), a, out_dtype=torch.float32, out=o)
-            return bool((o == 64).all())
-        except Exception:
-            return False
 
     # ---- kernels -----------------------------------------------------------------------------------------
     def _elu(self, y, lat=None, lat_cols=0):
@@ -128,15 +120,16 @@ class FusedNet:
         _chk(self.lib.go1ppo_elu_fwd(y.data_ptr(), y.shape[0], y.shape[1], _ld(y), _ptr(lat), _ld(lat) if lat is not None else 0,
                                      self.pol.npv if lat is not None else 0, _ptr(wz), HEAD, lat_cols, _stream()), "go1ppo_elu_fwd")
 
-    def _elu_bwd(self, d, h, bias_grad):
+    def _elu_bwd(self, d, h, bias_grad, out=None):
+        out = d if out is None else out
         _chk(self.lib.go1ppo_elu_bwd(d.data_ptr(), _ld(d), _ptr(h), _ld(h) if h is not None else 0, d.shape[0], d.shape[1],
-                                     _ptr(bias_grad), _stream()), "go1ppo_elu_bwd")
+                                     _ptr(bias_grad), out.data_ptr(), _ld(out), _stream()), "go1ppo_elu_bwd")
 
-    def _wgrad(self, dz, h, gW):
+    def _wgrad(self, dz, h, gW, gb=None):
         n, k = dz.shape[1], h.shape[1]
         assert gW.shape == (n, k) and gW.is_contiguous()
-        _chk(self.lib.go1ppo_wgrad(dz.data_ptr(), _ld(dz), h.data_ptr(), _ld(h), dz.shape[0], n, k, gW.data_ptr(), k, _stream()),
-             "go1ppo_wgrad")
+        _chk(self.lib.go1ppo_wgrad(dz.data_ptr(), _ld(dz), h.data_ptr(), _ld(h), dz.shape[0], n, k, gW.data_ptr(), k, _ptr(gb),
+                                   _stream()), "go1ppo_wgrad")
 
     # ---- forward -------------------------------------------------------------------------------------------
     def _tail(self, net, h):
@@ -167,50 +160,51 @@ class FusedNet:
         return self._tail("adaptation", self.Y1d)
 
     # ---- backward ------------------------------------------------------------------------------------------
-    def _tail_bwd(self, net, h0, dh0):
-        """Given dZ[net][last], accumulate the tail's parameter gradients and write d(loss)/d(h0) into dh0."""
+    def _tail_bwd(self, net, h0, dh0, head_bias_done=True):
+        """Given dZ[net][last], accumulate the tail's parameter gradients and write d(loss)/d(h0) into dh0.
+        Bias gradients (column sums of dZ) ride along with the weight-gradient kernel; the head's were already
+        produced by the loss kernel unless head_bias_done is False."""
         P, G, d = self.P, self.G, self.depth[net]
         for li in range(d - 1, 0, -1):
             dz = self.dZ[net][li]
             h_in = self.Z[net][li - 1] if li > 1 else h0
-            self._wgrad(dz, h_in, G[f"{net}.{li}.W"])
+            gb = None if (li == d - 1 and head_bias_done) else G[f"{net}.{li}.b"]
+            self._wgrad(dz, h_in, G[f"{net}.{li}.W"], gb)
             out = self.dZ[net][li - 1] if li > 1 else dh0
             torch.mm(dz, P[f"{net}.{li}.W"], out=out)
             if li > 1:
-                self._elu_bwd(out, h_in, G[f"{net}.{li - 1}.b"])
+                self._elu_bwd(out, h_in, None)
 
     def _big_wgrad(self, dY, x, gW, tmp):
-        if self._mm_f32:
-            torch.mm(dY.t(), x, out_dtype=torch.float32, out=gW)
-        else:
-            torch.mm(dY.t(), x, out=tmp)
-            gW.copy_(tmp)
+        """first-layer weight gradient: one (rows x M) @ (M x Kp) bf16 GEMM (stream-K kernel at ~1 PFLOP/s; the
+        fp32-output variants hipBLASLt offers for this shape are 3x slower), then one cast into the fp32 gradient."""
+        torch.mm(dY.t(), x, out=tmp)
+        gW.copy_(tmp)
 
     def backward(self, x):
         """After forward(x) and a loss kernel that filled dZ[actor][last], dZ[critic][last] (+ their bias / std
         gradients): everything else.  Gradients are ACCUMULATED into the (pre-zeroed) flat gradient."""
         nd, na = self.nd, self.na
-        G = self.G
-        Y1, dY1 = self.Y1, self.dY1
-        self._tail_bwd("actor", Y1[:, nd:nd + na], dY1[:, nd:nd + na])
-        self._tail_bwd("critic", Y1[:, nd + na:], dY1[:, nd + na:])
-        self._elu_bwd(dY1[:, nd:], Y1[:, nd:], None)
+        G, Y1, dY1, dH1 = self.G, self.Y1, self.dY1, self.dH1
+        cols = {"adaptation": slice(0, nd), "actor": slice(nd, nd + na), "critic": slice(nd + na, self.n1)}
+        for net in ("actor", "critic"):
+            self._tail_bwd(net, Y1[:, cols[net]], dH1[net])
+            self._elu_bwd(dH1[net], Y1[:, cols[net]], None, out=dY1[:, cols[net]])
         # actor first layer's latent columns: a1 += latent Wz^T
         last = self.depth["adaptation"] - 1
         latent, dlat = self.Z["adaptation"][last], self.dZ["adaptation"][last]
-        dA1 = dY1[:, nd:nd + na]
+        dA1 = dY1[:, cols["actor"]]
         self._wgrad(dA1, latent, G["Wz"])
         torch.mm(dA1, self.P["Wz"], out=dlat)
-        self._elu_bwd(dlat, None, G[f"adaptation.{last}.b"])
-        self._tail_bwd("adaptation", Y1[:, :nd], dY1[:, :nd])
-        self._elu_bwd(dY1[:, :nd], Y1[:, :nd], None)
+        self._tail_bwd("adaptation", Y1[:, :nd], dH1["adaptation"], head_bias_done=False)
+        self._elu_bwd(dH1["adaptation"], Y1[:, :nd], None, out=dY1[:, :nd])
         self._big_wgrad(dY1, x, G["W1"], self._w1_tmp)
 
     def backward_adaptation(self, x):
-        nd = self.nd
-        self._tail_bwd("adaptation", self.Y1d, self.dY1d)
-        self._elu_bwd(self.dY1d, self.Y1d, None)
-        self._big_wgrad(self.dY1d, x, self.G["W1"][:nd], self._w1_tmp[:nd])
+        nd, d = self.nd, self.dH1["adaptation"]
+        self._tail_bwd("adaptation", self.Y1d, d)
+        self._elu_bwd(d, self.Y1d, None)
+        self._big_wgrad(d, x, self.G["W1"][:nd], self._w1_tmp[:nd])
 
     # ---- losses ----------------------------------------------------------------------------------------------
     def ppo_loss(self, st, idx, std, g_std, A, kl, acc):
