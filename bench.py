@@ -56,8 +56,8 @@ def build_env(num_envs, rank, seed):
     return HistoryWrapper(env), cfg
 
 
-def cpu_baseline(num_envs, policy_steps=24):
-    """Oracle (fp64 port of the same step, OpenMP over envs) on the host cores: bounded sample."""
+def cpu_baseline(num_envs, target_seconds=15.0):
+    """Oracle (fp64 port of the same step, OpenMP over envs) on the host cores: bounded sample of ~target_seconds."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import numpy as np
     import pyoracle
@@ -72,11 +72,17 @@ def cpu_baseline(num_envs, policy_steps=24):
     orc = pyoracle.Oracle(S, B)
     orc.reset_idx()
     rng = np.random.default_rng(0)
-    acts = rng.standard_normal((policy_steps, num_envs, 12)).astype(np.float32)
-    orc.step(acts[0])
-    t0 = time.perf_counter()
-    for a in acts:
+    acts = rng.standard_normal((24, num_envs, 12)).astype(np.float32)
+    for a in acts[:8]:              # thread pool spin-up, first-touch page faults
         orc.step(a)
+    t0 = time.perf_counter()
+    for a in acts[8:16]:
+        orc.step(a)
+    per_step = (time.perf_counter() - t0) / 8
+    policy_steps = int(min(max(24, target_seconds / per_step), 20000))
+    t0 = time.perf_counter()
+    for i in range(policy_steps):
+        orc.step(acts[i % 24])
     dt = time.perf_counter() - t0
     cores = os.cpu_count() or 1
     return {"value": num_envs * policy_steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",

@@ -673,6 +673,12 @@ static void feet_state(const Phys* s, real fp[4][3], real fv[4][3]) {
 }
 
 /* ------------------------------------------------------------------ commands (device-curriculum semantics) */
+/* episode_log is a float sum over the envs that reset in a step: order-dependent.  When post-physics runs in
+ * parallel (go1_oracle_step) every resetting env parks its terms here and they are added serially in env order,
+ * which reproduces the serial result bit for bit. */
+static float* g_log_defer = NULL;
+static int g_log_stride = 0;
+
 static real fmod1(real x) { real r = fmod(x, 1.0); if (r < 0) r += 1.0; return r; }   /* torch `%` / remainder */
 
 static void resample_commands(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int64_t step, uint32_t purpose) {
@@ -689,7 +695,10 @@ static void resample_commands(const Go1SimConfig* cfg, const Go1SimBuffers* B, i
       if (!(val > cfg->curriculum_threshold[kx])) ok = 0;
     }
     int cat_old = B->env_command_categories[e], bin_old = B->env_command_bins[e];
-    if (ok) B->curriculum_success[cat_old * cfg->num_bins + bin_old] += 1;
+    if (ok) {
+#pragma omp atomic
+      B->curriculum_success[cat_old * cfg->num_bins + bin_old] += 1;
+    }
     /* new category and bin */
     float u0 = rng_uniform(cfg, eg, step, purpose, 0), u1 = rng_uniform(cfg, eg, step, purpose, 1);
     int cat = (int)(u0 * cfg->num_categories);
@@ -796,11 +805,17 @@ static void reset_env(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, in
   for (int j = 0; j < 12; j++) { AT(B->last_actions, j, e) = 0; AT(B->last_last_actions, j, e) = 0; AT(B->last_dof_vel, j, e) = 0; }
   B->episode_length_buf[e] = 0;
   B->reset_buf[e] = 1;
-  for (int kx = 0; kx <= cfg->num_rewards; kx++) {   /* :181-187 logged mean is formed by the host from episode_log */
-    B->episode_log[kx] += AT(B->episode_sums, kx, e);
-    AT(B->episode_sums, kx, e) = 0;
+  if (g_log_defer) {        /* parallel post-physics: park the per-env terms, the caller adds them in env order */
+    float* row = g_log_defer + (size_t)e * g_log_stride;
+    for (int kx = 0; kx <= cfg->num_rewards; kx++) { row[kx] = AT(B->episode_sums, kx, e); AT(B->episode_sums, kx, e) = 0; }
+    row[cfg->num_rewards + 1] = 1;
+  } else {
+    for (int kx = 0; kx <= cfg->num_rewards; kx++) {   /* :181-187 logged mean is formed by the host from episode_log */
+      B->episode_log[kx] += AT(B->episode_sums, kx, e);
+      AT(B->episode_sums, kx, e) = 0;
+    }
+    B->episode_log[cfg->num_rewards + 1] += 1;
   }
-  B->episode_log[cfg->num_rewards + 1] += 1;
   B->gait_indices[e] = 0;
   for (int sl = 0; sl < lag_slots; sl++)
     for (int j = 0; j < 12; j++) B->lag_buffer[((size_t)sl * 12 + j) * N + e] = 0;
@@ -1223,10 +1238,26 @@ void go1_oracle_step(const Go1SimConfig* cfg, const Go1SimBuffers* B, const floa
   }
   if (N > 0) ctr->lag_head = (ctr->lag_head + cfg->decimation) % nl;
   (void)head_end;
-  /* post-physics touches shared curriculum/episode_log accumulators: serial for determinism */
-  for (int e = 0; e < N; e++) {
-    post_physics(cfg, B, e, counter_post, grav, nl);
-    if (B->obs_history) history_append(cfg, B, e, ctr->history_slot);
+  /* post-physics: per-env work in parallel; the two shared accumulators stay deterministic (integer atomics for the
+   * curriculum success counts, env-ordered serial sum for episode_log) */
+  {
+    const int stride = cfg->num_rewards + 2;
+    float* defer = (float*)calloc((size_t)N * stride, sizeof(float));
+    g_log_defer = defer;
+    g_log_stride = stride;
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < N; e++) {
+      post_physics(cfg, B, e, counter_post, grav, nl);
+      if (B->obs_history) history_append(cfg, B, e, ctr->history_slot);
+    }
+    g_log_defer = NULL;
+    for (int e = 0; e < N; e++) {
+      const float* row = defer + (size_t)e * stride;
+      if (row[stride - 1] == 0) continue;
+      for (int kx = 0; kx < stride - 1; kx++) B->episode_log[kx] += row[kx];
+      B->episode_log[stride - 1] += 1;
+    }
+    free(defer);
   }
   ctr->common_step_counter = counter_post;
   ctr->history_slot = (ctr->history_slot + 1) % (cfg->num_obs_history + 1);
