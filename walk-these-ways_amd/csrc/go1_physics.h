@@ -285,6 +285,7 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
         V3 l = v3(hc.x, hc.y + (m ? 1.f : -1.f) * (float)GO1_HIP_CAPSULE_HALF, hc.z);
         cand_try(cfg, hs, cand[0], p[0] + mul(R[0], l), s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0]);
       }
+#ifndef GO1_ABLATE_CAND
 #pragma unroll 1
       for (int m = 0; m < 8; m++) {
         V3 l = v3(GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[0],
@@ -299,6 +300,7 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
                   GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[2]);
         cand_try(cfg, hs, cand[2], p[2] + mul(R[2], l), s.pos, 0.f, v[2]);
       }
+#endif
       cand_try(cfg, hs, cand[3], p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2]);
     }
     // ABA pass 2: calf -> thigh -> hip, then quad-sum into the base
@@ -423,6 +425,9 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
 
   __syncthreads();      // one-wave workgroup: orders this wave's LDS traffic between phases
   // ---- Delassus matrix by impulse propagation through the ABA factors ---------------------------------
+#ifdef GO1_ABLATE_DELASSUS
+  for (int c = leg; c < NR * NR; c += 4) LDS(L_W + c) = (c / NR == c % NR) ? 1.f : 0.f;
+#else
 #pragma unroll 1
   for (int k = 0; k < K; k++) {
     const V3 x = v3(LDS(L_CX + 3 * k), LDS(L_CX + 3 * k + 1), LDS(L_CX + 3 * k + 2));
@@ -483,38 +488,90 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
       }
     }
   }
+#endif
 
   __syncthreads();
-  // ---- projected Gauss-Seidel on the impulses: row dot-products split over the quad -------------------
+  // ---- projected Gauss-Seidel on the impulses -------------------------------------------------------------
+  // Row dot-products are split over the quad (lane `leg` owns columns c = leg, leg+4, ...).  Everything the sweep
+  // needs except the 15 W entries of the current contact row block lives in registers: the impulse vector
+  // (replicated + each lane's own columns), and per contact b, v*, 1/diag and the two normal->tangent couplings.
+  // The W entries come from LDS as one batch of independent reads per contact (constant offsets from one address).
   const float mu = 0.5f * (s.mu + cfg.terrain_friction);       // PhysX default combine mode: average
-#pragma unroll 1
-  for (int it = 0; it < cfg.solver_iterations; it++) {
-#pragma unroll 1
-    for (int k = 0; k < K; k++) {
+#ifndef GO1_ABLATE_PGS
+  {
+    int Kw = 0;                                                // wave-uniform max K: scalar branches below
+#pragma unroll
+    for (int kk = 1; kk <= MAXC; kk++) Kw = (__ballot(K >= kk) != 0ull) ? kk : Kw;
+    float lam[NR], lamloc[5];
+    float bvn[MAXC], bv1[MAXC], bv2[MAXC], vst[MAXC], idn[MAXC], id1[MAXC], id2[MAXC], w10[MAXC], w20[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; k++) {
       const int r0 = 3 * k;
-      float pn = 0.f, p1 = 0.f, p2 = 0.f;
+      const bool on = k < K;
+      lam[r0] = on ? LDS(L_LS + r0) : 0.f; lam[r0 + 1] = on ? LDS(L_LS + r0 + 1) : 0.f; lam[r0 + 2] = on ? LDS(L_LS + r0 + 2) : 0.f;
+      bvn[k] = on ? LDS(L_BV + r0) : 0.f; bv1[k] = on ? LDS(L_BV + r0 + 1) : 0.f; bv2[k] = on ? LDS(L_BV + r0 + 2) : 0.f;
+      vst[k] = on ? LDS(L_VSTAR + k) : 0.f;
+      idn[k] = on ? 1.f / LDS(L_W + r0 * NR + r0) : 0.f;
+      id1[k] = on ? 1.f / LDS(L_W + (r0 + 1) * NR + r0 + 1) : 0.f;
+      id2[k] = on ? 1.f / LDS(L_W + (r0 + 2) * NR + r0 + 2) : 0.f;
+      w10[k] = on ? LDS(L_W + (r0 + 1) * NR + r0) : 0.f;
+      w20[k] = on ? LDS(L_W + (r0 + 2) * NR + r0) : 0.f;
+    }
+    bool colok[5];
+#pragma unroll
+    for (int cc = 0; cc < 5; cc++) {
+      colok[cc] = leg + 4 * cc < 3 * K;
+      lamloc[cc] = colok[cc] ? LDS(L_LS + leg + 4 * cc) : 0.f;
+    }
+    const float* wcol = lds + (L_W + leg) * EPW + el;          // W[r][leg + 4 cc] = wcol[(r * NR + 4 cc) * EPW]
 #pragma unroll 1
-      for (int c = leg; c < 3 * K; c += 4) {
-        float l = LDS(L_LS + c);
-        pn = fmaf(LDS(L_W + r0 * NR + c), l, pn);
-        p1 = fmaf(LDS(L_W + (r0 + 1) * NR + c), l, p1);
-        p2 = fmaf(LDS(L_W + (r0 + 2) * NR + c), l, p2);
+    for (int it = 0; it < cfg.solver_iterations; it++) {
+#pragma unroll
+      for (int k = 0; k < MAXC; k++) {
+        if (k < Kw) {
+          const int r0 = 3 * k;
+          float wn[5], w1[5], w2[5];
+#pragma unroll
+          for (int cc = 0; cc < 5; cc++) {
+            wn[cc] = wcol[(r0 * NR + 4 * cc) * EPW];
+            w1[cc] = wcol[((r0 + 1) * NR + 4 * cc) * EPW];
+            w2[cc] = wcol[((r0 + 2) * NR + 4 * cc) * EPW];
+          }
+          float pn = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+          for (int cc = 0; cc < 5; cc++) {                     // same partition and order as the serial-in-c sum
+            const float l = lamloc[cc];
+            pn = fmaf(colok[cc] ? wn[cc] : 0.f, l, pn);
+            p1 = fmaf(colok[cc] ? w1[cc] : 0.f, l, p1);
+            p2 = fmaf(colok[cc] ? w2[cc] : 0.f, l, p2);
+          }
+          const float un = bvn[k] + quad_sum(pn);
+          float u1 = bv1[k] + quad_sum(p1);
+          float u2 = bv2[k] + quad_sum(p2);
+          const float ln_old = lam[r0];
+          const float ln = fmaxf(0.f, ln_old - (un - vst[k]) * idn[k]);
+          const float dln = ln - ln_old;
+          u1 = fmaf(w10[k], dln, u1);                          // the tangential rows see the updated normal impulse
+          u2 = fmaf(w20[k], dln, u2);
+          float l1 = lam[r0 + 1] - u1 * id1[k];
+          float l2 = lam[r0 + 2] - u2 * id2[k];
+          const float lim = mu * ln, nrm = sqrtf(l1 * l1 + l2 * l2);
+          if (nrm > lim) { const float sc = (nrm > 0.f) ? lim / nrm : 0.f; l1 *= sc; l2 *= sc; }
+          const bool on = k < K;                               // lanes of environments with fewer contacts idle here
+          lam[r0] = on ? ln : 0.f; lam[r0 + 1] = on ? l1 : 0.f; lam[r0 + 2] = on ? l2 : 0.f;
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+            if (leg == ((r0 + i) & 3)) lamloc[(r0 + i) >> 2] = lam[r0 + i];
+        }
       }
-      float un = LDS(L_BV + r0) + quad_sum(pn);
-      float u1 = LDS(L_BV + r0 + 1) + quad_sum(p1);
-      float u2 = LDS(L_BV + r0 + 2) + quad_sum(p2);
-      const float ln_old = LDS(L_LS + r0);
-      const float ln = fmaxf(0.f, ln_old - (un - LDS(L_VSTAR + k)) / LDS(L_W + r0 * NR + r0));
-      const float dln = ln - ln_old;
-      u1 = fmaf(LDS(L_W + (r0 + 1) * NR + r0), dln, u1);     // the tangential rows see the updated normal impulse
-      u2 = fmaf(LDS(L_W + (r0 + 2) * NR + r0), dln, u2);
-      float l1 = LDS(L_LS + r0 + 1) - u1 / LDS(L_W + (r0 + 1) * NR + r0 + 1);
-      float l2 = LDS(L_LS + r0 + 2) - u2 / LDS(L_W + (r0 + 2) * NR + r0 + 2);
-      float lim = mu * ln, nrm = sqrtf(l1 * l1 + l2 * l2);
-      if (nrm > lim) { float sc = (nrm > 0.f) ? lim / nrm : 0.f; l1 *= sc; l2 *= sc; }
-      if (leg == 0) { LDS(L_LS + r0) = ln; LDS(L_LS + r0 + 1) = l1; LDS(L_LS + r0 + 2) = l2; }
+    }
+    if (leg == 0) {
+#pragma unroll
+      for (int k = 0; k < MAXC; k++)
+        if (k < K) { LDS(L_LS + 3 * k) = lam[3 * k]; LDS(L_LS + 3 * k + 1) = lam[3 * k + 1]; LDS(L_LS + 3 * k + 2) = lam[3 * k + 2]; }
     }
   }
+#endif
 
   __syncthreads();
   // ---- apply all contact impulses with one propagation ------------------------------------------------
