@@ -1,0 +1,65 @@
+"""Per-phase cycle breakdown of go1_step_kernel (one wave: workgroup 0, lane 0), using the -DGO1_PROFILE build.
+GPU box:  python tools/phase_profile.py [--envs 4096] [--steps 50] [extra hipcc flags...]
+Rebuilds csrc/libgo1sim.so with the markers, runs `steps` env steps of the train.py configuration with N(0,1)
+actions, prints accumulated s_memtime deltas per phase, then restores the normal library."""
+import argparse
+import ctypes
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "walk-these-ways_amd")
+CSRC = os.path.join(PKG, "csrc")
+for p in (os.path.join(PKG, "shims"), PKG, REPO):
+    sys.path.insert(0, p)
+
+PHASES = ["load state/actions/warm start", "torque model (x4)", "kinematics + candidates + ABA 1,2 (x4)",
+          "ABA 3 + contact list + publish (x4)", "Delassus (x4)", "PGS (x4)", "apply + integrate (x4)",
+          "store state/feet/forces", "post: derived + callbacks", "post: gait clock + push/dof-rand",
+          "post: feet/heights/termination", "post: rewards", "post: reset", "post: observations", "post: privileged obs",
+          "post: roll"]
+
+
+def build(flags):
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + flags + \
+          ["-o", os.path.join(CSRC, "libgo1sim.so"), os.path.join(CSRC, "go1sim.hip")]
+    subprocess.check_call(cmd, cwd=CSRC)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=50)
+    args, extra = ap.parse_known_args()
+    build(["-DGO1_PROFILE"] + extra)
+    try:
+        import torch
+        import go1sim_host as H
+        from go1_gym.envs.base.legged_robot_config import make_cfg
+        from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+        from scripts.train_config import apply_train_config
+        cfg = apply_train_config(make_cfg(), num_envs=args.envs)
+        env = VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg)
+        lib = H.load_library()
+        lib.go1sim_debug_read_profile.argtypes = [ctypes.c_void_p]
+        buf = (ctypes.c_uint64 * 64)()
+        acts = torch.randn(args.steps, args.envs, 12, device="cuda")
+        for t in range(10):
+            env.step(acts[t])
+        torch.cuda.synchronize()
+        lib.go1sim_debug_read_profile(buf)            # clear
+        for t in range(args.steps):
+            env.step(acts[t])
+        torch.cuda.synchronize()
+        assert lib.go1sim_debug_read_profile(buf) == 0
+        tot = sum(buf[:16])
+        print(f"cycles per step (wave 0 lane 0, s_memtime ticks): {tot / args.steps:.0f}")
+        for i, name in enumerate(PHASES):
+            print(f"  {i:2d} {name:42s} {buf[i] / args.steps:10.0f}  {100.0 * buf[i] / tot:5.1f} %")
+    finally:
+        build([])
+
+
+if __name__ == "__main__":
+    main()

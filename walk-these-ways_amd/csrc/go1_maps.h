@@ -316,7 +316,7 @@ DEV int reward_raw_sign(int id) {
 // ================================================================================================
 #define QUAD_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)
 
-DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane, int e, int N, int64_t counter_post, V3 grav, int history_slot) {
+DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane, int e, int N, int64_t counter_post, V3 grav, int history_slot PROF_PARAM) {
   const int leg = lane & 3;
   const bool is0 = leg == 0;
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
@@ -349,6 +349,7 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
     if (ep_len % cfg.resample_interval == 0) resample_commands(cfg, B, e, N, counter_post, P_CMD_CB);
   }
   QUAD_SYNC();                // commands / command_sums of this step are final
+  PROF(8);
   // ---- gait clock of the own foot (_step_contact_targets) -----------------------------------------
   FootCtx F;
   F.foot_index = AT(B.foot_indices, leg, e);
@@ -383,6 +384,7 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
     }
     if (ep_len % cfg.rand_interval == 0) randomize_dof_props(cfg, B, e, N, counter_post, P_DOFPROPS_CB);
   }
+  PROF(9);
   // ---- own foot / bodies -------------------------------------------------------------------------
   F.pos = v3(AT(B.foot_positions, 3 * leg, e), AT(B.foot_positions, 3 * leg + 1, e), AT(B.foot_positions, 3 * leg + 2, e));
   F.vel = v3(AT(B.foot_velocities, 3 * leg, e), AT(B.foot_velocities, 3 * leg + 1, e), AT(B.foot_velocities, 3 * leg + 2, e));
@@ -431,6 +433,7 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
   if (cfg.use_terminal_body_height && root_z - mean_height < cfg.terminal_body_height) reset = true;
   if (is0) { B.time_out_buf[e] = (uint8_t)time_out; B.reset_buf[e] = (uint8_t)reset; }
 
+  PROF(10);
   // ---- compute_reward ----------------------------------------------------------------------------------
   float rew = 0.f, pos = 0.f, neg = 0.f;
 #pragma unroll 1
@@ -459,10 +462,12 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
     AT(B.command_sums, k0 + 3, e) += (d.bav.z - c2) * (d.bav.z - c2);
     AT(B.command_sums, k0 + 4, e) += 1.f;
   }
+  PROF(11);
   QUAD_SYNC();                // running sums complete before a reset logs / clears them
   // ---- reset ----------------------------------------------------------------------------------------
   if (reset && is0) reset_env(cfg, B, e, N, counter_post);
   QUAD_SYNC();                // the observation sees the post-reset state, as in the reference
+  PROF(12);
 
   // ---- compute_observations ---------------------------------------------------------------------------
   {
@@ -527,6 +532,7 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
       n += np;
     }
 
+    PROF(13);
     if (is0) {
       float* pv = B.privileged_obs_buf + (size_t)e * cfg.num_privileged_obs;
       int np = 0;
@@ -556,6 +562,7 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
       if (cfg.priv_enabled[GO1_PRIV_DESIRED_CONTACT]) for (int f = 0; f < 4; f++) privraw(AT(B.desired_contact_states, f, e));
     }
   }
+  PROF(14);
   // ---- roll (own joints) --------------------------------------------------------------------------------
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) {
@@ -566,4 +573,5 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
     AT(B.last_joint_pos_target, j, e) = AT(B.joint_pos_target, j, e);
     AT(B.last_dof_vel, j, e) = AT(B.dof_vel, j, e);
   }
+  PROF(15);
 }

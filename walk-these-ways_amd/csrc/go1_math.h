@@ -2,6 +2,25 @@
 // 3-vectors, spatial (6D) vectors [angular; linear], symmetric 6x6 articulated inertias,
 // xyzw quaternions, Philox4x32-10.  Everything is force-inlined and register resident.
 #pragma once
+
+// ---- optional phase profiling (build with -DGO1_PROFILE; tools/phase_profile.py): the first lane of workgroup 0
+// accumulates s_memtime deltas per phase into g_prof[]; everything compiles away otherwise ------------------
+#ifdef GO1_PROFILE
+__device__ unsigned long long g_prof[64];
+__shared__ unsigned long long s_prof[16];          // accumulated with fire-and-forget LDS adds: no memory stall per marker
+#define PROF_PARAM , unsigned long long& prof_t
+#define PROF_PASS , prof_t
+#define PROF_DECL if (threadIdx.x < 16) s_prof[threadIdx.x] = 0; __syncthreads(); unsigned long long prof_t = __builtin_readcyclecounter();
+#define PROF(i) do { unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&s_prof[i], now_ - prof_t); prof_t = now_; } while (0)
+#define PROF_FLUSH do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x < 16) g_prof[threadIdx.x] += s_prof[threadIdx.x]; } while (0)
+#else
+#define PROF_PARAM
+#define PROF_PASS
+#define PROF_DECL
+#define PROF(i) do { } while (0)
+#define PROF_FLUSH do { } while (0)
+#endif
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

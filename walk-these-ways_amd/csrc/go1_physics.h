@@ -33,7 +33,7 @@ enum {
   L_BV = 93,            // MAXC x 3  b = J v_free
   L_LS = 111,           // MAXC x 3  slot impulses (n, t1, t2)
   L_W = 129,            // NR x NR Delassus matrix
-  L_END = 129 + NR * NR
+  L_END = 129 + NR * NR + 2 // +2: the PGS column split reads W[r][18..19] (times a zero impulse) on its fifth pass
 };
 #define LDS(f) lds[(f) * EPW + el]
 
@@ -209,7 +209,7 @@ DEV SV leg_response(const SV S[3], const SV U[3], const float Dinv[3], SV a0, in
   return a;
 }
 
-DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs, float* lds, int lane, Base& s, Leg& L, V3 grav, bool use_warm, float h) {
+DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs, float* lds, int lane, Base& s, Leg& L, V3 grav, bool use_warm, float h PROF_PARAM) {
   const int leg = lane & 3, el = lane >> 2;
   const M3 R0 = quat_to_mat(s.qx, s.qy, s.qz, s.qw);
   const SV v0 = sv(s.w, s.v);
@@ -321,6 +321,7 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
     pA0 = pA0 + quad_sum(pa_hip);
   }
 
+  PROF(2);
   // ---- ABA pass 3 ------------------------------------------------------------------------------------
   const Sym6 I0inv = sym6_inverse(IA0);
   SV a0 = -sym6_mul(I0inv, pA0);
@@ -424,6 +425,7 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
   for (int i = 0; i < 12; i++) LDS(L_LAM + 3 * (1 + 4 * leg) + i) = 0.f;
 
   __syncthreads();      // one-wave workgroup: orders this wave's LDS traffic between phases
+  PROF(3);
   // ---- Delassus matrix by impulse propagation through the ABA factors ---------------------------------
 #ifdef GO1_ABLATE_DELASSUS
   for (int c = leg; c < NR * NR; c += 4) LDS(L_W + c) = (c / NR == c % NR) ? 1.f : 0.f;
@@ -491,6 +493,7 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
 #endif
 
   __syncthreads();
+  PROF(4);
   // ---- projected Gauss-Seidel on the impulses -------------------------------------------------------------
   // Row dot-products are split over the quad (lane `leg` owns columns c = leg, leg+4, ...).  Everything the sweep
   // needs except the 15 W entries of the current contact row block lives in registers: the impulse vector
@@ -517,12 +520,11 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
       w10[k] = on ? LDS(L_W + (r0 + 1) * NR + r0) : 0.f;
       w20[k] = on ? LDS(L_W + (r0 + 2) * NR + r0) : 0.f;
     }
-    bool colok[5];
 #pragma unroll
-    for (int cc = 0; cc < 5; cc++) {
-      colok[cc] = leg + 4 * cc < 3 * K;
-      lamloc[cc] = colok[cc] ? LDS(L_LS + leg + 4 * cc) : 0.f;
-    }
+    for (int cc = 0; cc < 5; cc++) lamloc[cc] = (leg + 4 * cc < 3 * K) ? LDS(L_LS + leg + 4 * cc) : 0.f;
+    // Columns >= 3K are never written by the Delassus phase: their impulses are exactly zero and the LDS words
+    // behind them are finite (zero-filled at kernel start, later only ever hold old W entries), so the products
+    // vanish without masking.
     const float* wcol = lds + (L_W + leg) * EPW + el;          // W[r][leg + 4 cc] = wcol[(r * NR + 4 cc) * EPW]
 #pragma unroll 1
     for (int it = 0; it < cfg.solver_iterations; it++) {
@@ -541,9 +543,9 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
 #pragma unroll
           for (int cc = 0; cc < 5; cc++) {                     // same partition and order as the serial-in-c sum
             const float l = lamloc[cc];
-            pn = fmaf(colok[cc] ? wn[cc] : 0.f, l, pn);
-            p1 = fmaf(colok[cc] ? w1[cc] : 0.f, l, p1);
-            p2 = fmaf(colok[cc] ? w2[cc] : 0.f, l, p2);
+            pn = fmaf(wn[cc], l, pn);
+            p1 = fmaf(w1[cc], l, p1);
+            p2 = fmaf(w2[cc], l, p2);
           }
           const float un = bvn[k] + quad_sum(pn);
           float u1 = bv1[k] + quad_sum(p1);
@@ -555,8 +557,8 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
           u2 = fmaf(w20[k], dln, u2);
           float l1 = lam[r0 + 1] - u1 * id1[k];
           float l2 = lam[r0 + 2] - u2 * id2[k];
-          const float lim = mu * ln, nrm = sqrtf(l1 * l1 + l2 * l2);
-          if (nrm > lim) { const float sc = (nrm > 0.f) ? lim / nrm : 0.f; l1 *= sc; l2 *= sc; }
+          const float lim = mu * ln, nn = l1 * l1 + l2 * l2;   // friction cone: |l_t| <= mu l_n
+          if (nn > lim * lim) { const float sc = lim * __builtin_amdgcn_rsqf(nn); l1 *= sc; l2 *= sc; }
           const bool on = k < K;                               // lanes of environments with fewer contacts idle here
           lam[r0] = on ? ln : 0.f; lam[r0 + 1] = on ? l1 : 0.f; lam[r0 + 2] = on ? l2 : 0.f;
 #pragma unroll
@@ -574,6 +576,7 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
 #endif
 
   __syncthreads();
+  PROF(5);
   // ---- apply all contact impulses with one propagation ------------------------------------------------
   SV pA[3];
 #pragma unroll
@@ -650,6 +653,7 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
     float inv = rsqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
     s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv; s.qw = nw * inv;
   }
+  PROF(6);
 }
 
 // own foot position / velocity at the current state (reference legged_robot.py:112-115)

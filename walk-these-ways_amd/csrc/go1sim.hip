@@ -43,6 +43,7 @@ struct StepArgs {
 // ================================================================================================
 extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArgs A) {
   __shared__ float lds[L_END * EPW];
+  for (int i = threadIdx.x; i < (L_END - L_W) * EPW; i += WAVE) lds[L_W * EPW + i] = 0.f;   // finite everywhere: see the PGS column split
   const Go1SimConfig& cfg = A.sc->cfg;
   const Go1SimBuffers& B = A.sc->buf;
   const int N = cfg.num_envs;
@@ -50,6 +51,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
   const int e = blockIdx.x * EPW + (lane >> 2);
   if (e >= N) return;
   const float h = cfg.sim_dt;
+  PROF_DECL
   Base s;
   Leg L;
   load_state(B, leg, e, N, s, L);
@@ -65,14 +67,16 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
   load_lambda(cfg, B, lds, lane, e, N, !warm);
   const int nl = cfg.lag_timesteps + 1;
   int head = A.lag_head;
+  PROF(0);
 #pragma unroll 1
   for (int sub = 0; sub < cfg.decimation; sub++) {
 #ifndef GO1_ABLATE_TORQUE
     compute_torques(cfg, B, L, leg, e, N, head);
 #endif
+    PROF(1);
     head = (head + 1) % nl;
 #ifndef GO1_ABLATE_PHYSICS
-    physics_substep(cfg, B.height_samples, lds, lane, s, L, grav, warm || (cfg.warm_start && sub > 0), h);
+    physics_substep(cfg, B.height_samples, lds, lane, s, L, grav, warm || (cfg.warm_start && sub > 0), h PROF_PASS);
 #endif
   }
   store_state(B, leg, e, N, s, L);
@@ -80,14 +84,17 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
   store_forces(cfg, B, lds, lane, e, N);
   __threadfence_block();
   __syncthreads();
+  PROF(7);
 #ifndef GO1_ABLATE_POST
-  post_physics(cfg, B, lane, e, N, A.counter + 1, grav, A.history_slot);
+  post_physics(cfg, B, lane, e, N, A.counter + 1, grav, A.history_slot PROF_PASS);
 #endif
+  PROF_FLUSH;
 }
 
 // piecewise entry points with the 4-lane mapping (parity tests): torques only / one physics substep / tensor maps only
 extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs A) {
   __shared__ float lds[L_END * EPW];
+  for (int i = threadIdx.x; i < (L_END - L_W) * EPW; i += WAVE) lds[L_W * EPW + i] = 0.f;   // finite everywhere: see the PGS column split
   const Go1SimConfig& cfg = A.sc->cfg;
   const Go1SimBuffers& B = A.sc->buf;
   const int N = cfg.num_envs;
@@ -95,7 +102,8 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   const int e = blockIdx.x * EPW + (lane >> 2);
   if (e >= N) return;
   if (A.mode == 4) {       // tensor maps only
-    post_physics(cfg, B, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot);
+    PROF_DECL
+    post_physics(cfg, B, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot PROF_PASS);
     return;
   }
   Base s;
@@ -112,7 +120,8 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) L.tau[jj] = AT(B.torques, 3 * leg + jj, e);
   load_lambda(cfg, B, lds, lane, e, N, false);
-  physics_substep(cfg, B.height_samples, lds, lane, s, L, grav, cfg.warm_start != 0, cfg.sim_dt);
+  PROF_DECL
+  physics_substep(cfg, B.height_samples, lds, lane, s, L, grav, cfg.warm_start != 0, cfg.sim_dt PROF_PASS);
   store_state(B, leg, e, N, s, L);
   foot_state(s, L, leg, B, e, N);
   store_forces(cfg, B, lds, lane, e, N);
@@ -358,3 +367,12 @@ extern "C" int go1sim_read_timings(Go1Sim* s, float* ms, int32_t max, int32_t* c
   return 0;
 }
 extern "C" const char* go1sim_version(void) { return "go1sim 0.3 (gfx950, abi 2, 4 lanes/env)"; }
+
+#ifdef GO1_PROFILE
+// debug build only (tools/phase_profile.py): read and clear the per-phase cycle accumulators of workgroup 0, lane 0
+extern "C" int go1sim_debug_read_profile(unsigned long long* out64) {
+  unsigned long long z[64] = {0};
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
