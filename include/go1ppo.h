@@ -77,6 +77,27 @@ int go1ppo_mse(const void* pred, int pred_ld, const float* target, int npv, cons
 int go1ppo_wgrad(const void* dz, int ld_dz, const void* h, int ld_h, int64_t rows, int n, int k, float* dW, int ldw,
                  float* bias_grad, void* stream);
 
+/* ---- rollout glue (PPO.act / process_env_step / RolloutStorage of the reference, ppo.py:60-97, rollout_storage.py:54-84) ---- */
+
+/* a = mean + std * noise; log N(a; mean, std) summed over actions; policy outputs written into the storage slot:
+ * actions, mu, sigma [rows][num_actions], values, logp [rows].  mean/value: bf16 [rows][head_ld] head outputs. */
+int go1ppo_act(const void* mean, const void* value, int head_ld, const float* std, int num_actions, int64_t rows,
+               const float* noise, float* actions, float* mu, float* sigma, float* values, float* logp, void* stream);
+
+/* rewards_out = rewards + gamma * values * time_outs (time_outs may be NULL), dones_out = dones,
+ * env_bins_out = (float)env_bins (env_bins may be NULL). */
+int go1ppo_store_step(const float* rewards, const uint8_t* dones, const uint8_t* time_outs, const int32_t* env_bins,
+                      const float* values, float gamma, int64_t n, float* rewards_out, uint8_t* dones_out,
+                      float* env_bins_out, void* stream);
+
+/* GAE(lambda) backward scan over [T][N] buffers; returns and un-normalised advantages (= returns - values);
+ * stats[0] += sum(adv), stats[1] += sum(adv^2) in double. */
+int go1ppo_gae(const float* rewards, const uint8_t* dones, const float* values, const float* last_values, int T, int64_t N,
+               float gamma, float lam, float* returns, float* advantages, double* stats, void* stream);
+
+/* adv = (adv - mean) / (std + 1e-8) with the unbiased std of stats = [sum, sum of squares, count]. */
+int go1ppo_normalize(float* adv, int64_t n, const double* stats, void* stream);
+
 const char* go1ppo_version(void);
 
 #ifdef __cplusplus

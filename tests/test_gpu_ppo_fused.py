@@ -186,6 +186,49 @@ def test_mse_kernel_matches_autograd(lib, selective):
     torch.testing.assert_close(out[2:], d[:, :npv].float().sum(0), rtol=1e-3, atol=1e-6)
 
 
+def test_rollout_glue_kernels_match_torch(lib):
+    """go1ppo_act / go1ppo_store_step / go1ppo_gae / go1ppo_normalize vs the torch statements of ppo.py / rollout_storage.py."""
+    from go1_gym_learn.ppo_cse import fused
+    from go1_gym_learn.ppo_cse.ppo import gaussian_log_prob
+    from go1_gym_learn.ppo_cse.rollout_storage import RolloutStorage
+    g = torch.Generator(device="cuda").manual_seed(6)
+    N, T, A = 1000, 7, 12
+    st = RolloutStorage(N, T, [70], [2], [2100], [A], "cuda:0", history_dtype=torch.bfloat16, history_pad_to=8, augment=True)
+    ref = RolloutStorage(N, T, [70], [2], [2100], [A], "cuda:0", history_dtype=torch.bfloat16, history_pad_to=8, augment=True)
+    std = torch.rand(A, device="cuda", generator=g) + 0.5
+    for s_ in range(T):
+        mean = torch.zeros(N, 64, device="cuda", dtype=torch.bfloat16)
+        value = torch.zeros(N, 64, device="cuda", dtype=torch.bfloat16)
+        mean[:, :A] = bf(torch.randn(N, A, device="cuda", generator=g))
+        value[:, :1] = bf(torch.randn(N, 1, device="cuda", generator=g))
+        noise = torch.randn(N, A, device="cuda", generator=g)
+        fused.act(lib, mean, value, std, noise, st, s_)
+        m = mean[:, :A].float()
+        a = m + std * noise
+        ref.actions[s_], ref.mu[s_], ref.sigma[s_], ref.values[s_] = a, m, std.expand_as(m), value[:, :1].float()
+        ref.actions_log_prob[s_] = gaussian_log_prob(a, m, std).unsqueeze(1)
+        rew = torch.randn(N, device="cuda", generator=g)
+        dones = (torch.rand(N, device="cuda", generator=g) < 0.1).to(torch.uint8)
+        tos = (torch.rand(N, device="cuda", generator=g) < 0.05)
+        bins = torch.randint(0, 4000, (N,), device="cuda", generator=g, dtype=torch.int32)
+        fused.store_step(lib, st, s_, rew, dones, tos.view(torch.uint8), bins, 0.99)
+        ref.rewards[s_] = (rew + 0.99 * (ref.values[s_].squeeze(1) * tos)).unsqueeze(1)
+        ref.dones[s_], ref.env_bins[s_] = dones.unsqueeze(1), bins.float().unsqueeze(1)
+    torch.cuda.synchronize()
+    for k in ("actions", "mu", "sigma", "values", "rewards", "env_bins"):
+        torch.testing.assert_close(getattr(st, k), getattr(ref, k), rtol=1e-6, atol=1e-6, msg=k)
+    torch.testing.assert_close(st.actions_log_prob, ref.actions_log_prob, rtol=1e-5, atol=1e-5)
+    assert torch.equal(st.dones, ref.dones)
+    last = torch.randn(N, 1, device="cuda", generator=g)
+    adv_ptr = st.advantages.data_ptr()
+    st.compute_returns(last, 0.99, 0.95, fused_lib=lib)
+    ref.compute_returns(last, 0.99, 0.95)
+    torch.cuda.synchronize()
+    assert st.advantages.data_ptr() == adv_ptr and ref.advantages.data_ptr() != 0      # in place: graphs hold the address
+    torch.testing.assert_close(st.returns, ref.returns, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(st.advantages, ref.advantages, rtol=1e-4, atol=1e-5)
+
+
 def make_alg(fused_on, N, T, seed=0):
     from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
     from go1_gym_learn.ppo_cse.ppo import PPO, PPO_Args

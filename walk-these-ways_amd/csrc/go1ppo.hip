@@ -409,6 +409,85 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* dz, int ld_dz
   }
 }
 
+// ---------------------------------------------------------------------------------------------- rollout glue
+// PPO.act (ppo.py:60-77): sample a = mu + sigma * noise, log-prob, and write the transition's policy outputs
+// straight into the rollout-storage slot.  One thread per environment.
+__global__ __launch_bounds__(256) void act_kernel(const bf16_t* mean, const bf16_t* value, int head_ld, const float* std, int A,
+                                                  int64_t rows, const float* noise, float* actions, float* mu, float* sigma,
+                                                  float* values, float* logp) {
+  int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const float HALF_LOG_2PI = 0.9189385332046727f;
+  float lp = 0.f, logs = 0.f;
+  for (int j = 0; j < A; j++) {
+    float sg = std[j], m = bf2f(mean[r * head_ld + j]);
+    float a = m + sg * noise[r * A + j];
+    float z = (a - m) / sg;
+    lp += -0.5f * z * z;
+    logs += logf(sg);
+    actions[r * A + j] = a;
+    mu[r * A + j] = m;
+    sigma[r * A + j] = sg;
+  }
+  logp[r] = lp - (logs + A * HALF_LOG_2PI);
+  values[r] = bf2f(value[r * head_ld]);
+}
+
+// PPO.process_env_step (ppo.py:79-91) + RolloutStorage.add_transitions: reward with the time-out bootstrap
+// r + gamma * V * time_out, done flags and curriculum bins into the storage slot.
+__global__ __launch_bounds__(256) void store_step_kernel(const float* rewards, const uint8_t* dones, const uint8_t* time_outs,
+                                                         const int32_t* env_bins, const float* values, float gamma, int64_t n,
+                                                         float* rewards_out, uint8_t* dones_out, float* env_bins_out) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float r = rewards[i];
+  if (time_outs) r += gamma * (values[i] * (time_outs[i] ? 1.f : 0.f));
+  rewards_out[i] = r;
+  dones_out[i] = dones[i];
+  if (env_bins) env_bins_out[i] = (float)env_bins[i];
+}
+
+// RolloutStorage.compute_returns (rollout_storage.py:72-84): backward GAE scan, one thread per environment, and the
+// sums the advantage normalisation needs (double accumulators; reduced over ranks by the caller when envs are sharded).
+__global__ __launch_bounds__(256) void gae_kernel(const float* rewards, const uint8_t* dones, const float* values, const float* last_values,
+                                                  int T, int64_t N, float gamma, float lam, float* returns, float* advantages, double* stats) {
+  __shared__ double red[2][4];
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  if (e < N) {
+    float adv = 0.f, next_v = last_values[e];
+    for (int t = T - 1; t >= 0; t--) {
+      const int64_t i = (int64_t)t * N + e;
+      const float alive = 1.f - (float)dones[i];
+      const float v = values[i];
+      const float delta = rewards[i] + alive * gamma * next_v - v;
+      adv = delta + alive * gamma * lam * adv;
+      const float ret = adv + v;
+      const float a = ret - v;
+      returns[i] = ret;
+      advantages[i] = a;
+      s1 += a;
+      s2 += (double)a * a;
+      next_v = v;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x < 2) atomicAdd(stats + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// advantages = (advantages - mean) / (std + 1e-8), unbiased std from stats = [sum, sum of squares, count]
+__global__ __launch_bounds__(256) void normalize_kernel(float* adv, int64_t n, const double* stats) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double cnt = stats[2], mean = stats[0] / cnt;
+  double var = (stats[1] - cnt * mean * mean) / (cnt - 1.0);
+  var = var > 0.0 ? var : 0.0;
+  const float m = (float)mean, sd = (float)sqrt(var);
+  adv[i] = (adv[i] - m) / (sd + 1e-8f);
+}
+
 // ---------------------------------------------------------------------------------------------- C-ABI
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -482,6 +561,39 @@ extern "C" int go1ppo_wgrad(const void* dz, int ld_dz, const void* h, int ld_h, 
   else
     wgrad2_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dz, ld_dz, (const bf16_t*)h, ld_h, rows,
                                                                (int)(chunk_steps * step), dW, ldw, bias_grad);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_act(const void* mean, const void* value, int head_ld, const float* std, int num_actions, int64_t rows,
+                          const float* noise, float* actions, float* mu, float* sigma, float* values, float* logp, void* stream) {
+  if (!mean || !value || !std || !noise || !actions || !mu || !sigma || !values || !logp || rows <= 0 || num_actions <= 0 ||
+      num_actions > head_ld)
+    return -1;
+  act_kernel<<<dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      (const bf16_t*)mean, (const bf16_t*)value, head_ld, std, num_actions, rows, noise, actions, mu, sigma, values, logp);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_store_step(const float* rewards, const uint8_t* dones, const uint8_t* time_outs, const int32_t* env_bins,
+                                 const float* values, float gamma, int64_t n, float* rewards_out, uint8_t* dones_out,
+                                 float* env_bins_out, void* stream) {
+  if (!rewards || !dones || !values || !rewards_out || !dones_out || n <= 0 || (env_bins && !env_bins_out)) return -1;
+  store_step_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      rewards, dones, time_outs, env_bins, values, gamma, n, rewards_out, dones_out, env_bins_out);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_gae(const float* rewards, const uint8_t* dones, const float* values, const float* last_values, int T, int64_t N,
+                          float gamma, float lam, float* returns, float* advantages, double* stats, void* stream) {
+  if (!rewards || !dones || !values || !last_values || !returns || !advantages || !stats || T <= 0 || N <= 0) return -1;
+  gae_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(rewards, dones, values, last_values, T, N, gamma, lam,
+                                                                                      returns, advantages, stats);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_normalize(float* adv, int64_t n, const double* stats, void* stream) {
+  if (!adv || !stats || n <= 0) return -1;
+  normalize_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(adv, n, stats);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 

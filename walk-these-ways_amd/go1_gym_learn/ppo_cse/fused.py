@@ -38,7 +38,8 @@ class LossArgs(ctypes.Structure):
                 ("value_loss", ctypes.c_void_p), ("surrogate_loss", ctypes.c_void_p)]
 
 
-EXPORTED_SYMBOLS = ["go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_version"]
+EXPORTED_SYMBOLS = ["go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_act",
+                    "go1ppo_store_step", "go1ppo_gae", "go1ppo_normalize", "go1ppo_version"]
 
 
 def load_library(path=None):
@@ -57,6 +58,11 @@ def load_library(path=None):
     L.go1ppo_loss.argtypes = [ctypes.POINTER(LossArgs), vp]
     L.go1ppo_mse.argtypes = [vp, i32, vp, i32, vp, i64, i64, i32, vp, vp, vp, vp, vp]
     L.go1ppo_wgrad.argtypes = [vp, i32, vp, i32, i64, i32, i32, vp, i32, vp, vp]
+    f32 = ctypes.c_float
+    L.go1ppo_act.argtypes = [vp, vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp]
+    L.go1ppo_store_step.argtypes = [vp, vp, vp, vp, vp, f32, i64, vp, vp, vp, vp]
+    L.go1ppo_gae.argtypes = [vp, vp, vp, vp, i32, i64, f32, f32, vp, vp, vp, vp]
+    L.go1ppo_normalize.argtypes = [vp, i64, vp, vp]
     for name in EXPORTED_SYMBOLS[:-1]:
         getattr(L, name).restype = ctypes.c_int
     L.go1ppo_version.restype = ctypes.c_char_p
@@ -239,3 +245,36 @@ class FusedNet:
         _chk(self.lib.go1ppo_mse(pred.data_ptr(), HEAD, target.data_ptr(), self.pol.npv, idx.data_ptr(), self.M, num_train,
                                  int(selective), dpred.data_ptr(), self.G[f"adaptation.{last}.b"].data_ptr(),
                                  acc[2:].data_ptr(), acc[3:].data_ptr(), _stream()), "go1ppo_mse")
+
+
+# ---- rollout glue ----------------------------------------------------------------------------------------------
+def act(lib, mean, value, std, noise, st, s):
+    """sample + log-prob + policy outputs into rollout-storage slot s (see go1ppo_act)."""
+    _chk(lib.go1ppo_act(mean.data_ptr(), value.data_ptr(), _ld(mean), std.data_ptr(), std.numel(), mean.shape[0], noise.data_ptr(),
+                        st.actions[s].data_ptr(), st.mu[s].data_ptr(), st.sigma[s].data_ptr(), st.values[s].data_ptr(),
+                        st.actions_log_prob[s].data_ptr(), _stream()), "go1ppo_act")
+
+
+def store_step(lib, st, s, rewards, dones, time_outs, env_bins, gamma):
+    n = rewards.shape[0]
+    for t, dt in ((rewards, torch.float32), (dones, torch.uint8)):
+        assert t.is_contiguous() and t.dtype == dt and t.shape[0] == n
+    if time_outs is not None:
+        assert time_outs.is_contiguous() and time_outs.element_size() == 1
+    if env_bins is not None:
+        assert env_bins.is_contiguous() and env_bins.dtype == torch.int32
+    _chk(lib.go1ppo_store_step(rewards.data_ptr(), dones.data_ptr(), _ptr(time_outs), _ptr(env_bins), st.values[s].data_ptr(), gamma, n,
+                               st.rewards[s].data_ptr(), st.dones[s].data_ptr(), st.env_bins[s].data_ptr() if env_bins is not None else None,
+                               _stream()), "go1ppo_store_step")
+
+
+def gae(lib, st, last_values, gamma, lam, stats):
+    T, N = st.num_transitions_per_env, st.num_envs
+    stats.zero_()
+    _chk(lib.go1ppo_gae(st.rewards.data_ptr(), st.dones.data_ptr(), st.values.data_ptr(), last_values.data_ptr(), T, N, gamma, lam,
+                        st.returns.data_ptr(), st.advantages.data_ptr(), stats.data_ptr(), _stream()), "go1ppo_gae")
+    stats[2] = float(T * N)
+
+
+def normalize(lib, st, stats):
+    _chk(lib.go1ppo_normalize(st.advantages.data_ptr(), st.advantages.numel(), stats.data_ptr(), _stream()), "go1ppo_normalize")

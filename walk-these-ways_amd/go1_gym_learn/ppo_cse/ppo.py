@@ -193,6 +193,8 @@ class PPO:
         slot = self.storage.observation_histories[self.storage.step]
         self.storage.write_history(slot, obs_history, privileged_obs)
         t.observation_histories = slot
+        if self._roll_net is not None and slot.shape[0] == self._roll_net.M:
+            return self._act_fused(slot, obs, privileged_obs)
         mean, value = self._infer(slot)
         std = self.std.detach()
         t.actions = mean + std * torch.randn_like(mean)
@@ -202,6 +204,24 @@ class PPO:
         t.action_sigma = std.expand_as(mean)
         t.observations = obs
         t.critic_observations = obs
+        t.privileged_observations = privileged_obs
+        return t.actions
+
+    def _act_fused(self, slot, obs, privileged_obs):
+        """inference on the static-buffer engine, then ONE kernel that samples, evaluates the log-prob and writes
+        actions / mean / sigma / value / log-prob straight into the storage slot (fused.act)."""
+        from go1_gym_learn.ppo_cse import fused
+        t, st = self.transition, self.storage
+        s = st.step
+        if s >= st.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        with torch.no_grad():
+            mean, value, _ = self._roll_net.forward(slot)
+            noise = torch.randn(slot.shape[0], self.n_std, device=slot.device)
+            fused.act(self._fused_lib, mean, value, self.std, noise, st, s)
+        t.actions, t.values, t.actions_log_prob = st.actions[s], st.values[s], st.actions_log_prob[s]
+        t.action_mean, t.action_sigma = st.mu[s], st.sigma[s]
+        t.observations = t.critic_observations = obs
         t.privileged_observations = privileged_obs
         return t.actions
 
@@ -216,6 +236,8 @@ class PPO:
 
     def process_env_step(self, rewards, dones, infos):
         t = self.transition
+        if t.actions is not None and self._roll_net is not None and t.actions.data_ptr() == self.storage.actions[self.storage.step].data_ptr():
+            return self._process_env_step_fused(rewards, dones, infos)
         t.rewards = rewards.clone()
         t.dones = dones
         t.env_bins = infos["env_bins"]
@@ -225,10 +247,29 @@ class PPO:
         t.clear()
         self.actor_critic.reset(dones)
 
+    def _process_env_step_fused(self, rewards, dones, infos):
+        """the policy outputs already sit in the slot (fused.act); rewards (+ time-out bootstrap), dones and bins go
+        in with one kernel, the two observation blocks with one copy each."""
+        from go1_gym_learn.ppo_cse import fused
+        t, st = self.transition, self.storage
+        s = st.step
+        tos = infos['time_outs'] if 'time_outs' in infos else None
+        if tos is not None and tos.dtype == torch.bool:
+            tos = tos.view(torch.uint8)
+        bins = infos["env_bins"][:rewards.shape[0]]
+        fused.store_step(self._fused_lib, st, s, rewards.contiguous(), dones if dones.dtype == torch.uint8 else dones.to(torch.uint8), tos,
+                         bins if bins.dtype == torch.int32 else bins.to(torch.int32), PPO_Args.gamma)
+        st.observations[s].copy_(t.observations)
+        st.privileged_observations[s].copy_(t.privileged_observations)
+        st.step += 1
+        t.clear()
+        self.actor_critic.reset(dones)
+
     def compute_returns(self, last_critic_obs, last_critic_privileged_obs):
         self.storage.write_history(self._last_hist, last_critic_obs, last_critic_privileged_obs)
         _, last_values = self._infer(self._last_hist)
-        self.storage.compute_returns(last_values.clone(), PPO_Args.gamma, PPO_Args.lam)
+        self.storage.compute_returns(last_values.clone(), PPO_Args.gamma, PPO_Args.lam,
+                                     fused_lib=self._fused_lib if self.fused else None)
 
     # ---- update ------------------------------------------------------------------------------------------
     def _adapt_lr(self, kl_mean):

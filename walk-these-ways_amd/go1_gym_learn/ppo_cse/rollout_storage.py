@@ -79,7 +79,10 @@ class RolloutStorage:
     def clear(self):
         self.step = 0
 
-    def compute_returns(self, last_values, gamma, lam):
+    def compute_returns(self, last_values, gamma, lam, fused_lib=None):
+        """`advantages` / `returns` are updated IN PLACE: the update's HIP graphs hold their addresses."""
+        if fused_lib is not None:
+            return self._compute_returns_fused(last_values, gamma, lam, fused_lib)
         advantage = 0
         for step in reversed(range(self.num_transitions_per_env)):
             next_values = last_values if step == self.num_transitions_per_env - 1 else self.values[step + 1]
@@ -87,9 +90,19 @@ class RolloutStorage:
             delta = self.rewards[step] + alive * gamma * next_values - self.values[step]
             advantage = delta + alive * gamma * lam * advantage
             self.returns[step] = advantage + self.values[step]
-        self.advantages = self.returns - self.values
+        torch.sub(self.returns, self.values, out=self.advantages)
         mean, std = self._global_mean_std(self.advantages)
-        self.advantages = (self.advantages - mean) / (std + 1e-8)
+        self.advantages.sub_(mean).div_(std + 1e-8)
+
+    def _compute_returns_fused(self, last_values, gamma, lam, lib):
+        """Same scan as one kernel (one thread per environment) + one normalisation kernel (csrc/go1ppo.hip)."""
+        from go1_gym_learn.ppo_cse import fused
+        if getattr(self, "_gae_stats", None) is None:
+            self._gae_stats = torch.zeros(3, device=self.device, dtype=torch.float64)
+        fused.gae(lib, self, last_values.contiguous().view(-1), gamma, lam, self._gae_stats)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self._gae_stats)          # global mean / std when the environments are sharded over ranks
+        fused.normalize(lib, self, self._gae_stats)
 
     @staticmethod
     def _global_mean_std(x):
