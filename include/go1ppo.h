@@ -98,6 +98,24 @@ int go1ppo_gae(const float* rewards, const uint8_t* dones, const float* values, 
 /* adv = (adv - mean) / (std + 1e-8) with the unbiased std of stats = [sum, sum of squares, count]. */
 int go1ppo_normalize(float* adv, int64_t n, const double* stats, void* stream);
 
+/* ---- optimiser step (ppo.py:126-160: adaptive-KL learning rate, clip_grad_norm_, Adam) ---- */
+
+/* number of floats `partial` must hold */
+int go1ppo_opt_partials(void);
+
+/* partial[b] = block b's sum of (g * gscale)^2 over [0, n) (partial == NULL: skipped); step[0] += 1;
+ * kl != NULL: lr[0] <- KL-adaptive schedule of ppo.py:126-136 on kl[0] * kl_scale. */
+int go1ppo_opt_prestep(const float* g, int64_t n, float gscale, float* partial, float* step, float* lr, const float* kl,
+                       float kl_scale, float desired_kl, float lr_min, float lr_max, void* stream);
+
+/* Adam (no weight decay, no amsgrad) on the elements [start0, start0+count0) U [start1, start1+count1) of the flat
+ * parameter p with gradient g * gscale * clip, clip = min(1, max_norm / (sqrt(sum partial) + 1e-6)) (partial == NULL:
+ * no clipping).  Refreshes the compute copies of the touched elements: body[i] (bf16) for i < n_body, tail[i - n_body]
+ * (fp32) behind it.  step / lr are the device scalars go1ppo_opt_prestep maintains. */
+int go1ppo_opt_adam(float* p, const float* g, float* m, float* v, int64_t start0, int64_t count0, int64_t start1,
+                    int64_t count1, float gscale, const float* partial, float max_norm, const float* step, const float* lr,
+                    float beta1, float beta2, float eps, void* body, int64_t n_body, float* tail, void* stream);
+
 const char* go1ppo_version(void);
 
 #ifdef __cplusplus

@@ -488,6 +488,73 @@ __global__ __launch_bounds__(256) void normalize_kernel(float* adv, int64_t n, c
   adv[i] = (adv[i] - m) / (sd + 1e-8f);
 }
 
+// ---------------------------------------------------------------------------------------------- optimiser step
+// PPO.update's step (ppo.py:126-160): KL-adaptive learning rate, global-norm clip, Adam, and the refresh of the bf16
+// compute copy — two kernels instead of ~25.
+//   prestep: per-block partial sums of g^2 (no atomics: deterministic), and by one thread the scalar bookkeeping
+//            that the second kernel only reads: step += 1, lr <- schedule(kl, lr).
+//   adam:    p, m, v update over up to two element ranges with the clip factor from the partials; writes the bf16
+//            copy of the updated parameters (and the fp32 tail, the action std) on the way.
+#define OPT_BLOCKS 512
+__global__ __launch_bounds__(256) void prestep_kernel(const float* g, int64_t n, float gscale, float* partial, float* step, float* lr,
+                                                      const float* kl, float kl_scale, float desired_kl, float lr_min, float lr_max) {
+  __shared__ float red[4];
+  float s = 0.f;
+  if (partial) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)OPT_BLOCKS * 256) {
+      float x = g[i] * gscale;
+      s = fmaf(x, x, s);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    step[0] += 1.f;
+    if (kl) {                         // ppo.py:126-136
+      const float k = kl[0] * kl_scale, l = lr[0];
+      if (k > desired_kl * 2.f) lr[0] = fmaxf(lr_min, l / 1.5f);
+      else if (k < desired_kl / 2.f && k > 0.f) lr[0] = fminf(lr_max, l * 1.5f);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t start0, int64_t count0,
+                                                   int64_t start1, int64_t count1, float gscale, const float* partial, float max_norm,
+                                                   const float* step, const float* lr, float beta1, float beta2, float eps,
+                                                   bf16_t* body, int64_t n_body, float* tail) {
+  __shared__ float clip_s;
+  if (threadIdx.x < 64) {
+    float c = 1.f;
+    if (partial) {
+      float s = 0.f;
+      for (int i = threadIdx.x; i < OPT_BLOCKS; i += 64) s += partial[i];
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      c = fminf(1.f, max_norm / (sqrtf(s) + 1e-6f));
+    }
+    if (threadIdx.x == 0) clip_s = c;
+  }
+  __syncthreads();
+  const float gs = gscale * clip_s;
+  const float t = step[0], l = lr[0];
+  const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
+  const float step_size = l / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  const int64_t total = count0 + count1;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total; j += (int64_t)gridDim.x * 256) {
+    const int64_t i = j < count0 ? start0 + j : start1 + (j - count0);
+    const float gi = g[i] * gs;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float pi = p[i] - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    p[i] = pi;
+    if (i < n_body) body[i] = f2bf(pi);
+    else if (tail) tail[i - n_body] = pi;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- C-ABI
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -596,5 +663,27 @@ extern "C" int go1ppo_normalize(float* adv, int64_t n, const double* stats, void
   normalize_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(adv, n, stats);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
+
+extern "C" int go1ppo_opt_prestep(const float* g, int64_t n, float gscale, float* partial, float* step, float* lr, const float* kl,
+                                  float kl_scale, float desired_kl, float lr_min, float lr_max, void* stream) {
+  if (!step || (partial && (!g || n <= 0)) || (kl && !lr)) return -1;
+  prestep_kernel<<<dim3(partial ? OPT_BLOCKS : 1), dim3(256), 0, (hipStream_t)stream>>>(g, n, gscale, partial, step, lr, kl, kl_scale,
+                                                                                       desired_kl, lr_min, lr_max);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_opt_adam(float* p, const float* g, float* m, float* v, int64_t start0, int64_t count0, int64_t start1,
+                               int64_t count1, float gscale, const float* partial, float max_norm, const float* step, const float* lr,
+                               float beta1, float beta2, float eps, void* body, int64_t n_body, float* tail, void* stream) {
+  if (!p || !g || !m || !v || !step || !lr || !body || count0 < 0 || count1 < 0 || count0 + count1 <= 0) return -1;
+  int64_t total = count0 + count1;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  adam_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, start0, count0, start1, count1, gscale, partial,
+                                                                             max_norm, step, lr, beta1, beta2, eps, (bf16_t*)body, n_body, tail);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_opt_partials(void) { return OPT_BLOCKS; }
 
 extern "C" const char* go1ppo_version(void) { return "go1ppo 0.1 (gfx950, abi 1)"; }

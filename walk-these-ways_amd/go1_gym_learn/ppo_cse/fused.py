@@ -39,7 +39,8 @@ class LossArgs(ctypes.Structure):
 
 
 EXPORTED_SYMBOLS = ["go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_act",
-                    "go1ppo_store_step", "go1ppo_gae", "go1ppo_normalize", "go1ppo_version"]
+                    "go1ppo_store_step", "go1ppo_gae", "go1ppo_normalize", "go1ppo_opt_partials", "go1ppo_opt_prestep",
+                    "go1ppo_opt_adam", "go1ppo_version"]
 
 
 def load_library(path=None):
@@ -63,6 +64,9 @@ def load_library(path=None):
     L.go1ppo_store_step.argtypes = [vp, vp, vp, vp, vp, f32, i64, vp, vp, vp, vp]
     L.go1ppo_gae.argtypes = [vp, vp, vp, vp, i32, i64, f32, f32, vp, vp, vp, vp]
     L.go1ppo_normalize.argtypes = [vp, i64, vp, vp]
+    L.go1ppo_opt_partials.argtypes = []
+    L.go1ppo_opt_prestep.argtypes = [vp, i64, f32, vp, vp, vp, vp, f32, f32, f32, f32, vp]
+    L.go1ppo_opt_adam.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, f32, vp, f32, vp, vp, f32, f32, f32, vp, i64, vp, vp]
     for name in EXPORTED_SYMBOLS[:-1]:
         getattr(L, name).restype = ctypes.c_int
     L.go1ppo_version.restype = ctypes.c_char_p
@@ -278,3 +282,33 @@ def gae(lib, st, last_values, gamma, lam, stats):
 
 def normalize(lib, st, stats):
     _chk(lib.go1ppo_normalize(st.advantages.data_ptr(), st.advantages.numel(), stats.data_ptr(), _stream()), "go1ppo_normalize")
+
+
+# ---- optimiser step ------------------------------------------------------------------------------------------------
+class FusedAdam:
+    """torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay) over element ranges of the flat fp32 master
+    parameter, with the gradient clip, the KL-adaptive learning rate and the refresh of the compute copies fused in
+    (go1ppo_opt_prestep + go1ppo_opt_adam).  `ranges`: up to two (start, count) pairs."""
+
+    def __init__(self, lib, master, body, std, n_body, lr, ranges=None, betas=(0.9, 0.999), eps=1e-8):
+        self.lib, self.master, self.body, self.std, self.n_body = lib, master, body, std, n_body
+        dev = master.device
+        self.m, self.v = torch.zeros_like(master), torch.zeros_like(master)
+        self.step = torch.zeros(1, device=dev)
+        self.lr = torch.full((1,), float(lr), device=dev)
+        self.partial = torch.zeros(lib.go1ppo_opt_partials(), device=dev)
+        self.betas, self.eps = betas, eps
+        r = list(ranges or [(0, master.numel())]) + [(0, 0)]
+        self.r0, self.r1 = r[0], r[1]
+
+    def step_(self, gscale=1.0, max_norm=None, kl=None, kl_scale=1.0, desired_kl=0.01, lr_min=1e-5, lr_max=1e-2):
+        g = self.master.grad
+        clip = max_norm is not None
+        _chk(self.lib.go1ppo_opt_prestep(g.data_ptr(), g.numel(), gscale, self.partial.data_ptr() if clip else None,
+                                         self.step.data_ptr(), self.lr.data_ptr(), _ptr(kl), kl_scale, desired_kl, lr_min, lr_max,
+                                         _stream()), "go1ppo_opt_prestep")
+        _chk(self.lib.go1ppo_opt_adam(self.master.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.r0[0], self.r0[1],
+                                      self.r1[0], self.r1[1], gscale, self.partial.data_ptr() if clip else None,
+                                      float(max_norm) if clip else 0.0, self.step.data_ptr(), self.lr.data_ptr(), self.betas[0],
+                                      self.betas[1], self.eps, self.body.data_ptr(), self.n_body, self.std.data_ptr(), _stream()),
+             "go1ppo_opt_adam")

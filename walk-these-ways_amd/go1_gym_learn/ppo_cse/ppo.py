@@ -111,9 +111,19 @@ class PPO:
         # when it applies and libgo1ppo.so is missing, load_library() raises.
         self.fused = bool(self.bf16 and PPO_Args.use_fused_kernels and self.policy.act is torch.nn.ELU)
         self._roll_net = self._train_net = None
+        self._opt = self._opt_ad = None
         if self.fused:
             from go1_gym_learn.ppo_cse import fused
             self._fused_lib = fused.load_library()
+            # optimiser steps as two kernels each (fused.FusedAdam); the adaptation optimiser only visits the
+            # adaptation module's elements (all other gradients of that stage are exactly zero, see above)
+            pol, ns = self.policy, self.n_std
+            self._opt = fused.FusedAdam(self._fused_lib, self.master, self.body, self.std, n, PPO_Args.learning_rate, ranges=[(0, n + ns)])
+            first, last = pol.index["adaptation.1.W"], pol.index[f"adaptation.{len(pol.nets['adaptation']) - 1}.b"]
+            tail = (pol.offsets[first], pol.offsets[last] + pol.sizes[last] - pol.offsets[first])
+            self._opt_ad = fused.FusedAdam(self._fused_lib, self.master, self.body, self.std, n, PPO_Args.adaptation_module_learning_rate,
+                                           ranges=[(pol.offsets[pol.index["W1"]], pol.first[0] * pol.Kp), tail])
+            self._lr = self._opt.lr
         if self.dp:                              # identical initial weights on every rank
             dist.broadcast(self.master, src=0)
         self._push_weights()
@@ -346,6 +356,12 @@ class PPO:
     def _stage_ppo_step(self):
         """adaptive-KL learning rate, global-norm clip, Adam, refresh the compute copies."""
         A = PPO_Args
+        if self._opt is not None:
+            adaptive = A.desired_kl is not None and A.schedule == 'adaptive'
+            w = float(_world()) if self.dp else 1.0
+            self._opt.step_(gscale=1.0 / w, max_norm=A.max_grad_norm, kl=self._kl if adaptive else None, kl_scale=1.0 / w,
+                            desired_kl=A.desired_kl if adaptive else 0.0)
+            return
         g = self.master.grad
         if self.dp:
             g.div_(_world())
@@ -375,6 +391,9 @@ class PPO:
         self._acc[3] += adaptation_test_loss.detach()
 
     def _stage_adapt_step(self):
+        if self._opt_ad is not None:
+            self._opt_ad.step_(gscale=1.0 / float(_world()) if self.dp else 1.0)
+            return
         if self.dp:
             self.master.grad.div_(_world())
         self.adaptation_module_optimizer.step()
