@@ -1,0 +1,58 @@
+"""Data-parallel path with the fused GPU update: 2 processes sharing cuda:0, gloo backend for the collectives (the
+production backend is RCCL; the code path — which buffers are all-reduced between which graph replays — is the same).
+Each rank holds a different env shard; after two updates (the second replays the HIP graphs) every rank must hold
+bit-identical master weights and learning rate."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, out):
+    sys.path[:0] = [os.path.join(HERE, "..", "walk-these-ways_amd", "shims"), os.path.join(HERE, "..", "walk-these-ways_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
+    from go1_gym_learn.ppo_cse.ppo import PPO, PPO_Args
+    PPO_Args.autocast_bf16, PPO_Args.use_fused_kernels, PPO_Args.use_hip_graphs = True, True, True
+    N, T = 256, 8
+    torch.manual_seed(100 + rank)                     # different initial weights: rank 0's are broadcast
+    alg = PPO(ActorCritic(70, 2, 2100, 12), device="cuda:0")
+    alg.init_storage(N, T, [70], [2], [2100], [12])
+    g = torch.Generator(device="cuda").manual_seed(7 + rank)       # different data per rank (env shard)
+    for it in range(2):
+        for t in range(T):
+            obs = torch.randn(N, 70, device="cuda", generator=g)
+            priv = torch.randn(N, 2, device="cuda", generator=g)
+            hist = torch.randn(N, 2100, device="cuda", generator=g)
+            alg.act(obs, priv, hist)
+            alg.process_env_step(torch.randn(N, device="cuda", generator=g), torch.zeros(N, dtype=torch.uint8, device="cuda"),
+                                 {"env_bins": torch.zeros(N, device="cuda", dtype=torch.int32),
+                                  "time_outs": torch.zeros(N, dtype=torch.bool, device="cuda")})
+        alg.compute_returns(hist, priv)
+        losses = alg.update()
+    torch.cuda.synchronize()
+    out[rank] = dict(w=alg.master.cpu().clone(), lr=alg.learning_rate, dp=alg.dp, fused=alg.fused, graphs=alg._graphs is not None,
+                     n_graphs=len(alg._graphs or []), losses=losses)
+    dist.destroy_process_group()
+
+
+def test_two_rank_fused_update_keeps_replicas_identical():
+    world = 2
+    port = 29500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    assert a["dp"] and a["fused"] and a["graphs"] and a["n_graphs"] == 3
+    assert torch.isfinite(a["w"]).all()
+    assert torch.equal(a["w"], b["w"])
+    assert a["lr"] == b["lr"]
+    assert a["losses"][0] != b["losses"][0]          # the shards really were different

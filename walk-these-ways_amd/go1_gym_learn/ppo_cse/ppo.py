@@ -112,6 +112,7 @@ class PPO:
         self.fused = bool(self.bf16 and PPO_Args.use_fused_kernels and self.policy.act is torch.nn.ELU)
         self._roll_net = self._train_net = None
         self._opt = self._opt_ad = None
+        self._ad_grad_views = [self.master.grad]      # what the adaptation stage's gradient all-reduce has to cover
         if self.fused:
             from go1_gym_learn.ppo_cse import fused
             self._fused_lib = fused.load_library()
@@ -124,6 +125,8 @@ class PPO:
             self._opt_ad = fused.FusedAdam(self._fused_lib, self.master, self.body, self.std, n, PPO_Args.adaptation_module_learning_rate,
                                            ranges=[(pol.offsets[pol.index["W1"]], pol.first[0] * pol.Kp), tail])
             self._lr = self._opt.lr
+            r0, r1 = self._opt_ad.r0, self._opt_ad.r1
+            self._ad_grad_views = [self.master.grad[r0[0]:r0[0] + r0[1]], self.master.grad[r1[0]:r1[0] + r1[1]]]
         if self.dp:                              # identical initial weights on every rank
             dist.broadcast(self.master, src=0)
         self._push_weights()
@@ -399,6 +402,12 @@ class PPO:
         self.adaptation_module_optimizer.step()
         self._push_weights()
 
+    def _allreduce_adapt_grads(self):
+        """the adaptation stage only produces gradients for the adaptation module: with the fused optimiser those are
+        two element ranges of the flat buffer (2.3 MB instead of 13 MB over xGMI per step)."""
+        for v in self._ad_grad_views:
+            dist.all_reduce(v)
+
     def _minibatch_eager(self, idx):
         self._stage_ppo_backward(idx)
         if self.dp:
@@ -408,7 +417,7 @@ class PPO:
         for _ in range(PPO_Args.num_adaptation_module_substeps):
             self._stage_adapt_backward(idx)
             if self.dp:
-                dist.all_reduce(self.master.grad)
+                self._allreduce_adapt_grads()
             self._stage_adapt_step()
 
     def _capture(self):
@@ -444,7 +453,7 @@ class PPO:
         dist.all_reduce(self.master.grad)
         dist.all_reduce(self._kl)
         g[1].replay()
-        dist.all_reduce(self.master.grad)
+        self._allreduce_adapt_grads()
         g[2].replay()
 
     def update(self):
