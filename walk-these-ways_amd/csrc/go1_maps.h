@@ -182,18 +182,45 @@ DEV float cf_norm(const Go1SimBuffers& B, int b, int e, int N) {
 }
 DEV float normal_cdf(float x, float sigma) { return 0.5f * (1.f + erff(x / (sigma * 1.41421356237309504880f))); }
 
+// Everything a reward term reads from HBM, fetched as ONE batch of independent loads before the term loop: with a
+// single wave per SIMD every dependent load inside the loop would expose a full memory round trip.
+struct RewardIn {
+  float cmd[14];
+  float tq[3], q[3], qd[3], lqd[3], act[3], lact[3], llact[3], jpt[3], ljpt[3], lljpt[3];
+  float cfn[4], cfn_base;          // contact-force norms of the own hip/thigh/calf/foot bodies, and of the trunk
+  float pfvz;
+  bool last_contact;
+};
+DEV void load_reward_inputs(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int leg, RewardIn& in) {
+#pragma unroll
+  for (int k = 0; k < 14; k++) in.cmd[k] = k < cfg.num_commands ? AT(B.commands, k, e) : 0.f;
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+    const int j = 3 * leg + jj;
+    in.tq[jj] = AT(B.torques, j, e); in.q[jj] = AT(B.dof_pos, j, e); in.qd[jj] = AT(B.dof_vel, j, e);
+    in.lqd[jj] = AT(B.last_dof_vel, j, e); in.act[jj] = AT(B.actions, j, e); in.lact[jj] = AT(B.last_actions, j, e);
+    in.llact[jj] = AT(B.last_last_actions, j, e); in.jpt[jj] = AT(B.joint_pos_target, j, e);
+    in.ljpt[jj] = AT(B.last_joint_pos_target, j, e); in.lljpt[jj] = AT(B.last_last_joint_pos_target, j, e);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) in.cfn[i] = cf_norm(B, 1 + 4 * leg + i, e, N);
+  in.cfn_base = cf_norm(B, 0, e, N);
+  in.pfvz = AT(B.prev_foot_velocities, 3 * leg + 2, e);
+  in.last_contact = AT(B.last_contacts, leg, e) != 0;
+}
+
 DEV float reward_partial(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int id, const Derived& d,
-                         const FootCtx& F, int leg) {
+                         const FootCtx& F, int leg, const RewardIn& in) {
   const bool is0 = leg == 0;
   const int j0 = 3 * leg;
   float r = 0.f;
   switch (id) {
     case GO1_REW_TRACKING_LIN_VEL: {
-      float ex = AT(B.commands, 0, e) - d.blv.x, ey = AT(B.commands, 1, e) - d.blv.y;
+      float ex = in.cmd[0] - d.blv.x, ey = in.cmd[1] - d.blv.y;
       return is0 ? expf(-(ex * ex + ey * ey) / cfg.tracking_sigma) : 0.f;
     }
     case GO1_REW_TRACKING_ANG_VEL: {
-      float ez = AT(B.commands, 2, e) - d.bav.z;
+      float ez = in.cmd[2] - d.bav.z;
       return is0 ? expf(-(ez * ez) / cfg.tracking_sigma_yaw) : 0.f;
     }
     case GO1_REW_LIN_VEL_Z: return is0 ? d.blv.z * d.blv.z : 0.f;
@@ -201,34 +228,35 @@ DEV float reward_partial(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e,
     case GO1_REW_ORIENTATION: return is0 ? d.pg.x * d.pg.x + d.pg.y * d.pg.y : 0.f;
     case GO1_REW_TORQUES:
 #pragma unroll
-      for (int j = j0; j < j0 + 3; j++) { float t = AT(B.torques, j, e); r = fmaf(t, t, r); }
+      for (int jj = 0; jj < 3; jj++) { float t = in.tq[jj]; r = fmaf(t, t, r); }
       return r;
     case GO1_REW_DOF_ACC:
 #pragma unroll
-      for (int j = j0; j < j0 + 3; j++) { float a = (AT(B.last_dof_vel, j, e) - AT(B.dof_vel, j, e)) / cfg.dt; r = fmaf(a, a, r); }
+      for (int jj = 0; jj < 3; jj++) { float a = (in.lqd[jj] - in.qd[jj]) / cfg.dt; r = fmaf(a, a, r); }
       return r;
     case GO1_REW_ACTION_RATE:
 #pragma unroll
-      for (int j = j0; j < j0 + 3; j++) { float a = AT(B.last_actions, j, e) - AT(B.actions, j, e); r = fmaf(a, a, r); }
+      for (int jj = 0; jj < 3; jj++) { float a = in.lact[jj] - in.act[jj]; r = fmaf(a, a, r); }
       return r;
     case GO1_REW_COLLISION:
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int b = 1 + 4 * leg + i;
-        if (cfg.penalised_body_mask & (1u << b)) r += (cf_norm(B, b, e, N) > 0.1f) ? 1.f : 0.f;
+        if (cfg.penalised_body_mask & (1u << b)) r += (in.cfn[i] > 0.1f) ? 1.f : 0.f;
       }
-      if (is0 && (cfg.penalised_body_mask & 1u)) r += (cf_norm(B, 0, e, N) > 0.1f) ? 1.f : 0.f;
+      if (is0 && (cfg.penalised_body_mask & 1u)) r += (in.cfn_base > 0.1f) ? 1.f : 0.f;
       return r;
     case GO1_REW_DOF_POS_LIMITS:
 #pragma unroll
-      for (int j = j0; j < j0 + 3; j++) {
-        float q = AT(B.dof_pos, j, e);
+      for (int jj = 0; jj < 3; jj++) {
+        const int j = j0 + jj;
+        float q = in.q[jj];
         float lo = q - cfg.dof_pos_soft_lower[j], hi = q - cfg.dof_pos_soft_upper[j];
         r += -fminf(lo, 0.f) + fmaxf(hi, 0.f);
       }
       return r;
     case GO1_REW_JUMP: {
-      float t = d.base_pos.z - (AT(B.commands, 3, e) + cfg.base_height_target);
+      float t = d.base_pos.z - (in.cmd[3] + cfg.base_height_target);
       return is0 ? -t * t : 0.f;
     }
     case GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE:
@@ -237,29 +265,29 @@ DEV float reward_partial(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e,
       return -(F.desired_contact * (1.f - expf(-dot(F.vel, F.vel) / cfg.gait_vel_sigma))) * 0.25f;
     case GO1_REW_DOF_POS:
 #pragma unroll
-      for (int j = j0; j < j0 + 3; j++) { float a = AT(B.dof_pos, j, e) - cfg.default_dof_pos[j]; r = fmaf(a, a, r); }
+      for (int jj = 0; jj < 3; jj++) { float a = in.q[jj] - cfg.default_dof_pos[j0 + jj]; r = fmaf(a, a, r); }
       return r;
     case GO1_REW_DOF_VEL:
 #pragma unroll
-      for (int j = j0; j < j0 + 3; j++) { float a = AT(B.dof_vel, j, e); r = fmaf(a, a, r); }
+      for (int jj = 0; jj < 3; jj++) { float a = in.qd[jj]; r = fmaf(a, a, r); }
       return r;
     case GO1_REW_ACTION_SMOOTHNESS_1:
 #pragma unroll
-      for (int j = j0; j < j0 + 3; j++) {
-        float a = AT(B.joint_pos_target, j, e) - AT(B.last_joint_pos_target, j, e);
-        r += a * a * (AT(B.last_actions, j, e) != 0.f ? 1.f : 0.f);
+      for (int jj = 0; jj < 3; jj++) {
+        float a = in.jpt[jj] - in.ljpt[jj];
+        r += a * a * (in.lact[jj] != 0.f ? 1.f : 0.f);
       }
       return r;
     case GO1_REW_ACTION_SMOOTHNESS_2:
 #pragma unroll
-      for (int j = j0; j < j0 + 3; j++) {
-        float a = AT(B.joint_pos_target, j, e) - 2.f * AT(B.last_joint_pos_target, j, e) + AT(B.last_last_joint_pos_target, j, e);
-        r += a * a * (AT(B.last_actions, j, e) != 0.f ? 1.f : 0.f) * (AT(B.last_last_actions, j, e) != 0.f ? 1.f : 0.f);
+      for (int jj = 0; jj < 3; jj++) {
+        float a = in.jpt[jj] - 2.f * in.ljpt[jj] + in.lljpt[jj];
+        r += a * a * (in.lact[jj] != 0.f ? 1.f : 0.f) * (in.llact[jj] != 0.f ? 1.f : 0.f);
       }
       return r;
     case GO1_REW_FEET_SLIP: {
       bool contact = F.force.z > 1.0f;
-      bool filt = contact || AT(B.last_contacts, leg, e);
+      bool filt = contact || in.last_contact;
       AT(B.last_contacts, leg, e) = (uint8_t)contact;
       return filt ? (F.vel.x * F.vel.x + F.vel.y * F.vel.y) : 0.f;
     }
@@ -268,16 +296,16 @@ DEV float reward_partial(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e,
     case GO1_REW_FEET_CLEARANCE_CMD_LINEAR: {
       float cl = fminf(fmaxf(F.foot_index * 2.0f - 1.0f, 0.f), 1.f);
       float ph = 1.f - fabsf(1.0f - cl * 2.0f);
-      float target = AT(B.commands, 9, e) * ph + 0.02f;
+      float target = in.cmd[9] * ph + 0.02f;
       float df = target - F.pos.z;
       return df * df * (1.f - F.desired_contact);
     }
     case GO1_REW_FEET_IMPACT_VEL: {
-      float pv = fminf(fmaxf(AT(B.prev_foot_velocities, 3 * leg + 2, e), -100.f), 0.f);
+      float pv = fminf(fmaxf(in.pfvz, -100.f), 0.f);
       return (F.fnorm > 1.0f) ? pv * pv : 0.f;
     }
     case GO1_REW_ORIENTATION_CONTROL: {
-      float pitch = AT(B.commands, 10, e), roll = AT(B.commands, 11, e);
+      float pitch = in.cmd[10], roll = in.cmd[11];
       float sr, cr, sp, cp;
       sincosf(-0.5f * roll, &sr, &cr);
       sincosf(-0.5f * pitch, &sp, &cp);
@@ -289,9 +317,9 @@ DEV float reward_partial(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e,
     case GO1_REW_RAIBERT_HEURISTIC: {
       float l = rsqrtf(d.qz * d.qz + d.qw * d.qw);
       float yz = -d.qz * l, yw = d.qw * l;
-      float width = cfg.num_commands >= 13 ? AT(B.commands, 12, e) : 0.3f;
-      float length = cfg.num_commands >= 14 ? AT(B.commands, 13, e) : 0.45f;
-      float freq = AT(B.commands, 4, e), xv = AT(B.commands, 0, e), yawv = AT(B.commands, 2, e);
+      float width = cfg.num_commands >= 13 ? in.cmd[12] : 0.3f;
+      float length = cfg.num_commands >= 14 ? in.cmd[13] : 0.45f;
+      float freq = in.cmd[4], xv = in.cmd[0], yawv = in.cmd[2];
       float yv = yawv * length / 2;
       V3 fb = quat_rotate(0.f, 0.f, yz, yw, F.pos - d.base_pos);
       float ys = (leg % 2 == 0 ? 1.f : -1.f) * width / 2, xs = (leg < 2 ? 1.f : -1.f) * length / 2;
@@ -420,13 +448,15 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
     mean_height = quad_sum(sum) / np;
   }
   // ---- check_termination ---------------------------------------------------------------------------
+  RewardIn rin;
+  load_reward_inputs(cfg, B, e, N, leg, rin);
   float term = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int b = 1 + 4 * leg + i;
-    if ((cfg.termination_body_mask & (1u << b)) && cf_norm(B, b, e, N) > 1.0f) term = 1.f;
+    if ((cfg.termination_body_mask & (1u << b)) && rin.cfn[i] > 1.0f) term = 1.f;
   }
-  if (is0 && (cfg.termination_body_mask & 1u) && cf_norm(B, 0, e, N) > 1.0f) term = 1.f;
+  if (is0 && (cfg.termination_body_mask & 1u) && rin.cfn_base > 1.0f) term = 1.f;
   bool reset = quad_sum(term) > 0.f;
   const bool time_out = ep_len > cfg.max_episode_length;
   reset = reset || time_out;
@@ -440,27 +470,28 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
   for (int kx = 0; kx < cfg.num_rewards; kx++) {
     const int id = cfg.reward_ids[kx];
     const float sc = cfg.reward_scales[kx];
-    const float r = quad_sum(reward_partial(cfg, B, e, N, id, d, F, leg)) * sc;
+    const float r = quad_sum(reward_partial(cfg, B, e, N, id, d, F, leg, rin)) * sc;
     rew += r;
     if (reward_raw_sign(id) * sc >= 0) pos += r; else neg += r;
-    if ((kx & 3) == leg) {      // the four lanes share the read-modify-write traffic of the running sums
-      AT(B.episode_sums, kx, e) += r;
+    if ((kx & 3) == leg) {      // running sums: fire-and-forget fp32 atomics (one writer per address, so the result is
+                                // the plain += of the reference; no load to wait for)
+      unsafeAtomicAdd(&AT(B.episode_sums, kx, e), r);
       const bool shaped = id == GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE || id == GO1_REW_TRACKING_CONTACTS_SHAPED_VEL;
-      AT(B.command_sums, kx, e) += shaped ? sc + r : r;
+      unsafeAtomicAdd(&AT(B.command_sums, kx, e), shaped ? sc + r : r);
     }
   }
   if (cfg.only_positive_rewards) rew = fmaxf(rew, 0.f);
   else if (cfg.only_positive_rewards_ji22_style) rew = pos * expf(neg / cfg.sigma_rew_neg);
   if (is0) {
     B.rew_buf[e] = rew;
-    AT(B.episode_sums, cfg.num_rewards, e) += rew;
+    unsafeAtomicAdd(&AT(B.episode_sums, cfg.num_rewards, e), rew);
     const int k0 = cfg.num_rewards;
-    const float c0 = AT(B.commands, 0, e), c2 = AT(B.commands, 2, e);
-    AT(B.command_sums, k0 + 0, e) += d.blv.x;
-    AT(B.command_sums, k0 + 1, e) += d.bav.z;
-    AT(B.command_sums, k0 + 2, e) += (d.blv.x - c0) * (d.blv.x - c0);
-    AT(B.command_sums, k0 + 3, e) += (d.bav.z - c2) * (d.bav.z - c2);
-    AT(B.command_sums, k0 + 4, e) += 1.f;
+    const float c0 = rin.cmd[0], c2 = rin.cmd[2];
+    unsafeAtomicAdd(&AT(B.command_sums, k0 + 0, e), d.blv.x);
+    unsafeAtomicAdd(&AT(B.command_sums, k0 + 1, e), d.bav.z);
+    unsafeAtomicAdd(&AT(B.command_sums, k0 + 2, e), (d.blv.x - c0) * (d.blv.x - c0));
+    unsafeAtomicAdd(&AT(B.command_sums, k0 + 3, e), (d.bav.z - c2) * (d.bav.z - c2));
+    unsafeAtomicAdd(&AT(B.command_sums, k0 + 4, e), 1.f);
   }
   PROF(11);
   QUAD_SYNC();                // running sums complete before a reset logs / clears them

@@ -359,23 +359,28 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
   K = K > MAXC ? MAXC : K;
   const float e_c = 0.5f * (s.rest + cfg.terrain_restitution);
 
+  // contact frames of the own candidates and of the trunk candidate: once per substep
+  V3 fn[4], ft1[4], ft2[4], bn, bt1, bt2;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    fn[i] = v3(cand[i].nx, cand[i].ny, cand[i].nz);
+    contact_frame(fn[i], ft1[i], ft2[i]);
+  }
+  bn = v3(cbase.nx, cbase.ny, cbase.nz);
+  contact_frame(bn, bt1, bt2);
   // impulses: listed bodies start from the warm value or zero, all others are dropped
   float lam0[4][3], lamb[3];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int b = 1 + 4 * leg + i;
     V3 wl = v3(LDS(L_LAM + 3 * b), LDS(L_LAM + 3 * b + 1), LDS(L_LAM + 3 * b + 2));
-    V3 n = v3(cand[i].nx, cand[i].ny, cand[i].nz), t1, t2;
-    contact_frame(n, t1, t2);
     const bool w = slot[i] >= 0 && use_warm;
-    lam0[i][0] = w ? dot(wl, n) : 0.f; lam0[i][1] = w ? dot(wl, t1) : 0.f; lam0[i][2] = w ? dot(wl, t2) : 0.f;
+    lam0[i][0] = w ? dot(wl, fn[i]) : 0.f; lam0[i][1] = w ? dot(wl, ft1[i]) : 0.f; lam0[i][2] = w ? dot(wl, ft2[i]) : 0.f;
   }
   {
     V3 wl = v3(LDS(L_LAM), LDS(L_LAM + 1), LDS(L_LAM + 2));
-    V3 n = v3(cbase.nx, cbase.ny, cbase.nz), t1, t2;
-    contact_frame(n, t1, t2);
     const bool w = sbase >= 0 && use_warm;
-    lamb[0] = w ? dot(wl, n) : 0.f; lamb[1] = w ? dot(wl, t1) : 0.f; lamb[2] = w ? dot(wl, t2) : 0.f;
+    lamb[0] = w ? dot(wl, bn) : 0.f; lamb[1] = w ? dot(wl, bt1) : 0.f; lamb[2] = w ? dot(wl, bt2) : 0.f;
   }
 
   // publish own contacts: point, target normal velocity, b = J v_free, start impulse
@@ -395,10 +400,9 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
         if (j <= depth) vb = vb + qd_free[j] * S[j];
       V3 xk = v3(c.x, c.y, c.z);
       V3 vp = vb.l + cross(vb.a, xk);
-      V3 n = v3(c.nx, c.ny, c.nz), t1, t2;
-      contact_frame(n, t1, t2);
+      const V3 n = fn[i];
       LDS(L_CN + 3 * k) = n.x; LDS(L_CN + 3 * k + 1) = n.y; LDS(L_CN + 3 * k + 2) = n.z;
-      LDS(L_BV + 3 * k) = dot(n, vp); LDS(L_BV + 3 * k + 1) = dot(t1, vp); LDS(L_BV + 3 * k + 2) = dot(t2, vp);
+      LDS(L_BV + 3 * k) = dot(n, vp); LDS(L_BV + 3 * k + 1) = dot(ft1[i], vp); LDS(L_BV + 3 * k + 2) = dot(ft2[i], vp);
       LDS(L_LS + 3 * k) = lam0[i][0]; LDS(L_LS + 3 * k + 1) = lam0[i][1]; LDS(L_LS + 3 * k + 2) = lam0[i][2];
     }
   }
@@ -410,10 +414,8 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
     LDS(L_VSTAR + k) = vs;
     V3 xk = v3(cbase.x, cbase.y, cbase.z);
     V3 vp = v_free + cross(w_free, xk);
-    V3 n = v3(cbase.nx, cbase.ny, cbase.nz), t1, t2;
-    contact_frame(n, t1, t2);
-    LDS(L_CN + 3 * k) = n.x; LDS(L_CN + 3 * k + 1) = n.y; LDS(L_CN + 3 * k + 2) = n.z;
-    LDS(L_BV + 3 * k) = dot(n, vp); LDS(L_BV + 3 * k + 1) = dot(t1, vp); LDS(L_BV + 3 * k + 2) = dot(t2, vp);
+    LDS(L_CN + 3 * k) = bn.x; LDS(L_CN + 3 * k + 1) = bn.y; LDS(L_CN + 3 * k + 2) = bn.z;
+    LDS(L_BV + 3 * k) = dot(bn, vp); LDS(L_BV + 3 * k + 1) = dot(bt1, vp); LDS(L_BV + 3 * k + 2) = dot(bt2, vp);
     LDS(L_LS + 3 * k) = lamb[0]; LDS(L_LS + 3 * k + 1) = lamb[1]; LDS(L_LS + 3 * k + 2) = lamb[2];
   }
   // clear the per-body impulses (re-filled for the listed bodies after the solve)
@@ -463,30 +465,37 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
       }
       SV p0 = quad_sum(contrib);
       SV a0c = -sym6_mul(I0inv, p0);
+      // response of the own leg: ONE recursion hip -> thigh -> calf, the acceleration of each body captured on the way
+      SV ab[3];
+      {
+        SV a = a0c;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const float uj = (mine && j <= mydepth) ? pu[j] : 0.f;
+          const float qdd = Dinv[j] * (uj - dot(U[j], a));
+          a = a + qdd * S[j];
+          ab[j] = a;
+        }
+      }
       // rows of W for my own contacts (and lane 0: the trunk contact)
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         if (slot[i] >= 0) {
           const int k2 = slot[i];
-          const int depth = i > 2 ? 2 : i;
-          SV ab = leg_response(S, U, Dinv, a0c, depth, mine, mydepth, pu);
+          const SV& abi = ab[i > 2 ? 2 : i];
           V3 x2 = v3(cand[i].x, cand[i].y, cand[i].z);
-          V3 vp = ab.l + cross(ab.a, x2);
-          V3 n2 = v3(cand[i].nx, cand[i].ny, cand[i].nz), t12, t22;
-          contact_frame(n2, t12, t22);
-          LDS(L_W + (3 * k2 + 0) * NR + 3 * k + r) = dot(n2, vp);
-          LDS(L_W + (3 * k2 + 1) * NR + 3 * k + r) = dot(t12, vp);
-          LDS(L_W + (3 * k2 + 2) * NR + 3 * k + r) = dot(t22, vp);
+          V3 vp = abi.l + cross(abi.a, x2);
+          LDS(L_W + (3 * k2 + 0) * NR + 3 * k + r) = dot(fn[i], vp);
+          LDS(L_W + (3 * k2 + 1) * NR + 3 * k + r) = dot(ft1[i], vp);
+          LDS(L_W + (3 * k2 + 2) * NR + 3 * k + r) = dot(ft2[i], vp);
         }
       }
       if (sbase >= 0 && leg == 0) {
         V3 x2 = v3(cbase.x, cbase.y, cbase.z);
         V3 vp = a0c.l + cross(a0c.a, x2);
-        V3 n2 = v3(cbase.nx, cbase.ny, cbase.nz), t12, t22;
-        contact_frame(n2, t12, t22);
-        LDS(L_W + (3 * sbase + 0) * NR + 3 * k + r) = dot(n2, vp);
-        LDS(L_W + (3 * sbase + 1) * NR + 3 * k + r) = dot(t12, vp);
-        LDS(L_W + (3 * sbase + 2) * NR + 3 * k + r) = dot(t22, vp);
+        LDS(L_W + (3 * sbase + 0) * NR + 3 * k + r) = dot(bn, vp);
+        LDS(L_W + (3 * sbase + 1) * NR + 3 * k + r) = dot(bt1, vp);
+        LDS(L_W + (3 * sbase + 2) * NR + 3 * k + r) = dot(bt2, vp);
       }
     }
   }
@@ -586,9 +595,7 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
     if (slot[i] >= 0) {
       const int k = slot[i], b = 1 + 4 * leg + i;
       const float ln = LDS(L_LS + 3 * k), l1 = LDS(L_LS + 3 * k + 1), l2 = LDS(L_LS + 3 * k + 2);
-      V3 n = v3(cand[i].nx, cand[i].ny, cand[i].nz), t1, t2;
-      contact_frame(n, t1, t2);
-      V3 f = ln * n + l1 * t1 + l2 * t2;           // world impulse
+      V3 f = ln * fn[i] + l1 * ft1[i] + l2 * ft2[i];           // world impulse
       LDS(L_LAM + 3 * b) = f.x; LDS(L_LAM + 3 * b + 1) = f.y; LDS(L_LAM + 3 * b + 2) = f.z;
       V3 x = v3(cand[i].x, cand[i].y, cand[i].z);
       SV ff = sv(cross(x, f), f);
@@ -609,9 +616,7 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
   }
   if (sbase >= 0 && leg == 0) {
     const float ln = LDS(L_LS + 3 * sbase), l1 = LDS(L_LS + 3 * sbase + 1), l2 = LDS(L_LS + 3 * sbase + 2);
-    V3 n = v3(cbase.nx, cbase.ny, cbase.nz), t1, t2;
-    contact_frame(n, t1, t2);
-    V3 f = ln * n + l1 * t1 + l2 * t2;
+    V3 f = ln * bn + l1 * bt1 + l2 * bt2;
     LDS(L_LAM) = f.x; LDS(L_LAM + 1) = f.y; LDS(L_LAM + 2) = f.z;
     V3 x = v3(cbase.x, cbase.y, cbase.z);
     contrib = contrib - sv(cross(x, f), f);
