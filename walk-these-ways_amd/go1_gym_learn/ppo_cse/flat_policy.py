@@ -40,15 +40,21 @@ class FlatPolicy:
         self.out_dims = {n: self.nets[n][-1].out_features for n in self.nets}
         # ---- layout -------------------------------------------------------------------------------------
         self.blocks = []         # (name, shape)
-        self.blocks.append(("W1", (sum(self.first), self.Kp)))
-        assert self.npv <= HEAD_COLS
-        self.blocks.append(("Wz", (self.first[1], HEAD_COLS)))      # columns >= npv stay exactly zero
-        for n, lins in self.nets.items():
+        # order: the adaptation module's tail first, then W1 (whose first rows are the adaptation module's first
+        # layer): everything the adaptation optimiser / its gradient all-reduce touches is ONE contiguous range
+        def tail(n):
+            lins = self.nets[n]
             for li, lin in enumerate(lins[1:], start=1):
                 last = li == len(lins) - 1
                 rows = max(lin.out_features, HEAD_COLS) if last else lin.out_features
                 self.blocks.append((f"{n}.{li}.W", (rows, lin.in_features)))
                 self.blocks.append((f"{n}.{li}.b", (rows,)))
+        tail("adaptation")
+        self.blocks.append(("W1", (sum(self.first), self.Kp)))
+        assert self.npv <= HEAD_COLS
+        self.blocks.append(("Wz", (self.first[1], HEAD_COLS)))      # columns >= npv stay exactly zero
+        tail("actor")
+        tail("critic")
         self.sizes, self.offsets, off = [], [], 0
         for _, shape in self.blocks:
             n = 1
@@ -60,6 +66,8 @@ class FlatPolicy:
             off += padded
         self.numel = off
         self.index = {name: i for i, (name, _) in enumerate(self.blocks)}
+        # [0, adaptation_numel): adaptation tail blocks + the adaptation rows of W1
+        self.adaptation_numel = self.offsets[self.index["W1"]] + self.first[0] * self.Kp
 
     # ---- module <-> flat ---------------------------------------------------------------------------------
     def _block(self, flat, name):

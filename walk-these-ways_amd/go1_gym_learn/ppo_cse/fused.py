@@ -300,11 +300,12 @@ class FusedAdam:
         self.betas, self.eps = betas, eps
         r = list(ranges or [(0, master.numel())]) + [(0, 0)]
         self.r0, self.r1 = r[0], r[1]
+        self.n_norm = max(a + b for a, b in r)          # elements the global norm runs over (padding slots excluded)
 
     def step_(self, gscale=1.0, max_norm=None, kl=None, kl_scale=1.0, desired_kl=0.01, lr_min=1e-5, lr_max=1e-2):
         g = self.master.grad
         clip = max_norm is not None
-        _chk(self.lib.go1ppo_opt_prestep(g.data_ptr(), g.numel(), gscale, self.partial.data_ptr() if clip else None,
+        _chk(self.lib.go1ppo_opt_prestep(g.data_ptr(), self.n_norm, gscale, self.partial.data_ptr() if clip else None,
                                          self.step.data_ptr(), self.lr.data_ptr(), _ptr(kl), kl_scale, desired_kl, lr_min, lr_max,
                                          _stream()), "go1ppo_opt_prestep")
         _chk(self.lib.go1ppo_opt_adam(self.master.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.r0[0], self.r0[1],

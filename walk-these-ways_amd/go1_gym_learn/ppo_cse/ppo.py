@@ -89,13 +89,16 @@ class PPO:
         self.policy.pack(ac, self.master[:n])
         self.master[n:n + self.n_std].copy_(ac.std.detach())
         self.master.grad = torch.zeros_like(self.master)
+        # the mean KL of a mini-batch rides in the first padding slot behind the std gradient: the data-parallel
+        # all-reduce of the flat gradient carries it along (one collective instead of two per optimiser step)
+        self._kl = self.master.grad[n + self.n_std:n + self.n_std + 1].view(())
+        self._g_live = self.master.grad[:n + self.n_std]          # what the norm / clip / optimiser see
         pol = self.policy
         self._priv_cols_grad = pol._block(self.master.grad[:n], "W1")[:pol.first[0] + pol.first[1], pol.K + 1:pol.K + 1 + pol.npv]
         # compute copies (leaves of the autograd graph): policy body in bf16 or fp32, std always fp32
         self.body = torch.zeros(n, device=device, dtype=torch.bfloat16 if self.bf16 else torch.float32).requires_grad_()
         self.std = torch.zeros(self.n_std, device=device).requires_grad_()
         kw = dict(fused=True, capturable=True) if self.on_gpu else {}
-        self._kl = torch.zeros((), device=device)
         self._acc = torch.zeros(4, device=device)        # value, surrogate, adaptation, adaptation-test losses
         self._idx, self._graphs, self._updates_done = None, None, 0
         lr = torch.tensor(PPO_Args.learning_rate, device=device) if self.on_gpu else PPO_Args.learning_rate
@@ -120,13 +123,10 @@ class PPO:
             # adaptation module's elements (all other gradients of that stage are exactly zero, see above)
             pol, ns = self.policy, self.n_std
             self._opt = fused.FusedAdam(self._fused_lib, self.master, self.body, self.std, n, PPO_Args.learning_rate, ranges=[(0, n + ns)])
-            first, last = pol.index["adaptation.1.W"], pol.index[f"adaptation.{len(pol.nets['adaptation']) - 1}.b"]
-            tail = (pol.offsets[first], pol.offsets[last] + pol.sizes[last] - pol.offsets[first])
             self._opt_ad = fused.FusedAdam(self._fused_lib, self.master, self.body, self.std, n, PPO_Args.adaptation_module_learning_rate,
-                                           ranges=[(pol.offsets[pol.index["W1"]], pol.first[0] * pol.Kp), tail])
+                                           ranges=[(0, pol.adaptation_numel)])
             self._lr = self._opt.lr
-            r0, r1 = self._opt_ad.r0, self._opt_ad.r1
-            self._ad_grad_views = [self.master.grad[r0[0]:r0[0] + r0[1]], self.master.grad[r1[0]:r1[0] + r1[1]]]
+            self._ad_grad_views = [self.master.grad[:pol.adaptation_numel]]
         if self.dp:                              # identical initial weights on every rank
             dist.broadcast(self.master, src=0)
         self._push_weights()
@@ -310,8 +310,7 @@ class PPO:
         net, n = self._train_net, self.n_body
         with torch.no_grad():
             torch.index_select(self.storage.observation_histories.flatten(0, 1), 0, idx, out=net.X)
-            self.master.grad.zero_()
-            self._kl.zero_()
+            self.master.grad.zero_()          # also clears the KL slot
             net.forward(net.X)
             net.ppo_loss(self.storage, idx, self.std, self.master.grad[n:n + self.n_std], PPO_Args, self._kl, self._acc)
             net.backward(net.X)
@@ -365,11 +364,12 @@ class PPO:
             self._opt.step_(gscale=1.0 / w, max_norm=A.max_grad_norm, kl=self._kl if adaptive else None, kl_scale=1.0 / w,
                             desired_kl=A.desired_kl if adaptive else 0.0)
             return
-        g = self.master.grad
+        g = self._g_live
         if self.dp:
             g.div_(_world())
         if A.desired_kl is not None and A.schedule == 'adaptive':
             self._adapt_lr(self._kl / _world() if self.dp else self._kl)
+        self._kl.zero_()          # the slot is padding of the parameter vector: Adam must see a zero gradient there
         g.mul_(torch.clamp(A.max_grad_norm / (torch.linalg.vector_norm(g) + 1e-6), max=1.0))
         self.optimizer.step()
         self._push_weights()
@@ -403,16 +403,15 @@ class PPO:
         self._push_weights()
 
     def _allreduce_adapt_grads(self):
-        """the adaptation stage only produces gradients for the adaptation module: with the fused optimiser those are
-        two element ranges of the flat buffer (2.3 MB instead of 13 MB over xGMI per step)."""
+        """the adaptation stage only produces gradients for the adaptation module: with the fused optimiser that is
+        the leading range of the flat buffer (FlatPolicy layout; 2.3 MB instead of 13 MB over xGMI per step)."""
         for v in self._ad_grad_views:
             dist.all_reduce(v)
 
     def _minibatch_eager(self, idx):
         self._stage_ppo_backward(idx)
         if self.dp:
-            dist.all_reduce(self.master.grad)
-            dist.all_reduce(self._kl)
+            dist.all_reduce(self.master.grad)          # gradient + KL slot
         self._stage_ppo_step()
         for _ in range(PPO_Args.num_adaptation_module_substeps):
             self._stage_adapt_backward(idx)
@@ -450,8 +449,7 @@ class PPO:
             g[0].replay()
             return
         g[0].replay()
-        dist.all_reduce(self.master.grad)
-        dist.all_reduce(self._kl)
+        dist.all_reduce(self.master.grad)          # gradient + KL slot
         g[1].replay()
         self._allreduce_adapt_grads()
         g[2].replay()
