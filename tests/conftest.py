@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# GEMM auto-tuning (PPO_Args.use_tuned_gemms) would tune every small test shape: keep the suite fast and deterministic
+os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "0")
+
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 PKG = os.path.join(REPO, "walk-these-ways_amd")
 for p in (os.path.join(PKG, "shims"), PKG, os.path.join(REPO, "oracle"), REPO, os.path.dirname(__file__)):

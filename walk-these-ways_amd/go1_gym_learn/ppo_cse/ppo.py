@@ -50,9 +50,27 @@ class PPO_Args(PrefixProto):
     data_parallel = True            # all-reduce gradients when torch.distributed is initialised with world_size > 1
     use_hip_graphs = True           # replay the mini-batch step as a HIP graph from the second update() on
     use_fused_kernels = True        # bf16 policy on a GPU: hand-scheduled forward/backward with csrc/go1ppo.hip (fused.py)
+    use_tuned_gemms = True          # PyTorch TunableOp with the gfx950 table shipped in walk-these-ways_amd/tuning/
 
 
 _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+def _enable_tuned_gemms():
+    """hipBLASLt's default heuristics pick poor kernels for this policy's tall-skinny bf16 shapes (M = 24576 rows,
+    N/K = 64..2104); TunableOp selections for gfx950 ship in walk-these-ways_amd/tuning/ (shapes that are not in the
+    table are tuned once on first use).  Environment variables (PYTORCH_TUNABLEOP_*) take precedence."""
+    import os
+    if "PYTORCH_TUNABLEOP_ENABLED" in os.environ:
+        return
+    try:
+        from torch.cuda import tunable
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tuning", "tunableop_gfx950.csv")
+        tunable.enable(True)
+        tunable.set_filename(os.path.normpath(path), insert_device_ordinal=False)
+        tunable.set_max_tuning_duration(30)
+    except Exception as err:          # an optimisation only
+        print(f"[ppo] TunableOp not enabled ({type(err).__name__}: {err})")
 
 
 def _world():
@@ -115,6 +133,8 @@ class PPO:
         self.fused = bool(self.bf16 and PPO_Args.use_fused_kernels and self.policy.act is torch.nn.ELU)
         self._roll_net = self._train_net = None
         self._opt = self._opt_ad = None
+        if self.on_gpu and PPO_Args.use_tuned_gemms:
+            _enable_tuned_gemms()
         self._ad_grad_views = [self.master.grad]      # what the adaptation stage's gradient all-reduce has to cover
         if self.fused:
             from go1_gym_learn.ppo_cse import fused
