@@ -71,11 +71,108 @@ DEV void actuator_net3(const float in[3][6], float out[3]) {
   out[0] = o0; out[1] = o1; out[2] = o2;
 }
 
+// ---- the same network on the matrix cores ------------------------------------------------------------------
+// A wavefront evaluates 16 envs x 12 joints = 192 rows per substep.  The 32x32 hidden layer (2/3 of the FLOPs) runs
+// as H1^T = W1 . H0^T on v_mfma_f32_16x16x32_bf16 with both operands split hi + lo in bf16 (3 MFMAs per 16x16 tile:
+// hi.hi + hi.lo + lo.hi, fp32 accumulate; the dropped lo.lo term is 2^-18 relative — the result is fp32-accurate to
+// ~1e-5, inside the parity tolerance of the torque test).  Data distribution, chosen so that nothing needs a
+// transpose: the 6 inputs of every row go through LDS (8 floats per row); lane (c = lane & 15, g = lane >> 4)
+// evaluates the first layer for row 16 t + c and hidden units 8 g .. 8 g + 7 — exactly its B fragment of tile t;
+// the W1 fragments (A operand) are converted once per launch and parked in LDS; the MFMA result leaves every lane
+// with hidden units {16 i + 4 g + q} of ONE row, so the output layer is 8 FMAs + a 4-lane butterfly.
+// Only used by full wavefronts (all 64 lanes alive): a partial last workgroup takes actuator_net3.
+typedef __attribute__((ext_vector_type(8))) __bf16 act_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float act_f32x4;
+enum { A_IN = 0, A_OUT = 192 * 8, A_W0 = A_OUT + 192, A_B1 = A_W0 + 32 * 8, A_W2 = A_B1 + 32, A_WF = A_W2 + 32, A_END = A_WF + 4 * 64 * 4 };
+
+DEV void actuator_lds_init(float* a, int lane) {          // once per launch, all 64 lanes
+  for (int i = lane; i < 32 * 8; i += WAVE) {
+    const int k = i >> 3, c = i & 7;
+    a[A_W0 + i] = c < 6 ? GO1_ACT_W0[k][c] : (c == 6 ? GO1_ACT_B0[k] : 0.f);
+  }
+  if (lane < 32) { a[A_B1 + lane] = GO1_ACT_B1[lane]; a[A_W2 + lane] = GO1_ACT_W2[lane]; }
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    act_bf16x8 hi, lo;
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+      const float w = GO1_ACT_W1[16 * i + c][8 * g + kk];
+      const __bf16 h = (__bf16)w;
+      hi[kk] = h;
+      lo[kk] = (__bf16)(w - (float)h);
+    }
+    *reinterpret_cast<act_bf16x8*>(a + A_WF + ((2 * i) * 64 + lane) * 4) = hi;
+    *reinterpret_cast<act_bf16x8*>(a + A_WF + ((2 * i + 1) * 64 + lane) * 4) = lo;
+  }
+}
+
+DEV void actuator_net_mfma(float* a, int lane, const float in[3][6], float out[3]) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+    f4* p = reinterpret_cast<f4*>(a + A_IN + (3 * lane + jj) * 8);
+    p[0] = (f4){in[jj][0], in[jj][1], in[jj][2], in[jj][3]};
+    p[1] = (f4){in[jj][4], in[jj][5], 1.f, 0.f};
+  }
+  __syncthreads();
+  const int c = lane & 15, g = lane >> 4;
+  float w0[8][7];
+#pragma unroll
+  for (int kk = 0; kk < 8; kk++) {
+    const f4* p = reinterpret_cast<const f4*>(a + A_W0 + (8 * g + kk) * 8);
+    const f4 u = p[0], v = p[1];
+    w0[kk][0] = u[0]; w0[kk][1] = u[1]; w0[kk][2] = u[2]; w0[kk][3] = u[3]; w0[kk][4] = v[0]; w0[kk][5] = v[1]; w0[kk][6] = v[2];
+  }
+  act_bf16x8 whi[2], wlo[2];
+  float b1v[8], w2v[8];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    whi[i] = *reinterpret_cast<const act_bf16x8*>(a + A_WF + ((2 * i) * 64 + lane) * 4);
+    wlo[i] = *reinterpret_cast<const act_bf16x8*>(a + A_WF + ((2 * i + 1) * 64 + lane) * 4);
+    const f4 bb = *reinterpret_cast<const f4*>(a + A_B1 + 16 * i + 4 * g), ww = *reinterpret_cast<const f4*>(a + A_W2 + 16 * i + 4 * g);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { b1v[4 * i + q] = bb[q]; w2v[4 * i + q] = ww[q]; }
+  }
+#pragma unroll 2
+  for (int t = 0; t < 12; t++) {
+    const f4* pin = reinterpret_cast<const f4*>(a + A_IN + (16 * t + c) * 8);
+    const f4 x0 = pin[0], x1 = pin[1];
+    act_bf16x8 bhi, blo;
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+      float s0 = w0[kk][6];
+      s0 = fmaf(w0[kk][0], x0[0], s0); s0 = fmaf(w0[kk][1], x0[1], s0); s0 = fmaf(w0[kk][2], x0[2], s0);
+      s0 = fmaf(w0[kk][3], x0[3], s0); s0 = fmaf(w0[kk][4], x1[0], s0); s0 = fmaf(w0[kk][5], x1[1], s0);
+      const float h = softsign(s0);
+      const __bf16 hh = (__bf16)h;
+      bhi[kk] = hh;
+      blo[kk] = (__bf16)(h - (float)hh);
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      act_f32x4 acc = (act_f32x4){0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[i], bhi, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[i], blo, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[i], bhi, acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; q++) part = fmaf(w2v[4 * i + q], softsign(acc[q] + b1v[4 * i + q]), part);
+    }
+    part += __shfl_xor(part, 16, 64);       // the 4 lanes (g = 0..3) holding the same row add up
+    part += __shfl_xor(part, 32, 64);
+    if (g == 0) a[A_OUT + 16 * t + c] = part + GO1_ACT_B2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) out[jj] = a[A_OUT + 3 * lane + jj];
+}
+
 struct Leg {             // the calling lane's leg
   float q[3], qd[3], tau[3];
 };
 
-DEV void compute_torques(const Go1SimConfig& cfg, const Go1SimBuffers& B, Leg& L, int leg, int e, int N, int head) {
+DEV void compute_torques(const Go1SimConfig& cfg, const Go1SimBuffers& B, Leg& L, int leg, int e, int N, int head, float* act_lds, bool full_wave) {
   const int nl = cfg.lag_timesteps + 1;
   const int h2 = (head + 1) % nl;
   float in[3][6], tq[3], tgt[3];
@@ -107,7 +204,8 @@ DEV void compute_torques(const Go1SimConfig& cfg, const Go1SimBuffers& B, Leg& L
       AT(B.joint_vel_last_last, j, e) = vl;
       AT(B.joint_vel_last, j, e) = L.qd[jj];
     }
-    actuator_net3(in, tq);
+    if (full_wave) actuator_net_mfma(act_lds, (int)threadIdx.x, in, tq);      // wave-uniform choice
+    else actuator_net3(in, tq);
   } else {
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) {

@@ -43,12 +43,15 @@ struct StepArgs {
 // ================================================================================================
 extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArgs A) {
   __shared__ float lds[L_END * EPW];
+  __shared__ __attribute__((aligned(16))) float act_lds[A_END];
   for (int i = threadIdx.x; i < (L_END - L_W) * EPW; i += WAVE) lds[L_W * EPW + i] = 0.f;   // finite everywhere: see the PGS column split
   const Go1SimConfig& cfg = A.sc->cfg;
   const Go1SimBuffers& B = A.sc->buf;
   const int N = cfg.num_envs;
   const int lane = threadIdx.x, leg = lane & 3;
   const int e = blockIdx.x * EPW + (lane >> 2);
+  const bool full_wave = (int)(blockIdx.x + 1) * EPW <= N;      // the MFMA torque model needs all 64 lanes
+  if (full_wave && cfg.control_type == 1) actuator_lds_init(act_lds, lane);
   if (e >= N) return;
   const float h = cfg.sim_dt;
   PROF_DECL
@@ -71,7 +74,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
 #pragma unroll 1
   for (int sub = 0; sub < cfg.decimation; sub++) {
 #ifndef GO1_ABLATE_TORQUE
-    compute_torques(cfg, B, L, leg, e, N, head);
+    compute_torques(cfg, B, L, leg, e, N, head, act_lds, full_wave);
 #endif
     PROF(1);
     head = (head + 1) % nl;
@@ -94,12 +97,15 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
 // piecewise entry points with the 4-lane mapping (parity tests): torques only / one physics substep / tensor maps only
 extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs A) {
   __shared__ float lds[L_END * EPW];
+  __shared__ __attribute__((aligned(16))) float act_lds[A_END];
   for (int i = threadIdx.x; i < (L_END - L_W) * EPW; i += WAVE) lds[L_W * EPW + i] = 0.f;   // finite everywhere: see the PGS column split
   const Go1SimConfig& cfg = A.sc->cfg;
   const Go1SimBuffers& B = A.sc->buf;
   const int N = cfg.num_envs;
   const int lane = threadIdx.x, leg = lane & 3;
   const int e = blockIdx.x * EPW + (lane >> 2);
+  const bool full_wave = (int)(blockIdx.x + 1) * EPW <= N;
+  if (A.mode == 1 && full_wave && cfg.control_type == 1) actuator_lds_init(act_lds, lane);
   if (e >= N) return;
   if (A.mode == 4) {       // tensor maps only
     PROF_DECL
@@ -112,7 +118,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   if (A.mode == 1) {       // torques only (actions given as SoA)
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) AT(B.actions, 3 * leg + jj, e) = AT(A.actions, 3 * leg + jj, e);
-    compute_torques(cfg, B, L, leg, e, N, A.lag_head);
+    compute_torques(cfg, B, L, leg, e, N, A.lag_head, act_lds, full_wave);
     return;
   }
   // mode 2: one physics substep with the torques in the buffer
