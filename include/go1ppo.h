@@ -77,6 +77,23 @@ int go1ppo_mse(const void* pred, int pred_ld, const float* target, int npv, cons
 int go1ppo_wgrad(const void* dz, int ld_dz, const void* h, int ld_h, int64_t rows, int n, int k, float* dW, int ldw,
                  float* bias_grad, void* stream);
 
+/* One weight-gradient problem of a batched launch (same contract as go1ppo_wgrad).  The caller fills the first ten
+ * fields on the host, go1ppo_wgrad_plan() fills chunk_rows / wg_offset and returns the number of workgroups; the
+ * table is then copied to device memory once and every backward pass is a single go1ppo_wgrad_batched() launch. */
+typedef struct {
+  const void* dz;
+  const void* h;
+  float* dW;
+  float* bias_grad;          /* may be NULL */
+  int64_t rows;
+  int32_t ld_dz, ld_h, n, k, ldw;
+  int32_t chunk_rows, wg_offset;      /* filled by go1ppo_wgrad_plan */
+  int32_t _pad;
+} Go1PpoWgradProblem;
+
+int go1ppo_wgrad_plan(Go1PpoWgradProblem* host_problems, int count);
+int go1ppo_wgrad_batched(const Go1PpoWgradProblem* device_problems, int count, int total_workgroups, void* stream);
+
 /* ---- rollout glue (PPO.act / process_env_step / RolloutStorage of the reference, ppo.py:60-97, rollout_storage.py:54-84) ---- */
 
 /* a = mean + std * noise; log N(a; mean, std) summed over actions; policy outputs written into the storage slot:

@@ -91,6 +91,20 @@ def test_ppo_loss_args_mirror_matches_header():
     assert names == [f[0] for f in fused.LossArgs._fields_]
 
 
+def test_ppo_wgrad_problem_mirror_matches_header():
+    import ctypes as C
+    from go1_gym_learn.ppo_cse import fused
+    src = re.sub(r"/\*.*?\*/", "", open(PPO_HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct \{([^}]*?)\} Go1PpoWgradProblem;", src, flags=re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            names += [n.strip().lstrip("*") for n in re.sub(r"^(const\s+)?\w+\s*\*?", "", decl, count=1).split(",")]
+    assert names == [f[0] for f in fused.WgradProblem._fields_]
+    assert C.sizeof(fused.WgradProblem) == 72
+
+
 def test_fused_update_fails_loudly_without_library(tmp_path):
     from go1_gym_learn.ppo_cse import fused
     with pytest.raises(fused.Go1PpoLibraryMissing):

@@ -330,12 +330,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* dz, int ld_dz,
 // v2: 64-row steps; every thread loads a 4-row x 8-column patch of one operand and stores its transpose with eight
 // 8-byte LDS writes (4 consecutive reduction indices each) instead of 32 two-byte ones.
 #define WG2_LDM 72
-__global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* dz, int ld_dz, const bf16_t* h, int ld_h, int64_t rows,
-                                                     int chunk_rows, float* dW, int ldw, float* bias_grad) {
-  __shared__ __attribute__((aligned(16))) bf16_t T[2][2][64][WG2_LDM];      // [buffer][operand][n or k][m]
-  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-  const int64_t m_begin = (int64_t)blockIdx.z * chunk_rows;
-  const int64_t m_end = m_begin + chunk_rows < rows ? m_begin + chunk_rows : rows;
+__device__ __forceinline__ void wgrad2_body(const bf16_t* dz, int ld_dz, const bf16_t* h, int ld_h, int64_t m_begin, int64_t m_end,
+                                            float* dW, int ldw, float* bias_grad, int n0, int k0, bool do_bias,
+                                            bf16_t (*T)[2][64][WG2_LDM]) {
   const int t = threadIdx.x, op = t >> 7, rq = (t & 127) >> 3, cg = t & 7, wave = t >> 6, lane = t & 63;
   const bf16_t* src = op ? h + k0 + 8 * cg : dz + n0 + 8 * cg;
   const int ld = op ? ld_h : ld_dz;
@@ -367,7 +364,6 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* dz, int ld_dz
     }
   };
   if (m_begin >= m_end) return;
-  const bool do_bias = bias_grad && blockIdx.y == 0;      // the k-tile-0 workgroups also own the column sums of dz
   float bsum = 0.f;
   gload(m_begin);
   sstore(0);
@@ -407,6 +403,32 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* dz, int ld_dz
     bsum += __shfl_xor(bsum, 2, 64);
     if ((t & 3) == 0) atomicAdd(bias_grad + n0 + (t >> 2), bsum);
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* dz, int ld_dz, const bf16_t* h, int ld_h, int64_t rows,
+                                                     int chunk_rows, float* dW, int ldw, float* bias_grad) {
+  __shared__ __attribute__((aligned(16))) bf16_t T[2][2][64][WG2_LDM];      // [buffer][operand][n or k][m]
+  const int64_t m_begin = (int64_t)blockIdx.z * chunk_rows;
+  const int64_t m_end = m_begin + chunk_rows < rows ? m_begin + chunk_rows : rows;
+  wgrad2_body(dz, ld_dz, h, ld_h, m_begin, m_end, dW, ldw, bias_grad, blockIdx.x * 64, blockIdx.y * 64, bias_grad && blockIdx.y == 0, T);
+}
+
+// every weight gradient of a backward pass in ONE launch: the layers' (n/64)(k/64) output tiles x row chunks are
+// independent work items; alone, each layer is too small to fill 256 CUs (2..32 tiles).
+__global__ __launch_bounds__(256) void wgrad_batched_kernel(const Go1PpoWgradProblem* __restrict__ probs, int count) {
+  __shared__ __attribute__((aligned(16))) bf16_t T[2][2][64][WG2_LDM];
+  int p = 0;
+  const int wg = blockIdx.x;
+  while (p + 1 < count && wg >= probs[p + 1].wg_offset) p++;
+  const Go1PpoWgradProblem P = probs[p];
+  const int local = wg - P.wg_offset;
+  const int tiles_k = P.k / 64, tiles = (P.n / 64) * tiles_k;
+  const int tile = local % tiles, split = local / tiles;
+  const int n0 = (tile / tiles_k) * 64, k0 = (tile % tiles_k) * 64;
+  const int64_t m_begin = (int64_t)split * P.chunk_rows;
+  const int64_t m_end = m_begin + P.chunk_rows < P.rows ? m_begin + P.chunk_rows : P.rows;
+  wgrad2_body((const bf16_t*)P.dz, P.ld_dz, (const bf16_t*)P.h, P.ld_h, m_begin, m_end, P.dW, P.ldw, P.bias_grad, n0, k0,
+              P.bias_grad && k0 == 0, T);
 }
 
 // ---------------------------------------------------------------------------------------------- rollout glue
@@ -555,6 +577,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
   }
 }
 
+// row split of one weight-gradient problem: enough workgroups to fill the chip, but a bounded fan-in per output
+// element — the partial sums meet in fp32 atomics, which resolve beyond the per-XCD L2 and serialise per address
+// (measured: 256x512 best at 32 splits, 128x256 at 64, 64x128 at 128)
+static void wgrad_split(int64_t rows, int n, int k, int step, int64_t* S_out, int64_t* chunk_steps_out) {
+  const int tiles = (n / 64) * (k / 64);
+  const int64_t steps = (rows + step - 1) / step;
+  int64_t S = 512 / tiles;
+  if (S < 32) S = 32;
+  if (S > 128) S = 128;
+  if (S > steps) S = steps;
+  const int64_t chunk_steps = (steps + S - 1) / S;
+  *S_out = (steps + chunk_steps - 1) / chunk_steps;
+  *chunk_steps_out = chunk_steps;
+}
+
 // ---------------------------------------------------------------------------------------------- C-ABI
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -603,24 +640,14 @@ extern "C" int go1ppo_wgrad(const void* dz, int ld_dz, const void* h, int ld_h, 
                             float* bias_grad, void* stream) {
   if (!dz || !h || !dW || rows <= 0 || n <= 0 || k <= 0 || (n & 63) || (k & 63) || (ld_dz & 7) || (ld_h & 7) || !aligned16(dz) || !aligned16(h))
     return -1;
-  static int variant = -1, wg_per_cu = 8;
+  static int variant = -1;
   if (variant < 0) {
     const char* e = getenv("GO1PPO_WGRAD_VARIANT");
     variant = e ? atoi(e) : 2;
-    const char* w0 = getenv("GO1PPO_WGRAD_WGS");
-    if (!w0) wg_per_cu = 4;
-    const char* w = getenv("GO1PPO_WGRAD_WGS");
-    if (w) wg_per_cu = atoi(w);
   }
   const int step = variant == 1 ? 32 : 64;
-  int tiles = (n / 64) * (k / 64);
-  int64_t steps = (rows + step - 1) / step;
-  int64_t S = (256 * wg_per_cu) / tiles;
-  if (S < 1) S = 1;
-  if (S > steps) S = steps;
-  if (S > 128) S = 128;                      // same-address atomics serialise in L2: keep the fan-in per output moderate
-  int64_t chunk_steps = (steps + S - 1) / S;
-  S = (steps + chunk_steps - 1) / chunk_steps;
+  int64_t S, chunk_steps;
+  wgrad_split(rows, n, k, step, &S, &chunk_steps);
   dim3 grid(n / 64, k / 64, (unsigned)S);
   if (variant == 1 && !bias_grad)
     wgrad_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dz, ld_dz, (const bf16_t*)h, ld_h, rows,
@@ -685,5 +712,28 @@ extern "C" int go1ppo_opt_adam(float* p, const float* g, float* m, float* v, int
 }
 
 extern "C" int go1ppo_opt_partials(void) { return OPT_BLOCKS; }
+
+extern "C" int go1ppo_wgrad_plan(Go1PpoWgradProblem* probs, int count) {
+  if (!probs || count <= 0) return -1;
+  int total = 0;
+  for (int i = 0; i < count; i++) {
+    Go1PpoWgradProblem& P = probs[i];
+    if (!P.dz || !P.h || !P.dW || P.rows <= 0 || P.n <= 0 || P.k <= 0 || (P.n & 63) || (P.k & 63) || (P.ld_dz & 7) || (P.ld_h & 7) ||
+        !aligned16(P.dz) || !aligned16(P.h))
+      return -1;
+    int64_t S, chunk_steps;
+    wgrad_split(P.rows, P.n, P.k, 64, &S, &chunk_steps);
+    P.chunk_rows = (int32_t)(chunk_steps * 64);
+    P.wg_offset = total;
+    total += (int)S * (P.n / 64) * (P.k / 64);
+  }
+  return total;
+}
+
+extern "C" int go1ppo_wgrad_batched(const Go1PpoWgradProblem* device_probs, int count, int total_workgroups, void* stream) {
+  if (!device_probs || count <= 0 || total_workgroups <= 0) return -1;
+  wgrad_batched_kernel<<<dim3((unsigned)total_workgroups), dim3(256), 0, (hipStream_t)stream>>>(device_probs, count);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
 
 extern "C" const char* go1ppo_version(void) { return "go1ppo 0.1 (gfx950, abi 1)"; }

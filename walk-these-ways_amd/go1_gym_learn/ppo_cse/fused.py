@@ -38,7 +38,15 @@ class LossArgs(ctypes.Structure):
                 ("value_loss", ctypes.c_void_p), ("surrogate_loss", ctypes.c_void_p)]
 
 
-EXPORTED_SYMBOLS = ["go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_act",
+class WgradProblem(ctypes.Structure):
+    _fields_ = [("dz", ctypes.c_void_p), ("h", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("bias_grad", ctypes.c_void_p),
+                ("rows", ctypes.c_int64), ("ld_dz", ctypes.c_int32), ("ld_h", ctypes.c_int32), ("n", ctypes.c_int32),
+                ("k", ctypes.c_int32), ("ldw", ctypes.c_int32), ("chunk_rows", ctypes.c_int32), ("wg_offset", ctypes.c_int32),
+                ("_pad", ctypes.c_int32)]
+
+
+EXPORTED_SYMBOLS = ["go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
+                    "go1ppo_wgrad_batched", "go1ppo_act",
                     "go1ppo_store_step", "go1ppo_gae", "go1ppo_normalize", "go1ppo_opt_partials", "go1ppo_opt_prestep",
                     "go1ppo_opt_adam", "go1ppo_version"]
 
@@ -59,6 +67,8 @@ def load_library(path=None):
     L.go1ppo_loss.argtypes = [ctypes.POINTER(LossArgs), vp]
     L.go1ppo_mse.argtypes = [vp, i32, vp, i32, vp, i64, i64, i32, vp, vp, vp, vp, vp]
     L.go1ppo_wgrad.argtypes = [vp, i32, vp, i32, i64, i32, i32, vp, i32, vp, vp]
+    L.go1ppo_wgrad_plan.argtypes = [ctypes.POINTER(WgradProblem), i32]
+    L.go1ppo_wgrad_batched.argtypes = [vp, i32, i32, vp]
     f32 = ctypes.c_float
     L.go1ppo_act.argtypes = [vp, vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp]
     L.go1ppo_store_step.argtypes = [vp, vp, vp, vp, vp, f32, i64, vp, vp, vp, vp]
@@ -114,6 +124,7 @@ class FusedNet:
         self.Z = {n: {li: torch.zeros(M, self.P[f"{n}.{li}.W"].shape[0], **bf) for li in range(1, d)}
                   for n, d in self.depth.items()}
         assert policy.npv <= HEAD and self.P["Wz"].shape == (self.na, HEAD)
+        self._recording, self._batched, self._plans = None, False, {}
         if with_grad:
             self.X = torch.zeros(M, policy.Kp, **bf)
             # GEMM outputs are never strided views: the tails' input gradients land in one contiguous buffer per net
@@ -136,8 +147,15 @@ class FusedNet:
                                      _ptr(bias_grad), out.data_ptr(), _ld(out), _stream()), "go1ppo_elu_bwd")
 
     def _wgrad(self, dz, h, gW, gb=None):
+        """weight (+ bias) gradient of one layer.  All operands are static buffers, so the calls of a backward pass are
+        recorded once (`_plan`) and afterwards executed together as ONE batched launch at the end of the pass."""
         n, k = dz.shape[1], h.shape[1]
         assert gW.shape == (n, k) and gW.is_contiguous()
+        if self._recording is not None:
+            self._recording.append((dz, h, gW, gb))
+            return
+        if self._batched:
+            return
         _chk(self.lib.go1ppo_wgrad(dz.data_ptr(), _ld(dz), h.data_ptr(), _ld(h), dz.shape[0], n, k, gW.data_ptr(), k, _ptr(gb),
                                    _stream()), "go1ppo_wgrad")
 
@@ -191,7 +209,40 @@ class FusedNet:
         torch.mm(dY.t(), x, out=tmp)
         gW.copy_(tmp)
 
+    def _run_planned(self, key, fn):
+        """first call: run `fn` recording its weight-gradient problems (nothing launched for them), build the device
+        table; every call: run `fn` with the per-layer launches suppressed, then the one batched launch."""
+        if key not in self._plans:
+            self._recording = []
+            fn()
+            rec, self._recording = self._recording, None
+            tab = (WgradProblem * len(rec))()
+            for P, (dz, h, gW, gb) in zip(tab, rec):
+                P.dz, P.h, P.dW, P.bias_grad = dz.data_ptr(), h.data_ptr(), gW.data_ptr(), _ptr(gb)
+                P.rows, P.ld_dz, P.ld_h, P.n, P.k, P.ldw = dz.shape[0], _ld(dz), _ld(h), dz.shape[1], h.shape[1], gW.shape[1]
+            total = self.lib.go1ppo_wgrad_plan(tab, len(rec))
+            if total <= 0:
+                raise RuntimeError(f"go1ppo_wgrad_plan failed with code {total}")
+            dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.Y1.device)
+            self._plans[key] = (dev, len(rec), total, rec)
+            # the recording pass skipped the launches AND ran the rest of fn: its dgrad results are valid, only the
+            # weight gradients are missing -> fall through to the batched launch
+        else:
+            self._batched = True
+            try:
+                fn()
+            finally:
+                self._batched = False
+        dev, count, total, _ = self._plans[key]
+        _chk(self.lib.go1ppo_wgrad_batched(dev.data_ptr(), count, total, _stream()), "go1ppo_wgrad_batched")
+
     def backward(self, x):
+        self._run_planned("ppo", lambda: self._backward(x))
+
+    def backward_adaptation(self, x):
+        self._run_planned("adaptation", lambda: self._backward_adaptation(x))
+
+    def _backward(self, x):
         """After forward(x) and a loss kernel that filled dZ[actor][last], dZ[critic][last] (+ their bias / std
         gradients): everything else.  Gradients are ACCUMULATED into the (pre-zeroed) flat gradient."""
         nd, na = self.nd, self.na
@@ -210,7 +261,7 @@ class FusedNet:
         self._elu_bwd(dH1["adaptation"], Y1[:, :nd], None, out=dY1[:, :nd])
         self._big_wgrad(dY1, x, G["W1"], self._w1_tmp)
 
-    def backward_adaptation(self, x):
+    def _backward_adaptation(self, x):
         nd, d = self.nd, self.dH1["adaptation"]
         self._tail_bwd("adaptation", self.Y1d, d)
         self._elu_bwd(d, self.Y1d, None)
