@@ -109,7 +109,7 @@ class FusedNet:
     `body` is the bf16 flat parameter buffer (FlatPolicy layout), `grad` the fp32 flat gradient (or None for
     inference-only engines)."""
 
-    def __init__(self, policy, body, grad, M, lib, with_grad):
+    def __init__(self, policy, body, grad, M, lib, with_grad, two_streams=True):
         assert body.dtype == torch.bfloat16 and body.is_cuda
         self.pol, self.M, self.lib = policy, M, lib
         dev = body.device
@@ -125,6 +125,9 @@ class FusedNet:
                   for n, d in self.depth.items()}
         assert policy.npv <= HEAD and self.P["Wz"].shape == (self.na, HEAD)
         self._recording, self._batched, self._plans = None, False, {}
+        # the critic's tail is independent of the actor / adaptation chain: it runs on a side stream (forked from and
+        # joined back into the caller's stream, so HIP-graph capture records it as a parallel branch)
+        self._side = torch.cuda.Stream(device=dev) if two_streams else None
         if with_grad:
             self.X = torch.zeros(M, policy.Kp, **bf)
             # GEMM outputs are never strided views: the tails' input gradients land in one contiguous buffer per net
@@ -178,9 +181,24 @@ class FusedNet:
         self._elu(self.Y1[:, :nd])
         latent = self._tail("adaptation", self.Y1[:, :nd])
         self._elu(self.Y1[:, nd:], latent, na)
+        with self._branch():
+            value = self._tail("critic", self.Y1[:, nd + na:])
         mean = self._tail("actor", self.Y1[:, nd:nd + na])
-        value = self._tail("critic", self.Y1[:, nd + na:])
+        self._join()
         return mean, value, latent
+
+    # ---- two-stream helpers ------------------------------------------------------------------------------------
+    def _branch(self):
+        """context: work issued inside runs on the side stream, ordered after everything issued so far."""
+        if self._side is None:
+            import contextlib
+            return contextlib.nullcontext()
+        self._side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self._side)
+
+    def _join(self):
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def forward_adaptation(self, x):
         torch.mm(x, self.P["W1"][:self.nd].t(), out=self.Y1d)
@@ -248,9 +266,11 @@ class FusedNet:
         nd, na = self.nd, self.na
         G, Y1, dY1, dH1 = self.G, self.Y1, self.dY1, self.dH1
         cols = {"adaptation": slice(0, nd), "actor": slice(nd, nd + na), "critic": slice(nd + na, self.n1)}
-        for net in ("actor", "critic"):
-            self._tail_bwd(net, Y1[:, cols[net]], dH1[net])
-            self._elu_bwd(dH1[net], Y1[:, cols[net]], None, out=dY1[:, cols[net]])
+        with self._branch():
+            self._tail_bwd("critic", Y1[:, cols["critic"]], dH1["critic"])
+            self._elu_bwd(dH1["critic"], Y1[:, cols["critic"]], None, out=dY1[:, cols["critic"]])
+        self._tail_bwd("actor", Y1[:, cols["actor"]], dH1["actor"])
+        self._elu_bwd(dH1["actor"], Y1[:, cols["actor"]], None, out=dY1[:, cols["actor"]])
         # actor first layer's latent columns: a1 += latent Wz^T
         last = self.depth["adaptation"] - 1
         latent, dlat = self.Z["adaptation"][last], self.dZ["adaptation"][last]
@@ -259,6 +279,7 @@ class FusedNet:
         torch.mm(dA1, self.P["Wz"], out=dlat)
         self._tail_bwd("adaptation", Y1[:, :nd], dH1["adaptation"], head_bias_done=False)
         self._elu_bwd(dH1["adaptation"], Y1[:, :nd], None, out=dY1[:, :nd])
+        self._join()
         self._big_wgrad(dY1, x, G["W1"], self._w1_tmp)
 
     def _backward_adaptation(self, x):

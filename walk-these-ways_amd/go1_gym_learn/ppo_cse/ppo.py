@@ -210,7 +210,7 @@ class PPO:
         self._last_hist = self.storage.observation_histories[0].clone()
         if self.fused:
             from go1_gym_learn.ppo_cse.fused import FusedNet
-            self._roll_net = FusedNet(self.policy, self.body, None, num_envs, self._fused_lib, with_grad=False)
+            self._roll_net = FusedNet(self.policy, self.body, None, num_envs, self._fused_lib, with_grad=False, two_streams=False)
 
     def test_mode(self):
         self.actor_critic.test()
