@@ -56,9 +56,31 @@ def build_env(num_envs, rank, seed):
     return HistoryWrapper(env), cfg
 
 
+def effective_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU boxes report 256
+    logical CPUs but run the container under a 16-CPU quota; 256 OpenMP threads on that only thrash)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())              # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(num_envs, target_seconds=15.0):
     """Oracle (fp64 port of the same step, OpenMP over envs) on the host cores: bounded sample of ~target_seconds."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
+    cores = effective_cpus()
+    os.environ["OMP_NUM_THREADS"] = str(cores)          # libgomp reads it at load time ...
+    torch.set_num_threads(cores)                        # ... and torch has usually loaded it already: set the shared ICV
     import numpy as np
     import pyoracle
     import go1sim_host as H
@@ -84,10 +106,9 @@ def cpu_baseline(num_envs, target_seconds=15.0):
     for i in range(policy_steps):
         orc.step(acts[i % 24])
     dt = time.perf_counter() - t0
-    cores = os.cpu_count() or 1
     return {"value": num_envs * policy_steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{num_envs} envs x {policy_steps} policy steps of the sim step only (no policy/PPO), fp64 oracle "
-                      f"(oracle/go1_oracle.c, OpenMP over envs), N(0,1) actions, {dt:.1f} s"}
+                      f"(oracle/go1_oracle.c, OpenMP over envs, {cores} threads = cgroup CPU quota), N(0,1) actions, {dt:.1f} s"}
 
 
 def main():
