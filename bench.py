@@ -28,14 +28,9 @@ for p in (os.path.join(PKG, "shims"), PKG, REPO):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# GEMM kernel selection for the PPO update (PyTorch TunableOp): hipBLASLt's default heuristics pick poor kernels for
-# the tall-skinny bf16 shapes of this policy (M = 24576, N/K = 64..2104).  Tuned choices for gfx950 ship in
-# walk-these-ways_amd/tuning/; shapes not in the file are tuned once during the warm-up iterations.
-_TUNE = os.path.join(PKG, "tuning", "tunableop_gfx950.csv")
-os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
-os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", _TUNE)      # no %d: every rank reads the same table
-os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "30")
-os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS", "5")
+# GEMM kernel selection for the PPO update: PPO() enables PyTorch TunableOp with the gfx950 table shipped in
+# walk-these-ways_amd/tuning/ (go1_gym_learn/ppo_cse/ppo.py::_enable_tuned_gemms; every rank reads the same file;
+# shapes missing from the table are tuned once during the warm-up iterations).  PYTORCH_TUNABLEOP_* overrides it.
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

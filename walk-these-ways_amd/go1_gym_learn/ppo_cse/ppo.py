@@ -67,8 +67,10 @@ def _enable_tuned_gemms():
         from torch.cuda import tunable
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tuning", "tunableop_gfx950.csv")
         tunable.enable(True)
-        tunable.set_filename(os.path.normpath(path), insert_device_ordinal=False)
+        tunable.set_filename(os.path.normpath(path), insert_device_ordinal=False)      # one table for every rank
         tunable.set_max_tuning_duration(30)
+        if hasattr(tunable, "write_file_on_exit"):
+            tunable.write_file_on_exit(False)       # the shipped table is read-only; tools/tune_gemms.sh regenerates it
     except Exception as err:          # an optimisation only
         print(f"[ppo] TunableOp not enabled ({type(err).__name__}: {err})")
 
