@@ -203,6 +203,12 @@ def main():
     if args.breakdown and rank == 0:
         n_it = args.steps
         print(f"[breakdown] rollout {1e3 * split['rollout'] / n_it:.1f} ms/iter, update {1e3 * split['update'] / n_it:.1f} ms/iter", file=sys.stderr)
+        try:
+            from torch.cuda import tunable
+            print(f"[breakdown] TunableOp enabled={tunable.is_enabled()} table entries={len(tunable.get_results())} file={tunable.get_filename()}",
+                  file=sys.stderr)
+        except Exception as err:
+            print(f"[breakdown] TunableOp state unavailable: {err}", file=sys.stderr)
     if rank == 0:
         total_env_steps = args.envs * T * args.steps * world
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
