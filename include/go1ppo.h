@@ -77,6 +77,30 @@ int go1ppo_mse(const void* pred, int pred_ld, const float* target, int npv, cons
 int go1ppo_wgrad(const void* dz, int ld_dz, const void* h, int ld_h, int64_t rows, int n, int k, float* dW, int ldw,
                  float* bias_grad, void* stream);
 
+/* ---- fused MLP tail, forward: for every net, out_l = act(in_l W_l^T + b_l) through up to 4 layers with the
+ * activations kept on chip (actor_critic.py:52-77: the nn.Sequential bodies behind their first layer).
+ * W_l: bf16 [n_out][k_in] row-major, bias bf16 [n_out]; k_in multiple of 32 and <= 512, n_out multiple of 16 and
+ * <= 512; out (bf16 [rows][ld_out]) may be NULL for activations nobody reads; elu != 0 applies ELU. */
+#define GO1PPO_TAIL_MAX_LAYERS 4
+#define GO1PPO_TAIL_MAX_NETS 3
+typedef struct {
+  const void* W;
+  const void* bias;
+  void* out;
+  int32_t n_out, k_in, ld_out, elu;
+} Go1PpoTailLayer;
+typedef struct {
+  const void* in;            /* bf16 [rows][ld_in], first layer's k_in columns used */
+  int64_t rows;
+  int32_t ld_in, num_layers;
+  Go1PpoTailLayer layer[GO1PPO_TAIL_MAX_LAYERS];
+} Go1PpoTailNet;
+typedef struct {
+  int32_t num_nets, _pad;
+  Go1PpoTailNet net[GO1PPO_TAIL_MAX_NETS];
+} Go1PpoTailArgs;
+int go1ppo_tail_fwd(const Go1PpoTailArgs* args, void* stream);
+
 /* One weight-gradient problem of a batched launch (same contract as go1ppo_wgrad).  The caller fills the first ten
  * fields on the host, go1ppo_wgrad_plan() fills chunk_rows / wg_offset and returns the number of workgroups; the
  * table is then copied to device memory once and every backward pass is a single go1ppo_wgrad_batched() launch. */

@@ -98,6 +98,46 @@ def test_wgrad_matches_fp32_matmul(lib, M, n, k, ld_dz, ld_h):
     assert lib.go1ppo_wgrad(dz.data_ptr(), ld_dz, h.data_ptr(), ld_h, M, 48, k, out.data_ptr(), k, None, stream()) == -1
 
 
+@pytest.mark.parametrize("M", [4096, 1000, 24576])
+def test_fused_tail_forward_matches_layerwise_torch(lib, M):
+    """go1ppo_tail_fwd (three layers, activations on chip) vs addmm + ELU per layer in fp32 on the same bf16 data."""
+    import ctypes
+    from go1_gym_learn.ppo_cse import fused
+    g = torch.Generator(device="cuda").manual_seed(9)
+    ld_in, off = 1280, 256
+    y1 = bf(torch.randn(M, ld_in, device="cuda", generator=g))
+    nets = {"actor": (off, [512, 256, 128, 64]), "critic": (off + 512, [512, 256, 128, 64])}
+    a = fused.TailArgs()
+    a.num_nets = 2
+    keep, refs = [], {}
+    for N, (name, (o, dims)) in zip(a.net, nets.items()):
+        h = y1[:, o:o + dims[0]]
+        N.in_, N.rows, N.ld_in, N.num_layers = h.data_ptr(), M, ld_in, len(dims) - 1
+        x = h.float()
+        for li in range(1, len(dims)):
+            W = bf(torch.randn(dims[li], dims[li - 1], device="cuda", generator=g) / dims[li - 1] ** 0.5)
+            b = bf(torch.randn(dims[li], device="cuda", generator=g) * 0.1)
+            out = torch.zeros(M, dims[li], device="cuda", dtype=torch.bfloat16)
+            last = li == len(dims) - 1
+            L = N.layer[li - 1]
+            L.W, L.bias, L.out, L.n_out, L.k_in, L.ld_out, L.elu = W.data_ptr(), b.data_ptr(), out.data_ptr(), dims[li], dims[li - 1], dims[li], 0 if last else 1
+            x = x @ W.float().t() + b.float()
+            if not last:
+                x = torch.nn.functional.elu(x)
+            x = bf(x).float()                       # the kernel rounds every layer's output to bf16 once
+            keep += [W, b, out]
+            refs[(name, li)] = (out, x)
+    assert lib.go1ppo_tail_fwd(ctypes.byref(a), stream()) == 0
+    torch.cuda.synchronize()
+    for (name, li), (out, ref) in refs.items():
+        # one bf16 ulp per layer, compounding through <= 3 layers of O(1) activations
+        torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2, msg=f"{name} layer {li}")
+        assert float((out.float() - ref).abs().mean()) < 2e-3
+    bad = fused.TailArgs()
+    bad.num_nets = 1
+    assert lib.go1ppo_tail_fwd(ctypes.byref(bad), stream()) == -1
+
+
 def autograd_losses(mean, value, std, b, A):
     from go1_gym_learn.ppo_cse.ppo import gaussian_log_prob, gaussian_entropy
     logp = gaussian_log_prob(b["actions"], mean, std)

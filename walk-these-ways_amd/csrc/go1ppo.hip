@@ -577,6 +577,95 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
   }
 }
 
+// ---------------------------------------------------------------------------------------------- fused MLP tail (forward)
+// The layers behind the shared first layer (actor / critic 512->256->128->64, adaptation 256->128->64) for a block
+// of 32 rows per workgroup, activations resident in LDS from layer to layer, weights streamed from L2 as MFMA B
+// fragments (W is [n][k] row-major: the 8 consecutive k a lane needs are 16 contiguous bytes — no staging, no
+// transpose).  Replaces 3 hipBLASLt GEMMs + 2 ELU kernels per net whose 6..40 us each are launch/occupancy bound
+// (M = 24576 or 4096 rows, N <= 256).  out = elu(in W^T + b) per layer (no ELU on the head); intermediate
+// activations are also written to global memory when the backward pass needs them.
+#define TF_MAXK 512
+template <int BM>          // rows per workgroup: 32 (small batches: more workgroups) or 64 (large: half the weight traffic)
+__global__ __launch_bounds__(256) void tail_fwd_kernel(Go1PpoTailArgs A) {
+  constexpr int RT = BM / 16;                                            // 16-row MFMA tiles per workgroup
+  __shared__ __attribute__((aligned(16))) bf16_t act[2][BM][TF_MAXK + 8];
+  const Go1PpoTailNet& N = A.net[blockIdx.y];
+  const int64_t row0 = (int64_t)blockIdx.x * BM;
+  if (row0 >= N.rows) return;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, c = lane & 15, g = lane >> 4;
+  // stage the input rows
+  {
+    const int k0 = N.layer[0].k_in, cgs = k0 >> 3;
+    for (int i = t; i < BM * cgs; i += 256) {
+      const int r = i / cgs, cg = i - r * cgs;
+      const int64_t row = row0 + r;
+      Bf8 v;
+      if (row < N.rows) v = *reinterpret_cast<const Bf8*>((const bf16_t*)N.in + row * N.ld_in + 8 * cg);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) v.v[e] = 0;
+      }
+      *reinterpret_cast<Bf8*>(&act[0][r][8 * cg]) = v;
+    }
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int li = 0; li < N.num_layers; li++) {
+    const Go1PpoTailLayer L = N.layer[li];
+    const bf16_t* W = (const bf16_t*)L.W;
+    const bf16_t* bias = (const bf16_t*)L.bias;
+    bf16_t* out = (bf16_t*)L.out;
+    const int ksteps = L.k_in >> 5;
+    const int ntiles = L.n_out >> 4;
+    for (int j0 = wave; j0 < ntiles; j0 += 16) {                // this wave's column tiles j0, j0+4, j0+8, j0+12: one pass
+      // register blocking: every A fragment read from LDS feeds up to 4 column tiles
+      f32x4 acc[4][RT];
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+        for (int h = 0; h < RT; h++) acc[jj][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const bf16_t* wrow = W + (int64_t)(16 * j0 + c) * L.k_in + 8 * g;
+      const int64_t wstep = (int64_t)64 * L.k_in;                 // 4 tiles = 64 rows of W further
+#pragma unroll 2
+      for (int ks = 0; ks < ksteps; ks++) {
+        bf16x8_t a[RT], bfr[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)
+          if (j0 + 4 * jj < ntiles) bfr[jj] = *reinterpret_cast<const bf16x8_t*>(wrow + jj * wstep + 32 * ks);
+#pragma unroll
+        for (int h = 0; h < RT; h++) a[h] = *reinterpret_cast<const bf16x8_t*>(&act[cur][16 * h + c][32 * ks + 8 * g]);
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)
+          if (j0 + 4 * jj < ntiles) {
+#pragma unroll
+            for (int h = 0; h < RT; h++) acc[jj][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[h], bfr[jj], acc[jj][h], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) {
+        if (j0 + 4 * jj < ntiles) {
+          const int n = 16 * (j0 + 4 * jj) + c;
+          const float bn = bf2f(bias[n]);
+#pragma unroll
+          for (int h = 0; h < RT; h++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              float v = acc[jj][h][q] + bn;
+              if (L.elu) v = elu1(v);
+              const bf16_t o = f2bf(v);
+              const int r = 16 * h + 4 * g + q;
+              act[cur ^ 1][r][n] = o;
+              if (out && row0 + r < N.rows) out[(row0 + r) * L.ld_out + n] = o;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
 // row split of one weight-gradient problem: enough workgroups to fill the chip, but a bounded fan-in per output
 // element — the partial sums meet in fp32 atomics, which resolve beyond the per-XCD L2 and serialise per address
 // (measured: 256x512 best at 32 splits, 128x256 at 64, 64x128 at 128)
@@ -712,6 +801,27 @@ extern "C" int go1ppo_opt_adam(float* p, const float* g, float* m, float* v, int
 }
 
 extern "C" int go1ppo_opt_partials(void) { return OPT_BLOCKS; }
+
+extern "C" int go1ppo_tail_fwd(const Go1PpoTailArgs* args, void* stream) {
+  if (!args || args->num_nets <= 0 || args->num_nets > GO1PPO_TAIL_MAX_NETS) return -1;
+  int64_t max_rows = 0;
+  for (int i = 0; i < args->num_nets; i++) {
+    const Go1PpoTailNet& N = args->net[i];
+    if (!N.in || N.rows <= 0 || N.num_layers <= 0 || N.num_layers > GO1PPO_TAIL_MAX_LAYERS || (N.ld_in & 7) || !aligned16(N.in)) return -1;
+    for (int l = 0; l < N.num_layers; l++) {
+      const Go1PpoTailLayer& L = N.layer[l];
+      if (!L.W || !L.bias || L.k_in <= 0 || L.k_in > TF_MAXK || (L.k_in & 31) || L.n_out <= 0 || L.n_out > TF_MAXK || (L.n_out & 15) ||
+          !aligned16(L.W) || (l > 0 && L.k_in != N.layer[l - 1].n_out) || (L.out && L.ld_out < L.n_out))
+        return -2;
+    }
+    if (N.rows > max_rows) max_rows = N.rows;
+  }
+  if (false)
+    tail_fwd_kernel<64><<<dim3((unsigned)((max_rows + 63) / 64), args->num_nets), dim3(256), 0, (hipStream_t)stream>>>(*args);
+  else
+    tail_fwd_kernel<32><<<dim3((unsigned)((max_rows + 31) / 32), args->num_nets), dim3(256), 0, (hipStream_t)stream>>>(*args);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
 
 extern "C" int go1ppo_wgrad_plan(Go1PpoWgradProblem* probs, int count) {
   if (!probs || count <= 0) return -1;

@@ -45,7 +45,21 @@ class WgradProblem(ctypes.Structure):
                 ("_pad", ctypes.c_int32)]
 
 
-EXPORTED_SYMBOLS = ["go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
+class TailLayer(ctypes.Structure):
+    _fields_ = [("W", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n_out", ctypes.c_int32),
+                ("k_in", ctypes.c_int32), ("ld_out", ctypes.c_int32), ("elu", ctypes.c_int32)]
+
+
+class TailNet(ctypes.Structure):
+    _fields_ = [("in_", ctypes.c_void_p), ("rows", ctypes.c_int64), ("ld_in", ctypes.c_int32), ("num_layers", ctypes.c_int32),
+                ("layer", TailLayer * 4)]
+
+
+class TailArgs(ctypes.Structure):
+    _fields_ = [("num_nets", ctypes.c_int32), ("_pad", ctypes.c_int32), ("net", TailNet * 3)]
+
+
+EXPORTED_SYMBOLS = ["go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
                     "go1ppo_wgrad_batched", "go1ppo_act",
                     "go1ppo_store_step", "go1ppo_gae", "go1ppo_normalize", "go1ppo_opt_partials", "go1ppo_opt_prestep",
                     "go1ppo_opt_adam", "go1ppo_version"]
@@ -68,6 +82,7 @@ def load_library(path=None):
     L.go1ppo_mse.argtypes = [vp, i32, vp, i32, vp, i64, i64, i32, vp, vp, vp, vp, vp]
     L.go1ppo_wgrad.argtypes = [vp, i32, vp, i32, i64, i32, i32, vp, i32, vp, vp]
     L.go1ppo_wgrad_plan.argtypes = [ctypes.POINTER(WgradProblem), i32]
+    L.go1ppo_tail_fwd.argtypes = [ctypes.POINTER(TailArgs), vp]
     L.go1ppo_wgrad_batched.argtypes = [vp, i32, i32, vp]
     f32 = ctypes.c_float
     L.go1ppo_act.argtypes = [vp, vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp]
@@ -109,7 +124,7 @@ class FusedNet:
     `body` is the bf16 flat parameter buffer (FlatPolicy layout), `grad` the fp32 flat gradient (or None for
     inference-only engines)."""
 
-    def __init__(self, policy, body, grad, M, lib, with_grad, two_streams=True):
+    def __init__(self, policy, body, grad, M, lib, with_grad, two_streams=True, fused_tails=None):
         assert body.dtype == torch.bfloat16 and body.is_cuda
         self.pol, self.M, self.lib = policy, M, lib
         dev = body.device
@@ -125,6 +140,16 @@ class FusedNet:
                   for n, d in self.depth.items()}
         assert policy.npv <= HEAD and self.P["Wz"].shape == (self.na, HEAD)
         self._recording, self._batched, self._plans = None, False, {}
+        self._tails = self._tails_ad = None
+        # measured on MI355X: one fused launch per dependency level beats 8 GEMMs + 5 ELU kernels 3.5x at M = 4096
+        # (rollout inference: 32 vs 110 us) but only ties hipBLASLt + the two-stream schedule at M = 24576
+        if fused_tails is None:
+            fused_tails = M <= 8192
+        if fused_tails and self._fused_tails_ok():
+            nd, na = self.nd, self.na
+            self._tails = (self._tail_args([("adaptation", self.Y1[:, :nd])], with_grad),
+                           self._tail_args([("actor", self.Y1[:, nd:nd + na]), ("critic", self.Y1[:, nd + na:])], with_grad))
+            self._tails_ad = self._tail_args([("adaptation", self.Y1d)], with_grad)
         # the critic's tail is independent of the actor / adaptation chain: it runs on a side stream (forked from and
         # joined back into the caller's stream, so HIP-graph capture records it as a parallel branch)
         self._side = torch.cuda.Stream(device=dev) if two_streams else None
@@ -163,6 +188,30 @@ class FusedNet:
                                    _stream()), "go1ppo_wgrad")
 
     # ---- forward -------------------------------------------------------------------------------------------
+    def _tail_args(self, nets_and_inputs, keep_intermediates):
+        """Go1PpoTailArgs for go1ppo_tail_fwd: the listed nets' layers behind the first one, reading their (post-ELU)
+        first-layer block and writing Z[net][li] (intermediates only when the backward pass needs them)."""
+        a = TailArgs()
+        a.num_nets = len(nets_and_inputs)
+        for N, (net, h) in zip(a.net, nets_and_inputs):
+            d = self.depth[net]
+            N.in_, N.rows, N.ld_in, N.num_layers = h.data_ptr(), h.shape[0], _ld(h), d - 1
+            for li in range(1, d):
+                L, W, z = N.layer[li - 1], self.P[f"{net}.{li}.W"], self.Z[net][li]
+                last = li == d - 1
+                L.W, L.bias = W.data_ptr(), self.P[f"{net}.{li}.b"].data_ptr()
+                L.out = z.data_ptr() if (last or keep_intermediates) else None
+                L.n_out, L.k_in, L.ld_out, L.elu = W.shape[0], W.shape[1], _ld(z), 0 if last else 1
+        return a
+
+    def _fused_tails_ok(self):
+        ok = all(self.depth[n] - 1 <= 4 for n in self.depth)
+        for n, d in self.depth.items():
+            for li in range(1, d):
+                r, k = self.P[f"{n}.{li}.W"].shape
+                ok = ok and k % 32 == 0 and k <= 512 and r % 16 == 0 and r <= 512
+        return ok
+
     def _tail(self, net, h):
         P, d = self.P, self.depth[net]
         for li in range(1, d):
@@ -179,6 +228,13 @@ class FusedNet:
         nd, na = self.nd, self.na
         torch.mm(x, self.P["W1"].t(), out=self.Y1)
         self._elu(self.Y1[:, :nd])
+        if self._tails is not None:               # fused MLP tails: one launch per dependency level
+            ta, tac = self._tails
+            _chk(self.lib.go1ppo_tail_fwd(ctypes.byref(ta), _stream()), "go1ppo_tail_fwd")
+            latent = self.Z["adaptation"][self.depth["adaptation"] - 1]
+            self._elu(self.Y1[:, nd:], latent, na)
+            _chk(self.lib.go1ppo_tail_fwd(ctypes.byref(tac), _stream()), "go1ppo_tail_fwd")
+            return self.Z["actor"][self.depth["actor"] - 1], self.Z["critic"][self.depth["critic"] - 1], latent
         latent = self._tail("adaptation", self.Y1[:, :nd])
         self._elu(self.Y1[:, nd:], latent, na)
         with self._branch():
@@ -203,6 +259,9 @@ class FusedNet:
     def forward_adaptation(self, x):
         torch.mm(x, self.P["W1"][:self.nd].t(), out=self.Y1d)
         self._elu(self.Y1d)
+        if self._tails_ad is not None:
+            _chk(self.lib.go1ppo_tail_fwd(ctypes.byref(self._tails_ad), _stream()), "go1ppo_tail_fwd")
+            return self.Z["adaptation"][self.depth["adaptation"] - 1]
         return self._tail("adaptation", self.Y1d)
 
     # ---- backward ------------------------------------------------------------------------------------------
