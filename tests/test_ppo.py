@@ -81,3 +81,49 @@ def test_state_dict_keys_match_reference_layout():
     ac = ActorCritic(70, 2, 2100, 12)
     torch.jit.script(ac.adaptation_module)      # export path of Runner.save
     torch.jit.script(ac.actor_body)
+
+
+def test_flat_layout_adaptation_prefix_and_roundtrip():
+    """FlatPolicy layout: pack/unpack is exact, the adaptation module's parameters (tail blocks + its rows of W1) are
+    one contiguous prefix [0, adaptation_numel) — what the adaptation optimiser / gradient all-reduce cover — and
+    the padded columns / rows stay exactly zero."""
+    from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
+    from go1_gym_learn.ppo_cse.flat_policy import FlatPolicy, HEAD_COLS
+    torch.manual_seed(0)
+    ac = ActorCritic(70, 2, 2100, 12)
+    pol = FlatPolicy(ac)
+    flat = torch.zeros(pol.numel)
+    pol.pack(ac, flat)
+    names = [n for n, _ in pol.blocks]
+    assert names[:4] == ["adaptation.1.W", "adaptation.1.b", "adaptation.2.W", "adaptation.2.b"] and names[4] == "W1"
+    n_ad = sum(p.numel() for p in ac.adaptation_module.parameters())
+    prefix = flat[:pol.adaptation_numel]
+    assert int((prefix != 0).sum()) == n_ad                       # every adaptation parameter, nothing else
+    assert not flat[pol.adaptation_numel:pol.adaptation_numel + 8].eq(0).all()        # actor rows of W1 follow directly
+    W1 = pol._block(flat, "W1")
+    nd, na = pol.first[0], pol.first[1]
+    assert not W1[:nd + na, pol.K + 1:].any()                     # adaptation / actor rows never see the privileged columns
+    assert not pol._block(flat, "Wz")[:, pol.npv:].any() and pol._block(flat, "Wz").shape[1] == HEAD_COLS
+    ac2 = ActorCritic(70, 2, 2100, 12)
+    FlatPolicy(ac2).unpack(flat, ac2)              # a FlatPolicy is bound to the module it was built from
+    for (k, a), (_, b) in zip(ac.state_dict().items(), ac2.state_dict().items()):
+        if k != "std":
+            assert torch.equal(a, b), k
+    # functional forward on the flat buffer == the nn.Module
+    h, p = torch.randn(5, 2100), torch.randn(5, 2)
+    x = torch.zeros(5, pol.Kp)
+    x[:, :2100], x[:, 2100], x[:, 2101:2103] = h, 1.0, p
+    mean, value, latent = pol.forward(flat, x)
+    torch.testing.assert_close(mean, ac.act_inference({"obs_history": h, "privileged_obs": p}), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(value, ac.evaluate(h, p), rtol=1e-4, atol=1e-5)
+
+
+def test_storage_returns_are_in_place():
+    """the update's HIP graphs (and the fused loss kernel) hold the addresses of advantages / returns."""
+    from go1_gym_learn.ppo_cse.rollout_storage import RolloutStorage
+    st = RolloutStorage(6, 4, [3], [2], [9], [2])
+    st.rewards.normal_(); st.values.normal_()
+    pa, pr = st.advantages.data_ptr(), st.returns.data_ptr()
+    st.compute_returns(torch.randn(6, 1), 0.99, 0.95)
+    assert st.advantages.data_ptr() == pa and st.returns.data_ptr() == pr
+    assert abs(float(st.advantages.mean())) < 1e-6 and abs(float(st.advantages.std()) - 1.0) < 1e-4
