@@ -151,3 +151,38 @@ def test_graph_replay_update_equals_eager_update():
     assert lr0 == lr1
     np.testing.assert_allclose(l0, l1, rtol=1e-5)
     assert torch.equal(w0, w1)
+
+
+def test_ppo_learns_on_the_hip_simulator(tmp_path):
+    """End to end: 200 PPO iterations (bf16 fused update, HIP graphs) on 2048 simulated Go1s with the train.py
+    configuration.  The mean step reward must grow and the adaptation module must fit the privileged parameters
+    better than at the start (measured at 4096 envs: reward x1.7 after 200 iterations, x3.7 after 400; 17 s)."""
+    from go1_gym_learn.ppo_cse import Runner, RunnerArgs
+    from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    from ml_logger import logger
+    logger.configure("run_learn", root=str(tmp_path))
+    logger.print_summary = False
+    PPO_Args.autocast_bf16 = True
+    RunnerArgs.save_video_interval = 0
+    torch.manual_seed(0)
+    env, cfg = build_env(2048)
+    runner = Runner(env, device="cuda:0")
+    T, n = runner.num_steps_per_env, env.num_train_envs
+    env.episode_length_buf.copy_(torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length)))
+    obs_dict = env.get_observations()
+    rew, adapt = [], []
+    for it in range(200):
+        acc = torch.zeros((), device="cuda")
+        with torch.inference_mode():
+            for _ in range(T):
+                obs_dict, _ = runner._rollout_step(obs_dict)
+                acc += env.rew_buf.mean()
+            runner.alg.compute_returns(obs_dict["obs_history"][:n], obs_dict["privileged_obs"][:n])
+        losses = runner.alg.update()
+        rew.append(float(acc) / T)
+        adapt.append(losses[2])
+    PPO_Args.autocast_bf16 = False
+    assert all(np.isfinite(rew)) and torch.isfinite(runner.alg.master).all()
+    first, last = float(np.mean(rew[:40])), float(np.mean(rew[-40:]))
+    assert last > 1.25 * first, (first, last)
+    assert np.mean(adapt[-40:]) < 0.9 * np.mean(adapt[:40]), (np.mean(adapt[:40]), np.mean(adapt[-40:]))
