@@ -186,3 +186,54 @@ def test_ppo_learns_on_the_hip_simulator(tmp_path):
     first, last = float(np.mean(rew[:40])), float(np.mean(rew[-40:]))
     assert last > 1.25 * first, (first, last)
     assert np.mean(adapt[-40:]) < 0.9 * np.mean(adapt[:40]), (np.mean(adapt[:40]), np.mean(adapt[-40:]))
+
+
+def test_rough_terrain_env_end_to_end():
+    """BASELINE config 3 through the env surface: curriculum tile grid (slopes / rough slopes / stairs / obstacles) as
+    a height field, 187-point height scan appended to the observation (70 + 187 = 257), height-relative termination."""
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+    from go1_gym.envs.wrappers.history_wrapper import HistoryWrapper
+    from scripts.train_config import apply_train_config
+    N = 512
+    cfg = apply_train_config(make_cfg(), num_envs=N)
+    t = cfg.terrain
+    t.mesh_type, t.terrain_proportions, t.curriculum = "heightfield", [0.1, 0.1, 0.35, 0.25, 0.2], True
+    t.num_rows, t.num_cols, t.terrain_length, t.terrain_width, t.border_size, t.center_robots = 10, 20, 8.0, 8.0, 25.0, False
+    t.measure_heights = True
+    cfg.env.observe_heights = True
+    cfg.env.num_observations = 70 + 187
+    cfg.env.num_scalar_observations = 70 + 187
+    torch.manual_seed(0)
+    env = HistoryWrapper(VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg))
+    base = env.env
+    assert base.sim_config.terrain_type == 1 and base.height_samples.shape == (1300, 2100)
+    assert env.num_obs == 257 and env.num_obs_history == 30 * 257
+    obs = env.reset()
+    assert obs["obs"].shape == (N, 257) and obs["obs_history"].shape == (N, 30 * 257)
+    # robots are spread over the tile grid: origins sit ON the terrain (z of the tile centre), several terrain types
+    org = base.env_origins
+    assert float(org[:, 2].max()) > 0.3 and float(org[:, 2].min()) >= 0.0
+    assert len(torch.unique(base.terrain_types)) == 20 and int(base.terrain_levels.max()) <= t.max_init_terrain_level
+    g = torch.Generator(device="cuda").manual_seed(1)
+    resets = 0
+    for step in range(150):
+        a = 0.5 * torch.randn(N, 12, device="cuda", generator=g)
+        obs, rew, done, info = env.step(a)
+        resets += int(done.sum())
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs["obs"]).all() and torch.isfinite(rew).all() and torch.isfinite(base.root_states).all()
+    scan = obs["obs"][:, 70:]
+    assert float(scan.abs().max()) <= 5.0 + 0.6 and float(scan.std()) > 0.05          # clip(z - 0.5 - h, -1, 1) * 5 + noise, varied relief
+    mh = base.measured_heights
+    assert mh.shape == (N, 187) and float(mh.max()) > 0.2
+    # nobody fell through or flew away: base height above the terrain under it stays in a sane band
+    px = ((base.root_states[:, 0] + t.border_size) / t.horizontal_scale).long().clamp(0, 1299)
+    py = ((base.root_states[:, 1] + t.border_size) / t.horizontal_scale).long().clamp(0, 2099)
+    ground = base.height_samples[px, py].float() * t.vertical_scale
+    rel = base.root_states[:, 2] - ground
+    # (the reference takes a tile's origin height as the max over the WHOLE tile — terrain.py:177 ignores its own
+    # centre window — so robots over the inverted-stairs pits spawn on the rim level and drop in: allow for those)
+    assert float(rel.min()) > -0.05 and float(rel.max()) < 2.5, (float(rel.min()), float(rel.max()))
+    assert 0.15 < float(rel.median()) < 0.45
+    assert resets > 0
