@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT/walk-these-ways_amd/csrc
 run() {
   name=$1; shift
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$@" -o libgo1sim.so go1sim.hip 2>/dev/null || { echo "$name: build failed"; return; }
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-hip-fp32-correctly-rounded-divide-sqrt "$@" -o libgo1sim.so go1sim.hip 2>/dev/null || { echo "$name: build failed"; return; }
   for a in "" "--zero-actions"; do
     echo -n "$name actions[$a]: "
     (cd $GRAFT_REPO_ROOT && python bench.py --steps 8 --warmup 4 --no-cpu-baseline --sim-only $a 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('launch_ms', round(d['roofline']['launch_ms'],4))")

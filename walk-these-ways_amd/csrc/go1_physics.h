@@ -541,7 +541,11 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
     const bool base_col = (sbase == k);
     V3 nk = v3(LDS(L_CN + 3 * k), LDS(L_CN + 3 * k + 1), LDS(L_CN + 3 * k + 2)), t1k, t2k;
     contact_frame(nk, t1k, t2k);
+#ifdef GO1_UNROLL_R
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int r = 0; r < 3; r++) {
       V3 d = r == 0 ? nk : r == 1 ? t1k : t2k;
       SV f = sv(cross(x, d), d);
