@@ -453,7 +453,9 @@ class PPO:
         def rec(fn):
             nonlocal pool
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            # thread-local capture mode: the RCCL watchdog thread of a data-parallel run polls events concurrently,
+            # which the default (global) mode treats as a capture violation
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 fn()
             pool = pool or g.pool()
             graphs.append(g)
