@@ -33,7 +33,7 @@ def main():
     lib = fused.load_library()
     s = torch.cuda.current_stream().cuda_stream
     bf = dict(device="cuda", dtype=torch.bfloat16)
-    print(f"rows = {M}; wgrad variant = {os.environ.get('GO1PPO_WGRAD_VARIANT', 'default')}, wgs/CU = {os.environ.get('GO1PPO_WGRAD_WGS', 'default')}")
+    print(f"rows = {M}")
     print("wgrad (n x k)      fused us   torch.mm us   GF    fused TF/s")
     for n, k, ld_dz, ld_h in ((256, 512, 256, 1280), (128, 256, 128, 256), (64, 128, 64, 128), (512, 64, 1280, 64), (128, 256, 128, 1280)):
         dz = torch.randn(M, ld_dz, **bf)

@@ -8,12 +8,13 @@
 //             std and the head biases, gathering the rollout-storage rows through the mini-batch index
 //   mse       adaptation-module regression loss and gradient
 //   wgrad     dW = dZ^T H for the small layers (n, k <= 512, 24576-row reduction): bf16 MFMA 16x16x32 with the
-//             operands transposed through LDS, split over row chunks, fp32 atomic accumulation.  hipBLASLt serves
-//             these shapes with 16x16 macro-tiles at ~50-70 us; this kernel fills the chip with (n/64)(k/64)S blocks.
+//             operands transposed through LDS, split over row chunks, fp32 atomic accumulation; all layers of a
+//             backward pass in one batched launch.  hipBLASLt serves these shapes at 90-135 us each.
+//   tail_fwd  the MLP layers behind the first one with the activations kept on chip (rollout inference)
+//   act / store_step / gae / normalize / opt_prestep / opt_adam: rollout glue and the optimiser step
 // bf16 activations, fp32 math, fp32 parameter gradients.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include "../../include/go1ppo.h"
 
 typedef uint16_t bf16_t;
@@ -266,69 +267,11 @@ __global__ __launch_bounds__(256) void mse_kernel(const bf16_t* pred, int pred_l
 // ---------------------------------------------------------------------------------------------- wgrad (MFMA, split rows)
 // dW[n0+i][k0+j] += sum_m dz[m][n0+i] h[m][k0+j] for a 64x64 output tile and one row chunk per workgroup.
 // MFMA 16x16x32 bf16 wants, per lane, 8 consecutive reduction indices (m) for one output row/column, but both
-// operands are m-major in memory; the 32-row step is therefore transposed on its way into LDS
-// (At[n][m], Bt[k][m], rows padded to 40 elements = 80 B: 16-byte aligned b128 reads that tile all 64 banks).
+// operands are m-major in memory; every 64-row step is therefore transposed on its way into LDS (T[op][n|k][m],
+// rows padded to 72 elements = 144 B: 16-byte aligned b128 fragment reads).
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-#define WG_LDM 40
-__global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* dz, int ld_dz, const bf16_t* h, int ld_h, int64_t rows,
-                                                    int chunk_rows, float* dW, int ldw) {
-  __shared__ __attribute__((aligned(16))) bf16_t At[2][64][WG_LDM];
-  __shared__ __attribute__((aligned(16))) bf16_t Bt[2][64][WG_LDM];
-  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-  const int64_t m_begin = (int64_t)blockIdx.z * chunk_rows;
-  const int64_t m_end = m_begin + chunk_rows < rows ? m_begin + chunk_rows : rows;
-  const int t = threadIdx.x, lrow = t >> 3, cg = t & 7, wave = t >> 6, lane = t & 63;
-  f32x4 acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  Bf8 ra, rb;
-  auto gload = [&](int64_t m) {
-    int64_t r = m + lrow;
-    if (r < m_end) {
-      ra = *reinterpret_cast<const Bf8*>(dz + r * ld_dz + n0 + 8 * cg);
-      rb = *reinterpret_cast<const Bf8*>(h + r * ld_h + k0 + 8 * cg);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; e++) ra.v[e] = rb.v[e] = 0;
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      At[buf][8 * cg + e][lrow] = ra.v[e];
-      Bt[buf][8 * cg + e][lrow] = rb.v[e];
-    }
-  };
-  if (m_begin >= m_end) return;
-  gload(m_begin);
-  sstore(0);
-  __syncthreads();
-  int buf = 0;
-  for (int64_t m = m_begin; m < m_end; m += 32) {
-    bool more = m + 32 < m_end;
-    if (more) gload(m + 32);
-    bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(&At[buf][16 * wave + (lane & 15)][(lane >> 4) * 8]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      bf16x8_t bv = *reinterpret_cast<const bf16x8_t*>(&Bt[buf][16 * j + (lane & 15)][(lane >> 4) * 8]);
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[j], 0, 0, 0);
-    }
-    if (more) sstore(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-  // C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-  for (int j = 0; j < 4; j++)
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      int row = n0 + 16 * wave + (lane >> 4) * 4 + q, col = k0 + 16 * j + (lane & 15);
-      atomicAdd(dW + (int64_t)row * ldw + col, acc[j][q]);
-    }
-}
-
-// v2: 64-row steps; every thread loads a 4-row x 8-column patch of one operand and stores its transpose with eight
-// 8-byte LDS writes (4 consecutive reduction indices each) instead of 32 two-byte ones.
+// Every thread loads a 4-row x 8-column patch of one operand and stores its transpose with eight 8-byte LDS writes
+// (4 consecutive reduction indices each).
 #define WG2_LDM 72
 __device__ __forceinline__ void wgrad2_body(const bf16_t* dz, int ld_dz, const bf16_t* h, int ld_h, int64_t m_begin, int64_t m_end,
                                             float* dW, int ldw, float* bias_grad, int n0, int k0, bool do_bias,
@@ -729,21 +672,12 @@ extern "C" int go1ppo_wgrad(const void* dz, int ld_dz, const void* h, int ld_h, 
                             float* bias_grad, void* stream) {
   if (!dz || !h || !dW || rows <= 0 || n <= 0 || k <= 0 || (n & 63) || (k & 63) || (ld_dz & 7) || (ld_h & 7) || !aligned16(dz) || !aligned16(h))
     return -1;
-  static int variant = -1;
-  if (variant < 0) {
-    const char* e = getenv("GO1PPO_WGRAD_VARIANT");
-    variant = e ? atoi(e) : 2;
-  }
-  const int step = variant == 1 ? 32 : 64;
+  const int step = 64;
   int64_t S, chunk_steps;
   wgrad_split(rows, n, k, step, &S, &chunk_steps);
   dim3 grid(n / 64, k / 64, (unsigned)S);
-  if (variant == 1 && !bias_grad)
-    wgrad_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dz, ld_dz, (const bf16_t*)h, ld_h, rows,
-                                                              (int)(chunk_steps * step), dW, ldw);
-  else
-    wgrad2_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dz, ld_dz, (const bf16_t*)h, ld_h, rows,
-                                                               (int)(chunk_steps * step), dW, ldw, bias_grad);
+  wgrad2_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dz, ld_dz, (const bf16_t*)h, ld_h, rows,
+                                                             (int)(chunk_steps * step), dW, ldw, bias_grad);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
