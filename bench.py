@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sim-only", action="store_true", help="diagnostic: time env.step alone with pre-generated actions")
     ap.add_argument("--zero-actions", action="store_true", help="diagnostic with --sim-only: standing robots (few resets)")
+    ap.add_argument("--rollout-only", action="store_true", help="diagnostic: sim + policy inference + storage, no update (SURVEY 8d metric 2)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry run: all ranks share GPU 0 (with --backend gloo)")
     ap.add_argument("--breakdown", action="store_true", help="diagnostic: print rollout/update split to stderr (adds syncs)")
@@ -167,6 +168,9 @@ def main():
         if args.breakdown:
             torch.cuda.synchronize()
             tb = time.perf_counter()
+        if args.rollout_only:
+            runner.alg.storage.clear()
+            return obs_dict
         runner.alg.update()
         if args.breakdown:
             torch.cuda.synchronize()
@@ -223,7 +227,8 @@ def main():
         bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * args.envs
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
-            "metric": "env-steps/sec (sim+PPO)" if not args.sim_only else "env-steps/sec (sim only, diagnostic)",
+            "metric": ("env-steps/sec (sim only, diagnostic)" if args.sim_only else
+                       "env-steps/sec (sim + policy inference, diagnostic)" if args.rollout_only else "env-steps/sec (sim+PPO)"),
             "value": total_env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

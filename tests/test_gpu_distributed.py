@@ -39,8 +39,8 @@ def _worker(rank, world, port, out):
         alg.compute_returns(hist, priv)
         losses = alg.update()
     torch.cuda.synchronize()
-    out[rank] = dict(w=alg.master.cpu().clone(), lr=alg.learning_rate, dp=alg.dp, fused=alg.fused, graphs=alg._graphs is not None,
-                     n_graphs=len(alg._graphs or []), losses=losses)
+    out[rank] = dict(w=alg.master.cpu().clone(), lr=alg.learning_rate, dp=alg.dp, fused=alg.fused, graphs=bool(alg._graphs),
+                     n_graphs=len(next(iter(alg._graphs.values()))) if alg._graphs else 0, n_sets=len(alg._graphs), losses=losses)
     dist.destroy_process_group()
 
 
@@ -51,7 +51,7 @@ def test_two_rank_fused_update_keeps_replicas_identical():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     a, b = out[0], out[1]
-    assert a["dp"] and a["fused"] and a["graphs"] and a["n_graphs"] == 3
+    assert a["dp"] and a["fused"] and a["graphs"] and a["n_graphs"] == 3 and a["n_sets"] == 4      # 3 graphs per mini-batch slot
     assert torch.isfinite(a["w"]).all()
     assert torch.equal(a["w"], b["w"])
     assert a["lr"] == b["lr"]

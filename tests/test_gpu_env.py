@@ -144,7 +144,7 @@ def test_graph_replay_update_equals_eager_update():
             alg.compute_returns(hist, priv)
             torch.manual_seed(100 + it)
             losses = alg.update()
-        assert (alg._graphs is not None) == use_graphs
+        assert bool(alg._graphs) == use_graphs
         results.append((alg.master.clone(), losses, alg.learning_rate))
     PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs, PPO_Args.use_fused_kernels = False, True, True
     (w0, l0, lr0), (w1, l1, lr1) = results

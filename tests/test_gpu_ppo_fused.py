@@ -412,7 +412,7 @@ def test_fused_update_tracks_autograd_update(use_graphs):
                                                                           "returns", "observation_histories", "privileged_observations")}
             torch.manual_seed(100 + it)
             losses = alg.update()
-        assert (alg._graphs is not None) == use_graphs
+        assert bool(alg._graphs) == use_graphs
         res.append((alg.master.clone(), losses, alg.learning_rate))
     PPO_Args.autocast_bf16, PPO_Args.use_fused_kernels, PPO_Args.use_hip_graphs = False, True, True
     (w0, l0, lr0), (w1, l1, lr1) = res

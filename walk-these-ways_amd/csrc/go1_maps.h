@@ -434,7 +434,10 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
       V3 w = quat_rotate(0.f, 0.f, yz, yw, v3(cfg.height_points_x[p / cfg.num_height_y], cfg.height_points_y[p % cfg.num_height_y], 0.f));
       float hgt = 0.f;
       if (cfg.terrain_type != 0 && B.height_samples) {
-        long px = (long)((w.x + bx + cfg.hf_border) / cfg.hf_hscale), py = (long)((w.y + by + cfg.hf_border) / cfg.hf_hscale);
+        // the sample index is the reference's fp32 quotient truncated (legged_robot.py:1795-1797): the library is built
+        // with approximate fp32 division, so form the correctly rounded quotient through fp64 (exact: 53 >= 2*24+2 bits)
+        long px = (long)(float)((double)(w.x + bx + cfg.hf_border) / (double)cfg.hf_hscale);
+        long py = (long)(float)((double)(w.y + by + cfg.hf_border) / (double)cfg.hf_hscale);
         px = px < 0 ? 0 : (px > cfg.hf_rows - 2 ? cfg.hf_rows - 2 : px);
         py = py < 0 ? 0 : (py > cfg.hf_cols - 2 ? cfg.hf_cols - 2 : py);
         const int16_t* q = B.height_samples + px * cfg.hf_cols + py;

@@ -120,7 +120,8 @@ class PPO:
         self.std = torch.zeros(self.n_std, device=device).requires_grad_()
         kw = dict(fused=True, capturable=True) if self.on_gpu else {}
         self._acc = torch.zeros(4, device=device)        # value, surrogate, adaptation, adaptation-test losses
-        self._idx, self._graphs, self._updates_done = None, None, 0
+        self._idx_all, self._graphs, self._updates_done = None, {}, 0
+        self._pregathered, self._Xall = False, None
         lr = torch.tensor(PPO_Args.learning_rate, device=device) if self.on_gpu else PPO_Args.learning_rate
         self.optimizer = optim.Adam([self.master], lr=lr, **kw)
         # the reference builds this optimiser over all parameters (ppo.py:45-46) but only the adaptation module ever
@@ -331,7 +332,8 @@ class PPO:
     def _stage_ppo_backward_fused(self, idx):
         net, n = self._train_net, self.n_body
         with torch.no_grad():
-            torch.index_select(self.storage.observation_histories.flatten(0, 1), 0, idx, out=net.X)
+            if not self._pregathered:         # graph mode gathers all mini-batches' rows once per update() instead
+                torch.index_select(self.storage.observation_histories.flatten(0, 1), 0, idx, out=net.X)
             self.master.grad.zero_()          # also clears the KL slot
             net.forward(net.X)
             net.ppo_loss(self.storage, idx, self.std, self.master.grad[n:n + self.n_std], PPO_Args, self._kl, self._acc)
@@ -441,11 +443,11 @@ class PPO:
                 self._allreduce_adapt_grads()
             self._stage_adapt_step()
 
-    def _capture(self):
+    def _capture(self, i):
         """Record the mini-batch stages as HIP graphs (launch-bound: ~350 small kernels per mini-batch).
         Single GPU: one graph for the whole mini-batch.  Data parallel: three graphs with the RCCL all-reduces
         issued eagerly between them."""
-        idx = self._idx
+        idx = self._idx_all[i]
         single = not self.dp and PPO_Args.num_adaptation_module_substeps == 1
         pool = None
         graphs = []
@@ -467,8 +469,8 @@ class PPO:
             rec(self._stage_adapt_step)
         return graphs
 
-    def _minibatch_replay(self):
-        g = self._graphs
+    def _minibatch_replay(self, i):
+        g = self._graphs[i]
         if len(g) == 1:
             g[0].replay()
             return
@@ -483,32 +485,45 @@ class PPO:
         st = self.storage
         batch_size = st.num_envs * st.num_transitions_per_env
         mb = batch_size // A.num_mini_batches
-        if self._idx is None or self._idx.numel() != mb:
-            self._idx = torch.zeros(mb, dtype=torch.long, device=self.device)
-            self._graphs = None
+        nmb = A.num_mini_batches
+        if self._idx_all is None or tuple(self._idx_all.shape) != (nmb, mb):
+            self._idx_all = torch.zeros(nmb, mb, dtype=torch.long, device=self.device)
+            self._graphs = {}
             if self.fused:
                 from go1_gym_learn.ppo_cse.fused import FusedNet
                 self._train_net = FusedNet(self.policy, self.body, self.master.grad[:self.n_body], mb, self._fused_lib, with_grad=True)
+                # one row block per mini-batch: the same nmb index sets are visited in every epoch, so in graph mode
+                # their history rows are gathered once per update() (nmb gathers instead of epochs x nmb)
+                self._Xall = torch.zeros(nmb, mb, self.policy.Kp, device=self.device, dtype=self.body.dtype)
         self._acc.zero_()
-        indices = torch.randperm(A.num_mini_batches * mb, requires_grad=False, device=self.device)   # rollout_storage.py:103
+        indices = torch.randperm(nmb * mb, requires_grad=False, device=self.device)   # rollout_storage.py:103
+        self._idx_all.copy_(indices.view(nmb, mb))
         use_graphs = (self.on_gpu and A.use_hip_graphs and A.num_adaptation_module_substeps == 1)
+        graph_mode = use_graphs and self._updates_done >= 1
+        self._pregathered = bool(graph_mode and self.fused)
+        if self._pregathered:
+            hist = self.storage.observation_histories.flatten(0, 1)
+            for i in range(nmb):
+                torch.index_select(hist, 0, self._idx_all[i], out=self._Xall[i])
         for epoch in range(A.num_learning_epochs):
-            for i in range(A.num_mini_batches):
-                self._idx.copy_(indices[i * mb:(i + 1) * mb])
-                if use_graphs and self._updates_done >= 1:
-                    if self._graphs is None:
+            for i in range(nmb):
+                idx = self._idx_all[i]
+                if self.fused:
+                    self._train_net.X = self._Xall[i]
+                if graph_mode:
+                    if i not in self._graphs:
                         try:
-                            self._graphs = self._capture()
+                            self._graphs[i] = self._capture(i)
                         except Exception as err:      # capture is an optimisation: fall back to eager launches
                             print(f"[ppo] HIP graph capture failed ({type(err).__name__}: {err}); running eagerly")
                             PPO_Args.use_hip_graphs = False
-                            use_graphs = False
+                            graph_mode = self._pregathered = False
                             torch.cuda.synchronize()
-                            self._minibatch_eager(self._idx)
+                            self._minibatch_eager(idx)
                             continue
-                    self._minibatch_replay()
+                    self._minibatch_replay(i)
                 else:
-                    self._minibatch_eager(self._idx)
+                    self._minibatch_eager(idx)
         self._updates_done += 1
         num_updates = A.num_learning_epochs * A.num_mini_batches
         v, s, a, at = (self._acc / num_updates).tolist()         # the only host read of the update
