@@ -196,6 +196,16 @@ DEV float u32_to_unit(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f
 DEV float dpp_xor1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false)); }   // quad_perm [1,0,3,2]
 DEV float dpp_xor2(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, false)); }   // quad_perm [2,3,0,1]
 DEV float quad_sum(float x) { x += dpp_xor1(x); x += dpp_xor2(x); return x; }
+// value of lane `src` of the quad in all four lanes (quad_perm [s,s,s,s]); `src` folds to a constant after unrolling
+DEV float quad_bcast(float x, int src) {
+  const int v = __float_as_int(x);
+  switch (src & 3) {
+    case 0: return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x00, 0xF, 0xF, false));
+    case 1: return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x55, 0xF, 0xF, false));
+    case 2: return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0xAA, 0xF, 0xF, false));
+    default: return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0xFF, 0xF, 0xF, false));
+  }
+}
 DEV SV quad_sum(SV s) {
   return sv(v3(quad_sum(s.a.x), quad_sum(s.a.y), quad_sum(s.a.z)), v3(quad_sum(s.l.x), quad_sum(s.l.y), quad_sum(s.l.z)));
 }

@@ -32,8 +32,12 @@ enum {
   L_VSTAR = 87,         // MAXC
   L_BV = 93,            // MAXC x 3  b = J v_free
   L_LS = 111,           // MAXC x 3  slot impulses (n, t1, t2)
-  L_W = 129,            // NR x NR Delassus matrix
-  L_END = 129 + NR * NR + 2 // +2: the PGS column split reads W[r][18..19] (times a zero impulse) on its fifth pass
+  L_G = 129,            // NR x 6  contact columns: the unit impulse propagated to the base, g_c
+  L_U3 = L_G + NR * 6,  // NR x 3  joint-space residuals u_j(c) along the contact's own leg (0 beyond its depth)
+  L_UD = L_U3 + NR * 3, // NR x 3  u_j(c) / D_j
+  L_LEG = L_UD + NR * 3,// NR      leg of the contact (4 = trunk)
+  L_W = 129,            // zero-filled at kernel start from here to L_END (unused columns must read finite)
+  L_END = L_LEG + NR
 };
 #define LDS(f) lds[(f) * EPW + el]
 
@@ -526,96 +530,100 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
 
   __syncthreads();      // one-wave workgroup: orders this wave's LDS traffic between phases
   PROF(3);
-  // ---- Delassus matrix by impulse propagation through the ABA factors ---------------------------------
-#ifdef GO1_ABLATE_DELASSUS
-  for (int c = leg; c < NR * NR; c += 4) LDS(L_W + c) = (c / NR == c % NR) ? 1.f : 0.f;
-#else
-#pragma unroll 1
-  for (int k = 0; k < K; k++) {
-    const V3 x = v3(LDS(L_CX + 3 * k), LDS(L_CX + 3 * k + 1), LDS(L_CX + 3 * k + 2));
-    // is slot k one of mine?  (at most one of the four can match)
-    int mydepth = -1;
+  // ---- Delassus matrix W = J M^-1 J^T from the ABA factors, without forming M^-1 J^T ------------------------
+  // For a unit impulse in contact column c (contact k, direction r) the backward ABA pass along the contact's leg
+  // leaves g_c, the wrench arriving at the base, and the joint residuals u_j(c).  By reciprocity the same vectors
+  // are the row functionals, so
+  //     W[r][c] = g_r . (I0^-1 g_c)  +  [same leg] sum_j u_j(r) u_j(c) / D_j
+  // (legs couple only through the base).  Each lane propagates ITS contacts (3 directions each) and publishes
+  // g, u, u/D; then lane `leg` builds the columns c = leg, leg+4, ... it owns in the PGS sweep — straight into
+  // registers, where the whole sweep runs without touching LDS.
 #pragma unroll
-    for (int i = 0; i < 4; i++) if (slot[i] == k) mydepth = i > 2 ? 2 : i;
-    const bool mine = mydepth >= 0;
-    const bool base_col = (sbase == k);
-    V3 nk = v3(LDS(L_CN + 3 * k), LDS(L_CN + 3 * k + 1), LDS(L_CN + 3 * k + 2)), t1k, t2k;
-    contact_frame(nk, t1k, t2k);
-#ifdef GO1_UNROLL_R
+  for (int i = 0; i < 4; i++) {
+    if (slot[i] >= 0) {
+      const int k = slot[i];
+      const int depth = i > 2 ? 2 : i;
+      const V3 x = v3(cand[i].x, cand[i].y, cand[i].z);
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
-    for (int r = 0; r < 3; r++) {
-      V3 d = r == 0 ? nk : r == 1 ? t1k : t2k;
-      SV f = sv(cross(x, d), d);
-      float pu[3] = {0.f, 0.f, 0.f};
-      SV contrib = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
-      if (mine) {
-        SV pA = -f;
+      for (int r = 0; r < 3; r++) {
+        const V3 d = r == 0 ? fn[i] : r == 1 ? ft1[i] : ft2[i];
+        SV pA = -sv(cross(x, d), d);
+        float uj[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 2; j >= 0; j--) {
-          if (j <= mydepth) {
-            float u = -dot(S[j], pA);
-            pu[j] = u;
+          if (j <= depth) {
+            const float u = -dot(S[j], pA);
+            uj[j] = u;
             pA = pA + (u * Dinv[j]) * U[j];
           }
         }
-        contrib = pA;
-      } else if (base_col && leg == 0) {
-        contrib = -f;
-      }
-      SV p0 = quad_sum(contrib);
-      SV a0c = -sym6_mul(I0inv, p0);
-      // response of the own leg: ONE recursion hip -> thigh -> calf, the acceleration of each body captured on the way
-      SV ab[3];
-      {
-        SV a = a0c;
+        const int c = 3 * k + r;
+        LDS(L_G + 6 * c) = pA.a.x; LDS(L_G + 6 * c + 1) = pA.a.y; LDS(L_G + 6 * c + 2) = pA.a.z;
+        LDS(L_G + 6 * c + 3) = pA.l.x; LDS(L_G + 6 * c + 4) = pA.l.y; LDS(L_G + 6 * c + 5) = pA.l.z;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const float uj = (mine && j <= mydepth) ? pu[j] : 0.f;
-          const float qdd = Dinv[j] * (uj - dot(U[j], a));
-          a = a + qdd * S[j];
-          ab[j] = a;
-        }
-      }
-      // rows of W for my own contacts (and lane 0: the trunk contact)
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        if (slot[i] >= 0) {
-          const int k2 = slot[i];
-          const SV& abi = ab[i > 2 ? 2 : i];
-          V3 x2 = v3(cand[i].x, cand[i].y, cand[i].z);
-          V3 vp = abi.l + cross(abi.a, x2);
-          LDS(L_W + (3 * k2 + 0) * NR + 3 * k + r) = dot(fn[i], vp);
-          LDS(L_W + (3 * k2 + 1) * NR + 3 * k + r) = dot(ft1[i], vp);
-          LDS(L_W + (3 * k2 + 2) * NR + 3 * k + r) = dot(ft2[i], vp);
-        }
-      }
-      if (sbase >= 0 && leg == 0) {
-        V3 x2 = v3(cbase.x, cbase.y, cbase.z);
-        V3 vp = a0c.l + cross(a0c.a, x2);
-        LDS(L_W + (3 * sbase + 0) * NR + 3 * k + r) = dot(bn, vp);
-        LDS(L_W + (3 * sbase + 1) * NR + 3 * k + r) = dot(bt1, vp);
-        LDS(L_W + (3 * sbase + 2) * NR + 3 * k + r) = dot(bt2, vp);
+        for (int j = 0; j < 3; j++) { LDS(L_U3 + 3 * c + j) = uj[j]; LDS(L_UD + 3 * c + j) = uj[j] * Dinv[j]; }
+        LDS(L_LEG + c) = (float)leg;
       }
     }
   }
-#endif
-
+  if (sbase >= 0 && leg == 0) {
+    const V3 x = v3(cbase.x, cbase.y, cbase.z);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const V3 d = r == 0 ? bn : r == 1 ? bt1 : bt2;
+      const SV g = -sv(cross(x, d), d);
+      const int c = 3 * sbase + r;
+      LDS(L_G + 6 * c) = g.a.x; LDS(L_G + 6 * c + 1) = g.a.y; LDS(L_G + 6 * c + 2) = g.a.z;
+      LDS(L_G + 6 * c + 3) = g.l.x; LDS(L_G + 6 * c + 4) = g.l.y; LDS(L_G + 6 * c + 5) = g.l.z;
+#pragma unroll
+      for (int j = 0; j < 3; j++) { LDS(L_U3 + 3 * c + j) = 0.f; LDS(L_UD + 3 * c + j) = 0.f; }
+      LDS(L_LEG + c) = 4.f;
+    }
+  }
   __syncthreads();
   PROF(4);
+  int Kw = 0;                                                  // wave-uniform max K: scalar branches below
+#pragma unroll
+  for (int kk = 1; kk <= MAXC; kk++) Kw = (__ballot(K >= kk) != 0ull) ? kk : Kw;
+  float Wc[NR][5];                                             // Wc[r][cc] = W[r][leg + 4 cc]
+  {
+    SV Y[5];
+    float ud[5][3], lg[5];
+#pragma unroll
+    for (int cc = 0; cc < 5; cc++) {
+      int c = leg + 4 * cc;
+      c = c < NR ? c : NR - 1;        // lanes 2, 3 have no fifth column: any finite stand-in (its impulse stays 0)
+      const SV g = sv(v3(LDS(L_G + 6 * c), LDS(L_G + 6 * c + 1), LDS(L_G + 6 * c + 2)),
+                      v3(LDS(L_G + 6 * c + 3), LDS(L_G + 6 * c + 4), LDS(L_G + 6 * c + 5)));
+      Y[cc] = sym6_mul(I0inv, g);
+#pragma unroll
+      for (int j = 0; j < 3; j++) ud[cc][j] = LDS(L_UD + 3 * c + j);
+      lg[cc] = LDS(L_LEG + c);
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      if (r < 3 * Kw) {
+        const SV g = sv(v3(LDS(L_G + 6 * r), LDS(L_G + 6 * r + 1), LDS(L_G + 6 * r + 2)),
+                        v3(LDS(L_G + 6 * r + 3), LDS(L_G + 6 * r + 4), LDS(L_G + 6 * r + 5)));
+        const float u0 = LDS(L_U3 + 3 * r), u1 = LDS(L_U3 + 3 * r + 1), u2 = LDS(L_U3 + 3 * r + 2), lr = LDS(L_LEG + r);
+#pragma unroll
+        for (int cc = 0; cc < 5; cc++) {
+          const float same = fmaf(u0, ud[cc][0], fmaf(u1, ud[cc][1], u2 * ud[cc][2]));
+          Wc[r][cc] = dot(g, Y[cc]) + (lr == lg[cc] ? same : 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < 5; cc++) Wc[r][cc] = 0.f;
+      }
+    }
+  }
   // ---- projected Gauss-Seidel on the impulses -------------------------------------------------------------
-  // Row dot-products are split over the quad (lane `leg` owns columns c = leg, leg+4, ...).  Everything the sweep
-  // needs except the 15 W entries of the current contact row block lives in registers: the impulse vector
-  // (replicated + each lane's own columns), and per contact b, v*, 1/diag and the two normal->tangent couplings.
-  // The W entries come from LDS as one batch of independent reads per contact (constant offsets from one address).
+  // Row dot-products are split over the quad (lane `leg` owns columns c = leg, leg+4, ...); W, the impulse vector
+  // (replicated + each lane's own columns) and per contact b, v*, 1/diag and the two normal->tangent couplings
+  // (quad-broadcast from the lane that owns the column) all live in registers: no memory traffic in the sweep.
   const float mu = 0.5f * (s.mu + cfg.terrain_friction);       // PhysX default combine mode: average
 #ifndef GO1_ABLATE_PGS
   {
-    int Kw = 0;                                                // wave-uniform max K: scalar branches below
-#pragma unroll
-    for (int kk = 1; kk <= MAXC; kk++) Kw = (__ballot(K >= kk) != 0ull) ? kk : Kw;
     float lam[NR], lamloc[5];
     float bvn[MAXC], bv1[MAXC], bv2[MAXC], vst[MAXC], idn[MAXC], id1[MAXC], id2[MAXC], w10[MAXC], w20[MAXC];
 #pragma unroll
@@ -625,38 +633,34 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
       lam[r0] = on ? LDS(L_LS + r0) : 0.f; lam[r0 + 1] = on ? LDS(L_LS + r0 + 1) : 0.f; lam[r0 + 2] = on ? LDS(L_LS + r0 + 2) : 0.f;
       bvn[k] = on ? LDS(L_BV + r0) : 0.f; bv1[k] = on ? LDS(L_BV + r0 + 1) : 0.f; bv2[k] = on ? LDS(L_BV + r0 + 2) : 0.f;
       vst[k] = on ? LDS(L_VSTAR + k) : 0.f;
-      idn[k] = on ? 1.f / LDS(L_W + r0 * NR + r0) : 0.f;
-      id1[k] = on ? 1.f / LDS(L_W + (r0 + 1) * NR + r0 + 1) : 0.f;
-      id2[k] = on ? 1.f / LDS(L_W + (r0 + 2) * NR + r0 + 2) : 0.f;
-      w10[k] = on ? LDS(L_W + (r0 + 1) * NR + r0) : 0.f;
-      w20[k] = on ? LDS(L_W + (r0 + 2) * NR + r0) : 0.f;
+      // W[r][c] sits in lane c & 3 at slot c >> 2
+      const float dn = quad_bcast(Wc[r0][(r0) >> 2], r0);
+      const float d1 = quad_bcast(Wc[r0 + 1][(r0 + 1) >> 2], r0 + 1);
+      const float d2 = quad_bcast(Wc[r0 + 2][(r0 + 2) >> 2], r0 + 2);
+      idn[k] = on ? 1.f / dn : 0.f;
+      id1[k] = on ? 1.f / d1 : 0.f;
+      id2[k] = on ? 1.f / d2 : 0.f;
+      w10[k] = on ? quad_bcast(Wc[r0 + 1][(r0) >> 2], r0) : 0.f;
+      w20[k] = on ? quad_bcast(Wc[r0 + 2][(r0) >> 2], r0) : 0.f;
     }
 #pragma unroll
     for (int cc = 0; cc < 5; cc++) lamloc[cc] = (leg + 4 * cc < 3 * K) ? LDS(L_LS + leg + 4 * cc) : 0.f;
-    // Columns >= 3K are never written by the Delassus phase: their impulses are exactly zero and the LDS words
-    // behind them are finite (zero-filled at kernel start, later only ever hold old W entries), so the products
-    // vanish without masking.
-    const float* wcol = lds + (L_W + leg) * EPW + el;          // W[r][leg + 4 cc] = wcol[(r * NR + 4 cc) * EPW]
+    // Columns >= 3K were not published this substep: their impulses are exactly zero and what the column build read
+    // for them is finite (the region is zero-filled at kernel start and only ever holds old columns), so their
+    // products vanish without masking.
 #pragma unroll 1
     for (int it = 0; it < cfg.solver_iterations; it++) {
 #pragma unroll
       for (int k = 0; k < MAXC; k++) {
         if (k < Kw) {
           const int r0 = 3 * k;
-          float wn[5], w1[5], w2[5];
-#pragma unroll
-          for (int cc = 0; cc < 5; cc++) {
-            wn[cc] = wcol[(r0 * NR + 4 * cc) * EPW];
-            w1[cc] = wcol[((r0 + 1) * NR + 4 * cc) * EPW];
-            w2[cc] = wcol[((r0 + 2) * NR + 4 * cc) * EPW];
-          }
           float pn = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
           for (int cc = 0; cc < 5; cc++) {                     // same partition and order as the serial-in-c sum
             const float l = lamloc[cc];
-            pn = fmaf(wn[cc], l, pn);
-            p1 = fmaf(w1[cc], l, p1);
-            p2 = fmaf(w2[cc], l, p2);
+            pn = fmaf(Wc[r0][cc], l, pn);
+            p1 = fmaf(Wc[r0 + 1][cc], l, p1);
+            p2 = fmaf(Wc[r0 + 2][cc], l, p2);
           }
           const float un = bvn[k] + quad_sum(pn);
           float u1 = bv1[k] + quad_sum(p1);
