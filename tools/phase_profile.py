@@ -18,7 +18,7 @@ PHASES = ["load state/actions/warm start", "torque model (x4)", "kinematics + ca
           "ABA 3 + contact list + publish (x4)", "Delassus (x4)", "PGS (x4)", "apply + integrate (x4)",
           "store state/feet/forces", "post: derived + callbacks", "post: gait clock + push/dof-rand",
           "post: feet/heights/termination", "post: rewards", "post: reset", "post: observations", "post: privileged obs",
-          "post: roll"]
+          "post: roll", "post: reward-input loads", "post: termination"]
 
 
 def build(flags):
@@ -54,7 +54,7 @@ def main():
             env.step(acts[t])
         torch.cuda.synchronize()
         assert lib.go1sim_debug_read_profile(buf) == 0
-        tot = sum(buf[:16])
+        tot = sum(buf[:len(PHASES)])
         print(f"cycles per step (wave 0 lane 0, s_memtime ticks): {tot / args.steps:.0f}")
         for i, name in enumerate(PHASES):
             print(f"  {i:2d} {name:42s} {buf[i] / args.steps:10.0f}  {100.0 * buf[i] / tot:5.1f} %")

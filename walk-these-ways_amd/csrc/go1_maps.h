@@ -4,12 +4,21 @@
 #include "go1_math.h"
 #include "../../include/go1sim.h"
 
+// The configuration, the buffer table and the derived tables live in ONE device struct that no kernel ever writes.
+// It is addressed through the constant address space: loads from it are invariant for the compiler — scalar
+// (s_load), batched and hoisted across the kernels' stores and atomics.  Through a generic pointer every store would
+// force the next configuration field or buffer pointer to be re-fetched from memory (one exposed round trip each,
+// with a single wave per SIMD).
+#define GO1_CONSTANT __attribute__((address_space(4)))
+typedef const GO1_CONSTANT Go1SimConfig& CfgRef;
+typedef const GO1_CONSTANT Go1SimBuffers& BufRef;
+
 #define PI_F 3.14159265358979323846f
 enum { P_NOISE = 1, P_RESET = 2, P_DOFPROPS_CB = 3, P_DOFPROPS_RESET = 4, P_CMD_CB = 5, P_CMD_RESET = 6, P_PUSH = 7, P_GRAVITY = 8 };
 
 #define AT(ptr, c, e) ((ptr)[(size_t)(c) * N + (e)])
 
-__device__ __noinline__ float rng_uniform(const Go1SimConfig& cfg, uint32_t env_global, int64_t step, uint32_t purpose, uint32_t idx) {
+__device__ __noinline__ float rng_uniform(CfgRef cfg, uint32_t env_global, int64_t step, uint32_t purpose, uint32_t idx) {
   uint32_t out[4];
   philox4x32_10(env_global, (uint32_t)step, purpose, idx >> 2, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), out);
   uint32_t sel = idx & 3;
@@ -17,7 +26,7 @@ __device__ __noinline__ float rng_uniform(const Go1SimConfig& cfg, uint32_t env_
   return u32_to_unit(v);
 }
 
-DEV V3 gravity_at(const Go1SimConfig& cfg, int64_t t) {
+DEV V3 gravity_at(CfgRef cfg, int64_t t) {
   V3 g = v3(cfg.gravity[0], cfg.gravity[1], cfg.gravity[2]);
   if (!cfg.randomize_gravity) return g;
   int64_t epoch = t / cfg.gravity_rand_interval, ph = t % cfg.gravity_rand_interval;
@@ -34,7 +43,7 @@ DEV V3 gravity_at(const Go1SimConfig& cfg, int64_t t) {
 // ================================================================================================
 DEV float fmod1(float x) { float r = fmodf(x, 1.0f); return r < 0.f ? r + 1.0f : r; }
 
-DEV void resample_commands(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int64_t step, uint32_t purpose) {
+DEV void resample_commands(CfgRef cfg, BufRef B, int e, int N, int64_t step, uint32_t purpose) {
   if (cfg.device_curriculum) {
     const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
     const int ep_len = cfg.max_episode_length < cfg.resample_interval ? cfg.max_episode_length : cfg.resample_interval;
@@ -94,7 +103,7 @@ DEV void resample_commands(const Go1SimConfig& cfg, const Go1SimBuffers& B, int 
   for (int kx = 0; kx < cfg.num_rewards + 5; kx++) AT(B.command_sums, kx, e) = 0.f;
 }
 
-DEV void randomize_dof_props(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int64_t step, uint32_t purpose) {
+DEV void randomize_dof_props(CfgRef cfg, BufRef B, int e, int N, int64_t step, uint32_t purpose) {
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
   if (cfg.randomize_motor_strength) {
     float v = rng_uniform(cfg, eg, step, purpose, 0) * (cfg.motor_strength_range[1] - cfg.motor_strength_range[0]) + cfg.motor_strength_range[0];
@@ -118,7 +127,7 @@ DEV void randomize_dof_props(const Go1SimConfig& cfg, const Go1SimBuffers& B, in
   }
 }
 
-DEV void reset_env(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int64_t step) {
+DEV void reset_env(CfgRef cfg, BufRef B, int e, int N, int64_t step) {
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
   resample_commands(cfg, B, e, N, step, P_CMD_RESET);
   randomize_dof_props(cfg, B, e, N, step, P_DOFPROPS_RESET);
@@ -176,7 +185,7 @@ struct FootCtx {            // the calling lane's foot
   float foot_index, desired_contact;
 };
 
-DEV float cf_norm(const Go1SimBuffers& B, int b, int e, int N) {
+DEV float cf_norm(BufRef B, int b, int e, int N) {
   float x = AT(B.contact_forces, 3 * b, e), y = AT(B.contact_forces, 3 * b + 1, e), z = AT(B.contact_forces, 3 * b + 2, e);
   return sqrtf(x * x + y * y + z * z);
 }
@@ -191,7 +200,7 @@ struct RewardIn {
   float pfvz;
   bool last_contact;
 };
-DEV void load_reward_inputs(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int leg, RewardIn& in) {
+DEV void load_reward_inputs(CfgRef cfg, BufRef B, int e, int N, int leg, RewardIn& in) {
 #pragma unroll
   for (int k = 0; k < 14; k++) in.cmd[k] = k < cfg.num_commands ? AT(B.commands, k, e) : 0.f;
 #pragma unroll
@@ -209,7 +218,7 @@ DEV void load_reward_inputs(const Go1SimConfig& cfg, const Go1SimBuffers& B, int
   in.last_contact = AT(B.last_contacts, leg, e) != 0;
 }
 
-DEV float reward_partial(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e, int N, int id, const Derived& d,
+DEV float reward_partial(CfgRef cfg, BufRef B, int e, int N, int id, const Derived& d,
                          const FootCtx& F, int leg, const RewardIn& in) {
   const bool is0 = leg == 0;
   const int j0 = 3 * leg;
@@ -332,6 +341,14 @@ DEV float reward_partial(const Go1SimConfig& cfg, const Go1SimBuffers& B, int e,
     default: return 0.f;
   }
 }
+#define GO1_REW_COUNT 24            // ids 0 .. GO1_REW_RAIBERT_HEURISTIC
+// The configuration lists its terms as (id, scale) pairs in dict order; the kernel walks the ids in a fully unrolled
+// loop instead (every term's code appears once, no jump table, the per-term scalars are fetched in one batch).
+struct RewardPlan {
+  int32_t kx_by_id[GO1_REW_COUNT];  // position in the configuration's list (= row of episode_sums / command_sums), -1: inactive
+  float scale_by_id[GO1_REW_COUNT];
+};
+typedef const GO1_CONSTANT RewardPlan& PlanRef;
 DEV int reward_raw_sign(int id) {
   return (id == GO1_REW_JUMP || id == GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE || id == GO1_REW_TRACKING_CONTACTS_SHAPED_VEL) ? -1 : 1;
 }
@@ -344,7 +361,8 @@ DEV int reward_raw_sign(int id) {
 // ================================================================================================
 #define QUAD_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)
 
-DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane, int e, int N, int64_t counter_post, V3 grav, int history_slot PROF_PARAM) {
+DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, int lane, int e, int N, int64_t counter_post, V3 grav,
+                      int history_slot PROF_PARAM) {
   const int leg = lane & 3;
   const bool is0 = leg == 0;
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
@@ -451,8 +469,10 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
     mean_height = quad_sum(sum) / np;
   }
   // ---- check_termination ---------------------------------------------------------------------------
+  PROF(10);
   RewardIn rin;
   load_reward_inputs(cfg, B, e, N, leg, rin);
+  PROF(16);
   float term = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -466,21 +486,23 @@ DEV void post_physics(const Go1SimConfig& cfg, const Go1SimBuffers& B, int lane,
   if (cfg.use_terminal_body_height && root_z - mean_height < cfg.terminal_body_height) reset = true;
   if (is0) { B.time_out_buf[e] = (uint8_t)time_out; B.reset_buf[e] = (uint8_t)reset; }
 
-  PROF(10);
+  PROF(17);
   // ---- compute_reward ----------------------------------------------------------------------------------
   float rew = 0.f, pos = 0.f, neg = 0.f;
-#pragma unroll 1
-  for (int kx = 0; kx < cfg.num_rewards; kx++) {
-    const int id = cfg.reward_ids[kx];
-    const float sc = cfg.reward_scales[kx];
-    const float r = quad_sum(reward_partial(cfg, B, e, N, id, d, F, leg, rin)) * sc;
-    rew += r;
-    if (reward_raw_sign(id) * sc >= 0) pos += r; else neg += r;
-    if ((kx & 3) == leg) {      // running sums: fire-and-forget fp32 atomics (one writer per address, so the result is
-                                // the plain += of the reference; no load to wait for)
-      unsafeAtomicAdd(&AT(B.episode_sums, kx, e), r);
-      const bool shaped = id == GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE || id == GO1_REW_TRACKING_CONTACTS_SHAPED_VEL;
-      unsafeAtomicAdd(&AT(B.command_sums, kx, e), shaped ? sc + r : r);
+#pragma unroll
+  for (int id = 0; id < GO1_REW_COUNT; id++) {
+    const int kx = plan.kx_by_id[id];
+    if (kx >= 0) {                  // wave-uniform
+      const float sc = plan.scale_by_id[id];
+      const float r = quad_sum(reward_partial(cfg, B, e, N, id, d, F, leg, rin)) * sc;
+      rew += r;
+      if (reward_raw_sign(id) * sc >= 0) pos += r; else neg += r;
+      if ((kx & 3) == leg) {      // running sums: fire-and-forget fp32 atomics (one writer per address, so the result is
+                                  // the plain += of the reference; no load to wait for)
+        unsafeAtomicAdd(&AT(B.episode_sums, kx, e), r);
+        const bool shaped = id == GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE || id == GO1_REW_TRACKING_CONTACTS_SHAPED_VEL;
+        unsafeAtomicAdd(&AT(B.command_sums, kx, e), shaped ? sc + r : r);
+      }
     }
   }
   if (cfg.only_positive_rewards) rew = fmaxf(rew, 0.f);

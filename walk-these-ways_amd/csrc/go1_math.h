@@ -7,12 +7,12 @@
 // accumulates s_memtime deltas per phase into g_prof[]; everything compiles away otherwise ------------------
 #ifdef GO1_PROFILE
 __device__ unsigned long long g_prof[64];
-__shared__ unsigned long long s_prof[16];          // accumulated with fire-and-forget LDS adds: no memory stall per marker
+__shared__ unsigned long long s_prof[24];          // accumulated with fire-and-forget LDS adds: no memory stall per marker
 #define PROF_PARAM , unsigned long long& prof_t
 #define PROF_PASS , prof_t
-#define PROF_DECL if (threadIdx.x < 16) s_prof[threadIdx.x] = 0; __syncthreads(); unsigned long long prof_t = __builtin_readcyclecounter();
+#define PROF_DECL if (threadIdx.x < 24) s_prof[threadIdx.x] = 0; __syncthreads(); unsigned long long prof_t = __builtin_readcyclecounter();
 #define PROF(i) do { unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&s_prof[i], now_ - prof_t); prof_t = now_; } while (0)
-#define PROF_FLUSH do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x < 16) g_prof[threadIdx.x] += s_prof[threadIdx.x]; } while (0)
+#define PROF_FLUSH do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x < 24) g_prof[threadIdx.x] += s_prof[threadIdx.x]; } while (0)
 #else
 #define PROF_PARAM
 #define PROF_PASS

@@ -176,7 +176,7 @@ struct Leg {             // the calling lane's leg
   float q[3], qd[3], tau[3];
 };
 
-DEV void compute_torques(const Go1SimConfig& cfg, const Go1SimBuffers& B, Leg& L, int leg, int e, int N, int head, float* act_lds, bool full_wave) {
+DEV void compute_torques(CfgRef cfg, BufRef B, Leg& L, int leg, int e, int N, int head, float* act_lds, bool full_wave) {
   const int nl = cfg.lag_timesteps + 1;
   const int h2 = (head + 1) % nl;
   float in[3][6], tq[3], tgt[3];
@@ -247,7 +247,7 @@ DEV void cand_init(Cand& c) { c.phi = 1e30f; c.x = c.y = c.z = c.un = 0.f; c.nx 
 
 // terrain height and unit normal at world (x, y): plane, or bilinear interpolation of the int16 height field
 // (same sample convention as _get_heights, reference legged_robot.py:1793-1806; oracle terrain_sample())
-DEV void terrain_sample(const Go1SimConfig& cfg, const int16_t* __restrict__ hs, float x, float y, float& h, V3& n) {
+DEV void terrain_sample(CfgRef cfg, const int16_t* __restrict__ hs, float x, float y, float& h, V3& n) {
   if (cfg.terrain_type == 0 || hs == nullptr) { h = 0.f; n = v3(0.f, 0.f, 1.f); return; }
   float fx = (x + cfg.hf_border) / cfg.hf_hscale, fy = (y + cfg.hf_border) / cfg.hf_hscale;
   fx = fminf(fmaxf(fx, 0.f), (float)cfg.hf_rows - 1.000001f);
@@ -264,7 +264,7 @@ DEV void terrain_sample(const Go1SimConfig& cfg, const int16_t* __restrict__ hs,
 }
 
 // x: candidate point relative to the base origin (world axes); bpos: world position of the base origin
-DEV void cand_try(const Go1SimConfig& cfg, const int16_t* __restrict__ hs, Cand& c, V3 x, V3 bpos, float radius, SV vb) {
+DEV void cand_try(CfgRef cfg, const int16_t* __restrict__ hs, Cand& c, V3 x, V3 bpos, float radius, SV vb) {
   float h;
   V3 n;
   terrain_sample(cfg, hs, bpos.x + x.x, bpos.y + x.y, h, n);
@@ -311,7 +311,7 @@ DEV SV leg_response(const SV S[3], const SV U[3], const float Dinv[3], SV a0, in
   return a;
 }
 
-DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs, float* lds, int lane, Base& s, Leg& L, V3 grav, bool use_warm, float h PROF_PARAM) {
+DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds, int lane, Base& s, Leg& L, V3 grav, bool use_warm, float h PROF_PARAM) {
   const int leg = lane & 3, el = lane >> 2;
   const M3 R0 = quat_to_mat(s.qx, s.qy, s.qz, s.qw);
   const SV v0 = sv(s.w, s.v);
@@ -768,7 +768,7 @@ DEV void physics_substep(const Go1SimConfig& cfg, const int16_t* __restrict__ hs
 }
 
 // own foot position / velocity at the current state (reference legged_robot.py:112-115)
-DEV void foot_state(const Base& s, const Leg& L, int leg, const Go1SimBuffers& B, int e, int N) {
+DEV void foot_state(const Base& s, const Leg& L, int leg, BufRef B, int e, int N) {
   M3 Rpar = quat_to_mat(s.qx, s.qy, s.qz, s.qw);
   V3 ppar = v3(0.f, 0.f, 0.f);
   SV vb = sv(s.w, s.v);
@@ -794,7 +794,7 @@ DEV void foot_state(const Base& s, const Leg& L, int leg, const Go1SimBuffers& B
 }
 
 // ---- state <-> HBM ----------------------------------------------------------------------------------------
-DEV void load_state(const Go1SimBuffers& B, int leg, int e, int N, Base& s, Leg& L) {
+DEV void load_state(BufRef B, int leg, int e, int N, Base& s, Leg& L) {
   s.pos = v3(AT(B.root_states, 0, e), AT(B.root_states, 1, e), AT(B.root_states, 2, e));
   s.qx = AT(B.root_states, 3, e); s.qy = AT(B.root_states, 4, e); s.qz = AT(B.root_states, 5, e); s.qw = AT(B.root_states, 6, e);
   s.v = v3(AT(B.root_states, 7, e), AT(B.root_states, 8, e), AT(B.root_states, 9, e));
@@ -806,7 +806,7 @@ DEV void load_state(const Go1SimBuffers& B, int leg, int e, int N, Base& s, Leg&
   s.mu = B.friction_coeffs[e];
   s.rest = B.restitutions[e];
 }
-DEV void store_state(const Go1SimBuffers& B, int leg, int e, int N, const Base& s, const Leg& L) {
+DEV void store_state(BufRef B, int leg, int e, int N, const Base& s, const Leg& L) {
   if (leg == 0) {
     AT(B.root_states, 0, e) = s.pos.x; AT(B.root_states, 1, e) = s.pos.y; AT(B.root_states, 2, e) = s.pos.z;
     AT(B.root_states, 3, e) = s.qx; AT(B.root_states, 4, e) = s.qy; AT(B.root_states, 5, e) = s.qz; AT(B.root_states, 6, e) = s.qw;
@@ -817,7 +817,7 @@ DEV void store_state(const Go1SimBuffers& B, int leg, int e, int N, const Base& 
   for (int j = 0; j < 3; j++) { AT(B.dof_pos, 3 * leg + j, e) = L.q[j]; AT(B.dof_vel, 3 * leg + j, e) = L.qd[j]; }
 }
 // per-body impulses <-> contact force buffer; each lane moves its leg's 4 bodies, lane 0 also the trunk
-DEV void load_lambda(const Go1SimConfig& cfg, const Go1SimBuffers& B, float* lds, int lane, int e, int N, bool zero) {
+DEV void load_lambda(CfgRef cfg, BufRef B, float* lds, int lane, int e, int N, bool zero) {
   const int leg = lane & 3, el = lane >> 2;
 #pragma unroll
   for (int i = 0; i < 5; i++) {
@@ -827,7 +827,7 @@ DEV void load_lambda(const Go1SimConfig& cfg, const Go1SimBuffers& B, float* lds
     for (int c = 0; c < 3; c++) LDS(L_LAM + 3 * b + c) = zero ? 0.f : AT(B.contact_forces, 3 * b + c, e) * cfg.sim_dt;
   }
 }
-DEV void store_forces(const Go1SimConfig& cfg, const Go1SimBuffers& B, const float* lds, int lane, int e, int N) {
+DEV void store_forces(CfgRef cfg, BufRef B, const float* lds, int lane, int e, int N) {
   const int leg = lane & 3, el = lane >> 2;
   const float inv = 1.f / cfg.sim_dt;
 #pragma unroll

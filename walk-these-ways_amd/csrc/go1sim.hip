@@ -25,6 +25,7 @@
 struct SimConst {            // lives in device memory (one per handle): indexable with scalar loads
   Go1SimConfig cfg;
   Go1SimBuffers buf;
+  RewardPlan rew;            // derived at create / set_config: reward terms indexed by id (go1_maps.h)
 };
 struct StepArgs {
   const SimConst* __restrict__ sc;
@@ -45,8 +46,9 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
   __shared__ float lds[L_END * EPW];
   __shared__ __attribute__((aligned(16))) float act_lds[A_END];
   for (int i = threadIdx.x; i < (L_END - L_W) * EPW; i += WAVE) lds[L_W * EPW + i] = 0.f;   // finite everywhere: see the PGS column split
-  const Go1SimConfig& cfg = A.sc->cfg;
-  const Go1SimBuffers& B = A.sc->buf;
+  const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
+  CfgRef cfg = csc->cfg;
+  BufRef B = csc->buf;
   const int N = cfg.num_envs;
   const int lane = threadIdx.x, leg = lane & 3;
   const int e = blockIdx.x * EPW + (lane >> 2);
@@ -89,7 +91,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
   __syncthreads();
   PROF(7);
 #ifndef GO1_ABLATE_POST
-  post_physics(cfg, B, lane, e, N, A.counter + 1, grav, A.history_slot PROF_PASS);
+  post_physics(cfg, B, csc->rew, lane, e, N, A.counter + 1, grav, A.history_slot PROF_PASS);
 #endif
   PROF_FLUSH;
 }
@@ -99,8 +101,9 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   __shared__ float lds[L_END * EPW];
   __shared__ __attribute__((aligned(16))) float act_lds[A_END];
   for (int i = threadIdx.x; i < (L_END - L_W) * EPW; i += WAVE) lds[L_W * EPW + i] = 0.f;   // finite everywhere: see the PGS column split
-  const Go1SimConfig& cfg = A.sc->cfg;
-  const Go1SimBuffers& B = A.sc->buf;
+  const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
+  CfgRef cfg = csc->cfg;
+  BufRef B = csc->buf;
   const int N = cfg.num_envs;
   const int lane = threadIdx.x, leg = lane & 3;
   const int e = blockIdx.x * EPW + (lane >> 2);
@@ -109,7 +112,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   if (e >= N) return;
   if (A.mode == 4) {       // tensor maps only
     PROF_DECL
-    post_physics(cfg, B, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot PROF_PASS);
+    post_physics(cfg, B, csc->rew, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot PROF_PASS);
     return;
   }
   Base s;
@@ -135,8 +138,9 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
 
 // one environment per lane: reset_idx
 extern "C" __global__ void __launch_bounds__(WAVE) go1_env_kernel(const StepArgs A) {
-  const Go1SimConfig& cfg = A.sc->cfg;
-  const Go1SimBuffers& B = A.sc->buf;
+  const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
+  CfgRef cfg = csc->cfg;
+  BufRef B = csc->buf;
   const int N = cfg.num_envs;
   const int e = blockIdx.x * WAVE + threadIdx.x;
   if (e < A.n_ids) reset_env(cfg, B, A.ids ? A.ids[e] : e, N, A.counter);
@@ -144,8 +148,9 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_env_kernel(const StepArgs
 
 // HistoryWrapper.get_observations: append the current obs_buf to the double-length ring
 extern "C" __global__ void __launch_bounds__(256) go1_history_kernel(const SimConst* __restrict__ sc, int slot) {
-  const Go1SimConfig& cfg = sc->cfg;
-  const Go1SimBuffers& B = sc->buf;
+  const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)sc;
+  CfgRef cfg = csc->cfg;
+  BufRef B = csc->buf;
   const int no = cfg.num_obs, R = cfg.num_obs_history + 1;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)cfg.num_envs * no) return;
@@ -158,8 +163,9 @@ extern "C" __global__ void __launch_bounds__(256) go1_history_kernel(const SimCo
 
 // curriculum weight update + CDF rebuild (reference curriculum.py:135-154): one workgroup per category
 extern "C" __global__ void __launch_bounds__(256) go1_curriculum_kernel(const SimConst* __restrict__ sc) {
-  const Go1SimConfig& cfg = sc->cfg;
-  const Go1SimBuffers& B = sc->buf;
+  const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)sc;
+  CfgRef cfg = csc->cfg;
+  BufRef B = csc->buf;
   __shared__ float part[256];
   const int c = blockIdx.x, nb = cfg.num_bins, t = threadIdx.x;
   float* w = B.curriculum_weights + (size_t)c * nb;
@@ -229,6 +235,11 @@ static int check_cfg(const Go1SimConfig* cfg) {
 static int upload_const(Go1Sim* s) {
   SimConst h;
   h.cfg = s->cfg; h.buf = s->buf;
+  for (int id = 0; id < GO1_REW_COUNT; id++) { h.rew.kx_by_id[id] = -1; h.rew.scale_by_id[id] = 0.f; }
+  for (int kx = 0; kx < s->cfg.num_rewards; kx++) {
+    const int id = s->cfg.reward_ids[kx];
+    if (id >= 0 && id < GO1_REW_COUNT) { h.rew.kx_by_id[id] = kx; h.rew.scale_by_id[id] = s->cfg.reward_scales[kx]; }
+  }
   return hipMemcpy(s->dconst, &h, sizeof(SimConst), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
 }
 
