@@ -87,7 +87,7 @@ DEV void actuator_net3(const float in[3][6], float out[3]) {
 // Only used by full wavefronts (all 64 lanes alive): a partial last workgroup takes actuator_net3.
 typedef __attribute__((ext_vector_type(8))) __bf16 act_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float act_f32x4;
-enum { A_IN = 0, A_OUT = 192 * 8, A_W0 = A_OUT + 192, A_B1 = A_W0 + 32 * 8, A_W2 = A_B1 + 32, A_WF = A_W2 + 32, A_END = A_WF + 4 * 64 * 4 };
+enum { A_IN = 0, A_OUT = 192 * 8, A_W0 = A_OUT + 4 * 192, A_B1 = A_W0 + 32 * 8, A_W2 = A_B1 + 32, A_WF = A_W2 + 32, A_END = A_WF + 4 * 64 * 4 };
 
 DEV void actuator_lds_init(float* a, int lane) {          // once per launch, all 64 lanes
   for (int i = lane; i < 32 * 8; i += WAVE) {
@@ -163,13 +163,14 @@ DEV void actuator_net_mfma(float* a, int lane, const float in[3][6], float out[3
 #pragma unroll
       for (int q = 0; q < 4; q++) part = fmaf(w2v[4 * i + q], softsign(acc[q] + b1v[4 * i + q]), part);
     }
-    part += __shfl_xor(part, 16, 64);       // the 4 lanes (g = 0..3) holding the same row add up
-    part += __shfl_xor(part, 32, 64);
-    if (g == 0) a[A_OUT + 16 * t + c] = part + GO1_ACT_B2;
+    a[A_OUT + 192 * g + 16 * t + c] = part;      // the 4 lanes (g = 0..3) holding the same row: partials meet in LDS
   }
   __syncthreads();
 #pragma unroll
-  for (int jj = 0; jj < 3; jj++) out[jj] = a[A_OUT + 3 * lane + jj];
+  for (int jj = 0; jj < 3; jj++) {
+    const int r = 3 * lane + jj;
+    out[jj] = ((a[A_OUT + r] + a[A_OUT + 192 + r]) + (a[A_OUT + 384 + r] + a[A_OUT + 576 + r])) + GO1_ACT_B2;
+  }
 }
 
 struct Leg {             // the calling lane's leg
