@@ -537,6 +537,17 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, int lane, int e, int N
       obs_row[n] = v;
       if (h0) { h0[n] = v; h1[n] = v; }
     };
+    // everything the default observation and the history roll read, as ONE batch of loads (post-reset values)
+    float o_q[3], o_qd[3], o_act[3], o_lact[3], o_jpt[3], o_ljpt[3], o_cmd[4];
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      o_q[jj] = AT(B.dof_pos, j, e); o_qd[jj] = AT(B.dof_vel, j, e); o_act[jj] = AT(B.actions, j, e);
+      o_lact[jj] = AT(B.last_actions, j, e); o_jpt[jj] = AT(B.joint_pos_target, j, e); o_ljpt[jj] = AT(B.last_joint_pos_target, j, e);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) o_cmd[i] = (leg + 4 * i < cfg.num_commands) ? AT(B.commands, leg + 4 * i, e) : 0.f;
+    const float o_gait = B.gait_indices[e];
     int n = 0;                // running column (identical on all lanes)
     if (cfg.observe_only_lin_vel) { if (is0) for (int i = 0; i < 3; i++) emit(n + i, AT(B.base_lin_vel, i, e) * cfg.obs_scale_lin_vel); n += 3; }
     if (cfg.observe_only_ang_vel) { if (is0) for (int i = 0; i < 3; i++) emit(n + i, AT(B.base_ang_vel, i, e) * cfg.obs_scale_ang_vel); n += 3; }
@@ -551,20 +562,23 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, int lane, int e, int N
     n += 3;
     if (cfg.observe_command) {
       // 15 command columns: spread over the quad
-#pragma unroll 1
-      for (int kx = leg; kx < cfg.num_commands; kx += 4) emit(n + kx, AT(B.commands, kx, e) * cfg.commands_scale[kx]);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int kx = leg + 4 * i;
+        if (kx < cfg.num_commands) emit(n + kx, o_cmd[i] * cfg.commands_scale[kx]);
+      }
       n += cfg.num_commands;
     }
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) {
       const int j = 3 * leg + jj;
-      emit(n + j, (AT(B.dof_pos, j, e) - cfg.default_dof_pos[j]) * cfg.obs_scale_dof_pos);
-      emit(n + 12 + j, AT(B.dof_vel, j, e) * cfg.obs_scale_dof_vel);
-      emit(n + 24 + j, AT(B.actions, j, e));
-      if (cfg.observe_two_prev_actions) emit(n + 36 + j, AT(B.last_actions, j, e));
+      emit(n + j, (o_q[jj] - cfg.default_dof_pos[j]) * cfg.obs_scale_dof_pos);
+      emit(n + 12 + j, o_qd[jj] * cfg.obs_scale_dof_vel);
+      emit(n + 24 + j, o_act[jj]);
+      if (cfg.observe_two_prev_actions) emit(n + 36 + j, o_lact[jj]);
     }
     n += cfg.observe_two_prev_actions ? 48 : 36;
-    if (cfg.observe_timing_parameter) { if (is0) emit(n, B.gait_indices[e]); n += 1; }
+    if (cfg.observe_timing_parameter) { if (is0) emit(n, o_gait); n += 1; }
     if (cfg.observe_clock_inputs) { emit(n + leg, clock_own); n += 4; }
     if (cfg.observe_yaw) {
       if (is0) {
@@ -617,17 +631,17 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, int lane, int e, int N
       if (cfg.priv_enabled[GO1_PRIV_CLOCK_INPUTS]) for (int f = 0; f < 4; f++) privraw(AT(B.clock_inputs, f, e));
       if (cfg.priv_enabled[GO1_PRIV_DESIRED_CONTACT]) for (int f = 0; f < 4; f++) privraw(AT(B.desired_contact_states, f, e));
     }
+    // ---- roll (own joints): from the values fetched above -------------------------------------------------
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      AT(B.last_last_actions, j, e) = o_lact[jj];
+      AT(B.last_actions, j, e) = o_act[jj];
+      AT(B.last_last_joint_pos_target, j, e) = o_ljpt[jj];
+      AT(B.last_joint_pos_target, j, e) = o_jpt[jj];
+      AT(B.last_dof_vel, j, e) = o_qd[jj];
+    }
   }
   PROF(14);
-  // ---- roll (own joints) --------------------------------------------------------------------------------
-#pragma unroll
-  for (int jj = 0; jj < 3; jj++) {
-    const int j = 3 * leg + jj;
-    AT(B.last_last_actions, j, e) = AT(B.last_actions, j, e);
-    AT(B.last_actions, j, e) = AT(B.actions, j, e);
-    AT(B.last_last_joint_pos_target, j, e) = AT(B.last_joint_pos_target, j, e);
-    AT(B.last_joint_pos_target, j, e) = AT(B.joint_pos_target, j, e);
-    AT(B.last_dof_vel, j, e) = AT(B.dof_vel, j, e);
-  }
   PROF(15);
 }

@@ -825,7 +825,10 @@ DEV void load_lambda(CfgRef cfg, BufRef B, float* lds, int lane, int e, int N, b
     if (i == 4 && leg != 0) continue;
     const int b = (i == 4) ? 0 : 1 + 4 * leg + i;       // world force -> world impulse
 #pragma unroll
-    for (int c = 0; c < 3; c++) LDS(L_LAM + 3 * b + c) = zero ? 0.f : AT(B.contact_forces, 3 * b + c, e) * cfg.sim_dt;
+    for (int c = 0; c < 3; c++) {          // unconditional load (joins the prologue's batch), then select
+      const float f = AT(B.contact_forces, 3 * b + c, e);
+      LDS(L_LAM + 3 * b + c) = zero ? 0.f : f * cfg.sim_dt;
+    }
   }
 }
 DEV void store_forces(CfgRef cfg, BufRef B, const float* lds, int lane, int e, int N) {

@@ -59,17 +59,25 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
   PROF_DECL
   Base s;
   Leg L;
+  // every load of the prologue is issued before its first store (a store in between would pin the later loads behind
+  // it — possible aliasing — and expose one HBM round trip per group)
   load_state(B, leg, e, N, s, L);
+  float act_in[3], fv_in[3];
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+    const int j = 3 * leg + jj;
+    act_in[jj] = A.actions[(size_t)e * 12 + j];
+    fv_in[jj] = AT(B.foot_velocities, j, e);
+  }
+  const bool warm = cfg.warm_start && B.episode_length_buf[e] > 0;
+  load_lambda(cfg, B, lds, lane, e, N, !warm);
   const V3 grav = gravity_at(cfg, A.counter);
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) {
     const int j = 3 * leg + jj;
-    float a = A.actions[(size_t)e * 12 + j];
-    AT(B.actions, j, e) = fminf(fmaxf(a, -cfg.clip_actions), cfg.clip_actions);
-    AT(B.prev_foot_velocities, j, e) = AT(B.foot_velocities, j, e);
+    AT(B.actions, j, e) = fminf(fmaxf(act_in[jj], -cfg.clip_actions), cfg.clip_actions);
+    AT(B.prev_foot_velocities, j, e) = fv_in[jj];
   }
-  const bool warm = cfg.warm_start && B.episode_length_buf[e] > 0;
-  load_lambda(cfg, B, lds, lane, e, N, !warm);
   const int nl = cfg.lag_timesteps + 1;
   int head = A.lag_head;
   PROF(0);
