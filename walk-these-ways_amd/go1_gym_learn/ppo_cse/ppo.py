@@ -16,6 +16,7 @@ Same algorithm, hyper-parameters (`PPO_Args`) and public methods (`act`, `proces
     loss statistics are accumulated on device and read once at the end.
 """
 import math
+import sys
 
 import torch
 import torch.distributed as dist
@@ -72,7 +73,7 @@ def _enable_tuned_gemms():
         if hasattr(tunable, "write_file_on_exit"):
             tunable.write_file_on_exit(False)       # the shipped table is read-only; tools/tune_gemms.sh regenerates it
     except Exception as err:          # an optimisation only
-        print(f"[ppo] TunableOp not enabled ({type(err).__name__}: {err})")
+        print(f"[ppo] TunableOp not enabled ({type(err).__name__}: {err})", file=sys.stderr)
 
 
 def _world():
@@ -515,7 +516,7 @@ class PPO:
                         try:
                             self._graphs[i] = self._capture(i)
                         except Exception as err:      # capture is an optimisation: fall back to eager launches
-                            print(f"[ppo] HIP graph capture failed ({type(err).__name__}: {err}); running eagerly")
+                            print(f"[ppo] HIP graph capture failed ({type(err).__name__}: {err}); running eagerly", file=sys.stderr)
                             PPO_Args.use_hip_graphs = False
                             graph_mode = self._pregathered = False
                             torch.cuda.synchronize()
