@@ -361,7 +361,7 @@ DEV int reward_raw_sign(int id) {
 // ================================================================================================
 #define QUAD_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)
 
-DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, int lane, int e, int N, int64_t counter_post, V3 grav,
+DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int lane, int e, int N, int64_t counter_post, V3 grav,
                       int history_slot PROF_PARAM) {
   const int leg = lane & 3;
   const bool is0 = leg == 0;
@@ -531,12 +531,11 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, int lane, int e, int N
     const int R = cfg.num_obs_history + 1;     // ring slots (one spare keeps the previous window intact)
     float* h0 = B.obs_history ? B.obs_history + (size_t)e * 2 * R * cfg.num_obs + (size_t)history_slot * cfg.num_obs : nullptr;
     float* h1 = h0 ? h0 + (size_t)R * cfg.num_obs : nullptr;
-    auto emit = [&](int n, float v) {
-      if (cfg.add_noise && cfg.noise_scale_vec[n] != 0.f) v += (2 * rng_uniform(cfg, eg, counter_post, P_NOISE, n) - 1) * cfg.noise_scale_vec[n];
-      v = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations);
-      obs_row[n] = v;
-      if (h0) { h0[n] = v; h1[n] = v; }
-    };
+    // Two passes.  (1) every lane stages the raw values of "its" columns in an LDS row; (2) the row is finished in
+    // blocks of 4 columns, block b by lane b & 3: ONE Philox4x32 call yields the noise of all 4 columns (drawing per
+    // column would run the generator 4x for the same counter), then clip and the three stores (obs, history x2).
+    float* orow = obs_stage + (lane >> 2) * GO1_MAX_OBS;
+    auto emit = [&](int n, float v) { orow[n] = v; };
     // everything the default observation and the history roll read, as ONE batch of loads (post-reset values)
     float o_q[3], o_qd[3], o_act[3], o_lact[3], o_jpt[3], o_ljpt[3], o_cmd[4];
 #pragma unroll
@@ -588,6 +587,38 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, int lane, int e, int N
       n += 1;
     }
     if (cfg.observe_contact_states) { emit(n + leg, F.force.z > 1.0f ? 1.0f : 0.0f); n += 4; }
+    {
+      const int n_def = n;                      // columns staged so far
+      QUAD_SYNC();
+#pragma unroll 1
+      for (int b = leg; 4 * b < n_def; b += 4) {
+        float v[4], sc[4];
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int c = 4 * b + i;
+          v[i] = c < n_def ? orow[c] : 0.f;
+          sc[i] = (cfg.add_noise && c < n_def) ? cfg.noise_scale_vec[c] : 0.f;
+          any = any || sc[i] != 0.f;
+        }
+        if (any) {
+          uint32_t out[4];
+          philox4x32_10(eg, (uint32_t)counter_post, P_NOISE, (uint32_t)b, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), out);
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (sc[i] != 0.f) v[i] += (2 * u32_to_unit(out[i]) - 1) * sc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int c = 4 * b + i;
+          if (c < n_def) {
+            const float x = fminf(fmaxf(v[i], -cfg.clip_observations), cfg.clip_observations);
+            obs_row[c] = x;
+            if (h0) { h0[c] = x; h1[c] = x; }
+          }
+        }
+      }
+    }
     if (cfg.observe_heights && cfg.measure_heights && B.measured_heights) {      // legacy legged_gym height block (BASELINE config 3)
       const int np = cfg.num_height_x * cfg.num_height_y;
       const float z = AT(B.root_states, 2, e);

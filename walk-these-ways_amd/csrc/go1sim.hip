@@ -22,6 +22,7 @@
 #include "go1_maps.h"
 #include "go1_physics.h"
 
+static_assert(L_END >= GO1_MAX_OBS, "post_physics stages the observation rows in the solver's LDS block");
 struct SimConst {            // lives in device memory (one per handle): indexable with scalar loads
   Go1SimConfig cfg;
   Go1SimBuffers buf;
@@ -99,7 +100,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
   __syncthreads();
   PROF(7);
 #ifndef GO1_ABLATE_POST
-  post_physics(cfg, B, csc->rew, lane, e, N, A.counter + 1, grav, A.history_slot PROF_PASS);
+  post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, grav, A.history_slot PROF_PASS);
 #endif
   PROF_FLUSH;
 }
@@ -120,7 +121,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   if (e >= N) return;
   if (A.mode == 4) {       // tensor maps only
     PROF_DECL
-    post_physics(cfg, B, csc->rew, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot PROF_PASS);
+    post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot PROF_PASS);
     return;
   }
   Base s;
