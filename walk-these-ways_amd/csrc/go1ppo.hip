@@ -21,38 +21,72 @@ typedef uint16_t bf16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {          // round to nearest even (inputs are finite)
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+__device__ __forceinline__ bf16_t f2bf(float f) {          // round to nearest even: v_cvt_pk_bf16_f32 on gfx950
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 struct alignas(16) Bf8 { bf16_t v[8]; };
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+// ELU with alpha = 1.  exp(x) - 1 through the hardware exponential loses relative accuracy only for |x| < ~1e-3, where the
+// two-term series is exact to fp32; both are far inside the bf16 rounding of the stored activation.
+__device__ __forceinline__ float elu1(float x) {
+  float em = x > -1e-3f ? fmaf(0.5f * x, x, x) : __expf(x) - 1.f;
+  return x > 0.f ? x : em;
+}
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// eight floats -> eight bf16 (round to nearest even) on v_cvt_pk_bf16_f32
+__device__ __forceinline__ Bf8 pack_bf8(const float (&x)[8]) {
+  union { Bf8 b; uint32_t u[4]; } r;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    f32x2 v = {x[2 * e], x[2 * e + 1]};
+    r.u[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+  }
+  return r.b;
+}
 
 // ---------------------------------------------------------------------------------------------- elu_fwd
-__global__ __launch_bounds__(256) void elu_fwd_kernel(bf16_t* y, int64_t rows, int cols, int ld, const bf16_t* lat,
-                                                      int lat_ld, int npv, const bf16_t* wz, int wz_ld, int lat_cols) {
-  int cgs = cols >> 3;
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows * cgs) return;
-  int64_t r = i / cgs;
-  int c0 = (int)(i - r * cgs) << 3;
-  Bf8* p = reinterpret_cast<Bf8*>(y + r * ld + c0);
-  Bf8 v = *p;
-  float x[8];
+// block = 16 column groups (8 columns each) x 16 row lanes, ELU_ROWS rows per lane: a 128-column x 64-row tile.
+#define ELU_ROWS 4
+template <bool LAT>
+__global__ __launch_bounds__(256) void elu_fwd_kernel(bf16_t* y, int rows, int cols, int ld, const bf16_t* lat, int lat_ld,
+                                                      int npv, const bf16_t* wz, int wz_ld, int lat_cols) {
+  int c0 = (blockIdx.x * 16 + (threadIdx.x & 15)) << 3;
+  int r0 = blockIdx.y * (16 * ELU_ROWS) + (threadIdx.x >> 4);
+  if (c0 >= cols) return;
+  Bf8 v[ELU_ROWS];
 #pragma unroll
-  for (int e = 0; e < 8; e++) x[e] = bf2f(v.v[e]);
-  if (lat && c0 < lat_cols) {
+  for (int u = 0; u < ELU_ROWS; u++) {
+    int r = r0 + u * 16;
+    if (r < rows) v[u] = *reinterpret_cast<const Bf8*>(y + (int64_t)r * ld + c0);
+  }
+  float x[ELU_ROWS][8];
+#pragma unroll
+  for (int u = 0; u < ELU_ROWS; u++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) x[u][e] = bf2f(v[u].v[e]);
+  if (LAT && c0 < lat_cols) {
     for (int q = 0; q < npv; q++) {
-      float l = bf2f(lat[r * lat_ld + q]);
+      float w[8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) x[e] = fmaf(l, bf2f(wz[(int64_t)(c0 + e) * wz_ld + q]), x[e]);
+      for (int e = 0; e < 8; e++) w[e] = bf2f(wz[(int64_t)(c0 + e) * wz_ld + q]);
+#pragma unroll
+      for (int u = 0; u < ELU_ROWS; u++) {
+        int r = r0 + u * 16;
+        float l = r < rows ? bf2f(lat[(int64_t)r * lat_ld + q]) : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) x[u][e] = fmaf(l, w[e], x[u][e]);
+      }
     }
   }
 #pragma unroll
-  for (int e = 0; e < 8; e++) v.v[e] = f2bf(elu1(x[e]));
-  *p = v;
+  for (int u = 0; u < ELU_ROWS; u++) {
+    int r = r0 + u * 16;
+#pragma unroll
+    for (int e = 0; e < 8; e++) x[u][e] = elu1(x[u][e]);
+    if (r < rows) *reinterpret_cast<Bf8*>(y + (int64_t)r * ld + c0) = pack_bf8(x[u]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- elu_bwd (+ column sums)
@@ -96,6 +130,34 @@ __global__ __launch_bounds__(256) void elu_bwd_kernel(const bf16_t* d, int ld_d,
     float t = 0.f;
     for (int q = 0; q < rlanes; q++) t += red[q * cg_per_block * 8 + o];
     atomicAdd(bias_grad + c, t);
+  }
+}
+
+// the same map without column sums (the weight-gradient kernel produces the bias gradients): elu_fwd's tiling
+__global__ __launch_bounds__(256) void elu_bwd_tile_kernel(const bf16_t* d, int ld_d, const bf16_t* h, int ld_h, int rows, int cols,
+                                                           bf16_t* out, int ld_out) {
+  int c0 = (blockIdx.x * 16 + (threadIdx.x & 15)) << 3;
+  int r0 = blockIdx.y * (16 * ELU_ROWS) + (threadIdx.x >> 4);
+  if (c0 >= cols) return;
+  Bf8 g[ELU_ROWS], a[ELU_ROWS];
+#pragma unroll
+  for (int u = 0; u < ELU_ROWS; u++) {
+    int r = r0 + u * 16;
+    if (r < rows) {
+      g[u] = *reinterpret_cast<const Bf8*>(d + (int64_t)r * ld_d + c0);
+      a[u] = *reinterpret_cast<const Bf8*>(h + (int64_t)r * ld_h + c0);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < ELU_ROWS; u++) {
+    int r = r0 + u * 16;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      float hv = bf2f(a[u].v[e]);
+      x[e] = bf2f(g[u].v[e]) * (hv > 0.f ? 1.f : hv + 1.f);
+    }
+    if (r < rows) *reinterpret_cast<Bf8*>(out + (int64_t)r * ld_out + c0) = pack_bf8(x);
   }
 }
 
@@ -631,9 +693,13 @@ extern "C" int go1ppo_elu_fwd(void* y, int64_t rows, int cols, int ld, const voi
                               int wz_ld, int lat_cols, void* stream) {
   if (!y || rows <= 0 || cols <= 0 || (cols & 7) || (ld & 7) || !aligned16(y)) return -1;
   if (lat && (!wz || npv <= 0 || (lat_cols & 7))) return -2;
-  int64_t n = rows * (cols >> 3);
-  elu_fwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-      (bf16_t*)y, rows, cols, ld, (const bf16_t*)lat, lat_ld, npv, (const bf16_t*)wz, wz_ld, lat_cols);
+  if (rows > INT32_MAX) return -1;
+  dim3 grid((unsigned)(((cols >> 3) + 15) / 16), (unsigned)((rows + 16 * ELU_ROWS - 1) / (16 * ELU_ROWS)));
+  if (lat)
+    elu_fwd_kernel<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>((bf16_t*)y, (int)rows, cols, ld, (const bf16_t*)lat, lat_ld, npv,
+                                                                      (const bf16_t*)wz, wz_ld, lat_cols);
+  else
+    elu_fwd_kernel<false><<<grid, dim3(256), 0, (hipStream_t)stream>>>((bf16_t*)y, (int)rows, cols, ld, nullptr, 0, 0, nullptr, 0, 0);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
@@ -642,6 +708,12 @@ extern "C" int go1ppo_elu_bwd(const void* d, int ld_d, const void* h, int ld_h, 
   if (!d || !out || rows <= 0 || cols <= 0 || (cols & 7) || (ld_d & 7) || (ld_out & 7) || (h && (ld_h & 7)) || !aligned16(d) ||
       !aligned16(out) || (h && !aligned16(h)))
     return -1;
+  if (h && !bias_grad && rows <= INT32_MAX) {
+    dim3 grid((unsigned)(((cols >> 3) + 15) / 16), (unsigned)((rows + 16 * ELU_ROWS - 1) / (16 * ELU_ROWS)));
+    elu_bwd_tile_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)d, ld_d, (const bf16_t*)h, ld_h, (int)rows, cols,
+                                                                     (bf16_t*)out, ld_out);
+    return hipGetLastError() == hipSuccess ? 0 : -9;
+  }
   int cgs = cols >> 3;
   int cgb = cgs >= 32 ? 32 : (cgs >= 16 ? 16 : 8);
   int xblocks = (cgs + cgb - 1) / cgb;
