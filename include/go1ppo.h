@@ -157,6 +157,24 @@ int go1ppo_opt_adam(float* p, const float* g, float* m, float* v, int64_t start0
                     int64_t count1, float gscale, const float* partial, float max_norm, const float* step, const float* lr,
                     float beta1, float beta2, float eps, void* body, int64_t n_body, float* tail, void* stream);
 
+/* ---- MLP-layer GEMM with fused epilogue (replaces torch.addmm + F.elu / the ELU-backward map around it) ---- */
+
+/* C (M x N, bf16, row stride ldc) = epilogue(A (M x K, bf16, lda) * B^T (B: N x K, bf16, ldb) + bias (fp32[N] or NULL)).
+ * epilogue 0: nothing more; 1: ELU on the columns [elu_c0, elu_c1); 2: multiplied element-wise by elu'(H[m][n])
+ * (H: the layer's post-ELU activations, bf16, ldh) — the input gradient of a hidden layer, B being the transposed
+ * weight.  K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0, ldc/ldh % 4 == 0, A/B 16-byte and C/H 8-byte aligned. */
+typedef struct Go1PpoGemmArgs {
+  const void* A; const void* B; void* C; const float* bias; const void* H;
+  int32_t M, N, K, lda, ldb, ldc, ldh, epilogue, elu_c0, elu_c1;
+} Go1PpoGemmArgs;
+int go1ppo_gemm_nt(const Go1PpoGemmArgs* args, void* stream);
+
+/* the same weight gradients on 128 x 128 tiles (LDS-DMA staging, hardware transpose reads): what the first-layer
+ * gradients (n = 256 .. 1280, k = 2112) and the batched tails use.  Same problem table as go1ppo_wgrad_plan /
+ * go1ppo_wgrad_batched, with rows % 64 == 0 and n, k % 8 == 0 instead of n, k % 64 == 0. */
+int go1ppo_wgrad_tn_plan(Go1PpoWgradProblem* problems, int count);
+int go1ppo_wgrad_tn_batched(const Go1PpoWgradProblem* device_problems, int count, int total_workgroups, void* stream);
+
 const char* go1ppo_version(void);
 
 #ifdef __cplusplus

@@ -98,6 +98,78 @@ def test_wgrad_matches_fp32_matmul(lib, M, n, k, ld_dz, ld_h):
     assert lib.go1ppo_wgrad(dz.data_ptr(), ld_dz, h.data_ptr(), ld_h, M, 48, k, out.data_ptr(), k, None, stream()) == -1
 
 
+def test_wgrad_tn_batched_matches_fp32_matmul(lib):
+    """the 128-tile weight-gradient kernel (LDS-DMA + transpose reads), several problems of different shapes in one
+    launch: first-layer sized (k = 2112: the last column tile is half empty), tails, a 64-row head, strided operands."""
+    import ctypes
+    from go1_gym_learn.ppo_cse import fused
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M = 24576
+    shapes = [(256, 2112, 1280, 2112, True), (256, 512, 256, 1280, True), (64, 128, 64, 128, False), (512, 64, 1280, 64, True),
+              (72, 200, 80, 256, True)]
+    tab = (fused.WgradProblem * len(shapes))()
+    keep, refs = [], []
+    for P, (n, k, ld_dz, ld_h, with_bias) in zip(tab, shapes):
+        rows = M if n * k > 100000 else 4096
+        dz = bf(torch.randn(rows, ld_dz, device="cuda", generator=g))
+        h = bf(torch.randn(rows, ld_h, device="cuda", generator=g))
+        out = torch.full((n, k), 1.0, device="cuda")
+        bias = torch.full((n,), -2.0, device="cuda") if with_bias else None
+        P.dz, P.h, P.dW, P.bias_grad = dz.data_ptr(), h.data_ptr(), out.data_ptr(), bias.data_ptr() if with_bias else None
+        P.rows, P.ld_dz, P.ld_h, P.n, P.k, P.ldw = rows, ld_dz, ld_h, n, k, k
+        keep.append((dz, h, out, bias))
+        refs.append((dz[:, :n].float().t() @ h[:, :k].float() + 1.0, dz[:, :n].float().sum(0) - 2.0, rows))
+    total = lib.go1ppo_wgrad_tn_plan(tab, len(shapes))
+    assert total > 0
+    dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).cuda()
+    assert lib.go1ppo_wgrad_tn_batched(dev.data_ptr(), len(shapes), total, stream()) == 0
+    torch.cuda.synchronize()
+    for (dz, h, out, bias), (ref, bref, rows) in zip(keep, refs):
+        torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-3 * rows ** 0.5)
+        if bias is not None:
+            torch.testing.assert_close(bias, bref, rtol=1e-4, atol=2e-3 * rows ** 0.5)
+    tab[0].rows = 1000                                             # not a multiple of 64
+    assert lib.go1ppo_wgrad_tn_plan(tab, 1) == -1
+
+
+@pytest.mark.parametrize("M,N,K", [(24576, 1280, 2112), (24576, 256, 2112), (4096, 128, 256), (1000, 64, 128), (130, 12, 64),
+                                   (257, 388, 192)])
+@pytest.mark.parametrize("epilogue", ["bias", "elu", "elu_range", "elu_bwd"])
+def test_gemm_nt_matches_fp32_matmul(lib, M, N, K, epilogue):
+    """go1ppo_gemm_nt vs fp32 matmul of the same bf16 operands; the fp32 result is rounded to bf16 once, the kernel
+    accumulates in fp32 in a different order -> 1 bf16 ulp of the pre-activation scale, plus 1 ulp of the result."""
+    from go1_gym_learn.ppo_cse import fused
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    big_a = bf(torch.randn(M, K + 64, device="cuda", generator=g))
+    a = big_a[:, :K]                                             # strided operand (lda > K)
+    b = bf(torch.randn(N, K, device="cuda", generator=g) / K ** 0.5)
+    bias = torch.randn(N, device="cuda", generator=g)
+    out_full = torch.full((M, N + 16), 7.0, device="cuda", dtype=torch.bfloat16)
+    c = out_full[:, :N]
+    pre = a.float() @ b.float().t() + bias
+    if epilogue == "bias":
+        fused.gemm_nt(lib, a, b, c, bias)
+        ref = pre
+    elif epilogue == "elu":
+        fused.gemm_nt(lib, a, b, c, bias, elu=True)
+        ref = torch.nn.functional.elu(pre)
+    elif epilogue == "elu_range":
+        c0, c1 = (N // 8) * 4, N
+        fused.gemm_nt(lib, a, b, c, bias, elu=(c0, c1))
+        ref = pre.clone()
+        ref[:, c0:c1] = torch.nn.functional.elu(pre[:, c0:c1])
+    else:
+        h = bf(torch.nn.functional.elu(torch.randn(M, N, device="cuda", generator=g)))
+        pre = a.float() @ b.float().t()
+        fused.gemm_nt(lib, a, b, c, None, elu_bwd_of=h)
+        ref = pre * torch.where(h.float() > 0, torch.ones_like(pre), h.float() + 1)
+    torch.cuda.synchronize()
+    assert torch.all(out_full[:, N:] == 7.0), "wrote outside the N columns"
+    err = (c.float() - ref).abs()
+    tol = 2 ** -8 * (ref.abs() + pre.abs().clamp(min=1.0)) + 1e-6
+    assert torch.all(err <= tol), f"max err {err.max().item()} at scale {ref.abs().max().item()}"
+
+
 @pytest.mark.parametrize("M", [4096, 1000, 24576])
 def test_fused_tail_forward_matches_layerwise_torch(lib, M):
     """go1ppo_tail_fwd (three layers, activations on chip) vs addmm + ELU per layer in fp32 on the same bf16 data."""

@@ -753,6 +753,8 @@ extern "C" int go1ppo_wgrad(const void* dz, int ld_dz, const void* h, int ld_h, 
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
+#include "go1ppo_gemm.h"
+
 extern "C" int go1ppo_act(const void* mean, const void* value, int head_ld, const float* std, int num_actions, int64_t rows,
                           const float* noise, float* actions, float* mu, float* sigma, float* values, float* logp, void* stream) {
   if (!mean || !value || !std || !noise || !actions || !mu || !sigma || !values || !logp || rows <= 0 || num_actions <= 0 ||

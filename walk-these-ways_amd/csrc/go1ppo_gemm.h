@@ -1,0 +1,316 @@
+// go1ppo_gemm.h — C = epilogue(A · Bᵀ) for the MLP layers of the PPO update, bf16 in / fp32 accumulate / bf16 out.
+//
+// A (M x K) and B (N x K) are both K-contiguous ("NT": activations times an nn.Linear weight), so both tiles stage
+// into LDS the same way.  One workgroup = 4 wavefronts = one 128 x 128 output tile, K in steps of 64:
+//   * staging: global_load_lds (16 B per lane, LDS-DMA), two LDS buffers, the loads of step t+1 in flight while step t
+//     is on the MFMAs; the LDS image is [row][64] bf16 (128-B rows) with the 16-B chunk index XOR-ed by (row >> 1) & 7
+//     — applied on the per-lane SOURCE address, the DMA destination is lane-linear — which makes every ds_read_b128
+//     lane group of a fragment read hit 16 distinct bank quads (MI355X_MICROARCH.md, LDS);
+//   * each wave owns a 64 x 64 sub-tile: 4 x 4 accumulators of v_mfma_f32_16x16x32_bf16, with the WEIGHT rows as the
+//     A operand so that a lane ends up with 4 consecutive output columns of one output row (8-B bf16 stores);
+//   * epilogue in registers: + bias[n], ELU on a column range, or the ELU-backward factor elu'(H) of another matrix
+//     (dgrad of a hidden layer), so the activation passes never exist as separate kernels;
+//   * workgroup -> tile map is XCD-aware: each of the 8 XCDs walks a contiguous range of tiles with the column tile
+//     fastest, so the A row block of a tile row is re-read from that XCD's L2.
+// M and N need not be multiples of 128 (rows are clamped on load and masked on store); K % 64 == 0.
+#pragma once
+
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 64
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_cvoid_t;
+
+__device__ __forceinline__ void glds16(const bf16_t* g, bf16_t* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((global_cvoid_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI>   // 0: bias only, 1: bias + ELU on [elu_c0, elu_c1), 2: times elu'(H)
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(Go1PpoGemmArgs a) {
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[2][2][GEMM_BM * GEMM_BK];   // [buffer][A|B][row][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // ---- XCD-aware tile index (bijective for any grid size)
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tiles_n = (a.N + GEMM_BN - 1) / GEMM_BN;
+  const int m0 = (logical / tiles_n) * GEMM_BM, n0 = (logical % tiles_n) * GEMM_BN;
+
+  // ---- staging addresses: wave w stages row blocks (8 rows each) w*4 .. w*4+3 of both tiles
+  const int srow = lane >> 3;                                  // row within the 8-row block
+  const bf16_t* ga[4];
+  const bf16_t* gb[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    int R = (wave * 4 + p) * 8 + srow;
+    int chunk = (lane & 7) ^ ((R >> 1) & 7);
+    int ra = m0 + R < a.M ? m0 + R : a.M - 1;
+    int rb = n0 + R < a.N ? n0 + R : a.N - 1;
+    ga[p] = (const bf16_t*)a.A + (int64_t)ra * a.lda + chunk * 8;
+    gb[p] = (const bf16_t*)a.B + (int64_t)rb * a.ldb + chunk * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      glds16(ga[p] + k0, &lds[buf][0][(wave * 4 + p) * 8 * GEMM_BK]);
+      glds16(gb[p] + k0, &lds[buf][1][(wave * 4 + p) * 8 * GEMM_BK]);
+    }
+  };
+
+  // ---- fragment read offsets (elements): row (lane & 15) of a 16-row fragment, k chunk kk*4 + (lane >> 4), swizzled
+  const int fr = lane & 15, fg = lane >> 4;
+  int foff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; kk++) foff[kk] = fr * GEMM_BK + (((kk * 4 + fg) ^ (fr >> 1)) << 3);
+  const int wm = wave >> 1, wn = wave & 1;                      // the wave's 64 x 64 sub-tile
+
+  f32x4 acc[4][4];                                              // [n fragment][m fragment]
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int KT = a.K / GEMM_BK;
+  stage(0, 0);
+  for (int kt = 0; kt < KT; kt++) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                            // step kt landed; everyone is done with buffer buf^1
+    if (kt + 1 < KT) stage(buf ^ 1, (kt + 1) * GEMM_BK);
+    const bf16_t* la = &lds[buf][0][wm * 64 * GEMM_BK];
+    const bf16_t* lb = &lds[buf][1][wn * 64 * GEMM_BK];
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      bf16x8_t xa[4], wb[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) xa[i] = *reinterpret_cast<const bf16x8_t*>(la + i * 16 * GEMM_BK + foff[kk]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) wb[j] = *reinterpret_cast<const bf16x8_t*>(lb + j * 16 * GEMM_BK + foff[kk]);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[j][i], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds D[n = 4*fg + e][m = fr] of each 16 x 16 fragment
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int n = n0 + wn * 64 + j * 16 + fg * 4;
+    if (n >= a.N) continue;                                     // N % 4 == 0: a 4-column group is in or out as a whole
+    f32x4 bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      if (m >= a.M) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = acc[j][i][e] + bias[e];
+      if (EPI == 1) {
+        if (n >= a.elu_c0 && n < a.elu_c1) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = elu1(v[e]);
+        }
+      } else if (EPI == 2) {
+        uint2 hraw = *reinterpret_cast<const uint2*>((const bf16_t*)a.H + (int64_t)m * a.ldh + n);
+        float h[4] = {__uint_as_float(hraw.x << 16), __uint_as_float(hraw.x & 0xffff0000u), __uint_as_float(hraw.y << 16),
+                      __uint_as_float(hraw.y & 0xffff0000u)};
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] *= h[e] > 0.f ? 1.f : h[e] + 1.f;
+      }
+      f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+      uint2 o;
+      o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2_t));
+      o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2_t));
+      *reinterpret_cast<uint2*>((bf16_t*)a.C + (int64_t)m * a.ldc + n) = o;
+    }
+  }
+}
+
+extern "C" int go1ppo_gemm_nt(const Go1PpoGemmArgs* a, void* stream) {
+  if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return -1;
+  if ((a->K % GEMM_BK) || (a->N & 3) || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 3) || !aligned16(a->A) || !aligned16(a->B) ||
+      ((uintptr_t)a->C & 7))
+    return -2;
+  if (a->epilogue == 2 && (!a->H || (a->ldh & 3) || ((uintptr_t)a->H & 7))) return -3;
+  if (a->bias && ((uintptr_t)a->bias & 15)) return -4;
+  int64_t tiles = (int64_t)((a->M + GEMM_BM - 1) / GEMM_BM) * ((a->N + GEMM_BN - 1) / GEMM_BN);
+  if (tiles > INT32_MAX) return -5;
+  dim3 grid((unsigned)tiles), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (a->epilogue) {
+    case 0: gemm_nt_kernel<0><<<grid, block, 0, s>>>(*a); break;
+    case 1: gemm_nt_kernel<1><<<grid, block, 0, s>>>(*a); break;
+    case 2: gemm_nt_kernel<2><<<grid, block, 0, s>>>(*a); break;
+    default: return -6;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+// ================================================================================================ weight gradients
+// dW[n][k] += sum_m dZ[m][n] H[m][k] ("TN": both operands are m-major, the reduction runs over the slow index).
+// Same skeleton as gemm_nt_kernel — 128 x 128 output tile, 4 waves of 64 x 64, 64 reduction rows per step, LDS-DMA
+// staging into two buffers — with the LDS image [m][128 columns] (256-B rows) read through ds_read_b64_tr_b16: a
+// 16-lane group hands the hardware a [4 m][16 columns] block and every lane receives the 4 m-values of ITS column,
+// i.e. half an MFMA operand (the reduction-slot order only has to agree between the two operands, and it does).
+// A 256-B row is exactly one bank row, so the 8 rows a 32-lane group touches would all collide; the 16-B chunk index
+// is XOR-ed with 2 * ((m & 3) | ((m >> 3) & 1) << 2) on the DMA source address, which spreads them over 8 distinct
+// 32-B slots.  The reduction is split over row chunks (the output has only (n/128)(k/128) tiles), partial tiles meet
+// in fp32 atomics on the gradient buffer itself; the bias gradient (column sums of dZ) is one more MFMA per fragment
+// against a fragment of ones, in the workgroups of the first column tile.  rows % 64 == 0, n % 8 == 0, k % 8 == 0.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* lds_base, int byte_off) {
+  typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+  const char* p = reinterpret_cast<const char*>(lds_base) + byte_off;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 4 * 256));
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+#define WTN_T 128            // output tile edge
+#define WTN_STEP 64          // reduction rows per step
+
+__device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf16_t* Q, int ldq, int64_t m_begin, int steps,
+                                              float* C, int ldc, float* bias_grad, int N, int K, int n0, int k0,
+                                              bf16_t (*lds)[2][WTN_STEP * WTN_T]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // ---- staging: wave w moves row blocks (4 rows of 256 B each) 4w .. 4w+3 of both operand tiles
+  const bf16_t* gp[4];
+  const bf16_t* gq[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const int row = (wave * 4 + p) * 4 + (lane >> 4);
+    const int chunk = (lane & 15) ^ (2 * ((row & 3) | (((row >> 3) & 1) << 2)));
+    int cn = n0 + chunk * 8, ck = k0 + chunk * 8;
+    cn = cn < N ? cn : N - 8;                                    // columns past the matrix: any legal address will do
+    ck = ck < K ? ck : K - 8;
+    gp[p] = P + (m_begin + row) * ldp + cn;
+    gq[p] = Q + (m_begin + row) * ldq + ck;
+  }
+  auto stage = [&](int buf, int64_t step) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      glds16(gp[p] + step * WTN_STEP * ldp, &lds[buf][0][(wave * 4 + p) * 4 * WTN_T]);
+      glds16(gq[p] + step * WTN_STEP * ldq, &lds[buf][1][(wave * 4 + p) * 4 * WTN_T]);
+    }
+  };
+  // ---- fragment addresses (bytes inside one operand tile): lane (g = lane >> 4, i = lane & 15) supplies the piece
+  // (row 8g + (i >> 2) [+4 for the upper half, +32 per k-half], 8 bytes at column 16 f + 4 (i & 3)) of fragment f
+  const int g = lane >> 4, i16 = lane & 15;
+  const int rowoff = (g * 8 + (i16 >> 2)) * 256 + ((i16 & 3) >> 1) * 16 + (i16 & 1) * 8;
+  const int swb = 32 * ((i16 >> 2) | ((g & 1) << 2));
+  const int wn = wave >> 1, wk = wave & 1;
+  int fa[4], fb[4];
+#pragma unroll
+  for (int f = 0; f < 4; f++) {
+    fa[f] = rowoff + (((wn * 64 + f * 16) * 2) ^ swb);
+    fb[f] = rowoff + (((wk * 64 + f * 16) * 2) ^ swb);
+  }
+  f32x4 acc[4][4], bacc[4];
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    bacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = bias_grad && k0 == 0 && wk == 0;
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  const s16x8_t ones_bits = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_bits);
+
+  stage(0, 0);
+  for (int s = 0; s < steps; s++) {
+    const int buf = s & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < steps) stage(buf ^ 1, s + 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      bf16x8_t za[4], hb[4];
+#pragma unroll
+      for (int f = 0; f < 4; f++) za[f] = tr_frag(&lds[buf][0][0], fa[f] + kk * 32 * 256);
+#pragma unroll
+      for (int f = 0; f < 4; f++) hb[f] = tr_frag(&lds[buf][1][0], fb[f] + kk * 32 * 256);
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[a], hb[b], acc[a][b], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) bacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[a], ones, bacc[a], 0, 0, 0);
+      }
+    }
+  }
+  // ---- lane holds D[n = 4g + e][k = i16] of each fragment pair
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int n = n0 + wn * 64 + a * 16 + 4 * g + e;
+      if (n >= N) continue;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int k = k0 + wk * 64 + b * 16 + i16;
+        if (k < K) atomicAdd(C + (int64_t)n * ldc + k, acc[a][b][e]);
+      }
+      if (do_bias && i16 == 0) atomicAdd(bias_grad + n, bacc[a][e]);
+    }
+  }
+}
+
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// every weight gradient of a backward pass in ONE launch (problem table built by go1ppo_wgrad_tn_plan)
+__global__ __launch_bounds__(256, 2) void wgrad_tn_batched_kernel(const Go1PpoWgradProblem* __restrict__ probs, int count) {
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[2][2][WTN_STEP * WTN_T];
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  int p = 0;
+  while (p + 1 < count && wg >= probs[p + 1].wg_offset) p++;
+  const Go1PpoWgradProblem P = probs[p];
+  const int local = wg - P.wg_offset;
+  const int tiles_k = (P.k + WTN_T - 1) / WTN_T, tiles = ((P.n + WTN_T - 1) / WTN_T) * tiles_k;
+  const int tile = local % tiles, split = local / tiles;
+  const int64_t m_begin = (int64_t)split * P.chunk_rows;
+  const int64_t m_end = m_begin + P.chunk_rows < P.rows ? m_begin + P.chunk_rows : P.rows;
+  wgrad_tn_body((const bf16_t*)P.dz, P.ld_dz, (const bf16_t*)P.h, P.ld_h, m_begin, (int)((m_end - m_begin) / WTN_STEP), P.dW, P.ldw,
+                P.bias_grad, P.n, P.k, (tile / tiles_k) * WTN_T, (tile % tiles_k) * WTN_T, lds);
+}
+
+extern "C" int go1ppo_wgrad_tn_plan(Go1PpoWgradProblem* probs, int count) {
+  if (!probs || count <= 0) return -1;
+  int64_t tile_steps = 0;
+  for (int i = 0; i < count; i++) {
+    Go1PpoWgradProblem& P = probs[i];
+    if (!P.dz || !P.h || !P.dW || P.rows <= 0 || (P.rows % WTN_STEP) || P.n < 8 || P.k < 8 || (P.n & 7) || (P.k & 7) ||
+        (P.ld_dz & 7) || (P.ld_h & 7) || !aligned16(P.dz) || !aligned16(P.h))
+      return -1;
+    tile_steps += (int64_t)((P.n + WTN_T - 1) / WTN_T) * ((P.k + WTN_T - 1) / WTN_T) * (P.rows / WTN_STEP);
+  }
+  // every partial tile costs 16384 fp32 atomics (~200 G/s on the whole chip), so the launch is cut into as few workgroups
+  // as fill the machine once: two workgroups are resident per CU -> ~512, each at least 4 reduction steps long
+  int64_t chunk_steps = (tile_steps + 511) / 512;
+  if (chunk_steps < 4) chunk_steps = 4;
+  int total = 0;
+  for (int i = 0; i < count; i++) {
+    Go1PpoWgradProblem& P = probs[i];
+    const int64_t steps = P.rows / WTN_STEP;
+    const int64_t cs = chunk_steps < steps ? chunk_steps : steps;
+    const int64_t S = (steps + cs - 1) / cs;
+    P.chunk_rows = (int32_t)(cs * WTN_STEP);
+    P.wg_offset = total;
+    total += (int)S * ((P.n + WTN_T - 1) / WTN_T) * ((P.k + WTN_T - 1) / WTN_T);
+  }
+  return total;
+}
+
+extern "C" int go1ppo_wgrad_tn_batched(const Go1PpoWgradProblem* device_probs, int count, int total_workgroups, void* stream) {
+  if (!device_probs || count <= 0 || total_workgroups <= 0) return -1;
+  wgrad_tn_batched_kernel<<<dim3((unsigned)total_workgroups), dim3(256), 0, (hipStream_t)stream>>>(device_probs, count);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}

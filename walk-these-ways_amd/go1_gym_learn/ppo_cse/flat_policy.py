@@ -27,10 +27,12 @@ def _linears(seq):
 
 
 class FlatPolicy:
-    def __init__(self, ac, align=16):
+    def __init__(self, ac, align=128):
         self.K = ac.num_obs_history
         self.npv = ac.num_privileged_obs
-        self.Kp = -(-(self.K + 1 + self.npv) // 8) * 8
+        # augmented row length, padded to the GEMM K-step: rows of X and W1 are then whole 128-B lines (hipBLASLt runs the
+        # first-layer GEMMs 2x faster on 2112 columns than on 2104, and go1ppo_gemm_nt requires K % 64 == 0)
+        self.Kp = -(-(self.K + 1 + self.npv) // 64) * 64
         self.act = type(ac.adaptation_module[1]) if len(ac.adaptation_module) > 1 else nn.ELU
         self.act_fn = {nn.ELU: F.elu, nn.ReLU: F.relu, nn.SELU: F.selu, nn.LeakyReLU: F.leaky_relu, nn.Tanh: torch.tanh,
                        nn.Sigmoid: torch.sigmoid}[self.act]

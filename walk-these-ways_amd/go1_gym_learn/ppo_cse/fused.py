@@ -59,7 +59,13 @@ class TailArgs(ctypes.Structure):
     _fields_ = [("num_nets", ctypes.c_int32), ("_pad", ctypes.c_int32), ("net", TailNet * 3)]
 
 
-EXPORTED_SYMBOLS = ["go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
+class GemmArgs(ctypes.Structure):
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("H", ctypes.c_void_p)] + [(n, ctypes.c_int32) for n in
+                                           ("M", "N", "K", "lda", "ldb", "ldc", "ldh", "epilogue", "elu_c0", "elu_c1")]
+
+
+EXPORTED_SYMBOLS = ["go1ppo_gemm_nt", "go1ppo_wgrad_tn_plan", "go1ppo_wgrad_tn_batched", "go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
                     "go1ppo_wgrad_batched", "go1ppo_act",
                     "go1ppo_store_step", "go1ppo_gae", "go1ppo_normalize", "go1ppo_opt_partials", "go1ppo_opt_prestep",
                     "go1ppo_opt_adam", "go1ppo_version"]
@@ -83,7 +89,10 @@ def load_library(path=None):
     L.go1ppo_wgrad.argtypes = [vp, i32, vp, i32, i64, i32, i32, vp, i32, vp, vp]
     L.go1ppo_wgrad_plan.argtypes = [ctypes.POINTER(WgradProblem), i32]
     L.go1ppo_tail_fwd.argtypes = [ctypes.POINTER(TailArgs), vp]
+    L.go1ppo_gemm_nt.argtypes = [ctypes.POINTER(GemmArgs), vp]
     L.go1ppo_wgrad_batched.argtypes = [vp, i32, i32, vp]
+    L.go1ppo_wgrad_tn_plan.argtypes = [ctypes.POINTER(WgradProblem), i32]
+    L.go1ppo_wgrad_tn_batched.argtypes = [vp, i32, i32, vp]
     f32 = ctypes.c_float
     L.go1ppo_act.argtypes = [vp, vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp]
     L.go1ppo_store_step.argtypes = [vp, vp, vp, vp, vp, f32, i64, vp, vp, vp, vp]
@@ -118,6 +127,29 @@ def _ld(t):
     return t.stride(0)
 
 
+def gemm_args(a, b, c, bias=None, elu=None, elu_bwd_of=None):
+    """Go1PpoGemmArgs for c = epilogue(a @ b.T + bias): `elu` = (c0, c1) column range to activate (True: all columns),
+    `elu_bwd_of` = post-ELU activations H, the result is multiplied by elu'(H)."""
+    g = GemmArgs()
+    g.A, g.B, g.C, g.bias, g.H = a.data_ptr(), b.data_ptr(), c.data_ptr(), _ptr(bias), _ptr(elu_bwd_of)
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc = a.shape[0], b.shape[0], a.shape[1], _ld(a), _ld(b), _ld(c)
+    assert b.shape[1] == g.K and c.shape == (g.M, g.N) and elu is None or elu_bwd_of is None
+    assert a.dtype == b.dtype == c.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.float32)
+    if elu_bwd_of is not None:
+        assert elu_bwd_of.shape == c.shape and elu_bwd_of.dtype == torch.bfloat16
+        g.epilogue, g.ldh = 2, _ld(elu_bwd_of)
+    elif elu is not None:
+        g.epilogue = 1
+        g.elu_c0, g.elu_c1 = (0, g.N) if elu is True else elu
+    return g
+
+
+def gemm_nt(lib, a, b, c, bias=None, elu=None, elu_bwd_of=None):
+    g = gemm_args(a, b, c, bias, elu, elu_bwd_of)
+    _chk(lib.go1ppo_gemm_nt(ctypes.byref(g), _stream()), "go1ppo_gemm_nt")
+    return c
+
+
 class FusedNet:
     """Static-buffer forward (and optionally backward) of the three MLPs for a fixed row count M.
 
@@ -140,6 +172,11 @@ class FusedNet:
                   for n, d in self.depth.items()}
         assert policy.npv <= HEAD and self.P["Wz"].shape == (self.na, HEAD)
         self._recording, self._batched, self._plans = None, False, {}
+        # weight gradients: 128-tile kernel for the batched tails; first layer (PPO pass, adaptation pass) on it or on
+        # hipBLASLt.  GO1_WGRAD = "<tails><ppo W1><adaptation W1>" digits for A/B runs (tools/), default below.
+        knob = os.environ.get("GO1_WGRAD", "101")
+        self._wgrad_tn = knob[0] == "1" and M % 64 == 0
+        self._w1_tn = (self._wgrad_tn and knob[1] == "1", self._wgrad_tn and knob[2] == "1")
         self._tails = self._tails_ad = None
         # measured on MI355X: one fused launch per dependency level beats 8 GEMMs + 5 ELU kernels 3.5x at M = 4096
         # (rollout inference: 32 vs 110 us) but only ties hipBLASLt + the two-stream schedule at M = 24576
@@ -280,9 +317,13 @@ class FusedNet:
             if li > 1:
                 self._elu_bwd(out, h_in, None)
 
-    def _big_wgrad(self, dY, x, gW, tmp):
-        """first-layer weight gradient: one (rows x M) @ (M x Kp) bf16 GEMM (stream-K kernel at ~1 PFLOP/s; the
-        fp32-output variants hipBLASLt offers for this shape are 3x slower), then one cast into the fp32 gradient."""
+    def _big_wgrad(self, dY, x, gW, tmp, own_kernel):
+        """first-layer weight gradient.  own_kernel: one more problem of the batched 128-tile launch (accumulates straight
+        into the fp32 gradient); otherwise one (rows x M) @ (M x Kp) bf16 hipBLASLt GEMM (the fp32-output variants it
+        offers for this shape are 3x slower) and one cast into the fp32 gradient."""
+        if own_kernel:
+            self._wgrad(dY, x, gW)
+            return
         torch.mm(dY.t(), x, out=tmp)
         gW.copy_(tmp)
 
@@ -297,11 +338,12 @@ class FusedNet:
             for P, (dz, h, gW, gb) in zip(tab, rec):
                 P.dz, P.h, P.dW, P.bias_grad = dz.data_ptr(), h.data_ptr(), gW.data_ptr(), _ptr(gb)
                 P.rows, P.ld_dz, P.ld_h, P.n, P.k, P.ldw = dz.shape[0], _ld(dz), _ld(h), dz.shape[1], h.shape[1], gW.shape[1]
-            total = self.lib.go1ppo_wgrad_plan(tab, len(rec))
+            tn = self._wgrad_tn and all(P.rows % 64 == 0 and P.n % 8 == 0 and P.k % 8 == 0 for P in tab)
+            total = (self.lib.go1ppo_wgrad_tn_plan if tn else self.lib.go1ppo_wgrad_plan)(tab, len(rec))
             if total <= 0:
                 raise RuntimeError(f"go1ppo_wgrad_plan failed with code {total}")
             dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.Y1.device)
-            self._plans[key] = (dev, len(rec), total, rec)
+            self._plans[key] = (dev, len(rec), total, rec, tn)
             # the recording pass skipped the launches AND ran the rest of fn: its dgrad results are valid, only the
             # weight gradients are missing -> fall through to the batched launch
         else:
@@ -310,14 +352,16 @@ class FusedNet:
                 fn()
             finally:
                 self._batched = False
-        dev, count, total, _ = self._plans[key]
-        _chk(self.lib.go1ppo_wgrad_batched(dev.data_ptr(), count, total, _stream()), "go1ppo_wgrad_batched")
+        dev, count, total, _, tn = self._plans[key]
+        launch = self.lib.go1ppo_wgrad_tn_batched if tn else self.lib.go1ppo_wgrad_batched
+        _chk(launch(dev.data_ptr(), count, total, _stream()), "go1ppo_wgrad_batched")
 
     def backward(self, x):
-        self._run_planned("ppo", lambda: self._backward(x))
+        # the plan holds device pointers: one per input block (graph mode feeds a different pre-gathered block per mini-batch)
+        self._run_planned(("ppo", x.data_ptr()), lambda: self._backward(x))
 
     def backward_adaptation(self, x):
-        self._run_planned("adaptation", lambda: self._backward_adaptation(x))
+        self._run_planned(("adaptation", x.data_ptr()), lambda: self._backward_adaptation(x))
 
     def _backward(self, x):
         """After forward(x) and a loss kernel that filled dZ[actor][last], dZ[critic][last] (+ their bias / std
@@ -339,13 +383,13 @@ class FusedNet:
         self._tail_bwd("adaptation", Y1[:, :nd], dH1["adaptation"], head_bias_done=False)
         self._elu_bwd(dH1["adaptation"], Y1[:, :nd], None, out=dY1[:, :nd])
         self._join()
-        self._big_wgrad(dY1, x, G["W1"], self._w1_tmp)
+        self._big_wgrad(dY1, x, G["W1"], self._w1_tmp, self._w1_tn[0])
 
     def _backward_adaptation(self, x):
         nd, d = self.nd, self.dH1["adaptation"]
         self._tail_bwd("adaptation", self.Y1d, d)
         self._elu_bwd(d, self.Y1d, None)
-        self._big_wgrad(d, x, self.G["W1"][:nd], self._w1_tmp[:nd])
+        self._big_wgrad(d, x, self.G["W1"][:nd], self._w1_tmp[:nd], self._w1_tn[1])
 
     # ---- losses ----------------------------------------------------------------------------------------------
     def ppo_loss(self, st, idx, std, g_std, A, kl, acc):

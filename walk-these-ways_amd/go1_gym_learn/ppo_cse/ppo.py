@@ -209,7 +209,7 @@ class PPO:
                      action_shape):
         self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, privileged_obs_shape,
                                       obs_history_shape, action_shape, self.device,
-                                      history_dtype=self.body.dtype, history_pad_to=8, augment=True)
+                                      history_dtype=self.body.dtype, history_pad_to=64, augment=True)
         assert self.storage.observation_histories.shape[-1] == self.policy.Kp
         self._last_hist = self.storage.observation_histories[0].clone()
         if self.fused:
