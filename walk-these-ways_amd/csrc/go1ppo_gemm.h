@@ -150,39 +150,76 @@ extern "C" int go1ppo_gemm_nt(const Go1PpoGemmArgs* a, void* stream) {
 
 // ================================================================================================ weight gradients
 // dW[n][k] += sum_m dZ[m][n] H[m][k] ("TN": both operands are m-major, the reduction runs over the slow index).
-// Same skeleton as gemm_nt_kernel — 128 x 128 output tile, 4 waves of 64 x 64, 64 reduction rows per step, LDS-DMA
-// staging into two buffers — with the LDS image [m][128 columns] (256-B rows) read through ds_read_b64_tr_b16: a
-// 16-lane group hands the hardware a [4 m][16 columns] block and every lane receives the 4 m-values of ITS column,
-// i.e. half an MFMA operand (the reduction-slot order only has to agree between the two operands, and it does).
-// A 256-B row is exactly one bank row, so the 8 rows a 32-lane group touches would all collide; the 16-B chunk index
-// is XOR-ed with 2 * ((m & 3) | ((m >> 3) & 1) << 2) on the DMA source address, which spreads them over 8 distinct
-// 32-B slots.  The reduction is split over row chunks (the output has only (n/128)(k/128) tiles), partial tiles meet
-// in fp32 atomics on the gradient buffer itself; the bias gradient (column sums of dZ) is one more MFMA per fragment
-// against a fragment of ones, in the workgroups of the first column tile.  rows % 64 == 0, n % 8 == 0, k % 8 == 0.
+// One workgroup = 8 wavefronts = one 128 x 128 output tile over a chunk of rows, 64 reduction rows per step:
+//   * staging by LDS-DMA into FOUR buffers, three steps ahead of the MFMAs: a step's operands are 32 KB and the loaded
+//     latency under load is ~3000 cycles, so one step in flight (the two-buffer scheme of gemm_nt_kernel) leaves the
+//     matrix cores waiting two thirds of the time.  Waits are counted (s_waitcnt vmcnt(8 / 4 / 0): each wave has 4 DMA
+//     instructions per step) and the barrier is a raw s_barrier, so that younger steps stay in flight across it;
+//   * the LDS image is [m][128 columns] (256-B rows) read through ds_read_b64_tr_b16: a 16-lane group hands the
+//     hardware a [4 m][16 columns] block and every lane receives the 4 m-values of ITS column, i.e. half an MFMA
+//     operand (the reduction-slot order only has to agree between the two operands, and it does).  A 256-B row is
+//     exactly one bank row, so the 8 rows a 32-lane group touches would all collide; the 16-B chunk index is XOR-ed
+//     with 2 * ((m & 3) | ((m >> 3) & 1) << 2) on the DMA source address, which spreads them over 8 distinct 32-B
+//     slots (tools/probes/tr_bank_probe.hip: same rate as a contiguous image);
+//   * each wave owns 64 (n) x 32 (k): 4 x 2 accumulators of v_mfma_f32_16x16x32_bf16;
+//   * the reduction is split over row chunks (the output has only (n/128)(k/128) tiles); partial tiles meet in fp32
+//     atomics on the gradient buffer itself (~200 G atomic adds/s chip-wide, which is why chunks are as long as filling
+//     the machine once allows); the bias gradient (column sums of dZ) is one more MFMA per fragment against a fragment
+//     of ones, in the workgroups of the first column tile.
+// rows % 64 == 0, n % 8 == 0, k % 8 == 0.
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* lds_base, int byte_off) {
-  typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
-  const char* p = reinterpret_cast<const char*>(lds_base) + byte_off;
-  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p));
-  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 4 * 256));
-  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-  s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+// The transpose reads are issued as inline asm: for loads the compiler can see, it drains the LDS-DMA queue (vmcnt(0))
+// before the first read that follows a DMA into the same array, which would serialise the pipeline.  The price: the
+// LDS counter is waited for by hand (lds_wait), with the fragment registers passed through the wait so that no consumer
+// can be scheduled above it.
+template <int OFF>
+__device__ __forceinline__ s16x4_t lds_tr(uint32_t addr) {
+  s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+struct TnFrags { s16x4_t lo[6], hi[6]; };                        // 4 dZ fragments + 2 H fragments, two 4-row halves each
+template <int KK>
+__device__ __forceinline__ void tn_read(TnFrags& f, const uint32_t (&aa)[4], const uint32_t (&ab)[2]) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    f.lo[i] = lds_tr<KK * 32 * 256>(aa[i]);
+    f.hi[i] = lds_tr<KK * 32 * 256 + 4 * 256>(aa[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    f.lo[4 + i] = lds_tr<KK * 32 * 256>(ab[i]);
+    f.hi[4 + i] = lds_tr<KK * 32 * 256 + 4 * 256>(ab[i]);
+  }
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(TnFrags& f) {
+  asm volatile("s_waitcnt lgkmcnt(%12)"
+               : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.lo[2]), "+v"(f.hi[2]), "+v"(f.lo[3]), "+v"(f.hi[3]),
+                 "+v"(f.lo[4]), "+v"(f.hi[4]), "+v"(f.lo[5]), "+v"(f.hi[5])
+               : "n"(N));
+}
+__device__ __forceinline__ bf16x8_t tn_operand(const TnFrags& f, int i) {
+  s16x8_t v = __builtin_shufflevector(f.lo[i], f.hi[i], 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
 #define WTN_T 128            // output tile edge
 #define WTN_STEP 64          // reduction rows per step
+#define WTN_BUFS 4           // LDS buffers: WTN_BUFS - 1 steps in flight
+#define WTN_THREADS 512
 
 __device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf16_t* Q, int ldq, int64_t m_begin, int steps,
                                               float* C, int ldc, float* bias_grad, int N, int K, int n0, int k0,
                                               bf16_t (*lds)[2][WTN_STEP * WTN_T]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // ---- staging: wave w moves row blocks (4 rows of 256 B each) 4w .. 4w+3 of both operand tiles
-  const bf16_t* gp[4];
-  const bf16_t* gq[4];
+  // ---- staging: wave w moves row blocks (4 rows of 256 B each) 2w, 2w+1 of both operand tiles
+  const bf16_t* gp[2];
+  const bf16_t* gq[2];
 #pragma unroll
-  for (int p = 0; p < 4; p++) {
-    const int row = (wave * 4 + p) * 4 + (lane >> 4);
+  for (int p = 0; p < 2; p++) {
+    const int row = (wave * 2 + p) * 4 + (lane >> 4);
     const int chunk = (lane & 15) ^ (2 * ((row & 3) | (((row >> 3) & 1) << 2)));
     int cn = n0 + chunk * 8, ck = k0 + chunk * 8;
     cn = cn < N ? cn : N - 8;                                    // columns past the matrix: any legal address will do
@@ -190,11 +227,12 @@ __device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf
     gp[p] = P + (m_begin + row) * ldp + cn;
     gq[p] = Q + (m_begin + row) * ldq + ck;
   }
-  auto stage = [&](int buf, int64_t step) {
+  auto stage = [&](int step) {                                   // 4 DMA instructions per wave
+    const int buf = step & (WTN_BUFS - 1);
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-      glds16(gp[p] + step * WTN_STEP * ldp, &lds[buf][0][(wave * 4 + p) * 4 * WTN_T]);
-      glds16(gq[p] + step * WTN_STEP * ldq, &lds[buf][1][(wave * 4 + p) * 4 * WTN_T]);
+    for (int p = 0; p < 2; p++) {
+      glds16(gp[p] + (int64_t)step * WTN_STEP * ldp, &lds[buf][0][(wave * 2 + p) * 4 * WTN_T]);
+      glds16(gq[p] + (int64_t)step * WTN_STEP * ldq, &lds[buf][1][(wave * 2 + p) * 4 * WTN_T]);
     }
   };
   // ---- fragment addresses (bytes inside one operand tile): lane (g = lane >> 4, i = lane & 15) supplies the piece
@@ -202,46 +240,64 @@ __device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf
   const int g = lane >> 4, i16 = lane & 15;
   const int rowoff = (g * 8 + (i16 >> 2)) * 256 + ((i16 & 3) >> 1) * 16 + (i16 & 1) * 8;
   const int swb = 32 * ((i16 >> 2) | ((g & 1) << 2));
-  const int wn = wave >> 1, wk = wave & 1;
-  int fa[4], fb[4];
+  const int wn = wave >> 2, wk = wave & 3;                        // 64 (n) x 32 (k) per wave
+  int fa[4], fb[2];
 #pragma unroll
-  for (int f = 0; f < 4; f++) {
-    fa[f] = rowoff + (((wn * 64 + f * 16) * 2) ^ swb);
-    fb[f] = rowoff + (((wk * 64 + f * 16) * 2) ^ swb);
-  }
-  f32x4 acc[4][4], bacc[4];
+  for (int f = 0; f < 4; f++) fa[f] = rowoff + (((wn * 64 + f * 16) * 2) ^ swb);
+#pragma unroll
+  for (int f = 0; f < 2; f++) fb[f] = rowoff + (((wk * 32 + f * 16) * 2) ^ swb);
+  f32x4 acc[4][2], bacc[4];
 #pragma unroll
   for (int a = 0; a < 4; a++) {
     bacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int b = 0; b < 4; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < 2; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const bool do_bias = bias_grad && k0 == 0 && wk == 0;
-  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
   const s16x8_t ones_bits = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_bits);
 
-  stage(0, 0);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)&lds[0][0][0];
+#pragma unroll
+  for (int s = 0; s < WTN_BUFS - 1; s++)
+    if (s < steps) stage(s);
   for (int s = 0; s < steps; s++) {
-    const int buf = s & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (s + 1 < steps) stage(buf ^ 1, s + 1);
+    // step s has landed once at most the DMAs of the younger steps in flight (4 per step and wave) are outstanding
+    const int younger = steps - 1 - s;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                // everyone's part of step s is in LDS, step s-1 is consumed
+    asm volatile("" ::: "memory");
+    if (s + WTN_BUFS - 1 < steps) stage(s + WTN_BUFS - 1);       // into the buffer step s-1 used
+    const uint32_t base = lds0 + (uint32_t)(s & (WTN_BUFS - 1)) * (2 * WTN_STEP * WTN_T * 2);
+    uint32_t aa[4], ab[2];
 #pragma unroll
-    for (int kk = 0; kk < 2; kk++) {
-      bf16x8_t za[4], hb[4];
+    for (int f = 0; f < 4; f++) aa[f] = base + fa[f];
 #pragma unroll
-      for (int f = 0; f < 4; f++) za[f] = tr_frag(&lds[buf][0][0], fa[f] + kk * 32 * 256);
+    for (int f = 0; f < 2; f++) ab[f] = base + WTN_STEP * WTN_T * 2 + fb[f];
+    TnFrags f0, f1;
+    tn_read<0>(f0, aa, ab);
+    tn_read<1>(f1, aa, ab);
+    lds_wait<12>(f0);                                            // LDS returns in order: the first 12 reads are back
 #pragma unroll
-      for (int f = 0; f < 4; f++) hb[f] = tr_frag(&lds[buf][1][0], fb[f] + kk * 32 * 256);
+    for (int a = 0; a < 4; a++)
 #pragma unroll
-      for (int a = 0; a < 4; a++)
+      for (int b = 0; b < 2; b++)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tn_operand(f0, a), tn_operand(f0, 4 + b), acc[a][b], 0, 0, 0);
+    if (do_bias) {
 #pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[a], hb[b], acc[a][b], 0, 0, 0);
-      if (do_bias) {
+      for (int a = 0; a < 4; a++) bacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tn_operand(f0, a), ones, bacc[a], 0, 0, 0);
+    }
+    lds_wait<0>(f1);
 #pragma unroll
-        for (int a = 0; a < 4; a++) bacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[a], ones, bacc[a], 0, 0, 0);
-      }
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tn_operand(f1, a), tn_operand(f1, 4 + b), acc[a][b], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+      for (int a = 0; a < 4; a++) bacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tn_operand(f1, a), ones, bacc[a], 0, 0, 0);
     }
   }
   // ---- lane holds D[n = 4g + e][k = i16] of each fragment pair
@@ -252,8 +308,8 @@ __device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf
       const int n = n0 + wn * 64 + a * 16 + 4 * g + e;
       if (n >= N) continue;
 #pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const int k = k0 + wk * 64 + b * 16 + i16;
+      for (int b = 0; b < 2; b++) {
+        const int k = k0 + wk * 32 + b * 16 + i16;
         if (k < K) atomicAdd(C + (int64_t)n * ldc + k, acc[a][b][e]);
       }
       if (do_bias && i16 == 0) atomicAdd(bias_grad + n, bacc[a][e]);
@@ -267,8 +323,8 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 }
 
 // every weight gradient of a backward pass in ONE launch (problem table built by go1ppo_wgrad_tn_plan)
-__global__ __launch_bounds__(256, 2) void wgrad_tn_batched_kernel(const Go1PpoWgradProblem* __restrict__ probs, int count) {
-  __shared__ __attribute__((aligned(1024))) bf16_t lds[2][2][WTN_STEP * WTN_T];
+__global__ __launch_bounds__(WTN_THREADS, 1) void wgrad_tn_batched_kernel(const Go1PpoWgradProblem* __restrict__ probs, int count) {
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[WTN_BUFS][2][WTN_STEP * WTN_T];
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   int p = 0;
   while (p + 1 < count && wg >= probs[p + 1].wg_offset) p++;
@@ -284,33 +340,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_batched_kernel(const Go1PpoWg
 
 extern "C" int go1ppo_wgrad_tn_plan(Go1PpoWgradProblem* probs, int count) {
   if (!probs || count <= 0) return -1;
-  int64_t tile_steps = 0;
+  int64_t tile_steps = 0, tiles = 0;
   for (int i = 0; i < count; i++) {
     Go1PpoWgradProblem& P = probs[i];
     if (!P.dz || !P.h || !P.dW || P.rows <= 0 || (P.rows % WTN_STEP) || P.n < 8 || P.k < 8 || (P.n & 7) || (P.k & 7) ||
         (P.ld_dz & 7) || (P.ld_h & 7) || !aligned16(P.dz) || !aligned16(P.h))
       return -1;
-    tile_steps += (int64_t)((P.n + WTN_T - 1) / WTN_T) * ((P.k + WTN_T - 1) / WTN_T) * (P.rows / WTN_STEP);
+    const int64_t t = (int64_t)((P.n + WTN_T - 1) / WTN_T) * ((P.k + WTN_T - 1) / WTN_T);
+    tiles += t;
+    tile_steps += t * (P.rows / WTN_STEP);
   }
-  // every partial tile costs 16384 fp32 atomics (~200 G/s on the whole chip), so the launch is cut into as few workgroups
-  // as fill the machine once: two workgroups are resident per CU -> ~512, each at least 4 reduction steps long
-  int64_t chunk_steps = (tile_steps + 511) / 512;
+  // every partial tile costs 16384 fp32 atomics, so chunks are long: one workgroup per CU and round, as few rounds as
+  // give each workgroup <= 96 steps (the atomics of one round hide behind the MFMAs of the next)
+  const int64_t cus = 256;
+  int64_t rounds = (tile_steps + cus * 96 - 1) / (cus * 96);
+  if (rounds < 1) rounds = 1;
+  int64_t chunk_steps = (tile_steps + cus * rounds - 1) / (cus * rounds);
   if (chunk_steps < 4) chunk_steps = 4;
-  int total = 0;
-  for (int i = 0; i < count; i++) {
-    Go1PpoWgradProblem& P = probs[i];
-    const int64_t steps = P.rows / WTN_STEP;
-    const int64_t cs = chunk_steps < steps ? chunk_steps : steps;
-    const int64_t S = (steps + cs - 1) / cs;
-    P.chunk_rows = (int32_t)(cs * WTN_STEP);
-    P.wg_offset = total;
-    total += (int)S * ((P.n + WTN_T - 1) / WTN_T) * ((P.k + WTN_T - 1) / WTN_T);
+  for (;; chunk_steps++) {                                       // smallest chunk whose launch fits `rounds` full rounds
+    int total = 0;
+    for (int i = 0; i < count; i++) {
+      Go1PpoWgradProblem& P = probs[i];
+      const int64_t steps = P.rows / WTN_STEP;
+      const int64_t S0 = (steps + chunk_steps - 1) / chunk_steps;  // splits, then equalise the chunks
+      const int64_t cs = (steps + S0 - 1) / S0;
+      P.chunk_rows = (int32_t)(cs * WTN_STEP);
+      P.wg_offset = total;
+      total += (int)((steps + cs - 1) / cs) * ((P.n + WTN_T - 1) / WTN_T) * ((P.k + WTN_T - 1) / WTN_T);
+    }
+    if (total <= cus * rounds || chunk_steps >= 4096) return total;
   }
-  return total;
 }
 
 extern "C" int go1ppo_wgrad_tn_batched(const Go1PpoWgradProblem* device_probs, int count, int total_workgroups, void* stream) {
   if (!device_probs || count <= 0 || total_workgroups <= 0) return -1;
-  wgrad_tn_batched_kernel<<<dim3((unsigned)total_workgroups), dim3(256), 0, (hipStream_t)stream>>>(device_probs, count);
+  wgrad_tn_batched_kernel<<<dim3((unsigned)total_workgroups), dim3(WTN_THREADS), 0, (hipStream_t)stream>>>(device_probs, count);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
