@@ -227,13 +227,13 @@ __device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf
     gp[p] = P + (m_begin + row) * ldp + cn;
     gq[p] = Q + (m_begin + row) * ldq + ck;
   }
-  auto stage = [&](int step) {                                   // 4 DMA instructions per wave
+  auto stage_piece = [&](int step, int p, int op) {              // one of the wave's 4 DMA instructions of a step
     const int buf = step & (WTN_BUFS - 1);
-#pragma unroll
-    for (int p = 0; p < 2; p++) {
-      glds16(gp[p] + (int64_t)step * WTN_STEP * ldp, &lds[buf][0][(wave * 2 + p) * 4 * WTN_T]);
-      glds16(gq[p] + (int64_t)step * WTN_STEP * ldq, &lds[buf][1][(wave * 2 + p) * 4 * WTN_T]);
-    }
+    if (op == 0) glds16(gp[p] + (int64_t)step * WTN_STEP * ldp, &lds[buf][0][(wave * 2 + p) * 4 * WTN_T]);
+    else glds16(gq[p] + (int64_t)step * WTN_STEP * ldq, &lds[buf][1][(wave * 2 + p) * 4 * WTN_T]);
+  };
+  auto stage = [&](int step) {
+    stage_piece(step, 0, 0); stage_piece(step, 0, 1); stage_piece(step, 1, 0); stage_piece(step, 1, 1);
   };
   // ---- fragment addresses (bytes inside one operand tile): lane (g = lane >> 4, i = lane & 15) supplies the piece
   // (row 8g + (i >> 2) [+4 for the upper half, +32 per k-half], 8 bytes at column 16 f + 4 (i & 3)) of fragment f
@@ -269,26 +269,33 @@ __device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                // everyone's part of step s is in LDS, step s-1 is consumed
     asm volatile("" ::: "memory");
-    if (s + WTN_BUFS - 1 < steps) stage(s + WTN_BUFS - 1);       // into the buffer step s-1 used
+    const bool more = s + WTN_BUFS - 1 < steps;                  // DMA of step s+3 goes into the buffer step s-1 used
+    const int nxt = s + WTN_BUFS - 1;
     const uint32_t base = lds0 + (uint32_t)(s & (WTN_BUFS - 1)) * (2 * WTN_STEP * WTN_T * 2);
     uint32_t aa[4], ab[2];
 #pragma unroll
     for (int f = 0; f < 4; f++) aa[f] = base + fa[f];
 #pragma unroll
     for (int f = 0; f < 2; f++) ab[f] = base + WTN_STEP * WTN_T * 2 + fb[f];
+    // order inside a step: all fragment reads first (LDS latency then runs under the DMA issue, which is the slow part:
+    // every wave of the CU queues on the one texture path), the DMA pieces spread between the MFMA groups
     TnFrags f0, f1;
     tn_read<0>(f0, aa, ab);
     tn_read<1>(f1, aa, ab);
+    if (more) { stage_piece(nxt, 0, 0); stage_piece(nxt, 0, 1); }
     lds_wait<12>(f0);                                            // LDS returns in order: the first 12 reads are back
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < 4; a++) {
 #pragma unroll
       for (int b = 0; b < 2; b++)
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tn_operand(f0, a), tn_operand(f0, 4 + b), acc[a][b], 0, 0, 0);
+      if (a == 1 && more) stage_piece(nxt, 1, 0);
+    }
     if (do_bias) {
 #pragma unroll
       for (int a = 0; a < 4; a++) bacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tn_operand(f0, a), ones, bacc[a], 0, 0, 0);
     }
+    if (more) stage_piece(nxt, 1, 1);
     lds_wait<0>(f1);
 #pragma unroll
     for (int a = 0; a < 4; a++)
