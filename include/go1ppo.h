@@ -175,6 +175,33 @@ int go1ppo_gemm_nt(const Go1PpoGemmArgs* args, void* stream);
 int go1ppo_wgrad_tn_plan(Go1PpoWgradProblem* problems, int count);
 int go1ppo_wgrad_tn_batched(const Go1PpoWgradProblem* device_problems, int count, int total_workgroups, void* stream);
 
+/* ---- the 256 -> 128 -> 64 end of an MLP with both weight matrices resident in LDS (csrc/go1ppo_mlp.h) ----
+ * Replaces, per net, F.elu + nn.Linear + F.elu + nn.Linear of actor_critic.py:51-92 (forward) and their autograd
+ * backward up to the gradient w.r.t. the 256-wide pre-activation.  Up to GO1PPO_MLP2_MAX_NETS nets per launch. */
+#define GO1PPO_MLP2_MAX_NETS 3
+typedef struct {
+  void* x;                     /* bf16 [rows][ld_x], 256 columns: pre-activations, replaced IN PLACE by elu(x) when
+                                  elu_input != 0; already activated inputs otherwise */
+  const void* W2; const void* b2;   /* bf16 [128][256], bf16 [128] */
+  const void* W3; const void* b3;   /* bf16 [64][128], bf16 [64] */
+  void* z2;                    /* out: bf16 [rows][ld_z2], elu(h0 W2^T + b2), 128 columns */
+  void* out;                   /* out: bf16 [rows][ld_out], z2 W3^T + b3, 64 columns */
+  int64_t rows;
+  int32_t ld_x, ld_z2, ld_out, elu_input;
+} Go1PpoMlp2Fwd;
+int go1ppo_mlp2_fwd(const Go1PpoMlp2Fwd* nets, int count, void* stream);
+
+typedef struct {
+  const void* d_out;           /* bf16 [rows][ld_dout], 64 columns: gradient w.r.t. the head output */
+  const void* z2; const void* h;    /* the forward pass's z2 (128 columns) and activated input elu(x) (256 columns) */
+  const void* W2; const void* W3;
+  void* d_z2;                  /* out: bf16 [rows][ld_dz2] = (d_out W3) * elu'(z2) */
+  void* d_x;                   /* out: bf16 [rows][ld_dx] = (d_z2 W2) * elu'(h): gradient w.r.t. the pre-activation x */
+  int64_t rows;
+  int32_t ld_dout, ld_z2, ld_h, ld_dz2, ld_dx, _pad;
+} Go1PpoMlp2Bwd;
+int go1ppo_mlp2_bwd(const Go1PpoMlp2Bwd* nets, int count, void* stream);
+
 const char* go1ppo_version(void);
 
 #ifdef __cplusplus

@@ -98,6 +98,51 @@ def test_wgrad_matches_fp32_matmul(lib, M, n, k, ld_dz, ld_h):
     assert lib.go1ppo_wgrad(dz.data_ptr(), ld_dz, h.data_ptr(), ld_h, M, 48, k, out.data_ptr(), k, None, stream()) == -1
 
 
+@pytest.mark.parametrize("M", [24576, 1000])
+def test_mlp2_forward_and_backward_match_fp32_torch(lib, M):
+    """the LDS-resident 256 -> 128 -> 64 kernels, two nets per launch with different strides, vs fp32 torch on the same
+    bf16 weights / inputs.  Intermediate activations are rounded to bf16 in both (the reference below rounds where the
+    kernel stores), so the comparison is 1-2 bf16 ulp of each tensor's scale."""
+    import ctypes
+    from go1_gym_learn.ppo_cse import fused
+    g = torch.Generator(device="cuda").manual_seed(M)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    F = torch.nn.functional
+    nets, fw, bw, keep = [], (fused.Mlp2Fwd * 2)(), (fused.Mlp2Bwd * 2)(), []
+    for i, (ld_x, elu_input) in enumerate(((1280, 1), (256, 0))):
+        xbuf = bf(rn(M, ld_x) * 1.5)
+        x = xbuf[:, ld_x - 256:]                                  # a column block of a wider matrix
+        W2, b2, W3, b3 = bf(rn(128, 256) / 16), bf(rn(128) * 0.1), bf(rn(64, 128) / 11), bf(rn(64) * 0.1)
+        z2, out = torch.zeros(M, 128, device="cuda", dtype=torch.bfloat16), torch.full((M, 64 + 8), 3.0, device="cuda", dtype=torch.bfloat16)
+        d_out = bf(rn(M, 64))
+        d_z2, d_xbuf = torch.zeros(M, 128, device="cuda", dtype=torch.bfloat16), torch.full((M, 320), 5.0, device="cuda", dtype=torch.bfloat16)
+        x0 = x.float().clone()
+        P, Q = fw[i], bw[i]
+        P.x, P.W2, P.b2, P.W3, P.b3, P.z2, P.out = x.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(), z2.data_ptr(), out.data_ptr()
+        P.rows, P.ld_x, P.ld_z2, P.ld_out, P.elu_input = M, ld_x, 128, 72, elu_input
+        Q.d_out, Q.z2, Q.h, Q.W2, Q.W3, Q.d_z2, Q.d_x = d_out.data_ptr(), z2.data_ptr(), x.data_ptr(), W2.data_ptr(), W3.data_ptr(), d_z2.data_ptr(), d_xbuf.data_ptr()
+        Q.rows, Q.ld_dout, Q.ld_z2, Q.ld_h, Q.ld_dz2, Q.ld_dx = M, 64, 128, ld_x, 128, 320
+        keep.append((xbuf, x, x0, W2, b2, W3, b3, z2, out, d_out, d_z2, d_xbuf, elu_input))
+    assert lib.go1ppo_mlp2_fwd(fw, 2, stream()) == 0
+    assert lib.go1ppo_mlp2_bwd(bw, 2, stream()) == 0
+    torch.cuda.synchronize()
+    ulp = 2.0 ** -8
+    close = lambda a, b, scale: torch.testing.assert_close(a.float(), b, rtol=2 * ulp, atol=2 * ulp * scale)
+    for xbuf, x, x0, W2, b2, W3, b3, z2, out, d_out, d_z2, d_xbuf, elu_input in keep:
+        h0 = bf(F.elu(x0)).float() if elu_input else x0
+        close(x, h0, 1.0)                                         # activated in place (or untouched)
+        z2_ref = F.elu(h0 @ W2.float().t() + b2.float())
+        close(z2, z2_ref, 1.0)
+        out_ref = z2.float() @ W3.float().t() + b3.float()        # from the kernel's own (bf16-rounded) hidden layer
+        close(out[:, :64], out_ref, 1.0)
+        assert torch.all(out[:, 64:] == 3.0)
+        dz2_ref = (d_out.float() @ W3.float()) * torch.where(z2.float() > 0, 1.0, z2.float() + 1.0)
+        close(d_z2, dz2_ref, float(dz2_ref.abs().max()) / 4)
+        dx_ref = (d_z2.float() @ W2.float()) * torch.where(x.float() > 0, 1.0, x.float() + 1.0)
+        close(d_xbuf[:, :256], dx_ref, float(dx_ref.abs().max()) / 4)
+        assert torch.all(d_xbuf[:, 256:] == 5.0)
+
+
 def test_wgrad_tn_batched_matches_fp32_matmul(lib):
     """the 128-tile weight-gradient kernel (LDS-DMA + transpose reads), several problems of different shapes in one
     launch: first-layer sized (k = 2112: the last column tile is half empty), tails, a 64-row head, strided operands."""
@@ -419,10 +464,17 @@ def block_errors(pol, ga, gb):
     return out
 
 
-def test_fused_minibatch_gradients_match_autograd():
+@pytest.mark.parametrize("engine", ["fused_tails", "mlp2", "per_layer"])
+def test_fused_minibatch_gradients_match_autograd(engine, monkeypatch):
     """Same weights, same storage, same mini-batch: the hand-scheduled backward must produce the autograd gradient
-    (both bf16 pipelines) for the PPO stage and for the adaptation stage."""
+    (both bf16 pipelines) for the PPO stage and for the adaptation stage — for each of the three engines the MLP
+    tails can run on (one fused forward kernel for small batches; the LDS-resident 256->128->64 kernels, forward and
+    backward, for large ones; plain per-layer GEMM + ELU launches)."""
     from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    if engine != "fused_tails":
+        monkeypatch.setenv("GO1_FUSED_TAILS_MAX_ROWS", "0")
+    if engine == "per_layer":
+        monkeypatch.setenv("GO1_MLP2", "0")
     N, T = 1024, 8
     algs = []
     for fused_on in (False, True):
@@ -442,6 +494,7 @@ def test_fused_minibatch_gradients_match_autograd():
     idx = torch.randperm(N * T, device="cuda")[:mb]
     from go1_gym_learn.ppo_cse.fused import FusedNet
     fus._train_net = FusedNet(fus.policy, fus.body, fus.master.grad[:fus.n_body], mb, fus._fused_lib, with_grad=True)
+    assert fus._train_net._mlp2 == (engine == "mlp2") and (fus._train_net._tails is not None) == (engine == "fused_tails")
     for stage in ("_stage_ppo_backward", "_stage_adapt_backward"):
         for alg in (ref, fus):
             alg._acc.zero_()
@@ -462,11 +515,13 @@ def test_fused_minibatch_gradients_match_autograd():
         assert float(fus.master.grad[:n].norm()) > 0
 
 
-@pytest.mark.parametrize("use_graphs", [False, True])
-def test_fused_update_tracks_autograd_update(use_graphs):
+@pytest.mark.parametrize("use_graphs,engine", [(False, "fused_tails"), (True, "fused_tails"), (False, "mlp2"), (True, "mlp2")])
+def test_fused_update_tracks_autograd_update(use_graphs, engine, monkeypatch):
     """Two full update() calls (5 epochs x 4 mini-batches each, Adam, adaptive LR): the fused path stays close to the
     autograd path — same losses to 2 %, same learning-rate trajectory, same weight trajectory within bf16 noise."""
     from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    if engine == "mlp2":
+        monkeypatch.setenv("GO1_FUSED_TAILS_MAX_ROWS", "0")
     N, T = 512, 8
     res, saved = [], {}
     for fused_on in (False, True):

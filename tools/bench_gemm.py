@@ -91,6 +91,25 @@ def main():
     for n, k, ld_dz, ld_h in ((1280, 2112, 1280, 2112), (256, 2112, 256, 2112), (256, 512, 256, 1280), (128, 256, 128, 256),
                               (64, 128, 64, 128), (512, 64, 1280, 64)):
         one(n, k, ld_dz, ld_h)
+    print("\nLDS-resident 256 -> 128 -> 64 tails (us per launch)")
+    for nets in (1, 2, 3):
+        sets = []
+        for _ in range(R):
+            fw, bw, keep = (fused.Mlp2Fwd * nets)(), (fused.Mlp2Bwd * nets)(), []
+            for i in range(nets):
+                x = torch.randn(M, 256, **bf); W2 = torch.randn(128, 256, **bf) / 16; b2 = torch.randn(128, **bf); W3 = torch.randn(64, 128, **bf) / 11
+                b3 = torch.randn(64, **bf); z2 = torch.zeros(M, 128, **bf); out = torch.zeros(M, 64, **bf); d_out = torch.randn(M, 64, **bf)
+                d_z2 = torch.zeros(M, 128, **bf); d_x = torch.zeros(M, 256, **bf)
+                P, Q = fw[i], bw[i]
+                P.x, P.W2, P.b2, P.W3, P.b3, P.z2, P.out = x.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(), z2.data_ptr(), out.data_ptr()
+                P.rows, P.ld_x, P.ld_z2, P.ld_out, P.elu_input = M, 256, 128, 64, 1
+                Q.d_out, Q.z2, Q.h, Q.W2, Q.W3, Q.d_z2, Q.d_x = d_out.data_ptr(), z2.data_ptr(), x.data_ptr(), W2.data_ptr(), W3.data_ptr(), d_z2.data_ptr(), d_x.data_ptr()
+                Q.rows, Q.ld_dout, Q.ld_z2, Q.ld_h, Q.ld_dz2, Q.ld_dx = M, 64, 128, 256, 128, 256
+                keep.append((x, W2, b2, W3, b3, z2, out, d_out, d_z2, d_x))
+            sets.append((fw, bw, keep))
+        tf = timeit([(lambda q=q: lib.go1ppo_mlp2_fwd(q[0], nets, s)) for q in sets])
+        tb = timeit([(lambda q=q: lib.go1ppo_mlp2_bwd(q[1], nets, s)) for q in sets])
+        print(f"  {nets} net(s): forward {tf:7.1f}   backward {tb:7.1f}")
 
 
 if __name__ == "__main__":

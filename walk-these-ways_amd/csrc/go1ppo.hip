@@ -754,6 +754,7 @@ extern "C" int go1ppo_wgrad(const void* dz, int ld_dz, const void* h, int ld_h, 
 }
 
 #include "go1ppo_gemm.h"
+#include "go1ppo_mlp.h"
 
 extern "C" int go1ppo_act(const void* mean, const void* value, int head_ld, const float* std, int num_actions, int64_t rows,
                           const float* noise, float* actions, float* mu, float* sigma, float* values, float* logp, void* stream) {

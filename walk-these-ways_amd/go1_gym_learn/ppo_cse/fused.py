@@ -59,13 +59,26 @@ class TailArgs(ctypes.Structure):
     _fields_ = [("num_nets", ctypes.c_int32), ("_pad", ctypes.c_int32), ("net", TailNet * 3)]
 
 
+class Mlp2Fwd(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("x", "W2", "b2", "W3", "b3", "z2", "out")] + [("rows", ctypes.c_int64)] + \
+               [(n, ctypes.c_int32) for n in ("ld_x", "ld_z2", "ld_out", "elu_input")]
+
+
+class Mlp2Bwd(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("d_out", "z2", "h", "W2", "W3", "d_z2", "d_x")] + [("rows", ctypes.c_int64)] + \
+               [(n, ctypes.c_int32) for n in ("ld_dout", "ld_z2", "ld_h", "ld_dz2", "ld_dx", "_pad")]
+
+
+MLP2_DIMS = (256, 128, 64)
+
+
 class GemmArgs(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
                 ("H", ctypes.c_void_p)] + [(n, ctypes.c_int32) for n in
                                            ("M", "N", "K", "lda", "ldb", "ldc", "ldh", "epilogue", "elu_c0", "elu_c1")]
 
 
-EXPORTED_SYMBOLS = ["go1ppo_gemm_nt", "go1ppo_wgrad_tn_plan", "go1ppo_wgrad_tn_batched", "go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
+EXPORTED_SYMBOLS = ["go1ppo_mlp2_fwd", "go1ppo_mlp2_bwd", "go1ppo_gemm_nt", "go1ppo_wgrad_tn_plan", "go1ppo_wgrad_tn_batched", "go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
                     "go1ppo_wgrad_batched", "go1ppo_act",
                     "go1ppo_store_step", "go1ppo_gae", "go1ppo_normalize", "go1ppo_opt_partials", "go1ppo_opt_prestep",
                     "go1ppo_opt_adam", "go1ppo_version"]
@@ -90,6 +103,8 @@ def load_library(path=None):
     L.go1ppo_wgrad_plan.argtypes = [ctypes.POINTER(WgradProblem), i32]
     L.go1ppo_tail_fwd.argtypes = [ctypes.POINTER(TailArgs), vp]
     L.go1ppo_gemm_nt.argtypes = [ctypes.POINTER(GemmArgs), vp]
+    L.go1ppo_mlp2_fwd.argtypes = [ctypes.POINTER(Mlp2Fwd), i32, vp]
+    L.go1ppo_mlp2_bwd.argtypes = [ctypes.POINTER(Mlp2Bwd), i32, vp]
     L.go1ppo_wgrad_batched.argtypes = [vp, i32, i32, vp]
     L.go1ppo_wgrad_tn_plan.argtypes = [ctypes.POINTER(WgradProblem), i32]
     L.go1ppo_wgrad_tn_batched.argtypes = [vp, i32, i32, vp]
@@ -181,12 +196,19 @@ class FusedNet:
         # measured on MI355X: one fused launch per dependency level beats 8 GEMMs + 5 ELU kernels 3.5x at M = 4096
         # (rollout inference: 32 vs 110 us) but only ties hipBLASLt + the two-stream schedule at M = 24576
         if fused_tails is None:
-            fused_tails = M <= 8192
+            fused_tails = M <= int(os.environ.get("GO1_FUSED_TAILS_MAX_ROWS", "8192"))     # (tests lower it to reach the other engine)
         if fused_tails and self._fused_tails_ok():
             nd, na = self.nd, self.na
             self._tails = (self._tail_args([("adaptation", self.Y1[:, :nd])], with_grad),
                            self._tail_args([("actor", self.Y1[:, nd:nd + na]), ("critic", self.Y1[:, nd + na:])], with_grad))
             self._tails_ad = self._tail_args([("adaptation", self.Y1d)], with_grad)
+        # large batches: the last two layers of every net (256 -> 128 -> 64) on the LDS-resident kernels of
+        # csrc/go1ppo_mlp.h, forward and backward (GO1_MLP2=0 switches back to per-layer GEMM + ELU launches)
+        self._mlp2 = (self._tails is None and os.environ.get("GO1_MLP2", "1") == "1" and self.nd == MLP2_DIMS[0] and
+                      all(self.depth[n] >= 3 and tuple(self.P[f"{n}.{self.depth[n] - 2}.W"].shape) == (MLP2_DIMS[1], MLP2_DIMS[0])
+                          and tuple(self.P[f"{n}.{self.depth[n] - 1}.W"].shape) == (MLP2_DIMS[2], MLP2_DIMS[1]) for n in self.depth)
+                      and self.depth["adaptation"] == 3 and self.depth["actor"] == 4 and self.depth["critic"] == 4)
+        self._mlp2_cache = {}
         # the critic's tail is independent of the actor / adaptation chain: it runs on a side stream (forked from and
         # joined back into the caller's stream, so HIP-graph capture records it as a parallel branch)
         self._side = torch.cuda.Stream(device=dev) if two_streams else None
@@ -263,6 +285,8 @@ class FusedNet:
         """x: (M, Kp) augmented rows.  Returns (mean (M, HEAD), value (M, HEAD), latent (M, HEAD)) padded head
         outputs (valid columns: num_actions / 1 / num_privileged_obs); views of static buffers."""
         nd, na = self.nd, self.na
+        if self._mlp2:
+            return self._forward_mlp2(x)
         torch.mm(x, self.P["W1"].t(), out=self.Y1)
         self._elu(self.Y1[:, :nd])
         if self._tails is not None:               # fused MLP tails: one launch per dependency level
@@ -280,6 +304,87 @@ class FusedNet:
         self._join()
         return mean, value, latent
 
+    # ---- LDS-resident 256 -> 128 -> 64 ends ------------------------------------------------------------------------
+    def _mlp2_fwd(self, key, items):
+        """items: [(net, x)] with x the 256-wide PRE-activation in front of the net's last two layers (activated in place)."""
+        key = ("fwd", key)
+        if key not in self._mlp2_cache:
+            arr = (Mlp2Fwd * len(items))()
+            for a, (net, x) in zip(arr, items):
+                d = self.depth[net]
+                W2, W3, z2, out = self.P[f"{net}.{d - 2}.W"], self.P[f"{net}.{d - 1}.W"], self.Z[net][d - 2], self.Z[net][d - 1]
+                a.x, a.W2, a.b2, a.W3, a.b3 = x.data_ptr(), W2.data_ptr(), self.P[f"{net}.{d - 2}.b"].data_ptr(), W3.data_ptr(), self.P[f"{net}.{d - 1}.b"].data_ptr()
+                a.z2, a.out, a.rows, a.ld_x, a.ld_z2, a.ld_out, a.elu_input = z2.data_ptr(), out.data_ptr(), x.shape[0], _ld(x), _ld(z2), _ld(out), 1
+            self._mlp2_cache[key] = (arr, len(items))
+        arr, n = self._mlp2_cache[key]
+        _chk(self.lib.go1ppo_mlp2_fwd(arr, n, _stream()), "go1ppo_mlp2_fwd")
+
+    def _mlp2_bwd(self, key, items):
+        """items: [(net, h, d_x)]: h = the activated 256-wide input of the last two layers, d_x = where the gradient w.r.t.
+        its pre-activation goes.  Reads dZ[net][last], writes dZ[net][last - 1] and d_x."""
+        key = ("bwd", key)
+        if key not in self._mlp2_cache:
+            arr = (Mlp2Bwd * len(items))()
+            for a, (net, h, d_x) in zip(arr, items):
+                d = self.depth[net]
+                d_out, z2, d_z2 = self.dZ[net][d - 1], self.Z[net][d - 2], self.dZ[net][d - 2]
+                a.d_out, a.z2, a.h, a.W2, a.W3 = d_out.data_ptr(), z2.data_ptr(), h.data_ptr(), self.P[f"{net}.{d - 2}.W"].data_ptr(), self.P[f"{net}.{d - 1}.W"].data_ptr()
+                a.d_z2, a.d_x, a.rows = d_z2.data_ptr(), d_x.data_ptr(), h.shape[0]
+                a.ld_dout, a.ld_z2, a.ld_h, a.ld_dz2, a.ld_dx = _ld(d_out), _ld(z2), _ld(h), _ld(d_z2), _ld(d_x)
+            self._mlp2_cache[key] = (arr, len(items))
+        arr, n = self._mlp2_cache[key]
+        _chk(self.lib.go1ppo_mlp2_bwd(arr, n, _stream()), "go1ppo_mlp2_bwd")
+
+    def _forward_mlp2(self, x):
+        P, Z, nd, na = self.P, self.Z, self.nd, self.na
+        torch.mm(x, P["W1"].t(), out=self.Y1)
+        self._mlp2_fwd("adaptation", [("adaptation", self.Y1[:, :nd])])
+        latent = Z["adaptation"][2]
+        self._elu(self.Y1[:, nd:], latent, na)
+        with self._branch():
+            torch.addmm(P["critic.1.b"], self.Y1[:, nd + na:], P["critic.1.W"].t(), out=Z["critic"][1])
+        torch.addmm(P["actor.1.b"], self.Y1[:, nd:nd + na], P["actor.1.W"].t(), out=Z["actor"][1])
+        self._join()
+        self._mlp2_fwd("ac", [("actor", Z["actor"][1]), ("critic", Z["critic"][1])])
+        return Z["actor"][3], Z["critic"][3], latent
+
+    def _backward_mlp2(self, x):
+        nd, na = self.nd, self.na
+        P, G, Z, dZ, Y1, dY1, dH1 = self.P, self.G, self.Z, self.dZ, self.Y1, self.dY1, self.dH1
+        cols = {"adaptation": slice(0, nd), "actor": slice(nd, nd + na), "critic": slice(nd + na, self.n1)}
+        self._mlp2_bwd("ac", [("actor", Z["actor"][1], dZ["actor"][1]), ("critic", Z["critic"][1], dZ["critic"][1])])
+        for net in ("actor", "critic"):                     # the loss kernel already produced the heads' bias gradients
+            self._wgrad(dZ[net][3], Z[net][2], G[f"{net}.3.W"], None)
+            self._wgrad(dZ[net][2], Z[net][1], G[f"{net}.2.W"], G[f"{net}.2.b"])
+            self._wgrad(dZ[net][1], Y1[:, cols[net]], G[f"{net}.1.W"], G[f"{net}.1.b"])
+        with self._branch():
+            torch.mm(dZ["critic"][1], P["critic.1.W"], out=dH1["critic"])
+            self._elu_bwd(dH1["critic"], Y1[:, cols["critic"]], None, out=dY1[:, cols["critic"]])
+        torch.mm(dZ["actor"][1], P["actor.1.W"], out=dH1["actor"])
+        self._elu_bwd(dH1["actor"], Y1[:, cols["actor"]], None, out=dY1[:, cols["actor"]])
+        # actor first layer's latent columns: a1 += latent Wz^T
+        latent, dlat = Z["adaptation"][2], dZ["adaptation"][2]
+        dA1 = dY1[:, cols["actor"]]
+        self._wgrad(dA1, latent, G["Wz"])
+        torch.mm(dA1, P["Wz"], out=dlat)
+        self._mlp2_bwd("adaptation", [("adaptation", Y1[:, :nd], dY1[:, :nd])])
+        self._wgrad(dlat, Z["adaptation"][1], G["adaptation.2.W"], G["adaptation.2.b"])
+        self._wgrad(dZ["adaptation"][1], Y1[:, :nd], G["adaptation.1.W"], G["adaptation.1.b"])
+        self._join()
+        self._big_wgrad(dY1, x, G["W1"], self._w1_tmp, self._w1_tn[0])
+
+    def _forward_adaptation_mlp2(self, x):
+        torch.mm(x, self.P["W1"][:self.nd].t(), out=self.Y1d)
+        self._mlp2_fwd("adaptation_only", [("adaptation", self.Y1d)])
+        return self.Z["adaptation"][2]
+
+    def _backward_adaptation_mlp2(self, x):
+        nd, d, G, Z, dZ = self.nd, self.dH1["adaptation"], self.G, self.Z, self.dZ
+        self._mlp2_bwd("adaptation_only", [("adaptation", self.Y1d, d)])
+        self._wgrad(dZ["adaptation"][2], Z["adaptation"][1], G["adaptation.2.W"], None)     # head bias: the MSE kernel's
+        self._wgrad(dZ["adaptation"][1], self.Y1d, G["adaptation.1.W"], G["adaptation.1.b"])
+        self._big_wgrad(d, x, G["W1"][:nd], self._w1_tmp[:nd], self._w1_tn[1])
+
     # ---- two-stream helpers ------------------------------------------------------------------------------------
     def _branch(self):
         """context: work issued inside runs on the side stream, ordered after everything issued so far."""
@@ -294,6 +399,8 @@ class FusedNet:
             torch.cuda.current_stream().wait_stream(self._side)
 
     def forward_adaptation(self, x):
+        if self._mlp2:
+            return self._forward_adaptation_mlp2(x)
         torch.mm(x, self.P["W1"][:self.nd].t(), out=self.Y1d)
         self._elu(self.Y1d)
         if self._tails_ad is not None:
@@ -358,10 +465,10 @@ class FusedNet:
 
     def backward(self, x):
         # the plan holds device pointers: one per input block (graph mode feeds a different pre-gathered block per mini-batch)
-        self._run_planned(("ppo", x.data_ptr()), lambda: self._backward(x))
+        self._run_planned(("ppo", x.data_ptr()), lambda: (self._backward_mlp2 if self._mlp2 else self._backward)(x))
 
     def backward_adaptation(self, x):
-        self._run_planned(("adaptation", x.data_ptr()), lambda: self._backward_adaptation(x))
+        self._run_planned(("adaptation", x.data_ptr()), lambda: (self._backward_adaptation_mlp2 if self._mlp2 else self._backward_adaptation)(x))
 
     def _backward(self, x):
         """After forward(x) and a loss kernel that filled dZ[actor][last], dZ[critic][last] (+ their bias / std
