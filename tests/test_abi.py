@@ -105,6 +105,22 @@ def test_ppo_wgrad_problem_mirror_matches_header():
     assert C.sizeof(fused.WgradProblem) == 72
 
 
+@pytest.mark.parametrize("cname,mirror,size", [("Go1PpoGemmArgs", "GemmArgs", 80), ("Go1PpoMlp2Fwd", "Mlp2Fwd", 80), ("Go1PpoMlp2Bwd", "Mlp2Bwd", 88)])
+def test_ppo_new_struct_mirrors_match_header(cname, mirror, size):
+    """field order and size of the ctypes mirrors of the GEMM / LDS-resident MLP argument structs."""
+    import ctypes as C
+    from go1_gym_learn.ppo_cse import fused
+    src = re.sub(r"/\*.*?\*/", "", open(PPO_HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct(?: \w+)? \{([^}]*?)\} %s;" % cname, src, flags=re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            names += [n.strip().lstrip("*") for n in re.sub(r"^(const\s+)?\w+\s*\*?", "", decl, count=1).split(",")]
+    assert names == [f[0] for f in getattr(fused, mirror)._fields_]
+    assert C.sizeof(getattr(fused, mirror)) == size
+
+
 def test_fused_update_fails_loudly_without_library(tmp_path):
     from go1_gym_learn.ppo_cse import fused
     with pytest.raises(fused.Go1PpoLibraryMissing):
