@@ -148,7 +148,7 @@ def gemm_args(a, b, c, bias=None, elu=None, elu_bwd_of=None):
     g = GemmArgs()
     g.A, g.B, g.C, g.bias, g.H = a.data_ptr(), b.data_ptr(), c.data_ptr(), _ptr(bias), _ptr(elu_bwd_of)
     g.M, g.N, g.K, g.lda, g.ldb, g.ldc = a.shape[0], b.shape[0], a.shape[1], _ld(a), _ld(b), _ld(c)
-    assert b.shape[1] == g.K and c.shape == (g.M, g.N) and elu is None or elu_bwd_of is None
+    assert b.shape[1] == g.K and tuple(c.shape) == (g.M, g.N) and (elu is None or elu_bwd_of is None)
     assert a.dtype == b.dtype == c.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.float32)
     if elu_bwd_of is not None:
         assert elu_bwd_of.shape == c.shape and elu_bwd_of.dtype == torch.bfloat16
