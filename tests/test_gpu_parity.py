@@ -108,18 +108,19 @@ def test_physics_substep_matches_oracle(scenario):
         assert float(Bc.contact_forces.abs().max()) > 1.0
 
 
-@pytest.mark.parametrize("variant", ["train_noise", "alt"])
-def test_full_step_matches_oracle(variant):
-    N = 512
-    cfg, S, meta, Bc, orc = gpu_pair(variant, N, seed=11)
+def run_full_step_comparison(variant, N, steps, seed=11):
+    """HIP step vs oracle step on identical state / action / RNG streams, re-synchronised after every step so that each
+    step is compared on its own (a free-running pair diverges through contact-mode flips, as two fp32 PhysX runs
+    would).  Returns (worst, mean) fraction of environments outside the per-quantity tolerances, and event counts."""
+    cfg, S, meta, Bc, orc = gpu_pair(variant, N, seed=seed)
     Bg, sim = to_gpu(S, Bc)
     rng = np.random.default_rng(0)
     Bc.episode_length_buf[:] = torch.randint(0, S.max_episode_length, (N,), dtype=torch.int32, generator=torch.Generator().manual_seed(2))
     sync_from(Bc, Bg, sim, orc)
     resets = 0
     resamples = 0
-    worst = 0.0
-    for step in range(40):
+    worst, total_bad, timeouts = 0.0, 0.0, 0
+    for step in range(steps):
         a = (rng.standard_normal((N, 12)) * (1.0 if step % 2 else 0.3)).astype(np.float32)
         if step == 20:
             a[:] = 12.0          # action clipping
@@ -144,13 +145,32 @@ def test_full_step_matches_oracle(variant):
         bad, _ = frac_bad(Bg.obs_history, Bc.obs_history, 3e-3, 1e-3)
         bad_env |= bad.any(1)
         worst = max(worst, float(bad_env.float().mean()))
+        total_bad += float(bad_env.float().mean())
+        timeouts += int(Bc.time_out_buf.sum())
         np.testing.assert_array_equal(Bg.env_command_bins.cpu().numpy()[~bad_env.numpy()], Bc.env_command_bins.numpy()[~bad_env.numpy()])
         np.testing.assert_allclose(Bg.curriculum_weights.cpu().numpy(), Bc.curriculum_weights.numpy(), atol=0.21 * float(bad_env.sum()) + 1e-6)
         resets += int(cpu_reset.sum())
         resamples += int((cmd_before != Bc.commands).any(0).sum())
         sync_from(Bc, Bg, sim, orc)
+    return worst, total_bad / steps, resets, resamples, timeouts
+
+
+@pytest.mark.parametrize("variant", ["train_noise", "alt"])
+def test_full_step_matches_oracle(variant):
+    worst, mean, resets, resamples, _ = run_full_step_comparison(variant, 512, 40)
     assert resets > 20 and resamples > 20      # resets and interval resamples were exercised
     assert worst <= 0.02, worst
+
+
+def test_thousand_steps_match_oracle():
+    """1000 consecutive policy steps (4000 physics substeps, a full episode length: time-outs, gravity
+    impulses, DR refreshes, curriculum updates and command resampling all occur) of the HIP kernel against the oracle
+    on identical streams, per-step tolerances of test_full_step_matches_oracle."""
+    worst, mean, resets, resamples, timeouts = run_full_step_comparison("train_noise", 128, 1000, seed=5)
+    assert resets > 100 and resamples > 100 and timeouts > 0, (resets, resamples, timeouts)
+    assert mean <= 0.01 and worst <= 0.05, (mean, worst)
+
+
 
 
 def rough_field(rows=240, cols=240, amp=0.08, seed=0, hscale=0.1, vscale=0.005):
