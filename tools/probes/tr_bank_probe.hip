@@ -1,5 +1,8 @@
 // LDS read throughput by instruction, address pattern and waves per CU: each wave issues REPS x 16 reads;
 // prints LDS cycles per wave-instruction = elapsed / (REPS * 16 * waves).
+// build + run on the GPU box: hipcc --offload-arch=gfx950 -O2 tr_bank_probe.hip -o tr_bank_probe && ./tr_bank_probe
+// (measured: the wgrad_tn / mlp2 swizzled images read at the same rate as a contiguous image; 256-byte rows
+//  without swizzle 2.4x slower at 8 waves)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef __attribute__((ext_vector_type(4))) short s4;

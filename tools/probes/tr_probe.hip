@@ -1,5 +1,6 @@
 // ds_read_b64_tr_b16 lane mapping probe: lds[i] = i; lane l (g = l >> 4, i = l & 15) supplies the address of the 4-element
 // piece (row 4g + (i >> 2), columns 4 (i & 3) ..) of a [16][128] image; prints what every lane receives.
+// build + run on the GPU box: hipcc --offload-arch=gfx950 -O2 tr_probe.hip -o tr_probe && ./tr_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef __attribute__((ext_vector_type(4))) short s4;
