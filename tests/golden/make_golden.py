@@ -360,11 +360,66 @@ def gen_ppo(seed=3):
     print("ppo losses", losses, "lr", alg.learning_rate)
 
 
+def gen_ppo_rma(seed=4):
+    """reference go1_gym_learn.ppo (the older teacher-student runner): compute_returns + PPO.update on a fixed rollout."""
+    ml = types.ModuleType("ml_logger")
+    ml.logger = object()
+    sys.modules["ml_logger"] = ml
+    from go1_gym_learn.ppo.actor_critic import ActorCritic, AC_Args
+    from go1_gym_learn.ppo.ppo import PPO, PPO_Args
+    AC_Args.actor_hidden_dims = [32, 16]
+    AC_Args.critic_hidden_dims = [24, 16]
+    AC_Args.adaptation_module_branch_hidden_dims = [[16, 8]]
+    AC_Args.env_factor_encoder_branch_input_dims = [5]
+    AC_Args.env_factor_encoder_branch_latent_dims = [4]
+    AC_Args.env_factor_encoder_branch_hidden_dims = [[12, 8]]
+    N, T, no, npv, H, na = 20, 6, 10, 5, 3, 12
+    torch.manual_seed(seed)
+    ac = ActorCritic(no, npv, no * H, na)
+    init = {k: v.clone() for k, v in ac.state_dict().items()}
+    alg = PPO(ac, device="cpu")
+    alg.init_storage(N, T, [no], [npv], [no * H], [na])
+    st = alg.storage
+    g = torch.Generator().manual_seed(seed + 1)
+    r = lambda *s: torch.randn(*s, generator=g)
+    st.observations.copy_(r(T, N, no)); st.privileged_observations.copy_(r(T, N, npv))
+    st.observation_histories.copy_(r(T, N, no * H)); st.actions.copy_(r(T, N, na))
+    st.rewards.copy_(0.1 * r(T, N, 1)); st.dones.copy_((torch.rand(T, N, 1, generator=g) < 0.1).byte())
+    st.values.copy_(r(T, N, 1)); st.mu.copy_(st.actions + 0.3 * r(T, N, na)); st.sigma.fill_(1.0)
+    st.actions_log_prob.copy_((-0.5 * (st.actions - st.mu) ** 2 - 0.9189385).sum(-1, keepdim=True))
+    st.env_bins.zero_()
+    st.step = T
+    last_values = r(N, 1)
+    rec = {"in_" + k: getattr(st, k).clone() for k in ("observations", "privileged_observations", "observation_histories",
+                                                        "actions", "rewards", "dones", "values", "mu", "sigma", "actions_log_prob")}
+    st.compute_returns(last_values, PPO_Args.gamma, PPO_Args.lam)
+    rec["out_returns"], rec["out_advantages"] = st.returns.clone(), st.advantages.clone()
+    # the rollout surface on fixed inputs: teacher / student means and the value (deterministic parts of act())
+    probe_obs, probe_priv, probe_hist = r(7, no), r(7, npv), r(7, no * H)
+    with torch.no_grad():
+        rec["probe_obs"], rec["probe_priv"], rec["probe_hist"] = probe_obs, probe_priv, probe_hist
+        rec["probe_teacher"] = ac.act_teacher(probe_obs, probe_priv)
+        rec["probe_student"] = ac.act_student(probe_obs, probe_hist)
+        rec["probe_value"] = ac.evaluate(probe_obs, probe_priv)
+    torch.manual_seed(seed + 2)
+    losses = alg.update()
+    out = {"init_" + k: v for k, v in init.items()}
+    out.update({"final_" + k: v.clone() for k, v in ac.state_dict().items()})
+    out.update(rec)
+    out.update(last_values=last_values, losses=torch.tensor(losses), final_lr=torch.tensor(alg.learning_rate),
+               dims=torch.tensor([N, T, no, npv, H, na]), seed=torch.tensor(seed))
+    np.savez_compressed(os.path.join(HERE, "ppo_rma.npz"), **flat(out))
+    print("ppo (teacher-student runner) losses", losses, "lr", alg.learning_rate)
+
+
 if __name__ == "__main__":
     install_stubs()
     torch.manual_seed(0)
     gen_curriculum()
     gen_ppo()
+    for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+        del sys.modules[m]
+    gen_ppo_rma()
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     gen_heights()

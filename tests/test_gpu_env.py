@@ -118,6 +118,41 @@ def test_runner_learns_and_exports(tmp_path):
     PPO_Args.autocast_bf16 = False
 
 
+def test_teacher_student_runner_on_the_hip_env(tmp_path):
+    """the older go1_gym_learn.ppo runner (privileged-latent teacher + adaptation-module student, plain PyTorch) drives the
+    same HIP environment: two iterations, checkpoint / TorchScript export under the reference's file names."""
+    from go1_gym_learn.ppo import Runner, RunnerArgs
+    from go1_gym_learn.ppo.actor_critic import AC_Args
+    from ml_logger import logger
+    logger.configure("run_rma", root=str(tmp_path))
+    logger.print_summary = False
+    old = (AC_Args.env_factor_encoder_branch_input_dims, AC_Args.env_factor_encoder_branch_latent_dims, RunnerArgs.save_interval,
+           RunnerArgs.log_freq, RunnerArgs.save_video_interval)
+    env, cfg = build_env(128)
+    AC_Args.env_factor_encoder_branch_input_dims = [env.num_privileged_obs]
+    AC_Args.env_factor_encoder_branch_latent_dims = [4]
+    RunnerArgs.save_interval, RunnerArgs.log_freq, RunnerArgs.save_video_interval = 1, 1, 0
+    os.chdir(tmp_path)
+    try:
+        runner = Runner(env, device="cuda:0")
+        w0 = [p.detach().clone() for p in runner.alg.actor_critic.parameters()]
+        runner.learn(num_learning_iterations=2, init_at_random_ep_len=True, eval_freq=100)
+    finally:
+        (AC_Args.env_factor_encoder_branch_input_dims, AC_Args.env_factor_encoder_branch_latent_dims, RunnerArgs.save_interval,
+         RunnerArgs.log_freq, RunnerArgs.save_video_interval) = old
+    w1 = list(runner.alg.actor_critic.parameters())
+    assert any(not torch.equal(a, b) for a, b in zip(w0, w1)) and all(torch.isfinite(p).all() for p in w1)
+    ck = tmp_path / "run_rma" / "checkpoints"
+    sd = torch.load(ck / "ac_weights_last.pt")
+    assert sd["actor_body.0.weight"].shape == (512, 70 + 4) and sd["encoder.0.weight"].shape == (256, env.num_privileged_obs)
+    body = torch.jit.load(str(ck / "body_latest.jit"))
+    adapt = torch.jit.load(str(ck / "adaptation_module_latest.jit"))
+    assert body(torch.cat((torch.randn(3, 70), adapt(torch.randn(3, 2100))), dim=-1)).shape == (3, 12)
+    policy = runner.get_inference_policy(device="cuda:0")
+    od = env.get_observations()
+    assert policy(od).shape == (128, 12)
+
+
 def test_graph_replay_update_equals_eager_update():
     """The HIP-graph replay of the mini-batch step must produce exactly what the eager launches produce
     (autograd path: deterministic kernels; the fused path accumulates with atomics and is compared with a

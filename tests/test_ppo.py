@@ -127,3 +127,82 @@ def test_storage_returns_are_in_place():
     st.compute_returns(torch.randn(6, 1), 0.99, 0.95)
     assert st.advantages.data_ptr() == pa and st.returns.data_ptr() == pr
     assert abs(float(st.advantages.mean())) < 1e-6 and abs(float(st.advantages.std()) - 1.0) < 1e-4
+
+
+# ---- the older teacher-student runner (go1_gym_learn.ppo) ----------------------------------------
+@pytest.fixture()
+def small_rma_args():
+    from go1_gym_learn.ppo.actor_critic import AC_Args
+    keys = ("actor_hidden_dims", "critic_hidden_dims", "adaptation_module_branch_hidden_dims", "env_factor_encoder_branch_input_dims",
+            "env_factor_encoder_branch_latent_dims", "env_factor_encoder_branch_hidden_dims")
+    old = {k: getattr(AC_Args, k) for k in keys}
+    AC_Args.actor_hidden_dims, AC_Args.critic_hidden_dims = [32, 16], [24, 16]
+    AC_Args.adaptation_module_branch_hidden_dims = [[16, 8]]
+    AC_Args.env_factor_encoder_branch_input_dims, AC_Args.env_factor_encoder_branch_latent_dims = [5], [4]
+    AC_Args.env_factor_encoder_branch_hidden_dims = [[12, 8]]
+    yield
+    for k, v in old.items():
+        setattr(AC_Args, k, v)
+
+
+def test_teacher_student_runner_matches_reference(small_rma_args):
+    """tests/golden/ppo_rma.npz: the REFERENCE go1_gym_learn.ppo classes (executed by make_golden.py) on a fixed rollout —
+    same state_dict keys, same teacher / student / value outputs, same returns, losses, learning rate and weights
+    after PPO.update()."""
+    from go1_gym_learn.ppo import ActorCritic
+    from go1_gym_learn.ppo.ppo import PPO, PPO_Args
+    d = np.load(os.path.join(GOLDEN, "ppo_rma.npz"))
+    N, T, no, npv, H, na = [int(x) for x in d["dims"]]
+    ac = ActorCritic(no, npv, no * H, na)
+    init = {k[5:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("init_")}
+    assert sorted(init) == sorted(ac.state_dict())                 # incl. the `encoder.*` alias of the env-factor encoder
+    ac.load_state_dict(init)
+    with torch.no_grad():
+        obs, priv, hist = (torch.from_numpy(d[k]) for k in ("probe_obs", "probe_priv", "probe_hist"))
+        np.testing.assert_allclose(ac.act_teacher(obs, priv).numpy(), d["probe_teacher"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ac.act_student(obs, hist).numpy(), d["probe_student"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ac.evaluate(obs, priv).numpy(), d["probe_value"], rtol=1e-5, atol=1e-6)
+        info = {}
+        ac.act_inference({"obs": obs, "privileged_obs": priv, "obs_history": hist}, policy_info=info)
+        assert info["gt_latents"].shape == (7, 4)      # (the student latent goes to act_student's own default dict, as upstream)
+    alg = PPO(ac, device="cpu")
+    alg.init_storage(N, T, [no], [npv], [no * H], [na])
+    st = alg.storage
+    for k in ("observations", "privileged_observations", "observation_histories", "actions", "rewards", "dones", "values", "mu", "sigma",
+              "actions_log_prob"):
+        getattr(st, k).copy_(torch.from_numpy(d["in_" + k]))
+    st.step = T
+    st.compute_returns(torch.from_numpy(d["last_values"]), PPO_Args.gamma, PPO_Args.lam)
+    np.testing.assert_allclose(st.returns.numpy(), d["out_returns"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st.advantages.numpy(), d["out_advantages"], rtol=1e-5, atol=1e-5)
+    torch.manual_seed(int(d["seed"]) + 2)                          # same randperm as the reference run
+    losses = alg.update()
+    np.testing.assert_allclose(losses, d["losses"], rtol=2e-4, atol=1e-6)
+    assert alg.learning_rate == pytest.approx(float(d["final_lr"]), rel=1e-6)
+    for k, v in ac.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), d["final_" + k], rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+def test_teacher_student_rollout_surface():
+    """act / process_env_step / compute_returns / update through the public surface, with the time-out bootstrap."""
+    from go1_gym_learn.ppo import ActorCritic, RunnerArgs, caches, class_to_dict
+    from go1_gym_learn.ppo.ppo import PPO, PPO_Args
+    torch.manual_seed(0)
+    ac = ActorCritic(70, 18, 2100, 12)
+    alg = PPO(ac)
+    alg.init_storage(8, 4, [70], [18], [2100], [12])
+    for t in range(4):
+        o, p, h = torch.randn(8, 70), torch.randn(8, 18), torch.randn(8, 2100)
+        a = alg.act(o, p, h)
+        assert a.shape == (8, 12)
+        values = alg.transition.values.clone()
+        rew = torch.randn(8)
+        time_outs = torch.tensor([1, 0, 0, 0, 0, 0, 0, 1], dtype=torch.bool)
+        alg.process_env_step(rew, time_outs.byte(), {"env_bins": torch.zeros(8), "time_outs": time_outs})
+        expect = rew + PPO_Args.gamma * values[:, 0] * time_outs
+        torch.testing.assert_close(alg.storage.rewards[t, :, 0], expect)
+    alg.compute_returns(o, p)
+    losses = alg.update()
+    assert len(losses) == 3 and all(np.isfinite(losses)) and alg.storage.step == 0
+    assert "sysid_residual" in caches.slot_cache.get_summary()
+    assert class_to_dict(RunnerArgs)["num_steps_per_env"] == 24
