@@ -67,16 +67,34 @@ __global__ __launch_bounds__(256) void elu_fwd_kernel(bf16_t* y, int rows, int c
 #pragma unroll
     for (int e = 0; e < 8; e++) x[u][e] = bf2f(v[u].v[e]);
   if (LAT && c0 < lat_cols) {
-    for (int q = 0; q < npv; q++) {
-      float w[8];
+    if (npv == 2) {                      // the train.py configuration: both latent columns in one 4-byte load
+      float w0[8], w1[8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) w[e] = bf2f(wz[(int64_t)(c0 + e) * wz_ld + q]);
+      for (int e = 0; e < 8; e++) {
+        const uint32_t p = *reinterpret_cast<const uint32_t*>(wz + (int64_t)(c0 + e) * wz_ld);
+        w0[e] = __uint_as_float(p << 16);
+        w1[e] = __uint_as_float(p & 0xffff0000u);
+      }
 #pragma unroll
       for (int u = 0; u < ELU_ROWS; u++) {
         int r = r0 + u * 16;
-        float l = r < rows ? bf2f(lat[(int64_t)r * lat_ld + q]) : 0.f;
+        const uint32_t p = r < rows ? *reinterpret_cast<const uint32_t*>(lat + (int64_t)r * lat_ld) : 0u;
+        const float l0 = __uint_as_float(p << 16), l1 = __uint_as_float(p & 0xffff0000u);
 #pragma unroll
-        for (int e = 0; e < 8; e++) x[u][e] = fmaf(l, w[e], x[u][e]);
+        for (int e = 0; e < 8; e++) x[u][e] = fmaf(l1, w1[e], fmaf(l0, w0[e], x[u][e]));
+      }
+    } else {
+      for (int q = 0; q < npv; q++) {
+        float w[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) w[e] = bf2f(wz[(int64_t)(c0 + e) * wz_ld + q]);
+#pragma unroll
+        for (int u = 0; u < ELU_ROWS; u++) {
+          int r = r0 + u * 16;
+          float l = r < rows ? bf2f(lat[(int64_t)r * lat_ld + q]) : 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; e++) x[u][e] = fmaf(l, w[e], x[u][e]);
+        }
       }
     }
   }
@@ -692,7 +710,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 extern "C" int go1ppo_elu_fwd(void* y, int64_t rows, int cols, int ld, const void* lat, int lat_ld, int npv, const void* wz,
                               int wz_ld, int lat_cols, void* stream) {
   if (!y || rows <= 0 || cols <= 0 || (cols & 7) || (ld & 7) || !aligned16(y)) return -1;
-  if (lat && (!wz || npv <= 0 || (lat_cols & 7))) return -2;
+  if (lat && (!wz || npv <= 0 || (lat_cols & 7) || (npv == 2 && ((lat_ld | wz_ld) & 1 || ((uintptr_t)lat | (uintptr_t)wz) & 3)))) return -2;
   if (rows > INT32_MAX) return -1;
   dim3 grid((unsigned)(((cols >> 3) + 15) / 16), (unsigned)((rows + 16 * ELU_ROWS - 1) / (16 * ELU_ROWS)));
   if (lat)
