@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--every", type=int, default=20)
     ap.add_argument("--fp32", action="store_true")
+    ap.add_argument("--check-finite", action="store_true", help="after every iteration: first non-finite tensor among "
+                    "observations / rewards / actions / returns / parameters / gradients, then stop")
     args = ap.parse_args()
     from bench import build_env
     from go1_gym_learn.ppo_cse import Runner, RunnerArgs
@@ -41,12 +43,68 @@ def main():
             for _ in range(T):
                 ep_before = env.episode_length_buf.clone()
                 obs_dict, infos = runner._rollout_step(obs_dict)
+                if args.check_finite and not torch.isfinite(env.rew_buf).all():
+                    base = env
+                    while not hasattr(base, "buffers"):
+                        base = base.env
+                    B = base.buffers
+                    e = int((~torch.isfinite(env.rew_buf)).nonzero()[0])
+                    print(f"it {it + 1}: non-finite reward from the simulator, env {e}, reward {float(env.rew_buf[e])}", flush=True)
+                    names = list(base.episode_sum_names)
+                    for k, t in B.tensors.items():
+                        if t is None or not t.is_floating_point() or t.shape[-1] != env.num_envs:
+                            continue
+                        col = t.reshape(-1, env.num_envs)[:, e].float().cpu()
+                        if not torch.isfinite(col).all():
+                            bad = (~torch.isfinite(col)).nonzero().flatten().tolist()
+                            label = [names[i] if k in ("episode_sums", "command_sums") and i < len(names) else i for i in bad]
+                            print(f"    {k}: non-finite rows {label}", flush=True)
+                    for k in ("root_states", "commands", "contact_forces", "foot_positions", "foot_velocities", "dof_pos", "dof_vel", "torques",
+                              "last_actions", "gait_indices", "desired_contact_states", "episode_length_buf"):
+                        t = B.tensors.get(k)
+                        if t is not None:
+                            print(f"    {k} = {[round(float(v), 4) for v in t.reshape(-1, env.num_envs)[:, e].float().cpu()]}", flush=True)
+                    return
                 done = env.reset_buf.bool()
                 acc[0] += env.rew_buf.sum(); acc[1] += n
                 acc[2] += done.sum(); acc[3] += (done & env.time_out_buf).sum()
                 ep_len_sum += (ep_before[done] + 1).sum()
             runner.alg.compute_returns(obs_dict["obs_history"][:n], obs_dict["privileged_obs"][:n])
+        if args.check_finite:
+            st = runner.alg.storage
+            pre = {k: getattr(st, k) for k in ("observation_histories", "privileged_observations", "actions", "rewards", "values", "returns",
+                                               "advantages", "mu", "sigma", "actions_log_prob")}
+            bad = [k for k, t in pre.items() if not torch.isfinite(t.float()).all()]
+            if bad:
+                print(f"it {it + 1}: non-finite BEFORE the update in storage fields {bad}; master finite: "
+                      f"{bool(torch.isfinite(runner.alg.master).all())}", flush=True)
+                for k in bad:
+                    t = pre[k].float()
+                    nz = (~torch.isfinite(t)).nonzero()
+                    print("   ", k, tuple(t.shape), "first bad index", nz[0].tolist(), "count", len(nz), flush=True)
+                return
         losses = runner.alg.update()
+        if args.check_finite:
+            alg = runner.alg
+            if not torch.isfinite(alg.master).all() or not all(map(lambda v: v == v, losses)):
+                n = alg.n_body
+                names = []
+                for name, _ in alg.policy.blocks:
+                    blk = alg.policy._block(alg.master[:n], name)
+                    if not torch.isfinite(blk).all():
+                        names.append(name)
+                print(f"it {it + 1}: non-finite AFTER the update; losses {losses}; parameter blocks {names}; std finite "
+                      f"{bool(torch.isfinite(alg.std).all())}", flush=True)
+                net = alg._train_net
+                if net is not None:
+                    for label, t in (("Y1", net.Y1), ("dY1", net.dY1), ("Y1d", net.Y1d)):
+                        print("   ", label, "finite:", bool(torch.isfinite(t.float()).all()), flush=True)
+                    for nname, zs in net.Z.items():
+                        for li, z in zs.items():
+                            if not torch.isfinite(z.float()).all() or not torch.isfinite(net.dZ[nname][li].float()).all():
+                                print("   ", nname, li, "Z finite", bool(torch.isfinite(z.float()).all()), "dZ finite",
+                                      bool(torch.isfinite(net.dZ[nname][li].float()).all()), flush=True)
+                return
         if (it + 1) % args.every == 0:
             a = acc.tolist()
             print(f"it {it + 1:4d}  mean step reward {a[0] / a[1]:8.5f}  mean ep len {float(ep_len_sum) / max(a[2], 1):7.1f}  "

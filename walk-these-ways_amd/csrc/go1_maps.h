@@ -477,9 +477,9 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int b = 1 + 4 * leg + i;
-    if ((cfg.termination_body_mask & (1u << b)) && rin.cfn[i] > 1.0f) term = 1.f;
+    if ((cfg.termination_body_mask & (1u << b)) && !(rin.cfn[i] <= 1.0f)) term = 1.f;      // (a NaN force terminates too)
   }
-  if (is0 && (cfg.termination_body_mask & 1u) && rin.cfn_base > 1.0f) term = 1.f;
+  if (is0 && (cfg.termination_body_mask & 1u) && !(rin.cfn_base <= 1.0f)) term = 1.f;
   bool reset = quad_sum(term) > 0.f;
   const bool time_out = ep_len > cfg.max_episode_length;
   reset = reset || time_out;
@@ -488,13 +488,18 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
 
   PROF(17);
   // ---- compute_reward ----------------------------------------------------------------------------------
+  // Failed-simulation guard: a term that is not finite (seen once per ~1e8 env-steps in long training runs, source not yet
+  // located — DESIGN.md §2) counts as 0 and ends the episode, instead of poisoning the running sums, the curriculum
+  // statistics and, through the advantage normalisation, every other environment's gradient.
+  bool sim_failed = false;
   float rew = 0.f, pos = 0.f, neg = 0.f;
 #pragma unroll
   for (int id = 0; id < GO1_REW_COUNT; id++) {
     const int kx = plan.kx_by_id[id];
     if (kx >= 0) {                  // wave-uniform
       const float sc = plan.scale_by_id[id];
-      const float r = quad_sum(reward_partial(cfg, B, e, N, id, d, F, leg, rin)) * sc;
+      float r = quad_sum(reward_partial(cfg, B, e, N, id, d, F, leg, rin)) * sc;
+      if (!(fabsf(r) <= 3.0e38f)) { r = 0.f; sim_failed = true; }
       rew += r;
       if (reward_raw_sign(id) * sc >= 0) pos += r; else neg += r;
       if ((kx & 3) == leg) {      // running sums: fire-and-forget fp32 atomics (one writer per address, so the result is
@@ -507,6 +512,11 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
   }
   if (cfg.only_positive_rewards) rew = fmaxf(rew, 0.f);
   else if (cfg.only_positive_rewards_ji22_style) rew = pos * expf(neg / cfg.sigma_rew_neg);
+  if (!(fabsf(rew) <= 3.0e38f)) { rew = 0.f; sim_failed = true; }
+  if (sim_failed) {
+    reset = true;
+    if (is0) B.reset_buf[e] = 1;
+  }
   if (is0) {
     B.rew_buf[e] = rew;
     unsafeAtomicAdd(&AT(B.episode_sums, cfg.num_rewards, e), rew);
