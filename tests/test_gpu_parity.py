@@ -356,3 +356,27 @@ def test_full_size_invariants_4096():
     assert off == ((c % (H_ + 1)) + 1) % (H_ + 1) * no
     win = Bg.obs_history[:, off:off + H_ * no]
     assert torch.equal(win[:, -no:], Bg.obs_buf)
+
+
+def test_failed_simulation_guard():
+    """A non-finite reward input (here: a NaN in the previous joint velocity of one environment, which only the dof_acc
+    term reads) must not leave the kernel: the term counts as 0, the episode ends, every other environment and the
+    running sums stay untouched and finite."""
+    N = 64
+    cfg, S, meta, Bc, orc = gpu_pair("train_noise", N, seed=21)
+    Bg, sim = to_gpu(S, Bc)
+    Bref, sim_ref = to_gpu(S, Bc)
+    sync_from(Bc, Bg, sim, orc)
+    sync_from(Bc, Bref, sim_ref, orc)
+    victim = 37
+    Bg.last_dof_vel[4, victim] = float("nan")
+    a = torch.zeros(N, 12, device="cuda")
+    sim.step(a)
+    sim_ref.step(a)
+    torch.cuda.synchronize()
+    assert torch.isfinite(Bg.rew_buf).all() and torch.isfinite(Bg.episode_sums).all() and torch.isfinite(Bg.obs_buf).all()
+    assert int(Bg.reset_buf[victim]) == 1 and int(Bg.time_out_buf[victim]) == 0
+    assert int(Bg.episode_length_buf[victim]) == 0                                   # re-initialised in the same step
+    others = torch.arange(N, device="cuda") != victim
+    torch.testing.assert_close(Bg.rew_buf[others], Bref.rew_buf[others], rtol=0, atol=0)
+    assert torch.equal(Bg.reset_buf[others], Bref.reset_buf[others])
