@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GO1SIM_ABI_VERSION 2
+#define GO1SIM_ABI_VERSION 3
 
 #define GO1_NUM_DOF 12
 #define GO1_NUM_BODIES 17        /* base, then FL,FR,RL,RR x (hip, thigh, calf, foot) */
@@ -81,6 +81,27 @@ enum Go1PrivObsId {
   GO1_PRIV_DESIRED_CONTACT = 10,/* :486 */
   GO1_PRIV_COUNT = 11
 };
+
+/* Fault word: one bit per site that can make the simulation state non-finite.  The step kernel ORs the bits of an
+ * environment into fault_flags[e] (sticky until the caller clears it) and counts every occurrence in
+ * fault_counts[bit].  PhysX never hands back a non-finite state (legged_robot.py:76-80 reads it unchecked), so a
+ * non-zero word is a defect of THIS simulator, not a condition of the reference; the kernel contains it (the episode
+ * ends, nothing non-finite leaves the launch) and reports it here instead of hiding it. */
+enum Go1FaultBit {
+  GO1_FAULT_STATE_IN = 0,       /* root / joint state already non-finite when the step started */
+  GO1_FAULT_TORQUE = 1,         /* torque model output non-finite before the clip */
+  GO1_FAULT_BASE_PIVOT = 2,     /* Cholesky pivot of the base articulated inertia <= 1e-9 or non-finite */
+  GO1_FAULT_JOINT_D = 3,        /* joint-space articulated inertia D_j <= 1e-9 or non-finite */
+  GO1_FAULT_CONTACT_FRAME = 4,  /* contact normal parallel to the x axis: tangent basis undefined */
+  GO1_FAULT_W_DIAG = 5,         /* Delassus diagonal of an active contact <= 1e-9 or non-finite */
+  GO1_FAULT_LAMBDA = 6,         /* contact impulse non-finite after the PGS sweeps */
+  GO1_FAULT_STATE_OUT = 7,      /* root / joint state non-finite after a substep's integration */
+  GO1_FAULT_REWARD = 8,         /* a reward term or the total was non-finite (counted as 0, episode ended) */
+  GO1_FAULT_OBS = 9,            /* an observation column was non-finite (written as 0) */
+  GO1_FAULT_CONTACT_DROPPED = 10, /* more active contact points than solver slots: the excess was not solved (count only) */
+  GO1_FAULT_BITS = 16
+};
+#define GO1_FAULT_FATAL_MASK 0x3FFu   /* bits that mean "simulation failed" (everything except CONTACT_DROPPED) */
 
 /* Everything that the reference reads from `Cfg` on the hot path, flattened.
  * Filled by the host mirror of LeggedRobot._parse_cfg/_init_buffers
@@ -256,6 +277,9 @@ typedef struct Go1SimBuffers {
   float* obs_buf;                  /* (N, num_obs) */
   float* privileged_obs_buf;       /* (N, num_privileged_obs) */
   float* obs_history;              /* (N, 2*(H+1)*num_obs): ring of H+1 slots stored twice; window via go1sim_history_window_offset */
+  /* fault reporting (enum Go1FaultBit) */
+  uint32_t* fault_flags;           /* [N] sticky OR of the fault bits of each environment; cleared by the caller */
+  uint32_t* fault_counts;          /* [GO1_FAULT_BITS] occurrences per bit since the caller last zeroed it */
   /* terrain */
   const int16_t* height_samples;   /* (hf_rows, hf_cols) or NULL for plane */
   float* measured_heights;         /* [num_height_x*num_height_y][N] or NULL */

@@ -380,3 +380,43 @@ def test_failed_simulation_guard():
     others = torch.arange(N, device="cuda") != victim
     torch.testing.assert_close(Bg.rew_buf[others], Bref.rew_buf[others], rtol=0, atol=0)
     assert torch.equal(Bg.reset_buf[others], Bref.reset_buf[others])
+    # the containment is reported, not hidden: fault word of the victim, one count, nothing anywhere else
+    bit = 1 << H.abi.GO1_FAULT_REWARD
+    assert int(Bg.fault_flags[victim]) == bit and int(Bg.fault_flags[others].abs().sum()) == 0
+    assert Bg.fault_counts.tolist()[H.abi.GO1_FAULT_REWARD] >= 1 and int(Bref.fault_counts.sum()) == 0
+
+
+@pytest.mark.parametrize("where", ["root_z", "quat", "dof_vel", "base_ang_vel"])
+def test_failed_state_is_contained_and_reported(where):
+    """A non-finite STATE (injected; PhysX never produces one, legged_robot.py:76-80) is caught at the site, the
+    environment is re-initialised in the same launch and no buffer the policy or the logger reads keeps a non-finite
+    value; all other environments are bit-identical to an undisturbed run."""
+    N = 128
+    cfg, S, meta, Bc, orc = gpu_pair("train_noise", N, seed=23)
+    Bg, sim = to_gpu(S, Bc)
+    Bref, sim_ref = to_gpu(S, Bc)
+    for _ in range(3):
+        a = torch.zeros(N, 12, device="cuda")
+        sim.step(a); sim_ref.step(a)
+    victim = 77
+    {"root_z": lambda: Bg.root_states[2].__setitem__(victim, float("nan")),
+     "quat": lambda: Bg.root_states[4].__setitem__(victim, float("inf")),
+     "dof_vel": lambda: Bg.dof_vel[7].__setitem__(victim, float("nan")),
+     "base_ang_vel": lambda: Bg.root_states[11].__setitem__(victim, float("-inf"))}[where]()
+    for _ in range(3):
+        a = torch.zeros(N, 12, device="cuda")
+        sim.step(a); sim_ref.step(a)
+    torch.cuda.synchronize()
+    for k, t in Bg.tensors.items():
+        if t is not None and t.is_floating_point() and k != "episode_log":
+            assert torch.isfinite(t).all(), k
+    word = int(Bg.fault_flags[victim])
+    assert word & (1 << H.abi.GO1_FAULT_STATE_IN) and word & H.FAULT_FATAL_MASK
+    others = torch.arange(N, device="cuda") != victim
+    assert int(Bg.fault_flags[others].abs().sum()) == 0 and int(Bref.fault_counts.sum()) == 0
+    for k in ("root_states", "dof_pos", "obs_buf", "rew_buf"):
+        a_, b_ = Bg.tensors[k], Bref.tensors[k]
+        if a_.shape[-1] == N:
+            assert torch.equal(a_[..., others], b_[..., others]), k
+        else:
+            assert torch.equal(a_[others], b_[others]), k

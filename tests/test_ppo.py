@@ -206,3 +206,46 @@ def test_teacher_student_rollout_surface():
     assert len(losses) == 3 and all(np.isfinite(losses)) and alg.storage.step == 0
     assert "sysid_residual" in caches.slot_cache.get_summary()
     assert class_to_dict(RunnerArgs)["num_steps_per_env"] == 24
+
+
+@pytest.mark.parametrize("which", ["ppo_cse", "ppo"])
+def test_storage_keeps_the_observations_the_policy_acted_on(which, small_ac_args, small_rma_args):
+    """The HIP environment returns the SAME obs / privileged_obs tensors from every step and overwrites them in place
+    (the reference allocates fresh ones, legged_robot.py:320-338).  Slot s of the storage must hold o_s — what act() saw —
+    not o_{s+1}; then pi_old(a_s | stored o_s) reproduces the stored log-prob, i.e. the first-epoch PPO ratio is exactly 1."""
+    torch.manual_seed(1)
+    N, T, no, npv, H, na = 6, 5, 7, 3, 4, 12
+    if which == "ppo_cse":
+        from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
+        from go1_gym_learn.ppo_cse.ppo import PPO, gaussian_log_prob
+    else:
+        from go1_gym_learn.ppo import ActorCritic
+        from go1_gym_learn.ppo.actor_critic import AC_Args
+        from go1_gym_learn.ppo.ppo import PPO
+        from go1_gym_learn.ppo_cse.ppo import gaussian_log_prob
+        AC_Args.env_factor_encoder_branch_input_dims = [npv]
+    ac = ActorCritic(no, npv, no * H, na)
+    alg = PPO(ac, device="cpu")
+    alg.init_storage(N, T, [no], [npv], [no * H], [na])
+    obs_buf, priv_buf, hist_buf = torch.zeros(N, no), torch.zeros(N, npv), torch.zeros(N, no * H)      # the env's live buffers
+    seen = []
+    for s in range(T):
+        obs_buf.normal_(); priv_buf.normal_(); hist_buf.normal_()          # "env.step" writes in place
+        seen.append((obs_buf.clone(), priv_buf.clone(), hist_buf.clone()))
+        alg.act(obs_buf, priv_buf, hist_buf)
+        obs_buf.fill_(float("nan")); priv_buf.fill_(float("nan")); hist_buf.fill_(float("nan"))      # the step overwrites them
+        alg.process_env_step(torch.randn(N), torch.zeros(N, dtype=torch.uint8), {"env_bins": torch.zeros(N)})
+    st = alg.storage
+    for s, (o, p, h) in enumerate(seen):
+        assert torch.equal(st.observations[s], o) and torch.equal(st.privileged_observations[s], p), s
+        assert torch.equal(st.observation_histories[s][:, :no * H].float(), h), s
+    with torch.no_grad():
+        for s, (o, p, h) in enumerate(seen):
+            if which == "ppo_cse":
+                mean, _, _ = alg.policy.forward(alg.body, st.observation_histories[s])
+                logp = gaussian_log_prob(st.actions[s], mean.float(), alg.std)
+            else:
+                mean = ac.actor_body(torch.cat((st.observations[s], ac.env_factor_encoder(st.privileged_observations[s])), dim=-1))
+                logp = gaussian_log_prob(st.actions[s], mean, ac.std)
+            ratio = torch.exp(logp - st.actions_log_prob[s, :, 0])
+            torch.testing.assert_close(ratio, torch.ones(N), rtol=1e-5, atol=1e-5)

@@ -362,7 +362,7 @@ DEV int reward_raw_sign(int id) {
 #define QUAD_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)
 
 DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int lane, int e, int N, int64_t counter_post, V3 grav,
-                      int history_slot PROF_PARAM) {
+                      int history_slot, uint32_t& fault PROF_PARAM) {
   const int leg = lane & 3;
   const bool is0 = leg == 0;
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
@@ -488,10 +488,11 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
 
   PROF(17);
   // ---- compute_reward ----------------------------------------------------------------------------------
-  // Failed-simulation guard: a term that is not finite (seen once per ~1e8 env-steps in long training runs, source not yet
-  // located — DESIGN.md §2) counts as 0 and ends the episode, instead of poisoning the running sums, the curriculum
-  // statistics and, through the advantage normalisation, every other environment's gradient.
-  bool sim_failed = false;
+  // Failed-simulation containment: a fault raised by the physics of this step (go1sim.h Go1FaultBit), or a reward term
+  // that is not finite, ends the episode and counts as reward 0 instead of poisoning the running sums, the curriculum
+  // statistics and, through the advantage normalisation, every other environment's gradient.  Every activation is
+  // reported through fault_flags / fault_counts.
+  bool sim_failed = quad_sum((fault & GO1_FAULT_FATAL_MASK) ? 1.f : 0.f) > 0.f;
   float rew = 0.f, pos = 0.f, neg = 0.f;
 #pragma unroll
   for (int id = 0; id < GO1_REW_COUNT; id++) {
@@ -499,7 +500,7 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
     if (kx >= 0) {                  // wave-uniform
       const float sc = plan.scale_by_id[id];
       float r = quad_sum(reward_partial(cfg, B, e, N, id, d, F, leg, rin)) * sc;
-      if (!(fabsf(r) <= 3.0e38f)) { r = 0.f; sim_failed = true; }
+      if (!(fabsf(r) <= 3.0e38f)) { r = 0.f; sim_failed = true; fault |= 1u << GO1_FAULT_REWARD; }
       rew += r;
       if (reward_raw_sign(id) * sc >= 0) pos += r; else neg += r;
       if ((kx & 3) == leg) {      // running sums: fire-and-forget fp32 atomics (one writer per address, so the result is
@@ -512,10 +513,30 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
   }
   if (cfg.only_positive_rewards) rew = fmaxf(rew, 0.f);
   else if (cfg.only_positive_rewards_ji22_style) rew = pos * expf(neg / cfg.sigma_rew_neg);
-  if (!(fabsf(rew) <= 3.0e38f)) { rew = 0.f; sim_failed = true; }
+  if (!(fabsf(rew) <= 3.0e38f)) { rew = 0.f; sim_failed = true; fault |= 1u << GO1_FAULT_REWARD; }
   if (sim_failed) {
+    rew = 0.f;
     reset = true;
     if (is0) B.reset_buf[e] = 1;
+    // nothing non-finite may survive the launch: the reported forces / foot velocities and the actuator-network
+    // histories (which reset_idx leaves alone, reference quirk App. D2) of a failed environment are cleared
+#pragma unroll
+    for (int i = 0; i < 12; i++) AT(B.contact_forces, 3 * (1 + 4 * leg) + i, e) = 0.f;
+    if (is0) { AT(B.contact_forces, 0, e) = 0.f; AT(B.contact_forces, 1, e) = 0.f; AT(B.contact_forces, 2, e) = 0.f; }
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      AT(B.foot_velocities, j, e) = 0.f; AT(B.prev_foot_velocities, j, e) = 0.f; AT(B.torques, j, e) = 0.f;
+      AT(B.foot_positions, j, e) = 0.f;
+      AT(B.joint_pos_err_last, j, e) = 0.f; AT(B.joint_pos_err_last_last, j, e) = 0.f;
+      AT(B.joint_vel_last, j, e) = 0.f; AT(B.joint_vel_last_last, j, e) = 0.f;
+    }
+    d.pg = d.gvec;            // the observation of the re-initialised environment must not see the failed orientation
+    if (is0) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) { AT(B.base_lin_vel, i, e) = 0.f; AT(B.base_ang_vel, i, e) = 0.f; }
+      AT(B.projected_gravity, 0, e) = d.pg.x; AT(B.projected_gravity, 1, e) = d.pg.y; AT(B.projected_gravity, 2, e) = d.pg.z;
+    }
   }
   if (is0) {
     B.rew_buf[e] = rew;
@@ -622,7 +643,8 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
         for (int i = 0; i < 4; i++) {
           const int c = 4 * b + i;
           if (c < n_def) {
-            const float x = fminf(fmaxf(v[i], -cfg.clip_observations), cfg.clip_observations);
+            float x = fminf(fmaxf(v[i], -cfg.clip_observations), cfg.clip_observations);
+            if (!(v[i] == v[i])) { x = 0.f; fault |= 1u << GO1_FAULT_OBS; }
             obs_row[c] = x;
             if (h0) { h0[c] = x; h1[c] = x; }
           }

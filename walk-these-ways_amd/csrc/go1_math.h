@@ -134,13 +134,16 @@ DEV void rotate_inertia(const M3& R, const float Il[6], float out[6]) {
   out[5] = a0.z * R.c0.z + a1.z * R.c1.z + a2.z * R.c2.z;
 }
 // inverse of a symmetric positive definite 6x6 via Cholesky (fully unrolled, registers)
-DEV Sym6 sym6_inverse(const Sym6& A) {
+// min_pivot: smallest Cholesky pivot met (<= 0 or NaN means A was not positive definite in fp32: fault site)
+DEV Sym6 sym6_inverse(const Sym6& A, float& min_pivot) {
   float L[6][6];
+  min_pivot = 3.0e38f;
 #pragma unroll
   for (int j = 0; j < 6; j++) {
     float d = A.m[s6(j, j)];
 #pragma unroll
     for (int k = 0; k < j; k++) d = fmaf(-L[j][k], L[j][k], d);
+    min_pivot = (d < min_pivot) ? d : (d == d ? min_pivot : d);      // a NaN pivot sticks
     float inv = rsqrtf(d);
     L[j][j] = d * inv;
 #pragma unroll
@@ -209,4 +212,6 @@ DEV float quad_bcast(float x, int src) {
 DEV SV quad_sum(SV s) {
   return sv(v3(quad_sum(s.a.x), quad_sum(s.a.y), quad_sum(s.a.z)), v3(quad_sum(s.l.x), quad_sum(s.l.y), quad_sum(s.l.z)));
 }
+// 0 when every argument seen so far is finite, NaN otherwise (x * 0 is NaN for x = +-Inf and NaN)
+DEV float nonfinite_acc(float acc, float x) { return fmaf(x, 0.f, acc); }
 DEV unsigned quad_ballot(bool p, int lane) { return (unsigned)((__ballot(p) >> (lane & ~3)) & 0xFull); }

@@ -177,7 +177,7 @@ struct Leg {             // the calling lane's leg
   float q[3], qd[3], tau[3];
 };
 
-DEV void compute_torques(CfgRef cfg, BufRef B, Leg& L, int leg, int e, int N, int head, float* act_lds, bool full_wave) {
+DEV void compute_torques(CfgRef cfg, BufRef B, Leg& L, int leg, int e, int N, int head, float* act_lds, bool full_wave, uint32_t& fault) {
   const int nl = cfg.lag_timesteps + 1;
   const int h2 = (head + 1) % nl;
   float in[3][6], tq[3], tgt[3];
@@ -222,6 +222,7 @@ DEV void compute_torques(CfgRef cfg, BufRef B, Leg& L, int leg, int e, int N, in
   for (int jj = 0; jj < 3; jj++) {
     const int j = 3 * leg + jj;
     float t = tq[jj] * AT(B.motor_strengths, j, e);
+    if (!(fabsf(t) <= 3.0e38f)) { fault |= 1u << GO1_FAULT_TORQUE; t = 0.f; }
     const float lim = cfg.torque_limits[j];
     t = fminf(fmaxf(t, -lim), lim);
     L.tau[jj] = t;
@@ -292,9 +293,18 @@ DEV void cand_min_dpp(Cand& c, int lane) {      // quad-wide deepest candidate (
   }
 }
 // contact frame: normal n, t1 = x-axis projected on the tangent plane, t2 = n x t1 (oracle detect_contacts())
-DEV void contact_frame(V3 n, V3& t1, V3& t2) {
+// A normal along the x axis leaves no projection: fall back to the y axis (terrain normals have n.z > 0, so this only
+// guards body-body normals and corrupted input) and report it.
+DEV void contact_frame(V3 n, V3& t1, V3& t2, uint32_t& fault) {
   V3 t = v3(1.f - n.x * n.x, -n.x * n.y, -n.x * n.z);
-  t1 = rsqrtf(dot(t, t)) * t;
+  float tt = dot(t, t);
+  if (!(tt > 1e-12f)) {
+    if (!(tt <= 1e-12f)) fault |= 1u << GO1_FAULT_CONTACT_FRAME;       // NaN normal
+    t = v3(-n.y * n.x, 1.f - n.y * n.y, -n.y * n.z);
+    tt = dot(t, t);
+    if (!(tt > 1e-12f)) { t = v3(0.f, 1.f, 0.f); tt = 1.f; }
+  }
+  t1 = rsqrtf(tt) * t;
   t2 = cross(n, t1);
 }
 
@@ -312,7 +322,8 @@ DEV SV leg_response(const SV S[3], const SV U[3], const float Dinv[3], SV a0, in
   return a;
 }
 
-DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds, int lane, Base& s, Leg& L, V3 grav, bool use_warm, float h PROF_PARAM) {
+DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds, int lane, Base& s, Leg& L, V3 grav, bool use_warm, float h,
+                         uint32_t& fault PROF_PARAM) {
   const int leg = lane & 3, el = lane >> 2;
   const M3 R0 = quat_to_mat(s.qx, s.qy, s.qz, s.qw);
   const SV v0 = sv(s.w, s.v);
@@ -412,6 +423,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     for (int j = 2; j >= 0; j--) {
       U[j] = sym6_mul(IA[j], S[j]);
       float D = dot(S[j], U[j]);
+      if (!(D > 1e-9f)) { fault |= 1u << GO1_FAULT_JOINT_D; D = 1e-9f; }
       Dinv[j] = 1.f / D;
       uu[j] = L.tau[j] - dot(S[j], pA[j]);
       sym6_rank1_sub(IA[j], U[j], Dinv[j]);
@@ -426,7 +438,9 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
 
   PROF(2);
   // ---- ABA pass 3 ------------------------------------------------------------------------------------
-  const Sym6 I0inv = sym6_inverse(IA0);
+  float min_pivot;
+  const Sym6 I0inv = sym6_inverse(IA0, min_pivot);
+  if (!(min_pivot > 1e-9f)) fault |= 1u << GO1_FAULT_BASE_PIVOT;
   SV a0 = -sym6_mul(I0inv, pA0);
   V3 w_free = s.w + h * a0.a;
   V3 v_free = s.v + h * (a0.l + cross(s.w, s.v));
@@ -459,6 +473,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   for (int i = 0; i < 4; i++) if (slot[i] >= MAXC) slot[i] = -1;
   const int sbase = (slot_base >= 0 && slot_base < MAXC) ? slot_base : -1;
   int K = nf + nb + nc + nt + nh;
+  if (K > MAXC && leg == 0) fault |= 1u << GO1_FAULT_CONTACT_DROPPED;
   K = K > MAXC ? MAXC : K;
   const float e_c = 0.5f * (s.rest + cfg.terrain_restitution);
 
@@ -467,10 +482,10 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     fn[i] = v3(cand[i].nx, cand[i].ny, cand[i].nz);
-    contact_frame(fn[i], ft1[i], ft2[i]);
+    contact_frame(fn[i], ft1[i], ft2[i], fault);
   }
   bn = v3(cbase.nx, cbase.ny, cbase.nz);
-  contact_frame(bn, bt1, bt2);
+  contact_frame(bn, bt1, bt2, fault);
   // impulses: listed bodies start from the warm value or zero, all others are dropped
   float lam0[4][3], lamb[3];
 #pragma unroll
@@ -638,6 +653,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       const float dn = quad_bcast(Wc[r0][(r0) >> 2], r0);
       const float d1 = quad_bcast(Wc[r0 + 1][(r0 + 1) >> 2], r0 + 1);
       const float d2 = quad_bcast(Wc[r0 + 2][(r0 + 2) >> 2], r0 + 2);
+      if (on && !(dn > 1e-9f && d1 > 1e-9f && d2 > 1e-9f)) fault |= 1u << GO1_FAULT_W_DIAG;
       idn[k] = on ? 1.f / dn : 0.f;
       id1[k] = on ? 1.f / d1 : 0.f;
       id2[k] = on ? 1.f / d2 : 0.f;
@@ -682,6 +698,12 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
             if (leg == ((r0 + i) & 3)) lamloc[(r0 + i) >> 2] = lam[r0 + i];
         }
       }
+    }
+    {
+      float nf_acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < NR; r++) nf_acc = nonfinite_acc(nf_acc, lam[r]);
+      if (nf_acc != nf_acc) fault |= 1u << GO1_FAULT_LAMBDA;
     }
     if (leg == 0) {
 #pragma unroll
@@ -764,6 +786,16 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     float nw = dw * s.qw - dx * s.qx - dy * s.qy - dz * s.qz;
     float inv = rsqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
     s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv; s.qw = nw * inv;
+  }
+  {
+    float a = 0.f;
+    a = nonfinite_acc(a, s.pos.x); a = nonfinite_acc(a, s.pos.y); a = nonfinite_acc(a, s.pos.z);
+    a = nonfinite_acc(a, s.qx); a = nonfinite_acc(a, s.qy); a = nonfinite_acc(a, s.qz); a = nonfinite_acc(a, s.qw);
+    a = nonfinite_acc(a, s.w.x); a = nonfinite_acc(a, s.w.y); a = nonfinite_acc(a, s.w.z);
+    a = nonfinite_acc(a, s.v.x); a = nonfinite_acc(a, s.v.y); a = nonfinite_acc(a, s.v.z);
+#pragma unroll
+    for (int j = 0; j < 3; j++) { a = nonfinite_acc(a, L.q[j]); a = nonfinite_acc(a, L.qd[j]); }
+    if (a != a) fault |= 1u << GO1_FAULT_STATE_OUT;
   }
   PROF(6);
 }

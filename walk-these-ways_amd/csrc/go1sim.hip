@@ -43,6 +43,15 @@ struct StepArgs {
 // ================================================================================================
 // kernels
 // ================================================================================================
+// rare path: publish the fault bits of this lane (go1sim.h Go1FaultBit)
+DEV void report_fault(BufRef B, int e, uint32_t fault) {
+  if (fault == 0 || B.fault_flags == nullptr) return;
+  atomicOr(&B.fault_flags[e], fault);
+  if (B.fault_counts == nullptr) return;
+  for (int b = 0; b < GO1_FAULT_BITS; b++)
+    if (fault & (1u << b)) atomicAdd(&B.fault_counts[b], 1u);
+}
+
 extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArgs A) {
   __shared__ float lds[L_END * EPW];
   __shared__ __attribute__((aligned(16))) float act_lds[A_END];
@@ -63,6 +72,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
   // every load of the prologue is issued before its first store (a store in between would pin the later loads behind
   // it — possible aliasing — and expose one HBM round trip per group)
   load_state(B, leg, e, N, s, L);
+  uint32_t fault = 0;
   float act_in[3], fv_in[3];
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) {
@@ -79,18 +89,28 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
     AT(B.actions, j, e) = fminf(fmaxf(act_in[jj], -cfg.clip_actions), cfg.clip_actions);
     AT(B.prev_foot_velocities, j, e) = fv_in[jj];
   }
+  {
+    float a = 0.f;
+    a = nonfinite_acc(a, s.pos.x); a = nonfinite_acc(a, s.pos.y); a = nonfinite_acc(a, s.pos.z);
+    a = nonfinite_acc(a, s.qx); a = nonfinite_acc(a, s.qy); a = nonfinite_acc(a, s.qz); a = nonfinite_acc(a, s.qw);
+    a = nonfinite_acc(a, s.w.x); a = nonfinite_acc(a, s.w.y); a = nonfinite_acc(a, s.w.z);
+    a = nonfinite_acc(a, s.v.x); a = nonfinite_acc(a, s.v.y); a = nonfinite_acc(a, s.v.z);
+#pragma unroll
+    for (int j = 0; j < 3; j++) { a = nonfinite_acc(a, L.q[j]); a = nonfinite_acc(a, L.qd[j]); }
+    if (a != a) fault |= 1u << GO1_FAULT_STATE_IN;
+  }
   const int nl = cfg.lag_timesteps + 1;
   int head = A.lag_head;
   PROF(0);
 #pragma unroll 1
   for (int sub = 0; sub < cfg.decimation; sub++) {
 #ifndef GO1_ABLATE_TORQUE
-    compute_torques(cfg, B, L, leg, e, N, head, act_lds, full_wave);
+    compute_torques(cfg, B, L, leg, e, N, head, act_lds, full_wave, fault);
 #endif
     PROF(1);
     head = (head + 1) % nl;
 #ifndef GO1_ABLATE_PHYSICS
-    physics_substep(cfg, B.height_samples, lds, lane, s, L, grav, warm || (cfg.warm_start && sub > 0), h PROF_PASS);
+    physics_substep(cfg, B.height_samples, lds, lane, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault PROF_PASS);
 #endif
   }
   store_state(B, leg, e, N, s, L);
@@ -100,8 +120,9 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
   __syncthreads();
   PROF(7);
 #ifndef GO1_ABLATE_POST
-  post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, grav, A.history_slot PROF_PASS);
+  post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, grav, A.history_slot, fault PROF_PASS);
 #endif
+  report_fault(B, e, fault);
   PROF_FLUSH;
 }
 
@@ -121,16 +142,20 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   if (e >= N) return;
   if (A.mode == 4) {       // tensor maps only
     PROF_DECL
-    post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot PROF_PASS);
+    uint32_t fault = 0;
+    post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot, fault PROF_PASS);
+    report_fault(B, e, fault);
     return;
   }
   Base s;
   Leg L;
   load_state(B, leg, e, N, s, L);
+  uint32_t fault = 0;
   if (A.mode == 1) {       // torques only (actions given as SoA)
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) AT(B.actions, 3 * leg + jj, e) = AT(A.actions, 3 * leg + jj, e);
-    compute_torques(cfg, B, L, leg, e, N, A.lag_head, act_lds, full_wave);
+    compute_torques(cfg, B, L, leg, e, N, A.lag_head, act_lds, full_wave, fault);
+    report_fault(B, e, fault);
     return;
   }
   // mode 2: one physics substep with the torques in the buffer
@@ -139,10 +164,11 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   for (int jj = 0; jj < 3; jj++) L.tau[jj] = AT(B.torques, 3 * leg + jj, e);
   load_lambda(cfg, B, lds, lane, e, N, false);
   PROF_DECL
-  physics_substep(cfg, B.height_samples, lds, lane, s, L, grav, cfg.warm_start != 0, cfg.sim_dt PROF_PASS);
+  physics_substep(cfg, B.height_samples, lds, lane, s, L, grav, cfg.warm_start != 0, cfg.sim_dt, fault PROF_PASS);
   store_state(B, leg, e, N, s, L);
   foot_state(s, L, leg, B, e, N);
   store_forces(cfg, B, lds, lane, e, N);
+  report_fault(B, e, fault);
 }
 
 // one environment per lane: reset_idx
@@ -392,7 +418,7 @@ extern "C" int go1sim_read_timings(Go1Sim* s, float* ms, int32_t max, int32_t* c
   *count = (int32_t)have;
   return 0;
 }
-extern "C" const char* go1sim_version(void) { return "go1sim 0.3 (gfx950, abi 2, 4 lanes/env)"; }
+extern "C" const char* go1sim_version(void) { return "go1sim 0.4 (gfx950, abi 3, 4 lanes/env)"; }
 
 #ifdef GO1_PROFILE
 // debug build only (tools/phase_profile.py): read and clear the per-phase cycle accumulators of workgroup 0, lane 0

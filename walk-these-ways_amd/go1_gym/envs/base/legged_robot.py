@@ -92,6 +92,35 @@ class _CurriculumDistribution(Mapping):
         return self.env.curricula[i].weights if kind == "weights" else self.env.curricula[i].grid
 
 
+class _SimFaults(Mapping):
+    """`extras["sim_faults"]`: occurrences per fault site since the counters were last consumed (include/go1sim.h
+    `Go1FaultBit`).  The reference has no such entry — PhysX never returns a non-finite state; here every containment
+    of a failed environment is reported instead of hidden.  Lazy: device reads happen on access only."""
+
+    def __init__(self, env):
+        self.env = env
+
+    def __iter__(self):
+        return iter(H.FAULT_NAMES[b] for b in sorted(H.FAULT_NAMES))
+
+    def __len__(self):
+        return len(H.FAULT_NAMES)
+
+    def __getitem__(self, key):
+        for b, name in H.FAULT_NAMES.items():
+            if name == key:
+                return self.env.buffers.fault_counts[b]
+        raise KeyError(key)
+
+    def consume(self):
+        """Counts as ints (one host sync) and restart; `fatal` = occurrences that ended an episode."""
+        counts = self.env.buffers.fault_counts.tolist()
+        self.env.buffers.fault_counts.zero_()
+        out = {name: int(counts[b]) for b, name in sorted(H.FAULT_NAMES.items())}
+        out["fatal"] = sum(int(counts[b]) for b in H.FAULT_NAMES if (H.FAULT_FATAL_MASK >> b) & 1)
+        return out
+
+
 class LeggedRobot(BaseTask):
     def __init__(self, cfg, sim_params, physics_engine, sim_device, headless, eval_cfg=None,
                  initial_dynamics_dict=None):
@@ -288,7 +317,8 @@ class LeggedRobot(BaseTask):
         self.common_step_counter = 0
         self.measured_heights = B.measured_heights.t() if S.measure_heights else 0
         self.add_noise = self.cfg.noise.add_noise
-        self.extras = {"env_bins": B.env_command_bins, "train/episode": _EpisodeStats(self)}
+        self.extras = {"env_bins": B.env_command_bins, "train/episode": _EpisodeStats(self), "sim_faults": _SimFaults(self)}
+        self.fault_flags = B.fault_flags
         if self.cfg.env.send_timeouts:
             self.extras["time_outs"] = self.time_out_buf
         if self.cfg.commands.command_curriculum:

@@ -62,9 +62,17 @@ class PPO:
         tr.actions_log_prob = ac.get_actions_log_prob(tr.actions).detach()
         tr.action_mean = ac.action_mean.detach()
         tr.action_sigma = ac.action_std.detach()
-        tr.observations = tr.critic_observations = obs
-        tr.privileged_observations = privileged_obs
-        tr.observation_histories = obs_history
+        # obs / privileged_obs / obs_history are the environment's own buffers and env.step overwrites them in place (the
+        # reference builds fresh tensors every step, legged_robot.py:320-338): the slot gets the values acted on, now
+        st, s = self.storage, self.storage.step
+        if s >= st.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        st.observations[s].copy_(obs)
+        st.privileged_observations[s].copy_(privileged_obs)
+        st.observation_histories[s][:, :obs_history.shape[-1]].copy_(obs_history)
+        tr.observations = tr.critic_observations = st.observations[s]
+        tr.privileged_observations = st.privileged_observations[s]
+        tr.observation_histories = st.observation_histories[s]
         return tr.actions
 
     def process_env_step(self, rewards, dones, infos):

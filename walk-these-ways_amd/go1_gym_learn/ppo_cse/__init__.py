@@ -126,6 +126,10 @@ class Runner:
                 if stats is not None:
                     with logger.Prefix(metrics="train/episode"):
                         logger.store_metrics(**(stats.consume() if hasattr(stats, "consume") else stats))
+                faults = infos.get('sim_faults') if hasattr(infos, "get") else None
+                if faults is not None and hasattr(faults, "consume"):       # containments of failed environments (go1sim.h Go1FaultBit)
+                    with logger.Prefix(metrics="sim_faults"):
+                        logger.store_metrics(**faults.consume())
                 logger.log_metrics_summary(key_values={"timesteps": self.tot_timesteps, "iterations": it})
                 logger.job_running()
             if it % RunnerArgs.save_interval == 0:

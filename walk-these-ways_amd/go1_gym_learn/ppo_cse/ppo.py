@@ -239,10 +239,21 @@ class PPO:
         t.actions_log_prob = gaussian_log_prob(t.actions, mean, std)
         t.action_mean = mean
         t.action_sigma = std.expand_as(mean)
-        t.observations = obs
-        t.critic_observations = obs
-        t.privileged_observations = privileged_obs
+        self._snapshot_obs(obs, privileged_obs)
         return t.actions
+
+    def _snapshot_obs(self, obs, privileged_obs):
+        """`obs` / `privileged_obs` are the environment's own output buffers, which `env.step` overwrites IN PLACE (the
+        reference allocates fresh tensors every step, legged_robot.py:320-338, so holding a reference was safe there):
+        the transition must keep the values the policy acted on, so they go into the storage slot now, before the step."""
+        t, st = self.transition, self.storage
+        s = st.step
+        if s >= st.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        st.observations[s].copy_(obs)
+        st.privileged_observations[s].copy_(privileged_obs)
+        t.observations = t.critic_observations = st.observations[s]
+        t.privileged_observations = st.privileged_observations[s]
 
     def _act_fused(self, slot, obs, privileged_obs):
         """inference on the static-buffer engine, then ONE kernel that samples, evaluates the log-prob and writes
@@ -258,8 +269,7 @@ class PPO:
             fused.act(self._fused_lib, mean, value, self.std, noise, st, s)
         t.actions, t.values, t.actions_log_prob = st.actions[s], st.values[s], st.actions_log_prob[s]
         t.action_mean, t.action_sigma = st.mu[s], st.sigma[s]
-        t.observations = t.critic_observations = obs
-        t.privileged_observations = privileged_obs
+        self._snapshot_obs(obs, privileged_obs)
         return t.actions
 
     def _infer(self, rows):
@@ -296,9 +306,7 @@ class PPO:
         bins = infos["env_bins"][:rewards.shape[0]]
         fused.store_step(self._fused_lib, st, s, rewards.contiguous(), dones if dones.dtype == torch.uint8 else dones.to(torch.uint8), tos,
                          bins if bins.dtype == torch.int32 else bins.to(torch.int32), PPO_Args.gamma)
-        st.observations[s].copy_(t.observations)
-        st.privileged_observations[s].copy_(t.privileged_observations)
-        st.step += 1
+        st.step += 1          # the two observation blocks were stored by act(), before the environment stepped
         t.clear()
         self.actor_critic.reset(dones)
 

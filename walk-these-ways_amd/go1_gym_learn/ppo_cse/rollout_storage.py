@@ -61,9 +61,11 @@ class RolloutStorage:
         if self.step >= self.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
         s = self.step
-        self.observations[s].copy_(transition.observations)
-        self.privileged_observations[s].copy_(transition.privileged_observations)
-        if transition.observation_histories is not self.observation_histories[s]:
+        if transition.observations.data_ptr() != self.observations[s].data_ptr():        # PPO.act stores these two itself
+            self.observations[s].copy_(transition.observations)
+        if transition.privileged_observations.data_ptr() != self.privileged_observations[s].data_ptr():
+            self.privileged_observations[s].copy_(transition.privileged_observations)
+        if transition.observation_histories.data_ptr() != self.observation_histories[s].data_ptr():
             src = transition.observation_histories
             self.observation_histories[s][:, :src.shape[-1]].copy_(src)
         self.actions[s].copy_(transition.actions)

@@ -46,6 +46,9 @@ _RANGE_ATTR = ["lin_vel_x", "lin_vel_y", "ang_vel_yaw", "body_height_cmd", "gait
 LOCAL_RANGE = np.array([0.55, 0.55, 0.55, 0.55, 0.35, 0.25, 0.25, 0.25, 0.25, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0])
 CURRICULUM_KEYS = ["tracking_lin_vel", "tracking_ang_vel", "tracking_contacts_shaped_force",
                    "tracking_contacts_shaped_vel"]
+FAULT_NAMES = {v: k[len("GO1_FAULT_"):].lower() for k, v in abi.CONSTS.items()
+               if k.startswith("GO1_FAULT_") and k != "GO1_FAULT_BITS"}
+FAULT_FATAL_MASK = 0x3FF          # GO1_FAULT_FATAL_MASK of include/go1sim.h
 COMMAND_SUM_EXTRA = ["lin_vel_raw", "ang_vel_raw", "lin_vel_residual", "ang_vel_residual", "ep_timesteps"]
 
 
@@ -360,6 +363,7 @@ def _buffer_specs(S):
         "obs_buf": (f, (N, S.num_obs)), "privileged_obs_buf": (f, (N, max(S.num_privileged_obs, 1))),
         "obs_history": (f, (N, 2 * (S.num_obs_history + 1) * S.num_obs)),
         "measured_heights": (f, (max(S.num_height_x * S.num_height_y, 1), N)),
+        "fault_flags": (i32, (N,)), "fault_counts": (i32, (abi.GO1_FAULT_BITS,)),
     }
 
 
