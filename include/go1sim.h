@@ -157,6 +157,10 @@ typedef struct Go1SimConfig {
   float max_push_vel_xy;
   int32_t randomize_motor_strength, randomize_motor_offset, randomize_Kp_factor, randomize_Kd_factor;
   float motor_strength_range[2], motor_offset_range[2], Kp_factor_range[2], Kd_factor_range[2];
+  /* re-draw of the rigid-body properties together with the DOF properties (legged_robot.py:706-708,611-633) */
+  int32_t randomize_rigids_after_start;
+  int32_t randomize_base_mass, randomize_com_displacement, randomize_friction, randomize_restitution;
+  float added_mass_range[2], com_displacement_range[2], friction_range[2], restitution_range[2];
   int32_t teleport_robots;
   float teleport_thresh, teleport_x_offset, terrain_length, terrain_width;
   int32_t terrain_num_rows, terrain_num_cols;
@@ -201,6 +205,7 @@ typedef struct Go1SimConfig {
   int32_t device_curriculum;       /* 1: in-kernel sampling; 0: kernel only raises resample flags */
   int32_t num_categories;          /* 4 when gaitwise_curricula (pronk, trot, pace, bound) else 1 */
   int32_t gaitwise_curricula, binary_phases;
+  int32_t exclusive_phase_offset, balance_gait_distribution;   /* legged_robot.py:783-812 (only without gaitwise_curricula) */
   int32_t num_bins;                /* product of num_bins_* */
   int32_t grid_bins[GO1_MAX_COMMANDS];
   float grid_low[GO1_MAX_COMMANDS], grid_high[GO1_MAX_COMMANDS];  /* limit_* ranges */

@@ -115,7 +115,7 @@ void go1_oracle_philox(const uint32_t ctr_in[4], const uint32_t key_in[2], uint3
   memcpy(out, c, sizeof c);
 }
 enum { P_NOISE = 1, P_RESET = 2, P_DOFPROPS_CB = 3, P_DOFPROPS_RESET = 4, P_CMD_CB = 5, P_CMD_RESET = 6,
-       P_PUSH = 7, P_GRAVITY = 8 };
+       P_PUSH = 7, P_GRAVITY = 8, P_RIGID = 9, P_RIGID_RESET = 10 };
 /* uniform [0,1) number `idx` of stream (env, step, purpose) */
 static float rng_uniform(const Go1SimConfig* cfg, uint32_t env_global, int64_t step, uint32_t purpose, uint32_t idx) {
   uint32_t ctr[4] = {env_global, (uint32_t)step, purpose, idx >> 2};
@@ -724,6 +724,25 @@ static void resample_commands(const Go1SimConfig* cfg, const Go1SimBuffers* B, i
         else if (cat == 1) { cmd[5] = cmd[5] / 2 + 0.25f; cmd[6] = 0; cmd[7] = 0; }
         else if (cat == 2) { cmd[5] = 0; cmd[6] = cmd[6] / 2 + 0.25f; cmd[7] = 0; }
         else { cmd[5] = 0; cmd[6] = 0; cmd[7] = cmd[7] / 2 + 0.25f; }
+      } else if (cfg->exclusive_phase_offset) {   /* legged_robot.py:783-793 */
+        float r = rng_uniform(cfg, eg, step, purpose, 2 + GO1_MAX_COMMANDS);
+        int trot = r < 0.34f, pace = 0.34f <= r && r < 0.67f, bnd = 0.67f <= r;
+        if (pace) cmd[5] = 0;
+        if (bnd) cmd[5] = 0;
+        if (trot) cmd[6] = 0;
+        if (bnd) cmd[6] = 0;
+        if (trot) cmd[7] = 0;
+        if (pace) cmd[7] = 0;
+      } else if (cfg->balance_gait_distribution) {   /* legged_robot.py:795-812, statement by statement */
+        float r = rng_uniform(cfg, eg, step, purpose, 2 + GO1_MAX_COMMANDS);
+        int pronk = r <= 0.25f, trot = 0.25f <= r && r < 0.50f, pace = 0.50f <= r && r < 0.75f, bnd = 0.75f <= r;
+        if (pronk) for (int kx = 5; kx < 8; kx++) cmd[kx] = (float)fmod1(cmd[kx] / 2 - 0.25f);
+        if (trot) { cmd[6] = 0; cmd[7] = 0; }
+        if (pace) { cmd[5] = 0; cmd[7] = 0; }
+        if (bnd) { cmd[5] = 0; cmd[6] = 0; }
+        if (trot) cmd[5] = cmd[5] / 2 + 0.25f;
+        if (pace) cmd[6] = cmd[6] / 2 + 0.25f;
+        if (bnd) cmd[7] = cmd[7] / 2 + 0.25f;
       }
       if (cfg->binary_phases)          /* :814-817; torch.round = round-half-even = rint */
         for (int kx = 5; kx < 8; kx++) cmd[kx] = (float)fmod1(rintf(2 * cmd[kx]) / 2.0f);
@@ -780,12 +799,28 @@ static void randomize_dof_props(const Go1SimConfig* cfg, const Go1SimBuffers* B,
   }
 }
 
+/* _randomize_rigid_body_props from the step callback (legged_robot.py:706-708,611-633); deviation: DESIGN.md */
+static void randomize_rigid_props(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int64_t step, uint32_t purpose) {
+  const int N = cfg->num_envs;
+  uint32_t eg = (uint32_t)(cfg->env_id_offset + e);
+  if (cfg->randomize_base_mass)
+    B->payloads[e] = rng_uniform(cfg, eg, step, purpose, 0) * (cfg->added_mass_range[1] - cfg->added_mass_range[0]) + cfg->added_mass_range[0];
+  if (cfg->randomize_com_displacement)
+    for (int i = 0; i < 3; i++)
+      AT(B->com_displacements, i, e) = rng_uniform(cfg, eg, step, purpose, 1 + i) * (cfg->com_displacement_range[1] - cfg->com_displacement_range[0]) + cfg->com_displacement_range[0];
+  if (cfg->randomize_friction)
+    B->friction_coeffs[e] = rng_uniform(cfg, eg, step, purpose, 4) * (cfg->friction_range[1] - cfg->friction_range[0]) + cfg->friction_range[0];
+  if (cfg->randomize_restitution)
+    B->restitutions[e] = rng_uniform(cfg, eg, step, purpose, 5) * (cfg->restitution_range[1] - cfg->restitution_range[0]) + cfg->restitution_range[0];
+}
+
 /* reset_idx for one env (legged_robot.py:150-239,948-1001) */
 static void reset_env(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int64_t step, int lag_slots) {
   const int N = cfg->num_envs;
   uint32_t eg = (uint32_t)(cfg->env_id_offset + e);
   resample_commands(cfg, B, e, step, P_CMD_RESET);
   randomize_dof_props(cfg, B, e, step, P_DOFPROPS_RESET);
+  if (cfg->randomize_rigids_after_start) randomize_rigid_props(cfg, B, e, step, P_RIGID_RESET);   /* :166-168 */
   for (int j = 0; j < 12; j++) {   /* _reset_dofs :956-958 */
     float u = rng_uniform(cfg, eg, step, P_RESET, j);
     AT(B->dof_pos, j, e) = cfg->default_dof_pos[j] * (0.5f + u);
@@ -1021,7 +1056,10 @@ static void post_physics(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e,
     for (int i = 0; i < 2; i++)
       AT(B->root_states, 7 + i, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, i) - 1) * cfg->max_push_vel_xy;
   }
-  if (B->episode_length_buf[e] % cfg->rand_interval == 0) randomize_dof_props(cfg, B, e, counter_post, P_DOFPROPS_CB);
+  if (B->episode_length_buf[e] % cfg->rand_interval == 0) {
+    randomize_dof_props(cfg, B, e, counter_post, P_DOFPROPS_CB);
+    if (cfg->randomize_rigids_after_start) randomize_rigid_props(cfg, B, e, counter_post, P_RIGID);
+  }
 
   /* ---- measured terrain heights (:689-691, _get_heights :1772-1806) ---- */
   real mean_height = 0;

@@ -412,9 +412,178 @@ def gen_ppo_rma(seed=4):
     print("ppo (teacher-student runner) losses", losses, "lr", alg.learning_rate)
 
 
+# ---- Philox4x32-10 (Random123) in numpy: the uniforms the oracle / kernel draw for an env (go1_math.h rng_uniform) -----
+def philox_uniform(seed, env, step, purpose, idx):
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c = [env & 0xFFFFFFFF, step & 0xFFFFFFFF, purpose, idx >> 2]
+    k = [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF]
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xFFFFFFFF]
+        k = [(k[0] + W0) & 0xFFFFFFFF, (k[1] + W1) & 0xFFFFFFFF]
+    return np.float32(c[idx & 3] >> 8) * np.float32(1.0 / 16777216.0)
+
+
+RESAMPLE_MODES = {"gaitwise": dict(gaitwise_curricula=True, exclusive_phase_offset=False, balance_gait_distribution=False, binary_phases=True),
+                  "exclusive": dict(gaitwise_curricula=False, exclusive_phase_offset=True, balance_gait_distribution=False, binary_phases=True),
+                  "balance": dict(gaitwise_curricula=False, exclusive_phase_offset=False, balance_gait_distribution=True, binary_phases=False),
+                  "plain": dict(gaitwise_curricula=False, exclusive_phase_offset=False, balance_gait_distribution=False, binary_phases=False)}
+
+
+def gen_resample(mode, N=96, seed=31, sim_seed=12345, step=77, purpose=6):
+    """reference LeggedRobot._resample_commands + RewardThresholdCurriculum.update (legged_robot.py:710-824,
+    curriculum.py:135-154) on a mock env.  The two RNG consumers are fed the uniforms the oracle / kernel draw for the
+    same (seed, env, step, purpose): `torch.rand` returns column 0 (category) and, for the phase-exclusion branches,
+    column 17; `curriculum.sample` is replaced by the inverse-CDF draw from column 1 (numpy's `choice(p=...)` is the same
+    searchsorted(cdf, u, 'right')) over the weights in force BEFORE this step's update plus the in-cell
+    jitter from columns 2..16.  Everything else — success test, weight update with neighbourhoods, category assignment,
+    gait remaps, binary phases, small-command zeroing, sum reset — is the reference's own code."""
+    np.int = int                                                   # legged_robot.py:1362 uses the removed alias (App. D13)
+    e, LR = make_env("train", N, seed)
+    c = e.cfg.commands
+    for k, v in RESAMPLE_MODES[mode].items():
+        setattr(c, k, v)
+    LR._init_command_distribution(e, torch.arange(N))
+    rng = np.random.default_rng(seed + 1)
+    ncat, nb = len(e.category_names), len(e.curricula[0])
+    for cur in e.curricula:                                         # a frontier: some bins partly open, some closed
+        on = np.flatnonzero(cur.weights > 0)
+        cur.weights[rng.choice(on, len(on) // 3, replace=False)] = 0.4
+        off = np.flatnonzero(cur.weights == 0)
+        cur.weights[rng.choice(off, 12, replace=False)] = 0.2
+    w0 = np.stack([cur.weights.copy() for cur in e.curricula])
+    open_bins = [np.flatnonzero(w > 0) for w in w0]
+    e.env_command_categories = rng.integers(0, ncat, N)
+    e.env_command_bins = np.array([rng.choice(open_bins[k]) for k in e.env_command_categories])
+    env_ids = torch.tensor(np.sort(rng.choice(N, (2 * N) // 3, replace=False)), dtype=torch.long)
+    ep_len = min(int(e.cfg.env.max_episode_length), int(c.resampling_time / e.dt))
+    for key in ("tracking_lin_vel", "tracking_ang_vel", "tracking_contacts_shaped_force", "tracking_contacts_shaped_vel"):
+        thr = e.curriculum_thresholds[key] * e.reward_scales[key]
+        mult = rng.choice([0.6, 1.5], N, p=[0.25, 0.75])            # clear of the threshold either way
+        e.command_sums[key] = torch.tensor(ep_len * thr * mult, dtype=torch.float)
+    cmd0 = e.commands.clone()
+    sums0 = torch.stack([e.command_sums[k] for k in e.command_sums]).clone()
+    bins0, cats0 = np.array(e.env_command_bins).copy(), np.array(e.env_command_categories).copy()
+    U = np.array([[philox_uniform(sim_seed, int(i), step, purpose, j) for j in range(18)] for i in range(N)], dtype=np.float32)
+    lim = [c.limit_vel_x, c.limit_vel_y, c.limit_vel_yaw, c.limit_body_height, c.limit_gait_frequency, c.limit_gait_phase,
+           c.limit_gait_offset, c.limit_gait_bound, c.limit_gait_duration, c.limit_footswing_height, c.limit_body_pitch,
+           c.limit_body_roll, c.limit_stance_width, c.limit_stance_length, c.limit_aux_reward_coef]
+    nbins = [c.num_bins_vel_x, c.num_bins_vel_y, c.num_bins_vel_yaw, c.num_bins_body_height, c.num_bins_gait_frequency,
+             c.num_bins_gait_phase, c.num_bins_gait_offset, c.num_bins_gait_bound, c.num_bins_gait_duration,
+             c.num_bins_footswing_height, c.num_bins_body_pitch, c.num_bins_body_roll, c.num_bins_stance_width,
+             c.num_bins_stance_length, c.num_bins_aux_reward_coef]
+    f32 = np.float32
+    cdf_pre = []
+    for w in w0:
+        cs = np.cumsum(w.astype(np.float32).astype(np.float64))
+        cdf_pre.append((cs / cs[-1]).astype(np.float32))
+    floats = torch.tensor(U[env_ids.numpy(), 0])
+    per = 1.0 / ncat
+    cat_ids = [env_ids[torch.logical_and(per * i <= floats, floats < per * (i + 1))] for i in range(ncat)]
+
+    def make_sample(i, cur):
+        def sample(batch_size, low=None, high=None):
+            ids = cat_ids[i].numpy()
+            assert len(ids) == batch_size
+            out, inds = np.zeros((batch_size, 15)), np.zeros(batch_size, dtype=int)
+            for r, env in enumerate(ids):
+                b = int(np.searchsorted(cdf_pre[i], U[env, 1], side="right"))
+                b = min(b, nb - 1)
+                inds[r] = b
+                rem = b
+                for kx in range(14, -1, -1):
+                    idx = rem % nbins[kx]
+                    rem //= nbins[kx]
+                    bs = (f32(lim[kx][1]) - f32(lim[kx][0])) / f32(nbins[kx])
+                    centroid = f32(lim[kx][0]) + bs * (f32(idx) + f32(0.5))
+                    assert abs(float(centroid) - cur.grid[kx, b]) < 1e-5      # same bin -> centroid decode as the reference grid
+                    out[r, kx] = centroid + (U[env, 2 + kx] - f32(0.5)) * bs
+            return out, inds
+        return sample
+    for i, cur in enumerate(e.curricula):
+        cur.sample = make_sample(i, cur)
+    calls = [torch.tensor(U[env_ids.numpy(), 0]), torch.tensor(U[env_ids.numpy(), 17])]
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: calls.pop(0)
+    try:
+        LR._resample_commands(e, env_ids)
+    finally:
+        torch.rand = real_rand
+    out = dict(env_ids=env_ids.numpy(), weights0=w0, weights1=np.stack([cur.weights for cur in e.curricula]),
+               commands0=cmd0.numpy(), commands1=e.commands.numpy(), command_sums0=sums0.numpy(),
+               command_sums1=torch.stack([e.command_sums[k] for k in e.command_sums]).numpy(),
+               bins0=bins0, cats0=cats0, bins1=np.asarray(e.env_command_bins), cats1=np.asarray(e.env_command_categories),
+               uniforms=U, sim_seed=np.array(sim_seed), step=np.array(step), purpose=np.array(purpose), ep_len=np.array(ep_len),
+               command_sum_names=np.array(list(e.command_sums)), category_names=np.array(e.category_names))
+    np.savez_compressed(os.path.join(HERE, f"resample_{mode}.npz"), **out)
+    ch = np.abs(out["weights1"] - w0).sum()
+    print("resample", mode, "envs", len(env_ids), "weight mass added", float(ch), "zeroed xy", int((np.abs(out["commands1"][env_ids.numpy(), :2]).sum(1) == 0).sum()))
+
+
+def gen_reset(N=80, seed=41, sim_seed=4242, step=311):
+    """reference `_randomize_dof_props`, `_reset_dofs`, `_reset_root_states` (legged_robot.py:645-665,948-1001) on a mock env,
+    with `torch.rand` / `torch_rand_float` serving the Philox uniforms the oracle / kernel draw for the same
+    (seed, env, step): purpose 4 (DOF properties at reset) columns 0..14, purpose 2 (reset) columns 0..20."""
+    import go1_gym.envs.base.legged_robot as ref_mod
+    e, LR = make_env("alt", N, seed)                               # alt: Kp / Kd factors randomised too
+    sys.modules["isaacgym.gymtorch"].unwrap_tensor = lambda t: t
+    ref_mod.gymtorch.unwrap_tensor = lambda t: t
+
+    class AnyCall:
+        def __getattr__(self, name):
+            return lambda *a, **k: True
+    e.gym, e.sim, e.dof_state = AnyCall(), None, torch.zeros(N * 12, 2)
+    e.eval_cfg = None
+    e.cfg.env.record_video = False
+    rng = np.random.default_rng(seed + 1)
+    e.custom_origins = True
+    e.env_origins = torch.tensor(rng.uniform(-20, 20, (N, 3)), dtype=torch.float)
+    e.env_origins[:, 2] = torch.tensor(rng.uniform(0, 0.3, N), dtype=torch.float)
+    st = e.cfg.init_state
+    e.base_init_state = torch.tensor(list(st.pos) + list(st.rot) + list(st.lin_vel) + list(st.ang_vel), dtype=torch.float)
+    ids = torch.tensor(np.sort(rng.choice(N, N // 2, replace=False)), dtype=torch.long)
+    U_dof = np.array([[philox_uniform(sim_seed, int(i), step, 4, j) for j in range(16)] for i in range(N)], dtype=np.float32)
+    U_rst = np.array([[philox_uniform(sim_seed, int(i), step, 2, j) for j in range(24)] for i in range(N)], dtype=np.float32)
+    pre = dict(dof_pos0=e.dof_pos.clone(), dof_vel0=e.dof_vel.clone(), root_states0=e.root_states.clone(),
+               motor_strengths0=e.motor_strengths.clone(), motor_offsets0=e.motor_offsets.clone(), Kp_factors0=e.Kp_factors.clone(),
+               Kd_factors0=e.Kd_factors.clone(), env_origins=e.env_origins.clone())
+    idn = ids.numpy()
+    q_dof = [torch.tensor(U_dof[idn, 0]), torch.tensor(U_dof[idn, 1:13]), torch.tensor(U_dof[idn, 13]), torch.tensor(U_dof[idn, 14])]
+    q_rst = [U_rst[idn, 0:12], U_rst[idn, 12:13], U_rst[idn, 13:14], U_rst[idn, 14:15], U_rst[idn, 15:21]]
+    real_rand, real_trf = torch.rand, ref_mod.torch_rand_float
+    torch.rand = lambda *a, **k: q_dof.pop(0)
+
+    def trf(lo, hi, shape, device=None):
+        u = torch.tensor(q_rst.pop(0))
+        assert tuple(u.shape) == tuple(shape)
+        return (hi - lo) * u + lo                                   # isaacgym.torch_utils.torch_rand_float (SURVEY App. E)
+    ref_mod.torch_rand_float = trf
+    try:
+        LR._randomize_dof_props(e, ids, e.cfg)
+        LR._reset_dofs(e, ids, e.cfg)
+        LR._reset_root_states(e, ids, e.cfg)
+    finally:
+        torch.rand, ref_mod.torch_rand_float = real_rand, real_trf
+    assert not q_dof and not q_rst
+    out = dict(env_ids=idn, dof_pos1=e.dof_pos, dof_vel1=e.dof_vel, root_states1=e.root_states, motor_strengths1=e.motor_strengths,
+               motor_offsets1=e.motor_offsets, Kp_factors1=e.Kp_factors, Kd_factors1=e.Kd_factors,
+               sim_seed=np.array(sim_seed), step=np.array(step))
+    np.savez_compressed(os.path.join(HERE, "reset.npz"), **flat(pre), **flat(out))
+    print("reset: envs", len(idn), "yaw span", float(e.root_states[ids, 5].abs().max()))
+
+
 if __name__ == "__main__":
     install_stubs()
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "resample":            # only the resample_*.npz fixtures
+        for mode in RESAMPLE_MODES:
+            for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+                del sys.modules[m]
+            gen_resample(mode)
+        for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+            del sys.modules[m]
+        gen_reset()
+        sys.exit(0)
     gen_curriculum()
     gen_ppo()
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
@@ -436,3 +605,10 @@ if __name__ == "__main__":
         for m in [k for k in sys.modules if k.startswith("go1_gym")]:
             del sys.modules[m]
         gen_torques(v)
+    for mode in RESAMPLE_MODES:
+        for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+            del sys.modules[m]
+        gen_resample(mode)
+    for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+        del sys.modules[m]
+    gen_reset()

@@ -22,6 +22,14 @@ VARIANTS = {
         "reward_scales": dict(tracking_lin_vel=20.0, orientation=-5.0, dof_pos=-0.05, feet_contact_forces=-0.01, feet_impact_vel=-0.1,
                               feet_contact_vel=-0.1),
     },
+    # north_star's "domain-randomisation pushes" and the other step-callback branches that train.py leaves off: velocity
+    # pushes (legged_robot.py:1017-1026), edge teleport (:1028-1051), re-drawn rigid-body properties (:706-708,166-168);
+    # kernel-vs-oracle only (no fixture: the reference draws these from torch's global RNG)
+    "dr": {
+        "domain_rand": dict(push_robots=True, push_interval_s=0.25, max_push_vel_xy=0.8, randomize_rigids_after_start=True,
+                            rand_interval_s=0.15, randomize_gravity=True),
+        "terrain": dict(teleport_robots=True, teleport_thresh=0.4),
+    },
 }
 
 

@@ -43,6 +43,36 @@ def test_hip_post_physics_maps_match_reference_golden(variant, fname):
     np.testing.assert_allclose(g("privileged_obs_buf").numpy()[keep][:, :S.num_privileged_obs], d["out_priv"][keep], rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("variant", ["train", "alt"])
+@pytest.mark.parametrize("n_env", [16, 8])
+def test_hip_torque_model_matches_reference_golden(variant, n_env):
+    """HIP torque model DIRECTLY against tests/golden/torques_*.npz — outputs of the reference's `_compute_torques` with the
+    TorchScript actuator network (legged_robot.py:907-946,1242-1251; fp32 torch).  ONE tolerance for both evaluation
+    paths of the kernel: 16 envs = a full wavefront = hidden layer on the matrix cores (fp16 hi/lo split, fp32
+    accumulate), 8 envs = partial wavefront = plain fp32 FMAs.  2e-5 N m absolute + 1e-5 relative is what separates two
+    correct fp32 evaluations of this network with different summation orders (the fp64 oracle meets the same bound in
+    tests/test_oracle_golden.py); SURVEY 8c(i)'s 1e-6 is below one fp32 ulp of a 20 N m torque (1.9e-6)."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", f"torques_{variant}.npz"))
+    steps = d["actions"].shape[0]
+    cfg, S, meta, Bc = make_sim(variant, n_env)
+    for k in ("motor_strengths", "motor_offsets", "Kp_factors", "Kd_factors"):
+        getattr(Bc, k)[:] = torch.from_numpy(d[k][:n_env]).t()
+    Bg = Bc.clone_to("cuda:0")
+    sim = H.Go1Sim(S, Bg, 0)
+    worst = 0.0
+    for s_ in range(steps):
+        Bg.dof_pos.copy_(torch.from_numpy(d["dof_pos"][s_][:n_env]).t())
+        Bg.dof_vel.copy_(torch.from_numpy(d["dof_vel"][s_][:n_env]).t())
+        sim.compute_torques(torch.from_numpy(np.ascontiguousarray(d["actions"][s_][:n_env].T)).cuda())
+        torch.cuda.synchronize()
+        tau = Bg.torques.t().cpu().numpy()
+        np.testing.assert_allclose(Bg.joint_pos_target.t().cpu().numpy(), d["joint_pos_target"][s_][:n_env], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(tau, d["torques"][s_][:n_env], rtol=1e-5, atol=2e-5)
+        worst = max(worst, float(np.abs(tau - d["torques"][s_][:n_env]).max()))
+    print(f"torque model vs reference ({variant}, {n_env} envs): max abs error {worst:.2e} N m")
+    assert int(Bg.fault_counts.sum()) == 0
+
+
 def build_env(N=64):
     from go1_gym.envs.base.legged_robot_config import make_cfg
     from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv

@@ -61,7 +61,7 @@ def test_torque_model_matches_oracle(variant):
         orc.compute_torques(a.numpy())
         sim.compute_torques(a.cuda().contiguous())
         torch.cuda.synchronize()
-        np.testing.assert_allclose(Bg.torques.cpu().numpy(), Bc.torques.numpy(), rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(Bg.torques.cpu().numpy(), Bc.torques.numpy(), rtol=1e-5, atol=2e-5)
         np.testing.assert_allclose(Bg.joint_pos_target.cpu().numpy(), Bc.joint_pos_target.numpy(), rtol=1e-6, atol=1e-6)
     for k in ("joint_pos_err_last", "joint_pos_err_last_last", "joint_vel_last", "joint_vel_last_last", "lag_buffer"):
         np.testing.assert_allclose(Bg.tensors[k].cpu().numpy(), Bc.tensors[k].numpy(), rtol=1e-6, atol=1e-6)
@@ -108,7 +108,7 @@ def test_physics_substep_matches_oracle(scenario):
         assert float(Bc.contact_forces.abs().max()) > 1.0
 
 
-def run_full_step_comparison(variant, N, steps, seed=11):
+def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=None):
     """HIP step vs oracle step on identical state / action / RNG streams, re-synchronised after every step so that each
     step is compared on its own (a free-running pair diverges through contact-mode flips, as two fp32 PhysX runs
     would).  Returns (worst, mean) fraction of environments outside the per-quantity tolerances, and event counts."""
@@ -116,6 +116,8 @@ def run_full_step_comparison(variant, N, steps, seed=11):
     Bg, sim = to_gpu(S, Bc)
     rng = np.random.default_rng(0)
     Bc.episode_length_buf[:] = torch.randint(0, S.max_episode_length, (N,), dtype=torch.int32, generator=torch.Generator().manual_seed(2))
+    if prepare is not None:
+        prepare(S, Bc)
     sync_from(Bc, Bg, sim, orc)
     resets = 0
     resamples = 0
@@ -125,6 +127,8 @@ def run_full_step_comparison(variant, N, steps, seed=11):
         if step == 20:
             a[:] = 12.0          # action clipping
         cmd_before = Bc.commands.clone()
+        if watch is not None:
+            watch(S, Bc, "before")
         orc.step(a)
         sim.step(torch.from_numpy(a).cuda())
         torch.cuda.synchronize()
@@ -151,7 +155,13 @@ def run_full_step_comparison(variant, N, steps, seed=11):
         np.testing.assert_allclose(Bg.curriculum_weights.cpu().numpy(), Bc.curriculum_weights.numpy(), atol=0.21 * float(bad_env.sum()) + 1e-6)
         resets += int(cpu_reset.sum())
         resamples += int((cmd_before != Bc.commands).any(0).sum())
+        if watch is not None:
+            watch(S, Bc, "after")
+            for k in ("payloads", "friction_coeffs", "restitutions", "com_displacements"):
+                bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], 1e-6)
+                assert not bool(bad[..., ~bad_env].any()), k
         sync_from(Bc, Bg, sim, orc)
+    assert int(Bg.fault_counts[:10].sum()) == 0, Bg.fault_counts.tolist()
     return worst, total_bad / steps, resets, resamples, timeouts
 
 
@@ -160,6 +170,40 @@ def test_full_step_matches_oracle(variant):
     worst, mean, resets, resamples, _ = run_full_step_comparison(variant, 512, 40)
     assert resets > 20 and resamples > 20      # resets and interval resamples were exercised
     assert worst <= 0.02, worst
+
+
+def test_push_teleport_and_rigid_rerandomisation_match_oracle():
+    """The step-callback branches train.py leaves switched off — velocity pushes (north_star's "domain-randomisation
+    pushes", legged_robot.py:1017-1026), edge teleport (:1028-1051) and re-drawn rigid-body properties
+    (:706-708, 166-168) — all enabled, kernel vs oracle on identical streams, and each observed to fire."""
+    seen = {"teleport": 0, "push": 0, "rigid": 0}
+    keep = {}
+
+    def prepare(S, B):
+        N = B.root_states.shape[1]
+        span_x, span_y = S.terrain_length * S.terrain_num_rows, S.terrain_width * S.terrain_num_cols
+        g = torch.Generator().manual_seed(5)
+        B.env_origins[0] = torch.where(torch.rand(N, generator=g) < 0.5, torch.full((N,), 0.45), torch.full((N,), span_x - 0.45))
+        B.env_origins[1] = torch.where(torch.rand(N, generator=g) < 0.5, torch.full((N,), 0.45), torch.full((N,), span_y - 0.45))
+        B.root_states[0] = B.env_origins[0] + torch.empty(N).uniform_(-0.2, 0.2, generator=g)
+        B.root_states[1] = B.env_origins[1] + torch.empty(N).uniform_(-0.2, 0.2, generator=g)
+
+    def watch(S, B, when):
+        if when == "before":
+            keep["xy"], keep["v"], keep["m"] = B.root_states[:2].clone(), B.root_states[7:9].clone(), B.payloads.clone()
+            keep["len"] = B.episode_length_buf.clone()
+            return
+        live = B.reset_buf == 0
+        jump = (B.root_states[:2] - keep["xy"]).abs().max(0).values
+        seen["teleport"] += int(((jump > 50.0) & live).sum())
+        pushed = live & ((keep["len"] + 1) % S.push_interval == 0)
+        seen["push"] += int(pushed.sum())
+        if bool(pushed.any()):
+            assert float(B.root_states[7:9][:, pushed].abs().max()) <= S.max_push_vel_xy + 1e-6
+        seen["rigid"] += int(((B.payloads != keep["m"]) & live).sum())
+    worst, mean, resets, resamples, _ = run_full_step_comparison("dr", 256, 60, seed=17, prepare=prepare, watch=watch)
+    assert seen["teleport"] > 10 and seen["push"] > 50 and seen["rigid"] > 50, seen
+    assert worst <= 0.03, worst
 
 
 def test_thousand_steps_match_oracle():
@@ -171,6 +215,47 @@ def test_thousand_steps_match_oracle():
     assert mean <= 0.01 and worst <= 0.05, (mean, worst)
 
 
+
+
+def test_free_running_distributions_match_oracle():
+    """No re-synchronisation: kernel and oracle start from the same state and receive the same action and RNG streams for
+    600 policy steps (256 envs, N(0,1) actions, train.py configuration).  Individual trajectories separate at the first
+    contact-mode flip — as two fp32 PhysX runs would — so the comparison is distributional: mean episode length, mean
+    step reward, per-term episode sums per episode, foot-contact duty factor, mean base height, command-curriculum mass.
+    ~2000 episodes per side: sampling noise is ~3 % (1 sigma) on the episode statistics; bounds are 4 sigma."""
+    N, steps = 256, 600
+    cfg, S, meta, Bc, orc = gpu_pair("train_noise", N, seed=29)
+    Bg, sim = to_gpu(S, Bc)
+    sync_from(Bc, Bg, sim, orc)
+    rng = np.random.default_rng(3)
+    nr = S.num_rewards
+    acc = {"cpu": np.zeros(5), "gpu": np.zeros(5)}
+    for step in range(steps):
+        a = rng.standard_normal((N, 12)).astype(np.float32)
+        orc.step(a)
+        sim.step(torch.from_numpy(a).cuda())
+        for tag, B in (("cpu", Bc), ("gpu", Bg)):
+            cf = B.contact_forces.view(17, 3, N)
+            acc[tag] += np.array([float(B.reset_buf.sum()), float(B.rew_buf.sum()), float((cf[[4, 8, 12, 16], 2] > 1.0).float().mean()),
+                                  float(B.root_states[2].mean()), float(B.time_out_buf.sum())])
+    torch.cuda.synchronize()
+    out = {}
+    for tag, B in (("cpu", Bc), ("gpu", Bg)):
+        log = B.episode_log.cpu().double().numpy()
+        n_ep = max(log[nr + 1], 1.0)
+        out[tag] = dict(ep_len=N * steps / max(acc[tag][0], 1), rew=acc[tag][1] / (N * steps), duty=acc[tag][2] / steps,
+                        height=acc[tag][3] / steps, terms=log[:nr + 1] / n_ep, weight_mass=float(B.curriculum_weights.sum()))
+    c, g = out["cpu"], out["gpu"]
+    print(f"free-running: episode length {c['ep_len']:.1f} / {g['ep_len']:.1f}, step reward {c['rew']:.5f} / {g['rew']:.5f}, "
+          f"foot duty {c['duty']:.3f} / {g['duty']:.3f}, base height {c['height']:.4f} / {g['height']:.4f} (oracle / HIP)")
+    assert acc["cpu"][0] > 1000 and acc["gpu"][0] > 1000
+    assert abs(c["ep_len"] - g["ep_len"]) <= 0.12 * c["ep_len"]
+    assert abs(c["duty"] - g["duty"]) <= 0.03 and abs(c["height"] - g["height"]) <= 0.01
+    assert abs(c["rew"] - g["rew"]) <= 0.15 * abs(c["rew"]) + 2e-4
+    scale = np.abs(c["terms"]).max()
+    assert np.all(np.abs(c["terms"] - g["terms"]) <= 0.15 * np.abs(c["terms"]) + 0.02 * scale), (c["terms"], g["terms"])
+    assert abs(c["weight_mass"] - g["weight_mass"]) <= 0.05 * c["weight_mass"] + 1.0
+    assert int(Bg.fault_counts[:10].sum()) == 0
 
 
 def rough_field(rows=240, cols=240, amp=0.08, seed=0, hscale=0.1, vscale=0.005):

@@ -73,3 +73,43 @@ def load_maps_fixture(name, S, meta, B):
     B.episode_sums[:] = t("episode_sums")
     B.command_sums[:] = t("command_sums")
     return d
+
+
+RESAMPLE_MODES = {"gaitwise": dict(gaitwise_curricula=True, exclusive_phase_offset=False, balance_gait_distribution=False, binary_phases=True),
+                  "exclusive": dict(gaitwise_curricula=False, exclusive_phase_offset=True, balance_gait_distribution=False, binary_phases=True),
+                  "balance": dict(gaitwise_curricula=False, exclusive_phase_offset=False, balance_gait_distribution=True, binary_phases=False),
+                  "plain": dict(gaitwise_curricula=False, exclusive_phase_offset=False, balance_gait_distribution=False, binary_phases=False)}
+
+
+def load_resample_fixture(mode):
+    """tests/golden/resample_<mode>.npz (reference `_resample_commands` + curriculum update, make_golden.py gen_resample) ->
+    (fixture, S, meta, B) with the pre-resample state in CPU buffers."""
+    d = np.load(os.path.join(GOLDEN, f"resample_{mode}.npz"))
+    N = d["commands0"].shape[0]
+    cfg, S, meta, B = make_sim("train", N, seed=int(d["sim_seed"]), extra={"commands": RESAMPLE_MODES[mode]})
+    assert meta["category_names"] == [str(x) for x in d["category_names"]]
+    assert meta["command_sum_names"] == [str(x) for x in d["command_sum_names"]]
+    B.commands[:] = torch.from_numpy(d["commands0"]).t()
+    B.command_sums[:] = torch.from_numpy(d["command_sums0"])
+    B.env_command_bins[:] = torch.from_numpy(d["bins0"]).int()
+    B.env_command_categories[:] = torch.from_numpy(d["cats0"]).int()
+    w0 = d["weights0"].astype(np.float32)
+    B.curriculum_weights[:] = torch.from_numpy(w0)
+    cdf = np.cumsum(w0.astype(np.float64), axis=1)
+    B.curriculum_cdf[:] = torch.from_numpy((cdf / cdf[:, -1:]).astype(np.float32))
+    return d, S, meta, B
+
+
+def check_resample_against_reference(d, B, atol=1e-6):
+    """commands / bins / categories / cleared sums of the resampled envs, untouched rows of the others, then the weights."""
+    ids = d["env_ids"]
+    rest = np.setdiff1d(np.arange(B.commands.shape[1]), ids)
+    cmd = B.commands.t().cpu().numpy()
+    np.testing.assert_array_equal(B.env_command_categories.cpu().numpy()[ids], d["cats1"][ids])
+    np.testing.assert_array_equal(B.env_command_bins.cpu().numpy()[ids], d["bins1"][ids])
+    np.testing.assert_allclose(cmd[ids], d["commands1"][ids], rtol=0, atol=atol)
+    np.testing.assert_array_equal(cmd[rest], d["commands0"][rest])
+    sums = B.command_sums.cpu().numpy()
+    assert np.all(sums[:, ids] == 0) and np.array_equal(sums[:, rest], d["command_sums0"][:, rest])
+    np.testing.assert_allclose(B.curriculum_weights.cpu().numpy(), d["weights1"], rtol=0, atol=1e-6)
+    assert np.abs(d["weights1"] - d["weights0"]).sum() > 1.0

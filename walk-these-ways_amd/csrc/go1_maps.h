@@ -14,7 +14,7 @@ typedef const GO1_CONSTANT Go1SimConfig& CfgRef;
 typedef const GO1_CONSTANT Go1SimBuffers& BufRef;
 
 #define PI_F 3.14159265358979323846f
-enum { P_NOISE = 1, P_RESET = 2, P_DOFPROPS_CB = 3, P_DOFPROPS_RESET = 4, P_CMD_CB = 5, P_CMD_RESET = 6, P_PUSH = 7, P_GRAVITY = 8 };
+enum { P_NOISE = 1, P_RESET = 2, P_DOFPROPS_CB = 3, P_DOFPROPS_RESET = 4, P_CMD_CB = 5, P_CMD_RESET = 6, P_PUSH = 7, P_GRAVITY = 8, P_RIGID = 9, P_RIGID_RESET = 10 };
 
 #define AT(ptr, c, e) ((ptr)[(size_t)(c) * N + (e)])
 
@@ -86,6 +86,22 @@ DEV void resample_commands(CfgRef cfg, BufRef B, int e, int N, int64_t step, uin
         else if (cat == 1) { cmd[5] = cmd[5] / 2 + 0.25f; cmd[6] = 0.f; cmd[7] = 0.f; }
         else if (cat == 2) { cmd[5] = 0.f; cmd[6] = cmd[6] / 2 + 0.25f; cmd[7] = 0.f; }
         else { cmd[5] = 0.f; cmd[6] = 0.f; cmd[7] = cmd[7] / 2 + 0.25f; }
+      } else if (cfg.exclusive_phase_offset) {            // legged_robot.py:783-793: one of phase / offset / bound survives
+        const float r = rng_uniform(cfg, eg, step, purpose, 2 + GO1_MAX_COMMANDS);
+        const bool trot = r < 0.34f, pace = 0.34f <= r && r < 0.67f, bnd = 0.67f <= r;
+        if (pace || bnd) cmd[5] = 0.f;
+        if (trot || bnd) cmd[6] = 0.f;
+        if (trot || pace) cmd[7] = 0.f;
+      } else if (cfg.balance_gait_distribution) {         // :795-812, same statement order (the 0.25 boundary belongs to two sets)
+        const float r = rng_uniform(cfg, eg, step, purpose, 2 + GO1_MAX_COMMANDS);
+        const bool pronk = r <= 0.25f, trot = 0.25f <= r && r < 0.50f, pace = 0.50f <= r && r < 0.75f, bnd = 0.75f <= r;
+        if (pronk) { cmd[5] = fmod1(cmd[5] / 2 - 0.25f); cmd[6] = fmod1(cmd[6] / 2 - 0.25f); cmd[7] = fmod1(cmd[7] / 2 - 0.25f); }
+        if (trot) { cmd[6] = 0.f; cmd[7] = 0.f; }
+        if (pace) { cmd[5] = 0.f; cmd[7] = 0.f; }
+        if (bnd) { cmd[5] = 0.f; cmd[6] = 0.f; }
+        if (trot) cmd[5] = cmd[5] / 2 + 0.25f;
+        if (pace) cmd[6] = cmd[6] / 2 + 0.25f;
+        if (bnd) cmd[7] = cmd[7] / 2 + 0.25f;
       }
       if (cfg.binary_phases) {
         cmd[5] = fmod1(rintf(2 * cmd[5]) / 2.0f); cmd[6] = fmod1(rintf(2 * cmd[6]) / 2.0f); cmd[7] = fmod1(rintf(2 * cmd[7]) / 2.0f);
@@ -127,10 +143,29 @@ DEV void randomize_dof_props(CfgRef cfg, BufRef B, int e, int N, int64_t step, u
   }
 }
 
+// _randomize_rigid_body_props when called from the step callback (randomize_rigids_after_start, legged_robot.py:706-708).
+// Deviation, documented in DESIGN.md: the reference re-draws payload / COM into its tensors but never pushes them into
+// PhysX (only friction / restitution of the first 12 of 17 shapes are refreshed, App. D9), so there the privileged
+// observation stops describing the simulated body; here the re-drawn values ARE the simulated body, whole robot.
+DEV void randomize_rigid_props(CfgRef cfg, BufRef B, int e, int N, int64_t step, uint32_t purpose) {
+  const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
+  if (cfg.randomize_base_mass)
+    B.payloads[e] = rng_uniform(cfg, eg, step, purpose, 0) * (cfg.added_mass_range[1] - cfg.added_mass_range[0]) + cfg.added_mass_range[0];
+  if (cfg.randomize_com_displacement)
+#pragma unroll 1
+    for (int i = 0; i < 3; i++)
+      AT(B.com_displacements, i, e) = rng_uniform(cfg, eg, step, purpose, 1 + i) * (cfg.com_displacement_range[1] - cfg.com_displacement_range[0]) + cfg.com_displacement_range[0];
+  if (cfg.randomize_friction)
+    B.friction_coeffs[e] = rng_uniform(cfg, eg, step, purpose, 4) * (cfg.friction_range[1] - cfg.friction_range[0]) + cfg.friction_range[0];
+  if (cfg.randomize_restitution)
+    B.restitutions[e] = rng_uniform(cfg, eg, step, purpose, 5) * (cfg.restitution_range[1] - cfg.restitution_range[0]) + cfg.restitution_range[0];
+}
+
 DEV void reset_env(CfgRef cfg, BufRef B, int e, int N, int64_t step) {
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
   resample_commands(cfg, B, e, N, step, P_CMD_RESET);
   randomize_dof_props(cfg, B, e, N, step, P_DOFPROPS_RESET);
+  if (cfg.randomize_rigids_after_start) randomize_rigid_props(cfg, B, e, N, step, P_RIGID_RESET);      // legged_robot.py:166-168
 #pragma unroll 1
   for (int j = 0; j < 12; j++) {
     AT(B.dof_pos, j, e) = cfg.default_dof_pos[j] * (0.5f + rng_uniform(cfg, eg, step, P_RESET, j));
@@ -428,7 +463,10 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
       AT(B.root_states, 7, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, 0) - 1) * cfg.max_push_vel_xy;
       AT(B.root_states, 8, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, 1) - 1) * cfg.max_push_vel_xy;
     }
-    if (ep_len % cfg.rand_interval == 0) randomize_dof_props(cfg, B, e, N, counter_post, P_DOFPROPS_CB);
+    if (ep_len % cfg.rand_interval == 0) {
+      randomize_dof_props(cfg, B, e, N, counter_post, P_DOFPROPS_CB);
+      if (cfg.randomize_rigids_after_start) randomize_rigid_props(cfg, B, e, N, counter_post, P_RIGID);
+    }
   }
   PROF(9);
   // ---- own foot / bodies -------------------------------------------------------------------------

@@ -168,6 +168,13 @@ def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curricu
     _fill(S.motor_offset_range, getattr(dr, "motor_offset_range", [0.0, 0.0]))
     _fill(S.Kp_factor_range, dr.Kp_factor_range)
     _fill(S.Kd_factor_range, dr.Kd_factor_range)
+    S.randomize_rigids_after_start = int(getattr(dr, "randomize_rigids_after_start", False))
+    S.randomize_base_mass, S.randomize_com_displacement = int(dr.randomize_base_mass), int(dr.randomize_com_displacement)
+    S.randomize_friction, S.randomize_restitution = int(dr.randomize_friction), int(dr.randomize_restitution)
+    _fill(S.added_mass_range, dr.added_mass_range)
+    _fill(S.com_displacement_range, dr.com_displacement_range)
+    _fill(S.friction_range, dr.friction_range)
+    _fill(S.restitution_range, dr.restitution_range)
     ter = cfg.terrain
     custom_origins = ter.mesh_type in ("heightfield", "trimesh")
     S.teleport_robots = int(ter.teleport_robots and custom_origins)
@@ -269,6 +276,8 @@ def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curricu
     S.device_curriculum = int(device_curriculum)
     S.gaitwise_curricula = int(cm.gaitwise_curricula)
     S.binary_phases = int(cm.binary_phases)
+    S.exclusive_phase_offset = int(getattr(cm, "exclusive_phase_offset", False))
+    S.balance_gait_distribution = int(getattr(cm, "balance_gait_distribution", False))
     cat_names, curricula = build_curricula(cfg)
     S.num_categories = len(cat_names)
     S.num_bins = len(curricula[0])
