@@ -39,7 +39,10 @@ ALGORITHMIC_BYTES_PER_ENV_STEP = 3444      # 1,332 B read + 1,
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def build_env(num_envs, rank, seed):
+def build_env(num_envs, rank, seed, rough=False):
+    """train.py configuration (BASELINE configs[1]); rough=True: configs[2] — the terrain curriculum's tile grid
+    (slopes / rough slopes / stairs / obstacles, cfg:64-102 defaults) as a height field + the 187-point height scan
+    appended to the observation (70 + 187 = 257)."""
     from go1_gym.envs.base.legged_robot_config import make_cfg
     from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
     from go1_gym.envs.wrappers.history_wrapper import HistoryWrapper
@@ -47,6 +50,13 @@ def build_env(num_envs, rank, seed):
     cfg = apply_train_config(make_cfg(), num_envs=num_envs)
     cfg.seed = seed
     cfg.env.env_id_offset = rank * num_envs
+    if rough:
+        t = cfg.terrain
+        t.mesh_type, t.terrain_proportions, t.curriculum = "heightfield", [0.1, 0.1, 0.35, 0.25, 0.2], True
+        t.num_rows, t.num_cols, t.terrain_length, t.terrain_width, t.border_size, t.center_robots = 10, 20, 8.0, 8.0, 25.0, False
+        t.measure_heights = True
+        cfg.env.observe_heights = True
+        cfg.env.num_observations = cfg.env.num_scalar_observations = 70 + 187
     env = VelocityTrackingEasyEnv(sim_device=f"cuda:{torch.cuda.current_device()}", headless=True, cfg=cfg)
     return HistoryWrapper(env), cfg
 
@@ -106,6 +116,88 @@ def cpu_baseline(num_envs, target_seconds=15.0):
                       f"(oracle/go1_oracle.c, OpenMP over envs, {cores} threads = cgroup CPU quota), N(0,1) actions, {dt:.1f} s"}
 
 
+def time_sim_only(env, sim, envs, policy_steps, device, warmup=48):
+    """SURVEY 8(d) metric 1: env.step alone with pre-generated N(0,1) actions; returns (env-steps/s, mean launch ms)."""
+    acts = torch.randn(24, envs, 12, device=device)
+    for t in range(warmup):
+        env.step(acts[t % 24])
+    sim.enable_timing(policy_steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(policy_steps):
+        env.step(acts[t % 24])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = sim.read_timings()
+    return envs * policy_steps / dt, sum(ms) / max(len(ms), 1)
+
+
+def time_iterations(runner, env, obs_dict, iters, rollout_only=False, warmup=2):
+    T, n = runner.num_steps_per_env, env.num_train_envs
+
+    def one(obs_dict):
+        with torch.inference_mode():
+            for _ in range(T):
+                obs_dict, _ = runner._rollout_step(obs_dict)
+            runner.alg.compute_returns(obs_dict["obs_history"][:n], obs_dict["privileged_obs"][:n])
+        if rollout_only:
+            runner.alg.storage.clear()
+        else:
+            runner.alg.update()
+        return obs_dict
+    for _ in range(warmup):
+        obs_dict = one(obs_dict)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        obs_dict = one(obs_dict)
+    torch.cuda.synchronize()
+    return env.num_envs * T * iters / (time.perf_counter() - t0), obs_dict
+
+
+def extra_records(args, env, runner, obs_dict, device):
+    """The other measurements SURVEY 8(d) defines, in the same JSON line (rank 0, one GPU): the sim-only and
+    sim + inference rates of the headline configuration, BASELINE configs[2] (rough terrain + height scan) and the
+    per-GPU size of configs[4] (8192 envs).  Each leg is independent: a failure is recorded, never raised."""
+    from go1_gym_learn.ppo_cse import Runner
+    out = {}
+    sim = env.env.sim
+    try:
+        roll, obs_dict = time_iterations(runner, env, obs_dict, 10, rollout_only=True)
+        so, ms = time_sim_only(env, sim, args.envs, 240, device)
+        out["rates"] = {"sim_only": so, "rollout_only": roll, "unit": "env-steps/s", "step_kernel_launch_ms_sim_only": ms,
+                        "note": "SURVEY 8(d) metrics 1 and 2 on the headline configuration; metric 3 is `value`"}
+    except Exception as err:
+        out["rates"] = {"error": f"{type(err).__name__}: {err}"}
+    try:
+        env3, _ = build_env(args.envs, 0, args.seed, rough=True)
+        env3.reset()
+        so, ms = time_sim_only(env3, env3.env.sim, args.envs, 240, device)
+        out["height_field"] = {"workload": "BASELINE configs[2]: terrain-curriculum tile grid as int16 height field, bilinear contact, "
+                                           "187-point height scan in the observation (257 wide), 4096 envs, N(0,1) actions, sim step only",
+                               "launch_ms": ms, "env_steps_s": so}
+        del env3
+    except Exception as err:
+        out["height_field"] = {"error": f"{type(err).__name__}: {err}"}
+    try:
+        from torch.cuda import tunable
+        if tunable.is_enabled():
+            tunable.tuning_enable(False)         # shapes of this size are not in the shipped table: use hipBLASLt's default pick
+        env8, _ = build_env(8192, 0, args.seed)
+        runner8 = Runner(env8, device=device)
+        env8.episode_length_buf.copy_(torch.randint_like(env8.episode_length_buf, high=int(env8.max_episode_length)))
+        od8 = env8.get_observations()
+        full, od8 = time_iterations(runner8, env8, od8, 5, warmup=3)
+        so, ms = time_sim_only(env8, env8.env.sim, 8192, 240, device)
+        out["envs_8192"] = {"workload": "per-GPU size of BASELINE configs[4]: 8192 envs, train.py configuration, one GPU; GEMM "
+                                        "selections untuned for this batch size", "env_steps_s": full, "sim_only_env_steps_s": so,
+                            "step_kernel_launch_ms": ms}
+        del runner8, env8
+    except Exception as err:
+        out["envs_8192"] = {"error": f"{type(err).__name__}: {err}"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +213,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry run: all ranks share GPU 0 (with --backend gloo)")
     ap.add_argument("--breakdown", action="store_true", help="diagnostic: print rollout/update split to stderr (adds syncs)")
+    ap.add_argument("--headline-only", action="store_true", help="skip the extra single-GPU records (rates, height field, 8192 envs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -216,14 +309,18 @@ def main():
     if rank == 0:
         total_env_steps = args.envs * T * args.steps * world
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
-        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same N)
-        try:
-            with open(os.path.join(REPO, "profiles", "r01_step_kernel_pmc.json")) as f:
-                pmc = json.load(f)
-            if args.envs == 4096:
-                traffic = pmc["hbm_traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_src = None, None   # HBM bytes per launch: NOT measured by this run — read from the committed PMC passes
+        for name in ("r02_step_kernel_pmc.json", "r01_step_kernel_pmc.json"):
+            try:
+                with open(os.path.join(REPO, "profiles", name)) as f:
+                    pmc = json.load(f)
+                if args.envs == 4096:
+                    traffic = pmc["hbm_traffic_bytes_per_launch"]
+                    traffic_src = f"profiles/{name} (committed rocprofv3 --pmc passes of this kernel at 4096 envs, not this run)"
+                break
+            except (OSError, KeyError, ValueError):
+                continue
+        faults = env.env.extras["sim_faults"].consume()
         bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * args.envs
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
@@ -238,11 +335,21 @@ def main():
                        "physics_dtype": "f32", "step": "one PPO iteration = 24 x envs env-steps + update",
                        "parallelism": f"dp{world} (envs sharded, RCCL gradient all-reduce)" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "go1_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": avg_ms, "launches": len(kernel_ms), "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "latency/issue-bound O(n_dof) recursion: the HBM fraction is reported as north_star requires, "
                                  "it is not the limiter (DESIGN.md Measurement)"},
         }
+        out["guard_activations"] = {"fatal": faults["fatal"], "by_site": {k: v for k, v in faults.items() if k != "fatal" and v},
+                                    "env_steps": args.envs * T * (args.steps + args.warmup),
+                                    "note": "containments of failed environments (include/go1sim.h Go1FaultBit) during warm-up + timed steps"}
+        if world == 1 and not args.headline_only and not (args.sim_only or args.rollout_only):
+            out.update(extra_records(args, env, runner, obs_dict, device))
+        try:
+            with open(os.path.join(REPO, "profiles", "reference_python_maps_cpu.json")) as f:
+                out["reference_python_maps_cpu"] = json.load(f)       # produced where /root/reference exists (tools/time_reference_maps.py)
+        except (OSError, ValueError):
+            out["reference_python_maps_cpu"] = None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.envs)
         print(json.dumps(out))

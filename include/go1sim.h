@@ -134,6 +134,9 @@ typedef struct Go1SimConfig {
   float bounce_threshold_velocity;
   float terrain_friction;          /* Cfg.terrain.static_friction */
   float terrain_restitution;
+  float max_linear_velocity, max_angular_velocity;   /* Cfg.asset.max_*_velocity (1000): magnitude caps on the base twist */
+  float joint_limit_margin;        /* rad/s, rad: a joint's limit row enters the solver when its free rate comes within      */
+  float joint_limit_pos_margin;    /* joint_limit_margin of +-vmax, or would carry it to within joint_limit_pos_margin of a stop  */
   int32_t solver_iterations;       /* PGS sweeps per substep */
   int32_t warm_start;              /* start PGS from last substep's impulses */
   int32_t terrain_type;            /* 0 plane, 1 height field */
@@ -203,6 +206,8 @@ typedef struct Go1SimConfig {
 
   /* --- commands / curriculum: legged_robot.py:710-824, curriculum.py --- */
   int32_t device_curriculum;       /* 1: in-kernel sampling; 0: kernel only raises resample flags */
+  int32_t defer_curriculum_update; /* 1: go1sim_step leaves the weight update to an explicit go1sim_curriculum_update call, so that the
+                                      caller can all-reduce curriculum_success over the ranks first (envs sharded over GPUs) */
   int32_t num_categories;          /* 4 when gaitwise_curricula (pronk, trot, pace, bound) else 1 */
   int32_t gaitwise_curricula, binary_phases;
   int32_t exclusive_phase_offset, balance_gait_distribution;   /* legged_robot.py:783-812 (only without gaitwise_curricula) */

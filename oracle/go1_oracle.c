@@ -395,6 +395,12 @@ static void jac_row(const Kin* k, int dynb, const real* x, const real* d, real* 
 /* Solver contact list: at most GO1_MAX_CONTACTS of the 17 per-body contacts are handed to the solver, taken in
  * this priority order (feet, trunk, calves, thighs, hips); the PGS sweeps follow the same order. */
 #define GO1_MAX_CONTACTS 6
+#define GO1_LIMIT_RECOVERY_RATE 10.0   /* rad/s */
+#define GO1_LIMIT_SAFETY 2.0           /* x velocity limit */
+#define GO1_LIMIT_SLACK 0.2            /* rad beyond a stop */
+#ifndef GO1_LIMIT_INNER
+#define GO1_LIMIT_INNER 4
+#endif
 static const int CONTACT_ORDER[17] = {4, 8, 12, 16, 0, 3, 7, 11, 15, 2, 6, 10, 14, 1, 5, 9, 13};
 
 /* ------------------------------------------------------------------ one physics substep (replaces gym.simulate) */
@@ -440,6 +446,33 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
       if (c->active && kept >= GO1_MAX_CONTACTS) c->active = 0;
       kept += c->active;
     }
+  }
+  /* Joint limits are solver rows, one per joint (generalised impulse along the joint coordinate: equal and opposite on
+   * child and parent, so an actuator pushing against a stop or against the velocity limit cannot create net momentum).
+   * Row j constrains the joint rate to [vlo, vhi] = [max((lo-q)/h, -vmax), min((hi-q)/h, vmax)]; it enters the solve when
+   * the free rate comes within joint_limit_margin of that band. */
+  real TJ[12][NV], AJ[12], vlo[12], vhi[12], lamj[12];
+  int jact[12];
+  for (int j = 0; j < 12; j++) {
+    real lo = (GO1_JOINT_LOWER[j] - s->q[j]) / h, hi = (GO1_JOINT_UPPER[j] - s->q[j]) / h, vl = GO1_JOINT_VEL_LIMIT[j];
+    if (lo > GO1_LIMIT_RECOVERY_RATE) lo = GO1_LIMIT_RECOVERY_RATE;        /* a joint found beyond a stop is brought back at a bounded rate */
+    if (hi < -GO1_LIMIT_RECOVERY_RATE) hi = -GO1_LIMIT_RECOVERY_RATE;
+    vlo[j] = lo > -vl ? lo : -vl;
+    vhi[j] = hi < vl ? hi : vl;
+    lamj[j] = 0;
+    const real mv = (real)cfg->joint_limit_margin, mp = (real)cfg->joint_limit_pos_margin / h;
+    jact[j] = !(v[6 + j] > lo + mp && v[6 + j] < hi - mp && v[6 + j] > -vl + mv && v[6 + j] < vl - mv);
+  }
+  for (int leg = 0; leg < 4; leg++) {        /* the joints of a leg are strongly coupled: one active row brings in the leg's other two */
+    int any = jact[3 * leg] || jact[3 * leg + 1] || jact[3 * leg + 2];
+    jact[3 * leg] = jact[3 * leg + 1] = jact[3 * leg + 2] = any;
+  }
+  for (int j = 0; j < 12; j++) {
+    if (!jact[j]) continue;
+    for (int i = 0; i < NV; i++) TJ[j][i] = 0;
+    TJ[j][6 + j] = 1;
+    chol_solve(L, NV, TJ[j]);
+    AJ[j] = TJ[j][6 + j];
   }
   real J[17][3][NV], T[17][3][NV], A[17][3], vstar[17];
   real mu = 0.5 * (s->mu + (real)cfg->terrain_friction);        /* PhysX default combine mode: average */
@@ -487,6 +520,18 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
       lam[b][1] = l1; lam[b][2] = l2;
       for (int i = 0; i < NV; i++) v[i] += T[b][1][i] * d1 + T[b][2][i] * d2;
     }
+    /* joint rows: leg by leg, GO1_LIMIT_INNER Gauss-Seidel passes over the (strongly coupled) rows of one leg */
+    for (int leg = 0; leg < 4; leg++)
+      for (int rep = 0; rep < GO1_LIMIT_INNER; rep++)
+        for (int j = 3 * leg; j < 3 * leg + 3; j++) {
+          if (!jact[j]) continue;
+          real u0 = v[6 + j] - AJ[j] * lamj[j];                     /* rate without this row's impulse */
+          real ut = u0 < vlo[j] ? vlo[j] : (u0 > vhi[j] ? vhi[j] : u0);
+          real ln = (ut - u0) / AJ[j];
+          real dl = ln - lamj[j];
+          lamj[j] = ln;
+          for (int i = 0; i < NV; i++) v[i] += TJ[j][i] * dl;
+        }
   }
   for (int b = 0; b < 17; b++) {
     for (int i = 0; i < 3; i++) {
@@ -494,11 +539,18 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
       out->force[b][i] = wl[b][i] / h;
     }
   }
-  /* joint velocity limits, then semi-implicit Euler */
+  /* The limit rows leave at most the solver's residual; it is NOT clamped away (a clamp on the joint coordinate alone is
+   * an unbalanced impulse: it breaks momentum conservation, which a learning policy turns into free thrust).  Only a
+   * solver failure far outside the admissible band is cut, at GO1_LIMIT_SAFETY x the limit. */
   for (int j = 0; j < 12; j++) {
-    real vl = GO1_JOINT_VEL_LIMIT[j];
+    real vl = GO1_LIMIT_SAFETY * GO1_JOINT_VEL_LIMIT[j];
     if (v[6 + j] > vl) v[6 + j] = vl;
     if (v[6 + j] < -vl) v[6 + j] = -vl;
+  }
+  {   /* Cfg.asset.max_angular_velocity / max_linear_velocity: magnitude caps on the base twist */
+    real wn2 = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), vn2 = sqrt(v[3] * v[3] + v[4] * v[4] + v[5] * v[5]);
+    if (wn2 > cfg->max_angular_velocity) for (int i = 0; i < 3; i++) v[i] *= cfg->max_angular_velocity / wn2;
+    if (vn2 > cfg->max_linear_velocity) for (int i = 0; i < 3; i++) v[3 + i] *= cfg->max_linear_velocity / vn2;
   }
   for (int i = 0; i < 3; i++) { s->vang[i] = v[i]; s->vlin[i] = v[3 + i]; s->pos[i] += h * v[3 + i]; }
   real wn = v3norm(s->vang);
@@ -512,8 +564,8 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
   for (int j = 0; j < 12; j++) {
     s->qd[j] = v[6 + j];
     s->q[j] += h * s->qd[j];
-    if (s->q[j] < GO1_JOINT_LOWER[j]) { s->q[j] = GO1_JOINT_LOWER[j]; if (s->qd[j] < 0) s->qd[j] = 0; }
-    if (s->q[j] > GO1_JOINT_UPPER[j]) { s->q[j] = GO1_JOINT_UPPER[j]; if (s->qd[j] > 0) s->qd[j] = 0; }
+    if (s->q[j] < GO1_JOINT_LOWER[j] - GO1_LIMIT_SLACK) { s->q[j] = GO1_JOINT_LOWER[j] - GO1_LIMIT_SLACK; if (s->qd[j] < 0) s->qd[j] = 0; }
+    if (s->q[j] > GO1_JOINT_UPPER[j] + GO1_LIMIT_SLACK) { s->q[j] = GO1_JOINT_UPPER[j] + GO1_LIMIT_SLACK; if (s->qd[j] > 0) s->qd[j] = 0; }
   }
 }
 
@@ -1299,7 +1351,7 @@ void go1_oracle_step(const Go1SimConfig* cfg, const Go1SimBuffers* B, const floa
   }
   ctr->common_step_counter = counter_post;
   ctr->history_slot = (ctr->history_slot + 1) % (cfg->num_obs_history + 1);
-  if (cfg->device_curriculum && B->curriculum_weights) go1_oracle_curriculum_update(cfg, B);
+  if (cfg->device_curriculum && B->curriculum_weights && !cfg->defer_curriculum_update) go1_oracle_curriculum_update(cfg, B);
 }
 
 /* piecewise entry points mirroring go1sim_compute_torques / go1sim_physics_substep */

@@ -1,0 +1,27 @@
+"""Build tests/emu/_build/libgo1sim_emu.so: the product's kernel sources (walk-these-ways_amd/csrc/go1sim.hip and its headers,
+unmodified) compiled for the HOST against the SIMT emulator in this directory.  TEST INFRASTRUCTURE: lets the parity tests
+exercise the real device code without a GPU; the product never loads this library."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+CSRC = os.path.join(REPO, "walk-these-ways_amd", "csrc")
+OUT = os.path.join(HERE, "_build", "libgo1sim_emu.so")
+CLANG = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+
+
+def build(force=False):
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
+    deps += [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "emu_runtime.cpp"), os.path.join(REPO, "include", "go1sim.h")]
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-Wno-everything",
+           "-I", HERE, "-o", OUT, os.path.join(CSRC, "go1sim.hip"), os.path.join(HERE, "emu_runtime.cpp")]
+    subprocess.check_call(cmd, cwd=CSRC)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,35 @@
+"""`EmuSim`: the C-ABI of include/go1sim.h served by tests/emu/_build/libgo1sim_emu.so — the product's kernel sources
+compiled for the host against the SIMT emulator — on CPU `SimBuffers`.  TEST INFRASTRUCTURE (see tests/emu/hip/hip_runtime.h)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import build as emu_build  # noqa: E402
+import go1sim_host as H  # noqa: E402
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = H.bind_library(ctypes.CDLL(emu_build.build()))
+    return _lib
+
+
+class EmuSim(H.Go1Sim):
+    def __init__(self, S, buffers, device_index=0):
+        assert buffers.device.type == "cpu"
+        super().__init__(S, buffers, device_index, lib=lib())
+
+    def _stream(self):
+        return ctypes.c_void_p(0)
+
+    def step(self, actions):
+        actions = actions.detach().float().contiguous()
+        self._keep_actions = actions
+        self._check(self.lib.go1sim_step(self.handle, ctypes.c_void_p(actions.data_ptr()), self._stream()), "go1sim_step")

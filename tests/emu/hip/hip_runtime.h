@@ -1,0 +1,200 @@
+// TEST INFRASTRUCTURE — a SIMT emulator that lets the UNMODIFIED kernel sources of walk-these-ways_amd/csrc compile with
+// the host compiler and run on CPU memory, so that the product's device code (not a restatement of it) can be checked
+// against the oracle in the GPU-less authoring container.  It is NOT a backend of the product: go1sim_host.load_library()
+// only ever loads csrc/libgo1sim.so (hipcc, gfx950); this header is reached solely through tests/emu/build.py, which puts
+// tests/emu in front of the include path so that `#include <hip/hip_runtime.h>` resolves here.
+//
+// Execution model: one workgroup = one OS thread; its lanes are ucontext fibers scheduled round-robin and switched only at
+// cross-lane operations (DPP quad permutes, ballots, __syncthreads, MFMA), which are implemented as exchange-through-memory
+// barriers over the lanes that are still running.  Everything between two cross-lane operations runs as ordinary scalar C++
+// in fp32, i.e. the same arithmetic the GPU executes lane by lane (libm instead of the hardware approximations).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <vector>
+
+#define __device__
+#define __global__
+#define __constant__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define __restrict__ __restrict
+#define GO1_CONSTANT            /* constant address space: plain pointers on the host */
+#define HIP_SYMBOL(x) x
+
+namespace emu {
+struct Lane {
+  ucontext_t ctx;
+  char* stack;
+  int tid;
+  bool done;
+};
+struct Block {
+  ucontext_t sched;
+  std::vector<Lane> lanes;
+  int nthreads, bid, cur;
+  int live;                 // lanes that have not returned
+  int arrived;              // lanes waiting at the current barrier
+  uint64_t generation;
+  int qlive[256], qarrived[256];      // the same per quad: DPP quad_perm only couples the four lanes of a quad, and device code
+  uint64_t qgen[256];                 // may execute it under a quad-uniform (not wave-uniform) condition
+  uint32_t slot[64][20];    // exchange area of the cross-lane operations
+};
+extern thread_local Block* blk;
+inline int tid() { return blk->lanes[blk->cur].tid; }
+// barrier over the live lanes: the last one to arrive opens it
+inline void barrier() {
+  Block* b = blk;
+  uint64_t gen = b->generation;
+  if (++b->arrived >= b->live) { b->arrived = 0; b->generation++; return; }
+  while (b->generation == gen) swapcontext(&b->lanes[b->cur].ctx, &b->sched);
+}
+inline void quad_barrier() {
+  Block* b = blk;
+  const int q = b->lanes[b->cur].tid >> 2;
+  uint64_t gen = b->qgen[q];
+  if (++b->qarrived[q] >= b->qlive[q]) { b->qarrived[q] = 0; b->qgen[q]++; return; }
+  while (b->qgen[q] == gen) swapcontext(&b->lanes[b->cur].ctx, &b->sched);
+}
+struct Dim3 { unsigned x, y, z; Dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct Idx { unsigned x, y, z; };
+inline Idx thread_idx() { return Idx{(unsigned)tid(), 0u, 0u}; }
+inline Idx block_idx() { return Idx{(unsigned)blk->bid, 0u, 0u}; }
+void run_block(int bid, int nthreads, void (*fn)(void*), void* arg);
+}  // namespace emu
+
+#define threadIdx (emu::thread_idx())
+#define blockIdx (emu::block_idx())
+typedef emu::Dim3 dim3;
+
+// ---- cross-lane operations ---------------------------------------------------------------------------------------
+inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+  emu::Block* b = emu::blk;
+  const int t = emu::tid();
+  b->slot[t][19] = (uint32_t)src;                                     // (own column of the exchange area: ballots / MFMA use 0..18)
+  emu::quad_barrier();
+  const int from = (t & ~3) | ((ctrl >> (2 * (t & 3))) & 3);          // quad_perm
+  const int r = (int)b->slot[from][19];
+  emu::quad_barrier();
+  return r;
+}
+#define __builtin_amdgcn_update_dpp emu_update_dpp
+inline unsigned long long emu_ballot(bool p) {
+  emu::Block* b = emu::blk;
+  const int t = emu::tid();
+  b->slot[t][0] = p ? 1u : 0u;
+  b->slot[t][1] = 1u;                                                  // "this lane executed the ballot"
+  emu::barrier();
+  unsigned long long m = 0;
+  for (int i = 0; i < b->nthreads; i++)
+    if (!b->lanes[i].done && b->slot[i][0]) m |= 1ull << i;
+  emu::barrier();
+  return m;
+}
+#define __ballot emu_ballot
+inline void __syncthreads() { emu::barrier(); }
+inline void __threadfence_block() {}
+inline void __threadfence() {}
+
+// v_mfma_f32_16x16x32_f16: D = A (16x32) . B (32x16) + C; lane l holds A[l % 16][8 (l / 16) + 0..7],
+// B[8 (l / 16) + 0..7][l % 16] and C/D[4 (l / 16) + 0..3][l % 16]
+typedef __attribute__((ext_vector_type(8))) _Float16 emu_f16x8;
+typedef __attribute__((ext_vector_type(4))) float emu_f32x4;
+inline emu_f32x4 emu_mfma_f32_16x16x32_f16(emu_f16x8 a, emu_f16x8 bb, emu_f32x4 c, int, int, int) {
+  emu::Block* b = emu::blk;
+  const int t = emu::tid();
+  for (int i = 0; i < 8; i++) {
+    float fa = (float)a[i], fb = (float)bb[i];
+    memcpy(&b->slot[t][i], &fa, 4);
+    memcpy(&b->slot[t][8 + i], &fb, 4);
+  }
+  emu::barrier();
+  emu_f32x4 d = c;
+  const int col = t & 15, g = t >> 4;
+  for (int i = 0; i < 4; i++) {
+    const int row = 4 * g + i;
+    float acc = 0.f;
+    for (int kg = 0; kg < 4; kg++)
+      for (int kk = 0; kk < 8; kk++) {
+        float fa, fb;
+        memcpy(&fa, &b->slot[16 * kg + row][kk], 4);
+        memcpy(&fb, &b->slot[16 * kg + col][8 + kk], 4);
+        acc += fa * fb;
+      }
+    d[i] = c[i] + acc;
+  }
+  emu::barrier();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 emu_mfma_f32_16x16x32_f16
+
+// ---- per-lane intrinsics -------------------------------------------------------------------------------------------
+inline float __builtin_amdgcn_rcpf_emu(float x) { return 1.0f / x; }
+inline float __builtin_amdgcn_rsqf_emu(float x) { return 1.0f / sqrtf(x); }
+#define __builtin_amdgcn_rcpf __builtin_amdgcn_rcpf_emu
+#define __builtin_amdgcn_rsqf __builtin_amdgcn_rsqf_emu
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline int __float_as_int(float x) { int r; memcpy(&r, &x, 4); return r; }
+inline float __int_as_float(int x) { float r; memcpy(&r, &x, 4); return r; }
+inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+template <typename T> inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline float atomicAdd(float* p, float v) {
+  uint32_t* ip = (uint32_t*)p;
+  uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED), nw;
+  float f;
+  do { memcpy(&f, &old, 4); f += v; memcpy(&nw, &f, 4); } while (!__atomic_compare_exchange_n(ip, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  memcpy(&f, &old, 4);
+  return f;
+}
+inline float unsafeAtomicAdd(float* p, float v) { return atomicAdd(p, v); }
+template <typename T> inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+
+// ---- runtime API subset used by the C-ABI part of go1sim.hip ------------------------------------------------------------
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+enum { hipSuccess = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : 1; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+
+namespace emu {
+template <typename F, typename... Args> struct Call {
+  F fn; std::tuple<Args...> args;
+};
+template <typename K, typename A> void launch(K kernel, dim3 grid, dim3 block, const A& arg) {
+  struct Ctx { K k; const A* a; };
+  const int nb = (int)grid.x;
+#pragma omp parallel for schedule(dynamic)
+  for (int bid = 0; bid < nb; bid++) {
+    Ctx c{kernel, &arg};
+    run_block(bid, (int)block.x, [](void* p) { Ctx* cc = (Ctx*)p; cc->k(*cc->a); }, &c);
+  }
+}
+template <typename K, typename A, typename B2> void launch(K kernel, dim3 grid, dim3 block, const A& a0, const B2& a1) {
+  struct Ctx { K k; const A* a; const B2* b; };
+  const int nb = (int)grid.x;
+#pragma omp parallel for schedule(dynamic)
+  for (int bid = 0; bid < nb; bid++) {
+    Ctx c{kernel, &a0, &a1};
+    run_block(bid, (int)block.x, [](void* p) { Ctx* cc = (Ctx*)p; cc->k(*cc->a, *cc->b); }, &c);
+  }
+}
+}  // namespace emu
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu::launch(kernel, grid, block, __VA_ARGS__)

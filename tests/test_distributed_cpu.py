@@ -68,3 +68,75 @@ def test_two_rank_gloo_update_keeps_replicas_identical():
     assert r0["lr"] == r1["lr"]
     assert r0["adv_ok"] and r1["adv_ok"]
     assert r0["grad_ok"] and r1["grad_ok"]
+
+
+# ---- one global command curriculum over sharded environments ---------------------------------------------
+def _curriculum_run(rank, world, n_local, steps):
+    """LeggedRobot.step on the oracle-backed stand-in (tests/fake_sim.py): `world` shards of `n_local` envs, or one run
+    over all of them.  Per-env inputs are functions of the GLOBAL env id, so only the sharding differs."""
+    import types
+    import fake_sim
+    import go1sim_host as H
+    from go1_gym.envs.base import base_task
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+    from scripts.train_config import apply_train_config
+    base_task.BaseTask._resolve_device = lambda self, d: (setattr(self, "sim_device_id", 0), "cpu")[1]
+    H.Go1Sim = fake_sim.OracleBackedSim
+    cfg = apply_train_config(make_cfg(), num_envs=n_local)
+    cfg.env.env_id_offset = rank * n_local
+    cfg.terrain.mesh_type = "plane"
+    cfg.commands.resampling_time = 0.16                                  # 8 steps: many interval resamples
+    for k in ("tracking_lin_vel", "tracking_ang_vel", "tracking_contacts_shaped_force", "tracking_contacts_shaped_vel"):
+        setattr(cfg.curriculum_thresholds, k, 0.05)                      # successes do happen under random actions
+    torch.manual_seed(0)
+    env = VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg)
+    gid = torch.arange(n_local) + rank * n_local
+    B = env.buffers
+    B.payloads[:] = -1.0 + 4.0 * ((gid * 37) % 101) / 101.0
+    B.friction_coeffs[:] = 0.1 + 2.9 * ((gid * 53) % 89) / 89.0
+    B.restitutions[:] = 0.4 * ((gid * 29) % 97) / 97.0
+    B.com_displacements.zero_()
+    B.env_origins.zero_()
+    env.reset()
+    g = torch.Generator().manual_seed(3)
+    acts = 0.4 * torch.randn(steps, n_local * world if world > 1 else n_local, 12, generator=g)
+    lo = rank * n_local if world > 1 else 0
+    for t in range(steps):
+        env.step(acts[t, lo:lo + n_local].contiguous())
+    return dict(weights=B.curriculum_weights.clone(), commands=B.commands.clone(), bins=B.env_command_bins.clone(),
+                sync=env._curriculum_sync)
+
+
+def _curriculum_worker(rank, world, port, out):
+    for p in (os.path.join(HERE, "..", "walk-these-ways_amd", "shims"), os.path.join(HERE, "..", "walk-these-ways_amd"),
+              os.path.join(HERE, "..", "oracle"), os.path.join(HERE, ".."), HERE):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out[rank] = _curriculum_run(rank, world, 48, 40)
+    dist.destroy_process_group()
+
+
+def test_two_rank_curriculum_equals_single_rank_over_the_concatenated_shards():
+    for p in (os.path.join(HERE, "..", "oracle"), os.path.join(HERE, ".."), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    world = 2
+    port = 31500 + os.getpid() % 2000
+    out = mp.Manager().dict()
+    mp.spawn(_curriculum_worker, args=(world, port, out), nprocs=world, join=True)
+    import go1sim_host as H
+    from go1_gym.envs.base import base_task
+    saved = (H.Go1Sim, base_task.BaseTask._resolve_device)
+    try:
+        single = _curriculum_run(0, 1, 96, 40)
+    finally:
+        H.Go1Sim, base_task.BaseTask._resolve_device = saved
+    r0, r1 = out[0], out[1]
+    assert r0["sync"] and r1["sync"] and not single["sync"]
+    assert torch.equal(r0["weights"], r1["weights"])                               # one curriculum on every rank ...
+    assert torch.equal(r0["weights"], single["weights"])                           # ... and it is the single-GPU one
+    assert bool(((single["weights"] > 0) & (single["weights"] < 1)).any())           # the frontier moved: successes were counted
+    assert torch.equal(torch.cat((r0["commands"], r1["commands"]), dim=1), single["commands"])
+    assert torch.equal(torch.cat((r0["bins"], r1["bins"])), single["bins"])

@@ -83,6 +83,28 @@ def build_env(N=64):
     return HistoryWrapper(env), cfg
 
 
+def test_config1_plumbing_16_envs_zero_actions_1000_steps():
+    """BASELINE configs[0] (scripts/test.py:188-200 semantics) on the HIP simulator: 16 envs, `env.reset()`, 1000 steps of
+    zero actions through the 4-tuple surface; shapes / dtypes / finiteness, the robots keep standing, episodes time out and
+    restart, no simulator fault."""
+    N = 16
+    env, cfg = build_env(N)
+    base = env.env
+    obs = base.reset()
+    assert obs.shape == (N, 70) and obs.dtype == torch.float32
+    z = 0. * torch.ones(base.num_envs, base.num_actions, device=base.device)
+    for i in range(1000):
+        obs, rew, done, info = base.step(z)
+    torch.cuda.synchronize()
+    assert obs.shape == (N, 70) and rew.shape == (N,) and done.shape == (N,) and rew.dtype == torch.float32
+    assert info["privileged_obs"].shape == (N, 2) and info["joint_pos"].shape == (N, 12) and info["contact_states"].shape == (N, 4)
+    for t in (obs, rew, base.root_states, base.dof_pos, base.dof_vel, base.contact_forces, base.torques):
+        assert torch.isfinite(t).all()
+    assert float(base.root_states[:, 2].min()) > 0.2 and int(base.episode_length_buf.max()) < 1002
+    assert base.common_step_counter == 1001
+    assert info["sim_faults"].consume()["fatal"] == 0
+
+
 def test_env_surface_and_history_semantics():
     N = 64
     env, cfg = build_env(N)

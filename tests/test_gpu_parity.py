@@ -230,18 +230,21 @@ def test_free_running_distributions_match_oracle():
     rng = np.random.default_rng(3)
     nr = S.num_rewards
     acc = {"cpu": np.zeros(5), "gpu": np.zeros(5)}
+    logs = {"cpu": np.zeros(nr + 2), "gpu": np.zeros(nr + 2)}
     for step in range(steps):
         a = rng.standard_normal((N, 12)).astype(np.float32)
         orc.step(a)
         sim.step(torch.from_numpy(a).cuda())
         for tag, B in (("cpu", Bc), ("gpu", Bg)):
+            logs[tag] += B.episode_log.cpu().double().numpy()      # the oracle restarts this sum every step, the kernel accumulates
             cf = B.contact_forces.view(17, 3, N)
             acc[tag] += np.array([float(B.reset_buf.sum()), float(B.rew_buf.sum()), float((cf[[4, 8, 12, 16], 2] > 1.0).float().mean()),
                                   float(B.root_states[2].mean()), float(B.time_out_buf.sum())])
+        Bg.episode_log.zero_()
     torch.cuda.synchronize()
     out = {}
     for tag, B in (("cpu", Bc), ("gpu", Bg)):
-        log = B.episode_log.cpu().double().numpy()
+        log = logs[tag]
         n_ep = max(log[nr + 1], 1.0)
         out[tag] = dict(ep_len=N * steps / max(acc[tag][0], 1), rew=acc[tag][1] / (N * steps), duty=acc[tag][2] / steps,
                         height=acc[tag][3] / steps, terms=log[:nr + 1] / n_ep, weight_mass=float(B.curriculum_weights.sum()))

@@ -22,7 +22,7 @@ def model():
     src = open(HDR).read()
     out = {}
     for name in ("GO1_BODY_MASS", "GO1_BODY_COM", "GO1_BODY_INERTIA", "GO1_JOINT_ORIGIN", "GO1_JOINT_AXIS", "GO1_FOOT_OFFSET",
-                 "GO1_JOINT_LOWER", "GO1_JOINT_UPPER"):
+                 "GO1_JOINT_LOWER", "GO1_JOINT_UPPER", "GO1_JOINT_VEL_LIMIT"):
         m = re.search(name + r"(?:\[\d+\])+\s*=\s*(\{.*?\});", src, flags=re.S)
         nums = [float(x) for x in re.findall(r"[-+]?\d+\.?\d*(?:e[-+]?\d+)?", m.group(1))]
         out[name] = np.array(nums)
@@ -215,10 +215,51 @@ def test_joint_limits_and_torque_saturation(oracle_lib):
         orc.step(a)
         live = ~B.reset_buf.numpy().astype(bool)    # _reset_dofs may itself place joints outside (default * U(0.5,1.5))
         q = B.dof_pos.numpy()[:, live]
-        assert (q >= md["GO1_JOINT_LOWER"][:, None] - 1e-6).all() and (q <= md["GO1_JOINT_UPPER"][:, None] + 1e-6).all()
+        # limits are solver rows (momentum-conserving impulses), not clamps: what remains is the PGS residual
+        assert (q >= md["GO1_JOINT_LOWER"][:, None] - 0.03).all() and (q <= md["GO1_JOINT_UPPER"][:, None] + 0.03).all()
         assert np.abs(B.torques.numpy()).max() <= 33.5 + 1e-5
-        assert np.abs(B.dof_vel.numpy()).max() <= 50.0 + 1e-4
+        assert (np.abs(B.dof_vel.numpy()) <= 1.05 * md["GO1_JOINT_VEL_LIMIT"][:, None]).all()
     assert np.abs(B.torques.numpy()).max() == pytest.approx(33.5)
+
+
+def _momentum(oracle_lib, B, e):
+    r = B.root_states[:, e].double().numpy()
+    q, qd = B.dof_pos[:, e].double().numpy(), B.dof_vel[:, e].double().numpy()
+    M, _, _ = oracle_lib.dynamics(r, q, qd, np.zeros(12), np.zeros(3), float(B.payloads[e]), B.com_displacements[:, e].double().numpy())
+    h = M @ np.concatenate([r[10:13], r[7:10], qd])
+    return h[3:6], h[:3]                                     # linear momentum, angular momentum about the base origin
+
+
+def test_actuators_pushing_against_joint_limits_create_no_momentum(oracle_lib):
+    """ROOT CAUSE of round 1's non-finite rewards: joint position / velocity limits used to be clamps on the
+    joint coordinate — an unbalanced impulse.  A torque held against a stop (or against the velocity limit) then acted on
+    the base without reaction: in free flight with zero gravity, 20 N m on the four hips spun the base to 1450 rad/s and
+    74 m/s within 50 substeps and to Inf within 100; a learning policy found this "thrust" after ~1e7 env-steps.  With
+    the limits as solver rows the internal torques can only exchange momentum between the bodies."""
+    N = 4
+    cfg, S, meta, B = make_sim("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
+    S.gravity[0] = S.gravity[1] = S.gravity[2] = 0.0
+    standing_state(S, B, z=5.0)
+    orc = oracle_lib.Oracle(S, B)
+    B.torques.zero_()
+    B.torques[[0, 3, 6, 9], 0] = 20.0                 # hips: into the velocity limit, then the upper stop
+    B.torques[[1, 4, 7, 10], 1] = -20.0               # thighs: into the lower stop
+    B.torques[:, 2] = torch.tensor([20.0, -20.0, 20.0] * 4)      # everything at once
+    B.dof_vel[[0, 3, 6, 9], 3] = 30.0                 # no torque: spinning hips run into their stops
+    p3_0, L3_0 = _momentum(oracle_lib, B, 3)
+    for it in range(400):                             # 2 s
+        orc.physics_substep()
+        assert torch.isfinite(B.root_states).all()
+    for e in range(3):
+        p, L = _momentum(oracle_lib, B, e)
+        # started from rest.  What is left is the O(h^2) error of the semi-implicit step during the first substeps, when the
+        # joints accelerate at ~1600 rad/s^2 (measured: |p| <= 0.65 kg m/s = 0.06 m/s of the 11.3 kg robot, then constant)
+        assert np.abs(p).max() < 1.2 and np.abs(L).max() < 1.0, (e, p, L)
+        assert float(B.root_states[10:13, e].norm()) < 3.0 and float(B.root_states[7:10, e].norm()) < 1.0
+    p3, L3 = _momentum(oracle_lib, B, 3)
+    # legs spinning at 30 rad/s slam into their stops: the limit impulses are exactly momentum-neutral, the explicit
+    # velocity-product terms of a 0.15 rad-per-substep rotation are not (first-order integrator): bounded, not growing
+    assert np.abs(p3 - p3_0).max() < 0.4 * np.abs(p3_0).max()
 
 
 def test_sliding_contacts_sit_on_the_friction_cone(oracle_lib):

@@ -9,7 +9,9 @@
 // (s_load), batched and hoisted across the kernels' stores and atomics.  Through a generic pointer every store would
 // force the next configuration field or buffer pointer to be re-fetched from memory (one exposed round trip each,
 // with a single wave per SIMD).
+#ifndef GO1_CONSTANT
 #define GO1_CONSTANT __attribute__((address_space(4)))
+#endif
 typedef const GO1_CONSTANT Go1SimConfig& CfgRef;
 typedef const GO1_CONSTANT Go1SimBuffers& BufRef;
 

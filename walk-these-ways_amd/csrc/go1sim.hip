@@ -335,7 +335,7 @@ extern "C" int go1sim_step(Go1Sim* s, const float* actions, void* stream) {
   s->counter += 1;
   s->lag_head = (s->lag_head + s->cfg.decimation) % (s->cfg.lag_timesteps + 1);
   s->history_slot = (s->history_slot + 1) % (s->cfg.num_obs_history + 1);
-  if (s->cfg.device_curriculum && s->buf.curriculum_weights) {
+  if (s->cfg.device_curriculum && s->buf.curriculum_weights && !s->cfg.defer_curriculum_update) {
     hipLaunchKernelGGL(go1_curriculum_kernel, dim3(s->cfg.num_categories), dim3(256), 0, st, (const SimConst*)s->dconst);
     if (hipGetLastError() != hipSuccess) return -21;
   }

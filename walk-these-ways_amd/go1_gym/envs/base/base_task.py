@@ -16,13 +16,8 @@ class BaseTask(gym.Env):
         self.sim_params = sim_params
         self.physics_engine = physics_engine
         self.sim_device = sim_device
-        sim_device_type, self.sim_device_id = parse_device_str(sim_device)
         self.headless = headless          # accepted and ignored: no viewer
-        if sim_device_type != "cuda":
-            raise RuntimeError(
-                f"sim_device={sim_device!r}: the Go1 step runs only as HIP kernels on an MI355X ('cuda:N' under "
-                f"PyTorch-ROCm); there is no CPU simulation path in the product")
-        self.device = f"cuda:{self.sim_device_id}"
+        self.device = self._resolve_device(sim_device)
         self.graphics_device_id = -1
         self.num_obs = cfg.env.num_observations
         self.num_privileged_obs = cfg.env.num_privileged_obs
@@ -34,6 +29,16 @@ class BaseTask(gym.Env):
         self.viewer = None
         self.enable_viewer_sync = True
         self.create_sim()
+
+    def _resolve_device(self, sim_device):
+        """'cuda:N' (HIP device N under PyTorch-ROCm) -> torch device string of every buffer.  The product has no other
+        case: the Go1 step exists only as HIP kernels."""
+        sim_device_type, self.sim_device_id = parse_device_str(sim_device)
+        if sim_device_type != "cuda":
+            raise RuntimeError(
+                f"sim_device={sim_device!r}: the Go1 step runs only as HIP kernels on an MI355X ('cuda:N' under "
+                f"PyTorch-ROCm); there is no CPU simulation path in the product")
+        return f"cuda:{self.sim_device_id}"
 
     def get_observations(self):
         return self.obs_buf

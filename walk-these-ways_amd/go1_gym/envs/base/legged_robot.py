@@ -171,9 +171,18 @@ class LeggedRobot(BaseTask):
             self.height_samples = torch.tensor(hs).view(self.terrain.tot_rows, self.terrain.tot_cols).to(self.device)
         seed = int(getattr(cfg, "seed", getattr(cfg.env, "seed", 0)))
         offset = int(getattr(cfg.env, "env_id_offset", 0))
+        # Environments sharded over ranks (one process per GPU): the command curriculum stays ONE global curriculum — every
+        # rank adds up the per-bin success counts of all shards before the weight update, so weights, CDFs and therefore
+        # the sampled commands are those of a single-GPU run over the concatenated shards (RNG streams are
+        # keyed by global env id).  7 KB int32 all-reduce per env step; `Cfg.commands.global_curriculum = False` keeps
+        # per-rank curricula instead.
+        import torch.distributed as dist
+        self._curriculum_sync = bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                                     and cfg.commands.command_curriculum and getattr(cfg.commands, "global_curriculum", True))
         self.sim_config, self.sim_meta = H.build_sim_config(
             cfg, num_envs=self.num_envs, seed=seed, env_id_offset=offset,
-            solver_iterations=int(getattr(cfg.sim.physx, "num_solver_sweeps", 8)))
+            solver_iterations=int(getattr(cfg.sim.physx, "num_solver_sweeps", 8)),
+            defer_curriculum_update=self._curriculum_sync)
         self.buffers = B = H.SimBuffers(self.sim_config, self.sim_meta, self.device)
         if mesh_type in ('heightfield', 'trimesh'):
             # both mesh types are simulated on the height field's bilinear surface (utils/terrain.py docstring)
@@ -331,6 +340,10 @@ class LeggedRobot(BaseTask):
         if not actions.is_contiguous():
             actions = actions.contiguous()
         self.sim.step(actions)
+        if self._curriculum_sync:
+            import torch.distributed as dist
+            dist.all_reduce(self.buffers.curriculum_success)
+            self.sim.curriculum_update()
         self.common_step_counter += 1
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 

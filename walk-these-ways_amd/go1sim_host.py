@@ -93,7 +93,7 @@ def active_rewards(cfg):
 
 
 def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curriculum=True,
-                     solver_iterations=8, warm_start=True):
+                     solver_iterations=8, warm_start=True, defer_curriculum_update=False):
     """Flatten `cfg` (a Cfg tree) into a Go1SimConfig.  Returns (struct, meta)."""
     S = abi.Go1SimConfig()
     S.abi_version = abi.GO1SIM_ABI_VERSION
@@ -136,6 +136,10 @@ def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curricu
     S.bounce_threshold_velocity = px.bounce_threshold_velocity
     S.terrain_friction = cfg.terrain.static_friction
     S.terrain_restitution = cfg.terrain.restitution
+    S.max_linear_velocity = float(cfg.asset.max_linear_velocity)
+    S.max_angular_velocity = float(cfg.asset.max_angular_velocity)
+    S.joint_limit_margin = float(getattr(px, "joint_limit_margin", 5.0))
+    S.joint_limit_pos_margin = float(getattr(px, "joint_limit_pos_margin", 0.1))
     S.solver_iterations = int(solver_iterations)
     S.warm_start = int(warm_start)
     S.terrain_type = 0                                          # set by bind_height_field() when a height field is bound
@@ -274,6 +278,7 @@ def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curricu
 
     cm = cfg.commands
     S.device_curriculum = int(device_curriculum)
+    S.defer_curriculum_update = int(defer_curriculum_update)
     S.gaitwise_curricula = int(cm.gaitwise_curricula)
     S.binary_phases = int(cm.binary_phases)
     S.exclusive_phase_offset = int(getattr(cm, "exclusive_phase_offset", False))
@@ -440,7 +445,12 @@ def load_library():
         raise Go1SimLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"(hipcc --offload-arch=gfx950). The Go1 step has no CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
+    _lib = bind_library(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+def bind_library(lib):
+    """ctypes prototypes of include/go1sim.h on a loaded library object."""
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     lib.go1sim_create.argtypes = [ctypes.POINTER(abi.Go1SimConfig), ctypes.POINTER(abi.Go1SimBuffers), ctypes.c_int, ctypes.POINTER(vp)]
     lib.go1sim_destroy.argtypes = [vp]
@@ -463,7 +473,6 @@ def load_library():
                "go1sim_append_history", "go1sim_history_window_offset",
                "go1sim_get_counters", "go1sim_set_counters", "go1sim_enable_timing", "go1sim_read_timings"):
         getattr(lib, fn).restype = ctypes.c_int
-    _lib = lib
     return lib
 
 
@@ -477,8 +486,8 @@ EXPORTED_SYMBOLS = ["go1sim_create", "go1sim_destroy", "go1sim_set_config", "go1
 class Go1Sim:
     """Thin RAII wrapper over the opaque handle."""
 
-    def __init__(self, S, buffers, device_index=0):
-        self.lib = load_library()
+    def __init__(self, S, buffers, device_index=0, lib=None):
+        self.lib = lib if lib is not None else load_library()
         self.S, self.buffers = S, buffers
         self.handle = ctypes.c_void_p()
         rc = self.lib.go1sim_create(ctypes.byref(S), ctypes.byref(buffers.struct), int(device_index), ctypes.byref(self.handle))
