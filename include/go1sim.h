@@ -99,6 +99,7 @@ enum Go1FaultBit {
   GO1_FAULT_REWARD = 8,         /* a reward term or the total was non-finite (counted as 0, episode ended) */
   GO1_FAULT_OBS = 9,            /* an observation column was non-finite (written as 0) */
   GO1_FAULT_CONTACT_DROPPED = 10, /* more active contact points than solver slots: the excess was not solved (count only) */
+  GO1_FAULT_LIMIT_SAFETY = 11,  /* a joint left its limit rows' band by more than the safety factor and was cut (count only) */
   GO1_FAULT_BITS = 16
 };
 #define GO1_FAULT_FATAL_MASK 0x3FFu   /* bits that mean "simulation failed" (everything except CONTACT_DROPPED) */

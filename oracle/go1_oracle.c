@@ -399,7 +399,7 @@ static void jac_row(const Kin* k, int dynb, const real* x, const real* d, real* 
 #define GO1_LIMIT_SAFETY 2.0           /* x velocity limit */
 #define GO1_LIMIT_SLACK 0.2            /* rad beyond a stop */
 #ifndef GO1_LIMIT_INNER
-#define GO1_LIMIT_INNER 4
+#define GO1_LIMIT_INNER 1
 #endif
 static const int CONTACT_ORDER[17] = {4, 8, 12, 16, 0, 3, 7, 11, 15, 2, 6, 10, 14, 1, 5, 9, 13};
 

@@ -28,6 +28,7 @@
 #define __restrict__ __restrict
 #define GO1_CONSTANT            /* constant address space: plain pointers on the host */
 #define HIP_SYMBOL(x) x
+#define LDS_PHASE() emu::barrier()
 
 namespace emu {
 struct Lane {

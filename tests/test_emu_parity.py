@@ -1,0 +1,189 @@
+"""The product's DEVICE CODE (walk-these-ways_amd/csrc/*.h, go1sim.hip — unmodified) executed lane by lane on the CPU by the
+SIMT emulator of tests/emu, against the fp64 oracle and against the reference-generated fixtures.  These are the same
+comparisons as the `-m gpu` parity tests at sizes the emulator finishes in seconds; they run where there is no GPU (here
+and in the driver's CPU tier).  The emulator is test infrastructure: the product only ever loads csrc/libgo1sim.so."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
+import go1sim_host as H  # noqa: E402
+from util import (GOLDEN, RESAMPLE_MODES, check_resample_against_reference, load_maps_fixture, load_resample_fixture,  # noqa: E402
+                  make_sim, randomize_dr, standing_state)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import emu_sim
+    emu_sim.lib()
+    return emu_sim
+
+
+def pair(oracle_lib, emu, variant, N, seed=3, **kw):
+    cfg, S, meta, Bc = make_sim(variant, N, seed=seed, **kw)
+    randomize_dr(Bc, seed)
+    orc = oracle_lib.Oracle(S, Bc)
+    orc.reset_idx()
+    Be = Bc.clone_to("cpu")
+    return S, Bc, orc, Be, emu.EmuSim(S, Be)
+
+
+def resync(Bc, Be, sim, orc):
+    for k, t in Bc.tensors.items():
+        if t is not None and Be.tensors.get(k) is not None:
+            Be.tensors[k].copy_(t)
+    sim.set_counters(orc.ctr.common_step_counter, orc.ctr.lag_head)
+
+
+def diff(Be, Bc, k):
+    return float((Be.tensors[k].double() - Bc.tensors[k].double()).abs().max())
+
+
+@pytest.mark.parametrize("variant,N", [("train_noise", 32), ("alt", 16), ("train_noise", 8), ("dr", 16)])
+def test_emulated_kernel_full_step_matches_oracle(oracle_lib, emu, variant, N):
+    """fp32 kernel vs fp64 oracle, identical state / action / RNG streams, re-synchronised every step: round-off only.
+    N = 32: two wavefronts, matrix-core torque path; N = 8: a partial wavefront, plain-FMA torque path."""
+    S, Bc, orc, Be, sim = pair(oracle_lib, emu, variant, N)
+    rng = np.random.default_rng(0)
+    for step in range(8):
+        a = (rng.standard_normal((N, 12)) * (2.5 if step % 3 == 0 else 0.5)).astype(np.float32)
+        orc.step(a)
+        sim.step(torch.from_numpy(a))
+        assert torch.equal(Be.reset_buf, Bc.reset_buf) and torch.equal(Be.time_out_buf, Bc.time_out_buf)
+        for k, tol in (("dof_pos", 5e-6), ("dof_vel", 1e-3), ("root_states", 2e-4), ("contact_forces", 2e-2), ("torques", 1e-3),
+                       ("obs_buf", 1e-4), ("rew_buf", 1e-5), ("commands", 1e-6), ("episode_sums", 1e-4), ("foot_positions", 1e-4)):      # (world coordinates reach 150 m: 1.5e-5 per fp32 ulp)
+            assert diff(Be, Bc, k) <= tol, (step, k, diff(Be, Bc, k))
+        resync(Bc, Be, sim, orc)
+    assert int(Be.fault_counts[:10].sum()) == 0
+
+
+@pytest.mark.parametrize("scenario", ["flight", "standing", "dropped", "tumbling"])
+def test_emulated_physics_substep_matches_oracle(oracle_lib, emu, scenario):
+    N = 32
+    S, Bc, orc, Be, sim = pair(oracle_lib, emu, "train", N, extra={"domain_rand": dict(randomize_gravity=False)})
+    g = torch.Generator().manual_seed(1)
+    if scenario == "flight":
+        Bc.root_states[2] = 2.0
+        Bc.dof_vel.uniform_(-5, 5, generator=g)
+        Bc.root_states[7:13].uniform_(-2, 2, generator=g)
+    elif scenario == "standing":
+        standing_state(S, Bc, z=0.28)
+    elif scenario == "dropped":
+        Bc.root_states[2].uniform_(0.05, 0.3, generator=g)
+        Bc.root_states[9] = -1.5
+    else:
+        q = torch.randn(4, N, generator=g)
+        Bc.root_states[3:7] = q / q.norm(dim=0, keepdim=True)
+        Bc.root_states[2].uniform_(0.08, 0.35, generator=g)
+        Bc.root_states[7:13].uniform_(-2, 2, generator=g)
+        Bc.dof_vel.uniform_(-5, 5, generator=g)
+    Bc.torques.uniform_(-20, 20, generator=g)
+    resync(Bc, Be, sim, orc)
+    bad = torch.zeros(N, dtype=torch.bool)
+    for it in range(5):
+        orc.physics_substep()
+        sim.physics_substep()
+        for k, tol in (("root_states", 2e-4), ("dof_pos", 2e-5), ("dof_vel", 3e-3)):
+            bad |= ((Be.tensors[k] - Bc.tensors[k]).abs() > tol).any(0)
+        bad |= ((Be.contact_forces - Bc.contact_forces).abs() > 5e-2 + 2e-3 * Bc.contact_forces.abs()).any(0)
+        resync(Bc, Be, sim, orc)
+    assert int(bad.sum()) <= (0 if scenario in ("flight", "standing") else 1), int(bad.sum())      # contact-mode flips at thresholds
+    if scenario != "flight":
+        assert float(Bc.contact_forces.abs().max()) > 1.0
+
+
+def test_emulated_limit_rows_conserve_momentum_and_match_oracle(oracle_lib, emu):
+    """The root-cause scenario of round 1's non-finite rewards through the KERNEL code: zero gravity, free flight, 20 N m
+    held against the hip velocity limit / the thigh stops.  The limit rows keep the base at rest (before: 1450 rad/s after
+    50 substeps) and the kernel follows the oracle to round-off, so the rows are the same rows."""
+    N = 16
+    cfg, S, meta, Bc = make_sim("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
+    S.gravity[0] = S.gravity[1] = S.gravity[2] = 0.0
+    standing_state(S, Bc, z=5.0)
+    Bc.torques.zero_()
+    Bc.torques[[0, 3, 6, 9], 0:4] = 20.0
+    Bc.torques[[1, 4, 7, 10], 4:8] = -20.0
+    Bc.torques[:, 8:12] = torch.tensor([20.0, -20.0, 20.0] * 4).unsqueeze(1)
+    Bc.dof_vel[[0, 3, 6, 9], 12:16] = 30.0
+    orc = oracle_lib.Oracle(S, Bc)
+    Be = Bc.clone_to("cpu")
+    sim = emu.EmuSim(S, Be)
+    for it in range(120):
+        orc.physics_substep()
+        sim.physics_substep()
+        for k, tol in (("root_states", 5e-4), ("dof_pos", 1e-4), ("dof_vel", 2e-2)):
+            assert diff(Be, Bc, k) <= tol, (it, k, diff(Be, Bc, k))
+        resync(Bc, Be, sim, orc)
+    assert torch.isfinite(Be.root_states).all()
+    assert float(Be.root_states[10:13, :12].norm(dim=0).max()) < 3.0 and float(Be.root_states[7:10, :12].norm(dim=0).max()) < 1.0
+    lo = torch.tensor([-0.802851455917, -1.0471975512, -2.69653369433] * 4).unsqueeze(1)
+    hi = torch.tensor([0.802851455917, 4.18879020479, -0.916297857297] * 4).unsqueeze(1)
+    assert bool(((Be.dof_pos >= lo - 0.03) & (Be.dof_pos <= hi + 0.03)).all())
+    assert int(Be.fault_counts[:10].sum()) == 0 and int(Be.fault_counts[H.abi.GO1_FAULT_LIMIT_SAFETY]) == 0
+
+
+@pytest.mark.parametrize("variant,fname", [("train", "maps_train.npz"), ("alt", "maps_alt_mild.npz")])
+def test_emulated_post_physics_maps_match_reference_golden(emu, variant, fname):
+    """kernel code vs the reference's own Python (tests/golden/maps_*.npz), same bounds as the -m gpu version."""
+    N = 48
+    cfg, S, meta, Bc = make_sim(variant, N)
+    d = load_maps_fixture(fname, S, meta, Bc)
+    sim = emu.EmuSim(S, Bc)
+    sim.set_counters(7, 0)
+    sim.post_physics(d["gravity"])
+    g = lambda k: Bc.tensors[k]
+    reset = d["out_reset_buf"].astype(bool)
+    keep = ~reset
+    np.testing.assert_array_equal(g("reset_buf").numpy().astype(bool), reset)
+    tol = dict(rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(g("base_lin_vel").t().numpy(), d["out_base_lin_vel"], **tol)
+    np.testing.assert_allclose(g("clock_inputs").t().numpy(), d["out_clock_inputs"], rtol=1e-5, atol=3e-5)
+    np.testing.assert_allclose(g("rew_buf").numpy(), d["out_rew_buf"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(g("episode_sums").numpy()[:, keep], d["out_episode_sums"][:, keep], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(g("obs_buf").numpy()[keep], d["out_obs"][keep], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(g("privileged_obs_buf").numpy()[keep][:, :S.num_privileged_obs], d["out_priv"][keep], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("variant", ["train", "alt"])
+def test_emulated_torque_model_matches_reference_golden(emu, variant):
+    d = np.load(os.path.join(GOLDEN, f"torques_{variant}.npz"))
+    cfg, S, meta, B = make_sim(variant, 16)
+    for k in ("motor_strengths", "motor_offsets", "Kp_factors", "Kd_factors"):
+        getattr(B, k)[:] = torch.from_numpy(d[k]).t()
+    sim = emu.EmuSim(S, B)
+    for s_ in range(d["actions"].shape[0]):
+        B.dof_pos.copy_(torch.from_numpy(d["dof_pos"][s_]).t())
+        B.dof_vel.copy_(torch.from_numpy(d["dof_vel"][s_]).t())
+        sim.compute_torques(torch.from_numpy(np.ascontiguousarray(d["actions"][s_].T)))
+        np.testing.assert_allclose(B.torques.t().numpy(), d["torques"][s_], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("mode", list(RESAMPLE_MODES))
+def test_emulated_resample_and_curriculum_update_match_reference(emu, mode):
+    d, S, meta, B = load_resample_fixture(mode)
+    sim = emu.EmuSim(S, B)
+    sim.set_counters(int(d["step"]), 0)
+    sim.reset_idx(torch.from_numpy(d["env_ids"]))
+    sim.curriculum_update()
+    check_resample_against_reference(d, B)
+
+
+def test_emulated_failed_state_is_contained(oracle_lib, emu):
+    N = 16
+    S, Bc, orc, Be, sim = pair(oracle_lib, emu, "train_noise", N, seed=23)
+    z = torch.zeros(N, 12)
+    sim.step(z)
+    Be.root_states[2, 5] = float("nan")
+    Be.dof_vel[7, 9] = float("inf")
+    for _ in range(2):
+        sim.step(z)
+    for k, t in Be.tensors.items():
+        if t is not None and t.is_floating_point() and k != "episode_log":
+            assert torch.isfinite(t).all(), k
+    assert int(Be.fault_flags[5]) & (1 << H.abi.GO1_FAULT_STATE_IN) and int(Be.fault_flags[9]) & H.FAULT_FATAL_MASK
+    others = torch.ones(N, dtype=torch.bool)
+    others[[5, 9]] = False
+    assert int(Be.fault_flags[others].abs().sum()) == 0

@@ -25,6 +25,12 @@ __shared__ unsigned long long s_prof[24];          // accumulated with fire-and-
 #include <stdint.h>
 
 #define DEV __device__ __forceinline__
+// Marks a point where the lanes of the wavefront hand data to each other through LDS.  The hardware executes one wave's
+// LDS operations in issue order, so no instruction is needed — only the compiler must not move LDS accesses across it.
+// (The SIMT emulator of tests/emu defines it as a real barrier: there the lanes do not run in lock step.)
+#ifndef LDS_PHASE
+#define LDS_PHASE() __builtin_amdgcn_wave_barrier()
+#endif
 
 struct V3 { float x, y, z; };
 DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }

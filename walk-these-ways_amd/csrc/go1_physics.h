@@ -22,24 +22,35 @@
 #define WAVE 64
 #define EPW 16                       // environments per wavefront
 #define MAXC 6                       // solver contacts per env (oracle: GO1_MAX_CONTACTS)
-#define NR (3 * MAXC)
+#define NRC (3 * MAXC)               // contact rows: contact k -> rows 3k (normal), 3k+1, 3k+2 (tangents)
+#define NRJ 12                       // joint-limit rows: joint j -> row NRC + j
+#define NRT 32                       // row capacity (NRC + NRJ = 30 in use)
+#define NCC (NRT / 4)                // Delassus columns per lane: lane `leg` owns the columns c = leg + 4 cc
+#define GO1_LIMIT_RECOVERY_RATE 10.0f   // rad/s: a joint found beyond a stop is brought back at a bounded rate
+#define GO1_LIMIT_SAFETY 2.0f           // x velocity limit: beyond this the limit rows have failed (cut + fault count)
+#define GO1_LIMIT_SLACK 0.2f            // rad beyond a stop: same
 
 // ---- LDS map (floats), index = field * EPW + env_local ---------------------------------------------
 enum {
-  L_LAM = 0,            // 17 x world impulse (x, y, z) per reported body: solver output / warm start
-  L_CX = 51,            // MAXC x 3 contact points (rel. base origin)
-  L_CN = 69,            // MAXC x 3 contact normals
-  L_VSTAR = 87,         // MAXC
-  L_BV = 93,            // MAXC x 3  b = J v_free
-  L_LS = 111,           // MAXC x 3  slot impulses (n, t1, t2)
-  L_G = 129,            // NR x 6  contact columns: the unit impulse propagated to the base, g_c
-  L_U3 = L_G + NR * 6,  // NR x 3  joint-space residuals u_j(c) along the contact's own leg (0 beyond its depth)
-  L_UD = L_U3 + NR * 3, // NR x 3  u_j(c) / D_j
-  L_LEG = L_UD + NR * 3,// NR      leg of the contact (4 = trunk)
-  L_W = 129,            // zero-filled at kernel start from here to L_END (unused columns must read finite)
-  L_END = L_LEG + NR
+  L_LAM = 0,                 // 17 x world impulse (x, y, z) per reported body: solver output / warm start
+  L_CX = 51,                 // MAXC x 3 contact points (rel. base origin)
+  L_RB = L_CX + 3 * MAXC,    // NRT   b = J v_free of the row
+  L_RP = L_RB + NRT,         // NRT   normal rows: target velocity v*; tangent rows: W[t][n]; joint rows: lower rate bound
+  L_RQ = L_RP + NRT,         // NRT   joint rows: upper rate bound
+  L_RI = L_RQ + NRT,         // NRT   1 / W[r][r]  (0: the row is not in this environment's solve)
+  L_RD = L_RI + NRT,         // NRT   W[r][r]
+  L_LS = L_RD + NRT,         // NRT   impulses: start values in, solution out
+  L_G = L_LS + NRT,          // NRT x 6  row functionals: the unit impulse of the row propagated to the base, g_r
+  L_U3 = L_G + NRT * 6,      // NRT x 3  joint-space residuals u_j(r) along the row's leg (0 beyond its depth)
+  L_UD = L_U3 + NRT * 3,     // NRT x 3  u_j(r) / D_j
+  L_LEG = L_UD + NRT * 3,    // NRT      leg of the row (4 = trunk)
+  L_W = L_RB,                // zero-filled at kernel start from here to L_END (rows that are not written must read finite)
+  L_END = L_LEG + NRT
 };
 #define LDS(f) lds[(f) * EPW + el]
+// Delassus matrix W = J M^-1 J^T in LDS: entry (r, c) sits in the share of lane c & 3 at column slot c >> 2
+#define LDSW_SIZE (NRT * NCC * 4 * EPW)
+#define LDSW(r, cc, lg) ldsw[(((r) * NCC + (cc)) * 4 + (lg)) * EPW + el]
 
 // ================================================================================================
 // torque model (reference legged_robot.py:907-946): the calling lane handles the 3 joints of its leg
@@ -324,8 +335,8 @@ DEV SV leg_response(const SV S[3], const SV U[3], const float Dinv[3], SV a0, in
   return a;
 }
 
-DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds, int lane, Base& s, Leg& L, V3 grav, bool use_warm, float h,
-                         uint32_t& fault PROF_PARAM) {
+DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds, float* ldsw, int lane, Base& s, Leg& L, V3 grav, bool use_warm,
+                         float h, uint32_t& fault PROF_PARAM) {
   const int leg = lane & 3, el = lane >> 2;
   const M3 R0 = quat_to_mat(s.qx, s.qy, s.qz, s.qw);
   const SV v0 = sv(s.w, s.v);
@@ -503,7 +514,32 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     lamb[0] = w ? dot(wl, bn) : 0.f; lamb[1] = w ? dot(wl, bt1) : 0.f; lamb[2] = w ? dot(wl, bt2) : 0.f;
   }
 
-  // publish own contacts: point, target normal velocity, b = J v_free, start impulse
+  // ---- joint-limit rows of the own leg ------------------------------------------------------------------
+  // A joint's position / velocity limits are ONE solver row: a generalised impulse along the joint coordinate (equal and
+  // opposite on child and parent) keeps the rate inside [vlo, vhi] = [max((lo - q)/h, -vmax), min((hi - q)/h, vmax)].
+  // Clamping the joint coordinate after the solve instead is an unbalanced impulse: a torque held against a stop then
+  // acts on the base without reaction (free thrust — the root cause of round 1's non-finite states).
+  // The rows of a leg enter the solve together, as soon as one free rate comes within the margins of its band.
+  float jlo[3], jhi[3];
+  bool legact = false;
+  {
+    const float mv = cfg.joint_limit_margin, mp = cfg.joint_limit_pos_margin / h;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int ji = 3 * leg + j;
+      float lo = (GO1_JOINT_LOWER[ji] - L.q[j]) / h, hi = (GO1_JOINT_UPPER[ji] - L.q[j]) / h;
+      const float vl = GO1_JOINT_VEL_LIMIT[ji];
+      lo = fminf(lo, GO1_LIMIT_RECOVERY_RATE);
+      hi = fmaxf(hi, -GO1_LIMIT_RECOVERY_RATE);
+      jlo[j] = fmaxf(lo, -vl);
+      jhi[j] = fminf(hi, vl);
+      const float vf = qd_free[j];
+      if (!(vf > lo + mp && vf < hi - mp && vf > -vl + mv && vf < vl - mv)) legact = true;
+    }
+  }
+  const unsigned lact = quad_ballot(legact, lane);      // legs of this environment whose limit rows are in the solve
+
+  // publish own rows: contact point, target normal velocity, b = J v_free, start impulse
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     if (slot[i] >= 0) {
@@ -513,16 +549,14 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       LDS(L_CX + 3 * k) = c.x; LDS(L_CX + 3 * k + 1) = c.y; LDS(L_CX + 3 * k + 2) = c.z;
       float vs = fminf(-c.phi / h, cfg.max_depenetration_velocity);
       if (c.un < -cfg.bounce_threshold_velocity && -e_c * c.un > vs) vs = -e_c * c.un;
-      LDS(L_VSTAR + k) = vs;
+      LDS(L_RP + 3 * k) = vs;
       SV vb = sv(w_free, v_free);
 #pragma unroll
       for (int j = 0; j < 3; j++)
         if (j <= depth) vb = vb + qd_free[j] * S[j];
       V3 xk = v3(c.x, c.y, c.z);
       V3 vp = vb.l + cross(vb.a, xk);
-      const V3 n = fn[i];
-      LDS(L_CN + 3 * k) = n.x; LDS(L_CN + 3 * k + 1) = n.y; LDS(L_CN + 3 * k + 2) = n.z;
-      LDS(L_BV + 3 * k) = dot(n, vp); LDS(L_BV + 3 * k + 1) = dot(ft1[i], vp); LDS(L_BV + 3 * k + 2) = dot(ft2[i], vp);
+      LDS(L_RB + 3 * k) = dot(fn[i], vp); LDS(L_RB + 3 * k + 1) = dot(ft1[i], vp); LDS(L_RB + 3 * k + 2) = dot(ft2[i], vp);
       LDS(L_LS + 3 * k) = lam0[i][0]; LDS(L_LS + 3 * k + 1) = lam0[i][1]; LDS(L_LS + 3 * k + 2) = lam0[i][2];
     }
   }
@@ -531,31 +565,28 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     LDS(L_CX + 3 * k) = cbase.x; LDS(L_CX + 3 * k + 1) = cbase.y; LDS(L_CX + 3 * k + 2) = cbase.z;
     float vs = fminf(-cbase.phi / h, cfg.max_depenetration_velocity);
     if (cbase.un < -cfg.bounce_threshold_velocity && -e_c * cbase.un > vs) vs = -e_c * cbase.un;
-    LDS(L_VSTAR + k) = vs;
+    LDS(L_RP + 3 * k) = vs;
     V3 xk = v3(cbase.x, cbase.y, cbase.z);
     V3 vp = v_free + cross(w_free, xk);
-    LDS(L_CN + 3 * k) = bn.x; LDS(L_CN + 3 * k + 1) = bn.y; LDS(L_CN + 3 * k + 2) = bn.z;
-    LDS(L_BV + 3 * k) = dot(bn, vp); LDS(L_BV + 3 * k + 1) = dot(bt1, vp); LDS(L_BV + 3 * k + 2) = dot(bt2, vp);
+    LDS(L_RB + 3 * k) = dot(bn, vp); LDS(L_RB + 3 * k + 1) = dot(bt1, vp); LDS(L_RB + 3 * k + 2) = dot(bt2, vp);
     LDS(L_LS + 3 * k) = lamb[0]; LDS(L_LS + 3 * k + 1) = lamb[1]; LDS(L_LS + 3 * k + 2) = lamb[2];
   }
-  // clear the per-body impulses (re-filled for the listed bodies after the solve)
-  if (leg == 0) {
+  if (legact) {
 #pragma unroll
-    for (int r = 0; r < 3; r++) LDS(L_LAM + r) = 0.f;
+    for (int j = 0; j < 3; j++) {
+      const int r = NRC + 3 * leg + j;
+      LDS(L_RB + r) = qd_free[j]; LDS(L_RP + r) = jlo[j]; LDS(L_RQ + r) = jhi[j]; LDS(L_LS + r) = 0.f;
+    }
   }
-#pragma unroll
-  for (int i = 0; i < 12; i++) LDS(L_LAM + 3 * (1 + 4 * leg) + i) = 0.f;
 
   __syncthreads();      // one-wave workgroup: orders this wave's LDS traffic between phases
   PROF(3);
-  // ---- Delassus matrix W = J M^-1 J^T from the ABA factors, without forming M^-1 J^T ------------------------
-  // For a unit impulse in contact column c (contact k, direction r) the backward ABA pass along the contact's leg
-  // leaves g_c, the wrench arriving at the base, and the joint residuals u_j(c).  By reciprocity the same vectors
-  // are the row functionals, so
+  // ---- row functionals: every row's unit impulse propagated through the ABA factors to the base ---------------
+  // For a unit impulse along row c the backward ABA pass along the row's leg leaves g_c, the wrench arriving at the base,
+  // and the joint residuals u_j(c).  By reciprocity the same vectors are the row functionals, so
   //     W[r][c] = g_r . (I0^-1 g_c)  +  [same leg] sum_j u_j(r) u_j(c) / D_j
-  // (legs couple only through the base).  Each lane propagates ITS contacts (3 directions each) and publishes
-  // g, u, u/D; then lane `leg` builds the columns c = leg, leg+4, ... it owns in the PGS sweep — straight into
-  // registers, where the whole sweep runs without touching LDS.
+  // (legs couple only through the base).  A contact row starts from the spatial force of the unit impulse at the contact
+  // point, a joint row from the unit generalised impulse at its joint.
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     if (slot[i] >= 0) {
@@ -598,75 +629,115 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       LDS(L_LEG + c) = 4.f;
     }
   }
+  if (legact) {
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      float uj[3] = {0.f, 0.f, 0.f};
+      uj[jj] = 1.f;
+      SV pA = Dinv[jj] * U[jj];
+#pragma unroll
+      for (int j = 1; j >= 0; j--) {
+        if (j < jj) {
+          const float u = -dot(S[j], pA);
+          uj[j] = u;
+          pA = pA + (u * Dinv[j]) * U[j];
+        }
+      }
+      const int c = NRC + 3 * leg + jj;
+      LDS(L_G + 6 * c) = pA.a.x; LDS(L_G + 6 * c + 1) = pA.a.y; LDS(L_G + 6 * c + 2) = pA.a.z;
+      LDS(L_G + 6 * c + 3) = pA.l.x; LDS(L_G + 6 * c + 4) = pA.l.y; LDS(L_G + 6 * c + 5) = pA.l.z;
+#pragma unroll
+      for (int j = 0; j < 3; j++) { LDS(L_U3 + 3 * c + j) = uj[j]; LDS(L_UD + 3 * c + j) = uj[j] * Dinv[j]; }
+      LDS(L_LEG + c) = (float)leg;
+    }
+  }
   __syncthreads();
   PROF(4);
+  // ---- Delassus matrix into LDS: lane `leg` builds the columns c = leg + 4 cc it owns in the sweep -------------------
   int Kw = 0;                                                  // wave-uniform max K: scalar branches below
 #pragma unroll
   for (int kk = 1; kk <= MAXC; kk++) Kw = (__ballot(K >= kk) != 0ull) ? kk : Kw;
-  float Wc[NR][5];                                             // Wc[r][cc] = W[r][leg + 4 cc]
+  unsigned LAw;                                                // wave-uniform: legs with limit rows in some environment
   {
-    SV Y[5];
-    float ud[5][3], lg[5];
+    unsigned long long bl = __ballot(legact);
+    bl |= bl >> 32; bl |= bl >> 16; bl |= bl >> 8; bl |= bl >> 4;
+    LAw = (unsigned)(bl & 0xFull);
+  }
+  bool colact[NCC];                                            // column c = leg + 4 cc is a row of THIS environment's solve
+  unsigned ccw = 0;                                            // wave-uniform: column slots with an active column somewhere
 #pragma unroll
-    for (int cc = 0; cc < 5; cc++) {
-      int c = leg + 4 * cc;
-      c = c < NR ? c : NR - 1;        // lanes 2, 3 have no fifth column: any finite stand-in (its impulse stays 0)
-      const SV g = sv(v3(LDS(L_G + 6 * c), LDS(L_G + 6 * c + 1), LDS(L_G + 6 * c + 2)),
-                      v3(LDS(L_G + 6 * c + 3), LDS(L_G + 6 * c + 4), LDS(L_G + 6 * c + 5)));
-      Y[cc] = sym6_mul(I0inv, g);
+  for (int cc = 0; cc < NCC; cc++) {
+    const int c = leg + 4 * cc;
+    colact[cc] = c < NRC ? (c < 3 * K) : (c < NRC + NRJ && ((lact >> ((c - NRC) / 3)) & 1u));
+    if (__ballot(colact[cc]) != 0ull) ccw |= 1u << cc;
+  }
+  {
+    SV Y[NCC];
+    float ud[NCC][3], lg[NCC];
 #pragma unroll
-      for (int j = 0; j < 3; j++) ud[cc][j] = LDS(L_UD + 3 * c + j);
-      lg[cc] = LDS(L_LEG + c);
+    for (int cc = 0; cc < NCC; cc++) {
+      if (ccw & (1u << cc)) {
+        int c = leg + 4 * cc;
+        c = c < NRC + NRJ ? c : NRC + NRJ - 1;     // lanes 2, 3 have no last column: any finite stand-in (its impulse stays 0)
+        const SV g = sv(v3(LDS(L_G + 6 * c), LDS(L_G + 6 * c + 1), LDS(L_G + 6 * c + 2)),
+                        v3(LDS(L_G + 6 * c + 3), LDS(L_G + 6 * c + 4), LDS(L_G + 6 * c + 5)));
+        Y[cc] = sym6_mul(I0inv, g);
+#pragma unroll
+        for (int j = 0; j < 3; j++) ud[cc][j] = LDS(L_UD + 3 * c + j);
+        lg[cc] = LDS(L_LEG + c);
+      }
     }
+    // rows: the contact rows of the wave's largest contact list, then the limit rows of every leg that is active somewhere
+#pragma unroll 1
+    for (int r = 0; r < NRC + NRJ; r++) {
+      const bool roww = r < NRC ? (r < 3 * Kw) : (((LAw >> ((r - NRC) / 3)) & 1u) != 0u);      // wave-uniform
+      if (!roww) continue;
+      const bool rowact = r < NRC ? (r < 3 * K) : (((lact >> ((r - NRC) / 3)) & 1u) != 0u);
+      const SV g = sv(v3(LDS(L_G + 6 * r), LDS(L_G + 6 * r + 1), LDS(L_G + 6 * r + 2)),
+                      v3(LDS(L_G + 6 * r + 3), LDS(L_G + 6 * r + 4), LDS(L_G + 6 * r + 5)));
+      const float u0 = LDS(L_U3 + 3 * r), u1 = LDS(L_U3 + 3 * r + 1), u2 = LDS(L_U3 + 3 * r + 2), lr = LDS(L_LEG + r);
 #pragma unroll
-    for (int r = 0; r < NR; r++) {
-      if (r < 3 * Kw) {
-        const SV g = sv(v3(LDS(L_G + 6 * r), LDS(L_G + 6 * r + 1), LDS(L_G + 6 * r + 2)),
-                        v3(LDS(L_G + 6 * r + 3), LDS(L_G + 6 * r + 4), LDS(L_G + 6 * r + 5)));
-        const float u0 = LDS(L_U3 + 3 * r), u1 = LDS(L_U3 + 3 * r + 1), u2 = LDS(L_U3 + 3 * r + 2), lr = LDS(L_LEG + r);
-#pragma unroll
-        for (int cc = 0; cc < 5; cc++) {
+      for (int cc = 0; cc < NCC; cc++) {
+        if (ccw & (1u << cc)) {
           const float same = fmaf(u0, ud[cc][0], fmaf(u1, ud[cc][1], u2 * ud[cc][2]));
-          Wc[r][cc] = dot(g, Y[cc]) + (lr == lg[cc] ? same : 0.f);
+          const float w = dot(g, Y[cc]) + (lr == lg[cc] ? same : 0.f);
+          LDSW(r, cc, leg) = w;
+          const int c = leg + 4 * cc;
+          if (r == c) {                                        // diagonal: the owner of the column keeps the row's records
+            if (rowact && !(w > 1e-9f)) fault |= 1u << GO1_FAULT_W_DIAG;
+            LDS(L_RD + r) = w;
+            LDS(L_RI + r) = rowact ? 1.f / w : 0.f;
+          }
+          if (c < NRC && (c % 3) == 0 && (r == c + 1 || r == c + 2)) LDS(L_RP + r) = w;      // tangent rows see the normal impulse
         }
-      } else {
-#pragma unroll
-        for (int cc = 0; cc < 5; cc++) Wc[r][cc] = 0.f;
       }
     }
   }
+  __syncthreads();
   // ---- projected Gauss-Seidel on the impulses -------------------------------------------------------------
-  // Row dot-products are split over the quad (lane `leg` owns columns c = leg, leg+4, ...); W, the impulse vector
-  // (replicated + each lane's own columns) and per contact b, v*, 1/diag and the two normal->tangent couplings
-  // (quad-broadcast from the lane that owns the column) all live in registers: no memory traffic in the sweep.
+  // Row dot-products are split over the quad (lane `leg` owns columns c = leg, leg+4, ...): W comes from LDS, the impulse
+  // vector (replicated + each lane's own columns) and the contact rows' constants live in registers.
   const float mu = 0.5f * (s.mu + cfg.terrain_friction);       // PhysX default combine mode: average
 #ifndef GO1_ABLATE_PGS
   {
-    float lam[NR], lamloc[5];
+    float lam[NRC], lamj[NRJ], lamloc[NCC];
     float bvn[MAXC], bv1[MAXC], bv2[MAXC], vst[MAXC], idn[MAXC], id1[MAXC], id2[MAXC], w10[MAXC], w20[MAXC];
 #pragma unroll
     for (int k = 0; k < MAXC; k++) {
       const int r0 = 3 * k;
       const bool on = k < K;
       lam[r0] = on ? LDS(L_LS + r0) : 0.f; lam[r0 + 1] = on ? LDS(L_LS + r0 + 1) : 0.f; lam[r0 + 2] = on ? LDS(L_LS + r0 + 2) : 0.f;
-      bvn[k] = on ? LDS(L_BV + r0) : 0.f; bv1[k] = on ? LDS(L_BV + r0 + 1) : 0.f; bv2[k] = on ? LDS(L_BV + r0 + 2) : 0.f;
-      vst[k] = on ? LDS(L_VSTAR + k) : 0.f;
-      // W[r][c] sits in lane c & 3 at slot c >> 2
-      const float dn = quad_bcast(Wc[r0][(r0) >> 2], r0);
-      const float d1 = quad_bcast(Wc[r0 + 1][(r0 + 1) >> 2], r0 + 1);
-      const float d2 = quad_bcast(Wc[r0 + 2][(r0 + 2) >> 2], r0 + 2);
-      if (on && !(dn > 1e-9f && d1 > 1e-9f && d2 > 1e-9f)) fault |= 1u << GO1_FAULT_W_DIAG;
-      idn[k] = on ? 1.f / dn : 0.f;
-      id1[k] = on ? 1.f / d1 : 0.f;
-      id2[k] = on ? 1.f / d2 : 0.f;
-      w10[k] = on ? quad_bcast(Wc[r0 + 1][(r0) >> 2], r0) : 0.f;
-      w20[k] = on ? quad_bcast(Wc[r0 + 2][(r0) >> 2], r0) : 0.f;
+      bvn[k] = on ? LDS(L_RB + r0) : 0.f; bv1[k] = on ? LDS(L_RB + r0 + 1) : 0.f; bv2[k] = on ? LDS(L_RB + r0 + 2) : 0.f;
+      vst[k] = on ? LDS(L_RP + r0) : 0.f;
+      idn[k] = on ? LDS(L_RI + r0) : 0.f; id1[k] = on ? LDS(L_RI + r0 + 1) : 0.f; id2[k] = on ? LDS(L_RI + r0 + 2) : 0.f;
+      w10[k] = on ? LDS(L_RP + r0 + 1) : 0.f; w20[k] = on ? LDS(L_RP + r0 + 2) : 0.f;
     }
 #pragma unroll
-    for (int cc = 0; cc < 5; cc++) lamloc[cc] = (leg + 4 * cc < 3 * K) ? LDS(L_LS + leg + 4 * cc) : 0.f;
-    // Columns >= 3K were not published this substep: their impulses are exactly zero and what the column build read
-    // for them is finite (the region is zero-filled at kernel start and only ever holds old columns), so their
-    // products vanish without masking.
+    for (int j = 0; j < NRJ; j++) lamj[j] = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < NCC; cc++) lamloc[cc] = (colact[cc] && leg + 4 * cc < NRC) ? LDS(L_LS + leg + 4 * cc) : 0.f;
+    // Columns that are not rows of this environment's solve keep impulse 0 and what the build wrote for them is finite
+    // (the matrix is zero-filled at kernel start and only ever holds old entries), so their products vanish without masking.
 #pragma unroll 1
     for (int it = 0; it < cfg.solver_iterations; it++) {
 #pragma unroll
@@ -675,11 +746,13 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
           const int r0 = 3 * k;
           float pn = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
-          for (int cc = 0; cc < 5; cc++) {                     // same partition and order as the serial-in-c sum
-            const float l = lamloc[cc];
-            pn = fmaf(Wc[r0][cc], l, pn);
-            p1 = fmaf(Wc[r0 + 1][cc], l, p1);
-            p2 = fmaf(Wc[r0 + 2][cc], l, p2);
+          for (int cc = 0; cc < NCC; cc++) {                   // same partition and order as the serial-in-c sum
+            if (ccw & (1u << cc)) {
+              const float l = lamloc[cc];
+              pn = fmaf(LDSW(r0, cc, leg), l, pn);
+              p1 = fmaf(LDSW(r0 + 1, cc, leg), l, p1);
+              p2 = fmaf(LDSW(r0 + 2, cc, leg), l, p2);
+            }
           }
           const float un = bvn[k] + quad_sum(pn);
           float u1 = bv1[k] + quad_sum(p1);
@@ -700,34 +773,62 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
             if (leg == ((r0 + i) & 3)) lamloc[(r0 + i) >> 2] = lam[r0 + i];
         }
       }
+      // limit rows, leg by leg: the rate without the row's own impulse is projected on [vlo, vhi]
+#pragma unroll
+      for (int lgi = 0; lgi < 4; lgi++) {
+        if (LAw & (1u << lgi)) {
+#pragma unroll
+          for (int jj = 0; jj < 3; jj++) {
+            const int j = 3 * lgi + jj, r = NRC + j;
+            float pj = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < NCC; cc++)
+              if (ccw & (1u << cc)) pj = fmaf(LDSW(r, cc, leg), lamloc[cc], pj);
+            const float u = LDS(L_RB + r) + quad_sum(pj);
+            const float idiag = LDS(L_RI + r);                 // 0: not a row of this environment
+            const float u0 = u - LDS(L_RD + r) * lamj[j];
+            const float ut = fminf(fmaxf(u0, LDS(L_RP + r)), LDS(L_RQ + r));
+            const float ln = (ut - u0) * idiag;
+            lamj[j] = ln;
+            if (leg == (r & 3)) lamloc[r >> 2] = ln;
+          }
+        }
+      }
     }
     {
       float nf_acc = 0.f;
 #pragma unroll
-      for (int r = 0; r < NR; r++) nf_acc = nonfinite_acc(nf_acc, lam[r]);
+      for (int r = 0; r < NRC; r++) nf_acc = nonfinite_acc(nf_acc, lam[r]);
+#pragma unroll
+      for (int j = 0; j < NRJ; j++) nf_acc = nonfinite_acc(nf_acc, lamj[j]);
       if (nf_acc != nf_acc) fault |= 1u << GO1_FAULT_LAMBDA;
     }
     if (leg == 0) {
 #pragma unroll
       for (int k = 0; k < MAXC; k++)
         if (k < K) { LDS(L_LS + 3 * k) = lam[3 * k]; LDS(L_LS + 3 * k + 1) = lam[3 * k + 1]; LDS(L_LS + 3 * k + 2) = lam[3 * k + 2]; }
+      if (lact != 0u) {
+#pragma unroll
+        for (int j = 0; j < NRJ; j++) LDS(L_LS + NRC + j) = lamj[j];
+      }
     }
   }
 #endif
 
   __syncthreads();
   PROF(5);
-  // ---- apply all contact impulses with one propagation ------------------------------------------------
+  // ---- apply all impulses with one propagation ---------------------------------------------------------
   SV pA[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) pA[j] = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
 #pragma unroll
   for (int i = 0; i < 4; i++) {
+    const int b = 1 + 4 * leg + i;
+    V3 f = v3(0.f, 0.f, 0.f);
     if (slot[i] >= 0) {
-      const int k = slot[i], b = 1 + 4 * leg + i;
+      const int k = slot[i];
       const float ln = LDS(L_LS + 3 * k), l1 = LDS(L_LS + 3 * k + 1), l2 = LDS(L_LS + 3 * k + 2);
-      V3 f = ln * fn[i] + l1 * ft1[i] + l2 * ft2[i];           // world impulse
-      LDS(L_LAM + 3 * b) = f.x; LDS(L_LAM + 3 * b + 1) = f.y; LDS(L_LAM + 3 * b + 2) = f.z;
+      f = ln * fn[i] + l1 * ft1[i] + l2 * ft2[i];              // world impulse
       V3 x = v3(cand[i].x, cand[i].y, cand[i].z);
       SV ff = sv(cross(x, f), f);
       const int depth = i > 2 ? 2 : i;
@@ -735,26 +836,40 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       for (int j = 0; j < 3; j++)
         if (j == depth) pA[j] = pA[j] - ff;
     }
+    LDS(L_LAM + 3 * b) = f.x; LDS(L_LAM + 3 * b + 1) = f.y; LDS(L_LAM + 3 * b + 2) = f.z;      // listed: impulse, else 0
+  }
+  float lj[3] = {0.f, 0.f, 0.f};                               // limit impulses of the own joints
+  if (legact) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) lj[j] = LDS(L_LS + NRC + 3 * leg + j);
   }
   SV contrib = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
   float du[3];
 #pragma unroll
   for (int j = 2; j >= 0; j--) {
-    float u = -dot(S[j], pA[j]);
+    float u = lj[j] - dot(S[j], pA[j]);
     du[j] = u;
     SV pa = pA[j] + (u * Dinv[j]) * U[j];
     if (j > 0) pA[j - 1] = pA[j - 1] + pa; else contrib = pa;
   }
-  if (sbase >= 0 && leg == 0) {
-    const float ln = LDS(L_LS + 3 * sbase), l1 = LDS(L_LS + 3 * sbase + 1), l2 = LDS(L_LS + 3 * sbase + 2);
-    V3 f = ln * bn + l1 * bt1 + l2 * bt2;
+  if (leg == 0) {
+    V3 f = v3(0.f, 0.f, 0.f);
+    if (sbase >= 0) {
+      const float ln = LDS(L_LS + 3 * sbase), l1 = LDS(L_LS + 3 * sbase + 1), l2 = LDS(L_LS + 3 * sbase + 2);
+      f = ln * bn + l1 * bt1 + l2 * bt2;
+      V3 x = v3(cbase.x, cbase.y, cbase.z);
+      contrib = contrib - sv(cross(x, f), f);
+    }
     LDS(L_LAM) = f.x; LDS(L_LAM + 1) = f.y; LDS(L_LAM + 2) = f.z;
-    V3 x = v3(cbase.x, cbase.y, cbase.z);
-    contrib = contrib - sv(cross(x, f), f);
   }
   SV dv0 = -sym6_mul(I0inv, quad_sum(contrib));
   s.w = w_free + dv0.a;
   s.v = v_free + dv0.l;
+  {   // Cfg.asset.max_angular_velocity / max_linear_velocity: magnitude caps on the base twist
+    const float wn2 = dot(s.w, s.w), vn2 = dot(s.v, s.v);
+    if (wn2 > cfg.max_angular_velocity * cfg.max_angular_velocity) s.w = (cfg.max_angular_velocity * rsqrtf(wn2)) * s.w;
+    if (vn2 > cfg.max_linear_velocity * cfg.max_linear_velocity) s.v = (cfg.max_linear_velocity * rsqrtf(vn2)) * s.v;
+  }
   {
     SV a = dv0;
 #pragma unroll
@@ -763,13 +878,14 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       float dqd = Dinv[j] * (du[j] - dot(U[j], a));
       a = a + dqd * S[j];
       float qd = qd_free[j] + dqd;
-      // joint velocity limit, semi-implicit Euler, hard position limits
-      float vl = GO1_JOINT_VEL_LIMIT[ji];
-      qd = fminf(fmaxf(qd, -vl), vl);
+      // What the limit rows leave is the solver's residual; it is NOT clamped away.  Only a failure of the rows far outside
+      // the admissible band is cut (and counted): GO1_LIMIT_SAFETY x the rate limit, GO1_LIMIT_SLACK beyond a stop.
+      const float vl = GO1_LIMIT_SAFETY * GO1_JOINT_VEL_LIMIT[ji];
+      if (!(fabsf(qd) <= vl)) { fault |= 1u << GO1_FAULT_LIMIT_SAFETY; qd = fminf(fmaxf(qd, -vl), vl); }
       float q = L.q[j] + h * qd;
-      float lo = GO1_JOINT_LOWER[ji], hi = GO1_JOINT_UPPER[ji];
-      if (q < lo) { q = lo; qd = fmaxf(qd, 0.f); }
-      if (q > hi) { q = hi; qd = fminf(qd, 0.f); }
+      const float lo = GO1_JOINT_LOWER[ji] - GO1_LIMIT_SLACK, hi = GO1_JOINT_UPPER[ji] + GO1_LIMIT_SLACK;
+      if (q < lo) { q = lo; qd = fmaxf(qd, 0.f); fault |= 1u << GO1_FAULT_LIMIT_SAFETY; }
+      if (q > hi) { q = hi; qd = fminf(qd, 0.f); fault |= 1u << GO1_FAULT_LIMIT_SAFETY; }
       L.q[j] = q;
       L.qd[j] = qd;
     }
@@ -799,6 +915,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     for (int j = 0; j < 3; j++) { a = nonfinite_acc(a, L.q[j]); a = nonfinite_acc(a, L.qd[j]); }
     if (a != a) fault |= 1u << GO1_FAULT_STATE_OUT;
   }
+  LDS_PHASE();          // the next substep's warm start reads what this one wrote (per-body impulses, row records)
   PROF(6);
 }
 
