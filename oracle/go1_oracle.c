@@ -398,9 +398,6 @@ static void jac_row(const Kin* k, int dynb, const real* x, const real* d, real* 
 #define GO1_LIMIT_RECOVERY_RATE 10.0   /* rad/s */
 #define GO1_LIMIT_SAFETY 2.0           /* x velocity limit */
 #define GO1_LIMIT_SLACK 0.2            /* rad beyond a stop */
-#ifndef GO1_LIMIT_INNER
-#define GO1_LIMIT_INNER 1
-#endif
 static const int CONTACT_ORDER[17] = {4, 8, 12, 16, 0, 3, 7, 11, 15, 2, 6, 10, 14, 1, 5, 9, 13};
 
 /* ------------------------------------------------------------------ one physics substep (replaces gym.simulate) */
@@ -520,18 +517,17 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
       lam[b][1] = l1; lam[b][2] = l2;
       for (int i = 0; i < NV; i++) v[i] += T[b][1][i] * d1 + T[b][2][i] * d2;
     }
-    /* joint rows: leg by leg, GO1_LIMIT_INNER Gauss-Seidel passes over the (strongly coupled) rows of one leg */
-    for (int leg = 0; leg < 4; leg++)
-      for (int rep = 0; rep < GO1_LIMIT_INNER; rep++)
-        for (int j = 3 * leg; j < 3 * leg + 3; j++) {
-          if (!jact[j]) continue;
-          real u0 = v[6 + j] - AJ[j] * lamj[j];                     /* rate without this row's impulse */
-          real ut = u0 < vlo[j] ? vlo[j] : (u0 > vhi[j] ? vhi[j] : u0);
-          real ln = (ut - u0) / AJ[j];
-          real dl = ln - lamj[j];
-          lamj[j] = ln;
-          for (int i = 0; i < NV; i++) v[i] += TJ[j][i] * dl;
-        }
+    /* joint rows, plain Gauss-Seidel in joint order.  (Running the four legs side by side — block Jacobi — was tried and
+     * does NOT converge: with the robot in the air the legs couple strongly through the light base.) */
+    for (int j = 0; j < 12; j++) {
+      if (!jact[j]) continue;
+      real u0 = v[6 + j] - AJ[j] * lamj[j];                     /* rate without this row's impulse */
+      real ut = u0 < vlo[j] ? vlo[j] : (u0 > vhi[j] ? vhi[j] : u0);
+      real ln = (ut - u0) / AJ[j];
+      real dl = ln - lamj[j];
+      lamj[j] = ln;
+      for (int i = 0; i < NV; i++) v[i] += TJ[j][i] * dl;
+    }
   }
   for (int b = 0; b < 17; b++) {
     for (int i = 0; i < 3; i++) {

@@ -219,14 +219,15 @@ def test_thousand_steps_match_oracle():
 
 def test_free_running_distributions_match_oracle():
     """No re-synchronisation: kernel and oracle start from the same state and receive the same action and RNG streams for
-    600 policy steps (256 envs, N(0,1) actions, train.py configuration).  Individual trajectories separate at the first
+    700 policy steps (512 envs, N(0,1) actions, train.py configuration).  Individual trajectories separate at the first
     contact-mode flip — as two fp32 PhysX runs would — so the comparison is distributional: mean episode length, mean
     step reward, per-term episode sums per episode, foot-contact duty factor, mean base height, command-curriculum mass.
-    ~2000 episodes per side: sampling noise is ~3 % (1 sigma) on the episode statistics; bounds are 4 sigma."""
-    N, steps = 256, 600
+    ~600 episodes per side: sampling noise is ~5 % (1 sigma) on the episode statistics; bounds are ~4 sigma."""
+    N, steps = 512, 700
     cfg, S, meta, Bc, orc = gpu_pair("train_noise", N, seed=29)
     Bg, sim = to_gpu(S, Bc)
     sync_from(Bc, Bg, sim, orc)
+    Bg.episode_log.zero_()               # (the copy carries the oracle's initial reset_idx: the kernel accumulates, the oracle restarts)
     rng = np.random.default_rng(3)
     nr = S.num_rewards
     acc = {"cpu": np.zeros(5), "gpu": np.zeros(5)}
@@ -251,12 +252,12 @@ def test_free_running_distributions_match_oracle():
     c, g = out["cpu"], out["gpu"]
     print(f"free-running: episode length {c['ep_len']:.1f} / {g['ep_len']:.1f}, step reward {c['rew']:.5f} / {g['rew']:.5f}, "
           f"foot duty {c['duty']:.3f} / {g['duty']:.3f}, base height {c['height']:.4f} / {g['height']:.4f} (oracle / HIP)")
-    assert acc["cpu"][0] > 1000 and acc["gpu"][0] > 1000
-    assert abs(c["ep_len"] - g["ep_len"]) <= 0.12 * c["ep_len"]
+    assert acc["cpu"][0] > 300 and acc["gpu"][0] > 300
+    assert abs(c["ep_len"] - g["ep_len"]) <= 0.2 * c["ep_len"]
     assert abs(c["duty"] - g["duty"]) <= 0.03 and abs(c["height"] - g["height"]) <= 0.01
-    assert abs(c["rew"] - g["rew"]) <= 0.15 * abs(c["rew"]) + 2e-4
+    assert abs(c["rew"] - g["rew"]) <= 0.2 * abs(c["rew"]) + 2e-4
     scale = np.abs(c["terms"]).max()
-    assert np.all(np.abs(c["terms"] - g["terms"]) <= 0.15 * np.abs(c["terms"]) + 0.02 * scale), (c["terms"], g["terms"])
+    assert np.all(np.abs(c["terms"] - g["terms"]) <= 0.25 * np.abs(c["terms"]) + 0.03 * scale), (c["terms"], g["terms"])
     assert abs(c["weight_mass"] - g["weight_mass"]) <= 0.05 * c["weight_mass"] + 1.0
     assert int(Bg.fault_counts[:10].sum()) == 0
 
@@ -470,8 +471,8 @@ def test_failed_simulation_guard():
     assert torch.equal(Bg.reset_buf[others], Bref.reset_buf[others])
     # the containment is reported, not hidden: fault word of the victim, one count, nothing anywhere else
     bit = 1 << H.abi.GO1_FAULT_REWARD
-    assert int(Bg.fault_flags[victim]) == bit and int(Bg.fault_flags[others].abs().sum()) == 0
-    assert Bg.fault_counts.tolist()[H.abi.GO1_FAULT_REWARD] >= 1 and int(Bref.fault_counts.sum()) == 0
+    assert int(Bg.fault_flags[victim]) & H.FAULT_FATAL_MASK == bit and int((Bg.fault_flags[others] & H.FAULT_FATAL_MASK).sum()) == 0
+    assert Bg.fault_counts.tolist()[H.abi.GO1_FAULT_REWARD] >= 1 and int(Bref.fault_counts[:10].sum()) == 0
 
 
 @pytest.mark.parametrize("where", ["root_z", "quat", "dof_vel", "base_ang_vel"])
@@ -501,7 +502,7 @@ def test_failed_state_is_contained_and_reported(where):
     word = int(Bg.fault_flags[victim])
     assert word & (1 << H.abi.GO1_FAULT_STATE_IN) and word & H.FAULT_FATAL_MASK
     others = torch.arange(N, device="cuda") != victim
-    assert int(Bg.fault_flags[others].abs().sum()) == 0 and int(Bref.fault_counts.sum()) == 0
+    assert int((Bg.fault_flags[others] & H.FAULT_FATAL_MASK).sum()) == 0 and int(Bref.fault_counts[:10].sum()) == 0
     for k in ("root_states", "dof_pos", "obs_buf", "rew_buf"):
         a_, b_ = Bg.tensors[k], Bref.tensors[k]
         if a_.shape[-1] == N:

@@ -15,10 +15,10 @@ for p in (os.path.join(PKG, "shims"), PKG, REPO):
     sys.path.insert(0, p)
 
 PHASES = ["load state/actions/warm start", "torque model (x4)", "kinematics + candidates + ABA 1,2 (x4)",
-          "ABA 3 + contact list + publish (x4)", "Delassus (x4)", "PGS (x4)", "apply + integrate (x4)",
+          "ABA 3 + contact list + publish (x4)", "row functionals (x4)", "PGS sweeps (x4)", "apply + integrate (x4)",
           "store state/feet/forces", "post: derived + callbacks", "post: gait clock + push/dof-rand",
           "post: feet/heights/termination", "post: rewards", "post: reset", "post: observations", "post: privileged obs",
-          "post: roll", "post: reward-input loads", "post: termination"]
+          "post: roll", "post: reward-input loads", "post: termination", "Delassus: matrix build (x4)"]
 
 
 def build(flags):

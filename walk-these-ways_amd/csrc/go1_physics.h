@@ -34,23 +34,29 @@
 enum {
   L_LAM = 0,                 // 17 x world impulse (x, y, z) per reported body: solver output / warm start
   L_CX = 51,                 // MAXC x 3 contact points (rel. base origin)
-  L_RB = L_CX + 3 * MAXC,    // NRT   b = J v_free of the row
-  L_RP = L_RB + NRT,         // NRT   normal rows: target velocity v*; tangent rows: W[t][n]; joint rows: lower rate bound
-  L_RQ = L_RP + NRT,         // NRT   joint rows: upper rate bound
-  L_RI = L_RQ + NRT,         // NRT   1 / W[r][r]  (0: the row is not in this environment's solve)
-  L_RD = L_RI + NRT,         // NRT   W[r][r]
-  L_LS = L_RD + NRT,         // NRT   impulses: start values in, solution out
-  L_G = L_LS + NRT,          // NRT x 6  row functionals: the unit impulse of the row propagated to the base, g_r
-  L_U3 = L_G + NRT * 6,      // NRT x 3  joint-space residuals u_j(r) along the row's leg (0 beyond its depth)
-  L_UD = L_U3 + NRT * 3,     // NRT x 3  u_j(r) / D_j
-  L_LEG = L_UD + NRT * 3,    // NRT      leg of the row (4 = trunk)
-  L_W = L_RB,                // zero-filled at kernel start from here to L_END (rows that are not written must read finite)
-  L_END = L_LEG + NRT
+  L_RB = L_CX + 3 * MAXC,    // NRC   contact rows: b = J v_free
+  L_RP = L_RB + NRC,         // NRC   normal rows: target velocity v*; tangent rows: W[t][n]
+  L_RI = L_RP + NRC,         // NRC   1 / W[r][r]
+  L_LS = L_RI + NRC,         // NRC   contact impulses: start values in, solution out
+  L_W = L_RB,                // zero-filled at kernel start from here to L_END
+  L_END = L_LS + NRC
 };
 #define LDS(f) lds[(f) * EPW + el]
-// Delassus matrix W = J M^-1 J^T in LDS: entry (r, c) sits in the share of lane c & 3 at column slot c >> 2
-#define LDSW_SIZE (NRT * NCC * 4 * EPW)
-#define LDSW(r, cc, lg) ldsw[(((r) * NCC + (cc)) * 4 + (lg)) * EPW + el]
+// Packed records, one per (row, environment), read with 16-byte LDS loads:
+//   row functional RF: [0..5] g_r (the row's unit impulse propagated to the base), [6..8] u_j(r) along the row's leg,
+//                      [9..11] u_j(r) / D_j, [12] leg of the row (4 = trunk)
+//   limit row      JR: [0] b = free joint rate, [1] lower, [2] upper rate bound, [3] W[r][r], [4] 1 / W[r][r] (0: not in the solve)
+//   Delassus row   W : the row's NRT entries in the order [owner lane c & 3][slot c >> 2] (lane `leg` reads its 8 contiguous
+//                      floats), rows padded to WST floats (spreads the environments over the banks)
+#define RF_ST 16
+#define RF(r) (rfl + ((r) * EPW + el) * RF_ST)
+#define JR_ST 8
+#define JR(j) (jrl + ((j) * EPW + el) * JR_ST)
+#define WST 36
+#define WROW(r) (ldsw + ((r) * EPW + el) * WST)
+#define LDSW_SIZE (NRT * EPW * WST)
+#define LDSX_SIZE (NRT * EPW * RF_ST + NRJ * EPW * JR_ST)       // RF records, then JR records
+typedef __attribute__((ext_vector_type(4))) float lf4;
 
 // ================================================================================================
 // torque model (reference legged_robot.py:907-946): the calling lane handles the 3 joints of its leg
@@ -335,8 +341,9 @@ DEV SV leg_response(const SV S[3], const SV U[3], const float Dinv[3], SV a0, in
   return a;
 }
 
-DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds, float* ldsw, int lane, Base& s, Leg& L, V3 grav, bool use_warm,
-                         float h, uint32_t& fault PROF_PARAM) {
+DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds, float* ldsw, float* rfl, int lane, Base& s, Leg& L, V3 grav,
+                         bool use_warm, float h, uint32_t& fault PROF_PARAM) {
+  float* const jrl = rfl + NRT * EPW * RF_ST;
   const int leg = lane & 3, el = lane >> 2;
   const M3 R0 = quat_to_mat(s.qx, s.qy, s.qz, s.qw);
   const SV v0 = sv(s.w, s.v);
@@ -574,8 +581,8 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   if (legact) {
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      const int r = NRC + 3 * leg + j;
-      LDS(L_RB + r) = qd_free[j]; LDS(L_RP + r) = jlo[j]; LDS(L_RQ + r) = jhi[j]; LDS(L_LS + r) = 0.f;
+      float* jr = JR(3 * leg + j);
+      jr[0] = qd_free[j]; jr[1] = jlo[j]; jr[2] = jhi[j];
     }
   }
 
@@ -606,12 +613,11 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
             pA = pA + (u * Dinv[j]) * U[j];
           }
         }
-        const int c = 3 * k + r;
-        LDS(L_G + 6 * c) = pA.a.x; LDS(L_G + 6 * c + 1) = pA.a.y; LDS(L_G + 6 * c + 2) = pA.a.z;
-        LDS(L_G + 6 * c + 3) = pA.l.x; LDS(L_G + 6 * c + 4) = pA.l.y; LDS(L_G + 6 * c + 5) = pA.l.z;
-#pragma unroll
-        for (int j = 0; j < 3; j++) { LDS(L_U3 + 3 * c + j) = uj[j]; LDS(L_UD + 3 * c + j) = uj[j] * Dinv[j]; }
-        LDS(L_LEG + c) = (float)leg;
+        lf4* rf = reinterpret_cast<lf4*>(RF(3 * k + r));
+        rf[0] = (lf4){pA.a.x, pA.a.y, pA.a.z, pA.l.x};
+        rf[1] = (lf4){pA.l.y, pA.l.z, uj[0], uj[1]};
+        rf[2] = (lf4){uj[2], uj[0] * Dinv[0], uj[1] * Dinv[1], uj[2] * Dinv[2]};
+        rf[3] = (lf4){(float)leg, 0.f, 0.f, 0.f};
       }
     }
   }
@@ -621,12 +627,11 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     for (int r = 0; r < 3; r++) {
       const V3 d = r == 0 ? bn : r == 1 ? bt1 : bt2;
       const SV g = -sv(cross(x, d), d);
-      const int c = 3 * sbase + r;
-      LDS(L_G + 6 * c) = g.a.x; LDS(L_G + 6 * c + 1) = g.a.y; LDS(L_G + 6 * c + 2) = g.a.z;
-      LDS(L_G + 6 * c + 3) = g.l.x; LDS(L_G + 6 * c + 4) = g.l.y; LDS(L_G + 6 * c + 5) = g.l.z;
-#pragma unroll
-      for (int j = 0; j < 3; j++) { LDS(L_U3 + 3 * c + j) = 0.f; LDS(L_UD + 3 * c + j) = 0.f; }
-      LDS(L_LEG + c) = 4.f;
+      lf4* rf = reinterpret_cast<lf4*>(RF(3 * sbase + r));
+      rf[0] = (lf4){g.a.x, g.a.y, g.a.z, g.l.x};
+      rf[1] = (lf4){g.l.y, g.l.z, 0.f, 0.f};
+      rf[2] = (lf4){0.f, 0.f, 0.f, 0.f};
+      rf[3] = (lf4){4.f, 0.f, 0.f, 0.f};
     }
   }
   if (legact) {
@@ -643,12 +648,11 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
           pA = pA + (u * Dinv[j]) * U[j];
         }
       }
-      const int c = NRC + 3 * leg + jj;
-      LDS(L_G + 6 * c) = pA.a.x; LDS(L_G + 6 * c + 1) = pA.a.y; LDS(L_G + 6 * c + 2) = pA.a.z;
-      LDS(L_G + 6 * c + 3) = pA.l.x; LDS(L_G + 6 * c + 4) = pA.l.y; LDS(L_G + 6 * c + 5) = pA.l.z;
-#pragma unroll
-      for (int j = 0; j < 3; j++) { LDS(L_U3 + 3 * c + j) = uj[j]; LDS(L_UD + 3 * c + j) = uj[j] * Dinv[j]; }
-      LDS(L_LEG + c) = (float)leg;
+      lf4* rf = reinterpret_cast<lf4*>(RF(NRC + 3 * leg + jj));
+      rf[0] = (lf4){pA.a.x, pA.a.y, pA.a.z, pA.l.x};
+      rf[1] = (lf4){pA.l.y, pA.l.z, uj[0], uj[1]};
+      rf[2] = (lf4){uj[2], uj[0] * Dinv[0], uj[1] * Dinv[1], uj[2] * Dinv[2]};
+      rf[3] = (lf4){(float)leg, 0.f, 0.f, 0.f};
     }
   }
   __syncthreads();
@@ -679,12 +683,11 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       if (ccw & (1u << cc)) {
         int c = leg + 4 * cc;
         c = c < NRC + NRJ ? c : NRC + NRJ - 1;     // lanes 2, 3 have no last column: any finite stand-in (its impulse stays 0)
-        const SV g = sv(v3(LDS(L_G + 6 * c), LDS(L_G + 6 * c + 1), LDS(L_G + 6 * c + 2)),
-                        v3(LDS(L_G + 6 * c + 3), LDS(L_G + 6 * c + 4), LDS(L_G + 6 * c + 5)));
-        Y[cc] = sym6_mul(I0inv, g);
-#pragma unroll
-        for (int j = 0; j < 3; j++) ud[cc][j] = LDS(L_UD + 3 * c + j);
-        lg[cc] = LDS(L_LEG + c);
+        const lf4* rf = reinterpret_cast<const lf4*>(RF(c));
+        const lf4 r0 = rf[0], r1 = rf[1], r2 = rf[2];
+        Y[cc] = sym6_mul(I0inv, sv(v3(r0[0], r0[1], r0[2]), v3(r0[3], r1[0], r1[1])));
+        ud[cc][0] = r2[1]; ud[cc][1] = r2[2]; ud[cc][2] = r2[3];
+        lg[cc] = rf[3][0];
       }
     }
     // rows: the contact rows of the wave's largest contact list, then the limit rows of every leg that is active somewhere
@@ -693,41 +696,49 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       const bool roww = r < NRC ? (r < 3 * Kw) : (((LAw >> ((r - NRC) / 3)) & 1u) != 0u);      // wave-uniform
       if (!roww) continue;
       const bool rowact = r < NRC ? (r < 3 * K) : (((lact >> ((r - NRC) / 3)) & 1u) != 0u);
-      const SV g = sv(v3(LDS(L_G + 6 * r), LDS(L_G + 6 * r + 1), LDS(L_G + 6 * r + 2)),
-                      v3(LDS(L_G + 6 * r + 3), LDS(L_G + 6 * r + 4), LDS(L_G + 6 * r + 5)));
-      const float u0 = LDS(L_U3 + 3 * r), u1 = LDS(L_U3 + 3 * r + 1), u2 = LDS(L_U3 + 3 * r + 2), lr = LDS(L_LEG + r);
+      const lf4* rf = reinterpret_cast<const lf4*>(RF(r));
+      const lf4 r0 = rf[0], r1 = rf[1], r2 = rf[2];
+      const SV g = sv(v3(r0[0], r0[1], r0[2]), v3(r0[3], r1[0], r1[1]));
+      const float u0 = r1[2], u1 = r1[3], u2 = r2[0], lr = rf[3][0];
+      float wv[NCC];
 #pragma unroll
       for (int cc = 0; cc < NCC; cc++) {
+        wv[cc] = 0.f;
         if (ccw & (1u << cc)) {
           const float same = fmaf(u0, ud[cc][0], fmaf(u1, ud[cc][1], u2 * ud[cc][2]));
           const float w = dot(g, Y[cc]) + (lr == lg[cc] ? same : 0.f);
-          LDSW(r, cc, leg) = w;
+          wv[cc] = w;
           const int c = leg + 4 * cc;
           if (r == c) {                                        // diagonal: the owner of the column keeps the row's records
             if (rowact && !(w > 1e-9f)) fault |= 1u << GO1_FAULT_W_DIAG;
-            LDS(L_RD + r) = w;
-            LDS(L_RI + r) = rowact ? 1.f / w : 0.f;
+            if (r < NRC) LDS(L_RI + r) = rowact ? 1.f / w : 0.f;
+            else { float* jr = JR(r - NRC); jr[3] = w; jr[4] = rowact ? 1.f / w : 0.f; }
           }
           if (c < NRC && (c % 3) == 0 && (r == c + 1 || r == c + 2)) LDS(L_RP + r) = w;      // tangent rows see the normal impulse
         }
       }
+      lf4* wp = reinterpret_cast<lf4*>(WROW(r) + NCC * leg);
+      wp[0] = (lf4){wv[0], wv[1], wv[2], wv[3]};
+      wp[1] = (lf4){wv[4], wv[5], wv[6], wv[7]};
     }
   }
   __syncthreads();
+  PROF(18);
   // ---- projected Gauss-Seidel on the impulses -------------------------------------------------------------
-  // Row dot-products are split over the quad (lane `leg` owns columns c = leg, leg+4, ...): W comes from LDS, the impulse
-  // vector (replicated + each lane's own columns) and the contact rows' constants live in registers.
+  // The sweep keeps the ROW VELOCITIES u = b + W lambda up to date instead of re-evaluating a row's dot product when its
+  // turn comes: lane `leg` holds u for its rows r = leg + 4 cc; a row's turn is then one quad broadcast of its u, the
+  // projection, and — off the critical path — 8 independent FMAs per lane that add the impulse change times the lane's
+  // share of that row of W (W is symmetric: the share of row c IS the lane's part of column c) to the velocities.
   const float mu = 0.5f * (s.mu + cfg.terrain_friction);       // PhysX default combine mode: average
 #ifndef GO1_ABLATE_PGS
   {
-    float lam[NRC], lamj[NRJ], lamloc[NCC];
-    float bvn[MAXC], bv1[MAXC], bv2[MAXC], vst[MAXC], idn[MAXC], id1[MAXC], id2[MAXC], w10[MAXC], w20[MAXC];
+    float lam[NRC], lamj[NRJ], uloc[NCC];
+    float vst[MAXC], idn[MAXC], id1[MAXC], id2[MAXC], w10[MAXC], w20[MAXC];
 #pragma unroll
     for (int k = 0; k < MAXC; k++) {
       const int r0 = 3 * k;
       const bool on = k < K;
       lam[r0] = on ? LDS(L_LS + r0) : 0.f; lam[r0 + 1] = on ? LDS(L_LS + r0 + 1) : 0.f; lam[r0 + 2] = on ? LDS(L_LS + r0 + 2) : 0.f;
-      bvn[k] = on ? LDS(L_RB + r0) : 0.f; bv1[k] = on ? LDS(L_RB + r0 + 1) : 0.f; bv2[k] = on ? LDS(L_RB + r0 + 2) : 0.f;
       vst[k] = on ? LDS(L_RP + r0) : 0.f;
       idn[k] = on ? LDS(L_RI + r0) : 0.f; id1[k] = on ? LDS(L_RI + r0 + 1) : 0.f; id2[k] = on ? LDS(L_RI + r0 + 2) : 0.f;
       w10[k] = on ? LDS(L_RP + r0 + 1) : 0.f; w20[k] = on ? LDS(L_RP + r0 + 2) : 0.f;
@@ -735,28 +746,40 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
 #pragma unroll
     for (int j = 0; j < NRJ; j++) lamj[j] = 0.f;
 #pragma unroll
-    for (int cc = 0; cc < NCC; cc++) lamloc[cc] = (colact[cc] && leg + 4 * cc < NRC) ? LDS(L_LS + leg + 4 * cc) : 0.f;
-    // Columns that are not rows of this environment's solve keep impulse 0 and what the build wrote for them is finite
-    // (the matrix is zero-filled at kernel start and only ever holds old entries), so their products vanish without masking.
+    for (int cc = 0; cc < NCC; cc++) {                         // u = b for the lane's rows (rows outside this env's solve: 0)
+      const int c = leg + 4 * cc;
+      float bb = 0.f;
+      if (colact[cc]) bb = c < NRC ? LDS(L_RB + (c < NRC ? c : 0)) : JR(c < NRC + NRJ ? c - NRC : 0)[0];
+      uloc[cc] = bb;
+    }
+    // u += (share of row c) * dl for the lane's rows.  Rows that are not in this environment's solve have impulse 0 and
+    // what the build wrote for them is finite (the matrix is zero-filled at kernel start), so their products vanish.
+    auto apply_col = [&](int c, float dl) {
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        if (ccw & (0xFu << (4 * hf))) {
+          const lf4 w = reinterpret_cast<const lf4*>(WROW(c) + NCC * leg)[hf];
+#pragma unroll
+          for (int i = 0; i < 4; i++) uloc[4 * hf + i] = fmaf(w[i], dl, uloc[4 * hf + i]);
+        }
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < MAXC; k++) {                           // warm start: the starting impulses' velocities
+      if (k < Kw) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) apply_col(3 * k + i, lam[3 * k + i]);
+      }
+    }
 #pragma unroll 1
     for (int it = 0; it < cfg.solver_iterations; it++) {
 #pragma unroll
       for (int k = 0; k < MAXC; k++) {
         if (k < Kw) {
           const int r0 = 3 * k;
-          float pn = 0.f, p1 = 0.f, p2 = 0.f;
-#pragma unroll
-          for (int cc = 0; cc < NCC; cc++) {                   // same partition and order as the serial-in-c sum
-            if (ccw & (1u << cc)) {
-              const float l = lamloc[cc];
-              pn = fmaf(LDSW(r0, cc, leg), l, pn);
-              p1 = fmaf(LDSW(r0 + 1, cc, leg), l, p1);
-              p2 = fmaf(LDSW(r0 + 2, cc, leg), l, p2);
-            }
-          }
-          const float un = bvn[k] + quad_sum(pn);
-          float u1 = bv1[k] + quad_sum(p1);
-          float u2 = bv2[k] + quad_sum(p2);
+          const float un = quad_bcast(uloc[r0 >> 2], r0);      // row r sits in lane r & 3 at slot r >> 2
+          float u1 = quad_bcast(uloc[(r0 + 1) >> 2], r0 + 1);
+          float u2 = quad_bcast(uloc[(r0 + 2) >> 2], r0 + 2);
           const float ln_old = lam[r0];
           const float ln = fmaxf(0.f, ln_old - (un - vst[k]) * idn[k]);
           const float dln = ln - ln_old;
@@ -767,30 +790,27 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
           const float lim = mu * ln, nn = l1 * l1 + l2 * l2;   // friction cone: |l_t| <= mu l_n
           if (nn > lim * lim) { const float sc = lim * __builtin_amdgcn_rsqf(nn); l1 *= sc; l2 *= sc; }
           const bool on = k < K;                               // lanes of environments with fewer contacts idle here
-          lam[r0] = on ? ln : 0.f; lam[r0 + 1] = on ? l1 : 0.f; lam[r0 + 2] = on ? l2 : 0.f;
-#pragma unroll
-          for (int i = 0; i < 3; i++)
-            if (leg == ((r0 + i) & 3)) lamloc[(r0 + i) >> 2] = lam[r0 + i];
+          const float nl0 = on ? ln : 0.f, nl1 = on ? l1 : 0.f, nl2 = on ? l2 : 0.f;
+          apply_col(r0, nl0 - lam[r0]); apply_col(r0 + 1, nl1 - lam[r0 + 1]); apply_col(r0 + 2, nl2 - lam[r0 + 2]);
+          lam[r0] = nl0; lam[r0 + 1] = nl1; lam[r0 + 2] = nl2;
         }
       }
-      // limit rows, leg by leg: the rate without the row's own impulse is projected on [vlo, vhi]
+      // limit rows in joint order: the rate without the row's own impulse is projected on [lower, upper]
 #pragma unroll
       for (int lgi = 0; lgi < 4; lgi++) {
         if (LAw & (1u << lgi)) {
 #pragma unroll
           for (int jj = 0; jj < 3; jj++) {
             const int j = 3 * lgi + jj, r = NRC + j;
-            float pj = 0.f;
-#pragma unroll
-            for (int cc = 0; cc < NCC; cc++)
-              if (ccw & (1u << cc)) pj = fmaf(LDSW(r, cc, leg), lamloc[cc], pj);
-            const float u = LDS(L_RB + r) + quad_sum(pj);
-            const float idiag = LDS(L_RI + r);                 // 0: not a row of this environment
-            const float u0 = u - LDS(L_RD + r) * lamj[j];
-            const float ut = fminf(fmaxf(u0, LDS(L_RP + r)), LDS(L_RQ + r));
+            const float* jr = JR(j);
+            const lf4 rec = *reinterpret_cast<const lf4*>(jr);   // b, lower, upper, W[r][r]
+            const float idiag = jr[4];                           // 0: not a row of this environment
+            const float u = quad_bcast(uloc[r >> 2], r);
+            const float u0 = u - rec[3] * lamj[j];
+            const float ut = fminf(fmaxf(u0, rec[1]), rec[2]);
             const float ln = (ut - u0) * idiag;
+            apply_col(r, ln - lamj[j]);
             lamj[j] = ln;
-            if (leg == (r & 3)) lamloc[r >> 2] = ln;
           }
         }
       }
@@ -809,7 +829,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
         if (k < K) { LDS(L_LS + 3 * k) = lam[3 * k]; LDS(L_LS + 3 * k + 1) = lam[3 * k + 1]; LDS(L_LS + 3 * k + 2) = lam[3 * k + 2]; }
       if (lact != 0u) {
 #pragma unroll
-        for (int j = 0; j < NRJ; j++) LDS(L_LS + NRC + j) = lamj[j];
+        for (int j = 0; j < NRJ; j++) JR(j)[5] = lamj[j];
       }
     }
   }
@@ -841,7 +861,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   float lj[3] = {0.f, 0.f, 0.f};                               // limit impulses of the own joints
   if (legact) {
 #pragma unroll
-    for (int j = 0; j < 3; j++) lj[j] = LDS(L_LS + NRC + 3 * leg + j);
+    for (int j = 0; j < 3; j++) lj[j] = JR(3 * leg + j)[5];
   }
   SV contrib = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
   float du[3];

@@ -55,11 +55,13 @@ DEV void report_fault(BufRef B, int e, uint32_t fault) {
 extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArgs A) {
   __shared__ float lds[L_END * EPW];
   __shared__ __attribute__((aligned(16))) float ldsw[LDSW_SIZE];
+  __shared__ __attribute__((aligned(16))) float ldsx[LDSX_SIZE];
   __shared__ __attribute__((aligned(16))) float act_lds[A_END];
   for (int i = threadIdx.x; i < (L_END - L_W) * EPW; i += WAVE) lds[L_W * EPW + i] = 0.f;   // finite everywhere: see the PGS column split
   {
     typedef __attribute__((ext_vector_type(4))) float zf4;
     for (int i = threadIdx.x; i < LDSW_SIZE / 4; i += WAVE) reinterpret_cast<zf4*>(ldsw)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < LDSX_SIZE / 4; i += WAVE) reinterpret_cast<zf4*>(ldsx)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
   }
   const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
   CfgRef cfg = csc->cfg;
@@ -116,7 +118,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
     PROF(1);
     head = (head + 1) % nl;
 #ifndef GO1_ABLATE_PHYSICS
-    physics_substep(cfg, B.height_samples, lds, ldsw, lane, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault PROF_PASS);
+    physics_substep(cfg, B.height_samples, lds, ldsw, ldsx, lane, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault PROF_PASS);
 #endif
   }
   store_state(B, leg, e, N, s, L);
@@ -136,11 +138,13 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
 extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs A) {
   __shared__ float lds[L_END * EPW];
   __shared__ __attribute__((aligned(16))) float ldsw[LDSW_SIZE];
+  __shared__ __attribute__((aligned(16))) float ldsx[LDSX_SIZE];
   __shared__ __attribute__((aligned(16))) float act_lds[A_END];
   for (int i = threadIdx.x; i < (L_END - L_W) * EPW; i += WAVE) lds[L_W * EPW + i] = 0.f;   // finite everywhere: see the PGS column split
   {
     typedef __attribute__((ext_vector_type(4))) float zf4;
     for (int i = threadIdx.x; i < LDSW_SIZE / 4; i += WAVE) reinterpret_cast<zf4*>(ldsw)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < LDSX_SIZE / 4; i += WAVE) reinterpret_cast<zf4*>(ldsx)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
   }
   const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
   CfgRef cfg = csc->cfg;
@@ -176,7 +180,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   load_lambda(cfg, B, lds, lane, e, N, false);
   LDS_PHASE();
   PROF_DECL
-  physics_substep(cfg, B.height_samples, lds, ldsw, lane, s, L, grav, cfg.warm_start != 0, cfg.sim_dt, fault PROF_PASS);
+  physics_substep(cfg, B.height_samples, lds, ldsw, ldsx, lane, s, L, grav, cfg.warm_start != 0, cfg.sim_dt, fault PROF_PASS);
   store_state(B, leg, e, N, s, L);
   foot_state(s, L, leg, B, e, N);
   store_forces(cfg, B, lds, lane, e, N);

@@ -188,6 +188,18 @@ class LeggedRobot(BaseTask):
             # both mesh types are simulated on the height field's bilinear surface (utils/terrain.py docstring)
             H.bind_height_field(self.sim_config, B, self.terrain.heightsamples, cfg.terrain.horizontal_scale,
                                 cfg.terrain.vertical_scale, cfg.terrain.border_size)
+            if mesh_type == 'trimesh' and self.sim_config.terrain_type != 0:
+                hs = np.asarray(self.terrain.heightsamples, dtype=np.float64) * cfg.terrain.vertical_scale
+                steep = max(np.abs(np.diff(hs, axis=0)).max(), np.abs(np.diff(hs, axis=1)).max()) / cfg.terrain.horizontal_scale
+                thr = float(getattr(cfg.terrain, "slope_treshold", 0.75))
+                if steep > thr:
+                    import warnings
+                    warnings.warn(
+                        f"mesh_type='trimesh' on a non-flat terrain with slopes up to {steep:.2f} (> slope_treshold {thr}): the "
+                        f"reference converts such faces into VERTICAL WALLS (terrain.py:33-36, convert_heightfield_to_trimesh); this "
+                        f"simulator collides with the bilinear height-field surface instead, so risers are steep ramps one cell "
+                        f"({cfg.terrain.horizontal_scale} m) wide.  Flat trimesh terrains (scripts/train.py) are unaffected.",
+                        RuntimeWarning, stacklevel=2)
         self.num_dof = self.num_dofs = self.num_actuated_dof = 12
         self.num_bodies = 17
         self.dof_names = list(H.DOF_NAMES)
