@@ -138,6 +138,8 @@ typedef struct Go1SimConfig {
   float max_linear_velocity, max_angular_velocity;   /* Cfg.asset.max_*_velocity (1000): magnitude caps on the base twist */
   float joint_limit_margin;        /* rad/s, rad: a joint's limit row enters the solver when its free rate comes within      */
   float joint_limit_pos_margin;    /* joint_limit_margin of +-vmax, or would carry it to within joint_limit_pos_margin of a stop  */
+  int32_t self_collision;          /* 1: lower legs collide with each other and with the trunk (asset self_collisions = 0 in the
+                                      reference means "no pair filtered": enabled, go1_config.py:44, legged_robot.py:1563-1564) */
   int32_t solver_iterations;       /* PGS sweeps per substep */
   int32_t warm_start;              /* start PGS from last substep's impulses */
   int32_t terrain_type;            /* 0 plane, 1 height field */

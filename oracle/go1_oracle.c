@@ -306,73 +306,172 @@ static void terrain_sample(const Terrain* t, real x, real y, real* h, real* n) {
 }
 
 /* ------------------------------------------------------------------ contacts
- * One contact per reported body (17): the deepest candidate point of its collision shape
- * (box corners, capsule end spheres, foot sphere) against the terrain.  Candidate lists follow the
- * URDF collision shapes with replace_cylinder_with_capsule (legged_robot_config.py:232). */
+ * Terrain: every collision shape of the URDF (trunk box, hip capsules [replace_cylinder_with_capsule,
+ * legged_robot_config.py:232], thigh and calf boxes, foot spheres) contributes up to TWO points: its candidate points
+ * (box corners, capsule end spheres, sphere centre) are split into the two ends of the shape's long axis; the deeper end's
+ * deepest point is the first contact, the other end's deepest point the second (a link lying on the ground is supported
+ * along its length; PhysX keeps up to 4 per pair).  A foot sphere has one.
+ * Self-collision (asset self_collisions = 0: enabled, go1_config.py:44): the lower legs (knee -> foot centre, radius of the
+ * foot sphere) against each other and against the trunk's capsule (the box's long axis, radius = its half width):
+ * closest points of the two segments, one contact per pair.
+ * Solver list: at most GO1_MAX_CONTACTS, in the priority order feet, self-contacts, trunk, calves, thighs, hips (first
+ * points before second points); what does not fit is dropped and counted. */
+typedef struct { real phi, x[3], n[3]; int valid; } Cand;
 typedef struct {
-  int active;
-  real x[3];      /* contact point, world, relative to base origin */
+  int repA, repB;   /* reported bodies (0..16) the force is booked on; repB = -1: terrain */
+  int dynA, dynB;   /* dynamic bodies (0..12) carrying the point; dynB = -1: terrain */
+  real x[3];        /* contact point, world axes, relative to the base origin */
   real n[3], t1[3], t2[3];
-  real phi;       /* signed separation */
-  int dyn_body;   /* dynamic body (0..12) carrying the point */
+  real phi;         /* signed separation */
+  real share;       /* part of repA's previous impulse this point starts from (warm start) */
 } Contact;
 
-static void candidate(const Terrain* ter, const Kin* k, const real* base_pos, int dynb, const real* local, real radius,
-                      Contact* best) {
+static void candidate(const Terrain* ter, const Kin* k, const real* base_pos, int dynb, const real* local, real radius, Cand* best) {
   real w[3], x[3];
   m3v(w, k->R[dynb], local);
   v3add(x, k->p[dynb], w);
   real h, n[3];
   terrain_sample(ter, base_pos[0] + x[0], base_pos[1] + x[1], &h, n);
   real phi = (base_pos[2] + x[2]) - radius - h;
-  if (!best->active || phi < best->phi) {
-    best->active = 1;
+  if (!best->valid || phi < best->phi) {
+    best->valid = 1;
     best->phi = phi;
-    best->dyn_body = dynb;
     for (int i = 0; i < 3; i++) best->x[i] = x[i] - radius * n[i];
     v3cpy(best->n, n);
   }
 }
 
-static void detect_contacts(const Go1SimConfig* cfg, const Terrain* ter, const Kin* k, const real* base_pos, Contact* C) {
-  for (int b = 0; b < 17; b++) C[b].active = 0;
-  /* trunk box */
-  for (int m = 0; m < 8; m++) {
+static void contact_frame(Contact* c) {   /* t1 = x axis projected on the tangent plane (y axis if n is along x), t2 = n x t1 */
+  real ex[3] = {1, 0, 0};
+  real d = v3dot(ex, c->n);
+  for (int i = 0; i < 3; i++) c->t1[i] = ex[i] - d * c->n[i];
+  real l2 = v3dot(c->t1, c->t1);
+  if (!(l2 > 1e-12)) {
+    real ey[3] = {0, 1, 0};
+    d = v3dot(ey, c->n);
+    for (int i = 0; i < 3; i++) c->t1[i] = ey[i] - d * c->n[i];
+    l2 = v3dot(c->t1, c->t1);
+    if (!(l2 > 1e-12)) { v3set(c->t1, 0, 1, 0); l2 = 1; }
+  }
+  real l = sqrt(l2);
+  for (int i = 0; i < 3; i++) c->t1[i] /= l;
+  v3cross(c->t2, c->n, c->t1);
+}
+
+/* closest points of the segments p1-q1 and p2-q2 (Ericson, Real-Time Collision Detection 5.1.9) */
+static void seg_seg(const real* p1, const real* q1, const real* p2, const real* q2, real* c1, real* c2) {
+  real d1[3], d2[3], r[3];
+  v3sub(d1, q1, p1); v3sub(d2, q2, p2); v3sub(r, p1, p2);
+  real a = v3dot(d1, d1), e = v3dot(d2, d2), f = v3dot(d2, r), cc = v3dot(d1, r), b = v3dot(d1, d2);
+  real den = a * e - b * b, sN = 0, tN;
+  if (den > 1e-12) { sN = (b * f - cc * e) / den; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN); }
+  tN = (b * sN + f) / e;
+  if (tN < 0) { tN = 0; sN = -cc / a; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN); }
+  else if (tN > 1) { tN = 1; sN = (b - cc) / a; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN); }
+  for (int i = 0; i < 3; i++) { c1[i] = p1[i] + sN * d1[i]; c2[i] = p2[i] + tN * d2[i]; }
+}
+
+#define GO1_MAX_CONTACTS 8
+#define GO1_SELF_LEG_RADIUS GO1_FOOT_RADIUS
+#define GO1_MAX_SELF_LEG_PAIRS 2
+#define GO1_LIMIT_RECOVERY_RATE 10.0   /* rad/s */
+#define GO1_LIMIT_SAFETY 2.0           /* x velocity limit */
+#define GO1_LIMIT_SLACK 0.2            /* rad beyond a stop */
+
+static int add_contact(Contact* list, int n, int* dropped, const Contact* c) {
+  if (n >= GO1_MAX_CONTACTS) { (*dropped)++; return n; }
+  list[n] = *c;
+  contact_frame(&list[n]);
+  return n + 1;
+}
+static int add_terrain(Contact* list, int n, int* dropped, real cd, const Cand* c, int rep, int dyn) {
+  if (!c->valid || !(c->phi < cd)) return n;
+  Contact t;
+  t.repA = rep; t.repB = -1; t.dynA = dyn; t.dynB = -1; t.phi = c->phi; t.share = 1;
+  v3cpy(t.x, c->x); v3cpy(t.n, c->n);
+  return add_contact(list, n, dropped, &t);
+}
+
+/* returns the number of solver contacts; *dropped = active contacts beyond the cap */
+static int detect_contacts(const Go1SimConfig* cfg, const Terrain* ter, const Kin* k, const real* base_pos, Contact* list, int* dropped) {
+  const real cd = cfg->contact_distance;
+  Cand trunk[2], hip[4][2], thigh[4][2], calf[4][2], foot[4];
+  memset(trunk, 0, sizeof trunk); memset(hip, 0, sizeof hip); memset(thigh, 0, sizeof thigh); memset(calf, 0, sizeof calf); memset(foot, 0, sizeof foot);
+  for (int m = 0; m < 8; m++) {       /* trunk box: long axis x -> ends by the sign of x */
     real l[3] = {(m & 1 ? 1 : -1) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1 : -1) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1 : -1) * GO1_TRUNK_BOX_HALF[2]};
-    candidate(ter, k, base_pos, 0, l, 0, &C[0]);
+    candidate(ter, k, base_pos, 0, l, 0, &trunk[m & 1]);
   }
   for (int leg = 0; leg < 4; leg++) {
-    int hipb = 1 + 3 * leg, rep = 1 + 4 * leg;
+    int hipb = 1 + 3 * leg;
     for (int m = 0; m < 2; m++) {
       real l[3] = {GO1_HIP_CAPSULE_CENTER[leg][0], GO1_HIP_CAPSULE_CENTER[leg][1] + (m ? 1 : -1) * GO1_HIP_CAPSULE_HALF, GO1_HIP_CAPSULE_CENTER[leg][2]};
-      candidate(ter, k, base_pos, hipb, l, GO1_HIP_CAPSULE_RADIUS, &C[rep]);
+      candidate(ter, k, base_pos, hipb, l, GO1_HIP_CAPSULE_RADIUS, &hip[leg][m]);
     }
-    for (int m = 0; m < 8; m++) {
+    for (int m = 0; m < 8; m++) {     /* thigh / calf boxes: long axis z -> ends by the sign of z */
       real l[3] = {GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1 : -1) * GO1_THIGH_BOX_HALF[0],
                    GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1 : -1) * GO1_THIGH_BOX_HALF[1],
                    GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1 : -1) * GO1_THIGH_BOX_HALF[2]};
-      candidate(ter, k, base_pos, hipb + 1, l, 0, &C[rep + 1]);
+      candidate(ter, k, base_pos, hipb + 1, l, 0, &thigh[leg][(m >> 2) & 1]);
     }
     for (int m = 0; m < 8; m++) {
       real l[3] = {GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1 : -1) * GO1_CALF_BOX_HALF[0],
                    GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1 : -1) * GO1_CALF_BOX_HALF[1],
                    GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1 : -1) * GO1_CALF_BOX_HALF[2]};
-      candidate(ter, k, base_pos, hipb + 2, l, 0, &C[rep + 2]);
+      candidate(ter, k, base_pos, hipb + 2, l, 0, &calf[leg][(m >> 2) & 1]);
     }
     real fo[3] = {GO1_FOOT_OFFSET[leg][0], GO1_FOOT_OFFSET[leg][1], GO1_FOOT_OFFSET[leg][2]};
-    candidate(ter, k, base_pos, hipb + 2, fo, GO1_FOOT_RADIUS, &C[rep + 3]);
+    candidate(ter, k, base_pos, hipb + 2, fo, GO1_FOOT_RADIUS, &foot[leg]);
   }
-  for (int b = 0; b < 17; b++) {
-    Contact* c = &C[b];
-    c->active = c->active && (c->phi < cfg->contact_distance);
-    if (!c->active) continue;
-    real ex[3] = {1, 0, 0};
-    real d = v3dot(ex, c->n);
-    for (int i = 0; i < 3; i++) c->t1[i] = ex[i] - d * c->n[i];
-    real l = v3norm(c->t1);
-    for (int i = 0; i < 3; i++) c->t1[i] /= l;
-    v3cross(c->t2, c->n, c->t1);
+  int n = 0;
+  *dropped = 0;
+  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &foot[leg], 4 + 4 * leg, 3 * leg + 3);
+  /* self-collision */
+  real P[4][3], Q[4][3], TA[3], TB[3];
+  for (int leg = 0; leg < 4; leg++) {
+    real fo[3] = {GO1_FOOT_OFFSET[leg][0], GO1_FOOT_OFFSET[leg][1], GO1_FOOT_OFFSET[leg][2]}, w[3];
+    v3cpy(P[leg], k->p[3 * leg + 3]);
+    m3v(w, k->R[3 * leg + 3], fo);
+    v3add(Q[leg], P[leg], w);
   }
+  {
+    real a = GO1_TRUNK_BOX_HALF[0] - GO1_TRUNK_BOX_HALF[1], la[3] = {-a, 0, 0}, lb[3] = {a, 0, 0};
+    m3v(TA, k->R[0], la); m3v(TB, k->R[0], lb);
+  }
+  int legpairs = 0;
+  for (int pair = 0; pair < (cfg->self_collision ? 10 : 0); pair++) {
+    static const int PI_[6] = {0, 0, 0, 1, 1, 2}, PJ_[6] = {1, 2, 3, 2, 3, 3};
+    int i = pair < 6 ? PI_[pair] : pair - 6, j = pair < 6 ? PJ_[pair] : -1;
+    real c1[3], c2[3], d[3];
+    real rb = j >= 0 ? GO1_SELF_LEG_RADIUS : GO1_TRUNK_BOX_HALF[1];
+    if (j >= 0) seg_seg(P[i], Q[i], P[j], Q[j], c1, c2); else seg_seg(P[i], Q[i], TA, TB, c1, c2);
+    v3sub(d, c1, c2);
+    real dist = v3norm(d);
+    if (!(dist > 1e-6)) continue;
+    real phi = dist - GO1_SELF_LEG_RADIUS - rb;
+    if (!(phi < cd)) continue;
+    if (j >= 0 && ++legpairs > GO1_MAX_SELF_LEG_PAIRS) { (*dropped)++; continue; }      /* the solver carries two leg-leg contacts */
+    Contact t;
+    t.repA = 1 + 4 * i + 2; t.dynA = 3 * i + 3;
+    t.repB = j >= 0 ? 1 + 4 * j + 2 : 0; t.dynB = j >= 0 ? 3 * j + 3 : 0;
+    t.phi = phi; t.share = 0;
+    for (int q = 0; q < 3; q++) { t.n[q] = d[q] / dist; t.x[q] = c2[q] + t.n[q] * (rb + 0.5 * phi); }
+    n = add_contact(list, n, dropped, &t);
+  }
+  /* remaining shapes: first points, then second points */
+#define FIRST(c) (((c)[1].valid && (!(c)[0].valid || (c)[1].phi < (c)[0].phi)) ? 1 : 0)
+  { int f = FIRST(trunk); n = add_terrain(list, n, dropped, cd, &trunk[f], 0, 0); n = add_terrain(list, n, dropped, cd, &trunk[1 - f], 0, 0); }
+  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &calf[leg][FIRST(calf[leg])], 3 + 4 * leg, 3 * leg + 3);
+  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &calf[leg][1 - FIRST(calf[leg])], 3 + 4 * leg, 3 * leg + 3);
+  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &thigh[leg][FIRST(thigh[leg])], 2 + 4 * leg, 3 * leg + 2);
+  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &thigh[leg][1 - FIRST(thigh[leg])], 2 + 4 * leg, 3 * leg + 2);
+  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &hip[leg][FIRST(hip[leg])], 1 + 4 * leg, 3 * leg + 1);
+  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &hip[leg][1 - FIRST(hip[leg])], 1 + 4 * leg, 3 * leg + 1);
+#undef FIRST
+  /* warm start: a body's previous impulse is shared equally by its listed terrain points */
+  int cnt[17] = {0};
+  for (int c = 0; c < n; c++) if (list[c].repB < 0) cnt[list[c].repA]++;
+  for (int c = 0; c < n; c++) list[c].share = list[c].repB < 0 ? 1.0 / cnt[list[c].repA] : 0;
+  return n;
 }
 
 /* Jacobian row for world direction d at point x (relative to base origin) on dynamic body dynb */
@@ -392,21 +491,12 @@ static void jac_row(const Kin* k, int dynb, const real* x, const real* d, real* 
   }
 }
 
-/* Solver contact list: at most GO1_MAX_CONTACTS of the 17 per-body contacts are handed to the solver, taken in
- * this priority order (feet, trunk, calves, thighs, hips); the PGS sweeps follow the same order. */
-#define GO1_MAX_CONTACTS 6
-#define GO1_LIMIT_RECOVERY_RATE 10.0   /* rad/s */
-#define GO1_LIMIT_SAFETY 2.0           /* x velocity limit */
-#define GO1_LIMIT_SLACK 0.2            /* rad beyond a stop */
-static const int CONTACT_ORDER[17] = {4, 8, 12, 16, 0, 3, 7, 11, 15, 2, 6, 10, 14, 1, 5, 9, 13};
-
 /* ------------------------------------------------------------------ one physics substep (replaces gym.simulate) */
-typedef struct { real force[17][3]; } ContactOut;
+typedef struct { real force[17][3]; int dropped; } ContactOut;
 
 /* wl[b]: world impulse vector (x,y,z) of body b's contact in the previous substep (warm start), updated in place */
 static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s, const real* tau, const real* grav,
                             real wl[17][3], int use_warm, ContactOut* out) {
-  real lam[17][3];
   const real h = (real)cfg->sim_dt;
   Kin k;
   kinematics(s, &k);
@@ -434,16 +524,10 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
   for (int i = 0; i < NV; i++) v[i] = vel[i] + h * acc[i];
 
   /* contacts at the start-of-step configuration */
-  Contact C[17];
-  detect_contacts(cfg, ter, &k, s->pos, C);
-  {
-    int kept = 0;
-    for (int o = 0; o < 17; o++) {
-      Contact* c = &C[CONTACT_ORDER[o]];
-      if (c->active && kept >= GO1_MAX_CONTACTS) c->active = 0;
-      kept += c->active;
-    }
-  }
+  Contact C[GO1_MAX_CONTACTS];
+  int dropped = 0;
+  const int nc = detect_contacts(cfg, ter, &k, s->pos, C, &dropped);
+  if (out) out->dropped = dropped;
   /* Joint limits are solver rows, one per joint (generalised impulse along the joint coordinate: equal and opposite on
    * child and parent, so an actuator pushing against a stop or against the velocity limit cannot create net momentum).
    * Row j constrains the joint rate to [vlo, vhi] = [max((lo-q)/h, -vmax), min((hi-q)/h, vmax)]; it enters the solve when
@@ -471,51 +555,57 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
     chol_solve(L, NV, TJ[j]);
     AJ[j] = TJ[j][6 + j];
   }
-  real J[17][3][NV], T[17][3][NV], A[17][3], vstar[17];
-  real mu = 0.5 * (s->mu + (real)cfg->terrain_friction);        /* PhysX default combine mode: average */
-  real e_c = 0.5 * (s->rest + (real)cfg->terrain_restitution);
-  for (int b = 0; b < 17; b++) {
-    if (!C[b].active) { lam[b][0] = lam[b][1] = lam[b][2] = 0; continue; }
-    const real* dirs[3] = {C[b].n, C[b].t1, C[b].t2};
+  real J[GO1_MAX_CONTACTS][3][NV], T[GO1_MAX_CONTACTS][3][NV], A[GO1_MAX_CONTACTS][3], vstar[GO1_MAX_CONTACTS], cmu[GO1_MAX_CONTACTS];
+  real lamc[GO1_MAX_CONTACTS][3];
+  for (int c = 0; c < nc; c++) {
+    const real* dirs[3] = {C[c].n, C[c].t1, C[c].t2};
     for (int r = 0; r < 3; r++) {
-      jac_row(&k, C[b].dyn_body, C[b].x, dirs[r], J[b][r]);
-      memcpy(T[b][r], J[b][r], sizeof(real) * NV);
-      chol_solve(L, NV, T[b][r]);
+      jac_row(&k, C[c].dynA, C[c].x, dirs[r], J[c][r]);
+      if (C[c].dynB >= 0) {                       /* body-body contact: +d on A, -d on B */
+        real JB[NV];
+        jac_row(&k, C[c].dynB, C[c].x, dirs[r], JB);
+        for (int i = 0; i < NV; i++) J[c][r][i] -= JB[i];
+      }
+      memcpy(T[c][r], J[c][r], sizeof(real) * NV);
+      chol_solve(L, NV, T[c][r]);
       real a = 0;
-      for (int i = 0; i < NV; i++) a += J[b][r][i] * T[b][r][i];
-      A[b][r] = a;
+      for (int i = 0; i < NV; i++) a += J[c][r][i] * T[c][r][i];
+      A[c][r] = a;
     }
-    real vs = -C[b].phi / h;
+    /* PhysX default combine mode: average of the two materials (robot-robot: the robot's own) */
+    const int self = C[c].repB >= 0;
+    cmu[c] = self ? s->mu : 0.5 * (s->mu + (real)cfg->terrain_friction);
+    const real e_c = self ? s->rest : 0.5 * (s->rest + (real)cfg->terrain_restitution);
+    real vs = -C[c].phi / h;
     if (vs > cfg->max_depenetration_velocity) vs = cfg->max_depenetration_velocity;
     real un_pre = 0;
-    for (int i = 0; i < NV; i++) un_pre += J[b][0][i] * vel[i];
+    for (int i = 0; i < NV; i++) un_pre += J[c][0][i] * vel[i];
     if (un_pre < -(real)cfg->bounce_threshold_velocity && -e_c * un_pre > vs) vs = -e_c * un_pre;
-    vstar[b] = vs;
-    lam[b][0] = use_warm ? v3dot(wl[b], C[b].n) : 0;      /* project last substep's impulse on the current contact frame */
-    lam[b][1] = use_warm ? v3dot(wl[b], C[b].t1) : 0;
-    lam[b][2] = use_warm ? v3dot(wl[b], C[b].t2) : 0;
+    vstar[c] = vs;
+    /* the body's last impulse, shared by its listed points and projected on the current contact frame */
+    const real* w = wl[C[c].repA];
+    const real sh = use_warm ? C[c].share : 0;
+    lamc[c][0] = sh * v3dot(w, C[c].n); lamc[c][1] = sh * v3dot(w, C[c].t1); lamc[c][2] = sh * v3dot(w, C[c].t2);
     for (int r = 0; r < 3; r++)
-      for (int i = 0; i < NV; i++) v[i] += T[b][r][i] * lam[b][r];
+      for (int i = 0; i < NV; i++) v[i] += T[c][r][i] * lamc[c][r];
   }
   for (int it = 0; it < cfg->solver_iterations; it++) {
-    for (int o = 0; o < 17; o++) {
-      const int b = CONTACT_ORDER[o];
-      if (!C[b].active) continue;
+    for (int c = 0; c < nc; c++) {
       real un = 0;
-      for (int i = 0; i < NV; i++) un += J[b][0][i] * v[i];
-      real ln = lam[b][0] - (un - vstar[b]) / A[b][0];
+      for (int i = 0; i < NV; i++) un += J[c][0][i] * v[i];
+      real ln = lamc[c][0] - (un - vstar[c]) / A[c][0];
       if (ln < 0) ln = 0;
-      real dl = ln - lam[b][0];
-      lam[b][0] = ln;
-      for (int i = 0; i < NV; i++) v[i] += T[b][0][i] * dl;
+      real dl = ln - lamc[c][0];
+      lamc[c][0] = ln;
+      for (int i = 0; i < NV; i++) v[i] += T[c][0][i] * dl;
       real u1 = 0, u2 = 0;
-      for (int i = 0; i < NV; i++) { u1 += J[b][1][i] * v[i]; u2 += J[b][2][i] * v[i]; }
-      real l1 = lam[b][1] - u1 / A[b][1], l2 = lam[b][2] - u2 / A[b][2];
-      real lim = mu * ln, nrm = sqrt(l1 * l1 + l2 * l2);
+      for (int i = 0; i < NV; i++) { u1 += J[c][1][i] * v[i]; u2 += J[c][2][i] * v[i]; }
+      real l1 = lamc[c][1] - u1 / A[c][1], l2 = lamc[c][2] - u2 / A[c][2];
+      real lim = cmu[c] * ln, nrm = sqrt(l1 * l1 + l2 * l2);
       if (nrm > lim) { real sc = (nrm > 0) ? lim / nrm : 0; l1 *= sc; l2 *= sc; }
-      real d1 = l1 - lam[b][1], d2 = l2 - lam[b][2];
-      lam[b][1] = l1; lam[b][2] = l2;
-      for (int i = 0; i < NV; i++) v[i] += T[b][1][i] * d1 + T[b][2][i] * d2;
+      real d1 = l1 - lamc[c][1], d2 = l2 - lamc[c][2];
+      lamc[c][1] = l1; lamc[c][2] = l2;
+      for (int i = 0; i < NV; i++) v[i] += T[c][1][i] * d1 + T[c][2][i] * d2;
     }
     /* joint rows, plain Gauss-Seidel in joint order.  (Running the four legs side by side — block Jacobi — was tried and
      * does NOT converge: with the robot in the air the legs couple strongly through the light base.) */
@@ -529,12 +619,15 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
       for (int i = 0; i < NV; i++) v[i] += TJ[j][i] * dl;
     }
   }
-  for (int b = 0; b < 17; b++) {
+  for (int b = 0; b < 17; b++) v3set(wl[b], 0, 0, 0);
+  for (int c = 0; c < nc; c++)
     for (int i = 0; i < 3; i++) {
-      wl[b][i] = C[b].active ? (C[b].n[i] * lam[b][0] + C[b].t1[i] * lam[b][1] + C[b].t2[i] * lam[b][2]) : 0;
-      out->force[b][i] = wl[b][i] / h;
+      real f = C[c].n[i] * lamc[c][0] + C[c].t1[i] * lamc[c][1] + C[c].t2[i] * lamc[c][2];
+      wl[C[c].repA][i] += f;
+      if (C[c].repB >= 0) wl[C[c].repB][i] -= f;
     }
-  }
+  for (int b = 0; b < 17; b++)
+    for (int i = 0; i < 3; i++) out->force[b][i] = wl[b][i] / h;
   /* The limit rows leave at most the solver's residual; it is NOT clamped away (a clamp on the joint coordinate alone is
    * an unbalanced impulse: it breaks momentum conservation, which a learning policy turns into free thrust).  Only a
    * solver failure far outside the admissible band is cut, at GO1_LIMIT_SAFETY x the limit. */

@@ -283,3 +283,92 @@ def test_sliding_contacts_sit_on_the_friction_cone(oracle_lib):
     ratio = (ft / (mu * cf[:, 2]))[sliding]
     np.testing.assert_allclose(ratio.numpy(), 1.0, rtol=1e-3)
     assert bool(((cf[:, 0] * fv[:, 0] + cf[:, 1] * fv[:, 1])[sliding] < 0).all())
+
+
+def _lower_leg_segments(md, root, q):
+    """knee and foot-centre positions (world) of the four legs, from independent numpy kinematics"""
+    R0 = quat_R(root[3:7])
+    out = []
+    for leg in range(4):
+        R, p = R0, root[0:3].copy()
+        for j in range(3):
+            ji = 3 * leg + j
+            p = p + R @ md["GO1_JOINT_ORIGIN"][ji]
+            c, s_ = np.cos(q[ji]), np.sin(q[ji])
+            Rj = np.array([[1, 0, 0], [0, c, -s_], [0, s_, c]]) if md["GO1_JOINT_AXIS"][ji] == 0 else np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]])
+            R = R @ Rj
+        out.append((p, p + R @ md["GO1_FOOT_OFFSET"][leg]))
+    return out
+
+
+def _seg_dist(a0, a1, b0, b1, n=60):
+    t = np.linspace(0, 1, n)
+    A = a0[None] + t[:, None] * (a1 - a0)[None]
+    Bp = b0[None] + t[:, None] * (b1 - b0)[None]
+    return np.sqrt(((A[:, None, :] - Bp[None, :, :]) ** 2).sum(-1)).min()
+
+
+def test_robot_on_its_side_rests_on_several_points(oracle_lib):
+    """Contact manifolds: dropped on its side with limp actuators the robot comes to rest on hips / thighs / calves / trunk
+    edge (two points per link end), the contact forces carry its weight, nothing sinks in, and it stays at rest."""
+    N = 4
+    cfg, S, meta, B = make_sim("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
+    standing_state(S, B, z=0.16)
+    half = np.sqrt(0.5)
+    B.root_states[3] = torch.tensor([half, -half, half * 0.98, 0.3])          # rolled +-90 deg (two not exactly)
+    B.root_states[4] = torch.tensor([0.0, 0.0, 0.0, 0.9])
+    B.root_states[6] = torch.tensor([half, half, half * 0.98, 0.3])
+    nq = B.root_states[3:7].norm(dim=0)
+    B.root_states[3:7] /= nq
+    B.payloads[:] = torch.tensor([0.0, 1.0, 2.0, -0.5])
+    orc = oracle_lib.Oracle(S, B)
+    B.torques.zero_()
+    for it in range(1600):                     # 8 s
+        orc.physics_substep()
+    assert torch.isfinite(B.root_states).all()
+    # At rest a period-2 chatter remains (known limitation, DESIGN.md): contact rows and limit rows both correct their
+    # position error at full rate within one substep and alternate.  Bounded (< 0.3 rad/s, 0.05 degrees), zero mean:
+    va, vsum, cfs = B.root_states[7:13].clone(), torch.zeros(6, N), torch.zeros(51, N)
+    for it in range(16):
+        orc.physics_substep()
+        vsum += B.root_states[7:13]
+        cfs += B.contact_forces
+    vmean, cf = vsum / 16, (cfs / 16).view(17, 3, N)
+    assert float(vmean[:, :3].abs().max()) < 0.06 and float(vmean.abs().max()) < 0.2 and float(va.abs().max()) < 0.4 and float(B.dof_vel.abs().max()) < 1.0
+    weight = (11.309932 + B.payloads) * 9.8
+    np.testing.assert_allclose(cf[:, 2].sum(0).numpy(), weight.numpy(), rtol=0.02)
+    assert float(cf[:, :2].sum(0).abs().max()) < 0.05 * float(weight.max())       # no net horizontal force at rest
+    assert int((cf.norm(dim=1) > 0.5).sum(0).min()) >= 3                           # at least three bodies carry load
+    z0 = B.root_states[2].clone()
+    for it in range(200):
+        orc.physics_substep()
+    assert float((B.root_states[2, :3] - z0[:3]).abs().max()) < 1e-3                # it stays there (env 3, dropped askew, is still settling)
+
+
+def test_self_collision_keeps_the_lower_legs_apart(oracle_lib):
+    """Self-collision (asset self_collisions = 0: enabled): in free flight the hips are driven so that the left and right
+    lower legs swing into each other; the capsules (radius of the foot sphere) do not interpenetrate and the contact
+    forces on the two calves are equal and opposite."""
+    N = 2
+    cfg, S, meta, B = make_sim("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
+    S.gravity[0] = S.gravity[1] = S.gravity[2] = 0.0
+    standing_state(S, B, z=3.0)
+    md = model()
+    orc = oracle_lib.Oracle(S, B)
+    B.torques.zero_()
+    B.torques[0] = torch.tensor([-1.0, 1.0])         # FL hip (gentle: discrete detection, a 4 cm capsule must not move
+    B.torques[3] = torch.tensor([1.0, -1.0])         # FR hip   through the other within one 5 ms substep)
+    B.torques[6] = torch.tensor([-1.0, 1.0])         # env 0 swings the left and right legs together, env 1 apart
+    B.torques[9] = torch.tensor([1.0, -1.0])
+    min_d, seen = 1e9, 0.0
+    for it in range(300):
+        orc.physics_substep()
+        segs = _lower_leg_segments(md, B.root_states[:, 0].double().numpy(), B.dof_pos[:, 0].double().numpy())
+        min_d = min(min_d, _seg_dist(*segs[0], *segs[1]), _seg_dist(*segs[2], *segs[3]))
+        cf = B.contact_forces.view(17, 3, N)[:, :, 0]
+        if float(cf[3].norm()) > 1.0:
+            seen = max(seen, float(cf[3].norm()))
+            torch.testing.assert_close(cf[3], -cf[7], rtol=1e-6, atol=1e-6)       # FL calf vs FR calf
+    assert seen > 5.0, "the front legs never touched"
+    assert min_d > 2 * 0.02 - 0.012, min_d                                         # capsule radius 0.02 each, contact_offset scale
+    assert float(B.contact_forces.view(17, 3, N)[:, :, 1].abs().max()) == 0.0      # legs swung apart: no contact at all

@@ -21,11 +21,11 @@
 
 #define WAVE 64
 #define EPW 16                       // environments per wavefront
-#define MAXC 6                       // solver contacts per env (oracle: GO1_MAX_CONTACTS)
+#define MAXC 8                       // solver contacts per env (oracle: GO1_MAX_CONTACTS)
 #define NRC (3 * MAXC)               // contact rows: contact k -> rows 3k (normal), 3k+1, 3k+2 (tangents)
 #define NRJ 12                       // joint-limit rows: joint j -> row NRC + j
-#define NRT 32                       // row capacity (NRC + NRJ = 30 in use)
-#define NCC (NRT / 4)                // Delassus columns per lane: lane `leg` owns the columns c = leg + 4 cc
+#define NRT 36                       // rows: NRC + NRJ
+#define NCC (NRT / 4)                // Delassus columns per lane (9): lane `leg` owns the columns c = leg + 4 cc
 #define GO1_LIMIT_RECOVERY_RATE 10.0f   // rad/s: a joint found beyond a stop is brought back at a bounded rate
 #define GO1_LIMIT_SAFETY 2.0f           // x velocity limit: beyond this the limit rows have failed (cut + fault count)
 #define GO1_LIMIT_SLACK 0.2f            // rad beyond a stop: same
@@ -34,7 +34,8 @@
 enum {
   L_LAM = 0,                 // 17 x world impulse (x, y, z) per reported body: solver output / warm start
   L_CX = 51,                 // MAXC x 3 contact points (rel. base origin)
-  L_RB = L_CX + 3 * MAXC,    // NRC   contact rows: b = J v_free
+  L_CN = L_CX + 3 * MAXC,    // MAXC x 3 contact normals
+  L_RB = L_CN + 3 * MAXC,    // NRC   contact rows: b = J v_free
   L_RP = L_RB + NRC,         // NRC   normal rows: target velocity v*; tangent rows: W[t][n]
   L_RI = L_RP + NRC,         // NRC   1 / W[r][r]
   L_LS = L_RI + NRC,         // NRC   contact impulses: start values in, solution out
@@ -46,14 +47,16 @@ enum {
 //   row functional RF: [0..5] g_r (the row's unit impulse propagated to the base), [6..8] u_j(r) along the row's leg,
 //                      [9..11] u_j(r) / D_j, [12] leg of the row (4 = trunk)
 //   limit row      JR: [0] b = free joint rate, [1] lower, [2] upper rate bound, [3] W[r][r], [4] 1 / W[r][r] (0: not in the solve)
-//   Delassus row   W : the row's NRT entries in the order [owner lane c & 3][slot c >> 2] (lane `leg` reads its 8 contiguous
-//                      floats), rows padded to WST floats (spreads the environments over the banks)
+//   Delassus row   W : the row's NRT entries; lane `leg` owns columns c = leg + 4 cc: slots cc = 0..7 are its 8 contiguous
+//                      floats at [8 leg], slot cc = 8 sits at [32 + leg]
 #define RF_ST 16
 #define RF(r) (rfl + ((r) * EPW + el) * RF_ST)
 #define JR_ST 8
 #define JR(j) (jrl + ((j) * EPW + el) * JR_ST)
 #define WST 36
 #define WROW(r) (ldsw + ((r) * EPW + el) * WST)
+#define WSH4(r, hf) (reinterpret_cast<lf4*>(WROW(r) + 8 * leg)[hf])       // the lane's column slots 4 hf .. 4 hf + 3 of row r
+#define WSH8(r) (WROW(r)[32 + leg])                                        // the lane's column slot 8 of row r
 #define LDSW_SIZE (NRT * EPW * WST)
 #define LDSX_SIZE (NRT * EPW * RF_ST + NRJ * EPW * JR_ST)       // RF records, then JR records
 typedef __attribute__((ext_vector_type(4))) float lf4;
@@ -106,7 +109,8 @@ DEV void actuator_net3(const float in[3][6], float out[3]) {
 // Only used by full wavefronts (all 64 lanes alive): a partial last workgroup takes actuator_net3.
 typedef __attribute__((ext_vector_type(8))) _Float16 act_f16x8;
 typedef __attribute__((ext_vector_type(4))) float act_f32x4;
-enum { A_IN = 0, A_OUT = 192 * 8, A_W0 = A_OUT + 4 * 192, A_B1 = A_W0 + 32 * 8, A_W2 = A_B1 + 32, A_WF = A_W2 + 32, A_END = A_WF + 4 * 64 * 4 };
+enum { A_IN = 0, A_OUT = 192 * 8, A_IO_END = A_OUT + 4 * 192 };      // transient rows in / partial sums out: overlaid on the solver's matrix
+enum { A_W0 = 0, A_B1 = A_W0 + 32 * 8, A_W2 = A_B1 + 32, A_WF = A_W2 + 32, A_END = A_WF + 4 * 64 * 4 };      // constants of the launch
 
 DEV void actuator_lds_init(float* a, int lane) {          // once per launch, all 64 lanes
   for (int i = lane; i < 32 * 8; i += WAVE) {
@@ -130,11 +134,11 @@ DEV void actuator_lds_init(float* a, int lane) {          // once per launch, al
   }
 }
 
-DEV void actuator_net_mfma(float* a, int lane, const float in[3][6], float out[3]) {
+DEV void actuator_net_mfma(float* a, float* io, int lane, const float in[3][6], float out[3]) {
   typedef __attribute__((ext_vector_type(4))) float f4;
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) {
-    f4* p = reinterpret_cast<f4*>(a + A_IN + (3 * lane + jj) * 8);
+    f4* p = reinterpret_cast<f4*>(io + A_IN + (3 * lane + jj) * 8);
     p[0] = (f4){in[jj][0], in[jj][1], in[jj][2], in[jj][3]};
     p[1] = (f4){in[jj][4], in[jj][5], 1.f, 0.f};
   }
@@ -159,7 +163,7 @@ DEV void actuator_net_mfma(float* a, int lane, const float in[3][6], float out[3
   }
 #pragma unroll 2
   for (int t = 0; t < 12; t++) {
-    const f4* pin = reinterpret_cast<const f4*>(a + A_IN + (16 * t + c) * 8);
+    const f4* pin = reinterpret_cast<const f4*>(io + A_IN + (16 * t + c) * 8);
     const f4 x0 = pin[0], x1 = pin[1];
     act_f16x8 bhi, blo;
 #pragma unroll
@@ -182,13 +186,13 @@ DEV void actuator_net_mfma(float* a, int lane, const float in[3][6], float out[3
 #pragma unroll
       for (int q = 0; q < 4; q++) part = fmaf(w2v[4 * i + q], softsign(acc[q] + b1v[4 * i + q]), part);
     }
-    a[A_OUT + 192 * g + 16 * t + c] = part;      // the 4 lanes (g = 0..3) holding the same row: partials meet in LDS
+    io[A_OUT + 192 * g + 16 * t + c] = part;      // the 4 lanes (g = 0..3) holding the same row: partials meet in LDS
   }
   __syncthreads();
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) {
     const int r = 3 * lane + jj;
-    out[jj] = ((a[A_OUT + r] + a[A_OUT + 192 + r]) + (a[A_OUT + 384 + r] + a[A_OUT + 576 + r])) + GO1_ACT_B2;
+    out[jj] = ((io[A_OUT + r] + io[A_OUT + 192 + r]) + (io[A_OUT + 384 + r] + io[A_OUT + 576 + r])) + GO1_ACT_B2;
   }
 }
 
@@ -196,7 +200,7 @@ struct Leg {             // the calling lane's leg
   float q[3], qd[3], tau[3];
 };
 
-DEV void compute_torques(CfgRef cfg, BufRef B, Leg& L, int leg, int e, int N, int head, float* act_lds, bool full_wave, uint32_t& fault) {
+DEV void compute_torques(CfgRef cfg, BufRef B, Leg& L, int leg, int e, int N, int head, float* act_lds, float* act_io, bool full_wave, uint32_t& fault) {
   const int nl = cfg.lag_timesteps + 1;
   const int h2 = (head + 1) % nl;
   float in[3][6], tq[3], tgt[3];
@@ -228,7 +232,7 @@ DEV void compute_torques(CfgRef cfg, BufRef B, Leg& L, int leg, int e, int N, in
       AT(B.joint_vel_last_last, j, e) = vl;
       AT(B.joint_vel_last, j, e) = L.qd[jj];
     }
-    if (full_wave) actuator_net_mfma(act_lds, (int)threadIdx.x, in, tq);      // wave-uniform choice
+    if (full_wave) actuator_net_mfma(act_lds, act_io, (int)threadIdx.x, in, tq);      // wave-uniform choice
     else actuator_net3(in, tq);
   } else {
 #pragma unroll
@@ -362,22 +366,24 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     V3 fg = s.mass0 * grav;
     pA0 = cross_force(v0, hv) - sv(cross(c, fg), fg);
   }
-  // trunk box: two corners per lane, quad-wide minimum
-  Cand cbase;
-  cand_init(cbase);
+  // Contact candidates: every collision shape contributes up to TWO points — its candidate points are split into the two
+  // ends of the shape's long axis, the deeper end's deepest point is the first contact, the other end's deepest the second
+  // (oracle detect_contacts()).  Trunk box (long axis x): each lane has one corner of either end, quad-wide minimum.
+  Cand cb[2];
 #pragma unroll
   for (int mm = 0; mm < 2; mm++) {
-    const int m = 2 * leg + mm;
+    cand_init(cb[mm]);
+    const int m = 2 * leg + mm;            // m & 1 = mm: the end
     V3 l = v3((m & 1 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[2]);
-    cand_try(cfg, hs, cbase, mul(R0, l), s.pos, 0.f, v0);
+    cand_try(cfg, hs, cb[mm], mul(R0, l), s.pos, 0.f, v0);
+    cand_min_dpp(cb[mm], lane);
   }
-  cand_min_dpp(cbase, lane);
 
   // ---- own leg: kinematics, contact candidates, ABA passes 1+2 ---------------------------------------
   SV S[3], U[3];
   float Dinv[3], uu[3];
   SV cj[3];
-  Cand cand[4];            // hip, thigh, calf, foot of this leg
+  Cand ch[2], ct[2], ck[2], cf;      // hip, thigh, calf: one candidate per end; foot
   {
     M3 R[3];
     V3 p[3];
@@ -411,31 +417,35 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       Rpar = R[j]; ppar = p[j]; vpar = v[j];
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) cand_init(cand[i]);
+    for (int i = 0; i < 2; i++) { cand_init(ch[i]); cand_init(ct[i]); cand_init(ck[i]); }
+    cand_init(cf);
     {
       V3 hc = model_v3(GO1_HIP_CAPSULE_CENTER, leg);
 #pragma unroll
       for (int m = 0; m < 2; m++) {
         V3 l = v3(hc.x, hc.y + (m ? 1.f : -1.f) * (float)GO1_HIP_CAPSULE_HALF, hc.z);
-        cand_try(cfg, hs, cand[0], p[0] + mul(R[0], l), s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0]);
+        cand_try(cfg, hs, ch[m], p[0] + mul(R[0], l), s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0]);
       }
 #ifndef GO1_ABLATE_CAND
+#pragma unroll
+      for (int en = 0; en < 2; en++) {       // thigh / calf boxes: long axis z -> ends by the sign of z (corner bit 2)
 #pragma unroll 1
-      for (int m = 0; m < 8; m++) {
-        V3 l = v3(GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[0],
-                  GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[1],
-                  GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[2]);
-        cand_try(cfg, hs, cand[1], p[1] + mul(R[1], l), s.pos, 0.f, v[1]);
-      }
+        for (int m = 4 * en; m < 4 * en + 4; m++) {
+          V3 l = v3(GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[0],
+                    GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[1],
+                    GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[2]);
+          cand_try(cfg, hs, ct[en], p[1] + mul(R[1], l), s.pos, 0.f, v[1]);
+        }
 #pragma unroll 1
-      for (int m = 0; m < 8; m++) {
-        V3 l = v3(GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[0],
-                  GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[1],
-                  GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[2]);
-        cand_try(cfg, hs, cand[2], p[2] + mul(R[2], l), s.pos, 0.f, v[2]);
+        for (int m = 4 * en; m < 4 * en + 4; m++) {
+          V3 l = v3(GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[0],
+                    GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[1],
+                    GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[2]);
+          cand_try(cfg, hs, ck[en], p[2] + mul(R[2], l), s.pos, 0.f, v[2]);
+        }
       }
 #endif
-      cand_try(cfg, hs, cand[3], p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2]);
+      cand_try(cfg, hs, cf, p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2]);
     }
     // ABA pass 2: calf -> thigh -> hip, then quad-sum into the base
     SV pa_hip;
@@ -476,50 +486,50 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     }
   }
 
-  // ---- solver contact list: priority feet, trunk, calves, thighs, hips; at most MAXC -----------------
+  // ---- solver contact list (oracle detect_contacts()): feet, trunk (first, second point), calves (first points, second
+  // points), thighs, hips; at most MAXC, the rest is dropped and counted -------------------------------------------------
   const float cd = cfg.contact_distance;
-  const bool act_h = cand[0].phi < cd, act_t = cand[1].phi < cd, act_c = cand[2].phi < cd, act_f = cand[3].phi < cd;
-  const bool act_b = cbase.phi < cd;
+  // own items in priority order: 0 foot, 1 calf first, 2 calf second, 3 thigh first, 4 thigh second, 5 hip first, 6 hip second
+  const int fk = ck[1].phi < ck[0].phi ? 1 : 0, ft = ct[1].phi < ct[0].phi ? 1 : 0, fh = ch[1].phi < ch[0].phi ? 1 : 0;
+  const int fb = cb[1].phi < cb[0].phi ? 1 : 0;
+  Cand item[7];
+  item[0] = cf;
+  item[1] = fk ? ck[1] : ck[0]; item[2] = fk ? ck[0] : ck[1];
+  item[3] = ft ? ct[1] : ct[0]; item[4] = ft ? ct[0] : ct[1];
+  item[5] = fh ? ch[1] : ch[0]; item[6] = fh ? ch[0] : ch[1];
+  const Cand tb0 = fb ? cb[1] : cb[0], tb1 = fb ? cb[0] : cb[1];
+  const bool act_b0 = tb0.phi < cd, act_b1 = tb1.phi < cd;
   const unsigned below = (1u << leg) - 1u;
-  const unsigned mf = quad_ballot(act_f, lane), mc = quad_ballot(act_c, lane), mt = quad_ballot(act_t, lane), mh = quad_ballot(act_h, lane);
-  const int nf = __popc(mf), nb = act_b ? 1 : 0, nc = __popc(mc), nt = __popc(mt), nh = __popc(mh);
-  int slot[4];             // own hip, thigh, calf, foot -> solver slot or -1
-  slot[3] = act_f ? __popc(mf & below) : -1;
-  const int slot_base = act_b ? nf : -1;
-  slot[2] = act_c ? nf + nb + __popc(mc & below) : -1;
-  slot[1] = act_t ? nf + nb + nc + __popc(mt & below) : -1;
-  slot[0] = act_h ? nf + nb + nc + nt + __popc(mh & below) : -1;
-#pragma unroll
-  for (int i = 0; i < 4; i++) if (slot[i] >= MAXC) slot[i] = -1;
-  const int sbase = (slot_base >= 0 && slot_base < MAXC) ? slot_base : -1;
-  int K = nf + nb + nc + nt + nh;
-  if (K > MAXC && leg == 0) fault |= 1u << GO1_FAULT_CONTACT_DROPPED;
-  K = K > MAXC ? MAXC : K;
-  const float e_c = 0.5f * (s.rest + cfg.terrain_restitution);
-
-  // contact frames of the own candidates and of the trunk candidate: once per substep
-  V3 fn[4], ft1[4], ft2[4], bn, bt1, bt2;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    fn[i] = v3(cand[i].nx, cand[i].ny, cand[i].nz);
-    contact_frame(fn[i], ft1[i], ft2[i], fault);
-  }
-  bn = v3(cbase.nx, cbase.ny, cbase.nz);
-  contact_frame(bn, bt1, bt2, fault);
-  // impulses: listed bodies start from the warm value or zero, all others are dropped
-  float lam0[4][3], lamb[3];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int b = 1 + 4 * leg + i;
-    V3 wl = v3(LDS(L_LAM + 3 * b), LDS(L_LAM + 3 * b + 1), LDS(L_LAM + 3 * b + 2));
-    const bool w = slot[i] >= 0 && use_warm;
-    lam0[i][0] = w ? dot(wl, fn[i]) : 0.f; lam0[i][1] = w ? dot(wl, ft1[i]) : 0.f; lam0[i][2] = w ? dot(wl, ft2[i]) : 0.f;
-  }
+  int slot[7], slot_b0, slot_b1;
+  int K;
   {
-    V3 wl = v3(LDS(L_LAM), LDS(L_LAM + 1), LDS(L_LAM + 2));
-    const bool w = sbase >= 0 && use_warm;
-    lamb[0] = w ? dot(wl, bn) : 0.f; lamb[1] = w ? dot(wl, bt1) : 0.f; lamb[2] = w ? dot(wl, bt2) : 0.f;
+    int base_ofs = 0;
+    unsigned m0 = quad_ballot(item[0].phi < cd, lane);
+    slot[0] = (item[0].phi < cd) ? __popc(m0 & below) : -1;
+    base_ofs += __popc(m0);
+    // (self-contacts take their slots here)
+    const int ofs_b0 = base_ofs;
+    base_ofs += (act_b0 ? 1 : 0) + (act_b1 ? 1 : 0);
+#pragma unroll
+    for (int i = 1; i < 7; i++) {
+      const bool a = item[i].phi < cd;
+      const unsigned m = quad_ballot(a, lane);
+      slot[i] = a ? base_ofs + __popc(m & below) : -1;
+      base_ofs += __popc(m);
+    }
+    K = base_ofs;
+    if (K > MAXC && leg == 0) fault |= 1u << GO1_FAULT_CONTACT_DROPPED;
+    K = K > MAXC ? MAXC : K;
+#pragma unroll
+    for (int i = 0; i < 7; i++) if (slot[i] >= MAXC) slot[i] = -1;
+    // trunk slots (handled by lane 0, known to all)
+    slot_b0 = act_b0 && ofs_b0 < MAXC ? ofs_b0 : -1;
+    slot_b1 = act_b1 && ofs_b0 + (act_b0 ? 1 : 0) < MAXC ? ofs_b0 + (act_b0 ? 1 : 0) : -1;
   }
+  const float e_c = 0.5f * (s.rest + cfg.terrain_restitution);
+  // warm start: a body's previous impulse is shared equally by its listed points
+  const float share_k = (slot[1] >= 0 && slot[2] >= 0) ? 0.5f : 1.f, share_t = (slot[3] >= 0 && slot[4] >= 0) ? 0.5f : 1.f,
+              share_h = (slot[5] >= 0 && slot[6] >= 0) ? 0.5f : 1.f, share_b = (slot_b0 >= 0 && slot_b1 >= 0) ? 0.5f : 1.f;
 
   // ---- joint-limit rows of the own leg ------------------------------------------------------------------
   // A joint's position / velocity limits are ONE solver row: a generalised impulse along the joint coordinate (equal and
@@ -546,97 +556,69 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   }
   const unsigned lact = quad_ballot(legact, lane);      // legs of this environment whose limit rows are in the solve
 
-  // publish own rows: contact point, target normal velocity, b = J v_free, start impulse
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    if (slot[i] >= 0) {
-      const int k = slot[i];
-      const int depth = i > 2 ? 2 : i;
-      const Cand& c = cand[i];
-      LDS(L_CX + 3 * k) = c.x; LDS(L_CX + 3 * k + 1) = c.y; LDS(L_CX + 3 * k + 2) = c.z;
-      float vs = fminf(-c.phi / h, cfg.max_depenetration_velocity);
-      if (c.un < -cfg.bounce_threshold_velocity && -e_c * c.un > vs) vs = -e_c * c.un;
-      LDS(L_RP + 3 * k) = vs;
-      SV vb = sv(w_free, v_free);
-#pragma unroll
-      for (int j = 0; j < 3; j++)
-        if (j <= depth) vb = vb + qd_free[j] * S[j];
-      V3 xk = v3(c.x, c.y, c.z);
-      V3 vp = vb.l + cross(vb.a, xk);
-      LDS(L_RB + 3 * k) = dot(fn[i], vp); LDS(L_RB + 3 * k + 1) = dot(ft1[i], vp); LDS(L_RB + 3 * k + 2) = dot(ft2[i], vp);
-      LDS(L_LS + 3 * k) = lam0[i][0]; LDS(L_LS + 3 * k + 1) = lam0[i][1]; LDS(L_LS + 3 * k + 2) = lam0[i][2];
-    }
-  }
-  if (sbase >= 0 && leg == 0) {
-    const int k = sbase;
-    LDS(L_CX + 3 * k) = cbase.x; LDS(L_CX + 3 * k + 1) = cbase.y; LDS(L_CX + 3 * k + 2) = cbase.z;
-    float vs = fminf(-cbase.phi / h, cfg.max_depenetration_velocity);
-    if (cbase.un < -cfg.bounce_threshold_velocity && -e_c * cbase.un > vs) vs = -e_c * cbase.un;
-    LDS(L_RP + 3 * k) = vs;
-    V3 xk = v3(cbase.x, cbase.y, cbase.z);
-    V3 vp = v_free + cross(w_free, xk);
-    LDS(L_RB + 3 * k) = dot(bn, vp); LDS(L_RB + 3 * k + 1) = dot(bt1, vp); LDS(L_RB + 3 * k + 2) = dot(bt2, vp);
-    LDS(L_LS + 3 * k) = lamb[0]; LDS(L_LS + 3 * k + 1) = lamb[1]; LDS(L_LS + 3 * k + 2) = lamb[2];
-  }
-  if (legact) {
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      float* jr = JR(3 * leg + j);
-      jr[0] = qd_free[j]; jr[1] = jlo[j]; jr[2] = jhi[j];
-    }
-  }
-
-  __syncthreads();      // one-wave workgroup: orders this wave's LDS traffic between phases
-  PROF(3);
-  // ---- row functionals: every row's unit impulse propagated through the ABA factors to the base ---------------
-  // For a unit impulse along row c the backward ABA pass along the row's leg leaves g_c, the wrench arriving at the base,
-  // and the joint residuals u_j(c).  By reciprocity the same vectors are the row functionals, so
+  // publish the listed contacts: point, normal, target normal velocity, b = J v_free, start impulse — and the row
+  // functionals: each row's unit impulse propagated through the ABA factors of the contact's leg to the base.
+  // For a unit impulse along row c the backward ABA pass leaves g_c, the wrench arriving at the base, and the joint
+  // residuals u_j(c).  By reciprocity the same vectors are the row functionals, so
   //     W[r][c] = g_r . (I0^-1 g_c)  +  [same leg] sum_j u_j(r) u_j(c) / D_j
   // (legs couple only through the base).  A contact row starts from the spatial force of the unit impulse at the contact
   // point, a joint row from the unit generalised impulse at its joint.
+  auto emit = [&](int k, const Cand& c, int depth, int body, float share) {      // depth < 0: trunk
+    const V3 n = v3(c.nx, c.ny, c.nz);
+    V3 t1, t2;
+    contact_frame(n, t1, t2, fault);
+    const V3 x = v3(c.x, c.y, c.z);
+    LDS(L_CX + 3 * k) = c.x; LDS(L_CX + 3 * k + 1) = c.y; LDS(L_CX + 3 * k + 2) = c.z;
+    LDS(L_CN + 3 * k) = c.nx; LDS(L_CN + 3 * k + 1) = c.ny; LDS(L_CN + 3 * k + 2) = c.nz;
+    float vs = fminf(-c.phi / h, cfg.max_depenetration_velocity);
+    if (c.un < -cfg.bounce_threshold_velocity && -e_c * c.un > vs) vs = -e_c * c.un;
+    LDS(L_RP + 3 * k) = vs;
+    SV vb = sv(w_free, v_free);
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    if (slot[i] >= 0) {
-      const int k = slot[i];
-      const int depth = i > 2 ? 2 : i;
-      const V3 x = v3(cand[i].x, cand[i].y, cand[i].z);
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const V3 d = r == 0 ? fn[i] : r == 1 ? ft1[i] : ft2[i];
-        SV pA = -sv(cross(x, d), d);
-        float uj[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 2; j >= 0; j--) {
-          if (j <= depth) {
-            const float u = -dot(S[j], pA);
-            uj[j] = u;
-            pA = pA + (u * Dinv[j]) * U[j];
-          }
-        }
-        lf4* rf = reinterpret_cast<lf4*>(RF(3 * k + r));
-        rf[0] = (lf4){pA.a.x, pA.a.y, pA.a.z, pA.l.x};
-        rf[1] = (lf4){pA.l.y, pA.l.z, uj[0], uj[1]};
-        rf[2] = (lf4){uj[2], uj[0] * Dinv[0], uj[1] * Dinv[1], uj[2] * Dinv[2]};
-        rf[3] = (lf4){(float)leg, 0.f, 0.f, 0.f};
-      }
-    }
-  }
-  if (sbase >= 0 && leg == 0) {
-    const V3 x = v3(cbase.x, cbase.y, cbase.z);
+    for (int j = 0; j < 3; j++)
+      if (j <= depth) vb = vb + qd_free[j] * S[j];
+    const V3 vp = vb.l + cross(vb.a, x);
+    LDS(L_RB + 3 * k) = dot(n, vp); LDS(L_RB + 3 * k + 1) = dot(t1, vp); LDS(L_RB + 3 * k + 2) = dot(t2, vp);
+    const V3 wl = v3(LDS(L_LAM + 3 * body), LDS(L_LAM + 3 * body + 1), LDS(L_LAM + 3 * body + 2));
+    const float sh = use_warm ? share : 0.f;
+    LDS(L_LS + 3 * k) = sh * dot(wl, n); LDS(L_LS + 3 * k + 1) = sh * dot(wl, t1); LDS(L_LS + 3 * k + 2) = sh * dot(wl, t2);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      const V3 d = r == 0 ? bn : r == 1 ? bt1 : bt2;
-      const SV g = -sv(cross(x, d), d);
-      lf4* rf = reinterpret_cast<lf4*>(RF(3 * sbase + r));
-      rf[0] = (lf4){g.a.x, g.a.y, g.a.z, g.l.x};
-      rf[1] = (lf4){g.l.y, g.l.z, 0.f, 0.f};
-      rf[2] = (lf4){0.f, 0.f, 0.f, 0.f};
-      rf[3] = (lf4){4.f, 0.f, 0.f, 0.f};
+      const V3 d = r == 0 ? n : r == 1 ? t1 : t2;
+      SV pA = -sv(cross(x, d), d);
+      float uj[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 2; j >= 0; j--) {
+        if (j <= depth) {
+          const float u = -dot(S[j], pA);
+          uj[j] = u;
+          pA = pA + (u * Dinv[j]) * U[j];
+        }
+      }
+      lf4* rf = reinterpret_cast<lf4*>(RF(3 * k + r));
+      rf[0] = (lf4){pA.a.x, pA.a.y, pA.a.z, pA.l.x};
+      rf[1] = (lf4){pA.l.y, pA.l.z, uj[0], uj[1]};
+      rf[2] = (lf4){uj[2], uj[0] * Dinv[0], uj[1] * Dinv[1], uj[2] * Dinv[2]};
+      rf[3] = (lf4){depth < 0 ? 4.f : (float)leg, 0.f, 0.f, 0.f};
     }
+  };
+  // (the trunk's impulse is read by lane 0 only; own bodies by the own lane: no cross-lane hazard on L_LAM here)
+  if (slot[0] >= 0) emit(slot[0], item[0], 2, 4 + 4 * leg, 1.f);
+  if (slot[1] >= 0) emit(slot[1], item[1], 2, 3 + 4 * leg, share_k);
+  if (slot[2] >= 0) emit(slot[2], item[2], 2, 3 + 4 * leg, share_k);
+  if (slot[3] >= 0) emit(slot[3], item[3], 1, 2 + 4 * leg, share_t);
+  if (slot[4] >= 0) emit(slot[4], item[4], 1, 2 + 4 * leg, share_t);
+  if (slot[5] >= 0) emit(slot[5], item[5], 0, 1 + 4 * leg, share_h);
+  if (slot[6] >= 0) emit(slot[6], item[6], 0, 1 + 4 * leg, share_h);
+  if (leg == 0) {
+    if (slot_b0 >= 0) emit(slot_b0, tb0, -1, 0, share_b);
+    if (slot_b1 >= 0) emit(slot_b1, tb1, -1, 0, share_b);
   }
   if (legact) {
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) {
+      float* jr = JR(3 * leg + jj);
+      jr[0] = qd_free[jj]; jr[1] = jlo[jj]; jr[2] = jhi[jj];
       float uj[3] = {0.f, 0.f, 0.f};
       uj[jj] = 1.f;
       SV pA = Dinv[jj] * U[jj];
@@ -690,36 +672,57 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
         lg[cc] = rf[3][0];
       }
     }
-    // rows: the contact rows of the wave's largest contact list, then the limit rows of every leg that is active somewhere
+    // rows: the contact rows of the wave's largest contact list, then the limit rows of every leg that is active somewhere.
+    // The loop body is branch-free apart from the wave-uniform skips; the next row's record is fetched while this row's
+    // entries are computed.
+    int r = 0;
+    auto row_in_wave = [&](int rr) { return rr < NRC ? (rr < 3 * Kw) : (((LAw >> ((rr - NRC) / 3)) & 1u) != 0u); };
+    while (r < NRC + NRJ && !row_in_wave(r)) r++;
+    lf4 n0, n1, n2, n3;
+    if (r < NRC + NRJ) { const lf4* rf = reinterpret_cast<const lf4*>(RF(r)); n0 = rf[0]; n1 = rf[1]; n2 = rf[2]; n3 = rf[3]; }
 #pragma unroll 1
-    for (int r = 0; r < NRC + NRJ; r++) {
-      const bool roww = r < NRC ? (r < 3 * Kw) : (((LAw >> ((r - NRC) / 3)) & 1u) != 0u);      // wave-uniform
-      if (!roww) continue;
-      const bool rowact = r < NRC ? (r < 3 * K) : (((lact >> ((r - NRC) / 3)) & 1u) != 0u);
-      const lf4* rf = reinterpret_cast<const lf4*>(RF(r));
-      const lf4 r0 = rf[0], r1 = rf[1], r2 = rf[2];
+    while (r < NRC + NRJ) {
+      const lf4 r0 = n0, r1 = n1, r2 = n2;
+      const float lr = n3[0];
+      int rn = r + 1;
+      while (rn < NRC + NRJ && !row_in_wave(rn)) rn++;
+      if (rn < NRC + NRJ) { const lf4* rf = reinterpret_cast<const lf4*>(RF(rn)); n0 = rf[0]; n1 = rf[1]; n2 = rf[2]; n3 = rf[3]; }
       const SV g = sv(v3(r0[0], r0[1], r0[2]), v3(r0[3], r1[0], r1[1]));
-      const float u0 = r1[2], u1 = r1[3], u2 = r2[0], lr = rf[3][0];
+      const float u0 = r1[2], u1 = r1[3], u2 = r2[0];
       float wv[NCC];
 #pragma unroll
       for (int cc = 0; cc < NCC; cc++) {
         wv[cc] = 0.f;
         if (ccw & (1u << cc)) {
           const float same = fmaf(u0, ud[cc][0], fmaf(u1, ud[cc][1], u2 * ud[cc][2]));
-          const float w = dot(g, Y[cc]) + (lr == lg[cc] ? same : 0.f);
-          wv[cc] = w;
-          const int c = leg + 4 * cc;
-          if (r == c) {                                        // diagonal: the owner of the column keeps the row's records
-            if (rowact && !(w > 1e-9f)) fault |= 1u << GO1_FAULT_W_DIAG;
-            if (r < NRC) LDS(L_RI + r) = rowact ? 1.f / w : 0.f;
-            else { float* jr = JR(r - NRC); jr[3] = w; jr[4] = rowact ? 1.f / w : 0.f; }
-          }
-          if (c < NRC && (c % 3) == 0 && (r == c + 1 || r == c + 2)) LDS(L_RP + r) = w;      // tangent rows see the normal impulse
+          wv[cc] = dot(g, Y[cc]) + (lr == lg[cc] ? same : 0.f);
         }
       }
-      lf4* wp = reinterpret_cast<lf4*>(WROW(r) + NCC * leg);
-      wp[0] = (lf4){wv[0], wv[1], wv[2], wv[3]};
-      wp[1] = (lf4){wv[4], wv[5], wv[6], wv[7]};
+      WSH4(r, 0) = (lf4){wv[0], wv[1], wv[2], wv[3]};
+      WSH4(r, 1) = (lf4){wv[4], wv[5], wv[6], wv[7]};
+      if (ccw & 0x100u) WSH8(r) = wv[8];
+      r = rn;
+    }
+  }
+  LDS_PHASE();
+  // row records from the finished matrix: every lane reads back the diagonal entries of its own columns, and the owner
+  // of a contact's normal column the two entries that couple the tangent rows to it
+#pragma unroll
+  for (int cc = 0; cc < NCC; cc++) {
+    const int c = leg + 4 * cc;
+    if ((ccw & (1u << cc)) && c < NRC + NRJ) {
+      const float w = cc < 8 ? WROW(c)[8 * leg + cc] : WSH8(c);
+      if (colact[cc] && !(w > 1e-9f)) fault |= 1u << GO1_FAULT_W_DIAG;
+      const float iw = colact[cc] ? 1.f / w : 0.f;
+      if (c < NRC) LDS(L_RI + c) = iw;
+      else { float* jr = JR(c - NRC); jr[3] = w; jr[4] = iw; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXC; k++) {
+    if (k < Kw && ((3 * k) & 3) == leg) {
+      LDS(L_RP + 3 * k + 1) = WROW(3 * k + 1)[8 * leg + ((3 * k) >> 2)];       // (3 k < 24: slots 0..5)
+      LDS(L_RP + 3 * k + 2) = WROW(3 * k + 2)[8 * leg + ((3 * k) >> 2)];
     }
   }
   __syncthreads();
@@ -758,11 +761,12 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
 #pragma unroll
       for (int hf = 0; hf < 2; hf++) {
         if (ccw & (0xFu << (4 * hf))) {
-          const lf4 w = reinterpret_cast<const lf4*>(WROW(c) + NCC * leg)[hf];
+          const lf4 w = WSH4(c, hf);
 #pragma unroll
           for (int i = 0; i < 4; i++) uloc[4 * hf + i] = fmaf(w[i], dl, uloc[4 * hf + i]);
         }
       }
+      if (ccw & 0x100u) uloc[8] = fmaf(WSH8(c), dl, uloc[8]);
     };
 #pragma unroll
     for (int k = 0; k < MAXC; k++) {                           // warm start: the starting impulses' velocities
@@ -841,22 +845,36 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   SV pA[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) pA[j] = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
+  V3 fbody[4];                                                 // world impulse per own body (hip, thigh, calf, foot)
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int b = 1 + 4 * leg + i;
-    V3 f = v3(0.f, 0.f, 0.f);
+  for (int i = 0; i < 4; i++) fbody[i] = v3(0.f, 0.f, 0.f);
+  auto take = [&](int k, V3& x) {                              // world impulse of solver contact k and its point
+    const V3 n = v3(LDS(L_CN + 3 * k), LDS(L_CN + 3 * k + 1), LDS(L_CN + 3 * k + 2));
+    V3 t1, t2;
+    contact_frame(n, t1, t2, fault);
+    x = v3(LDS(L_CX + 3 * k), LDS(L_CX + 3 * k + 1), LDS(L_CX + 3 * k + 2));
+    return LDS(L_LS + 3 * k) * n + LDS(L_LS + 3 * k + 1) * t1 + LDS(L_LS + 3 * k + 2) * t2;
+  };
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
     if (slot[i] >= 0) {
-      const int k = slot[i];
-      const float ln = LDS(L_LS + 3 * k), l1 = LDS(L_LS + 3 * k + 1), l2 = LDS(L_LS + 3 * k + 2);
-      f = ln * fn[i] + l1 * ft1[i] + l2 * ft2[i];              // world impulse
-      V3 x = v3(cand[i].x, cand[i].y, cand[i].z);
-      SV ff = sv(cross(x, f), f);
-      const int depth = i > 2 ? 2 : i;
+      const int depth = i == 0 ? 2 : i <= 2 ? 2 : i <= 4 ? 1 : 0;       // foot, calf: joint 2; thigh: 1; hip: 0
+      const int bi = i == 0 ? 3 : i <= 2 ? 2 : i <= 4 ? 1 : 0;          // own body index: hip 0, thigh 1, calf 2, foot 3
+      V3 x;
+      const V3 f = take(slot[i], x);
+      const SV ff = sv(cross(x, f), f);
 #pragma unroll
       for (int j = 0; j < 3; j++)
         if (j == depth) pA[j] = pA[j] - ff;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (q == bi) fbody[q] = fbody[q] + f;
     }
-    LDS(L_LAM + 3 * b) = f.x; LDS(L_LAM + 3 * b + 1) = f.y; LDS(L_LAM + 3 * b + 2) = f.z;      // listed: impulse, else 0
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int b = 1 + 4 * leg + i;
+    LDS(L_LAM + 3 * b) = fbody[i].x; LDS(L_LAM + 3 * b + 1) = fbody[i].y; LDS(L_LAM + 3 * b + 2) = fbody[i].z;      // listed: impulse, else 0
   }
   float lj[3] = {0.f, 0.f, 0.f};                               // limit impulses of the own joints
   if (legact) {
@@ -874,12 +892,8 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   }
   if (leg == 0) {
     V3 f = v3(0.f, 0.f, 0.f);
-    if (sbase >= 0) {
-      const float ln = LDS(L_LS + 3 * sbase), l1 = LDS(L_LS + 3 * sbase + 1), l2 = LDS(L_LS + 3 * sbase + 2);
-      f = ln * bn + l1 * bt1 + l2 * bt2;
-      V3 x = v3(cbase.x, cbase.y, cbase.z);
-      contrib = contrib - sv(cross(x, f), f);
-    }
+    if (slot_b0 >= 0) { V3 x; const V3 f0 = take(slot_b0, x); contrib = contrib - sv(cross(x, f0), f0); f = f + f0; }
+    if (slot_b1 >= 0) { V3 x; const V3 f1 = take(slot_b1, x); contrib = contrib - sv(cross(x, f1), f1); f = f + f1; }
     LDS(L_LAM) = f.x; LDS(L_LAM + 1) = f.y; LDS(L_LAM + 2) = f.z;
   }
   SV dv0 = -sym6_mul(I0inv, quad_sum(contrib));

@@ -22,6 +22,7 @@
 #include "go1_maps.h"
 #include "go1_physics.h"
 
+static_assert(A_IO_END <= LDSW_SIZE, "the actuator network's transient rows are overlaid on the solver's matrix");
 static_assert(L_END >= GO1_MAX_OBS, "post_physics stages the observation rows in the solver's LDS block");
 struct SimConst {            // lives in device memory (one per handle): indexable with scalar loads
   Go1SimConfig cfg;
@@ -63,6 +64,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
     for (int i = threadIdx.x; i < LDSW_SIZE / 4; i += WAVE) reinterpret_cast<zf4*>(ldsw)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
     for (int i = threadIdx.x; i < LDSX_SIZE / 4; i += WAVE) reinterpret_cast<zf4*>(ldsx)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
   }
+  LDS_PHASE();
   const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
   CfgRef cfg = csc->cfg;
   BufRef B = csc->buf;
@@ -113,7 +115,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
 #pragma unroll 1
   for (int sub = 0; sub < cfg.decimation; sub++) {
 #ifndef GO1_ABLATE_TORQUE
-    compute_torques(cfg, B, L, leg, e, N, head, act_lds, full_wave, fault);
+    compute_torques(cfg, B, L, leg, e, N, head, act_lds, ldsw, full_wave, fault);
 #endif
     PROF(1);
     head = (head + 1) % nl;
@@ -146,6 +148,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
     for (int i = threadIdx.x; i < LDSW_SIZE / 4; i += WAVE) reinterpret_cast<zf4*>(ldsw)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
     for (int i = threadIdx.x; i < LDSX_SIZE / 4; i += WAVE) reinterpret_cast<zf4*>(ldsx)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
   }
+  LDS_PHASE();
   const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
   CfgRef cfg = csc->cfg;
   BufRef B = csc->buf;
@@ -169,7 +172,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   if (A.mode == 1) {       // torques only (actions given as SoA)
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) AT(B.actions, 3 * leg + jj, e) = AT(A.actions, 3 * leg + jj, e);
-    compute_torques(cfg, B, L, leg, e, N, A.lag_head, act_lds, full_wave, fault);
+    compute_torques(cfg, B, L, leg, e, N, A.lag_head, act_lds, ldsw, full_wave, fault);
     report_fault(B, e, fault);
     return;
   }
