@@ -58,7 +58,10 @@ enum {
 #define WSH4(r, hf) (reinterpret_cast<lf4*>(WROW(r) + 8 * leg)[hf])       // the lane's column slots 4 hf .. 4 hf + 3 of row r
 #define WSH8(r) (WROW(r)[32 + leg])                                        // the lane's column slot 8 of row r
 #define LDSW_SIZE (NRT * EPW * WST)
-#define LDSX_SIZE (NRT * EPW * RF_ST + NRJ * EPW * JR_ST)       // RF records, then JR records
+#define MAXSB 2                      // leg-leg self-contacts per env (oracle: GO1_MAX_SELF_LEG_PAIRS)
+#define LDSX_SIZE (NRT * EPW * RF_ST + NRJ * EPW * JR_ST + 3 * MAXSB * EPW * RF_ST)       // RF, JR, then the B sides of leg-leg rows
+#define SB(i) (rfl + NRT * EPW * RF_ST + NRJ * EPW * JR_ST + ((i) * EPW + el) * RF_ST)
+#define GO1_SELF_LEG_RADIUS ((float)GO1_FOOT_RADIUS)
 typedef __attribute__((ext_vector_type(4))) float lf4;
 
 // ================================================================================================
@@ -331,6 +334,33 @@ DEV void contact_frame(V3 n, V3& t1, V3& t2, uint32_t& fault) {
   t2 = cross(n, t1);
 }
 
+// closest points of the segments p1-q1 and p2-q2 (Ericson 5.1.9; oracle seg_seg())
+DEV void seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3& c1, V3& c2) {
+  const V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+  const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), cc = dot(d1, r), b = dot(d1, d2);
+  const float den = a * e - b * b;
+  float sN = 0.f;
+  if (den > 1e-12f) sN = fminf(fmaxf((b * f - cc * e) / den, 0.f), 1.f);
+  float tN = (b * sN + f) / e;
+  if (tN < 0.f) { tN = 0.f; sN = fminf(fmaxf(-cc / a, 0.f), 1.f); }
+  else if (tN > 1.f) { tN = 1.f; sN = fminf(fmaxf((b - cc) / a, 0.f), 1.f); }
+  c1 = p1 + sN * d1;
+  c2 = p2 + tN * d2;
+}
+// contact of capsule A (p1-q1, ra) with capsule B (p2-q2, rb): normal from B to A, point midway between the surfaces
+DEV bool capsule_contact(V3 p1, V3 q1, float ra, V3 p2, V3 q2, float rb, float cd, Cand& o) {
+  V3 c1, c2;
+  seg_seg(p1, q1, p2, q2, c1, c2);
+  const V3 d = c1 - c2;
+  const float d2 = dot(d, d);
+  if (!(d2 > 1e-12f)) return false;
+  const float dist = sqrtf(d2), phi = dist - ra - rb;
+  if (!(phi < cd)) return false;
+  const V3 n = (1.f / dist) * d, x = c2 + (rb + 0.5f * phi) * n;
+  o.phi = phi; o.x = x.x; o.y = x.y; o.z = x.z; o.nx = n.x; o.ny = n.y; o.nz = n.z; o.un = 0.f;
+  return true;
+}
+
 // velocity change of the lane's own leg body at `depth` for the current impulse-propagation state
 DEV SV leg_response(const SV S[3], const SV U[3], const float Dinv[3], SV a0, int depth, bool on_path, int path_depth, const float pu[3]) {
   SV a = a0;
@@ -384,6 +414,9 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   float Dinv[3], uu[3];
   SV cj[3];
   Cand ch[2], ct[2], ck[2], cf;      // hip, thigh, calf: one candidate per end; foot
+  V3 pknee, pfoot;                   // own lower leg for the self-collision test: knee, foot centre (rel. base origin)
+  SV vleg2;                          //   and the calf body's twist before the step
+  const float cd0 = cfg.contact_distance;
   {
     M3 R[3];
     V3 p[3];
@@ -446,6 +479,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       }
 #endif
       cand_try(cfg, hs, cf, p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2]);
+      pknee = p[2]; pfoot = p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)); vleg2 = v[2];
     }
     // ABA pass 2: calf -> thigh -> hip, then quad-sum into the base
     SV pa_hip;
@@ -486,6 +520,74 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     }
   }
 
+  // ---- self-collision (asset self_collisions = 0: enabled): the lower legs (knee -> foot centre, radius of the foot sphere)
+  // against each other and against the trunk's capsule.  Every lane publishes its lower leg (segment, body twist before the
+  // step, free twist), reads the other three, and evaluates the pairs it is part of in the canonical (lower leg first)
+  // order, so both lanes of a pair hold bit-identical contact data. -------------------------------------------------------
+  Cand sc[4];                      // contact with partner leg (leg + 1 + i) & 3 for i < 3; [3]: with the trunk (un: A - B normal velocity)
+  V3 sfree[4];                     // relative free velocity (A - B) at the contact point
+  bool sact[4] = {false, false, false, false};
+  unsigned smask = 0;              // environment-wide: bit pid of every active pair (pairs 0..5 leg-leg, 6..9 trunk-leg)
+  SV sv_pre_own, sv_free_own;      // own lower leg: twist before the step / free twist (about the base origin, world axes)
+  if (cfg.self_collision) {
+    SV vfree = sv(w_free, v_free);
+#pragma unroll
+    for (int j = 0; j < 3; j++) vfree = vfree + qd_free[j] * S[j];
+    sv_pre_own = vleg2; sv_free_own = vfree;
+    {
+      lf4* a = reinterpret_cast<lf4*>(RF(2 * leg));
+      a[0] = (lf4){pknee.x, pknee.y, pknee.z, pfoot.x};
+      a[1] = (lf4){pfoot.y, pfoot.z, vleg2.a.x, vleg2.a.y};
+      a[2] = (lf4){vleg2.a.z, vleg2.l.x, vleg2.l.y, vleg2.l.z};
+      lf4* bq = reinterpret_cast<lf4*>(RF(2 * leg + 1));
+      bq[0] = (lf4){vfree.a.x, vfree.a.y, vfree.a.z, vfree.l.x};
+      bq[1] = (lf4){vfree.l.y, vfree.l.z, 0.f, 0.f};
+    }
+    LDS_PHASE();
+    unsigned mybits = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int j = (leg + 1 + i) & 3;
+      const lf4* a = reinterpret_cast<const lf4*>(RF(2 * j));
+      const lf4 a0 = a[0], a1 = a[1];
+      const V3 pj = v3(a0[0], a0[1], a0[2]), qj = v3(a0[3], a1[0], a1[1]);
+      const bool lower = leg < j;                               // canonical order: lower leg index is body A
+      sact[i] = lower ? capsule_contact(pknee, pfoot, GO1_SELF_LEG_RADIUS, pj, qj, GO1_SELF_LEG_RADIUS, cd0, sc[i])
+                      : capsule_contact(pj, qj, GO1_SELF_LEG_RADIUS, pknee, pfoot, GO1_SELF_LEG_RADIUS, cd0, sc[i]);
+      const int lo_ = lower ? leg : j, hi_ = lower ? j : leg;
+      const int pid = lo_ == 0 ? hi_ - 1 : lo_ == 1 ? hi_ + 1 : 5;
+      if (sact[i] && lower) mybits |= 1u << pid;
+      if (sact[i]) {                                            // relative velocity (A - B) at the contact point
+        const lf4 a2 = a[2];
+        const SV vpreJ = sv(v3(a1[2], a1[3], a2[0]), v3(a2[1], a2[2], a2[3]));
+        const lf4* bq = reinterpret_cast<const lf4*>(RF(2 * j + 1));
+        const lf4 b0 = bq[0], b1 = bq[1];
+        const SV vfreeJ = sv(v3(b0[0], b0[1], b0[2]), v3(b0[3], b1[0], b1[1]));
+        const V3 x = v3(sc[i].x, sc[i].y, sc[i].z), n = v3(sc[i].nx, sc[i].ny, sc[i].nz);
+        const SV pa = lower ? sv_pre_own : vpreJ, pb = lower ? vpreJ : sv_pre_own;
+        const SV fa = lower ? sv_free_own : vfreeJ, fbq = lower ? vfreeJ : sv_free_own;
+        sc[i].un = dot(n, (pa.l + cross(pa.a, x)) - (pb.l + cross(pb.a, x)));
+        sfree[i] = (fa.l + cross(fa.a, x)) - (fbq.l + cross(fbq.a, x));
+      }
+    }
+    {
+      const float ta = (float)(GO1_TRUNK_BOX_HALF[0] - GO1_TRUNK_BOX_HALF[1]);
+      sact[3] = capsule_contact(pknee, pfoot, GO1_SELF_LEG_RADIUS, mul(R0, v3(-ta, 0.f, 0.f)), mul(R0, v3(ta, 0.f, 0.f)),
+                                (float)GO1_TRUNK_BOX_HALF[1], cd0, sc[3]);
+      if (sact[3]) {
+        mybits |= 1u << (6 + leg);
+        const V3 x = v3(sc[3].x, sc[3].y, sc[3].z), n = v3(sc[3].nx, sc[3].ny, sc[3].nz);
+        const SV fb0 = sv(w_free, v_free);
+        sc[3].un = dot(n, (sv_pre_own.l + cross(sv_pre_own.a, x)) - (v0.l + cross(v0.a, x)));
+        sfree[3] = (sv_free_own.l + cross(sv_free_own.a, x)) - (fb0.l + cross(fb0.a, x));
+      }
+    }
+    mybits |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mybits, 0xB1, 0xF, 0xF, false);
+    mybits |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mybits, 0x4E, 0xF, 0xF, false);
+    smask = mybits;
+    LDS_PHASE();                   // the published segments are overwritten by the row functionals below
+  }
+
   // ---- solver contact list (oracle detect_contacts()): feet, trunk (first, second point), calves (first points, second
   // points), thighs, hips; at most MAXC, the rest is dropped and counted -------------------------------------------------
   const float cd = cfg.contact_distance;
@@ -500,14 +602,25 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   const Cand tb0 = fb ? cb[1] : cb[0], tb1 = fb ? cb[0] : cb[1];
   const bool act_b0 = tb0.phi < cd, act_b1 = tb1.phi < cd;
   const unsigned below = (1u << leg) - 1u;
-  int slot[7], slot_b0, slot_b1;
+  int slot[7], slot_b0, slot_b1, nF;
   int K;
   {
     int base_ofs = 0;
     unsigned m0 = quad_ballot(item[0].phi < cd, lane);
     slot[0] = (item[0].phi < cd) ? __popc(m0 & below) : -1;
     base_ofs += __popc(m0);
-    // (self-contacts take their slots here)
+    // self-contacts: pair order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3), then trunk-leg 0..3; at most MAXSB leg-leg pairs
+    {
+      const unsigned legpairs = smask & 0x3Fu;
+      unsigned keep = 0, cnt = 0;
+#pragma unroll
+      for (int pid = 0; pid < 6; pid++)
+        if (legpairs & (1u << pid)) { if (cnt < MAXSB) keep |= 1u << pid; cnt++; }
+      if (cnt > MAXSB && leg == 0) fault |= 1u << GO1_FAULT_CONTACT_DROPPED;
+      smask = keep | (smask & 0x3C0u);
+    }
+    nF = base_ofs;
+    base_ofs += __popc(smask);
     const int ofs_b0 = base_ofs;
     base_ofs += (act_b0 ? 1 : 0) + (act_b1 ? 1 : 0);
 #pragma unroll
@@ -599,7 +712,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       rf[0] = (lf4){pA.a.x, pA.a.y, pA.a.z, pA.l.x};
       rf[1] = (lf4){pA.l.y, pA.l.z, uj[0], uj[1]};
       rf[2] = (lf4){uj[2], uj[0] * Dinv[0], uj[1] * Dinv[1], uj[2] * Dinv[2]};
-      rf[3] = (lf4){depth < 0 ? 4.f : (float)leg, 0.f, 0.f, 0.f};
+      rf[3] = (lf4){depth < 0 ? 4.f : (float)leg, -1.f, 0.f, 0.f};
     }
   };
   // (the trunk's impulse is read by lane 0 only; own bodies by the own lane: no cross-lane hazard on L_LAM here)
@@ -613,6 +726,65 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   if (leg == 0) {
     if (slot_b0 >= 0) emit(slot_b0, tb0, -1, 0, share_b);
     if (slot_b1 >= 0) emit(slot_b1, tb1, -1, 0, share_b);
+  }
+  // self-contacts.  Body A (the lower leg of the lower-numbered leg, or the leg of a trunk pair) publishes the contact and
+  // its side of the row functionals; for a leg-leg pair body B's lane adds its side (record SB); the trunk as body B has
+  // no joints: its side is the unit wrench itself.
+  int sslot[4] = {-1, -1, -1, -1};     // solver slot of the pair with partner i / the trunk
+  int ssb[3] = {-1, -1, -1};           // index of the leg-leg pair among the listed leg-leg pairs (its SB record)
+  if (smask != 0u) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int j = (leg + 1 + i) & 3;
+      const bool lower = i == 3 || leg < j;
+      const int lo_ = lower ? leg : j, hi_ = lower ? j : leg;
+      const int pid = i == 3 ? 6 + leg : (lo_ == 0 ? hi_ - 1 : lo_ == 1 ? hi_ + 1 : 5);
+      if (!(smask & (1u << pid))) continue;
+      const int k = nF + __popc(smask & ((1u << pid) - 1u));
+      if (k >= MAXC) continue;
+      sslot[i] = k;
+      if (i < 3) ssb[i] = __popc(smask & 0x3Fu & ((1u << pid) - 1u));
+    }
+  }
+  if (smask != 0u) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (sslot[i] < 0) continue;
+      const int j = (leg + 1 + i) & 3, k = sslot[i];
+      const bool lower = i == 3 || leg < j;
+      const Cand& c = sc[i];
+      const V3 n = v3(c.nx, c.ny, c.nz), x = v3(c.x, c.y, c.z);
+      V3 t1, t2;
+      contact_frame(n, t1, t2, fault);
+      if (lower) {                           // body A publishes the contact
+        LDS(L_CX + 3 * k) = c.x; LDS(L_CX + 3 * k + 1) = c.y; LDS(L_CX + 3 * k + 2) = c.z;
+        LDS(L_CN + 3 * k) = c.nx; LDS(L_CN + 3 * k + 1) = c.ny; LDS(L_CN + 3 * k + 2) = c.nz;
+        float vs = fminf(-c.phi / h, cfg.max_depenetration_velocity);
+        if (c.un < -cfg.bounce_threshold_velocity && -s.rest * c.un > vs) vs = -s.rest * c.un;      // robot-robot: the robot's own material
+        LDS(L_RP + 3 * k) = vs;
+        LDS(L_RB + 3 * k) = dot(n, sfree[i]); LDS(L_RB + 3 * k + 1) = dot(t1, sfree[i]); LDS(L_RB + 3 * k + 2) = dot(t2, sfree[i]);
+        LDS(L_LS + 3 * k) = 0.f; LDS(L_LS + 3 * k + 1) = 0.f; LDS(L_LS + 3 * k + 2) = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const V3 d = r == 0 ? n : r == 1 ? t1 : t2;
+        const SV unit = sv(cross(x, d), d);
+        SV pA = lower ? -unit : unit;        // +d on body A, -d on body B
+        float uj[3];
+#pragma unroll
+        for (int jq = 2; jq >= 0; jq--) {
+          const float u = -dot(S[jq], pA);
+          uj[jq] = u;
+          pA = pA + (u * Dinv[jq]) * U[jq];
+        }
+        if (i == 3) pA = pA + unit;          // the trunk's side
+        lf4* rf = reinterpret_cast<lf4*>(lower ? RF(3 * k + r) : SB(3 * ssb[i] + r));
+        rf[0] = (lf4){pA.a.x, pA.a.y, pA.a.z, pA.l.x};
+        rf[1] = (lf4){pA.l.y, pA.l.z, uj[0], uj[1]};
+        rf[2] = (lf4){uj[2], uj[0] * Dinv[0], uj[1] * Dinv[1], uj[2] * Dinv[2]};
+        rf[3] = (lf4){(float)leg, (lower && i < 3) ? (float)ssb[i] : -1.f, 0.f, 0.f};       // [1]: index of the row's SB record, -1: none
+      }
+    }
   }
   if (legact) {
 #pragma unroll
@@ -634,10 +806,29 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       rf[0] = (lf4){pA.a.x, pA.a.y, pA.a.z, pA.l.x};
       rf[1] = (lf4){pA.l.y, pA.l.z, uj[0], uj[1]};
       rf[2] = (lf4){uj[2], uj[0] * Dinv[0], uj[1] * Dinv[1], uj[2] * Dinv[2]};
-      rf[3] = (lf4){(float)leg, 0.f, 0.f, 0.f};
+      rf[3] = (lf4){(float)leg, -1.f, 0.f, 0.f};
     }
   }
   __syncthreads();
+  // leg-leg self-contacts: body A's lane folds body B's wrench into the row functional (g = g_A + g_B)
+  const bool selfw = __ballot((smask & 0x3Fu) != 0u) != 0ull;      // wave-uniform
+  if (selfw) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (sslot[i] >= 0 && leg < ((leg + 1 + i) & 3)) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          lf4* rf = reinterpret_cast<lf4*>(RF(3 * sslot[i] + r));
+          const lf4* sb = reinterpret_cast<const lf4*>(SB(3 * ssb[i] + r));
+          lf4 a0 = rf[0], a1 = rf[1];
+          const lf4 b0 = sb[0], b1 = sb[1];
+          a0 = a0 + b0; a1[0] += b1[0]; a1[1] += b1[1];
+          rf[0] = a0; rf[1] = a1;
+        }
+      }
+    }
+    LDS_PHASE();
+  }
   PROF(4);
   // ---- Delassus matrix into LDS: lane `leg` builds the columns c = leg + 4 cc it owns in the sweep -------------------
   int Kw = 0;                                                  // wave-uniform max K: scalar branches below
@@ -702,6 +893,54 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       WSH4(r, 1) = (lf4){wv[4], wv[5], wv[6], wv[7]};
       if (ccw & 0x100u) WSH8(r) = wv[8];
       r = rn;
+    }
+    // Rows of leg-leg self-contacts carry TWO leg parts (A: in the row record, B: in its SB record).  The loop above used
+    // the total wrench g but only the A parts in the same-leg term; such rows (at most 3 MAXSB per environment) are redone
+    // here with all parts, row and mirrored column.  Rare: skipped unless some environment of the wave has such a contact.
+    if (selfw) {
+      LDS_PHASE();
+      int colsb[NCC];
+#pragma unroll
+      for (int cc = 0; cc < NCC; cc++) {
+        int c = leg + 4 * cc;
+        c = c < NRC + NRJ ? c : NRC + NRJ - 1;
+        colsb[cc] = (ccw & (1u << cc)) ? (int)RF(c)[13] : -1;
+      }
+      const int nS = __popc(smask);
+#pragma unroll 1
+      for (int q = 0; q < 3 * MAXC; q++) {                      // candidate rows: the self slots' rows
+        const int x = 3 * nF + q;
+        const bool inr = q < 3 * nS && x < NRC;
+        const int sbx = inr ? (int)RF(x < NRC ? x : 0)[13] : -1;
+        if (__ballot(sbx >= 0) == 0ull) { if (__ballot(inr) == 0ull) break; continue; }
+        if (sbx >= 0) {
+          const lf4* rf = reinterpret_cast<const lf4*>(RF(x));
+          const lf4 r0 = rf[0], r1 = rf[1], r2 = rf[2];
+          const lf4* sb = reinterpret_cast<const lf4*>(SB(3 * sbx + (x % 3)));
+          const lf4 s1 = sb[1], s2 = sb[2];
+          const SV g = sv(v3(r0[0], r0[1], r0[2]), v3(r0[3], r1[0], r1[1]));
+          const float uA0 = r1[2], uA1 = r1[3], uA2 = r2[0], lA = rf[3][0];
+          const float uB0 = s1[2], uB1 = s1[3], uB2 = s2[0], lB = sb[3][0];
+#pragma unroll
+          for (int cc = 0; cc < NCC; cc++) {
+            const int c = leg + 4 * cc;
+            if ((ccw & (1u << cc)) && c < NRC + NRJ) {
+              float w = dot(g, Y[cc]);
+              if (lA == lg[cc]) w += fmaf(uA0, ud[cc][0], fmaf(uA1, ud[cc][1], uA2 * ud[cc][2]));
+              if (lB == lg[cc]) w += fmaf(uB0, ud[cc][0], fmaf(uB1, ud[cc][1], uB2 * ud[cc][2]));
+              if (colsb[cc] >= 0) {
+                const lf4* sc_ = reinterpret_cast<const lf4*>(SB(3 * colsb[cc] + (c % 3)));
+                const lf4 c2 = sc_[2];
+                const float lgB = sc_[3][0];
+                if (lA == lgB) w += fmaf(uA0, c2[1], fmaf(uA1, c2[2], uA2 * c2[3]));
+                if (lB == lgB) w += fmaf(uB0, c2[1], fmaf(uB1, c2[2], uB2 * c2[3]));
+              }
+              if (cc < 8) WROW(x)[8 * leg + cc] = w; else WSH8(x) = w;
+              if ((x >> 2) < 8) WROW(c)[8 * (x & 3) + (x >> 2)] = w; else WROW(c)[32 + (x & 3)] = w;      // mirrored entry
+            }
+          }
+        }
+      }
     }
   }
   LDS_PHASE();
@@ -791,7 +1030,8 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
           u2 = fmaf(w20[k], dln, u2);
           float l1 = lam[r0 + 1] - u1 * id1[k];
           float l2 = lam[r0 + 2] - u2 * id2[k];
-          const float lim = mu * ln, nn = l1 * l1 + l2 * l2;   // friction cone: |l_t| <= mu l_n
+          const float muk = (k >= nF && k < nF + __popc(smask)) ? s.mu : mu;      // robot-robot: the robot's own material
+          const float lim = muk * ln, nn = l1 * l1 + l2 * l2;  // friction cone: |l_t| <= mu l_n
           if (nn > lim * lim) { const float sc = lim * __builtin_amdgcn_rsqf(nn); l1 *= sc; l2 *= sc; }
           const bool on = k < K;                               // lanes of environments with fewer contacts idle here
           const float nl0 = on ? ln : 0.f, nl1 = on ? l1 : 0.f, nl2 = on ? l2 : 0.f;
@@ -871,6 +1111,22 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
         if (q == bi) fbody[q] = fbody[q] + f;
     }
   }
+  SV self_base = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));     // trunk-leg self-contacts: wrench on the base
+  V3 self_trunk = v3(0.f, 0.f, 0.f);                            //   and the impulse booked on the trunk
+  if (smask != 0u) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (sslot[i] >= 0) {
+        V3 x;
+        V3 f = take(sslot[i], x);
+        const bool lower = i == 3 || leg < ((leg + 1 + i) & 3);
+        if (!lower) f = -f;                                     // body B receives the opposite impulse
+        pA[2] = pA[2] - sv(cross(x, f), f);
+        fbody[2] = fbody[2] + f;                                // booked on the calf (a penalised body: corl_rewards.py:49-52)
+        if (i == 3) { self_base = self_base + sv(cross(x, f), f); self_trunk = self_trunk - f; }
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int b = 1 + 4 * leg + i;
@@ -890,8 +1146,10 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     SV pa = pA[j] + (u * Dinv[j]) * U[j];
     if (j > 0) pA[j - 1] = pA[j - 1] + pa; else contrib = pa;
   }
+  contrib = contrib + self_base;                               // the trunk's share of trunk-leg contacts (-f at x)
+  if (cfg.self_collision) self_trunk = v3(quad_sum(self_trunk.x), quad_sum(self_trunk.y), quad_sum(self_trunk.z));
   if (leg == 0) {
-    V3 f = v3(0.f, 0.f, 0.f);
+    V3 f = self_trunk;
     if (slot_b0 >= 0) { V3 x; const V3 f0 = take(slot_b0, x); contrib = contrib - sv(cross(x, f0), f0); f = f + f0; }
     if (slot_b1 >= 0) { V3 x; const V3 f1 = take(slot_b1, x); contrib = contrib - sv(cross(x, f1), f1); f = f + f1; }
     LDS(L_LAM) = f.x; LDS(L_LAM + 1) = f.y; LDS(L_LAM + 2) = f.z;

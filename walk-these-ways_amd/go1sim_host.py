@@ -140,7 +140,7 @@ def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curricu
     S.max_angular_velocity = float(cfg.asset.max_angular_velocity)
     S.joint_limit_margin = float(getattr(px, "joint_limit_margin", 5.0))
     S.joint_limit_pos_margin = float(getattr(px, "joint_limit_pos_margin", 0.1))
-    S.self_collision = 0 * int(getattr(cfg.asset, "self_collisions", 0) == 0)   # TODO(stage 2) the flag is a collision FILTER: 0 = enabled
+    S.self_collision = int(getattr(cfg.asset, "self_collisions", 0) == 0)       # the flag is a collision FILTER: 0 = enabled
     S.solver_iterations = int(solver_iterations)
     S.warm_start = int(warm_start)
     S.terrain_type = 0                                          # set by bind_height_field() when a height field is bound
