@@ -19,6 +19,9 @@ static void lane_main() {
   // a lane that leaves may be the one the others are waiting for
   if (b->live > 0 && b->arrived >= b->live) { b->arrived = 0; b->generation++; }
   if (b->qlive[q] > 0 && b->qarrived[q] >= b->qlive[q]) { b->qarrived[q] = 0; b->qgen[q]++; }
+  const int w = me.tid >> 6;
+  b->wlive[w]--;
+  if (b->wlive[w] > 0 && b->warrived[w] >= b->wlive[w]) { b->warrived[w] = 0; b->wgen[w]++; }
   swapcontext(&me.ctx, &b->sched);
 }
 
@@ -32,6 +35,7 @@ void run_block(int bid, int nthreads, void (*fn)(void*), void* arg) {
   Block* b = cache;
   blk = b;
   b->nthreads = nthreads; b->bid = bid; b->live = nthreads; b->arrived = 0; b->generation = 0;
+  for (int w = 0; w < (nthreads + 63) / 64; w++) { b->wlive[w] = (nthreads - 64 * w) < 64 ? (nthreads - 64 * w) : 64; b->warrived[w] = 0; b->wgen[w] = 0; }
   for (int q = 0; q < (nthreads + 3) / 4; q++) { b->qlive[q] = (nthreads - 4 * q) < 4 ? (nthreads - 4 * q) : 4; b->qarrived[q] = 0; b->qgen[q] = 0; }
   g_tramp = Tramp{fn, arg};
   for (int t = 0; t < nthreads; t++) {

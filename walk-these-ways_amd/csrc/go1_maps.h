@@ -396,7 +396,7 @@ DEV int reward_raw_sign(int id) {
 // on every lane; per-environment scalar work on the leg-0 lane; `__syncthreads()` (one-wave workgroup) orders the
 // hand-overs through HBM/L2.  Must be called by all four lanes of the environment.
 // ================================================================================================
-#define QUAD_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)
+#define QUAD_SYNC() do { __threadfence_block(); LDS_PHASE(); } while (0)      // (one wavefront: memory fence + ordering, no s_barrier)
 
 DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int lane, int e, int N, int64_t counter_post, V3 grav,
                       int history_slot, uint32_t& fault PROF_PARAM) {

@@ -10,12 +10,14 @@ __device__ unsigned long long g_prof[64];
 __shared__ unsigned long long s_prof[24];          // accumulated with fire-and-forget LDS adds: no memory stall per marker
 #define PROF_PARAM , unsigned long long& prof_t
 #define PROF_PASS , prof_t
-#define PROF_DECL if (threadIdx.x < 24) s_prof[threadIdx.x] = 0; __syncthreads(); unsigned long long prof_t = __builtin_readcyclecounter();
+#define PROF_INIT if (threadIdx.x < 24) s_prof[threadIdx.x] = 0; __syncthreads();
+#define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter();
 #define PROF(i) do { unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&s_prof[i], now_ - prof_t); prof_t = now_; } while (0)
-#define PROF_FLUSH do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x < 24) g_prof[threadIdx.x] += s_prof[threadIdx.x]; } while (0)
+#define PROF_FLUSH do { LDS_PHASE(); if (blockIdx.x == 0 && threadIdx.x < 24) g_prof[threadIdx.x] += s_prof[threadIdx.x]; } while (0)
 #else
 #define PROF_PARAM
 #define PROF_PASS
+#define PROF_INIT
 #define PROF_DECL
 #define PROF(i) do { } while (0)
 #define PROF_FLUSH do { } while (0)
@@ -31,6 +33,8 @@ __shared__ unsigned long long s_prof[24];          // accumulated with fire-and-
 #ifndef LDS_PHASE
 #define LDS_PHASE() __builtin_amdgcn_wave_barrier()
 #endif
+// hand-over between the wavefronts of a workgroup (nw of them); with one wavefront it degenerates to the marker above
+#define BLOCK_SYNC(nw) do { if ((nw) > 1) __syncthreads(); else LDS_PHASE(); } while (0)
 
 struct V3 { float x, y, z; };
 DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }

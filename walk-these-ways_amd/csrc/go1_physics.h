@@ -39,8 +39,10 @@ enum {
   L_RP = L_RB + NRC,         // NRC   normal rows: target velocity v*; tangent rows: W[t][n]
   L_RI = L_RP + NRC,         // NRC   1 / W[r][r]
   L_LS = L_RI + NRC,         // NRC   contact impulses: start values in, solution out
+  L_I0 = L_LS + NRC,         // 21    inverse of the base's articulated inertia (upper triangle): for the wavefronts that build W
+  L_KL = L_I0 + 21,          // 2     contacts in the solver list, mask of the legs whose limit rows are in the solve
   L_W = L_RB,                // zero-filled at kernel start from here to L_END
-  L_END = L_LS + NRC
+  L_END = L_KL + 2
 };
 #define LDS(f) lds[(f) * EPW + el]
 // Packed records, one per (row, environment), read with 16-byte LDS loads:
@@ -137,15 +139,20 @@ DEV void actuator_lds_init(float* a, int lane) {          // once per launch, al
   }
 }
 
-DEV void actuator_net_mfma(float* a, float* io, int lane, const float in[3][6], float out[3]) {
+// The 12 row tiles of a substep are split over the workgroup's nw wavefronts (wave wv takes t = wv, wv + nw, ...): the
+// master wave (wv = 0, the one that runs the physics) writes the 192 input rows, everybody evaluates tiles, the master
+// collects the outputs.  Helper waves call it with master = false.
+DEV void actuator_net_mfma(float* a, float* io, int lane, int wv, int nw, bool master, const float in[3][6], float out[3]) {
   typedef __attribute__((ext_vector_type(4))) float f4;
+  if (master) {
 #pragma unroll
-  for (int jj = 0; jj < 3; jj++) {
-    f4* p = reinterpret_cast<f4*>(io + A_IN + (3 * lane + jj) * 8);
-    p[0] = (f4){in[jj][0], in[jj][1], in[jj][2], in[jj][3]};
-    p[1] = (f4){in[jj][4], in[jj][5], 1.f, 0.f};
+    for (int jj = 0; jj < 3; jj++) {
+      f4* p = reinterpret_cast<f4*>(io + A_IN + (3 * lane + jj) * 8);
+      p[0] = (f4){in[jj][0], in[jj][1], in[jj][2], in[jj][3]};
+      p[1] = (f4){in[jj][4], in[jj][5], 1.f, 0.f};
+    }
   }
-  __syncthreads();
+  BLOCK_SYNC(nw);
   const int c = lane & 15, g = lane >> 4;
   float w0[8][7];
 #pragma unroll
@@ -164,8 +171,8 @@ DEV void actuator_net_mfma(float* a, float* io, int lane, const float in[3][6], 
 #pragma unroll
     for (int q = 0; q < 4; q++) { b1v[4 * i + q] = bb[q]; w2v[4 * i + q] = ww[q]; }
   }
-#pragma unroll 2
-  for (int t = 0; t < 12; t++) {
+#pragma unroll 1
+  for (int t = wv; t < 12; t += nw) {
     const f4* pin = reinterpret_cast<const f4*>(io + A_IN + (16 * t + c) * 8);
     const f4 x0 = pin[0], x1 = pin[1];
     act_f16x8 bhi, blo;
@@ -191,11 +198,13 @@ DEV void actuator_net_mfma(float* a, float* io, int lane, const float in[3][6], 
     }
     io[A_OUT + 192 * g + 16 * t + c] = part;      // the 4 lanes (g = 0..3) holding the same row: partials meet in LDS
   }
-  __syncthreads();
+  BLOCK_SYNC(nw);
+  if (master) {
 #pragma unroll
-  for (int jj = 0; jj < 3; jj++) {
-    const int r = 3 * lane + jj;
-    out[jj] = ((io[A_OUT + r] + io[A_OUT + 192 + r]) + (io[A_OUT + 384 + r] + io[A_OUT + 576 + r])) + GO1_ACT_B2;
+    for (int jj = 0; jj < 3; jj++) {
+      const int r = 3 * lane + jj;
+      out[jj] = ((io[A_OUT + r] + io[A_OUT + 192 + r]) + (io[A_OUT + 384 + r] + io[A_OUT + 576 + r])) + GO1_ACT_B2;
+    }
   }
 }
 
@@ -203,7 +212,7 @@ struct Leg {             // the calling lane's leg
   float q[3], qd[3], tau[3];
 };
 
-DEV void compute_torques(CfgRef cfg, BufRef B, Leg& L, int leg, int e, int N, int head, float* act_lds, float* act_io, bool full_wave, uint32_t& fault) {
+DEV void compute_torques(CfgRef cfg, BufRef B, Leg& L, int leg, int e, int N, int head, float* act_lds, float* act_io, bool full_wave, int nw, uint32_t& fault) {
   const int nl = cfg.lag_timesteps + 1;
   const int h2 = (head + 1) % nl;
   float in[3][6], tq[3], tgt[3];
@@ -235,7 +244,7 @@ DEV void compute_torques(CfgRef cfg, BufRef B, Leg& L, int leg, int e, int N, in
       AT(B.joint_vel_last_last, j, e) = vl;
       AT(B.joint_vel_last, j, e) = L.qd[jj];
     }
-    if (full_wave) actuator_net_mfma(act_lds, act_io, (int)threadIdx.x, in, tq);      // wave-uniform choice
+    if (full_wave) actuator_net_mfma(act_lds, act_io, (int)threadIdx.x & 63, 0, nw, true, in, tq);      // wave-uniform choice
     else actuator_net3(in, tq);
   } else {
 #pragma unroll
@@ -375,7 +384,92 @@ DEV SV leg_response(const SV S[3], const SV U[3], const float Dinv[3], SV a0, in
   return a;
 }
 
-DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds, float* ldsw, float* rfl, int lane, Base& s, Leg& L, V3 grav,
+// ---- Delassus matrix W = J M^-1 J^T into LDS ------------------------------------------------------------------------
+// Which rows / columns exist: wave-uniform bounds (scalar branches) from the per-environment contact count and limit-row legs.
+struct SolveMasks {
+  int Kw;                  // wave-uniform max K
+  unsigned LAw;            // wave-uniform: legs with limit rows in some environment
+  unsigned ccw;            // wave-uniform: column slots cc with an active column somewhere
+  bool colact[NCC];        // column c = leg + 4 cc is a row of THIS environment's solve
+};
+DEV void solver_masks(int K, unsigned lact, bool legact, int leg, SolveMasks& m) {
+  m.Kw = 0;
+#pragma unroll
+  for (int kk = 1; kk <= MAXC; kk++) m.Kw = (__ballot(K >= kk) != 0ull) ? kk : m.Kw;
+  unsigned long long bl = __ballot(legact);
+  bl |= bl >> 32; bl |= bl >> 16; bl |= bl >> 8; bl |= bl >> 4;
+  m.LAw = (unsigned)(bl & 0xFull);
+  m.ccw = 0;
+#pragma unroll
+  for (int cc = 0; cc < NCC; cc++) {
+    const int c = leg + 4 * cc;
+    m.colact[cc] = c < NRC ? (c < 3 * K) : (c < NRC + NRJ && ((lact >> ((c - NRC) / 3)) & 1u));
+    if (__ballot(m.colact[cc]) != 0ull) m.ccw |= 1u << cc;
+  }
+}
+// the lane's columns: Y_c = I0^-1 g_c, u_j(c) / D_j and the leg of the column
+DEV void lane_columns(const float* rfl, const Sym6& I0inv, int leg, int el, unsigned ccw, SV Y[NCC], float ud[NCC][3], float lg[NCC]) {
+#pragma unroll
+  for (int cc = 0; cc < NCC; cc++) {
+    if (ccw & (1u << cc)) {
+      int c = leg + 4 * cc;
+      c = c < NRC + NRJ ? c : NRC + NRJ - 1;     // lanes 2, 3 have no last column: any finite stand-in (its impulse stays 0)
+      const lf4* rf = reinterpret_cast<const lf4*>(RF(c));
+      const lf4 r0 = rf[0], r1 = rf[1], r2 = rf[2];
+      Y[cc] = sym6_mul(I0inv, sv(v3(r0[0], r0[1], r0[2]), v3(r0[3], r1[0], r1[1])));
+      ud[cc][0] = r2[1]; ud[cc][1] = r2[2]; ud[cc][2] = r2[3];
+      lg[cc] = rf[3][0];
+    }
+  }
+}
+// Rows wv, wv + nw, ... of the rows that exist somewhere in the wavefront (every wavefront of the workgroup takes its part;
+// within a wavefront lane `leg` writes the columns c = leg + 4 cc it owns in the sweep).  Inputs come from LDS only: the row
+// functionals, the base's inverse inertia, the per-environment row counts.
+DEV void delassus_rows(const float* lds, float* ldsw, const float* rfl, int lane, int wv, int nw) {
+  const int leg = lane & 3, el = lane >> 2;
+  Sym6 I0inv;
+#pragma unroll
+  for (int i = 0; i < 21; i++) I0inv.m[i] = LDS(L_I0 + i);
+  const int K = (int)LDS(L_KL);
+  const unsigned lact = (unsigned)LDS(L_KL + 1);
+  SolveMasks m;
+  solver_masks(K, lact, ((lact >> leg) & 1u) != 0u, leg, m);
+  SV Y[NCC];
+  float ud[NCC][3], lg[NCC];
+  lane_columns(rfl, I0inv, leg, el, m.ccw, Y, ud, lg);
+  // The loop body is branch-free apart from the wave-uniform skips; the next row's record is fetched while this row's
+  // entries are computed.
+  auto row_here = [&](int rr) { return (rr % nw) == wv && (rr < NRC ? (rr < 3 * m.Kw) : (((m.LAw >> ((rr - NRC) / 3)) & 1u) != 0u)); };
+  int r = 0;
+  while (r < NRC + NRJ && !row_here(r)) r++;
+  lf4 n0, n1, n2, n3;
+  if (r < NRC + NRJ) { const lf4* rf = reinterpret_cast<const lf4*>(RF(r)); n0 = rf[0]; n1 = rf[1]; n2 = rf[2]; n3 = rf[3]; }
+#pragma unroll 1
+  while (r < NRC + NRJ) {
+    const lf4 r0 = n0, r1 = n1, r2 = n2;
+    const float lr = n3[0];
+    int rn = r + 1;
+    while (rn < NRC + NRJ && !row_here(rn)) rn++;
+    if (rn < NRC + NRJ) { const lf4* rf = reinterpret_cast<const lf4*>(RF(rn)); n0 = rf[0]; n1 = rf[1]; n2 = rf[2]; n3 = rf[3]; }
+    const SV g = sv(v3(r0[0], r0[1], r0[2]), v3(r0[3], r1[0], r1[1]));
+    const float u0 = r1[2], u1 = r1[3], u2 = r2[0];
+    float wv_[NCC];
+#pragma unroll
+    for (int cc = 0; cc < NCC; cc++) {
+      wv_[cc] = 0.f;
+      if (m.ccw & (1u << cc)) {
+        const float same = fmaf(u0, ud[cc][0], fmaf(u1, ud[cc][1], u2 * ud[cc][2]));
+        wv_[cc] = dot(g, Y[cc]) + (lr == lg[cc] ? same : 0.f);
+      }
+    }
+    WSH4(r, 0) = (lf4){wv_[0], wv_[1], wv_[2], wv_[3]};
+    WSH4(r, 1) = (lf4){wv_[4], wv_[5], wv_[6], wv_[7]};
+    if (m.ccw & 0x100u) WSH8(r) = wv_[8];
+    r = rn;
+  }
+}
+
+DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds, float* ldsw, float* rfl, int lane, int nw, Base& s, Leg& L, V3 grav,
                          bool use_warm, float h, uint32_t& fault PROF_PARAM) {
   float* const jrl = rfl + NRT * EPW * RF_ST;
   const int leg = lane & 3, el = lane >> 2;
@@ -809,7 +903,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       rf[3] = (lf4){(float)leg, -1.f, 0.f, 0.f};
     }
   }
-  __syncthreads();
+  LDS_PHASE();
   // leg-leg self-contacts: body A's lane folds body B's wrench into the row functional (g = g_A + g_B)
   const bool selfw = __ballot((smask & 0x3Fu) != 0u) != 0ull;      // wave-uniform
   if (selfw) {
@@ -830,75 +924,30 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     LDS_PHASE();
   }
   PROF(4);
-  // ---- Delassus matrix into LDS: lane `leg` builds the columns c = leg + 4 cc it owns in the sweep -------------------
-  int Kw = 0;                                                  // wave-uniform max K: scalar branches below
+  // ---- Delassus matrix into LDS: every wavefront of the workgroup builds its share of the rows (delassus_rows) -----------
+  if (leg == 0) {
 #pragma unroll
-  for (int kk = 1; kk <= MAXC; kk++) Kw = (__ballot(K >= kk) != 0ull) ? kk : Kw;
-  unsigned LAw;                                                // wave-uniform: legs with limit rows in some environment
-  {
-    unsigned long long bl = __ballot(legact);
-    bl |= bl >> 32; bl |= bl >> 16; bl |= bl >> 8; bl |= bl >> 4;
-    LAw = (unsigned)(bl & 0xFull);
+    for (int i = 0; i < 21; i++) LDS(L_I0 + i) = I0inv.m[i];
+    LDS(L_KL) = (float)K; LDS(L_KL + 1) = (float)lact;
   }
-  bool colact[NCC];                                            // column c = leg + 4 cc is a row of THIS environment's solve
-  unsigned ccw = 0;                                            // wave-uniform: column slots with an active column somewhere
+  BLOCK_SYNC(nw);
+  delassus_rows(lds, ldsw, rfl, lane, 0, nw);
+  BLOCK_SYNC(nw);
+  SolveMasks sm;
+  solver_masks(K, lact, legact, leg, sm);
+  const int Kw = sm.Kw;
+  const unsigned LAw = sm.LAw, ccw = sm.ccw;
+  bool colact[NCC];
 #pragma unroll
-  for (int cc = 0; cc < NCC; cc++) {
-    const int c = leg + 4 * cc;
-    colact[cc] = c < NRC ? (c < 3 * K) : (c < NRC + NRJ && ((lact >> ((c - NRC) / 3)) & 1u));
-    if (__ballot(colact[cc]) != 0ull) ccw |= 1u << cc;
-  }
+  for (int cc = 0; cc < NCC; cc++) colact[cc] = sm.colact[cc];
   {
-    SV Y[NCC];
-    float ud[NCC][3], lg[NCC];
-#pragma unroll
-    for (int cc = 0; cc < NCC; cc++) {
-      if (ccw & (1u << cc)) {
-        int c = leg + 4 * cc;
-        c = c < NRC + NRJ ? c : NRC + NRJ - 1;     // lanes 2, 3 have no last column: any finite stand-in (its impulse stays 0)
-        const lf4* rf = reinterpret_cast<const lf4*>(RF(c));
-        const lf4 r0 = rf[0], r1 = rf[1], r2 = rf[2];
-        Y[cc] = sym6_mul(I0inv, sv(v3(r0[0], r0[1], r0[2]), v3(r0[3], r1[0], r1[1])));
-        ud[cc][0] = r2[1]; ud[cc][1] = r2[2]; ud[cc][2] = r2[3];
-        lg[cc] = rf[3][0];
-      }
-    }
-    // rows: the contact rows of the wave's largest contact list, then the limit rows of every leg that is active somewhere.
-    // The loop body is branch-free apart from the wave-uniform skips; the next row's record is fetched while this row's
-    // entries are computed.
-    int r = 0;
-    auto row_in_wave = [&](int rr) { return rr < NRC ? (rr < 3 * Kw) : (((LAw >> ((rr - NRC) / 3)) & 1u) != 0u); };
-    while (r < NRC + NRJ && !row_in_wave(r)) r++;
-    lf4 n0, n1, n2, n3;
-    if (r < NRC + NRJ) { const lf4* rf = reinterpret_cast<const lf4*>(RF(r)); n0 = rf[0]; n1 = rf[1]; n2 = rf[2]; n3 = rf[3]; }
-#pragma unroll 1
-    while (r < NRC + NRJ) {
-      const lf4 r0 = n0, r1 = n1, r2 = n2;
-      const float lr = n3[0];
-      int rn = r + 1;
-      while (rn < NRC + NRJ && !row_in_wave(rn)) rn++;
-      if (rn < NRC + NRJ) { const lf4* rf = reinterpret_cast<const lf4*>(RF(rn)); n0 = rf[0]; n1 = rf[1]; n2 = rf[2]; n3 = rf[3]; }
-      const SV g = sv(v3(r0[0], r0[1], r0[2]), v3(r0[3], r1[0], r1[1]));
-      const float u0 = r1[2], u1 = r1[3], u2 = r2[0];
-      float wv[NCC];
-#pragma unroll
-      for (int cc = 0; cc < NCC; cc++) {
-        wv[cc] = 0.f;
-        if (ccw & (1u << cc)) {
-          const float same = fmaf(u0, ud[cc][0], fmaf(u1, ud[cc][1], u2 * ud[cc][2]));
-          wv[cc] = dot(g, Y[cc]) + (lr == lg[cc] ? same : 0.f);
-        }
-      }
-      WSH4(r, 0) = (lf4){wv[0], wv[1], wv[2], wv[3]};
-      WSH4(r, 1) = (lf4){wv[4], wv[5], wv[6], wv[7]};
-      if (ccw & 0x100u) WSH8(r) = wv[8];
-      r = rn;
-    }
     // Rows of leg-leg self-contacts carry TWO leg parts (A: in the row record, B: in its SB record).  The loop above used
     // the total wrench g but only the A parts in the same-leg term; such rows (at most 3 MAXSB per environment) are redone
     // here with all parts, row and mirrored column.  Rare: skipped unless some environment of the wave has such a contact.
     if (selfw) {
-      LDS_PHASE();
+      SV Y[NCC];
+      float ud[NCC][3], lg[NCC];
+      lane_columns(rfl, I0inv, leg, el, ccw, Y, ud, lg);
       int colsb[NCC];
 #pragma unroll
       for (int cc = 0; cc < NCC; cc++) {
@@ -964,7 +1013,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       LDS(L_RP + 3 * k + 2) = WROW(3 * k + 2)[8 * leg + ((3 * k) >> 2)];
     }
   }
-  __syncthreads();
+  LDS_PHASE();
   PROF(18);
   // ---- projected Gauss-Seidel on the impulses -------------------------------------------------------------
   // The sweep keeps the ROW VELOCITIES u = b + W lambda up to date instead of re-evaluating a row's dot product when its
@@ -1079,7 +1128,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   }
 #endif
 
-  __syncthreads();
+  LDS_PHASE();
   PROF(5);
   // ---- apply all impulses with one propagation ---------------------------------------------------------
   SV pA[3];

@@ -53,27 +53,48 @@ DEV void report_fault(BufRef B, int e, uint32_t fault) {
     if (fault & (1u << b)) atomicAdd(&B.fault_counts[b], 1u);
 }
 
-extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArgs A) {
+// Workgroup = STEP_WAVES wavefronts for 16 environments.  Wavefront 0 (the "master") runs the step — four lanes per
+// environment, one per leg; the other wavefronts are helpers on the CU's other SIMDs: they take their share of the two
+// data-parallel blocks of every substep (the actuator network's row tiles, the rows of the Delassus matrix), fed through
+// LDS, and wait at workgroup barriers otherwise.  4096 environments -> 256 workgroups x 4 wavefronts: one per SIMD.
+#define STEP_WAVES 4
+extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(const StepArgs A) {
   __shared__ float lds[L_END * EPW];
   __shared__ __attribute__((aligned(16))) float ldsw[LDSW_SIZE];
   __shared__ __attribute__((aligned(16))) float ldsx[LDSX_SIZE];
   __shared__ __attribute__((aligned(16))) float act_lds[A_END];
-  for (int i = threadIdx.x; i < (L_END - L_W) * EPW; i += WAVE) lds[L_W * EPW + i] = 0.f;   // finite everywhere: see the PGS column split
+  const int nw = STEP_WAVES, wv = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63, leg = lane & 3;
+  for (int i = threadIdx.x; i < (L_END - L_W) * EPW; i += WAVE * STEP_WAVES) lds[L_W * EPW + i] = 0.f;   // finite everywhere: see the PGS column split
   {
     typedef __attribute__((ext_vector_type(4))) float zf4;
-    for (int i = threadIdx.x; i < LDSW_SIZE / 4; i += WAVE) reinterpret_cast<zf4*>(ldsw)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < LDSX_SIZE / 4; i += WAVE) reinterpret_cast<zf4*>(ldsx)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < LDSW_SIZE / 4; i += WAVE * STEP_WAVES) reinterpret_cast<zf4*>(ldsw)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < LDSX_SIZE / 4; i += WAVE * STEP_WAVES) reinterpret_cast<zf4*>(ldsx)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
   }
-  LDS_PHASE();
   const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
   CfgRef cfg = csc->cfg;
   BufRef B = csc->buf;
   const int N = cfg.num_envs;
-  const int lane = threadIdx.x, leg = lane & 3;
   const int e = blockIdx.x * EPW + (lane >> 2);
   const bool full_wave = (int)(blockIdx.x + 1) * EPW <= N;      // the MFMA torque model needs all 64 lanes
-  if (full_wave && cfg.control_type == 1) actuator_lds_init(act_lds, lane);
+  const bool mfma_torque = full_wave && cfg.control_type == 1;
+  if (mfma_torque && wv == 0) actuator_lds_init(act_lds, lane);
+  PROF_INIT
+  __syncthreads();
   if (e >= N) return;
+  if (wv != 0) {           // helper wavefront: the same sequence of workgroup barriers as the master's substep loop
+#pragma unroll 1
+    for (int sub = 0; sub < cfg.decimation; sub++) {
+#ifndef GO1_ABLATE_TORQUE
+      if (mfma_torque) actuator_net_mfma(act_lds, ldsw, lane, wv, nw, false, nullptr, nullptr);
+#endif
+#ifndef GO1_ABLATE_PHYSICS
+      BLOCK_SYNC(nw);
+      delassus_rows(lds, ldsw, ldsx, lane, wv, nw);
+      BLOCK_SYNC(nw);
+#endif
+    }
+    return;
+  }
   const float h = cfg.sim_dt;
   PROF_DECL
   Base s;
@@ -115,19 +136,19 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_step_kernel(const StepArg
 #pragma unroll 1
   for (int sub = 0; sub < cfg.decimation; sub++) {
 #ifndef GO1_ABLATE_TORQUE
-    compute_torques(cfg, B, L, leg, e, N, head, act_lds, ldsw, full_wave, fault);
+    compute_torques(cfg, B, L, leg, e, N, head, act_lds, ldsw, full_wave, nw, fault);
 #endif
     PROF(1);
     head = (head + 1) % nl;
 #ifndef GO1_ABLATE_PHYSICS
-    physics_substep(cfg, B.height_samples, lds, ldsw, ldsx, lane, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault PROF_PASS);
+    physics_substep(cfg, B.height_samples, lds, ldsw, ldsx, lane, nw, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault PROF_PASS);
 #endif
   }
   store_state(B, leg, e, N, s, L);
   foot_state(s, L, leg, B, e, N);
   store_forces(cfg, B, lds, lane, e, N);
   __threadfence_block();
-  __syncthreads();
+  LDS_PHASE();
   PROF(7);
 #ifndef GO1_ABLATE_POST
   post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, grav, A.history_slot, fault PROF_PASS);
@@ -172,7 +193,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   if (A.mode == 1) {       // torques only (actions given as SoA)
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) AT(B.actions, 3 * leg + jj, e) = AT(A.actions, 3 * leg + jj, e);
-    compute_torques(cfg, B, L, leg, e, N, A.lag_head, act_lds, ldsw, full_wave, fault);
+    compute_torques(cfg, B, L, leg, e, N, A.lag_head, act_lds, ldsw, full_wave, 1, fault);
     report_fault(B, e, fault);
     return;
   }
@@ -183,7 +204,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   load_lambda(cfg, B, lds, lane, e, N, false);
   LDS_PHASE();
   PROF_DECL
-  physics_substep(cfg, B.height_samples, lds, ldsw, ldsx, lane, s, L, grav, cfg.warm_start != 0, cfg.sim_dt, fault PROF_PASS);
+  physics_substep(cfg, B.height_samples, lds, ldsw, ldsx, lane, 1, s, L, grav, cfg.warm_start != 0, cfg.sim_dt, fault PROF_PASS);
   store_state(B, leg, e, N, s, L);
   foot_state(s, L, leg, B, e, N);
   store_forces(cfg, B, lds, lane, e, N);
@@ -336,7 +357,7 @@ static int launch(Go1Sim* s, int mode, const float* actions, const int32_t* ids,
   A.history_slot = s->history_slot; A.mode = mode; A.ids = ids; A.n_ids = n_ids;
   const int n = (mode == 3) ? n_ids : s->cfg.num_envs;
   const int per_block = (mode == 3) ? WAVE : EPW;
-  dim3 grid((n + per_block - 1) / per_block), block(WAVE);
+  dim3 grid((n + per_block - 1) / per_block), block(mode == 0 ? WAVE * STEP_WAVES : WAVE);
   const int slot = timed ? (int)(s->timing_n % s->timing_cap) : 0;
   if (timed) (void)hipEventRecord(s->ev[2 * slot], st);
   if (mode == 0) hipLaunchKernelGGL(go1_step_kernel, grid, block, 0, st, A);

@@ -93,7 +93,7 @@ def active_rewards(cfg):
 
 
 def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curriculum=True,
-                     solver_iterations=8, warm_start=True, defer_curriculum_update=False):
+                     solver_iterations=4, warm_start=True, defer_curriculum_update=False):
     """Flatten `cfg` (a Cfg tree) into a Go1SimConfig.  Returns (struct, meta)."""
     S = abi.Go1SimConfig()
     S.abi_version = abi.GO1SIM_ABI_VERSION
