@@ -23,7 +23,7 @@ PHASES = ["load state/actions/warm start", "torque model (x4)", "kinematics + ca
 
 def build(flags):
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-hip-fp32-correctly-rounded-divide-sqrt"] + flags + \
+           "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"] + flags + \
           ["-o", os.path.join(CSRC, "libgo1sim.so"), os.path.join(CSRC, "go1sim.hip")]
     subprocess.check_call(cmd, cwd=CSRC)
 

@@ -931,7 +931,11 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     LDS(L_KL) = (float)K; LDS(L_KL + 1) = (float)lact;
   }
   BLOCK_SYNC(nw);
+#ifdef GO1_ROWS_HELPERS_ONLY
+  if (nw == 1) delassus_rows(lds, ldsw, rfl, lane, 0, 1);
+#else
   delassus_rows(lds, ldsw, rfl, lane, 0, nw);
+#endif
   BLOCK_SYNC(nw);
   SolveMasks sm;
   solver_masks(K, lact, legact, leg, sm);

@@ -57,7 +57,9 @@ DEV void report_fault(BufRef B, int e, uint32_t fault) {
 // environment, one per leg; the other wavefronts are helpers on the CU's other SIMDs: they take their share of the two
 // data-parallel blocks of every substep (the actuator network's row tiles, the rows of the Delassus matrix), fed through
 // LDS, and wait at workgroup barriers otherwise.  4096 environments -> 256 workgroups x 4 wavefronts: one per SIMD.
+#ifndef STEP_WAVES
 #define STEP_WAVES 4
+#endif
 extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(const StepArgs A) {
   __shared__ float lds[L_END * EPW];
   __shared__ __attribute__((aligned(16))) float ldsw[LDSW_SIZE];
@@ -89,7 +91,11 @@ extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(
 #endif
 #ifndef GO1_ABLATE_PHYSICS
       BLOCK_SYNC(nw);
+#ifdef GO1_ROWS_HELPERS_ONLY
+      delassus_rows(lds, ldsw, ldsx, lane, wv - 1, nw - 1);
+#else
       delassus_rows(lds, ldsw, ldsx, lane, wv, nw);
+#endif
       BLOCK_SYNC(nw);
 #endif
     }
