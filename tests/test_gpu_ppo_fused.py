@@ -431,6 +431,18 @@ def test_fused_adam_matches_torch_adam(lib):
     changed = (opt_sub.master != before).nonzero().flatten()
     expect = torch.cat((torch.arange(1000, 1500), torch.arange(70000, 70064))).cuda()
     assert torch.equal(changed, expect)
+    assert float(opt_sub.master.grad.min()) == 1.0          # zero_grad off: the gradient is left alone
+    # zero_grad: exactly the visited gradient elements (and the extra slot) are cleared, the step itself is unchanged
+    twin = fused.FusedAdam(lib, opt_sub.master.clone(), body.clone(), std.clone(), n_body, 1e-3, ranges=[(1000, 500), (70000, 64)])
+    twin.m.copy_(opt_sub.m); twin.v.copy_(opt_sub.v); twin.step.copy_(opt_sub.step)
+    twin.master.grad = torch.ones_like(master)
+    slot = torch.ones(1, device="cuda")
+    opt_sub.step_()
+    twin.step_(zero_grad=True, zero_slot=slot)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(twin.master, opt_sub.master, rtol=0, atol=0)
+    cleared = (twin.master.grad == 0).nonzero().flatten()
+    assert torch.equal(cleared, expect) and float(slot) == 0.0
 
 
 def make_alg(fused_on, N, T, seed=0):
@@ -498,6 +510,7 @@ def test_fused_minibatch_gradients_match_autograd(engine, monkeypatch):
     for stage in ("_stage_ppo_backward", "_stage_adapt_backward"):
         for alg in (ref, fus):
             alg._acc.zero_()
+            alg.master.grad.zero_()          # (update() / the fused optimiser steps keep the flat gradient clean between stages)
             getattr(alg, stage)(idx)
         torch.cuda.synchronize()
         np.testing.assert_allclose(fus._acc.cpu().numpy(), ref._acc.cpu().numpy(), rtol=1e-2, atol=1e-6)

@@ -565,10 +565,10 @@ __global__ __launch_bounds__(256) void prestep_kernel(const float* g, int64_t n,
   }
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t start0, int64_t count0,
+__global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m, float* v, int64_t start0, int64_t count0,
                                                    int64_t start1, int64_t count1, float gscale, const float* partial, float max_norm,
                                                    const float* step, const float* lr, float beta1, float beta2, float eps,
-                                                   bf16_t* body, int64_t n_body, float* tail) {
+                                                   bf16_t* body, int64_t n_body, float* tail, int zero_grad, float* zero_slot) {
   __shared__ float clip_s;
   if (threadIdx.x < 64) {
     float c = 1.f;
@@ -589,6 +589,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total; j += (int64_t)gridDim.x * 256) {
     const int64_t i = j < count0 ? start0 + j : start1 + (j - count0);
     const float gi = g[i] * gs;
+    if (zero_grad) g[i] = 0.f;          // the next backward pass accumulates into a clean gradient: no separate fill pass
     const float mi = beta1 * m[i] + (1.f - beta1) * gi;
     const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
     m[i] = mi;
@@ -598,6 +599,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     if (i < n_body) body[i] = f2bf(pi);
     else if (tail) tail[i - n_body] = pi;
   }
+  if (zero_slot && blockIdx.x == 0 && threadIdx.x == 0) *zero_slot = 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------- fused MLP tail (forward)
@@ -815,15 +817,16 @@ extern "C" int go1ppo_opt_prestep(const float* g, int64_t n, float gscale, float
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
-extern "C" int go1ppo_opt_adam(float* p, const float* g, float* m, float* v, int64_t start0, int64_t count0, int64_t start1,
+extern "C" int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t start0, int64_t count0, int64_t start1,
                                int64_t count1, float gscale, const float* partial, float max_norm, const float* step, const float* lr,
-                               float beta1, float beta2, float eps, void* body, int64_t n_body, float* tail, void* stream) {
+                               float beta1, float beta2, float eps, void* body, int64_t n_body, float* tail, int zero_grad,
+                               float* zero_slot, void* stream) {
   if (!p || !g || !m || !v || !step || !lr || !body || count0 < 0 || count1 < 0 || count0 + count1 <= 0) return -1;
   int64_t total = count0 + count1;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   adam_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, start0, count0, start1, count1, gscale, partial,
-                                                                             max_norm, step, lr, beta1, beta2, eps, (bf16_t*)body, n_body, tail);
+                                                                             max_norm, step, lr, beta1, beta2, eps, (bf16_t*)body, n_body, tail, zero_grad, zero_slot);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 

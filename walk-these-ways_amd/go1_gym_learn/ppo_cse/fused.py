@@ -115,7 +115,7 @@ def load_library(path=None):
     L.go1ppo_normalize.argtypes = [vp, i64, vp, vp]
     L.go1ppo_opt_partials.argtypes = []
     L.go1ppo_opt_prestep.argtypes = [vp, i64, f32, vp, vp, vp, vp, f32, f32, f32, f32, vp]
-    L.go1ppo_opt_adam.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, f32, vp, f32, vp, vp, f32, f32, f32, vp, i64, vp, vp]
+    L.go1ppo_opt_adam.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, f32, vp, f32, vp, vp, f32, f32, f32, vp, i64, vp, i32, vp, vp]
     for name in EXPORTED_SYMBOLS[:-1]:
         getattr(L, name).restype = ctypes.c_int
     L.go1ppo_version.restype = ctypes.c_char_p
@@ -220,7 +220,14 @@ class FusedNet:
                         "critic": torch.zeros(M, self.nc, **bf)}
             self.dY1 = torch.zeros(M, self.n1, **bf)
             self.dZ = {n: {li: torch.zeros_like(z) for li, z in zs.items()} for n, zs in self.Z.items()}
-            self._w1_tmp = torch.zeros(self.n1, policy.Kp, **bf)
+            # first-layer weight gradient on hipBLASLt: the output is small (n1 x Kp) and the reduction long (M rows), which
+            # the library's single-GEMM kernels split badly (0.74 PFLOP/s); as a BATCHED GEMM over row chunks — a manual
+            # split-K, partial products in bf16, summed into the fp32 gradient by the pass that used to be the cast — it
+            # runs 25 % faster (tools/probes/wgrad_splitk.py: 4 chunks of 6144 rows at M = 24576)
+            self._w1_split = next((b for b in (M // 6144, 4, 2) if b >= 2 and M % b == 0 and (M // b) % 64 == 0), 1)
+            if os.environ.get("GO1_W1_SPLIT"):
+                self._w1_split = int(os.environ["GO1_W1_SPLIT"])
+            self._w1_tmp = torch.zeros(self._w1_split, self.n1, policy.Kp, **bf)
 
     # ---- kernels -----------------------------------------------------------------------------------------
     def _elu(self, y, lat=None, lat_cols=0):
@@ -383,7 +390,7 @@ class FusedNet:
         self._mlp2_bwd("adaptation_only", [("adaptation", self.Y1d, d)])
         self._wgrad(dZ["adaptation"][2], Z["adaptation"][1], G["adaptation.2.W"], None)     # head bias: the MSE kernel's
         self._wgrad(dZ["adaptation"][1], self.Y1d, G["adaptation.1.W"], G["adaptation.1.b"])
-        self._big_wgrad(d, x, G["W1"][:nd], self._w1_tmp[:nd], self._w1_tn[1])
+        self._big_wgrad(d, x, G["W1"][:nd], self._w1_tmp[:, :nd], self._w1_tn[1])
 
     # ---- two-stream helpers ------------------------------------------------------------------------------------
     def _branch(self):
@@ -431,8 +438,13 @@ class FusedNet:
         if own_kernel:
             self._wgrad(dY, x, gW)
             return
-        torch.mm(dY.t(), x, out=tmp)
-        gW.copy_(tmp)
+        b = tmp.shape[0]
+        if b == 1 or not tmp.is_contiguous():
+            torch.mm(dY.t(), x, out=tmp[0])
+            gW.copy_(tmp[0])
+        else:
+            torch.bmm(dY.view(b, dY.shape[0] // b, dY.shape[1]).transpose(1, 2), x.view(b, x.shape[0] // b, x.shape[1]), out=tmp)
+            torch.sum(tmp, dim=0, dtype=torch.float32, out=gW)
 
     def _run_planned(self, key, fn):
         """first call: run `fn` recording its weight-gradient problems (nothing launched for them), build the device
@@ -496,7 +508,7 @@ class FusedNet:
         nd, d = self.nd, self.dH1["adaptation"]
         self._tail_bwd("adaptation", self.Y1d, d)
         self._elu_bwd(d, self.Y1d, None)
-        self._big_wgrad(d, x, self.G["W1"][:nd], self._w1_tmp[:nd], self._w1_tn[1])
+        self._big_wgrad(d, x, self.G["W1"][:nd], self._w1_tmp[:, :nd], self._w1_tn[1])
 
     # ---- losses ----------------------------------------------------------------------------------------------
     def ppo_loss(self, st, idx, std, g_std, A, kl, acc):
@@ -584,7 +596,9 @@ class FusedAdam:
         self.r0, self.r1 = r[0], r[1]
         self.n_norm = max(a + b for a, b in r)          # elements the global norm runs over (padding slots excluded)
 
-    def step_(self, gscale=1.0, max_norm=None, kl=None, kl_scale=1.0, desired_kl=0.01, lr_min=1e-5, lr_max=1e-2):
+    def step_(self, gscale=1.0, max_norm=None, kl=None, kl_scale=1.0, desired_kl=0.01, lr_min=1e-5, lr_max=1e-2, zero_grad=False,
+              zero_slot=None):
+        """zero_grad: clear the visited gradient elements (and `zero_slot`, a one-element tensor) inside the Adam kernel."""
         g = self.master.grad
         clip = max_norm is not None
         _chk(self.lib.go1ppo_opt_prestep(g.data_ptr(), self.n_norm, gscale, self.partial.data_ptr() if clip else None,
@@ -593,5 +607,6 @@ class FusedAdam:
         _chk(self.lib.go1ppo_opt_adam(self.master.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.r0[0], self.r0[1],
                                       self.r1[0], self.r1[1], gscale, self.partial.data_ptr() if clip else None,
                                       float(max_norm) if clip else 0.0, self.step.data_ptr(), self.lr.data_ptr(), self.betas[0],
-                                      self.betas[1], self.eps, self.body.data_ptr(), self.n_body, self.std.data_ptr(), _stream()),
+                                      self.betas[1], self.eps, self.body.data_ptr(), self.n_body, self.std.data_ptr(), int(zero_grad),
+                                      _ptr(zero_slot), _stream()),
              "go1ppo_opt_adam")

@@ -343,7 +343,8 @@ class PPO:
         with torch.no_grad():
             if not self._pregathered:         # graph mode gathers all mini-batches' rows once per update() instead
                 torch.index_select(self.storage.observation_histories.flatten(0, 1), 0, idx, out=net.X)
-            self.master.grad.zero_()          # also clears the KL slot
+            # (the flat gradient and the KL slot are clean here: update() clears them once, every fused optimiser step
+            # clears what it has consumed)
             net.forward(net.X)
             net.ppo_loss(self.storage, idx, self.std, self.master.grad[n:n + self.n_std], PPO_Args, self._kl, self._acc)
             net.backward(net.X)
@@ -353,7 +354,6 @@ class PPO:
         net = self._train_net          # net.X still holds this mini-batch's rows (gathered by the PPO stage)
         num_train = int(idx.numel() // 5 * 4)
         with torch.no_grad():
-            self.master.grad.zero_()
             net.forward_adaptation(net.X)
             net.adaptation_loss(self.storage, idx, num_train, PPO_Args.selective_adaptation_module_loss, self._acc)
             net.backward_adaptation(net.X)
@@ -395,7 +395,7 @@ class PPO:
             adaptive = A.desired_kl is not None and A.schedule == 'adaptive'
             w = float(_world()) if self.dp else 1.0
             self._opt.step_(gscale=1.0 / w, max_norm=A.max_grad_norm, kl=self._kl if adaptive else None, kl_scale=1.0 / w,
-                            desired_kl=A.desired_kl if adaptive else 0.0)
+                            desired_kl=A.desired_kl if adaptive else 0.0, zero_grad=True, zero_slot=self._kl)
             return
         g = self._g_live
         if self.dp:
@@ -428,7 +428,7 @@ class PPO:
 
     def _stage_adapt_step(self):
         if self._opt_ad is not None:
-            self._opt_ad.step_(gscale=1.0 / float(_world()) if self.dp else 1.0)
+            self._opt_ad.step_(gscale=1.0 / float(_world()) if self.dp else 1.0, zero_grad=True)
             return
         if self.dp:
             self.master.grad.div_(_world())
@@ -505,6 +505,8 @@ class PPO:
                 # their history rows are gathered once per update() (nmb gathers instead of epochs x nmb)
                 self._Xall = torch.zeros(nmb, mb, self.policy.Kp, device=self.device, dtype=self.body.dtype)
         self._acc.zero_()
+        if self.fused:
+            self.master.grad.zero_()          # once per update; afterwards the fused optimiser steps keep it clean (and the KL slot)
         indices = torch.randperm(nmb * mb, requires_grad=False, device=self.device)   # rollout_storage.py:103
         self._idx_all.copy_(indices.view(nmb, mb))
         use_graphs = (self.on_gpu and A.use_hip_graphs and A.num_adaptation_module_substeps == 1)
@@ -528,6 +530,7 @@ class PPO:
                             PPO_Args.use_hip_graphs = False
                             graph_mode = self._pregathered = False
                             torch.cuda.synchronize()
+                            self.master.grad.zero_()
                             self._minibatch_eager(idx)
                             continue
                     self._minibatch_replay(i)
