@@ -29,6 +29,8 @@
 #define GO1_CONSTANT            /* constant address space: plain pointers on the host */
 #define HIP_SYMBOL(x) x
 #define LDS_PHASE() emu::wave_barrier()
+#define VALUE_BARRIER(x) ((void)0)
+#define WAVE_UNIFORM(x) (x)
 
 namespace emu {
 struct Lane {

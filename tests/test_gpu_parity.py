@@ -139,7 +139,10 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
                            ("commands", 1e-5, 0), ("gait_indices", 1e-5, 0), ("clock_inputs", 1e-4, 0),
                            ("desired_contact_states", 1e-4, 0), ("torques", 5e-3, 1e-3), ("foot_positions", 1e-3, 0),
                            ("episode_sums", 1e-3, 1e-3), ("command_sums", 1e-3, 1e-3), ("motor_offsets", 1e-6, 0),
-                           ("motor_strengths", 1e-6, 0), ("last_actions", 1e-6, 0)):
+                           ("motor_strengths", 1e-6, 0), ("last_actions", 1e-6, 0),
+                           # state the torque model carries (LDS stash in the step kernel, written back once per step)
+                           ("joint_pos_err_last", 1e-3, 0), ("joint_pos_err_last_last", 1e-3, 0), ("joint_vel_last", 2e-2, 1e-3),
+                           ("joint_vel_last_last", 2e-2, 1e-3), ("joint_pos_target", 1e-5, 0), ("lag_buffer", 1e-5, 0)):
             bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], tol, rt)
             bad_env |= bad.reshape(-1, N).any(0)
         bad, _ = frac_bad(Bg.obs_buf, Bc.obs_buf, 3e-3, 1e-3)

@@ -33,6 +33,17 @@ __shared__ unsigned long long s_prof[24];          // accumulated with fire-and-
 #ifndef LDS_PHASE
 #define LDS_PHASE() __builtin_amdgcn_wave_barrier()
 #endif
+// Pins a value to ONE rounded fp32 register.  Needed where the same value is rounded twice to a narrower type (the fp16
+// hi/lo split of the actuator network): left alone the compiler contracts `(f16)(x * r)` into a single-rounding
+// v_fma_mix at one use and keeps the double rounding f16(f32(x * r)) at the other, and hi + lo no longer adds up.
+#ifndef VALUE_BARRIER
+#define VALUE_BARRIER(x) asm volatile("" : "+v"(x))
+#endif
+// A value that is the same in every lane of the wavefront but that the compiler cannot prove uniform (the wavefront's index
+// in its workgroup): as a scalar it keeps loops over it on the scalar unit instead of turning them into masked vector loops.
+#ifndef WAVE_UNIFORM
+#define WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
 // hand-over between the wavefronts of a workgroup (nw of them); with one wavefront it degenerates to the marker above
 #define BLOCK_SYNC(nw) do { if ((nw) > 1) __syncthreads(); else LDS_PHASE(); } while (0)
 

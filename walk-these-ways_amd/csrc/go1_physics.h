@@ -40,9 +40,10 @@ enum {
   L_RI = L_RP + NRC,         // NRC   1 / W[r][r]
   L_LS = L_RI + NRC,         // NRC   contact impulses: start values in, solution out
   L_I0 = L_LS + NRC,         // 21    inverse of the base's articulated inertia (upper triangle): for the wavefronts that build W
-  L_KL = L_I0 + 21,          // 2     contacts in the solver list, mask of the legs whose limit rows are in the solve
+  L_KL = L_I0 + 21,          // 3     contacts in the solver list, mask of the legs whose limit rows are in the solve, 1: the build
+                             //       also adds W lambda_start to the rows' right-hand sides (see delassus_rows)
   L_W = L_RB,                // zero-filled at kernel start from here to L_END
-  L_END = L_KL + 2
+  L_END = L_KL + 3
 };
 #define LDS(f) lds[(f) * EPW + el]
 // Packed records, one per (row, environment), read with 16-byte LDS loads:
@@ -139,20 +140,10 @@ DEV void actuator_lds_init(float* a, int lane) {          // once per launch, al
   }
 }
 
-// The 12 row tiles of a substep are split over the workgroup's nw wavefronts (wave wv takes t = wv, wv + nw, ...): the
-// master wave (wv = 0, the one that runs the physics) writes the 192 input rows, everybody evaluates tiles, the master
-// collects the outputs.  Helper waves call it with master = false.
-DEV void actuator_net_mfma(float* a, float* io, int lane, int wv, int nw, bool master, const float in[3][6], float out[3]) {
+// The 12 row tiles of a substep are split over wavefronts: `actuator_tiles` evaluates tiles t = t0, t0 + ts, ... from the
+// 192 input rows in io[A_IN] and leaves the four partial sums of every row in io[A_OUT].
+DEV void actuator_tiles(const float* a, float* io, int lane, int t0, int ts) {
   typedef __attribute__((ext_vector_type(4))) float f4;
-  if (master) {
-#pragma unroll
-    for (int jj = 0; jj < 3; jj++) {
-      f4* p = reinterpret_cast<f4*>(io + A_IN + (3 * lane + jj) * 8);
-      p[0] = (f4){in[jj][0], in[jj][1], in[jj][2], in[jj][3]};
-      p[1] = (f4){in[jj][4], in[jj][5], 1.f, 0.f};
-    }
-  }
-  BLOCK_SYNC(nw);
   const int c = lane & 15, g = lane >> 4;
   float w0[8][7];
 #pragma unroll
@@ -172,7 +163,7 @@ DEV void actuator_net_mfma(float* a, float* io, int lane, int wv, int nw, bool m
     for (int q = 0; q < 4; q++) { b1v[4 * i + q] = bb[q]; w2v[4 * i + q] = ww[q]; }
   }
 #pragma unroll 1
-  for (int t = wv; t < 12; t += nw) {
+  for (int t = t0; t < 12; t += ts) {
     const f4* pin = reinterpret_cast<const f4*>(io + A_IN + (16 * t + c) * 8);
     const f4 x0 = pin[0], x1 = pin[1];
     act_f16x8 bhi, blo;
@@ -181,7 +172,8 @@ DEV void actuator_net_mfma(float* a, float* io, int lane, int wv, int nw, bool m
       float s0 = w0[kk][6];
       s0 = fmaf(w0[kk][0], x0[0], s0); s0 = fmaf(w0[kk][1], x0[1], s0); s0 = fmaf(w0[kk][2], x0[2], s0);
       s0 = fmaf(w0[kk][3], x0[3], s0); s0 = fmaf(w0[kk][4], x1[0], s0); s0 = fmaf(w0[kk][5], x1[1], s0);
-      const float h = softsign(s0);
+      float h = softsign(s0);
+      VALUE_BARRIER(h);
       const _Float16 hh = (_Float16)h;
       bhi[kk] = hh;
       blo[kk] = (_Float16)(h - (float)hh);
@@ -198,14 +190,30 @@ DEV void actuator_net_mfma(float* a, float* io, int lane, int wv, int nw, bool m
     }
     io[A_OUT + 192 * g + 16 * t + c] = part;      // the 4 lanes (g = 0..3) holding the same row: partials meet in LDS
   }
-  BLOCK_SYNC(nw);
-  if (master) {
+}
+DEV void actuator_publish(float* io, int lane, const float in[3][6]) {       // the calling lane's three input rows
+  typedef __attribute__((ext_vector_type(4))) float f4;
 #pragma unroll
-    for (int jj = 0; jj < 3; jj++) {
-      const int r = 3 * lane + jj;
-      out[jj] = ((io[A_OUT + r] + io[A_OUT + 192 + r]) + (io[A_OUT + 384 + r] + io[A_OUT + 576 + r])) + GO1_ACT_B2;
-    }
+  for (int jj = 0; jj < 3; jj++) {
+    f4* p = reinterpret_cast<f4*>(io + A_IN + (3 * lane + jj) * 8);
+    p[0] = (f4){in[jj][0], in[jj][1], in[jj][2], in[jj][3]};
+    p[1] = (f4){in[jj][4], in[jj][5], 1.f, 0.f};
   }
+}
+DEV void actuator_collect(const float* io, int lane, float out[3]) {
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+    const int r = 3 * lane + jj;
+    out[jj] = ((io[A_OUT + r] + io[A_OUT + 192 + r]) + (io[A_OUT + 384 + r] + io[A_OUT + 576 + r])) + GO1_ACT_B2;
+  }
+}
+// Everything in one call (the piecewise entry points and workgroups of one wavefront): wave wv of nw takes tiles wv, wv + nw, ...
+DEV void actuator_net_mfma(float* a, float* io, int lane, int wv, int nw, bool master, const float in[3][6], float out[3]) {
+  if (master) actuator_publish(io, lane, in);
+  BLOCK_SYNC(nw);
+  actuator_tiles(a, io, lane, wv, nw);
+  BLOCK_SYNC(nw);
+  if (master) actuator_collect(io, lane, out);
 }
 
 struct Leg {             // the calling lane's leg
@@ -262,6 +270,90 @@ DEV void compute_torques(CfgRef cfg, BufRef B, Leg& L, int leg, int e, int N, in
     t = fminf(fmaxf(t, -lim), lim);
     L.tau[jj] = t;
     AT(B.torques, j, e) = t;
+  }
+}
+
+// ---- the torque model OFF the critical path (step kernel, workgroups of several wavefronts) ----------------------------
+// The actuator network only needs q, qd and the history; the first third of a substep (kinematics, contact candidates,
+// ABA pass 1) does not need the torques.  So the master wavefront publishes the 192 input rows, the HELPER wavefronts
+// evaluate all 12 tiles while the master runs the kinematics, and the master picks the torques up right before ABA pass 2.
+// What compute_torques() keeps in global memory between substeps (actuator history, lagged targets) lives in a per-lane LDS
+// stash for the duration of the step: loaded by the prologue in one batch (torque_stash_load), written back once
+// (torque_stash_store).  Same arithmetic in the same order as compute_torques(): results are bit-identical.
+#define ACT_MAX_DEC 4
+enum { AH_E1 = 0, AH_E2 = 3, AH_V1 = 6, AH_V2 = 9, AH_MS = 12, AH_MO = 15, AH_TGT = 18, AH_END = AH_TGT + 3 * ACT_MAX_DEC };
+#define ACTH(k) acth[(k) * WAVE + lane]
+
+// act[jj]: the clipped action.  All loads of the lag buffer come before its stores (a substep reads the slot the NEXT
+// substep overwrites).
+DEV void torque_stash_load(CfgRef cfg, BufRef B, float* acth, int lane, int leg, int e, int N, int head, const float act[3]) {
+  const int nl = cfg.lag_timesteps + 1;
+  float a[3], tg[ACT_MAX_DEC][3];
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+    a[jj] = act[jj] * cfg.action_scale;
+    if (jj == 0) a[jj] *= cfg.hip_scale_reduction;
+  }
+#pragma unroll
+  for (int sb = 0; sb < ACT_MAX_DEC; sb++)
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      float t = a[jj];
+      if (cfg.use_lag && sb < cfg.decimation && sb + 1 < nl) t = B.lag_buffer[((size_t)((head + sb + 1) % nl) * 12 + j) * N + e];
+      tg[sb][jj] = t + cfg.default_dof_pos[j];
+    }
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+    const int j = 3 * leg + jj;
+    ACTH(AH_E1 + jj) = AT(B.joint_pos_err_last, j, e);
+    ACTH(AH_E2 + jj) = AT(B.joint_pos_err_last_last, j, e);
+    ACTH(AH_V1 + jj) = AT(B.joint_vel_last, j, e);
+    ACTH(AH_V2 + jj) = AT(B.joint_vel_last_last, j, e);
+    ACTH(AH_MS + jj) = AT(B.motor_strengths, j, e);
+    ACTH(AH_MO + jj) = AT(B.motor_offsets, j, e);
+  }
+#pragma unroll
+  for (int sb = 0; sb < ACT_MAX_DEC; sb++)
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      ACTH(AH_TGT + 3 * sb + jj) = tg[sb][jj];
+      if (cfg.use_lag && sb < cfg.decimation) B.lag_buffer[((size_t)((head + sb) % nl) * 12 + 3 * leg + jj) * N + e] = a[jj];
+    }
+}
+// input rows of substep `sub` into io[A_IN]; the history advances
+DEV void torque_publish(const Leg& L, float* acth, float* io, int lane, int sub) {
+  float in[3][6];
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+    const float err = L.q[jj] - ACTH(AH_TGT + 3 * sub + jj) + ACTH(AH_MO + jj);
+    const float e1 = ACTH(AH_E1 + jj), e2 = ACTH(AH_E2 + jj), v1 = ACTH(AH_V1 + jj), v2 = ACTH(AH_V2 + jj);
+    in[jj][0] = err; in[jj][1] = e1; in[jj][2] = e2; in[jj][3] = L.qd[jj]; in[jj][4] = v1; in[jj][5] = v2;
+    ACTH(AH_E2 + jj) = e1; ACTH(AH_E1 + jj) = err; ACTH(AH_V2 + jj) = v1; ACTH(AH_V1 + jj) = L.qd[jj];
+  }
+  actuator_publish(io, lane, in);
+}
+DEV void torque_collect(CfgRef cfg, Leg& L, const float* acth, const float* io, int lane, int leg, uint32_t& fault) {
+  float tq[3];
+  actuator_collect(io, lane, tq);
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+    float t = tq[jj] * ACTH(AH_MS + jj);
+    if (!(fabsf(t) <= 3.0e38f)) { fault |= 1u << GO1_FAULT_TORQUE; t = 0.f; }
+    const float lim = cfg.torque_limits[3 * leg + jj];
+    L.tau[jj] = fminf(fmaxf(t, -lim), lim);
+  }
+}
+DEV void torque_stash_store(CfgRef cfg, BufRef B, const Leg& L, const float* acth, int lane, int leg, int e, int N) {
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+    const int j = 3 * leg + jj;
+    AT(B.joint_pos_err_last, j, e) = ACTH(AH_E1 + jj);
+    AT(B.joint_pos_err_last_last, j, e) = ACTH(AH_E2 + jj);
+    AT(B.joint_vel_last, j, e) = ACTH(AH_V1 + jj);
+    AT(B.joint_vel_last_last, j, e) = ACTH(AH_V2 + jj);
+    AT(B.joint_pos_target, j, e) = ACTH(AH_TGT + 3 * (cfg.decimation - 1) + jj);
+    AT(B.torques, j, e) = L.tau[jj];
   }
 }
 
@@ -425,7 +517,12 @@ DEV void lane_columns(const float* rfl, const Sym6& I0inv, int leg, int el, unsi
 // Rows wv, wv + nw, ... of the rows that exist somewhere in the wavefront (every wavefront of the workgroup takes its part;
 // within a wavefront lane `leg` writes the columns c = leg + 4 cc it owns in the sweep).  Inputs come from LDS only: the row
 // functionals, the base's inverse inertia, the per-environment row counts.
-DEV void delassus_rows(const float* lds, float* ldsw, const float* rfl, int lane, int wv, int nw) {
+// Warm start in the build: the sweep starts from the row velocities u = b + W lambda_start; the wavefront that builds row r
+// has the whole row in its lanes, so it adds the row's W lambda_start to the stored b (one FMA per entry and a quad sum)
+// instead of the master wavefront streaming the matrix a second time before the first sweep.  Not when some environment
+// of the wavefront has leg-leg self-contacts: their rows are corrected after the build (flag in L_KL + 2).
+DEV void delassus_rows(float* lds, float* ldsw, float* rfl, int lane, int wv, int nw PROF_PARAM) {
+  float* const jrl = rfl + NRT * EPW * RF_ST;
   const int leg = lane & 3, el = lane >> 2;
   Sym6 I0inv;
 #pragma unroll
@@ -437,6 +534,14 @@ DEV void delassus_rows(const float* lds, float* ldsw, const float* rfl, int lane
   SV Y[NCC];
   float ud[NCC][3], lg[NCC];
   lane_columns(rfl, I0inv, leg, el, m.ccw, Y, ud, lg);
+  const bool warm_in_build = __ballot(LDS(L_KL + 2) != 0.f) != 0ull;
+  float lamc[NCC];
+#pragma unroll
+  for (int cc = 0; cc < NCC; cc++) {
+    const int c = leg + 4 * cc;
+    lamc[cc] = (warm_in_build && c < 3 * K && c < NRC) ? LDS(L_LS + (c < NRC ? c : 0)) : 0.f;      // (limit rows start from 0)
+  }
+  PROF(3);
   // The loop body is branch-free apart from the wave-uniform skips; the next row's record is fetched while this row's
   // entries are computed.
   auto row_here = [&](int rr) { return (rr % nw) == wv && (rr < NRC ? (rr < 3 * m.Kw) : (((m.LAw >> ((rr - NRC) / 3)) & 1u) != 0u)); };
@@ -465,12 +570,25 @@ DEV void delassus_rows(const float* lds, float* ldsw, const float* rfl, int lane
     WSH4(r, 0) = (lf4){wv_[0], wv_[1], wv_[2], wv_[3]};
     WSH4(r, 1) = (lf4){wv_[4], wv_[5], wv_[6], wv_[7]};
     if (m.ccw & 0x100u) WSH8(r) = wv_[8];
+    if (warm_in_build) {
+      float uw = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < NCC; cc++) uw = fmaf(wv_[cc], lamc[cc], uw);      // (inactive slots: entry and impulse are 0)
+      uw = quad_sum(uw);
+      const bool row_on = r < NRC ? (r < 3 * K) : (((lact >> ((r - NRC) / 3)) & 1u) != 0u);
+      if (leg == 0 && row_on) {
+        if (r < NRC) LDS(L_RB + (r < NRC ? r : 0)) += uw;
+        else JR(r < NRC ? 0 : r - NRC)[0] += uw;
+      }
+    }
     r = rn;
   }
 }
 
+// acth != nullptr: the torques of this substep are being evaluated by the helper wavefronts (torque_publish was called, the
+// workgroup barrier behind it passed): they are picked up right before ABA pass 2.
 DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds, float* ldsw, float* rfl, int lane, int nw, Base& s, Leg& L, V3 grav,
-                         bool use_warm, float h, uint32_t& fault PROF_PARAM) {
+                         bool use_warm, float h, uint32_t& fault, const float* acth PROF_PARAM) {
   float* const jrl = rfl + NRT * EPW * RF_ST;
   const int leg = lane & 3, el = lane >> 2;
   const M3 R0 = quat_to_mat(s.qx, s.qy, s.qz, s.qw);
@@ -574,6 +692,10 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
 #endif
       cand_try(cfg, hs, cf, p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2]);
       pknee = p[2]; pfoot = p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)); vleg2 = v[2];
+    }
+    if (acth) {
+      BLOCK_SYNC(nw);                       // the helpers' partial sums are in io[A_OUT]
+      torque_collect(cfg, L, acth, ldsw, lane, leg, fault);
     }
     // ABA pass 2: calf -> thigh -> hip, then quad-sum into the base
     SV pa_hip;
@@ -733,6 +855,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     slot_b0 = act_b0 && ofs_b0 < MAXC ? ofs_b0 : -1;
     slot_b1 = act_b1 && ofs_b0 + (act_b0 ? 1 : 0) < MAXC ? ofs_b0 + (act_b0 ? 1 : 0) : -1;
   }
+  PROF(19);
   const float e_c = 0.5f * (s.rest + cfg.terrain_restitution);
   // warm start: a body's previous impulse is shared equally by its listed points
   const float share_k = (slot[1] >= 0 && slot[2] >= 0) ? 0.5f : 1.f, share_t = (slot[3] >= 0 && slot[4] >= 0) ? 0.5f : 1.f,
@@ -770,6 +893,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   //     W[r][c] = g_r . (I0^-1 g_c)  +  [same leg] sum_j u_j(r) u_j(c) / D_j
   // (legs couple only through the base).  A contact row starts from the spatial force of the unit impulse at the contact
   // point, a joint row from the unit generalised impulse at its joint.
+  PROF(20);
   auto emit = [&](int k, const Cand& c, int depth, int body, float share) {      // depth < 0: trunk
     const V3 n = v3(c.nx, c.ny, c.nz);
     V3 t1, t2;
@@ -928,15 +1052,17 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   if (leg == 0) {
 #pragma unroll
     for (int i = 0; i < 21; i++) LDS(L_I0 + i) = I0inv.m[i];
-    LDS(L_KL) = (float)K; LDS(L_KL + 1) = (float)lact;
+    LDS(L_KL) = (float)K; LDS(L_KL + 1) = (float)lact; LDS(L_KL + 2) = selfw ? 0.f : 1.f;
   }
   BLOCK_SYNC(nw);
+  PROF(19);            // (profile builds: the wait at the first barrier is booked on phase 19)
 #ifdef GO1_ROWS_HELPERS_ONLY
-  if (nw == 1) delassus_rows(lds, ldsw, rfl, lane, 0, 1);
+  if (nw == 1) delassus_rows(lds, ldsw, rfl, lane, 0, 1 PROF_PASS);
 #else
-  delassus_rows(lds, ldsw, rfl, lane, 0, nw);
+  delassus_rows(lds, ldsw, rfl, lane, 0, nw PROF_PASS);
 #endif
   BLOCK_SYNC(nw);
+  PROF(21);
   SolveMasks sm;
   solver_masks(K, lact, legact, leg, sm);
   const int Kw = sm.Kw;
@@ -997,6 +1123,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     }
   }
   LDS_PHASE();
+  PROF(22);
   // row records from the finished matrix: every lane reads back the diagonal entries of its own columns, and the owner
   // of a contact's normal column the two entries that couple the tangent rows to it
 #pragma unroll
@@ -1060,6 +1187,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       }
       if (ccw & 0x100u) uloc[8] = fmaf(WSH8(c), dl, uloc[8]);
     };
+    if (selfw)                                                 // (otherwise the build has already added W lambda_start to b)
 #pragma unroll
     for (int k = 0; k < MAXC; k++) {                           // warm start: the starting impulses' velocities
       if (k < Kw) {
@@ -1067,6 +1195,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
         for (int i = 0; i < 3; i++) apply_col(3 * k + i, lam[3 * k + i]);
       }
     }
+    PROF(23);
 #pragma unroll 1
     for (int it = 0; it < cfg.solver_iterations; it++) {
 #pragma unroll

@@ -65,7 +65,8 @@ extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(
   __shared__ __attribute__((aligned(16))) float ldsw[LDSW_SIZE];
   __shared__ __attribute__((aligned(16))) float ldsx[LDSX_SIZE];
   __shared__ __attribute__((aligned(16))) float act_lds[A_END];
-  const int nw = STEP_WAVES, wv = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63, leg = lane & 3;
+  __shared__ float acth[AH_END * WAVE];          // per-lane stash of the deferred torque path (torque_stash_load)
+  const int nw = STEP_WAVES, wv = WAVE_UNIFORM((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63, leg = lane & 3;
   for (int i = threadIdx.x; i < (L_END - L_W) * EPW; i += WAVE * STEP_WAVES) lds[L_W * EPW + i] = 0.f;   // finite everywhere: see the PGS column split
   {
     typedef __attribute__((ext_vector_type(4))) float zf4;
@@ -79,22 +80,32 @@ extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(
   const int e = blockIdx.x * EPW + (lane >> 2);
   const bool full_wave = (int)(blockIdx.x + 1) * EPW <= N;      // the MFMA torque model needs all 64 lanes
   const bool mfma_torque = full_wave && cfg.control_type == 1;
+#if defined(GO1_ABLATE_TORQUE) || defined(GO1_ABLATE_PHYSICS) || defined(GO1_NO_DEFERRED_TORQUE)
+  const bool deferred = false;
+#else
+  const bool deferred = mfma_torque && nw > 1 && cfg.decimation <= ACT_MAX_DEC;      // torque model entirely on the helper wavefronts
+#endif
   if (mfma_torque && wv == 0) actuator_lds_init(act_lds, lane);
   PROF_INIT
   __syncthreads();
   if (e >= N) return;
   if (wv != 0) {           // helper wavefront: the same sequence of workgroup barriers as the master's substep loop
+    PROF_DECL
 #pragma unroll 1
     for (int sub = 0; sub < cfg.decimation; sub++) {
 #ifndef GO1_ABLATE_TORQUE
-      if (mfma_torque) actuator_net_mfma(act_lds, ldsw, lane, wv, nw, false, nullptr, nullptr);
+      if (deferred) {
+        BLOCK_SYNC(nw);                                   // the master's input rows are in LDS
+        actuator_tiles(act_lds, ldsw, lane, wv - 1, nw - 1);
+        BLOCK_SYNC(nw);                                   // (the master arrives here when it needs the torques)
+      } else if (mfma_torque) actuator_net_mfma(act_lds, ldsw, lane, wv, nw, false, nullptr, nullptr);
 #endif
 #ifndef GO1_ABLATE_PHYSICS
       BLOCK_SYNC(nw);
 #ifdef GO1_ROWS_HELPERS_ONLY
-      delassus_rows(lds, ldsw, ldsx, lane, wv - 1, nw - 1);
+      delassus_rows(lds, ldsw, ldsx, lane, wv - 1, nw - 1 PROF_PASS);
 #else
-      delassus_rows(lds, ldsw, ldsx, lane, wv, nw);
+      delassus_rows(lds, ldsw, ldsx, lane, wv, nw PROF_PASS);
 #endif
       BLOCK_SYNC(nw);
 #endif
@@ -120,10 +131,14 @@ extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(
   load_lambda(cfg, B, lds, lane, e, N, !warm);
   LDS_PHASE();           // the trunk's warm-start impulse is read by all four lanes of the environment
   const V3 grav = gravity_at(cfg, A.counter);
+  float act_clipped[3];
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) act_clipped[jj] = fminf(fmaxf(act_in[jj], -cfg.clip_actions), cfg.clip_actions);
+  if (deferred) torque_stash_load(cfg, B, acth, lane, leg, e, N, A.lag_head, act_clipped);
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) {
     const int j = 3 * leg + jj;
-    AT(B.actions, j, e) = fminf(fmaxf(act_in[jj], -cfg.clip_actions), cfg.clip_actions);
+    AT(B.actions, j, e) = act_clipped[jj];
     AT(B.prev_foot_velocities, j, e) = fv_in[jj];
   }
   {
@@ -142,14 +157,19 @@ extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(
 #pragma unroll 1
   for (int sub = 0; sub < cfg.decimation; sub++) {
 #ifndef GO1_ABLATE_TORQUE
-    compute_torques(cfg, B, L, leg, e, N, head, act_lds, ldsw, full_wave, nw, fault);
+    if (deferred) {
+      torque_publish(L, acth, ldsw, lane, sub);
+      BLOCK_SYNC(nw);
+    } else compute_torques(cfg, B, L, leg, e, N, head, act_lds, ldsw, full_wave, nw, fault);
 #endif
     PROF(1);
     head = (head + 1) % nl;
 #ifndef GO1_ABLATE_PHYSICS
-    physics_substep(cfg, B.height_samples, lds, ldsw, ldsx, lane, nw, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault PROF_PASS);
+    physics_substep(cfg, B.height_samples, lds, ldsw, ldsx, lane, nw, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault,
+                    deferred ? acth : nullptr PROF_PASS);
 #endif
   }
+  if (deferred) torque_stash_store(cfg, B, L, acth, lane, leg, e, N);
   store_state(B, leg, e, N, s, L);
   foot_state(s, L, leg, B, e, N);
   store_forces(cfg, B, lds, lane, e, N);
@@ -210,7 +230,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   load_lambda(cfg, B, lds, lane, e, N, false);
   LDS_PHASE();
   PROF_DECL
-  physics_substep(cfg, B.height_samples, lds, ldsw, ldsx, lane, 1, s, L, grav, cfg.warm_start != 0, cfg.sim_dt, fault PROF_PASS);
+  physics_substep(cfg, B.height_samples, lds, ldsw, ldsx, lane, 1, s, L, grav, cfg.warm_start != 0, cfg.sim_dt, fault, nullptr PROF_PASS);
   store_state(B, leg, e, N, s, L);
   foot_state(s, L, leg, B, e, N);
   store_forces(cfg, B, lds, lane, e, N);
