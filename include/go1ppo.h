@@ -139,6 +139,24 @@ int go1ppo_gae(const float* rewards, const uint8_t* dones, const float* values, 
 /* adv = (adv - mean) / (std + 1e-8) with the unbiased std of stats = [sum, sum of squares, count]. */
 int go1ppo_normalize(float* adv, int64_t n, const double* stats, void* stream);
 
+/* ---- observation ring (replaces the (T, N, H * num_obs) history block of rollout_storage.py:36-38) ----
+ * ring: bf16 [T + H - 1][N][no] (no even); the history window of rollout step s is rows s .. s + H - 1 (oldest first).
+ * Augmented GEMM rows (Kp bf16, Kp even, Kp >= H * no + 1 + npv): [window | 1 | privileged obs | 0 ...]. */
+
+/* rows 0 .. H - 1 of the ring <- the environments' fp32 history windows hist[n * ld_hist + j * no + c] (first step of a
+ * rollout: from there on only the newest observation is appended, history_wrapper.py:23's sliding window). */
+int go1ppo_ring_snapshot(const float* hist, int64_t ld_hist, int64_t N, int H, int no, void* ring, void* stream);
+
+/* One rollout step: ring_dst (row s + H - 1 of the ring, or NULL when the snapshot already wrote it) <- bf16(obs);
+ * X (N x Kp) <- augmented rows of the windows starting at ring_window (= row s), the newest entry taken from `obs`;
+ * obs_store / priv_store (fp32, or NULL) <- copies of obs (N x no) and priv (N x npv). */
+int go1ppo_ring_step(const float* obs, const float* priv, void* ring_dst, const void* ring_window, int64_t N, int H, int no,
+                     int npv, int Kp, void* X, float* obs_store, float* priv_store, void* stream);
+
+/* X (rows x Kp) <- augmented rows of the storage entries idx[i] = s * N + n; priv_store: fp32 [T * N][npv]. */
+int go1ppo_ring_gather(const void* ring, const float* priv_store, const int64_t* idx, int64_t rows, int64_t N, int H, int no,
+                       int npv, int Kp, void* X, void* stream);
+
 /* ---- optimiser step (ppo.py:126-160: adaptive-KL learning rate, clip_grad_norm_, Adam) ---- */
 
 /* number of floats `partial` must hold */

@@ -563,3 +563,59 @@ def test_fused_update_tracks_autograd_update(use_graphs, engine, monkeypatch):
     moved = float((w0 - w_init).norm())
     rel = float((w1 - w0).norm()) / moved
     assert moved > 0 and rel < 0.1, (rel, moved)
+
+
+def test_observation_ring_storage_is_bit_identical_to_the_history_block():
+    """RolloutStorage(ring=True) — every observation stored once, (T + H - 1, N, 70) bf16 — against the reference layout
+    (rollout_storage.py:36-38: every window stored, here (T, N, 2112) bf16): same sliding-window input stream
+    (history_wrapper.py:23), then (a) the inference rows of every rollout step, (b) the stored obs / privileged obs, (c) the
+    gathered mini-batch rows X of a shuffled index set — all bit for bit — and (d) two full update() calls: same losses and
+    weights up to the run-to-run round-off of the update's atomic accumulations."""
+    from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    N, T, H, no = 512, 8, 30, 70
+    algs = []
+    for ring in (False, True):
+        alg = make_alg(True, N, T)
+        if ring:
+            alg.init_storage(N, T, [70], [2], [2100], [12], sliding_history=True)
+        assert alg.storage.ring == ring
+        algs.append(alg)
+    full, ring = algs
+    assert ring.storage.observation_histories is None and tuple(ring.storage.obs_ring.shape) == (T + H - 1, N, no)
+    assert ring.storage.obs_ring.numel() * 4 < full.storage.observation_histories.numel()          # (T = 8: 6.5x; T = 24: 13.6x)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    # a history that is NOT all-zero at the start of the first rollout and lives in a wider strided buffer, like the env's ring view
+    wide = torch.randn(N, 2 * (H + 1) * no, device="cuda", generator=g)
+    off = 3 * no
+    for rollout in range(2):
+        for t in range(T):
+            obs = torch.randn(N, no, device="cuda", generator=g)
+            priv = torch.randn(N, 2, device="cuda", generator=g)
+            wide[:, off:off + (H - 1) * no] = wide[:, off + no:off + H * no].clone()       # slide, append
+            wide[:, off + (H - 1) * no:off + H * no] = obs
+            hist = wide[:, off:off + H * no]
+            rew = torch.randn(N, device="cuda", generator=g)
+            for alg in (full, ring):
+                torch.manual_seed(100 * rollout + t)
+                a = alg.act(obs, priv, hist)
+                if alg is ring:
+                    assert torch.equal(alg._X_roll, full.storage.observation_histories[t]), (rollout, t)
+                    assert torch.equal(a, a_full)
+                a_full = a.clone()
+                alg.process_env_step(rew, torch.zeros(N, dtype=torch.uint8, device="cuda"),
+                                     {"env_bins": torch.zeros(N, dtype=torch.int32, device="cuda"), "time_outs": torch.zeros(N, dtype=torch.bool, device="cuda")})
+        for k in ("observations", "privileged_observations", "actions", "values", "rewards", "mu", "actions_log_prob"):
+            assert torch.equal(getattr(ring.storage, k), getattr(full.storage, k)), k
+        idx = torch.randperm(N * T, device="cuda")[:N * T // 4]
+        Xf, Xr = (torch.zeros(idx.numel(), alg.policy.Kp, device="cuda", dtype=torch.bfloat16) for alg in (full, ring))
+        full._gather_rows(idx, Xf)
+        ring._gather_rows(idx, Xr)
+        assert torch.equal(Xf, Xr)
+        out = []
+        for alg in (full, ring):
+            alg.compute_returns(hist, priv)
+            torch.manual_seed(7 + rollout)
+            out.append(alg.update())
+        # identical inputs; the update itself sums weight gradients and losses with fp32 atomics (run-to-run round-off)
+        np.testing.assert_allclose(out[1], out[0], rtol=1e-3, atol=1e-6)
+        torch.testing.assert_close(ring.master, full.master, rtol=0, atol=2e-4)

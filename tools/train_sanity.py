@@ -72,7 +72,7 @@ def main():
             runner.alg.compute_returns(obs_dict["obs_history"][:n], obs_dict["privileged_obs"][:n])
         if args.check_finite:
             st = runner.alg.storage
-            pre = {k: getattr(st, k) for k in ("observation_histories", "privileged_observations", "actions", "rewards", "values", "returns",
+            pre = {k: getattr(st, k) for k in ("obs_ring" if st.ring else "observation_histories", "privileged_observations", "actions", "rewards", "values", "returns",
                                                "advantages", "mu", "sigma", "actions_log_prob")}
             bad = [k for k, t in pre.items() if not torch.isfinite(t.float()).all()]
             if bad:

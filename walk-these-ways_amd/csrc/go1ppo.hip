@@ -803,6 +803,104 @@ extern "C" int go1ppo_gae(const float* rewards, const uint8_t* dones, const floa
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
+// ---------------------------------------------------------------------------------------------- observation ring
+// The rollout storage of the observation histories (reference rollout_storage.py:36-38: a (T, N, H * num_obs) block) holds
+// every observation H times: consecutive windows overlap in H - 1 entries.  The ring keeps each observation ONCE —
+// ring[t][n][num_obs] in bf16, t = 0 .. T + H - 2, the window of rollout step s being rows s .. s + H - 1 — and the
+// augmented GEMM rows [window | 1 | privileged | 0 pad] are assembled where they are consumed: for the inference of the
+// current step (ring_step) and for the rows of a mini-batch (ring_gather).  One thread per output dword (two bf16).
+__device__ __forceinline__ uint32_t ring_pack(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+// one augmented row: the window's H entries are `no`/2 dwords each, entry j read from win + j * stride
+__device__ __forceinline__ void ring_row(const uint32_t* __restrict__ win, int64_t stride_dw, const float* __restrict__ newest,
+                                         const float* __restrict__ priv, int H, int no, int npv, int Kp, uint32_t* __restrict__ out) {
+  const int nod = no >> 1, Kd = H * nod;
+  for (int d = threadIdx.x; d < (Kp >> 1); d += blockDim.x) {
+    uint32_t v;
+    if (d < Kd) {
+      const int j = d / nod, c = d - j * nod;
+      if (newest && j == H - 1) v = ring_pack(newest[2 * c], newest[2 * c + 1]);
+      else v = win[(int64_t)j * stride_dw + c];
+    } else {
+      float e[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int col = 2 * d + q - 2 * Kd;             // 0: the bias column, 1 .. npv: privileged observations, then padding
+        e[q] = col == 0 ? 1.f : (col <= npv ? priv[col - 1] : 0.f);
+      }
+      v = ring_pack(e[0], e[1]);
+    }
+    out[d] = v;
+  }
+}
+
+// rows 0 .. H-1 of the ring from the environment's fp32 history window (first step of a rollout)
+__global__ __launch_bounds__(256) void ring_snapshot_kernel(const float* __restrict__ hist, int64_t ld_hist, int64_t N, int H, int no,
+                                                            uint32_t* __restrict__ ring) {
+  const int nod = no >> 1;
+  const int64_t total = N * H * nod, i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % nod);
+  const int64_t r = i / nod, n = r % N, j = r / N;
+  const float* src = hist + n * ld_hist + j * no + 2 * c;
+  ring[(j * N + n) * nod + c] = ring_pack(src[0], src[1]);
+}
+
+// one workgroup per environment: append the new observation (row s + H - 1; dst == NULL: the snapshot already holds it),
+// assemble the inference row, keep the fp32 copies of obs / privileged obs the storage wants
+__global__ __launch_bounds__(256) void ring_step_kernel(const float* __restrict__ obs, const float* __restrict__ priv, uint32_t* __restrict__ dst,
+                                                        const uint32_t* __restrict__ window, int64_t N, int H, int no, int npv, int Kp,
+                                                        uint32_t* __restrict__ X, float* __restrict__ obs_store, float* __restrict__ priv_store) {
+  const int64_t n = blockIdx.x;
+  const int nod = no >> 1;
+  const float* o = obs + n * no;
+  const float* pv = priv + n * npv;
+  for (int c = threadIdx.x; c < nod; c += blockDim.x) {
+    if (dst) dst[n * nod + c] = ring_pack(o[2 * c], o[2 * c + 1]);
+    if (obs_store) { obs_store[n * no + 2 * c] = o[2 * c]; obs_store[n * no + 2 * c + 1] = o[2 * c + 1]; }
+  }
+  if (priv_store && threadIdx.x < npv) priv_store[n * npv + threadIdx.x] = pv[threadIdx.x];
+  ring_row(window + n * nod, N * nod, o, pv, H, no, npv, Kp, X + n * (Kp >> 1));
+}
+
+// one workgroup per mini-batch row: storage index f = s * N + n
+__global__ __launch_bounds__(256) void ring_gather_kernel(const uint32_t* __restrict__ ring, const float* __restrict__ priv_store,
+                                                          const int64_t* __restrict__ idx, int64_t N, int H, int no, int npv, int Kp,
+                                                          uint32_t* __restrict__ X) {
+  const int64_t f = idx[blockIdx.x], s = f / N, n = f - s * N;
+  const int nod = no >> 1;
+  ring_row(ring + (s * N + n) * nod, N * nod, nullptr, priv_store + f * npv, H, no, npv, Kp, X + (int64_t)blockIdx.x * (Kp >> 1));
+}
+
+extern "C" int go1ppo_ring_snapshot(const float* hist, int64_t ld_hist, int64_t N, int H, int no, void* ring, void* stream) {
+  if (!hist || !ring || N <= 0 || H <= 0 || no <= 0 || (no & 1) || ld_hist < (int64_t)H * no) return -1;
+  const int64_t total = N * H * (no >> 1);
+  ring_snapshot_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(hist, ld_hist, N, H, no, (uint32_t*)ring);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_ring_step(const float* obs, const float* priv, void* ring_dst, const void* ring_window, int64_t N, int H, int no,
+                                int npv, int Kp, void* X, float* obs_store, float* priv_store, void* stream) {
+  if (!obs || !priv || !ring_window || !X || N <= 0 || H <= 0 || no <= 0 || (no & 1) || npv < 0 || npv > 256 || (Kp & 1) ||
+      Kp < H * no + 1 + npv)
+    return -1;
+  ring_step_kernel<<<dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream>>>(obs, priv, (uint32_t*)ring_dst, (const uint32_t*)ring_window, N, H,
+                                                                            no, npv, Kp, (uint32_t*)X, obs_store, priv_store);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_ring_gather(const void* ring, const float* priv_store, const int64_t* idx, int64_t rows, int64_t N, int H, int no,
+                                  int npv, int Kp, void* X, void* stream) {
+  if (!ring || !priv_store || !idx || !X || rows <= 0 || N <= 0 || H <= 0 || no <= 0 || (no & 1) || npv < 0 || (Kp & 1) ||
+      Kp < H * no + 1 + npv)
+    return -1;
+  ring_gather_kernel<<<dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream>>>((const uint32_t*)ring, priv_store, idx, N, H, no, npv, Kp,
+                                                                                 (uint32_t*)X);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
 extern "C" int go1ppo_normalize(float* adv, int64_t n, const double* stats, void* stream) {
   if (!adv || !stats || n <= 0) return -1;
   normalize_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(adv, n, stats);

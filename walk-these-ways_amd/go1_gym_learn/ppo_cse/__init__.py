@@ -60,8 +60,10 @@ class Runner:
                 self.env.sync_curricula_to_device()
         self.alg = PPO(actor_critic, device=self.device)
         self.num_steps_per_env = RunnerArgs.num_steps_per_env
+        # HistoryWrapper: obs_history is a sliding window over obs that nothing rewrites during a rollout -> ring storage
         self.alg.init_storage(self.env.num_train_envs, self.num_steps_per_env, [self.env.num_obs],
-                              [self.env.num_privileged_obs], [self.env.num_obs_history], [self.env.num_actions])
+                              [self.env.num_privileged_obs], [self.env.num_obs_history], [self.env.num_actions],
+                              sliding_history=hasattr(self.env, "obs_history_length"))
         self.tot_timesteps = 0
         self.tot_time = 0
         self.current_learning_iteration = 0

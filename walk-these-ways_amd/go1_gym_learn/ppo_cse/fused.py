@@ -80,7 +80,7 @@ class GemmArgs(ctypes.Structure):
 
 EXPORTED_SYMBOLS = ["go1ppo_mlp2_fwd", "go1ppo_mlp2_bwd", "go1ppo_gemm_nt", "go1ppo_wgrad_tn_plan", "go1ppo_wgrad_tn_batched", "go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
                     "go1ppo_wgrad_batched", "go1ppo_act",
-                    "go1ppo_store_step", "go1ppo_gae", "go1ppo_normalize", "go1ppo_opt_partials", "go1ppo_opt_prestep",
+                    "go1ppo_store_step", "go1ppo_ring_snapshot", "go1ppo_ring_step", "go1ppo_ring_gather", "go1ppo_gae", "go1ppo_normalize", "go1ppo_opt_partials", "go1ppo_opt_prestep",
                     "go1ppo_opt_adam", "go1ppo_version"]
 
 
@@ -111,6 +111,9 @@ def load_library(path=None):
     f32 = ctypes.c_float
     L.go1ppo_act.argtypes = [vp, vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp]
     L.go1ppo_store_step.argtypes = [vp, vp, vp, vp, vp, f32, i64, vp, vp, vp, vp]
+    L.go1ppo_ring_snapshot.argtypes = [vp, i64, i64, i32, i32, vp, vp]
+    L.go1ppo_ring_step.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.go1ppo_ring_gather.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, i32, vp, vp]
     L.go1ppo_gae.argtypes = [vp, vp, vp, vp, i32, i64, f32, f32, vp, vp, vp, vp]
     L.go1ppo_normalize.argtypes = [vp, i64, vp, vp]
     L.go1ppo_opt_partials.argtypes = []
@@ -564,6 +567,35 @@ def store_step(lib, st, s, rewards, dones, time_outs, env_bins, gamma):
     _chk(lib.go1ppo_store_step(rewards.data_ptr(), dones.data_ptr(), _ptr(time_outs), _ptr(env_bins), st.values[s].data_ptr(), gamma, n,
                                st.rewards[s].data_ptr(), st.dones[s].data_ptr(), st.env_bins[s].data_ptr() if env_bins is not None else None,
                                _stream()), "go1ppo_store_step")
+
+
+# ---- observation ring (RolloutStorage(ring=True)) ----------------------------------------------------------------
+def ring_step(lib, st, s, obs, privileged_obs, obs_history, X):
+    """rollout step s: (s == 0: the whole window from the environment's fp32 history into ring rows 0 .. H-1;) append the
+    new observation, assemble the augmented inference rows X (N x Kp), store the fp32 obs / privileged obs of the step."""
+    N, no, H = st.num_envs, st.obs_ring.shape[2], st.history_length
+    npv = st.privileged_observations.shape[-1]
+    for t in (obs, privileged_obs):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] == N
+    assert X.dtype == torch.bfloat16 and X.is_contiguous() and tuple(X.shape) == (N, st.padded_width)
+    if s == 0:
+        assert obs_history.dtype == torch.float32 and obs_history.stride(1) == 1 and tuple(obs_history.shape) == (N, H * no)
+        _chk(lib.go1ppo_ring_snapshot(obs_history.data_ptr(), obs_history.stride(0), N, H, no, st.obs_ring.data_ptr(), _stream()),
+             "go1ppo_ring_snapshot")
+    dst = None if s == 0 else st.obs_ring[s + H - 1].data_ptr()
+    _chk(lib.go1ppo_ring_step(obs.data_ptr(), privileged_obs.data_ptr(), dst, st.obs_ring[s].data_ptr(), N, H, no, npv, st.padded_width,
+                              X.data_ptr(), st.observations[s].data_ptr(), st.privileged_observations[s].data_ptr(), _stream()),
+         "go1ppo_ring_step")
+
+
+def ring_gather(lib, st, idx, X):
+    """X (len(idx) x Kp) <- augmented history rows of the storage entries idx (flat index s * N + n)."""
+    N, no, H = st.num_envs, st.obs_ring.shape[2], st.history_length
+    priv = st.privileged_observations
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and X.is_contiguous() and tuple(X.shape) == (idx.numel(), st.padded_width)
+    assert priv.dtype == torch.float32 and priv.is_contiguous()
+    _chk(lib.go1ppo_ring_gather(st.obs_ring.data_ptr(), priv.data_ptr(), idx.data_ptr(), idx.numel(), N, H, no, priv.shape[-1],
+                                st.padded_width, X.data_ptr(), _stream()), "go1ppo_ring_gather")
 
 
 def gae(lib, st, last_values, gamma, lam, stats):

@@ -49,6 +49,7 @@ class PPO_Args(PrefixProto):
     # MI355X additions
     autocast_bf16 = False           # BASELINE config 2: "bf16 policy" (fp32 master weights + bf16 compute replica)
     data_parallel = True            # all-reduce gradients when torch.distributed is initialised with world_size > 1
+    history_ring = True             # keep each observation once when init_storage(..., sliding_history=True) allows it
     use_hip_graphs = True           # replay the mini-batch step as a HIP graph from the second update() on
     use_fused_kernels = True        # bf16 policy on a GPU: hand-scheduled forward/backward with csrc/go1ppo.hip (fused.py)
     use_tuned_gemms = True          # PyTorch TunableOp with the gfx950 table shipped in walk-these-ways_amd/tuning/
@@ -206,12 +207,20 @@ class PPO:
         return float(self._lr)
 
     def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, privileged_obs_shape, obs_history_shape,
-                     action_shape):
+                     action_shape, sliding_history=False):
+        """`sliding_history`: the caller guarantees that the `obs_history` it passes to act() is a sliding window over the
+        `obs` it passes (HistoryWrapper: each step drops the oldest entry and appends the new observation,
+        history_wrapper.py:23), and that it is not rewritten in the middle of a rollout.  On the fused GPU path the
+        storage then keeps every observation once (RolloutStorage ring) instead of every window."""
+        no = int(actor_obs_shape[0])
+        ring = bool(sliding_history and self.fused and PPO_Args.history_ring and no % 2 == 0 and int(obs_history_shape[0]) % no == 0)
         self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, privileged_obs_shape,
                                       obs_history_shape, action_shape, self.device,
-                                      history_dtype=self.body.dtype, history_pad_to=64, augment=True)
-        assert self.storage.observation_histories.shape[-1] == self.policy.Kp
-        self._last_hist = self.storage.observation_histories[0].clone()
+                                      history_dtype=self.body.dtype, history_pad_to=64, augment=True, ring=ring)
+        assert self.storage.padded_width == self.policy.Kp
+        self._last_hist = torch.zeros(num_envs, self.policy.Kp, device=self.device, dtype=self.body.dtype)
+        self._last_hist[:, self.storage.history_width] = 1.0
+        self._X_roll = torch.zeros_like(self._last_hist) if ring else None
         if self.fused:
             from go1_gym_learn.ppo_cse.fused import FusedNet
             self._roll_net = FusedNet(self.policy, self.body, None, num_envs, self._fused_lib, with_grad=False, two_streams=False)
@@ -225,6 +234,8 @@ class PPO:
     # ---- rollout -----------------------------------------------------------------------------------------
     def act(self, obs, privileged_obs, obs_history):
         t = self.transition
+        if self.storage.ring:
+            return self._act_ring(obs, privileged_obs, obs_history)
         # the env's obs_history is a live view of its ring buffer: take the storage copy now, before env.step
         # (it is also the dtype / padding the policy GEMMs want)
         slot = self.storage.observation_histories[self.storage.step]
@@ -255,7 +266,20 @@ class PPO:
         t.observations = t.critic_observations = st.observations[s]
         t.privileged_observations = st.privileged_observations[s]
 
-    def _act_fused(self, slot, obs, privileged_obs):
+    def _act_ring(self, obs, privileged_obs, obs_history):
+        """ring storage: one kernel appends the observation, assembles the inference rows and stores obs / privileged obs."""
+        from go1_gym_learn.ppo_cse import fused
+        st = self.storage
+        s = st.step
+        if s >= st.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        if st.num_envs != self._roll_net.M:
+            raise AssertionError("ring storage needs the static-buffer inference engine of its own batch size")
+        fused.ring_step(self._fused_lib, st, s, obs.contiguous(), privileged_obs.contiguous(), obs_history, self._X_roll)
+        self.transition.observation_histories = self._X_roll
+        return self._act_fused(self._X_roll, obs, privileged_obs, stored=True)
+
+    def _act_fused(self, slot, obs, privileged_obs, stored=False):
         """inference on the static-buffer engine, then ONE kernel that samples, evaluates the log-prob and writes
         actions / mean / sigma / value / log-prob straight into the storage slot (fused.act)."""
         from go1_gym_learn.ppo_cse import fused
@@ -269,7 +293,11 @@ class PPO:
             fused.act(self._fused_lib, mean, value, self.std, noise, st, s)
         t.actions, t.values, t.actions_log_prob = st.actions[s], st.values[s], st.actions_log_prob[s]
         t.action_mean, t.action_sigma = st.mu[s], st.sigma[s]
-        self._snapshot_obs(obs, privileged_obs)
+        if stored:          # (ring_step wrote the two observation blocks)
+            t.observations = t.critic_observations = st.observations[s]
+            t.privileged_observations = st.privileged_observations[s]
+        else:
+            self._snapshot_obs(obs, privileged_obs)
         return t.actions
 
     def _infer(self, rows):
@@ -342,13 +370,21 @@ class PPO:
         net, n = self._train_net, self.n_body
         with torch.no_grad():
             if not self._pregathered:         # graph mode gathers all mini-batches' rows once per update() instead
-                torch.index_select(self.storage.observation_histories.flatten(0, 1), 0, idx, out=net.X)
+                self._gather_rows(idx, net.X)
             # (the flat gradient and the KL slot are clean here: update() clears them once, every fused optimiser step
             # clears what it has consumed)
             net.forward(net.X)
             net.ppo_loss(self.storage, idx, self.std, self.master.grad[n:n + self.n_std], PPO_Args, self._kl, self._acc)
             net.backward(net.X)
             self._priv_cols_grad.zero_()
+
+    def _gather_rows(self, idx, out):
+        """augmented history rows of the storage entries idx into the (len(idx), Kp) buffer `out`"""
+        if self.storage.ring:
+            from go1_gym_learn.ppo_cse import fused
+            fused.ring_gather(self._fused_lib, self.storage, idx, out)
+        else:
+            torch.index_select(self.storage.observation_histories.flatten(0, 1), 0, idx, out=out)
 
     def _stage_adapt_backward_fused(self, idx):
         net = self._train_net          # net.X still holds this mini-batch's rows (gathered by the PPO stage)
@@ -513,9 +549,8 @@ class PPO:
         graph_mode = use_graphs and self._updates_done >= 1
         self._pregathered = bool(graph_mode and self.fused)
         if self._pregathered:
-            hist = self.storage.observation_histories.flatten(0, 1)
             for i in range(nmb):
-                torch.index_select(hist, 0, self._idx_all[i], out=self._Xall[i])
+                self._gather_rows(self._idx_all[i], self._Xall[i])
         for epoch in range(A.num_learning_epochs):
             for i in range(nmb):
                 idx = self._idx_all[i]

@@ -18,11 +18,16 @@ class RolloutStorage:
             self.__init__()
 
     def __init__(self, num_envs, num_transitions_per_env, obs_shape, privileged_obs_shape, obs_history_shape,
-                 actions_shape, device='cpu', history_dtype=torch.float32, history_pad_to=1, augment=False):
+                 actions_shape, device='cpu', history_dtype=torch.float32, history_pad_to=1, augment=False, ring=False):
         """`history_dtype` / `history_pad_to`: the (T, N, H*num_obs) history block is the dominant storage
         (826 MB in fp32 at N=4096); under the bf16 policy it is kept in bf16 with rows zero-padded to a multiple
         of `history_pad_to` elements, which is exactly what the policy GEMMs consume.  `augment`: the padding
-        columns carry [1, privileged_obs] so that biases and the critic's privileged inputs ride in the GEMM."""
+        columns carry [1, privileged_obs] so that biases and the critic's privileged inputs ride in the GEMM.
+
+        `ring`: the histories are sliding windows over one observation stream (history_wrapper.py:23), so every
+        observation is stored ONCE — `obs_ring` (T + H - 1, N, num_obs), 30 MB instead of 415 MB at N=4096 — and the
+        augmented rows are assembled by the kernels that consume them (include/go1ppo.h, observation ring); there is
+        no `observation_histories` block then.  GPU + bf16 + augment only (the caller decides, PPO.init_storage)."""
         self.device = device
         self.obs_shape, self.privileged_obs_shape = obs_shape, privileged_obs_shape
         self.obs_history_shape, self.actions_shape = obs_history_shape, actions_shape
@@ -34,9 +39,18 @@ class RolloutStorage:
         self.augment = bool(augment)
         extra = (1 + int(privileged_obs_shape[0])) if augment else 0
         padded = -(-(self.history_width + extra) // history_pad_to) * history_pad_to
-        self.observation_histories = z(padded, dtype=history_dtype)
-        if augment:
-            self.observation_histories[..., self.history_width] = 1.0
+        self.padded_width = padded
+        self.ring = bool(ring)
+        if self.ring:
+            no = int(obs_shape[0])
+            assert augment and history_dtype == torch.bfloat16 and no % 2 == 0 and self.history_width % no == 0
+            self.history_length = self.history_width // no
+            self.obs_ring = torch.zeros(T + self.history_length - 1, N, no, device=self.device, dtype=torch.bfloat16)
+            self.observation_histories = None
+        else:
+            self.observation_histories = z(padded, dtype=history_dtype)
+            if augment:
+                self.observation_histories[..., self.history_width] = 1.0
         self.rewards = z(1)
         self.actions = z(*actions_shape)
         self.dones = z(1).byte()
@@ -65,6 +79,8 @@ class RolloutStorage:
             self.observations[s].copy_(transition.observations)
         if transition.privileged_observations.data_ptr() != self.privileged_observations[s].data_ptr():
             self.privileged_observations[s].copy_(transition.privileged_observations)
+        if self.ring:
+            raise AssertionError("ring storage is filled by PPO.act (go1ppo_ring_step), not by add_transitions")
         if transition.observation_histories.data_ptr() != self.observation_histories[s].data_ptr():
             src = transition.observation_histories
             self.observation_histories[s][:, :src.shape[-1]].copy_(src)
@@ -130,6 +146,7 @@ class RolloutStorage:
         mini_batch_size = batch_size // num_mini_batches
         indices = torch.randperm(num_mini_batches * mini_batch_size, requires_grad=False, device=self.device)
         flat = lambda t: t.flatten(0, 1)
+        assert not self.ring, "ring storage: mini-batch rows are assembled by go1ppo_ring_gather (PPO.update)"
         observations, privileged_obs, obs_history = flat(self.observations), flat(self.privileged_observations), flat(self.observation_histories)
         actions, values, returns = flat(self.actions), flat(self.values), flat(self.returns)
         old_log_prob, advantages = flat(self.actions_log_prob), flat(self.advantages)
