@@ -212,6 +212,8 @@ def main():
     ap.add_argument("--rollout-only", action="store_true", help="diagnostic: sim + policy inference + storage, no update (SURVEY 8d metric 2)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry run: all ranks share GPU 0 (with --backend gloo)")
+    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="N > 1: dtype of the PPO-stage gradient exchange (PPO_Args.dp_grad_dtype)")
+    ap.add_argument("--zero1", action="store_true", help="N > 1: reduce-scatter + sharded optimiser step + all-gather (PPO_Args.dp_zero1)")
     ap.add_argument("--breakdown", action="store_true", help="diagnostic: print rollout/update split to stderr (adds syncs)")
     ap.add_argument("--headline-only", action="store_true", help="skip the extra single-GPU records (rates, height field, 8192 envs)")
     args = ap.parse_args()
@@ -233,6 +235,7 @@ def main():
     from go1_gym_learn.ppo_cse import Runner, RunnerArgs
     from go1_gym_learn.ppo_cse.ppo import PPO_Args
     PPO_Args.autocast_bf16 = not args.fp32
+    PPO_Args.dp_grad_dtype, PPO_Args.dp_zero1 = args.grad_dtype, bool(args.zero1)
     RunnerArgs.save_video_interval = 0
     torch.manual_seed(args.seed + rank)
     env, cfg = build_env(args.envs, rank, args.seed)
@@ -333,7 +336,9 @@ def main():
                                    "curriculum), HIP sim + ppo_cse, 24 steps/iter, 5 epochs x 4 minibatches",
                        "envs_per_gpu": args.envs, "policy_dtype": "fp32" if args.fp32 else "bf16 autocast (fp32 master)",
                        "physics_dtype": "f32", "step": "one PPO iteration = 24 x envs env-steps + update",
-                       "parallelism": f"dp{world} (envs sharded, RCCL gradient all-reduce)" if world > 1 else "single GPU"},
+                       "parallelism": (f"dp{world} (envs sharded, {args.backend} gradient "
+                                       f"{'reduce-scatter + sharded step + all-gather' if args.zero1 else 'all-reduce'}, {args.grad_dtype})")
+                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "go1_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": avg_ms, "launches": len(kernel_ms), "algorithmic_bytes_per_launch": bytes_per_launch,

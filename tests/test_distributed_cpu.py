@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, grad_dtype="fp32", zero1=False):
     sys.path[:0] = [os.path.join(HERE, "..", "walk-these-ways_amd", "shims"), os.path.join(HERE, "..", "walk-these-ways_amd")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -21,6 +21,7 @@ def _worker(rank, world, port, out):
     from go1_gym_learn.ppo_cse.ppo import PPO, PPO_Args
     from go1_gym_learn.ppo_cse.rollout_storage import RolloutStorage
     AC_Args.actor_hidden_dims, AC_Args.critic_hidden_dims, AC_Args.adaptation_module_branch_hidden_dims = [32, 16], [24, 16], [16, 8]
+    PPO_Args.dp_grad_dtype, PPO_Args.dp_zero1 = grad_dtype, zero1
     N, T, no, npv, H, na = 12, 5, 10, 2, 3, 12
     torch.manual_seed(100 + rank)                     # different initial weights: rank 0's must win
     alg = PPO(ActorCritic(no, npv, no * H, na), device="cpu")
@@ -54,13 +55,26 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_update_keeps_replicas_identical():
+_DP_RESULTS = {}
+
+
+@pytest.mark.parametrize("grad_dtype,zero1", [("fp32", False), ("bf16", False), ("fp32", True), ("bf16", True)])
+def test_two_rank_gloo_update_keeps_replicas_identical(grad_dtype, zero1):
+    """every exchange mode (PPO_Args.dp_grad_dtype, PPO_Args.dp_zero1): both ranks end with bit-identical weights and
+    learning rate; the sharded step (reduce-scatter, every rank steps its slice with the global norm / KL, all-gather)
+    reproduces the all-reduce step's weights to round-off, the bf16 exchange stays within bf16 gradient noise of it."""
     world = 2
-    port = 29500 + os.getpid() % 2000
+    port = 29500 + (os.getpid() + 17 * len(_DP_RESULTS)) % 2000
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, grad_dtype, zero1), nprocs=world, join=True)
     r0, r1 = out[0], out[1]
+    _DP_RESULTS[(grad_dtype, zero1)] = r0["w"].clone()
+    if (grad_dtype, zero1) != ("fp32", False) and ("fp32", False) in _DP_RESULTS:
+        base = _DP_RESULTS[("fp32", False)]
+        n = base.numel()
+        tol = 1e-5 if grad_dtype == "fp32" else 5e-3           # Adam's normalised step amplifies the bf16 rounding of small gradients
+        assert float((r0["w"][:n] - base).abs().max()) < tol, (grad_dtype, zero1, float((r0["w"][:n] - base).abs().max()))
     assert r0["dp"] and r1["dp"]
     assert torch.equal(r0["w0"], r1["w0"])                 # broadcast of rank 0's initial weights
     assert torch.equal(r0["w"], r1["w"])                   # identical after 20 + 20 optimiser steps

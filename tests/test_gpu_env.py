@@ -324,3 +324,29 @@ def test_rough_terrain_env_end_to_end():
     assert float(rel.min()) > -0.05 and float(rel.max()) < 2.5, (float(rel.min()), float(rel.max()))
     assert 0.15 < float(rel.median()) < 0.45
     assert resets > 0
+
+
+@pytest.mark.parametrize("extra", [[], ["--grad-dtype", "bf16", "--zero1"]])
+def test_two_rank_bench_dry_run_on_one_gpu(extra):
+    """The data-parallel code path of bench.py itself — launched exactly as the driver launches N > 1, but with two ranks
+    sharing GPU 0 over gloo (no RCCL on a 1-GPU box): env sharding by rank, gradient exchange in every mini-batch (eager
+    first update, graph replay with the collectives between the graphs afterwards), barrier + max-over-ranks timing, one
+    JSON line from rank 0.  Covers the default all-reduce and the bf16 reduce-scatter / sharded-step / all-gather mode."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29600 + os.getpid() % 1000 + (7 if extra else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--envs", "256",
+           "--backend", "gloo", "--same-device", "--no-cpu-baseline", "--headline-only"] + extra
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTORCH_TUNABLEOP_ENABLED="0")          # (256 envs: GEMM shapes outside the shipped table; no tuning pass in a smoke test)
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 2 and rec["value"] > 0
+    assert rec["config"]["envs_per_gpu"] == 256 and "dp2" in rec["config"]["parallelism"]
+    assert rec["value"] == pytest.approx(2 * 256 * 24 / (rec["ms_per_step"] * 1e-3), rel=1e-6)      # whole-job rate

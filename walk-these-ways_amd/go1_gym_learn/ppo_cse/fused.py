@@ -628,14 +628,23 @@ class FusedAdam:
         self.r0, self.r1 = r[0], r[1]
         self.n_norm = max(a + b for a, b in r)          # elements the global norm runs over (padding slots excluded)
 
+    def set_ranges(self, ranges):
+        """restrict the step to these (start, count) element ranges (at most two) — e.g. one rank's slice of a sharded step"""
+        r = list(ranges) + [(0, 0)]
+        self.r0, self.r1 = r[0], r[1]
+
     def step_(self, gscale=1.0, max_norm=None, kl=None, kl_scale=1.0, desired_kl=0.01, lr_min=1e-5, lr_max=1e-2, zero_grad=False,
-              zero_slot=None):
-        """zero_grad: clear the visited gradient elements (and `zero_slot`, a one-element tensor) inside the Adam kernel."""
+              zero_slot=None, between=None):
+        """zero_grad: clear the visited gradient elements (and `zero_slot`, a one-element tensor) inside the Adam kernel.
+        between: called between the two kernels with the per-block partial sums of the squared gradient norm — a sharded
+        step all-reduces them there, so that every rank clips by the GLOBAL norm."""
         g = self.master.grad
         clip = max_norm is not None
         _chk(self.lib.go1ppo_opt_prestep(g.data_ptr(), self.n_norm, gscale, self.partial.data_ptr() if clip else None,
                                          self.step.data_ptr(), self.lr.data_ptr(), _ptr(kl), kl_scale, desired_kl, lr_min, lr_max,
                                          _stream()), "go1ppo_opt_prestep")
+        if between is not None:
+            between(self.partial)
         _chk(self.lib.go1ppo_opt_adam(self.master.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.r0[0], self.r0[1],
                                       self.r1[0], self.r1[1], gscale, self.partial.data_ptr() if clip else None,
                                       float(max_norm) if clip else 0.0, self.step.data_ptr(), self.lr.data_ptr(), self.betas[0],

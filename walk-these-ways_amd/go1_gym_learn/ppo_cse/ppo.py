@@ -49,6 +49,9 @@ class PPO_Args(PrefixProto):
     # MI355X additions
     autocast_bf16 = False           # BASELINE config 2: "bf16 policy" (fp32 master weights + bf16 compute replica)
     data_parallel = True            # all-reduce gradients when torch.distributed is initialised with world_size > 1
+    dp_grad_dtype = "fp32"          # "bf16": the PPO-stage gradient crosses the links in bf16 (half the bytes of the 13 MB exchange)
+    dp_zero1 = False                # PPO stage: reduce-scatter the gradient, every rank steps its 1/world slice of the flat
+                                    # parameter (global norm / KL by two scalar-sized all-reduces), all-gather the result
     history_ring = True             # keep each observation once when init_storage(..., sliding_history=True) allows it
     use_hip_graphs = True           # replay the mini-batch step as a HIP graph from the second update() on
     use_fused_kernels = True        # bf16 policy on a GPU: hand-scheduled forward/backward with csrc/go1ppo.hip (fused.py)
@@ -106,8 +109,10 @@ class PPO:
         self.policy = FlatPolicy(ac)
         n = self.policy.numel
         self.n_body, self.n_std = n, ac.std.numel()
-        # fp32 master: [flat policy | std | pad]; the single tensor both optimisers step
-        self.master = torch.zeros(n + 16, device=device)
+        # fp32 master: [flat policy | std | pad]; the single tensor both optimisers step (length: a multiple of the world
+        # size, so that it splits into equal slices for the sharded step)
+        w = _world() if PPO_Args.data_parallel else 1
+        self.master = torch.zeros(-(-(n + 16) // w) * w, device=device)
         self.policy.pack(ac, self.master[:n])
         self.master[n:n + self.n_std].copy_(ac.std.detach())
         self.master.grad = torch.zeros_like(self.master)
@@ -154,6 +159,19 @@ class PPO:
             self._ad_grad_views = [self.master.grad[:pol.adaptation_numel]]
         if self.dp:                              # identical initial weights on every rank
             dist.broadcast(self.master, src=0)
+        self._dp_lowp = self._dp_shard = None
+        if self.dp:
+            A = PPO_Args
+            assert A.dp_grad_dtype in ("fp32", "bf16")
+            if A.dp_grad_dtype == "bf16":
+                self._dp_lowp = torch.zeros(self.master.numel(), device=device, dtype=torch.bfloat16)
+            if A.dp_zero1:
+                per = self.master.numel() // _world()
+                self._dp_shard = (dist.get_rank() * per, per)
+                self._dp_shard_buf = torch.zeros(per, device=device, dtype=torch.bfloat16 if self._dp_lowp is not None else torch.float32)
+                self._dp_tail = torch.zeros(self.master.numel() - n, device=device)
+                if self._opt is not None:
+                    self._opt.set_ranges([self._dp_shard])
         self._push_weights()
 
     # ---- precision plumbing --------------------------------------------------------------------------
@@ -427,11 +445,15 @@ class PPO:
     def _stage_ppo_step(self):
         """adaptive-KL learning rate, global-norm clip, Adam, refresh the compute copies."""
         A = PPO_Args
+        sharded = self.dp and self._dp_shard is not None
         if self._opt is not None:
             adaptive = A.desired_kl is not None and A.schedule == 'adaptive'
             w = float(_world()) if self.dp else 1.0
             self._opt.step_(gscale=1.0 / w, max_norm=A.max_grad_norm, kl=self._kl if adaptive else None, kl_scale=1.0 / w,
-                            desired_kl=A.desired_kl if adaptive else 0.0, zero_grad=True, zero_slot=self._kl)
+                            desired_kl=A.desired_kl if adaptive else 0.0, zero_grad=True, zero_slot=self._kl,
+                            between=(lambda partial: dist.all_reduce(partial)) if sharded else None)
+            if sharded:
+                self._dp_gather_params()
             return
         g = self._g_live
         if self.dp:
@@ -439,9 +461,17 @@ class PPO:
         if A.desired_kl is not None and A.schedule == 'adaptive':
             self._adapt_lr(self._kl / _world() if self.dp else self._kl)
         self._kl.zero_()          # the slot is padding of the parameter vector: Adam must see a zero gradient there
-        g.mul_(torch.clamp(A.max_grad_norm / (torch.linalg.vector_norm(g) + 1e-6), max=1.0))
-        self.optimizer.step()
-        self._push_weights()
+        norm = torch.linalg.vector_norm(g)
+        if sharded:               # g holds this rank's slice only: the clip needs the norm of the whole gradient
+            n2 = norm * norm
+            dist.all_reduce(n2)
+            norm = n2.sqrt()
+        g.mul_(torch.clamp(A.max_grad_norm / (norm + 1e-6), max=1.0))
+        self.optimizer.step()     # (zero gradient and zero moments outside the slice: those parameters do not move)
+        if sharded:
+            self._dp_gather_params()
+        else:
+            self._push_weights()
 
     def _stage_adapt_backward(self, idx):
         """adaptation-module regression on the same mini-batch (reference ppo.py:163-190)."""
@@ -471,6 +501,43 @@ class PPO:
         self.adaptation_module_optimizer.step()
         self._push_weights()
 
+    # ---- data-parallel exchange of the PPO-stage gradient ---------------------------------------------------
+    def _dp_exchange_ppo(self):
+        """all-reduce of the flat gradient (+ the KL slot riding in its padding), in fp32 or — dp_grad_dtype = "bf16" —
+        through a bf16 copy (every rank receives the same sum, so the replicas stay bit-identical either way); with
+        dp_zero1 a reduce-scatter instead: afterwards the rank holds the summed gradient of ITS slice only (zeros elsewhere)
+        and `self._dp_tail` the summed tail [std gradient | KL | pad] every rank needs."""
+        g = self.master.grad
+        if self._dp_shard is None:
+            if self._dp_lowp is None:
+                dist.all_reduce(g)
+            else:
+                self._dp_lowp.copy_(g)
+                dist.all_reduce(self._dp_lowp)
+                g.copy_(self._dp_lowp)
+            return
+        lo, per = self._dp_shard
+        self._dp_tail.copy_(g[self.n_body:])
+        dist.all_reduce(self._dp_tail)                     # std gradient + KL: a few dozen floats
+        src = g
+        if self._dp_lowp is not None:
+            self._dp_lowp.copy_(g)
+            src = self._dp_lowp
+        try:
+            dist.reduce_scatter_tensor(self._dp_shard_buf, src)
+        except (RuntimeError, NotImplementedError):        # backend without reduce-scatter: same result from an all-reduce
+            dist.all_reduce(src)
+            self._dp_shard_buf.copy_(src[lo:lo + per])
+        g.zero_()
+        g[lo:lo + per].copy_(self._dp_shard_buf)
+        self._kl.copy_(self._dp_tail[self.n_std])           # the global KL on every rank (its slot belongs to the last slice)
+
+    def _dp_gather_params(self):
+        """sharded step: every rank contributes its updated slice of the fp32 master; compute copies refreshed from it"""
+        lo, per = self._dp_shard
+        dist.all_gather_into_tensor(self.master.data, self.master.data[lo:lo + per].clone())
+        self._push_weights()
+
     def _allreduce_adapt_grads(self):
         """the adaptation stage only produces gradients for the adaptation module: with the fused optimiser that is
         the leading range of the flat buffer (FlatPolicy layout; 2.3 MB instead of 13 MB over xGMI per step)."""
@@ -480,7 +547,7 @@ class PPO:
     def _minibatch_eager(self, idx):
         self._stage_ppo_backward(idx)
         if self.dp:
-            dist.all_reduce(self.master.grad)          # gradient + KL slot
+            self._dp_exchange_ppo()                    # gradient + KL slot
         self._stage_ppo_step()
         for _ in range(PPO_Args.num_adaptation_module_substeps):
             self._stage_adapt_backward(idx)
@@ -510,7 +577,10 @@ class PPO:
             rec(lambda: self._minibatch_eager(idx))
         else:
             rec(lambda: self._stage_ppo_backward(idx))
-            rec(lambda: (self._stage_ppo_step(), self._stage_adapt_backward(idx)))
+            if self._dp_shard is not None:      # the sharded step has collectives in its middle: it stays eager
+                rec(lambda: self._stage_adapt_backward(idx))
+            else:
+                rec(lambda: (self._stage_ppo_step(), self._stage_adapt_backward(idx)))
             rec(self._stage_adapt_step)
         return graphs
 
@@ -520,7 +590,9 @@ class PPO:
             g[0].replay()
             return
         g[0].replay()
-        dist.all_reduce(self.master.grad)          # gradient + KL slot
+        self._dp_exchange_ppo()                    # gradient + KL slot
+        if self._dp_shard is not None:
+            self._stage_ppo_step()
         g[1].replay()
         self._allreduce_adapt_grads()
         g[2].replay()
