@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GO1SIM_ABI_VERSION 3
+#define GO1SIM_ABI_VERSION 4
 
 #define GO1_NUM_DOF 12
 #define GO1_NUM_BODIES 17        /* base, then FL,FR,RL,RR x (hip, thigh, calf, foot) */
@@ -266,8 +266,10 @@ typedef struct Go1SimBuffers {
   float* rew_buf;                  /* [N] */
   float* episode_sums;             /* [num_rewards+1][N], last row = "total" */
   float* command_sums;             /* [num_rewards+5][N]: +lin_vel_raw, ang_vel_raw, lin_vel_residual, ang_vel_residual, ep_timesteps */
-  float* episode_log;              /* [num_rewards+1 +1]: running sum over reset envs of episode_sums, last = count;
+  float* episode_log;              /* [num_rewards+1 +1]: running sum over reset TRAIN envs of episode_sums, last = count;
                                       accumulated atomically by step/reset_idx, zeroed by the caller when consumed */
+  float* episode_sums_eval;        /* [num_rewards+1][N] or NULL: an evaluation environment's episode sums at the end of its first
+                                      episode after the caller set the entries to -1 (legged_robot.py:188-195, 1420-1424) */
   /* domain randomisation parameters — legged_robot.py:1260-1288 */
   float* friction_coeffs;          /* [N] */
   float* restitutions;             /* [N] */
@@ -307,6 +309,14 @@ int go1sim_destroy(Go1Sim* sim);
 
 /* Update config fields that scripts mutate after construction (e.g. play.py changes ranges). */
 int go1sim_set_config(Go1Sim* sim, const Go1SimConfig* cfg);
+
+/* Train / evaluation split (reference `eval_cfg`: base_task.py:43-49, legged_robot.py:531-544 `_call_train_eval`): the
+ * environments [num_train_envs, num_envs) run under `eval_cfg` wherever the reference dispatches on the environment's group
+ * — domain-randomisation ranges and switches, pushes, teleports, the reset distribution — and are kept out of
+ * `episode_log`.  `eval_cfg` must describe the same simulation (num_envs = the TOTAL, same dimensions, control, physics,
+ * rewards and command distribution: the caller copies those from the train configuration); the kernels select the block
+ * per wavefront, so num_train_envs must be a multiple of 16 (-3 otherwise).  num_train_envs == num_envs: no split. */
+int go1sim_set_eval_config(Go1Sim* sim, const Go1SimConfig* eval_cfg, int32_t num_train_envs);
 
 /* One policy step for all environments: clip actions, `decimation` x {torque model, physics substep},
  * derived state, gait clock, command resampling, DR cadence, termination, rewards, in-kernel reset,

@@ -955,6 +955,19 @@ static void randomize_rigid_props(const Go1SimConfig* cfg, const Go1SimBuffers* 
     B->restitutions[e] = rng_uniform(cfg, eg, step, purpose, 5) * (cfg->restitution_range[1] - cfg->restitution_range[0]) + cfg->restitution_range[0];
 }
 
+/* ---- train / evaluation split (reference eval_cfg: base_task.py:43-49, legged_robot.py:531-544 _call_train_eval) ----
+ * environments [g_num_train, N) take their domain-randomisation / push / teleport / reset parameters from a second
+ * configuration and stay out of the training episode log (include/go1sim.h go1sim_set_eval_config) */
+static Go1SimConfig g_eval_copy;
+static const Go1SimConfig* g_eval_cfg = NULL;
+static int g_num_train = 0;
+void go1_oracle_set_eval(const Go1SimConfig* eval_cfg, int num_train) {
+  if (eval_cfg) { g_eval_copy = *eval_cfg; g_eval_cfg = &g_eval_copy; g_num_train = num_train; }
+  else g_eval_cfg = NULL;
+}
+static int env_is_eval(int e) { return g_eval_cfg != NULL && e >= g_num_train; }
+static const Go1SimConfig* env_cfg(const Go1SimConfig* cfg, int e) { return env_is_eval(e) ? g_eval_cfg : cfg; }
+
 /* reset_idx for one env (legged_robot.py:150-239,948-1001) */
 static void reset_env(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int64_t step, int lag_slots) {
   const int N = cfg->num_envs;
@@ -981,7 +994,12 @@ static void reset_env(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, in
   for (int j = 0; j < 12; j++) { AT(B->last_actions, j, e) = 0; AT(B->last_last_actions, j, e) = 0; AT(B->last_dof_vel, j, e) = 0; }
   B->episode_length_buf[e] = 0;
   B->reset_buf[e] = 1;
-  if (g_log_defer) {        /* parallel post-physics: park the per-env terms, the caller adds them in env order */
+  if (env_is_eval(e)) {     /* :188-195: kept out of the training log; the first finished episode is remembered */
+    for (int kx = 0; kx <= cfg->num_rewards; kx++) {
+      if (B->episode_sums_eval && AT(B->episode_sums_eval, kx, e) == -1.f) AT(B->episode_sums_eval, kx, e) = AT(B->episode_sums, kx, e);
+      AT(B->episode_sums, kx, e) = 0;
+    }
+  } else if (g_log_defer) { /* parallel post-physics: park the per-env terms, the caller adds them in env order */
     float* row = g_log_defer + (size_t)e * g_log_stride;
     for (int kx = 0; kx <= cfg->num_rewards; kx++) { row[kx] = AT(B->episode_sums, kx, e); AT(B->episode_sums, kx, e) = 0; }
     row[cfg->num_rewards + 1] = 1;
@@ -999,7 +1017,10 @@ static void reset_env(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, in
 
 void go1_oracle_reset_idx(const Go1SimConfig* cfg, const Go1SimBuffers* B, const int32_t* ids, int n, int64_t step) {
   for (int kx = 0; kx <= cfg->num_rewards + 1; kx++) B->episode_log[kx] = 0;
-  for (int i = 0; i < (ids ? n : cfg->num_envs); i++) reset_env(cfg, B, ids ? ids[i] : i, step, cfg->lag_timesteps + 1);
+  for (int i = 0; i < (ids ? n : cfg->num_envs); i++) {
+    const int e = ids ? ids[i] : i;
+    reset_env(env_cfg(cfg, e), B, e, step, cfg->lag_timesteps + 1);
+  }
 }
 
 /* ------------------------------------------------------------------ rewards (corl_rewards.py) */
@@ -1426,7 +1447,7 @@ void go1_oracle_step(const Go1SimConfig* cfg, const Go1SimBuffers* B, const floa
     g_log_stride = stride;
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < N; e++) {
-      post_physics(cfg, B, e, counter_post, grav, nl);
+      post_physics(env_cfg(cfg, e), B, e, counter_post, grav, nl);
       if (B->obs_history) history_append(cfg, B, e, ctr->history_slot);
     }
     g_log_defer = NULL;
@@ -1485,7 +1506,7 @@ void go1_oracle_physics_substep(const Go1SimConfig* cfg, const Go1SimBuffers* B,
 void go1_oracle_post_physics(const Go1SimConfig* cfg, const Go1SimBuffers* B, const double* grav_used, Go1OracleCounters* ctr) {
   int64_t counter_post = ctr->common_step_counter + 1;
   for (int kx = 0; kx <= cfg->num_rewards + 1; kx++) B->episode_log[kx] = 0;
-  for (int e = 0; e < cfg->num_envs; e++) post_physics(cfg, B, e, counter_post, grav_used, cfg->lag_timesteps + 1);
+  for (int e = 0; e < cfg->num_envs; e++) post_physics(env_cfg(cfg, e), B, e, counter_post, grav_used, cfg->lag_timesteps + 1);
   ctr->common_step_counter = counter_post;
 }
 

@@ -50,6 +50,7 @@ def lib():
         L.go1_oracle_post_physics.argtypes = [cfgp, bufp, vp, ctrp]
         L.go1_oracle_reset_idx.argtypes = [cfgp, bufp, vp, ctypes.c_int, ctypes.c_int64]
         L.go1_oracle_curriculum_update.argtypes = [cfgp, bufp]
+        L.go1_oracle_set_eval.argtypes = [cfgp, ctypes.c_int]
         L.go1_oracle_dynamics.argtypes = [vp] * 5 + [ctypes.c_double] + [vp] * 4
         L.go1_oracle_actuator_net.argtypes = [vp, ctypes.c_int, vp]
         L.go1_oracle_philox.argtypes = [vp, vp, vp]
@@ -75,7 +76,17 @@ class Oracle:
         self.ctr = Counters(0, 0, 0)
         self.L = lib()
 
+    def set_eval_config(self, S_eval, num_train_envs):
+        """environments [num_train_envs, N) run under S_eval (module-global in the oracle: None switches the split off)"""
+        self.S_eval, self.num_train_envs = S_eval, int(num_train_envs)
+        self._apply_eval()
+
+    def _apply_eval(self):
+        S_eval = getattr(self, "S_eval", None)
+        self.L.go1_oracle_set_eval(ctypes.byref(S_eval) if S_eval is not None else None, getattr(self, "num_train_envs", 0))
+
     def step(self, actions):
+        self._apply_eval()
         a = np.ascontiguousarray(actions, dtype=np.float32)
         assert a.shape == (self.S.num_envs, 12)
         self.L.go1_oracle_step(ctypes.byref(self.S), ctypes.byref(self.buffers.struct), _ptr(a), ctypes.byref(self.ctr))
@@ -89,10 +100,12 @@ class Oracle:
         self.L.go1_oracle_physics_substep(ctypes.byref(self.S), ctypes.byref(self.buffers.struct), ctypes.byref(self.ctr))
 
     def post_physics(self, gravity):
+        self._apply_eval()
         g = np.ascontiguousarray(gravity, dtype=np.float64)
         self.L.go1_oracle_post_physics(ctypes.byref(self.S), ctypes.byref(self.buffers.struct), _ptr(g), ctypes.byref(self.ctr))
 
     def reset_idx(self, ids=None):
+        self._apply_eval()
         if ids is None:
             self.L.go1_oracle_reset_idx(ctypes.byref(self.S), ctypes.byref(self.buffers.struct), None, 0, self.ctr.common_step_counter)
         else:

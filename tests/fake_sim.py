@@ -34,6 +34,9 @@ class OracleBackedSim:
     def set_config(self, S):
         self.S = self.orc.S = S
 
+    def set_eval_config(self, S_eval, num_train_envs):
+        self.orc.set_eval_config(S_eval, num_train_envs)
+
     def counters(self):
         return self.orc.ctr.common_step_counter, self.orc.ctr.lag_head
 

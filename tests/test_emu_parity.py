@@ -232,3 +232,55 @@ def test_emulated_self_collision_matches_oracle(oracle_lib, emu):
     assert leg_leg > 200, (leg_leg, trunk_leg)      # (the trunk pairs are evaluated too, but the Go1's lower legs cannot reach
                                                     #  the trunk's capsule within the joint limits: they never fire on either side)
     assert int(Be.fault_counts[:10].sum()) == 0
+
+
+def test_emulated_train_eval_split_matches_oracle(oracle_lib, emu):
+    """eval_cfg (reference base_task.py:43-49, legged_robot.py:531-544 `_call_train_eval`): 16 training + 16 evaluation
+    environments, the evaluation group with its own domain-randomisation ranges, push settings and reset distribution
+    (include/go1sim.h go1sim_set_eval_config: second configuration block, selected per wavefront).  Kernel (emulated) vs
+    oracle over steps full of resets; every freshly drawn parameter lies in ITS group's range; evaluation episodes stay out
+    of the training episode log and their first finished episode lands in episode_sums_eval."""
+    N, NT = 32, 16
+    ev = {"domain_rand": dict(friction_range=[5.0, 5.5], restitution_range=[0.7, 0.8], added_mass_range=[4.0, 4.5],
+                              motor_strength_range=[1.5, 1.6], motor_offset_range=[0.10, 0.11], push_robots=True, max_push_vel_xy=2.0,
+                              randomize_rigids_after_start=True, randomize_friction=True, randomize_restitution=True, randomize_base_mass=True),
+          "terrain": dict(yaw_init_range=0.1)}
+    cfg, S, meta, Bc = make_sim("dr", N, seed=5)
+    _, S_ev_full, _, _ = make_sim("dr", N, seed=5, extra=ev)
+    S_eval = H.make_eval_sim_config(S, S_ev_full)
+    assert S_eval.num_envs == N and list(S_eval.friction_range) == [5.0, 5.5] and list(S.friction_range) != [5.0, 5.5]
+    assert S_eval.num_rewards == S.num_rewards and S_eval.resample_interval == S.resample_interval
+    randomize_dr(Bc, 5)
+    Bc.episode_sums_eval.fill_(-1.0)
+    orc = oracle_lib.Oracle(S, Bc)
+    orc.set_eval_config(S_eval, NT)
+    orc.reset_idx()
+    Bc.episode_length_buf[:] = torch.randint(int(S.max_episode_length) - 6, int(S.max_episode_length) - 1, (N,), dtype=torch.int32,
+                                             generator=torch.Generator().manual_seed(1))      # time-outs in the next steps
+    Be = Bc.clone_to("cpu")
+    sim = emu.EmuSim(S, Be)
+    sim.set_eval_config(S_eval, NT)
+    sim.set_counters(orc.ctr.common_step_counter, orc.ctr.lag_head)
+    with pytest.raises(RuntimeError):
+        sim.set_eval_config(S_eval, 8)                       # not a multiple of 16: refused, nothing changes
+    rng = np.random.default_rng(2)
+    log_e = np.zeros(Bc.episode_log.shape[0])
+    for step in range(8):
+        a = (rng.standard_normal((N, 12)) * 0.5).astype(np.float32)
+        Be.episode_log.zero_()
+        orc.step(a)
+        sim.step(torch.from_numpy(a))
+        assert torch.equal(Be.reset_buf, Bc.reset_buf), step
+        for k, tol in (("dof_pos", 5e-6), ("root_states", 2e-4), ("friction_coeffs", 1e-6), ("restitutions", 1e-6), ("payloads", 1e-6),
+                       ("motor_strengths", 1e-6), ("motor_offsets", 1e-6), ("obs_buf", 1e-4), ("rew_buf", 1e-5), ("commands", 1e-6),
+                       ("episode_sums", 1e-4), ("episode_sums_eval", 1e-4), ("episode_log", 1e-3)):
+            assert diff(Be, Bc, k) <= tol, (step, k, diff(Be, Bc, k))
+        log_e += Be.episode_log.numpy()
+        resync(Bc, Be, sim, orc)
+    done = Bc.episode_sums_eval[-1] != -1.0
+    assert int(done[NT:].sum()) > 0 and int(done[:NT].sum()) == 0          # only evaluation environments write the snapshot
+    assert 0 < log_e[-1] <= NT                                               # the training log counted training resets only
+    fr, ms = Bc.friction_coeffs, Bc.motor_strengths
+    assert bool(((fr[NT:] >= 5.0) & (fr[NT:] <= 5.5)).all()) and bool((fr[:NT] < 5.0).all())
+    assert bool(((ms[:, NT:] >= 1.5) & (ms[:, NT:] <= 1.6)).all()) and bool((ms[:, :NT] < 1.5).all())
+    assert bool(((Bc.payloads[NT:] >= 4.0) & (Bc.payloads[NT:] <= 4.5)).all())

@@ -512,3 +512,60 @@ def test_failed_state_is_contained_and_reported(where):
             assert torch.equal(a_[..., others], b_[..., others]), k
         else:
             assert torch.equal(a_[others], b_[others]), k
+
+
+def test_train_eval_split_matches_oracle():
+    """eval_cfg (reference base_task.py:43-49, legged_robot.py:531-544): 256 training + 128 evaluation environments, the
+    evaluation group with its own domain-randomisation ranges, pushes and reset distribution (go1sim_set_eval_config:
+    second configuration block selected per wavefront).  HIP kernel vs oracle on identical streams through 40 steps full of
+    time-outs; every re-drawn parameter lies in ITS group's range; evaluation episodes stay out of the training log."""
+    import pyoracle
+    N, NT = 384, 256
+    ev = {"domain_rand": dict(friction_range=[5.0, 5.5], restitution_range=[0.7, 0.8], added_mass_range=[4.0, 4.5],
+                              motor_strength_range=[1.5, 1.6], motor_offset_range=[0.10, 0.11], push_robots=True, max_push_vel_xy=2.0,
+                              randomize_rigids_after_start=True, randomize_friction=True, randomize_restitution=True, randomize_base_mass=True),
+          "terrain": dict(yaw_init_range=0.1)}
+    cfg, S, meta, Bc = make_sim("dr", N, seed=5)
+    _, S_ev_full, _, _ = make_sim("dr", N, seed=5, extra=ev)
+    S_eval = H.make_eval_sim_config(S, S_ev_full)
+    randomize_dr(Bc, 5)
+    Bc.episode_sums_eval.fill_(-1.0)
+    orc = pyoracle.Oracle(S, Bc)
+    orc.set_eval_config(S_eval, NT)
+    orc.reset_idx()
+    Bc.episode_length_buf[:] = torch.randint(int(S.max_episode_length) - 30, int(S.max_episode_length) - 1, (N,), dtype=torch.int32,
+                                             generator=torch.Generator().manual_seed(1))
+    Bg, sim = to_gpu(S, Bc)
+    sim.set_eval_config(S_eval, NT)
+    with pytest.raises(RuntimeError):
+        sim.set_eval_config(S_eval, 250)                    # not a multiple of 16
+    sync_from(Bc, Bg, sim, orc)
+    rng = np.random.default_rng(2)
+    bad_total, train_resets = 0.0, 0
+    for step in range(40):
+        a = (rng.standard_normal((N, 12)) * 0.5).astype(np.float32)
+        Bg.episode_log.zero_()
+        orc.step(a)
+        sim.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        bad_env = Bg.reset_buf.cpu().bool() != Bc.reset_buf.bool()
+        for k, tol, rt in (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("friction_coeffs", 1e-6, 0), ("restitutions", 1e-6, 0),
+                           ("payloads", 1e-6, 0), ("motor_strengths", 1e-6, 0), ("motor_offsets", 1e-6, 0), ("rew_buf", 2e-4, 1e-3),
+                           ("commands", 1e-5, 0), ("episode_sums", 1e-3, 1e-3), ("episode_sums_eval", 1e-3, 1e-3)):
+            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], tol, rt)
+            bad_env |= bad.reshape(-1, N).any(0)
+        bad_total += float(bad_env.float().mean())
+        good = ~bad_env
+        n_tr = int((Bc.reset_buf[:NT].bool() & good[:NT]).sum())
+        if bool(good.all()):
+            np.testing.assert_allclose(Bg.episode_log.cpu().numpy(), Bc.episode_log.numpy(), rtol=1e-3, atol=1e-3)
+            assert int(round(float(Bg.episode_log[-1]))) == int(Bc.reset_buf[:NT].sum())        # training resets only
+        train_resets += n_tr
+        sync_from(Bc, Bg, sim, orc)
+    assert bad_total / 40 <= 0.02, bad_total / 40
+    done = Bg.episode_sums_eval[-1].cpu() != -1.0
+    assert int(done[NT:].sum()) > 50 and int(done[:NT].sum()) == 0 and train_resets > 50
+    fr, ms, pl = Bg.friction_coeffs.cpu(), Bg.motor_strengths.cpu(), Bg.payloads.cpu()
+    assert bool(((fr[NT:] >= 5.0) & (fr[NT:] <= 5.5)).all()) and bool((fr[:NT] < 5.0).all())
+    assert bool(((ms[:, NT:] >= 1.5) & (ms[:, NT:] <= 1.6)).all()) and bool((ms[:, :NT] < 1.5).all())
+    assert bool(((pl[NT:] >= 4.0) & (pl[NT:] <= 4.5)).all())

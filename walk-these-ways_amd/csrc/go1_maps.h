@@ -163,7 +163,9 @@ DEV void randomize_rigid_props(CfgRef cfg, BufRef B, int e, int N, int64_t step,
     B.restitutions[e] = rng_uniform(cfg, eg, step, purpose, 5) * (cfg.restitution_range[1] - cfg.restitution_range[0]) + cfg.restitution_range[0];
 }
 
-DEV void reset_env(CfgRef cfg, BufRef B, int e, int N, int64_t step) {
+// is_eval: an evaluation environment (legged_robot.py:188-195): its episode sums stay out of the training log; the first
+// finished episode after the caller armed episode_sums_eval with -1 is kept there
+DEV void reset_env(CfgRef cfg, BufRef B, int e, int N, int64_t step, bool is_eval) {
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
   resample_commands(cfg, B, e, N, step, P_CMD_RESET);
   randomize_dof_props(cfg, B, e, N, step, P_DOFPROPS_RESET);
@@ -194,10 +196,12 @@ DEV void reset_env(CfgRef cfg, BufRef B, int e, int N, int64_t step) {
   B.reset_buf[e] = 1;
 #pragma unroll 1
   for (int kx = 0; kx <= cfg.num_rewards; kx++) {
-    atomicAdd(&B.episode_log[kx], AT(B.episode_sums, kx, e));
+    const float sum = AT(B.episode_sums, kx, e);
+    if (!is_eval) atomicAdd(&B.episode_log[kx], sum);
+    else if (B.episode_sums_eval && AT(B.episode_sums_eval, kx, e) == -1.f) AT(B.episode_sums_eval, kx, e) = sum;
     AT(B.episode_sums, kx, e) = 0.f;
   }
-  atomicAdd(&B.episode_log[cfg.num_rewards + 1], 1.0f);
+  if (!is_eval) atomicAdd(&B.episode_log[cfg.num_rewards + 1], 1.0f);
   B.gait_indices[e] = 0.f;
   const int nl = cfg.lag_timesteps + 1;
 #pragma unroll 1
@@ -399,7 +403,7 @@ DEV int reward_raw_sign(int id) {
 #define QUAD_SYNC() do { __threadfence_block(); LDS_PHASE(); } while (0)      // (one wavefront: memory fence + ordering, no s_barrier)
 
 DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int lane, int e, int N, int64_t counter_post, V3 grav,
-                      int history_slot, uint32_t& fault PROF_PARAM) {
+                      int history_slot, uint32_t& fault, bool is_eval PROF_PARAM) {
   const int leg = lane & 3;
   const bool is0 = leg == 0;
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
@@ -592,7 +596,7 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
   PROF(11);
   QUAD_SYNC();                // running sums complete before a reset logs / clears them
   // ---- reset ----------------------------------------------------------------------------------------
-  if (reset && is0) reset_env(cfg, B, e, N, counter_post);
+  if (reset && is0) reset_env(cfg, B, e, N, counter_post, is_eval);
   QUAD_SYNC();                // the observation sees the post-reset state, as in the reference
   PROF(12);
 

@@ -26,9 +26,13 @@ static_assert(A_IO_END <= LDSW_SIZE, "the actuator network's transient rows are 
 static_assert(L_END >= GO1_MAX_OBS, "post_physics stages the observation rows in the solver's LDS block");
 struct SimConst {            // lives in device memory (one per handle): indexable with scalar loads
   Go1SimConfig cfg;
+  Go1SimConfig cfg_eval;     // configuration of the environments [num_train_envs, num_envs) (a copy of cfg without a split)
+  int32_t num_train_envs;
   Go1SimBuffers buf;
   RewardPlan rew;            // derived at create / set_config: reward terms indexed by id (go1_maps.h)
 };
+// the wavefront's configuration block: 16 consecutive environments are all train or all evaluation environments
+#define WAVE_CFG(csc, first_env) (((first_env) >= (csc)->num_train_envs) ? (csc)->cfg_eval : (csc)->cfg)
 struct StepArgs {
   const SimConst* __restrict__ sc;
   const float* actions;      // (N,12) row-major, or SoA for the piecewise entry points
@@ -74,7 +78,7 @@ extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(
     for (int i = threadIdx.x; i < LDSX_SIZE / 4; i += WAVE * STEP_WAVES) reinterpret_cast<zf4*>(ldsx)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
   }
   const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
-  CfgRef cfg = csc->cfg;
+  CfgRef cfg = WAVE_CFG(csc, (int)blockIdx.x * EPW);
   BufRef B = csc->buf;
   const int N = cfg.num_envs;
   const int e = blockIdx.x * EPW + (lane >> 2);
@@ -177,7 +181,7 @@ extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(
   LDS_PHASE();
   PROF(7);
 #ifndef GO1_ABLATE_POST
-  post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, grav, A.history_slot, fault PROF_PASS);
+  post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, grav, A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs PROF_PASS);
 #endif
   report_fault(B, e, fault);
   PROF_FLUSH;
@@ -197,7 +201,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   }
   LDS_PHASE();
   const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
-  CfgRef cfg = csc->cfg;
+  CfgRef cfg = WAVE_CFG(csc, (int)blockIdx.x * EPW);
   BufRef B = csc->buf;
   const int N = cfg.num_envs;
   const int lane = threadIdx.x, leg = lane & 3;
@@ -208,7 +212,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   if (A.mode == 4) {       // tensor maps only
     PROF_DECL
     uint32_t fault = 0;
-    post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot, fault PROF_PASS);
+    post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs PROF_PASS);
     report_fault(B, e, fault);
     return;
   }
@@ -240,11 +244,15 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
 // one environment per lane: reset_idx
 extern "C" __global__ void __launch_bounds__(WAVE) go1_env_kernel(const StepArgs A) {
   const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
-  CfgRef cfg = csc->cfg;
   BufRef B = csc->buf;
-  const int N = cfg.num_envs;
-  const int e = blockIdx.x * WAVE + threadIdx.x;
-  if (e < A.n_ids) reset_env(cfg, B, A.ids ? A.ids[e] : e, N, A.counter);
+  const int N = csc->cfg.num_envs;
+  const int i = blockIdx.x * WAVE + threadIdx.x;
+  if (i < A.n_ids) {
+    const int e = A.ids ? A.ids[i] : i;
+    const bool ev = e >= csc->num_train_envs;              // per lane here: the ids are arbitrary
+    CfgRef cfg = ev ? csc->cfg_eval : csc->cfg;
+    reset_env(cfg, B, e, N, A.counter, ev);
+  }
 }
 
 // HistoryWrapper.get_observations: append the current obs_buf to the double-length ring
@@ -312,6 +320,8 @@ extern "C" __global__ void __launch_bounds__(256) go1_curriculum_kernel(const Si
 // ================================================================================================
 struct Go1Sim {
   Go1SimConfig cfg;
+  Go1SimConfig cfg_eval;
+  int32_t num_train;   // == cfg.num_envs: no evaluation environments
   Go1SimBuffers buf;
   int device;
   int64_t counter;
@@ -336,6 +346,9 @@ static int check_cfg(const Go1SimConfig* cfg) {
 static int upload_const(Go1Sim* s) {
   SimConst h;
   h.cfg = s->cfg; h.buf = s->buf;
+  const bool split = s->num_train > 0 && s->num_train < s->cfg.num_envs;
+  h.cfg_eval = split ? s->cfg_eval : s->cfg;
+  h.num_train_envs = split ? s->num_train : s->cfg.num_envs;
   for (int id = 0; id < GO1_REW_COUNT; id++) { h.rew.kx_by_id[id] = -1; h.rew.scale_by_id[id] = 0.f; }
   for (int kx = 0; kx < s->cfg.num_rewards; kx++) {
     const int id = s->cfg.reward_ids[kx];
@@ -351,6 +364,7 @@ extern "C" int go1sim_create(const Go1SimConfig* cfg, const Go1SimBuffers* buffe
   if (hipSetDevice(device) != hipSuccess) return -10;
   Go1Sim* s = new Go1Sim();
   s->cfg = *cfg; s->buf = *buffers; s->device = device;
+  s->cfg_eval = *cfg; s->num_train = cfg->num_envs;
   s->counter = 0; s->lag_head = 0; s->history_slot = 0; s->timing_cap = 0; s->timing_n = 0; s->ev = nullptr;
   s->dconst = nullptr;
   if (hipMalloc((void**)&s->dconst, sizeof(SimConst)) != hipSuccess) { delete s; return -12; }
@@ -373,6 +387,22 @@ extern "C" int go1sim_set_config(Go1Sim* s, const Go1SimConfig* cfg) {
   if (cfg->num_envs != s->cfg.num_envs) return -6;
   s->cfg = *cfg;
   return upload_const(s);      // blocking copy: configuration changes are rare and never on the step path
+}
+extern "C" int go1sim_set_eval_config(Go1Sim* s, const Go1SimConfig* cfg, int32_t num_train_envs) {
+  if (!s) return -1;
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  const Go1SimConfig& t = s->cfg;
+  if (cfg->num_envs != t.num_envs || cfg->num_obs != t.num_obs || cfg->num_privileged_obs != t.num_privileged_obs ||
+      cfg->num_obs_history != t.num_obs_history || cfg->num_rewards != t.num_rewards || cfg->decimation != t.decimation ||
+      cfg->lag_timesteps != t.lag_timesteps || cfg->control_type != t.control_type || cfg->num_commands != t.num_commands ||
+      cfg->num_bins != t.num_bins || cfg->num_categories != t.num_categories || cfg->terrain_type != t.terrain_type ||
+      cfg->seed != t.seed || cfg->env_id_offset != t.env_id_offset)
+    return -6;
+  if (num_train_envs <= 0 || num_train_envs > t.num_envs || (num_train_envs < t.num_envs && (num_train_envs % EPW) != 0)) return -3;
+  s->cfg_eval = *cfg;
+  s->num_train = num_train_envs;
+  return upload_const(s);
 }
 
 static int launch(Go1Sim* s, int mode, const float* actions, const int32_t* ids, int n_ids, hipStream_t st, bool timed,

@@ -11,8 +11,6 @@ def parse_device_str(device_str):
 
 class BaseTask(gym.Env):
     def __init__(self, cfg, sim_params, physics_engine, sim_device, headless, eval_cfg=None):
-        if eval_cfg is not None:
-            raise NotImplementedError("train/eval env split (SURVEY.md §8f rank 4)")
         self.sim_params = sim_params
         self.physics_engine = physics_engine
         self.sim_device = sim_device
@@ -22,9 +20,14 @@ class BaseTask(gym.Env):
         self.num_obs = cfg.env.num_observations
         self.num_privileged_obs = cfg.env.num_privileged_obs
         self.num_actions = cfg.env.num_actions
-        self.num_eval_envs = 0
-        self.num_train_envs = cfg.env.num_envs
-        self.num_envs = cfg.env.num_envs
+        if eval_cfg is not None:          # reference base_task.py:43-49: evaluation environments behind the training ones
+            self.num_eval_envs = eval_cfg.env.num_envs
+            self.num_train_envs = cfg.env.num_envs
+            self.num_envs = self.num_eval_envs + self.num_train_envs
+        else:
+            self.num_eval_envs = 0
+            self.num_train_envs = cfg.env.num_envs
+            self.num_envs = cfg.env.num_envs
         self.extras = {}
         self.viewer = None
         self.enable_viewer_sync = True

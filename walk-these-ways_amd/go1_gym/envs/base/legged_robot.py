@@ -131,6 +131,8 @@ class LeggedRobot(BaseTask):
         self.debug_viz = False
         self.init_done = False
         self.initial_dynamics_dict = initial_dynamics_dict
+        if eval_cfg is not None:          # reference legged_robot.py:41-42
+            self._parse_cfg(eval_cfg)
         self._parse_cfg(cfg)
         super().__init__(cfg, sim_params, physics_engine, sim_device, headless, eval_cfg)
         self._init_buffers()
@@ -165,6 +167,14 @@ class LeggedRobot(BaseTask):
         if mesh_type not in (None, 'plane', 'heightfield', 'trimesh'):
             raise ValueError("Terrain mesh type not recognised. Allowed types are [None, plane, heightfield, trimesh]")
         self.up_axis_idx = 2
+        if self.eval_cfg is not None:
+            if mesh_type in ('heightfield', 'trimesh') or self.eval_cfg.terrain.mesh_type in ('heightfield', 'trimesh'):
+                raise NotImplementedError("eval_cfg with a generated terrain: the reference appends a second terrain region for "
+                                          "the evaluation environments (legged_robot.py:502-503, terrain.py); only built for "
+                                          "mesh_type None / 'plane' here")
+            if self.num_train_envs % 16 != 0:
+                raise ValueError(f"eval_cfg: cfg.env.num_envs = {self.num_train_envs} must be a multiple of 16 (the step kernel "
+                                 f"selects the train / evaluation configuration per wavefront of 16 environments)")
         if mesh_type in ('heightfield', 'trimesh'):
             self.terrain = Terrain(cfg.terrain, self.num_train_envs)
             hs = self.terrain.heightsamples
@@ -213,10 +223,33 @@ class LeggedRobot(BaseTask):
             [i for i in range(17) if self.sim_config.termination_body_mask >> i & 1], device=self.device)
         self._get_env_origins()
         self._init_custom_buffers__()
-        self._randomize_rigid_body_props(torch.arange(self.num_envs, device=self.device), cfg)
+        self._call_train_eval(self._randomize_rigid_body_props, torch.arange(self.num_envs, device=self.device))
         self.category_names = self.sim_meta["category_names"]
         self.curricula = self.sim_meta["curricula"]
         self.sim = H.Go1Sim(self.sim_config, B, self.sim_device_id)
+        self.sim_config_eval = None
+        if self.eval_cfg is not None:
+            # evaluation environments: the train block with the fields the reference dispatches per group taken from
+            # eval_cfg (go1sim_host.EVAL_CFG_FIELDS); selected per wavefront inside the kernels
+            S_e, _ = H.build_sim_config(self.eval_cfg, num_envs=self.num_envs, seed=seed, env_id_offset=offset,
+                                        solver_iterations=self.sim_config.solver_iterations,
+                                        defer_curriculum_update=self._curriculum_sync)
+            self.sim_config_eval = H.make_eval_sim_config(self.sim_config, S_e)
+            self.sim.set_eval_config(self.sim_config_eval, self.num_train_envs)
+        B.episode_sums_eval.fill_(-1.0)          # reference legged_robot.py:1420-1424 (only evaluation environments ever write it)
+
+    def _call_train_eval(self, func, env_ids):
+        """reference legged_robot.py:531-544: func(ids, cfg) for the training environments, func(ids, eval_cfg) for the others"""
+        env_ids_train = env_ids[env_ids < self.num_train_envs]
+        env_ids_eval = env_ids[env_ids >= self.num_train_envs]
+        ret, ret_eval = None, None
+        if len(env_ids_train) > 0:
+            ret = func(env_ids_train, self.cfg)
+        if len(env_ids_eval) > 0:
+            ret_eval = func(env_ids_eval, self.eval_cfg)
+            if ret is not None and ret_eval is not None:
+                ret = torch.cat((ret, ret_eval), axis=-1)
+        return ret
 
     def _get_env_origins(self):
         """reference legged_robot.py:1675-1714."""
@@ -239,12 +272,16 @@ class LeggedRobot(BaseTask):
             origins = ter.terrain_origins[self.terrain_levels, self.terrain_types]
         else:
             self.custom_origins = False
-            cols = np.floor(np.sqrt(N))
-            rows = np.ceil(N / cols)
-            xx, yy = torch.meshgrid(torch.arange(rows), torch.arange(cols), indexing="ij")
             origins = torch.zeros(N, 3, device=self.device)
-            origins[:, 0] = cfg.env.env_spacing * xx.flatten()[:N].to(self.device)
-            origins[:, 1] = cfg.env.env_spacing * yy.flatten()[:N].to(self.device)
+            # one grid per group (reference: _call_train_eval(self._get_env_origins, ...), :1538, :1704-1714)
+            for lo_, n_, c_ in ((0, self.num_train_envs, cfg), (self.num_train_envs, self.num_eval_envs, self.eval_cfg)):
+                if n_ == 0:
+                    continue
+                cols = np.floor(np.sqrt(n_))
+                rows = np.ceil(n_ / cols)
+                xx, yy = torch.meshgrid(torch.arange(rows), torch.arange(cols), indexing="ij")
+                origins[lo_:lo_ + n_, 0] = c_.env.env_spacing * xx.flatten()[:n_].to(self.device)
+                origins[lo_:lo_ + n_, 1] = c_.env.env_spacing * yy.flatten()[:n_].to(self.device)
             self.terrain_levels = torch.zeros(N, dtype=torch.long, device=self.device)
             self.terrain_types = torch.zeros(N, dtype=torch.long, device=self.device)
         B.env_origins.copy_(origins.t())
@@ -340,10 +377,16 @@ class LeggedRobot(BaseTask):
         self.common_step_counter = 0
         self.measured_heights = B.measured_heights.t() if S.measure_heights else 0
         self.add_noise = self.cfg.noise.add_noise
-        self.extras = {"env_bins": B.env_command_bins, "train/episode": _EpisodeStats(self), "sim_faults": _SimFaults(self)}
+        nt = self.num_train_envs
+        self.extras = {"env_bins": B.env_command_bins[:nt], "train/episode": _EpisodeStats(self), "sim_faults": _SimFaults(self)}
         self.fault_flags = B.fault_flags
+        # evaluation environments (reference legged_robot.py:188-195, 1420-1424): their first finished episode's sums;
+        # the reference's extras["eval/episode"] is created empty and never filled — kept so for the Runner's logging branch
+        self.episode_sums_eval = {n: B.episode_sums_eval[i] for i, n in enumerate(self.episode_sum_names)}
+        if self.num_eval_envs > 0:
+            self.extras["eval/episode"] = {}
         if self.cfg.env.send_timeouts:
-            self.extras["time_outs"] = self.time_out_buf
+            self.extras["time_outs"] = self.time_out_buf[:nt]
         if self.cfg.commands.command_curriculum:
             self.extras["curriculum/distribution"] = _CurriculumDistribution(self)
 

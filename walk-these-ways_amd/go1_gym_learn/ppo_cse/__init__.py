@@ -70,13 +70,23 @@ class Runner:
         self.last_recording_it = 0
         self.collection_time = 0.0
         self.learn_time = 0.0
+        self._it_now = 0
+        self._eval_module_it = None          # iteration whose weights the nn.Module (evaluation actions) was last refreshed with
         self.env.reset()
 
     # one policy step of the rollout (reference :139-154)
-    def _rollout_step(self, obs_dict):
+    def _rollout_step(self, obs_dict, eval_expert=False):
         n = self.env.num_train_envs
         obs, priv, hist = obs_dict["obs"], obs_dict["privileged_obs"], obs_dict["obs_history"]
         actions = self.alg.act(obs[:n], priv[:n], hist[:n])
+        if self.env.num_eval_envs > 0:          # evaluation environments: deterministic student / teacher actions (:142-147)
+            ac = self.alg.sync_module() if self._eval_module_it != self._it_now else self.alg.actor_critic
+            self._eval_module_it = self._it_now
+            if eval_expert:
+                actions_eval = ac.act_teacher(hist[n:], priv[n:])
+            else:
+                actions_eval = ac.act_student(hist[n:])
+            actions = torch.cat((actions, actions_eval), dim=0)
         obs_dict, rewards, dones, infos = self.env.step(actions)
         self.alg.process_env_step(rewards[:n], dones[:n], infos)
         return obs_dict, infos
@@ -97,8 +107,9 @@ class Runner:
         for it in range(self.current_learning_iteration, tot_iter):
             start = time.time()
             with torch.inference_mode():
+                self._it_now = it
                 for _ in range(self.num_steps_per_env):
-                    obs_dict, infos = self._rollout_step(obs_dict)
+                    obs_dict, infos = self._rollout_step(obs_dict, eval_expert)
                 stop = time.time()
                 self.collection_time = stop - start
                 start = stop

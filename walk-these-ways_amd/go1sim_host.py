@@ -369,7 +369,7 @@ def _buffer_specs(S):
         "episode_length_buf": (i32, (N,)), "reset_buf": (u8, (N,)), "time_out_buf": (u8, (N,)),
         "last_contacts": (u8, (4, N)), "resample_flags": (u8, (N,)),
         "rew_buf": (f, (N,)), "episode_sums": (f, (nr + 1, N)), "command_sums": (f, (nr + 5, N)),
-        "episode_log": (f, (nr + 2,)),
+        "episode_log": (f, (nr + 2,)), "episode_sums_eval": (f, (nr + 1, N)),
         "friction_coeffs": (f, (N,)), "restitutions": (f, (N,)), "payloads": (f, (N,)),
         "com_displacements": (f, (3, N)), "motor_strengths": (f, (12, N)), "motor_offsets": (f, (12, N)),
         "Kp_factors": (f, (12, N)), "Kd_factors": (f, (12, N)), "env_origins": (f, (3, N)),
@@ -429,6 +429,36 @@ class SimBuffers:
         return other
 
 
+# The fields the reference reads from the environment's OWN group configuration (`_call_train_eval(func, env_ids)` ->
+# func(env_ids, cfg | eval_cfg), legged_robot.py:531-544): _randomize_dof_props :646-665, _randomize_rigid_body_props
+# :611-633, _push_robots :1020-1026, _teleport_robots :1031-1045, _reset_root_states :973-980.  Everything else
+# (commands / curriculum, rewards, observations, control, physics) comes from the train configuration for all environments.
+EVAL_CFG_FIELDS = ("randomize_motor_strength", "randomize_motor_offset", "randomize_Kp_factor", "randomize_Kd_factor",
+                   "motor_strength_range", "motor_offset_range", "Kp_factor_range", "Kd_factor_range",
+                   "randomize_base_mass", "randomize_com_displacement", "randomize_friction", "randomize_restitution",
+                   "added_mass_range", "com_displacement_range", "friction_range", "restitution_range",
+                   "push_robots", "push_interval", "max_push_vel_xy",
+                   "teleport_robots", "teleport_thresh", "teleport_x_offset", "terrain_length", "terrain_width",
+                   "terrain_num_rows", "terrain_num_cols",
+                   "x_init_range", "y_init_range", "yaw_init_range", "x_init_offset", "y_init_offset")
+
+
+def make_eval_sim_config(S_train, S_from_eval_cfg):
+    """Go1SimConfig of the evaluation environments: the train block with the group-dispatched fields of `eval_cfg`
+    (S_from_eval_cfg = build_sim_config(eval_cfg, ...))."""
+    S = abi.Go1SimConfig()
+    ctypes.memmove(ctypes.byref(S), ctypes.byref(S_train), ctypes.sizeof(S))
+    for name in EVAL_CFG_FIELDS:
+        v = getattr(S_from_eval_cfg, name)
+        if hasattr(v, "__len__"):
+            dst = getattr(S, name)
+            for i in range(len(v)):
+                dst[i] = v[i]
+        else:
+            setattr(S, name, v)
+    return S
+
+
 # ---------------------------------------------------------------------------------------------
 _lib = None
 
@@ -456,6 +486,7 @@ def bind_library(lib):
     lib.go1sim_create.argtypes = [ctypes.POINTER(abi.Go1SimConfig), ctypes.POINTER(abi.Go1SimBuffers), ctypes.c_int, ctypes.POINTER(vp)]
     lib.go1sim_destroy.argtypes = [vp]
     lib.go1sim_set_config.argtypes = [vp, ctypes.POINTER(abi.Go1SimConfig)]
+    lib.go1sim_set_eval_config.argtypes = [vp, ctypes.POINTER(abi.Go1SimConfig), i32]
     lib.go1sim_step.argtypes = [vp, vp, vp]
     lib.go1sim_reset_idx.argtypes = [vp, vp, i32, vp]
     lib.go1sim_compute_torques.argtypes = [vp, vp, vp]
@@ -469,7 +500,7 @@ def bind_library(lib):
     lib.go1sim_enable_timing.argtypes = [vp, ctypes.c_int]
     lib.go1sim_read_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float), i32, ctypes.POINTER(i32)]
     lib.go1sim_version.restype = ctypes.c_char_p
-    for fn in ("go1sim_create", "go1sim_destroy", "go1sim_set_config", "go1sim_step", "go1sim_reset_idx",
+    for fn in ("go1sim_create", "go1sim_destroy", "go1sim_set_config", "go1sim_set_eval_config", "go1sim_step", "go1sim_reset_idx",
                "go1sim_compute_torques", "go1sim_physics_substep", "go1sim_curriculum_update", "go1sim_post_physics",
                "go1sim_append_history", "go1sim_history_window_offset",
                "go1sim_get_counters", "go1sim_set_counters", "go1sim_enable_timing", "go1sim_read_timings"):
@@ -477,7 +508,7 @@ def bind_library(lib):
     return lib
 
 
-EXPORTED_SYMBOLS = ["go1sim_create", "go1sim_destroy", "go1sim_set_config", "go1sim_step", "go1sim_reset_idx",
+EXPORTED_SYMBOLS = ["go1sim_create", "go1sim_destroy", "go1sim_set_config", "go1sim_set_eval_config", "go1sim_step", "go1sim_reset_idx",
                     "go1sim_compute_torques", "go1sim_physics_substep", "go1sim_curriculum_update",
                     "go1sim_post_physics", "go1sim_append_history", "go1sim_history_window_offset",
                     "go1sim_get_counters", "go1sim_set_counters", "go1sim_enable_timing",
@@ -539,6 +570,11 @@ class Go1Sim:
     def set_config(self, S):
         self.S = S
         self._check(self.lib.go1sim_set_config(self.handle, ctypes.byref(S)), "go1sim_set_config")
+
+    def set_eval_config(self, S_eval, num_train_envs):
+        """environments [num_train_envs, N) run under S_eval (make_eval_sim_config); num_train_envs % 16 == 0"""
+        self.S_eval, self.num_train_envs = S_eval, int(num_train_envs)
+        self._check(self.lib.go1sim_set_eval_config(self.handle, ctypes.byref(S_eval), int(num_train_envs)), "go1sim_set_eval_config")
 
     def counters(self):
         c, h = ctypes.c_int64(), ctypes.c_int32()
