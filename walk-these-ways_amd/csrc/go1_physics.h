@@ -1196,12 +1196,25 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       }
     }
     PROF(23);
+    // The lane's shares of a row of W do not depend on the iterate: a contact's nine loads (three rows x [4 + 4 + 1]) are
+    // issued together, UNCONDITIONALLY, before its projection — one LDS latency per contact, running under the projection
+    // arithmetic, instead of nine exposed ones (a load behind a wave-uniform `if (ccw & ..)` sits in its own basic block
+    // with its own wait).  Slots of columns that exist nowhere in the wavefront hold finite leftovers (zero fill, earlier
+    // substeps) and only ever update row velocities nobody reads.
+    struct Share { lf4 a, b; float c; };
+    auto fetch = [&](int c) { Share sh; sh.a = WSH4(c, 0); sh.b = WSH4(c, 1); sh.c = WSH8(c); return sh; };
+    auto apply_share = [&](const Share& sh, float dl) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) { uloc[i] = fmaf(sh.a[i], dl, uloc[i]); uloc[4 + i] = fmaf(sh.b[i], dl, uloc[4 + i]); }
+      uloc[8] = fmaf(sh.c, dl, uloc[8]);
+    };
 #pragma unroll 1
     for (int it = 0; it < cfg.solver_iterations; it++) {
 #pragma unroll
       for (int k = 0; k < MAXC; k++) {
         if (k < Kw) {
           const int r0 = 3 * k;
+          const Share s0 = fetch(r0), s1 = fetch(r0 + 1), s2 = fetch(r0 + 2);
           const float un = quad_bcast(uloc[r0 >> 2], r0);      // row r sits in lane r & 3 at slot r >> 2
           float u1 = quad_bcast(uloc[(r0 + 1) >> 2], r0 + 1);
           float u2 = quad_bcast(uloc[(r0 + 2) >> 2], r0 + 2);
@@ -1217,7 +1230,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
           if (nn > lim * lim) { const float sc = lim * __builtin_amdgcn_rsqf(nn); l1 *= sc; l2 *= sc; }
           const bool on = k < K;                               // lanes of environments with fewer contacts idle here
           const float nl0 = on ? ln : 0.f, nl1 = on ? l1 : 0.f, nl2 = on ? l2 : 0.f;
-          apply_col(r0, nl0 - lam[r0]); apply_col(r0 + 1, nl1 - lam[r0 + 1]); apply_col(r0 + 2, nl2 - lam[r0 + 2]);
+          apply_share(s0, nl0 - lam[r0]); apply_share(s1, nl1 - lam[r0 + 1]); apply_share(s2, nl2 - lam[r0 + 2]);
           lam[r0] = nl0; lam[r0 + 1] = nl1; lam[r0 + 2] = nl2;
         }
       }
@@ -1225,17 +1238,24 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
 #pragma unroll
       for (int lgi = 0; lgi < 4; lgi++) {
         if (LAw & (1u << lgi)) {
+          Share sj[3];
+          lf4 rec[3];
+          float idg[3];
+#pragma unroll
+          for (int jj = 0; jj < 3; jj++) {                     // the leg's three rows: records and shares up front
+            const float* jr = JR(3 * lgi + jj);
+            rec[jj] = *reinterpret_cast<const lf4*>(jr);       // b, lower, upper, W[r][r]
+            idg[jj] = jr[4];                                   // 0: not a row of this environment
+            sj[jj] = fetch(NRC + 3 * lgi + jj);
+          }
 #pragma unroll
           for (int jj = 0; jj < 3; jj++) {
             const int j = 3 * lgi + jj, r = NRC + j;
-            const float* jr = JR(j);
-            const lf4 rec = *reinterpret_cast<const lf4*>(jr);   // b, lower, upper, W[r][r]
-            const float idiag = jr[4];                           // 0: not a row of this environment
             const float u = quad_bcast(uloc[r >> 2], r);
-            const float u0 = u - rec[3] * lamj[j];
-            const float ut = fminf(fmaxf(u0, rec[1]), rec[2]);
-            const float ln = (ut - u0) * idiag;
-            apply_col(r, ln - lamj[j]);
+            const float u0 = u - rec[jj][3] * lamj[j];
+            const float ut = fminf(fmaxf(u0, rec[jj][1]), rec[jj][2]);
+            const float ln = (ut - u0) * idg[jj];
+            apply_share(sj[jj], ln - lamj[j]);
             lamj[j] = ln;
           }
         }
