@@ -231,6 +231,12 @@ class FusedNet:
             if os.environ.get("GO1_W1_SPLIT"):
                 self._w1_split = int(os.environ["GO1_W1_SPLIT"])
             self._w1_tmp = torch.zeros(self._w1_split, self.n1, policy.Kp, **bf)
+            # GO1_DGRAD_NT=1: the 512 -> 256 input gradients on go1ppo_gemm_nt with the ELU' epilogue.  Measured in situ it is
+            # 0.6 ms per iteration SLOWER than hipBLASLt + the element-wise pass on two streams (the microbenchmark with cold
+            # operands says the opposite, tools/bench_gemm.py): off by default, kept for A/B runs
+            self._dgrad_nt = os.environ.get("GO1_DGRAD_NT", "0") == "1" and self._mlp2
+            self._WT = {n: torch.zeros(self.P[f"{n}.1.W"].shape[1], self.P[f"{n}.1.W"].shape[0], **bf) for n in ("actor", "critic")} \
+                if self._dgrad_nt else None
 
     # ---- kernels -----------------------------------------------------------------------------------------
     def _elu(self, y, lat=None, lat_cols=0):
@@ -367,11 +373,21 @@ class FusedNet:
             self._wgrad(dZ[net][3], Z[net][2], G[f"{net}.3.W"], None)
             self._wgrad(dZ[net][2], Z[net][1], G[f"{net}.2.W"], G[f"{net}.2.b"])
             self._wgrad(dZ[net][1], Y1[:, cols[net]], G[f"{net}.1.W"], G[f"{net}.1.b"])
-        with self._branch():
-            torch.mm(dZ["critic"][1], P["critic.1.W"], out=dH1["critic"])
-            self._elu_bwd(dH1["critic"], Y1[:, cols["critic"]], None, out=dY1[:, cols["critic"]])
-        torch.mm(dZ["actor"][1], P["actor.1.W"], out=dH1["actor"])
-        self._elu_bwd(dH1["actor"], Y1[:, cols["actor"]], None, out=dY1[:, cols["actor"]])
+        if self._dgrad_nt:
+            # input gradient of the 512 -> 256 layers with the ELU-backward factor of the first layer folded into the GEMM's
+            # epilogue (go1ppo_gemm_nt, epilogue 2): dY1 = (dz1 W) * elu'(h1) in one pass per net instead of a hipBLASLt GEMM
+            # + an element-wise pass over (M x 512).  The kernel wants the weight K-contiguous: W^T, refreshed here (256 KB).
+            with self._branch():
+                self._WT["critic"].copy_(P["critic.1.W"].t())
+                gemm_nt(self.lib, dZ["critic"][1], self._WT["critic"], dY1[:, cols["critic"]], elu_bwd_of=Y1[:, cols["critic"]])
+            self._WT["actor"].copy_(P["actor.1.W"].t())
+            gemm_nt(self.lib, dZ["actor"][1], self._WT["actor"], dY1[:, cols["actor"]], elu_bwd_of=Y1[:, cols["actor"]])
+        else:
+            with self._branch():
+                torch.mm(dZ["critic"][1], P["critic.1.W"], out=dH1["critic"])
+                self._elu_bwd(dH1["critic"], Y1[:, cols["critic"]], None, out=dY1[:, cols["critic"]])
+            torch.mm(dZ["actor"][1], P["actor.1.W"], out=dH1["actor"])
+            self._elu_bwd(dH1["actor"], Y1[:, cols["actor"]], None, out=dY1[:, cols["actor"]])
         # actor first layer's latent columns: a1 += latent Wz^T
         latent, dlat = Z["adaptation"][2], dZ["adaptation"][2]
         dA1 = dY1[:, cols["actor"]]
