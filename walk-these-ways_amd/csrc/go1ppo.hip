@@ -651,20 +651,47 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(Go1PpoTailArgs A) {
         for (int h = 0; h < RT; h++) acc[jj][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const bf16_t* wrow = W + (int64_t)(16 * j0 + c) * L.k_in + 8 * g;
       const int64_t wstep = (int64_t)64 * L.k_in;                 // 4 tiles = 64 rows of W further
-#pragma unroll 2
-      for (int ks = 0; ks < ksteps; ks++) {
-        bf16x8_t a[RT], bfr[4];
+      // The weight fragments come straight from L2 (16 B per lane, no staging): a load waited for where it is issued costs a
+      // full L2 round trip (~700 cycles) per k-step with one wavefront per SIMD.  So they are fetched a CHUNK of 4 k-steps
+      // ahead into a second register set: 16 loads in flight under the 32 MFMAs of the current chunk.
+      constexpr int CH = 4;
+      const int nch = (ksteps + CH - 1) / CH;
+      bf16x8_t BA[CH][4], BB[CH][4];
+      auto fetch = [&](bf16x8_t (&B)[CH][4], int kc) {
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++)
-          if (j0 + 4 * jj < ntiles) bfr[jj] = *reinterpret_cast<const bf16x8_t*>(wrow + jj * wstep + 32 * ks);
+        for (int s_ = 0; s_ < CH; s_++) {
+          const int ks = kc * CH + s_;
 #pragma unroll
-        for (int h = 0; h < RT; h++) a[h] = *reinterpret_cast<const bf16x8_t*>(&act[cur][16 * h + c][32 * ks + 8 * g]);
+          for (int jj = 0; jj < 4; jj++)
+            if (ks < ksteps && j0 + 4 * jj < ntiles) B[s_][jj] = *reinterpret_cast<const bf16x8_t*>(wrow + jj * wstep + 32 * ks);
+        }
+      };
+      auto compute = [&](const bf16x8_t (&B)[CH][4], int kc) {
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++)
-          if (j0 + 4 * jj < ntiles) {
+        for (int s_ = 0; s_ < CH; s_++) {
+          const int ks = kc * CH + s_;
+          if (ks < ksteps) {
+            bf16x8_t a[RT];
 #pragma unroll
-            for (int h = 0; h < RT; h++) acc[jj][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[h], bfr[jj], acc[jj][h], 0, 0, 0);
+            for (int h = 0; h < RT; h++) a[h] = *reinterpret_cast<const bf16x8_t*>(&act[cur][16 * h + c][32 * ks + 8 * g]);
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++)
+              if (j0 + 4 * jj < ntiles) {
+#pragma unroll
+                for (int h = 0; h < RT; h++) acc[jj][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[h], B[s_][jj], acc[jj][h], 0, 0, 0);
+              }
           }
+        }
+      };
+      fetch(BA, 0);
+#pragma unroll 1
+      for (int kc = 0; kc < nch; kc += 2) {
+        if (kc + 1 < nch) fetch(BB, kc + 1);
+        compute(BA, kc);
+        if (kc + 1 < nch) {
+          if (kc + 2 < nch) fetch(BA, kc + 2);
+          compute(BB, kc + 1);
+        }
       }
 #pragma unroll
       for (int jj = 0; jj < 4; jj++) {
