@@ -71,6 +71,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(Go1PpoGemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // epilogue 2 multiplies by elu'(H): its 16 H fragments are requested NOW — a load issued in the epilogue is waited for right
+  // there (an HBM round trip per fragment with nothing to hide it: 19 such waits made this variant slower than GEMM + a
+  // separate element-wise pass)
+  uint2 hpre[4][4];
+  if (EPI == 2) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int n = n0 + wn * 64 + j * 16 + fg * 4;
+      n = n < a.N ? n : a.N - 4;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        int m = m0 + wm * 64 + i * 16 + fr;
+        m = m < a.M ? m : a.M - 1;
+        hpre[j][i] = *reinterpret_cast<const uint2*>((const bf16_t*)a.H + (int64_t)m * a.ldh + n);
+      }
+    }
+  }
   const int KT = a.K / GEMM_BK;
   stage(0, 0);
   for (int kt = 0; kt < KT; kt++) {
@@ -113,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(Go1PpoGemmArgs a) {
           for (int e = 0; e < 4; e++) v[e] = elu1(v[e]);
         }
       } else if (EPI == 2) {
-        uint2 hraw = *reinterpret_cast<const uint2*>((const bf16_t*)a.H + (int64_t)m * a.ldh + n);
+        const uint2 hraw = hpre[j][i];
         float h[4] = {__uint_as_float(hraw.x << 16), __uint_as_float(hraw.x & 0xffff0000u), __uint_as_float(hraw.y << 16),
                       __uint_as_float(hraw.y & 0xffff0000u)};
 #pragma unroll

@@ -231,10 +231,10 @@ class FusedNet:
             if os.environ.get("GO1_W1_SPLIT"):
                 self._w1_split = int(os.environ["GO1_W1_SPLIT"])
             self._w1_tmp = torch.zeros(self._w1_split, self.n1, policy.Kp, **bf)
-            # GO1_DGRAD_NT=1: the 512 -> 256 input gradients on go1ppo_gemm_nt with the ELU' epilogue.  Measured in situ it is
-            # 0.6 ms per iteration SLOWER than hipBLASLt + the element-wise pass on two streams (the microbenchmark with cold
-            # operands says the opposite, tools/bench_gemm.py): off by default, kept for A/B runs
-            self._dgrad_nt = os.environ.get("GO1_DGRAD_NT", "0") == "1" and self._mlp2
+            # GO1_DGRAD_NT: the 512 -> 256 input gradients on go1ppo_gemm_nt with the ELU' epilogue instead of hipBLASLt + the
+            # element-wise pass.  In situ A/B on one box: 23.30 vs 23.43 ms per iteration (it was 0.6 ms SLOWER while the
+            # epilogue still loaded its ELU' operand where it used it: 19 exposed HBM round trips per workgroup)
+            self._dgrad_nt = os.environ.get("GO1_DGRAD_NT", "1") == "1" and self._mlp2
             self._WT = {n: torch.zeros(self.P[f"{n}.1.W"].shape[1], self.P[f"{n}.1.W"].shape[0], **bf) for n in ("actor", "critic")} \
                 if self._dgrad_nt else None
 
