@@ -211,7 +211,7 @@ __device__ __forceinline__ void block_reduce_atomic(float (&v)[NV], float* const
 __global__ __launch_bounds__(256) void loss_kernel(Go1PpoLossArgs a) {
   __shared__ float lds[4 * (4 + 2 * GO1PPO_MAX_ACTIONS)];
   const int A = a.num_actions;
-  int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool on = r < a.rows;
   float invM = 1.f / (float)a.rows;
   float sur = 0.f, vl = 0.f, kl = 0.f, dvb = 0.f;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void wgrad_batched_kernel(const Go1PpoWgradPro
 __global__ __launch_bounds__(256) void act_kernel(const bf16_t* mean, const bf16_t* value, int head_ld, const float* std, int A,
                                                   int64_t rows, const float* noise, float* actions, float* mu, float* sigma,
                                                   float* values, float* logp) {
-  int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   const float HALF_LOG_2PI = 0.9189385332046727f;
   float lp = 0.f, logs = 0.f;
@@ -774,7 +774,9 @@ extern "C" int go1ppo_elu_bwd(const void* d, int ld_d, const void* h, int ld_h, 
 
 extern "C" int go1ppo_loss(const Go1PpoLossArgs* a, void* stream) {
   if (!a || a->rows <= 0 || a->num_actions <= 0 || a->num_actions > GO1PPO_MAX_ACTIONS || a->head_ld < a->num_actions) return -1;
-  loss_kernel<<<dim3((unsigned)((a->rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(*a);
+  // one wavefront per workgroup: a thread carries a whole sample (~40 gathered loads, latency-bound), so the 24576 samples of
+  // a mini-batch are only 384 wavefronts — as 256-thread workgroups they would occupy 96 of the 256 CUs
+  loss_kernel<<<dim3((unsigned)((a->rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream>>>(*a);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
@@ -808,7 +810,8 @@ extern "C" int go1ppo_act(const void* mean, const void* value, int head_ld, cons
   if (!mean || !value || !std || !noise || !actions || !mu || !sigma || !values || !logp || rows <= 0 || num_actions <= 0 ||
       num_actions > head_ld)
     return -1;
-  act_kernel<<<dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+  act_kernel<<<dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream>>>(          // (4096 rows: 64 CUs instead of 16)
+      
       (const bf16_t*)mean, (const bf16_t*)value, head_ld, std, num_actions, rows, noise, actions, mu, sigma, values, logp);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
