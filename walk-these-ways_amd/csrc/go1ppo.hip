@@ -774,9 +774,8 @@ extern "C" int go1ppo_elu_bwd(const void* d, int ld_d, const void* h, int ld_h, 
 
 extern "C" int go1ppo_loss(const Go1PpoLossArgs* a, void* stream) {
   if (!a || a->rows <= 0 || a->num_actions <= 0 || a->num_actions > GO1PPO_MAX_ACTIONS || a->head_ld < a->num_actions) return -1;
-  // one wavefront per workgroup: a thread carries a whole sample (~40 gathered loads, latency-bound), so the 24576 samples of
-  // a mini-batch are only 384 wavefronts — as 256-thread workgroups they would occupy 96 of the 256 CUs
-  loss_kernel<<<dim3((unsigned)((a->rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream>>>(*a);
+  // (measured: 64-thread workgroups — 384 instead of 96 — are slower, 33 vs 26 us: four times the atomics on the same 28 words)
+  loss_kernel<<<dim3((unsigned)((a->rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(*a);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
@@ -843,26 +842,32 @@ __device__ __forceinline__ uint32_t ring_pack(float a, float b) {
   f32x2 v = {a, b};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
-// one augmented row: the window's H entries are `no`/2 dwords each, entry j read from win + j * stride
+// one augmented row by ONE WAVEFRONT: the window's H entries are `no`/2 dwords each (140 B for the Go1: contiguous, 4-byte
+// aligned), entry j read from win + j * stride; lanes walk the entry's dwords, several entries in flight per lane
 __device__ __forceinline__ void ring_row(const uint32_t* __restrict__ win, int64_t stride_dw, const float* __restrict__ newest,
                                          const float* __restrict__ priv, int H, int no, int npv, int Kp, uint32_t* __restrict__ out) {
-  const int nod = no >> 1, Kd = H * nod;
-  for (int d = threadIdx.x; d < (Kp >> 1); d += blockDim.x) {
-    uint32_t v;
-    if (d < Kd) {
-      const int j = d / nod, c = d - j * nod;
-      if (newest && j == H - 1) v = ring_pack(newest[2 * c], newest[2 * c + 1]);
-      else v = win[(int64_t)j * stride_dw + c];
-    } else {
-      float e[2];
+  const int lane = threadIdx.x & 63, nod = no >> 1, Kd = H * nod;
+  const int Hm = newest ? H - 1 : H;
+  for (int c = lane; c < nod; c += 64) {
+    int j = 0;
+    for (; j + 6 <= Hm; j += 6) {
+      uint32_t v[6];
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
-        const int col = 2 * d + q - 2 * Kd;             // 0: the bias column, 1 .. npv: privileged observations, then padding
-        e[q] = col == 0 ? 1.f : (col <= npv ? priv[col - 1] : 0.f);
-      }
-      v = ring_pack(e[0], e[1]);
+      for (int u = 0; u < 6; u++) v[u] = win[(int64_t)(j + u) * stride_dw + c];
+#pragma unroll
+      for (int u = 0; u < 6; u++) out[(j + u) * nod + c] = v[u];
     }
-    out[d] = v;
+    for (; j < Hm; j++) out[j * nod + c] = win[(int64_t)j * stride_dw + c];
+    if (newest) out[(H - 1) * nod + c] = ring_pack(newest[2 * c], newest[2 * c + 1]);
+  }
+  for (int d = Kd + lane; d < (Kp >> 1); d += 64) {
+    float e[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int col = 2 * d + q - 2 * Kd;               // 0: the bias column, 1 .. npv: privileged observations, then padding
+      e[q] = col == 0 ? 1.f : (col <= npv ? priv[col - 1] : 0.f);
+    }
+    out[d] = ring_pack(e[0], e[1]);
   }
 }
 
@@ -878,30 +883,33 @@ __global__ __launch_bounds__(256) void ring_snapshot_kernel(const float* __restr
   ring[(j * N + n) * nod + c] = ring_pack(src[0], src[1]);
 }
 
-// one workgroup per environment: append the new observation (row s + H - 1; dst == NULL: the snapshot already holds it),
-// assemble the inference row, keep the fp32 copies of obs / privileged obs the storage wants
+// one WAVEFRONT per environment (4 per workgroup): append the new observation (row s + H - 1; dst == NULL: the snapshot
+// already holds it), assemble the inference row, keep the fp32 copies of obs / privileged obs the storage wants
 __global__ __launch_bounds__(256) void ring_step_kernel(const float* __restrict__ obs, const float* __restrict__ priv, uint32_t* __restrict__ dst,
                                                         const uint32_t* __restrict__ window, int64_t N, int H, int no, int npv, int Kp,
                                                         uint32_t* __restrict__ X, float* __restrict__ obs_store, float* __restrict__ priv_store) {
-  const int64_t n = blockIdx.x;
-  const int nod = no >> 1;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int lane = threadIdx.x & 63, nod = no >> 1;
   const float* o = obs + n * no;
   const float* pv = priv + n * npv;
-  for (int c = threadIdx.x; c < nod; c += blockDim.x) {
+  for (int c = lane; c < nod; c += 64) {
     if (dst) dst[n * nod + c] = ring_pack(o[2 * c], o[2 * c + 1]);
     if (obs_store) { obs_store[n * no + 2 * c] = o[2 * c]; obs_store[n * no + 2 * c + 1] = o[2 * c + 1]; }
   }
-  if (priv_store && threadIdx.x < npv) priv_store[n * npv + threadIdx.x] = pv[threadIdx.x];
+  if (priv_store && lane < npv) priv_store[n * npv + lane] = pv[lane];
   ring_row(window + n * nod, N * nod, o, pv, H, no, npv, Kp, X + n * (Kp >> 1));
 }
 
-// one workgroup per mini-batch row: storage index f = s * N + n
+// one wavefront per mini-batch row: storage index f = s * N + n
 __global__ __launch_bounds__(256) void ring_gather_kernel(const uint32_t* __restrict__ ring, const float* __restrict__ priv_store,
-                                                          const int64_t* __restrict__ idx, int64_t N, int H, int no, int npv, int Kp,
-                                                          uint32_t* __restrict__ X) {
-  const int64_t f = idx[blockIdx.x], s = f / N, n = f - s * N;
+                                                          const int64_t* __restrict__ idx, int64_t rows, int64_t N, int H, int no, int npv,
+                                                          int Kp, uint32_t* __restrict__ X) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= rows) return;
+  const int64_t f = idx[i], s = f / N, n = f - s * N;
   const int nod = no >> 1;
-  ring_row(ring + (s * N + n) * nod, N * nod, nullptr, priv_store + f * npv, H, no, npv, Kp, X + (int64_t)blockIdx.x * (Kp >> 1));
+  ring_row(ring + (s * N + n) * nod, N * nod, nullptr, priv_store + f * npv, H, no, npv, Kp, X + i * (Kp >> 1));
 }
 
 extern "C" int go1ppo_ring_snapshot(const float* hist, int64_t ld_hist, int64_t N, int H, int no, void* ring, void* stream) {
@@ -916,7 +924,7 @@ extern "C" int go1ppo_ring_step(const float* obs, const float* priv, void* ring_
   if (!obs || !priv || !ring_window || !X || N <= 0 || H <= 0 || no <= 0 || (no & 1) || npv < 0 || npv > 256 || (Kp & 1) ||
       Kp < H * no + 1 + npv)
     return -1;
-  ring_step_kernel<<<dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream>>>(obs, priv, (uint32_t*)ring_dst, (const uint32_t*)ring_window, N, H,
+  ring_step_kernel<<<dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(obs, priv, (uint32_t*)ring_dst, (const uint32_t*)ring_window, N, H,
                                                                             no, npv, Kp, (uint32_t*)X, obs_store, priv_store);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
@@ -926,8 +934,8 @@ extern "C" int go1ppo_ring_gather(const void* ring, const float* priv_store, con
   if (!ring || !priv_store || !idx || !X || rows <= 0 || N <= 0 || H <= 0 || no <= 0 || (no & 1) || npv < 0 || (Kp & 1) ||
       Kp < H * no + 1 + npv)
     return -1;
-  ring_gather_kernel<<<dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream>>>((const uint32_t*)ring, priv_store, idx, N, H, no, npv, Kp,
-                                                                                 (uint32_t*)X);
+  ring_gather_kernel<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>((const uint32_t*)ring, priv_store, idx, rows, N,
+                                                                                           H, no, npv, Kp, (uint32_t*)X);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
