@@ -93,6 +93,13 @@ typedef struct {
   const void* in;            /* bf16 [rows][ld_in], first layer's k_in columns used */
   int64_t rows;
   int32_t ld_in, num_layers;
+  /* input activation applied while the rows are staged (inference engines: the first layer's ELU pass disappears):
+   * elu_in != 0: x <- elu(x + sum_q latent[row][q] * wz[col][q]) (latent == NULL: no latent term), exactly what
+   * go1ppo_elu_fwd writes for these columns; the pre-activations in memory stay untouched */
+  int32_t elu_in, npv;
+  const void* latent;        /* bf16 [rows][lat_ld] or NULL */
+  const void* wz;            /* bf16 [k_in][wz_ld] */
+  int32_t lat_ld, wz_ld;
   Go1PpoTailLayer layer[GO1PPO_TAIL_MAX_LAYERS];
 } Go1PpoTailNet;
 typedef struct {

@@ -630,6 +630,22 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(Go1PpoTailArgs A) {
 #pragma unroll
         for (int e = 0; e < 8; e++) v.v[e] = 0;
       }
+      if (N.elu_in && row < N.rows) {                              // the first layer's activation, on the way in
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) x[e] = bf2f(v.v[e]);
+        if (N.latent) {
+          const bf16_t* lat = (const bf16_t*)N.latent + row * N.lat_ld;
+          for (int q = 0; q < N.npv; q++) {
+            const float l = bf2f(lat[q]);
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = fmaf(l, bf2f(((const bf16_t*)N.wz)[(int64_t)(8 * cg + e) * N.wz_ld + q]), x[e]);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) x[e] = elu1(x[e]);
+        v = pack_bf8(x);
+      }
       *reinterpret_cast<Bf8*>(&act[0][r][8 * cg]) = v;
     }
   }

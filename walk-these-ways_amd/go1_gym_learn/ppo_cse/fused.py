@@ -52,6 +52,8 @@ class TailLayer(ctypes.Structure):
 
 class TailNet(ctypes.Structure):
     _fields_ = [("in_", ctypes.c_void_p), ("rows", ctypes.c_int64), ("ld_in", ctypes.c_int32), ("num_layers", ctypes.c_int32),
+                ("elu_in", ctypes.c_int32), ("npv", ctypes.c_int32), ("latent", ctypes.c_void_p), ("wz", ctypes.c_void_p),
+                ("lat_ld", ctypes.c_int32), ("wz_ld", ctypes.c_int32),
                 ("layer", TailLayer * 4)]
 
 
@@ -200,10 +202,16 @@ class FusedNet:
         # (rollout inference: 32 vs 110 us) but only ties hipBLASLt + the two-stream schedule at M = 24576
         if fused_tails is None:
             fused_tails = M <= int(os.environ.get("GO1_FUSED_TAILS_MAX_ROWS", "8192"))     # (tests lower it to reach the other engine)
+        # inference-only engines: the first layer's ELU (+ the actor's latent columns) is applied by the tail kernel while it
+        # stages its input rows — two element-wise launches per rollout step less; an engine with a backward pass keeps the
+        # separate pass, which leaves the activated first layer in memory for the weight gradients
+        self._elu_on_load = not with_grad
         if fused_tails and self._fused_tails_ok():
             nd, na = self.nd, self.na
-            self._tails = (self._tail_args([("adaptation", self.Y1[:, :nd])], with_grad),
-                           self._tail_args([("actor", self.Y1[:, nd:nd + na]), ("critic", self.Y1[:, nd + na:])], with_grad))
+            eol = self._elu_on_load
+            self._tails = (self._tail_args([("adaptation", self.Y1[:, :nd])], with_grad, elu_in=eol),
+                           self._tail_args([("actor", self.Y1[:, nd:nd + na]), ("critic", self.Y1[:, nd + na:])], with_grad, elu_in=eol,
+                                           latent_for="actor" if eol else None))
             self._tails_ad = self._tail_args([("adaptation", self.Y1d)], with_grad)
         # large batches: the last two layers of every net (256 -> 128 -> 64) on the LDS-resident kernels of
         # csrc/go1ppo_mlp.h, forward and backward (GO1_MLP2=0 switches back to per-layer GEMM + ELU launches)
@@ -263,14 +271,19 @@ class FusedNet:
                                    _stream()), "go1ppo_wgrad")
 
     # ---- forward -------------------------------------------------------------------------------------------
-    def _tail_args(self, nets_and_inputs, keep_intermediates):
-        """Go1PpoTailArgs for go1ppo_tail_fwd: the listed nets' layers behind the first one, reading their (post-ELU)
-        first-layer block and writing Z[net][li] (intermediates only when the backward pass needs them)."""
+    def _tail_args(self, nets_and_inputs, keep_intermediates, elu_in=False, latent_for=None):
+        """Go1PpoTailArgs for go1ppo_tail_fwd: the listed nets' layers behind the first one, reading their first-layer block
+        (post-ELU, or with elu_in the pre-activation, activated on the way in — `latent_for`: the net whose input also gets
+        the latent columns latent Wz^T) and writing Z[net][li] (intermediates only when the backward pass needs them)."""
         a = TailArgs()
         a.num_nets = len(nets_and_inputs)
         for N, (net, h) in zip(a.net, nets_and_inputs):
             d = self.depth[net]
             N.in_, N.rows, N.ld_in, N.num_layers = h.data_ptr(), h.shape[0], _ld(h), d - 1
+            N.elu_in = int(bool(elu_in))
+            if elu_in and latent_for == net:
+                lat, wz = self.Z["adaptation"][self.depth["adaptation"] - 1], self.P["Wz"]
+                N.latent, N.wz, N.lat_ld, N.wz_ld, N.npv = lat.data_ptr(), wz.data_ptr(), _ld(lat), HEAD, self.pol.npv
             for li in range(1, d):
                 L, W, z = N.layer[li - 1], self.P[f"{net}.{li}.W"], self.Z[net][li]
                 last = li == d - 1
@@ -304,14 +317,17 @@ class FusedNet:
         if self._mlp2:
             return self._forward_mlp2(x)
         torch.mm(x, self.P["W1"].t(), out=self.Y1)
-        self._elu(self.Y1[:, :nd])
         if self._tails is not None:               # fused MLP tails: one launch per dependency level
             ta, tac = self._tails
+            if not self._elu_on_load:
+                self._elu(self.Y1[:, :nd])
             _chk(self.lib.go1ppo_tail_fwd(ctypes.byref(ta), _stream()), "go1ppo_tail_fwd")
             latent = self.Z["adaptation"][self.depth["adaptation"] - 1]
-            self._elu(self.Y1[:, nd:], latent, na)
+            if not self._elu_on_load:
+                self._elu(self.Y1[:, nd:], latent, na)
             _chk(self.lib.go1ppo_tail_fwd(ctypes.byref(tac), _stream()), "go1ppo_tail_fwd")
             return self.Z["actor"][self.depth["actor"] - 1], self.Z["critic"][self.depth["critic"] - 1], latent
+        self._elu(self.Y1[:, :nd])
         latent = self._tail("adaptation", self.Y1[:, :nd])
         self._elu(self.Y1[:, nd:], latent, na)
         with self._branch():
