@@ -312,6 +312,7 @@ def main():
     if rank == 0:
         total_env_steps = args.envs * T * args.steps * world
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        valu_insts = None
         traffic, traffic_src = None, None   # HBM bytes per launch: NOT measured by this run — read from the committed PMC passes
         for name in ("r02_step_kernel_pmc.json", "r01_step_kernel_pmc.json"):
             try:
@@ -320,9 +321,20 @@ def main():
                 if args.envs == 4096:
                     traffic = pmc["hbm_traffic_bytes_per_launch"]
                     traffic_src = f"profiles/{name} (committed rocprofv3 --pmc passes of this kernel at 4096 envs, not this run)"
+                    valu_insts = pmc.get("per_launch", {}).get("SQ_INSTS_VALU")
                 break
             except (OSError, KeyError, ValueError):
                 continue
+        # what the kernel IS bound by: vector-ALU issue of the master wavefronts.  Wave-level VALU instructions (committed PMC pass)
+        # x 64 lanes over this run's launch time, against the fp32 vector rate (157.3 TFLOP/s = 78.6 T lane-FMAs/s,
+        # MI355X_MICROARCH.md) — an issue-slot fraction, not a FLOP count (moves, compares and selects occupy slots too)
+        valu = None
+        if valu_insts and avg_ms > 0:
+            lane_ops = valu_insts * 64 / (avg_ms * 1e-3)
+            valu = {"wave_instructions_per_launch": valu_insts, "lane_ops_per_s": lane_ops, "peak_lane_ops_per_s": 78.65e12,
+                    "frac_of_fp32_vector_issue_peak": lane_ops / 78.65e12,
+                    "note": "chip-wide; the step's serial spine runs on 256 of the 1024 SIMDs (one master wavefront per CU), the helper "
+                            "wavefronts fill the other SIMDs only during the actuator network and the Delassus build"}
         faults = env.env.extras["sim_faults"].consume()
         bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * args.envs
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -342,6 +354,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "go1_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": avg_ms, "launches": len(kernel_ms), "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "valu": valu,
                          "note": "latency/issue-bound O(n_dof) recursion: the HBM fraction is reported as north_star requires, "
                                  "it is not the limiter (DESIGN.md Measurement)"},
         }
