@@ -618,6 +618,14 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(Go1PpoTailArgs A) {
   const int64_t row0 = (int64_t)blockIdx.x * BM;
   if (row0 >= N.rows) return;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, c = lane & 15, g = lane >> 4;
+  // the latent weights Wz (k_in rows of npv = 2 bf16: one dword each) once per workgroup into LDS — as global loads inside the
+  // staging loop they cost 8 extra load instructions per 16-byte chunk of input and doubled the kernel's time
+  __shared__ uint32_t wzl[TF_MAXK];
+  const bool lat2 = N.elu_in && N.latent && N.npv == 2 && !(N.wz_ld & 1) && !(N.lat_ld & 1) && !(((uintptr_t)N.wz | (uintptr_t)N.latent) & 3);
+  if (lat2) {
+    for (int i = t; i < N.layer[0].k_in; i += 256) wzl[i] = *reinterpret_cast<const uint32_t*>((const bf16_t*)N.wz + (int64_t)i * N.wz_ld);
+    __syncthreads();
+  }
   // stage the input rows
   {
     const int k0 = N.layer[0].k_in, cgs = k0 >> 3;
@@ -634,7 +642,15 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(Go1PpoTailArgs A) {
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) x[e] = bf2f(v.v[e]);
-        if (N.latent) {
+        if (lat2) {                                                // both latent columns of a Wz row are one dword (in LDS)
+          const uint32_t lp = *reinterpret_cast<const uint32_t*>((const bf16_t*)N.latent + row * N.lat_ld);
+          const float l0 = __uint_as_float(lp << 16), l1 = __uint_as_float(lp & 0xffff0000u);
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const uint32_t wp = wzl[8 * cg + e];
+            x[e] = fmaf(l1, __uint_as_float(wp & 0xffff0000u), fmaf(l0, __uint_as_float(wp << 16), x[e]));
+          }
+        } else if (N.latent) {
           const bf16_t* lat = (const bf16_t*)N.latent + row * N.lat_ld;
           for (int q = 0; q < N.npv; q++) {
             const float l = bf2f(lat[q]);

@@ -205,7 +205,7 @@ class FusedNet:
         # inference-only engines: the first layer's ELU (+ the actor's latent columns) is applied by the tail kernel while it
         # stages its input rows — two element-wise launches per rollout step less; an engine with a backward pass keeps the
         # separate pass, which leaves the activated first layer in memory for the weight gradients
-        self._elu_on_load = not with_grad
+        self._elu_on_load = not with_grad and os.environ.get("GO1_ELU_ON_LOAD", "1") == "1"
         if fused_tails and self._fused_tails_ok():
             nd, na = self.nd, self.na
             eol = self._elu_on_load
