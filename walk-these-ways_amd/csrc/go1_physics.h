@@ -511,6 +511,10 @@ DEV void lane_columns(const float* rfl, const Sym6& I0inv, int leg, int el, unsi
       Y[cc] = sym6_mul(I0inv, sv(v3(r0[0], r0[1], r0[2]), v3(r0[3], r1[0], r1[1])));
       ud[cc][0] = r2[1]; ud[cc][1] = r2[2]; ud[cc][2] = r2[3];
       lg[cc] = rf[3][0];
+    } else {                 // a slot no environment of the wavefront uses: zeros, so that the row loop can run branch-free
+      Y[cc] = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
+      ud[cc][0] = ud[cc][1] = ud[cc][2] = 0.f;
+      lg[cc] = -1.f;
     }
   }
 }
@@ -560,12 +564,9 @@ DEV void delassus_rows(float* lds, float* ldsw, float* rfl, int lane, int wv, in
     const float u0 = r1[2], u1 = r1[3], u2 = r2[0];
     float wv_[NCC];
 #pragma unroll
-    for (int cc = 0; cc < NCC; cc++) {
-      wv_[cc] = 0.f;
-      if (m.ccw & (1u << cc)) {
-        const float same = fmaf(u0, ud[cc][0], fmaf(u1, ud[cc][1], u2 * ud[cc][2]));
-        wv_[cc] = dot(g, Y[cc]) + (lr == lg[cc] ? same : 0.f);
-      }
+    for (int cc = 0; cc < NCC; cc++) {            // branch-free: one basic block of ~130 independent-enough instructions per row
+      const float same = fmaf(u0, ud[cc][0], fmaf(u1, ud[cc][1], u2 * ud[cc][2]));
+      wv_[cc] = dot(g, Y[cc]) + (lr == lg[cc] ? same : 0.f);
     }
     WSH4(r, 0) = (lf4){wv_[0], wv_[1], wv_[2], wv_[3]};
     WSH4(r, 1) = (lf4){wv_[4], wv_[5], wv_[6], wv_[7]};
