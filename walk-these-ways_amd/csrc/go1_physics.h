@@ -40,10 +40,11 @@ enum {
   L_RI = L_RP + NRC,         // NRC   1 / W[r][r]
   L_LS = L_RI + NRC,         // NRC   contact impulses: start values in, solution out
   L_I0 = L_LS + NRC,         // 21    inverse of the base's articulated inertia (upper triangle): for the wavefronts that build W
-  L_KL = L_I0 + 21,          // 3     contacts in the solver list, mask of the legs whose limit rows are in the solve, 1: the build
-                             //       also adds W lambda_start to the rows' right-hand sides (see delassus_rows)
+  L_KL = L_I0 + 21,          // 4     contacts in the solver list, mask of the legs whose limit rows are in the solve, 1: the build
+                             //       also adds W lambda_start to the rows' right-hand sides (see delassus_rows), != 0: a helper
+                             //       wavefront met a degenerate contact normal (emit_contacts_helper)
   L_W = L_RB,                // zero-filled at kernel start from here to L_END
-  L_END = L_KL + 3
+  L_END = L_KL + 4
 };
 #define LDS(f) lds[(f) * EPW + el]
 // Packed records, one per (row, environment), read with 16-byte LDS loads:
@@ -478,6 +479,90 @@ DEV SV leg_response(const SV S[3], const SV U[3], const float Dinv[3], SV a0, in
 
 // ---- Delassus matrix W = J M^-1 J^T into LDS ------------------------------------------------------------------------
 // Which rows / columns exist: wave-uniform bounds (scalar branches) from the per-environment contact count and limit-row legs.
+// ---- contact emission on the helper wavefronts ---------------------------------------------------------------------------
+// Publishing a listed contact — frame, target velocity, b = J v_free, start impulse and the three row functionals (a unit
+// impulse propagated through the ABA factors of the contact's leg) — is ~230 instructions, and the master wavefront walks
+// its up to nine items per lane one after the other.  With several wavefronts per workgroup the master only writes
+// PACKETS into the (at that time unused) matrix block — the leg's ABA factors, the environment's free twist, one record per
+// listed terrain contact — and 128 helper lanes take one contact each (contact k of environment el: lane 4 el + (k & 3) of
+// helper wavefront 1 + (k >> 2)).  Self-contacts and limit rows stay with the master, which emits them meanwhile.
+enum { PK_LEG = 0, PK_LEG_ST = 44, PK_ENV = PK_LEG + WAVE * PK_LEG_ST, PK_ENV_ST = 12, PK_ITEM = PK_ENV + EPW * PK_ENV_ST, PK_ITEM_ST = 12,
+       PK_END = PK_ITEM + MAXC * EPW * PK_ITEM_ST };
+
+DEV void emit_contact(CfgRef cfg, float* lds, float* rfl, int el, int k, const Cand& c, int depth, int leg, int body, float share,
+                      const SV (&S)[3], const SV (&U)[3], const float (&Dinv)[3], const float (&qd_free)[3], V3 w_free, V3 v_free,
+                      float e_c, bool use_warm, float h, uint32_t& fault) {
+  const V3 n = v3(c.nx, c.ny, c.nz);
+  V3 t1, t2;
+  contact_frame(n, t1, t2, fault);
+  const V3 x = v3(c.x, c.y, c.z);
+  LDS(L_CX + 3 * k) = c.x; LDS(L_CX + 3 * k + 1) = c.y; LDS(L_CX + 3 * k + 2) = c.z;
+  LDS(L_CN + 3 * k) = c.nx; LDS(L_CN + 3 * k + 1) = c.ny; LDS(L_CN + 3 * k + 2) = c.nz;
+  float vs = fminf(-c.phi / h, cfg.max_depenetration_velocity);
+  if (c.un < -cfg.bounce_threshold_velocity && -e_c * c.un > vs) vs = -e_c * c.un;
+  LDS(L_RP + 3 * k) = vs;
+  SV vb = sv(w_free, v_free);
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+    if (j <= depth) vb = vb + qd_free[j] * S[j];
+  const V3 vp = vb.l + cross(vb.a, x);
+  LDS(L_RB + 3 * k) = dot(n, vp); LDS(L_RB + 3 * k + 1) = dot(t1, vp); LDS(L_RB + 3 * k + 2) = dot(t2, vp);
+  const V3 wl = v3(LDS(L_LAM + 3 * body), LDS(L_LAM + 3 * body + 1), LDS(L_LAM + 3 * body + 2));
+  const float sh = use_warm ? share : 0.f;
+  LDS(L_LS + 3 * k) = sh * dot(wl, n); LDS(L_LS + 3 * k + 1) = sh * dot(wl, t1); LDS(L_LS + 3 * k + 2) = sh * dot(wl, t2);
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const V3 d = r == 0 ? n : r == 1 ? t1 : t2;
+    SV pA = -sv(cross(x, d), d);
+    float uj[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 2; j >= 0; j--) {
+      if (j <= depth) {
+        const float u = -dot(S[j], pA);
+        uj[j] = u;
+        pA = pA + (u * Dinv[j]) * U[j];
+      }
+    }
+    lf4* rf = reinterpret_cast<lf4*>(RF(3 * k + r));
+    rf[0] = (lf4){pA.a.x, pA.a.y, pA.a.z, pA.l.x};
+    rf[1] = (lf4){pA.l.y, pA.l.z, uj[0], uj[1]};
+    rf[2] = (lf4){uj[2], uj[0] * Dinv[0], uj[1] * Dinv[1], uj[2] * Dinv[2]};
+    rf[3] = (lf4){depth < 0 ? 4.f : (float)leg, -1.f, 0.f, 0.f};
+  }
+}
+
+// helper wavefront hw (0, 1: contacts 0..3 / 4..7 of every environment; 2: idle): one listed terrain contact per lane
+DEV void emit_contacts_helper(CfgRef cfg, float* lds, const float* ldsw, float* rfl, int lane, int hw, float h) {
+  if (hw >= (MAXC + 3) / 4) return;
+  const int el = lane >> 2, k = 4 * hw + (lane & 3);
+  const lf4* ep = reinterpret_cast<const lf4*>(ldsw + PK_ENV + el * PK_ENV_ST);
+  const lf4 e0 = ep[0], e1 = ep[1], e2 = ep[2];
+  const int K = (int)e2[0], nF = (int)e2[1], nS = (int)e2[2];
+  if (k >= K || (k >= nF && k < nF + nS)) return;           // not listed / a self-contact (the master's)
+  const lf4* ip = reinterpret_cast<const lf4*>(ldsw + PK_ITEM + (k * EPW + el) * PK_ITEM_ST);
+  const lf4 i0 = ip[0], i1 = ip[1], i2 = ip[2];
+  Cand c;
+  c.phi = i0[0]; c.x = i0[1]; c.y = i0[2]; c.z = i0[3]; c.un = i1[0]; c.nx = i1[1]; c.ny = i1[2]; c.nz = i1[3];
+  const int depth = (int)i2[0], leg = (int)i2[1], body = (int)i2[2];
+  const lf4* lp = reinterpret_cast<const lf4*>(ldsw + PK_LEG + (4 * el + (leg & 3)) * PK_LEG_ST);
+  float f[44];
+#pragma unroll
+  for (int q = 0; q < 11; q++) { const lf4 v = lp[q]; f[4 * q] = v[0]; f[4 * q + 1] = v[1]; f[4 * q + 2] = v[2]; f[4 * q + 3] = v[3]; }
+  SV S[3], U[3];
+  float Dinv[3], qd_free[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    S[j] = sv(v3(f[6 * j], f[6 * j + 1], f[6 * j + 2]), v3(f[6 * j + 3], f[6 * j + 4], f[6 * j + 5]));
+    U[j] = sv(v3(f[18 + 6 * j], f[19 + 6 * j], f[20 + 6 * j]), v3(f[21 + 6 * j], f[22 + 6 * j], f[23 + 6 * j]));
+    Dinv[j] = f[36 + j];
+    qd_free[j] = f[39 + j];
+  }
+  uint32_t fl = 0;
+  emit_contact(cfg, lds, rfl, el, k, c, depth, leg, body, i2[3], S, U, Dinv, qd_free, v3(e0[0], e0[1], e0[2]), v3(e0[3], e1[0], e1[1]),
+               e1[2], e1[3] != 0.f, h, fl);
+  if (fl) LDS(L_KL + 3) = 1.f;
+}
+
 struct SolveMasks {
   int Kw;                  // wave-uniform max K
   unsigned LAw;            // wave-uniform: legs with limit rows in some environment
@@ -895,56 +980,61 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   // (legs couple only through the base).  A contact row starts from the spatial force of the unit impulse at the contact
   // point, a joint row from the unit generalised impulse at its joint.
   PROF(20);
-  auto emit = [&](int k, const Cand& c, int depth, int body, float share) {      // depth < 0: trunk
-    const V3 n = v3(c.nx, c.ny, c.nz);
-    V3 t1, t2;
-    contact_frame(n, t1, t2, fault);
-    const V3 x = v3(c.x, c.y, c.z);
-    LDS(L_CX + 3 * k) = c.x; LDS(L_CX + 3 * k + 1) = c.y; LDS(L_CX + 3 * k + 2) = c.z;
-    LDS(L_CN + 3 * k) = c.nx; LDS(L_CN + 3 * k + 1) = c.ny; LDS(L_CN + 3 * k + 2) = c.nz;
-    float vs = fminf(-c.phi / h, cfg.max_depenetration_velocity);
-    if (c.un < -cfg.bounce_threshold_velocity && -e_c * c.un > vs) vs = -e_c * c.un;
-    LDS(L_RP + 3 * k) = vs;
-    SV vb = sv(w_free, v_free);
+  const bool offload = nw > 1;         // terrain contacts on the helper wavefronts (emit_contacts_helper)
+  if (offload) {
+    lf4* lp = reinterpret_cast<lf4*>(ldsw + PK_LEG + lane * PK_LEG_ST);
+    float f[44];
 #pragma unroll
-    for (int j = 0; j < 3; j++)
-      if (j <= depth) vb = vb + qd_free[j] * S[j];
-    const V3 vp = vb.l + cross(vb.a, x);
-    LDS(L_RB + 3 * k) = dot(n, vp); LDS(L_RB + 3 * k + 1) = dot(t1, vp); LDS(L_RB + 3 * k + 2) = dot(t2, vp);
-    const V3 wl = v3(LDS(L_LAM + 3 * body), LDS(L_LAM + 3 * body + 1), LDS(L_LAM + 3 * body + 2));
-    const float sh = use_warm ? share : 0.f;
-    LDS(L_LS + 3 * k) = sh * dot(wl, n); LDS(L_LS + 3 * k + 1) = sh * dot(wl, t1); LDS(L_LS + 3 * k + 2) = sh * dot(wl, t2);
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const V3 d = r == 0 ? n : r == 1 ? t1 : t2;
-      SV pA = -sv(cross(x, d), d);
-      float uj[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 2; j >= 0; j--) {
-        if (j <= depth) {
-          const float u = -dot(S[j], pA);
-          uj[j] = u;
-          pA = pA + (u * Dinv[j]) * U[j];
-        }
-      }
-      lf4* rf = reinterpret_cast<lf4*>(RF(3 * k + r));
-      rf[0] = (lf4){pA.a.x, pA.a.y, pA.a.z, pA.l.x};
-      rf[1] = (lf4){pA.l.y, pA.l.z, uj[0], uj[1]};
-      rf[2] = (lf4){uj[2], uj[0] * Dinv[0], uj[1] * Dinv[1], uj[2] * Dinv[2]};
-      rf[3] = (lf4){depth < 0 ? 4.f : (float)leg, -1.f, 0.f, 0.f};
+    for (int j = 0; j < 3; j++) {
+      f[6 * j] = S[j].a.x; f[6 * j + 1] = S[j].a.y; f[6 * j + 2] = S[j].a.z; f[6 * j + 3] = S[j].l.x; f[6 * j + 4] = S[j].l.y; f[6 * j + 5] = S[j].l.z;
+      f[18 + 6 * j] = U[j].a.x; f[19 + 6 * j] = U[j].a.y; f[20 + 6 * j] = U[j].a.z; f[21 + 6 * j] = U[j].l.x; f[22 + 6 * j] = U[j].l.y; f[23 + 6 * j] = U[j].l.z;
+      f[36 + j] = Dinv[j];
+      f[39 + j] = qd_free[j];
     }
-  };
-  // (the trunk's impulse is read by lane 0 only; own bodies by the own lane: no cross-lane hazard on L_LAM here)
-  if (slot[0] >= 0) emit(slot[0], item[0], 2, 4 + 4 * leg, 1.f);
-  if (slot[1] >= 0) emit(slot[1], item[1], 2, 3 + 4 * leg, share_k);
-  if (slot[2] >= 0) emit(slot[2], item[2], 2, 3 + 4 * leg, share_k);
-  if (slot[3] >= 0) emit(slot[3], item[3], 1, 2 + 4 * leg, share_t);
-  if (slot[4] >= 0) emit(slot[4], item[4], 1, 2 + 4 * leg, share_t);
-  if (slot[5] >= 0) emit(slot[5], item[5], 0, 1 + 4 * leg, share_h);
-  if (slot[6] >= 0) emit(slot[6], item[6], 0, 1 + 4 * leg, share_h);
-  if (leg == 0) {
-    if (slot_b0 >= 0) emit(slot_b0, tb0, -1, 0, share_b);
-    if (slot_b1 >= 0) emit(slot_b1, tb1, -1, 0, share_b);
+    f[42] = f[43] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 11; q++) lp[q] = (lf4){f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]};
+    if (leg == 0) {
+      lf4* ep = reinterpret_cast<lf4*>(ldsw + PK_ENV + el * PK_ENV_ST);
+      ep[0] = (lf4){w_free.x, w_free.y, w_free.z, v_free.x};
+      ep[1] = (lf4){v_free.y, v_free.z, e_c, use_warm ? 1.f : 0.f};
+      ep[2] = (lf4){(float)K, (float)nF, (float)__popc(smask), 0.f};
+      LDS(L_KL + 3) = 0.f;
+    }
+    auto post = [&](int k, const Cand& c, int depth, int body, float share) {
+      lf4* ip = reinterpret_cast<lf4*>(ldsw + PK_ITEM + (k * EPW + el) * PK_ITEM_ST);
+      ip[0] = (lf4){c.phi, c.x, c.y, c.z};
+      ip[1] = (lf4){c.un, c.nx, c.ny, c.nz};
+      ip[2] = (lf4){(float)depth, (float)leg, (float)body, share};
+    };
+    if (slot[0] >= 0) post(slot[0], item[0], 2, 4 + 4 * leg, 1.f);
+    if (slot[1] >= 0) post(slot[1], item[1], 2, 3 + 4 * leg, share_k);
+    if (slot[2] >= 0) post(slot[2], item[2], 2, 3 + 4 * leg, share_k);
+    if (slot[3] >= 0) post(slot[3], item[3], 1, 2 + 4 * leg, share_t);
+    if (slot[4] >= 0) post(slot[4], item[4], 1, 2 + 4 * leg, share_t);
+    if (slot[5] >= 0) post(slot[5], item[5], 0, 1 + 4 * leg, share_h);
+    if (slot[6] >= 0) post(slot[6], item[6], 0, 1 + 4 * leg, share_h);
+    if (leg == 0) {
+      if (slot_b0 >= 0) post(slot_b0, tb0, -1, 0, share_b);
+      if (slot_b1 >= 0) post(slot_b1, tb1, -1, 0, share_b);
+    }
+    BLOCK_SYNC(nw);                      // the helpers emit while this wavefront goes on with the self-contacts and limit rows
+  } else {
+    auto emit = [&](int k, const Cand& c, int depth, int body, float share) {      // depth < 0: trunk
+      emit_contact(cfg, lds, rfl, el, k, c, depth, leg, body, share, S, U, Dinv, qd_free, w_free, v_free, e_c, use_warm, h, fault);
+    };
+    // (the trunk's impulse is read by lane 0 only; own bodies by the own lane: no cross-lane hazard on L_LAM here)
+    if (slot[0] >= 0) emit(slot[0], item[0], 2, 4 + 4 * leg, 1.f);
+    if (slot[1] >= 0) emit(slot[1], item[1], 2, 3 + 4 * leg, share_k);
+    if (slot[2] >= 0) emit(slot[2], item[2], 2, 3 + 4 * leg, share_k);
+    if (slot[3] >= 0) emit(slot[3], item[3], 1, 2 + 4 * leg, share_t);
+    if (slot[4] >= 0) emit(slot[4], item[4], 1, 2 + 4 * leg, share_t);
+    if (slot[5] >= 0) emit(slot[5], item[5], 0, 1 + 4 * leg, share_h);
+    if (slot[6] >= 0) emit(slot[6], item[6], 0, 1 + 4 * leg, share_h);
+    if (leg == 0) {
+      if (slot_b0 >= 0) emit(slot_b0, tb0, -1, 0, share_b);
+      if (slot_b1 >= 0) emit(slot_b1, tb1, -1, 0, share_b);
+    }
   }
   // self-contacts.  Body A (the lower leg of the lower-numbered leg, or the leg of a trunk pair) publishes the contact and
   // its side of the row functionals; for a leg-leg pair body B's lane adds its side (record SB); the trunk as body B has
@@ -1064,6 +1154,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
 #endif
   BLOCK_SYNC(nw);
   PROF(21);
+  if (offload && LDS(L_KL + 3) != 0.f) fault |= 1u << GO1_FAULT_CONTACT_FRAME;
   SolveMasks sm;
   solver_masks(K, lact, legact, leg, sm);
   const int Kw = sm.Kw;

@@ -23,6 +23,7 @@
 #include "go1_physics.h"
 
 static_assert(A_IO_END <= LDSW_SIZE, "the actuator network's transient rows are overlaid on the solver's matrix");
+static_assert(PK_END <= LDSW_SIZE, "the contact packets of the emission hand-over are overlaid on the solver's matrix");
 static_assert(L_END >= GO1_MAX_OBS, "post_physics stages the observation rows in the solver's LDS block");
 struct SimConst {            // lives in device memory (one per handle): indexable with scalar loads
   Go1SimConfig cfg;
@@ -105,6 +106,8 @@ extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(
       } else if (mfma_torque) actuator_net_mfma(act_lds, ldsw, lane, wv, nw, false, nullptr, nullptr);
 #endif
 #ifndef GO1_ABLATE_PHYSICS
+      BLOCK_SYNC(nw);                                     // the master's contact packets are in LDS
+      emit_contacts_helper(cfg, lds, ldsw, ldsx, lane, wv - 1, cfg.sim_dt);
       BLOCK_SYNC(nw);
 #ifdef GO1_ROWS_HELPERS_ONLY
       delassus_rows(lds, ldsw, ldsx, lane, wv - 1, nw - 1 PROF_PASS);
