@@ -227,10 +227,12 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        tmo = datetime.timedelta(seconds=600)          # ranks may start minutes apart (first `import torch` on a fresh box); a dead peer must not hang the job
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
 
     from go1_gym_learn.ppo_cse import Runner, RunnerArgs
     from go1_gym_learn.ppo_cse.ppo import PPO_Args

@@ -16,7 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _worker(rank, world, port, out, grad_dtype="fp32", zero1=False):
     sys.path[:0] = [os.path.join(HERE, "..", "walk-these-ways_amd", "shims"), os.path.join(HERE, "..", "walk-these-ways_amd")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from go1_gym_learn.ppo_cse.actor_critic import AC_Args, ActorCritic
     from go1_gym_learn.ppo_cse.ppo import PPO, PPO_Args
     from go1_gym_learn.ppo_cse.rollout_storage import RolloutStorage

@@ -344,7 +344,7 @@ def test_two_rank_bench_dry_run_on_one_gpu(extra):
            "--backend", "gloo", "--same-device", "--no-cpu-baseline", "--headline-only"] + extra
     env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
                PYTORCH_TUNABLEOP_ENABLED="0")          # (256 envs: GEMM shapes outside the shipped table; no tuning pass in a smoke test)
-    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
