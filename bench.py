@@ -229,6 +229,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         tmo = datetime.timedelta(seconds=600)          # ranks may start minutes apart (first `import torch` on a fresh box); a dead peer must not hang the job
+        if args.backend == "gloo":
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # single-node dry runs: do not depend on the host name resolving
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:

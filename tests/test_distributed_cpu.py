@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _worker(rank, world, port, out, grad_dtype="fp32", zero1=False):
     sys.path[:0] = [os.path.join(HERE, "..", "walk-these-ways_amd", "shims"), os.path.join(HERE, "..", "walk-these-ways_amd")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # (gloo otherwise resolves the host name, which may not resolve in a container)
     import datetime
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from go1_gym_learn.ppo_cse.actor_critic import AC_Args, ActorCritic
@@ -128,6 +129,7 @@ def _curriculum_worker(rank, world, port, out):
               os.path.join(HERE, "..", "oracle"), os.path.join(HERE, ".."), HERE):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     out[rank] = _curriculum_run(rank, world, 48, 40)
     dist.destroy_process_group()

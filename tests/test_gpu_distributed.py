@@ -17,6 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _worker(rank, world, port, out):
     sys.path[:0] = [os.path.join(HERE, "..", "walk-these-ways_amd", "shims"), os.path.join(HERE, "..", "walk-these-ways_amd")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # (gloo otherwise resolves the host name, which may not resolve in a container)
     import datetime
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))      # a dead peer raises, never hangs
     torch.cuda.set_device(0)

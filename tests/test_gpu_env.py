@@ -342,7 +342,7 @@ def test_two_rank_bench_dry_run_on_one_gpu(extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--envs", "256",
            "--backend", "gloo", "--same-device", "--no-cpu-baseline", "--headline-only"] + extra
-    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", GLOO_SOCKET_IFNAME="lo",
                PYTORCH_TUNABLEOP_ENABLED="0")          # (256 envs: GEMM shapes outside the shipped table; no tuning pass in a smoke test)
     r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
