@@ -284,3 +284,40 @@ def test_emulated_train_eval_split_matches_oracle(oracle_lib, emu):
     assert bool(((fr[NT:] >= 5.0) & (fr[NT:] <= 5.5)).all()) and bool((fr[:NT] < 5.0).all())
     assert bool(((ms[:, NT:] >= 1.5) & (ms[:, NT:] <= 1.6)).all()) and bool((ms[:, :NT] < 1.5).all())
     assert bool(((Bc.payloads[NT:] >= 4.0) & (Bc.payloads[NT:] <= 4.5)).all())
+
+
+def test_emulated_full_step_in_the_contact_heavy_regime(oracle_lib, emu):
+    """The 4-wavefront step kernel (helper hand-overs: actuator tiles, contact emission on one helper lane per contact, Delassus
+    rows) with robots thrown onto the ground in random orientations with folded / splayed legs: trunk, hip, thigh and calf
+    contacts, lists filled to the cap of 8 (overflow counted), leg-leg self-contacts — against the oracle, re-synchronised
+    every step.  The piecewise substep test above covers these states only through the single-wavefront entry point."""
+    N = 32
+    S, Bc, orc, Be, sim = pair(oracle_lib, emu, "train", N, extra={"domain_rand": dict(randomize_gravity=False)})
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(4, N, generator=g)
+    Bc.root_states[3:7] = q / q.norm(dim=0, keepdim=True)
+    Bc.root_states[2].uniform_(0.06, 0.25, generator=g)
+    Bc.root_states[7:13].uniform_(-1.5, 1.5, generator=g)
+    lo = torch.tensor([-0.86, -0.68, -2.81] * 4).unsqueeze(1)
+    hi = torch.tensor([0.86, 4.50, -0.89] * 4).unsqueeze(1)
+    Bc.dof_pos[:] = lo + (hi - lo) * torch.rand(12, N, generator=g)
+    Bc.dof_vel.uniform_(-4, 4, generator=g)
+    Bc.episode_length_buf[:] = 5
+    resync(Bc, Be, sim, orc)
+    rng = np.random.default_rng(5)
+    bad = torch.zeros(N, dtype=torch.bool)
+    peak_contacts = 0
+    for step in range(6):
+        a = (rng.standard_normal((N, 12)) * 1.5).astype(np.float32)
+        orc.step(a)
+        sim.step(torch.from_numpy(a))
+        assert torch.equal(Be.reset_buf, Bc.reset_buf), step
+        for k, tol in (("root_states", 5e-4), ("dof_pos", 5e-5), ("dof_vel", 1e-2), ("torques", 2e-3), ("rew_buf", 5e-5)):
+            bad |= ((Be.tensors[k] - Bc.tensors[k]).abs() > tol).reshape(-1, N).any(0)
+        bad |= ((Be.contact_forces - Bc.contact_forces).abs() > 1e-1 + 5e-3 * Bc.contact_forces.abs()).any(0)
+        nz = (Bc.contact_forces.view(17, 3, N).abs().sum(1) > 0).sum(0)
+        peak_contacts = max(peak_contacts, int(nz.max()))
+        resync(Bc, Be, sim, orc)
+    assert int(bad.sum()) <= 2, int(bad.sum())                        # contact-mode flips at thresholds
+    assert peak_contacts >= 5, peak_contacts                          # bodies beyond the feet carried load
+    assert int(Be.fault_counts[:10].sum()) == 0
