@@ -321,3 +321,54 @@ def test_emulated_full_step_in_the_contact_heavy_regime(oracle_lib, emu):
     assert int(bad.sum()) <= 2, int(bad.sum())                        # contact-mode flips at thresholds
     assert peak_contacts >= 5, peak_contacts                          # bodies beyond the feet carried load
     assert int(Be.fault_counts[:10].sum()) == 0
+
+
+def test_emulated_full_step_on_a_height_field(oracle_lib, emu):
+    """BASELINE config 3 through the emulated step kernel: rough int16 height field with a staircase strip (bilinear height,
+    tilted contact normals), the 187-point height scan in the observation (257 columns), resets onto the field — against
+    the oracle, re-synchronised every step (the GPU counterpart: tests/test_gpu_parity.py::test_full_step_on_height_field)."""
+    N = 32
+    pts_x = [round(-0.8 + 0.1 * i, 1) for i in range(17)]
+    pts_y = [round(-0.5 + 0.1 * i, 1) for i in range(11)]
+    ex = {"terrain": dict(measure_heights=True, measured_points_x=pts_x, measured_points_y=pts_y),
+          "env": dict(observe_heights=True, num_observations=70 + 187),
+          "domain_rand": dict(randomize_gravity=False)}
+    cfg, S, meta, Bc = make_sim("train_noise", N, seed=13, extra=ex)
+    rng = np.random.default_rng(2)
+    z = rng.uniform(-1, 1, (62, 62))
+    z = np.kron(z, np.ones((4, 4)))[:240, :240]
+    for _ in range(3):
+        z = 0.25 * (np.roll(z, 1, 0) + np.roll(z, -1, 0) + np.roll(z, 1, 1) + np.roll(z, -1, 1))
+    z = 0.08 * z / np.abs(z).max()
+    z[:, 100:140] += 0.1 * (np.arange(40) // 4)[None, :] % 0.5
+    hscale, vscale = 0.1, 0.005
+    hs = np.rint(z / vscale).astype(np.int16)
+    H.bind_height_field(S, Bc, hs, hscale, vscale, 0.0)
+    randomize_dr(Bc, 13)
+    Bc.env_origins[0].uniform_(4.0, 19.0, generator=torch.Generator().manual_seed(1))
+    Bc.env_origins[1].uniform_(4.0, 19.0, generator=torch.Generator().manual_seed(2))
+    ix, iy = (Bc.env_origins[0] / hscale).long(), (Bc.env_origins[1] / hscale).long()
+    Bc.env_origins[2] = torch.from_numpy(hs.astype(np.float32))[ix, iy] * vscale + 0.05
+    orc = oracle_lib.Oracle(S, Bc)
+    orc.reset_idx()
+    Bc.episode_length_buf[:8] = int(S.max_episode_length) - 3          # a few time-outs: resets onto the field
+    Be = Bc.clone_to("cpu")
+    sim = emu.EmuSim(S, Be)
+    sim.set_counters(orc.ctr.common_step_counter, orc.ctr.lag_head)
+    arng = np.random.default_rng(0)
+    bad = torch.zeros(N, dtype=torch.bool)
+    resets = 0
+    for step in range(6):
+        a = (arng.standard_normal((N, 12)) * (1.0 if step % 2 else 0.3)).astype(np.float32)
+        orc.step(a)
+        sim.step(torch.from_numpy(a))
+        assert torch.equal(Be.reset_buf, Bc.reset_buf), step
+        for k, tol in (("root_states", 5e-4), ("dof_pos", 5e-5), ("dof_vel", 1e-2), ("rew_buf", 5e-5), ("torques", 2e-3),
+                       ("measured_heights", 1e-4)):
+            bad |= ((Be.tensors[k] - Bc.tensors[k]).abs() > tol).reshape(-1, N).any(0)
+        bad |= ((Be.obs_buf - Bc.obs_buf).abs() > 2e-3).any(1)
+        resets += int(Bc.reset_buf.sum())
+        resync(Bc, Be, sim, orc)
+    assert Bc.obs_buf.shape[1] == 257 and float(Bc.obs_buf[:, 70:].abs().max()) > 0.1
+    assert resets >= 8 and int(bad.sum()) <= 1, (resets, int(bad.sum()))
+    assert int(Be.fault_counts[:10].sum()) == 0
