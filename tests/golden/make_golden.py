@@ -572,9 +572,87 @@ def gen_reset(N=80, seed=41, sim_seed=4242, step=311):
     print("reset: envs", len(idn), "yaw span", float(e.root_states[ids, 5].abs().max()))
 
 
+EVAL_OVERRIDES = {"domain_rand": dict(motor_strength_range=[1.3, 1.5], motor_offset_range=[0.05, 0.08], Kp_factor_range=[1.4, 1.6],
+                                      Kd_factor_range=[0.2, 0.4]),
+                  "terrain": dict(x_init_range=0.2, y_init_range=0.3, yaw_init_range=0.4, x_init_offset=1.5, y_init_offset=-2.5)}
+
+
+def gen_reset_eval(N=64, NT=32, seed=43, sim_seed=777, step=123):
+    """the train / evaluation dispatch of the reference (`_call_train_eval`, legged_robot.py:531-544) around
+    `_randomize_dof_props`, `_reset_dofs`, `_reset_root_states`: environments >= NT are handled with `eval_cfg` (other
+    domain-randomisation ranges, other reset distribution).  Same Philox uniforms as gen_reset; every dispatched call
+    serves the training ids first, then the evaluation ids (the order `_call_train_eval` calls `func` in)."""
+    import copy
+    import types
+    import go1_gym.envs.base.legged_robot as ref_mod
+    e, LR = make_env("alt", N, seed)
+    sys.modules["isaacgym.gymtorch"].unwrap_tensor = lambda t: t
+    ref_mod.gymtorch.unwrap_tensor = lambda t: t
+
+    class AnyCall:
+        def __getattr__(self, name):
+            return lambda *a, **k: True
+    e.gym, e.sim, e.dof_state = AnyCall(), None, torch.zeros(N * 12, 2)
+    e.num_train_envs = NT
+    e.cfg.env.record_video = False
+    ev = types.SimpleNamespace()
+    for sec in ("domain_rand", "terrain", "env"):
+        src = getattr(e.cfg, sec)
+        ns = types.SimpleNamespace(**{k: copy.deepcopy(getattr(src, k)) for k in dir(src) if not k.startswith("_") and not callable(getattr(src, k))})
+        for k, v in EVAL_OVERRIDES.get(sec, {}).items():
+            setattr(ns, k, v)
+        setattr(ev, sec, ns)
+    e.eval_cfg = ev
+    rng = np.random.default_rng(seed + 1)
+    e.custom_origins = True
+    e.env_origins = torch.tensor(rng.uniform(-20, 20, (N, 3)), dtype=torch.float)
+    e.env_origins[:, 2] = torch.tensor(rng.uniform(0, 0.3, N), dtype=torch.float)
+    st = e.cfg.init_state
+    e.base_init_state = torch.tensor(list(st.pos) + list(st.rot) + list(st.lin_vel) + list(st.ang_vel), dtype=torch.float)
+    ids = torch.tensor(np.sort(rng.choice(N, N // 2, replace=False)), dtype=torch.long)
+    U_dof = np.array([[philox_uniform(sim_seed, int(i), step, 4, j) for j in range(16)] for i in range(N)], dtype=np.float32)
+    U_rst = np.array([[philox_uniform(sim_seed, int(i), step, 2, j) for j in range(24)] for i in range(N)], dtype=np.float32)
+    pre = dict(dof_pos0=e.dof_pos.clone(), dof_vel0=e.dof_vel.clone(), root_states0=e.root_states.clone(),
+               motor_strengths0=e.motor_strengths.clone(), motor_offsets0=e.motor_offsets.clone(), Kp_factors0=e.Kp_factors.clone(),
+               Kd_factors0=e.Kd_factors.clone(), env_origins=e.env_origins.clone())
+    idn = ids.numpy()
+    groups = [idn[idn < NT], idn[idn >= NT]]
+    assert len(groups[0]) > 4 and len(groups[1]) > 4
+    q_dof, q_dofs, q_root = [], [], []
+    for gidx in groups:
+        q_dof += [torch.tensor(U_dof[gidx, 0]), torch.tensor(U_dof[gidx, 1:13]), torch.tensor(U_dof[gidx, 13]), torch.tensor(U_dof[gidx, 14])]
+        q_dofs += [U_rst[gidx, 0:12]]
+        q_root += [U_rst[gidx, 12:13], U_rst[gidx, 13:14], U_rst[gidx, 14:15], U_rst[gidx, 15:21]]
+    q_rst = q_dofs + q_root
+    real_rand, real_trf = torch.rand, ref_mod.torch_rand_float
+    torch.rand = lambda *a, **k: q_dof.pop(0)
+
+    def trf(lo, hi, shape, device=None):
+        u = torch.tensor(q_rst.pop(0))
+        assert tuple(u.shape) == tuple(shape)
+        return (hi - lo) * u + lo
+    ref_mod.torch_rand_float = trf
+    try:
+        LR._call_train_eval(e, lambda i_, c_: LR._randomize_dof_props(e, i_, c_), ids)
+        LR._call_train_eval(e, lambda i_, c_: LR._reset_dofs(e, i_, c_), ids)
+        LR._call_train_eval(e, lambda i_, c_: LR._reset_root_states(e, i_, c_), ids)
+    finally:
+        torch.rand, ref_mod.torch_rand_float = real_rand, real_trf
+    assert not q_dof and not q_rst
+    out = dict(env_ids=idn, dof_pos1=e.dof_pos, dof_vel1=e.dof_vel, root_states1=e.root_states, motor_strengths1=e.motor_strengths,
+               motor_offsets1=e.motor_offsets, Kp_factors1=e.Kp_factors, Kd_factors1=e.Kd_factors,
+               sim_seed=np.array(sim_seed), step=np.array(step), num_train=np.array(NT))
+    np.savez_compressed(os.path.join(HERE, "reset_eval.npz"), **flat(pre), **flat(out))
+    ms = e.motor_strengths[ids]
+    print("reset_eval: train ids", len(groups[0]), "eval ids", len(groups[1]), "eval strength min", float(ms[len(groups[0]):].min()))
+
+
 if __name__ == "__main__":
     install_stubs()
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "reset_eval":           # only reset_eval.npz
+        gen_reset_eval()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "resample":            # only the resample_*.npz fixtures
         for mode in RESAMPLE_MODES:
             for m in [k for k in sys.modules if k.startswith("go1_gym")]:
@@ -583,6 +661,9 @@ if __name__ == "__main__":
         for m in [k for k in sys.modules if k.startswith("go1_gym")]:
             del sys.modules[m]
         gen_reset()
+        for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+            del sys.modules[m]
+        gen_reset_eval()
         sys.exit(0)
     gen_curriculum()
     gen_ppo()
@@ -612,3 +693,6 @@ if __name__ == "__main__":
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     gen_reset()
+    for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+        del sys.modules[m]
+    gen_reset_eval()

@@ -95,3 +95,78 @@ def test_hip_reset_matches_reference():
     sim.reset_idx(torch.from_numpy(d["env_ids"]))
     torch.cuda.synchronize()
     _check_reset(d, Bg)
+
+
+# ---- the train / evaluation dispatch (`_call_train_eval`, legged_robot.py:531-544) against the reference ---------------------
+EVAL_OVERRIDES = {"domain_rand": dict(motor_strength_range=[1.3, 1.5], motor_offset_range=[0.05, 0.08], Kp_factor_range=[1.4, 1.6],
+                                      Kd_factor_range=[0.2, 0.4]),
+                  "terrain": dict(x_init_range=0.2, y_init_range=0.3, yaw_init_range=0.4, x_init_offset=1.5, y_init_offset=-2.5)}       # = make_golden.py
+
+
+def _load_reset_eval_fixture():
+    import os
+    import numpy as np
+    from util import GOLDEN, make_sim
+    d = np.load(os.path.join(GOLDEN, "reset_eval.npz"))
+    N = d["dof_pos0"].shape[0]
+    cfg, S, meta, B = make_sim("alt", N, seed=int(d["sim_seed"]))
+    _, S_full, _, _ = make_sim("alt", N, seed=int(d["sim_seed"]), extra=EVAL_OVERRIDES)
+    S_eval = H.make_eval_sim_config(S, S_full)
+    t = lambda k: torch.from_numpy(d[k])
+    B.dof_pos[:] = t("dof_pos0").t(); B.dof_vel[:] = t("dof_vel0").t(); B.root_states[:] = t("root_states0").t()
+    B.env_origins[:] = t("env_origins").t()
+    for k in ("motor_strengths", "motor_offsets", "Kp_factors", "Kd_factors"):
+        getattr(B, k)[:] = t(k + "0").t()
+    B.last_actions.fill_(3.0); B.last_last_actions.fill_(3.0); B.last_dof_vel.fill_(3.0); B.lag_buffer.fill_(3.0)
+    B.gait_indices.fill_(0.3); B.episode_length_buf.fill_(57)
+    return d, S, S_eval, int(d["num_train"]), B
+
+
+def _check_reset_eval(d, B, NT):
+    import numpy as np
+    _check_reset(d, B)
+    ids = d["env_ids"]
+    ev = ids[ids >= NT]
+    ms = B.motor_strengths.cpu().numpy().T
+    assert ms[ev].min() >= 1.3 and ms[ev].max() <= 1.5 and ms[ids[ids < NT]].max() < 1.3          # each group from ITS range
+
+
+def test_oracle_train_eval_reset_matches_reference(oracle_lib):
+    """`_call_train_eval` around `_randomize_dof_props` / `_reset_dofs` / `_reset_root_states` executed by the reference's own
+    code with a second configuration for the evaluation environments (tests/golden/reset_eval.npz) against the oracle's
+    per-environment configuration selection."""
+    d, S, S_eval, NT, B = _load_reset_eval_fixture()
+    orc = oracle_lib.Oracle(S, B)
+    orc.set_eval_config(S_eval, NT)
+    orc.ctr.common_step_counter = int(d["step"])
+    orc.reset_idx(d["env_ids"])
+    _check_reset_eval(d, B, NT)
+    orc.S_eval = None
+    orc._apply_eval()                        # (the split is module-global in the oracle: switch it off for the tests that follow)
+
+
+def test_emulated_train_eval_reset_matches_reference():
+    """the same fixture through the product's reset kernel (go1_env_kernel: configuration selected per lane), executed by
+    the SIMT emulator"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
+    import emu_sim
+    d, S, S_eval, NT, B = _load_reset_eval_fixture()
+    sim = emu_sim.EmuSim(S, B)
+    sim.set_eval_config(S_eval, NT)
+    sim.set_counters(int(d["step"]), 0)
+    sim.reset_idx(torch.from_numpy(d["env_ids"]).to(torch.int32))
+    _check_reset_eval(d, B, NT)
+
+
+@pytest.mark.gpu
+def test_hip_train_eval_reset_matches_reference():
+    d, S, S_eval, NT, Bc = _load_reset_eval_fixture()
+    Bg = Bc.clone_to("cuda:0")
+    sim = H.Go1Sim(S, Bg, 0)
+    sim.set_eval_config(S_eval, NT)
+    sim.set_counters(int(d["step"]), 0)
+    sim.reset_idx(torch.from_numpy(d["env_ids"]))
+    torch.cuda.synchronize()
+    _check_reset_eval(d, Bg, NT)
