@@ -647,9 +647,154 @@ def gen_reset_eval(N=64, NT=32, seed=43, sim_seed=777, step=123):
     print("reset_eval: train ids", len(groups[0]), "eval ids", len(groups[1]), "eval strength min", float(ms[len(groups[0]):].min()))
 
 
+def gen_gravity(seed=61, sim_seed=4242):
+    """the gravity impulse schedule (legged_robot.py:546-561 `_randomize_gravity`, :701-705 its cadence, :1549 the draw at
+    creation): the reference's own statements, extracted from `_post_physics_step_callback` with inspect and executed for
+    common_step_counter = 1 .. 3 intervals on a mock env (variant "dr"); `torch.rand(3)` serves the Philox uniforms the
+    oracle / kernel draw for (seed, all-envs, epoch = counter // interval, purpose 8).  Saved: the gravity vector in force
+    after the callback of every counter value (index 0 = after creation)."""
+    import inspect
+    import textwrap
+    import go1_gym.envs.base.legged_robot as ref_mod
+    e, LR = make_env("dr", 4, seed, mild=True)
+    ref_mod.gymapi.Vec3 = lambda x, y, z: (float(x), float(y), float(z))
+    params = Mock()
+
+    class Gym:
+        def get_sim_params(self, sim):
+            return params
+
+        def set_sim_params(self, sim, p):
+            pass
+    e.gym, e.sim = Gym(), None
+    e._randomize_gravity = lambda *a, **k: LR._randomize_gravity(e, *a, **k)
+    dr = e.cfg.domain_rand
+    interval, duration = int(dr.gravity_rand_interval), int(dr.gravity_rand_duration)
+    lines = inspect.getsource(LR._post_physics_step_callback).splitlines()
+    first = next(i for i, l in enumerate(lines) if "gravity_rand_interval" in l)
+    last = max(i for i, l in enumerate(lines) if "_randomize_gravity(" in l)
+    block = compile(textwrap.dedent("\n".join(lines[first:last + 1])), "<reference legged_robot.py gravity cadence>", "exec")
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: torch.tensor([philox_uniform(sim_seed, 0xFFFFFFFF, e.common_step_counter // interval, 8, i) for i in range(3)])
+    T = 3 * interval + 5
+    g = np.zeros((T, 3), np.float32)
+    gv = np.zeros((T, 3), np.float32)
+    try:
+        e.common_step_counter = 0
+        LR._randomize_gravity(e)                                   # create_envs (:1549)
+        g[0], gv[0] = params.gravity, e.gravity_vec[0].numpy()
+        for c in range(1, T):
+            e.common_step_counter = c
+            exec(block, {"self": e, "torch": torch, "int": int})
+            g[c], gv[c] = params.gravity, e.gravity_vec[0].numpy()
+    finally:
+        torch.rand = real_rand
+    np.savez_compressed(os.path.join(HERE, "gravity.npz"), gravity=g, gravity_vec=gv, interval=np.array(interval),
+                        duration=np.array(duration), sim_seed=np.array(sim_seed))
+    print("gravity: interval", interval, "duration", duration, "impulse steps", int((np.abs(g[:, :2]).max(1) > 0).sum()), "of", T)
+
+
+def gen_callbacks(N=64, seed=51, sim_seed=999, step=200):
+    """the randomising branches of `_post_physics_step_callback` that scripts/train.py leaves off (legged_robot.py:675-708):
+    `_teleport_robots` :1028-1051, `_push_robots` :1017-1026, `_randomize_dof_props` :645-665 and
+    `_randomize_rigid_body_props` :611-633 on their episode-length cadence — the reference's own methods on a mock env
+    (variant "dr"), `torch.rand` / `torch_rand_float` serving the Philox uniforms the oracle / kernel draw for the same
+    (seed, env, step): purpose 7 (push) columns 0..1, purpose 3 (DOF properties) 0..14, purpose 9 (rigid properties) 0..5."""
+    import go1_gym.envs.base.legged_robot as ref_mod
+    e, LR = make_env("dr", N, seed, mild=True)
+    sys.modules["isaacgym.gymtorch"].unwrap_tensor = lambda t: t
+    ref_mod.gymtorch.unwrap_tensor = lambda t: t
+
+    class AnyCall:
+        def __getattr__(self, name):
+            return lambda *a, **k: True
+    e.gym, e.sim = AnyCall(), None
+    e.eval_cfg = None
+    e.cfg.env.record_video = False
+    cfg = e.cfg
+    rng = np.random.default_rng(seed + 1)
+    ter, dr = cfg.terrain, cfg.domain_rand
+    ter.x_offset = 0                       # set by the reference's Terrain class (terrain.py:42); no terrain object on the mock
+    span_x, span_y = ter.terrain_length * ter.num_rows, ter.terrain_width * ter.num_cols
+    xo = int(ter.x_offset * ter.horizontal_scale)
+    kind = rng.integers(0, 5, N)
+    e.root_states[:, 0] = torch.tensor(np.where(kind == 0, ter.teleport_thresh + xo - 0.15, np.where(kind == 1, span_x - ter.teleport_thresh + xo + 0.15,
+                                                rng.uniform(5.0, span_x - 5.0, N))), dtype=torch.float)
+    kind = rng.integers(0, 5, N)
+    e.root_states[:, 1] = torch.tensor(np.where(kind == 0, ter.teleport_thresh - 0.15, np.where(kind == 1, span_y - ter.teleport_thresh + 0.15,
+                                                rng.uniform(5.0, span_y - 5.0, N))), dtype=torch.float)
+    pi, ri = int(dr.push_interval), int(dr.rand_interval)
+    choice = rng.integers(0, 4, N)
+    mult = rng.integers(1, 6, N)
+    ep = np.where(choice == 0, pi * mult, np.where(choice == 1, ri * mult, np.where(choice == 2, pi * ri, 3 + 17 * mult)))
+    e.episode_length_buf = torch.tensor(ep, dtype=torch.long)                 # values AFTER the increment of post_physics_step (:101)
+    inp = dict(root_states=e.root_states.clone(), dof_pos=e.dof_pos.clone(), dof_vel=e.dof_vel.clone(),
+               gravity=torch.tensor([0.0, 0.0, -9.8]), foot_positions=e.foot_positions.clone(),
+               foot_velocities=e.foot_velocities.clone(), prev_foot_velocities=e.prev_foot_velocities.clone(),
+               contact_forces=e.contact_forces.clone(), actions=e.actions.clone(), last_actions=e.last_actions.clone(),
+               last_last_actions=e.last_last_actions.clone(), joint_pos_target=e.joint_pos_target.clone(),
+               last_joint_pos_target=e.last_joint_pos_target.clone(),
+               last_last_joint_pos_target=e.last_last_joint_pos_target.clone(), last_dof_vel=e.last_dof_vel.clone(),
+               torques=e.torques.clone(), last_contacts=e.last_contacts.clone(), commands=e.commands.clone(),
+               gait_indices=e.gait_indices.clone(), episode_length_buf=e.episode_length_buf.clone(),
+               friction_coeffs=e.friction_coeffs[:, 0].clone(), restitutions=e.restitutions[:, 0].clone(),
+               payloads=e.payloads.clone(), com_displacements=e.com_displacements.clone(),
+               motor_strengths=e.motor_strengths.clone(), motor_offsets=e.motor_offsets.clone(),
+               Kp_factors=e.Kp_factors.clone(), Kd_factors=e.Kd_factors.clone(),
+               episode_sums=torch.stack([e.episode_sums[k] for k in e.episode_sums]).clone(),
+               command_sums=torch.stack([e.command_sums[k] for k in e.command_sums]).clone())
+    names = dict(episode_sum_names=np.array(list(e.episode_sums)), command_sum_names=np.array(list(e.command_sums)))
+    U = {p_: np.array([[philox_uniform(sim_seed, int(i), step, p_, j) for j in range(16)] for i in range(N)], dtype=np.float32) for p_ in (3, 7, 9)}
+    all_ids = torch.arange(N)
+    push_ids = np.nonzero(ep % pi == 0)[0]
+    rand_ids = torch.tensor(np.nonzero(ep % ri == 0)[0], dtype=torch.long)
+    rn = rand_ids.numpy()
+    q_rand = []                                                                  # in the order the two methods draw
+    for flag, cols in ((dr.randomize_motor_strength, slice(0, 1)), (dr.randomize_motor_offset, slice(1, 13)),
+                       (dr.randomize_Kp_factor, slice(13, 14)), (dr.randomize_Kd_factor, slice(14, 15))):
+        if flag:
+            u = U[3][rn, cols]
+            q_rand.append(torch.tensor(u[:, 0] if u.shape[1] == 1 else u))
+    for flag, cols, squeeze in ((dr.randomize_base_mass, slice(0, 1), True), (dr.randomize_com_displacement, slice(1, 4), False),
+                                (dr.randomize_friction, slice(4, 5), False), (dr.randomize_restitution, slice(5, 6), False)):
+        if flag:
+            u = U[9][rn, cols]
+            q_rand.append(torch.tensor(u[:, 0] if squeeze else u))
+    q_push = [U[7][push_ids, 0:2]]
+    real_rand, real_trf = torch.rand, ref_mod.torch_rand_float
+    torch.rand = lambda *a, **k: q_rand.pop(0)
+
+    def trf(lo, hi, shape, device=None):
+        u = torch.tensor(q_push.pop(0))
+        assert tuple(u.shape) == tuple(shape), (u.shape, shape)
+        return (hi - lo) * u + lo
+    ref_mod.torch_rand_float = trf
+    try:
+        LR._teleport_robots(e, all_ids, cfg)
+        LR._push_robots(e, all_ids, cfg)
+        LR._randomize_dof_props(e, rand_ids, cfg)
+        LR._randomize_rigid_body_props(e, rand_ids, cfg)
+    finally:
+        torch.rand, ref_mod.torch_rand_float = real_rand, real_trf
+    assert not q_rand and not q_push, (len(q_rand), len(q_push))
+    out = dict(out_root_states=e.root_states, out_motor_strengths=e.motor_strengths, out_motor_offsets=e.motor_offsets,
+               out_Kp_factors=e.Kp_factors, out_Kd_factors=e.Kd_factors, out_payloads=e.payloads, out_com_displacements=e.com_displacements,
+               out_friction_coeffs=e.friction_coeffs[:, 0], out_restitutions=e.restitutions[:, 0],
+               push_ids=push_ids, rand_ids=rn, sim_seed=np.array(sim_seed), step=np.array(step))
+    np.savez_compressed(os.path.join(HERE, "callbacks.npz"), **flat(inp), **flat(out), **names)
+    moved = int(((e.root_states[:, :2] - inp["root_states"][:, :2]).abs().max(1).values > 1.0).sum())
+    print("callbacks: teleported", moved, "pushed", len(push_ids), "re-randomised", len(rn))
+
+
 if __name__ == "__main__":
     install_stubs()
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "callbacks":            # only callbacks.npz
+        gen_callbacks()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "gravity":              # only gravity.npz
+        gen_gravity()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "reset_eval":           # only reset_eval.npz
         gen_reset_eval()
         sys.exit(0)
@@ -696,3 +841,9 @@ if __name__ == "__main__":
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     gen_reset_eval()
+    for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+        del sys.modules[m]
+    gen_callbacks()
+    for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+        del sys.modules[m]
+    gen_gravity()

@@ -170,3 +170,88 @@ def test_hip_train_eval_reset_matches_reference():
     sim.reset_idx(torch.from_numpy(d["env_ids"]))
     torch.cuda.synchronize()
     _check_reset_eval(d, Bg, NT)
+
+
+# ---- the randomising branches of _post_physics_step_callback against the reference (tests/golden/callbacks.npz) -------------
+def _load_callbacks_fixture():
+    import os
+    import numpy as np
+    from util import GOLDEN, load_maps_fixture, make_sim
+    d0 = np.load(os.path.join(GOLDEN, "callbacks.npz"))
+    N = d0["root_states"].shape[0]
+    cfg, S, meta, B = make_sim("dr", N, seed=int(d0["sim_seed"]))
+    d = load_maps_fixture("callbacks.npz", S, meta, B)
+    B.Kp_factors[:] = torch.from_numpy(d["Kp_factors"]).t()
+    B.Kd_factors[:] = torch.from_numpy(d["Kd_factors"]).t()
+    assert S.push_robots and S.teleport_robots and S.randomize_rigids_after_start
+    return d, S, B
+
+
+def _check_callbacks(d, B):
+    import numpy as np
+    g = lambda k: B.tensors[k].cpu().numpy()
+    keep = g("reset_buf") == 0                    # (an environment that terminated was re-initialised after the callback)
+    assert keep.sum() >= 0.8 * keep.size
+    rs0, rs1 = d["root_states"], d["out_root_states"]
+    got = g("root_states").T
+    np.testing.assert_allclose(got[keep][:, 0:2], rs1[keep][:, 0:2], rtol=1e-6, atol=1e-5)          # teleport (:1028-1051)
+    np.testing.assert_allclose(got[keep][:, 7:9], rs1[keep][:, 7:9], rtol=1e-6, atol=1e-6)          # push (:1017-1026)
+    assert (np.abs(rs1[:, 0:2] - rs0[:, 0:2]).max(1) > 1.0).sum() > 10 and len(d["push_ids"]) > 10 and len(d["rand_ids"]) > 10
+    for k in ("motor_strengths", "motor_offsets", "Kp_factors", "Kd_factors", "com_displacements"):
+        np.testing.assert_allclose(g(k).T[keep], d["out_" + k][keep], rtol=1e-6, atol=1e-7, err_msg=k)
+    for k in ("payloads", "friction_coeffs", "restitutions"):
+        np.testing.assert_allclose(g(k)[keep], d["out_" + k][keep], rtol=1e-6, atol=1e-7, err_msg=k)
+    changed = np.abs(d["out_payloads"] - d["payloads"]) > 0
+    assert changed[d["rand_ids"]].all() and not changed[np.setdiff1d(np.arange(len(changed)), d["rand_ids"])].any()
+
+
+def test_oracle_callbacks_match_reference(oracle_lib):
+    """`_teleport_robots`, `_push_robots`, `_randomize_dof_props`, `_randomize_rigid_body_props` on their episode-length
+    cadence (legged_robot.py:675-708) — the reference's own methods fed the oracle's Philox uniforms (callbacks.npz)."""
+    d, S, B = _load_callbacks_fixture()
+    orc = oracle_lib.Oracle(S, B)
+    orc.ctr.common_step_counter = int(d["step"]) - 1
+    orc.post_physics(d["gravity"].astype("float64"))
+    _check_callbacks(d, B)
+
+
+def test_emulated_callbacks_match_reference():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
+    import emu_sim
+    d, S, B = _load_callbacks_fixture()
+    sim = emu_sim.EmuSim(S, B)
+    sim.set_counters(int(d["step"]) - 1, 0)
+    sim.post_physics(d["gravity"])
+    _check_callbacks(d, B)
+
+
+@pytest.mark.gpu
+def test_hip_callbacks_match_reference():
+    d, S, Bc = _load_callbacks_fixture()
+    Bg = Bc.clone_to("cuda:0")
+    sim = H.Go1Sim(S, Bg, 0)
+    sim.set_counters(int(d["step"]) - 1, 0)
+    sim.post_physics(d["gravity"])
+    torch.cuda.synchronize()
+    _check_callbacks(d, Bg)
+
+
+def test_oracle_gravity_schedule_matches_reference(oracle_lib):
+    """`_randomize_gravity` on its cadence (legged_robot.py:546-561, :701-705, :1549): the vector in force during the policy
+    step with pre-increment counter t over three intervals — the impulse is up for `duration` steps, then exactly the
+    nominal gravity — reference statements executed by make_golden.py gen_gravity."""
+    import os
+    import numpy as np
+    from util import GOLDEN, make_sim
+    d = np.load(os.path.join(GOLDEN, "gravity.npz"))
+    cfg, S, meta, B = make_sim("dr", 16, seed=int(d["sim_seed"]))
+    assert (S.gravity_rand_interval, S.gravity_rand_duration) == (int(d["interval"]), int(d["duration"]))
+    orc = oracle_lib.Oracle(S, B)
+    got = np.stack([orc.gravity_at(t) for t in range(len(d["gravity"]))])
+    np.testing.assert_allclose(got, d["gravity"], rtol=0, atol=2e-6)
+    quiet = np.abs(d["gravity"][:, :2]).max(1) == 0
+    assert quiet.sum() == 3 * (int(d["interval"]) - int(d["duration"])) and (got[quiet] == np.array([0.0, 0.0, -9.8], np.float32).astype(np.float64)).all()
+    unit = got / np.linalg.norm(got, axis=1, keepdims=True)                  # gravity_vec (:559), what projected_gravity rotates
+    np.testing.assert_allclose(unit, d["gravity_vec"], atol=1e-6)
