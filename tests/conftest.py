@@ -22,3 +22,14 @@ def oracle_lib():
     import pyoracle
     pyoracle.build()
     return pyoracle
+
+
+# Under `-x` the first failure ends the run.  The exact parity tests (kernel vs oracle / reference fixtures) come first;
+# tests whose verdict is statistical (a learning curve, distributions of a free-running simulation) or that start other
+# processes (torchrun, spawn) run last, so that a box-dependent hiccup in those cannot hide the parity results.
+_RUN_LAST = ("test_two_rank", "test_ppo_learns_on_the_hip_simulator", "test_free_running_distributions",
+             "test_runner_learns_and_exports", "test_teacher_student_runner", "test_distributed")
+
+
+def pytest_collection_modifyitems(config, items):
+    items.sort(key=lambda it: any(k in it.nodeid for k in _RUN_LAST))          # stable: file order otherwise kept
