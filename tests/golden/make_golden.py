@@ -694,7 +694,48 @@ def gen_gravity(seed=61, sim_seed=4242):
     print("gravity: interval", interval, "duration", duration, "impulse steps", int((np.abs(g[:, :2]).max(1) > 0).sum()), "of", T)
 
 
-def gen_callbacks(N=64, seed=51, sim_seed=999, step=200):
+TERRAIN_LAYOUT = dict(
+    train=dict(mesh_type="trimesh", num_rows=3, num_cols=5, terrain_length=4.0, terrain_width=4.0, border_size=2.0,
+               horizontal_scale=0.1, vertical_scale=0.005, curriculum=True, selected=False, difficulty_scale=1.0,
+               terrain_proportions=[0.1, 0.1, 0.2, 0.2, 0.2, 0.0, 0.0, 0.0, 0.2], terrain_noise_magnitude=0.03,
+               terrain_smoothness=0.005, max_platform_height=0.2, slope_treshold=0.75),
+    eval=dict(mesh_type="trimesh", num_rows=2, num_cols=7, terrain_length=4.0, terrain_width=4.0, border_size=2.0,
+              horizontal_scale=0.1, vertical_scale=0.005, curriculum=False, selected=False, difficulty_scale=1.0,
+              terrain_proportions=[0.2, 0.2, 0.1, 0.1, 0.2, 0.0, 0.0, 0.0, 0.1, 0.1], terrain_noise_magnitude=0.02,
+              terrain_smoothness=0.005, max_platform_height=0.2, slope_treshold=0.75))
+
+
+def gen_terrain_layout(seed=71):
+    """reference go1_gym/utils/terrain.py `Terrain` (tile grid, borders, the evaluation region appended behind the training one
+    :37-54, `make_terrain`'s choice / difficulty -> generator mapping :114-159, env origins :161-179) executed with this repo's
+    sub-terrain generators standing in for the closed `isaacgym.terrain_utils` (so the fixture pins the LAYOUT code; the
+    generators themselves are re-derived) — training grid in curriculum mode, evaluation grid in randomised mode."""
+    gens = load_private("_wtw_terrain", os.path.join(PKG, "go1_gym", "utils", "terrain.py"))
+    tu = sys.modules["isaacgym.terrain_utils"]
+    for n in ("SubTerrain", "random_uniform_terrain", "pyramid_sloped_terrain", "pyramid_stairs_terrain", "discrete_obstacles_terrain",
+              "stepping_stones_terrain"):
+        setattr(tu, n, getattr(gens, n))
+    tu.convert_heightfield_to_trimesh = lambda *a, **k: (None, None)
+    import isaacgym
+    isaacgym.terrain_utils = tu
+    from go1_gym.utils.terrain import Terrain                     # the REFERENCE class
+    out = {}
+    for tag, with_eval in (("solo", False), ("split", True)):
+        tr, ev = types.SimpleNamespace(**TERRAIN_LAYOUT["train"]), types.SimpleNamespace(**TERRAIN_LAYOUT["eval"])
+        np.random.seed(seed)
+        T = Terrain(tr, 32, ev, 16) if with_eval else Terrain(tr, 32)
+        out[f"{tag}_heights"] = T.height_field_raw.copy()
+        out[f"{tag}_train_origins"] = tr.env_origins.copy()
+        out[f"{tag}_tot"] = np.array([T.tot_rows, T.tot_cols])
+        if with_eval:
+            out[f"{tag}_eval_origins"] = ev.env_origins.copy()
+            out[f"{tag}_eval_offsets"] = np.array([ev.x_offset, ev.rows_offset])
+    import json
+    np.savez_compressed(os.path.join(HERE, "terrain_layout.npz"), seed=np.array(seed), config=np.array(json.dumps(TERRAIN_LAYOUT)), **out)
+    print("terrain_layout:", out["solo_tot"], out["split_tot"], "non-flat samples", int((out["split_heights"] != 0).sum()))
+
+
+def gen_callbacks(N=64, seed=51, sim_seed=999, step=200, x_offset_px=0, name="callbacks.npz"):
     """the randomising branches of `_post_physics_step_callback` that scripts/train.py leaves off (legged_robot.py:675-708):
     `_teleport_robots` :1028-1051, `_push_robots` :1017-1026, `_randomize_dof_props` :645-665 and
     `_randomize_rigid_body_props` :611-633 on their episode-length cadence — the reference's own methods on a mock env
@@ -714,12 +755,12 @@ def gen_callbacks(N=64, seed=51, sim_seed=999, step=200):
     cfg = e.cfg
     rng = np.random.default_rng(seed + 1)
     ter, dr = cfg.terrain, cfg.domain_rand
-    ter.x_offset = 0                       # set by the reference's Terrain class (terrain.py:42); no terrain object on the mock
+    ter.x_offset = x_offset_px             # set by the reference's Terrain class (terrain.py:42 / :51, in samples); no terrain object on the mock
     span_x, span_y = ter.terrain_length * ter.num_rows, ter.terrain_width * ter.num_cols
     xo = int(ter.x_offset * ter.horizontal_scale)
     kind = rng.integers(0, 5, N)
     e.root_states[:, 0] = torch.tensor(np.where(kind == 0, ter.teleport_thresh + xo - 0.15, np.where(kind == 1, span_x - ter.teleport_thresh + xo + 0.15,
-                                                rng.uniform(5.0, span_x - 5.0, N))), dtype=torch.float)
+                                                rng.uniform(5.0, span_x - 5.0, N) + xo)), dtype=torch.float)
     kind = rng.integers(0, 5, N)
     e.root_states[:, 1] = torch.tensor(np.where(kind == 0, ter.teleport_thresh - 0.15, np.where(kind == 1, span_y - ter.teleport_thresh + 0.15,
                                                 rng.uniform(5.0, span_y - 5.0, N))), dtype=torch.float)
@@ -780,17 +821,21 @@ def gen_callbacks(N=64, seed=51, sim_seed=999, step=200):
     out = dict(out_root_states=e.root_states, out_motor_strengths=e.motor_strengths, out_motor_offsets=e.motor_offsets,
                out_Kp_factors=e.Kp_factors, out_Kd_factors=e.Kd_factors, out_payloads=e.payloads, out_com_displacements=e.com_displacements,
                out_friction_coeffs=e.friction_coeffs[:, 0], out_restitutions=e.restitutions[:, 0],
-               push_ids=push_ids, rand_ids=rn, sim_seed=np.array(sim_seed), step=np.array(step))
-    np.savez_compressed(os.path.join(HERE, "callbacks.npz"), **flat(inp), **flat(out), **names)
+               push_ids=push_ids, rand_ids=rn, sim_seed=np.array(sim_seed), step=np.array(step), teleport_x_offset=np.array(float(xo)))
+    np.savez_compressed(os.path.join(HERE, name), **flat(inp), **flat(out), **names)
     moved = int(((e.root_states[:, :2] - inp["root_states"][:, :2]).abs().max(1).values > 1.0).sum())
-    print("callbacks: teleported", moved, "pushed", len(push_ids), "re-randomised", len(rn))
+    print(name, "teleported", moved, "pushed", len(push_ids), "re-randomised", len(rn))
 
 
 if __name__ == "__main__":
     install_stubs()
     torch.manual_seed(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "callbacks":            # only callbacks.npz
+    if len(sys.argv) > 1 and sys.argv[1] == "callbacks":            # only callbacks*.npz
         gen_callbacks()
+        gen_callbacks(seed=52, x_offset_px=163, name="callbacks_offset.npz")      # an evaluation region's teleport window
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "terrain_layout":       # only terrain_layout.npz
+        gen_terrain_layout()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gravity":              # only gravity.npz
         gen_gravity()
@@ -844,6 +889,10 @@ if __name__ == "__main__":
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     gen_callbacks()
+    gen_callbacks(seed=52, x_offset_px=163, name="callbacks_offset.npz")
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     gen_gravity()
+    for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+        del sys.modules[m]
+    gen_terrain_layout()

@@ -74,3 +74,49 @@ def test_eval_cfg_needs_wavefront_aligned_train_count(monkeypatch):
     cfg, ev = _cfgs(24, 8)
     with pytest.raises(ValueError, match="multiple of 16"):
         VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg, eval_cfg=ev)
+
+
+def test_eval_environments_on_their_own_terrain_region(monkeypatch):
+    """generated terrain with `eval_cfg` (reference legged_robot.py:502-503, terrain.py:37-54): the evaluation tile grid lies
+    behind the training one in the same height field, the evaluation environments start on its tiles, and their teleport
+    window is shifted by the region's offset (`_teleport_robots` :1033)."""
+    import fake_sim
+    from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+    fake_sim.install(monkeypatch)
+    NT, NE = 32, 16
+    cfg, ev = _cfgs(NT, NE)
+    for c, rows, cols in ((cfg, 3, 4), (ev, 2, 6)):
+        t = c.terrain
+        t.mesh_type, t.num_rows, t.num_cols, t.terrain_length, t.terrain_width, t.border_size = "heightfield", rows, cols, 4.0, 4.0, 2.0
+        t.terrain_proportions, t.curriculum, t.teleport_robots, t.teleport_thresh = [0.2, 0.2, 0.2, 0.2, 0.2], True, True, 0.3
+        t.min_init_terrain_level, t.max_init_terrain_level, t.center_robots = 0, rows - 1, False
+    torch.manual_seed(0)
+    env = VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg, eval_cfg=ev)
+    tr_rows = 3 * 40 + 40
+    assert env.terrain.heightsamples.shape == (tr_rows + 2 * 40 + 40, max(4 * 40 + 40, 6 * 40 + 40))
+    assert (ev.terrain.x_offset, ev.terrain.rows_offset) == (tr_rows, 3)
+    S, Se = env.sim_config, env.sim_config_eval
+    assert (S.teleport_x_offset, Se.teleport_x_offset) == (0.0, float(int(tr_rows * 0.1)))
+    assert (Se.terrain_num_rows, Se.terrain_num_cols, S.terrain_num_rows, S.terrain_num_cols) == (2, 6, 3, 4)
+    assert S.custom_origins == 1 and Se.custom_origins == 1 and S.hf_rows == env.terrain.tot_rows
+    ox = env.env_origins[:, 0]
+    assert float(ox[:NT].max()) < 12.0 and float(ox[NT:].min()) > tr_rows * 0.1               # metres: behind the training region
+    # every evaluation origin is one of eval_cfg's tile origins, at that tile's height
+    tiles = torch.from_numpy(ev.terrain.env_origins).float().reshape(-1, 3)
+    dist = (env.env_origins[NT:, None, :] - tiles[None]).abs().amax(-1).amin(-1)
+    assert float(dist.max()) < 1e-5
+    assert bool((env.terrain_types[NT:] == torch.div(torch.arange(NE), NE / 6, rounding_mode="floor").long()).all())
+    env.step(torch.zeros(NT + NE, 12))
+    assert bool(torch.isfinite(env.obs_buf).all())
+    # the reset positions of the evaluation environments stay on their region
+    assert float(env.root_states[NT:, 0].min()) > tr_rows * 0.1 - 1.0
+
+
+def test_eval_terrain_needs_a_training_terrain(monkeypatch):
+    import fake_sim
+    from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+    fake_sim.install(monkeypatch)
+    cfg, ev = _cfgs(32, 16)
+    ev.terrain.mesh_type = "heightfield"
+    with pytest.raises(ValueError, match="appended to the training terrain"):
+        VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg, eval_cfg=ev)

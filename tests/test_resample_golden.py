@@ -173,14 +173,18 @@ def test_hip_train_eval_reset_matches_reference():
 
 
 # ---- the randomising branches of _post_physics_step_callback against the reference (tests/golden/callbacks.npz) -------------
-def _load_callbacks_fixture():
+CALLBACK_FIXTURES = ["callbacks.npz", "callbacks_offset.npz"]       # the second: the teleport window of an evaluation region
+
+
+def _load_callbacks_fixture(fname):
     import os
     import numpy as np
     from util import GOLDEN, load_maps_fixture, make_sim
-    d0 = np.load(os.path.join(GOLDEN, "callbacks.npz"))
+    d0 = np.load(os.path.join(GOLDEN, fname))
     N = d0["root_states"].shape[0]
     cfg, S, meta, B = make_sim("dr", N, seed=int(d0["sim_seed"]))
-    d = load_maps_fixture("callbacks.npz", S, meta, B)
+    S.teleport_x_offset = float(d0["teleport_x_offset"])          # int(cfg.terrain.x_offset * horizontal_scale), :1033
+    d = load_maps_fixture(fname, S, meta, B)
     B.Kp_factors[:] = torch.from_numpy(d["Kp_factors"]).t()
     B.Kd_factors[:] = torch.from_numpy(d["Kd_factors"]).t()
     assert S.push_robots and S.teleport_robots and S.randomize_rigids_after_start
@@ -205,22 +209,24 @@ def _check_callbacks(d, B):
     assert changed[d["rand_ids"]].all() and not changed[np.setdiff1d(np.arange(len(changed)), d["rand_ids"])].any()
 
 
-def test_oracle_callbacks_match_reference(oracle_lib):
+@pytest.mark.parametrize("fname", CALLBACK_FIXTURES)
+def test_oracle_callbacks_match_reference(oracle_lib, fname):
     """`_teleport_robots`, `_push_robots`, `_randomize_dof_props`, `_randomize_rigid_body_props` on their episode-length
     cadence (legged_robot.py:675-708) — the reference's own methods fed the oracle's Philox uniforms (callbacks.npz)."""
-    d, S, B = _load_callbacks_fixture()
+    d, S, B = _load_callbacks_fixture(fname)
     orc = oracle_lib.Oracle(S, B)
     orc.ctr.common_step_counter = int(d["step"]) - 1
     orc.post_physics(d["gravity"].astype("float64"))
     _check_callbacks(d, B)
 
 
-def test_emulated_callbacks_match_reference():
+@pytest.mark.parametrize("fname", CALLBACK_FIXTURES)
+def test_emulated_callbacks_match_reference(fname):
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
     import emu_sim
-    d, S, B = _load_callbacks_fixture()
+    d, S, B = _load_callbacks_fixture(fname)
     sim = emu_sim.EmuSim(S, B)
     sim.set_counters(int(d["step"]) - 1, 0)
     sim.post_physics(d["gravity"])
@@ -228,8 +234,9 @@ def test_emulated_callbacks_match_reference():
 
 
 @pytest.mark.gpu
-def test_hip_callbacks_match_reference():
-    d, S, Bc = _load_callbacks_fixture()
+@pytest.mark.parametrize("fname", CALLBACK_FIXTURES)
+def test_hip_callbacks_match_reference(fname):
+    d, S, Bc = _load_callbacks_fixture(fname)
     Bg = Bc.clone_to("cuda:0")
     sim = H.Go1Sim(S, Bg, 0)
     sim.set_counters(int(d["step"]) - 1, 0)

@@ -44,6 +44,30 @@ def test_hip_height_scan_matches_reference():
     np.testing.assert_allclose(Bg.measured_heights.t().cpu().numpy(), d["heights"], rtol=0, atol=1e-6)
 
 
+def test_terrain_layout_matches_reference():
+    """tile grid, borders, the evaluation region behind the training one, `make_terrain`'s mapping and the env origins against
+    the reference `Terrain` class (terrain.py:12-179) run over the same sub-terrain generators (terrain_layout.npz)."""
+    import json
+    import types
+    from util import GOLDEN
+    from go1_gym.utils import terrain as T
+    d = np.load(os.path.join(GOLDEN, "terrain_layout.npz"))
+    conf = json.loads(str(d["config"]))
+    for tag, with_eval in (("solo", False), ("split", True)):
+        tr, ev = types.SimpleNamespace(**conf["train"]), types.SimpleNamespace(**conf["eval"])
+        np.random.seed(int(d["seed"]))
+        ter = T.Terrain(tr, 32, ev, 16) if with_eval else T.Terrain(tr, 32)
+        assert (ter.tot_rows, ter.tot_cols) == tuple(d[f"{tag}_tot"])
+        assert np.array_equal(ter.heightsamples, d[f"{tag}_heights"]) and ter.heightsamples.dtype == np.int16
+        np.testing.assert_array_equal(tr.env_origins, d[f"{tag}_train_origins"])
+        assert (tr.x_offset, tr.rows_offset) == (0, 0)
+        if with_eval:
+            np.testing.assert_array_equal(ev.env_origins, d[f"{tag}_eval_origins"])
+            assert (ev.x_offset, ev.rows_offset) == tuple(d[f"{tag}_eval_offsets"])
+            assert ev.env_origins[..., 0].min() > tr.terrain_length * tr.num_rows          # behind the training region
+            assert d[f"{tag}_heights"][tr.tot_rows:].any()
+
+
 def test_terrain_generators_and_tile_grid():
     from go1_gym.envs.base.legged_robot_config import make_cfg
     from go1_gym.utils import terrain as T

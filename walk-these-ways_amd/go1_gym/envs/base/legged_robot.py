@@ -168,15 +168,24 @@ class LeggedRobot(BaseTask):
             raise ValueError("Terrain mesh type not recognised. Allowed types are [None, plane, heightfield, trimesh]")
         self.up_axis_idx = 2
         if self.eval_cfg is not None:
-            if mesh_type in ('heightfield', 'trimesh') or self.eval_cfg.terrain.mesh_type in ('heightfield', 'trimesh'):
-                raise NotImplementedError("eval_cfg with a generated terrain: the reference appends a second terrain region for "
-                                          "the evaluation environments (legged_robot.py:502-503, terrain.py); only built for "
-                                          "mesh_type None / 'plane' here")
+            et = self.eval_cfg.terrain
+            if et.mesh_type in ('heightfield', 'trimesh') and mesh_type not in ('heightfield', 'trimesh'):
+                # (the reference builds no Terrain then, legged_robot.py:500-505, and fails in _get_env_origins)
+                raise ValueError("eval_cfg.terrain.mesh_type is a generated terrain but cfg.terrain.mesh_type is not: the "
+                                 "evaluation region is appended to the training terrain (terrain.py:37-54)")
+            if mesh_type in ('heightfield', 'trimesh') and et.mesh_type in ('heightfield', 'trimesh') and \
+                    (et.horizontal_scale, et.vertical_scale) != (cfg.terrain.horizontal_scale, cfg.terrain.vertical_scale):
+                raise ValueError("eval_cfg.terrain: horizontal_scale / vertical_scale must equal the training terrain's (both "
+                                 "regions live in one height field, converted with the training scales: terrain.py:30-36)")
             if self.num_train_envs % 16 != 0:
                 raise ValueError(f"eval_cfg: cfg.env.num_envs = {self.num_train_envs} must be a multiple of 16 (the step kernel "
                                  f"selects the train / evaluation configuration per wavefront of 16 environments)")
         if mesh_type in ('heightfield', 'trimesh'):
-            self.terrain = Terrain(cfg.terrain, self.num_train_envs)
+            if self.eval_cfg is not None and self.eval_cfg.terrain.mesh_type in ('heightfield', 'trimesh'):
+                # reference legged_robot.py:502-503: a second tile grid for the evaluation environments behind the training one
+                self.terrain = Terrain(cfg.terrain, self.num_train_envs, self.eval_cfg.terrain, self.num_eval_envs)
+            else:
+                self.terrain = Terrain(cfg.terrain, self.num_train_envs)
             hs = self.terrain.heightsamples
             self.height_samples = torch.tensor(hs).view(self.terrain.tot_rows, self.terrain.tot_cols).to(self.device)
         seed = int(getattr(cfg, "seed", getattr(cfg.env, "seed", 0)))
@@ -252,38 +261,40 @@ class LeggedRobot(BaseTask):
         return ret
 
     def _get_env_origins(self):
-        """reference legged_robot.py:1675-1714."""
-        cfg, B, N = self.cfg, self.buffers, self.num_envs
-        ter = cfg.terrain
-        if ter.mesh_type in ("heightfield", "trimesh"):
-            self.custom_origins = True
-            lo, hi = (ter.min_init_terrain_level, ter.max_init_terrain_level) if ter.curriculum else (0, ter.num_rows - 1)
-            if ter.center_robots:
-                lo, hi = ter.num_rows // 2 - ter.center_span, ter.num_rows // 2 + ter.center_span - 1
-                tlo, thi = ter.num_cols // 2 - ter.center_span, ter.num_cols // 2 + ter.center_span - 1
-                self.terrain_levels = torch.randint(lo, hi + 1, (N,), device=self.device)
-                self.terrain_types = torch.randint(tlo, thi + 1, (N,), device=self.device)
+        """reference legged_robot.py:1675-1714, once per group (`_call_train_eval(self._get_env_origins, ...)`, :1538): the
+        training environments on cfg's tiles or grid, the evaluation environments on eval_cfg's."""
+        B, N = self.buffers, self.num_envs
+        origins = torch.zeros(N, 3, device=self.device)
+        self.terrain_levels = torch.zeros(N, dtype=torch.long, device=self.device)
+        self.terrain_types = torch.zeros(N, dtype=torch.long, device=self.device)
+        self.custom_origins = False
+        for lo_, n_, c_ in ((0, self.num_train_envs, self.cfg), (self.num_train_envs, self.num_eval_envs, self.eval_cfg)):
+            if n_ == 0:
+                continue
+            ter = c_.terrain
+            self.custom_origins = ter.mesh_type in ("heightfield", "trimesh")      # (an attribute: the last group's value stays)
+            if self.custom_origins:
+                lo, hi = (ter.min_init_terrain_level, ter.max_init_terrain_level) if ter.curriculum else (0, ter.num_rows - 1)
+                if ter.center_robots:
+                    lo, hi = ter.num_rows // 2 - ter.center_span, ter.num_rows // 2 + ter.center_span - 1
+                    tlo, thi = ter.num_cols // 2 - ter.center_span, ter.num_cols // 2 + ter.center_span - 1
+                    levels = torch.randint(lo, hi + 1, (n_,), device=self.device)
+                    types = torch.randint(tlo, thi + 1, (n_,), device=self.device)
+                else:
+                    levels = torch.randint(lo, hi + 1, (n_,), device=self.device)
+                    types = torch.div(torch.arange(n_, device=self.device), (n_ / ter.num_cols), rounding_mode='floor').to(torch.long)
+                ter.max_terrain_level = ter.num_rows
+                ter.terrain_origins = torch.from_numpy(ter.env_origins).to(self.device).to(torch.float)
+                self.terrain_levels[lo_:lo_ + n_], self.terrain_types[lo_:lo_ + n_] = levels, types
+                origins[lo_:lo_ + n_] = ter.terrain_origins[levels, types]
             else:
-                self.terrain_levels = torch.randint(lo, hi + 1, (N,), device=self.device)
-                self.terrain_types = torch.div(torch.arange(N, device=self.device), (N / ter.num_cols),
-                                               rounding_mode='floor').to(torch.long)
-            ter.max_terrain_level = ter.num_rows
-            ter.terrain_origins = torch.from_numpy(ter.env_origins).to(self.device).to(torch.float)
-            origins = ter.terrain_origins[self.terrain_levels, self.terrain_types]
-        else:
-            self.custom_origins = False
-            origins = torch.zeros(N, 3, device=self.device)
-            # one grid per group (reference: _call_train_eval(self._get_env_origins, ...), :1538, :1704-1714)
-            for lo_, n_, c_ in ((0, self.num_train_envs, cfg), (self.num_train_envs, self.num_eval_envs, self.eval_cfg)):
-                if n_ == 0:
-                    continue
                 cols = np.floor(np.sqrt(n_))
                 rows = np.ceil(n_ / cols)
                 xx, yy = torch.meshgrid(torch.arange(rows), torch.arange(cols), indexing="ij")
                 origins[lo_:lo_ + n_, 0] = c_.env.env_spacing * xx.flatten()[:n_].to(self.device)
                 origins[lo_:lo_ + n_, 1] = c_.env.env_spacing * yy.flatten()[:n_].to(self.device)
-            self.terrain_levels = torch.zeros(N, dtype=torch.long, device=self.device)
-            self.terrain_types = torch.zeros(N, dtype=torch.long, device=self.device)
+        # `_reset_root_states` branches on this attribute for every environment (reference :966-980), whatever its group
+        self.sim_config.custom_origins = int(self.custom_origins)
         B.env_origins.copy_(origins.t())
         self.env_origins = B.env_origins.t()
 

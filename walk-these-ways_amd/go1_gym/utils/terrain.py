@@ -1,7 +1,7 @@
 """Height-field terrain built at set-up time (mirror of reference go1_gym/utils/terrain.py:12-179).
 
 `Terrain` lays sub-terrain tiles into one int16 height field and records the per-tile env origins, exactly like
-the reference class (tile grid, borders, `curriculum` / randomised / `selected` modes, the `choice`/`difficulty`
+the reference class (tile grid, borders, the evaluation region behind the training one, `curriculum` / randomised / `selected` modes, the `choice`/`difficulty`
 → generator mapping of `make_terrain` :114-159).  The sub-terrain *generators* themselves live in the closed
 `isaacgym.terrain_utils` package, which is not part of the reference tree; the ones below are re-derived from their
 documented behaviour (parameters have the same names and units: metres, with `horizontal_scale` /
@@ -121,21 +121,33 @@ def stepping_stones_terrain(terrain, stone_size, stone_distance, max_height, pla
 
 class Terrain:
     def __init__(self, cfg, num_robots, eval_cfg=None, num_eval_robots=0):
+        """reference terrain.py:13-54: the training tile grid, and — with `eval_cfg` — a second grid for the evaluation
+        environments appended along x (rows) in the same height field: `x_offset` = the training region's height in samples,
+        columns = the wider of the two."""
         self.cfg, self.eval_cfg, self.num_robots = cfg, eval_cfg, num_robots
         self.type = cfg.mesh_type
         if self.type in ("none", "plane"):
             return
-        if eval_cfg is not None:
-            raise NotImplementedError("eval terrain split (SURVEY.md §8f rank 4)")
         self._load_cfg(cfg)
         cfg.row_indices = np.arange(0, cfg.tot_rows)
         cfg.col_indices = np.arange(0, cfg.tot_cols)
         cfg.x_offset = 0
         cfg.rows_offset = 0
-        self.tot_rows, self.tot_cols = cfg.tot_rows, cfg.tot_cols
+        self.train_rows, self.train_cols, self.eval_rows, self.eval_cols = cfg.row_indices, cfg.col_indices, [], []
+        if eval_cfg is not None:
+            self._load_cfg(eval_cfg)
+            eval_cfg.row_indices = np.arange(cfg.tot_rows, cfg.tot_rows + eval_cfg.tot_rows)
+            eval_cfg.col_indices = np.arange(0, eval_cfg.tot_cols)
+            eval_cfg.x_offset = cfg.tot_rows
+            eval_cfg.rows_offset = cfg.num_rows
+            self.eval_rows, self.eval_cols = eval_cfg.row_indices, eval_cfg.col_indices
+        self.tot_rows = len(self.train_rows) + len(self.eval_rows)
+        self.tot_cols = max(len(self.train_cols), len(self.eval_cols))
         cfg.env_length, cfg.env_width = cfg.terrain_length, cfg.terrain_width
         self.height_field_raw = np.zeros((self.tot_rows, self.tot_cols), dtype=np.int16)
         self._populate(cfg)
+        if eval_cfg is not None:
+            self._populate(eval_cfg)
         self.heightsamples = self.height_field_raw
 
     @staticmethod
