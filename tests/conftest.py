@@ -28,7 +28,7 @@ def oracle_lib():
 # tests whose verdict is statistical (a learning curve, distributions of a free-running simulation) or that start other
 # processes (torchrun, spawn) run last, so that a box-dependent hiccup in those cannot hide the parity results.
 _RUN_LAST = ("test_two_rank", "test_ppo_learns_on_the_hip_simulator", "test_free_running_distributions",
-             "test_runner_learns_and_exports", "test_teacher_student_runner", "test_distributed")
+             "test_runner_learns_and_exports", "test_teacher_student_runner", "test_distributed", "test_ragged_env_counts")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -735,6 +735,43 @@ def gen_terrain_layout(seed=71):
     print("terrain_layout:", out["solo_tot"], out["split_tot"], "non-flat samples", int((out["split_heights"] != 0).sum()))
 
 
+def gen_pretrain_parameters():
+    """the `parameters.pkl` the reference ships with its pretrained run (runs/gait-conditioned-agility/pretrain-v0/train/
+    025417.456545; written by `logger.log_params(..., Cfg=vars(Cfg))`, train.py:209-210, read back by scripts/play.py:37-47) as
+    JSON: the run's effective configuration INCLUDING the values the reference derived at construction (`_parse_cfg`:
+    max_episode_length, push / rand / gravity intervals; `Terrain`: tile grid sizes, env origins)."""
+    import io
+    import json
+    import pickle
+
+    class CpuUnpickler(pickle.Unpickler):                         # (the tensors were pickled on a CUDA device)
+        def find_class(self, module, name):
+            if module == "torch.storage" and name == "_load_from_bytes":
+                return lambda b: torch.load(io.BytesIO(b), map_location="cpu", weights_only=False)
+            return super().find_class(module, name)
+
+    def plain(v):
+        if isinstance(v, dict):
+            return {str(k): plain(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [plain(x) for x in v]
+        if isinstance(v, torch.Tensor):
+            return v.tolist()
+        if isinstance(v, np.ndarray):
+            return v.tolist()
+        if isinstance(v, np.generic):
+            return v.item()
+        return v
+    with open(os.path.join(REF, "runs/gait-conditioned-agility/pretrain-v0/train/025417.456545/parameters.pkl"), "rb") as f:
+        d = CpuUnpickler(f).load()
+    out = plain(d)
+    for k in ("row_indices", "col_indices"):                      # arange(tot_rows): 1500 integers each, implied by tot_rows / tot_cols
+        out["Cfg"]["terrain"].pop(k, None)
+    with open(os.path.join(HERE, "pretrain_parameters.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("pretrain_parameters:", list(out), "max_episode_length", out["Cfg"]["env"]["max_episode_length"])
+
+
 def gen_callbacks(N=64, seed=51, sim_seed=999, step=200, x_offset_px=0, name="callbacks.npz"):
     """the randomising branches of `_post_physics_step_callback` that scripts/train.py leaves off (legged_robot.py:675-708):
     `_teleport_robots` :1028-1051, `_push_robots` :1017-1026, `_randomize_dof_props` :645-665 and
@@ -837,6 +874,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "terrain_layout":       # only terrain_layout.npz
         gen_terrain_layout()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pretrain_parameters":  # only pretrain_parameters.json
+        gen_pretrain_parameters()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gravity":              # only gravity.npz
         gen_gravity()
         sys.exit(0)
@@ -896,3 +936,4 @@ if __name__ == "__main__":
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     gen_terrain_layout()
+    gen_pretrain_parameters()

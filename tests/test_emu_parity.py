@@ -42,10 +42,12 @@ def diff(Be, Bc, k):
     return float((Be.tensors[k].double() - Bc.tensors[k].double()).abs().max())
 
 
-@pytest.mark.parametrize("variant,N", [("train_noise", 32), ("alt", 16), ("train_noise", 8), ("dr", 16)])
+@pytest.mark.parametrize("variant,N", [("train_noise", 32), ("alt", 16), ("train_noise", 8), ("dr", 16), ("train_noise", 1),
+                                       ("dr", 21)])
 def test_emulated_kernel_full_step_matches_oracle(oracle_lib, emu, variant, N):
     """fp32 kernel vs fp64 oracle, identical state / action / RNG streams, re-synchronised every step: round-off only.
-    N = 32: two wavefronts, matrix-core torque path; N = 8: a partial wavefront, plain-FMA torque path."""
+    N = 32: two wavefronts, matrix-core torque path; N = 8: a partial wavefront, plain-FMA torque path; N = 1: scripts/play.py's
+    single environment (play.py:62); N = 21: a ragged second workgroup."""
     S, Bc, orc, Be, sim = pair(oracle_lib, emu, variant, N)
     rng = np.random.default_rng(0)
     for step in range(8):

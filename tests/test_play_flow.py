@@ -1,0 +1,139 @@
+"""scripts/play.py's flow through the product's host classes, fed the `parameters.pkl` of the reference's pretrained run
+(tests/golden/pretrain_parameters.json, make_golden.py gen_pretrain_parameters): the configuration is applied the way
+`load_env` applies it (play.py:37-47), the values the reference DERIVED at construction and stored in that file
+(`_parse_cfg` legged_robot.py:1716-1754; `Terrain._load_cfg` / env origins, terrain.py:56-66,161-179) must come out the same
+here, and the play loop (one environment, commands written into `env.commands` every step, play.py:62-139) runs.  No GPU: the
+simulator handle is the oracle-backed stand-in of tests/fake_sim.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import GOLDEN
+
+
+def _apply_like_load_env(Cfg, stored):
+    for key, value in stored.items():                 # play.py:43-46
+        if hasattr(Cfg, key):
+            for key2, value2 in value.items():
+                setattr(getattr(Cfg, key), key2, value2)
+
+
+def _pretrained():
+    with open(os.path.join(GOLDEN, "pretrain_parameters.json")) as f:
+        return json.load(f)
+
+
+def test_train_config_equals_the_pretrained_runs_parameters():
+    """scripts/train_config.py (the mirror of train.py:21-204) against what the reference's own run logged: every stored field
+    is equal except the three the current train.py sets differently from that run (train.py:49,112-113) and the derived ones."""
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from scripts.train_config import apply_train_config
+    stored = _pretrained()["Cfg"]
+    cfg = apply_train_config(make_cfg())
+    derived = {"domain_rand": {"gravity_rand_duration", "gravity_rand_interval", "push_interval", "rand_interval"},
+               "env": {"max_episode_length"},
+               "terrain": {"border", "env_length", "env_origins", "env_width", "length_per_env_pixels", "max_terrain_level",
+                           "num_sub_terrains", "proportions", "rows_offset", "terrain_origins", "tot_cols", "tot_rows",
+                           "width_per_env_pixels", "x_offset"}}
+    differs = {}
+    for sec, vals in stored.items():
+        if sec == "command_ranges":                   # = vars(cfg.commands), created by _parse_cfg (:1721)
+            continue
+        for k, v in vals.items():
+            if k in derived.get(sec, ()) or (sec, k) == ("reward_scales", "jump_amplitude"):       # (a term the run's code had)
+                continue
+            m = getattr(getattr(cfg, sec), k)
+            m = vars(m) if hasattr(m, "__dict__") and not isinstance(m, dict) else m
+            m = list(m) if isinstance(m, tuple) else m
+            if m != v:
+                differs[(sec, k)] = (m, v)
+    assert differs == {("domain_rand", "gravity_range"): ([-1.0, 1.0], [-2.0, 2.0]),
+                       ("rewards", "terminal_body_ori"): (1.6, 0.5),
+                       ("rewards", "use_terminal_roll_pitch"): (True, False)}, differs
+    P = _pretrained()
+    from go1_gym_learn.ppo_cse.actor_critic import AC_Args
+    from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    from go1_gym_learn.ppo_cse import RunnerArgs
+    for cls, name in ((AC_Args, "AC_Args"), (PPO_Args, "PPO_Args"), (RunnerArgs, "RunnerArgs")):
+        for k, v in P[name].items():
+            assert getattr(cls, k) == v, (name, k, getattr(cls, k), v)
+
+
+def test_derived_configuration_and_play_loop(monkeypatch):
+    import fake_sim
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from go1_gym.envs.go1.go1_config import config_go1
+    from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+    from go1_gym.envs.wrappers.history_wrapper import HistoryWrapper
+    fake_sim.install(monkeypatch)
+    stored = _pretrained()["Cfg"]
+    want = json.loads(json.dumps(stored))             # (the constructor overwrites the derived entries in place)
+
+    # ---- the run's own configuration (fewer environments): the derived values must be the stored ones
+    Cfg = make_cfg()
+    config_go1(Cfg)
+    _apply_like_load_env(Cfg, stored)
+    Cfg.env.num_envs = 32
+    torch.manual_seed(0)
+    env = VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=Cfg)
+    assert float(env.max_episode_length) == want["env"]["max_episode_length"] == 1001.0
+    for k in ("push_interval", "rand_interval", "gravity_rand_interval", "gravity_rand_duration"):
+        assert float(getattr(Cfg.domain_rand, k)) == want["domain_rand"][k], k
+    for k in ("border", "env_length", "env_width", "length_per_env_pixels", "width_per_env_pixels", "num_sub_terrains", "tot_cols",
+              "tot_rows", "x_offset", "rows_offset", "max_terrain_level"):
+        assert getattr(Cfg.terrain, k) == want["terrain"][k], k
+    assert [float(p) for p in Cfg.terrain.proportions] == [float(p) for p in want["terrain"]["proportions"]]
+    np.testing.assert_array_equal(np.asarray(Cfg.terrain.env_origins), np.asarray(want["terrain"]["env_origins"]))
+    np.testing.assert_array_equal(Cfg.terrain.terrain_origins.cpu().numpy(), np.asarray(want["terrain"]["terrain_origins"], dtype=np.float32))
+    assert Cfg.command_ranges == vars(Cfg.commands) and Cfg.command_ranges["num_bins_vel_x"] == want["command_ranges"]["num_bins_vel_x"]
+    # center_robots: the environments start on the central (2 * center_span)^2 tiles (:1686-1694)
+    lv, ty = env.terrain_levels, env.terrain_types
+    assert int(lv.min()) >= 11 and int(lv.max()) <= 18 and int(ty.min()) >= 11 and int(ty.max()) <= 18
+    S = env.sim_config
+    assert (S.gravity_rand_interval, S.gravity_rand_duration, S.rand_interval, S.max_episode_length) == (401, 397, 201, 1001)
+    assert tuple(S.gravity_range) == (-2.0, 2.0) and S.lag_timesteps == 6 and S.hf_rows == 1500
+
+    # ---- play.py:48-78 on top, then the loop of :120-139 with its command writes
+    Cfg = make_cfg()
+    config_go1(Cfg)
+    _apply_like_load_env(Cfg, want)
+    dr = Cfg.domain_rand
+    dr.push_robots = dr.randomize_friction = dr.randomize_gravity = dr.randomize_restitution = dr.randomize_motor_offset = False
+    dr.randomize_motor_strength = dr.randomize_friction_indep = dr.randomize_ground_friction = dr.randomize_base_mass = False
+    dr.randomize_Kd_factor = dr.randomize_Kp_factor = dr.randomize_joint_friction = dr.randomize_com_displacement = False
+    Cfg.env.num_recording_envs = 1
+    Cfg.env.num_envs = 1
+    Cfg.terrain.num_rows = Cfg.terrain.num_cols = 5
+    Cfg.terrain.border_size = 0
+    Cfg.terrain.center_robots = True
+    Cfg.terrain.center_span = 1
+    Cfg.terrain.teleport_robots = True
+    dr.lag_timesteps = 6
+    dr.randomize_lag_timesteps = True
+    Cfg.control.control_type = "actuator_net"
+    env = HistoryWrapper(VelocityTrackingEasyEnv(sim_device="cuda:0", headless=False, cfg=Cfg))
+    assert env.num_envs == 1 and env.env.sim_config.teleport_robots == 1 and env.env.terrain.tot_rows == 250
+    obs = env.reset()
+    assert obs["obs"].shape == (1, 70) and obs["obs_history"].shape == (1, 2100) and obs["privileged_obs"].shape == (1, 2)
+    gait = torch.tensor([0.5, 0.0, 0.0])
+    for i in range(20):
+        actions = torch.zeros(1, 12)
+        env.commands[:, 0] = 1.5
+        env.commands[:, 1] = 0.0
+        env.commands[:, 2] = 0.0
+        env.commands[:, 3] = 0.0
+        env.commands[:, 4] = 3.0
+        env.commands[:, 5:8] = gait
+        env.commands[:, 8] = 0.5
+        env.commands[:, 9] = 0.08
+        env.commands[:, 10] = 0.0
+        env.commands[:, 11] = 0.0
+        env.commands[:, 12] = 0.25
+        obs, rew, done, info = env.step(actions)
+        assert float(env.base_lin_vel[0, 0]) == float(env.base_lin_vel[0, 0]) and env.dof_pos[0, :].cpu().shape == (12,)
+    # the written commands are what the observation carries (scaled, legged_robot.py:325): they were not resampled away
+    assert float(obs["obs"][0, 3]) == pytest.approx(1.5 * Cfg.obs_scales.lin_vel) and bool(torch.isfinite(obs["obs_history"]).all())
+    assert float(obs["obs"][0, 3 + 4]) == pytest.approx(3.0 * Cfg.obs_scales.gait_freq_cmd)

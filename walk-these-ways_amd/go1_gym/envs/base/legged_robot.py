@@ -202,7 +202,8 @@ class LeggedRobot(BaseTask):
             cfg, num_envs=self.num_envs, seed=seed, env_id_offset=offset,
             # solver sweeps per substep = the reference's PhysX setting (num_position_iterations = 4, num_velocity_iterations
             # = 0, legged_robot_config.py:413-414); `num_solver_sweeps` overrides it
-            solver_iterations=int(getattr(cfg.sim.physx, "num_solver_sweeps", getattr(cfg.sim.physx, "num_position_iterations", 4))),
+            solver_iterations=int(getattr(H.physx_section(cfg), "num_solver_sweeps",
+                                          getattr(H.physx_section(cfg), "num_position_iterations", 4))),
             defer_curriculum_update=self._curriculum_sync)
         self.buffers = B = H.SimBuffers(self.sim_config, self.sim_meta, self.device)
         if mesh_type in ('heightfield', 'trimesh'):

@@ -92,6 +92,16 @@ def active_rewards(cfg):
     return names, scales
 
 
+def physx_section(cfg):
+    """`cfg.sim.physx` as an attribute bag: a config class normally, a plain dict after scripts/play.py has restored the
+    configuration from `parameters.pkl` (`setattr(Cfg.sim, "physx", {...})`, play.py:43-46)."""
+    px = cfg.sim.physx
+    if isinstance(px, dict):
+        import types
+        px = types.SimpleNamespace(**px)
+    return px
+
+
 def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curriculum=True,
                      solver_iterations=4, warm_start=True, defer_curriculum_update=False):
     """Flatten `cfg` (a Cfg tree) into a Go1SimConfig.  Returns (struct, meta)."""
@@ -129,7 +139,7 @@ def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curricu
         S.dof_pos_soft_lower[i] = float(m - np.float32(0.5) * r * np.float32(soft))
         S.dof_pos_soft_upper[i] = float(m + np.float32(0.5) * r * np.float32(soft))
 
-    px = cfg.sim.physx
+    px = physx_section(cfg)
     _fill(S.gravity, [0.0, 0.0, -9.8])                          # legged_robot.py:558
     S.contact_distance = 2.0 * px.contact_offset
     S.max_depenetration_velocity = px.max_depenetration_velocity
