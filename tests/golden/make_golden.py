@@ -772,6 +772,67 @@ def gen_pretrain_parameters():
     print("pretrain_parameters:", list(out), "max_episode_length", out["Cfg"]["env"]["max_episode_length"])
 
 
+def gen_traj_utils(seed=81):
+    """reference go1_gym_learn/utils/utils.py `split_and_pad_trajectories` / `unpad_trajectories` (:5-43) on a random rollout."""
+    from go1_gym_learn.utils.utils import split_and_pad_trajectories, unpad_trajectories        # the REFERENCE functions
+    g = torch.Generator().manual_seed(seed)
+    T, N, D = 24, 7, 5
+    x = torch.randn(T, N, D, generator=g)
+    dones = (torch.rand(T, N, 1, generator=g) < 0.15).to(torch.uint8)
+    dones[:, 3] = 0                                               # one environment that never ends: a full-length piece
+    padded, masks = split_and_pad_trajectories(x, dones)
+    back = unpad_trajectories(padded, masks)
+    np.savez_compressed(os.path.join(HERE, "traj_utils.npz"), x=x.numpy(), dones=dones.numpy(), padded=padded.numpy(),
+                        masks=masks.numpy(), back=back.numpy())
+    print("traj_utils: pieces", padded.shape[1], "longest", padded.shape[0])
+
+
+def gen_sum_curriculum(seed=91):
+    """reference curriculum.py `SumCurriculum` (:92-109) on random updates (the module imports standalone)."""
+    spec = importlib.util.spec_from_file_location("_ref_curriculum", os.path.join(REF, "go1_gym/envs/base/curriculum.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules.setdefault("matplotlib", types.ModuleType("matplotlib"))
+    sys.modules.setdefault("matplotlib.pyplot", types.ModuleType("matplotlib.pyplot"))
+    sys.modules["matplotlib"].pyplot = sys.modules["matplotlib.pyplot"]
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(seed)
+    c = mod.SumCurriculum(seed=3, x=(-1.0, 1.0, 5), y=(0.0, 2.0, 3), z=(0.0, 1.0, 2))
+    bins, errs = [], []
+    for _ in range(6):
+        b = rng.integers(0, len(c), 12)
+        e = rng.uniform(0, 1, 12)
+        c.update(b, e, 0.4)
+        bins.append(b)
+        errs.append(e)
+    np.savez_compressed(os.path.join(HERE, "sum_curriculum.npz"), bins=np.array(bins), errs=np.array(errs), success=c.success,
+                        trials=c.trials, rates_all=c.success_rates("x", "y", "z"), rates_x=c.success_rates("x"),
+                        rates_xz=c.success_rates("x", "z"), met=np.array([mod.is_met(2.0, 0.5, 0.3), mod.is_met(2.0, 0.7, 0.3),
+                                                                          mod.key_is_met(None, None, 10, "k", 0, 0.1)]))
+    print("sum_curriculum: trials", int(c.trials.sum()), "successes", int(c.success.sum()))
+
+
+def gen_recurrent_batches(seed=95):
+    """reference `RolloutStorage.reccurent_mini_batch_generator` (rollout_storage.py:141-180) on a random filled storage."""
+    from go1_gym_learn.ppo_cse.rollout_storage import RolloutStorage            # the REFERENCE class
+    g = torch.Generator().manual_seed(seed)
+    T, N = 12, 6
+    st = RolloutStorage(N, T, [7], [2], [21], [3], device="cpu")
+    fill = {}
+    for name in ("observations", "privileged_observations", "observation_histories", "actions", "values", "advantages", "returns",
+                 "actions_log_prob", "mu", "sigma"):
+        t = getattr(st, name)
+        t.copy_(torch.randn(t.shape, generator=g))
+        fill[name] = t.numpy().copy()
+    st.dones.copy_((torch.rand(T, N, 1, generator=g) < 0.2).to(torch.uint8))
+    fill["dones"] = st.dones.numpy().copy()
+    out = {}
+    for i, batch in enumerate(st.reccurent_mini_batch_generator(2, num_epochs=2)):
+        for j, t in enumerate(batch):
+            out[f"b{i}_{j}"] = t.numpy()
+    np.savez_compressed(os.path.join(HERE, "recurrent_batches.npz"), **{"in_" + k: v for k, v in fill.items()}, **out)
+    print("recurrent_batches:", i + 1, "batches of", len(batch), "tensors")
+
+
 def gen_callbacks(N=64, seed=51, sim_seed=999, step=200, x_offset_px=0, name="callbacks.npz"):
     """the randomising branches of `_post_physics_step_callback` that scripts/train.py leaves off (legged_robot.py:675-708):
     `_teleport_robots` :1028-1051, `_push_robots` :1017-1026, `_randomize_dof_props` :645-665 and
@@ -877,6 +938,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pretrain_parameters":  # only pretrain_parameters.json
         gen_pretrain_parameters()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "traj_utils":           # only traj_utils.npz
+        gen_traj_utils()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sum_curriculum":       # only sum_curriculum.npz
+        gen_sum_curriculum()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "recurrent_batches":    # only recurrent_batches.npz
+        gen_recurrent_batches()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gravity":              # only gravity.npz
         gen_gravity()
         sys.exit(0)
@@ -937,3 +1007,6 @@ if __name__ == "__main__":
         del sys.modules[m]
     gen_terrain_layout()
     gen_pretrain_parameters()
+    gen_traj_utils()
+    gen_sum_curriculum()
+    gen_recurrent_batches()

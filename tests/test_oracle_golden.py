@@ -102,3 +102,17 @@ def test_curriculum_matches_reference():
     ptr, idx = c.neighbourhood_csr(d["local_range"])
     for b, row in zip([0, 300, 1322], d["local"]):
         np.testing.assert_array_equal(idx[ptr[b]:ptr[b + 1]], row.nonzero()[0])
+
+
+def test_sum_curriculum_matches_reference():
+    """`SumCurriculum`, `is_met`, `key_is_met` (reference curriculum.py:6-14, 92-109; sum_curriculum.npz)"""
+    from go1_gym.envs.base.curriculum import SumCurriculum, is_met, key_is_met
+    d = np.load(os.path.join(GOLDEN, "sum_curriculum.npz"))
+    c = SumCurriculum(seed=3, x=(-1.0, 1.0, 5), y=(0.0, 2.0, 3), z=(0.0, 1.0, 2))
+    for b, e in zip(d["bins"], d["errs"]):
+        c.update(b, e, 0.4)
+    assert np.array_equal(c.success, d["success"]) and np.array_equal(c.trials, d["trials"])
+    np.testing.assert_array_equal(c.success_rates("x", "y", "z"), d["rates_all"])
+    np.testing.assert_allclose(c.success_rates("x"), d["rates_x"], rtol=1e-15)
+    np.testing.assert_allclose(c.success_rates("x", "z"), d["rates_xz"], rtol=1e-15)
+    assert [bool(is_met(2.0, 0.5, 0.3)), bool(is_met(2.0, 0.7, 0.3)), bool(key_is_met(None, None, 10, "k", 0, 0.1))] == list(d["met"])

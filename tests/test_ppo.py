@@ -249,3 +249,36 @@ def test_storage_keeps_the_observations_the_policy_acted_on(which, small_ac_args
                 logp = gaussian_log_prob(st.actions[s], mean, ac.std)
             ratio = torch.exp(logp - st.actions_log_prob[s, :, 0])
             torch.testing.assert_close(ratio, torch.ones(N), rtol=1e-5, atol=1e-5)
+
+
+def test_trajectory_helpers_match_reference():
+    """go1_gym_learn.utils against the reference's functions (traj_utils.npz; recurrent-policy helpers, unused by ppo_cse)."""
+    import os
+    import numpy as np
+    from util import GOLDEN
+    from go1_gym_learn.utils import split_and_pad_trajectories, unpad_trajectories
+    d = np.load(os.path.join(GOLDEN, "traj_utils.npz"))
+    padded, masks = split_and_pad_trajectories(torch.from_numpy(d["x"]), torch.from_numpy(d["dones"]))
+    assert np.array_equal(padded.numpy(), d["padded"]) and np.array_equal(masks.numpy(), d["masks"])
+    assert np.array_equal(unpad_trajectories(padded, masks).numpy(), d["back"]) and np.array_equal(d["back"], d["x"])
+
+
+def test_recurrent_mini_batches_match_reference():
+    """`RolloutStorage.reccurent_mini_batch_generator` against the reference class (recurrent_batches.npz; an interface the
+    feed-forward policy never uses)."""
+    import os
+    import numpy as np
+    from util import GOLDEN
+    from go1_gym_learn.ppo_cse.rollout_storage import RolloutStorage
+    d = np.load(os.path.join(GOLDEN, "recurrent_batches.npz"))
+    T, N = d["in_dones"].shape[:2]
+    st = RolloutStorage(N, T, [7], [2], [21], [3], device="cpu")
+    for name in ("observations", "privileged_observations", "observation_histories", "actions", "values", "advantages", "returns",
+                 "actions_log_prob", "mu", "sigma", "dones"):
+        getattr(st, name).copy_(torch.from_numpy(d["in_" + name]))
+    batches = list(st.reccurent_mini_batch_generator(2, num_epochs=2))
+    assert len(batches) == 4
+    for i, batch in enumerate(batches):
+        assert len(batch) == 12
+        for j, t in enumerate(batch):
+            assert np.array_equal(t.numpy(), d[f"b{i}_{j}"]), (i, j)

@@ -13,6 +13,16 @@ the kernel consumes and remains the reference-exact host implementation for test
 import numpy as np
 
 
+def is_met(scale, l2_err, threshold):
+    """reference curriculum.py:6-7"""
+    return (l2_err / scale) < threshold
+
+
+def key_is_met(metric_cache, config, ep_len, target_key, env_id, threshold):
+    """reference curriculum.py:10-14: a stub there as well (scale 1, error 0: always met for a positive threshold)"""
+    return is_met(1, 0, threshold)
+
+
 class Curriculum:
     def __init__(self, seed, **key_ranges):
         self.rng = np.random.RandomState(seed)
@@ -35,6 +45,9 @@ class Curriculum:
 
     def __len__(self):
         return self._l
+
+    def __getitem__(self, *keys):
+        pass                                           # (a stub in the reference too, curriculum.py:61-62)
 
     def set_to(self, low, high, value=1.0):
         inside = np.logical_and(self.grid >= low[:, None], self.grid <= high[:, None]).all(axis=0)
@@ -59,6 +72,27 @@ class Curriculum:
 
     def update(self, **kwargs):
         pass
+
+
+class SumCurriculum(Curriculum):
+    """Success / trial counts per bin (reference curriculum.py:92-109; not used by scripts/train.py, whose
+    `curriculum_type` is RewardThresholdCurriculum)."""
+
+    def __init__(self, seed, **kwargs):
+        super().__init__(seed, **kwargs)
+        self.success = np.zeros(len(self))
+        self.trials = np.zeros(len(self))
+
+    def update(self, bin_inds, l1_error, threshold):
+        ok = l1_error < threshold
+        self.success[bin_inds[ok]] += 1                # (fancy-index +=: a bin listed twice counts once, as in the reference)
+        self.trials[bin_inds] += 1
+
+    def success_rates(self, *keys):
+        """success rate per bin on the N-d grid, averaged over the axes whose key is not named (all axes kept if none is left out)"""
+        rate = (self.success / (self.trials + 1e-6)).reshape(list(self.ls.values()))
+        drop = tuple(i for i, k in enumerate(self.keys) if k not in keys)
+        return rate.mean(axis=drop) if drop else rate
 
 
 class RewardThresholdCurriculum(Curriculum):

@@ -128,27 +128,30 @@ class Terrain:
         self.type = cfg.mesh_type
         if self.type in ("none", "plane"):
             return
+        self.train_rows, self.train_cols, self.eval_rows, self.eval_cols = self.load_cfgs()
+        self.tot_rows = len(self.train_rows) + len(self.eval_rows)
+        self.tot_cols = max(len(self.train_cols), len(self.eval_cols))
+        cfg.env_length, cfg.env_width = cfg.terrain_length, cfg.terrain_width
+        self.height_field_raw = np.zeros((self.tot_rows, self.tot_cols), dtype=np.int16)
+        self.initialize_terrains()
+        self.heightsamples = self.height_field_raw
+
+    def load_cfgs(self):
+        """grid sizes of both regions and where the evaluation one starts (reference :37-54)"""
+        cfg, eval_cfg = self.cfg, self.eval_cfg
         self._load_cfg(cfg)
         cfg.row_indices = np.arange(0, cfg.tot_rows)
         cfg.col_indices = np.arange(0, cfg.tot_cols)
         cfg.x_offset = 0
         cfg.rows_offset = 0
-        self.train_rows, self.train_cols, self.eval_rows, self.eval_cols = cfg.row_indices, cfg.col_indices, [], []
-        if eval_cfg is not None:
-            self._load_cfg(eval_cfg)
-            eval_cfg.row_indices = np.arange(cfg.tot_rows, cfg.tot_rows + eval_cfg.tot_rows)
-            eval_cfg.col_indices = np.arange(0, eval_cfg.tot_cols)
-            eval_cfg.x_offset = cfg.tot_rows
-            eval_cfg.rows_offset = cfg.num_rows
-            self.eval_rows, self.eval_cols = eval_cfg.row_indices, eval_cfg.col_indices
-        self.tot_rows = len(self.train_rows) + len(self.eval_rows)
-        self.tot_cols = max(len(self.train_cols), len(self.eval_cols))
-        cfg.env_length, cfg.env_width = cfg.terrain_length, cfg.terrain_width
-        self.height_field_raw = np.zeros((self.tot_rows, self.tot_cols), dtype=np.int16)
-        self._populate(cfg)
-        if eval_cfg is not None:
-            self._populate(eval_cfg)
-        self.heightsamples = self.height_field_raw
+        if eval_cfg is None:
+            return cfg.row_indices, cfg.col_indices, [], []
+        self._load_cfg(eval_cfg)
+        eval_cfg.row_indices = np.arange(cfg.tot_rows, cfg.tot_rows + eval_cfg.tot_rows)
+        eval_cfg.col_indices = np.arange(0, eval_cfg.tot_cols)
+        eval_cfg.x_offset = cfg.tot_rows
+        eval_cfg.rows_offset = cfg.num_rows
+        return cfg.row_indices, cfg.col_indices, eval_cfg.row_indices, eval_cfg.col_indices
 
     @staticmethod
     def _load_cfg(cfg):
@@ -161,27 +164,45 @@ class Terrain:
         cfg.tot_cols = int(cfg.num_cols * cfg.width_per_env_pixels) + 2 * cfg.border
         cfg.tot_rows = int(cfg.num_rows * cfg.length_per_env_pixels) + 2 * cfg.border
 
-    def _populate(self, cfg):
-        if cfg.selected:
-            kind = cfg.terrain_kwargs.pop('type')
-            gen = {f.__name__: f for f in (random_uniform_terrain, pyramid_sloped_terrain, pyramid_stairs_terrain,
-                                           discrete_obstacles_terrain, stepping_stones_terrain)}[kind.split(".")[-1]]
-            for k in range(cfg.num_sub_terrains):
-                i, j = k // cfg.num_cols, k % cfg.num_cols
-                tile = self._blank(cfg)
-                gen(tile, **cfg.terrain_kwargs.terrain_kwargs)
-                self.add_terrain_to_map(cfg, tile, i, j)
-        elif cfg.curriculum:       # reference :81-89: difficulty grows with the row, type with the column
-            for j in range(cfg.num_cols):
-                for i in range(cfg.num_rows):
-                    self.add_terrain_to_map(cfg, self.make_terrain(cfg, j / cfg.num_cols + 0.001, i / cfg.num_rows * cfg.difficulty_scale,
-                                                                   cfg.proportions), i, j)
-        else:                      # reference :71-79
-            for k in range(cfg.num_sub_terrains):
-                i, j = k // cfg.num_cols, k % cfg.num_cols
-                choice = np.random.uniform(0, 1)
-                difficulty = np.random.choice([0.5, 0.75, 0.9])
-                self.add_terrain_to_map(cfg, self.make_terrain(cfg, choice, difficulty, cfg.proportions), i, j)
+    def initialize_terrains(self):
+        self._initialize_terrain(self.cfg)
+        if self.eval_cfg is not None:
+            self._initialize_terrain(self.eval_cfg)
+
+    def _initialize_terrain(self, cfg):
+        """reference :68-74: curriculum beats `selected` beats randomised"""
+        if cfg.curriculum:
+            self.curriculum(cfg)
+        elif cfg.selected:
+            self.selected_terrain(cfg)
+        else:
+            self.randomized_terrain(cfg)
+
+    def randomized_terrain(self, cfg):
+        """reference :76-85: a random type and one of three difficulties per tile"""
+        for k in range(cfg.num_sub_terrains):
+            i, j = k // cfg.num_cols, k % cfg.num_cols
+            choice = np.random.uniform(0, 1)
+            difficulty = np.random.choice([0.5, 0.75, 0.9])
+            self.add_terrain_to_map(cfg, self.make_terrain(cfg, choice, difficulty, cfg.proportions), i, j)
+
+    def curriculum(self, cfg):
+        """reference :87-95: difficulty grows with the row, the type follows the column"""
+        for j in range(cfg.num_cols):
+            for i in range(cfg.num_rows):
+                self.add_terrain_to_map(cfg, self.make_terrain(cfg, j / cfg.num_cols + 0.001, i / cfg.num_rows * cfg.difficulty_scale,
+                                                               cfg.proportions), i, j)
+
+    def selected_terrain(self, cfg):
+        """reference :97-112: one named generator with `terrain_kwargs` on every tile"""
+        kind = cfg.terrain_kwargs.pop('type')
+        gen = {f.__name__: f for f in (random_uniform_terrain, pyramid_sloped_terrain, pyramid_stairs_terrain,
+                                       discrete_obstacles_terrain, stepping_stones_terrain)}[kind.split(".")[-1]]
+        for k in range(cfg.num_sub_terrains):
+            i, j = k // cfg.num_cols, k % cfg.num_cols
+            tile = self._blank(cfg)
+            gen(tile, **cfg.terrain_kwargs.terrain_kwargs)
+            self.add_terrain_to_map(cfg, tile, i, j)
 
     @staticmethod
     def _blank(cfg):

@@ -16,6 +16,17 @@ from .actor_critic import ActorCritic
 from .rollout_storage import RolloutStorage
 
 
+def class_to_dict(obj) -> dict:
+    """nested plain-dict view of a params_proto-style class tree: public attributes, `terrain` skipped (reference :14-29)"""
+    if not hasattr(obj, "__dict__"):
+        return obj
+    view = {}
+    for key in (k for k in dir(obj) if not k.startswith("_") and k != "terrain"):
+        val = getattr(obj, key)
+        view[key] = [class_to_dict(v) for v in val] if isinstance(val, list) else class_to_dict(val)
+    return view
+
+
 class DataCaches:
     def __init__(self, curriculum_bins):
         from go1_gym_learn.ppo.metrics_caches import DistCache, SlotCache

@@ -58,6 +58,14 @@ class ActorCritic(nn.Module):
         self.distribution = None
         Normal.set_default_validate_args = False
 
+    @staticmethod
+    def init_weights(sequential, scales):
+        """orthogonal initialisation of the Linear layers of `sequential`, gain scales[i] for the i-th (reference
+        actor_critic.py:89-93, unused there as well)"""
+        linears = [m for m in sequential if isinstance(m, nn.Linear)]
+        for layer, gain in zip(linears, scales):
+            torch.nn.init.orthogonal_(layer.weight, gain=gain)
+
     # -- fused path used by PPO on MI355X ------------------------------------------------------------
     @staticmethod
     def _side(y, z, Wz, b):

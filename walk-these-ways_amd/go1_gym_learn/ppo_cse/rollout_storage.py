@@ -156,3 +156,27 @@ class RolloutStorage:
                 idx = indices[i * mini_batch_size:(i + 1) * mini_batch_size]
                 yield (observations[idx], observations[idx], privileged_obs[idx], obs_history[idx], actions[idx], values[idx],
                        advantages[idx], returns[idx], old_log_prob[idx], old_mu[idx], old_sigma[idx], None, old_bins[idx])
+
+    def reccurent_mini_batch_generator(self, num_mini_batches, num_epochs=8):
+        """Mini-batches of whole trajectories for a recurrent policy (reference rollout_storage.py:141-180; name as spelt
+        there).  The feed-forward ppo_cse policy never asks for it: kept for the storage's interface, block storage only."""
+        from go1_gym_learn.utils import split_and_pad_trajectories
+        assert not self.ring, "ring storage holds no per-step history rows"
+        K = self.history_width
+        obs_traj, masks = split_and_pad_trajectories(self.observations, self.dones)
+        priv_traj, _ = split_and_pad_trajectories(self.privileged_observations, self.dones)
+        hist_traj, _ = split_and_pad_trajectories(self.observation_histories[..., :K].float(), self.dones)
+        per_batch = self.num_envs // num_mini_batches
+        dones = self.dones.squeeze(-1).bool()
+        starts_here = torch.ones_like(dones)                    # a trajectory starts at t = 0 and after every done
+        starts_here[1:] = dones[:-1]
+        for _ in range(num_epochs):
+            first = 0
+            for i in range(num_mini_batches):
+                env = slice(i * per_batch, (i + 1) * per_batch)
+                last = first + int(starts_here[:, env].sum())
+                traj = slice(first, last)
+                yield (obs_traj[:, traj], obs_traj[:, traj], priv_traj[:, traj], hist_traj[:, traj], self.actions[:, env],
+                       self.values[:, env], self.advantages[:, env], self.returns[:, env], self.actions_log_prob[:, env],
+                       self.mu[:, env], self.sigma[:, env], masks[:, traj])
+                first = last
