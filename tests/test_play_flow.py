@@ -137,3 +137,37 @@ def test_derived_configuration_and_play_loop(monkeypatch):
     # the written commands are what the observation carries (scaled, legged_robot.py:325): they were not resampled away
     assert float(obs["obs"][0, 3]) == pytest.approx(1.5 * Cfg.obs_scales.lin_vel) and bool(torch.isfinite(obs["obs_history"]).all())
     assert float(obs["obs"][0, 3 + 4]) == pytest.approx(3.0 * Cfg.obs_scales.gait_freq_cmd)
+
+
+def test_gravity_attributes_follow_the_simulators_schedule(monkeypatch):
+    """`env.gravities` / `env.gravity_vec` (reference legged_robot.py:549-559) are evaluated on the host from (seed, step counter);
+    the projected gravity the simulator returns for step k was rotated from the vector in force DURING that step (:104 precedes
+    the callback that may change it, :701-705)."""
+    import fake_sim
+    import go1sim_host as H
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+    from go1_gym.utils.math_utils import quat_rotate_inverse
+    from scripts.train_config import apply_train_config
+    fake_sim.install(monkeypatch)
+    cfg = apply_train_config(make_cfg(), num_envs=16)
+    cfg.terrain.mesh_type = "plane"
+    cfg.domain_rand.gravity_rand_interval_s, cfg.domain_rand.gravity_impulse_duration = 0.06, 0.67      # 3 steps: 2 on, 1 off
+    env = VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg)
+    S = env.sim_config
+    assert S.gravity_rand_duration < S.gravity_rand_interval <= 4
+    env.reset()                                                    # (reset_idx of everything + one zero-action step, :241-246)
+    k0 = env.common_step_counter
+    seen_on = seen_off = 0
+    for k in range(k0 + 1, k0 + 10):
+        env.step(torch.zeros(16, 12))
+        assert env.common_step_counter == k and env.gravities.shape == (16, 3) and env.gravity_vec.shape == (16, 3)
+        during = torch.from_numpy(H.gravity_at(S, k - 1))
+        want = quat_rotate_inverse(env.base_quat, (during / during.norm()).repeat(16, 1))
+        keep = ~env.reset_buf.bool()                               # (a reset environment reports its re-initialised state)
+        assert int(keep.sum()) >= 12 and float((env.projected_gravity - want)[keep].abs().max()) < 2e-5
+        off = float(env.gravities.abs().max())
+        seen_on += off > 0
+        seen_off += off == 0
+        assert float((env.gravity_vec.norm(dim=1) - 1).abs().max()) < 1e-6
+    assert seen_on >= 3 and seen_off >= 1 and env.default_body_mass == pytest.approx(4.801)

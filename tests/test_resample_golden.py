@@ -262,3 +262,19 @@ def test_oracle_gravity_schedule_matches_reference(oracle_lib):
     assert quiet.sum() == 3 * (int(d["interval"]) - int(d["duration"])) and (got[quiet] == np.array([0.0, 0.0, -9.8], np.float32).astype(np.float64)).all()
     unit = got / np.linalg.norm(got, axis=1, keepdims=True)                  # gravity_vec (:559), what projected_gravity rotates
     np.testing.assert_allclose(unit, d["gravity_vec"], atol=1e-6)
+
+
+def test_host_gravity_schedule_matches_reference_and_oracle(oracle_lib):
+    """`go1sim_host.gravity_at` (what `env.gravities` / `env.gravity_vec` report) against the reference's schedule (gravity.npz)
+    and against the oracle under a second seed and range."""
+    import os
+    import numpy as np
+    from util import GOLDEN, make_sim
+    d = np.load(os.path.join(GOLDEN, "gravity.npz"))
+    cfg, S, meta, B = make_sim("dr", 16, seed=int(d["sim_seed"]))
+    got = np.stack([H.gravity_at(S, t) for t in range(len(d["gravity"]))])
+    np.testing.assert_allclose(got, d["gravity"], rtol=0, atol=2e-6)
+    cfg, S, meta, B = make_sim("dr", 16, seed=(7 << 32) + 12345, extra={"domain_rand": dict(gravity_range=[-2.0, 0.5])})
+    orc = oracle_lib.Oracle(S, B)
+    for t in (0, 1, 396, 397, 400, 401, 802, 5000, 123456):
+        np.testing.assert_allclose(H.gravity_at(S, t), orc.gravity_at(t), rtol=0, atol=2e-6)

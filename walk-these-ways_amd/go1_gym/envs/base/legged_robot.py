@@ -364,6 +364,15 @@ class LeggedRobot(BaseTask):
         self.last_joint_pos_target = B.last_joint_pos_target.t()
         self.last_last_joint_pos_target = B.last_last_joint_pos_target.t()
         self.last_dof_vel = B.last_dof_vel.t()
+        # what the actuator network carries from substep to substep (reference :1226-1231)
+        self.joint_pos_err_last = B.joint_pos_err_last.t()
+        self.joint_pos_err_last_last = B.joint_pos_err_last_last.t()
+        self.joint_vel_last = B.joint_vel_last.t()
+        self.joint_vel_last_last = B.joint_vel_last_last.t()
+        self.p_gains = torch.full((12,), float(S.kp), device=self.device)                 # :1206-1222 (one gain for every joint)
+        self.d_gains = torch.full((12,), float(S.kd), device=self.device)
+        self.base_init_state = torch.tensor(list(S.base_init_state), device=self.device)  # :1590-1594
+        self.forward_vec = torch.tensor([1.0, 0.0, 0.0], device=self.device).repeat(N, 1)
         self.commands = B.commands.t()[:, :self.cfg.commands.num_commands]
         self.gait_indices = B.gait_indices
         self.clock_inputs = B.clock_inputs.t()
@@ -415,6 +424,21 @@ class LeggedRobot(BaseTask):
             self.sim.curriculum_update()
         self.common_step_counter += 1
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    # gravity is a function of (seed, step counter) that kernels and host evaluate alike: no device buffer, no read-back
+    @property
+    def gravities(self):
+        """(N, 3) offset of the gravity vector from (0, 0, -9.8) now in force (reference `self.gravities`, :549-555)"""
+        g = torch.from_numpy(H.gravity_at(self.sim_config, self.common_step_counter) - np.array([0.0, 0.0, -9.8], np.float32))
+        return g.to(self.device).unsqueeze(0).repeat(self.num_envs, 1)
+
+    @property
+    def gravity_vec(self):
+        """(N, 3) unit vector along the gravity now in force (reference `self.gravity_vec`, :559)"""
+        g = torch.from_numpy(H.gravity_at(self.sim_config, self.common_step_counter))
+        return (g / g.norm()).to(self.device).unsqueeze(0).repeat(self.num_envs, 1)
+
+    default_body_mass = 4.801          # base link after the fixed-joint collapse (trunk + imu; csrc/go1_model_data.h GO1_BODY_MASS[0])
 
     def reset_idx(self, env_ids):
         """reference legged_robot.py:150-239."""

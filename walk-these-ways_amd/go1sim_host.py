@@ -453,6 +453,35 @@ EVAL_CFG_FIELDS = ("randomize_motor_strength", "randomize_motor_offset", "random
                    "x_init_range", "y_init_range", "yaw_init_range", "x_init_offset", "y_init_offset")
 
 
+def _philox4x32_10(ctr, key):
+    """Philox-4x32-10 (Random123) — the generator of the kernels (csrc/go1_math.h), for the few values the host derives itself."""
+    M0, M1, W0, W1, mask = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
+    c, k = [int(x) & mask for x in ctr], [int(x) & mask for x in key]
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & mask, (p0 >> 32) ^ c[3] ^ k[1], p0 & mask]
+        k = [(k[0] + W0) & mask, (k[1] + W1) & mask]
+    return c
+
+
+def gravity_at(S, t):
+    """Gravity vector in force once `t` policy steps have been taken (= during step t + 1): the nominal vector plus, for
+    `gravity_rand_duration` steps out of every `gravity_rand_interval`, one offset drawn for ALL environments from
+    U(gravity_range)^3 (reference `_randomize_gravity` legged_robot.py:546-561 on the cadence of :701-705; the kernels evaluate
+    the same function of (seed, epoch), csrc/go1_maps.h `gravity_at`, so nothing has to be read back)."""
+    g = np.array([S.gravity[0], S.gravity[1], S.gravity[2]], dtype=np.float32)
+    if not S.randomize_gravity:
+        return g
+    epoch, phase = divmod(int(t), int(S.gravity_rand_interval))
+    if phase >= int(S.gravity_rand_duration):
+        return g
+    seed = int(S.seed) & 0xFFFFFFFFFFFFFFFF
+    word = _philox4x32_10((0xFFFFFFFF, epoch, 8, 0), (seed & 0xFFFFFFFF, seed >> 32))      # purpose 8 = gravity, columns 0..2
+    lo, hi = np.float32(S.gravity_range[0]), np.float32(S.gravity_range[1])
+    u = np.array([np.float32(w >> 8) * np.float32(1.0 / 16777216.0) for w in word[:3]], dtype=np.float32)
+    return g + (u * (hi - lo) + lo)
+
+
 def make_eval_sim_config(S_train, S_from_eval_cfg):
     """Go1SimConfig of the evaluation environments: the train block with the group-dispatched fields of `eval_cfg`
     (S_from_eval_cfg = build_sim_config(eval_cfg, ...))."""

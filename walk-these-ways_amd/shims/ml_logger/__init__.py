@@ -24,6 +24,10 @@ class _Logger:
         self.root = str(root) if root is not None else os.path.abspath("runs")
         self.prefix = prefix or "."
         os.makedirs(self._path(""), exist_ok=True)
+        # a new run: nothing of the previous one (pending metrics, `every` phases, timers) carries over
+        self._metrics.clear()
+        self._counters.clear()
+        self._timers.clear()
 
     def utcnow(self, fmt="%Y-%m-%d/%H%M%S.%f"):
         return datetime.datetime.utcnow().strftime(fmt)
