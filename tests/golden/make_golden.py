@@ -833,6 +833,42 @@ def gen_recurrent_batches(seed=95):
     print("recurrent_batches:", i + 1, "batches of", len(batch), "tensors")
 
 
+def gen_cfg_defaults():
+    """every default of the reference's configuration classes — `Cfg` as declared (legged_robot_config.py), `Cfg` after
+    `config_go1` (go1_config.py), and the `AC_Args` / `PPO_Args` / `RunnerArgs` of both learners — as one JSON tree."""
+    import inspect
+    import json
+    from go1_gym.envs.base.legged_robot_config import Cfg                      # the REFERENCE classes
+    from go1_gym.envs.go1.go1_config import config_go1
+
+    def tree(node):
+        out = {}
+        for k in dir(node):
+            if k.startswith("_"):
+                continue
+            v = getattr(node, k)
+            if inspect.isclass(v):
+                out[k] = tree(v)
+            elif callable(v):
+                continue
+            elif isinstance(v, tuple):
+                out[k] = list(v)
+            else:
+                out[k] = v
+        return out
+    res = {"Cfg": tree(Cfg)}
+    config_go1(Cfg)
+    res["Cfg_go1"] = tree(Cfg)
+    for pkg in ("ppo", "ppo_cse"):
+        ac = importlib.import_module(f"go1_gym_learn.{pkg}.actor_critic")
+        pp = importlib.import_module(f"go1_gym_learn.{pkg}.ppo")
+        rn = importlib.import_module(f"go1_gym_learn.{pkg}")
+        res[pkg] = {"AC_Args": tree(ac.AC_Args), "PPO_Args": tree(pp.PPO_Args), "RunnerArgs": tree(rn.RunnerArgs)}
+    with open(os.path.join(HERE, "cfg_defaults.json"), "w") as f:
+        json.dump(res, f, indent=0, sort_keys=True)
+    print("cfg_defaults: sections", len(res["Cfg"]), "leaves", sum(len(v) if isinstance(v, dict) else 1 for v in res["Cfg"].values()))
+
+
 def gen_callbacks(N=64, seed=51, sim_seed=999, step=200, x_offset_px=0, name="callbacks.npz"):
     """the randomising branches of `_post_physics_step_callback` that scripts/train.py leaves off (legged_robot.py:675-708):
     `_teleport_robots` :1028-1051, `_push_robots` :1017-1026, `_randomize_dof_props` :645-665 and
@@ -947,6 +983,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "recurrent_batches":    # only recurrent_batches.npz
         gen_recurrent_batches()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg_defaults":         # only cfg_defaults.json
+        gen_cfg_defaults()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gravity":              # only gravity.npz
         gen_gravity()
         sys.exit(0)
@@ -1010,3 +1049,6 @@ if __name__ == "__main__":
     gen_traj_utils()
     gen_sum_curriculum()
     gen_recurrent_batches()
+    for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+        del sys.modules[m]
+    gen_cfg_defaults()

@@ -185,3 +185,60 @@ def test_every_reference_module_path_on_the_hot_path_resolves():
         m = importlib.import_module(mod)
         for n in names:
             assert hasattr(m, n), (mod, n)
+
+
+def _tree(node):
+    import inspect
+    out = {}
+    for k in dir(node):
+        if k.startswith("_"):
+            continue
+        v = getattr(node, k)
+        if inspect.isclass(v):
+            out[k] = _tree(v)
+        elif callable(v):
+            continue
+        else:
+            out[k] = list(v) if isinstance(v, tuple) else v
+    return out
+
+
+def _tree_diff(mine, ref, path=""):
+    out = []
+    for k in sorted(set(mine) | set(ref)):
+        if k not in mine:
+            out.append((path + k, "<absent>", ref[k]))
+        elif k not in ref:
+            out.append((path + k, mine[k], "<absent>"))
+        elif isinstance(mine[k], dict) and isinstance(ref[k], dict):
+            out += _tree_diff(mine[k], ref[k], path + k + ".")
+        elif mine[k] != ref[k]:
+            out.append((path + k, mine[k], ref[k]))
+    return out
+
+
+def test_every_configuration_default_equals_the_reference():
+    """`Cfg` as declared, `Cfg` after `config_go1`, and AC_Args / PPO_Args / RunnerArgs of both learners, leaf by leaf against
+    the reference's classes (cfg_defaults.json).  Allowed: keys this repo ADDS (MI355X options, all inert by default)."""
+    import importlib
+    import json
+    import os
+    from util import GOLDEN
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from go1_gym.envs.go1.go1_config import config_go1
+    with open(os.path.join(GOLDEN, "cfg_defaults.json")) as f:
+        ref = json.load(f)
+    cfg = make_cfg()
+    diffs = {"Cfg": _tree_diff(_tree(cfg), ref["Cfg"])}
+    config_go1(cfg)
+    diffs["Cfg_go1"] = _tree_diff(_tree(cfg), ref["Cfg_go1"])
+    for pkg in ("ppo", "ppo_cse"):
+        ac = importlib.import_module(f"go1_gym_learn.{pkg}.actor_critic")
+        pp = importlib.import_module(f"go1_gym_learn.{pkg}.ppo")
+        rn = importlib.import_module(f"go1_gym_learn.{pkg}")
+        for name, cls in (("AC_Args", ac.AC_Args), ("PPO_Args", pp.PPO_Args), ("RunnerArgs", rn.RunnerArgs)):
+            diffs[f"{pkg}.{name}"] = _tree_diff(_tree(cls), ref[pkg][name])
+    wrong = {k: [d for d in v if d[2] != "<absent>"] for k, v in diffs.items()}          # a value that differs or a key we lack
+    assert not any(wrong.values()), wrong
+    added = sorted({d[0] for v in diffs.values() for d in v if d[2] == "<absent>"})
+    print("keys added by this repo:", added)
