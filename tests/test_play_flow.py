@@ -171,3 +171,45 @@ def test_gravity_attributes_follow_the_simulators_schedule(monkeypatch):
         seen_off += off == 0
         assert float((env.gravity_vec.norm(dim=1) - 1).abs().max()) < 1e-6
     assert seen_on >= 3 and seen_off >= 1 and env.default_body_mass == pytest.approx(4.801)
+
+
+def test_state_writes_are_the_push(monkeypatch):
+    """Ownership / aliasing of SURVEY 8b: `root_states`, `dof_pos`, `commands` are the simulator's own state — a write
+    (`set_idx_pose`, `set_main_agent_pose`, direct indexing; reference legged_robot.py:241-261, 525-528) is what the next step
+    starts from; `reset_idx` of nothing is a no-op and of a subset touches only that subset (:150-153)."""
+    import fake_sim
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+    from scripts.train_config import apply_train_config
+    fake_sim.install(monkeypatch)
+    cfg = apply_train_config(make_cfg(), num_envs=16)
+    cfg.terrain.mesh_type = "plane"
+    cfg.domain_rand.randomize_gravity = False
+    cfg.commands.resampling_time = 1000.0
+    env = VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg)
+    env.reset()
+    for _ in range(3):
+        env.step(torch.zeros(16, 12))
+    ids = torch.tensor([3, 9, 0])
+    pose = env.default_dof_pos.repeat(3, 1)
+    base = torch.zeros(3, 13)
+    base[:, 2], base[:, 6] = 1.0, 1.0                 # 1 m up, identity quaternion, at rest
+    base[:, 0:2] = env.root_states[ids, 0:2]
+    env.set_idx_pose(ids, pose, base)
+    env.set_main_agent_pose([0.5, -0.5, 2.0], [0.0, 0.0, 0.0, 1.0])
+    env.root_states[0, 7:13] = 0.0
+    env.commands[:, 0] = 0.7
+    before_len = env.episode_length_buf.clone()
+    env.step(torch.zeros(16, 12))
+    h = 0.02
+    for i, z0 in ((3, 1.0), (9, 1.0), (0, 2.0)):      # free fall for one policy step (4 substeps, semi-implicit Euler)
+        assert float(env.root_states[i, 2]) == pytest.approx(z0 - 0.5 * 9.8 * h * h * (1 + 1 / 4), abs=2e-3), i
+        assert float(env.root_states[i, 9]) == pytest.approx(-9.8 * h, abs=0.02)      # (base origin, not COM: the legs are moving)
+    assert float(env.root_states[0, 0]) == pytest.approx(0.5, abs=1e-3) and float(env.root_states[0, 1]) == pytest.approx(-0.5, abs=1e-3)
+    assert float((env.dof_pos[ids] - pose).abs().max()) < 0.05          # (held at the written pose by the actuators)
+    assert float(env.obs_buf[5, 3]) == pytest.approx(0.7 * cfg.obs_scales.lin_vel)
+    assert bool((env.episode_length_buf == before_len + 1).all())
+    env.reset_idx(torch.tensor([], dtype=torch.long))
+    assert bool((env.episode_length_buf == before_len + 1).all())
+    env.reset_idx(torch.tensor([4, 11]))
+    assert [int(v) for v in env.episode_length_buf[[4, 11]]] == [0, 0] and int((env.episode_length_buf == 0).sum()) == 2
