@@ -869,6 +869,77 @@ def gen_cfg_defaults():
     print("cfg_defaults: sections", len(res["Cfg"]), "leaves", sum(len(v) if isinstance(v, dict) else 1 for v in res["Cfg"].values()))
 
 
+HISTORY_SCRIPT = ["reset", "get_observations", "step", "step", "get_observations", "step", "step", "step", "step", "step", "step",
+                  "get_observations", "reset", "step", "step"]           # (`reset_idx` of the wrapper cannot run: gym.Wrapper has none)
+
+
+def gen_history_trace():
+    """reference `HistoryWrapper` (history_wrapper.py:6-41) driven through HISTORY_SCRIPT over a mock environment whose k-th
+    observation is the constant k: which observation sits in which history slot after every call (0 = still empty) — the
+    extra shift of `get_observations` (:29), the zeroing of `reset` / `reset_idx` (:32-41)."""
+    import json
+
+    class Wrapper:                                                 # gym.Wrapper's two behaviours the class relies on
+        def __init__(self, env):
+            self.env = env
+
+        def __getattr__(self, name):
+            return getattr(self.__dict__["env"], name)
+
+        def step(self, action):
+            return self.env.step(action)
+
+        def reset(self, **kwargs):
+            return self.env.reset(**kwargs)
+    sys.modules["gym"].Wrapper = Wrapper
+    mod = load_private("_ref_history_wrapper", os.path.join(REF, "go1_gym/envs/wrappers/history_wrapper.py"))
+
+    class Env:
+        num_envs, num_obs, num_privileged_obs, device = 2, 3, 2, "cpu"
+
+        def __init__(self):
+            self.cfg = Mock()
+            self.cfg.env = Mock()
+            self.cfg.env.num_observation_history = 4
+            self.k = 0
+            self.obs_buf = torch.zeros(2, 3)
+
+        def _new(self):
+            self.k += 1
+            self.obs_buf = torch.full((2, 3), float(self.k))
+            return self.obs_buf
+
+        def step(self, action):
+            return self._new(), torch.zeros(2), torch.zeros(2), {"privileged_obs": torch.zeros(2, 2)}
+
+        def reset(self):
+            return self._new()
+
+        def reset_idx(self, env_ids):
+            return None
+
+        def get_observations(self):
+            return self.obs_buf
+
+        def get_privileged_observations(self):
+            return torch.zeros(2, 2)
+    w = mod.HistoryWrapper(Env())
+    trace = []
+    for call in HISTORY_SCRIPT:
+        if call == "reset":
+            out = w.reset()
+        elif call == "get_observations":
+            out = w.get_observations()
+        elif call == "step":
+            out = w.step(torch.zeros(2, 12))[0]
+        h = out["obs_history"].reshape(2, 4, 3)
+        assert bool((h == h[..., :1]).all())
+        trace.append(h[..., 0].to(torch.int64).tolist())
+    with open(os.path.join(HERE, "history_trace.json"), "w") as f:
+        json.dump({"script": HISTORY_SCRIPT, "trace": trace}, f)
+    print("history_trace:", trace[-1])
+
+
 def gen_callbacks(N=64, seed=51, sim_seed=999, step=200, x_offset_px=0, name="callbacks.npz"):
     """the randomising branches of `_post_physics_step_callback` that scripts/train.py leaves off (legged_robot.py:675-708):
     `_teleport_robots` :1028-1051, `_push_robots` :1017-1026, `_randomize_dof_props` :645-665 and
@@ -986,6 +1057,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cfg_defaults":         # only cfg_defaults.json
         gen_cfg_defaults()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "history_trace":        # only history_trace.json
+        gen_history_trace()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gravity":              # only gravity.npz
         gen_gravity()
         sys.exit(0)
@@ -1052,3 +1126,4 @@ if __name__ == "__main__":
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     gen_cfg_defaults()
+    gen_history_trace()

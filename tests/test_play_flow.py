@@ -213,3 +213,38 @@ def test_state_writes_are_the_push(monkeypatch):
     assert bool((env.episode_length_buf == before_len + 1).all())
     env.reset_idx(torch.tensor([4, 11]))
     assert [int(v) for v in env.episode_length_buf[[4, 11]]] == [0, 0] and int((env.episode_length_buf == 0).sum()) == 2
+
+
+def test_history_wrapper_slots_match_reference(monkeypatch):
+    """which observation sits in which history slot after every call, against the reference `HistoryWrapper` driven through the
+    same call script over a mock environment (history_trace.json): oldest first, the extra shift of `get_observations`
+    (history_wrapper.py:29), everything cleared by `reset` (:40).  Here the history is a window of the ring the simulator
+    appends to, not a concatenation."""
+    import fake_sim
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+    from go1_gym.envs.wrappers.history_wrapper import HistoryWrapper
+    from scripts.train_config import apply_train_config
+    with open(os.path.join(GOLDEN, "history_trace.json")) as f:
+        ref = json.load(f)
+    fake_sim.install(monkeypatch)
+    cfg = apply_train_config(make_cfg(), num_envs=16)
+    cfg.terrain.mesh_type = "plane"
+    cfg.env.num_observation_history = H = 4
+    env = HistoryWrapper(VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg))
+    no = env.num_obs
+    seen = [torch.zeros(16, no)]                       # observation k of the run (0 = an empty slot)
+    g = torch.Generator().manual_seed(0)
+    for call, want in zip(ref["script"], ref["trace"]):
+        if call == "reset":
+            out = env.reset()
+            seen.append(out["obs"].clone())
+        elif call == "step":
+            out = env.step(torch.randn(16, 12, generator=g))[0]
+            seen.append(out["obs"].clone())
+        else:
+            out = env.get_observations()
+            assert torch.equal(out["obs"], seen[-1])
+        hist = out["obs_history"].reshape(16, H, no)
+        for slot, k in enumerate(want[0]):
+            assert torch.equal(hist[:, slot], seen[k]), (call, slot, k)
