@@ -248,3 +248,31 @@ def test_history_wrapper_slots_match_reference(monkeypatch):
         hist = out["obs_history"].reshape(16, H, no)
         for slot, k in enumerate(want[0]):
             assert torch.equal(hist[:, slot], seen[k]), (call, slot, k)
+
+
+def test_step_extras_carry_the_reference_keys_and_values(monkeypatch):
+    """`VelocityTrackingEasyEnv.step` (velocity_tracking/__init__.py:22-44): the thirteen entries it adds to `extras`, each equal
+    to the expression the reference builds it from (numpy on the host, read lazily here), and the 4-tuple it returns."""
+    import fake_sim
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+    from scripts.train_config import apply_train_config
+    fake_sim.install(monkeypatch)
+    cfg = apply_train_config(make_cfg(), num_envs=16)
+    cfg.terrain.mesh_type = "plane"
+    env = VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg)
+    env.reset()
+    ret = env.step(0.3 * torch.randn(16, 12, generator=torch.Generator().manual_seed(1)))
+    assert len(ret) == 4 and ret[0] is env.obs_buf and ret[1] is env.rew_buf and ret[2] is env.reset_buf
+    ex = ret[3]
+    want = {"joint_pos": env.dof_pos, "joint_vel": env.dof_vel, "joint_pos_target": env.joint_pos_target,
+            "body_linear_vel": env.base_lin_vel, "body_angular_vel": env.base_ang_vel, "body_linear_vel_cmd": env.commands[:, 0:2],
+            "body_angular_vel_cmd": env.commands[:, 2:], "contact_states": env.contact_forces[:, env.feet_indices, 2] > 1.0,
+            "foot_positions": env.foot_positions, "body_pos": env.root_states[:, 0:3], "torques": env.torques}
+    for k, t in want.items():
+        v = ex[k]
+        assert isinstance(v, np.ndarray) and v.shape == tuple(t.shape), k
+        assert np.array_equal(v, t.cpu().numpy()), k
+    assert torch.equal(ex["joint_vel_target"], torch.zeros(12)) and ex["privileged_obs"] is env.privileged_obs_buf
+    assert ex["contact_states"].dtype == np.bool_ and ex["foot_positions"].shape == (16, 4, 3)
+    assert {"env_bins", "time_outs", "train/episode"} <= set(ex)
