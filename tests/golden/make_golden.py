@@ -940,6 +940,20 @@ def gen_history_trace():
     print("history_trace:", trace[-1])
 
 
+def gen_pretrain_jit_layout():
+    """structure of the TorchScript `adaptation_module_latest.jit` the reference ships with its pretrained run (what scripts/
+    play.py:17-29 and the deployment stack load): parameter names / shapes and the module sequence — no weights."""
+    import json
+    m = torch.jit.load(os.path.join(REF, "runs/gait-conditioned-agility/pretrain-v0/train/025417.456545/checkpoints/adaptation_module_latest.jit"),
+                       map_location="cpu")
+    out = {"original_name": m.original_name, "state_dict": {k: list(v.shape) for k, v in m.state_dict().items()},
+           "children": [[n, c.original_name] for n, c in m.named_children()],
+           "dtypes": sorted({str(v.dtype) for v in m.state_dict().values()})}
+    with open(os.path.join(HERE, "pretrain_jit_layout.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("pretrain_jit_layout:", out["children"])
+
+
 def gen_callbacks(N=64, seed=51, sim_seed=999, step=200, x_offset_px=0, name="callbacks.npz"):
     """the randomising branches of `_post_physics_step_callback` that scripts/train.py leaves off (legged_robot.py:675-708):
     `_teleport_robots` :1028-1051, `_push_robots` :1017-1026, `_randomize_dof_props` :645-665 and
@@ -1060,6 +1074,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "history_trace":        # only history_trace.json
         gen_history_trace()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pretrain_jit_layout":  # only pretrain_jit_layout.json
+        gen_pretrain_jit_layout()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gravity":              # only gravity.npz
         gen_gravity()
         sys.exit(0)
@@ -1127,3 +1144,4 @@ if __name__ == "__main__":
         del sys.modules[m]
     gen_cfg_defaults()
     gen_history_trace()
+    gen_pretrain_jit_layout()

@@ -112,6 +112,8 @@ def test_reference_train_script_runs_one_iteration_end_to_end(monkeypatch, tmp_p
     assert seen["learn_kwargs"] == dict(num_learning_iterations=100000, init_at_random_ep_len=True, eval_freq=100)   # train.py:216
     ck = tmp_path / "dropin" / "checkpoints"
     assert (ck / "ac_weights_last.pt").exists() and (ck / "adaptation_module_latest.jit").exists() and (ck / "body_latest.jit").exists()
+    from util import check_exported_policy_layout
+    check_exported_policy_layout(str(ck))
     metrics = logger.load_pkl("metrics.pkl")
     assert metrics and metrics[-1]["timesteps"] == 24 * 48
     assert any(k.startswith("train/episode/rew_") for k in metrics[-1])

@@ -65,6 +65,8 @@ def test_env_with_eval_cfg_and_runner_iteration(monkeypatch, tmp_path):
     done = B.episode_sums_eval[-1] != -1
     assert int(done[NT:].sum()) > 0 and int(done[:NT].sum()) == 0
     assert env.episode_sums_eval["total"].data_ptr() == B.episode_sums_eval[-1].data_ptr()
+    from util import check_exported_policy_layout
+    check_exported_policy_layout(str(tmp_path / "evalsplit" / "checkpoints"))      # (no reference tree needed for this one)
 
 
 def test_eval_cfg_needs_wavefront_aligned_train_count(monkeypatch):

@@ -113,3 +113,26 @@ def check_resample_against_reference(d, B, atol=1e-6):
     assert np.all(sums[:, ids] == 0) and np.array_equal(sums[:, rest], d["command_sums0"][:, rest])
     np.testing.assert_allclose(B.curriculum_weights.cpu().numpy(), d["weights1"], rtol=0, atol=1e-6)
     assert np.abs(d["weights1"] - d["weights0"]).sum() > 1.0
+
+
+def check_exported_policy_layout(ckpt_dir):
+    """the Runner's TorchScript exports against the structure of the reference's shipped `adaptation_module_latest.jit`
+    (tests/golden/pretrain_jit_layout.json): same parameter names / shapes / dtype and module sequence, loadable on the CPU the
+    way scripts/play.py:17-29 loads them, and composable as body(cat(history, adaptation_module(history)))."""
+    import json
+    with open(os.path.join(GOLDEN, "pretrain_jit_layout.json")) as f:
+        ref = json.load(f)
+    adapt = torch.jit.load(os.path.join(ckpt_dir, "adaptation_module_latest.jit"))
+    body = torch.jit.load(os.path.join(ckpt_dir, "body_latest.jit"))
+    assert adapt.original_name == ref["original_name"] == body.original_name
+    assert {k: list(v.shape) for k, v in adapt.state_dict().items()} == ref["state_dict"]
+    assert [[n, c.original_name] for n, c in adapt.named_children()] == ref["children"]
+    assert sorted({str(v.dtype) for v in adapt.state_dict().values()}) == ref["dtypes"]
+    assert all(v.device.type == "cpu" for v in list(adapt.state_dict().values()) + list(body.state_dict().values()))
+    assert [c.original_name for _, c in body.named_children()] == ["Linear", "ELU", "Linear", "ELU", "Linear", "ELU", "Linear"]
+    assert {k: tuple(v.shape) for k, v in body.state_dict().items()}["0.weight"] == (512, 2102)
+    hist = torch.randn(3, 2100)
+    assert body(torch.cat((hist, adapt(hist)), dim=-1)).shape == (3, 12)
+    weights = torch.load(os.path.join(ckpt_dir, "ac_weights_last.pt"), map_location="cpu")
+    groups = {k.split(".")[0] for k in weights}
+    assert groups == {"std", "adaptation_module", "actor_body", "critic_body"}, groups      # ppo_cse/__init__.py:231-251 consumers
