@@ -60,19 +60,22 @@ def _worker(rank, world, port, out, grad_dtype="fp32", zero1=False):
 _DP_RESULTS = {}
 
 
-@pytest.mark.parametrize("grad_dtype,zero1", [("fp32", False), ("bf16", False), ("fp32", True), ("bf16", True)])
-def test_two_rank_gloo_update_keeps_replicas_identical(grad_dtype, zero1):
+@pytest.mark.parametrize("grad_dtype,zero1,world", [("fp32", False, 2), ("bf16", False, 2), ("fp32", True, 2), ("bf16", True, 2),
+                                                    ("fp32", True, 3)])
+def test_two_rank_gloo_update_keeps_replicas_identical(grad_dtype, zero1, world):
     """every exchange mode (PPO_Args.dp_grad_dtype, PPO_Args.dp_zero1): both ranks end with bit-identical weights and
     learning rate; the sharded step (reduce-scatter, every rank steps its slice with the global norm / KL, all-gather)
-    reproduces the all-reduce step's weights to round-off, the bf16 exchange stays within bf16 gradient noise of it."""
-    world = 2
+    reproduces the all-reduce step's weights to round-off, the bf16 exchange stays within bf16 gradient noise of it.  Three
+    ranks: the parameter count is not a multiple of the world size (the flat master is padded for the scatter)."""
     port = 29500 + (os.getpid() + 17 * len(_DP_RESULTS)) % 2000
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out, grad_dtype, zero1), nprocs=world, join=True)
-    r0, r1 = out[0], out[1]
-    _DP_RESULTS[(grad_dtype, zero1)] = r0["w"].clone()
-    if (grad_dtype, zero1) != ("fp32", False) and ("fp32", False) in _DP_RESULTS:
+    r0, r1 = out[0], out[world - 1]
+    assert all(torch.equal(out[r]["w"], r0["w"]) for r in range(world))
+    if world == 2:
+        _DP_RESULTS[(grad_dtype, zero1)] = r0["w"].clone()
+    if world == 2 and (grad_dtype, zero1) != ("fp32", False) and ("fp32", False) in _DP_RESULTS:
         base = _DP_RESULTS[("fp32", False)]
         n = base.numel()
         tol = 1e-5 if grad_dtype == "fp32" else 5e-3           # Adam's normalised step amplifies the bf16 rounding of small gradients
