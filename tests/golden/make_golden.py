@@ -1077,6 +1077,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pretrain_jit_layout":  # only pretrain_jit_layout.json
         gen_pretrain_jit_layout()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "maps":                 # only maps_<variant>[_mild].npz of the named variant
+        gen_maps(sys.argv[2])
+        for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+            del sys.modules[m]
+        gen_maps(sys.argv[2], seed=23, mild=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gravity":              # only gravity.npz
         gen_gravity()
         sys.exit(0)
@@ -1105,7 +1111,7 @@ if __name__ == "__main__":
     gen_heights()
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
-    for v in ("train", "alt"):
+    for v in ("train", "alt", "alt2"):
         # the reference mutates the global Cfg: one process state per variant
         for m in [k for k in sys.modules if k.startswith("go1_gym")]:
             del sys.modules[m]

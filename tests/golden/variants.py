@@ -22,6 +22,16 @@ VARIANTS = {
         "reward_scales": dict(tracking_lin_vel=20.0, orientation=-5.0, dof_pos=-0.05, feet_contact_forces=-0.01, feet_impact_vel=-0.1,
                               feet_contact_vel=-0.1),
     },
+    # the remaining observation switches: no command block, linear velocity only, no clock inputs (legged_robot.py:319, 358,
+    # 336), a single privileged term, roll / pitch termination off.  (`observe_gait_commands=False` cannot be pinned: the
+    # reference then never defines `foot_indices`, which train.py's active rewards read, corl_rewards.py:128.)
+    "alt2": {
+        "noise": dict(add_noise=False),
+        "env": dict(observe_command=False, observe_only_lin_vel=True, observe_clock_inputs=False,
+                    observe_two_prev_actions=True, num_observations=3 + 12 + 12 + 12 + 12 + 3, num_scalar_observations=54,
+                    priv_observe_friction=False, priv_observe_restitution=True, num_privileged_obs=1),
+        "rewards": dict(use_terminal_roll_pitch=False),
+    },
     # north_star's "domain-randomisation pushes" and the other step-callback branches that train.py leaves off: velocity
     # pushes (legged_robot.py:1017-1026), edge teleport (:1028-1051), re-drawn rigid-body properties (:706-708,166-168);
     # kernel-vs-oracle only (no fixture: the reference draws these from torch's global RNG)

@@ -43,7 +43,7 @@ def diff(Be, Bc, k):
 
 
 @pytest.mark.parametrize("variant,N", [("train_noise", 32), ("alt", 16), ("train_noise", 8), ("dr", 16), ("train_noise", 1),
-                                       ("dr", 21)])
+                                       ("dr", 21), ("alt2", 16)])
 def test_emulated_kernel_full_step_matches_oracle(oracle_lib, emu, variant, N):
     """fp32 kernel vs fp64 oracle, identical state / action / RNG streams, re-synchronised every step: round-off only.
     N = 32: two wavefronts, matrix-core torque path; N = 8: a partial wavefront, plain-FMA torque path; N = 1: scripts/play.py's
@@ -131,7 +131,8 @@ def test_emulated_limit_rows_conserve_momentum_and_match_oracle(oracle_lib, emu)
     assert int(Be.fault_counts[:10].sum()) == 0 and int(Be.fault_counts[H.abi.GO1_FAULT_LIMIT_SAFETY]) == 0
 
 
-@pytest.mark.parametrize("variant,fname", [("train", "maps_train.npz"), ("alt", "maps_alt_mild.npz")])
+@pytest.mark.parametrize("variant,fname", [("train", "maps_train.npz"), ("alt", "maps_alt_mild.npz"), ("alt2", "maps_alt2.npz"),
+                                           ("alt2", "maps_alt2_mild.npz")])
 def test_emulated_post_physics_maps_match_reference_golden(emu, variant, fname):
     """kernel code vs the reference's own Python (tests/golden/maps_*.npz), same bounds as the -m gpu version."""
     N = 48

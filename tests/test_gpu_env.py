@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("variant,fname", [("train", "maps_train.npz"), ("train", "maps_train_mild.npz"),
-                                           ("alt", "maps_alt.npz"), ("alt", "maps_alt_mild.npz")])
+                                           ("alt", "maps_alt.npz"), ("alt", "maps_alt_mild.npz"), ("alt2", "maps_alt2.npz"),
+                                           ("alt2", "maps_alt2_mild.npz")])
 def test_hip_post_physics_maps_match_reference_golden(variant, fname):
     """fp32 HIP kernel vs the reference's fp32 PyTorch: 1e-5 relative on sums, 2e-5 absolute on elementwise maps."""
     N = 48

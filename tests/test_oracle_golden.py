@@ -13,7 +13,8 @@ from util import GOLDEN, load_maps_fixture, make_sim
 
 
 @pytest.mark.parametrize("variant,fname", [("train", "maps_train.npz"), ("train", "maps_train_mild.npz"),
-                                           ("alt", "maps_alt.npz"), ("alt", "maps_alt_mild.npz")])
+                                           ("alt", "maps_alt.npz"), ("alt", "maps_alt_mild.npz"), ("alt2", "maps_alt2.npz"),
+                                           ("alt2", "maps_alt2_mild.npz")])
 def test_post_physics_maps_match_reference(oracle_lib, variant, fname):
     N = 48
     cfg, S, meta, B = make_sim(variant, N)
