@@ -1121,7 +1121,8 @@ if __name__ == "__main__":
         gen_maps(v, seed=23, mild=True)
         for m in [k for k in sys.modules if k.startswith("go1_gym")]:
             del sys.modules[m]
-        gen_torques(v)
+        if v != "alt2":                                           # (alt2 changes observations only: its torque model is train's)
+            gen_torques(v)
     for mode in RESAMPLE_MODES:
         for m in [k for k in sys.modules if k.startswith("go1_gym")]:
             del sys.modules[m]
