@@ -68,8 +68,9 @@ def torch_rand_sqrt_float(lower, upper, shape, device):
     return (upper - lower) * (r + 1.) / 2. + lower
 
 
-def get_scale_shift(rng):
-    return 2. / (rng[1] - rng[0]), (rng[1] + rng[0]) / 2.
+def get_scale_shift(range):          # noqa: A002  (the reference's keyword name, math_utils.py:35)
+    lo, hi = range[0], range[1]
+    return 2. / (hi - lo), (hi + lo) / 2.
 
 
 def to_torch(x, dtype=torch.float, device='cpu', requires_grad=False):
