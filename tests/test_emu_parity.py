@@ -247,10 +247,11 @@ def test_emulated_train_eval_split_matches_oracle(oracle_lib, emu):
     ev = {"domain_rand": dict(friction_range=[5.0, 5.5], restitution_range=[0.7, 0.8], added_mass_range=[4.0, 4.5],
                               motor_strength_range=[1.5, 1.6], motor_offset_range=[0.10, 0.11], push_robots=True, max_push_vel_xy=2.0,
                               randomize_rigids_after_start=True, randomize_friction=True, randomize_restitution=True, randomize_base_mass=True),
-          "terrain": dict(yaw_init_range=0.1)}
+          "terrain": dict(yaw_init_range=0.1, x_offset=163)}            # (an evaluation terrain region 163 samples behind, terrain.py:51)
     cfg, S, meta, Bc = make_sim("dr", N, seed=5)
     _, S_ev_full, _, _ = make_sim("dr", N, seed=5, extra=ev)
     S_eval = H.make_eval_sim_config(S, S_ev_full)
+    assert (S.teleport_x_offset, S_eval.teleport_x_offset) == (0.0, 16.0) and S.teleport_robots and S_eval.teleport_robots
     assert S_eval.num_envs == N and list(S_eval.friction_range) == [5.0, 5.5] and list(S.friction_range) != [5.0, 5.5]
     assert S_eval.num_rewards == S.num_rewards and S_eval.resample_interval == S.resample_interval
     randomize_dr(Bc, 5)
@@ -260,6 +261,11 @@ def test_emulated_train_eval_split_matches_oracle(oracle_lib, emu):
     orc.reset_idx()
     Bc.episode_length_buf[:] = torch.randint(int(S.max_episode_length) - 6, int(S.max_episode_length) - 1, (N,), dtype=torch.int32,
                                              generator=torch.Generator().manual_seed(1))      # time-outs in the next steps
+    # the teleport window of each group (`_teleport_robots` :1033-1038): x = 16.2 is inside the evaluation region's low edge zone
+    # (16 + 0.4) and an interior point of the training terrain
+    Bc.root_states[0, [3, NT + 3]] = 16.2
+    Bc.root_states[0, [5, NT + 5]] = 0.2                    # below the training window's low edge, far below the evaluation one's
+    x_before = Bc.root_states[0].clone()
     Be = Bc.clone_to("cpu")
     sim = emu.EmuSim(S, Be)
     sim.set_eval_config(S_eval, NT)
@@ -278,6 +284,12 @@ def test_emulated_train_eval_split_matches_oracle(oracle_lib, emu):
                        ("motor_strengths", 1e-6), ("motor_offsets", 1e-6), ("obs_buf", 1e-4), ("rew_buf", 1e-5), ("commands", 1e-6),
                        ("episode_sums", 1e-4), ("episode_sums_eval", 1e-4), ("episode_log", 1e-3)):
             assert diff(Be, Bc, k) <= tol, (step, k, diff(Be, Bc, k))
+        if step == 0:
+            jump = (Be.root_states[0] - x_before) / (S.terrain_length * (S.terrain_num_rows - 1))
+            keep = ~Be.reset_buf.bool()
+            want = torch.ones(N)                              # everything else starts near x = 0: below both low edges
+            want[3] = 0.0                                     # 16.2 is interior for the training group, edge zone for NT + 3
+            assert float((jump - want)[keep].abs().max()) < 0.01 and bool(keep[[3, NT + 3, 5, NT + 5]].all())
         log_e += Be.episode_log.numpy()
         resync(Bc, Be, sim, orc)
     done = Bc.episode_sums_eval[-1] != -1.0
