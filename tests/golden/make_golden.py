@@ -200,7 +200,9 @@ def flat(d):
     return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
 
 
-def gen_maps(variant, N=48, seed=11, mild=False):
+def gen_maps(variant, N=48, seed=11, mild=False, noise=None):
+    """`noise` = (sim_seed, step): observation noise on — `torch.rand_like(obs_buf)` (legged_robot.py:375-376) returns the uniforms
+    the oracle / kernel draw for (sim_seed, env, step, purpose 1, column)."""
     e, LR = make_env(variant, N, seed, mild)
     inp = dict(root_states=e.root_states.clone(), dof_pos=e.dof_pos.clone(), dof_vel=e.dof_vel.clone(),
                gravity=torch.tensor([0.3, -0.2, -9.8]), foot_positions=e.foot_positions.clone(),
@@ -223,7 +225,21 @@ def gen_maps(variant, N=48, seed=11, mild=False):
     LR._step_contact_targets(e)
     LR.check_termination(e)
     LR.compute_reward(e)
-    LR.compute_observations(e)
+    extra = {}
+    if noise is None:
+        LR.compute_observations(e)
+    else:
+        sim_seed, step = noise
+        assert e.cfg.noise.add_noise
+        e.add_noise = True
+        real = torch.rand_like
+        torch.rand_like = lambda t, **k: torch.tensor([[philox_uniform(sim_seed, i, step, 1, c) for c in range(t.shape[1])]
+                                                       for i in range(t.shape[0])])
+        try:
+            LR.compute_observations(e)
+        finally:
+            torch.rand_like = real
+        extra = dict(sim_seed=np.array(sim_seed), step=np.array(step))
     clip = e.cfg.normalization.clip_observations
     out = dict(out_gait_indices=e.gait_indices, out_foot_indices=e.foot_indices, out_clock_inputs=e.clock_inputs,
                out_desired_contact_states=e.desired_contact_states, out_reset_buf=e.reset_buf, out_time_out_buf=e.time_out_buf,
@@ -235,7 +251,7 @@ def gen_maps(variant, N=48, seed=11, mild=False):
                out_projected_gravity=e.projected_gravity,
                out_max_episode_length=np.array(int(e.cfg.env.max_episode_length)),
                out_dof_pos_soft_limits=e.dof_pos_limits)
-    np.savez_compressed(os.path.join(HERE, f"maps_{variant}{'_mild' if mild else ''}.npz"), **flat(inp), **flat(out), **names)
+    np.savez_compressed(os.path.join(HERE, f"maps_{variant}{'_mild' if mild else ''}.npz"), **flat(inp), **flat(out), **names, **extra)
     print("maps", variant, "rew mean", float(e.rew_buf.mean()), "resets", int(e.reset_buf.sum()))
 
 
@@ -1077,6 +1093,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pretrain_jit_layout":  # only pretrain_jit_layout.json
         gen_pretrain_jit_layout()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "maps_noise":           # only maps_train_noise.npz
+        gen_maps("train_noise", seed=29, mild=True, noise=(777, 321))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "maps":                 # only maps_<variant>[_mild].npz of the named variant
         gen_maps(sys.argv[2])
         for m in [k for k in sys.modules if k.startswith("go1_gym")]:
@@ -1123,6 +1142,9 @@ if __name__ == "__main__":
             del sys.modules[m]
         if v != "alt2":                                           # (alt2 changes observations only: its torque model is train's)
             gen_torques(v)
+    for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+        del sys.modules[m]
+    gen_maps("train_noise", seed=29, mild=True, noise=(777, 321))
     for mode in RESAMPLE_MODES:
         for m in [k for k in sys.modules if k.startswith("go1_gym")]:
             del sys.modules[m]

@@ -2,6 +2,8 @@
 Each variant = train config (walk-these-ways_amd/scripts/train_config.py) + these overrides."""
 
 VARIANTS = {
+    # scripts/train.py as it is: observation noise on (`torch.rand_like` of the reference is fed the kernels' Philox uniforms)
+    "train_noise": {},
     # scripts/train.py effective config (noise off: the reference draws it from torch's global RNG)
     "train": {"noise": dict(add_noise=False)},
     # exercises the other branches: 'P' control without lag, velocity/yaw/contact observations, more privileged

@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
 import go1sim_host as H  # noqa: E402
-from util import (GOLDEN, RESAMPLE_MODES, check_resample_against_reference, load_maps_fixture, load_resample_fixture,  # noqa: E402
+from util import (GOLDEN, RESAMPLE_MODES, check_resample_against_reference, load_maps_fixture, load_resample_fixture, maps_fixture_stream,  # noqa: E402
                   make_sim, randomize_dr, standing_state)
 
 
@@ -132,14 +132,15 @@ def test_emulated_limit_rows_conserve_momentum_and_match_oracle(oracle_lib, emu)
 
 
 @pytest.mark.parametrize("variant,fname", [("train", "maps_train.npz"), ("alt", "maps_alt_mild.npz"), ("alt2", "maps_alt2.npz"),
-                                           ("alt2", "maps_alt2_mild.npz")])
+                                           ("alt2", "maps_alt2_mild.npz"), ("train_noise", "maps_train_noise_mild.npz")])
 def test_emulated_post_physics_maps_match_reference_golden(emu, variant, fname):
     """kernel code vs the reference's own Python (tests/golden/maps_*.npz), same bounds as the -m gpu version."""
     N = 48
-    cfg, S, meta, Bc = make_sim(variant, N)
+    seed, counter = maps_fixture_stream(fname)
+    cfg, S, meta, Bc = make_sim(variant, N, seed=seed)
     d = load_maps_fixture(fname, S, meta, Bc)
     sim = emu.EmuSim(S, Bc)
-    sim.set_counters(7, 0)
+    sim.set_counters(counter, 0)
     sim.post_physics(d["gravity"])
     g = lambda k: Bc.tensors[k]
     reset = d["out_reset_buf"].astype(bool)

@@ -7,22 +7,23 @@ import pytest
 import torch
 
 import go1sim_host as H
-from util import load_maps_fixture, make_sim
+from util import load_maps_fixture, make_sim, maps_fixture_stream
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("variant,fname", [("train", "maps_train.npz"), ("train", "maps_train_mild.npz"),
                                            ("alt", "maps_alt.npz"), ("alt", "maps_alt_mild.npz"), ("alt2", "maps_alt2.npz"),
-                                           ("alt2", "maps_alt2_mild.npz")])
+                                           ("alt2", "maps_alt2_mild.npz"), ("train_noise", "maps_train_noise_mild.npz")])
 def test_hip_post_physics_maps_match_reference_golden(variant, fname):
     """fp32 HIP kernel vs the reference's fp32 PyTorch: 1e-5 relative on sums, 2e-5 absolute on elementwise maps."""
     N = 48
-    cfg, S, meta, Bc = make_sim(variant, N)
+    seed, counter = maps_fixture_stream(fname)
+    cfg, S, meta, Bc = make_sim(variant, N, seed=seed)
     d = load_maps_fixture(fname, S, meta, Bc)
     Bg = Bc.clone_to("cuda:0")
     sim = H.Go1Sim(S, Bg, 0)
-    sim.set_counters(7, 0)
+    sim.set_counters(counter, 0)
     sim.post_physics(d["gravity"])
     torch.cuda.synchronize()
     g = lambda k: Bg.tensors[k].cpu()

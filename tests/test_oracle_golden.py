@@ -9,15 +9,16 @@ import pytest
 import torch
 
 import go1sim_host as H
-from util import GOLDEN, load_maps_fixture, make_sim
+from util import GOLDEN, load_maps_fixture, make_sim, maps_fixture_stream
 
 
 @pytest.mark.parametrize("variant,fname", [("train", "maps_train.npz"), ("train", "maps_train_mild.npz"),
                                            ("alt", "maps_alt.npz"), ("alt", "maps_alt_mild.npz"), ("alt2", "maps_alt2.npz"),
-                                           ("alt2", "maps_alt2_mild.npz")])
+                                           ("alt2", "maps_alt2_mild.npz"), ("train_noise", "maps_train_noise_mild.npz")])
 def test_post_physics_maps_match_reference(oracle_lib, variant, fname):
     N = 48
-    cfg, S, meta, B = make_sim(variant, N)
+    seed, counter = maps_fixture_stream(fname)          # (the noise fixture: observation noise from the Philox stream, :375-376)
+    cfg, S, meta, B = make_sim(variant, N, seed=seed)
     d = load_maps_fixture(fname, S, meta, B)
     assert [str(x) for x in d["reward_names"]] == meta["reward_names"]
     np.testing.assert_allclose(d["reward_scales"], [meta["reward_scales"][n] for n in meta["reward_names"]], rtol=1e-6)
@@ -26,7 +27,7 @@ def test_post_physics_maps_match_reference(oracle_lib, variant, fname):
     np.testing.assert_allclose(d["out_dof_pos_soft_limits"][:, 0], list(S.dof_pos_soft_lower), rtol=1e-6)
     np.testing.assert_allclose(d["out_dof_pos_soft_limits"][:, 1], list(S.dof_pos_soft_upper), rtol=1e-6)
     orc = oracle_lib.Oracle(S, B)
-    orc.ctr.common_step_counter = 7
+    orc.ctr.common_step_counter = counter
     orc.post_physics(d["gravity"].astype(np.float64))
 
     reset = d["out_reset_buf"].astype(bool)
@@ -49,6 +50,8 @@ def test_post_physics_maps_match_reference(oracle_lib, variant, fname):
     # command sums are cleared for reset envs by the resample; compare the others
     np.testing.assert_allclose(B.command_sums.numpy()[:, keep], d["out_command_sums"][:, keep], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(B.obs_buf.numpy()[keep], d["out_obs"][keep], rtol=1e-5, atol=2e-6)
+    if variant == "train_noise":
+        assert S.add_noise and np.count_nonzero(d["out_noise_scale_vec"]) == 3 + 12 + 12          # gravity, joint angles, joint rates
     np.testing.assert_allclose(B.privileged_obs_buf.numpy()[keep][:, :S.num_privileged_obs], d["out_priv"][keep], rtol=1e-5, atol=2e-6)
 
 

@@ -75,6 +75,13 @@ def load_maps_fixture(name, S, meta, B):
     return d
 
 
+def maps_fixture_stream(fname):
+    """(simulator seed, step counter before the call) a maps fixture was generated for: the noise fixture fixes both (its
+    `torch.rand_like` was fed the uniforms of that stream), the others carry no draw of their own."""
+    d = np.load(os.path.join(GOLDEN, fname))
+    return (int(d["sim_seed"]), int(d["step"]) - 1) if "sim_seed" in d.files else (3, 7)
+
+
 RESAMPLE_MODES = {"gaitwise": dict(gaitwise_curricula=True, exclusive_phase_offset=False, balance_gait_distribution=False, binary_phases=True),
                   "exclusive": dict(gaitwise_curricula=False, exclusive_phase_offset=True, balance_gait_distribution=False, binary_phases=True),
                   "balance": dict(gaitwise_curricula=False, exclusive_phase_offset=False, balance_gait_distribution=True, binary_phases=False),
