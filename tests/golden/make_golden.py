@@ -255,6 +255,15 @@ def gen_maps(variant, N=48, seed=11, mild=False, noise=None):
     print("maps", variant, "rew mean", float(e.rew_buf.mean()), "resets", int(e.reset_buf.sum()))
 
 
+def gen_maps_fuzz():
+    """tensor maps under the random switch sets of variants.py (FUZZ_VARIANTS)"""
+    var = load_private("_wtw_variants_count", os.path.join(HERE, "variants.py"))
+    for k in range(var.FUZZ_VARIANTS):
+        for m in [x for x in sys.modules if x.startswith("go1_gym")]:
+            del sys.modules[m]
+        gen_maps(f"fuzz{k}", seed=60 + k, mild=True)
+
+
 def gen_torques(variant, N=16, steps=12, seed=5):
     e, LR = make_env(variant, N, seed)
     net = torch.jit.load(os.path.join(REF, "resources/actuator_nets/unitree_go1.pt"), map_location="cpu")
@@ -1093,6 +1102,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pretrain_jit_layout":  # only pretrain_jit_layout.json
         gen_pretrain_jit_layout()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "maps_fuzz":            # only maps_fuzz<k>_mild.npz
+        gen_maps_fuzz()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "maps_noise":           # only maps_train_noise.npz
         gen_maps("train_noise", seed=29, mild=True, noise=(777, 321))
         sys.exit(0)
@@ -1145,6 +1157,7 @@ if __name__ == "__main__":
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     gen_maps("train_noise", seed=29, mild=True, noise=(777, 321))
+    gen_maps_fuzz()
     for mode in RESAMPLE_MODES:
         for m in [k for k in sys.modules if k.startswith("go1_gym")]:
             del sys.modules[m]

@@ -45,6 +45,49 @@ VARIANTS = {
 }
 
 
+def random_switches(rng, physics=True):
+    """a random but consistent configuration: observation / privileged-observation blocks (widths per legged_robot.py:319-372,
+    383-489), reward shaping, termination and command switches; with `physics` also controller and domain-randomisation
+    cadence switches (irrelevant for the tensor maps)"""
+    pick = lambda p=0.5: bool(rng.random() < p)
+    env = dict(observe_command=pick(0.7), observe_two_prev_actions=pick(), observe_timing_parameter=pick(), observe_clock_inputs=pick(),
+               observe_vel=False, observe_only_lin_vel=False, observe_yaw=pick(), observe_contact_states=pick())
+    vel = rng.integers(0, 3)
+    env["observe_vel"], env["observe_only_lin_vel"] = bool(vel == 1), bool(vel == 2)
+    width = 39 + 15 * env["observe_command"] + 12 * env["observe_two_prev_actions"] + env["observe_timing_parameter"] + \
+        4 * env["observe_clock_inputs"] + 6 * env["observe_vel"] + 3 * env["observe_only_lin_vel"] + env["observe_yaw"] + \
+        4 * env["observe_contact_states"]
+    env["num_observations"] = env["num_scalar_observations"] = int(width)
+    priv_w = dict(friction=1, restitution=1, base_mass=1, com_displacement=3, motor_strength=12, motor_offset=12, body_height=1,
+                  body_velocity=3, gravity=3, clock_inputs=4, desired_contact_states=4)
+    npv = 0
+    for k, w in priv_w.items():
+        on = pick(0.4)
+        env["priv_observe_" + k] = on
+        npv += w * on
+    if npv == 0:
+        env["priv_observe_friction"], npv = True, 1
+    env["num_privileged_obs"] = int(npv)
+    positive = pick()
+    extra = {"env": env,
+             "commands": dict(pacing_offset=pick(), binary_phases=pick(), gaitwise_curricula=pick(),
+                              exclusive_phase_offset=False, balance_gait_distribution=pick()),
+             "rewards": dict(only_positive_rewards=positive, only_positive_rewards_ji22_style=not positive,
+                             use_terminal_body_height=pick(), use_terminal_roll_pitch=pick())}
+    if physics:
+        extra["control"] = dict(control_type="P" if pick(0.3) else "actuator_net")
+        extra["domain_rand"] = dict(randomize_lag_timesteps=pick(0.7), randomize_Kp_factor=pick(), randomize_Kd_factor=pick(),
+                                    push_robots=pick(), push_interval_s=0.1, randomize_rigids_after_start=pick(), rand_interval_s=0.1)
+    return extra
+
+
+# tensor-map fixtures under random switch sets (reference-pinned like "alt": tests/golden/maps_fuzz<k>_mild.npz)
+FUZZ_VARIANTS = 6
+for _k in range(FUZZ_VARIANTS):
+    import numpy as _np
+    VARIANTS[f"fuzz{_k}"] = dict(random_switches(_np.random.default_rng(500 + _k), physics=False), noise=dict(add_noise=False))
+
+
 def apply_variant(Cfg, name):
     for section, values in VARIANTS[name].items():
         target = getattr(Cfg, section)

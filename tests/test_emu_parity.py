@@ -11,7 +11,8 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
 import go1sim_host as H  # noqa: E402
-from util import (GOLDEN, RESAMPLE_MODES, check_resample_against_reference, load_maps_fixture, load_resample_fixture, maps_fixture_stream,  # noqa: E402
+from golden.variants import FUZZ_VARIANTS, random_switches  # noqa: E402
+from util import (GOLDEN, RESAMPLE_MODES, check_resample_against_reference, load_maps_fixture, load_resample_fixture, maps_fixture_stream, maps_keep,  # noqa: E402
                   make_sim, randomize_dr, standing_state)
 
 
@@ -132,7 +133,8 @@ def test_emulated_limit_rows_conserve_momentum_and_match_oracle(oracle_lib, emu)
 
 
 @pytest.mark.parametrize("variant,fname", [("train", "maps_train.npz"), ("alt", "maps_alt_mild.npz"), ("alt2", "maps_alt2.npz"),
-                                           ("alt2", "maps_alt2_mild.npz"), ("train_noise", "maps_train_noise_mild.npz")])
+                                           ("alt2", "maps_alt2_mild.npz"), ("train_noise", "maps_train_noise_mild.npz")]
+                                          + [(f"fuzz{k}", f"maps_fuzz{k}_mild.npz") for k in range(FUZZ_VARIANTS)])
 def test_emulated_post_physics_maps_match_reference_golden(emu, variant, fname):
     """kernel code vs the reference's own Python (tests/golden/maps_*.npz), same bounds as the -m gpu version."""
     N = 48
@@ -144,7 +146,7 @@ def test_emulated_post_physics_maps_match_reference_golden(emu, variant, fname):
     sim.post_physics(d["gravity"])
     g = lambda k: Bc.tensors[k]
     reset = d["out_reset_buf"].astype(bool)
-    keep = ~reset
+    keep = maps_keep(d, S)
     np.testing.assert_array_equal(g("reset_buf").numpy().astype(bool), reset)
     tol = dict(rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(g("base_lin_vel").t().numpy(), d["out_base_lin_vel"], **tol)
@@ -388,3 +390,25 @@ def test_emulated_full_step_on_a_height_field(oracle_lib, emu):
     assert Bc.obs_buf.shape[1] == 257 and float(Bc.obs_buf[:, 70:].abs().max()) > 0.1
     assert resets >= 8 and int(bad.sum()) <= 1, (resets, int(bad.sum()))
     assert int(Be.fault_counts[:10].sum()) == 0
+
+
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("GO1_FUZZ_CASES", "8"))))
+def test_emulated_kernel_under_random_configurations(oracle_lib, emu, case):
+    """configuration fuzz (fixed seeds): random consistent sets of the observation, privileged-observation, controller, reward,
+    termination and command-sampling switches; emulated kernel vs oracle, three steps each, observation noise on."""
+    rng = np.random.default_rng(1000 + case)
+    extra = random_switches(rng)
+    N = 16
+    S, Bc, orc, Be, sim = pair(oracle_lib, emu, "train_noise", N, seed=40 + case, extra=extra)
+    assert S.num_obs == extra["env"]["num_observations"]
+    Bc.episode_length_buf[:] = torch.randint(0, int(S.max_episode_length), (N,), dtype=torch.int32, generator=torch.Generator().manual_seed(case))
+    resync(Bc, Be, sim, orc)
+    for step in range(3):
+        a = (rng.standard_normal((N, 12)) * (2.0 if step == 1 else 0.5)).astype(np.float32)
+        orc.step(a)
+        sim.step(torch.from_numpy(a))
+        assert torch.equal(Be.reset_buf, Bc.reset_buf) and torch.equal(Be.time_out_buf, Bc.time_out_buf), (case, step)
+        for k, tol in (("dof_pos", 5e-6), ("dof_vel", 1e-3), ("root_states", 2e-4), ("torques", 1e-3), ("obs_buf", 1e-4),
+                       ("privileged_obs_buf", 1e-4), ("rew_buf", 1e-5), ("commands", 1e-6), ("episode_sums", 1e-4), ("command_sums", 1e-4)):
+            assert diff(Be, Bc, k) <= tol, (case, step, k, diff(Be, Bc, k), extra)
+        resync(Bc, Be, sim, orc)

@@ -7,14 +7,16 @@ import pytest
 import torch
 
 import go1sim_host as H
-from util import load_maps_fixture, make_sim, maps_fixture_stream
+from util import load_maps_fixture, make_sim, maps_fixture_stream, maps_keep
+from golden.variants import FUZZ_VARIANTS
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("variant,fname", [("train", "maps_train.npz"), ("train", "maps_train_mild.npz"),
                                            ("alt", "maps_alt.npz"), ("alt", "maps_alt_mild.npz"), ("alt2", "maps_alt2.npz"),
-                                           ("alt2", "maps_alt2_mild.npz"), ("train_noise", "maps_train_noise_mild.npz")])
+                                           ("alt2", "maps_alt2_mild.npz"), ("train_noise", "maps_train_noise_mild.npz")]
+                                          + [(f"fuzz{k}", f"maps_fuzz{k}_mild.npz") for k in range(FUZZ_VARIANTS)])
 def test_hip_post_physics_maps_match_reference_golden(variant, fname):
     """fp32 HIP kernel vs the reference's fp32 PyTorch: 1e-5 relative on sums, 2e-5 absolute on elementwise maps."""
     N = 48
@@ -28,7 +30,7 @@ def test_hip_post_physics_maps_match_reference_golden(variant, fname):
     torch.cuda.synchronize()
     g = lambda k: Bg.tensors[k].cpu()
     reset = d["out_reset_buf"].astype(bool)
-    keep = ~reset
+    keep = maps_keep(d, S)
     np.testing.assert_array_equal(g("reset_buf").numpy().astype(bool), reset)
     np.testing.assert_array_equal(g("time_out_buf").numpy().astype(bool), d["out_time_out_buf"].astype(bool))
     tol = dict(rtol=1e-5, atol=2e-5)

@@ -9,12 +9,14 @@ import pytest
 import torch
 
 import go1sim_host as H
-from util import GOLDEN, load_maps_fixture, make_sim, maps_fixture_stream
+from util import GOLDEN, load_maps_fixture, make_sim, maps_fixture_stream, maps_keep
+from golden.variants import FUZZ_VARIANTS
 
 
 @pytest.mark.parametrize("variant,fname", [("train", "maps_train.npz"), ("train", "maps_train_mild.npz"),
                                            ("alt", "maps_alt.npz"), ("alt", "maps_alt_mild.npz"), ("alt2", "maps_alt2.npz"),
-                                           ("alt2", "maps_alt2_mild.npz"), ("train_noise", "maps_train_noise_mild.npz")])
+                                           ("alt2", "maps_alt2_mild.npz"), ("train_noise", "maps_train_noise_mild.npz")]
+                                          + [(f"fuzz{k}", f"maps_fuzz{k}_mild.npz") for k in range(FUZZ_VARIANTS)])
 def test_post_physics_maps_match_reference(oracle_lib, variant, fname):
     N = 48
     seed, counter = maps_fixture_stream(fname)          # (the noise fixture: observation noise from the Philox stream, :375-376)
@@ -34,7 +36,7 @@ def test_post_physics_maps_match_reference(oracle_lib, variant, fname):
     np.testing.assert_array_equal(B.reset_buf.numpy().astype(bool), reset)
     np.testing.assert_array_equal(B.time_out_buf.numpy().astype(bool), d["out_time_out_buf"].astype(bool))
     assert reset.any() and (~reset).any()
-    keep = ~reset   # reset envs were re-initialised from the oracle's own RNG stream
+    keep = maps_keep(d, S)
     tol = dict(rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(B.base_lin_vel.t().numpy(), d["out_base_lin_vel"], **tol)
     np.testing.assert_allclose(B.base_ang_vel.t().numpy(), d["out_base_ang_vel"], **tol)

@@ -82,6 +82,14 @@ def maps_fixture_stream(fname):
     return (int(d["sim_seed"]), int(d["step"]) - 1) if "sim_seed" in d.files else (3, 7)
 
 
+def maps_keep(d, S):
+    """environments of a maps fixture whose outputs are comparable one to one: not reset (re-initialised from the simulator's own
+    stream) and not on the DOF-property re-randomisation cadence this step (the fixture runs the reference's maps, not its
+    `_post_physics_step_callback`, so the privileged observation there still shows the old motor strengths / offsets)."""
+    keep = ~d["out_reset_buf"].astype(bool)
+    return keep & (d["episode_length_buf"] % int(S.rand_interval) != 0)
+
+
 RESAMPLE_MODES = {"gaitwise": dict(gaitwise_curricula=True, exclusive_phase_offset=False, balance_gait_distribution=False, binary_phases=True),
                   "exclusive": dict(gaitwise_curricula=False, exclusive_phase_offset=True, balance_gait_distribution=False, binary_phases=True),
                   "balance": dict(gaitwise_curricula=False, exclusive_phase_offset=False, balance_gait_distribution=True, binary_phases=False),
