@@ -93,7 +93,12 @@ def maps_keep(d, S):
 RESAMPLE_MODES = {"gaitwise": dict(gaitwise_curricula=True, exclusive_phase_offset=False, balance_gait_distribution=False, binary_phases=True),
                   "exclusive": dict(gaitwise_curricula=False, exclusive_phase_offset=True, balance_gait_distribution=False, binary_phases=True),
                   "balance": dict(gaitwise_curricula=False, exclusive_phase_offset=False, balance_gait_distribution=True, binary_phases=False),
-                  "plain": dict(gaitwise_curricula=False, exclusive_phase_offset=False, balance_gait_distribution=False, binary_phases=False)}
+                  "plain": dict(gaitwise_curricula=False, exclusive_phase_offset=False, balance_gait_distribution=False, binary_phases=False),
+                  # the same four branches with the other setting of `binary_phases` (legged_robot.py:814-817, 1361)
+                  "gaitwise_smooth": dict(gaitwise_curricula=True, exclusive_phase_offset=False, balance_gait_distribution=False, binary_phases=False),
+                  "exclusive_smooth": dict(gaitwise_curricula=False, exclusive_phase_offset=True, balance_gait_distribution=False, binary_phases=False),
+                  "balance_binary": dict(gaitwise_curricula=False, exclusive_phase_offset=False, balance_gait_distribution=True, binary_phases=True),
+                  "plain_binary": dict(gaitwise_curricula=False, exclusive_phase_offset=False, balance_gait_distribution=False, binary_phases=True)}
 
 
 def load_resample_fixture(mode):
