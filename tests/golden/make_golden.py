@@ -343,7 +343,26 @@ def gen_heights(seed=9, N=24):
     print("heights", h.shape, float(h.min()), float(h.max()))
 
 
-def gen_ppo(seed=3):
+PPO_FUZZ = [dict(schedule="fixed", use_clipped_value_loss=False, clip_param=0.1, entropy_coef=0.0, num_learning_epochs=2, num_mini_batches=3,
+                 num_adaptation_module_substeps=2, max_grad_norm=0.3),
+            dict(schedule="adaptive", desired_kl=0.002, value_loss_coef=0.5, entropy_coef=0.03, num_learning_epochs=3, num_mini_batches=2,
+                 selective_adaptation_module_loss=True, gamma=0.97, lam=0.9),
+            dict(schedule="adaptive", desired_kl=0.05, learning_rate=3.e-4, adaptation_module_learning_rate=3.e-3, clip_param=0.3,
+                 num_learning_epochs=1, num_mini_batches=5, max_grad_norm=10.0),
+            dict(schedule="fixed", use_clipped_value_loss=True, value_loss_coef=2.0, num_learning_epochs=4, num_mini_batches=1,
+                 num_adaptation_module_substeps=3, selective_adaptation_module_loss=True, lam=1.0)]
+
+
+def gen_ppo_fuzz():
+    """the same fixed-rollout update under four other settings of PPO_Args (ppo.py:11-31): fixed / adaptive schedule, plain value
+    loss, several adaptation sub-steps, selective adaptation loss, other clip / entropy / value coefficients, epochs, batches"""
+    for k, over in enumerate(PPO_FUZZ):
+        for m in [x for x in sys.modules if x.startswith("go1_gym")]:
+            del sys.modules[m]
+        gen_ppo(seed=10 + k, over=over, name=f"ppo_fuzz{k}.npz")
+
+
+def gen_ppo(seed=3, over=None, name="ppo.npz"):
     """reference go1_gym_learn.ppo_cse: RolloutStorage.compute_returns + PPO.update on a fixed rollout."""
     ml = types.ModuleType("ml_logger")
     ml.logger = object()
@@ -353,6 +372,9 @@ def gen_ppo(seed=3):
     AC_Args.actor_hidden_dims = [32, 16]
     AC_Args.critic_hidden_dims = [24, 16]
     AC_Args.adaptation_module_branch_hidden_dims = [16, 8]
+    for k_, v_ in (over or {}).items():
+        assert hasattr(PPO_Args, k_), k_
+        setattr(PPO_Args, k_, v_)
     N, T, no, npv, H, na = 20, 6, 10, 2, 3, 12
     torch.manual_seed(seed)
     ac = ActorCritic(no, npv, no * H, na)
@@ -381,8 +403,9 @@ def gen_ppo(seed=3):
     out.update(rec)
     out.update(last_values=last_values, losses=torch.tensor(losses), final_lr=torch.tensor(alg.learning_rate),
                dims=torch.tensor([N, T, no, npv, H, na]), seed=torch.tensor(seed))
-    np.savez_compressed(os.path.join(HERE, "ppo.npz"), **flat(out))
-    print("ppo losses", losses, "lr", alg.learning_rate)
+    import json
+    np.savez_compressed(os.path.join(HERE, name), **flat(out), ppo_args=np.array(json.dumps(over or {})))
+    print(name, "losses", losses, "lr", alg.learning_rate)
 
 
 def gen_ppo_rma(seed=4):
@@ -1107,6 +1130,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pretrain_jit_layout":  # only pretrain_jit_layout.json
         gen_pretrain_jit_layout()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ppo_fuzz":             # only ppo_fuzz<k>.npz
+        gen_ppo_fuzz()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "maps_fuzz":            # only maps_fuzz<k>_mild.npz
         gen_maps_fuzz()
         sys.exit(0)
@@ -1142,6 +1168,7 @@ if __name__ == "__main__":
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     gen_ppo_rma()
+    gen_ppo_fuzz()
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     gen_heights()

@@ -20,10 +20,25 @@ def small_ac_args():
     AC_Args.actor_hidden_dims, AC_Args.critic_hidden_dims, AC_Args.adaptation_module_branch_hidden_dims = old
 
 
-def test_update_matches_reference(small_ac_args):
+@pytest.fixture()
+def ppo_args_guard():
+    from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    saved = {k: getattr(PPO_Args, k) for k in dir(PPO_Args) if not k.startswith("_") and not callable(getattr(PPO_Args, k))}
+    yield PPO_Args
+    for k, v in saved.items():
+        setattr(PPO_Args, k, v)
+
+
+@pytest.mark.parametrize("fname", ["ppo.npz", "ppo_fuzz0.npz", "ppo_fuzz1.npz", "ppo_fuzz2.npz", "ppo_fuzz3.npz"])
+def test_update_matches_reference(small_ac_args, ppo_args_guard, fname):
+    """ppo.npz: train.py's PPO_Args; ppo_fuzz*.npz: four other settings (fixed schedule, plain value loss, several adaptation
+    sub-steps, selective adaptation loss, other coefficients / epochs / batch counts; make_golden.py PPO_FUZZ)."""
+    import json
     from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
     from go1_gym_learn.ppo_cse.ppo import PPO, PPO_Args
-    d = np.load(os.path.join(GOLDEN, "ppo.npz"))
+    d = np.load(os.path.join(GOLDEN, fname))
+    for k, v in (json.loads(str(d["ppo_args"])) if "ppo_args" in d.files else {}).items():
+        setattr(PPO_Args, k, v)
     N, T, no, npv, H, na = [int(x) for x in d["dims"]]
     ac = ActorCritic(no, npv, no * H, na)
     ac.load_state_dict({k[5:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("init_")})
