@@ -1130,6 +1130,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pretrain_jit_layout":  # only pretrain_jit_layout.json
         gen_pretrain_jit_layout()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "torques":              # only torques_<variant>.npz of the named variant
+        gen_torques(sys.argv[2])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_fuzz":             # only ppo_fuzz<k>.npz
         gen_ppo_fuzz()
         sys.exit(0)
@@ -1190,6 +1193,10 @@ if __name__ == "__main__":
         del sys.modules[m]
     gen_maps("train_noise", seed=29, mild=True, noise=(777, 321))
     gen_maps_fuzz()
+    for v in ("act_nolag", "pd_lag"):
+        for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+            del sys.modules[m]
+        gen_torques(v)
     for mode in RESAMPLE_MODES:
         for m in [k for k in sys.modules if k.startswith("go1_gym")]:
             del sys.modules[m]

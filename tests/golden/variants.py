@@ -34,6 +34,10 @@ VARIANTS = {
                     priv_observe_friction=False, priv_observe_restitution=True, num_privileged_obs=1),
         "rewards": dict(use_terminal_roll_pitch=False),
     },
+    # the two remaining combinations of the torque model's switches (train: actuator network with lag; alt: PD without)
+    "act_nolag": {"noise": dict(add_noise=False), "domain_rand": dict(randomize_lag_timesteps=False, randomize_Kp_factor=True)},
+    "pd_lag": {"noise": dict(add_noise=False), "control": dict(control_type="P"),
+               "domain_rand": dict(randomize_lag_timesteps=True, lag_timesteps=3, randomize_Kp_factor=True, randomize_Kd_factor=True)},
     # north_star's "domain-randomisation pushes" and the other step-callback branches that train.py leaves off: velocity
     # pushes (legged_robot.py:1017-1026), edge teleport (:1028-1051), re-drawn rigid-body properties (:706-708,166-168);
     # kernel-vs-oracle only (no fixture: the reference draws these from torch's global RNG)

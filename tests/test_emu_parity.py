@@ -157,7 +157,7 @@ def test_emulated_post_physics_maps_match_reference_golden(emu, variant, fname):
     np.testing.assert_allclose(g("privileged_obs_buf").numpy()[keep][:, :S.num_privileged_obs], d["out_priv"][keep], rtol=1e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("variant", ["train", "alt"])
+@pytest.mark.parametrize("variant", ["train", "alt", "act_nolag", "pd_lag"])
 def test_emulated_torque_model_matches_reference_golden(emu, variant):
     d = np.load(os.path.join(GOLDEN, f"torques_{variant}.npz"))
     cfg, S, meta, B = make_sim(variant, 16)

@@ -47,7 +47,7 @@ def test_hip_post_physics_maps_match_reference_golden(variant, fname):
     np.testing.assert_allclose(g("privileged_obs_buf").numpy()[keep][:, :S.num_privileged_obs], d["out_priv"][keep], rtol=1e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("variant", ["train", "alt"])
+@pytest.mark.parametrize("variant", ["train", "alt", "act_nolag", "pd_lag"])
 @pytest.mark.parametrize("n_env", [16, 8])
 def test_hip_torque_model_matches_reference_golden(variant, n_env):
     """HIP torque model DIRECTLY against tests/golden/torques_*.npz — outputs of the reference's `_compute_torques` with the

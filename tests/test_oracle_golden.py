@@ -57,7 +57,7 @@ def test_post_physics_maps_match_reference(oracle_lib, variant, fname):
     np.testing.assert_allclose(B.privileged_obs_buf.numpy()[keep][:, :S.num_privileged_obs], d["out_priv"][keep], rtol=1e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("variant", ["train", "alt"])
+@pytest.mark.parametrize("variant", ["train", "alt", "act_nolag", "pd_lag"])
 def test_compute_torques_matches_reference(oracle_lib, variant):
     d = np.load(os.path.join(GOLDEN, f"torques_{variant}.npz"))
     steps, N = d["actions"].shape[:2]
