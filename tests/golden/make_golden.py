@@ -312,8 +312,8 @@ def gen_curriculum():
     print("curriculum weights", w0.sum(), r.weights.sum())
 
 
-def gen_heights(seed=9, N=24):
-    """reference LeggedRobot._init_height_points / _get_heights on a random height field."""
+def gen_heights(seed=9, N=24, name="heights.npz", border=2.0, hscale=0.1, vscale=0.005, rows=120, cols=90, points=None):
+    """reference LeggedRobot._init_height_points / _get_heights on a random height field (`points`: other measured_points_x / _y)."""
     from go1_gym.envs.base.legged_robot import LeggedRobot
     from go1_gym.envs.base.legged_robot_config import Cfg
     rng = np.random.default_rng(seed)
@@ -321,25 +321,26 @@ def gen_heights(seed=9, N=24):
     e.device = "cpu"
     e.num_envs = N
     Cfg.terrain.mesh_type = "heightfield"
-    Cfg.terrain.border_size = 2.0
-    Cfg.terrain.horizontal_scale = 0.1
-    Cfg.terrain.vertical_scale = 0.005
+    Cfg.terrain.border_size = border
+    Cfg.terrain.horizontal_scale = hscale
+    Cfg.terrain.vertical_scale = vscale
+    if points is not None:
+        Cfg.terrain.measured_points_x, Cfg.terrain.measured_points_y = points
     e.terrain = Mock()
     e.terrain.cfg = Cfg.terrain
-    rows, cols = 120, 90
     e.height_samples = torch.tensor(rng.integers(-60, 60, (rows, cols)), dtype=torch.int16)
     e.root_states = torch.zeros(N, 13)
-    e.root_states[:, 0] = torch.tensor(rng.uniform(-3.0, rows * 0.1 - 1.0, N), dtype=torch.float)     # some scans leave the map
-    e.root_states[:, 1] = torch.tensor(rng.uniform(-3.0, cols * 0.1 - 1.0, N), dtype=torch.float)
+    e.root_states[:, 0] = torch.tensor(rng.uniform(-3.0, rows * hscale - border + 1.0, N), dtype=torch.float)     # some scans leave the map
+    e.root_states[:, 1] = torch.tensor(rng.uniform(-3.0, cols * hscale - border + 1.0, N), dtype=torch.float)
     e.root_states[:, 2] = 0.4
     e.root_states[:, 3:7] = rand_quat(rng, N, tilt=0.3)
     e.base_quat = e.root_states[:, 3:7]
     ids = torch.arange(N)
     e.height_points = LeggedRobot._init_height_points(e, ids, Cfg)
     h = LeggedRobot._get_heights(e, ids, Cfg)
-    np.savez_compressed(os.path.join(HERE, "heights.npz"), height_samples=e.height_samples.numpy(), root_states=e.root_states.numpy(),
+    np.savez_compressed(os.path.join(HERE, name), height_samples=e.height_samples.numpy(), root_states=e.root_states.numpy(),
                         heights=h.numpy(), points_x=np.array(Cfg.terrain.measured_points_x), points_y=np.array(Cfg.terrain.measured_points_y),
-                        border=np.array(2.0), hscale=np.array(0.1), vscale=np.array(0.005))
+                        border=np.array(border), hscale=np.array(hscale), vscale=np.array(vscale))
     print("heights", h.shape, float(h.min()), float(h.max()))
 
 
@@ -1130,6 +1131,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pretrain_jit_layout":  # only pretrain_jit_layout.json
         gen_pretrain_jit_layout()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "heights":              # only heights*.npz
+        gen_heights()
+        for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+            del sys.modules[m]
+        gen_heights(seed=10, N=16, name="heights_coarse.npz", border=5.0, hscale=0.25, vscale=0.01, rows=70, cols=50,
+                    points=([-0.6, -0.3, 0.0, 0.3, 0.6], [-0.25, 0.0, 0.25]))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "torques":              # only torques_<variant>.npz of the named variant
         gen_torques(sys.argv[2])
         sys.exit(0)
@@ -1175,6 +1183,10 @@ if __name__ == "__main__":
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     gen_heights()
+    for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+        del sys.modules[m]
+    gen_heights(seed=10, N=16, name="heights_coarse.npz", border=5.0, hscale=0.25, vscale=0.01, rows=70, cols=50,
+                points=([-0.6, -0.3, 0.0, 0.3, 0.6], [-0.25, 0.0, 0.25]))
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     for v in ("train", "alt", "alt2"):

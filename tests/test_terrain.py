@@ -10,8 +10,11 @@ import go1sim_host as H
 from util import GOLDEN, make_sim, standing_state
 
 
-def heights_sim(N, extra=None):
-    d = np.load(os.path.join(GOLDEN, "heights.npz"))
+HEIGHT_FIXTURES = ["heights.npz", "heights_coarse.npz"]      # 187 points on a 0.1 m grid; 15 points, 0.25 m grid, 5 m border
+
+
+def heights_sim(N, extra=None, fname="heights.npz"):
+    d = np.load(os.path.join(GOLDEN, fname))
     ex = {"terrain": dict(measure_heights=True, measured_points_x=[float(x) for x in d["points_x"]],
                           measured_points_y=[float(y) for y in d["points_y"]])}
     for k, v in (extra or {}).items():
@@ -22,9 +25,10 @@ def heights_sim(N, extra=None):
     return d, cfg, S, meta, B
 
 
-def test_height_scan_matches_reference(oracle_lib):
-    d, cfg, S, meta, B = heights_sim(24)
-    assert S.terrain_type == 1 and S.measure_heights == 1 and S.num_height_x * S.num_height_y == 187
+@pytest.mark.parametrize("fname", HEIGHT_FIXTURES)
+def test_height_scan_matches_reference(oracle_lib, fname):
+    d, cfg, S, meta, B = heights_sim(len(np.load(os.path.join(GOLDEN, fname))["root_states"]), fname=fname)
+    assert S.terrain_type == 1 and S.measure_heights == 1 and S.num_height_x * S.num_height_y == d["heights"].shape[1]
     B.commands[4] = 3.0
     B.commands[8] = 0.5
     orc = oracle_lib.Oracle(S, B)
@@ -33,8 +37,9 @@ def test_height_scan_matches_reference(oracle_lib):
 
 
 @pytest.mark.gpu
-def test_hip_height_scan_matches_reference():
-    d, cfg, S, meta, Bc = heights_sim(24)
+@pytest.mark.parametrize("fname", HEIGHT_FIXTURES)
+def test_hip_height_scan_matches_reference(fname):
+    d, cfg, S, meta, Bc = heights_sim(len(np.load(os.path.join(GOLDEN, fname))["root_states"]), fname=fname)
     Bc.commands[4] = 3.0
     Bc.commands[8] = 0.5
     Bg = Bc.clone_to("cuda:0")
@@ -42,6 +47,20 @@ def test_hip_height_scan_matches_reference():
     sim.post_physics([0.0, 0.0, -9.8])
     torch.cuda.synchronize()
     np.testing.assert_allclose(Bg.measured_heights.t().cpu().numpy(), d["heights"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("fname", HEIGHT_FIXTURES)
+def test_emulated_height_scan_matches_reference(fname):
+    """the kernel's own scan code (csrc/go1_maps.h) on the CPU through the SIMT emulator"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
+    import emu_sim
+    d, cfg, S, meta, B = heights_sim(len(np.load(os.path.join(GOLDEN, fname))["root_states"]), fname=fname)
+    B.commands[4] = 3.0
+    B.commands[8] = 0.5
+    sim = emu_sim.EmuSim(S, B)
+    sim.post_physics([0.0, 0.0, -9.8])
+    np.testing.assert_allclose(B.measured_heights.t().numpy(), d["heights"], rtol=0, atol=1e-6)
 
 
 def test_terrain_layout_matches_reference():
