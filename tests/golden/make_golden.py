@@ -1008,6 +1008,45 @@ def gen_pretrain_jit_layout():
     print("pretrain_jit_layout:", out["children"])
 
 
+def gen_rollout(seed=21):
+    """reference go1_gym_learn.ppo_cse rollout path: PPO.act (ppo.py:65-77; sampling from torch's global generator) ->
+    process_env_step (:79-91; time-out bootstrap) for T steps -> compute_returns, on fixed observation streams."""
+    ml = types.ModuleType("ml_logger")
+    ml.logger = object()
+    sys.modules["ml_logger"] = ml
+    from go1_gym_learn.ppo_cse.actor_critic import ActorCritic, AC_Args
+    from go1_gym_learn.ppo_cse.ppo import PPO
+    AC_Args.actor_hidden_dims, AC_Args.critic_hidden_dims, AC_Args.adaptation_module_branch_hidden_dims = [32, 16], [24, 16], [16, 8]
+    N, T, no, npv, H, na = 9, 5, 10, 2, 3, 12
+    torch.manual_seed(seed)
+    ac = ActorCritic(no, npv, no * H, na)
+    init = {k: v.clone() for k, v in ac.state_dict().items()}
+    alg = PPO(ac, device="cpu")
+    alg.init_storage(N, T, [no], [npv], [no * H], [na])
+    g = torch.Generator().manual_seed(seed + 1)
+    r = lambda *s: torch.randn(*s, generator=g)
+    obs, priv, hist = r(T + 1, N, no), r(T + 1, N, npv), r(T + 1, N, no * H)
+    rew = 0.1 * r(T, N)
+    dones = (torch.rand(T, N, generator=g) < 0.2)
+    touts = dones & (torch.rand(T, N, generator=g) < 0.5)
+    bins = torch.randint(0, 50, (T, N), generator=g).float()
+    torch.manual_seed(seed + 2)
+    acts = []
+    for t in range(T):
+        acts.append(alg.act(obs[t], priv[t], hist[t]).clone())
+        alg.process_env_step(rew[t].clone(), dones[t].clone(), {"env_bins": bins[t], "time_outs": touts[t]})
+    alg.compute_returns(hist[T], priv[T])
+    st = alg.storage
+    out = {"init_" + k: v for k, v in init.items()}
+    out.update({"st_" + k: getattr(st, k).clone() for k in ("observations", "privileged_observations", "observation_histories", "actions",
+                                                             "rewards", "dones", "values", "actions_log_prob", "mu", "sigma", "env_bins",
+                                                             "returns", "advantages")})
+    out.update(obs=obs, priv=priv, hist=hist, rew=rew, dones_in=dones, touts=touts, bins=bins, acts=torch.stack(acts),
+               dims=torch.tensor([N, T, no, npv, H, na]), seed=torch.tensor(seed))
+    np.savez_compressed(os.path.join(HERE, "rollout.npz"), **flat(out))
+    print("rollout: bootstrapped", int(touts.sum()), "of", int(dones.sum()), "dones")
+
+
 def gen_callbacks(N=64, seed=51, sim_seed=999, step=200, x_offset_px=0, name="callbacks.npz"):
     """the randomising branches of `_post_physics_step_callback` that scripts/train.py leaves off (legged_robot.py:675-708):
     `_teleport_robots` :1028-1051, `_push_robots` :1017-1026, `_randomize_dof_props` :645-665 and
@@ -1131,6 +1170,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pretrain_jit_layout":  # only pretrain_jit_layout.json
         gen_pretrain_jit_layout()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rollout":              # only rollout.npz
+        gen_rollout()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "heights":              # only heights*.npz
         gen_heights()
         for m in [k for k in sys.modules if k.startswith("go1_gym")]:
@@ -1180,6 +1222,9 @@ if __name__ == "__main__":
         del sys.modules[m]
     gen_ppo_rma()
     gen_ppo_fuzz()
+    for m in [k for k in sys.modules if k.startswith("go1_gym")]:
+        del sys.modules[m]
+    gen_rollout()
     for m in [k for k in sys.modules if k.startswith("go1_gym")]:
         del sys.modules[m]
     gen_heights()

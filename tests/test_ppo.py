@@ -297,3 +297,31 @@ def test_recurrent_mini_batches_match_reference():
         assert len(batch) == 12
         for j, t in enumerate(batch):
             assert np.array_equal(t.numpy(), d[f"b{i}_{j}"]), (i, j)
+
+
+def test_rollout_path_matches_reference(small_ac_args):
+    """PPO.act -> process_env_step x T -> compute_returns against the reference classes on the same observation streams and the
+    same global-generator seed (rollout.npz): sampled actions, log-probabilities, values, the time-out bootstrap of the rewards
+    (ppo.py:83-86), what the storage holds, returns and advantages."""
+    from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
+    from go1_gym_learn.ppo_cse.ppo import PPO
+    d = np.load(os.path.join(GOLDEN, "rollout.npz"))
+    N, T, no, npv, H, na = [int(x) for x in d["dims"]]
+    ac = ActorCritic(no, npv, no * H, na)
+    ac.load_state_dict({k[5:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("init_")})
+    alg = PPO(ac, device="cpu")
+    alg.init_storage(N, T, [no], [npv], [no * H], [na])
+    t_ = lambda k: torch.from_numpy(d[k])
+    torch.manual_seed(int(d["seed"]) + 2)
+    for t in range(T):
+        a = alg.act(t_("obs")[t], t_("priv")[t], t_("hist")[t])
+        np.testing.assert_allclose(a.numpy(), d["acts"][t], rtol=1e-5, atol=1e-6)
+        alg.process_env_step(t_("rew")[t].clone(), t_("dones_in")[t].clone(), {"env_bins": t_("bins")[t], "time_outs": t_("touts")[t]})
+    alg.compute_returns(t_("hist")[T], t_("priv")[T])
+    st = alg.storage
+    for k in ("observations", "privileged_observations", "actions", "rewards", "values", "actions_log_prob", "mu", "sigma", "env_bins",
+              "returns", "advantages"):
+        np.testing.assert_allclose(getattr(st, k).numpy(), d["st_" + k], rtol=2e-5, atol=2e-5, err_msg=k)
+    assert np.array_equal(st.dones.numpy().astype(bool), d["st_dones"].astype(bool))
+    np.testing.assert_allclose(st.observation_histories[..., :no * H].float().numpy(), d["st_observation_histories"], rtol=1e-6, atol=1e-6)
+    assert np.abs(d["st_rewards"][..., 0] - d["rew"]).max() > 0.05                       # the bootstrap did act
