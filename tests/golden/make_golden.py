@@ -1283,3 +1283,5 @@ if __name__ == "__main__":
     gen_cfg_defaults()
     gen_history_trace()
     gen_pretrain_jit_layout()
+    import subprocess
+    subprocess.check_call([sys.executable, os.path.join(HERE, "gen_runner_iteration.py")])      # (its own interpreter: two go1_gym_learn packages)

@@ -244,3 +244,45 @@ def test_every_configuration_default_equals_the_reference():
     assert not any(wrong.values()), wrong
     added = sorted({d[0] for v in diffs.values() for d in v if d[2] == "<absent>"})
     print("keys added by this repo:", added)
+
+
+def test_runner_reproduces_the_reference_runner_end_to_end(monkeypatch, tmp_path):
+    """Two learning iterations of the product's `Runner` (restructured PPO: fused first layer, flat gradient buffer, explicit
+    Gaussian algebra, lazy episode statistics) against the REFERENCE Runner / PPO / ActorCritic / RolloutStorage driving the same
+    environment from the same seeds (tests/golden/runner_iteration.npz, gen_runner_iteration.py): same last rollout, same
+    learning rate, same weights.  Episodes end and restart inside the run (time-outs with value bootstrap, falls)."""
+    import json
+    import sys
+    import numpy as np
+    import torch
+    import fake_sim
+    from util import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import gen_runner_iteration as G
+    from go1_gym_learn.ppo_cse import Runner, RunnerArgs
+    from go1_gym_learn.ppo_cse.actor_critic import AC_Args
+    from ml_logger import logger
+    d = np.load(os.path.join(GOLDEN, "runner_iteration.npz"))
+    st_ = json.loads(str(d["settings"]))
+    fake_sim.install(monkeypatch)
+    env = G.build_env(st_)
+    logger.configure("runner_iteration", root=str(tmp_path))
+    logger.print_summary = False
+    monkeypatch.chdir(tmp_path)
+    for k, v in (("actor_hidden_dims", st_["actor"]), ("critic_hidden_dims", st_["critic"]), ("adaptation_module_branch_hidden_dims", st_["adaptation"])):
+        monkeypatch.setattr(AC_Args, k, v)
+    monkeypatch.setattr(RunnerArgs, "num_steps_per_env", st_["num_steps_per_env"])
+    monkeypatch.setattr(RunnerArgs, "save_video_interval", 0)
+    torch.manual_seed(st_["seed"] + 1)
+    runner = Runner(env, device="cpu")
+    for k, v in runner.alg.sync_module().state_dict().items():
+        assert np.array_equal(v.numpy(), d["init_" + k]), k                     # same initialisation from the same seed
+    runner.learn(num_learning_iterations=st_["iterations"], init_at_random_ep_len=False, eval_freq=100)
+    st = runner.alg.storage
+    assert int(d["last_dones"].sum()) > 0 and runner.tot_timesteps == int(d["tot_timesteps"])
+    assert np.array_equal(st.dones.numpy().astype(bool), d["last_dones"].astype(bool))
+    for k, tol in (("actions", 1e-4), ("rewards", 1e-4), ("values", 1e-4), ("returns", 1e-4), ("advantages", 1e-3)):
+        np.testing.assert_allclose(getattr(st, k).numpy(), d["last_" + k], rtol=tol, atol=tol, err_msg=k)
+    assert runner.alg.learning_rate == pytest.approx(float(d["lr"]), rel=1e-6)
+    for k, v in runner.alg.sync_module().state_dict().items():
+        np.testing.assert_allclose(v.numpy(), d["final_" + k], rtol=1e-3, atol=1e-4, err_msg=k)

@@ -626,6 +626,11 @@ class PPO:
         for epoch in range(A.num_learning_epochs):
             for i in range(nmb):
                 idx = self._idx_all[i]
+                if not self.on_gpu:
+                    # the reference's update() calls actor_critic.act(...) for every mini-batch (ppo.py:107): the sample is thrown
+                    # away but advances torch's generator.  Same consumption here, so that a CPU run follows the reference's
+                    # random stream over any number of iterations (tests/golden/runner_iteration.npz); not on the GPU path.
+                    torch.randn(mb, self.n_std)
                 if self.fused:
                     self._train_net.X = self._Xall[i]
                 if graph_mode:
