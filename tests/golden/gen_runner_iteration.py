@@ -18,7 +18,10 @@ PKG = os.path.join(REPO, "walk-these-ways_amd")
 REF = "/root/reference"
 
 SETTINGS = dict(num_envs=32, num_steps_per_env=6, iterations=2, actor=[32, 16], critic=[24, 16], adaptation=[16, 8], seed=0,
-                episode_length_s=0.16)
+                episode_length_s=0.16, num_eval_envs=0, name="runner_iteration.npz")
+# the same with 16 evaluation environments behind the training ones (eval_cfg: the Runner appends the deterministic student
+# actions for them, ppo_cse/__init__.py:139-147, and learns from the training ones only)
+SETTINGS_EVAL = dict(SETTINGS, num_eval_envs=16, seed=3, name="runner_iteration_eval.npz")
 
 
 def build_env(settings):
@@ -31,11 +34,17 @@ def build_env(settings):
     cfg = apply_train_config(make_cfg(), num_envs=settings["num_envs"])
     cfg.terrain.mesh_type = "plane"
     cfg.env.episode_length_s = settings["episode_length_s"]          # resets and time-outs inside the two iterations
+    ev = None
+    if settings.get("num_eval_envs", 0):
+        ev = apply_train_config(make_cfg(), num_envs=settings["num_eval_envs"])
+        ev.terrain.mesh_type = "plane"
+        ev.env.episode_length_s = settings["episode_length_s"]
+        ev.domain_rand.friction_range = [2.0, 2.5]
     torch.manual_seed(settings["seed"])
-    return HistoryWrapper(VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg))
+    return HistoryWrapper(VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg, eval_cfg=ev))
 
 
-def main():
+def main(SETTINGS):
     for p in (os.path.join(PKG, "shims"), PKG, os.path.join(REPO, "oracle"), REPO, TESTS):
         sys.path.insert(0, p)
     import numpy as np
@@ -72,10 +81,10 @@ def main():
                last_returns=st.returns.numpy(), last_advantages=st.advantages.numpy(), lr=np.array(runner.alg.learning_rate),
                tot_timesteps=np.array(runner.tot_timesteps))
     import json
-    np.savez_compressed(os.path.join(HERE, "runner_iteration.npz"), settings=np.array(json.dumps(SETTINGS)), **out)
-    print("runner_iteration: dones in the last rollout", int(st.dones.sum()), "lr", runner.alg.learning_rate, "timesteps", runner.tot_timesteps)
+    np.savez_compressed(os.path.join(HERE, SETTINGS["name"]), settings=np.array(json.dumps(SETTINGS)), **out)
+    print(SETTINGS["name"], "dones in the last rollout", int(st.dones.sum()), "lr", runner.alg.learning_rate, "timesteps", runner.tot_timesteps)
     mp.undo()
 
 
 if __name__ == "__main__":
-    main()
+    main(SETTINGS_EVAL if sys.argv[1:] == ["eval"] else SETTINGS)

@@ -1285,3 +1285,4 @@ if __name__ == "__main__":
     gen_pretrain_jit_layout()
     import subprocess
     subprocess.check_call([sys.executable, os.path.join(HERE, "gen_runner_iteration.py")])      # (its own interpreter: two go1_gym_learn packages)
+    subprocess.check_call([sys.executable, os.path.join(HERE, "gen_runner_iteration.py"), "eval"])

@@ -246,7 +246,8 @@ def test_every_configuration_default_equals_the_reference():
     print("keys added by this repo:", added)
 
 
-def test_runner_reproduces_the_reference_runner_end_to_end(monkeypatch, tmp_path):
+@pytest.mark.parametrize("fname", ["runner_iteration.npz", "runner_iteration_eval.npz"])
+def test_runner_reproduces_the_reference_runner_end_to_end(monkeypatch, tmp_path, fname):
     """Two learning iterations of the product's `Runner` (restructured PPO: fused first layer, flat gradient buffer, explicit
     Gaussian algebra, lazy episode statistics) against the REFERENCE Runner / PPO / ActorCritic / RolloutStorage driving the same
     environment from the same seeds (tests/golden/runner_iteration.npz, gen_runner_iteration.py): same last rollout, same
@@ -262,7 +263,7 @@ def test_runner_reproduces_the_reference_runner_end_to_end(monkeypatch, tmp_path
     from go1_gym_learn.ppo_cse import Runner, RunnerArgs
     from go1_gym_learn.ppo_cse.actor_critic import AC_Args
     from ml_logger import logger
-    d = np.load(os.path.join(GOLDEN, "runner_iteration.npz"))
+    d = np.load(os.path.join(GOLDEN, fname))                      # (the second: 16 evaluation environments behind the 32 training ones)
     st_ = json.loads(str(d["settings"]))
     fake_sim.install(monkeypatch)
     env = G.build_env(st_)
