@@ -287,3 +287,48 @@ def test_runner_reproduces_the_reference_runner_end_to_end(monkeypatch, tmp_path
     assert runner.alg.learning_rate == pytest.approx(float(d["lr"]), rel=1e-6)
     for k, v in runner.alg.sync_module().state_dict().items():
         np.testing.assert_allclose(v.numpy(), d["final_" + k], rtol=1e-3, atol=1e-4, err_msg=k)
+
+
+REF_WRAPPER = "/root/reference/go1_gym/envs/wrappers/history_wrapper.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_WRAPPER), reason="reference tree not present")
+def test_reference_history_wrapper_over_this_environment(monkeypatch):
+    """The REFERENCE `HistoryWrapper` class (history_wrapper.py:6-41, `torch.cat` of the history every call) wrapped around this
+    repository's environment, next to the product's wrapper (a window of the ring the simulator appends to) around an identical
+    second environment: same observation dicts call by call — reset, the extra shift of get_observations, steps across episode
+    ends (the history is not cleared when an environment resets)."""
+    import numpy as np
+    import torch
+    import fake_sim
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+    from go1_gym.envs.wrappers.history_wrapper import HistoryWrapper
+    from scripts.train_config import apply_train_config
+    fake_sim.install(monkeypatch)
+    spec = importlib.util.spec_from_file_location("_ref_history_wrapper", REF_WRAPPER)
+    ref_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_mod)
+
+    def build():
+        cfg = apply_train_config(make_cfg(), num_envs=16)
+        cfg.terrain.mesh_type = "plane"
+        cfg.env.episode_length_s = 0.2                 # episodes end inside the run
+        cfg.env.num_observation_history = 5
+        torch.manual_seed(0)
+        return VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg)
+    mine, ref = HistoryWrapper(build()), ref_mod.HistoryWrapper(build())
+    assert (mine.num_obs_history, mine.obs_history_length) == (ref.num_obs_history, ref.obs_history_length) == (350, 5)
+    g = torch.Generator().manual_seed(1)
+    resets = 0
+    for call in ["reset", "get_observations"] + ["step"] * 7 + ["get_observations"] + ["step"] * 9 + ["reset", "step", "step"]:
+        if call == "step":
+            a = 0.5 * torch.randn(16, 12, generator=g)
+            (om, rm, dm, _), (orf, rr, dr, _) = mine.step(a.clone()), ref.step(a.clone())
+            assert torch.equal(rm, rr) and torch.equal(dm, dr)
+            resets += int(dm.sum())
+        else:
+            om, orf = getattr(mine, call)(), getattr(ref, call)()
+        for k in ("obs", "privileged_obs", "obs_history"):
+            assert torch.equal(om[k], orf[k]), (call, k, float((om[k] - orf[k]).abs().max()))
+    assert resets > 0

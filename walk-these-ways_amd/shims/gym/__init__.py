@@ -22,6 +22,23 @@ class Wrapper(Env):
     def unwrapped(self):
         return getattr(self.env, "unwrapped", self.env)
 
+    # gym.Wrapper's explicit delegations: subclasses reach them through super() (the reference HistoryWrapper calls
+    # super().reset(), history_wrapper.py:38 — attribute fall-through does not serve super objects)
+    def step(self, action):
+        return self.env.step(action)
+
+    def reset(self, **kwargs):
+        return self.env.reset(**kwargs)
+
+    def render(self, mode="human", **kwargs):
+        return self.env.render(mode, **kwargs)
+
+    def close(self):
+        return self.env.close()
+
+    def seed(self, seed=None):
+        return self.env.seed(seed)
+
 
 class spaces:  # noqa: N801
     pass
