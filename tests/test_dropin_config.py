@@ -69,7 +69,9 @@ def test_reference_train_script_runs_one_iteration_end_to_end(monkeypatch, tmp_p
     (train.py:207-216): env construction, HistoryWrapper, logger.log_params / log_text, Runner with RunnerArgs,
     one full PPO iteration (rollout, GAE, update, metrics, checkpoint + TorchScript export).  No GPU in this container:
     the simulator handle is the oracle-backed stand-in (tests/fake_sim.py) on CPU buffers, the env is shrunk to 48
-    robots and the Runner is pointed at 'cpu'; every class in between is the product's."""
+    robots and the Runner is pointed at 'cpu'; every class in between is the product's.  Then the reference's scripts/play.py
+    on the run directory this produced: `load_policy` on the exported TorchScript files and `play_go1` verbatim (configuration
+    read back from the logged parameters.pkl, one environment, 250 policy steps)."""
     import fake_sim
     import go1_gym.envs.go1.velocity_tracking as vt
     import go1_gym_learn.ppo_cse as runner_mod
@@ -114,6 +116,32 @@ def test_reference_train_script_runs_one_iteration_end_to_end(monkeypatch, tmp_p
     assert (ck / "ac_weights_last.pt").exists() and (ck / "adaptation_module_latest.jit").exists() and (ck / "body_latest.jit").exists()
     from util import check_exported_policy_layout
     check_exported_policy_layout(str(ck))
+    # ... and the reference's own play.py loader (`load_policy`, play.py:17-29) turns that run directory into a policy
+    import torch
+    spec = importlib.util.spec_from_file_location("ref_play", "/root/reference/scripts/play.py")
+    play = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(play)
+    policy = play.load_policy(str(tmp_path / "dropin"))
+    info = {}
+    act = policy({"obs_history": torch.randn(5, 2100)}, info)
+    assert act.shape == (5, 12) and info["latent"].shape == (5, 2) and bool(torch.isfinite(act).all())
+    # ... and `play_go1` verbatim (play.py:89-157): the run directory found by its glob, `parameters.pkl` as train.py logged it
+    # read back into Cfg, one environment, the policy in the loop for 250 steps, the two plots (Agg backend)
+    import matplotlib
+    matplotlib.use("Agg")
+    run = tmp_path / "runs" / "gait-conditioned-agility" / "pretrain-v0" / "train"
+    run.mkdir(parents=True)
+    os.symlink(tmp_path / "dropin", run / "000000.000000")
+    (tmp_path / "scripts").mkdir()
+    monkeypatch.chdir(tmp_path / "scripts")
+    monkeypatch.setattr(vt, "VelocityTrackingEasyEnv", real_env)           # (play.py builds its single environment itself)
+    monkeypatch.setattr(play, "VelocityTrackingEasyEnv", real_env)
+    monkeypatch.setattr(play, "tqdm", lambda it: it)
+    fresh = make_cfg()                                                     # (play.py runs in its own process: a pristine Cfg)
+    monkeypatch.setattr(legged_robot_config, "Cfg", fresh)
+    monkeypatch.setattr(play, "Cfg", fresh)
+    play.play_go1(headless=True)
+    monkeypatch.chdir(tmp_path)
     metrics = logger.load_pkl("metrics.pkl")
     assert metrics and metrics[-1]["timesteps"] == 24 * 48
     assert any(k.startswith("train/episode/rew_") for k in metrics[-1])
