@@ -125,6 +125,15 @@ def test_reference_train_script_runs_one_iteration_end_to_end(monkeypatch, tmp_p
     info = {}
     act = policy({"obs_history": torch.randn(5, 2100)}, info)
     assert act.shape == (5, 12) and info["latent"].shape == (5, 2) and bool(torch.isfinite(act).all())
+    # ... the REFERENCE ActorCritic loads the weights file strictly (its own interpreter: the package names collide)
+    import subprocess
+    code = ("import sys, torch; sys.path[:0] = [%r, '/root/reference']; "
+            "from go1_gym_learn.ppo_cse.actor_critic import ActorCritic; import go1_gym_learn; "
+            "assert go1_gym_learn.__file__.startswith('/root/reference'); ac = ActorCritic(70, 2, 2100, 12); "
+            "r = ac.load_state_dict(torch.load(%r, map_location='cpu'), strict=True); print('LOADED', r)"
+            % (os.path.join(os.path.dirname(__file__), "..", "walk-these-ways_amd", "shims"), str(ck / "ac_weights_last.pt")))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "LOADED <All keys matched successfully>" in res.stdout, res.stdout[-500:] + res.stderr[-1500:]
     # ... and `play_go1` verbatim (play.py:89-157): the run directory found by its glob, `parameters.pkl` as train.py logged it
     # read back into Cfg, one environment, the policy in the loop for 250 steps, the two plots (Agg backend)
     import matplotlib
