@@ -276,3 +276,33 @@ def test_step_extras_carry_the_reference_keys_and_values(monkeypatch):
     assert torch.equal(ex["joint_vel_target"], torch.zeros(12)) and ex["privileged_obs"] is env.privileged_obs_buf
     assert ex["contact_states"].dtype == np.bool_ and ex["foot_positions"].shape == (16, 4, 3)
     assert {"env_bins", "time_outs", "train/episode"} <= set(ex)
+
+
+def test_initial_dynamics_dict_presets(monkeypatch):
+    """`initial_dynamics_dict` (velocity_tracking/__init__.py:11, legged_robot.py:1283-1288): preset per-environment dynamics
+    parameters survive construction for the quantities whose randomisation switch is off and are re-drawn for those whose
+    switch is on (the set-up draw of :1548 comes after the preset); motor strengths last until the first reset re-draws them."""
+    import fake_sim
+    from go1_gym.envs.base.legged_robot_config import make_cfg
+    from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
+    from scripts.train_config import apply_train_config
+    fake_sim.install(monkeypatch)
+    N = 16
+    cfg = apply_train_config(make_cfg(), num_envs=N)
+    cfg.terrain.mesh_type = "plane"
+    dr = cfg.domain_rand
+    dr.randomize_friction, dr.randomize_restitution, dr.randomize_base_mass = False, True, False
+    preset = dict(friction_coeffs=torch.full((N, 4), 0.77), restitutions=torch.full((N, 4), 0.9), payloads=torch.full((N,), 2.5),
+                  com_displacements=torch.full((N, 3), 0.05), motor_strengths=torch.full((N, 12), 1.07),
+                  Kp_factors=torch.full((N, 12), 1.2), Kd_factors=torch.full((N, 12), 0.8))
+    torch.manual_seed(0)
+    env = VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg, initial_dynamics_dict=preset)
+    B = env.buffers
+    assert bool((B.friction_coeffs == 0.77).all()) and bool((B.payloads == 2.5).all())                 # switches off: kept
+    assert bool((B.restitutions <= 0.4).all()) and not bool((B.restitutions == 0.9).any())              # switch on: re-drawn in range
+    assert bool((env.com_displacements == 0.05).all()) and bool((env.Kp_factors == 1.2).all()) and bool((env.Kd_factors == 0.8).all())
+    assert bool((env.motor_strengths == 1.07).all())
+    assert env.friction_coeffs.shape == (N, 4) and float(env.friction_coeffs[3, 2]) == pytest.approx(0.77)
+    env.reset()                                           # reset_idx re-draws the DOF properties (:164)
+    assert not bool((env.motor_strengths == 1.07).any()) and bool(((env.motor_strengths >= 0.9) & (env.motor_strengths <= 1.1)).all())
+    assert bool((B.friction_coeffs == 0.77).all())

@@ -337,8 +337,8 @@ class LeggedRobot(BaseTask):
         randomize_rigids_after_start, which is not on the train.py path)."""
         B, dr, n = self.buffers, cfg.domain_rand, len(env_ids)
         u = lambda rng, *shape: torch.rand(*shape, device=self.device) * (rng[1] - rng[0]) + rng[0]
-        if self.initial_dynamics_dict is not None:
-            return
+        # (values preset through `initial_dynamics_dict` are overwritten by this draw when the switch of their quantity is on, as in
+        # the reference: _init_custom_buffers__ :1283-1288 runs before it, :1547-1548)
         if dr.randomize_base_mass:
             B.payloads[env_ids] = u(dr.added_mass_range, n)
         if dr.randomize_com_displacement:
