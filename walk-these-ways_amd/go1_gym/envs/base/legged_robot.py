@@ -18,7 +18,7 @@ from go1_gym.envs.base.base_task import BaseTask
 from go1_gym.utils.terrain import Terrain
 
 
-class _LazyExtras(Mapping):
+class _LazyMapping(Mapping):
     """Base of the `extras` entries that are evaluated on access.  Pickled (the reference Runner dumps
     `extras["curriculum/distribution"]` with `logger.save_pkl`, ppo_cse/__init__.py:200-208) and deep-copied as the plain dict
     of their current values — never as a reference to the environment."""
@@ -27,7 +27,7 @@ class _LazyExtras(Mapping):
         return (dict, (dict(self.items()),))
 
 
-class _EpisodeStats(_LazyExtras):
+class _EpisodeStats(_LazyMapping):
     """`extras["train/episode"]` (reference legged_robot.py:181-227): means of the per-term episode sums over the
     environments that were reset, plus command-range statistics.  Evaluated lazily on access (device reductions,
     no work and no sync inside step()); the running sums are kept by the kernel in `episode_log`."""
@@ -80,7 +80,7 @@ class _EpisodeStats(_LazyExtras):
         return out
 
 
-class _CurriculumDistribution(_LazyExtras):
+class _CurriculumDistribution(_LazyMapping):
     """`extras["curriculum/distribution"]` (reference legged_robot.py:229-232)."""
 
     def __init__(self, env):
@@ -101,7 +101,7 @@ class _CurriculumDistribution(_LazyExtras):
         return self.env.curricula[i].weights if kind == "weights" else self.env.curricula[i].grid
 
 
-class _SimFaults(_LazyExtras):
+class _SimFaults(_LazyMapping):
     """`extras["sim_faults"]`: occurrences per fault site since the counters were last consumed (include/go1sim.h
     `Go1FaultBit`).  The reference has no such entry — PhysX never returns a non-finite state; here every containment
     of a failed environment is reported instead of hidden.  Lazy: device reads happen on access only."""
