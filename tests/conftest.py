@@ -31,7 +31,7 @@ _RUN_LATE = ("test_two_rank", "test_ppo_learns_on_the_hip_simulator", "test_free
              "test_runner_learns_and_exports", "test_teacher_student_runner", "test_distributed")
 # cases added after the last run on hardware (validated through the emulated kernel only): behind everything proven
 _RUN_LAST = ("maps_fuzz", "maps_alt2", "maps_train_noise", "test_hip_callbacks", "test_ragged_env_counts", "gaitwise_smooth",
-             "exclusive_smooth", "balance_binary", "plain_binary", "act_nolag", "pd_lag", "heights_coarse")
+             "exclusive_smooth", "balance_binary", "plain_binary", "act_nolag", "pd_lag", "heights_coarse", "test_full_step_under_random_configurations")
 
 
 def _rank(nodeid):

@@ -185,6 +185,40 @@ def test_ragged_env_counts_match_oracle(variant, N):
     assert worst * N <= 2.01 and mean * steps * N <= (2.01 if N == 1 else 6.01), (worst, mean)
 
 
+@pytest.mark.parametrize("case", range(6))
+def test_full_step_under_random_configurations(case):
+    """configuration fuzz on the hardware (fixed seeds; the generator of tests/golden/variants.py, the same that drives the emulated
+    kernel's fuzz in tests/test_emu_parity.py): random consistent sets of observation / privileged-observation / controller /
+    reward / termination / command switches, HIP step vs oracle on identical streams, re-synchronised every step; the bound is
+    the one of test_full_step_matches_oracle scaled to 128 environments (at most three outside the tolerances in a step)."""
+    from golden.variants import random_switches
+    rng = np.random.default_rng(1000 + case)
+    extra = random_switches(rng)
+    N, steps = 128, 6
+    cfg, S, meta, Bc, orc = gpu_pair("train_noise", N, seed=40 + case, extra=extra)
+    Bg, sim = to_gpu(S, Bc)
+    Bc.episode_length_buf[:] = torch.randint(0, int(S.max_episode_length), (N,), dtype=torch.int32, generator=torch.Generator().manual_seed(case))
+    sync_from(Bc, Bg, sim, orc)
+    worst = 0
+    for step in range(steps):
+        a = (rng.standard_normal((N, 12)) * (2.0 if step == 1 else 0.5)).astype(np.float32)
+        orc.step(a)
+        sim.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        bad_env = Bg.reset_buf.cpu().bool() != Bc.reset_buf.bool()
+        for k, tol, rt in (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
+                           ("commands", 1e-5, 0), ("torques", 5e-3, 1e-3), ("episode_sums", 1e-3, 1e-3), ("command_sums", 1e-3, 1e-3)):
+            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], tol, rt)
+            bad_env |= bad.reshape(-1, N).any(0)
+        for k in ("obs_buf", "privileged_obs_buf"):
+            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], 3e-3, 1e-3)
+            bad_env |= bad.any(1)
+        worst = max(worst, int(bad_env.sum()))
+        sync_from(Bc, Bg, sim, orc)
+    assert worst <= 3, (worst, extra)
+    assert int(Bg.fault_counts[:10].sum()) == 0
+
+
 def test_push_teleport_and_rigid_rerandomisation_match_oracle():
     """The step-callback branches train.py leaves switched off — velocity pushes (north_star's "domain-randomisation
     pushes", legged_robot.py:1017-1026), edge teleport (:1028-1051) and re-drawn rigid-body properties
