@@ -225,8 +225,13 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dp = os.environ.get("GO1_FORCE_DP", "0") not in ("", "0")        # one-rank process group: the DP path on a 1-GPU box
+    use_dist = world > 1 or force_dp
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import datetime
         tmo = datetime.timedelta(seconds=600)          # ranks may start minutes apart (first `import torch` on a fresh box); a dead peer must not hang the job
         if args.backend == "gloo":
@@ -235,6 +240,29 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
             dist.init_process_group(args.backend, timeout=tmo)
+
+    dp_trace = None
+    if os.environ.get("GO1_DP_TRACE", "0") not in ("", "0") and use_dist:
+        # count what actually executes (tests/test_gpu_env.py, the one-rank RCCL run): collectives by kind, graph replays
+        dp_trace = {"backend": dist.get_backend(), "all_reduce": 0, "curriculum_all_reduce": 0, "reduce_scatter": 0, "all_gather": 0,
+                    "broadcast": 0, "graph_replays": 0}
+
+        def _counted(name, fn):
+            def wrapped(t, *a, **k):
+                key = "curriculum_all_reduce" if name == "all_reduce" and t.dtype == torch.int32 else name
+                dp_trace[key] += 1
+                return fn(t, *a, **k)
+            return wrapped
+        dist.all_reduce = _counted("all_reduce", dist.all_reduce)
+        dist.reduce_scatter_tensor = _counted("reduce_scatter", dist.reduce_scatter_tensor)
+        dist.all_gather_into_tensor = _counted("all_gather", dist.all_gather_into_tensor)
+        dist.broadcast = _counted("broadcast", dist.broadcast)
+        _replay = torch.cuda.CUDAGraph.replay
+
+        def replay(self):
+            dp_trace["graph_replays"] += 1
+            return _replay(self)
+        torch.cuda.CUDAGraph.replay = replay
 
     from go1_gym_learn.ppo_cse import Runner, RunnerArgs
     from go1_gym_learn.ppo_cse.ppo import PPO_Args
@@ -284,7 +312,7 @@ def main():
         return obs_dict
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -298,12 +326,15 @@ def main():
         obs_dict = sim_iteration(obs_dict, acts) if args.sim_only else iteration(obs_dict)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
     kernel_ms = sim.read_timings()
+    if dp_trace is not None and rank == 0:
+        dp_trace.update(dp=bool(runner.alg.dp), curriculum_sync=bool(env.env._curriculum_sync), world=world)
+        print("[dp-trace]" + json.dumps(dp_trace), file=sys.stderr)
     if args.breakdown and rank == 0:
         n_it = args.steps
         print(f"[breakdown] rollout {1e3 * split['rollout'] / n_it:.1f} ms/iter, update {1e3 * split['update'] / n_it:.1f} ms/iter", file=sys.stderr)
@@ -354,7 +385,7 @@ def main():
                        "physics_dtype": "f32", "step": "one PPO iteration = 24 x envs env-steps + update",
                        "parallelism": (f"dp{world} (envs sharded, {args.backend} gradient "
                                        f"{'reduce-scatter + sharded step + all-gather' if args.zero1 else 'all-reduce'}, {args.grad_dtype})")
-                       if world > 1 else "single GPU"},
+                       if use_dist else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "go1_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": avg_ms, "launches": len(kernel_ms), "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -375,7 +406,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.envs)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -177,13 +177,14 @@ int go1ppo_opt_prestep(const float* g, int64_t n, float gscale, float* partial, 
 /* Adam (no weight decay, no amsgrad) on the elements [start0, start0+count0) U [start1, start1+count1) of the flat
  * parameter p with gradient g * gscale * clip, clip = min(1, max_norm / (sqrt(sum partial) + 1e-6)) (partial == NULL:
  * no clipping).  Refreshes the compute copies of the touched elements: body[i] (bf16) for i < n_body, tail[i - n_body]
- * (fp32) behind it.  step / lr are the device scalars go1ppo_opt_prestep maintains.
+ * (fp32) for i - n_body < n_tail behind it (elements beyond have no compute copy).  count0 + count1 == 0 is allowed (only
+ * zero_slot is cleared).  step / lr are the device scalars go1ppo_opt_prestep maintains.
  * zero_grad != 0: every visited g[i] is cleared after it has been read (the following backward pass accumulates into a
  * clean gradient without a fill pass of its own); zero_slot (or NULL): one more float cleared — the KL accumulator that
  * rides in the gradient's padding. */
 int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t start0, int64_t count0, int64_t start1,
                     int64_t count1, float gscale, const float* partial, float max_norm, const float* step, const float* lr,
-                    float beta1, float beta2, float eps, void* body, int64_t n_body, float* tail, int zero_grad,
+                    float beta1, float beta2, float eps, void* body, int64_t n_body, float* tail, int64_t n_tail, int zero_grad,
                     float* zero_slot, void* stream);
 
 /* ---- MLP-layer GEMM with fused epilogue (replaces torch.addmm + F.elu / the ELU-backward map around it) ---- */

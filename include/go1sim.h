@@ -102,7 +102,7 @@ enum Go1FaultBit {
   GO1_FAULT_LIMIT_SAFETY = 11,  /* a joint left its limit rows' band by more than the safety factor and was cut (count only) */
   GO1_FAULT_BITS = 16
 };
-#define GO1_FAULT_FATAL_MASK 0x3FFu   /* bits that mean "simulation failed" (everything except CONTACT_DROPPED) */
+#define GO1_FAULT_FATAL_MASK 0x3FFu   /* bits 0..9: "simulation failed"; CONTACT_DROPPED and LIMIT_SAFETY are count-only */
 
 /* Everything that the reference reads from `Cfg` on the hot path, flattened.
  * Filled by the host mirror of LeggedRobot._parse_cfg/_init_buffers
@@ -307,7 +307,9 @@ typedef struct Go1Sim Go1Sim;      /* opaque handle */
 int go1sim_create(const Go1SimConfig* cfg, const Go1SimBuffers* buffers, int device, Go1Sim** out);
 int go1sim_destroy(Go1Sim* sim);
 
-/* Update config fields that scripts mutate after construction (e.g. play.py changes ranges). */
+/* Update config fields that scripts mutate after construction (e.g. play.py changes ranges).  Replaces the TRAIN block only:
+ * with an evaluation split installed, follow it with go1sim_set_eval_config(new cfg + the group-dispatched fields) so that the
+ * evaluation block does not keep the old rewards / commands / control / physics (the host mirror does: Go1Sim.set_config). */
 int go1sim_set_config(Go1Sim* sim, const Go1SimConfig* cfg);
 
 /* Train / evaluation split (reference `eval_cfg`: base_task.py:43-49, legged_robot.py:531-544 `_call_train_eval`): the

@@ -30,8 +30,8 @@ def oracle_lib():
 _RUN_LATE = ("test_two_rank", "test_ppo_learns_on_the_hip_simulator", "test_free_running_distributions",
              "test_runner_learns_and_exports", "test_teacher_student_runner", "test_distributed")
 # cases added after the last run on hardware (validated through the emulated kernel only): behind everything proven
-_RUN_LAST = ("maps_fuzz", "maps_alt2", "maps_train_noise", "test_hip_callbacks", "test_ragged_env_counts", "gaitwise_smooth",
-             "exclusive_smooth", "balance_binary", "plain_binary", "act_nolag", "pd_lag", "heights_coarse", "test_full_step_under_random_configurations")
+# (everything listed here in round 2 passed on hardware at that round's end: GPUTEST_r02.json, 128 passed)
+_RUN_LAST = ("test_wall_", "test_rccl_", "test_zero1_", "test_ring_rows_with_wide", "ppo_fuzz", "test_play_eval")
 
 
 def _rank(nodeid):
@@ -40,5 +40,18 @@ def _rank(nodeid):
     return 1 if any(k in nodeid for k in _RUN_LATE) else 0
 
 
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
 def pytest_collection_modifyitems(config, items):
     items.sort(key=lambda it: _rank(it.nodeid))          # stable: file order otherwise kept
+    if not _have_gpu():                                   # a plain `pytest` on a box without an MI355X: skipped, not failed
+        skip = pytest.mark.skip(reason="needs a real MI355X (torch.cuda.is_available() is False)")
+        for it in items:
+            if "gpu" in it.keywords:
+                it.add_marker(skip)

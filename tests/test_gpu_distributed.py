@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, zero1=False, grad_dtype="fp32"):
     sys.path[:0] = [os.path.join(HERE, "..", "walk-these-ways_amd", "shims"), os.path.join(HERE, "..", "walk-these-ways_amd")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # (gloo otherwise resolves the host name, which may not resolve in a container)
@@ -24,6 +24,7 @@ def _worker(rank, world, port, out):
     from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
     from go1_gym_learn.ppo_cse.ppo import PPO, PPO_Args
     PPO_Args.autocast_bf16, PPO_Args.use_fused_kernels, PPO_Args.use_hip_graphs = True, True, True
+    PPO_Args.dp_zero1, PPO_Args.dp_grad_dtype = bool(zero1), grad_dtype
     N, T = 256, 8
     torch.manual_seed(100 + rank)                     # different initial weights: rank 0's are broadcast
     alg = PPO(ActorCritic(70, 2, 2100, 12), device="cuda:0")
@@ -41,7 +42,10 @@ def _worker(rank, world, port, out):
         alg.compute_returns(hist, priv)
         losses = alg.update()
     torch.cuda.synchronize()
-    out[rank] = dict(w=alg.master.cpu().clone(), lr=alg.learning_rate, dp=alg.dp, fused=alg.fused, graphs=bool(alg._graphs),
+    live = alg.n_body + alg.n_std
+    out[rank] = dict(pad=alg.master[live:].cpu().clone(), m_pad=(alg._opt.m[live:].abs().sum().item() if alg._opt is not None else 0.0),
+                     std=alg.std.detach().cpu().clone(), w_std=alg.master[alg.n_body:live].cpu().clone(),
+                     w=alg.master.cpu().clone(), lr=alg.learning_rate, dp=alg.dp, fused=alg.fused, graphs=bool(alg._graphs),
                      n_graphs=len(next(iter(alg._graphs.values()))) if alg._graphs else 0, n_sets=len(alg._graphs), losses=losses)
     dist.destroy_process_group()
 
@@ -65,3 +69,29 @@ def test_two_rank_fused_update_keeps_replicas_identical():
     assert torch.equal(a["w"], b["w"])
     assert a["lr"] == b["lr"]
     assert a["losses"][0] != b["losses"][0]          # the shards really were different
+
+
+@pytest.mark.parametrize("grad_dtype", ["fp32", "bf16"])
+def test_zero1_sharded_step_on_the_fused_path(grad_dtype):
+    """dp_zero1 with the fused optimiser on the GPU (2 ranks sharing cuda:0 over gloo): reduce-scatter, each rank's Adam slice,
+    all-gather.  The last rank's slice ends at the last live parameter: the KL slot and the padding behind `std` in the flat
+    buffer are never stepped (the padding stays exactly zero, its Adam moments too), the fp32 `std` compute copy equals the
+    master's std block, replicas stay bit-identical."""
+    world = 2
+    port = 31500 + os.getpid() % 2000 + (11 if grad_dtype == "bf16" else 0)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    ctx = mp.spawn(_worker, args=(world, port, out, True, grad_dtype), nprocs=world, join=False)
+    import time
+    deadline = time.time() + 300
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail("two-rank workers did not finish within 300 s")
+    a, b = out[0], out[1]
+    assert a["dp"] and a["fused"] and torch.isfinite(a["w"]).all()
+    assert torch.equal(a["w"], b["w"]) and a["lr"] == b["lr"]
+    for r in (a, b):
+        assert float(r["pad"].abs().max()) == 0.0 and r["m_pad"] == 0.0       # KL slot + padding: never treated as parameters
+        assert torch.equal(r["std"], r["w_std"])                                # the compute copy follows the master

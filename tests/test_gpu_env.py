@@ -356,3 +356,38 @@ def test_two_rank_bench_dry_run_on_one_gpu(extra):
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 2 and rec["value"] > 0
     assert rec["config"]["envs_per_gpu"] == 256 and "dp2" in rec["config"]["parallelism"]
     assert rec["value"] == pytest.approx(2 * 256 * 24 / (rec["ms_per_step"] * 1e-3), rel=1e-6)      # whole-job rate
+
+
+@pytest.mark.parametrize("extra", [[], ["--grad-dtype", "bf16"], ["--zero1"], ["--grad-dtype", "bf16", "--zero1"]])
+def test_rccl_one_rank_bench_runs_the_data_parallel_path(extra):
+    """RCCL on hardware within the 1-GPU constraint: bench.py under torch.distributed.run with ONE rank, backend nccl
+    (= RCCL on ROCm) and GO1_FORCE_DP=1, which makes PPO and the environment take the data-parallel path in a process group of
+    one: RCCL communicator init on the GPU, broadcast of the initial weights, the advantage-statistics and per-mini-batch
+    gradient all-reduces (fp32 / bf16), reduce_scatter_tensor + sharded Adam + all_gather_into_tensor (--zero1), the placement
+    of the collectives between the captured HIP graphs, and the command curriculum's success-count all-reduce.  With one rank
+    every collective is the identity, so the run must also reproduce the plain single-GPU trajectory: same fault counts and a
+    finite, positive rate."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + os.getpid() % 1000 + 3 * len(extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--envs", "256",
+           "--backend", "nccl", "--no-cpu-baseline", "--headline-only"] + extra
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTORCH_TUNABLEOP_ENABLED="0", GO1_FORCE_DP="1",
+               GO1_DP_TRACE="1")
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and "dp1" in rec["config"]["parallelism"] and "nccl" in rec["config"]["parallelism"]
+    trace = [l for l in r.stderr.splitlines() if l.startswith("[dp-trace]")]
+    assert trace, r.stderr[-2000:]
+    t = json.loads(trace[-1][len("[dp-trace]"):])
+    assert t["backend"] == "nccl" and t["dp"] and t["curriculum_sync"]
+    assert t["graph_replays"] > 0                                       # the collectives sat between replayed graphs
+    assert t["all_reduce"] > 0 and t["curriculum_all_reduce"] > 0
+    if "--zero1" in extra:
+        assert t["reduce_scatter"] > 0 and t["all_gather"] > 0

@@ -621,3 +621,55 @@ def test_observation_ring_storage_is_bit_identical_to_the_history_block():
             np.testing.assert_allclose(out[1], out[0], rtol=1e-3, atol=1e-6)
             # (Adam normalises the step: an element whose tiny gradient differs in the last bits can move by ~lr per step)
             assert float((ring.master - full.master).abs().max()) < 5e-3 and float((ring.master - full.master).abs().mean()) < 2e-5
+
+
+def test_adam_slice_reaching_past_the_live_parameters_leaves_the_tail_copy_alone(lib):
+    """go1ppo_opt_adam over a range that extends beyond n_body + n_tail (a sharded step whose last slice covers the KL slot and the
+    padding of the flat buffer): the fp32 tail copy is only written for its n_tail elements — the words behind it keep their
+    sentinel — and an empty range is accepted (clears zero_slot only)."""
+    n_body, n_tail, pad = 1000, 12, 52
+    tot = n_body + n_tail + pad
+    p = torch.randn(tot, device="cuda"); g = torch.randn(tot, device="cuda"); m = torch.zeros(tot, device="cuda"); v = torch.zeros(tot, device="cuda")
+    step = torch.ones(1, device="cuda"); lr = torch.full((1,), 1e-3, device="cuda")
+    body = torch.zeros(n_body, device="cuda", dtype=torch.bfloat16)
+    arena = torch.full((n_tail + 64,), 777.0, device="cuda")
+    slot = torch.ones(1, device="cuda")
+    p0 = p.clone()
+    assert lib.go1ppo_opt_adam(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 500, tot - 500, 0, 0, 1.0, None, 0.0, step.data_ptr(),
+                               lr.data_ptr(), 0.9, 0.999, 1e-8, body.data_ptr(), n_body, arena.data_ptr(), n_tail, 0, slot.data_ptr(), stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(arena[:n_tail], p[n_body:n_body + n_tail]) and bool((arena[n_tail:] == 777.0).all())
+    assert torch.equal(p[:500], p0[:500]) and not torch.equal(p[500:], p0[500:]) and float(slot) == 0.0
+    slot.fill_(1.0)
+    assert lib.go1ppo_opt_adam(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 0, 0, 0, 0, 1.0, None, 0.0, step.data_ptr(),
+                               lr.data_ptr(), 0.9, 0.999, 1e-8, body.data_ptr(), n_body, arena.data_ptr(), n_tail, 0, slot.data_ptr(), stream()) == 0
+    torch.cuda.synchronize()
+    assert float(slot) == 0.0
+
+
+def test_ring_rows_with_wide_privileged_observations(lib):
+    """go1ppo_ring_step / go1ppo_ring_gather with more than 64 privileged columns (one wavefront per environment: the fp32
+    privileged copy is written by a strided loop): stored rows and gathered rows carry every column."""
+    N, H, no, npv = 37, 5, 6, 150
+    Kp = ((H * no + 1 + npv + 63) // 64) * 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    obs = torch.randn(N, no, device="cuda", generator=g)
+    priv = torch.randn(N, npv, device="cuda", generator=g)
+    ring = bf(torch.randn(H, N, no, device="cuda", generator=g))
+    ring[H - 1] = bf(obs)
+    X = torch.zeros(N, Kp, device="cuda", dtype=torch.bfloat16)
+    obs_store = torch.zeros(N, no, device="cuda"); priv_store = torch.zeros(N, npv, device="cuda")
+    assert lib.go1ppo_ring_step(obs.data_ptr(), priv.data_ptr(), None, ring.data_ptr(), N, H, no, npv, Kp, X.data_ptr(), obs_store.data_ptr(),
+                                priv_store.data_ptr(), stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(priv_store, priv) and torch.equal(obs_store, obs)
+    want = torch.zeros(N, Kp, device="cuda", dtype=torch.bfloat16)
+    want[:, :H * no] = ring.permute(1, 0, 2).reshape(N, H * no)
+    want[:, H * no] = 1.0
+    want[:, H * no + 1:H * no + 1 + npv] = bf(priv)
+    assert torch.equal(X, want)
+    idx = torch.arange(N, device="cuda", dtype=torch.int64).flip(0).contiguous()
+    Xg = torch.zeros(N, Kp, device="cuda", dtype=torch.bfloat16)
+    assert lib.go1ppo_ring_gather(ring.data_ptr(), priv_store.data_ptr(), idx.data_ptr(), N, N, H, no, npv, Kp, Xg.data_ptr(), stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(Xg, want.flip(0))

@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void prestep_kernel(const float* g, int64_t n,
 __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m, float* v, int64_t start0, int64_t count0,
                                                    int64_t start1, int64_t count1, float gscale, const float* partial, float max_norm,
                                                    const float* step, const float* lr, float beta1, float beta2, float eps,
-                                                   bf16_t* body, int64_t n_body, float* tail, int zero_grad, float* zero_slot) {
+                                                   bf16_t* body, int64_t n_body, float* tail, int64_t n_tail, int zero_grad, float* zero_slot) {
   __shared__ float clip_s;
   if (threadIdx.x < 64) {
     float c = 1.f;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m,
     const float pi = p[i] - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
     p[i] = pi;
     if (i < n_body) body[i] = f2bf(pi);
-    else if (tail) tail[i - n_body] = pi;
+    else if (tail && i - n_body < n_tail) tail[i - n_body] = pi;      // (slots behind the tail — KL, padding — have no compute copy)
   }
   if (zero_slot && blockIdx.x == 0 && threadIdx.x == 0) *zero_slot = 0.f;
 }
@@ -929,7 +929,8 @@ __global__ __launch_bounds__(256) void ring_step_kernel(const float* __restrict_
     if (dst) dst[n * nod + c] = ring_pack(o[2 * c], o[2 * c + 1]);
     if (obs_store) { obs_store[n * no + 2 * c] = o[2 * c]; obs_store[n * no + 2 * c + 1] = o[2 * c + 1]; }
   }
-  if (priv_store && lane < npv) priv_store[n * npv + lane] = pv[lane];
+  if (priv_store)
+    for (int c = lane; c < npv; c += 64) priv_store[n * npv + c] = pv[c];
   ring_row(window + n * nod, N * nod, o, pv, H, no, npv, Kp, X + n * (Kp >> 1));
 }
 
@@ -987,14 +988,18 @@ extern "C" int go1ppo_opt_prestep(const float* g, int64_t n, float gscale, float
 
 extern "C" int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t start0, int64_t count0, int64_t start1,
                                int64_t count1, float gscale, const float* partial, float max_norm, const float* step, const float* lr,
-                               float beta1, float beta2, float eps, void* body, int64_t n_body, float* tail, int zero_grad,
+                               float beta1, float beta2, float eps, void* body, int64_t n_body, float* tail, int64_t n_tail, int zero_grad,
                                float* zero_slot, void* stream) {
-  if (!p || !g || !m || !v || !step || !lr || !body || count0 < 0 || count1 < 0 || count0 + count1 <= 0) return -1;
+  if (!p || !g || !m || !v || !step || !lr || !body || count0 < 0 || count1 < 0 || n_tail < 0) return -1;
+  if (count0 + count1 == 0) {           // an empty slice (a rank of a sharded step that owns padding only): just the slot
+    if (zero_slot && hipMemsetAsync(zero_slot, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return -9;
+    return 0;
+  }
   int64_t total = count0 + count1;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   adam_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, start0, count0, start1, count1, gscale, partial,
-                                                                             max_norm, step, lr, beta1, beta2, eps, (bf16_t*)body, n_body, tail, zero_grad, zero_slot);
+                                                                             max_norm, step, lr, beta1, beta2, eps, (bf16_t*)body, n_body, tail, n_tail, zero_grad, zero_slot);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 

@@ -21,6 +21,8 @@
 #include "go1_math.h"
 #include "go1_maps.h"
 #include "go1_physics.h"
+#define GO1SIM_STR_(x) #x
+#define GO1SIM_STR(x) GO1SIM_STR_(x)
 
 static_assert(A_IO_END <= LDSW_SIZE, "the actuator network's transient rows are overlaid on the solver's matrix");
 static_assert(PK_END <= LDSW_SIZE, "the contact packets of the emission hand-over are overlaid on the solver's matrix");
@@ -49,8 +51,13 @@ struct StepArgs {
 // ================================================================================================
 // kernels
 // ================================================================================================
-// rare path: publish the fault bits of this lane (go1sim.h Go1FaultBit)
+// rare path: publish the fault bits of this environment (go1sim.h Go1FaultBit).  The four lanes of an environment raise
+// environment-wide bits identically and per-leg bits on their own: the word is OR-ed over the quad and the leg-0 lane
+// publishes it, so every event counts once per environment and step.
 DEV void report_fault(BufRef B, int e, uint32_t fault) {
+  fault |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)fault, 0xB1, 0xF, 0xF, false);
+  fault |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)fault, 0x4E, 0xF, 0xF, false);
+  if ((threadIdx.x & 3) != 0) return;
   if (fault == 0 || B.fault_flags == nullptr) return;
   atomicOr(&B.fault_flags[e], fault);
   if (B.fault_counts == nullptr) return;
@@ -517,7 +524,7 @@ extern "C" int go1sim_read_timings(Go1Sim* s, float* ms, int32_t max, int32_t* c
   *count = (int32_t)have;
   return 0;
 }
-extern "C" const char* go1sim_version(void) { return "go1sim 0.4 (gfx950, abi 3, 4 lanes/env)"; }
+extern "C" const char* go1sim_version(void) { return "go1sim 0.5 (gfx950, abi " GO1SIM_STR(GO1SIM_ABI_VERSION) ", 4 lanes/env)"; }
 
 #ifdef GO1_PROFILE
 // debug build only (tools/phase_profile.py): read and clear the per-phase cycle accumulators of workgroup 0, lane 0

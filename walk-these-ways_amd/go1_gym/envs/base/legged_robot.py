@@ -8,6 +8,7 @@ every tensor map of `post_physics_step` in a single kernel launch on the current
 host synchronisation.  This class owns the device buffers (torch tensors, SoA layout) and exposes them
 under the reference's attribute names as (N, ...) views.
 """
+import os
 from collections.abc import Mapping
 
 import numpy as np
@@ -205,7 +206,8 @@ class LeggedRobot(BaseTask):
         # keyed by global env id).  7 KB int32 all-reduce per env step; `Cfg.commands.global_curriculum = False` keeps
         # per-rank curricula instead.
         import torch.distributed as dist
-        self._curriculum_sync = bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self._curriculum_sync = bool(dist.is_available() and dist.is_initialized()
+                                     and (dist.get_world_size() > 1 or os.environ.get("GO1_FORCE_DP", "0") not in ("", "0"))
                                      and cfg.commands.command_curriculum and getattr(cfg.commands, "global_curriculum", True))
         self.sim_config, self.sim_meta = H.build_sim_config(
             cfg, num_envs=self.num_envs, seed=seed, env_id_offset=offset,

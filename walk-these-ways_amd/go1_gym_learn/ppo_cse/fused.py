@@ -120,7 +120,7 @@ def load_library(path=None):
     L.go1ppo_normalize.argtypes = [vp, i64, vp, vp]
     L.go1ppo_opt_partials.argtypes = []
     L.go1ppo_opt_prestep.argtypes = [vp, i64, f32, vp, vp, vp, vp, f32, f32, f32, f32, vp]
-    L.go1ppo_opt_adam.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, f32, vp, f32, vp, vp, f32, f32, f32, vp, i64, vp, i32, vp, vp]
+    L.go1ppo_opt_adam.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, f32, vp, f32, vp, vp, f32, f32, f32, vp, i64, vp, i64, i32, vp, vp]
     for name in EXPORTED_SYMBOLS[:-1]:
         getattr(L, name).restype = ctypes.c_int
     L.go1ppo_version.restype = ctypes.c_char_p
@@ -698,6 +698,6 @@ class FusedAdam:
         _chk(self.lib.go1ppo_opt_adam(self.master.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.r0[0], self.r0[1],
                                       self.r1[0], self.r1[1], gscale, self.partial.data_ptr() if clip else None,
                                       float(max_norm) if clip else 0.0, self.step.data_ptr(), self.lr.data_ptr(), self.betas[0],
-                                      self.betas[1], self.eps, self.body.data_ptr(), self.n_body, self.std.data_ptr(), int(zero_grad),
+                                      self.betas[1], self.eps, self.body.data_ptr(), self.n_body, self.std.data_ptr(), self.std.numel(), int(zero_grad),
                                       _ptr(zero_slot), _stream()),
              "go1ppo_opt_adam")

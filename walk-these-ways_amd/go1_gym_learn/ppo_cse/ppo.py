@@ -16,6 +16,7 @@ Same algorithm, hyper-parameters (`PPO_Args`) and public methods (`act`, `proces
     loss statistics are accumulated on device and read once at the end.
 """
 import math
+import os
 import sys
 
 import torch
@@ -80,6 +81,10 @@ def _enable_tuned_gemms():
         print(f"[ppo] TunableOp not enabled ({type(err).__name__}: {err})", file=sys.stderr)
 
 
+def _force_dp():
+    return os.environ.get("GO1_FORCE_DP", "0") not in ("", "0")
+
+
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -137,7 +142,9 @@ class PPO:
         self.adaptation_module_optimizer = optim.Adam([self.master], lr=PPO_Args.adaptation_module_learning_rate, **kw)
         self.transition = RolloutStorage.Transition()
         self._lr = torch.tensor(PPO_Args.learning_rate, device=device)
-        self.dp = PPO_Args.data_parallel and _world() > 1
+        # GO1_FORCE_DP=1: take the data-parallel path in a process group of ONE rank too (every collective, the graph split and
+        # the sharded step then execute — how the RCCL path is exercised on a single-GPU box, tests/test_gpu_distributed.py)
+        self.dp = bool(PPO_Args.data_parallel and (_world() > 1 or (_force_dp() and dist.is_available() and dist.is_initialized())))
         # hand-scheduled forward/backward (fused.py): bf16 policy with ELU activations on a GPU.  No silent fallback:
         # when it applies and libgo1ppo.so is missing, load_library() raises.
         self.fused = bool(self.bf16 and PPO_Args.use_fused_kernels and self.policy.act is torch.nn.ELU)
@@ -171,7 +178,10 @@ class PPO:
                 self._dp_shard_buf = torch.zeros(per, device=device, dtype=torch.bfloat16 if self._dp_lowp is not None else torch.float32)
                 self._dp_tail = torch.zeros(self.master.numel() - n, device=device)
                 if self._opt is not None:
-                    self._opt.set_ranges([self._dp_shard])
+                    # the slice stops at the last live parameter: the KL slot and the padding behind it are carried by the
+                    # flat buffer for the exchange only — stepping them would write past `std` and treat KL as a gradient
+                    lo = self._dp_shard[0]
+                    self._opt.set_ranges([(lo, max(0, min(lo + per, n + self.n_std) - lo))])
         self._push_weights()
 
     # ---- precision plumbing --------------------------------------------------------------------------

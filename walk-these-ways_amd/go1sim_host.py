@@ -607,8 +607,13 @@ class Go1Sim:
         return off.value
 
     def set_config(self, S):
+        """Replace the (train) configuration.  With an evaluation split installed the evaluation block is rebuilt as the new
+        configuration plus the group-dispatched fields it carried (EVAL_CFG_FIELDS): every field the reference reads from the
+        train configuration for ALL environments (rewards, commands, control, physics) follows the change."""
         self.S = S
         self._check(self.lib.go1sim_set_config(self.handle, ctypes.byref(S)), "go1sim_set_config")
+        if getattr(self, "S_eval", None) is not None:
+            self.set_eval_config(make_eval_sim_config(S, self.S_eval), self.num_train_envs)
 
     def set_eval_config(self, S_eval, num_train_envs):
         """environments [num_train_envs, N) run under S_eval (make_eval_sim_config); num_train_envs % 16 == 0"""
