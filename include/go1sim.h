@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GO1SIM_ABI_VERSION 4
+#define GO1SIM_ABI_VERSION 5
 
 #define GO1_NUM_DOF 12
 #define GO1_NUM_BODIES 17        /* base, then FL,FR,RL,RR x (hip, thigh, calf, foot) */
@@ -37,6 +37,24 @@ extern "C" {
 #define GO1_MAX_LAG 8            /* lag_timesteps + 1 <= 8 */
 #define GO1_MAX_CATEGORIES 4
 #define GO1_MAX_HEIGHT_AXIS 32   /* measured_points_x / _y entries */
+#define GO1_MAX_CONTACTS 24      /* solver contacts per environment and substep (a Go1 lying on its side with every link down: 14-18) */
+#define GO1_MAX_CURRICULUM_INTERVAL 64
+
+/* Classes of the solver's contact list (priority order); contact_drop_counts[class] counts the active points of a class that
+ * found no solver slot, contact_signature names the listed points (tests: which environments differ in their active set) */
+enum Go1ContactClass {
+  GO1_CC_FOOT = 0,        /* foot sphere on the terrain's top surface */
+  GO1_CC_FOOT_WALL = 1,   /* foot sphere against a vertical terrain face */
+  GO1_CC_SELF = 2,        /* body-body: lower legs / thighs of different legs, lower legs against the trunk */
+  GO1_CC_TRUNK = 3,
+  GO1_CC_CALF = 4,
+  GO1_CC_THIGH = 5,
+  GO1_CC_HIP = 6,
+  GO1_CC_WALL = 7,        /* trunk / calf / thigh against a vertical terrain face */
+  GO1_CC_COUNT = 8
+};
+#define GO1_SIG_WORDS 3          /* per substep: [top-surface points | wall points | self pairs + legs with limit rows] */
+#define GO1_SIG_MAX_SUBSTEPS 4
 
 /* canonical reward ids: one per `_reward_*` in go1_gym/envs/rewards/corl_rewards.py:15-202 */
 enum Go1RewardId {
@@ -134,6 +152,7 @@ typedef struct Go1SimConfig {
   float max_depenetration_velocity;
   float bounce_threshold_velocity;
   float terrain_friction;          /* Cfg.terrain.static_friction */
+  float terrain_dynamic_friction;  /* Cfg.terrain.dynamic_friction (legged_robot.py:1437,1454,1474): the cone of a SLIDING contact */
   float terrain_restitution;
   float max_linear_velocity, max_angular_velocity;   /* Cfg.asset.max_*_velocity (1000): magnitude caps on the base twist */
   float joint_limit_margin;        /* rad/s, rad: a joint's limit row enters the solver when its free rate comes within      */
@@ -145,6 +164,8 @@ typedef struct Go1SimConfig {
   int32_t terrain_type;            /* 0 plane, 1 height field */
   int32_t hf_rows, hf_cols;        /* height_samples shape */
   float hf_hscale, hf_vscale, hf_border;
+  float hf_wall_threshold;         /* m; > 0: a cell edge rising by more than this is a vertical face (the `trimesh` terrain's
+                                      slope_treshold * horizontal_scale, terrain.py:33-36); 0: plain bilinear height field */
   /* height scan: legged_robot.py:1756-1806 (_init_height_points, _get_heights) */
   int32_t measure_heights;         /* Cfg.terrain.measure_heights */
   int32_t num_height_x, num_height_y;
@@ -209,6 +230,9 @@ typedef struct Go1SimConfig {
 
   /* --- commands / curriculum: legged_robot.py:710-824, curriculum.py --- */
   int32_t device_curriculum;       /* 1: in-kernel sampling; 0: kernel only raises resample flags */
+  int32_t curriculum_update_interval; /* K >= 1: the successes of step t are logged in slot t % K of curriculum_success and the K per-step
+                                      weight updates are applied, in order, after every K-th step (K = 1: after every step, the
+                                      reference's cadence).  Environments sharded over ranks exchange the K slots in ONE all-reduce */
   int32_t defer_curriculum_update; /* 1: go1sim_step leaves the weight update to an explicit go1sim_curriculum_update call, so that the
                                       caller can all-reduce curriculum_success over the ranks first (envs sharded over GPUs) */
   int32_t num_categories;          /* 4 when gaitwise_curricula (pronk, trot, pace, bound) else 1 */
@@ -285,7 +309,7 @@ typedef struct Go1SimBuffers {
   int32_t* env_command_categories; /* [N] */
   float* curriculum_weights;       /* [num_categories][num_bins] */
   float* curriculum_cdf;           /* [num_categories][num_bins] normalised inclusive prefix sums */
-  int32_t* curriculum_success;     /* [num_categories][num_bins] successes recorded this step */
+  int32_t* curriculum_success;     /* [curriculum_update_interval][num_categories][num_bins] successes per step slot */
   const int32_t* curriculum_nbr_ptr; /* [num_bins+1] CSR of get_local_bins neighbourhoods (incl. self) */
   const int32_t* curriculum_nbr_idx;
   /* outputs consumed by the policy */
@@ -295,6 +319,9 @@ typedef struct Go1SimBuffers {
   /* fault reporting (enum Go1FaultBit) */
   uint32_t* fault_flags;           /* [N] sticky OR of the fault bits of each environment; cleared by the caller */
   uint32_t* fault_counts;          /* [GO1_FAULT_BITS] occurrences per bit since the caller last zeroed it */
+  uint32_t* contact_drop_counts;   /* [GO1_CC_COUNT] or NULL: active contact points without a solver slot, per class */
+  uint32_t* contact_signature;     /* [GO1_SIG_MAX_SUBSTEPS * GO1_SIG_WORDS][N] or NULL (tests): the listed contact points, self pairs and
+                                      limit-row legs of each substep of the last step, bit per candidate (csrc/go1_physics.h) */
   /* terrain */
   const int16_t* height_samples;   /* (hf_rows, hf_cols) or NULL for plane */
   float* measured_heights;         /* [num_height_x*num_height_y][N] or NULL */

@@ -33,7 +33,13 @@
 #include "../walk-these-ways_amd/csrc/go1_model_data.h"
 #include "../walk-these-ways_amd/csrc/go1_actuator_data.h"
 
+#ifdef GO1_ORACLE_FP32
+typedef float real;      /* fp32 build (oracle/_build/libgo1oracle32.so): the SAME restatement in the kernel's precision — what
+                            separates it from the fp64 build is round-off, which is how the tests attribute environments whose
+                            contact set flips to precision rather than to logic */
+#else
 typedef double real;
+#endif
 #define NV 18
 #define PI 3.14159265358979323846
 
@@ -284,19 +290,63 @@ static void chol_solve(const real* L, int n, real* b) {
 
 /* ------------------------------------------------------------------ terrain */
 typedef struct { const Go1SimConfig* cfg; const int16_t* hs; } Terrain;
-/* height and unit normal at world (x, y).  Height field: bilinear interpolation of the int16 samples
- * (same sample convention as _get_heights, legged_robot.py:1793-1806: index = (x + border) / hscale). */
-static void terrain_sample(const Terrain* t, real x, real y, real* h, real* n) {
+typedef struct { int on; real n[3]; real d; real top; } Wall;   /* vertical face: unit horizontal normal (towards the low side),
+                                                                    horizontal distance of the sample point, height of its upper edge */
+/* Height and unit normal of the terrain's TOP surface at world (x, y), and the vertical face next to the point (if any).
+ * Height field: bilinear interpolation of the int16 samples (same sample convention as _get_heights,
+ * legged_robot.py:1793-1806: index = (x + border) / hscale).
+ * Vertical faces (hf_wall_threshold T > 0; the `trimesh` terrain's slope_treshold, terrain.py:33-36, legged_robot_config.py:91:
+ * where two neighbouring samples differ by more than the threshold the reference's mesh moves the LOWER vertex under the upper
+ * one, so the low ground runs on flat to a vertical riser).  Restated on the height field per cell: an edge of the cell whose
+ * end heights differ by more than T is "steep"; the cell's corner heights are lowered along steep edges to the lower end (two
+ * passes over the four edges: the low level spreads through chains of steep edges) and the top surface is the bilinear
+ * interpolant of the LOWERED corners; if both x-edges of the cell are steep in the same direction the cell ends in a wall in
+ * the plane x = x(high side), normal towards the low side, upper edge = the interpolated original heights of the high side
+ * (same for y; with both, the nearer one is reported). */
+static void terrain_sample(const Terrain* t, real x, real y, real* h, real* n, Wall* wall) {
   const Go1SimConfig* c = t->cfg;
+  if (wall) wall->on = 0;
   if (c->terrain_type == 0 || !t->hs) { *h = 0; v3set(n, 0, 0, 1); return; }
   real fx = (x + c->hf_border) / c->hf_hscale, fy = (y + c->hf_border) / c->hf_hscale;
   if (fx < 0) fx = 0; if (fy < 0) fy = 0;
-  if (fx > c->hf_rows - 1.000001) fx = c->hf_rows - 1.000001;
-  if (fy > c->hf_cols - 1.000001) fy = c->hf_cols - 1.000001;
+  if (fx > c->hf_rows - (real)1.000001) fx = c->hf_rows - (real)1.000001;
+  if (fy > c->hf_cols - (real)1.000001) fy = c->hf_cols - (real)1.000001;
   int ix = (int)fx, iy = (int)fy;
   real ax = fx - ix, ay = fy - iy;
   real h00 = t->hs[ix * c->hf_cols + iy] * (real)c->hf_vscale, h10 = t->hs[(ix + 1) * c->hf_cols + iy] * (real)c->hf_vscale;
   real h01 = t->hs[ix * c->hf_cols + iy + 1] * (real)c->hf_vscale, h11 = t->hs[(ix + 1) * c->hf_cols + iy + 1] * (real)c->hf_vscale;
+  const real T = (real)c->hf_wall_threshold;
+  if (T > 0) {
+    const real dx0 = h10 - h00, dx1 = h11 - h01, dy0 = h01 - h00, dy1 = h11 - h10;
+    const int sx0 = fabs(dx0) > T, sx1 = fabs(dx1) > T, sy0 = fabs(dy0) > T, sy1 = fabs(dy1) > T;
+    if (sx0 || sx1 || sy0 || sy1) {
+      if (wall) {
+        real best = 1e30;
+        if (sx0 && sx1 && dx0 * dx1 > 0) {
+          const int up = dx0 > 0;
+          wall->on = 1; v3set(wall->n, up ? -1 : 1, 0, 0);
+          wall->d = (up ? (1 - ax) : ax) * (real)c->hf_hscale;
+          wall->top = up ? h10 * (1 - ay) + h11 * ay : h00 * (1 - ay) + h01 * ay;
+          best = wall->d;
+        }
+        if (sy0 && sy1 && dy0 * dy1 > 0) {
+          const int up = dy0 > 0;
+          const real d = (up ? (1 - ay) : ay) * (real)c->hf_hscale;
+          if (d < best) {
+            wall->on = 1; v3set(wall->n, 0, up ? -1 : 1, 0);
+            wall->d = d;
+            wall->top = up ? h01 * (1 - ax) + h11 * ax : h00 * (1 - ax) + h10 * ax;
+          }
+        }
+      }
+      for (int pass = 0; pass < 2; pass++) {
+        if (sx0) { real lo = h00 < h10 ? h00 : h10; h00 = h10 = lo; }
+        if (sx1) { real lo = h01 < h11 ? h01 : h11; h01 = h11 = lo; }
+        if (sy0) { real lo = h00 < h01 ? h00 : h01; h00 = h01 = lo; }
+        if (sy1) { real lo = h10 < h11 ? h10 : h11; h10 = h11 = lo; }
+      }
+    }
+  }
   *h = h00 * (1 - ax) * (1 - ay) + h10 * ax * (1 - ay) + h01 * (1 - ax) * ay + h11 * ax * ay;
   real dhdx = ((h10 - h00) * (1 - ay) + (h11 - h01) * ay) / c->hf_hscale;
   real dhdy = ((h01 - h00) * (1 - ax) + (h11 - h10) * ax) / c->hf_hscale;
@@ -306,16 +356,23 @@ static void terrain_sample(const Terrain* t, real x, real y, real* h, real* n) {
 }
 
 /* ------------------------------------------------------------------ contacts
- * Terrain: every collision shape of the URDF (trunk box, hip capsules [replace_cylinder_with_capsule,
- * legged_robot_config.py:232], thigh and calf boxes, foot spheres) contributes up to TWO points: its candidate points
- * (box corners, capsule end spheres, sphere centre) are split into the two ends of the shape's long axis; the deeper end's
- * deepest point is the first contact, the other end's deepest point the second (a link lying on the ground is supported
- * along its length; PhysX keeps up to 4 per pair).  A foot sphere has one.
- * Self-collision (asset self_collisions = 0: enabled, go1_config.py:44): the lower legs (knee -> foot centre, radius of the
- * foot sphere) against each other and against the trunk's capsule (the box's long axis, radius = its half width):
- * closest points of the two segments, one contact per pair.
- * Solver list: at most GO1_MAX_CONTACTS, in the priority order feet, self-contacts, trunk, calves, thighs, hips (first
- * points before second points); what does not fit is dropped and counted. */
+ * Terrain, top surface: every collision shape of the URDF contributes points of its own —
+ *   trunk box: every corner within the contact distance, at most four (corner order), so that a trunk lying on a face rests on
+ *              that face's four corners (two points per shape left it rocking about the line through them);
+ *   hip capsules [replace_cylinder_with_capsule, legged_robot_config.py:232], thigh and calf boxes: up to TWO — the candidate
+ *              points (capsule end spheres, box corners) are split into the two ends of the shape's long axis, the deeper end's
+ *              deepest point is the first contact, the other end's deepest point the second;
+ *   foot spheres: one.
+ * Terrain, vertical faces (hf_wall_threshold > 0): one point per foot, calf, thigh and one for the trunk — the candidate point
+ * below the face's upper edge with the smallest horizontal separation from it; normal horizontal.
+ * Self-collision (asset self_collisions = 0: nothing filtered, go1_config.py:44, legged_robot.py:1563-1564): capsules —
+ * lower leg (knee -> foot centre, radius of the foot sphere), thigh (thigh joint -> knee, GO1_SELF_THIGH_RADIUS), trunk (the
+ * box's long axis, radius = its half width) — lower legs and thighs of DIFFERENT legs against each other (24 pairs) and
+ * lower legs against the trunk (4); closest points of the two segments, one contact per pair.  Not modelled: pairs within one
+ * leg and the hip capsules (mechanically out of reach within the joint limits).
+ * Solver list: at most GO1_MAX_CONTACTS, in the priority order feet, foot walls, self-contacts (at most GO1_MAX_SELF_LEG_PAIRS
+ * leg-leg), trunk, trunk wall, calves (first points, walls, second points), thighs (same), hips; what does not fit is dropped
+ * and counted per class. */
 typedef struct { real phi, x[3], n[3]; int valid; } Cand;
 typedef struct {
   int repA, repB;   /* reported bodies (0..16) the force is booked on; repB = -1: terrain */
@@ -324,20 +381,33 @@ typedef struct {
   real n[3], t1[3], t2[3];
   real phi;         /* signed separation */
   real share;       /* part of repA's previous impulse this point starts from (warm start) */
+  int cls;          /* Go1ContactClass */
+  int top;          /* 1: on the terrain's top surface (takes part in the warm-start shares) */
 } Contact;
 
-static void candidate(const Terrain* ter, const Kin* k, const real* base_pos, int dynb, const real* local, real radius, Cand* best) {
+/* candidate point `local` of dynamic body dynb: top-surface candidate into *best, wall candidate into *bestw (may be NULL) */
+static void candidate(const Terrain* ter, const Kin* k, const real* base_pos, int dynb, const real* local, real radius, Cand* best, Cand* bestw) {
   real w[3], x[3];
   m3v(w, k->R[dynb], local);
   v3add(x, k->p[dynb], w);
   real h, n[3];
-  terrain_sample(ter, base_pos[0] + x[0], base_pos[1] + x[1], &h, n);
+  Wall wl;
+  terrain_sample(ter, base_pos[0] + x[0], base_pos[1] + x[1], &h, n, bestw ? &wl : NULL);
   real phi = (base_pos[2] + x[2]) - radius - h;
   if (!best->valid || phi < best->phi) {
     best->valid = 1;
     best->phi = phi;
     for (int i = 0; i < 3; i++) best->x[i] = x[i] - radius * n[i];
     v3cpy(best->n, n);
+  }
+  if (bestw && wl.on && base_pos[2] + x[2] < wl.top) {
+    real phiw = wl.d - radius;
+    if (!bestw->valid || phiw < bestw->phi) {
+      bestw->valid = 1;
+      bestw->phi = phiw;
+      for (int i = 0; i < 3; i++) bestw->x[i] = x[i] - radius * wl.n[i];
+      v3cpy(bestw->n, wl.n);
+    }
   }
 }
 
@@ -346,12 +416,12 @@ static void contact_frame(Contact* c) {   /* t1 = x axis projected on the tangen
   real d = v3dot(ex, c->n);
   for (int i = 0; i < 3; i++) c->t1[i] = ex[i] - d * c->n[i];
   real l2 = v3dot(c->t1, c->t1);
-  if (!(l2 > 1e-12)) {
+  if (!(l2 > (real)1e-12)) {
     real ey[3] = {0, 1, 0};
     d = v3dot(ey, c->n);
     for (int i = 0; i < 3; i++) c->t1[i] = ey[i] - d * c->n[i];
     l2 = v3dot(c->t1, c->t1);
-    if (!(l2 > 1e-12)) { v3set(c->t1, 0, 1, 0); l2 = 1; }
+    if (!(l2 > (real)1e-12)) { v3set(c->t1, 0, 1, 0); l2 = 1; }
   }
   real l = sqrt(l2);
   for (int i = 0; i < 3; i++) c->t1[i] /= l;
@@ -364,114 +434,141 @@ static void seg_seg(const real* p1, const real* q1, const real* p2, const real* 
   v3sub(d1, q1, p1); v3sub(d2, q2, p2); v3sub(r, p1, p2);
   real a = v3dot(d1, d1), e = v3dot(d2, d2), f = v3dot(d2, r), cc = v3dot(d1, r), b = v3dot(d1, d2);
   real den = a * e - b * b, sN = 0, tN;
-  if (den > 1e-12) { sN = (b * f - cc * e) / den; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN); }
+  if (den > (real)1e-12) { sN = (b * f - cc * e) / den; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN); }
   tN = (b * sN + f) / e;
   if (tN < 0) { tN = 0; sN = -cc / a; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN); }
   else if (tN > 1) { tN = 1; sN = (b - cc) / a; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN); }
   for (int i = 0; i < 3; i++) { c1[i] = p1[i] + sN * d1[i]; c2[i] = p2[i] + tN * d2[i]; }
 }
 
-#define GO1_MAX_CONTACTS 8
 #define GO1_SELF_LEG_RADIUS GO1_FOOT_RADIUS
-#define GO1_MAX_SELF_LEG_PAIRS 2
+#define GO1_SELF_THIGH_RADIUS 0.017    /* half of the thigh box's larger cross-section side (urdf: 0.0245 x 0.034) */
+#define GO1_MAX_SELF_LEG_PAIRS 4
+#define GO1_MAX_TRUNK_POINTS 4
 #define GO1_LIMIT_RECOVERY_RATE 10.0   /* rad/s */
 #define GO1_LIMIT_SAFETY 2.0           /* x velocity limit */
 #define GO1_LIMIT_SLACK 0.2            /* rad beyond a stop */
 
-static int add_contact(Contact* list, int n, int* dropped, const Contact* c) {
-  if (n >= GO1_MAX_CONTACTS) { (*dropped)++; return n; }
-  list[n] = *c;
-  contact_frame(&list[n]);
-  return n + 1;
+typedef struct { int n; int dropped[GO1_CC_COUNT]; uint32_t sig[GO1_SIG_WORDS]; } ContactList;
+
+/* sigw: signature word (0 top surface, 1 walls, 2 self pairs), sigb: bit */
+static void add_contact(Contact* list, ContactList* L, const Contact* c, int sigw, int sigb) {
+  if (L->n >= GO1_MAX_CONTACTS) { L->dropped[c->cls]++; L->sig[1] |= 1u << 31; return; }
+  list[L->n] = *c;
+  contact_frame(&list[L->n]);
+  L->n++;
+  L->sig[sigw] |= 1u << sigb;
 }
-static int add_terrain(Contact* list, int n, int* dropped, real cd, const Cand* c, int rep, int dyn) {
-  if (!c->valid || !(c->phi < cd)) return n;
+static void add_terrain(Contact* list, ContactList* L, real cd, const Cand* c, int rep, int dyn, int cls, int top, int sigw, int sigb) {
+  if (!c->valid || !(c->phi < cd)) return;
   Contact t;
-  t.repA = rep; t.repB = -1; t.dynA = dyn; t.dynB = -1; t.phi = c->phi; t.share = 1;
+  t.repA = rep; t.repB = -1; t.dynA = dyn; t.dynB = -1; t.phi = c->phi; t.share = 1; t.cls = cls; t.top = top;
   v3cpy(t.x, c->x); v3cpy(t.n, c->n);
-  return add_contact(list, n, dropped, &t);
+  add_contact(list, L, &t, sigw, sigb);
 }
 
-/* returns the number of solver contacts; *dropped = active contacts beyond the cap */
-static int detect_contacts(const Go1SimConfig* cfg, const Terrain* ter, const Kin* k, const real* base_pos, Contact* list, int* dropped) {
+/* fills `list`, returns the bookkeeping (count, drops per class, signature words 0..2 without the limit-row bits) */
+static ContactList detect_contacts(const Go1SimConfig* cfg, const Terrain* ter, const Kin* k, const real* base_pos, Contact* list) {
   const real cd = cfg->contact_distance;
-  Cand trunk[2], hip[4][2], thigh[4][2], calf[4][2], foot[4];
+  const int walls = cfg->terrain_type != 0 && ter->hs && cfg->hf_wall_threshold > 0;
+  Cand trunk[8], hip[4][2], thigh[4][2], calf[4][2], foot[4], trunkw, thighw[4], calfw[4], footw[4];
   memset(trunk, 0, sizeof trunk); memset(hip, 0, sizeof hip); memset(thigh, 0, sizeof thigh); memset(calf, 0, sizeof calf); memset(foot, 0, sizeof foot);
-  for (int m = 0; m < 8; m++) {       /* trunk box: long axis x -> ends by the sign of x */
+  memset(&trunkw, 0, sizeof trunkw); memset(thighw, 0, sizeof thighw); memset(calfw, 0, sizeof calfw); memset(footw, 0, sizeof footw);
+  for (int m = 0; m < 8; m++) {       /* trunk box corners */
     real l[3] = {(m & 1 ? 1 : -1) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1 : -1) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1 : -1) * GO1_TRUNK_BOX_HALF[2]};
-    candidate(ter, k, base_pos, 0, l, 0, &trunk[m & 1]);
+    candidate(ter, k, base_pos, 0, l, 0, &trunk[m], walls ? &trunkw : NULL);
   }
   for (int leg = 0; leg < 4; leg++) {
     int hipb = 1 + 3 * leg;
     for (int m = 0; m < 2; m++) {
       real l[3] = {GO1_HIP_CAPSULE_CENTER[leg][0], GO1_HIP_CAPSULE_CENTER[leg][1] + (m ? 1 : -1) * GO1_HIP_CAPSULE_HALF, GO1_HIP_CAPSULE_CENTER[leg][2]};
-      candidate(ter, k, base_pos, hipb, l, GO1_HIP_CAPSULE_RADIUS, &hip[leg][m]);
+      candidate(ter, k, base_pos, hipb, l, GO1_HIP_CAPSULE_RADIUS, &hip[leg][m], NULL);
     }
     for (int m = 0; m < 8; m++) {     /* thigh / calf boxes: long axis z -> ends by the sign of z */
       real l[3] = {GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1 : -1) * GO1_THIGH_BOX_HALF[0],
                    GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1 : -1) * GO1_THIGH_BOX_HALF[1],
                    GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1 : -1) * GO1_THIGH_BOX_HALF[2]};
-      candidate(ter, k, base_pos, hipb + 1, l, 0, &thigh[leg][(m >> 2) & 1]);
+      candidate(ter, k, base_pos, hipb + 1, l, 0, &thigh[leg][(m >> 2) & 1], walls ? &thighw[leg] : NULL);
     }
     for (int m = 0; m < 8; m++) {
       real l[3] = {GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1 : -1) * GO1_CALF_BOX_HALF[0],
                    GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1 : -1) * GO1_CALF_BOX_HALF[1],
                    GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1 : -1) * GO1_CALF_BOX_HALF[2]};
-      candidate(ter, k, base_pos, hipb + 2, l, 0, &calf[leg][(m >> 2) & 1]);
+      candidate(ter, k, base_pos, hipb + 2, l, 0, &calf[leg][(m >> 2) & 1], walls ? &calfw[leg] : NULL);
     }
     real fo[3] = {GO1_FOOT_OFFSET[leg][0], GO1_FOOT_OFFSET[leg][1], GO1_FOOT_OFFSET[leg][2]};
-    candidate(ter, k, base_pos, hipb + 2, fo, GO1_FOOT_RADIUS, &foot[leg]);
+    candidate(ter, k, base_pos, hipb + 2, fo, GO1_FOOT_RADIUS, &foot[leg], walls ? &footw[leg] : NULL);
   }
-  int n = 0;
-  *dropped = 0;
-  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &foot[leg], 4 + 4 * leg, 3 * leg + 3);
-  /* self-collision */
-  real P[4][3], Q[4][3], TA[3], TB[3];
+  ContactList L;
+  memset(&L, 0, sizeof L);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &foot[leg], 4 + 4 * leg, 3 * leg + 3, GO1_CC_FOOT, 1, 0, leg);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &footw[leg], 4 + 4 * leg, 3 * leg + 3, GO1_CC_FOOT_WALL, 0, 1, leg);
+  /* self-collision: segments of the lower legs [0] and thighs [1], trunk axis */
+  real P[4][2][3], Q[4][2][3], TA[3], TB[3];
   for (int leg = 0; leg < 4; leg++) {
     real fo[3] = {GO1_FOOT_OFFSET[leg][0], GO1_FOOT_OFFSET[leg][1], GO1_FOOT_OFFSET[leg][2]}, w[3];
-    v3cpy(P[leg], k->p[3 * leg + 3]);
+    v3cpy(P[leg][0], k->p[3 * leg + 3]);
     m3v(w, k->R[3 * leg + 3], fo);
-    v3add(Q[leg], P[leg], w);
+    v3add(Q[leg][0], P[leg][0], w);
+    v3cpy(P[leg][1], k->p[3 * leg + 2]);
+    v3cpy(Q[leg][1], k->p[3 * leg + 3]);
   }
   {
     real a = GO1_TRUNK_BOX_HALF[0] - GO1_TRUNK_BOX_HALF[1], la[3] = {-a, 0, 0}, lb[3] = {a, 0, 0};
     m3v(TA, k->R[0], la); m3v(TB, k->R[0], lb);
   }
   int legpairs = 0;
-  for (int pair = 0; pair < (cfg->self_collision ? 10 : 0); pair++) {
+  for (int pid = 0; pid < (cfg->self_collision ? 28 : 0); pid++) {
+    /* pid = 6 * type + pair for the leg-leg pairs: type 0 lower-lower, 1 lower(i)-thigh(j), 2 thigh(i)-lower(j), 3 thigh-thigh,
+     * pair (i, j) in the order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); pid 24 + leg: lower leg against the trunk */
     static const int PI_[6] = {0, 0, 0, 1, 1, 2}, PJ_[6] = {1, 2, 3, 2, 3, 3};
-    int i = pair < 6 ? PI_[pair] : pair - 6, j = pair < 6 ? PJ_[pair] : -1;
+    const int type = pid < 24 ? pid / 6 : 0, i = pid < 24 ? PI_[pid % 6] : pid - 24, j = pid < 24 ? PJ_[pid % 6] : -1;
+    const int sa = (type >> 1) & 1, sb = type & 1;          /* segment of body A / B: 0 lower leg, 1 thigh */
     real c1[3], c2[3], d[3];
-    real rb = j >= 0 ? GO1_SELF_LEG_RADIUS : GO1_TRUNK_BOX_HALF[1];
-    if (j >= 0) seg_seg(P[i], Q[i], P[j], Q[j], c1, c2); else seg_seg(P[i], Q[i], TA, TB, c1, c2);
+    const real ra = sa ? (real)GO1_SELF_THIGH_RADIUS : (real)GO1_SELF_LEG_RADIUS;
+    const real rb = j >= 0 ? (sb ? (real)GO1_SELF_THIGH_RADIUS : (real)GO1_SELF_LEG_RADIUS) : (real)GO1_TRUNK_BOX_HALF[1];
+    if (j >= 0) seg_seg(P[i][sa], Q[i][sa], P[j][sb], Q[j][sb], c1, c2); else seg_seg(P[i][0], Q[i][0], TA, TB, c1, c2);
     v3sub(d, c1, c2);
     real dist = v3norm(d);
-    if (!(dist > 1e-6)) continue;
-    real phi = dist - GO1_SELF_LEG_RADIUS - rb;
+    if (!(dist > (real)1e-6)) continue;
+    real phi = dist - ra - rb;
     if (!(phi < cd)) continue;
-    if (j >= 0 && ++legpairs > GO1_MAX_SELF_LEG_PAIRS) { (*dropped)++; continue; }      /* the solver carries two leg-leg contacts */
+    if (j >= 0 && ++legpairs > GO1_MAX_SELF_LEG_PAIRS) { L.dropped[GO1_CC_SELF]++; L.sig[1] |= 1u << 31; continue; }
     Contact t;
-    t.repA = 1 + 4 * i + 2; t.dynA = 3 * i + 3;
-    t.repB = j >= 0 ? 1 + 4 * j + 2 : 0; t.dynB = j >= 0 ? 3 * j + 3 : 0;
-    t.phi = phi; t.share = 0;
-    for (int q = 0; q < 3; q++) { t.n[q] = d[q] / dist; t.x[q] = c2[q] + t.n[q] * (rb + 0.5 * phi); }
-    n = add_contact(list, n, dropped, &t);
+    t.repA = 1 + 4 * i + (sa ? 1 : 2); t.dynA = 3 * i + (sa ? 2 : 3);
+    t.repB = j >= 0 ? 1 + 4 * j + (sb ? 1 : 2) : 0; t.dynB = j >= 0 ? 3 * j + (sb ? 2 : 3) : 0;
+    t.phi = phi; t.share = 0; t.cls = GO1_CC_SELF; t.top = 0;
+    for (int q = 0; q < 3; q++) { t.n[q] = d[q] / dist; t.x[q] = c2[q] + t.n[q] * (rb + (real)0.5 * phi); }
+    add_contact(list, &L, &t, 2, pid);
   }
-  /* remaining shapes: first points, then second points */
+  /* remaining shapes */
 #define FIRST(c) (((c)[1].valid && (!(c)[0].valid || (c)[1].phi < (c)[0].phi)) ? 1 : 0)
-  { int f = FIRST(trunk); n = add_terrain(list, n, dropped, cd, &trunk[f], 0, 0); n = add_terrain(list, n, dropped, cd, &trunk[1 - f], 0, 0); }
-  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &calf[leg][FIRST(calf[leg])], 3 + 4 * leg, 3 * leg + 3);
-  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &calf[leg][1 - FIRST(calf[leg])], 3 + 4 * leg, 3 * leg + 3);
-  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &thigh[leg][FIRST(thigh[leg])], 2 + 4 * leg, 3 * leg + 2);
-  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &thigh[leg][1 - FIRST(thigh[leg])], 2 + 4 * leg, 3 * leg + 2);
-  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &hip[leg][FIRST(hip[leg])], 1 + 4 * leg, 3 * leg + 1);
-  for (int leg = 0; leg < 4; leg++) n = add_terrain(list, n, dropped, cd, &hip[leg][1 - FIRST(hip[leg])], 1 + 4 * leg, 3 * leg + 1);
+  {
+    int listed = 0;
+    for (int m = 0; m < 8; m++) {
+      if (!(trunk[m].valid && trunk[m].phi < cd)) continue;
+      if (listed >= GO1_MAX_TRUNK_POINTS) { L.dropped[GO1_CC_TRUNK]++; L.sig[1] |= 1u << 31; continue; }
+      listed++;
+      add_terrain(list, &L, cd, &trunk[m], 0, 0, GO1_CC_TRUNK, 1, 0, 4 + m);
+    }
+  }
+  add_terrain(list, &L, cd, &trunkw, 0, 0, GO1_CC_WALL, 0, 1, 4);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &calf[leg][FIRST(calf[leg])], 3 + 4 * leg, 3 * leg + 3, GO1_CC_CALF, 1, 0, 12 + 2 * leg + FIRST(calf[leg]));
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &calfw[leg], 3 + 4 * leg, 3 * leg + 3, GO1_CC_WALL, 0, 1, 5 + leg);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &calf[leg][1 - FIRST(calf[leg])], 3 + 4 * leg, 3 * leg + 3, GO1_CC_CALF, 1, 0, 12 + 2 * leg + 1 - FIRST(calf[leg]));
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &thigh[leg][FIRST(thigh[leg])], 2 + 4 * leg, 3 * leg + 2, GO1_CC_THIGH, 1, 0, 20 + 2 * leg + FIRST(thigh[leg]));
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &thighw[leg], 2 + 4 * leg, 3 * leg + 2, GO1_CC_WALL, 0, 1, 9 + leg);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &thigh[leg][1 - FIRST(thigh[leg])], 2 + 4 * leg, 3 * leg + 2, GO1_CC_THIGH, 1, 0, 20 + 2 * leg + 1 - FIRST(thigh[leg]));
+  /* (hip points: their signature bits sit in word 1 behind the wall bits) */
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &hip[leg][FIRST(hip[leg])], 1 + 4 * leg, 3 * leg + 1, GO1_CC_HIP, 1, 1, 13 + 2 * leg + FIRST(hip[leg]));
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &hip[leg][1 - FIRST(hip[leg])], 1 + 4 * leg, 3 * leg + 1, GO1_CC_HIP, 1, 1, 13 + 2 * leg + 1 - FIRST(hip[leg]));
 #undef FIRST
-  /* warm start: a body's previous impulse is shared equally by its listed terrain points */
+  /* warm start: a body's previous impulse is shared equally by its listed top-surface points; wall and body-body points
+   * start from zero */
   int cnt[17] = {0};
-  for (int c = 0; c < n; c++) if (list[c].repB < 0) cnt[list[c].repA]++;
-  for (int c = 0; c < n; c++) list[c].share = list[c].repB < 0 ? 1.0 / cnt[list[c].repA] : 0;
-  return n;
+  for (int c = 0; c < L.n; c++) if (list[c].top) cnt[list[c].repA]++;
+  for (int c = 0; c < L.n; c++) list[c].share = list[c].top ? (real)1.0 / cnt[list[c].repA] : 0;
+  return L;
 }
 
 /* Jacobian row for world direction d at point x (relative to base origin) on dynamic body dynb */
@@ -492,7 +589,7 @@ static void jac_row(const Kin* k, int dynb, const real* x, const real* d, real* 
 }
 
 /* ------------------------------------------------------------------ one physics substep (replaces gym.simulate) */
-typedef struct { real force[17][3]; int dropped; } ContactOut;
+typedef struct { real force[17][3]; int dropped[GO1_CC_COUNT]; uint32_t sig[GO1_SIG_WORDS]; } ContactOut;
 
 /* wl[b]: world impulse vector (x,y,z) of body b's contact in the previous substep (warm start), updated in place */
 static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s, const real* tau, const real* grav,
@@ -525,9 +622,9 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
 
   /* contacts at the start-of-step configuration */
   Contact C[GO1_MAX_CONTACTS];
-  int dropped = 0;
-  const int nc = detect_contacts(cfg, ter, &k, s->pos, C, &dropped);
-  if (out) out->dropped = dropped;
+  const ContactList CL = detect_contacts(cfg, ter, &k, s->pos, C);
+  const int nc = CL.n;
+  if (out) { memcpy(out->dropped, CL.dropped, sizeof CL.dropped); memcpy(out->sig, CL.sig, sizeof CL.sig); }
   /* Joint limits are solver rows, one per joint (generalised impulse along the joint coordinate: equal and opposite on
    * child and parent, so an actuator pushing against a stop or against the velocity limit cannot create net momentum).
    * Row j constrains the joint rate to [vlo, vhi] = [max((lo-q)/h, -vmax), min((hi-q)/h, vmax)]; it enters the solve when
@@ -547,6 +644,7 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
   for (int leg = 0; leg < 4; leg++) {        /* the joints of a leg are strongly coupled: one active row brings in the leg's other two */
     int any = jact[3 * leg] || jact[3 * leg + 1] || jact[3 * leg + 2];
     jact[3 * leg] = jact[3 * leg + 1] = jact[3 * leg + 2] = any;
+    if (any && out) out->sig[2] |= 1u << (28 + leg);
   }
   for (int j = 0; j < 12; j++) {
     if (!jact[j]) continue;
@@ -555,7 +653,7 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
     chol_solve(L, NV, TJ[j]);
     AJ[j] = TJ[j][6 + j];
   }
-  real J[GO1_MAX_CONTACTS][3][NV], T[GO1_MAX_CONTACTS][3][NV], A[GO1_MAX_CONTACTS][3], vstar[GO1_MAX_CONTACTS], cmu[GO1_MAX_CONTACTS];
+  real J[GO1_MAX_CONTACTS][3][NV], T[GO1_MAX_CONTACTS][3][NV], A[GO1_MAX_CONTACTS][3], vstar[GO1_MAX_CONTACTS], cmu[GO1_MAX_CONTACTS], cmud[GO1_MAX_CONTACTS];
   real lamc[GO1_MAX_CONTACTS][3];
   for (int c = 0; c < nc; c++) {
     const real* dirs[3] = {C[c].n, C[c].t1, C[c].t2};
@@ -574,8 +672,10 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
     }
     /* PhysX default combine mode: average of the two materials (robot-robot: the robot's own) */
     const int self = C[c].repB >= 0;
-    cmu[c] = self ? s->mu : 0.5 * (s->mu + (real)cfg->terrain_friction);
-    const real e_c = self ? s->rest : 0.5 * (s->rest + (real)cfg->terrain_restitution);
+    cmu[c] = self ? s->mu : (real)0.5 * (s->mu + (real)cfg->terrain_friction);
+    cmud[c] = self ? s->mu : (real)0.5 * (s->mu + (real)cfg->terrain_dynamic_friction);      /* cone of a sliding contact */
+    if (cmud[c] > cmu[c]) cmud[c] = cmu[c];                                                      /* (never wider than the static cone) */
+    const real e_c = self ? s->rest : (real)0.5 * (s->rest + (real)cfg->terrain_restitution);
     real vs = -C[c].phi / h;
     if (vs > cfg->max_depenetration_velocity) vs = cfg->max_depenetration_velocity;
     real un_pre = 0;
@@ -601,8 +701,10 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
       real u1 = 0, u2 = 0;
       for (int i = 0; i < NV; i++) { u1 += J[c][1][i] * v[i]; u2 += J[c][2][i] * v[i]; }
       real l1 = lamc[c][1] - u1 / A[c][1], l2 = lamc[c][2] - u2 / A[c][2];
+      /* Coulomb cone: a tangential impulse inside the static cone sticks, beyond it the contact slides on the dynamic cone
+       * (PhysX: static / dynamic friction of the material pair) */
       real lim = cmu[c] * ln, nrm = sqrt(l1 * l1 + l2 * l2);
-      if (nrm > lim) { real sc = (nrm > 0) ? lim / nrm : 0; l1 *= sc; l2 *= sc; }
+      if (nrm > lim) { real sc = (nrm > 0) ? cmud[c] * ln / nrm : 0; l1 *= sc; l2 *= sc; }
       real d1 = l1 - lamc[c][1], d2 = l2 - lamc[c][2];
       lamc[c][1] = l1; lamc[c][2] = l2;
       for (int i = 0; i < NV; i++) v[i] += T[c][1][i] * d1 + T[c][2][i] * d2;
@@ -659,15 +761,16 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
 }
 
 /* exported for the invariant tests: mass matrix, bias and free acceleration at a state */
-void go1_oracle_dynamics(const double* root13, const double* q, const double* qd, const double* tau, const double* grav,
+void go1_oracle_dynamics(const double* root13, const double* q, const double* qd, const double* tau, const double* grav_d,
                          double payload, const double* com_disp, double* M_out, double* bias_out, double* acc_out) {
   Phys s;
-  memcpy(s.pos, root13, 3 * sizeof(double)); memcpy(s.quat, root13 + 3, 4 * sizeof(double));
-  memcpy(s.vlin, root13 + 7, 3 * sizeof(double)); memcpy(s.vang, root13 + 10, 3 * sizeof(double));
-  memcpy(s.q, q, 12 * sizeof(double)); memcpy(s.qd, qd, 12 * sizeof(double));
-  s.mass0 = GO1_BODY_MASS[0] + payload;
-  v3set(s.com0, com_disp[0], com_disp[1], com_disp[2]);
+  for (int i = 0; i < 3; i++) { s.pos[i] = (real)root13[i]; s.vlin[i] = (real)root13[7 + i]; s.vang[i] = (real)root13[10 + i]; }
+  for (int i = 0; i < 4; i++) s.quat[i] = (real)root13[3 + i];
+  for (int j = 0; j < 12; j++) { s.q[j] = (real)q[j]; s.qd[j] = (real)qd[j]; }
+  s.mass0 = (real)(GO1_BODY_MASS[0] + payload);
+  v3set(s.com0, (real)com_disp[0], (real)com_disp[1], (real)com_disp[2]);
   s.mu = 1; s.rest = 0;
+  real grav[3] = {(real)grav_d[0], (real)grav_d[1], (real)grav_d[2]};
   Kin k;
   kinematics(&s, &k);
   real vel[NV], zero[NV] = {0}, bias[NV], M[NV * NV];
@@ -680,15 +783,15 @@ void go1_oracle_dynamics(const double* root13, const double* q, const double* qd
     rnea(&k, NULL, e, NULL, col);
     for (int r = 0; r < NV; r++) M[r * NV + c] = col[r];
   }
-  memcpy(M_out, M, sizeof M);
-  memcpy(bias_out, bias, sizeof bias);
+  for (int i = 0; i < NV * NV; i++) M_out[i] = M[i];
+  for (int i = 0; i < NV; i++) bias_out[i] = bias[i];
   real L[NV * NV], acc[NV];
   memcpy(L, M, sizeof M);
   cholesky(L, NV);
   for (int i = 0; i < 6; i++) acc[i] = -bias[i];
-  for (int j = 0; j < 12; j++) acc[6 + j] = tau[j] - bias[6 + j];
+  for (int j = 0; j < 12; j++) acc[6 + j] = (real)tau[j] - bias[6 + j];
   chol_solve(L, NV, acc);
-  memcpy(acc_out, acc, sizeof acc);
+  for (int i = 0; i < NV; i++) acc_out[i] = acc[i];
 }
 
 /* ------------------------------------------------------------------ torque model (legged_robot.py:907-946) */
@@ -710,7 +813,11 @@ static real actuator_net(const real* in6) {
   return o;
 }
 void go1_oracle_actuator_net(const double* in6, int n, double* out) {
-  for (int i = 0; i < n; i++) out[i] = actuator_net(in6 + 6 * i);
+  for (int i = 0; i < n; i++) {
+    real x[6];
+    for (int kx = 0; kx < 6; kx++) x[kx] = (real)in6[6 * i + kx];
+    out[i] = actuator_net(x);
+  }
 }
 
 #define AT(buf, c, e) ((buf)[(size_t)(c) * N + (e)])
@@ -822,7 +929,9 @@ static int g_log_stride = 0;
 
 static real fmod1(real x) { real r = fmod(x, 1.0); if (r < 0) r += 1.0; return r; }   /* torch `%` / remainder */
 
-static void resample_commands(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int64_t step, uint32_t purpose) {
+/* slot_step: the policy step the bookkeeping belongs to (in-step calls: the step in progress; reset_idx between steps: the next
+ * one) — its successes go to slot slot_step % curriculum_update_interval of curriculum_success */
+static void resample_commands(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int64_t step, uint32_t purpose, int64_t slot_step) {
   const int N = cfg->num_envs;
   if (!cfg->device_curriculum) { B->resample_flags[e] |= (purpose == P_CMD_CB) ? 1 : 2; goto clear; }
   {
@@ -838,7 +947,7 @@ static void resample_commands(const Go1SimConfig* cfg, const Go1SimBuffers* B, i
     int cat_old = B->env_command_categories[e], bin_old = B->env_command_bins[e];
     if (ok) {
 #pragma omp atomic
-      B->curriculum_success[cat_old * cfg->num_bins + bin_old] += 1;
+      B->curriculum_success[((size_t)(slot_step % cfg->curriculum_update_interval) * cfg->num_categories + cat_old) * cfg->num_bins + bin_old] += 1;
     }
     /* new category and bin */
     float u0 = rng_uniform(cfg, eg, step, purpose, 0), u1 = rng_uniform(cfg, eg, step, purpose, 1);
@@ -896,23 +1005,28 @@ clear:
   for (int kx = 0; kx < cfg->num_rewards + 5; kx++) AT(B->command_sums, kx, e) = 0;   /* :823-824 */
 }
 
+/* applies the logged per-step updates in slot order (curriculum.py:135-154 once per step and category), then rebuilds the CDFs */
 void go1_oracle_curriculum_update(const Go1SimConfig* cfg, const Go1SimBuffers* B) {
+  const int K = cfg->curriculum_update_interval;
+  float* add = (float*)calloc(cfg->num_bins, sizeof(float));
   for (int c = 0; c < cfg->num_categories; c++) {
     float* w = B->curriculum_weights + (size_t)c * cfg->num_bins;
-    int32_t* s = B->curriculum_success + (size_t)c * cfg->num_bins;
     float* cdf = B->curriculum_cdf + (size_t)c * cfg->num_bins;
-    float* add = (float*)calloc(cfg->num_bins, sizeof(float));
-    for (int b = 0; b < cfg->num_bins; b++) {
-      int cnt = s[b] > 0 ? 1 : 0;
-      for (int p = B->curriculum_nbr_ptr[b]; p < B->curriculum_nbr_ptr[b + 1]; p++) cnt += s[B->curriculum_nbr_idx[p]];
-      add[b] = 0.2f * cnt;
+    for (int slot = 0; slot < K; slot++) {
+      int32_t* s = B->curriculum_success + ((size_t)slot * cfg->num_categories + c) * cfg->num_bins;
+      for (int b = 0; b < cfg->num_bins; b++) {
+        int cnt = s[b] > 0 ? 1 : 0;
+        for (int p = B->curriculum_nbr_ptr[b]; p < B->curriculum_nbr_ptr[b + 1]; p++) cnt += s[B->curriculum_nbr_idx[p]];
+        add[b] = 0.2f * cnt;
+      }
+      for (int b = 0; b < cfg->num_bins; b++) { w[b] = fminf(1.0f, w[b] + add[b]); s[b] = 0; }
     }
     double tot = 0;
-    for (int b = 0; b < cfg->num_bins; b++) { w[b] = fminf(1.0f, w[b] + add[b]); s[b] = 0; tot += w[b]; }
+    for (int b = 0; b < cfg->num_bins; b++) tot += w[b];
     double run = 0;
     for (int b = 0; b < cfg->num_bins; b++) { run += w[b]; cdf[b] = (float)(run / tot); }
-    free(add);
   }
+  free(add);
 }
 
 static void randomize_dof_props(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int64_t step, uint32_t purpose) {
@@ -969,10 +1083,10 @@ static int env_is_eval(int e) { return g_eval_cfg != NULL && e >= g_num_train; }
 static const Go1SimConfig* env_cfg(const Go1SimConfig* cfg, int e) { return env_is_eval(e) ? g_eval_cfg : cfg; }
 
 /* reset_idx for one env (legged_robot.py:150-239,948-1001) */
-static void reset_env(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int64_t step, int lag_slots) {
+static void reset_env(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int64_t step, int lag_slots, int64_t slot_step) {
   const int N = cfg->num_envs;
   uint32_t eg = (uint32_t)(cfg->env_id_offset + e);
-  resample_commands(cfg, B, e, step, P_CMD_RESET);
+  resample_commands(cfg, B, e, step, P_CMD_RESET, slot_step);
   randomize_dof_props(cfg, B, e, step, P_DOFPROPS_RESET);
   if (cfg->randomize_rigids_after_start) randomize_rigid_props(cfg, B, e, step, P_RIGID_RESET);   /* :166-168 */
   for (int j = 0; j < 12; j++) {   /* _reset_dofs :956-958 */
@@ -1019,7 +1133,7 @@ void go1_oracle_reset_idx(const Go1SimConfig* cfg, const Go1SimBuffers* B, const
   for (int kx = 0; kx <= cfg->num_rewards + 1; kx++) B->episode_log[kx] = 0;
   for (int i = 0; i < (ids ? n : cfg->num_envs); i++) {
     const int e = ids ? ids[i] : i;
-    reset_env(env_cfg(cfg, e), B, e, step, cfg->lag_timesteps + 1);
+    reset_env(env_cfg(cfg, e), B, e, step, cfg->lag_timesteps + 1, step);
   }
 }
 
@@ -1194,7 +1308,7 @@ static void post_physics(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e,
     if (y > cfg->terrain_width * cfg->terrain_num_cols - th) y -= cfg->terrain_width * (cfg->terrain_num_cols - 1);
     AT(B->root_states, 0, e) = x; AT(B->root_states, 1, e) = y;
   }
-  if (B->episode_length_buf[e] % cfg->resample_interval == 0) resample_commands(cfg, B, e, counter_post, P_CMD_CB);
+  if (B->episode_length_buf[e] % cfg->resample_interval == 0) resample_commands(cfg, B, e, counter_post, P_CMD_CB, counter_post - 1);
   if (cfg->observe_gait_commands) {   /* _step_contact_targets :826-905 (float32 arithmetic order preserved where it matters) */
     float freq = AT(B->commands, 4, e), phase = AT(B->commands, 5, e), offset = AT(B->commands, 6, e), bound = AT(B->commands, 7, e), dur = AT(B->commands, 8, e);
     float gi = (float)fmod1((real)(float)(B->gait_indices[e] + cfg->dt * freq));
@@ -1291,7 +1405,7 @@ static void post_physics(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e,
   }
 
   /* ---- reset (:122-123) ---- */
-  if (reset) reset_env(cfg, B, e, counter_post, lag_slots);
+  if (reset) reset_env(cfg, B, e, counter_post, lag_slots, counter_post - 1);
 
   /* ---- compute_observations (:302-491) ---- */
   {
@@ -1388,6 +1502,19 @@ static void history_append(const Go1SimConfig* cfg, const Go1SimBuffers* B, int 
   memcpy(row + (size_t)(slot + R) * no, obs, no * sizeof(float));
 }
 
+/* per-substep contact bookkeeping into the (optional) buffers: drops per class, signature words of substep `sub` */
+static void publish_contact_stats(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int sub, const ContactOut* co) {
+  const int N = cfg->num_envs;
+  if (B->contact_drop_counts)
+    for (int c = 0; c < GO1_CC_COUNT; c++)
+      if (co->dropped[c]) {
+#pragma omp atomic
+        B->contact_drop_counts[c] += (uint32_t)co->dropped[c];
+      }
+  if (B->contact_signature && sub < GO1_SIG_MAX_SUBSTEPS)
+    for (int w = 0; w < GO1_SIG_WORDS; w++) AT(B->contact_signature, sub * GO1_SIG_WORDS + w, e) = co->sig[w];
+}
+
 /* ------------------------------------------------------------------ public step */
 typedef struct { int64_t common_step_counter; int32_t lag_head; int32_t history_slot; } Go1OracleCounters;
 
@@ -1421,11 +1548,13 @@ void go1_oracle_step(const Go1SimConfig* cfg, const Go1SimBuffers* B, const floa
         for (int i = 0; i < 3; i++) lam[b][i] = (real)AT(B->contact_forces, 3 * b + i, e) * (real)cfg->sim_dt;
     }
     ContactOut co;
+  memset(&co, 0, sizeof co);
     int head = ctr->lag_head;
     for (int sub = 0; sub < cfg->decimation; sub++) {
       real tau[12];
       compute_torques(cfg, B, e, &head, 1, s.q, s.qd, tau);
       physics_substep(cfg, &ter, &s, tau, grav, lam, warm || (cfg->warm_start && sub > 0), &co);
+      publish_contact_stats(cfg, B, e, sub, &co);
     }
     store_phys(cfg, B, e, &s);
     real fp[4][3], fv[4][3];
@@ -1461,7 +1590,8 @@ void go1_oracle_step(const Go1SimConfig* cfg, const Go1SimBuffers* B, const floa
   }
   ctr->common_step_counter = counter_post;
   ctr->history_slot = (ctr->history_slot + 1) % (cfg->num_obs_history + 1);
-  if (cfg->device_curriculum && B->curriculum_weights && !cfg->defer_curriculum_update) go1_oracle_curriculum_update(cfg, B);
+  if (cfg->device_curriculum && B->curriculum_weights && !cfg->defer_curriculum_update && counter_post % cfg->curriculum_update_interval == 0)
+    go1_oracle_curriculum_update(cfg, B);
 }
 
 /* piecewise entry points mirroring go1sim_compute_torques / go1sim_physics_substep */
@@ -1490,7 +1620,9 @@ void go1_oracle_physics_substep(const Go1SimConfig* cfg, const Go1SimBuffers* B,
       for (int i = 0; i < 3; i++) lam[b][i] = (real)AT(B->contact_forces, 3 * b + i, e) * (real)cfg->sim_dt;
     for (int j = 0; j < 12; j++) tau[j] = AT(B->torques, j, e);
     ContactOut co;
+  memset(&co, 0, sizeof co);
     physics_substep(cfg, &ter, &s, tau, grav, lam, cfg->warm_start, &co);
+    publish_contact_stats(cfg, B, e, 0, &co);
     store_phys(cfg, B, e, &s);
     real fp[4][3], fv[4][3];
     feet_state(&s, fp, fv);
@@ -1503,14 +1635,20 @@ void go1_oracle_physics_substep(const Go1SimConfig* cfg, const Go1SimBuffers* B,
 
 /* post-physics only (tensor maps) on whatever is in the buffers: used to pin the maps against the
  * reference's Python (tests/test_oracle_golden.py).  grav_used: gravity vector of the step. */
-void go1_oracle_post_physics(const Go1SimConfig* cfg, const Go1SimBuffers* B, const double* grav_used, Go1OracleCounters* ctr) {
+void go1_oracle_post_physics(const Go1SimConfig* cfg, const Go1SimBuffers* B, const double* grav_d, Go1OracleCounters* ctr) {
+  const real grav_used[3] = {(real)grav_d[0], (real)grav_d[1], (real)grav_d[2]};
   int64_t counter_post = ctr->common_step_counter + 1;
   for (int kx = 0; kx <= cfg->num_rewards + 1; kx++) B->episode_log[kx] = 0;
   for (int e = 0; e < cfg->num_envs; e++) post_physics(env_cfg(cfg, e), B, e, counter_post, grav_used, cfg->lag_timesteps + 1);
   ctr->common_step_counter = counter_post;
 }
 
-void go1_oracle_gravity_at(const Go1SimConfig* cfg, int64_t t, double* g) { gravity_at(cfg, t, g); }
+void go1_oracle_gravity_at(const Go1SimConfig* cfg, int64_t t, double* g) {
+  real gr[3];
+  gravity_at(cfg, t, gr);
+  for (int i = 0; i < 3; i++) g[i] = gr[i];
+}
+int go1_oracle_real_bytes(void) { return (int)sizeof(real); }
 float go1_oracle_uniform(const Go1SimConfig* cfg, uint32_t env, int64_t step, uint32_t purpose, uint32_t idx) {
   return rng_uniform(cfg, env, step, purpose, idx);
 }

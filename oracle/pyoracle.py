@@ -19,11 +19,12 @@ for p in (_PKG, os.path.join(_PKG, "shims")):
 import go1sim_abi as abi  # noqa: E402
 
 LIB = os.path.join(_HERE, "_build", "libgo1oracle.so")
+LIB32 = os.path.join(_HERE, "_build", "libgo1oracle32.so")        # the same restatement with real = float (Makefile)
 
 
 def build(force=False):
     src = os.path.join(_HERE, "go1_oracle.c")
-    stale = (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(
+    stale = (not os.path.exists(LIB)) or (not os.path.exists(LIB32)) or min(os.path.getmtime(LIB), os.path.getmtime(LIB32) if os.path.exists(LIB32) else 0) < max(
         os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "..", "include", "go1sim.h")))
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
@@ -35,13 +36,26 @@ class Counters(ctypes.Structure):
 
 
 _lib = None
+_lib32 = None
 
 
-def lib():
-    global _lib
+def lib(fp32=False):
+    global _lib, _lib32
+    if fp32:
+        if _lib32 is None:
+            build()
+            _lib32 = _bind(ctypes.CDLL(LIB32))
+            assert _lib32.go1_oracle_real_bytes() == 4
+        return _lib32
     if _lib is None:
         build()
-        L = ctypes.CDLL(LIB)
+        _lib = _bind(ctypes.CDLL(LIB))
+        assert _lib.go1_oracle_real_bytes() == 8
+    return _lib
+
+
+def _bind(L):
+    if True:
         cfgp, bufp, ctrp = ctypes.POINTER(abi.Go1SimConfig), ctypes.POINTER(abi.Go1SimBuffers), ctypes.POINTER(Counters)
         vp = ctypes.c_void_p
         L.go1_oracle_step.argtypes = [cfgp, bufp, vp, ctrp]
@@ -59,8 +73,7 @@ def lib():
         L.go1_oracle_uniform.restype = ctypes.c_float
         assert L.go1_oracle_sizeof_config() == ctypes.sizeof(abi.Go1SimConfig)
         assert L.go1_oracle_sizeof_buffers() == ctypes.sizeof(abi.Go1SimBuffers)
-        _lib = L
-    return _lib
+    return L
 
 
 def _ptr(a):
@@ -70,11 +83,12 @@ def _ptr(a):
 class Oracle:
     """Steps CPU `SimBuffers` (go1sim_host.SimBuffers on device 'cpu') with the oracle."""
 
-    def __init__(self, S, buffers):
+    def __init__(self, S, buffers, fp32=False):
+        """fp32=True: the fp32 build of the same source (precision attribution in the parity tests)"""
         assert buffers.device.type == "cpu"
         self.S, self.buffers = S, buffers
         self.ctr = Counters(0, 0, 0)
-        self.L = lib()
+        self.L = lib(fp32)
 
     def set_eval_config(self, S_eval, num_train_envs):
         """environments [num_train_envs, N) run under S_eval (module-global in the oracle: None switches the split off)"""

@@ -135,7 +135,7 @@ def test_incline_friction_holds_or_slides(oracle_lib, slope, mu_robot, holds):
     hs, hscale, vscale = inclined_field(400, 60, slope)
     H.bind_height_field(S, B, hs, hscale, vscale, 0.0)
     if not holds:
-        S.terrain_friction = 0.0
+        S.terrain_friction = S.terrain_dynamic_friction = 0.0
     standing_state(S, B, z=0.30)
     th = np.arctan(slope)
     B.root_states[0] = 20.0

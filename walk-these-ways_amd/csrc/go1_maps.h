@@ -45,7 +45,8 @@ DEV V3 gravity_at(CfgRef cfg, int64_t t) {
 // ================================================================================================
 DEV float fmod1(float x) { float r = fmodf(x, 1.0f); return r < 0.f ? r + 1.0f : r; }
 
-DEV void resample_commands(CfgRef cfg, BufRef B, int e, int N, int64_t step, uint32_t purpose) {
+// slot_step: the policy step the success bookkeeping belongs to (oracle resample_commands()): slot slot_step % curriculum_update_interval
+DEV void resample_commands(CfgRef cfg, BufRef B, int e, int N, int64_t step, uint32_t purpose, int64_t slot_step) {
   if (cfg.device_curriculum) {
     const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
     const int ep_len = cfg.max_episode_length < cfg.resample_interval ? cfg.max_episode_length : cfg.resample_interval;
@@ -57,7 +58,7 @@ DEV void resample_commands(CfgRef cfg, BufRef B, int e, int N, int64_t step, uin
       if (!(val > cfg.curriculum_threshold[kx])) ok = false;
     }
     int cat_old = B.env_command_categories[e], bin_old = B.env_command_bins[e];
-    if (ok) atomicAdd(&B.curriculum_success[cat_old * cfg.num_bins + bin_old], 1);
+    if (ok) atomicAdd(&B.curriculum_success[((int)(slot_step % cfg.curriculum_update_interval) * cfg.num_categories + cat_old) * cfg.num_bins + bin_old], 1);
     float u0 = rng_uniform(cfg, eg, step, purpose, 0), u1 = rng_uniform(cfg, eg, step, purpose, 1);
     int cat = (int)(u0 * cfg.num_categories);
     if (cat >= cfg.num_categories) cat = cfg.num_categories - 1;
@@ -165,9 +166,9 @@ DEV void randomize_rigid_props(CfgRef cfg, BufRef B, int e, int N, int64_t step,
 
 // is_eval: an evaluation environment (legged_robot.py:188-195): its episode sums stay out of the training log; the first
 // finished episode after the caller armed episode_sums_eval with -1 is kept there
-DEV void reset_env(CfgRef cfg, BufRef B, int e, int N, int64_t step, bool is_eval) {
+DEV void reset_env(CfgRef cfg, BufRef B, int e, int N, int64_t step, bool is_eval, int64_t slot_step) {
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
-  resample_commands(cfg, B, e, N, step, P_CMD_RESET);
+  resample_commands(cfg, B, e, N, step, P_CMD_RESET, slot_step);
   randomize_dof_props(cfg, B, e, N, step, P_DOFPROPS_RESET);
   if (cfg.randomize_rigids_after_start) randomize_rigid_props(cfg, B, e, N, step, P_RIGID_RESET);      // legged_robot.py:166-168
 #pragma unroll 1
@@ -433,7 +434,7 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
       if (y > cfg.terrain_width * cfg.terrain_num_cols - th) y -= cfg.terrain_width * (cfg.terrain_num_cols - 1);
       AT(B.root_states, 0, e) = x; AT(B.root_states, 1, e) = y;
     }
-    if (ep_len % cfg.resample_interval == 0) resample_commands(cfg, B, e, N, counter_post, P_CMD_CB);
+    if (ep_len % cfg.resample_interval == 0) resample_commands(cfg, B, e, N, counter_post, P_CMD_CB, counter_post - 1);
   }
   QUAD_SYNC();                // commands / command_sums of this step are final
   PROF(8);
@@ -596,7 +597,7 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
   PROF(11);
   QUAD_SYNC();                // running sums complete before a reset logs / clears them
   // ---- reset ----------------------------------------------------------------------------------------
-  if (reset && is0) reset_env(cfg, B, e, N, counter_post, is_eval);
+  if (reset && is0) reset_env(cfg, B, e, N, counter_post, is_eval, counter_post - 1);
   QUAD_SYNC();                // the observation sees the post-reset state, as in the reference
   PROF(12);
 

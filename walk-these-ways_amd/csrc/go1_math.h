@@ -156,7 +156,8 @@ DEV void rotate_inertia(const M3& R, const float Il[6], float out[6]) {
 }
 // inverse of a symmetric positive definite 6x6 via Cholesky (fully unrolled, registers)
 // min_pivot: smallest Cholesky pivot met (<= 0 or NaN means A was not positive definite in fp32: fault site)
-DEV Sym6 sym6_inverse(const Sym6& A, float& min_pivot) {
+// Li (may be null): the rows of L^-1, lower triangle row-major (entry (i, j), j <= i, at i (i + 1) / 2 + j): A^-1 = L^-T L^-1
+DEV Sym6 sym6_inverse(const Sym6& A, float& min_pivot, float* Li_out = nullptr) {
   float L[6][6];
   min_pivot = 3.0e38f;
 #pragma unroll
@@ -187,6 +188,12 @@ DEV Sym6 sym6_inverse(const Sym6& A, float& min_pivot) {
       for (int k = j; k < i; k++) s = fmaf(-L[i][k], Li[k][j], s);
       Li[i][j] = s / L[i][i];
     }
+  }
+  if (Li_out) {
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) Li_out[i * (i + 1) / 2 + j] = Li[i][j];
   }
   Sym6 inv;
 #pragma unroll
@@ -235,4 +242,9 @@ DEV SV quad_sum(SV s) {
 }
 // 0 when every argument seen so far is finite, NaN otherwise (x * 0 is NaN for x = +-Inf and NaN)
 DEV float nonfinite_acc(float acc, float x) { return fmaf(x, 0.f, acc); }
+DEV unsigned quad_or(unsigned x) {
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);
+  return x;
+}
 DEV unsigned quad_ballot(bool p, int lane) { return (unsigned)((__ballot(p) >> (lane & ~3)) & 0xFull); }

@@ -21,52 +21,71 @@
 
 #define WAVE 64
 #define EPW 16                       // environments per wavefront
-#define MAXC 8                       // solver contacts per env (oracle: GO1_MAX_CONTACTS)
-#define NRC (3 * MAXC)               // contact rows: contact k -> rows 3k (normal), 3k+1, 3k+2 (tangents)
-#define NRJ 12                       // joint-limit rows: joint j -> row NRC + j
-#define NRT 36                       // rows: NRC + NRJ
-#define NCC (NRT / 4)                // Delassus columns per lane (9): lane `leg` owns the columns c = leg + 4 cc
+#define MAXC GO1_MAX_CONTACTS        // solver contacts per env (24; oracle: the same constant of include/go1sim.h)
+#define NRJ 12                       // joint-limit rows: joint j
+#define MAXSB 4                      // leg-leg self-contacts per env (oracle: GO1_MAX_SELF_LEG_PAIRS)
+#define MAXTR 4                      // trunk corners per env (oracle: GO1_MAX_TRUNK_POINTS)
 #define GO1_LIMIT_RECOVERY_RATE 10.0f   // rad/s: a joint found beyond a stop is brought back at a bounded rate
 #define GO1_LIMIT_SAFETY 2.0f           // x velocity limit: beyond this the limit rows have failed (cut + fault count)
 #define GO1_LIMIT_SLACK 0.2f            // rad beyond a stop: same
+#define GO1_SELF_LEG_RADIUS ((float)GO1_FOOT_RADIUS)
+#define GO1_SELF_THIGH_RADIUS 0.017f
+typedef __attribute__((ext_vector_type(4))) float lf4;
 
-// ---- LDS map (floats), index = field * EPW + env_local ---------------------------------------------
+// ---- LDS map of the solver ------------------------------------------------------------------------------------------------
+// The solve is MATRIX-FREE.  With the ABA factors of the substep, M^-1 factorises: for a row r (a contact direction or a
+// joint coordinate) the backward pass of a unit impulse leaves the wrench g_r arriving at the base and the joint residuals
+// u_j(r) of the row's leg, and
+//     W[r][c] = g_r . I0^-1 g_c + [same leg] sum_j u_j(r) u_j(c) / D_j  =  a_r . a_c,
+//     a_r = [ L^-1 g_r (6) ; u_j(r) / sqrt(D_j) (3, in the slots of the row's leg) ],   I0 = L L^T.
+// The sweep keeps s = sum_r lambda_r a_r — 6 base components replicated in the four lanes of the environment, 3 leg
+// components in the lane of the leg — and evaluates a row's velocity as b_r + a_r . s (9 FMAs) instead of reading a row of an
+// explicit Delassus matrix: no O(rows^2) build, no (rows x rows) LDS block, and the number of contacts is only bounded by the
+// 40-float record each one keeps in LDS (24 per environment; round 2: 8, with an 83 KB matrix).
+//   lds  : per-environment scalars, lds[field * EPW + env_local]
+//   cr   : contact records, 12 x 16-byte slots per contact: cr[(k * CR_Q + q) * EPW + env_local]  (a quad reads one address,
+//          the 16 environments of the wavefront 256 contiguous bytes: conflict-free)
+//          q0..q6  a_n, a_t1, a_t2 (6 + 3 each), flags      q7  c_n = b_n - v*, b_t1, b_t2, -      q8  1/W_nn, 1/W_t1t1, 1/W_t2t2, W_t1n
+//          q9  W_t2n, lambda_n, lambda_t1, lambda_t2          q10 contact point (rel. base origin)   q11 normal
+//          before the emission q9..q11 hold the ITEM the master posted: (phi, x) (u_n, n) (depth, leg, body, share)
+//   jr   : joint-limit rows, 4 slots per joint: a (6 + 3), b, lower, upper, W, 1/W, lambda
+//   sb   : body-B side of the leg-leg self-contacts (exchange between the two lanes of a pair, then u_B of the three rows)
+//   pkl / pke : the emission hand-over — per lane the leg's ABA factors, per environment the free base twist and L^-1
+//   seg  : lower-leg / thigh segments and body twists of every leg (self-collision)
 enum {
   L_LAM = 0,                 // 17 x world impulse (x, y, z) per reported body: solver output / warm start
-  L_CX = 51,                 // MAXC x 3 contact points (rel. base origin)
-  L_CN = L_CX + 3 * MAXC,    // MAXC x 3 contact normals
-  L_RB = L_CN + 3 * MAXC,    // NRC   contact rows: b = J v_free
-  L_RP = L_RB + NRC,         // NRC   normal rows: target velocity v*; tangent rows: W[t][n]
-  L_RI = L_RP + NRC,         // NRC   1 / W[r][r]
-  L_LS = L_RI + NRC,         // NRC   contact impulses: start values in, solution out
-  L_I0 = L_LS + NRC,         // 21    inverse of the base's articulated inertia (upper triangle): for the wavefronts that build W
-  L_KL = L_I0 + 21,          // 4     contacts in the solver list, mask of the legs whose limit rows are in the solve, 1: the build
-                             //       also adds W lambda_start to the rows' right-hand sides (see delassus_rows), != 0: a helper
-                             //       wavefront met a degenerate contact normal (emit_contacts_helper)
-  L_W = L_RB,                // zero-filled at kernel start from here to L_END
-  L_END = L_KL + 4
+  L_KL = 51,                 // +0 contacts listed, +1 mask of the legs with limit rows, +2 contacts listed in the previous substep,
+                             // +3 / +6 != 0: an emitting lane met a non-finite normal / a degenerate row (faults), +4 slot of the
+                             // first self-contact, +5 number of self-contacts
+  L_END = GO1_MAX_OBS        // (post_physics stages the observation rows here)
 };
 #define LDS(f) lds[(f) * EPW + el]
-// Packed records, one per (row, environment), read with 16-byte LDS loads:
-//   row functional RF: [0..5] g_r (the row's unit impulse propagated to the base), [6..8] u_j(r) along the row's leg,
-//                      [9..11] u_j(r) / D_j, [12] leg of the row (4 = trunk)
-//   limit row      JR: [0] b = free joint rate, [1] lower, [2] upper rate bound, [3] W[r][r], [4] 1 / W[r][r] (0: not in the solve)
-//   Delassus row   W : the row's NRT entries; lane `leg` owns columns c = leg + 4 cc: slots cc = 0..7 are its 8 contiguous
-//                      floats at [8 leg], slot cc = 8 sits at [32 + leg]
-#define RF_ST 16
-#define RF(r) (rfl + ((r) * EPW + el) * RF_ST)
-#define JR_ST 8
-#define JR(j) (jrl + ((j) * EPW + el) * JR_ST)
-#define WST 36
-#define WROW(r) (ldsw + ((r) * EPW + el) * WST)
-#define WSH4(r, hf) (reinterpret_cast<lf4*>(WROW(r) + 8 * leg)[hf])       // the lane's column slots 4 hf .. 4 hf + 3 of row r
-#define WSH8(r) (WROW(r)[32 + leg])                                        // the lane's column slot 8 of row r
-#define LDSW_SIZE (NRT * EPW * WST)
-#define MAXSB 2                      // leg-leg self-contacts per env (oracle: GO1_MAX_SELF_LEG_PAIRS)
-#define LDSX_SIZE (NRT * EPW * RF_ST + NRJ * EPW * JR_ST + 3 * MAXSB * EPW * RF_ST)       // RF, JR, then the B sides of leg-leg rows
-#define SB(i) (rfl + NRT * EPW * RF_ST + NRJ * EPW * JR_ST + ((i) * EPW + el) * RF_ST)
-#define GO1_SELF_LEG_RADIUS ((float)GO1_FOOT_RADIUS)
-typedef __attribute__((ext_vector_type(4))) float lf4;
+#define CR_Q 12
+#define JR_Q 4
+#define SB_Q 8
+#define PKL_Q 12
+#define PKE_Q 9
+#define SEG_Q 6
+#define TW_Q 6
+enum {
+  X_CR = 0, X_JR = X_CR + MAXC * CR_Q * EPW, X_SB = X_JR + NRJ * JR_Q * EPW, X_PKL = X_SB + MAXSB * SB_Q * EPW,
+  X_PKE = X_PKL + PKL_Q * WAVE, X_SEG = X_PKE + PKE_Q * EPW, X_TW = X_SEG + SEG_Q * WAVE, X_END = X_TW + TW_Q * WAVE       // (in lf4 units)
+};
+#define CRQ(k, q) crl[((k) * CR_Q + (q)) * EPW + el]
+#define JRQ(j, q) jrl[((j) * JR_Q + (q)) * EPW + el]
+#define SBQ(i, q) sbl[((i) * SB_Q + (q)) * EPW + el]
+struct SolverLds {
+  float* lds;            // L_END * EPW floats
+  lf4* x;                // X_END lf4
+  DEV lf4* cr() const { return x + X_CR; }
+  DEV lf4* jr() const { return x + X_JR; }
+  DEV lf4* sb() const { return x + X_SB; }
+  DEV lf4* pkl() const { return x + X_PKL; }
+  DEV lf4* pke() const { return x + X_PKE; }
+  DEV lf4* seg() const { return x + X_SEG; }
+  DEV lf4* tw() const { return x + X_TW; }
+  DEV float* act_io() const { return reinterpret_cast<float*>(x + X_PKL); }        // the actuator network's transient rows (overlay)
+};
 
 // ================================================================================================
 // torque model (reference legged_robot.py:907-946): the calling lane handles the 3 joints of its leg
@@ -372,12 +391,17 @@ struct Base {             // replicated in the 4 lanes of the environment
 
 DEV V3 model_v3(const float (*tab)[3], int i) { return v3(tab[i][0], tab[i][1], tab[i][2]); }
 
-struct Cand { float phi, x, y, z, un, nx, ny, nz; };     // deepest contact candidate of one reported body
+struct Cand { float phi, x, y, z, un, nx, ny, nz; };     // deepest contact candidate of one group of points
 DEV void cand_init(Cand& c) { c.phi = 1e30f; c.x = c.y = c.z = c.un = 0.f; c.nx = c.ny = 0.f; c.nz = 1.f; }
 
-// terrain height and unit normal at world (x, y): plane, or bilinear interpolation of the int16 height field
-// (same sample convention as _get_heights, reference legged_robot.py:1793-1806; oracle terrain_sample())
-DEV void terrain_sample(CfgRef cfg, const int16_t* __restrict__ hs, float x, float y, float& h, V3& n) {
+// Terrain at world (x, y): height and unit normal of the TOP surface — plane, or bilinear interpolation of the int16 height
+// field (same sample convention as _get_heights, reference legged_robot.py:1793-1806) — and, with WALLS, the vertical face
+// next to the point: unit horizontal normal (towards the low side), horizontal distance, height of its upper edge
+// (oracle terrain_sample(): the `trimesh` terrain's slope_treshold restated per cell of the height field).
+struct Wall { bool on; V3 n; float d, top; };
+template <bool WALLS>
+DEV void terrain_sample(CfgRef cfg, const int16_t* __restrict__ hs, float x, float y, float& h, V3& n, Wall& wall) {
+  wall.on = false; wall.n = v3(1.f, 0.f, 0.f); wall.d = 0.f; wall.top = 0.f;
   if (cfg.terrain_type == 0 || hs == nullptr) { h = 0.f; n = v3(0.f, 0.f, 1.f); return; }
   float fx = (x + cfg.hf_border) / cfg.hf_hscale, fy = (y + cfg.hf_border) / cfg.hf_hscale;
   fx = fminf(fmaxf(fx, 0.f), (float)cfg.hf_rows - 1.000001f);
@@ -385,7 +409,38 @@ DEV void terrain_sample(CfgRef cfg, const int16_t* __restrict__ hs, float x, flo
   const int ix = (int)fx, iy = (int)fy;
   const float ax = fx - ix, ay = fy - iy;
   const int16_t* p = hs + (size_t)ix * cfg.hf_cols + iy;
-  const float h00 = p[0] * cfg.hf_vscale, h01 = p[1] * cfg.hf_vscale, h10 = p[cfg.hf_cols] * cfg.hf_vscale, h11 = p[cfg.hf_cols + 1] * cfg.hf_vscale;
+  float h00 = p[0] * cfg.hf_vscale, h01 = p[1] * cfg.hf_vscale, h10 = p[cfg.hf_cols] * cfg.hf_vscale, h11 = p[cfg.hf_cols + 1] * cfg.hf_vscale;
+  if (WALLS) {
+    const float T = cfg.hf_wall_threshold;
+    const float dx0 = h10 - h00, dx1 = h11 - h01, dy0 = h01 - h00, dy1 = h11 - h10;
+    const bool sx0 = fabsf(dx0) > T, sx1 = fabsf(dx1) > T, sy0 = fabsf(dy0) > T, sy1 = fabsf(dy1) > T;
+    if (sx0 || sx1 || sy0 || sy1) {
+      float best = 1e30f;
+      if (sx0 && sx1 && dx0 * dx1 > 0.f) {
+        const bool up = dx0 > 0.f;
+        wall.on = true; wall.n = v3(up ? -1.f : 1.f, 0.f, 0.f);
+        wall.d = (up ? (1.f - ax) : ax) * cfg.hf_hscale;
+        wall.top = up ? h10 * (1.f - ay) + h11 * ay : h00 * (1.f - ay) + h01 * ay;
+        best = wall.d;
+      }
+      if (sy0 && sy1 && dy0 * dy1 > 0.f) {
+        const bool up = dy0 > 0.f;
+        const float d = (up ? (1.f - ay) : ay) * cfg.hf_hscale;
+        if (d < best) {
+          wall.on = true; wall.n = v3(0.f, up ? -1.f : 1.f, 0.f);
+          wall.d = d;
+          wall.top = up ? h01 * (1.f - ax) + h11 * ax : h00 * (1.f - ax) + h10 * ax;
+        }
+      }
+#pragma unroll
+      for (int pass = 0; pass < 2; pass++) {
+        if (sx0) { const float lo = fminf(h00, h10); h00 = h10 = lo; }
+        if (sx1) { const float lo = fminf(h01, h11); h01 = h11 = lo; }
+        if (sy0) { const float lo = fminf(h00, h01); h00 = h01 = lo; }
+        if (sy1) { const float lo = fminf(h10, h11); h10 = h11 = lo; }
+      }
+    }
+  }
   h = h00 * (1.f - ax) * (1.f - ay) + h10 * ax * (1.f - ay) + h01 * (1.f - ax) * ay + h11 * ax * ay;
   const float dhdx = ((h10 - h00) * (1.f - ay) + (h11 - h01) * ay) / cfg.hf_hscale;
   const float dhdy = ((h01 - h00) * (1.f - ax) + (h11 - h10) * ax) / cfg.hf_hscale;
@@ -393,17 +448,29 @@ DEV void terrain_sample(CfgRef cfg, const int16_t* __restrict__ hs, float x, flo
   n = v3(-dhdx * inv, -dhdy * inv, inv);
 }
 
-// x: candidate point relative to the base origin (world axes); bpos: world position of the base origin
-DEV void cand_try(CfgRef cfg, const int16_t* __restrict__ hs, Cand& c, V3 x, V3 bpos, float radius, SV vb) {
+// x: candidate point relative to the base origin (world axes); bpos: world position of the base origin.  c: deepest
+// top-surface candidate of the point's group, cw: closest wall candidate of its shape
+template <bool WALLS>
+DEV void cand_try(CfgRef cfg, const int16_t* __restrict__ hs, Cand& c, Cand& cw, V3 x, V3 bpos, float radius, SV vb) {
   float h;
   V3 n;
-  terrain_sample(cfg, hs, bpos.x + x.x, bpos.y + x.y, h, n);
-  float phi = (bpos.z + x.z) - radius - h;
+  Wall wl;
+  terrain_sample<WALLS>(cfg, hs, bpos.x + x.x, bpos.y + x.y, h, n, wl);
+  const float phi = (bpos.z + x.z) - radius - h;
   if (phi < c.phi) {
-    V3 xs = x - radius * n;               // contact point on the shape surface
-    V3 vp = vb.l + cross(vb.a, xs);
+    const V3 xs = x - radius * n;               // contact point on the shape surface
+    const V3 vp = vb.l + cross(vb.a, xs);
     c.phi = phi; c.x = xs.x; c.y = xs.y; c.z = xs.z; c.un = dot(n, vp);
     c.nx = n.x; c.ny = n.y; c.nz = n.z;
+  }
+  if (WALLS) {
+    const float phiw = wl.d - radius;
+    if (wl.on && bpos.z + x.z < wl.top && phiw < cw.phi) {
+      const V3 xs = x - radius * wl.n;
+      const V3 vp = vb.l + cross(vb.a, xs);
+      cw.phi = phiw; cw.x = xs.x; cw.y = xs.y; cw.z = xs.z; cw.un = dot(wl.n, vp);
+      cw.nx = wl.n.x; cw.ny = wl.n.y; cw.nz = wl.n.z;
+    }
   }
 }
 DEV void cand_min_dpp(Cand& c, int lane) {      // quad-wide deepest candidate (ties: lower leg index, as the serial scan)
@@ -420,9 +487,9 @@ DEV void cand_min_dpp(Cand& c, int lane) {      // quad-wide deepest candidate (
     if (take) c = o;
   }
 }
-// contact frame: normal n, t1 = x-axis projected on the tangent plane, t2 = n x t1 (oracle detect_contacts())
-// A normal along the x axis leaves no projection: fall back to the y axis (terrain normals have n.z > 0, so this only
-// guards body-body normals and corrupted input) and report it.
+// contact frame: normal n, t1 = x-axis projected on the tangent plane, t2 = n x t1 (oracle contact_frame()).  A normal along
+// the x axis (a wall facing x, a body-body normal) leaves no projection: the y axis takes its place.  Only a non-finite
+// normal is a fault.
 DEV void contact_frame(V3 n, V3& t1, V3& t2, uint32_t& fault) {
   V3 t = v3(1.f - n.x * n.x, -n.x * n.y, -n.x * n.z);
   float tt = dot(t, t);
@@ -463,222 +530,201 @@ DEV bool capsule_contact(V3 p1, V3 q1, float ra, V3 p2, V3 q2, float rb, float c
   return true;
 }
 
-// velocity change of the lane's own leg body at `depth` for the current impulse-propagation state
-DEV SV leg_response(const SV S[3], const SV U[3], const float Dinv[3], SV a0, int depth, bool on_path, int path_depth, const float pu[3]) {
-  SV a = a0;
+// ---- rows ---------------------------------------------------------------------------------------------------------------
+// the ABA factors of one leg as the emission reads them (from registers on the lane that owns the leg, from the hand-over
+// packet on any other lane)
+struct LegFac { SV S[3], U[3]; float Dinv[3], sD[3], qdf[3]; };
+DEV void legfac_store(lf4* pkl, int lane, const LegFac& F) {
+  float f[48];
 #pragma unroll
   for (int j = 0; j < 3; j++) {
+    f[6 * j] = F.S[j].a.x; f[6 * j + 1] = F.S[j].a.y; f[6 * j + 2] = F.S[j].a.z; f[6 * j + 3] = F.S[j].l.x; f[6 * j + 4] = F.S[j].l.y; f[6 * j + 5] = F.S[j].l.z;
+    f[18 + 6 * j] = F.U[j].a.x; f[19 + 6 * j] = F.U[j].a.y; f[20 + 6 * j] = F.U[j].a.z; f[21 + 6 * j] = F.U[j].l.x; f[22 + 6 * j] = F.U[j].l.y; f[23 + 6 * j] = F.U[j].l.z;
+    f[36 + j] = F.Dinv[j]; f[39 + j] = F.sD[j]; f[42 + j] = F.qdf[j];
+  }
+  f[45] = f[46] = f[47] = 0.f;
+#pragma unroll
+  for (int q = 0; q < PKL_Q; q++) pkl[q * WAVE + lane] = (lf4){f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]};
+}
+DEV void legfac_load(const lf4* pkl, int lane_src, LegFac& F) {
+  float f[48];
+#pragma unroll
+  for (int q = 0; q < PKL_Q; q++) { const lf4 v = pkl[q * WAVE + lane_src]; f[4 * q] = v[0]; f[4 * q + 1] = v[1]; f[4 * q + 2] = v[2]; f[4 * q + 3] = v[3]; }
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    F.S[j] = sv(v3(f[6 * j], f[6 * j + 1], f[6 * j + 2]), v3(f[6 * j + 3], f[6 * j + 4], f[6 * j + 5]));
+    F.U[j] = sv(v3(f[18 + 6 * j], f[19 + 6 * j], f[20 + 6 * j]), v3(f[21 + 6 * j], f[22 + 6 * j], f[23 + 6 * j]));
+    F.Dinv[j] = f[36 + j]; F.sD[j] = f[39 + j]; F.qdf[j] = f[42 + j];
+  }
+}
+// the base's side of the hand-over: free twist, restitution of the pair, warm-start switch, rows of L^-1
+struct EnvPk { V3 w_free, v_free; float e_c, warm; float Li[21]; };
+DEV void envpk_store(lf4* pke, int el, const EnvPk& E) {
+  float f[36];
+  f[0] = E.w_free.x; f[1] = E.w_free.y; f[2] = E.w_free.z; f[3] = E.v_free.x; f[4] = E.v_free.y; f[5] = E.v_free.z; f[6] = E.e_c; f[7] = E.warm;
+#pragma unroll
+  for (int i = 0; i < 21; i++) f[8 + i] = E.Li[i];
+#pragma unroll
+  for (int i = 29; i < 36; i++) f[i] = 0.f;
+#pragma unroll
+  for (int q = 0; q < PKE_Q; q++) pke[q * EPW + el] = (lf4){f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]};
+}
+DEV void envpk_load(const lf4* pke, int el, EnvPk& E) {
+  float f[36];
+#pragma unroll
+  for (int q = 0; q < PKE_Q; q++) { const lf4 v = pke[q * EPW + el]; f[4 * q] = v[0]; f[4 * q + 1] = v[1]; f[4 * q + 2] = v[2]; f[4 * q + 3] = v[3]; }
+  E.w_free = v3(f[0], f[1], f[2]); E.v_free = v3(f[3], f[4], f[5]); E.e_c = f[6]; E.warm = f[7];
+#pragma unroll
+  for (int i = 0; i < 21; i++) E.Li[i] = f[8 + i];
+}
+// One solver row in the factorised coordinates (header of this file): a = [L^-1 g ; u_j / sqrt(D_j)]
+struct Row { float g[6], u[3]; };
+DEV float row_dot(const Row& a, const Row& b) {
+  float s = a.g[0] * b.g[0];
+#pragma unroll
+  for (int i = 1; i < 6; i++) s = fmaf(a.g[i], b.g[i], s);
+#pragma unroll
+  for (int i = 0; i < 3; i++) s = fmaf(a.u[i], b.u[i], s);
+  return s;
+}
+// a unit impulse (spatial force pA0 on the body at `depth` of the leg; depth < 0: on the base itself) propagated to the base
+// through the leg's ABA factors: the wrench g arriving at the base and the joint residuals u_j (not yet scaled)
+DEV void row_propagate(const LegFac& F, int depth, SV pA, SV& g, float uj[3]) {
+  uj[0] = uj[1] = uj[2] = 0.f;
+#pragma unroll
+  for (int j = 2; j >= 0; j--) {
     if (j <= depth) {
-      float uu = (on_path && j <= path_depth) ? pu[j] : 0.f;
-      float qdd = Dinv[j] * (uu - dot(U[j], a));
-      a = a + qdd * S[j];
+      const float u = -dot(F.S[j], pA);
+      uj[j] = u;
+      pA = pA + (u * F.Dinv[j]) * F.U[j];
     }
   }
-  return a;
+  g = pA;
+}
+DEV void row_finish(const float Li[21], SV g, const float uj[3], const float sD[3], Row& r) {
+  const float in[6] = {g.a.x, g.a.y, g.a.z, g.l.x, g.l.y, g.l.z};
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float s = Li[i * (i + 1) / 2] * in[0];
+#pragma unroll
+    for (int j = 1; j <= i; j++) s = fmaf(Li[i * (i + 1) / 2 + j], in[j], s);
+    r.g[i] = s;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) r.u[j] = uj[j] * sD[j];
+}
+// flags word of a contact record: leg of body A (4: the base), self-contact bit, 1 + index of the B-side record (0: none)
+DEV float cr_flags(int legA, bool self, int sb1) { return (float)(legA | (self ? 8 : 0) | (sb1 << 4)); }
+// a finished contact into its record.  c_n = b_n - v*
+DEV void contact_record_store(lf4* crl, int el, int k, const Row& an, const Row& a1, const Row& a2, float flags, float cn, float b1, float b2,
+                              float wnn, float w11, float w22, float w1n, float w2n, V3 lam, V3 x, V3 n, uint32_t& fault) {
+  if (!(wnn > 1e-9f) || !(w11 > 1e-9f) || !(w22 > 1e-9f)) fault |= 1u << GO1_FAULT_W_DIAG;
+  CRQ(k, 0) = (lf4){an.g[0], an.g[1], an.g[2], an.g[3]};
+  CRQ(k, 1) = (lf4){an.g[4], an.g[5], an.u[0], an.u[1]};
+  CRQ(k, 2) = (lf4){an.u[2], a1.g[0], a1.g[1], a1.g[2]};
+  CRQ(k, 3) = (lf4){a1.g[3], a1.g[4], a1.g[5], a1.u[0]};
+  CRQ(k, 4) = (lf4){a1.u[1], a1.u[2], a2.g[0], a2.g[1]};
+  CRQ(k, 5) = (lf4){a2.g[2], a2.g[3], a2.g[4], a2.g[5]};
+  CRQ(k, 6) = (lf4){a2.u[0], a2.u[1], a2.u[2], flags};
+  CRQ(k, 7) = (lf4){cn, b1, b2, 0.f};
+  CRQ(k, 8) = (lf4){1.f / wnn, 1.f / w11, 1.f / w22, w1n};
+  CRQ(k, 9) = (lf4){w2n, lam.x, lam.y, lam.z};
+  CRQ(k, 10) = (lf4){x.x, x.y, x.z, 0.f};
+  CRQ(k, 11) = (lf4){n.x, n.y, n.z, 0.f};
+}
+struct Row3 { Row n, t1, t2; int legA, sb1; bool self; };
+DEV void contact_rows_load(const lf4* crl, int el, int k, Row3& R) {
+  const lf4 q0 = CRQ(k, 0), q1 = CRQ(k, 1), q2 = CRQ(k, 2), q3 = CRQ(k, 3), q4 = CRQ(k, 4), q5 = CRQ(k, 5), q6 = CRQ(k, 6);
+  R.n.g[0] = q0[0]; R.n.g[1] = q0[1]; R.n.g[2] = q0[2]; R.n.g[3] = q0[3]; R.n.g[4] = q1[0]; R.n.g[5] = q1[1];
+  R.n.u[0] = q1[2]; R.n.u[1] = q1[3]; R.n.u[2] = q2[0];
+  R.t1.g[0] = q2[1]; R.t1.g[1] = q2[2]; R.t1.g[2] = q2[3]; R.t1.g[3] = q3[0]; R.t1.g[4] = q3[1]; R.t1.g[5] = q3[2];
+  R.t1.u[0] = q3[3]; R.t1.u[1] = q4[0]; R.t1.u[2] = q4[1];
+  R.t2.g[0] = q4[2]; R.t2.g[1] = q4[3]; R.t2.g[2] = q5[0]; R.t2.g[3] = q5[1]; R.t2.g[4] = q5[2]; R.t2.g[5] = q5[3];
+  R.t2.u[0] = q6[0]; R.t2.u[1] = q6[1]; R.t2.u[2] = q6[2];
+  const int fl = (int)q6[3];
+  R.legA = fl & 7; R.self = (fl & 8) != 0; R.sb1 = fl >> 4;
 }
 
-// ---- Delassus matrix W = J M^-1 J^T into LDS ------------------------------------------------------------------------
-// Which rows / columns exist: wave-uniform bounds (scalar branches) from the per-environment contact count and limit-row legs.
-// ---- contact emission on the helper wavefronts ---------------------------------------------------------------------------
-// Publishing a listed contact — frame, target velocity, b = J v_free, start impulse and the three row functionals (a unit
-// impulse propagated through the ABA factors of the contact's leg) — is ~230 instructions, and the master wavefront walks
-// its up to nine items per lane one after the other.  With several wavefronts per workgroup the master only writes
-// PACKETS into the (at that time unused) matrix block — the leg's ABA factors, the environment's free twist, one record per
-// listed terrain contact — and 128 helper lanes take one contact each (contact k of environment el: lane 4 el + (k & 3) of
-// helper wavefront 1 + (k >> 2)).  Self-contacts and limit rows stay with the master, which emits them meanwhile.
-enum { PK_LEG = 0, PK_LEG_ST = 44, PK_ENV = PK_LEG + WAVE * PK_LEG_ST, PK_ENV_ST = 12, PK_ITEM = PK_ENV + EPW * PK_ENV_ST, PK_ITEM_ST = 12,
-       PK_END = PK_ITEM + MAXC * EPW * PK_ITEM_ST };
-
-DEV void emit_contact(CfgRef cfg, float* lds, float* rfl, int el, int k, const Cand& c, int depth, int leg, int body, float share,
-                      const SV (&S)[3], const SV (&U)[3], const float (&Dinv)[3], const float (&qd_free)[3], V3 w_free, V3 v_free,
-                      float e_c, bool use_warm, float h, uint32_t& fault) {
-  const V3 n = v3(c.nx, c.ny, c.nz);
+// Finish the listed TERRAIN contact k of environment el from the item the master posted in its record (any lane may do this:
+// everything comes from LDS): frame, target velocity, b = J v_free, start impulse, the three rows.
+DEV void emit_terrain_contact(CfgRef cfg, const SolverLds& Z, int el, int k, float h, uint32_t& fault) {
+  float* const lds = Z.lds;
+  lf4* const crl = Z.cr();
+  const lf4 i0 = CRQ(k, 9), i1 = CRQ(k, 10), i2 = CRQ(k, 11);
+  const float phi = i0[0], un_pre = i1[0], share = i2[3];
+  const V3 x = v3(i0[1], i0[2], i0[3]), n = v3(i1[1], i1[2], i1[3]);
+  const int depth = (int)i2[0], leg = (int)i2[1], body = (int)i2[2];
+  EnvPk E;
+  envpk_load(Z.pke(), el, E);
+  LegFac F;
+  legfac_load(Z.pkl(), 4 * el + (leg & 3), F);
   V3 t1, t2;
   contact_frame(n, t1, t2, fault);
-  const V3 x = v3(c.x, c.y, c.z);
-  LDS(L_CX + 3 * k) = c.x; LDS(L_CX + 3 * k + 1) = c.y; LDS(L_CX + 3 * k + 2) = c.z;
-  LDS(L_CN + 3 * k) = c.nx; LDS(L_CN + 3 * k + 1) = c.ny; LDS(L_CN + 3 * k + 2) = c.nz;
-  float vs = fminf(-c.phi / h, cfg.max_depenetration_velocity);
-  if (c.un < -cfg.bounce_threshold_velocity && -e_c * c.un > vs) vs = -e_c * c.un;
-  LDS(L_RP + 3 * k) = vs;
-  SV vb = sv(w_free, v_free);
+  float vs = fminf(-phi / h, cfg.max_depenetration_velocity);
+  if (un_pre < -cfg.bounce_threshold_velocity && -E.e_c * un_pre > vs) vs = -E.e_c * un_pre;
+  SV vb = sv(E.w_free, E.v_free);
 #pragma unroll
   for (int j = 0; j < 3; j++)
-    if (j <= depth) vb = vb + qd_free[j] * S[j];
+    if (j <= depth) vb = vb + F.qdf[j] * F.S[j];
   const V3 vp = vb.l + cross(vb.a, x);
-  LDS(L_RB + 3 * k) = dot(n, vp); LDS(L_RB + 3 * k + 1) = dot(t1, vp); LDS(L_RB + 3 * k + 2) = dot(t2, vp);
   const V3 wl = v3(LDS(L_LAM + 3 * body), LDS(L_LAM + 3 * body + 1), LDS(L_LAM + 3 * body + 2));
-  const float sh = use_warm ? share : 0.f;
-  LDS(L_LS + 3 * k) = sh * dot(wl, n); LDS(L_LS + 3 * k + 1) = sh * dot(wl, t1); LDS(L_LS + 3 * k + 2) = sh * dot(wl, t2);
+  const float sh = E.warm != 0.f ? share : 0.f;
+  const V3 lam = v3(sh * dot(wl, n), sh * dot(wl, t1), sh * dot(wl, t2));
+  Row a[3];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
     const V3 d = r == 0 ? n : r == 1 ? t1 : t2;
-    SV pA = -sv(cross(x, d), d);
-    float uj[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 2; j >= 0; j--) {
-      if (j <= depth) {
-        const float u = -dot(S[j], pA);
-        uj[j] = u;
-        pA = pA + (u * Dinv[j]) * U[j];
-      }
-    }
-    lf4* rf = reinterpret_cast<lf4*>(RF(3 * k + r));
-    rf[0] = (lf4){pA.a.x, pA.a.y, pA.a.z, pA.l.x};
-    rf[1] = (lf4){pA.l.y, pA.l.z, uj[0], uj[1]};
-    rf[2] = (lf4){uj[2], uj[0] * Dinv[0], uj[1] * Dinv[1], uj[2] * Dinv[2]};
-    rf[3] = (lf4){depth < 0 ? 4.f : (float)leg, -1.f, 0.f, 0.f};
+    SV g;
+    float uj[3];
+    row_propagate(F, depth, -sv(cross(x, d), d), g, uj);
+    row_finish(E.Li, g, uj, F.sD, a[r]);
   }
+  contact_record_store(crl, el, k, a[0], a[1], a[2], cr_flags(depth < 0 ? 4 : leg, false, 0), dot(n, vp) - vs, dot(t1, vp), dot(t2, vp),
+                       row_dot(a[0], a[0]), row_dot(a[1], a[1]), row_dot(a[2], a[2]), row_dot(a[1], a[0]), row_dot(a[2], a[0]), lam, x, n, fault);
 }
-
-// helper wavefront hw (0, 1: contacts 0..3 / 4..7 of every environment; 2: idle): one listed terrain contact per lane
-DEV void emit_contacts_helper(CfgRef cfg, float* lds, const float* ldsw, float* rfl, int lane, int hw, float h) {
-  if (hw >= (MAXC + 3) / 4) return;
-  const int el = lane >> 2, k = 4 * hw + (lane & 3);
-  const lf4* ep = reinterpret_cast<const lf4*>(ldsw + PK_ENV + el * PK_ENV_ST);
-  const lf4 e0 = ep[0], e1 = ep[1], e2 = ep[2];
-  const int K = (int)e2[0], nF = (int)e2[1], nS = (int)e2[2];
-  if (k >= K || (k >= nF && k < nF + nS)) return;           // not listed / a self-contact (the master's)
-  const lf4* ip = reinterpret_cast<const lf4*>(ldsw + PK_ITEM + (k * EPW + el) * PK_ITEM_ST);
-  const lf4 i0 = ip[0], i1 = ip[1], i2 = ip[2];
-  Cand c;
-  c.phi = i0[0]; c.x = i0[1]; c.y = i0[2]; c.z = i0[3]; c.un = i1[0]; c.nx = i1[1]; c.ny = i1[2]; c.nz = i1[3];
-  const int depth = (int)i2[0], leg = (int)i2[1], body = (int)i2[2];
-  const lf4* lp = reinterpret_cast<const lf4*>(ldsw + PK_LEG + (4 * el + (leg & 3)) * PK_LEG_ST);
-  float f[44];
-#pragma unroll
-  for (int q = 0; q < 11; q++) { const lf4 v = lp[q]; f[4 * q] = v[0]; f[4 * q + 1] = v[1]; f[4 * q + 2] = v[2]; f[4 * q + 3] = v[3]; }
-  SV S[3], U[3];
-  float Dinv[3], qd_free[3];
-#pragma unroll
-  for (int j = 0; j < 3; j++) {
-    S[j] = sv(v3(f[6 * j], f[6 * j + 1], f[6 * j + 2]), v3(f[6 * j + 3], f[6 * j + 4], f[6 * j + 5]));
-    U[j] = sv(v3(f[18 + 6 * j], f[19 + 6 * j], f[20 + 6 * j]), v3(f[21 + 6 * j], f[22 + 6 * j], f[23 + 6 * j]));
-    Dinv[j] = f[36 + j];
-    qd_free[j] = f[39 + j];
-  }
+// terrain contacts k = k0, k0 + kstride, ... of environment el (K listed, nF .. nF + nS - 1 are self-contacts: the master's)
+DEV void emit_terrain_contacts(CfgRef cfg, const SolverLds& Z, int el, int k0, int kstride, float h) {
+  float* const lds = Z.lds;
+  const int K = (int)LDS(L_KL), nF = (int)LDS(L_KL + 4), nS = (int)LDS(L_KL + 5);
   uint32_t fl = 0;
-  emit_contact(cfg, lds, rfl, el, k, c, depth, leg, body, i2[3], S, U, Dinv, qd_free, v3(e0[0], e0[1], e0[2]), v3(e0[3], e1[0], e1[1]),
-               e1[2], e1[3] != 0.f, h, fl);
-  if (fl) LDS(L_KL + 3) = 1.f;
+#pragma unroll 1
+  for (int k = k0; k < K; k += kstride)
+    if (!(k >= nF && k < nF + nS)) emit_terrain_contact(cfg, Z, el, k, h, fl);
+  if (fl & (1u << GO1_FAULT_CONTACT_FRAME)) LDS(L_KL + 3) = 1.f;
+  if (fl & (1u << GO1_FAULT_W_DIAG)) LDS(L_KL + 6) = 1.f;
 }
 
-struct SolveMasks {
-  int Kw;                  // wave-uniform max K
-  unsigned LAw;            // wave-uniform: legs with limit rows in some environment
-  unsigned ccw;            // wave-uniform: column slots cc with an active column somewhere
-  bool colact[NCC];        // column c = leg + 4 cc is a row of THIS environment's solve
-};
-DEV void solver_masks(int K, unsigned lact, bool legact, int leg, SolveMasks& m) {
+// ---- the substep ------------------------------------------------------------------------------------------------------
+// Wave-uniform bounds of the sweep
+struct SolveBounds { int Kw; unsigned LAw; };
+DEV SolveBounds solve_bounds(int K, bool legact) {
+  SolveBounds m;
   m.Kw = 0;
-#pragma unroll
-  for (int kk = 1; kk <= MAXC; kk++) m.Kw = (__ballot(K >= kk) != 0ull) ? kk : m.Kw;
+#pragma unroll 1
+  for (int kk = 1; kk <= MAXC; kk++) { if (__ballot(K >= kk) == 0ull) break; m.Kw = kk; }
   unsigned long long bl = __ballot(legact);
   bl |= bl >> 32; bl |= bl >> 16; bl |= bl >> 8; bl |= bl >> 4;
   m.LAw = (unsigned)(bl & 0xFull);
-  m.ccw = 0;
-#pragma unroll
-  for (int cc = 0; cc < NCC; cc++) {
-    const int c = leg + 4 * cc;
-    m.colact[cc] = c < NRC ? (c < 3 * K) : (c < NRC + NRJ && ((lact >> ((c - NRC) / 3)) & 1u));
-    if (__ballot(m.colact[cc]) != 0ull) m.ccw |= 1u << cc;
-  }
+  return m;
 }
-// the lane's columns: Y_c = I0^-1 g_c, u_j(c) / D_j and the leg of the column
-DEV void lane_columns(const float* rfl, const Sym6& I0inv, int leg, int el, unsigned ccw, SV Y[NCC], float ud[NCC][3], float lg[NCC]) {
-#pragma unroll
-  for (int cc = 0; cc < NCC; cc++) {
-    if (ccw & (1u << cc)) {
-      int c = leg + 4 * cc;
-      c = c < NRC + NRJ ? c : NRC + NRJ - 1;     // lanes 2, 3 have no last column: any finite stand-in (its impulse stays 0)
-      const lf4* rf = reinterpret_cast<const lf4*>(RF(c));
-      const lf4 r0 = rf[0], r1 = rf[1], r2 = rf[2];
-      Y[cc] = sym6_mul(I0inv, sv(v3(r0[0], r0[1], r0[2]), v3(r0[3], r1[0], r1[1])));
-      ud[cc][0] = r2[1]; ud[cc][1] = r2[2]; ud[cc][2] = r2[3];
-      lg[cc] = rf[3][0];
-    } else {                 // a slot no environment of the wavefront uses: zeros, so that the row loop can run branch-free
-      Y[cc] = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
-      ud[cc][0] = ud[cc][1] = ud[cc][2] = 0.f;
-      lg[cc] = -1.f;
-    }
-  }
-}
-// Rows wv, wv + nw, ... of the rows that exist somewhere in the wavefront (every wavefront of the workgroup takes its part;
-// within a wavefront lane `leg` writes the columns c = leg + 4 cc it owns in the sweep).  Inputs come from LDS only: the row
-// functionals, the base's inverse inertia, the per-environment row counts.
-// Warm start in the build: the sweep starts from the row velocities u = b + W lambda_start; the wavefront that builds row r
-// has the whole row in its lanes, so it adds the row's W lambda_start to the stored b (one FMA per entry and a quad sum)
-// instead of the master wavefront streaming the matrix a second time before the first sweep.  Not when some environment
-// of the wavefront has leg-leg self-contacts: their rows are corrected after the build (flag in L_KL + 2).
-DEV void delassus_rows(float* lds, float* ldsw, float* rfl, int lane, int wv, int nw PROF_PARAM) {
-  float* const jrl = rfl + NRT * EPW * RF_ST;
-  const int leg = lane & 3, el = lane >> 2;
-  Sym6 I0inv;
-#pragma unroll
-  for (int i = 0; i < 21; i++) I0inv.m[i] = LDS(L_I0 + i);
-  const int K = (int)LDS(L_KL);
-  const unsigned lact = (unsigned)LDS(L_KL + 1);
-  SolveMasks m;
-  solver_masks(K, lact, ((lact >> leg) & 1u) != 0u, leg, m);
-  SV Y[NCC];
-  float ud[NCC][3], lg[NCC];
-  lane_columns(rfl, I0inv, leg, el, m.ccw, Y, ud, lg);
-  const bool warm_in_build = __ballot(LDS(L_KL + 2) != 0.f) != 0ull;
-  float lamc[NCC];
-#pragma unroll
-  for (int cc = 0; cc < NCC; cc++) {
-    const int c = leg + 4 * cc;
-    lamc[cc] = (warm_in_build && c < 3 * K && c < NRC) ? LDS(L_LS + (c < NRC ? c : 0)) : 0.f;      // (limit rows start from 0)
-  }
-  PROF(3);
-  // The loop body is branch-free apart from the wave-uniform skips; the next row's record is fetched while this row's
-  // entries are computed.
-  auto row_here = [&](int rr) { return (rr % nw) == wv && (rr < NRC ? (rr < 3 * m.Kw) : (((m.LAw >> ((rr - NRC) / 3)) & 1u) != 0u)); };
-  int r = 0;
-  while (r < NRC + NRJ && !row_here(r)) r++;
-  lf4 n0, n1, n2, n3;
-  if (r < NRC + NRJ) { const lf4* rf = reinterpret_cast<const lf4*>(RF(r)); n0 = rf[0]; n1 = rf[1]; n2 = rf[2]; n3 = rf[3]; }
-#pragma unroll 1
-  while (r < NRC + NRJ) {
-    const lf4 r0 = n0, r1 = n1, r2 = n2;
-    const float lr = n3[0];
-    int rn = r + 1;
-    while (rn < NRC + NRJ && !row_here(rn)) rn++;
-    if (rn < NRC + NRJ) { const lf4* rf = reinterpret_cast<const lf4*>(RF(rn)); n0 = rf[0]; n1 = rf[1]; n2 = rf[2]; n3 = rf[3]; }
-    const SV g = sv(v3(r0[0], r0[1], r0[2]), v3(r0[3], r1[0], r1[1]));
-    const float u0 = r1[2], u1 = r1[3], u2 = r2[0];
-    float wv_[NCC];
-#pragma unroll
-    for (int cc = 0; cc < NCC; cc++) {            // branch-free: one basic block of ~130 independent-enough instructions per row
-      const float same = fmaf(u0, ud[cc][0], fmaf(u1, ud[cc][1], u2 * ud[cc][2]));
-      wv_[cc] = dot(g, Y[cc]) + (lr == lg[cc] ? same : 0.f);
-    }
-    WSH4(r, 0) = (lf4){wv_[0], wv_[1], wv_[2], wv_[3]};
-    WSH4(r, 1) = (lf4){wv_[4], wv_[5], wv_[6], wv_[7]};
-    if (m.ccw & 0x100u) WSH8(r) = wv_[8];
-    if (warm_in_build) {
-      float uw = 0.f;
-#pragma unroll
-      for (int cc = 0; cc < NCC; cc++) uw = fmaf(wv_[cc], lamc[cc], uw);      // (inactive slots: entry and impulse are 0)
-      uw = quad_sum(uw);
-      const bool row_on = r < NRC ? (r < 3 * K) : (((lact >> ((r - NRC) / 3)) & 1u) != 0u);
-      if (leg == 0 && row_on) {
-        if (r < NRC) LDS(L_RB + (r < NRC ? r : 0)) += uw;
-        else JR(r < NRC ? 0 : r - NRC)[0] += uw;
-      }
-    }
-    r = rn;
-  }
-}
+// pair index of the legs lo < hi in the order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+DEV int leg_pair_index(int lo, int hi) { return lo == 0 ? hi - 1 : lo == 1 ? hi + 1 : 5; }
 
 // acth != nullptr: the torques of this substep are being evaluated by the helper wavefronts (torque_publish was called, the
 // workgroup barrier behind it passed): they are picked up right before ABA pass 2.
-DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds, float* ldsw, float* rfl, int lane, int nw, Base& s, Leg& L, V3 grav,
-                         bool use_warm, float h, uint32_t& fault, const float* acth PROF_PARAM) {
-  float* const jrl = rfl + NRT * EPW * RF_ST;
+// nw > 1: helper wavefronts run emit_terrain_contacts() between the two workgroup barriers of the emission hand-over.
+template <bool WALLS>
+DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int nw, Base& s, Leg& L, V3 grav,
+                         bool use_warm, float h, uint32_t& fault, const float* acth, int e, int N, int sub PROF_PARAM) {
+  float* const lds = Z.lds;
+  lf4* const crl = Z.cr();
+  lf4* const jrl = Z.jr();
+  lf4* const sbl = Z.sb();
+  const int16_t* __restrict__ hs = B.height_samples;
   const int leg = lane & 3, el = lane >> 2;
   const M3 R0 = quat_to_mat(s.qx, s.qy, s.qz, s.qw);
   const SV v0 = sv(s.w, s.v);
+  const float cd = cfg.contact_distance;
   // ---- base body (replicated) ----------------------------------------------------------------------
   Sym6 IA0;
   SV pA0;
@@ -694,32 +740,32 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     V3 fg = s.mass0 * grav;
     pA0 = cross_force(v0, hv) - sv(cross(c, fg), fg);
   }
-  // Contact candidates: every collision shape contributes up to TWO points — its candidate points are split into the two
-  // ends of the shape's long axis, the deeper end's deepest point is the first contact, the other end's deepest the second
-  // (oracle detect_contacts()).  Trunk box (long axis x): each lane has one corner of either end, quad-wide minimum.
-  Cand cb[2];
+  // Contact candidates (oracle detect_contacts()).  Trunk box: every corner is a candidate of its own (the lane holds corners
+  // 2 leg and 2 leg + 1); its wall candidate is the quad-wide closest.
+  Cand cb[2], cwb;
+  cand_init(cwb);
 #pragma unroll
   for (int mm = 0; mm < 2; mm++) {
     cand_init(cb[mm]);
-    const int m = 2 * leg + mm;            // m & 1 = mm: the end
+    const int m = 2 * leg + mm;
     V3 l = v3((m & 1 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[2]);
-    cand_try(cfg, hs, cb[mm], mul(R0, l), s.pos, 0.f, v0);
-    cand_min_dpp(cb[mm], lane);
+    cand_try<WALLS>(cfg, hs, cb[mm], cwb, mul(R0, l), s.pos, 0.f, v0);
   }
+  if (WALLS) cand_min_dpp(cwb, lane);
 
-  // ---- own leg: kinematics, contact candidates, ABA passes 1+2 ---------------------------------------
-  SV S[3], U[3];
-  float Dinv[3], uu[3];
+  // ---- own leg: kinematics, contact candidates, ABA pass 1 -------------------------------------------
+  LegFac F;
+  float uu[3];
   SV cj[3];
-  Cand ch[2], ct[2], ck[2], cf;      // hip, thigh, calf: one candidate per end; foot
-  V3 pknee, pfoot;                   // own lower leg for the self-collision test: knee, foot centre (rel. base origin)
-  SV vleg2;                          //   and the calf body's twist before the step
-  const float cd0 = cfg.contact_distance;
+  Cand ch[2], ct[2], ck[2], cf, cwt, cwk, cwf;      // hip, thigh, calf: one candidate per end; foot; wall candidates of thigh, calf, foot
+  V3 pthigh, pknee, pfoot;            // own thigh / lower-leg segments for the self-collision test (rel. base origin)
+  SV vthigh, vlow;                    //   and the two bodies' twists before the step
+  SV pA[3];
+  Sym6 IA[3];
   {
     M3 R[3];
     V3 p[3];
-    SV v[3], pA[3];
-    Sym6 IA[3];
+    SV v[3];
     M3 Rpar = R0;
     V3 ppar = v3(0.f, 0.f, 0.f);
     SV vpar = v0;
@@ -731,8 +777,8 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       float sn, cs;
       sincosf(L.q[j], &sn, &cs);
       R[j] = (j == 0) ? rot_x(Rpar, sn, cs) : rot_y(Rpar, sn, cs);
-      S[j] = sv(ax, cross(p[j], ax));
-      SV vj = L.qd[j] * S[j];
+      F.S[j] = sv(ax, cross(p[j], ax));
+      SV vj = L.qd[j] * F.S[j];
       v[j] = vpar + vj;
       cj[j] = cross_motion(v[j], vj);
       float Il[6], Iw[6];
@@ -749,13 +795,15 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     }
 #pragma unroll
     for (int i = 0; i < 2; i++) { cand_init(ch[i]); cand_init(ct[i]); cand_init(ck[i]); }
-    cand_init(cf);
+    cand_init(cf); cand_init(cwt); cand_init(cwk); cand_init(cwf);
     {
+      Cand nowall;
+      cand_init(nowall);
       V3 hc = model_v3(GO1_HIP_CAPSULE_CENTER, leg);
 #pragma unroll
       for (int m = 0; m < 2; m++) {
         V3 l = v3(hc.x, hc.y + (m ? 1.f : -1.f) * (float)GO1_HIP_CAPSULE_HALF, hc.z);
-        cand_try(cfg, hs, ch[m], p[0] + mul(R[0], l), s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0]);
+        cand_try<false>(cfg, hs, ch[m], nowall, p[0] + mul(R[0], l), s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0]);
       }
 #ifndef GO1_ABLATE_CAND
 #pragma unroll
@@ -765,35 +813,236 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
           V3 l = v3(GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[0],
                     GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[1],
                     GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[2]);
-          cand_try(cfg, hs, ct[en], p[1] + mul(R[1], l), s.pos, 0.f, v[1]);
+          cand_try<WALLS>(cfg, hs, ct[en], cwt, p[1] + mul(R[1], l), s.pos, 0.f, v[1]);
         }
 #pragma unroll 1
         for (int m = 4 * en; m < 4 * en + 4; m++) {
           V3 l = v3(GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[0],
                     GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[1],
                     GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[2]);
-          cand_try(cfg, hs, ck[en], p[2] + mul(R[2], l), s.pos, 0.f, v[2]);
+          cand_try<WALLS>(cfg, hs, ck[en], cwk, p[2] + mul(R[2], l), s.pos, 0.f, v[2]);
         }
       }
 #endif
-      cand_try(cfg, hs, cf, p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2]);
-      pknee = p[2]; pfoot = p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)); vleg2 = v[2];
+      cand_try<WALLS>(cfg, hs, cf, cwf, p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2]);
+      pthigh = p[1]; pknee = p[2]; pfoot = p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg));
+      vthigh = v[1]; vlow = v[2];
     }
-    if (acth) {
-      BLOCK_SYNC(nw);                       // the helpers' partial sums are in io[A_OUT]
-      torque_collect(cfg, L, acth, ldsw, lane, leg, fault);
+  }
+
+  // ---- self-collision, geometry (asset self_collisions = 0: enabled): capsules — lower leg (knee -> foot centre, radius of
+  // the foot sphere), thigh (thigh joint -> knee) — of DIFFERENT legs against each other and lower legs against the trunk's
+  // capsule.  Every lane publishes its two segments and the two bodies' twists, tests the pairs it is part of in the
+  // canonical order (body A on the lower-numbered leg), and the environment's pair mask is the OR over the quad.
+  // pid = 6 type + pair (type 0 lower-lower, 1 lower(A)-thigh(B), 2 thigh(A)-lower(B), 3 thigh-thigh); 24 + leg: lower leg - trunk.
+  unsigned smask = 0;              // listed pairs of the environment
+  int nS = 0;
+  if (cfg.self_collision) {
+    lf4* seg = Z.seg();
+    seg[0 * WAVE + lane] = (lf4){pknee.x, pknee.y, pknee.z, pfoot.x};
+    seg[1 * WAVE + lane] = (lf4){pfoot.y, pfoot.z, pthigh.x, pthigh.y};
+    seg[2 * WAVE + lane] = (lf4){pthigh.z, vlow.a.x, vlow.a.y, vlow.a.z};
+    seg[3 * WAVE + lane] = (lf4){vlow.l.x, vlow.l.y, vlow.l.z, vthigh.a.x};
+    seg[4 * WAVE + lane] = (lf4){vthigh.a.y, vthigh.a.z, vthigh.l.x, vthigh.l.y};
+    seg[5 * WAVE + lane] = (lf4){vthigh.l.z, 0.f, 0.f, 0.f};
+    LDS_PHASE();
+    unsigned mybits = 0;
+    const V3 own_p[2] = {pknee, pthigh}, own_q[2] = {pfoot, pknee};
+    // broad phase: the two segments' midpoints further apart than both half lengths + radii + contact distance
+    const float reach = 2.f * 0.1065f + 2.f * GO1_SELF_LEG_RADIUS + cd + 0.01f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int j = (leg + 1 + i) & 3, lj = (lane & ~3) | j;
+      const lf4 a0 = seg[0 * WAVE + lj], a1 = seg[1 * WAVE + lj], a2 = seg[2 * WAVE + lj];
+      const V3 par_p[2] = {v3(a0[0], a0[1], a0[2]), v3(a1[2], a1[3], a2[0])}, par_q[2] = {v3(a0[3], a1[0], a1[1]), v3(a0[0], a0[1], a0[2])};
+      const bool lower = leg < j;
+      const int pair = lower ? leg_pair_index(leg, j) : leg_pair_index(j, leg);
+#pragma unroll
+      for (int type = 0; type < 4; type++) {
+        const int sa = (type >> 1) & 1, sbq = type & 1;                      // segment of body A / B: 0 lower leg, 1 thigh
+        const int so = lower ? sa : sbq, sp = lower ? sbq : sa;               // own / partner segment
+        const V3 mo = 0.5f * (own_p[so] + own_q[so]), mp = 0.5f * (par_p[sp] + par_q[sp]), dm = mo - mp;
+        const bool near = dot(dm, dm) < reach * reach;
+        if (__ballot(near) != 0ull) {
+          Cand c;
+          const float ra = sa ? GO1_SELF_THIGH_RADIUS : GO1_SELF_LEG_RADIUS, rb = sbq ? GO1_SELF_THIGH_RADIUS : GO1_SELF_LEG_RADIUS;
+          const bool hit = near && (lower ? capsule_contact(own_p[so], own_q[so], ra, par_p[sp], par_q[sp], rb, cd, c)
+                                          : capsule_contact(par_p[sp], par_q[sp], ra, own_p[so], own_q[so], rb, cd, c));
+          if (hit) mybits |= 1u << (6 * type + pair);
+        }
+      }
     }
-    // ABA pass 2: calf -> thigh -> hip, then quad-sum into the base
+    {
+      const float ta = (float)(GO1_TRUNK_BOX_HALF[0] - GO1_TRUNK_BOX_HALF[1]);
+      Cand c;
+      if (capsule_contact(pknee, pfoot, GO1_SELF_LEG_RADIUS, mul(R0, v3(-ta, 0.f, 0.f)), mul(R0, v3(ta, 0.f, 0.f)), (float)GO1_TRUNK_BOX_HALF[1], cd, c))
+        mybits |= 1u << (24 + leg);
+    }
+    smask = quad_or(mybits);
+    {   // at most MAXSB leg-leg pairs, in pid order
+      const unsigned legpairs = smask & 0xFFFFFFu;
+      if (__popc(legpairs) > MAXSB) {
+        unsigned keep = 0, cnt = 0;
+#pragma unroll 1
+        for (int pid = 0; pid < 24; pid++)
+          if (legpairs & (1u << pid)) { if (cnt < MAXSB) keep |= 1u << pid; cnt++; }
+        if (leg == 0) {
+          fault |= 1u << GO1_FAULT_CONTACT_DROPPED;
+          if (B.contact_drop_counts) atomicAdd(&B.contact_drop_counts[GO1_CC_SELF], (uint32_t)(cnt - MAXSB));
+        }
+        smask = keep | (smask & 0xF000000u);
+      }
+    }
+    nS = __popc(smask);
+  }
+
+  // ---- solver contact list (oracle detect_contacts()): slots in the priority order feet, foot walls, self-contacts, trunk
+  // corners, trunk wall, calves (first points, walls, second points), thighs (same), hips; at most MAXC, the rest is dropped
+  // and counted per class ---------------------------------------------------------------------------------------------------
+  // own items: 0 foot, 1 foot wall, 2 calf first, 3 calf wall, 4 calf second, 5 thigh first, 6 thigh wall, 7 thigh second,
+  //            8 hip first, 9 hip second, 10 / 11 trunk corners 2 leg, 2 leg + 1, 12 trunk wall (lane 0)
+  const int fk = ck[1].phi < ck[0].phi ? 1 : 0, ft = ct[1].phi < ct[0].phi ? 1 : 0, fh = ch[1].phi < ch[0].phi ? 1 : 0;
+  enum { IT_FOOT = 0, IT_FOOTW, IT_CALF1, IT_CALFW, IT_CALF2, IT_THIGH1, IT_THIGHW, IT_THIGH2, IT_HIP1, IT_HIP2, IT_TR0, IT_TR1, IT_TRW, IT_N };
+  int slot[IT_N];
+  int K, nF;
+  {
+    const unsigned below = (1u << leg) - 1u;
+    int base_ofs = 0;
+    unsigned sig0 = 0, sig1 = 0;
+    int drops[GO1_CC_COUNT];
+#pragma unroll
+    for (int c = 0; c < GO1_CC_COUNT; c++) drops[c] = 0;
+    auto place = [&](int it, bool a, int cls) {
+      const unsigned m = quad_ballot(a, lane);
+      const int cnt = __popc(m);
+      slot[it] = a ? base_ofs + __popc(m & below) : -1;
+      const int over = base_ofs + cnt - (base_ofs > MAXC ? base_ofs : MAXC);
+      if (over > 0) drops[cls] += over;
+      base_ofs += cnt;
+    };
+    place(IT_FOOT, cf.phi < cd, GO1_CC_FOOT);
+    place(IT_FOOTW, WALLS && cwf.phi < cd, GO1_CC_FOOT_WALL);
+    nF = base_ofs;
+    {
+      const int over = base_ofs + nS - (base_ofs > MAXC ? base_ofs : MAXC);
+      if (over > 0) drops[GO1_CC_SELF] += over;
+      base_ofs += nS;
+    }
+    {   // trunk corners in corner order, at most MAXTR
+      const bool a0 = cb[0].phi < cd, a1 = cb[1].phi < cd;
+      const unsigned m0 = quad_ballot(a0, lane), m1 = quad_ballot(a1, lane);
+      const int before = __popc(m0 & below) + __popc(m1 & below);
+      const int r0 = before, r1 = before + (a0 ? 1 : 0);
+      const int tot = __popc(m0) + __popc(m1), listed = tot < MAXTR ? tot : MAXTR;
+      slot[IT_TR0] = (a0 && r0 < MAXTR) ? base_ofs + r0 : -1;
+      slot[IT_TR1] = (a1 && r1 < MAXTR) ? base_ofs + r1 : -1;
+      drops[GO1_CC_TRUNK] += tot - listed;
+      const int over = base_ofs + listed - (base_ofs > MAXC ? base_ofs : MAXC);
+      if (over > 0) drops[GO1_CC_TRUNK] += over;
+      base_ofs += listed;
+    }
+    place(IT_TRW, WALLS && leg == 0 && cwb.phi < cd, GO1_CC_WALL);
+    place(IT_CALF1, (fk ? ck[1].phi : ck[0].phi) < cd, GO1_CC_CALF);
+    place(IT_CALFW, WALLS && cwk.phi < cd, GO1_CC_WALL);
+    place(IT_CALF2, (fk ? ck[0].phi : ck[1].phi) < cd, GO1_CC_CALF);
+    place(IT_THIGH1, (ft ? ct[1].phi : ct[0].phi) < cd, GO1_CC_THIGH);
+    place(IT_THIGHW, WALLS && cwt.phi < cd, GO1_CC_WALL);
+    place(IT_THIGH2, (ft ? ct[0].phi : ct[1].phi) < cd, GO1_CC_THIGH);
+    place(IT_HIP1, (fh ? ch[1].phi : ch[0].phi) < cd, GO1_CC_HIP);
+    place(IT_HIP2, (fh ? ch[0].phi : ch[1].phi) < cd, GO1_CC_HIP);
+    K = base_ofs > MAXC ? MAXC : base_ofs;
+#pragma unroll
+    for (int it = 0; it < IT_N; it++) if (slot[it] >= MAXC) slot[it] = -1;
+    if (base_ofs > MAXC || drops[GO1_CC_TRUNK] > 0) {
+      if (leg == 0) {
+        fault |= 1u << GO1_FAULT_CONTACT_DROPPED;
+        if (B.contact_drop_counts) {
+#pragma unroll
+          for (int c = 0; c < GO1_CC_COUNT; c++)
+            if (drops[c] > 0) atomicAdd(&B.contact_drop_counts[c], (uint32_t)drops[c]);
+        }
+      }
+      sig1 |= 1u << 31;
+    }
+    if (B.contact_signature != nullptr && sub < GO1_SIG_MAX_SUBSTEPS) {      // tests only: which points are listed
+      if (slot[IT_FOOT] >= 0) sig0 |= 1u << leg;
+      if (slot[IT_TR0] >= 0) sig0 |= 1u << (4 + 2 * leg);
+      if (slot[IT_TR1] >= 0) sig0 |= 1u << (5 + 2 * leg);
+      if (slot[IT_CALF1] >= 0) sig0 |= 1u << (12 + 2 * leg + fk);
+      if (slot[IT_CALF2] >= 0) sig0 |= 1u << (12 + 2 * leg + 1 - fk);
+      if (slot[IT_THIGH1] >= 0) sig0 |= 1u << (20 + 2 * leg + ft);
+      if (slot[IT_THIGH2] >= 0) sig0 |= 1u << (20 + 2 * leg + 1 - ft);
+      if (slot[IT_FOOTW] >= 0) sig1 |= 1u << leg;
+      if (slot[IT_TRW] >= 0) sig1 |= 1u << 4;
+      if (slot[IT_CALFW] >= 0) sig1 |= 1u << (5 + leg);
+      if (slot[IT_THIGHW] >= 0) sig1 |= 1u << (9 + leg);
+      if (slot[IT_HIP1] >= 0) sig1 |= 1u << (13 + 2 * leg + fh);
+      if (slot[IT_HIP2] >= 0) sig1 |= 1u << (13 + 2 * leg + 1 - fh);
+      unsigned sself = 0, pos = nF;          // self pairs that found a slot
+#pragma unroll 1
+      for (int pid = 0; pid < 28; pid++)
+        if (smask & (1u << pid)) { if ((int)pos < MAXC) sself |= 1u << pid; pos++; }
+      sig0 = quad_or(sig0); sig1 = quad_or(sig1);
+      if (leg == 0) {
+        AT(B.contact_signature, sub * GO1_SIG_WORDS + 0, e) = sig0;
+        AT(B.contact_signature, sub * GO1_SIG_WORDS + 1, e) = sig1;
+        AT(B.contact_signature, sub * GO1_SIG_WORDS + 2, e) = sself;       // (limit-row legs are OR-ed in below)
+      }
+    }
+  }
+  PROF(19);
+  // ---- post the listed terrain points as items into their records (q9 .. q11), invalidate the records the previous
+  // substep used beyond this one's count (their impulses and inverse diagonals: the sweep then leaves them at zero) ----------
+  {
+    // warm start: a body's previous impulse is shared equally by its listed top-surface points; wall points start from zero
+    const float share_k = (slot[IT_CALF1] >= 0 && slot[IT_CALF2] >= 0) ? 0.5f : 1.f, share_t = (slot[IT_THIGH1] >= 0 && slot[IT_THIGH2] >= 0) ? 0.5f : 1.f,
+                share_h = (slot[IT_HIP1] >= 0 && slot[IT_HIP2] >= 0) ? 0.5f : 1.f;
+    const int ntr = __popc(quad_ballot(slot[IT_TR0] >= 0, lane)) + __popc(quad_ballot(slot[IT_TR1] >= 0, lane));
+    const float share_b = ntr > 0 ? 1.f / (float)ntr : 0.f;
+    auto post = [&](int k, const Cand& c, int depth, int body, float share) {
+      CRQ(k, 9) = (lf4){c.phi, c.x, c.y, c.z};
+      CRQ(k, 10) = (lf4){c.un, c.nx, c.ny, c.nz};
+      CRQ(k, 11) = (lf4){(float)depth, (float)leg, (float)body, share};
+    };
+    if (slot[IT_FOOT] >= 0) post(slot[IT_FOOT], cf, 2, 4 + 4 * leg, 1.f);
+    if (WALLS && slot[IT_FOOTW] >= 0) post(slot[IT_FOOTW], cwf, 2, 4 + 4 * leg, 0.f);
+    if (slot[IT_CALF1] >= 0) post(slot[IT_CALF1], fk ? ck[1] : ck[0], 2, 3 + 4 * leg, share_k);
+    if (WALLS && slot[IT_CALFW] >= 0) post(slot[IT_CALFW], cwk, 2, 3 + 4 * leg, 0.f);
+    if (slot[IT_CALF2] >= 0) post(slot[IT_CALF2], fk ? ck[0] : ck[1], 2, 3 + 4 * leg, share_k);
+    if (slot[IT_THIGH1] >= 0) post(slot[IT_THIGH1], ft ? ct[1] : ct[0], 1, 2 + 4 * leg, share_t);
+    if (WALLS && slot[IT_THIGHW] >= 0) post(slot[IT_THIGHW], cwt, 1, 2 + 4 * leg, 0.f);
+    if (slot[IT_THIGH2] >= 0) post(slot[IT_THIGH2], ft ? ct[0] : ct[1], 1, 2 + 4 * leg, share_t);
+    if (slot[IT_HIP1] >= 0) post(slot[IT_HIP1], fh ? ch[1] : ch[0], 0, 1 + 4 * leg, share_h);
+    if (slot[IT_HIP2] >= 0) post(slot[IT_HIP2], fh ? ch[0] : ch[1], 0, 1 + 4 * leg, share_h);
+    if (slot[IT_TR0] >= 0) post(slot[IT_TR0], cb[0], -1, 0, share_b);
+    if (slot[IT_TR1] >= 0) post(slot[IT_TR1], cb[1], -1, 0, share_b);
+    if (WALLS && slot[IT_TRW] >= 0) post(slot[IT_TRW], cwb, -1, 0, 0.f);
+    if (leg == 0) {
+      const int Kprev = (int)LDS(L_KL + 2);
+#pragma unroll 1
+      for (int k = K; k < Kprev; k++) { CRQ(k, 8) = (lf4){0.f, 0.f, 0.f, 0.f}; CRQ(k, 9) = (lf4){0.f, 0.f, 0.f, 0.f}; }
+      LDS(L_KL) = (float)K; LDS(L_KL + 2) = (float)K; LDS(L_KL + 3) = 0.f; LDS(L_KL + 4) = (float)nF; LDS(L_KL + 5) = (float)nS; LDS(L_KL + 6) = 0.f;
+    }
+  }
+  PROF(20);
+  if (acth) {
+    BLOCK_SYNC(nw);                       // the helpers' partial sums are in io[A_OUT]
+    torque_collect(cfg, L, acth, Z.act_io(), lane, leg, fault);
+  }
+  // ---- ABA pass 2: calf -> thigh -> hip, then quad-sum into the base -------------------------------------------------------
+  {
     SV pa_hip;
 #pragma unroll
     for (int j = 2; j >= 0; j--) {
-      U[j] = sym6_mul(IA[j], S[j]);
-      float D = dot(S[j], U[j]);
+      F.U[j] = sym6_mul(IA[j], F.S[j]);
+      float D = dot(F.S[j], F.U[j]);
       if (!(D > 1e-9f)) { fault |= 1u << GO1_FAULT_JOINT_D; D = 1e-9f; }
-      Dinv[j] = 1.f / D;
-      uu[j] = L.tau[j] - dot(S[j], pA[j]);
-      sym6_rank1_sub(IA[j], U[j], Dinv[j]);
-      SV pa = pA[j] + sym6_mul(IA[j], cj[j]) + (uu[j] * Dinv[j]) * U[j];
+      const float rs = rsqrtf(D);
+      F.sD[j] = rs;
+      F.Dinv[j] = rs * rs;
+      uu[j] = L.tau[j] - dot(F.S[j], pA[j]);
+      sym6_rank1_sub(IA[j], F.U[j], F.Dinv[j]);
+      SV pa = pA[j] + sym6_mul(IA[j], cj[j]) + (uu[j] * F.Dinv[j]) * F.U[j];
       if (j > 0) { sym6_add(IA[j - 1], IA[j]); pA[j - 1] = pA[j - 1] + pa; }
       else pa_hip = pa;
     }
@@ -801,151 +1050,26 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     for (int i = 0; i < 21; i++) IA0.m[i] += quad_sum(IA[0].m[i]);
     pA0 = pA0 + quad_sum(pa_hip);
   }
-
   PROF(2);
   // ---- ABA pass 3 ------------------------------------------------------------------------------------
+  EnvPk E;
   float min_pivot;
-  const Sym6 I0inv = sym6_inverse(IA0, min_pivot);
+  const Sym6 I0inv = sym6_inverse(IA0, min_pivot, E.Li);
   if (!(min_pivot > 1e-9f)) fault |= 1u << GO1_FAULT_BASE_PIVOT;
   SV a0 = -sym6_mul(I0inv, pA0);
-  V3 w_free = s.w + h * a0.a;
-  V3 v_free = s.v + h * (a0.l + cross(s.w, s.v));
-  float qd_free[3];
+  const V3 w_free = s.w + h * a0.a;
+  const V3 v_free = s.v + h * (a0.l + cross(s.w, s.v));
   {
     SV a = a0;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       SV ap = a + cj[j];
-      float qdd = Dinv[j] * (uu[j] - dot(U[j], ap));
-      a = ap + qdd * S[j];
-      qd_free[j] = L.qd[j] + h * qdd;
+      float qdd = F.Dinv[j] * (uu[j] - dot(F.U[j], ap));
+      a = ap + qdd * F.S[j];
+      F.qdf[j] = L.qd[j] + h * qdd;
     }
   }
-
-  // ---- self-collision (asset self_collisions = 0: enabled): the lower legs (knee -> foot centre, radius of the foot sphere)
-  // against each other and against the trunk's capsule.  Every lane publishes its lower leg (segment, body twist before the
-  // step, free twist), reads the other three, and evaluates the pairs it is part of in the canonical (lower leg first)
-  // order, so both lanes of a pair hold bit-identical contact data. -------------------------------------------------------
-  Cand sc[4];                      // contact with partner leg (leg + 1 + i) & 3 for i < 3; [3]: with the trunk (un: A - B normal velocity)
-  V3 sfree[4];                     // relative free velocity (A - B) at the contact point
-  bool sact[4] = {false, false, false, false};
-  unsigned smask = 0;              // environment-wide: bit pid of every active pair (pairs 0..5 leg-leg, 6..9 trunk-leg)
-  SV sv_pre_own, sv_free_own;      // own lower leg: twist before the step / free twist (about the base origin, world axes)
-  if (cfg.self_collision) {
-    SV vfree = sv(w_free, v_free);
-#pragma unroll
-    for (int j = 0; j < 3; j++) vfree = vfree + qd_free[j] * S[j];
-    sv_pre_own = vleg2; sv_free_own = vfree;
-    {
-      lf4* a = reinterpret_cast<lf4*>(RF(2 * leg));
-      a[0] = (lf4){pknee.x, pknee.y, pknee.z, pfoot.x};
-      a[1] = (lf4){pfoot.y, pfoot.z, vleg2.a.x, vleg2.a.y};
-      a[2] = (lf4){vleg2.a.z, vleg2.l.x, vleg2.l.y, vleg2.l.z};
-      lf4* bq = reinterpret_cast<lf4*>(RF(2 * leg + 1));
-      bq[0] = (lf4){vfree.a.x, vfree.a.y, vfree.a.z, vfree.l.x};
-      bq[1] = (lf4){vfree.l.y, vfree.l.z, 0.f, 0.f};
-    }
-    LDS_PHASE();
-    unsigned mybits = 0;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const int j = (leg + 1 + i) & 3;
-      const lf4* a = reinterpret_cast<const lf4*>(RF(2 * j));
-      const lf4 a0 = a[0], a1 = a[1];
-      const V3 pj = v3(a0[0], a0[1], a0[2]), qj = v3(a0[3], a1[0], a1[1]);
-      const bool lower = leg < j;                               // canonical order: lower leg index is body A
-      sact[i] = lower ? capsule_contact(pknee, pfoot, GO1_SELF_LEG_RADIUS, pj, qj, GO1_SELF_LEG_RADIUS, cd0, sc[i])
-                      : capsule_contact(pj, qj, GO1_SELF_LEG_RADIUS, pknee, pfoot, GO1_SELF_LEG_RADIUS, cd0, sc[i]);
-      const int lo_ = lower ? leg : j, hi_ = lower ? j : leg;
-      const int pid = lo_ == 0 ? hi_ - 1 : lo_ == 1 ? hi_ + 1 : 5;
-      if (sact[i] && lower) mybits |= 1u << pid;
-      if (sact[i]) {                                            // relative velocity (A - B) at the contact point
-        const lf4 a2 = a[2];
-        const SV vpreJ = sv(v3(a1[2], a1[3], a2[0]), v3(a2[1], a2[2], a2[3]));
-        const lf4* bq = reinterpret_cast<const lf4*>(RF(2 * j + 1));
-        const lf4 b0 = bq[0], b1 = bq[1];
-        const SV vfreeJ = sv(v3(b0[0], b0[1], b0[2]), v3(b0[3], b1[0], b1[1]));
-        const V3 x = v3(sc[i].x, sc[i].y, sc[i].z), n = v3(sc[i].nx, sc[i].ny, sc[i].nz);
-        const SV pa = lower ? sv_pre_own : vpreJ, pb = lower ? vpreJ : sv_pre_own;
-        const SV fa = lower ? sv_free_own : vfreeJ, fbq = lower ? vfreeJ : sv_free_own;
-        sc[i].un = dot(n, (pa.l + cross(pa.a, x)) - (pb.l + cross(pb.a, x)));
-        sfree[i] = (fa.l + cross(fa.a, x)) - (fbq.l + cross(fbq.a, x));
-      }
-    }
-    {
-      const float ta = (float)(GO1_TRUNK_BOX_HALF[0] - GO1_TRUNK_BOX_HALF[1]);
-      sact[3] = capsule_contact(pknee, pfoot, GO1_SELF_LEG_RADIUS, mul(R0, v3(-ta, 0.f, 0.f)), mul(R0, v3(ta, 0.f, 0.f)),
-                                (float)GO1_TRUNK_BOX_HALF[1], cd0, sc[3]);
-      if (sact[3]) {
-        mybits |= 1u << (6 + leg);
-        const V3 x = v3(sc[3].x, sc[3].y, sc[3].z), n = v3(sc[3].nx, sc[3].ny, sc[3].nz);
-        const SV fb0 = sv(w_free, v_free);
-        sc[3].un = dot(n, (sv_pre_own.l + cross(sv_pre_own.a, x)) - (v0.l + cross(v0.a, x)));
-        sfree[3] = (sv_free_own.l + cross(sv_free_own.a, x)) - (fb0.l + cross(fb0.a, x));
-      }
-    }
-    mybits |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mybits, 0xB1, 0xF, 0xF, false);
-    mybits |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mybits, 0x4E, 0xF, 0xF, false);
-    smask = mybits;
-    LDS_PHASE();                   // the published segments are overwritten by the row functionals below
-  }
-
-  // ---- solver contact list (oracle detect_contacts()): feet, trunk (first, second point), calves (first points, second
-  // points), thighs, hips; at most MAXC, the rest is dropped and counted -------------------------------------------------
-  const float cd = cfg.contact_distance;
-  // own items in priority order: 0 foot, 1 calf first, 2 calf second, 3 thigh first, 4 thigh second, 5 hip first, 6 hip second
-  const int fk = ck[1].phi < ck[0].phi ? 1 : 0, ft = ct[1].phi < ct[0].phi ? 1 : 0, fh = ch[1].phi < ch[0].phi ? 1 : 0;
-  const int fb = cb[1].phi < cb[0].phi ? 1 : 0;
-  Cand item[7];
-  item[0] = cf;
-  item[1] = fk ? ck[1] : ck[0]; item[2] = fk ? ck[0] : ck[1];
-  item[3] = ft ? ct[1] : ct[0]; item[4] = ft ? ct[0] : ct[1];
-  item[5] = fh ? ch[1] : ch[0]; item[6] = fh ? ch[0] : ch[1];
-  const Cand tb0 = fb ? cb[1] : cb[0], tb1 = fb ? cb[0] : cb[1];
-  const bool act_b0 = tb0.phi < cd, act_b1 = tb1.phi < cd;
-  const unsigned below = (1u << leg) - 1u;
-  int slot[7], slot_b0, slot_b1, nF;
-  int K;
-  {
-    int base_ofs = 0;
-    unsigned m0 = quad_ballot(item[0].phi < cd, lane);
-    slot[0] = (item[0].phi < cd) ? __popc(m0 & below) : -1;
-    base_ofs += __popc(m0);
-    // self-contacts: pair order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3), then trunk-leg 0..3; at most MAXSB leg-leg pairs
-    {
-      const unsigned legpairs = smask & 0x3Fu;
-      unsigned keep = 0, cnt = 0;
-#pragma unroll
-      for (int pid = 0; pid < 6; pid++)
-        if (legpairs & (1u << pid)) { if (cnt < MAXSB) keep |= 1u << pid; cnt++; }
-      if (cnt > MAXSB && leg == 0) fault |= 1u << GO1_FAULT_CONTACT_DROPPED;
-      smask = keep | (smask & 0x3C0u);
-    }
-    nF = base_ofs;
-    base_ofs += __popc(smask);
-    const int ofs_b0 = base_ofs;
-    base_ofs += (act_b0 ? 1 : 0) + (act_b1 ? 1 : 0);
-#pragma unroll
-    for (int i = 1; i < 7; i++) {
-      const bool a = item[i].phi < cd;
-      const unsigned m = quad_ballot(a, lane);
-      slot[i] = a ? base_ofs + __popc(m & below) : -1;
-      base_ofs += __popc(m);
-    }
-    K = base_ofs;
-    if (K > MAXC && leg == 0) fault |= 1u << GO1_FAULT_CONTACT_DROPPED;
-    K = K > MAXC ? MAXC : K;
-#pragma unroll
-    for (int i = 0; i < 7; i++) if (slot[i] >= MAXC) slot[i] = -1;
-    // trunk slots (handled by lane 0, known to all)
-    slot_b0 = act_b0 && ofs_b0 < MAXC ? ofs_b0 : -1;
-    slot_b1 = act_b1 && ofs_b0 + (act_b0 ? 1 : 0) < MAXC ? ofs_b0 + (act_b0 ? 1 : 0) : -1;
-  }
-  PROF(19);
-  const float e_c = 0.5f * (s.rest + cfg.terrain_restitution);
-  // warm start: a body's previous impulse is shared equally by its listed points
-  const float share_k = (slot[1] >= 0 && slot[2] >= 0) ? 0.5f : 1.f, share_t = (slot[3] >= 0 && slot[4] >= 0) ? 0.5f : 1.f,
-              share_h = (slot[5] >= 0 && slot[6] >= 0) ? 0.5f : 1.f, share_b = (slot_b0 >= 0 && slot_b1 >= 0) ? 0.5f : 1.f;
+  E.w_free = w_free; E.v_free = v_free; E.e_c = 0.5f * (s.rest + cfg.terrain_restitution); E.warm = use_warm ? 1.f : 0.f;
 
   // ---- joint-limit rows of the own leg ------------------------------------------------------------------
   // A joint's position / velocity limits are ONE solver row: a generalised impulse along the joint coordinate (equal and
@@ -966,409 +1090,289 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
       hi = fmaxf(hi, -GO1_LIMIT_RECOVERY_RATE);
       jlo[j] = fmaxf(lo, -vl);
       jhi[j] = fminf(hi, vl);
-      const float vf = qd_free[j];
+      const float vf = F.qdf[j];
       if (!(vf > lo + mp && vf < hi - mp && vf > -vl + mv && vf < vl - mv)) legact = true;
     }
   }
   const unsigned lact = quad_ballot(legact, lane);      // legs of this environment whose limit rows are in the solve
+  if (B.contact_signature != nullptr && sub < GO1_SIG_MAX_SUBSTEPS && leg == 0) AT(B.contact_signature, sub * GO1_SIG_WORDS + 2, e) |= lact << 28;
 
-  // publish the listed contacts: point, normal, target normal velocity, b = J v_free, start impulse — and the row
-  // functionals: each row's unit impulse propagated through the ABA factors of the contact's leg to the base.
-  // For a unit impulse along row c the backward ABA pass leaves g_c, the wrench arriving at the base, and the joint
-  // residuals u_j(c).  By reciprocity the same vectors are the row functionals, so
-  //     W[r][c] = g_r . (I0^-1 g_c)  +  [same leg] sum_j u_j(r) u_j(c) / D_j
-  // (legs couple only through the base).  A contact row starts from the spatial force of the unit impulse at the contact
-  // point, a joint row from the unit generalised impulse at its joint.
-  PROF(20);
-  const bool offload = nw > 1;         // terrain contacts on the helper wavefronts (emit_contacts_helper)
-  if (offload) {
-    lf4* lp = reinterpret_cast<lf4*>(ldsw + PK_LEG + lane * PK_LEG_ST);
-    float f[44];
+  // ---- hand-over: the leg's factors, the base's free twist and L^-1; the terrain contacts are finished by the helper
+  // wavefronts (nw > 1) while this one emits the self-contacts and the limit rows --------------------------------------------
+  legfac_store(Z.pkl(), lane, F);
+  if (leg == 0) { envpk_store(Z.pke(), el, E); LDS(L_KL + 1) = (float)lact; }
+  if (cfg.self_collision && __ballot(smask != 0u) != 0ull) {          // free twists of the own lower leg / thigh for the partners
+    SV fl = sv(w_free, v_free), ft_;
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-      f[6 * j] = S[j].a.x; f[6 * j + 1] = S[j].a.y; f[6 * j + 2] = S[j].a.z; f[6 * j + 3] = S[j].l.x; f[6 * j + 4] = S[j].l.y; f[6 * j + 5] = S[j].l.z;
-      f[18 + 6 * j] = U[j].a.x; f[19 + 6 * j] = U[j].a.y; f[20 + 6 * j] = U[j].a.z; f[21 + 6 * j] = U[j].l.x; f[22 + 6 * j] = U[j].l.y; f[23 + 6 * j] = U[j].l.z;
-      f[36 + j] = Dinv[j];
-      f[39 + j] = qd_free[j];
-    }
-    f[42] = f[43] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 11; q++) lp[q] = (lf4){f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]};
-    if (leg == 0) {
-      lf4* ep = reinterpret_cast<lf4*>(ldsw + PK_ENV + el * PK_ENV_ST);
-      ep[0] = (lf4){w_free.x, w_free.y, w_free.z, v_free.x};
-      ep[1] = (lf4){v_free.y, v_free.z, e_c, use_warm ? 1.f : 0.f};
-      ep[2] = (lf4){(float)K, (float)nF, (float)__popc(smask), 0.f};
-      LDS(L_KL + 3) = 0.f;
-    }
-    auto post = [&](int k, const Cand& c, int depth, int body, float share) {
-      lf4* ip = reinterpret_cast<lf4*>(ldsw + PK_ITEM + (k * EPW + el) * PK_ITEM_ST);
-      ip[0] = (lf4){c.phi, c.x, c.y, c.z};
-      ip[1] = (lf4){c.un, c.nx, c.ny, c.nz};
-      ip[2] = (lf4){(float)depth, (float)leg, (float)body, share};
-    };
-    if (slot[0] >= 0) post(slot[0], item[0], 2, 4 + 4 * leg, 1.f);
-    if (slot[1] >= 0) post(slot[1], item[1], 2, 3 + 4 * leg, share_k);
-    if (slot[2] >= 0) post(slot[2], item[2], 2, 3 + 4 * leg, share_k);
-    if (slot[3] >= 0) post(slot[3], item[3], 1, 2 + 4 * leg, share_t);
-    if (slot[4] >= 0) post(slot[4], item[4], 1, 2 + 4 * leg, share_t);
-    if (slot[5] >= 0) post(slot[5], item[5], 0, 1 + 4 * leg, share_h);
-    if (slot[6] >= 0) post(slot[6], item[6], 0, 1 + 4 * leg, share_h);
-    if (leg == 0) {
-      if (slot_b0 >= 0) post(slot_b0, tb0, -1, 0, share_b);
-      if (slot_b1 >= 0) post(slot_b1, tb1, -1, 0, share_b);
-    }
-    BLOCK_SYNC(nw);                      // the helpers emit while this wavefront goes on with the self-contacts and limit rows
-  } else {
-    auto emit = [&](int k, const Cand& c, int depth, int body, float share) {      // depth < 0: trunk
-      emit_contact(cfg, lds, rfl, el, k, c, depth, leg, body, share, S, U, Dinv, qd_free, w_free, v_free, e_c, use_warm, h, fault);
-    };
-    // (the trunk's impulse is read by lane 0 only; own bodies by the own lane: no cross-lane hazard on L_LAM here)
-    if (slot[0] >= 0) emit(slot[0], item[0], 2, 4 + 4 * leg, 1.f);
-    if (slot[1] >= 0) emit(slot[1], item[1], 2, 3 + 4 * leg, share_k);
-    if (slot[2] >= 0) emit(slot[2], item[2], 2, 3 + 4 * leg, share_k);
-    if (slot[3] >= 0) emit(slot[3], item[3], 1, 2 + 4 * leg, share_t);
-    if (slot[4] >= 0) emit(slot[4], item[4], 1, 2 + 4 * leg, share_t);
-    if (slot[5] >= 0) emit(slot[5], item[5], 0, 1 + 4 * leg, share_h);
-    if (slot[6] >= 0) emit(slot[6], item[6], 0, 1 + 4 * leg, share_h);
-    if (leg == 0) {
-      if (slot_b0 >= 0) emit(slot_b0, tb0, -1, 0, share_b);
-      if (slot_b1 >= 0) emit(slot_b1, tb1, -1, 0, share_b);
-    }
+    for (int j = 0; j < 3; j++) { fl = fl + F.qdf[j] * F.S[j]; if (j == 1) ft_ = fl; }
+    lf4* tw = Z.tw();
+    tw[0 * WAVE + lane] = (lf4){fl.a.x, fl.a.y, fl.a.z, fl.l.x};
+    tw[1 * WAVE + lane] = (lf4){fl.l.y, fl.l.z, ft_.a.x, ft_.a.y};
+    tw[2 * WAVE + lane] = (lf4){ft_.a.z, ft_.l.x, ft_.l.y, ft_.l.z};
   }
-  // self-contacts.  Body A (the lower leg of the lower-numbered leg, or the leg of a trunk pair) publishes the contact and
-  // its side of the row functionals; for a leg-leg pair body B's lane adds its side (record SB); the trunk as body B has
-  // no joints: its side is the unit wrench itself.
-  int sslot[4] = {-1, -1, -1, -1};     // solver slot of the pair with partner i / the trunk
-  int ssb[3] = {-1, -1, -1};           // index of the leg-leg pair among the listed leg-leg pairs (its SB record)
-  if (smask != 0u) {
+  BLOCK_SYNC(nw);
+  PROF(4);
+  if (nw == 1) emit_terrain_contacts(cfg, Z, el, leg, 4, h);
+  // self-contacts (rare: skipped unless some environment of the wavefront lists one).  Pair pid at slot nF + rank(pid).  The
+  // lane of body A (the lower-numbered leg; the leg of a trunk pair) owns the record; for a leg-leg pair the lane of body B
+  // hands its side over through the pair's SB slots.
+  int sslot[MAXSB + 1];            // slots of the (at most MAXSB + 1) listed pairs this lane is body A or B of ...
+  int sdepth[MAXSB + 1];           // ... own body's depth (1 thigh, 2 lower leg) ...
+  float ssign[MAXSB + 1];          // ... and the sign of the impulse it receives (+1 body A, -1 body B)
+  int nown = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int j = (leg + 1 + i) & 3;
-      const bool lower = i == 3 || leg < j;
-      const int lo_ = lower ? leg : j, hi_ = lower ? j : leg;
-      const int pid = i == 3 ? 6 + leg : (lo_ == 0 ? hi_ - 1 : lo_ == 1 ? hi_ + 1 : 5);
-      if (!(smask & (1u << pid))) continue;
-      const int k = nF + __popc(smask & ((1u << pid) - 1u));
-      if (k >= MAXC) continue;
-      sslot[i] = k;
-      if (i < 3) ssb[i] = __popc(smask & 0x3Fu & ((1u << pid) - 1u));
-    }
-  }
-  if (smask != 0u) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if (sslot[i] < 0) continue;
-      const int j = (leg + 1 + i) & 3, k = sslot[i];
-      const bool lower = i == 3 || leg < j;
-      const Cand& c = sc[i];
-      const V3 n = v3(c.nx, c.ny, c.nz), x = v3(c.x, c.y, c.z);
-      V3 t1, t2;
-      contact_frame(n, t1, t2, fault);
-      if (lower) {                           // body A publishes the contact
-        LDS(L_CX + 3 * k) = c.x; LDS(L_CX + 3 * k + 1) = c.y; LDS(L_CX + 3 * k + 2) = c.z;
-        LDS(L_CN + 3 * k) = c.nx; LDS(L_CN + 3 * k + 1) = c.ny; LDS(L_CN + 3 * k + 2) = c.nz;
-        float vs = fminf(-c.phi / h, cfg.max_depenetration_velocity);
-        if (c.un < -cfg.bounce_threshold_velocity && -s.rest * c.un > vs) vs = -s.rest * c.un;      // robot-robot: the robot's own material
-        LDS(L_RP + 3 * k) = vs;
-        LDS(L_RB + 3 * k) = dot(n, sfree[i]); LDS(L_RB + 3 * k + 1) = dot(t1, sfree[i]); LDS(L_RB + 3 * k + 2) = dot(t2, sfree[i]);
-        LDS(L_LS + 3 * k) = 0.f; LDS(L_LS + 3 * k + 1) = 0.f; LDS(L_LS + 3 * k + 2) = 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const V3 d = r == 0 ? n : r == 1 ? t1 : t2;
-        const SV unit = sv(cross(x, d), d);
-        SV pA = lower ? -unit : unit;        // +d on body A, -d on body B
-        float uj[3];
-#pragma unroll
-        for (int jq = 2; jq >= 0; jq--) {
-          const float u = -dot(S[jq], pA);
-          uj[jq] = u;
-          pA = pA + (u * Dinv[jq]) * U[jq];
+  for (int i = 0; i <= MAXSB; i++) { sslot[i] = -1; sdepth[i] = 2; ssign[i] = 0.f; }
+  if (cfg.self_collision && __ballot(smask != 0u) != 0ull) {
+    const lf4* seg = Z.seg();
+    const lf4* tw = Z.tw();
+    int rank = 0, sbi = 0;         // rank among the listed pairs / among the listed leg-leg pairs (wave-uniform loop, per-lane counters)
+#pragma unroll 1
+    for (int pid = 0; pid < 28; pid++) {
+      const bool on = (smask & (1u << pid)) != 0u;
+      if (__ballot(on) == 0ull) continue;
+      const int type = pid < 24 ? pid / 6 : 0, pr = pid % 6;
+      const int lo_ = pid < 24 ? (pr < 3 ? 0 : pr < 5 ? 1 : 2) : pid - 24, hi_ = pid < 24 ? (pr < 3 ? pr + 1 : pr < 5 ? pr - 1 : 3) : -1;
+      const int sa = (type >> 1) & 1, sbq = type & 1;
+      const int k = nF + rank;
+      const bool isA = on && leg == lo_ && k < MAXC, isB = on && leg == hi_ && k < MAXC;
+      Cand c;
+      cand_init(c);
+      V3 n = v3(0.f, 0.f, 1.f), x = v3(0.f, 0.f, 0.f), t1 = v3(1.f, 0.f, 0.f), t2 = v3(0.f, 1.f, 0.f);
+      SV g[3];
+      float uj[3][3];
+      int depth = 2;
+      const int lj = (lane & ~3) | (isA ? (hi_ < 0 ? leg : hi_) : (lo_ & 3));       // partner lane (trunk pair: unused)
+      if (isA || isB) {
+        const lf4 a0 = seg[0 * WAVE + lj], a1 = seg[1 * WAVE + lj], a2 = seg[2 * WAVE + lj];
+        const V3 par_p[2] = {v3(a0[0], a0[1], a0[2]), v3(a1[2], a1[3], a2[0])}, par_q[2] = {v3(a0[3], a1[0], a1[1]), v3(a0[0], a0[1], a0[2])};
+        const V3 own_p[2] = {pknee, pthigh}, own_q[2] = {pfoot, pknee};
+        const int so = isA ? sa : sbq, sp = isA ? sbq : sa;
+        const float ra = sa ? GO1_SELF_THIGH_RADIUS : GO1_SELF_LEG_RADIUS;
+        if (hi_ < 0) {
+          const float ta = (float)(GO1_TRUNK_BOX_HALF[0] - GO1_TRUNK_BOX_HALF[1]);
+          capsule_contact(pknee, pfoot, ra, mul(R0, v3(-ta, 0.f, 0.f)), mul(R0, v3(ta, 0.f, 0.f)), (float)GO1_TRUNK_BOX_HALF[1], cd, c);
+        } else {
+          const float rb = sbq ? GO1_SELF_THIGH_RADIUS : GO1_SELF_LEG_RADIUS;
+          if (isA) capsule_contact(own_p[so], own_q[so], ra, par_p[sp], par_q[sp], rb, cd, c);
+          else capsule_contact(par_p[sp], par_q[sp], ra, own_p[so], own_q[so], rb, cd, c);
         }
-        if (i == 3) pA = pA + unit;          // the trunk's side
-        lf4* rf = reinterpret_cast<lf4*>(lower ? RF(3 * k + r) : SB(3 * ssb[i] + r));
-        rf[0] = (lf4){pA.a.x, pA.a.y, pA.a.z, pA.l.x};
-        rf[1] = (lf4){pA.l.y, pA.l.z, uj[0], uj[1]};
-        rf[2] = (lf4){uj[2], uj[0] * Dinv[0], uj[1] * Dinv[1], uj[2] * Dinv[2]};
-        rf[3] = (lf4){(float)leg, (lower && i < 3) ? (float)ssb[i] : -1.f, 0.f, 0.f};       // [1]: index of the row's SB record, -1: none
+        n = v3(c.nx, c.ny, c.nz); x = v3(c.x, c.y, c.z);
+        contact_frame(n, t1, t2, fault);
+        depth = so ? 1 : 2;
+        if (nown <= MAXSB) {
+#pragma unroll
+          for (int i = 0; i <= MAXSB; i++) if (i == nown) { sslot[i] = k; sdepth[i] = depth; ssign[i] = isA ? 1.f : -1.f; }
+        }
+        nown++;
+        // own side of the three rows: +d on body A, -d on body B
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          const V3 d = r == 0 ? n : r == 1 ? t1 : t2;
+          const SV unit = sv(cross(x, d), d);
+          row_propagate(F, depth, isA ? -unit : unit, g[r], uj[r]);
+          if (hi_ < 0) g[r] = g[r] + unit;                               // the trunk's side: the opposite unit wrench on the base
+        }
+        if (isB) {                                                         // hand g_B and u_B over
+          SBQ(sbi, 0) = (lf4){g[0].a.x, g[0].a.y, g[0].a.z, g[0].l.x};
+          SBQ(sbi, 1) = (lf4){g[0].l.y, g[0].l.z, g[1].a.x, g[1].a.y};
+          SBQ(sbi, 2) = (lf4){g[1].a.z, g[1].l.x, g[1].l.y, g[1].l.z};
+          SBQ(sbi, 3) = (lf4){g[2].a.x, g[2].a.y, g[2].a.z, g[2].l.x};
+          SBQ(sbi, 4) = (lf4){g[2].l.y, g[2].l.z, uj[0][0] * F.sD[0], uj[0][1] * F.sD[1]};
+          SBQ(sbi, 5) = (lf4){uj[0][2] * F.sD[2], uj[1][0] * F.sD[0], uj[1][1] * F.sD[1], uj[1][2] * F.sD[2]};
+          SBQ(sbi, 6) = (lf4){uj[2][0] * F.sD[0], uj[2][1] * F.sD[1], uj[2][2] * F.sD[2], (float)leg};
+        }
       }
+      LDS_PHASE();                 // (wave-uniform point: the loop and its skips depend on ballots only)
+      if (isA) {
+        // relative velocities (A - B) at the contact point: before the step (restitution) and free
+        const lf4 s2 = seg[2 * WAVE + lj], s3 = seg[3 * WAVE + lj], s4 = seg[4 * WAVE + lj], s5 = seg[5 * WAVE + lj];
+        const lf4 f0 = tw[0 * WAVE + lj], f1 = tw[1 * WAVE + lj], f2 = tw[2 * WAVE + lj];
+        SV preB, freeB;
+        if (hi_ < 0) { preB = v0; freeB = sv(w_free, v_free); }
+        else if (sbq) { preB = sv(v3(s3[3], s4[0], s4[1]), v3(s4[2], s4[3], s5[0])); freeB = sv(v3(f1[2], f1[3], f2[0]), v3(f2[1], f2[2], f2[3])); }
+        else { preB = sv(v3(s2[1], s2[2], s2[3]), v3(s3[0], s3[1], s3[2])); freeB = sv(v3(f0[0], f0[1], f0[2]), v3(f0[3], f1[0], f1[1])); }
+        const SV preA = sa ? vthigh : vlow;
+        SV freeA = sv(w_free, v_free);
+#pragma unroll
+        for (int j = 0; j < 3; j++) if (j <= depth) freeA = freeA + F.qdf[j] * F.S[j];
+        const float un_pre = dot(n, (preA.l + cross(preA.a, x)) - (preB.l + cross(preB.a, x)));
+        const V3 vrel = (freeA.l + cross(freeA.a, x)) - (freeB.l + cross(freeB.a, x));
+        float vs = fminf(-c.phi / h, cfg.max_depenetration_velocity);
+        if (un_pre < -cfg.bounce_threshold_velocity && -s.rest * un_pre > vs) vs = -s.rest * un_pre;      // robot-robot: the robot's own material
+        Row a[3], ab[3];
+        float wB[5] = {0.f, 0.f, 0.f, 0.f, 0.f};          // u_B . u_B terms: nn, t1t1, t2t2, t1n, t2n
+        if (hi_ >= 0) {
+          const lf4 b0 = SBQ(sbi, 0), b1 = SBQ(sbi, 1), b2 = SBQ(sbi, 2), b3 = SBQ(sbi, 3), b4 = SBQ(sbi, 4), b5 = SBQ(sbi, 5), b6 = SBQ(sbi, 6);
+          g[0] = g[0] + sv(v3(b0[0], b0[1], b0[2]), v3(b0[3], b1[0], b1[1]));
+          g[1] = g[1] + sv(v3(b1[2], b1[3], b2[0]), v3(b2[1], b2[2], b2[3]));
+          g[2] = g[2] + sv(v3(b3[0], b3[1], b3[2]), v3(b3[3], b4[0], b4[1]));
+          ab[0].u[0] = b4[2]; ab[0].u[1] = b4[3]; ab[0].u[2] = b5[0];
+          ab[1].u[0] = b5[1]; ab[1].u[1] = b5[2]; ab[1].u[2] = b5[3];
+          ab[2].u[0] = b6[0]; ab[2].u[1] = b6[1]; ab[2].u[2] = b6[2];
+          auto d3 = [](const Row& p, const Row& q) { return fmaf(p.u[0], q.u[0], fmaf(p.u[1], q.u[1], p.u[2] * q.u[2])); };
+          wB[0] = d3(ab[0], ab[0]); wB[1] = d3(ab[1], ab[1]); wB[2] = d3(ab[2], ab[2]); wB[3] = d3(ab[1], ab[0]); wB[4] = d3(ab[2], ab[0]);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++) row_finish(E.Li, g[r], uj[r], F.sD, a[r]);
+        contact_record_store(crl, el, k, a[0], a[1], a[2], cr_flags(leg, true, hi_ >= 0 ? sbi + 1 : 0), dot(n, vrel) - vs, dot(t1, vrel), dot(t2, vrel),
+                             row_dot(a[0], a[0]) + wB[0], row_dot(a[1], a[1]) + wB[1], row_dot(a[2], a[2]) + wB[2],
+                             row_dot(a[1], a[0]) + wB[3], row_dot(a[2], a[0]) + wB[4], v3(0.f, 0.f, 0.f), x, n, fault);
+      }
+      if (on) { rank++; if (pid < 24) sbi++; }
     }
   }
   if (legact) {
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) {
-      float* jr = JR(3 * leg + jj);
-      jr[0] = qd_free[jj]; jr[1] = jlo[jj]; jr[2] = jhi[jj];
       float uj[3] = {0.f, 0.f, 0.f};
       uj[jj] = 1.f;
-      SV pA = Dinv[jj] * U[jj];
+      SV pAj = F.Dinv[jj] * F.U[jj];
 #pragma unroll
       for (int j = 1; j >= 0; j--) {
         if (j < jj) {
-          const float u = -dot(S[j], pA);
+          const float u = -dot(F.S[j], pAj);
           uj[j] = u;
-          pA = pA + (u * Dinv[j]) * U[j];
+          pAj = pAj + (u * F.Dinv[j]) * F.U[j];
         }
       }
-      lf4* rf = reinterpret_cast<lf4*>(RF(NRC + 3 * leg + jj));
-      rf[0] = (lf4){pA.a.x, pA.a.y, pA.a.z, pA.l.x};
-      rf[1] = (lf4){pA.l.y, pA.l.z, uj[0], uj[1]};
-      rf[2] = (lf4){uj[2], uj[0] * Dinv[0], uj[1] * Dinv[1], uj[2] * Dinv[2]};
-      rf[3] = (lf4){(float)leg, -1.f, 0.f, 0.f};
+      Row a;
+      row_finish(E.Li, pAj, uj, F.sD, a);
+      const float w = row_dot(a, a);
+      if (!(w > 1e-9f)) fault |= 1u << GO1_FAULT_W_DIAG;
+      const int j = 3 * leg + jj;
+      JRQ(j, 0) = (lf4){a.g[0], a.g[1], a.g[2], a.g[3]};
+      JRQ(j, 1) = (lf4){a.g[4], a.g[5], a.u[0], a.u[1]};
+      JRQ(j, 2) = (lf4){a.u[2], F.qdf[jj], jlo[jj], jhi[jj]};
+      JRQ(j, 3) = (lf4){w, 1.f / w, 0.f, 0.f};
     }
   }
-  LDS_PHASE();
-  // leg-leg self-contacts: body A's lane folds body B's wrench into the row functional (g = g_A + g_B)
-  const bool selfw = __ballot((smask & 0x3Fu) != 0u) != 0ull;      // wave-uniform
-  if (selfw) {
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      if (sslot[i] >= 0 && leg < ((leg + 1 + i) & 3)) {
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-          lf4* rf = reinterpret_cast<lf4*>(RF(3 * sslot[i] + r));
-          const lf4* sb = reinterpret_cast<const lf4*>(SB(3 * ssb[i] + r));
-          lf4 a0 = rf[0], a1 = rf[1];
-          const lf4 b0 = sb[0], b1 = sb[1];
-          a0 = a0 + b0; a1[0] += b1[0]; a1[1] += b1[1];
-          rf[0] = a0; rf[1] = a1;
-        }
-      }
-    }
-    LDS_PHASE();
-  }
-  PROF(4);
-  // ---- Delassus matrix into LDS: every wavefront of the workgroup builds its share of the rows (delassus_rows) -----------
-  if (leg == 0) {
-#pragma unroll
-    for (int i = 0; i < 21; i++) LDS(L_I0 + i) = I0inv.m[i];
-    LDS(L_KL) = (float)K; LDS(L_KL + 1) = (float)lact; LDS(L_KL + 2) = selfw ? 0.f : 1.f;
-  }
-  BLOCK_SYNC(nw);
-  PROF(19);            // (profile builds: the wait at the first barrier is booked on phase 19)
-#ifdef GO1_ROWS_HELPERS_ONLY
-  if (nw == 1) delassus_rows(lds, ldsw, rfl, lane, 0, 1 PROF_PASS);
-#else
-  delassus_rows(lds, ldsw, rfl, lane, 0, nw PROF_PASS);
-#endif
   BLOCK_SYNC(nw);
   PROF(21);
-  if (offload && LDS(L_KL + 3) != 0.f) fault |= 1u << GO1_FAULT_CONTACT_FRAME;
-  SolveMasks sm;
-  solver_masks(K, lact, legact, leg, sm);
+  if (LDS(L_KL + 3) != 0.f) fault |= 1u << GO1_FAULT_CONTACT_FRAME;
+  if (LDS(L_KL + 6) != 0.f) fault |= 1u << GO1_FAULT_W_DIAG;
+  const SolveBounds sm = solve_bounds(K, legact);
   const int Kw = sm.Kw;
-  const unsigned LAw = sm.LAw, ccw = sm.ccw;
-  bool colact[NCC];
-#pragma unroll
-  for (int cc = 0; cc < NCC; cc++) colact[cc] = sm.colact[cc];
-  {
-    // Rows of leg-leg self-contacts carry TWO leg parts (A: in the row record, B: in its SB record).  The loop above used
-    // the total wrench g but only the A parts in the same-leg term; such rows (at most 3 MAXSB per environment) are redone
-    // here with all parts, row and mirrored column.  Rare: skipped unless some environment of the wave has such a contact.
-    if (selfw) {
-      SV Y[NCC];
-      float ud[NCC][3], lg[NCC];
-      lane_columns(rfl, I0inv, leg, el, ccw, Y, ud, lg);
-      int colsb[NCC];
-#pragma unroll
-      for (int cc = 0; cc < NCC; cc++) {
-        int c = leg + 4 * cc;
-        c = c < NRC + NRJ ? c : NRC + NRJ - 1;
-        colsb[cc] = (ccw & (1u << cc)) ? (int)RF(c)[13] : -1;
-      }
-      const int nS = __popc(smask);
-#pragma unroll 1
-      for (int q = 0; q < 3 * MAXC; q++) {                      // candidate rows: the self slots' rows
-        const int x = 3 * nF + q;
-        const bool inr = q < 3 * nS && x < NRC;
-        const int sbx = inr ? (int)RF(x < NRC ? x : 0)[13] : -1;
-        if (__ballot(sbx >= 0) == 0ull) { if (__ballot(inr) == 0ull) break; continue; }
-        if (sbx >= 0) {
-          const lf4* rf = reinterpret_cast<const lf4*>(RF(x));
-          const lf4 r0 = rf[0], r1 = rf[1], r2 = rf[2];
-          const lf4* sb = reinterpret_cast<const lf4*>(SB(3 * sbx + (x % 3)));
-          const lf4 s1 = sb[1], s2 = sb[2];
-          const SV g = sv(v3(r0[0], r0[1], r0[2]), v3(r0[3], r1[0], r1[1]));
-          const float uA0 = r1[2], uA1 = r1[3], uA2 = r2[0], lA = rf[3][0];
-          const float uB0 = s1[2], uB1 = s1[3], uB2 = s2[0], lB = sb[3][0];
-#pragma unroll
-          for (int cc = 0; cc < NCC; cc++) {
-            const int c = leg + 4 * cc;
-            if ((ccw & (1u << cc)) && c < NRC + NRJ) {
-              float w = dot(g, Y[cc]);
-              if (lA == lg[cc]) w += fmaf(uA0, ud[cc][0], fmaf(uA1, ud[cc][1], uA2 * ud[cc][2]));
-              if (lB == lg[cc]) w += fmaf(uB0, ud[cc][0], fmaf(uB1, ud[cc][1], uB2 * ud[cc][2]));
-              if (colsb[cc] >= 0) {
-                const lf4* sc_ = reinterpret_cast<const lf4*>(SB(3 * colsb[cc] + (c % 3)));
-                const lf4 c2 = sc_[2];
-                const float lgB = sc_[3][0];
-                if (lA == lgB) w += fmaf(uA0, c2[1], fmaf(uA1, c2[2], uA2 * c2[3]));
-                if (lB == lgB) w += fmaf(uB0, c2[1], fmaf(uB1, c2[2], uB2 * c2[3]));
-              }
-              if (cc < 8) WROW(x)[8 * leg + cc] = w; else WSH8(x) = w;
-              if ((x >> 2) < 8) WROW(c)[8 * (x & 3) + (x >> 2)] = w; else WROW(c)[32 + (x & 3)] = w;      // mirrored entry
-            }
-          }
-        }
-      }
-    }
-  }
-  LDS_PHASE();
-  PROF(22);
-  // row records from the finished matrix: every lane reads back the diagonal entries of its own columns, and the owner
-  // of a contact's normal column the two entries that couple the tangent rows to it
-#pragma unroll
-  for (int cc = 0; cc < NCC; cc++) {
-    const int c = leg + 4 * cc;
-    if ((ccw & (1u << cc)) && c < NRC + NRJ) {
-      const float w = cc < 8 ? WROW(c)[8 * leg + cc] : WSH8(c);
-      if (colact[cc] && !(w > 1e-9f)) fault |= 1u << GO1_FAULT_W_DIAG;
-      const float iw = colact[cc] ? 1.f / w : 0.f;
-      if (c < NRC) LDS(L_RI + c) = iw;
-      else { float* jr = JR(c - NRC); jr[3] = w; jr[4] = iw; }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < MAXC; k++) {
-    if (k < Kw && ((3 * k) & 3) == leg) {
-      LDS(L_RP + 3 * k + 1) = WROW(3 * k + 1)[8 * leg + ((3 * k) >> 2)];       // (3 k < 24: slots 0..5)
-      LDS(L_RP + 3 * k + 2) = WROW(3 * k + 2)[8 * leg + ((3 * k) >> 2)];
-    }
-  }
-  LDS_PHASE();
+  const unsigned LAw = sm.LAw;
   PROF(18);
-  // ---- projected Gauss-Seidel on the impulses -------------------------------------------------------------
-  // The sweep keeps the ROW VELOCITIES u = b + W lambda up to date instead of re-evaluating a row's dot product when its
-  // turn comes: lane `leg` holds u for its rows r = leg + 4 cc; a row's turn is then one quad broadcast of its u, the
-  // projection, and — off the critical path — 8 independent FMAs per lane that add the impulse change times the lane's
-  // share of that row of W (W is symmetric: the share of row c IS the lane's part of column c) to the velocities.
-  const float mu = 0.5f * (s.mu + cfg.terrain_friction);       // PhysX default combine mode: average
+  // ---- projected Gauss-Seidel on the impulses, matrix-free ---------------------------------------------------------------
+  // State s = sum_r lambda_r a_r: z (6, replicated in the quad) and y (3, the own leg's).  A row's velocity is b_r + a_r . s;
+  // the leg part of a contact's three rows is evaluated by every lane on its own y, masked by "the contact is on my leg"
+  // and summed over the quad.  Contacts in list order (normal, then the two tangents against the updated normal impulse,
+  // Coulomb cone: static inside, dynamic when sliding), then the limit rows in joint order.
+  const float mu_s = 0.5f * (s.mu + cfg.terrain_friction);       // PhysX default combine mode: average
+  const float mu_d = fminf(0.5f * (s.mu + cfg.terrain_dynamic_friction), mu_s);
+  float lamj[3] = {0.f, 0.f, 0.f};                                 // limit impulses of the own joints
 #ifndef GO1_ABLATE_PGS
   {
-    float lam[NRC], lamj[NRJ], uloc[NCC];
-    float vst[MAXC], idn[MAXC], id1[MAXC], id2[MAXC], w10[MAXC], w20[MAXC];
+    float z[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, y[3] = {0.f, 0.f, 0.f};
+    auto add_rows = [&](const Row3& R, float m, float d0, float d1, float d2) {
 #pragma unroll
-    for (int k = 0; k < MAXC; k++) {
-      const int r0 = 3 * k;
-      const bool on = k < K;
-      lam[r0] = on ? LDS(L_LS + r0) : 0.f; lam[r0 + 1] = on ? LDS(L_LS + r0 + 1) : 0.f; lam[r0 + 2] = on ? LDS(L_LS + r0 + 2) : 0.f;
-      vst[k] = on ? LDS(L_RP + r0) : 0.f;
-      idn[k] = on ? LDS(L_RI + r0) : 0.f; id1[k] = on ? LDS(L_RI + r0 + 1) : 0.f; id2[k] = on ? LDS(L_RI + r0 + 2) : 0.f;
-      w10[k] = on ? LDS(L_RP + r0 + 1) : 0.f; w20[k] = on ? LDS(L_RP + r0 + 2) : 0.f;
-    }
+      for (int i = 0; i < 6; i++) z[i] = fmaf(R.n.g[i], d0, fmaf(R.t1.g[i], d1, fmaf(R.t2.g[i], d2, z[i])));
+      const float m0 = m * d0, m1 = m * d1, m2 = m * d2;
 #pragma unroll
-    for (int j = 0; j < NRJ; j++) lamj[j] = 0.f;
-#pragma unroll
-    for (int cc = 0; cc < NCC; cc++) {                         // u = b for the lane's rows (rows outside this env's solve: 0)
-      const int c = leg + 4 * cc;
-      float bb = 0.f;
-      if (colact[cc]) bb = c < NRC ? LDS(L_RB + (c < NRC ? c : 0)) : JR(c < NRC + NRJ ? c - NRC : 0)[0];
-      uloc[cc] = bb;
-    }
-    // u += (share of row c) * dl for the lane's rows.  Rows that are not in this environment's solve have impulse 0 and
-    // what the build wrote for them is finite (the matrix is zero-filled at kernel start), so their products vanish.
-    auto apply_col = [&](int c, float dl) {
-#pragma unroll
-      for (int hf = 0; hf < 2; hf++) {
-        if (ccw & (0xFu << (4 * hf))) {
-          const lf4 w = WSH4(c, hf);
-#pragma unroll
-          for (int i = 0; i < 4; i++) uloc[4 * hf + i] = fmaf(w[i], dl, uloc[4 * hf + i]);
-        }
-      }
-      if (ccw & 0x100u) uloc[8] = fmaf(WSH8(c), dl, uloc[8]);
+      for (int i = 0; i < 3; i++) y[i] = fmaf(R.n.u[i], m0, fmaf(R.t1.u[i], m1, fmaf(R.t2.u[i], m2, y[i])));
     };
-    if (selfw)                                                 // (otherwise the build has already added W lambda_start to b)
-#pragma unroll
-    for (int k = 0; k < MAXC; k++) {                           // warm start: the starting impulses' velocities
-      if (k < Kw) {
-#pragma unroll
-        for (int i = 0; i < 3; i++) apply_col(3 * k + i, lam[3 * k + i]);
-      }
+    // B side of a leg-leg self-contact: u_B of the three rows and its leg
+    struct RowB { float u[3][3]; int legB; };
+    auto load_b = [&](int sb1, RowB& Bq) {
+      const int i = sb1 > 0 ? sb1 - 1 : 0;
+      const lf4 b4 = SBQ(i, 4), b5 = SBQ(i, 5), b6 = SBQ(i, 6);
+      Bq.u[0][0] = b4[2]; Bq.u[0][1] = b4[3]; Bq.u[0][2] = b5[0];
+      Bq.u[1][0] = b5[1]; Bq.u[1][1] = b5[2]; Bq.u[1][2] = b5[3];
+      Bq.u[2][0] = b6[0]; Bq.u[2][1] = b6[1]; Bq.u[2][2] = b6[2];
+      Bq.legB = (int)b6[3];
+    };
+    // warm start: the state of the starting impulses (self-contacts and limit rows start from zero)
+#pragma unroll 1
+    for (int k = 0; k < Kw; k++) {
+      Row3 R;
+      contact_rows_load(crl, el, k, R);
+      const lf4 q9 = CRQ(k, 9);
+      add_rows(R, R.legA == leg ? 1.f : 0.f, q9[1], q9[2], q9[3]);
     }
     PROF(23);
-    // The lane's shares of a row of W do not depend on the iterate: a contact's nine loads (three rows x [4 + 4 + 1]) are
-    // issued together, UNCONDITIONALLY, before its projection — one LDS latency per contact, running under the projection
-    // arithmetic, instead of nine exposed ones (a load behind a wave-uniform `if (ccw & ..)` sits in its own basic block
-    // with its own wait).  Slots of columns that exist nowhere in the wavefront hold finite leftovers (zero fill, earlier
-    // substeps) and only ever update row velocities nobody reads.
-    struct Share { lf4 a, b; float c; };
-    auto fetch = [&](int c) { Share sh; sh.a = WSH4(c, 0); sh.b = WSH4(c, 1); sh.c = WSH8(c); return sh; };
-    auto apply_share = [&](const Share& sh, float dl) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) { uloc[i] = fmaf(sh.a[i], dl, uloc[i]); uloc[4 + i] = fmaf(sh.b[i], dl, uloc[4 + i]); }
-      uloc[8] = fmaf(sh.c, dl, uloc[8]);
-    };
 #pragma unroll 1
     for (int it = 0; it < cfg.solver_iterations; it++) {
+#pragma unroll 1
+      for (int k = 0; k < Kw; k++) {
+        Row3 R;
+        contact_rows_load(crl, el, k, R);
+        const lf4 q7 = CRQ(k, 7), q8 = CRQ(k, 8), q9 = CRQ(k, 9);
+        const float m = R.legA == leg ? 1.f : 0.f;
+        float dn = q7[0], d1 = q7[1], d2 = q7[2];
 #pragma unroll
-      for (int k = 0; k < MAXC; k++) {
-        if (k < Kw) {
-          const int r0 = 3 * k;
-          const Share s0 = fetch(r0), s1 = fetch(r0 + 1), s2 = fetch(r0 + 2);
-          const float un = quad_bcast(uloc[r0 >> 2], r0);      // row r sits in lane r & 3 at slot r >> 2
-          float u1 = quad_bcast(uloc[(r0 + 1) >> 2], r0 + 1);
-          float u2 = quad_bcast(uloc[(r0 + 2) >> 2], r0 + 2);
-          const float ln_old = lam[r0];
-          const float ln = fmaxf(0.f, ln_old - (un - vst[k]) * idn[k]);
-          const float dln = ln - ln_old;
-          u1 = fmaf(w10[k], dln, u1);                          // the tangential rows see the updated normal impulse
-          u2 = fmaf(w20[k], dln, u2);
-          float l1 = lam[r0 + 1] - u1 * id1[k];
-          float l2 = lam[r0 + 2] - u2 * id2[k];
-          const float muk = (k >= nF && k < nF + __popc(smask)) ? s.mu : mu;      // robot-robot: the robot's own material
-          const float lim = muk * ln, nn = l1 * l1 + l2 * l2;  // friction cone: |l_t| <= mu l_n
-          if (nn > lim * lim) { const float sc = lim * __builtin_amdgcn_rsqf(nn); l1 *= sc; l2 *= sc; }
-          const bool on = k < K;                               // lanes of environments with fewer contacts idle here
-          const float nl0 = on ? ln : 0.f, nl1 = on ? l1 : 0.f, nl2 = on ? l2 : 0.f;
-          apply_share(s0, nl0 - lam[r0]); apply_share(s1, nl1 - lam[r0 + 1]); apply_share(s2, nl2 - lam[r0 + 2]);
-          lam[r0] = nl0; lam[r0 + 1] = nl1; lam[r0 + 2] = nl2;
+        for (int i = 0; i < 6; i++) { dn = fmaf(R.n.g[i], z[i], dn); d1 = fmaf(R.t1.g[i], z[i], d1); d2 = fmaf(R.t2.g[i], z[i], d2); }
+        float pn = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { pn = fmaf(R.n.u[i], y[i], pn); p1 = fmaf(R.t1.u[i], y[i], p1); p2 = fmaf(R.t2.u[i], y[i], p2); }
+        pn *= m; p1 *= m; p2 *= m;
+        RowB Bq;
+        float mB = 0.f;
+        const bool anyB = __ballot(R.sb1 > 0) != 0ull;                  // leg-leg self-contact somewhere in the wavefront at this slot
+        if (anyB) {
+          load_b(R.sb1, Bq);
+          mB = (R.sb1 > 0 && Bq.legB == leg) ? 1.f : 0.f;
+          float bn = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < 3; i++) { bn = fmaf(Bq.u[0][i], y[i], bn); b1 = fmaf(Bq.u[1][i], y[i], b1); b2 = fmaf(Bq.u[2][i], y[i], b2); }
+          pn = fmaf(mB, bn, pn); p1 = fmaf(mB, b1, p1); p2 = fmaf(mB, b2, p2);
         }
+        const float un = dn + quad_sum(pn);                              // = u_n - v*
+        float u1 = d1 + quad_sum(p1), u2 = d2 + quad_sum(p2);
+        const float ln_old = q9[1];
+        const float ln = fmaxf(0.f, ln_old - un * q8[0]);
+        const float dln = ln - ln_old;
+        u1 = fmaf(q8[3], dln, u1);                                       // the tangential rows see the updated normal impulse
+        u2 = fmaf(q9[0], dln, u2);
+        float l1 = q9[2] - u1 * q8[1];
+        float l2 = q9[3] - u2 * q8[2];
+        const float lim = (R.self ? s.mu : mu_s) * ln, nn = l1 * l1 + l2 * l2;      // robot-robot: the robot's own material
+        if (nn > lim * lim) { const float sc = (R.self ? s.mu : mu_d) * ln * __builtin_amdgcn_rsqf(nn); l1 *= sc; l2 *= sc; }
+        const float e1 = l1 - q9[2], e2 = l2 - q9[3];
+        add_rows(R, m, dln, e1, e2);
+        if (anyB) {
+          const float m0 = mB * dln, m1 = mB * e1, m2 = mB * e2;
+#pragma unroll
+          for (int i = 0; i < 3; i++) y[i] = fmaf(Bq.u[0][i], m0, fmaf(Bq.u[1][i], m1, fmaf(Bq.u[2][i], m2, y[i])));
+        }
+        if (leg == 0) CRQ(k, 9) = (lf4){q9[0], ln, l1, l2};
       }
       // limit rows in joint order: the rate without the row's own impulse is projected on [lower, upper]
 #pragma unroll
       for (int lgi = 0; lgi < 4; lgi++) {
         if (LAw & (1u << lgi)) {
-          Share sj[3];
-          lf4 rec[3];
-          float idg[3];
-#pragma unroll
-          for (int jj = 0; jj < 3; jj++) {                     // the leg's three rows: records and shares up front
-            const float* jr = JR(3 * lgi + jj);
-            rec[jj] = *reinterpret_cast<const lf4*>(jr);       // b, lower, upper, W[r][r]
-            idg[jj] = jr[4];                                   // 0: not a row of this environment
-            sj[jj] = fetch(NRC + 3 * lgi + jj);
-          }
 #pragma unroll
           for (int jj = 0; jj < 3; jj++) {
-            const int j = 3 * lgi + jj, r = NRC + j;
-            const float u = quad_bcast(uloc[r >> 2], r);
-            const float u0 = u - rec[jj][3] * lamj[j];
-            const float ut = fminf(fmaxf(u0, rec[jj][1]), rec[jj][2]);
-            const float ln = (ut - u0) * idg[jj];
-            apply_share(sj[jj], ln - lamj[j]);
-            lamj[j] = ln;
+            const int j = 3 * lgi + jj;
+            const lf4 r0 = JRQ(j, 0), r1 = JRQ(j, 1), r2 = JRQ(j, 2), r3 = JRQ(j, 3);
+            const bool rowon = (lact >> lgi) & 1u;
+            float u = r2[1];
+            u = fmaf(r0[0], z[0], u); u = fmaf(r0[1], z[1], u); u = fmaf(r0[2], z[2], u); u = fmaf(r0[3], z[3], u); u = fmaf(r1[0], z[4], u); u = fmaf(r1[1], z[5], u);
+            const float pj = fmaf(r1[2], y[0], fmaf(r1[3], y[1], r2[0] * y[2]));
+            u += quad_bcast(pj, lgi);
+            const float lold = quad_bcast(lamj[jj], lgi);
+            const float u0 = u - r3[0] * lold;
+            const float ut = fminf(fmaxf(u0, r2[2]), r2[3]);
+            const float ln = rowon ? (ut - u0) * r3[1] : 0.f;
+            const float dl = rowon ? ln - lold : 0.f;
+            z[0] = fmaf(r0[0], dl, z[0]); z[1] = fmaf(r0[1], dl, z[1]); z[2] = fmaf(r0[2], dl, z[2]);
+            z[3] = fmaf(r0[3], dl, z[3]); z[4] = fmaf(r1[0], dl, z[4]); z[5] = fmaf(r1[1], dl, z[5]);
+            if (leg == lgi) {
+              y[0] = fmaf(r1[2], dl, y[0]); y[1] = fmaf(r1[3], dl, y[1]); y[2] = fmaf(r2[0], dl, y[2]);
+              lamj[jj] = ln;
+            }
           }
         }
       }
+      LDS_PHASE();          // the next sweep re-reads the impulses the leg-0 lanes stored in this one
     }
     {
       float nf_acc = 0.f;
 #pragma unroll
-      for (int r = 0; r < NRC; r++) nf_acc = nonfinite_acc(nf_acc, lam[r]);
+      for (int i = 0; i < 6; i++) nf_acc = nonfinite_acc(nf_acc, z[i]);
 #pragma unroll
-      for (int j = 0; j < NRJ; j++) nf_acc = nonfinite_acc(nf_acc, lamj[j]);
+      for (int i = 0; i < 3; i++) { nf_acc = nonfinite_acc(nf_acc, y[i]); nf_acc = nonfinite_acc(nf_acc, lamj[i]); }
       if (nf_acc != nf_acc) fault |= 1u << GO1_FAULT_LAMBDA;
-    }
-    if (leg == 0) {
-#pragma unroll
-      for (int k = 0; k < MAXC; k++)
-        if (k < K) { LDS(L_LS + 3 * k) = lam[3 * k]; LDS(L_LS + 3 * k + 1) = lam[3 * k + 1]; LDS(L_LS + 3 * k + 2) = lam[3 * k + 2]; }
-      if (lact != 0u) {
-#pragma unroll
-        for (int j = 0; j < NRJ; j++) JR(j)[5] = lamj[j];
-      }
     }
   }
 #endif
@@ -1376,48 +1380,53 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
   LDS_PHASE();
   PROF(5);
   // ---- apply all impulses with one propagation ---------------------------------------------------------
-  SV pA[3];
+  SV pAq[3];
 #pragma unroll
-  for (int j = 0; j < 3; j++) pA[j] = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
+  for (int j = 0; j < 3; j++) pAq[j] = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
   V3 fbody[4];                                                 // world impulse per own body (hip, thigh, calf, foot)
 #pragma unroll
   for (int i = 0; i < 4; i++) fbody[i] = v3(0.f, 0.f, 0.f);
   auto take = [&](int k, V3& x) {                              // world impulse of solver contact k and its point
-    const V3 n = v3(LDS(L_CN + 3 * k), LDS(L_CN + 3 * k + 1), LDS(L_CN + 3 * k + 2));
+    const lf4 q9 = CRQ(k, 9), q10 = CRQ(k, 10), q11 = CRQ(k, 11);
+    const V3 n = v3(q11[0], q11[1], q11[2]);
     V3 t1, t2;
     contact_frame(n, t1, t2, fault);
-    x = v3(LDS(L_CX + 3 * k), LDS(L_CX + 3 * k + 1), LDS(L_CX + 3 * k + 2));
-    return LDS(L_LS + 3 * k) * n + LDS(L_LS + 3 * k + 1) * t1 + LDS(L_LS + 3 * k + 2) * t2;
+    x = v3(q10[0], q10[1], q10[2]);
+    return q9[1] * n + q9[2] * t1 + q9[3] * t2;
   };
+  SV contrib = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));       // wrench of the impulses acting directly on the base
+  V3 ftrunk = v3(0.f, 0.f, 0.f);                                //   and the impulse booked on the trunk
 #pragma unroll
-  for (int i = 0; i < 7; i++) {
+  for (int i = 0; i < IT_N; i++) {
+    if (!WALLS && (i == IT_FOOTW || i == IT_CALFW || i == IT_THIGHW || i == IT_TRW)) continue;
     if (slot[i] >= 0) {
-      const int depth = i == 0 ? 2 : i <= 2 ? 2 : i <= 4 ? 1 : 0;       // foot, calf: joint 2; thigh: 1; hip: 0
-      const int bi = i == 0 ? 3 : i <= 2 ? 2 : i <= 4 ? 1 : 0;          // own body index: hip 0, thigh 1, calf 2, foot 3
       V3 x;
       const V3 f = take(slot[i], x);
       const SV ff = sv(cross(x, f), f);
+      if (i >= IT_TR0) { contrib = contrib - ff; ftrunk = ftrunk + f; }
+      else {
+        const int depth = i <= IT_CALF2 ? 2 : i <= IT_THIGH2 ? 1 : 0;     // foot, calf: joint 2; thigh: 1; hip: 0
+        const int bi = i <= IT_FOOTW ? 3 : i <= IT_CALF2 ? 2 : i <= IT_THIGH2 ? 1 : 0;      // own body index: hip 0, thigh 1, calf 2, foot 3
 #pragma unroll
-      for (int j = 0; j < 3; j++)
-        if (j == depth) pA[j] = pA[j] - ff;
+        for (int j = 0; j < 3; j++)
+          if (j == depth) pAq[j] = pAq[j] - ff;
 #pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (q == bi) fbody[q] = fbody[q] + f;
+        for (int q = 0; q < 4; q++)
+          if (q == bi) fbody[q] = fbody[q] + f;
+      }
     }
   }
-  SV self_base = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));     // trunk-leg self-contacts: wrench on the base
-  V3 self_trunk = v3(0.f, 0.f, 0.f);                            //   and the impulse booked on the trunk
-  if (smask != 0u) {
+  if (nown > 0) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i <= MAXSB; i++) {
       if (sslot[i] >= 0) {
         V3 x;
-        V3 f = take(sslot[i], x);
-        const bool lower = i == 3 || leg < ((leg + 1 + i) & 3);
-        if (!lower) f = -f;                                     // body B receives the opposite impulse
-        pA[2] = pA[2] - sv(cross(x, f), f);
-        fbody[2] = fbody[2] + f;                                // booked on the calf (a penalised body: corl_rewards.py:49-52)
-        if (i == 3) { self_base = self_base + sv(cross(x, f), f); self_trunk = self_trunk - f; }
+        const V3 f = ssign[i] * take(sslot[i], x);              // body B receives the opposite impulse
+        const SV ff = sv(cross(x, f), f);
+        if (sdepth[i] == 1) { pAq[1] = pAq[1] - ff; fbody[1] = fbody[1] + f; }        // booked on the thigh / the calf (penalised bodies:
+        else { pAq[2] = pAq[2] - ff; fbody[2] = fbody[2] + f; }                        //  the collision reward sees it, corl_rewards.py:49-52)
+        const bool trunk_pair = (((int)CRQ(sslot[i], 6)[3]) & 0x78) == 8;              // self, no B record: the trunk is body B
+        if (trunk_pair) { contrib = contrib + ff; ftrunk = ftrunk - f; }
       }
     }
   }
@@ -1426,28 +1435,16 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     const int b = 1 + 4 * leg + i;
     LDS(L_LAM + 3 * b) = fbody[i].x; LDS(L_LAM + 3 * b + 1) = fbody[i].y; LDS(L_LAM + 3 * b + 2) = fbody[i].z;      // listed: impulse, else 0
   }
-  float lj[3] = {0.f, 0.f, 0.f};                               // limit impulses of the own joints
-  if (legact) {
-#pragma unroll
-    for (int j = 0; j < 3; j++) lj[j] = JR(3 * leg + j)[5];
-  }
-  SV contrib = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));
   float du[3];
 #pragma unroll
   for (int j = 2; j >= 0; j--) {
-    float u = lj[j] - dot(S[j], pA[j]);
+    float u = lamj[j] - dot(F.S[j], pAq[j]);
     du[j] = u;
-    SV pa = pA[j] + (u * Dinv[j]) * U[j];
-    if (j > 0) pA[j - 1] = pA[j - 1] + pa; else contrib = pa;
+    SV pa = pAq[j] + (u * F.Dinv[j]) * F.U[j];
+    if (j > 0) pAq[j - 1] = pAq[j - 1] + pa; else contrib = contrib + pa;
   }
-  contrib = contrib + self_base;                               // the trunk's share of trunk-leg contacts (-f at x)
-  if (cfg.self_collision) self_trunk = v3(quad_sum(self_trunk.x), quad_sum(self_trunk.y), quad_sum(self_trunk.z));
-  if (leg == 0) {
-    V3 f = self_trunk;
-    if (slot_b0 >= 0) { V3 x; const V3 f0 = take(slot_b0, x); contrib = contrib - sv(cross(x, f0), f0); f = f + f0; }
-    if (slot_b1 >= 0) { V3 x; const V3 f1 = take(slot_b1, x); contrib = contrib - sv(cross(x, f1), f1); f = f + f1; }
-    LDS(L_LAM) = f.x; LDS(L_LAM + 1) = f.y; LDS(L_LAM + 2) = f.z;
-  }
+  ftrunk = v3(quad_sum(ftrunk.x), quad_sum(ftrunk.y), quad_sum(ftrunk.z));
+  if (leg == 0) { LDS(L_LAM) = ftrunk.x; LDS(L_LAM + 1) = ftrunk.y; LDS(L_LAM + 2) = ftrunk.z; }
   SV dv0 = -sym6_mul(I0inv, quad_sum(contrib));
   s.w = w_free + dv0.a;
   s.v = v_free + dv0.l;
@@ -1461,9 +1458,9 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const int ji = 3 * leg + j;
-      float dqd = Dinv[j] * (du[j] - dot(U[j], a));
-      a = a + dqd * S[j];
-      float qd = qd_free[j] + dqd;
+      float dqd = F.Dinv[j] * (du[j] - dot(F.U[j], a));
+      a = a + dqd * F.S[j];
+      float qd = F.qdf[j] + dqd;
       // What the limit rows leave is the solver's residual; it is NOT clamped away.  Only a failure of the rows far outside
       // the admissible band is cut (and counted): GO1_LIMIT_SAFETY x the rate limit, GO1_LIMIT_SLACK beyond a stop.
       const float vl = GO1_LIMIT_SAFETY * GO1_JOINT_VEL_LIMIT[ji];
@@ -1487,9 +1484,9 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     float nx = dw * s.qx + dx * s.qw + dy * s.qz - dz * s.qy;
     float ny = dw * s.qy - dx * s.qz + dy * s.qw + dz * s.qx;
     float nz = dw * s.qz + dx * s.qy - dy * s.qx + dz * s.qw;
-    float nw = dw * s.qw - dx * s.qx - dy * s.qy - dz * s.qz;
-    float inv = rsqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
-    s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv; s.qw = nw * inv;
+    float nw_ = dw * s.qw - dx * s.qx - dy * s.qy - dz * s.qz;
+    float inv = rsqrtf(nx * nx + ny * ny + nz * nz + nw_ * nw_);
+    s.qx = nx * inv; s.qy = ny * inv; s.qz = nz * inv; s.qw = nw_ * inv;
   }
   {
     float a = 0.f;
@@ -1501,7 +1498,7 @@ DEV void physics_substep(CfgRef cfg, const int16_t* __restrict__ hs, float* lds,
     for (int j = 0; j < 3; j++) { a = nonfinite_acc(a, L.q[j]); a = nonfinite_acc(a, L.qd[j]); }
     if (a != a) fault |= 1u << GO1_FAULT_STATE_OUT;
   }
-  LDS_PHASE();          // the next substep's warm start reads what this one wrote (per-body impulses, row records)
+  LDS_PHASE();          // the next substep's warm start reads what this one wrote (per-body impulses)
   PROF(6);
 }
 

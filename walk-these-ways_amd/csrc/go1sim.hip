@@ -1,17 +1,22 @@
 // go1sim.hip — MI355X (gfx950 / CDNA4) Go1 vectorised step: kernels + the C-ABI of include/go1sim.h.
 //
-// Mapping: FOUR lanes per environment (one per leg), 16 environments per 64-lane wavefront, one wavefront per
-// workgroup: 4096 envs -> 256 workgroups = one per CU.  The step is a latency-bound O(n_dof) recursion (not a
-// bandwidth- or MFMA-bound kernel: DESIGN.md §5), so the design spends lanes on the only parallelism a single robot
-// has — its four independent leg chains — and keeps each chain in registers (go1_physics.h).  State lives in HBM as
-// SoA [component][env]; the tensor maps of post_physics_step (go1_maps.h) run on the leg-0 lane of each environment.
+// Mapping: FOUR lanes per environment (one per leg), 16 environments per 64-lane wavefront; the step kernel's workgroup is
+// 4 wavefronts for those 16 environments — one MASTER that runs the step and three HELPERS on the CU's other SIMDs, fed through
+// LDS (4096 envs -> 256 workgroups x 4 wavefronts: one wavefront per SIMD of the chip).  The step is a latency / issue-bound
+// O(n_dof) recursion (not a bandwidth- or MFMA-bound kernel: DESIGN.md §5), so the design spends lanes on the parallelism a
+// single robot has — its four independent leg chains (kept in registers, go1_physics.h) — and wavefronts on the data-parallel
+// blocks of a substep.  State lives in HBM as SoA [component][env]; the tensor maps of post_physics_step (go1_maps.h) run
+// 4-wide on the master.
 //
-// Physics per substep (replaces gym.simulate, reference legged_robot.py:76-80):
-//   1. forward kinematics + per-body deepest-point contact detection        (per leg lane)
-//   2. Featherstone articulated-body algorithm, world-aligned frame at the base origin; base terms quad-reduced
-//   3. Delassus matrix W = J M^-1 J^T of the <= 6 solver contacts by O(n) impulse propagation
-//      through the ABA factors; projected Gauss-Seidel on (normal, 2 tangents) with a Coulomb cone
-//   4. one more impulse propagation applies all contact impulses; semi-implicit Euler; joint limits
+// Physics per substep (replaces gym.simulate, reference legged_robot.py:76-80; contract: DESIGN.md §2, oracle/go1_oracle.c):
+//   1. torque model: the helpers evaluate the actuator network (hidden layer on MFMA, fp16 hi/lo split) while the master runs
+//   2. forward kinematics + contact candidates (terrain top surface, vertical faces of a trimesh terrain, self-collision
+//      capsules), the solver's contact list (<= 24 contacts, priority order, overflow counted per class)
+//   3. Featherstone articulated-body algorithm, world-aligned frame at the base origin; base terms quad-reduced
+//   4. the rows of the solve in factorised coordinates (M^-1 = A A^T from the ABA factors): terrain contacts finished by the
+//      helpers, self-contacts and joint-limit rows by the master
+//   5. matrix-free projected Gauss-Seidel on (normal, 2 tangents | limit rows), static / dynamic Coulomb cone
+//   6. one more impulse propagation applies all impulses; semi-implicit Euler
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -24,9 +29,9 @@
 #define GO1SIM_STR_(x) #x
 #define GO1SIM_STR(x) GO1SIM_STR_(x)
 
-static_assert(A_IO_END <= LDSW_SIZE, "the actuator network's transient rows are overlaid on the solver's matrix");
-static_assert(PK_END <= LDSW_SIZE, "the contact packets of the emission hand-over are overlaid on the solver's matrix");
-static_assert(L_END >= GO1_MAX_OBS, "post_physics stages the observation rows in the solver's LDS block");
+static_assert(A_IO_END <= PKL_Q * WAVE * 4, "the actuator network's transient rows are overlaid on the emission hand-over packets");
+static_assert(L_KL + 7 <= L_END && L_END >= GO1_MAX_OBS, "post_physics stages the observation rows in the solver's scalar block");
+static_assert(MAXC == GO1_MAX_CONTACTS && GO1_SIG_MAX_SUBSTEPS >= 1, "contact list size is part of the ABI (oracle and kernel share it)");
 struct SimConst {            // lives in device memory (one per handle): indexable with scalar loads
   Go1SimConfig cfg;
   Go1SimConfig cfg_eval;     // configuration of the environments [num_train_envs, num_envs) (a copy of cfg without a split)
@@ -66,25 +71,20 @@ DEV void report_fault(BufRef B, int e, uint32_t fault) {
 }
 
 // Workgroup = STEP_WAVES wavefronts for 16 environments.  Wavefront 0 (the "master") runs the step — four lanes per
-// environment, one per leg; the other wavefronts are helpers on the CU's other SIMDs: they take their share of the two
-// data-parallel blocks of every substep (the actuator network's row tiles, the rows of the Delassus matrix), fed through
-// LDS, and wait at workgroup barriers otherwise.  4096 environments -> 256 workgroups x 4 wavefronts: one per SIMD.
+// environment, one per leg; the other wavefronts are helpers on the CU's other SIMDs: they take the two data-parallel
+// blocks of every substep (the actuator network's row tiles, the rows of the listed terrain contacts), fed through LDS,
+// and wait at workgroup barriers otherwise.  4096 environments -> 256 workgroups x 4 wavefronts: one per SIMD.
+// WALLS: the terrain has vertical faces (hf_wall_threshold > 0); the plain instance carries none of that code or its registers.
 #ifndef STEP_WAVES
 #define STEP_WAVES 4
 #endif
-extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(const StepArgs A) {
-  __shared__ float lds[L_END * EPW];
-  __shared__ __attribute__((aligned(16))) float ldsw[LDSW_SIZE];
-  __shared__ __attribute__((aligned(16))) float ldsx[LDSX_SIZE];
-  __shared__ __attribute__((aligned(16))) float act_lds[A_END];
-  __shared__ float acth[AH_END * WAVE];          // per-lane stash of the deferred torque path (torque_stash_load)
+template <bool WALLS>
+DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, float* acth) {
   const int nw = STEP_WAVES, wv = WAVE_UNIFORM((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63, leg = lane & 3;
-  for (int i = threadIdx.x; i < (L_END - L_W) * EPW; i += WAVE * STEP_WAVES) lds[L_W * EPW + i] = 0.f;   // finite everywhere: see the PGS column split
-  {
-    typedef __attribute__((ext_vector_type(4))) float zf4;
-    for (int i = threadIdx.x; i < LDSW_SIZE / 4; i += WAVE * STEP_WAVES) reinterpret_cast<zf4*>(ldsw)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < LDSX_SIZE / 4; i += WAVE * STEP_WAVES) reinterpret_cast<zf4*>(ldsx)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
-  }
+  for (int i = threadIdx.x; i < L_END * EPW; i += WAVE * STEP_WAVES) lds[i] = 0.f;
+  for (int i = threadIdx.x; i < X_END; i += WAVE * STEP_WAVES) ldsx[i] = (lf4){0.f, 0.f, 0.f, 0.f};      // finite everywhere: stale records are read (with zero weight)
+  SolverLds Z;
+  Z.lds = lds; Z.x = ldsx;
   const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
   CfgRef cfg = WAVE_CFG(csc, (int)blockIdx.x * EPW);
   BufRef B = csc->buf;
@@ -102,25 +102,18 @@ extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(
   __syncthreads();
   if (e >= N) return;
   if (wv != 0) {           // helper wavefront: the same sequence of workgroup barriers as the master's substep loop
-    PROF_DECL
 #pragma unroll 1
     for (int sub = 0; sub < cfg.decimation; sub++) {
 #ifndef GO1_ABLATE_TORQUE
       if (deferred) {
         BLOCK_SYNC(nw);                                   // the master's input rows are in LDS
-        actuator_tiles(act_lds, ldsw, lane, wv - 1, nw - 1);
+        actuator_tiles(act_lds, Z.act_io(), lane, wv - 1, nw - 1);
         BLOCK_SYNC(nw);                                   // (the master arrives here when it needs the torques)
-      } else if (mfma_torque) actuator_net_mfma(act_lds, ldsw, lane, wv, nw, false, nullptr, nullptr);
+      } else if (mfma_torque) actuator_net_mfma(act_lds, Z.act_io(), lane, wv, nw, false, nullptr, nullptr);
 #endif
 #ifndef GO1_ABLATE_PHYSICS
-      BLOCK_SYNC(nw);                                     // the master's contact packets are in LDS
-      emit_contacts_helper(cfg, lds, ldsw, ldsx, lane, wv - 1, cfg.sim_dt);
-      BLOCK_SYNC(nw);
-#ifdef GO1_ROWS_HELPERS_ONLY
-      delassus_rows(lds, ldsw, ldsx, lane, wv - 1, nw - 1 PROF_PASS);
-#else
-      delassus_rows(lds, ldsw, ldsx, lane, wv, nw PROF_PASS);
-#endif
+      BLOCK_SYNC(nw);                                     // the master's items and hand-over packets are in LDS
+      emit_terrain_contacts(cfg, Z, lane >> 2, 4 * (wv - 1) + (lane & 3), 4 * (nw - 1), cfg.sim_dt);
       BLOCK_SYNC(nw);
 #endif
     }
@@ -172,15 +165,14 @@ extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(
   for (int sub = 0; sub < cfg.decimation; sub++) {
 #ifndef GO1_ABLATE_TORQUE
     if (deferred) {
-      torque_publish(L, acth, ldsw, lane, sub);
+      torque_publish(L, acth, Z.act_io(), lane, sub);
       BLOCK_SYNC(nw);
-    } else compute_torques(cfg, B, L, leg, e, N, head, act_lds, ldsw, full_wave, nw, fault);
+    } else compute_torques(cfg, B, L, leg, e, N, head, act_lds, Z.act_io(), full_wave, nw, fault);
 #endif
     PROF(1);
     head = (head + 1) % nl;
 #ifndef GO1_ABLATE_PHYSICS
-    physics_substep(cfg, B.height_samples, lds, ldsw, ldsx, lane, nw, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault,
-                    deferred ? acth : nullptr PROF_PASS);
+    physics_substep<WALLS>(cfg, B, Z, lane, nw, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault, deferred ? acth : nullptr, e, N, sub PROF_PASS);
 #endif
   }
   if (deferred) torque_stash_store(cfg, B, L, acth, lane, leg, e, N);
@@ -196,20 +188,24 @@ extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(
   report_fault(B, e, fault);
   PROF_FLUSH;
 }
+#define STEP_LDS \
+  __shared__ float lds[L_END * EPW]; \
+  __shared__ __attribute__((aligned(16))) lf4 ldsx[X_END]; \
+  __shared__ __attribute__((aligned(16))) float act_lds[A_END]; \
+  __shared__ float acth[AH_END * WAVE];          /* per-lane stash of the deferred torque path (torque_stash_load) */
+extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(const StepArgs A) { STEP_LDS step_body<false>(A, lds, ldsx, act_lds, acth); }
+extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel_walls(const StepArgs A) { STEP_LDS step_body<true>(A, lds, ldsx, act_lds, acth); }
 
 // piecewise entry points with the 4-lane mapping (parity tests): torques only / one physics substep / tensor maps only
 extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs A) {
   __shared__ float lds[L_END * EPW];
-  __shared__ __attribute__((aligned(16))) float ldsw[LDSW_SIZE];
-  __shared__ __attribute__((aligned(16))) float ldsx[LDSX_SIZE];
+  __shared__ __attribute__((aligned(16))) lf4 ldsx[X_END];
   __shared__ __attribute__((aligned(16))) float act_lds[A_END];
-  for (int i = threadIdx.x; i < (L_END - L_W) * EPW; i += WAVE) lds[L_W * EPW + i] = 0.f;   // finite everywhere: see the PGS column split
-  {
-    typedef __attribute__((ext_vector_type(4))) float zf4;
-    for (int i = threadIdx.x; i < LDSW_SIZE / 4; i += WAVE) reinterpret_cast<zf4*>(ldsw)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < LDSX_SIZE / 4; i += WAVE) reinterpret_cast<zf4*>(ldsx)[i] = (zf4){0.f, 0.f, 0.f, 0.f};
-  }
+  for (int i = threadIdx.x; i < L_END * EPW; i += WAVE) lds[i] = 0.f;
+  for (int i = threadIdx.x; i < X_END; i += WAVE) ldsx[i] = (lf4){0.f, 0.f, 0.f, 0.f};
   LDS_PHASE();
+  SolverLds Z;
+  Z.lds = lds; Z.x = ldsx;
   const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
   CfgRef cfg = WAVE_CFG(csc, (int)blockIdx.x * EPW);
   BufRef B = csc->buf;
@@ -233,7 +229,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   if (A.mode == 1) {       // torques only (actions given as SoA)
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) AT(B.actions, 3 * leg + jj, e) = AT(A.actions, 3 * leg + jj, e);
-    compute_torques(cfg, B, L, leg, e, N, A.lag_head, act_lds, ldsw, full_wave, 1, fault);
+    compute_torques(cfg, B, L, leg, e, N, A.lag_head, act_lds, Z.act_io(), full_wave, 1, fault);
     report_fault(B, e, fault);
     return;
   }
@@ -244,7 +240,10 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   load_lambda(cfg, B, lds, lane, e, N, false);
   LDS_PHASE();
   PROF_DECL
-  physics_substep(cfg, B.height_samples, lds, ldsw, ldsx, lane, 1, s, L, grav, cfg.warm_start != 0, cfg.sim_dt, fault, nullptr PROF_PASS);
+  if (cfg.terrain_type != 0 && cfg.hf_wall_threshold > 0.f)
+    physics_substep<true>(cfg, B, Z, lane, 1, s, L, grav, cfg.warm_start != 0, cfg.sim_dt, fault, nullptr, e, N, 0 PROF_PASS);
+  else
+    physics_substep<false>(cfg, B, Z, lane, 1, s, L, grav, cfg.warm_start != 0, cfg.sim_dt, fault, nullptr, e, N, 0 PROF_PASS);
   store_state(B, leg, e, N, s, L);
   foot_state(s, L, leg, B, e, N);
   store_forces(cfg, B, lds, lane, e, N);
@@ -261,7 +260,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_env_kernel(const StepArgs
     const int e = A.ids ? A.ids[i] : i;
     const bool ev = e >= csc->num_train_envs;              // per lane here: the ids are arbitrary
     CfgRef cfg = ev ? csc->cfg_eval : csc->cfg;
-    reset_env(cfg, B, e, N, A.counter, ev);
+    reset_env(cfg, B, e, N, A.counter, ev, A.counter);
   }
 }
 
@@ -280,7 +279,10 @@ extern "C" __global__ void __launch_bounds__(256) go1_history_kernel(const SimCo
   row[(size_t)(slot + R) * no + c] = v;
 }
 
-// curriculum weight update + CDF rebuild (reference curriculum.py:135-154): one workgroup per category
+// curriculum weight update + CDF rebuild (reference curriculum.py:135-154): one workgroup per category.  The successes of the
+// last curriculum_update_interval steps sit in one slot per step; their updates are applied in step order (each the
+// reference's per-step rule: +0.2 on a bin with a success and +0.2 per successful environment on the bins of its
+// neighbourhood, clipped at 1), then the CDF is rebuilt once.
 extern "C" __global__ void __launch_bounds__(256) go1_curriculum_kernel(const SimConst* __restrict__ sc) {
   const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)sc;
   CfgRef cfg = csc->cfg;
@@ -288,27 +290,32 @@ extern "C" __global__ void __launch_bounds__(256) go1_curriculum_kernel(const Si
   __shared__ float part[256];
   const int c = blockIdx.x, nb = cfg.num_bins, t = threadIdx.x;
   float* w = B.curriculum_weights + (size_t)c * nb;
-  int32_t* s = B.curriculum_success + (size_t)c * nb;
   float* cdf = B.curriculum_cdf + (size_t)c * nb;
-  // 1. increments (read all successes before anyone clears them)
   const int per = (nb + 255) / 256;
+  for (int slot = 0; slot < cfg.curriculum_update_interval; slot++) {
+    int32_t* s = B.curriculum_success + ((size_t)slot * cfg.num_categories + c) * nb;
+    // increments (read all successes of the slot before anyone clears them)
+    for (int i = 0; i < per; i++) {
+      int b = t * per + i;
+      if (b < nb) {
+        int cnt = s[b] > 0 ? 1 : 0;
+        for (int p = B.curriculum_nbr_ptr[b]; p < B.curriculum_nbr_ptr[b + 1]; p++) cnt += s[B.curriculum_nbr_idx[p]];
+        cdf[b] = fminf(1.0f, w[b] + 0.2f * cnt);        // stage the new weight in the cdf array until every thread has read `s`
+      }
+    }
+    __syncthreads();
+    for (int i = 0; i < per; i++) {
+      int b = t * per + i;
+      if (b < nb) { w[b] = cdf[b]; s[b] = 0; }
+    }
+    __syncthreads();
+  }
   float local = 0.f;
   for (int i = 0; i < per; i++) {
     int b = t * per + i;
-    if (b < nb) {
-      int cnt = s[b] > 0 ? 1 : 0;
-      for (int p = B.curriculum_nbr_ptr[b]; p < B.curriculum_nbr_ptr[b + 1]; p++) cnt += s[B.curriculum_nbr_idx[p]];
-      float nw = fminf(1.0f, w[b] + 0.2f * cnt);
-      cdf[b] = nw;        // stage the new weight in the cdf array until every thread has read `s`
-      local += nw;
-    }
+    if (b < nb) local += w[b];
   }
-  __syncthreads();
-  for (int i = 0; i < per; i++) {
-    int b = t * per + i;
-    if (b < nb) { w[b] = cdf[b]; s[b] = 0; }
-  }
-  // 2. block prefix sum of the per-thread totals
+  // block prefix sum of the per-thread totals
   part[t] = local;
   __syncthreads();
   for (int off = 1; off < 256; off <<= 1) {
@@ -346,6 +353,7 @@ struct Go1Sim {
 static int check_cfg(const Go1SimConfig* cfg) {
   if (!cfg || cfg->abi_version != GO1SIM_ABI_VERSION) return -2;
   if (cfg->num_envs <= 0 || cfg->lag_timesteps + 1 > GO1_MAX_LAG) return -3;
+  if (cfg->curriculum_update_interval < 1 || cfg->curriculum_update_interval > GO1_MAX_CURRICULUM_INTERVAL) return -3;
   const int scan = cfg->observe_heights ? cfg->num_height_x * cfg->num_height_y : 0;
   if (cfg->num_obs - scan > GO1_MAX_OBS || cfg->num_privileged_obs > GO1_MAX_PRIV_OBS || cfg->num_rewards > GO1_MAX_REWARDS) return -4;
   if (cfg->terrain_type != 0 && (cfg->hf_rows < 2 || cfg->hf_cols < 2)) return -5;
@@ -426,7 +434,10 @@ static int launch(Go1Sim* s, int mode, const float* actions, const int32_t* ids,
   dim3 grid((n + per_block - 1) / per_block), block(mode == 0 ? WAVE * STEP_WAVES : WAVE);
   const int slot = timed ? (int)(s->timing_n % s->timing_cap) : 0;
   if (timed) (void)hipEventRecord(s->ev[2 * slot], st);
-  if (mode == 0) hipLaunchKernelGGL(go1_step_kernel, grid, block, 0, st, A);
+  if (mode == 0) {
+    if (s->cfg.terrain_type != 0 && s->cfg.hf_wall_threshold > 0.f) hipLaunchKernelGGL(go1_step_kernel_walls, grid, block, 0, st, A);
+    else hipLaunchKernelGGL(go1_step_kernel, grid, block, 0, st, A);
+  }
   else if (mode == 3) hipLaunchKernelGGL(go1_env_kernel, grid, block, 0, st, A);
   else hipLaunchKernelGGL(go1_aux_kernel, grid, block, 0, st, A);
   if (timed) { (void)hipEventRecord(s->ev[2 * slot + 1], st); s->timing_n++; }
@@ -441,7 +452,7 @@ extern "C" int go1sim_step(Go1Sim* s, const float* actions, void* stream) {
   s->counter += 1;
   s->lag_head = (s->lag_head + s->cfg.decimation) % (s->cfg.lag_timesteps + 1);
   s->history_slot = (s->history_slot + 1) % (s->cfg.num_obs_history + 1);
-  if (s->cfg.device_curriculum && s->buf.curriculum_weights && !s->cfg.defer_curriculum_update) {
+  if (s->cfg.device_curriculum && s->buf.curriculum_weights && !s->cfg.defer_curriculum_update && s->counter % s->cfg.curriculum_update_interval == 0) {
     hipLaunchKernelGGL(go1_curriculum_kernel, dim3(s->cfg.num_categories), dim3(256), 0, st, (const SimConst*)s->dconst);
     if (hipGetLastError() != hipSuccess) return -21;
   }

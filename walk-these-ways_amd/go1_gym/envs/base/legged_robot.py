@@ -219,20 +219,12 @@ class LeggedRobot(BaseTask):
         self.buffers = B = H.SimBuffers(self.sim_config, self.sim_meta, self.device)
         if mesh_type in ('heightfield', 'trimesh'):
             # both mesh types are simulated on the height field's bilinear surface (utils/terrain.py docstring)
+            # 'heightfield': the bilinear surface.  'trimesh': the reference corrects faces steeper than slope_treshold into vertical
+            # walls (terrain.py:33-36, convert_heightfield_to_trimesh) — simulated as vertical contact faces on the same height
+            # field (include/go1sim.h hf_wall_threshold)
             H.bind_height_field(self.sim_config, B, self.terrain.heightsamples, cfg.terrain.horizontal_scale,
-                                cfg.terrain.vertical_scale, cfg.terrain.border_size)
-            if mesh_type == 'trimesh' and self.sim_config.terrain_type != 0:
-                hs = np.asarray(self.terrain.heightsamples, dtype=np.float64) * cfg.terrain.vertical_scale
-                steep = max(np.abs(np.diff(hs, axis=0)).max(), np.abs(np.diff(hs, axis=1)).max()) / cfg.terrain.horizontal_scale
-                thr = float(getattr(cfg.terrain, "slope_treshold", 0.75))
-                if steep > thr:
-                    import warnings
-                    warnings.warn(
-                        f"mesh_type='trimesh' on a non-flat terrain with slopes up to {steep:.2f} (> slope_treshold {thr}): the "
-                        f"reference converts such faces into VERTICAL WALLS (terrain.py:33-36, convert_heightfield_to_trimesh); this "
-                        f"simulator collides with the bilinear height-field surface instead, so risers are steep ramps one cell "
-                        f"({cfg.terrain.horizontal_scale} m) wide.  Flat trimesh terrains (scripts/train.py) are unaffected.",
-                        RuntimeWarning, stacklevel=2)
+                                cfg.terrain.vertical_scale, cfg.terrain.border_size,
+                                slope_threshold=float(getattr(cfg.terrain, "slope_treshold", 0.75)) if mesh_type == 'trimesh' else None)
         self.num_dof = self.num_dofs = self.num_actuated_dof = 12
         self.num_bodies = 17
         self.dof_names = list(H.DOF_NAMES)
@@ -429,7 +421,9 @@ class LeggedRobot(BaseTask):
         if not actions.is_contiguous():
             actions = actions.contiguous()
         self.sim.step(actions)
-        if self._curriculum_sync:
+        if self._curriculum_sync and (self.common_step_counter + 1) % self.sim_config.curriculum_update_interval == 0:
+            # ONE exchange for the last `curriculum_update_interval` steps' success counts (a slot per step), then the per-step
+            # updates in order: every rank applies what a single process over the concatenated shards would
             import torch.distributed as dist
             dist.all_reduce(self.buffers.curriculum_success)
             self.sim.curriculum_update()

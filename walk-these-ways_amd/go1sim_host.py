@@ -103,7 +103,7 @@ def physx_section(cfg):
 
 
 def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curriculum=True,
-                     solver_iterations=4, warm_start=True, defer_curriculum_update=False):
+                     solver_iterations=4, warm_start=True, defer_curriculum_update=False, curriculum_update_interval=None):
     """Flatten `cfg` (a Cfg tree) into a Go1SimConfig.  Returns (struct, meta)."""
     S = abi.Go1SimConfig()
     S.abi_version = abi.GO1SIM_ABI_VERSION
@@ -145,6 +145,8 @@ def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curricu
     S.max_depenetration_velocity = px.max_depenetration_velocity
     S.bounce_threshold_velocity = px.bounce_threshold_velocity
     S.terrain_friction = cfg.terrain.static_friction
+    S.terrain_dynamic_friction = getattr(cfg.terrain, "dynamic_friction", cfg.terrain.static_friction)
+    S.hf_wall_threshold = 0.0                                   # set by bind_height_field(slope_threshold=...) for a trimesh terrain
     S.terrain_restitution = cfg.terrain.restitution
     S.max_linear_velocity = float(cfg.asset.max_linear_velocity)
     S.max_angular_velocity = float(cfg.asset.max_angular_velocity)
@@ -290,6 +292,9 @@ def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curricu
     cm = cfg.commands
     S.device_curriculum = int(device_curriculum)
     S.defer_curriculum_update = int(defer_curriculum_update)
+    K = curriculum_update_interval if curriculum_update_interval is not None else getattr(cm, "curriculum_update_interval", 1)
+    S.curriculum_update_interval = int(K)
+    assert 1 <= S.curriculum_update_interval <= abi.GO1_MAX_CURRICULUM_INTERVAL
     S.gaitwise_curricula = int(cm.gaitwise_curricula)
     S.binary_phases = int(cm.binary_phases)
     S.exclusive_phase_offset = int(getattr(cm, "exclusive_phase_offset", False))
@@ -319,14 +324,23 @@ def ter_measure(cfg):
     return bool(cfg.terrain.measure_heights)
 
 
-def bind_height_field(S, buffers, heights_int16, hscale, vscale, border):
+def bind_height_field(S, buffers, heights_int16, hscale, vscale, border, slope_threshold=None):
     """`_create_heightfield` / `_create_trimesh` (legged_robot.py:1441-1479): hand the int16 height samples to the
-    simulator.  A constant field is served by the plane fast path (same physics, no gathers)."""
+    simulator.  A constant field is served by the plane fast path (same physics, no gathers).  `slope_threshold` (the
+    trimesh terrain's `slope_treshold`, terrain.py:33-36): cell edges rising by more than slope_threshold * hscale become
+    vertical faces (include/go1sim.h hf_wall_threshold) — only when the field has such an edge at all."""
     hs = torch.as_tensor(np.ascontiguousarray(heights_int16), dtype=torch.int16)
     S.hf_rows, S.hf_cols = int(hs.shape[0]), int(hs.shape[1])
     S.hf_hscale, S.hf_vscale, S.hf_border = float(hscale), float(vscale), float(border)
     flat = bool((hs == hs.flatten()[0]).all()) and int(hs.flatten()[0]) == 0
     S.terrain_type = 0 if flat else 1
+    S.hf_wall_threshold = 0.0
+    if slope_threshold is not None and not flat:
+        thr = float(slope_threshold) * float(hscale)
+        h = hs.to(torch.float64) * float(vscale)
+        steepest = max(float((h[1:] - h[:-1]).abs().max()), float((h[:, 1:] - h[:, :-1]).abs().max()))
+        if steepest > thr:
+            S.hf_wall_threshold = thr
     buffers.tensors["height_samples"] = hs.to(buffers.device)
     buffers.refresh_struct()
     return S
@@ -361,7 +375,7 @@ def noise_scale_vec(cfg):
 def _buffer_specs(S):
     N, nr, nl = S.num_envs, S.num_rewards, S.lag_timesteps + 1
     f, i32, u8 = torch.float32, torch.int32, torch.uint8
-    nb, nc = S.num_bins, S.num_categories
+    nb, nc, ki = S.num_bins, S.num_categories, max(int(S.curriculum_update_interval), 1)
     return {
         "root_states": (f, (13, N)), "dof_pos": (f, (12, N)), "dof_vel": (f, (12, N)),
         "contact_forces": (f, (51, N)), "foot_positions": (f, (12, N)), "foot_velocities": (f, (12, N)),
@@ -384,11 +398,12 @@ def _buffer_specs(S):
         "com_displacements": (f, (3, N)), "motor_strengths": (f, (12, N)), "motor_offsets": (f, (12, N)),
         "Kp_factors": (f, (12, N)), "Kd_factors": (f, (12, N)), "env_origins": (f, (3, N)),
         "env_command_bins": (i32, (N,)), "env_command_categories": (i32, (N,)),
-        "curriculum_weights": (f, (nc, nb)), "curriculum_cdf": (f, (nc, nb)), "curriculum_success": (i32, (nc, nb)),
+        "curriculum_weights": (f, (nc, nb)), "curriculum_cdf": (f, (nc, nb)), "curriculum_success": (i32, (ki, nc, nb)),
         "obs_buf": (f, (N, S.num_obs)), "privileged_obs_buf": (f, (N, max(S.num_privileged_obs, 1))),
         "obs_history": (f, (N, 2 * (S.num_obs_history + 1) * S.num_obs)),
         "measured_heights": (f, (max(S.num_height_x * S.num_height_y, 1), N)),
         "fault_flags": (i32, (N,)), "fault_counts": (i32, (abi.GO1_FAULT_BITS,)),
+        "contact_drop_counts": (i32, (abi.GO1_CC_COUNT,)),
     }
 
 
@@ -416,8 +431,16 @@ class SimBuffers:
         t["curriculum_nbr_ptr"] = torch.from_numpy(ptr).to(self.device)
         t["curriculum_nbr_idx"] = torch.from_numpy(idx).to(self.device)
         t["height_samples"] = None
+        t["contact_signature"] = None       # tests: enable_contact_signature()
         self.struct = abi.Go1SimBuffers()
         self.refresh_struct()
+
+    def enable_contact_signature(self):
+        """allocate the per-substep record of listed contact points / self pairs / limit-row legs (include/go1sim.h)"""
+        n = self.tensors["root_states"].shape[1]
+        self.tensors["contact_signature"] = torch.zeros(abi.GO1_SIG_MAX_SUBSTEPS * abi.GO1_SIG_WORDS, n, dtype=torch.int32, device=self.device)
+        self.refresh_struct()
+        return self.tensors["contact_signature"]
 
     def refresh_struct(self):
         for name in abi.BUFFER_FIELDS:
