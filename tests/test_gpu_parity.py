@@ -1,9 +1,13 @@
 """HIP step (through the C-ABI) vs the CPU oracle on identical seeded inputs.  fp32 kernel vs fp64 oracle.
 
-Tolerances (stated per quantity): one physics substep from identical state —
-q, qd, root: 2e-4 abs; contact forces: 2e-2 N + 1e-3 rel; full step — obs 2e-3, rewards 2e-4.  Contact
-on/off decisions sit on float thresholds, so a small fraction of environments may take a different branch in
-fp32 than in fp64; those are bounded by an outlier budget (<= 1 %) instead of loosening everyone's tolerance.
+Tolerances are stated per quantity where they are applied (one physics substep from identical state: q, root 2e-4, qd 3e-3,
+contact forces 5e-2 N + 2e-3 rel; full step: q, root 1e-3, qd 2e-2, rewards 2e-4, observations 3e-3, torques 5e-3 — each with
+the relative part given next to it).  There is NO free outlier budget: an environment may exceed a tolerance only if it is
+ATTRIBUTED — the set of contact points / self pairs / limit-row legs the solver listed in some substep of the step differs
+between kernel and oracle (both record it, include/go1sim.h `contact_signature`: a point sitting on the activation
+threshold falls on different sides in fp32 and fp64) — and even then its error stays below ATTRIBUTED_BOUND x the tolerance.
+tests/test_oracle_precision.py shows that the fp32 BUILD OF THE ORACLE against the fp64 build flips at the same (tiny) rate:
+the flips are round-off, not logic.
 """
 import numpy as np
 import pytest
@@ -21,6 +25,7 @@ def gpu_pair(variant, N, seed=3, **kw):
     import pyoracle
     cfg, S, meta, Bc = make_sim(variant, N, seed=seed, **kw)
     randomize_dr(Bc, seed)
+    Bc.enable_contact_signature()
     orc = pyoracle.Oracle(S, Bc)
     orc.reset_idx()
     return cfg, S, meta, Bc, orc
@@ -37,6 +42,48 @@ def sync_from(Bc, Bg, sim, orc):
         if t is not None and k in Bg.tensors and Bg.tensors[k] is not None:
             Bg.tensors[k].copy_(t)
     sim.set_counters(orc.ctr.common_step_counter, orc.ctr.lag_head)
+
+
+ATTRIBUTED_BOUND = 50.0          # x tolerance: what a contact point entering / leaving the solver's list may change in one step
+ATTRIBUTED_RATE = 2e-3           # fraction of environment-steps allowed to be attributed (measured: ~1e-4; fp32-vs-fp64 oracle: same order)
+
+
+class Attribution:
+    """Per-step bookkeeping of the environments outside the tolerances: every one must differ in its contact signature."""
+
+    def __init__(self, N):
+        self.N, self.env_steps, self.bad, self.attributed, self.worst_ratio, self.worst_unattr = N, 0, 0, 0, 0.0, 0.0
+
+    def ratio(self, a, b, atol, rtol=0.0, env_dim=-1):
+        a, b = a.double().cpu(), b.double().cpu()
+        r = (a - b).abs() / (atol + rtol * b.abs())
+        r = torch.nan_to_num(r, nan=float("inf"))
+        if env_dim == 0:
+            return r.reshape(self.N, -1).max(1).values
+        return r.reshape(-1, self.N).max(0).values
+
+    def step(self, ratio, Bg, Bc, extra_bad=None):
+        """ratio: (N,) worst error / tolerance of every environment this step"""
+        sig = (Bg.contact_signature.cpu() != Bc.contact_signature).any(0)
+        bad = ratio > 1.0
+        if extra_bad is not None:
+            bad = bad | extra_bad
+        un = bad & ~sig
+        self.env_steps += self.N
+        self.bad += int(bad.sum()); self.attributed += int((bad & sig).sum())
+        if bool((bad & sig).any()):
+            self.worst_ratio = max(self.worst_ratio, float(ratio[bad & sig].max()))
+        if bool(un.any()):
+            self.worst_unattr = max(self.worst_unattr, float(ratio[un].max()))
+        assert not bool(un.any()), f"environments {un.nonzero().flatten().tolist()[:8]} exceed the tolerances (worst x{float(ratio[un].max()):.1f}) with identical contact sets"
+        return bad
+
+    def finish(self, what):
+        rate = self.attributed / max(self.env_steps, 1)
+        print(f"{what}: {self.env_steps} env-steps, {self.bad} outside the tolerances, all attributed to a different contact set "
+              f"(rate {rate:.2e}, worst x{self.worst_ratio:.1f} of the tolerance)")
+        assert rate <= ATTRIBUTED_RATE, rate
+        assert self.worst_ratio <= ATTRIBUTED_BOUND, self.worst_ratio
 
 
 def frac_bad(a, b, atol, rtol=0.0):
@@ -89,29 +136,50 @@ def test_physics_substep_matches_oracle(scenario):
         Bc.dof_vel.uniform_(-5, 5, generator=g)
     Bc.torques.uniform_(-20, 20, generator=g)
     Bg, sim = to_gpu(S, Bc)
-    worst = 0.0
+    att = Attribution(N)
     for it in range(6):
         orc.physics_substep()
         sim.physics_substep()
         torch.cuda.synchronize()
         assert torch.isfinite(Bg.root_states).all() and torch.isfinite(Bg.dof_vel).all()
-        bad_env = torch.zeros(N, dtype=torch.bool)
-        for k, tol in (("root_states", 2e-4), ("dof_pos", 2e-4), ("dof_vel", 3e-3)):
-            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], tol, 1e-4)
-            bad_env |= bad.any(0)
-        bad, _ = frac_bad(Bg.contact_forces, Bc.contact_forces, 5e-2, 2e-3)
-        bad_env |= bad.any(0)
-        worst = max(worst, float(bad_env.float().mean()))
+        ratio = torch.zeros(N, dtype=torch.float64)
+        for k, tol, rt in (("root_states", 2e-4, 1e-4), ("dof_pos", 2e-4, 1e-4), ("dof_vel", 3e-3, 1e-4), ("contact_forces", 5e-2, 2e-3)):
+            ratio = torch.maximum(ratio, att.ratio(Bg.tensors[k], Bc.tensors[k], tol, rt))
+        att.step(ratio, Bg, Bc)
         sync_from(Bc, Bg, sim, orc)      # re-synchronise so that one substep is compared at a time
-    assert worst <= (0.0 if scenario in ("flight", "standing") else 0.02), worst
+    att.finish(f"substep[{scenario}]")
+    if scenario in ("flight", "standing"):
+        assert att.bad == 0
     if scenario != "flight":
         assert float(Bc.contact_forces.abs().max()) > 1.0
 
 
-def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=None):
+FULL_STEP_TOL = (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
+                 ("commands", 1e-5, 0), ("gait_indices", 1e-5, 0), ("clock_inputs", 1e-4, 0),
+                 ("desired_contact_states", 1e-4, 0), ("torques", 5e-3, 1e-3), ("foot_positions", 1e-3, 0),
+                 ("episode_sums", 1e-3, 1e-3), ("command_sums", 1e-3, 1e-3), ("motor_offsets", 1e-6, 0),
+                 ("motor_strengths", 1e-6, 0), ("last_actions", 1e-6, 0),
+                 # state the torque model carries (LDS stash in the step kernel, written back once per step)
+                 ("joint_pos_err_last", 1e-3, 0), ("joint_pos_err_last_last", 1e-3, 0), ("joint_vel_last", 2e-2, 1e-3),
+                 ("joint_vel_last_last", 2e-2, 1e-3), ("joint_pos_target", 1e-5, 0), ("lag_buffer", 1e-5, 0))
+ROW_TOL = (("obs_buf", 3e-3, 1e-3), ("privileged_obs_buf", 1e-5, 0), ("obs_history", 3e-3, 1e-3))
+
+
+def step_ratio(att, Bg, Bc, keys=FULL_STEP_TOL, rows=ROW_TOL):
+    """(N,) worst error / tolerance over the compared quantities of one full step"""
+    ratio = torch.zeros(att.N, dtype=torch.float64)
+    for k, tol, rt in keys:
+        ratio = torch.maximum(ratio, att.ratio(Bg.tensors[k], Bc.tensors[k], tol, rt))
+    for k, tol, rt in rows:
+        ratio = torch.maximum(ratio, att.ratio(Bg.tensors[k], Bc.tensors[k], tol, rt, env_dim=0))
+    return ratio
+
+
+def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=None, what="full step"):
     """HIP step vs oracle step on identical state / action / RNG streams, re-synchronised after every step so that each
     step is compared on its own (a free-running pair diverges through contact-mode flips, as two fp32 PhysX runs
-    would).  Returns (worst, mean) fraction of environments outside the per-quantity tolerances, and event counts."""
+    would).  Every environment outside the per-quantity tolerances must be attributed (module docstring); returns the
+    Attribution record and event counts."""
     cfg, S, meta, Bc, orc = gpu_pair(variant, N, seed=seed)
     Bg, sim = to_gpu(S, Bc)
     rng = np.random.default_rng(0)
@@ -121,7 +189,8 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
     sync_from(Bc, Bg, sim, orc)
     resets = 0
     resamples = 0
-    worst, total_bad, timeouts = 0.0, 0.0, 0
+    timeouts = 0
+    att = Attribution(N)
     for step in range(steps):
         a = (rng.standard_normal((N, 12)) * (1.0 if step % 2 else 0.3)).astype(np.float32)
         if step == 20:
@@ -134,25 +203,7 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
         torch.cuda.synchronize()
         cpu_reset = Bc.reset_buf.bool()
         np.testing.assert_array_equal(Bg.time_out_buf.cpu().numpy(), Bc.time_out_buf.numpy())
-        bad_env = (Bg.reset_buf.cpu().bool() != cpu_reset)
-        for k, tol, rt in (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
-                           ("commands", 1e-5, 0), ("gait_indices", 1e-5, 0), ("clock_inputs", 1e-4, 0),
-                           ("desired_contact_states", 1e-4, 0), ("torques", 5e-3, 1e-3), ("foot_positions", 1e-3, 0),
-                           ("episode_sums", 1e-3, 1e-3), ("command_sums", 1e-3, 1e-3), ("motor_offsets", 1e-6, 0),
-                           ("motor_strengths", 1e-6, 0), ("last_actions", 1e-6, 0),
-                           # state the torque model carries (LDS stash in the step kernel, written back once per step)
-                           ("joint_pos_err_last", 1e-3, 0), ("joint_pos_err_last_last", 1e-3, 0), ("joint_vel_last", 2e-2, 1e-3),
-                           ("joint_vel_last_last", 2e-2, 1e-3), ("joint_pos_target", 1e-5, 0), ("lag_buffer", 1e-5, 0)):
-            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], tol, rt)
-            bad_env |= bad.reshape(-1, N).any(0)
-        bad, _ = frac_bad(Bg.obs_buf, Bc.obs_buf, 3e-3, 1e-3)
-        bad_env |= bad.any(1)
-        bad, _ = frac_bad(Bg.privileged_obs_buf, Bc.privileged_obs_buf, 1e-5)
-        bad_env |= bad.any(1)
-        bad, _ = frac_bad(Bg.obs_history, Bc.obs_history, 3e-3, 1e-3)
-        bad_env |= bad.any(1)
-        worst = max(worst, float(bad_env.float().mean()))
-        total_bad += float(bad_env.float().mean())
+        bad_env = att.step(step_ratio(att, Bg, Bc), Bg, Bc, extra_bad=(Bg.reset_buf.cpu().bool() != cpu_reset))
         timeouts += int(Bc.time_out_buf.sum())
         np.testing.assert_array_equal(Bg.env_command_bins.cpu().numpy()[~bad_env.numpy()], Bc.env_command_bins.numpy()[~bad_env.numpy()])
         np.testing.assert_allclose(Bg.curriculum_weights.cpu().numpy(), Bc.curriculum_weights.numpy(), atol=0.21 * float(bad_env.sum()) + 1e-6)
@@ -165,32 +216,28 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
                 assert not bool(bad[..., ~bad_env].any()), k
         sync_from(Bc, Bg, sim, orc)
     assert int(Bg.fault_counts[:10].sum()) == 0, Bg.fault_counts.tolist()
-    return worst, total_bad / steps, resets, resamples, timeouts
+    att.finish(f"{what} [{variant}, {N} envs x {steps} steps]")
+    return att, resets, resamples, timeouts
 
 
 @pytest.mark.parametrize("variant", ["train_noise", "alt"])
 def test_full_step_matches_oracle(variant):
-    worst, mean, resets, resamples, _ = run_full_step_comparison(variant, 512, 40)
+    att, resets, resamples, _ = run_full_step_comparison(variant, 512, 40)
     assert resets > 20 and resamples > 20      # resets and interval resamples were exercised
-    assert worst <= 0.02, worst
 
 
 @pytest.mark.parametrize("variant,N", [("train_noise", 1), ("dr", 21)])
 def test_ragged_env_counts_match_oracle(variant, N):
     """environment counts that do not fill a workgroup of 16: scripts/play.py's single environment (play.py:62) and a ragged
-    second workgroup.  Few environments, so the bound is a count: at most two environments outside the tolerances in any step
-    (N = 1: in at most two of the steps)."""
-    steps = 12
-    worst, mean, *_ = run_full_step_comparison(variant, N, steps)
-    assert worst * N <= 2.01 and mean * steps * N <= (2.01 if N == 1 else 6.01), (worst, mean)
+    second workgroup."""
+    run_full_step_comparison(variant, N, 12, what="ragged")
 
 
 @pytest.mark.parametrize("case", range(6))
 def test_full_step_under_random_configurations(case):
     """configuration fuzz on the hardware (fixed seeds; the generator of tests/golden/variants.py, the same that drives the emulated
     kernel's fuzz in tests/test_emu_parity.py): random consistent sets of observation / privileged-observation / controller /
-    reward / termination / command switches, HIP step vs oracle on identical streams, re-synchronised every step; the bound is
-    the one of test_full_step_matches_oracle scaled to 128 environments (at most three outside the tolerances in a step)."""
+    reward / termination / command switches, HIP step vs oracle on identical streams, re-synchronised every step."""
     from golden.variants import random_switches
     rng = np.random.default_rng(1000 + case)
     extra = random_switches(rng)
@@ -199,23 +246,18 @@ def test_full_step_under_random_configurations(case):
     Bg, sim = to_gpu(S, Bc)
     Bc.episode_length_buf[:] = torch.randint(0, int(S.max_episode_length), (N,), dtype=torch.int32, generator=torch.Generator().manual_seed(case))
     sync_from(Bc, Bg, sim, orc)
-    worst = 0
+    att = Attribution(N)
     for step in range(steps):
         a = (rng.standard_normal((N, 12)) * (2.0 if step == 1 else 0.5)).astype(np.float32)
         orc.step(a)
         sim.step(torch.from_numpy(a).cuda())
         torch.cuda.synchronize()
-        bad_env = Bg.reset_buf.cpu().bool() != Bc.reset_buf.bool()
-        for k, tol, rt in (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
-                           ("commands", 1e-5, 0), ("torques", 5e-3, 1e-3), ("episode_sums", 1e-3, 1e-3), ("command_sums", 1e-3, 1e-3)):
-            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], tol, rt)
-            bad_env |= bad.reshape(-1, N).any(0)
-        for k in ("obs_buf", "privileged_obs_buf"):
-            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], 3e-3, 1e-3)
-            bad_env |= bad.any(1)
-        worst = max(worst, int(bad_env.sum()))
+        keys = (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
+                ("commands", 1e-5, 0), ("torques", 5e-3, 1e-3), ("episode_sums", 1e-3, 1e-3), ("command_sums", 1e-3, 1e-3))
+        rows = (("obs_buf", 3e-3, 1e-3), ("privileged_obs_buf", 3e-3, 1e-3))
+        att.step(step_ratio(att, Bg, Bc, keys, rows), Bg, Bc, extra_bad=(Bg.reset_buf.cpu().bool() != Bc.reset_buf.bool()))
         sync_from(Bc, Bg, sim, orc)
-    assert worst <= 3, (worst, extra)
+    att.finish(f"fuzz case {case}")
     assert int(Bg.fault_counts[:10].sum()) == 0
 
 
@@ -248,18 +290,16 @@ def test_push_teleport_and_rigid_rerandomisation_match_oracle():
         if bool(pushed.any()):
             assert float(B.root_states[7:9][:, pushed].abs().max()) <= S.max_push_vel_xy + 1e-6
         seen["rigid"] += int(((B.payloads != keep["m"]) & live).sum())
-    worst, mean, resets, resamples, _ = run_full_step_comparison("dr", 256, 60, seed=17, prepare=prepare, watch=watch)
+    run_full_step_comparison("dr", 256, 60, seed=17, prepare=prepare, watch=watch, what="callbacks")
     assert seen["teleport"] > 10 and seen["push"] > 50 and seen["rigid"] > 50, seen
-    assert worst <= 0.03, worst
 
 
 def test_thousand_steps_match_oracle():
     """1000 consecutive policy steps (4000 physics substeps, a full episode length: time-outs, gravity
     impulses, DR refreshes, curriculum updates and command resampling all occur) of the HIP kernel against the oracle
     on identical streams, per-step tolerances of test_full_step_matches_oracle."""
-    worst, mean, resets, resamples, timeouts = run_full_step_comparison("train_noise", 128, 1000, seed=5)
+    att, resets, resamples, timeouts = run_full_step_comparison("train_noise", 128, 1000, seed=5, what="episode")
     assert resets > 100 and resamples > 100 and timeouts > 0, (resets, resamples, timeouts)
-    assert mean <= 0.01 and worst <= 0.05, (mean, worst)
 
 
 
@@ -331,15 +371,17 @@ def scatter_on_field(S, B, g, hs, hscale, vscale, clearance):
     B.root_states[2] = ground + clearance
 
 
+@pytest.mark.parametrize("walls", [False, True])
 @pytest.mark.parametrize("scenario", ["standing", "tumbling"])
-def test_physics_substep_on_height_field(scenario):
-    """Same comparison as above on a rough int16 height field (BASELINE config 3): bilinear height + tilted contact
-    frames + world-impulse warm start."""
+def test_physics_substep_on_height_field(scenario, walls):
+    """Same comparison as above on a rough int16 height field with a staircase strip (BASELINE config 3): bilinear height +
+    tilted contact frames + world-impulse warm start; walls: the same field as a `trimesh` terrain (slope_treshold 0.75): the
+    0.1 m risers of the strip are vertical faces with horizontal contact normals (the kernel's WALLS instance)."""
     N = 256
     cfg, S, meta, Bc, orc = gpu_pair("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
     hs, hscale, vscale = rough_field()
-    H.bind_height_field(S, Bc, hs, hscale, vscale, 0.0)
-    assert S.terrain_type == 1
+    H.bind_height_field(S, Bc, hs, hscale, vscale, 0.0, slope_threshold=0.75 if walls else None)
+    assert S.terrain_type == 1 and (S.hf_wall_threshold > 0) == walls
     g = torch.Generator().manual_seed(4)
     if scenario == "standing":
         standing_state(S, Bc, z=0.28)
@@ -351,31 +393,34 @@ def test_physics_substep_on_height_field(scenario):
         Bc.root_states[2] += torch.empty(N).uniform_(0.08, 0.35, generator=g)
         Bc.root_states[7:13].uniform_(-2, 2, generator=g)
         Bc.dof_vel.uniform_(-5, 5, generator=g)
+    if walls:
+        Bc.root_states[1, ::2].uniform_(10.2, 13.8, generator=g)       # half of the robots over the staircase strip
     Bc.torques.uniform_(-20, 20, generator=g)
     orc = __import__("pyoracle").Oracle(S, Bc)
     Bg, sim = to_gpu(S, Bc)
-    worst = 0.0
+    att = Attribution(N)
+    wall_contacts = 0
     for it in range(8):
         orc.physics_substep()
         sim.physics_substep()
         torch.cuda.synchronize()
         assert torch.isfinite(Bg.root_states).all() and torch.isfinite(Bg.dof_vel).all()
-        bad_env = torch.zeros(N, dtype=torch.bool)
-        for k, tol in (("root_states", 2e-4), ("dof_pos", 2e-4), ("dof_vel", 3e-3)):
-            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], tol, 1e-4)
-            bad_env |= bad.any(0)
-        bad, _ = frac_bad(Bg.contact_forces, Bc.contact_forces, 5e-2, 2e-3)
-        bad_env |= bad.any(0)
-        worst = max(worst, float(bad_env.float().mean()))
+        ratio = torch.zeros(N, dtype=torch.float64)
+        for k, tol, rt in (("root_states", 2e-4, 1e-4), ("dof_pos", 2e-4, 1e-4), ("dof_vel", 3e-3, 1e-4), ("contact_forces", 5e-2, 2e-3)):
+            ratio = torch.maximum(ratio, att.ratio(Bg.tensors[k], Bc.tensors[k], tol, rt))
+        att.step(ratio, Bg, Bc)
+        wall_contacts += int((Bc.contact_signature[1] & 0x1FFF != 0).sum())
         sync_from(Bc, Bg, sim, orc)
-    assert worst <= 0.02, worst
+    att.finish(f"height-field substep[{scenario}, walls={walls}]")
     cf = Bc.contact_forces.view(17, 3, N)
     assert float(cf[:, 2].abs().max()) > 1.0 and float(cf[:, :2].abs().max()) > 0.5       # tilted normals / friction at work
+    assert wall_contacts == 0 if not walls else (wall_contacts > 0 or scenario == "standing"), wall_contacts       # the vertical faces were hit
 
 
-def test_full_step_on_height_field():
+@pytest.mark.parametrize("walls", [False, True])
+def test_full_step_on_height_field(walls):
     """40 full steps with the 187-point height scan in the observation, resets onto the field and the
-    height-relative termination test (legged_robot.py:160-178, 1793-1806)."""
+    height-relative termination test (legged_robot.py:160-178, 1793-1806); walls: as a `trimesh` terrain (vertical risers)."""
     N = 256
     pts_x = [round(-0.8 + 0.1 * i, 1) for i in range(17)]
     pts_y = [round(-0.5 + 0.1 * i, 1) for i in range(11)]
@@ -385,8 +430,9 @@ def test_full_step_on_height_field():
     import pyoracle
     cfg, S, meta, Bc = make_sim("train_noise", N, seed=13, extra=ex)
     hs, hscale, vscale = rough_field(seed=2)
-    H.bind_height_field(S, Bc, hs, hscale, vscale, 0.0)
+    H.bind_height_field(S, Bc, hs, hscale, vscale, 0.0, slope_threshold=0.75 if walls else None)
     randomize_dr(Bc, 13)
+    Bc.enable_contact_signature()
     Bc.env_origins[0].uniform_(4.0, 19.0, generator=torch.Generator().manual_seed(1))
     Bc.env_origins[1].uniform_(4.0, 19.0, generator=torch.Generator().manual_seed(2))
     ix = (Bc.env_origins[0] / hscale).long()
@@ -397,26 +443,22 @@ def test_full_step_on_height_field():
     Bg, sim = to_gpu(S, Bc)
     sync_from(Bc, Bg, sim, orc)
     rng = np.random.default_rng(0)
-    worst, resets = 0.0, 0
+    resets = 0
+    att = Attribution(N)
     for step in range(40):
         a = (rng.standard_normal((N, 12)) * (1.0 if step % 2 else 0.3)).astype(np.float32)
         orc.step(a)
         sim.step(torch.from_numpy(a).cuda())
         torch.cuda.synchronize()
         cpu_reset = Bc.reset_buf.bool()
-        bad_env = (Bg.reset_buf.cpu().bool() != cpu_reset)
-        for k, tol, rt in (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
-                           ("torques", 5e-3, 1e-3), ("foot_positions", 1e-3, 0), ("measured_heights", 1e-3, 0)):
-            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], tol, rt)
-            bad_env |= bad.reshape(-1, N).any(0)
-        bad, _ = frac_bad(Bg.obs_buf, Bc.obs_buf, 5e-3, 1e-3)
-        bad_env |= bad.any(1)
-        worst = max(worst, float(bad_env.float().mean()))
+        keys = (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
+                ("torques", 5e-3, 1e-3), ("foot_positions", 1e-3, 0), ("measured_heights", 1e-3, 0))
+        att.step(step_ratio(att, Bg, Bc, keys, (("obs_buf", 5e-3, 1e-3),)), Bg, Bc, extra_bad=(Bg.reset_buf.cpu().bool() != cpu_reset))
         resets += int(cpu_reset.sum())
         sync_from(Bc, Bg, sim, orc)
+    att.finish(f"height-field full step (walls={walls})")
     assert Bc.obs_buf.shape[1] == 257 and float(Bc.obs_buf[:, 70:].abs().max()) > 0.1
     assert resets > 5
-    assert worst <= 0.03, worst
 
 
 def test_determinism_and_shard_independence():

@@ -712,7 +712,7 @@ DEV int leg_pair_index(int lo, int hi) { return lo == 0 ? hi - 1 : lo == 1 ? hi 
 
 // acth != nullptr: the torques of this substep are being evaluated by the helper wavefronts (torque_publish was called, the
 // workgroup barrier behind it passed): they are picked up right before ABA pass 2.
-// nw > 1: helper wavefronts run emit_terrain_contacts() between the two workgroup barriers of the emission hand-over.
+// The helper wavefronts (nw > 1, always) run emit_terrain_contacts() between the two workgroup barriers of the emission hand-over.
 template <bool WALLS>
 DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int nw, Base& s, Leg& L, V3 grav,
                          bool use_warm, float h, uint32_t& fault, const float* acth, int e, int N, int sub PROF_PARAM) {
@@ -1112,7 +1112,6 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
   }
   BLOCK_SYNC(nw);
   PROF(4);
-  if (nw == 1) emit_terrain_contacts(cfg, Z, el, leg, 4, h);
   // self-contacts (rare: skipped unless some environment of the wavefront lists one).  Pair pid at slot nF + rank(pid).  The
   // lane of body A (the lower-numbered leg; the leg of a trunk pair) owns the record; for a leg-leg pair the lane of body B
   // hands its side over through the pair's SB slots.

@@ -91,7 +91,8 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   const int N = cfg.num_envs;
   const int e = blockIdx.x * EPW + (lane >> 2);
   const bool full_wave = (int)(blockIdx.x + 1) * EPW <= N;      // the MFMA torque model needs all 64 lanes
-  const bool mfma_torque = full_wave && cfg.control_type == 1;
+  const bool substep_only = A.mode == 2;                         // piecewise entry point: ONE physics substep with the torques in the buffer
+  const bool mfma_torque = full_wave && cfg.control_type == 1 && !substep_only;
 #if defined(GO1_ABLATE_TORQUE) || defined(GO1_ABLATE_PHYSICS) || defined(GO1_NO_DEFERRED_TORQUE)
   const bool deferred = false;
 #else
@@ -101,11 +102,13 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   PROF_INIT
   __syncthreads();
   if (e >= N) return;
+  const int nsub = substep_only ? 1 : cfg.decimation;
   if (wv != 0) {           // helper wavefront: the same sequence of workgroup barriers as the master's substep loop
 #pragma unroll 1
-    for (int sub = 0; sub < cfg.decimation; sub++) {
+    for (int sub = 0; sub < nsub; sub++) {
 #ifndef GO1_ABLATE_TORQUE
-      if (deferred) {
+      if (substep_only) {
+      } else if (deferred) {
         BLOCK_SYNC(nw);                                   // the master's input rows are in LDS
         actuator_tiles(act_lds, Z.act_io(), lane, wv - 1, nw - 1);
         BLOCK_SYNC(nw);                                   // (the master arrives here when it needs the torques)
@@ -131,10 +134,10 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) {
     const int j = 3 * leg + jj;
-    act_in[jj] = A.actions[(size_t)e * 12 + j];
+    act_in[jj] = substep_only ? 0.f : A.actions[(size_t)e * 12 + j];
     fv_in[jj] = AT(B.foot_velocities, j, e);
   }
-  const bool warm = cfg.warm_start && B.episode_length_buf[e] > 0;
+  const bool warm = substep_only ? cfg.warm_start != 0 : (cfg.warm_start && B.episode_length_buf[e] > 0);
   load_lambda(cfg, B, lds, lane, e, N, !warm);
   LDS_PHASE();           // the trunk's warm-start impulse is read by all four lanes of the environment
   const V3 grav = gravity_at(cfg, A.counter);
@@ -142,11 +145,16 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) act_clipped[jj] = fminf(fmaxf(act_in[jj], -cfg.clip_actions), cfg.clip_actions);
   if (deferred) torque_stash_load(cfg, B, acth, lane, leg, e, N, A.lag_head, act_clipped);
+  if (substep_only) {
 #pragma unroll
-  for (int jj = 0; jj < 3; jj++) {
-    const int j = 3 * leg + jj;
-    AT(B.actions, j, e) = act_clipped[jj];
-    AT(B.prev_foot_velocities, j, e) = fv_in[jj];
+    for (int jj = 0; jj < 3; jj++) L.tau[jj] = AT(B.torques, 3 * leg + jj, e);
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      AT(B.actions, j, e) = act_clipped[jj];
+      AT(B.prev_foot_velocities, j, e) = fv_in[jj];
+    }
   }
   {
     float a = 0.f;
@@ -162,12 +170,13 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   int head = A.lag_head;
   PROF(0);
 #pragma unroll 1
-  for (int sub = 0; sub < cfg.decimation; sub++) {
+  for (int sub = 0; sub < nsub; sub++) {
 #ifndef GO1_ABLATE_TORQUE
-    if (deferred) {
+    if (substep_only) {
+    } else if (deferred) {
       torque_publish(L, acth, Z.act_io(), lane, sub);
       BLOCK_SYNC(nw);
-    } else compute_torques(cfg, B, L, leg, e, N, head, act_lds, Z.act_io(), full_wave, nw, fault);
+    } else compute_torques(cfg, B, L, leg, e, N, head, act_lds, Z.act_io(), mfma_torque, nw, fault);
 #endif
     PROF(1);
     head = (head + 1) % nl;
@@ -183,7 +192,8 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   LDS_PHASE();
   PROF(7);
 #ifndef GO1_ABLATE_POST
-  post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, grav, A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs PROF_PASS);
+  if (!substep_only)
+    post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, grav, A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs PROF_PASS);
 #endif
   report_fault(B, e, fault);
   PROF_FLUSH;
@@ -196,16 +206,14 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
 extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(const StepArgs A) { STEP_LDS step_body<false>(A, lds, ldsx, act_lds, acth); }
 extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel_walls(const StepArgs A) { STEP_LDS step_body<true>(A, lds, ldsx, act_lds, acth); }
 
-// piecewise entry points with the 4-lane mapping (parity tests): torques only / one physics substep / tensor maps only
+// piecewise entry points with the 4-lane mapping (parity tests): torques only / tensor maps only (a single physics substep is
+// mode 2 of the step kernels: the production structure, master + helper wavefronts)
 extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs A) {
   __shared__ float lds[L_END * EPW];
-  __shared__ __attribute__((aligned(16))) lf4 ldsx[X_END];
+  __shared__ __attribute__((aligned(16))) float act_io[A_IO_END];
   __shared__ __attribute__((aligned(16))) float act_lds[A_END];
   for (int i = threadIdx.x; i < L_END * EPW; i += WAVE) lds[i] = 0.f;
-  for (int i = threadIdx.x; i < X_END; i += WAVE) ldsx[i] = (lf4){0.f, 0.f, 0.f, 0.f};
   LDS_PHASE();
-  SolverLds Z;
-  Z.lds = lds; Z.x = ldsx;
   const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
   CfgRef cfg = WAVE_CFG(csc, (int)blockIdx.x * EPW);
   BufRef B = csc->buf;
@@ -229,25 +237,10 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   if (A.mode == 1) {       // torques only (actions given as SoA)
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) AT(B.actions, 3 * leg + jj, e) = AT(A.actions, 3 * leg + jj, e);
-    compute_torques(cfg, B, L, leg, e, N, A.lag_head, act_lds, Z.act_io(), full_wave, 1, fault);
+    compute_torques(cfg, B, L, leg, e, N, A.lag_head, act_lds, act_io, full_wave, 1, fault);
     report_fault(B, e, fault);
     return;
   }
-  // mode 2: one physics substep with the torques in the buffer
-  const V3 grav = gravity_at(cfg, A.counter);
-#pragma unroll
-  for (int jj = 0; jj < 3; jj++) L.tau[jj] = AT(B.torques, 3 * leg + jj, e);
-  load_lambda(cfg, B, lds, lane, e, N, false);
-  LDS_PHASE();
-  PROF_DECL
-  if (cfg.terrain_type != 0 && cfg.hf_wall_threshold > 0.f)
-    physics_substep<true>(cfg, B, Z, lane, 1, s, L, grav, cfg.warm_start != 0, cfg.sim_dt, fault, nullptr, e, N, 0 PROF_PASS);
-  else
-    physics_substep<false>(cfg, B, Z, lane, 1, s, L, grav, cfg.warm_start != 0, cfg.sim_dt, fault, nullptr, e, N, 0 PROF_PASS);
-  store_state(B, leg, e, N, s, L);
-  foot_state(s, L, leg, B, e, N);
-  store_forces(cfg, B, lds, lane, e, N);
-  report_fault(B, e, fault);
 }
 
 // one environment per lane: reset_idx
@@ -431,10 +424,10 @@ static int launch(Go1Sim* s, int mode, const float* actions, const int32_t* ids,
   A.history_slot = s->history_slot; A.mode = mode; A.ids = ids; A.n_ids = n_ids;
   const int n = (mode == 3) ? n_ids : s->cfg.num_envs;
   const int per_block = (mode == 3) ? WAVE : EPW;
-  dim3 grid((n + per_block - 1) / per_block), block(mode == 0 ? WAVE * STEP_WAVES : WAVE);
+  dim3 grid((n + per_block - 1) / per_block), block((mode == 0 || mode == 2) ? WAVE * STEP_WAVES : WAVE);
   const int slot = timed ? (int)(s->timing_n % s->timing_cap) : 0;
   if (timed) (void)hipEventRecord(s->ev[2 * slot], st);
-  if (mode == 0) {
+  if (mode == 0 || mode == 2) {
     if (s->cfg.terrain_type != 0 && s->cfg.hf_wall_threshold > 0.f) hipLaunchKernelGGL(go1_step_kernel_walls, grid, block, 0, st, A);
     else hipLaunchKernelGGL(go1_step_kernel, grid, block, 0, st, A);
   }
