@@ -53,7 +53,8 @@ enum Go1ContactClass {
   GO1_CC_WALL = 7,        /* trunk / calf / thigh against a vertical terrain face */
   GO1_CC_COUNT = 8
 };
-#define GO1_SIG_WORDS 3          /* per substep: [top-surface points | wall points | self pairs + legs with limit rows] */
+#define GO1_SIG_WORDS 4          /* per substep: [top-surface points | wall points | self pairs + legs with limit rows | geometry hash:
+                                    the height-field cell and the candidate point (corner / end) every listed terrain contact came from] */
 #define GO1_SIG_MAX_SUBSTEPS 4
 
 /* canonical reward ids: one per `_reward_*` in go1_gym/envs/rewards/corl_rewards.py:15-202 */
@@ -164,8 +165,9 @@ typedef struct Go1SimConfig {
   int32_t terrain_type;            /* 0 plane, 1 height field */
   int32_t hf_rows, hf_cols;        /* height_samples shape */
   float hf_hscale, hf_vscale, hf_border;
-  float hf_wall_threshold;         /* m; > 0: a cell edge rising by more than this is a vertical face (the `trimesh` terrain's
-                                      slope_treshold * horizontal_scale, terrain.py:33-36); 0: plain bilinear height field */
+  int32_t hf_wall_units;           /* > 0: two neighbouring height samples differing by MORE than this many units are the ends of a
+                                      vertical face — the `trimesh` terrain's slope_treshold * horizontal_scale / vertical_scale
+                                      (terrain.py:33-36), compared on the int16 samples as the reference does; 0: plain bilinear field */
   /* height scan: legged_robot.py:1756-1806 (_init_height_points, _get_heights) */
   int32_t measure_heights;         /* Cfg.terrain.measure_heights */
   int32_t num_height_x, num_height_y;

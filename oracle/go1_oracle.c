@@ -290,12 +290,13 @@ static void chol_solve(const real* L, int n, real* b) {
 
 /* ------------------------------------------------------------------ terrain */
 typedef struct { const Go1SimConfig* cfg; const int16_t* hs; } Terrain;
-typedef struct { int on; real n[3]; real d; real top; } Wall;   /* vertical face: unit horizontal normal (towards the low side),
+typedef struct { int on; real n[3]; real d; real top; } Wall;
+static __thread int g_last_cell;      /* height-field cell of the last terrain_sample() call (contact signature) */   /* vertical face: unit horizontal normal (towards the low side),
                                                                     horizontal distance of the sample point, height of its upper edge */
 /* Height and unit normal of the terrain's TOP surface at world (x, y), and the vertical face next to the point (if any).
  * Height field: bilinear interpolation of the int16 samples (same sample convention as _get_heights,
  * legged_robot.py:1793-1806: index = (x + border) / hscale).
- * Vertical faces (hf_wall_threshold T > 0; the `trimesh` terrain's slope_treshold, terrain.py:33-36, legged_robot_config.py:91:
+ * Vertical faces (hf_wall_units T > 0; the `trimesh` terrain's slope_treshold, terrain.py:33-36, legged_robot_config.py:91:
  * where two neighbouring samples differ by more than the threshold the reference's mesh moves the LOWER vertex under the upper
  * one, so the low ground runs on flat to a vertical riser).  Restated on the height field per cell: an edge of the cell whose
  * end heights differ by more than T is "steep"; the cell's corner heights are lowered along steep edges to the lower end (two
@@ -306,6 +307,7 @@ typedef struct { int on; real n[3]; real d; real top; } Wall;   /* vertical face
 static void terrain_sample(const Terrain* t, real x, real y, real* h, real* n, Wall* wall) {
   const Go1SimConfig* c = t->cfg;
   if (wall) wall->on = 0;
+  g_last_cell = 0;
   if (c->terrain_type == 0 || !t->hs) { *h = 0; v3set(n, 0, 0, 1); return; }
   real fx = (x + c->hf_border) / c->hf_hscale, fy = (y + c->hf_border) / c->hf_hscale;
   if (fx < 0) fx = 0; if (fy < 0) fy = 0;
@@ -313,23 +315,24 @@ static void terrain_sample(const Terrain* t, real x, real y, real* h, real* n, W
   if (fy > c->hf_cols - (real)1.000001) fy = c->hf_cols - (real)1.000001;
   int ix = (int)fx, iy = (int)fy;
   real ax = fx - ix, ay = fy - iy;
-  real h00 = t->hs[ix * c->hf_cols + iy] * (real)c->hf_vscale, h10 = t->hs[(ix + 1) * c->hf_cols + iy] * (real)c->hf_vscale;
-  real h01 = t->hs[ix * c->hf_cols + iy + 1] * (real)c->hf_vscale, h11 = t->hs[(ix + 1) * c->hf_cols + iy + 1] * (real)c->hf_vscale;
-  const real T = (real)c->hf_wall_threshold;
+  g_last_cell = ix * c->hf_cols + iy;
+  const int p00 = t->hs[ix * c->hf_cols + iy], p10 = t->hs[(ix + 1) * c->hf_cols + iy], p01 = t->hs[ix * c->hf_cols + iy + 1], p11 = t->hs[(ix + 1) * c->hf_cols + iy + 1];
+  real h00 = p00 * (real)c->hf_vscale, h10 = p10 * (real)c->hf_vscale, h01 = p01 * (real)c->hf_vscale, h11 = p11 * (real)c->hf_vscale;
+  const int T = c->hf_wall_units;
   if (T > 0) {
-    const real dx0 = h10 - h00, dx1 = h11 - h01, dy0 = h01 - h00, dy1 = h11 - h10;
-    const int sx0 = fabs(dx0) > T, sx1 = fabs(dx1) > T, sy0 = fabs(dy0) > T, sy1 = fabs(dy1) > T;
+    const int dx0 = p10 - p00, dx1 = p11 - p01, dy0 = p01 - p00, dy1 = p11 - p10;          /* steepness is decided on the integer samples */
+    const int sx0 = abs(dx0) > T, sx1 = abs(dx1) > T, sy0 = abs(dy0) > T, sy1 = abs(dy1) > T;
     if (sx0 || sx1 || sy0 || sy1) {
       if (wall) {
         real best = 1e30;
-        if (sx0 && sx1 && dx0 * dx1 > 0) {
+        if (sx0 && sx1 && (dx0 > 0) == (dx1 > 0)) {
           const int up = dx0 > 0;
           wall->on = 1; v3set(wall->n, up ? -1 : 1, 0, 0);
           wall->d = (up ? (1 - ax) : ax) * (real)c->hf_hscale;
           wall->top = up ? h10 * (1 - ay) + h11 * ay : h00 * (1 - ay) + h01 * ay;
           best = wall->d;
         }
-        if (sy0 && sy1 && dy0 * dy1 > 0) {
+        if (sy0 && sy1 && (dy0 > 0) == (dy1 > 0)) {
           const int up = dy0 > 0;
           const real d = (up ? (1 - ay) : ay) * (real)c->hf_hscale;
           if (d < best) {
@@ -363,7 +366,7 @@ static void terrain_sample(const Terrain* t, real x, real y, real* h, real* n, W
  *              points (capsule end spheres, box corners) are split into the two ends of the shape's long axis, the deeper end's
  *              deepest point is the first contact, the other end's deepest point the second;
  *   foot spheres: one.
- * Terrain, vertical faces (hf_wall_threshold > 0): one point per foot, calf, thigh and one for the trunk — the candidate point
+ * Terrain, vertical faces (hf_wall_units > 0): one point per foot, calf, thigh and one for the trunk — the candidate point
  * below the face's upper edge with the smallest horizontal separation from it; normal horizontal.
  * Self-collision (asset self_collisions = 0: nothing filtered, go1_config.py:44, legged_robot.py:1563-1564): capsules —
  * lower leg (knee -> foot centre, radius of the foot sphere), thigh (thigh joint -> knee, GO1_SELF_THIGH_RADIUS), trunk (the
@@ -373,7 +376,7 @@ static void terrain_sample(const Terrain* t, real x, real y, real* h, real* n, W
  * Solver list: at most GO1_MAX_CONTACTS, in the priority order feet, foot walls, self-contacts (at most GO1_MAX_SELF_LEG_PAIRS
  * leg-leg), trunk, trunk wall, calves (first points, walls, second points), thighs (same), hips; what does not fit is dropped
  * and counted per class. */
-typedef struct { real phi, x[3], n[3]; int valid; } Cand;
+typedef struct { real phi, x[3], n[3]; int valid; uint32_t tag; } Cand;   /* tag: 16 * height-field cell + candidate point index */
 typedef struct {
   int repA, repB;   /* reported bodies (0..16) the force is booked on; repB = -1: terrain */
   int dynA, dynB;   /* dynamic bodies (0..12) carrying the point; dynB = -1: terrain */
@@ -386,7 +389,7 @@ typedef struct {
 } Contact;
 
 /* candidate point `local` of dynamic body dynb: top-surface candidate into *best, wall candidate into *bestw (may be NULL) */
-static void candidate(const Terrain* ter, const Kin* k, const real* base_pos, int dynb, const real* local, real radius, Cand* best, Cand* bestw) {
+static void candidate(const Terrain* ter, const Kin* k, const real* base_pos, int dynb, const real* local, real radius, Cand* best, Cand* bestw, int m) {
   real w[3], x[3];
   m3v(w, k->R[dynb], local);
   v3add(x, k->p[dynb], w);
@@ -396,6 +399,7 @@ static void candidate(const Terrain* ter, const Kin* k, const real* base_pos, in
   real phi = (base_pos[2] + x[2]) - radius - h;
   if (!best->valid || phi < best->phi) {
     best->valid = 1;
+    best->tag = 16u * (uint32_t)g_last_cell + (uint32_t)m;
     best->phi = phi;
     for (int i = 0; i < 3; i++) best->x[i] = x[i] - radius * n[i];
     v3cpy(best->n, n);
@@ -404,6 +408,7 @@ static void candidate(const Terrain* ter, const Kin* k, const real* base_pos, in
     real phiw = wl.d - radius;
     if (!bestw->valid || phiw < bestw->phi) {
       bestw->valid = 1;
+      bestw->tag = 16u * (uint32_t)g_last_cell + (uint32_t)m;
       bestw->phi = phiw;
       for (int i = 0; i < 3; i++) bestw->x[i] = x[i] - radius * wl.n[i];
       v3cpy(bestw->n, wl.n);
@@ -459,8 +464,11 @@ static void add_contact(Contact* list, ContactList* L, const Contact* c, int sig
   L->n++;
   L->sig[sigw] |= 1u << sigb;
 }
-static void add_terrain(Contact* list, ContactList* L, real cd, const Cand* c, int rep, int dyn, int cls, int top, int sigw, int sigb) {
+/* item: the kernel's item index of the point (go1_physics.h IT_*): its weight in the geometry hash */
+enum { IT_FOOT = 0, IT_FOOTW, IT_CALF1, IT_CALFW, IT_CALF2, IT_THIGH1, IT_THIGHW, IT_THIGH2, IT_HIP1, IT_HIP2, IT_TR0, IT_TR1, IT_TRW };
+static void add_terrain(Contact* list, ContactList* L, real cd, const Cand* c, int rep, int dyn, int cls, int top, int sigw, int sigb, int item) {
   if (!c->valid || !(c->phi < cd)) return;
+  if (L->n < GO1_MAX_CONTACTS) L->sig[3] += c->tag * (uint32_t)(2 * item + 1) * 2654435761u;
   Contact t;
   t.repA = rep; t.repB = -1; t.dynA = dyn; t.dynB = -1; t.phi = c->phi; t.share = 1; t.cls = cls; t.top = top;
   v3cpy(t.x, c->x); v3cpy(t.n, c->n);
@@ -470,39 +478,39 @@ static void add_terrain(Contact* list, ContactList* L, real cd, const Cand* c, i
 /* fills `list`, returns the bookkeeping (count, drops per class, signature words 0..2 without the limit-row bits) */
 static ContactList detect_contacts(const Go1SimConfig* cfg, const Terrain* ter, const Kin* k, const real* base_pos, Contact* list) {
   const real cd = cfg->contact_distance;
-  const int walls = cfg->terrain_type != 0 && ter->hs && cfg->hf_wall_threshold > 0;
+  const int walls = cfg->terrain_type != 0 && ter->hs && cfg->hf_wall_units > 0;
   Cand trunk[8], hip[4][2], thigh[4][2], calf[4][2], foot[4], trunkw, thighw[4], calfw[4], footw[4];
   memset(trunk, 0, sizeof trunk); memset(hip, 0, sizeof hip); memset(thigh, 0, sizeof thigh); memset(calf, 0, sizeof calf); memset(foot, 0, sizeof foot);
   memset(&trunkw, 0, sizeof trunkw); memset(thighw, 0, sizeof thighw); memset(calfw, 0, sizeof calfw); memset(footw, 0, sizeof footw);
   for (int m = 0; m < 8; m++) {       /* trunk box corners */
     real l[3] = {(m & 1 ? 1 : -1) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1 : -1) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1 : -1) * GO1_TRUNK_BOX_HALF[2]};
-    candidate(ter, k, base_pos, 0, l, 0, &trunk[m], walls ? &trunkw : NULL);
+    candidate(ter, k, base_pos, 0, l, 0, &trunk[m], walls ? &trunkw : NULL, m);
   }
   for (int leg = 0; leg < 4; leg++) {
     int hipb = 1 + 3 * leg;
     for (int m = 0; m < 2; m++) {
       real l[3] = {GO1_HIP_CAPSULE_CENTER[leg][0], GO1_HIP_CAPSULE_CENTER[leg][1] + (m ? 1 : -1) * GO1_HIP_CAPSULE_HALF, GO1_HIP_CAPSULE_CENTER[leg][2]};
-      candidate(ter, k, base_pos, hipb, l, GO1_HIP_CAPSULE_RADIUS, &hip[leg][m], NULL);
+      candidate(ter, k, base_pos, hipb, l, GO1_HIP_CAPSULE_RADIUS, &hip[leg][m], NULL, m);
     }
     for (int m = 0; m < 8; m++) {     /* thigh / calf boxes: long axis z -> ends by the sign of z */
       real l[3] = {GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1 : -1) * GO1_THIGH_BOX_HALF[0],
                    GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1 : -1) * GO1_THIGH_BOX_HALF[1],
                    GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1 : -1) * GO1_THIGH_BOX_HALF[2]};
-      candidate(ter, k, base_pos, hipb + 1, l, 0, &thigh[leg][(m >> 2) & 1], walls ? &thighw[leg] : NULL);
+      candidate(ter, k, base_pos, hipb + 1, l, 0, &thigh[leg][(m >> 2) & 1], walls ? &thighw[leg] : NULL, m);
     }
     for (int m = 0; m < 8; m++) {
       real l[3] = {GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1 : -1) * GO1_CALF_BOX_HALF[0],
                    GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1 : -1) * GO1_CALF_BOX_HALF[1],
                    GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1 : -1) * GO1_CALF_BOX_HALF[2]};
-      candidate(ter, k, base_pos, hipb + 2, l, 0, &calf[leg][(m >> 2) & 1], walls ? &calfw[leg] : NULL);
+      candidate(ter, k, base_pos, hipb + 2, l, 0, &calf[leg][(m >> 2) & 1], walls ? &calfw[leg] : NULL, m);
     }
     real fo[3] = {GO1_FOOT_OFFSET[leg][0], GO1_FOOT_OFFSET[leg][1], GO1_FOOT_OFFSET[leg][2]};
-    candidate(ter, k, base_pos, hipb + 2, fo, GO1_FOOT_RADIUS, &foot[leg], walls ? &footw[leg] : NULL);
+    candidate(ter, k, base_pos, hipb + 2, fo, GO1_FOOT_RADIUS, &foot[leg], walls ? &footw[leg] : NULL, 0);
   }
   ContactList L;
   memset(&L, 0, sizeof L);
-  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &foot[leg], 4 + 4 * leg, 3 * leg + 3, GO1_CC_FOOT, 1, 0, leg);
-  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &footw[leg], 4 + 4 * leg, 3 * leg + 3, GO1_CC_FOOT_WALL, 0, 1, leg);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &foot[leg], 4 + 4 * leg, 3 * leg + 3, GO1_CC_FOOT, 1, 0, leg, IT_FOOT);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &footw[leg], 4 + 4 * leg, 3 * leg + 3, GO1_CC_FOOT_WALL, 0, 1, leg, IT_FOOTW);
   /* self-collision: segments of the lower legs [0] and thighs [1], trunk axis */
   real P[4][2][3], Q[4][2][3], TA[3], TB[3];
   for (int leg = 0; leg < 4; leg++) {
@@ -549,19 +557,19 @@ static ContactList detect_contacts(const Go1SimConfig* cfg, const Terrain* ter, 
       if (!(trunk[m].valid && trunk[m].phi < cd)) continue;
       if (listed >= GO1_MAX_TRUNK_POINTS) { L.dropped[GO1_CC_TRUNK]++; L.sig[1] |= 1u << 31; continue; }
       listed++;
-      add_terrain(list, &L, cd, &trunk[m], 0, 0, GO1_CC_TRUNK, 1, 0, 4 + m);
+      add_terrain(list, &L, cd, &trunk[m], 0, 0, GO1_CC_TRUNK, 1, 0, 4 + m, IT_TR0 + (m & 1));
     }
   }
-  add_terrain(list, &L, cd, &trunkw, 0, 0, GO1_CC_WALL, 0, 1, 4);
-  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &calf[leg][FIRST(calf[leg])], 3 + 4 * leg, 3 * leg + 3, GO1_CC_CALF, 1, 0, 12 + 2 * leg + FIRST(calf[leg]));
-  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &calfw[leg], 3 + 4 * leg, 3 * leg + 3, GO1_CC_WALL, 0, 1, 5 + leg);
-  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &calf[leg][1 - FIRST(calf[leg])], 3 + 4 * leg, 3 * leg + 3, GO1_CC_CALF, 1, 0, 12 + 2 * leg + 1 - FIRST(calf[leg]));
-  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &thigh[leg][FIRST(thigh[leg])], 2 + 4 * leg, 3 * leg + 2, GO1_CC_THIGH, 1, 0, 20 + 2 * leg + FIRST(thigh[leg]));
-  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &thighw[leg], 2 + 4 * leg, 3 * leg + 2, GO1_CC_WALL, 0, 1, 9 + leg);
-  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &thigh[leg][1 - FIRST(thigh[leg])], 2 + 4 * leg, 3 * leg + 2, GO1_CC_THIGH, 1, 0, 20 + 2 * leg + 1 - FIRST(thigh[leg]));
+  add_terrain(list, &L, cd, &trunkw, 0, 0, GO1_CC_WALL, 0, 1, 4, IT_TRW);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &calf[leg][FIRST(calf[leg])], 3 + 4 * leg, 3 * leg + 3, GO1_CC_CALF, 1, 0, 12 + 2 * leg + FIRST(calf[leg]), IT_CALF1);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &calfw[leg], 3 + 4 * leg, 3 * leg + 3, GO1_CC_WALL, 0, 1, 5 + leg, IT_CALFW);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &calf[leg][1 - FIRST(calf[leg])], 3 + 4 * leg, 3 * leg + 3, GO1_CC_CALF, 1, 0, 12 + 2 * leg + 1 - FIRST(calf[leg]), IT_CALF2);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &thigh[leg][FIRST(thigh[leg])], 2 + 4 * leg, 3 * leg + 2, GO1_CC_THIGH, 1, 0, 20 + 2 * leg + FIRST(thigh[leg]), IT_THIGH1);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &thighw[leg], 2 + 4 * leg, 3 * leg + 2, GO1_CC_WALL, 0, 1, 9 + leg, IT_THIGHW);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &thigh[leg][1 - FIRST(thigh[leg])], 2 + 4 * leg, 3 * leg + 2, GO1_CC_THIGH, 1, 0, 20 + 2 * leg + 1 - FIRST(thigh[leg]), IT_THIGH2);
   /* (hip points: their signature bits sit in word 1 behind the wall bits) */
-  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &hip[leg][FIRST(hip[leg])], 1 + 4 * leg, 3 * leg + 1, GO1_CC_HIP, 1, 1, 13 + 2 * leg + FIRST(hip[leg]));
-  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &hip[leg][1 - FIRST(hip[leg])], 1 + 4 * leg, 3 * leg + 1, GO1_CC_HIP, 1, 1, 13 + 2 * leg + 1 - FIRST(hip[leg]));
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &hip[leg][FIRST(hip[leg])], 1 + 4 * leg, 3 * leg + 1, GO1_CC_HIP, 1, 1, 13 + 2 * leg + FIRST(hip[leg]), IT_HIP1);
+  for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &hip[leg][1 - FIRST(hip[leg])], 1 + 4 * leg, 3 * leg + 1, GO1_CC_HIP, 1, 1, 13 + 2 * leg + 1 - FIRST(hip[leg]), IT_HIP2);
 #undef FIRST
   /* warm start: a body's previous impulse is shared equally by its listed top-surface points; wall and body-body points
    * start from zero */

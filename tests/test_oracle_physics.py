@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 import torch
 
+import go1sim_host as H
 from util import make_sim, randomize_dr, standing_state
 
 HDR = os.path.join(os.path.dirname(__file__), "..", "walk-these-ways_amd", "csrc", "go1_model_data.h")
@@ -301,6 +302,23 @@ def _lower_leg_segments(md, root, q):
     return out
 
 
+def _thigh_segments(md, root, q):
+    """thigh-joint and knee positions (world) of the four legs"""
+    R0 = quat_R(root[3:7])
+    out = []
+    for leg in range(4):
+        R, p, pts = R0, root[0:3].copy(), []
+        for j in range(3):
+            ji = 3 * leg + j
+            p = p + R @ md["GO1_JOINT_ORIGIN"][ji]
+            pts.append(p.copy())
+            c, s_ = np.cos(q[ji]), np.sin(q[ji])
+            Rj = np.array([[1, 0, 0], [0, c, -s_], [0, s_, c]]) if md["GO1_JOINT_AXIS"][ji] == 0 else np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]])
+            R = R @ Rj
+        out.append((pts[1], pts[2]))
+    return out
+
+
 def _seg_dist(a0, a1, b0, b1, n=60):
     t = np.linspace(0, 1, n)
     A = a0[None] + t[:, None] * (a1 - a0)[None]
@@ -372,3 +390,142 @@ def test_self_collision_keeps_the_lower_legs_apart(oracle_lib):
     assert seen > 5.0, "the front legs never touched"
     assert min_d > 2 * 0.02 - 0.012, min_d                                         # capsule radius 0.02 each, contact_offset scale
     assert float(B.contact_forces.view(17, 3, N)[:, :, 1].abs().max()) == 0.0      # legs swung apart: no contact at all
+
+
+def test_limp_robot_comes_to_rest(oracle_lib):
+    """Robot at rest on many points: limp actuators, dropped on its feet (collapses onto belly and folded
+    legs), on its side, on its belly with the legs folded, on its back.  One second after the last bounce the base does not
+    move: |omega| < 0.02 rad/s, |v| < 0.01 m/s over 40 consecutive substeps — no period-2 chatter (round 2: +-0.2 rad/s with
+    two contact points per trunk end; the trunk now rests on the corners of the face it lies on), and no contact point was
+    ever left without a solver slot."""
+    N = 4
+    cfg, S, meta, B = make_sim("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
+    standing_state(S, B, 0.30)
+    B.root_states[2, 1] = 0.12; B.root_states[3, 1] = np.sin(np.pi / 4); B.root_states[6, 1] = np.cos(np.pi / 4)
+    B.root_states[2, 2] = 0.10; B.dof_pos[:, 2] = torch.tensor([0.0, 1.3, -2.6] * 4)
+    B.root_states[2, 3] = 0.15; B.root_states[3, 3] = 1.0; B.root_states[6, 3] = 0.0
+    orc = oracle_lib.Oracle(S, B)
+    B.torques.zero_()
+    B.contact_drop_counts.zero_()
+    for it in range(800):                      # 4 s: every pose has settled
+        orc.physics_substep()
+    wmax, vmax, cfs = torch.zeros(N), torch.zeros(N), torch.zeros(51, N)
+    for it in range(40):
+        orc.physics_substep()
+        wmax = torch.maximum(wmax, B.root_states[10:13].norm(dim=0))
+        vmax = torch.maximum(vmax, B.root_states[7:10].norm(dim=0))
+        cfs += B.contact_forces / 40
+    # belly / folded / back: at rest.  The side-lying robot is tangled (two leg-leg self-contacts, limit rows of two legs, 13
+    # terrain points): what remains there is a CONSTANT creep of the 4-sweep solve's friction residual (0.03 rad/s about the
+    # vertical, no alternation) — it vanishes with more sweeps (tools/solver_convergence.py, profiles/r03_solver_convergence.txt)
+    assert float(wmax[[0, 2, 3]].max()) < 0.02 and float(wmax[1]) < 0.05 and float(vmax.max()) < 0.01, (wmax, vmax)
+    assert float(B.dof_vel.abs().max()) < 0.1
+    np.testing.assert_allclose(cfs.view(17, 3, N)[:, 2].sum(0).numpy(), 11.309932 * 9.8, rtol=0.01)
+    assert int(B.contact_drop_counts.sum()) == 0
+
+
+def staircase_field(rows=200, cols=60, step_h=0.15, step_w=4, hscale=0.1, vscale=0.005, first=100):
+    """flat ground, then treads `step_w` cells deep rising `step_h` each (along +x)"""
+    h = np.zeros((rows, cols))
+    for i in range(first, rows):
+        h[i] = step_h * ((i - first) // step_w + 1)
+    return np.rint(h / vscale).astype(np.int16), hscale, vscale
+
+
+def _robot_before_the_step(walls, foot_gap, mu):
+    N = 2
+    cfg, S, meta, B = make_sim("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
+    hs, hscale, vscale = staircase_field()
+    H.bind_height_field(S, B, hs, hscale, vscale, 0.0, slope_threshold=0.75 if walls else None)
+    assert (S.hf_wall_units > 0) == walls
+    standing_state(S, B, z=0.31)
+    x_wall = 100 * hscale                      # the riser's plane (the row of the high vertices)
+    B.root_states[0] = x_wall - 0.1881 - foot_gap      # front feet `foot_gap` in front of the riser
+    B.root_states[1] = torch.tensor([2.0, 3.5])
+    B.friction_coeffs[:] = mu
+    S.terrain_friction = S.terrain_dynamic_friction = mu
+    return S, B, x_wall
+
+
+def test_foot_sliding_into_a_riser_is_blocked_not_lifted(oracle_lib):
+    """`trimesh` terrain with slope_treshold (terrain.py:33-36, legged_robot_config.py:91): the reference's mesh turns a face
+    steeper than the threshold into a VERTICAL wall.  A robot standing on frictionless ground in front of a 0.15 m step is given
+    a forward velocity: the front feet slide up to the riser and are stopped AT its plane by a horizontal contact force — they
+    neither cross it nor ride up — and the robot comes to a halt against it."""
+    S, B, x_wall = _robot_before_the_step(True, 0.10, 0.0)
+    orc = oracle_lib.Oracle(S, B)
+    sig = B.enable_contact_signature()
+    a = np.zeros((2, 12), np.float32)
+    for _ in range(25):                        # settle on the flat part
+        orc.step(a)
+        B.reset_buf.zero_()
+    z0 = B.foot_positions.view(4, 3, 2)[:2, 2].clone()
+    B.root_states[7] = 0.5
+    fx, x_max, z_max, wall_bits = [], -1e9, -1e9, 0
+    for _ in range(30):
+        orc.step(a)
+        B.reset_buf.zero_()
+        fp, cf = B.foot_positions.view(4, 3, 2), B.contact_forces.view(17, 3, 2)
+        fx.append(float(cf[[4, 8], 0].max()))
+        x_max = max(x_max, float(fp[:2, 0].max()))
+        z_max = max(z_max, float((fp[:2, 2] - z0).max()))
+        wall_bits |= int(sig[1, 0]) & 0xF
+    assert wall_bits & 0x3 == 0x3                              # foot-wall contacts of both front legs were listed
+    assert x_wall - 0.02 - 0.002 < x_max < x_wall - 0.02 + 0.002, x_max       # the foot spheres (r = 0.02) stop at the wall plane
+    assert z_max < 0.005, z_max                                 # ... on the ground
+    assert max(fx[10:]) < -1.0                                  # a steady horizontal force against the motion
+    assert float(B.root_states[7].abs().max()) < 0.1            # the robot has come to a halt
+
+
+@pytest.mark.parametrize("walls", [True, False])
+def test_foot_in_a_risers_cell_stands_on_the_ground_not_on_a_ramp(oracle_lib, walls):
+    """The cell in front of a riser: on the bilinear height field (walls off: mesh_type 'heightfield') it is a 56-degree ramp from
+    the lower to the upper tread — a foot put down there is pushed back out of it; with the vertical faces of the `trimesh` terrain
+    the cell belongs to the lower tread: the foot stands on the ground, 5 cm in front of the wall."""
+    S, B, x_wall = _robot_before_the_step(walls, 0.05, 1.0)
+    orc = oracle_lib.Oracle(S, B)
+    a = np.zeros((2, 12), np.float32)
+    orc.step(a)
+    x0 = B.foot_positions.view(4, 3, 2)[:2, 0].clone()
+    if walls:
+        assert float(x0.min()) > x_wall - 0.1 + 0.02 and float(x0.max()) < x_wall - 0.04       # put down inside the riser's cell
+    for _ in range(60):
+        orc.step(a)
+        B.reset_buf.zero_()
+    fp = B.foot_positions.view(4, 3, 2)
+    if walls:
+        assert float((fp[:2, 0] - x0).abs().max()) < 0.01                        # where it was put down, inside the riser's cell ...
+        assert float(fp[:2, 2].max()) < 0.02 + 0.003                              # ... foot sphere resting on the lower tread
+    else:
+        assert float(fp[:2, 0].max()) < x_wall - 0.1 + 0.005                      # the 56-degree ramp pushed the feet out of the cell
+
+
+def test_thigh_capsules_take_part_in_the_self_collision(oracle_lib):
+    """`self_collisions = 0` filters nothing (go1_config.py:44): besides the lower legs, the thighs of different legs collide
+    with each other and with the other legs' lower legs.  In free flight both front hips are rolled inwards with the legs
+    stretched, so that the two front legs cross like scissors at thigh height: thigh-thigh and thigh - lower-leg pairs are listed,
+    the body-body forces sum to zero, the thighs carry load, and the thigh capsules do not pass through each other."""
+    N = 1
+    cfg, S, meta, B = make_sim("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
+    S.gravity[0] = S.gravity[1] = S.gravity[2] = 0.0
+    standing_state(S, B, z=3.0)
+    B.dof_pos[:, 0] = torch.tensor([-0.3, 0.1, -0.95, 0.3, 0.1, -0.95, 0.1, 1.0, -1.5, -0.1, 1.0, -1.5])      # front legs stretched
+    sig = B.enable_contact_signature()
+    orc = oracle_lib.Oracle(S, B)
+    B.torques.zero_()
+    B.torques[0] = -6.0          # FL hip rolls inwards ...
+    B.torques[3] = 6.0           # ... FR hip too
+    md = model()
+    seen_pairs, fmax, min_d = 0, 0.0, 1e9
+    for it in range(200):
+        orc.physics_substep()
+        w2 = int(sig[2, 0]) & 0xFFFFFF
+        seen_pairs |= w2
+        cf = B.contact_forces.view(17, 3, N)[:, :, 0]
+        if w2 >> 6:                                                    # a pair with a thigh is listed
+            torch.testing.assert_close(cf.sum(0), torch.zeros(3), rtol=0, atol=1e-4)       # body-body forces cancel (nothing else touches)
+            fmax = max(fmax, float(cf[2].norm()), float(cf[6].norm()))
+        th = _thigh_segments(md, B.root_states[:, 0].double().numpy(), B.dof_pos[:, 0].double().numpy())
+        min_d = min(min_d, _seg_dist(*th[0], *th[1]))
+    assert seen_pairs >> 6, f"no pair with a thigh was ever listed (mask {seen_pairs:#x})"
+    assert fmax > 1.0 and min_d > 2 * 0.017 - 0.012, (fmax, min_d)

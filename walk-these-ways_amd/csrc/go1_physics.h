@@ -391,40 +391,43 @@ struct Base {             // replicated in the 4 lanes of the environment
 
 DEV V3 model_v3(const float (*tab)[3], int i) { return v3(tab[i][0], tab[i][1], tab[i][2]); }
 
-struct Cand { float phi, x, y, z, un, nx, ny, nz; };     // deepest contact candidate of one group of points
-DEV void cand_init(Cand& c) { c.phi = 1e30f; c.x = c.y = c.z = c.un = 0.f; c.nx = c.ny = 0.f; c.nz = 1.f; }
+struct Cand { float phi, x, y, z, un, nx, ny, nz; uint32_t tag; };     // deepest contact candidate of one group of points; tag (contact
+                                                                         // signature only): 16 x height-field cell + index of the winning point
+DEV void cand_init(Cand& c) { c.phi = 1e30f; c.x = c.y = c.z = c.un = 0.f; c.nx = c.ny = 0.f; c.nz = 1.f; c.tag = 0u; }
 
 // Terrain at world (x, y): height and unit normal of the TOP surface — plane, or bilinear interpolation of the int16 height
 // field (same sample convention as _get_heights, reference legged_robot.py:1793-1806) — and, with WALLS, the vertical face
 // next to the point: unit horizontal normal (towards the low side), horizontal distance, height of its upper edge
 // (oracle terrain_sample(): the `trimesh` terrain's slope_treshold restated per cell of the height field).
-struct Wall { bool on; V3 n; float d, top; };
+struct Wall { bool on; V3 n; float d, top; int cell; };
 template <bool WALLS>
 DEV void terrain_sample(CfgRef cfg, const int16_t* __restrict__ hs, float x, float y, float& h, V3& n, Wall& wall) {
-  wall.on = false; wall.n = v3(1.f, 0.f, 0.f); wall.d = 0.f; wall.top = 0.f;
+  wall.on = false; wall.n = v3(1.f, 0.f, 0.f); wall.d = 0.f; wall.top = 0.f; wall.cell = 0;
   if (cfg.terrain_type == 0 || hs == nullptr) { h = 0.f; n = v3(0.f, 0.f, 1.f); return; }
   float fx = (x + cfg.hf_border) / cfg.hf_hscale, fy = (y + cfg.hf_border) / cfg.hf_hscale;
   fx = fminf(fmaxf(fx, 0.f), (float)cfg.hf_rows - 1.000001f);
   fy = fminf(fmaxf(fy, 0.f), (float)cfg.hf_cols - 1.000001f);
   const int ix = (int)fx, iy = (int)fy;
   const float ax = fx - ix, ay = fy - iy;
+  wall.cell = ix * cfg.hf_cols + iy;
   const int16_t* p = hs + (size_t)ix * cfg.hf_cols + iy;
-  float h00 = p[0] * cfg.hf_vscale, h01 = p[1] * cfg.hf_vscale, h10 = p[cfg.hf_cols] * cfg.hf_vscale, h11 = p[cfg.hf_cols + 1] * cfg.hf_vscale;
+  const int p00 = p[0], p01 = p[1], p10 = p[cfg.hf_cols], p11 = p[cfg.hf_cols + 1];
+  float h00 = p00 * cfg.hf_vscale, h01 = p01 * cfg.hf_vscale, h10 = p10 * cfg.hf_vscale, h11 = p11 * cfg.hf_vscale;
   if (WALLS) {
-    const float T = cfg.hf_wall_threshold;
-    const float dx0 = h10 - h00, dx1 = h11 - h01, dy0 = h01 - h00, dy1 = h11 - h10;
-    const bool sx0 = fabsf(dx0) > T, sx1 = fabsf(dx1) > T, sy0 = fabsf(dy0) > T, sy1 = fabsf(dy1) > T;
+    const int T = cfg.hf_wall_units;
+    const int dx0 = p10 - p00, dx1 = p11 - p01, dy0 = p01 - p00, dy1 = p11 - p10;          // steepness is decided on the integer samples
+    const bool sx0 = abs(dx0) > T, sx1 = abs(dx1) > T, sy0 = abs(dy0) > T, sy1 = abs(dy1) > T;
     if (sx0 || sx1 || sy0 || sy1) {
       float best = 1e30f;
-      if (sx0 && sx1 && dx0 * dx1 > 0.f) {
-        const bool up = dx0 > 0.f;
+      if (sx0 && sx1 && (dx0 > 0) == (dx1 > 0)) {
+        const bool up = dx0 > 0;
         wall.on = true; wall.n = v3(up ? -1.f : 1.f, 0.f, 0.f);
         wall.d = (up ? (1.f - ax) : ax) * cfg.hf_hscale;
         wall.top = up ? h10 * (1.f - ay) + h11 * ay : h00 * (1.f - ay) + h01 * ay;
         best = wall.d;
       }
-      if (sy0 && sy1 && dy0 * dy1 > 0.f) {
-        const bool up = dy0 > 0.f;
+      if (sy0 && sy1 && (dy0 > 0) == (dy1 > 0)) {
+        const bool up = dy0 > 0;
         const float d = (up ? (1.f - ay) : ay) * cfg.hf_hscale;
         if (d < best) {
           wall.on = true; wall.n = v3(0.f, up ? -1.f : 1.f, 0.f);
@@ -450,8 +453,9 @@ DEV void terrain_sample(CfgRef cfg, const int16_t* __restrict__ hs, float x, flo
 
 // x: candidate point relative to the base origin (world axes); bpos: world position of the base origin.  c: deepest
 // top-surface candidate of the point's group, cw: closest wall candidate of its shape
-template <bool WALLS>
-DEV void cand_try(CfgRef cfg, const int16_t* __restrict__ hs, Cand& c, Cand& cw, V3 x, V3 bpos, float radius, SV vb) {
+// WANTW: also keep the wall candidate (hip capsules do not: their points are too high up to meet a riser)
+template <bool WALLS, bool WANTW = WALLS>
+DEV void cand_try(CfgRef cfg, const int16_t* __restrict__ hs, Cand& c, Cand& cw, V3 x, V3 bpos, float radius, SV vb, int m) {
   float h;
   V3 n;
   Wall wl;
@@ -462,14 +466,16 @@ DEV void cand_try(CfgRef cfg, const int16_t* __restrict__ hs, Cand& c, Cand& cw,
     const V3 vp = vb.l + cross(vb.a, xs);
     c.phi = phi; c.x = xs.x; c.y = xs.y; c.z = xs.z; c.un = dot(n, vp);
     c.nx = n.x; c.ny = n.y; c.nz = n.z;
+    c.tag = 16u * (uint32_t)wl.cell + (uint32_t)m;
   }
-  if (WALLS) {
+  if (WALLS && WANTW) {
     const float phiw = wl.d - radius;
     if (wl.on && bpos.z + x.z < wl.top && phiw < cw.phi) {
       const V3 xs = x - radius * wl.n;
       const V3 vp = vb.l + cross(vb.a, xs);
       cw.phi = phiw; cw.x = xs.x; cw.y = xs.y; cw.z = xs.z; cw.un = dot(wl.n, vp);
       cw.nx = wl.n.x; cw.ny = wl.n.y; cw.nz = wl.n.z;
+      cw.tag = 16u * (uint32_t)wl.cell + (uint32_t)m;
     }
   }
 }
@@ -478,9 +484,11 @@ DEV void cand_min_dpp(Cand& c, int lane) {      // quad-wide deepest candidate (
   for (int step = 0; step < 2; step++) {
     Cand o;
     if (step == 0) { o.phi = dpp_xor1(c.phi); o.x = dpp_xor1(c.x); o.y = dpp_xor1(c.y); o.z = dpp_xor1(c.z); o.un = dpp_xor1(c.un);
-                     o.nx = dpp_xor1(c.nx); o.ny = dpp_xor1(c.ny); o.nz = dpp_xor1(c.nz); }
+                     o.nx = dpp_xor1(c.nx); o.ny = dpp_xor1(c.ny); o.nz = dpp_xor1(c.nz);
+                     o.tag = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.tag, 0xB1, 0xF, 0xF, false); }
     else           { o.phi = dpp_xor2(c.phi); o.x = dpp_xor2(c.x); o.y = dpp_xor2(c.y); o.z = dpp_xor2(c.z); o.un = dpp_xor2(c.un);
-                     o.nx = dpp_xor2(c.nx); o.ny = dpp_xor2(c.ny); o.nz = dpp_xor2(c.nz); }
+                     o.nx = dpp_xor2(c.nx); o.ny = dpp_xor2(c.ny); o.nz = dpp_xor2(c.nz);
+                     o.tag = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.tag, 0x4E, 0xF, 0xF, false); }
     const int bit = step == 0 ? 1 : 2;
     const bool other_is_lower = ((lane & bit) != 0);
     bool take = (o.phi < c.phi) || (o.phi == c.phi && other_is_lower);
@@ -713,7 +721,7 @@ DEV int leg_pair_index(int lo, int hi) { return lo == 0 ? hi - 1 : lo == 1 ? hi 
 // acth != nullptr: the torques of this substep are being evaluated by the helper wavefronts (torque_publish was called, the
 // workgroup barrier behind it passed): they are picked up right before ABA pass 2.
 // The helper wavefronts (nw > 1, always) run emit_terrain_contacts() between the two workgroup barriers of the emission hand-over.
-template <bool WALLS>
+template <bool WALLS, bool SIG>
 DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int nw, Base& s, Leg& L, V3 grav,
                          bool use_warm, float h, uint32_t& fault, const float* acth, int e, int N, int sub PROF_PARAM) {
   float* const lds = Z.lds;
@@ -749,7 +757,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     cand_init(cb[mm]);
     const int m = 2 * leg + mm;
     V3 l = v3((m & 1 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[2]);
-    cand_try<WALLS>(cfg, hs, cb[mm], cwb, mul(R0, l), s.pos, 0.f, v0);
+    cand_try<WALLS>(cfg, hs, cb[mm], cwb, mul(R0, l), s.pos, 0.f, v0, m);
   }
   if (WALLS) cand_min_dpp(cwb, lane);
 
@@ -803,7 +811,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
 #pragma unroll
       for (int m = 0; m < 2; m++) {
         V3 l = v3(hc.x, hc.y + (m ? 1.f : -1.f) * (float)GO1_HIP_CAPSULE_HALF, hc.z);
-        cand_try<false>(cfg, hs, ch[m], nowall, p[0] + mul(R[0], l), s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0]);
+        cand_try<WALLS, false>(cfg, hs, ch[m], nowall, p[0] + mul(R[0], l), s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0], m);      // (same top surface as every other shape)
       }
 #ifndef GO1_ABLATE_CAND
 #pragma unroll
@@ -813,18 +821,18 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
           V3 l = v3(GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[0],
                     GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[1],
                     GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[2]);
-          cand_try<WALLS>(cfg, hs, ct[en], cwt, p[1] + mul(R[1], l), s.pos, 0.f, v[1]);
+          cand_try<WALLS>(cfg, hs, ct[en], cwt, p[1] + mul(R[1], l), s.pos, 0.f, v[1], m);
         }
 #pragma unroll 1
         for (int m = 4 * en; m < 4 * en + 4; m++) {
           V3 l = v3(GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[0],
                     GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[1],
                     GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[2]);
-          cand_try<WALLS>(cfg, hs, ck[en], cwk, p[2] + mul(R[2], l), s.pos, 0.f, v[2]);
+          cand_try<WALLS>(cfg, hs, ck[en], cwk, p[2] + mul(R[2], l), s.pos, 0.f, v[2], m);
         }
       }
 #endif
-      cand_try<WALLS>(cfg, hs, cf, cwf, p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2]);
+      cand_try<WALLS>(cfg, hs, cf, cwf, p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2], 0);
       pthigh = p[1]; pknee = p[2]; pfoot = p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg));
       vthigh = v[1]; vlow = v[2];
     }
@@ -964,7 +972,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       }
       sig1 |= 1u << 31;
     }
-    if (B.contact_signature != nullptr && sub < GO1_SIG_MAX_SUBSTEPS) {      // tests only: which points are listed
+    if (SIG && B.contact_signature != nullptr && sub < GO1_SIG_MAX_SUBSTEPS) {      // tests only (the SIG instances): which points are listed
       if (slot[IT_FOOT] >= 0) sig0 |= 1u << leg;
       if (slot[IT_TR0] >= 0) sig0 |= 1u << (4 + 2 * leg);
       if (slot[IT_TR1] >= 0) sig0 |= 1u << (5 + 2 * leg);
@@ -983,7 +991,18 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       for (int pid = 0; pid < 28; pid++)
         if (smask & (1u << pid)) { if ((int)pos < MAXC) sself |= 1u << pid; pos++; }
       sig0 = quad_or(sig0); sig1 = quad_or(sig1);
+      // geometry hash: the cell and candidate point of every listed terrain contact, weighted by its item index
+      uint32_t gh = 0;
+      auto hash_item = [&](int it, const Cand& c) { if (slot[it] >= 0) gh += c.tag * (uint32_t)(2 * it + 1) * 2654435761u; };
+      hash_item(IT_FOOT, cf); hash_item(IT_FOOTW, cwf);
+      hash_item(IT_CALF1, fk ? ck[1] : ck[0]); hash_item(IT_CALFW, cwk); hash_item(IT_CALF2, fk ? ck[0] : ck[1]);
+      hash_item(IT_THIGH1, ft ? ct[1] : ct[0]); hash_item(IT_THIGHW, cwt); hash_item(IT_THIGH2, ft ? ct[0] : ct[1]);
+      hash_item(IT_HIP1, fh ? ch[1] : ch[0]); hash_item(IT_HIP2, fh ? ch[0] : ch[1]);
+      hash_item(IT_TR0, cb[0]); hash_item(IT_TR1, cb[1]); hash_item(IT_TRW, cwb);
+      gh += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gh, 0xB1, 0xF, 0xF, false);
+      gh += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gh, 0x4E, 0xF, 0xF, false);
       if (leg == 0) {
+        AT(B.contact_signature, sub * GO1_SIG_WORDS + 3, e) = gh;
         AT(B.contact_signature, sub * GO1_SIG_WORDS + 0, e) = sig0;
         AT(B.contact_signature, sub * GO1_SIG_WORDS + 1, e) = sig1;
         AT(B.contact_signature, sub * GO1_SIG_WORDS + 2, e) = sself;       // (limit-row legs are OR-ed in below)
@@ -1095,7 +1114,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     }
   }
   const unsigned lact = quad_ballot(legact, lane);      // legs of this environment whose limit rows are in the solve
-  if (B.contact_signature != nullptr && sub < GO1_SIG_MAX_SUBSTEPS && leg == 0) AT(B.contact_signature, sub * GO1_SIG_WORDS + 2, e) |= lact << 28;
+  if (SIG && B.contact_signature != nullptr && sub < GO1_SIG_MAX_SUBSTEPS && leg == 0) AT(B.contact_signature, sub * GO1_SIG_WORDS + 2, e) |= lact << 28;
 
   // ---- hand-over: the leg's factors, the base's free twist and L^-1; the terrain contacts are finished by the helper
   // wavefronts (nw > 1) while this one emits the self-contacts and the limit rows --------------------------------------------

@@ -74,11 +74,11 @@ DEV void report_fault(BufRef B, int e, uint32_t fault) {
 // environment, one per leg; the other wavefronts are helpers on the CU's other SIMDs: they take the two data-parallel
 // blocks of every substep (the actuator network's row tiles, the rows of the listed terrain contacts), fed through LDS,
 // and wait at workgroup barriers otherwise.  4096 environments -> 256 workgroups x 4 wavefronts: one per SIMD.
-// WALLS: the terrain has vertical faces (hf_wall_threshold > 0); the plain instance carries none of that code or its registers.
+// WALLS: the terrain has vertical faces (hf_wall_units > 0); the plain instance carries none of that code or its registers.
 #ifndef STEP_WAVES
 #define STEP_WAVES 4
 #endif
-template <bool WALLS>
+template <bool WALLS, bool SIG>
 DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, float* acth) {
   const int nw = STEP_WAVES, wv = WAVE_UNIFORM((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63, leg = lane & 3;
   for (int i = threadIdx.x; i < L_END * EPW; i += WAVE * STEP_WAVES) lds[i] = 0.f;
@@ -181,7 +181,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
     PROF(1);
     head = (head + 1) % nl;
 #ifndef GO1_ABLATE_PHYSICS
-    physics_substep<WALLS>(cfg, B, Z, lane, nw, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault, deferred ? acth : nullptr, e, N, sub PROF_PASS);
+    physics_substep<WALLS, SIG>(cfg, B, Z, lane, nw, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault, deferred ? acth : nullptr, e, N, sub PROF_PASS);
 #endif
   }
   if (deferred) torque_stash_store(cfg, B, L, acth, lane, leg, e, N);
@@ -203,8 +203,11 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   __shared__ __attribute__((aligned(16))) lf4 ldsx[X_END]; \
   __shared__ __attribute__((aligned(16))) float act_lds[A_END]; \
   __shared__ float acth[AH_END * WAVE];          /* per-lane stash of the deferred torque path (torque_stash_load) */
-extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(const StepArgs A) { STEP_LDS step_body<false>(A, lds, ldsx, act_lds, acth); }
-extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel_walls(const StepArgs A) { STEP_LDS step_body<true>(A, lds, ldsx, act_lds, acth); }
+extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(const StepArgs A) { STEP_LDS step_body<false, false>(A, lds, ldsx, act_lds, acth); }
+extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel_walls(const StepArgs A) { STEP_LDS step_body<true, false>(A, lds, ldsx, act_lds, acth); }
+// the same with the contact signature recorded (Go1SimBuffers.contact_signature != NULL: parity tests)
+extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel_sig(const StepArgs A) { STEP_LDS step_body<false, true>(A, lds, ldsx, act_lds, acth); }
+extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel_walls_sig(const StepArgs A) { STEP_LDS step_body<true, true>(A, lds, ldsx, act_lds, acth); }
 
 // piecewise entry points with the 4-lane mapping (parity tests): torques only / tensor maps only (a single physics substep is
 // mode 2 of the step kernels: the production structure, master + helper wavefronts)
@@ -428,7 +431,10 @@ static int launch(Go1Sim* s, int mode, const float* actions, const int32_t* ids,
   const int slot = timed ? (int)(s->timing_n % s->timing_cap) : 0;
   if (timed) (void)hipEventRecord(s->ev[2 * slot], st);
   if (mode == 0 || mode == 2) {
-    if (s->cfg.terrain_type != 0 && s->cfg.hf_wall_threshold > 0.f) hipLaunchKernelGGL(go1_step_kernel_walls, grid, block, 0, st, A);
+    const bool walls = s->cfg.terrain_type != 0 && s->cfg.hf_wall_units > 0, sig = s->buf.contact_signature != nullptr;
+    if (walls && sig) hipLaunchKernelGGL(go1_step_kernel_walls_sig, grid, block, 0, st, A);
+    else if (walls) hipLaunchKernelGGL(go1_step_kernel_walls, grid, block, 0, st, A);
+    else if (sig) hipLaunchKernelGGL(go1_step_kernel_sig, grid, block, 0, st, A);
     else hipLaunchKernelGGL(go1_step_kernel, grid, block, 0, st, A);
   }
   else if (mode == 3) hipLaunchKernelGGL(go1_env_kernel, grid, block, 0, st, A);

@@ -221,7 +221,7 @@ class LeggedRobot(BaseTask):
             # both mesh types are simulated on the height field's bilinear surface (utils/terrain.py docstring)
             # 'heightfield': the bilinear surface.  'trimesh': the reference corrects faces steeper than slope_treshold into vertical
             # walls (terrain.py:33-36, convert_heightfield_to_trimesh) — simulated as vertical contact faces on the same height
-            # field (include/go1sim.h hf_wall_threshold)
+            # field (include/go1sim.h hf_wall_units)
             H.bind_height_field(self.sim_config, B, self.terrain.heightsamples, cfg.terrain.horizontal_scale,
                                 cfg.terrain.vertical_scale, cfg.terrain.border_size,
                                 slope_threshold=float(getattr(cfg.terrain, "slope_treshold", 0.75)) if mesh_type == 'trimesh' else None)

@@ -146,7 +146,7 @@ def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curricu
     S.bounce_threshold_velocity = px.bounce_threshold_velocity
     S.terrain_friction = cfg.terrain.static_friction
     S.terrain_dynamic_friction = getattr(cfg.terrain, "dynamic_friction", cfg.terrain.static_friction)
-    S.hf_wall_threshold = 0.0                                   # set by bind_height_field(slope_threshold=...) for a trimesh terrain
+    S.hf_wall_units = 0                                         # set by bind_height_field(slope_threshold=...) for a trimesh terrain
     S.terrain_restitution = cfg.terrain.restitution
     S.max_linear_velocity = float(cfg.asset.max_linear_velocity)
     S.max_angular_velocity = float(cfg.asset.max_angular_velocity)
@@ -328,19 +328,21 @@ def bind_height_field(S, buffers, heights_int16, hscale, vscale, border, slope_t
     """`_create_heightfield` / `_create_trimesh` (legged_robot.py:1441-1479): hand the int16 height samples to the
     simulator.  A constant field is served by the plane fast path (same physics, no gathers).  `slope_threshold` (the
     trimesh terrain's `slope_treshold`, terrain.py:33-36): cell edges rising by more than slope_threshold * hscale become
-    vertical faces (include/go1sim.h hf_wall_threshold) — only when the field has such an edge at all."""
+    vertical faces (include/go1sim.h hf_wall_units) — only when the field has such an edge at all."""
     hs = torch.as_tensor(np.ascontiguousarray(heights_int16), dtype=torch.int16)
     S.hf_rows, S.hf_cols = int(hs.shape[0]), int(hs.shape[1])
     S.hf_hscale, S.hf_vscale, S.hf_border = float(hscale), float(vscale), float(border)
     flat = bool((hs == hs.flatten()[0]).all()) and int(hs.flatten()[0]) == 0
     S.terrain_type = 0 if flat else 1
-    S.hf_wall_threshold = 0.0
+    S.hf_wall_units = 0
     if slope_threshold is not None and not flat:
-        thr = float(slope_threshold) * float(hscale)
-        h = hs.to(torch.float64) * float(vscale)
-        steepest = max(float((h[1:] - h[:-1]).abs().max()), float((h[:, 1:] - h[:, :-1]).abs().max()))
-        if steepest > thr:
-            S.hf_wall_threshold = thr
+        # the reference compares int16 sample differences with slope_threshold * (horizontal_scale / vertical_scale), a Python
+        # float (isaacgym.terrain_utils.convert_heightfield_to_trimesh): the largest difference that is NOT steep
+        units = int(np.floor(float(slope_threshold) * (float(hscale) / float(vscale))))
+        h = hs.to(torch.int32)
+        steepest = max(int((h[1:] - h[:-1]).abs().max()), int((h[:, 1:] - h[:, :-1]).abs().max()))
+        if steepest > units:
+            S.hf_wall_units = max(units, 1)
     buffers.tensors["height_samples"] = hs.to(buffers.device)
     buffers.refresh_struct()
     return S
