@@ -14,14 +14,14 @@ CSRC = os.path.join(PKG, "csrc")
 for p in (os.path.join(PKG, "shims"), PKG, REPO):
     sys.path.insert(0, p)
 
-PHASES = ["load state/actions/warm start", "torque model (x4)", "kinematics + candidates + ABA 1,2 (x4)",
-          "Delassus: I0inv + lane columns (x4)", "row functionals (x4)", "PGS sweeps (x4)", "apply + integrate (x4)",
+PHASES = ["load state/actions/warm start", "torque model: publish (x4)", "torque pick-up (barrier wait) + ABA pass 2 (x4)",
+          "(unused)", "ABA pass 3 + limit-row bounds + hand-over packets + barrier (x4)", "PGS sweeps (x4)", "apply + integrate (x4)",
           "store state/feet/forces", "post: derived + callbacks", "post: gait clock + push/dof-rand",
           "post: feet/heights/termination", "post: rewards", "post: reset", "post: observations", "post: privileged obs",
-          "post: roll", "post: reward-input loads", "post: termination", "Delassus: record read-back (x4)",
-          "ABA 3 + self-collision detection + slots (x4)", "joint-limit rows (x4)", "Delassus: publish + rows + barriers (x4)",
-          "Delassus: leg-leg row corrections (x4)", "PGS: setup + warm start (x4)"]
-# (3: unused; 4: contact emission = row functionals; 5: PGS sweeps only)
+          "post: roll", "post: reward-input loads", "post: termination", "fault flags + sweep bounds (x4)",
+          "kinematics + candidates + self-collision geometry + contact list (x4)", "post items into the records (x4)",
+          "self-contacts + limit rows + barrier wait for the helpers' rows (x4)",
+          "(unused)", "PGS: warm-start state (x4)"]
 
 
 def build(flags):
