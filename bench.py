@@ -39,10 +39,10 @@ ALGORITHMIC_BYTES_PER_ENV_STEP = 3444      # 1,332 B read + 1,
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def build_env(num_envs, rank, seed, rough=False):
+def build_env(num_envs, rank, seed, rough=False, curriculum_update_interval=None):
     """train.py configuration (BASELINE configs[1]); rough=True: configs[2] — the terrain curriculum's tile grid
-    (slopes / rough slopes / stairs / obstacles, cfg:64-102 defaults) as a height field + the 187-point height scan
-    appended to the observation (70 + 187 = 257)."""
+    (slopes / rough slopes / stairs / obstacles, cfg:64-102 defaults) as a trimesh terrain (vertical risers) + the 187-point
+    height scan appended to the observation (70 + 187 = 257)."""
     from go1_gym.envs.base.legged_robot_config import make_cfg
     from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
     from go1_gym.envs.wrappers.history_wrapper import HistoryWrapper
@@ -50,9 +50,12 @@ def build_env(num_envs, rank, seed, rough=False):
     cfg = apply_train_config(make_cfg(), num_envs=num_envs)
     cfg.seed = seed
     cfg.env.env_id_offset = rank * num_envs
+    if curriculum_update_interval is not None:
+        cfg.commands.curriculum_update_interval = int(curriculum_update_interval)
     if rough:
         t = cfg.terrain
-        t.mesh_type, t.terrain_proportions, t.curriculum = "heightfield", [0.1, 0.1, 0.35, 0.25, 0.2], True
+        # 'trimesh' with the default slope_treshold 0.75: stair risers / obstacle sides are VERTICAL faces (terrain.py:33-36)
+        t.mesh_type, t.terrain_proportions, t.curriculum = "trimesh", [0.1, 0.1, 0.35, 0.25, 0.2], True
         t.num_rows, t.num_cols, t.terrain_length, t.terrain_width, t.border_size, t.center_robots = 10, 20, 8.0, 8.0, 25.0, False
         t.measure_heights = True
         cfg.env.observe_heights = True
@@ -170,15 +173,27 @@ def extra_records(args, env, runner, obs_dict, device):
     except Exception as err:
         out["rates"] = {"error": f"{type(err).__name__}: {err}"}
     try:
+        from torch.cuda import tunable
+        if tunable.is_enabled():
+            tunable.tuning_enable(False)         # the 7710-wide history's GEMM shapes are not in the shipped table: hipBLASLt's default pick
         env3, _ = build_env(args.envs, 0, args.seed, rough=True)
-        env3.reset()
+        runner3 = Runner(env3, device=device)
+        env3.episode_length_buf.copy_(torch.randint_like(env3.episode_length_buf, high=int(env3.max_episode_length)))
+        od3 = env3.get_observations()
+        full, od3 = time_iterations(runner3, env3, od3, 5, warmup=2)
         so, ms = time_sim_only(env3, env3.env.sim, args.envs, 240, device)
-        out["height_field"] = {"workload": "BASELINE configs[2]: terrain-curriculum tile grid as int16 height field, bilinear contact, "
-                                           "187-point height scan in the observation (257 wide), 4096 envs, N(0,1) actions, sim step only",
-                               "launch_ms": ms, "env_steps_s": so}
-        del env3
+        f3 = env3.env.extras["sim_faults"].consume()
+        out["rough_trimesh"] = {"workload": "BASELINE configs[2]: terrain-curriculum tile grid (slopes, rough slopes, stairs up / down, discrete "
+                                            "obstacles) as a `trimesh` terrain — int16 height field with vertical faces where the slope exceeds "
+                                            "slope_treshold 0.75 —, 187-point height scan in the observation (257 wide, history 7710), 4096 envs",
+                                "sim_ppo_env_steps_s": full, "sim_only_env_steps_s": so, "step_kernel_launch_ms": ms,
+                                "wall_instance": bool(env3.env.sim_config.hf_wall_units > 0),
+                                "guard_activations": {k: v for k, v in f3.items() if v},
+                                "note": "sim+PPO: 5 timed PPO iterations (live policy), GEMM selections untuned for the 7744-wide first layer; "
+                                        "sim only: N(0,1) actions"}
+        del runner3, env3
     except Exception as err:
-        out["height_field"] = {"error": f"{type(err).__name__}: {err}"}
+        out["rough_trimesh"] = {"error": f"{type(err).__name__}: {err}"}
     try:
         from torch.cuda import tunable
         if tunable.is_enabled():
@@ -270,7 +285,9 @@ def main():
     PPO_Args.dp_grad_dtype, PPO_Args.dp_zero1 = args.grad_dtype, bool(args.zero1)
     RunnerArgs.save_video_interval = 0
     torch.manual_seed(args.seed + rank)
-    env, cfg = build_env(args.envs, rank, args.seed)
+    # environments sharded over ranks: the command curriculum's success counts are exchanged once per rollout (T = 24 steps, one
+    # 170 KB all-reduce) instead of once per step; the 1-rank run keeps the reference's per-step cadence
+    env, cfg = build_env(args.envs, rank, args.seed, curriculum_update_interval=24 if use_dist else None)
     device = f"cuda:{local_rank}"
     runner = Runner(env, device=device)
     sim = env.env.sim
@@ -349,7 +366,7 @@ def main():
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         valu_insts = None
         traffic, traffic_src = None, None   # HBM bytes per launch: NOT measured by this run — read from the committed PMC passes
-        for name in ("r02_step_kernel_pmc.json", "r01_step_kernel_pmc.json"):
+        for name in ("r03_step_kernel_pmc.json", "r02_step_kernel_pmc.json", "r01_step_kernel_pmc.json"):
             try:
                 with open(os.path.join(REPO, "profiles", name)) as f:
                     pmc = json.load(f)
@@ -397,6 +414,11 @@ def main():
                                     "env_steps": args.envs * T * (args.steps + args.warmup),
                                     "note": "containments of failed environments (include/go1sim.h Go1FaultBit) during warm-up + timed steps"}
         if world == 1 and not args.headline_only and not (args.sim_only or args.rollout_only):
+            # the driver times --steps 20 (0.45 s): the same measurement over a 200-iteration window next to it
+            long_iters = 200
+            rate, obs_dict = time_iterations(runner, env, obs_dict, long_iters, warmup=0)
+            out["long_window"] = {"iterations": long_iters, "value": rate, "ms_per_step": 1e3 * args.envs * T / rate, "unit": "env-steps/s",
+                                  "note": "same workload and code path as `value`, timed over 200 PPO iterations in one window"}
             out.update(extra_records(args, env, runner, obs_dict, device))
         try:
             with open(os.path.join(REPO, "profiles", "reference_python_maps_cpu.json")) as f:

@@ -41,6 +41,8 @@ def _rank(nodeid):
 
 
 def _have_gpu():
+    if os.environ.get("GO1_DRY_RUN_GPU_TESTS"):          # tools/dry_run_gpu_tests.py: the simulator tests through the SIMT emulator
+        return True
     try:
         import torch
         return torch.cuda.is_available()

@@ -8,7 +8,10 @@ ATTRIBUTED, in one of two checkable ways, and even then its error stays below AT
       corner a listed point came from, differ between kernel and oracle — both record them (include/go1sim.h
       `contact_signature`): a point sitting on an activation threshold or a cell boundary falls on different sides in fp32
       and fp64;
-  (b) precision: the fp32 BUILD OF THE ORACLE (oracle/_build/libgo1oracle32.so, the same restatement with real = float), run on
+  (c) the kernel reproduces, within the tolerances, the fp32 BUILD OF THE ORACLE run beside the fp64 one on the same inputs (a
+      decision both fp32 evaluations take the same way and fp64 the other, e.g. the termination threshold on the base height):
+      no bound applies — the kernel IS a valid fp32 evaluation of the restatement there;
+  (b) precision: the fp32 build of the oracle (oracle/_build/libgo1oracle32.so, the same restatement with real = float), run on
       the same inputs beside the fp64 one, uses up a quarter of a tolerance itself in that environment-step (it typically
       needs 1-3 %) or comes within a factor 5 of the kernel's error: the state is ill-conditioned in fp32 (deep interpenetration
       with kilonewton impulses, a non-converged 20-contact solve), whoever computes it.
@@ -87,24 +90,39 @@ class Attribution:
             return r.reshape(self.N, -1).max(1).values
         return r.reshape(-1, self.N).max(0).values
 
-    def step(self, ratio, Bg, Bc, extra_bad=None, ratio32=None):
-        """ratio: (N,) worst error / tolerance of every environment this step; ratio32: the same for the fp32 oracle"""
+    def step(self, ratio_fn, Bg, Bc, B32=None, reset_key=None, also_attributed=None):
+        """ratio_fn(Bx, Bref) -> (N,) worst error / tolerance of every environment this step; B32: the fp32 oracle's buffers;
+        reset_key: a buffer whose mismatch (termination decided differently) puts the environment outside the tolerances."""
+        ratio = ratio_fn(Bg, Bc)
         sig = (Bg.contact_signature.cpu() != Bc.contact_signature).any(0)
         bad = ratio > 1.0
-        if extra_bad is not None:
-            bad = bad | extra_bad
-        if ratio32 is not None:
+        if reset_key is not None:
+            bad = bad | (Bg.tensors[reset_key].cpu().bool() != Bc.tensors[reset_key].bool())
+        same32 = torch.zeros_like(bad)
+        if also_attributed is not None:            # a test-specific, stated rule (e.g. height-scan samples on a cell boundary)
+            sig = sig | also_attributed
+        if B32 is not None:
             # (b): ill-conditioned in fp32 — the fp32 oracle, whose error in a well-conditioned environment-step is 1-3 % of a
-            # tolerance (printed by finish()), uses up a quarter of it here, or comes within a factor 5 of the kernel's error
-            sig = sig | (ratio32 > 0.25) | (ratio32 > 0.2 * ratio)
+            # tolerance (printed by finish()), uses up a quarter of it here, or comes within a factor 5 of the kernel's error;
+            # (c): the kernel REPRODUCES the fp32 oracle within the tolerances (a decision both fp32 evaluations take the same
+            # way and fp64 the other — e.g. a termination threshold): no bound on how far that is from the fp64 result
+            ratio32 = ratio_fn(B32, Bc)
+            same32 = ratio_fn(Bg, B32) <= 1.0
+            if reset_key is not None:
+                same32 = same32 & (Bg.tensors[reset_key].cpu().bool() == B32.tensors[reset_key].bool())
+            sig = sig | (ratio32 > 0.25) | (ratio32 > 0.2 * ratio) | same32
             self.r32_all.append(ratio32.clone()); self.r_all.append(ratio.clone())
         un = bad & ~sig
-        if bool(un.any()) and ratio32 is not None:
-            print("UNATTRIBUTED", [(int(e), round(float(ratio[e]), 2), round(float(ratio32[e]), 3)) for e in un.nonzero().flatten()[:8]])
+        if bool(un.any()) and B32 is not None:
+            print("UNATTRIBUTED", [(int(e), round(float(ratio[e]), 2), round(float(ratio32[e]), 3)) for e in un.nonzero().flatten()[:8]],
+                  getattr(ratio_fn, "detail", lambda *_: "")(Bg, Bc, un))
         self.env_steps += self.N
         self.bad += int(bad.sum()); self.attributed += int((bad & sig).sum())
-        if bool((bad & sig).any()):
-            self.worst_ratio = max(self.worst_ratio, float(ratio[bad & sig].max()))
+        bounded = bad & sig & ~same32
+        if also_attributed is not None:            # (its size is that of the terrain's steps, not of a tolerance)
+            bounded = bounded & ~also_attributed
+        if bool(bounded.any()):
+            self.worst_ratio = max(self.worst_ratio, float(ratio[bounded].max()))
         if bool(un.any()):
             self.worst_unattr = max(self.worst_unattr, float(ratio[un].max()))
         assert not bool(un.any()), f"environments {un.nonzero().flatten().tolist()[:8]} exceed the tolerances (worst x{float(ratio[un].max()):.1f}) with identical contact sets"
@@ -126,11 +144,25 @@ class Attribution:
 SUBSTEP_TOL = (("root_states", 2e-4, 1e-4), ("dof_pos", 2e-4, 1e-4), ("dof_vel", 3e-3, 1e-4), ("contact_forces", 5e-2, 2e-3))
 
 
-def substep_ratio(att, Bx, Bc):
-    ratio = torch.zeros(att.N, dtype=torch.float64)
-    for k, tol, rt in SUBSTEP_TOL:
-        ratio = torch.maximum(ratio, att.ratio(Bx.tensors[k], Bc.tensors[k], tol, rt))
-    return ratio
+def make_ratio(att, keys, rows=()):
+    """ratio_fn for Attribution.step over [C][N] quantities `keys` and (N, K) row-major ones `rows`: (name, atol, rtol)"""
+    def fn(Bx, Bref):
+        ratio = torch.zeros(att.N, dtype=torch.float64)
+        for k, tol, rt in keys:
+            ratio = torch.maximum(ratio, att.ratio(Bx.tensors[k], Bref.tensors[k], tol, rt))
+        for k, tol, rt in rows:
+            ratio = torch.maximum(ratio, att.ratio(Bx.tensors[k], Bref.tensors[k], tol, rt, env_dim=0))
+        return ratio
+
+    def detail(Bx, Bref, mask):
+        out = {}
+        for k, tol, rt in keys:
+            out[k] = round(float(att.ratio(Bx.tensors[k], Bref.tensors[k], tol, rt)[mask].max()), 2)
+        for k, tol, rt in rows:
+            out[k] = round(float(att.ratio(Bx.tensors[k], Bref.tensors[k], tol, rt, env_dim=0)[mask].max()), 2)
+        return {k: v for k, v in out.items() if v > 0.5}
+    fn.detail = detail
+    return fn
 
 
 def frac_bad(a, b, atol, rtol=0.0):
@@ -191,7 +223,7 @@ def test_physics_substep_matches_oracle(scenario):
         sim.physics_substep()
         torch.cuda.synchronize()
         assert torch.isfinite(Bg.root_states).all() and torch.isfinite(Bg.dof_vel).all()
-        att.step(substep_ratio(att, Bg, Bc), Bg, Bc, ratio32=substep_ratio(att, sh.B, Bc))
+        att.step(make_ratio(att, SUBSTEP_TOL), Bg, Bc, sh.B)
         sync_from(Bc, Bg, sim, orc)      # re-synchronise so that one substep is compared at a time
         sh.sync()
     att.finish(f"substep[{scenario}]")
@@ -210,16 +242,6 @@ FULL_STEP_TOL = (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 
                  ("joint_pos_err_last", 1e-3, 0), ("joint_pos_err_last_last", 1e-3, 0), ("joint_vel_last", 2e-2, 1e-3),
                  ("joint_vel_last_last", 2e-2, 1e-3), ("joint_pos_target", 1e-5, 0), ("lag_buffer", 1e-5, 0))
 ROW_TOL = (("obs_buf", 3e-3, 1e-3), ("privileged_obs_buf", 1e-5, 0), ("obs_history", 3e-3, 1e-3))
-
-
-def step_ratio(att, Bg, Bc, keys=FULL_STEP_TOL, rows=ROW_TOL):
-    """(N,) worst error / tolerance over the compared quantities of one full step"""
-    ratio = torch.zeros(att.N, dtype=torch.float64)
-    for k, tol, rt in keys:
-        ratio = torch.maximum(ratio, att.ratio(Bg.tensors[k], Bc.tensors[k], tol, rt))
-    for k, tol, rt in rows:
-        ratio = torch.maximum(ratio, att.ratio(Bg.tensors[k], Bc.tensors[k], tol, rt, env_dim=0))
-    return ratio
 
 
 def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=None, what="full step"):
@@ -252,7 +274,7 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
         torch.cuda.synchronize()
         cpu_reset = Bc.reset_buf.bool()
         np.testing.assert_array_equal(Bg.time_out_buf.cpu().numpy(), Bc.time_out_buf.numpy())
-        bad_env = att.step(step_ratio(att, Bg, Bc), Bg, Bc, extra_bad=(Bg.reset_buf.cpu().bool() != cpu_reset), ratio32=step_ratio(att, sh.B, Bc))
+        bad_env = att.step(make_ratio(att, FULL_STEP_TOL, ROW_TOL), Bg, Bc, sh.B, reset_key="reset_buf")
         timeouts += int(Bc.time_out_buf.sum())
         np.testing.assert_array_equal(Bg.env_command_bins.cpu().numpy()[~bad_env.numpy()], Bc.env_command_bins.numpy()[~bad_env.numpy()])
         np.testing.assert_allclose(Bg.curriculum_weights.cpu().numpy(), Bc.curriculum_weights.numpy(), atol=0.21 * float(bad_env.sum()) + 1e-6)
@@ -307,8 +329,7 @@ def test_full_step_under_random_configurations(case):
         keys = (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
                 ("commands", 1e-5, 0), ("torques", 5e-3, 1e-3), ("episode_sums", 1e-3, 1e-3), ("command_sums", 1e-3, 1e-3))
         rows = (("obs_buf", 3e-3, 1e-3), ("privileged_obs_buf", 3e-3, 1e-3))
-        att.step(step_ratio(att, Bg, Bc, keys, rows), Bg, Bc, extra_bad=(Bg.reset_buf.cpu().bool() != Bc.reset_buf.bool()),
-                 ratio32=step_ratio(att, sh.B, Bc, keys, rows))
+        att.step(make_ratio(att, keys, rows), Bg, Bc, sh.B, reset_key="reset_buf")
         sync_from(Bc, Bg, sim, orc)
         sh.sync()
     att.finish(f"fuzz case {case}")
@@ -464,7 +485,7 @@ def test_physics_substep_on_height_field(scenario, walls):
         sim.physics_substep()
         torch.cuda.synchronize()
         assert torch.isfinite(Bg.root_states).all() and torch.isfinite(Bg.dof_vel).all()
-        att.step(substep_ratio(att, Bg, Bc), Bg, Bc, ratio32=substep_ratio(att, sh.B, Bc))
+        att.step(make_ratio(att, SUBSTEP_TOL), Bg, Bc, sh.B)
         wall_contacts += int((Bc.contact_signature[1] & 0x1FFF != 0).sum())
         sync_from(Bc, Bg, sim, orc)
         sh.sync()
@@ -512,8 +533,14 @@ def test_full_step_on_height_field(walls):
         cpu_reset = Bc.reset_buf.bool()
         keys = (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
                 ("torques", 5e-3, 1e-3), ("foot_positions", 1e-3, 0), ("measured_heights", 1e-3, 0))
-        att.step(step_ratio(att, Bg, Bc, keys, (("obs_buf", 5e-3, 1e-3),)), Bg, Bc, extra_bad=(Bg.reset_buf.cpu().bool() != cpu_reset),
-                 ratio32=step_ratio(att, sh.B, Bc, keys, (("obs_buf", 5e-3, 1e-3),)))
+        # A scan point within round-off of a cell boundary reads the neighbouring sample in fp32 (legged_robot.py:1793-1806 floors
+        # (x + border) / scale): environments whose ONLY differences are a few of the 187 scan heights (and their observation
+        # columns) are attributed to that — the rest of their state, rewards and the 70 proprioceptive columns must agree
+        scan_pts = ((Bg.measured_heights.cpu() - Bc.measured_heights).abs() > 1e-3).sum(0)
+        core = make_ratio(att, keys[:-1])(Bg, Bc)
+        prop = att.ratio(Bg.obs_buf[:, :70].contiguous(), Bc.obs_buf[:, :70].contiguous(), 5e-3, 1e-3, env_dim=0)
+        scan_flip = (scan_pts > 0) & (scan_pts <= 4) & (core <= 1.0) & (prop <= 1.0)
+        att.step(make_ratio(att, keys, (("obs_buf", 5e-3, 1e-3),)), Bg, Bc, sh.B, reset_key="reset_buf", also_attributed=scan_flip)
         resets += int(cpu_reset.sum())
         sync_from(Bc, Bg, sim, orc)
         sh.sync()

@@ -26,6 +26,7 @@ def install():
 
 
 if __name__ == "__main__":
+    os.environ["GO1_DRY_RUN_GPU_TESTS"] = "1"
     import pytest
 
     class Plugin:

@@ -128,6 +128,10 @@ class _SimFaults(_LazyMapping):
         self.env.buffers.fault_counts.zero_()
         out = {name: int(counts[b]) for b, name in sorted(H.FAULT_NAMES.items())}
         out["fatal"] = sum(int(counts[b]) for b in H.FAULT_NAMES if (H.FAULT_FATAL_MASK >> b) & 1)
+        drops = self.env.buffers.contact_drop_counts.tolist()          # contact points that found no solver slot, per class
+        self.env.buffers.contact_drop_counts.zero_()
+        if any(drops):
+            out["contact_dropped_by_class"] = {name: int(drops[c]) for c, name in sorted(H.CONTACT_CLASS_NAMES.items()) if drops[c]}
         return out
 
 

@@ -152,8 +152,10 @@ class Runner:
                         logger.store_metrics(**(stats.consume() if hasattr(stats, "consume") else stats))
                 faults = infos.get('sim_faults') if hasattr(infos, "get") else None
                 if faults is not None and hasattr(faults, "consume"):       # containments of failed environments (go1sim.h Go1FaultBit)
+                    fc = faults.consume()
+                    fc.update({f"contact_dropped_{k}": v for k, v in fc.pop("contact_dropped_by_class", {}).items()})
                     with logger.Prefix(metrics="sim_faults"):
-                        logger.store_metrics(**faults.consume())
+                        logger.store_metrics(**fc)
                 logger.log_metrics_summary(key_values={"timesteps": self.tot_timesteps, "iterations": it})
                 logger.job_running()
             if it % RunnerArgs.save_interval == 0:

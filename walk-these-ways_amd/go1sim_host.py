@@ -49,6 +49,7 @@ CURRICULUM_KEYS = ["tracking_lin_vel", "tracking_ang_vel", "tracking_contacts_sh
 FAULT_NAMES = {v: k[len("GO1_FAULT_"):].lower() for k, v in abi.CONSTS.items()
                if k.startswith("GO1_FAULT_") and k != "GO1_FAULT_BITS"}
 FAULT_FATAL_MASK = 0x3FF          # GO1_FAULT_FATAL_MASK of include/go1sim.h
+CONTACT_CLASS_NAMES = {v: k[len("GO1_CC_"):].lower() for k, v in abi.CONSTS.items() if k.startswith("GO1_CC_") and k != "GO1_CC_COUNT"}
 COMMAND_SUM_EXTRA = ["lin_vel_raw", "ang_vel_raw", "lin_vel_residual", "ang_vel_residual", "ep_timesteps"]
 
 
