@@ -688,7 +688,10 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
     if (vs > cfg->max_depenetration_velocity) vs = cfg->max_depenetration_velocity;
     real un_pre = 0;
     for (int i = 0; i < NV; i++) un_pre += J[c][0][i] * vel[i];
-    if (un_pre < -(real)cfg->bounce_threshold_velocity && -e_c * un_pre > vs) vs = -e_c * un_pre;
+    if (un_pre < -(real)cfg->bounce_threshold_velocity && -e_c * un_pre > vs) {
+      vs = -e_c * un_pre;
+      if (out) out->sig[3] += (uint32_t)(c + 1) * 0x9E3779B1u;       /* signature: this contact took the restitution branch */
+    }
     vstar[c] = vs;
     /* the body's last impulse, shared by its listed points and projected on the current contact frame */
     const real* w = wl[C[c].repA];

@@ -45,8 +45,10 @@ typedef __attribute__((ext_vector_type(4))) float lf4;
 //   lds  : per-environment scalars, lds[field * EPW + env_local]
 //   cr   : contact records, 12 x 16-byte slots per contact: cr[(k * CR_Q + q) * EPW + env_local]  (a quad reads one address,
 //          the 16 environments of the wavefront 256 contiguous bytes: conflict-free)
-//          q0..q6  a_n, a_t1, a_t2 (6 + 3 each), flags      q7  c_n = b_n - v*, b_t1, b_t2, -      q8  1/W_nn, 1/W_t1t1, 1/W_t2t2, W_t1n
-//          q9  W_t2n, lambda_n, lambda_t1, lambda_t2          q10 contact point (rel. base origin)   q11 normal
+//          q0 q1 q2  normal row: a_n (6 + 3), c_n = b_n - v*, 1/W_nn, W_t1n          q3 q4 q5  first tangent: a_t1, b_t1, 1/W_t1t1, W_t2n
+//          q6 q7 q8  second tangent: a_t2, b_t2, 1/W_t2t2, flags   (rows start on 16-byte slots: their components sit in even-aligned
+//          register pairs after the load, which is what the packed-f32 arithmetic of the sweep wants)
+//          q9  lambda_n, lambda_t1, lambda_t2          q10 contact point (rel. base origin)   q11 normal
 //          before the emission q9..q11 hold the ITEM the master posted: (phi, x) (u_n, n) (depth, leg, body, share)
 //   jr   : joint-limit rows, 4 slots per joint: a (6 + 3), b, lower, upper, W, 1/W, lambda
 //   sb   : body-B side of the leg-leg self-contacts (exchange between the two lanes of a pair, then u_B of the three rows)
@@ -625,32 +627,52 @@ DEV void row_finish(const float Li[21], SV g, const float uj[3], const float sD[
 DEV float cr_flags(int legA, bool self, int sb1) { return (float)(legA | (self ? 8 : 0) | (sb1 << 4)); }
 // a finished contact into its record.  c_n = b_n - v*
 DEV void contact_record_store(lf4* crl, int el, int k, const Row& an, const Row& a1, const Row& a2, float flags, float cn, float b1, float b2,
-                              float wnn, float w11, float w22, float w1n, float w2n, V3 lam, V3 x, V3 n, uint32_t& fault) {
+                              float wnn, float w11, float w22, float w1n, float w2n, V3 lam, V3 x, V3 n, bool bounce, uint32_t& fault) {
   if (!(wnn > 1e-9f) || !(w11 > 1e-9f) || !(w22 > 1e-9f)) fault |= 1u << GO1_FAULT_W_DIAG;
   CRQ(k, 0) = (lf4){an.g[0], an.g[1], an.g[2], an.g[3]};
   CRQ(k, 1) = (lf4){an.g[4], an.g[5], an.u[0], an.u[1]};
-  CRQ(k, 2) = (lf4){an.u[2], a1.g[0], a1.g[1], a1.g[2]};
-  CRQ(k, 3) = (lf4){a1.g[3], a1.g[4], a1.g[5], a1.u[0]};
-  CRQ(k, 4) = (lf4){a1.u[1], a1.u[2], a2.g[0], a2.g[1]};
-  CRQ(k, 5) = (lf4){a2.g[2], a2.g[3], a2.g[4], a2.g[5]};
-  CRQ(k, 6) = (lf4){a2.u[0], a2.u[1], a2.u[2], flags};
-  CRQ(k, 7) = (lf4){cn, b1, b2, 0.f};
-  CRQ(k, 8) = (lf4){1.f / wnn, 1.f / w11, 1.f / w22, w1n};
-  CRQ(k, 9) = (lf4){w2n, lam.x, lam.y, lam.z};
+  CRQ(k, 2) = (lf4){an.u[2], cn, 1.f / wnn, w1n};
+  CRQ(k, 3) = (lf4){a1.g[0], a1.g[1], a1.g[2], a1.g[3]};
+  CRQ(k, 4) = (lf4){a1.g[4], a1.g[5], a1.u[0], a1.u[1]};
+  CRQ(k, 5) = (lf4){a1.u[2], b1, 1.f / w11, w2n};
+  CRQ(k, 6) = (lf4){a2.g[0], a2.g[1], a2.g[2], a2.g[3]};
+  CRQ(k, 7) = (lf4){a2.g[4], a2.g[5], a2.u[0], a2.u[1]};
+  CRQ(k, 8) = (lf4){a2.u[2], b2, 1.f / w22, flags};
+  CRQ(k, 9) = (lf4){lam.x, lam.y, lam.z, bounce ? 1.f : 0.f};       // ([3]: the restitution branch was taken — contact signature)
   CRQ(k, 10) = (lf4){x.x, x.y, x.z, 0.f};
   CRQ(k, 11) = (lf4){n.x, n.y, n.z, 0.f};
 }
-struct Row3 { Row n, t1, t2; int legA, sb1; bool self; };
-DEV void contact_rows_load(const lf4* crl, int el, int k, Row3& R) {
-  const lf4 q0 = CRQ(k, 0), q1 = CRQ(k, 1), q2 = CRQ(k, 2), q3 = CRQ(k, 3), q4 = CRQ(k, 4), q5 = CRQ(k, 5), q6 = CRQ(k, 6);
-  R.n.g[0] = q0[0]; R.n.g[1] = q0[1]; R.n.g[2] = q0[2]; R.n.g[3] = q0[3]; R.n.g[4] = q1[0]; R.n.g[5] = q1[1];
-  R.n.u[0] = q1[2]; R.n.u[1] = q1[3]; R.n.u[2] = q2[0];
-  R.t1.g[0] = q2[1]; R.t1.g[1] = q2[2]; R.t1.g[2] = q2[3]; R.t1.g[3] = q3[0]; R.t1.g[4] = q3[1]; R.t1.g[5] = q3[2];
-  R.t1.u[0] = q3[3]; R.t1.u[1] = q4[0]; R.t1.u[2] = q4[1];
-  R.t2.g[0] = q4[2]; R.t2.g[1] = q4[3]; R.t2.g[2] = q5[0]; R.t2.g[3] = q5[1]; R.t2.g[4] = q5[2]; R.t2.g[5] = q5[3];
-  R.t2.u[0] = q6[0]; R.t2.u[1] = q6[1]; R.t2.u[2] = q6[2];
-  const int fl = (int)q6[3];
-  R.legA = fl & 7; R.self = (fl & 8) != 0; R.sb1 = fl >> 4;
+// the ten slots of a contact the sweep reads, and the packed-f32 arithmetic on them: v_pk_fma_f32 does two lanes' worth of FMAs
+// per issue slot, and the issue slot is what the sweep is bound by
+typedef __attribute__((ext_vector_type(2))) float f2;
+struct SweepRec { lf4 q[10]; };
+DEV void sweep_rec_load(const lf4* crl, int el, int k, SweepRec& r) {
+#pragma unroll
+  for (int q = 0; q < 10; q++) r.q[q] = CRQ(k, q);
+}
+DEV f2 lo2(lf4 v) { return (f2){v[0], v[1]}; }
+DEV f2 hi2(lf4 v) { return (f2){v[2], v[3]}; }
+DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+DEV f2 splat2(float x) { return (f2){x, x}; }
+struct SweepState { f2 z01, z23, z45, y01; float y2; };
+// a . s of row r (slots 3r .. 3r + 2): base part, and the leg part (to be masked by "the row is on my leg")
+DEV void sweep_row_dot(const SweepRec& R, int r, const SweepState& S, float& base, float& legpart) {
+  f2 acc = lo2(R.q[3 * r]) * S.z01;
+  acc = fma2(hi2(R.q[3 * r]), S.z23, acc);
+  acc = fma2(lo2(R.q[3 * r + 1]), S.z45, acc);
+  base = acc[0] + acc[1];
+  const f2 pu = hi2(R.q[3 * r + 1]) * S.y01;
+  legpart = fmaf(R.q[3 * r + 2][0], S.y2, pu[0] + pu[1]);
+}
+// s += d_r a_r for the three rows; m: 1 on the lane of the contact's leg, 0 elsewhere
+DEV void sweep_add_rows(const SweepRec& R, SweepState& S, float m, float d0, float d1, float d2) {
+  const f2 s0 = splat2(d0), s1 = splat2(d1), s2 = splat2(d2);
+  S.z01 = fma2(lo2(R.q[0]), s0, fma2(lo2(R.q[3]), s1, fma2(lo2(R.q[6]), s2, S.z01)));
+  S.z23 = fma2(hi2(R.q[0]), s0, fma2(hi2(R.q[3]), s1, fma2(hi2(R.q[6]), s2, S.z23)));
+  S.z45 = fma2(lo2(R.q[1]), s0, fma2(lo2(R.q[4]), s1, fma2(lo2(R.q[7]), s2, S.z45)));
+  const float m0 = m * d0, m1 = m * d1, m2 = m * d2;
+  S.y01 = fma2(hi2(R.q[1]), splat2(m0), fma2(hi2(R.q[4]), splat2(m1), fma2(hi2(R.q[7]), splat2(m2), S.y01)));
+  S.y2 = fmaf(R.q[2][0], m0, fmaf(R.q[5][0], m1, fmaf(R.q[8][0], m2, S.y2)));
 }
 
 // Finish the listed TERRAIN contact k of environment el from the item the master posted in its record (any lane may do this:
@@ -669,7 +691,8 @@ DEV void emit_terrain_contact(CfgRef cfg, const SolverLds& Z, int el, int k, flo
   V3 t1, t2;
   contact_frame(n, t1, t2, fault);
   float vs = fminf(-phi / h, cfg.max_depenetration_velocity);
-  if (un_pre < -cfg.bounce_threshold_velocity && -E.e_c * un_pre > vs) vs = -E.e_c * un_pre;
+  const bool bounce = un_pre < -cfg.bounce_threshold_velocity && -E.e_c * un_pre > vs;
+  if (bounce) vs = -E.e_c * un_pre;
   SV vb = sv(E.w_free, E.v_free);
 #pragma unroll
   for (int j = 0; j < 3; j++)
@@ -688,7 +711,7 @@ DEV void emit_terrain_contact(CfgRef cfg, const SolverLds& Z, int el, int k, flo
     row_finish(E.Li, g, uj, F.sD, a[r]);
   }
   contact_record_store(crl, el, k, a[0], a[1], a[2], cr_flags(depth < 0 ? 4 : leg, false, 0), dot(n, vp) - vs, dot(t1, vp), dot(t2, vp),
-                       row_dot(a[0], a[0]), row_dot(a[1], a[1]), row_dot(a[2], a[2]), row_dot(a[1], a[0]), row_dot(a[2], a[0]), lam, x, n, fault);
+                       row_dot(a[0], a[0]), row_dot(a[1], a[1]), row_dot(a[2], a[2]), row_dot(a[1], a[0]), row_dot(a[2], a[0]), lam, x, n, bounce, fault);
 }
 // terrain contacts k = k0, k0 + kstride, ... of environment el (K listed, nF .. nF + nS - 1 are self-contacts: the master's)
 DEV void emit_terrain_contacts(CfgRef cfg, const SolverLds& Z, int el, int k0, int kstride, float h) {
@@ -1039,7 +1062,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     if (leg == 0) {
       const int Kprev = (int)LDS(L_KL + 2);
 #pragma unroll 1
-      for (int k = K; k < Kprev; k++) { CRQ(k, 8) = (lf4){0.f, 0.f, 0.f, 0.f}; CRQ(k, 9) = (lf4){0.f, 0.f, 0.f, 0.f}; }
+      for (int k = K; k < Kprev; k++) { CRQ(k, 2) = CRQ(k, 5) = CRQ(k, 8) = CRQ(k, 9) = (lf4){0.f, 0.f, 0.f, 0.f}; }
       LDS(L_KL) = (float)K; LDS(L_KL + 2) = (float)K; LDS(L_KL + 3) = 0.f; LDS(L_KL + 4) = (float)nF; LDS(L_KL + 5) = (float)nS; LDS(L_KL + 6) = 0.f;
     }
   }
@@ -1216,7 +1239,8 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         const float un_pre = dot(n, (preA.l + cross(preA.a, x)) - (preB.l + cross(preB.a, x)));
         const V3 vrel = (freeA.l + cross(freeA.a, x)) - (freeB.l + cross(freeB.a, x));
         float vs = fminf(-c.phi / h, cfg.max_depenetration_velocity);
-        if (un_pre < -cfg.bounce_threshold_velocity && -s.rest * un_pre > vs) vs = -s.rest * un_pre;      // robot-robot: the robot's own material
+        const bool bounce = un_pre < -cfg.bounce_threshold_velocity && -s.rest * un_pre > vs;      // robot-robot: the robot's own material
+        if (bounce) vs = -s.rest * un_pre;
         Row a[3], ab[3];
         float wB[5] = {0.f, 0.f, 0.f, 0.f, 0.f};          // u_B . u_B terms: nn, t1t1, t2t2, t1n, t2n
         if (hi_ >= 0) {
@@ -1234,7 +1258,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         for (int r = 0; r < 3; r++) row_finish(E.Li, g[r], uj[r], F.sD, a[r]);
         contact_record_store(crl, el, k, a[0], a[1], a[2], cr_flags(leg, true, hi_ >= 0 ? sbi + 1 : 0), dot(n, vrel) - vs, dot(t1, vrel), dot(t2, vrel),
                              row_dot(a[0], a[0]) + wB[0], row_dot(a[1], a[1]) + wB[1], row_dot(a[2], a[2]) + wB[2],
-                             row_dot(a[1], a[0]) + wB[3], row_dot(a[2], a[0]) + wB[4], v3(0.f, 0.f, 0.f), x, n, fault);
+                             row_dot(a[1], a[0]) + wB[3], row_dot(a[2], a[0]) + wB[4], v3(0.f, 0.f, 0.f), x, n, bounce, fault);
       }
       if (on) { rank++; if (pid < 24) sbi++; }
     }
@@ -1268,6 +1292,12 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
   PROF(21);
   if (LDS(L_KL + 3) != 0.f) fault |= 1u << GO1_FAULT_CONTACT_FRAME;
   if (LDS(L_KL + 6) != 0.f) fault |= 1u << GO1_FAULT_W_DIAG;
+  if (SIG && B.contact_signature != nullptr && sub < GO1_SIG_MAX_SUBSTEPS && leg == 0) {      // which contacts took the restitution branch
+    uint32_t bh = 0;
+#pragma unroll 1
+    for (int k = 0; k < K; k++) if (CRQ(k, 9)[3] != 0.f) bh += (uint32_t)(k + 1) * 0x9E3779B1u;
+    AT(B.contact_signature, sub * GO1_SIG_WORDS + 3, e) += bh;
+  }
   const SolveBounds sm = solve_bounds(K, legact);
   const int Kw = sm.Kw;
   const unsigned LAw = sm.LAw;
@@ -1282,14 +1312,9 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
   float lamj[3] = {0.f, 0.f, 0.f};                                 // limit impulses of the own joints
 #ifndef GO1_ABLATE_PGS
   {
-    float z[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, y[3] = {0.f, 0.f, 0.f};
-    auto add_rows = [&](const Row3& R, float m, float d0, float d1, float d2) {
-#pragma unroll
-      for (int i = 0; i < 6; i++) z[i] = fmaf(R.n.g[i], d0, fmaf(R.t1.g[i], d1, fmaf(R.t2.g[i], d2, z[i])));
-      const float m0 = m * d0, m1 = m * d1, m2 = m * d2;
-#pragma unroll
-      for (int i = 0; i < 3; i++) y[i] = fmaf(R.n.u[i], m0, fmaf(R.t1.u[i], m1, fmaf(R.t2.u[i], m2, y[i])));
-    };
+    SweepState st;
+    st.z01 = st.z23 = st.z45 = st.y01 = splat2(0.f);
+    st.y2 = 0.f;
     // B side of a leg-leg self-contact: u_B of the three rows and its leg
     struct RowB { float u[3][3]; int legB; };
     auto load_b = [&](int sb1, RowB& Bq) {
@@ -1303,57 +1328,68 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     // warm start: the state of the starting impulses (self-contacts and limit rows start from zero)
 #pragma unroll 1
     for (int k = 0; k < Kw; k++) {
-      Row3 R;
-      contact_rows_load(crl, el, k, R);
-      const lf4 q9 = CRQ(k, 9);
-      add_rows(R, R.legA == leg ? 1.f : 0.f, q9[1], q9[2], q9[3]);
+      SweepRec R;
+      sweep_rec_load(crl, el, k, R);
+      sweep_add_rows(R, st, (((int)R.q[8][3]) & 7) == leg ? 1.f : 0.f, R.q[9][0], R.q[9][1], R.q[9][2]);
     }
     PROF(23);
+    // one contact's turn (its record already in registers)
+    auto contact_turn = [&](int k, const SweepRec& R) {
+      const int fl = (int)R.q[8][3];
+      const int legA = fl & 7, sb1 = fl >> 4;
+      const bool self = (fl & 8) != 0;
+      const float m = legA == leg ? 1.f : 0.f;
+      float dn, d1, d2, pn, p1, p2;
+      sweep_row_dot(R, 0, st, dn, pn);
+      sweep_row_dot(R, 1, st, d1, p1);
+      sweep_row_dot(R, 2, st, d2, p2);
+      pn *= m; p1 *= m; p2 *= m;
+      RowB Bq;
+      float mB = 0.f;
+      const bool anyB = __ballot(sb1 > 0) != 0ull;                    // leg-leg self-contact somewhere in the wavefront at this slot
+      if (anyB) {
+        load_b(sb1, Bq);
+        mB = (sb1 > 0 && Bq.legB == leg) ? 1.f : 0.f;
+        const float y0 = st.y01[0], y1 = st.y01[1];
+        pn = fmaf(mB, fmaf(Bq.u[0][0], y0, fmaf(Bq.u[0][1], y1, Bq.u[0][2] * st.y2)), pn);
+        p1 = fmaf(mB, fmaf(Bq.u[1][0], y0, fmaf(Bq.u[1][1], y1, Bq.u[1][2] * st.y2)), p1);
+        p2 = fmaf(mB, fmaf(Bq.u[2][0], y0, fmaf(Bq.u[2][1], y1, Bq.u[2][2] * st.y2)), p2);
+      }
+      const float un = R.q[2][1] + dn + quad_sum(pn);                 // = u_n - v*
+      float u1 = R.q[5][1] + d1 + quad_sum(p1), u2 = R.q[8][1] + d2 + quad_sum(p2);
+      const float ln_old = R.q[9][0];
+      const float ln = fmaxf(0.f, ln_old - un * R.q[2][2]);
+      const float dln = ln - ln_old;
+      u1 = fmaf(R.q[2][3], dln, u1);                                   // the tangential rows see the updated normal impulse
+      u2 = fmaf(R.q[5][3], dln, u2);
+      float l1 = R.q[9][1] - u1 * R.q[5][2];
+      float l2 = R.q[9][2] - u2 * R.q[8][2];
+      const float lim = (self ? s.mu : mu_s) * ln, nn = l1 * l1 + l2 * l2;      // robot-robot: the robot's own material
+      if (nn > lim * lim) { const float sc = (self ? s.mu : mu_d) * ln * __builtin_amdgcn_rsqf(nn); l1 *= sc; l2 *= sc; }
+      const float e1 = l1 - R.q[9][1], e2 = l2 - R.q[9][2];
+      sweep_add_rows(R, st, m, dln, e1, e2);
+      if (anyB) {
+        const float m0 = mB * dln, m1 = mB * e1, m2 = mB * e2;
+        st.y01[0] = fmaf(Bq.u[0][0], m0, fmaf(Bq.u[1][0], m1, fmaf(Bq.u[2][0], m2, st.y01[0])));
+        st.y01[1] = fmaf(Bq.u[0][1], m0, fmaf(Bq.u[1][1], m1, fmaf(Bq.u[2][1], m2, st.y01[1])));
+        st.y2 = fmaf(Bq.u[0][2], m0, fmaf(Bq.u[1][2], m1, fmaf(Bq.u[2][2], m2, st.y2)));
+      }
+      if (leg == 0) CRQ(k, 9) = (lf4){ln, l1, l2, 0.f};
+    };
 #pragma unroll 1
     for (int it = 0; it < cfg.solver_iterations; it++) {
+      // two records in flight: the next contact's ten slots are requested before the current contact's arithmetic starts
+      // (one wavefront per SIMD: nothing else hides the LDS round trip)
+      SweepRec RA, RB;
+      if (Kw > 0) sweep_rec_load(crl, el, 0, RA);
 #pragma unroll 1
-      for (int k = 0; k < Kw; k++) {
-        Row3 R;
-        contact_rows_load(crl, el, k, R);
-        const lf4 q7 = CRQ(k, 7), q8 = CRQ(k, 8), q9 = CRQ(k, 9);
-        const float m = R.legA == leg ? 1.f : 0.f;
-        float dn = q7[0], d1 = q7[1], d2 = q7[2];
-#pragma unroll
-        for (int i = 0; i < 6; i++) { dn = fmaf(R.n.g[i], z[i], dn); d1 = fmaf(R.t1.g[i], z[i], d1); d2 = fmaf(R.t2.g[i], z[i], d2); }
-        float pn = 0.f, p1 = 0.f, p2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; i++) { pn = fmaf(R.n.u[i], y[i], pn); p1 = fmaf(R.t1.u[i], y[i], p1); p2 = fmaf(R.t2.u[i], y[i], p2); }
-        pn *= m; p1 *= m; p2 *= m;
-        RowB Bq;
-        float mB = 0.f;
-        const bool anyB = __ballot(R.sb1 > 0) != 0ull;                  // leg-leg self-contact somewhere in the wavefront at this slot
-        if (anyB) {
-          load_b(R.sb1, Bq);
-          mB = (R.sb1 > 0 && Bq.legB == leg) ? 1.f : 0.f;
-          float bn = 0.f, b1 = 0.f, b2 = 0.f;
-#pragma unroll
-          for (int i = 0; i < 3; i++) { bn = fmaf(Bq.u[0][i], y[i], bn); b1 = fmaf(Bq.u[1][i], y[i], b1); b2 = fmaf(Bq.u[2][i], y[i], b2); }
-          pn = fmaf(mB, bn, pn); p1 = fmaf(mB, b1, p1); p2 = fmaf(mB, b2, p2);
+      for (int k = 0; k < Kw; k += 2) {
+        if (k + 1 < Kw) sweep_rec_load(crl, el, k + 1, RB);
+        contact_turn(k, RA);
+        if (k + 1 < Kw) {
+          if (k + 2 < Kw) sweep_rec_load(crl, el, k + 2, RA);
+          contact_turn(k + 1, RB);
         }
-        const float un = dn + quad_sum(pn);                              // = u_n - v*
-        float u1 = d1 + quad_sum(p1), u2 = d2 + quad_sum(p2);
-        const float ln_old = q9[1];
-        const float ln = fmaxf(0.f, ln_old - un * q8[0]);
-        const float dln = ln - ln_old;
-        u1 = fmaf(q8[3], dln, u1);                                       // the tangential rows see the updated normal impulse
-        u2 = fmaf(q9[0], dln, u2);
-        float l1 = q9[2] - u1 * q8[1];
-        float l2 = q9[3] - u2 * q8[2];
-        const float lim = (R.self ? s.mu : mu_s) * ln, nn = l1 * l1 + l2 * l2;      // robot-robot: the robot's own material
-        if (nn > lim * lim) { const float sc = (R.self ? s.mu : mu_d) * ln * __builtin_amdgcn_rsqf(nn); l1 *= sc; l2 *= sc; }
-        const float e1 = l1 - q9[2], e2 = l2 - q9[3];
-        add_rows(R, m, dln, e1, e2);
-        if (anyB) {
-          const float m0 = mB * dln, m1 = mB * e1, m2 = mB * e2;
-#pragma unroll
-          for (int i = 0; i < 3; i++) y[i] = fmaf(Bq.u[0][i], m0, fmaf(Bq.u[1][i], m1, fmaf(Bq.u[2][i], m2, y[i])));
-        }
-        if (leg == 0) CRQ(k, 9) = (lf4){q9[0], ln, l1, l2};
       }
       // limit rows in joint order: the rate without the row's own impulse is projected on [lower, upper]
 #pragma unroll
@@ -1364,19 +1400,22 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
             const int j = 3 * lgi + jj;
             const lf4 r0 = JRQ(j, 0), r1 = JRQ(j, 1), r2 = JRQ(j, 2), r3 = JRQ(j, 3);
             const bool rowon = (lact >> lgi) & 1u;
-            float u = r2[1];
-            u = fmaf(r0[0], z[0], u); u = fmaf(r0[1], z[1], u); u = fmaf(r0[2], z[2], u); u = fmaf(r0[3], z[3], u); u = fmaf(r1[0], z[4], u); u = fmaf(r1[1], z[5], u);
-            const float pj = fmaf(r1[2], y[0], fmaf(r1[3], y[1], r2[0] * y[2]));
+            f2 acc = lo2(r0) * st.z01;
+            acc = fma2(hi2(r0), st.z23, acc);
+            acc = fma2(lo2(r1), st.z45, acc);
+            const f2 pu = hi2(r1) * st.y01;
+            float u = r2[1] + acc[0] + acc[1];
+            const float pj = fmaf(r2[0], st.y2, pu[0] + pu[1]);
             u += quad_bcast(pj, lgi);
             const float lold = quad_bcast(lamj[jj], lgi);
             const float u0 = u - r3[0] * lold;
             const float ut = fminf(fmaxf(u0, r2[2]), r2[3]);
             const float ln = rowon ? (ut - u0) * r3[1] : 0.f;
             const float dl = rowon ? ln - lold : 0.f;
-            z[0] = fmaf(r0[0], dl, z[0]); z[1] = fmaf(r0[1], dl, z[1]); z[2] = fmaf(r0[2], dl, z[2]);
-            z[3] = fmaf(r0[3], dl, z[3]); z[4] = fmaf(r1[0], dl, z[4]); z[5] = fmaf(r1[1], dl, z[5]);
+            const f2 sd = splat2(dl);
+            st.z01 = fma2(lo2(r0), sd, st.z01); st.z23 = fma2(hi2(r0), sd, st.z23); st.z45 = fma2(lo2(r1), sd, st.z45);
             if (leg == lgi) {
-              y[0] = fmaf(r1[2], dl, y[0]); y[1] = fmaf(r1[3], dl, y[1]); y[2] = fmaf(r2[0], dl, y[2]);
+              st.y01 = fma2(hi2(r1), sd, st.y01); st.y2 = fmaf(r2[0], dl, st.y2);
               lamj[jj] = ln;
             }
           }
@@ -1386,10 +1425,11 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     }
     {
       float nf_acc = 0.f;
+      nf_acc = nonfinite_acc(nf_acc, st.z01[0]); nf_acc = nonfinite_acc(nf_acc, st.z01[1]); nf_acc = nonfinite_acc(nf_acc, st.z23[0]);
+      nf_acc = nonfinite_acc(nf_acc, st.z23[1]); nf_acc = nonfinite_acc(nf_acc, st.z45[0]); nf_acc = nonfinite_acc(nf_acc, st.z45[1]);
+      nf_acc = nonfinite_acc(nf_acc, st.y01[0]); nf_acc = nonfinite_acc(nf_acc, st.y01[1]); nf_acc = nonfinite_acc(nf_acc, st.y2);
 #pragma unroll
-      for (int i = 0; i < 6; i++) nf_acc = nonfinite_acc(nf_acc, z[i]);
-#pragma unroll
-      for (int i = 0; i < 3; i++) { nf_acc = nonfinite_acc(nf_acc, y[i]); nf_acc = nonfinite_acc(nf_acc, lamj[i]); }
+      for (int i = 0; i < 3; i++) nf_acc = nonfinite_acc(nf_acc, lamj[i]);
       if (nf_acc != nf_acc) fault |= 1u << GO1_FAULT_LAMBDA;
     }
   }
@@ -1410,7 +1450,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     V3 t1, t2;
     contact_frame(n, t1, t2, fault);
     x = v3(q10[0], q10[1], q10[2]);
-    return q9[1] * n + q9[2] * t1 + q9[3] * t2;
+    return q9[0] * n + q9[1] * t1 + q9[2] * t2;
   };
   SV contrib = sv(v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f));       // wrench of the impulses acting directly on the base
   V3 ftrunk = v3(0.f, 0.f, 0.f);                                //   and the impulse booked on the trunk
@@ -1443,7 +1483,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         const SV ff = sv(cross(x, f), f);
         if (sdepth[i] == 1) { pAq[1] = pAq[1] - ff; fbody[1] = fbody[1] + f; }        // booked on the thigh / the calf (penalised bodies:
         else { pAq[2] = pAq[2] - ff; fbody[2] = fbody[2] + f; }                        //  the collision reward sees it, corl_rewards.py:49-52)
-        const bool trunk_pair = (((int)CRQ(sslot[i], 6)[3]) & 0x78) == 8;              // self, no B record: the trunk is body B
+        const bool trunk_pair = (((int)CRQ(sslot[i], 8)[3]) & 0x78) == 8;              // self, no B record: the trunk is body B
         if (trunk_pair) { contrib = contrib + ff; ftrunk = ftrunk - f; }
       }
     }
