@@ -531,7 +531,9 @@ def test_full_step_on_height_field(walls):
         sim.step(torch.from_numpy(a).cuda())
         torch.cuda.synchronize()
         cpu_reset = Bc.reset_buf.bool()
-        keys = (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
+        # (root 2e-3 here: on the relief the contact normals are the bilinear interpolant's gradient AT the contact point, so a
+        #  round-off sized shift of the point tilts the whole contact frame — the flat-terrain tests keep 1e-3)
+        keys = (("root_states", 2e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
                 ("torques", 5e-3, 1e-3), ("foot_positions", 1e-3, 0), ("measured_heights", 1e-3, 0))
         # A scan point within round-off of a cell boundary reads the neighbouring sample in fp32 (legged_robot.py:1793-1806 floors
         # (x + border) / scale): environments whose ONLY differences are a few of the 187 scan heights (and their observation

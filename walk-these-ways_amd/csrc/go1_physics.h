@@ -402,10 +402,10 @@ DEV void cand_init(Cand& c) { c.phi = 1e30f; c.x = c.y = c.z = c.un = 0.f; c.nx 
 // next to the point: unit horizontal normal (towards the low side), horizontal distance, height of its upper edge
 // (oracle terrain_sample(): the `trimesh` terrain's slope_treshold restated per cell of the height field).
 struct Wall { bool on; V3 n; float d, top; int cell; };
-template <bool WALLS>
+template <bool WALLS, bool PLANE = false>
 DEV void terrain_sample(CfgRef cfg, const int16_t* __restrict__ hs, float x, float y, float& h, V3& n, Wall& wall) {
   wall.on = false; wall.n = v3(1.f, 0.f, 0.f); wall.d = 0.f; wall.top = 0.f; wall.cell = 0;
-  if (cfg.terrain_type == 0 || hs == nullptr) { h = 0.f; n = v3(0.f, 0.f, 1.f); return; }
+  if (PLANE || cfg.terrain_type == 0 || hs == nullptr) { h = 0.f; n = v3(0.f, 0.f, 1.f); return; }
   float fx = (x + cfg.hf_border) / cfg.hf_hscale, fy = (y + cfg.hf_border) / cfg.hf_hscale;
   fx = fminf(fmaxf(fx, 0.f), (float)cfg.hf_rows - 1.000001f);
   fy = fminf(fmaxf(fy, 0.f), (float)cfg.hf_cols - 1.000001f);
@@ -456,12 +456,12 @@ DEV void terrain_sample(CfgRef cfg, const int16_t* __restrict__ hs, float x, flo
 // x: candidate point relative to the base origin (world axes); bpos: world position of the base origin.  c: deepest
 // top-surface candidate of the point's group, cw: closest wall candidate of its shape
 // WANTW: also keep the wall candidate (hip capsules do not: their points are too high up to meet a riser)
-template <bool WALLS, bool WANTW = WALLS>
+template <bool WALLS, bool WANTW = WALLS, bool PLANE = false>
 DEV void cand_try(CfgRef cfg, const int16_t* __restrict__ hs, Cand& c, Cand& cw, V3 x, V3 bpos, float radius, SV vb, int m) {
   float h;
   V3 n;
   Wall wl;
-  terrain_sample<WALLS>(cfg, hs, bpos.x + x.x, bpos.y + x.y, h, n, wl);
+  terrain_sample<WALLS, PLANE>(cfg, hs, bpos.x + x.x, bpos.y + x.y, h, n, wl);
   const float phi = (bpos.z + x.z) - radius - h;
   if (phi < c.phi) {
     const V3 xs = x - radius * n;               // contact point on the shape surface
@@ -744,7 +744,9 @@ DEV int leg_pair_index(int lo, int hi) { return lo == 0 ? hi - 1 : lo == 1 ? hi 
 // acth != nullptr: the torques of this substep are being evaluated by the helper wavefronts (torque_publish was called, the
 // workgroup barrier behind it passed): they are picked up right before ABA pass 2.
 // The helper wavefronts (nw > 1, always) run emit_terrain_contacts() between the two workgroup barriers of the emission hand-over.
-template <bool WALLS, bool SIG>
+// PLANE: the terrain is the plane z = 0 (terrain_type 0; never with WALLS): no height samples, and the deepest corner of a box end
+// is known from the signs of the box axes' z components — one candidate per end instead of four
+template <bool WALLS, bool SIG, bool PLANE>
 DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int nw, Base& s, Leg& L, V3 grav,
                          bool use_warm, float h, uint32_t& fault, const float* acth, int e, int N, int sub PROF_PARAM) {
   float* const lds = Z.lds;
@@ -780,7 +782,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     cand_init(cb[mm]);
     const int m = 2 * leg + mm;
     V3 l = v3((m & 1 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[2]);
-    cand_try<WALLS>(cfg, hs, cb[mm], cwb, mul(R0, l), s.pos, 0.f, v0, m);
+    cand_try<WALLS, WALLS, PLANE>(cfg, hs, cb[mm], cwb, mul(R0, l), s.pos, 0.f, v0, m);
   }
   if (WALLS) cand_min_dpp(cwb, lane);
 
@@ -834,28 +836,43 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
 #pragma unroll
       for (int m = 0; m < 2; m++) {
         V3 l = v3(hc.x, hc.y + (m ? 1.f : -1.f) * (float)GO1_HIP_CAPSULE_HALF, hc.z);
-        cand_try<WALLS, false>(cfg, hs, ch[m], nowall, p[0] + mul(R[0], l), s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0], m);      // (same top surface as every other shape)
+        cand_try<WALLS, false, PLANE>(cfg, hs, ch[m], nowall, p[0] + mul(R[0], l), s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0], m);      // (same top surface as every other shape)
       }
 #ifndef GO1_ABLATE_CAND
 #pragma unroll
       for (int en = 0; en < 2; en++) {       // thigh / calf boxes: long axis z -> ends by the sign of z (corner bit 2)
+        if (PLANE) {
+          // on the plane the deepest corner of an end minimises z = ... + sx hx R.c0.z + sy hy R.c1.z: sx = -sign(R.c0.z), sy likewise
+          // (ties: the lower corner index, i.e. the negative sign — the order the scan over the corners resolves them in)
+          const int mt = (R[1].c0.z < 0.f ? 1 : 0) | (R[1].c1.z < 0.f ? 2 : 0) | (4 * en);
+          const int mk = (R[2].c0.z < 0.f ? 1 : 0) | (R[2].c1.z < 0.f ? 2 : 0) | (4 * en);
+          const V3 lt = v3(GO1_THIGH_BOX_CENTER[0] + (mt & 1 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[0],
+                           GO1_THIGH_BOX_CENTER[1] + (mt & 2 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[1],
+                           GO1_THIGH_BOX_CENTER[2] + (mt & 4 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[2]);
+          const V3 lk = v3(GO1_CALF_BOX_CENTER[0] + (mk & 1 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[0],
+                           GO1_CALF_BOX_CENTER[1] + (mk & 2 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[1],
+                           GO1_CALF_BOX_CENTER[2] + (mk & 4 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[2]);
+          cand_try<false, false, true>(cfg, hs, ct[en], cwt, p[1] + mul(R[1], lt), s.pos, 0.f, v[1], mt);
+          cand_try<false, false, true>(cfg, hs, ck[en], cwk, p[2] + mul(R[2], lk), s.pos, 0.f, v[2], mk);
+        } else {
 #pragma unroll 1
-        for (int m = 4 * en; m < 4 * en + 4; m++) {
-          V3 l = v3(GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[0],
-                    GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[1],
-                    GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[2]);
-          cand_try<WALLS>(cfg, hs, ct[en], cwt, p[1] + mul(R[1], l), s.pos, 0.f, v[1], m);
-        }
+          for (int m = 4 * en; m < 4 * en + 4; m++) {
+            V3 l = v3(GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[0],
+                      GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[1],
+                      GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[2]);
+            cand_try<WALLS>(cfg, hs, ct[en], cwt, p[1] + mul(R[1], l), s.pos, 0.f, v[1], m);
+          }
 #pragma unroll 1
-        for (int m = 4 * en; m < 4 * en + 4; m++) {
-          V3 l = v3(GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[0],
-                    GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[1],
-                    GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[2]);
-          cand_try<WALLS>(cfg, hs, ck[en], cwk, p[2] + mul(R[2], l), s.pos, 0.f, v[2], m);
+          for (int m = 4 * en; m < 4 * en + 4; m++) {
+            V3 l = v3(GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[0],
+                      GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[1],
+                      GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[2]);
+            cand_try<WALLS>(cfg, hs, ck[en], cwk, p[2] + mul(R[2], l), s.pos, 0.f, v[2], m);
+          }
         }
       }
 #endif
-      cand_try<WALLS>(cfg, hs, cf, cwf, p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2], 0);
+      cand_try<WALLS, WALLS, PLANE>(cfg, hs, cf, cwf, p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2], 0);
       pthigh = p[1]; pknee = p[2]; pfoot = p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg));
       vthigh = v[1]; vlow = v[2];
     }

@@ -78,7 +78,7 @@ DEV void report_fault(BufRef B, int e, uint32_t fault) {
 #ifndef STEP_WAVES
 #define STEP_WAVES 4
 #endif
-template <bool WALLS, bool SIG>
+template <bool WALLS, bool SIG, bool PLANE>
 DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, float* acth) {
   const int nw = STEP_WAVES, wv = WAVE_UNIFORM((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63, leg = lane & 3;
   for (int i = threadIdx.x; i < L_END * EPW; i += WAVE * STEP_WAVES) lds[i] = 0.f;
@@ -181,7 +181,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
     PROF(1);
     head = (head + 1) % nl;
 #ifndef GO1_ABLATE_PHYSICS
-    physics_substep<WALLS, SIG>(cfg, B, Z, lane, nw, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault, deferred ? acth : nullptr, e, N, sub PROF_PASS);
+    physics_substep<WALLS, SIG, PLANE>(cfg, B, Z, lane, nw, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault, deferred ? acth : nullptr, e, N, sub PROF_PASS);
 #endif
   }
   if (deferred) torque_stash_store(cfg, B, L, acth, lane, leg, e, N);
@@ -203,11 +203,15 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   __shared__ __attribute__((aligned(16))) lf4 ldsx[X_END]; \
   __shared__ __attribute__((aligned(16))) float act_lds[A_END]; \
   __shared__ float acth[AH_END * WAVE];          /* per-lane stash of the deferred torque path (torque_stash_load) */
-extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel(const StepArgs A) { STEP_LDS step_body<false, false>(A, lds, ldsx, act_lds, acth); }
-extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel_walls(const StepArgs A) { STEP_LDS step_body<true, false>(A, lds, ldsx, act_lds, acth); }
-// the same with the contact signature recorded (Go1SimBuffers.contact_signature != NULL: parity tests)
-extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel_sig(const StepArgs A) { STEP_LDS step_body<false, true>(A, lds, ldsx, act_lds, acth); }
-extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) go1_step_kernel_walls_sig(const StepArgs A) { STEP_LDS step_body<true, true>(A, lds, ldsx, act_lds, acth); }
+// instances: terrain (plane | height field | height field with vertical faces) x (plain | contact signature recorded: parity tests)
+#define STEP_KERNEL(name, WALLS, SIG, PLANE) \
+  extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) name(const StepArgs A) { STEP_LDS step_body<WALLS, SIG, PLANE>(A, lds, ldsx, act_lds, acth); }
+STEP_KERNEL(go1_step_kernel, false, false, true)
+STEP_KERNEL(go1_step_kernel_hf, false, false, false)
+STEP_KERNEL(go1_step_kernel_walls, true, false, false)
+STEP_KERNEL(go1_step_kernel_sig, false, true, true)
+STEP_KERNEL(go1_step_kernel_hf_sig, false, true, false)
+STEP_KERNEL(go1_step_kernel_walls_sig, true, true, false)
 
 // piecewise entry points with the 4-lane mapping (parity tests): torques only / tensor maps only (a single physics substep is
 // mode 2 of the step kernels: the production structure, master + helper wavefronts)
@@ -431,11 +435,11 @@ static int launch(Go1Sim* s, int mode, const float* actions, const int32_t* ids,
   const int slot = timed ? (int)(s->timing_n % s->timing_cap) : 0;
   if (timed) (void)hipEventRecord(s->ev[2 * slot], st);
   if (mode == 0 || mode == 2) {
-    const bool walls = s->cfg.terrain_type != 0 && s->cfg.hf_wall_units > 0, sig = s->buf.contact_signature != nullptr;
-    if (walls && sig) hipLaunchKernelGGL(go1_step_kernel_walls_sig, grid, block, 0, st, A);
-    else if (walls) hipLaunchKernelGGL(go1_step_kernel_walls, grid, block, 0, st, A);
-    else if (sig) hipLaunchKernelGGL(go1_step_kernel_sig, grid, block, 0, st, A);
-    else hipLaunchKernelGGL(go1_step_kernel, grid, block, 0, st, A);
+    const bool hf = s->cfg.terrain_type != 0 && s->buf.height_samples != nullptr, walls = hf && s->cfg.hf_wall_units > 0;
+    const bool sig = s->buf.contact_signature != nullptr;
+    if (walls) { if (sig) hipLaunchKernelGGL(go1_step_kernel_walls_sig, grid, block, 0, st, A); else hipLaunchKernelGGL(go1_step_kernel_walls, grid, block, 0, st, A); }
+    else if (hf) { if (sig) hipLaunchKernelGGL(go1_step_kernel_hf_sig, grid, block, 0, st, A); else hipLaunchKernelGGL(go1_step_kernel_hf, grid, block, 0, st, A); }
+    else { if (sig) hipLaunchKernelGGL(go1_step_kernel_sig, grid, block, 0, st, A); else hipLaunchKernelGGL(go1_step_kernel, grid, block, 0, st, A); }
   }
   else if (mode == 3) hipLaunchKernelGGL(go1_env_kernel, grid, block, 0, st, A);
   else hipLaunchKernelGGL(go1_aux_kernel, grid, block, 0, st, A);
