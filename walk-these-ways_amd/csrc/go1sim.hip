@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/go1sim.h"
 #include "go1_math.h"
@@ -435,7 +436,8 @@ static int launch(Go1Sim* s, int mode, const float* actions, const int32_t* ids,
   const int slot = timed ? (int)(s->timing_n % s->timing_cap) : 0;
   if (timed) (void)hipEventRecord(s->ev[2 * slot], st);
   if (mode == 0 || mode == 2) {
-    const bool hf = s->cfg.terrain_type != 0 && s->buf.height_samples != nullptr, walls = hf && s->cfg.hf_wall_units > 0;
+    static const bool force_hf = getenv("GO1_FORCE_HF_INSTANCE") != nullptr;        // A/B of the plane instance (tools/variant_bench.sh)
+    const bool hf = force_hf || (s->cfg.terrain_type != 0 && s->buf.height_samples != nullptr), walls = hf && s->cfg.terrain_type != 0 && s->cfg.hf_wall_units > 0;
     const bool sig = s->buf.contact_signature != nullptr;
     if (walls) { if (sig) hipLaunchKernelGGL(go1_step_kernel_walls_sig, grid, block, 0, st, A); else hipLaunchKernelGGL(go1_step_kernel_walls, grid, block, 0, st, A); }
     else if (hf) { if (sig) hipLaunchKernelGGL(go1_step_kernel_hf_sig, grid, block, 0, st, A); else hipLaunchKernelGGL(go1_step_kernel_hf, grid, block, 0, st, A); }
