@@ -371,10 +371,9 @@ static void terrain_sample(const Terrain* t, real x, real y, real* h, real* n, W
  * Self-collision (asset self_collisions = 0: nothing filtered, go1_config.py:44, legged_robot.py:1563-1564): capsules —
  * lower leg (knee -> foot centre, radius of the foot sphere), thigh (thigh joint -> knee, GO1_SELF_THIGH_RADIUS), trunk (the
  * box's long axis, radius = its half width) — lower legs and thighs of DIFFERENT legs against each other (24 pairs) and
- * lower legs against the trunk (4); closest points of the two segments, one contact per pair.  Not modelled: pairs within one
- * leg and the hip capsules (mechanically out of reach within the joint limits).
- * Solver list: at most GO1_MAX_CONTACTS, in the priority order feet, foot walls, self-contacts (at most GO1_MAX_SELF_LEG_PAIRS
- * leg-leg), trunk, trunk wall, calves (first points, walls, second points), thighs (same), hips; what does not fit is dropped
+ * lower legs against the trunk (4); closest points of the two segments; two legs touch in ONE point (the deepest of their four
+ * capsule combinations).  Not modelled: pairs within one leg and the hip capsules (mechanically out of reach within the joint limits).
+ * Solver list: at most GO1_MAX_CONTACTS, in the priority order feet, foot walls, self-contacts (at most 6 leg-leg), trunk, trunk wall, calves (first points, walls, second points), thighs (same), hips; what does not fit is dropped
  * and counted per class. */
 typedef struct { real phi, x[3], n[3]; int valid; uint32_t tag; } Cand;   /* tag: 16 * height-field cell + candidate point index */
 typedef struct {
@@ -448,7 +447,6 @@ static void seg_seg(const real* p1, const real* q1, const real* p2, const real* 
 
 #define GO1_SELF_LEG_RADIUS GO1_FOOT_RADIUS
 #define GO1_SELF_THIGH_RADIUS 0.017    /* half of the thigh box's larger cross-section side (urdf: 0.0245 x 0.034) */
-#define GO1_MAX_SELF_LEG_PAIRS 4
 #define GO1_MAX_TRUNK_POINTS 4
 #define GO1_LIMIT_RECOVERY_RATE 10.0   /* rad/s */
 #define GO1_LIMIT_SAFETY 2.0           /* x velocity limit */
@@ -525,11 +523,16 @@ static ContactList detect_contacts(const Go1SimConfig* cfg, const Terrain* ter, 
     real a = GO1_TRUNK_BOX_HALF[0] - GO1_TRUNK_BOX_HALF[1], la[3] = {-a, 0, 0}, lb[3] = {a, 0, 0};
     m3v(TA, k->R[0], la); m3v(TB, k->R[0], lb);
   }
-  int legpairs = 0;
+  /* pid = 6 * type + pair for the leg-leg pairs: type 0 lower-lower, 1 lower(i)-thigh(j), 2 thigh(i)-lower(j), 3 thigh-thigh,
+   * pair (i, j) in the order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); pid 24 + leg: lower leg against the trunk.  Two legs touch in ONE
+   * point: of the four capsule combinations of a pair of legs only the deepest is a contact (ties: the lower type), so at most six
+   * leg-leg contacts exist and none is ever dropped for lack of a slot of its own. */
+  static const int PI_[6] = {0, 0, 0, 1, 1, 2}, PJ_[6] = {1, 2, 3, 2, 3, 3};
+  int best_type[6];
+  Contact pairc[28];
+  int pair_on[28] = {0};
+  for (int pr = 0; pr < 6; pr++) best_type[pr] = -1;
   for (int pid = 0; pid < (cfg->self_collision ? 28 : 0); pid++) {
-    /* pid = 6 * type + pair for the leg-leg pairs: type 0 lower-lower, 1 lower(i)-thigh(j), 2 thigh(i)-lower(j), 3 thigh-thigh,
-     * pair (i, j) in the order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); pid 24 + leg: lower leg against the trunk */
-    static const int PI_[6] = {0, 0, 0, 1, 1, 2}, PJ_[6] = {1, 2, 3, 2, 3, 3};
     const int type = pid < 24 ? pid / 6 : 0, i = pid < 24 ? PI_[pid % 6] : pid - 24, j = pid < 24 ? PJ_[pid % 6] : -1;
     const int sa = (type >> 1) & 1, sb = type & 1;          /* segment of body A / B: 0 lower leg, 1 thigh */
     real c1[3], c2[3], d[3];
@@ -541,14 +544,22 @@ static ContactList detect_contacts(const Go1SimConfig* cfg, const Terrain* ter, 
     if (!(dist > (real)1e-6)) continue;
     real phi = dist - ra - rb;
     if (!(phi < cd)) continue;
-    if (j >= 0 && ++legpairs > GO1_MAX_SELF_LEG_PAIRS) { L.dropped[GO1_CC_SELF]++; L.sig[1] |= 1u << 31; continue; }
     Contact t;
     t.repA = 1 + 4 * i + (sa ? 1 : 2); t.dynA = 3 * i + (sa ? 2 : 3);
     t.repB = j >= 0 ? 1 + 4 * j + (sb ? 1 : 2) : 0; t.dynB = j >= 0 ? 3 * j + (sb ? 2 : 3) : 0;
     t.phi = phi; t.share = 0; t.cls = GO1_CC_SELF; t.top = 0;
     for (int q = 0; q < 3; q++) { t.n[q] = d[q] / dist; t.x[q] = c2[q] + t.n[q] * (rb + (real)0.5 * phi); }
-    add_contact(list, &L, &t, 2, pid);
+    pairc[pid] = t;
+    if (j < 0) { pair_on[pid] = 1; continue; }
+    const int pr = pid % 6;
+    if (best_type[pr] < 0 || phi < pairc[6 * best_type[pr] + pr].phi) {
+      if (best_type[pr] >= 0) pair_on[6 * best_type[pr] + pr] = 0;
+      best_type[pr] = type;
+      pair_on[pid] = 1;
+    }
   }
+  for (int pid = 0; pid < 28; pid++)
+    if (pair_on[pid]) add_contact(list, &L, &pairc[pid], 2, pid);
   /* remaining shapes */
 #define FIRST(c) (((c)[1].valid && (!(c)[0].valid || (c)[1].phi < (c)[0].phi)) ? 1 : 0)
   {

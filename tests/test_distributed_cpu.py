@@ -90,7 +90,7 @@ def test_two_rank_gloo_update_keeps_replicas_identical(grad_dtype, zero1, world)
 
 
 # ---- one global command curriculum over sharded environments ---------------------------------------------
-def _curriculum_run(rank, world, n_local, steps):
+def _curriculum_run(rank, world, n_local, steps, interval=1):
     """LeggedRobot.step on the oracle-backed stand-in (tests/fake_sim.py): `world` shards of `n_local` envs, or one run
     over all of them.  Per-env inputs are functions of the GLOBAL env id, so only the sharding differs."""
     import types
@@ -106,6 +106,7 @@ def _curriculum_run(rank, world, n_local, steps):
     cfg.env.env_id_offset = rank * n_local
     cfg.terrain.mesh_type = "plane"
     cfg.commands.resampling_time = 0.16                                  # 8 steps: many interval resamples
+    cfg.commands.curriculum_update_interval = interval                   # steps between weight updates (= between exchanges when sharded)
     for k in ("tracking_lin_vel", "tracking_ang_vel", "tracking_contacts_shaped_force", "tracking_contacts_shaped_vel"):
         setattr(cfg.curriculum_thresholds, k, 0.05)                      # successes do happen under random actions
     torch.manual_seed(0)
@@ -127,30 +128,34 @@ def _curriculum_run(rank, world, n_local, steps):
                 sync=env._curriculum_sync)
 
 
-def _curriculum_worker(rank, world, port, out):
+def _curriculum_worker(rank, world, port, out, interval=1):
     for p in (os.path.join(HERE, "..", "walk-these-ways_amd", "shims"), os.path.join(HERE, "..", "walk-these-ways_amd"),
               os.path.join(HERE, "..", "oracle"), os.path.join(HERE, ".."), HERE):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    out[rank] = _curriculum_run(rank, world, 48, 40)
+    out[rank] = _curriculum_run(rank, world, 48, 40, interval)
     dist.destroy_process_group()
 
 
-def test_two_rank_curriculum_equals_single_rank_over_the_concatenated_shards():
+@pytest.mark.parametrize("interval", [1, 8])
+def test_two_rank_curriculum_equals_single_rank_over_the_concatenated_shards(interval):
+    """interval 1: the success counts are exchanged after every step (the reference's update cadence); interval 8: the counts of 8
+    steps sit in 8 slots, ONE all-reduce carries them and the 8 per-step updates are applied in order (what bench.py uses over
+    ranks, with the rollout length) — either way the sharded run IS the single-process run with the same interval."""
     for p in (os.path.join(HERE, "..", "oracle"), os.path.join(HERE, ".."), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
     world = 2
     port = 31500 + os.getpid() % 2000
     out = mp.Manager().dict()
-    mp.spawn(_curriculum_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_curriculum_worker, args=(world, port + interval, out, interval), nprocs=world, join=True)
     import go1sim_host as H
     from go1_gym.envs.base import base_task
     saved = (H.Go1Sim, base_task.BaseTask._resolve_device)
     try:
-        single = _curriculum_run(0, 1, 96, 40)
+        single = _curriculum_run(0, 1, 96, 40, interval)
     finally:
         H.Go1Sim, base_task.BaseTask._resolve_device = saved
     r0, r1 = out[0], out[1]

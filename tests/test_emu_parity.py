@@ -282,18 +282,20 @@ def test_emulated_self_collision_matches_oracle(oracle_lib, emu):
 
 def test_emulated_thigh_capsules_match_oracle(oracle_lib, emu):
     """Thigh capsules in the self-collision (pairs with a thigh: types 1-3 of the pair mask) through the KERNEL code: in free
-    flight the front hips roll inwards with the legs stretched until the front legs cross at thigh height; kernel and oracle list the same pairs
+    flight the front hips roll inwards, one thigh pitched forward and one back, and the thighs scissor into each other; kernel and oracle list the same pairs
     and agree to round-off, and a pair with a thigh does fire."""
     N = 16
     cfg, S, meta, Bc = make_sim("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
     S.gravity[0] = S.gravity[1] = S.gravity[2] = 0.0
     standing_state(S, Bc, z=3.0)
     g = torch.Generator().manual_seed(7)
-    Bc.dof_pos[:] = torch.tensor([-0.3, 0.1, -0.95, 0.3, 0.1, -0.95, 0.1, 1.0, -1.5, -0.1, 1.0, -1.5]).unsqueeze(1)
+    Bc.dof_pos[:] = torch.tensor([-0.3, 1.1, -1.0, 0.3, -0.5, -1.0, 0.1, 1.0, -1.5, -0.1, 1.0, -1.5]).unsqueeze(1)
     Bc.dof_pos[[1, 4]] += torch.empty(2, N).uniform_(-0.3, 0.3, generator=g)
     Bc.torques.zero_()
     Bc.torques[0] = -torch.empty(N).uniform_(3.0, 8.0, generator=g)
     Bc.torques[3] = torch.empty(N).uniform_(3.0, 8.0, generator=g)
+    Bc.torques[1] = -torch.empty(N).uniform_(0.5, 2.5, generator=g)
+    Bc.torques[4] = torch.empty(N).uniform_(0.5, 2.5, generator=g)
     Bc.enable_contact_signature()
     orc = oracle_lib.Oracle(S, Bc)
     Be = Bc.clone_to("cpu")

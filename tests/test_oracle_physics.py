@@ -502,19 +502,21 @@ def test_foot_in_a_risers_cell_stands_on_the_ground_not_on_a_ramp(oracle_lib, wa
 
 def test_thigh_capsules_take_part_in_the_self_collision(oracle_lib):
     """`self_collisions = 0` filters nothing (go1_config.py:44): besides the lower legs, the thighs of different legs collide
-    with each other and with the other legs' lower legs.  In free flight both front hips are rolled inwards with the legs
-    stretched, so that the two front legs cross like scissors at thigh height: thigh-thigh and thigh - lower-leg pairs are listed,
+    with each other and with the other legs' lower legs.  In free flight both front hips are rolled inwards with one
+    thigh pitched forward and one back, and the thighs are driven together: they cross like scissors at mid-thigh — a thigh-thigh pair is listed (the deepest of the pair of legs' four capsule combinations),
     the body-body forces sum to zero, the thighs carry load, and the thigh capsules do not pass through each other."""
     N = 1
     cfg, S, meta, B = make_sim("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
     S.gravity[0] = S.gravity[1] = S.gravity[2] = 0.0
     standing_state(S, B, z=3.0)
-    B.dof_pos[:, 0] = torch.tensor([-0.3, 0.1, -0.95, 0.3, 0.1, -0.95, 0.1, 1.0, -1.5, -0.1, 1.0, -1.5])      # front legs stretched
+    B.dof_pos[:, 0] = torch.tensor([-0.3, 1.1, -1.0, 0.3, -0.5, -1.0, 0.1, 1.0, -1.5, -0.1, 1.0, -1.5])      # FL thigh forward, FR thigh back
     sig = B.enable_contact_signature()
     orc = oracle_lib.Oracle(S, B)
     B.torques.zero_()
     B.torques[0] = -6.0          # FL hip rolls inwards ...
-    B.torques[3] = 6.0           # ... FR hip too
+    B.torques[3] = 6.0           # ... FR hip too,
+    B.torques[1] = -1.5          # and the two thighs (one pitched forward, one back) scissor into each other
+    B.torques[4] = 1.5
     md = model()
     seen_pairs, fmax, min_d = 0, 0.0, 1e9
     for it in range(200):

@@ -1,0 +1,61 @@
+"""Debug: the autograd PPO update replayed as HIP graphs vs launched eagerly, on identical synthetic rollouts, over several
+update() calls (tests/test_gpu_env.py::test_graph_replay_update_equals_eager_update only reaches the capture update).
+Prints max |master_graph - master_eager| after every update.   python tools/debug/graph_vs_eager.py [--bf16] [--updates 6]"""
+import argparse
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = os.path.join(REPO, "walk-these-ways_amd")
+for p in (os.path.join(PKG, "shims"), PKG, REPO):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+
+def run(use_graphs, bf16, updates, N, T, inference_mode):
+    from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
+    from go1_gym_learn.ppo_cse.ppo import PPO, PPO_Args
+    PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs, PPO_Args.use_fused_kernels = bf16, use_graphs, False
+    torch.manual_seed(0)
+    alg = PPO(ActorCritic(70, 2, 2100, 12), device="cuda:0")
+    alg.init_storage(N, T, [70], [2], [2100], [12])
+    g = torch.Generator(device="cuda").manual_seed(1)
+    out = []
+    import contextlib
+    for it in range(updates):
+        with (torch.inference_mode() if inference_mode else contextlib.nullcontext()):
+            for t in range(T):
+                obs = torch.randn(N, 70, device="cuda", generator=g)
+                priv = torch.randn(N, 2, device="cuda", generator=g)
+                hist = torch.randn(N, 2100, device="cuda", generator=g)
+                torch.manual_seed(10 * it + t)
+                alg.act(obs, priv, hist)
+                alg.process_env_step(torch.randn(N, device="cuda", generator=g), torch.zeros(N, dtype=torch.uint8, device="cuda"),
+                                     {"env_bins": torch.zeros(N, device="cuda"), "time_outs": torch.zeros(N, dtype=torch.bool, device="cuda")})
+            alg.compute_returns(hist, priv)
+        torch.manual_seed(100 + it)
+        losses = alg.update()
+        out.append((alg.master.clone(), losses, alg.learning_rate, alg.master.grad.clone()))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--updates", type=int, default=6)
+    ap.add_argument("--envs", type=int, default=512)
+    ap.add_argument("--T", type=int, default=8)
+    ap.add_argument("--no-inference-mode", action="store_true")
+    args = ap.parse_args()
+    im = not args.no_inference_mode
+    a = run(False, args.bf16, args.updates, args.envs, args.T, im)
+    a2 = run(False, args.bf16, args.updates, args.envs, args.T, im)
+    b = run(True, args.bf16, args.updates, args.envs, args.T, im)
+    for u in range(args.updates):
+        (w0, l0, lr0, g0), (w1, l1, lr1, g1), (w2, _, _, _) = a[u], b[u], a2[u]
+        print(f"update {u}: eager-vs-eager {float((w0 - w2).abs().max()):.3e}   graph-vs-eager max|dw| {float((w0 - w1).abs().max()):.3e}  "
+              f"lr {lr0:.3e} / {lr1:.3e}  losses eager {[round(x, 5) for x in l0[:3]]} graph {[round(x, 5) for x in l1[:3]]}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

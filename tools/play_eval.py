@@ -78,9 +78,12 @@ def main():
     ap.add_argument("--eval-at", type=int, nargs="*", default=None)
     ap.add_argument("--vx", type=float, nargs="*", default=[1.0, 1.5])
     ap.add_argument("--log-every", type=int, default=500)
+    ap.add_argument("--fp32", action="store_true", help="the autograd fp32 update instead of the bf16 fused one (bench.py's configuration)")
     args = ap.parse_args()
     from bench import build_env
     from go1_gym_learn.ppo_cse import Runner, RunnerArgs
+    from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    PPO_Args.autocast_bf16 = not args.fp32
     RunnerArgs.save_video_interval = 0
     torch.manual_seed(0)
     env, cfg = build_env(args.envs, 0, 0)
@@ -92,7 +95,8 @@ def main():
     eval_at = sorted(set(args.eval_at or [args.iters]))
     t0 = time.time()
     rew_acc, cnt = torch.zeros((), device="cuda"), 0
-    print(f"# train.py configuration, {args.envs} envs, ppo_cse, bf16 policy; evaluation: {args.eval_envs} fresh environments, play.py commands", flush=True)
+    totals = {}
+    print(f"# train.py configuration, {args.envs} envs, ppo_cse, {'fp32' if args.fp32 else 'bf16'} policy; evaluation: {args.eval_envs} fresh environments, play.py commands", flush=True)
     for it in range(1, args.iters + 1):
         with torch.inference_mode():
             for _ in range(T):
@@ -102,8 +106,14 @@ def main():
         runner.alg.update()
         if it % args.log_every == 0:
             faults = env.env.extras["sim_faults"].consume()
+            for k, v in faults.items():
+                if isinstance(v, dict):
+                    for kk, vv in v.items():
+                        totals[f"{k}.{kk}"] = totals.get(f"{k}.{kk}", 0) + int(vv)
+                else:
+                    totals[k] = totals.get(k, 0) + int(v)
             print(f"it {it:5d}  {it * T * args.envs / 1e6:7.1f} M env-steps  mean step reward {float(rew_acc) / cnt:8.5f}  lr {runner.alg.learning_rate:.2e}  "
-                  f"sim faults fatal {faults['fatal']} dropped {faults.get('contact_dropped', 0)}  [{time.time() - t0:6.1f} s]", flush=True)
+                  f"std {float(runner.alg.std.mean()):.3f}  sim faults fatal {faults['fatal']} dropped {faults.get('contact_dropped', 0)}  [{time.time() - t0:6.1f} s]", flush=True)
             rew_acc.zero_(); cnt = 0
         if it in eval_at:
             for vx in args.vx:
@@ -111,6 +121,8 @@ def main():
                 print(f"EVAL it {it:5d}  v_cmd {vx:.1f}: mean v_x {r['mean_vx']:.3f}  |v_x - v_cmd| {r['vel_err']:.3f} m/s  yaw drift {r['yaw_drift']:.3f} rad  "
                       f"gait-schedule match {r['gait_match']:.3f}  fall rate {r['fall_rate']:.3f}", flush=True)
             runner.alg.actor_critic.train()
+    steps = args.iters * T * args.envs
+    print(f"FAULT SOAK over {steps / 1e6:.1f} M env-steps of training: " + "  ".join(f"{k} {v} ({v / steps:.2e}/env-step)" for k, v in sorted(totals.items())), flush=True)
 
 
 if __name__ == "__main__":

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--every", type=int, default=20)
     ap.add_argument("--fp32", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="PPO_Args.use_hip_graphs = False")
     ap.add_argument("--check-finite", action="store_true", help="after every iteration: first non-finite tensor among "
                     "observations / rewards / actions / returns / parameters / gradients, then stop")
     args = ap.parse_args()
@@ -26,6 +27,8 @@ def main():
     from go1_gym_learn.ppo_cse import Runner, RunnerArgs
     from go1_gym_learn.ppo_cse.ppo import PPO_Args
     PPO_Args.autocast_bf16 = not args.fp32
+    if args.no_graphs:
+        PPO_Args.use_hip_graphs = False
     RunnerArgs.save_video_interval = 0
     torch.manual_seed(0)
     env, cfg = build_env(args.envs, 0, 0)
@@ -106,10 +109,17 @@ def main():
                                       bool(torch.isfinite(net.dZ[nname][li].float()).all()), flush=True)
                 return
         if (it + 1) % args.every == 0:
+            base = env
+            while not hasattr(base, "buffers"):
+                base = base.env
+            fl = base.extras["sim_faults"].consume()
+            diag = (f"  | max|obs| {float(obs_dict['obs'].abs().max()):6.2f} max|v_base| {float(base.root_states[:, 7:10].norm(dim=1).max()):6.2f} "
+                    f"max|qd| {float(base.dof_vel.abs().max()):5.1f} fallen {float((base.root_states[:, 2] < 0.15).float().mean()):.3f} "
+                    f"fatal {fl['fatal']} dropped {fl.get('contact_dropped', 0)} {fl.get('contact_dropped_by_class', '')} limit_safety {fl.get('limit_safety', 0)}")
             a = acc.tolist()
             print(f"it {it + 1:4d}  mean step reward {a[0] / a[1]:8.5f}  mean ep len {float(ep_len_sum) / max(a[2], 1):7.1f}  "
                   f"time-outs/resets {a[3] / max(a[2], 1):5.3f}  lr {runner.alg.learning_rate:.2e}  value loss {losses[0]:.4f}  "
-                  f"surr {losses[1]:+.4f}  adapt {losses[2]:.4f}  std {float(runner.alg.std.mean()):.3f}  [{time.time() - t0:5.1f} s]", flush=True)
+                  f"surr {losses[1]:+.4f}  adapt {losses[2]:.4f}  std {float(runner.alg.std.mean()):.3f}  [{time.time() - t0:5.1f} s]{diag}", flush=True)
             acc.zero_(); ep_len_sum.zero_()
 
 

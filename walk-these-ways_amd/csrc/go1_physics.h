@@ -23,7 +23,7 @@
 #define EPW 16                       // environments per wavefront
 #define MAXC GO1_MAX_CONTACTS        // solver contacts per env (24; oracle: the same constant of include/go1sim.h)
 #define NRJ 12                       // joint-limit rows: joint j
-#define MAXSB 4                      // leg-leg self-contacts per env (oracle: GO1_MAX_SELF_LEG_PAIRS)
+#define MAXSB 6                      // leg-leg self-contacts per env: one per pair of legs (the deepest of its four capsule combinations)
 #define MAXTR 4                      // trunk corners per env (oracle: GO1_MAX_TRUNK_POINTS)
 #define GO1_LIMIT_RECOVERY_RATE 10.0f   // rad/s: a joint found beyond a stop is brought back at a bounded rate
 #define GO1_LIMIT_SAFETY 2.0f           // x velocity limit: beyond this the limit rows have failed (cut + fault count)
@@ -748,7 +748,7 @@ DEV int leg_pair_index(int lo, int hi) { return lo == 0 ? hi - 1 : lo == 1 ? hi 
 // is known from the signs of the box axes' z components — one candidate per end instead of four
 template <bool WALLS, bool SIG, bool PLANE>
 DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int nw, Base& s, Leg& L, V3 grav,
-                         bool use_warm, float h, uint32_t& fault, const float* acth, int e, int N, int sub PROF_PARAM) {
+                         bool use_warm, float h, uint32_t& fault, uint32_t (&dropacc)[GO1_CC_COUNT], const float* acth, int e, int N, int sub PROF_PARAM) {
   float* const lds = Z.lds;
   lf4* const crl = Z.cr();
   lf4* const jrl = Z.jr();
@@ -905,6 +905,8 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       const V3 par_p[2] = {v3(a0[0], a0[1], a0[2]), v3(a1[2], a1[3], a2[0])}, par_q[2] = {v3(a0[3], a1[0], a1[1]), v3(a0[0], a0[1], a0[2])};
       const bool lower = leg < j;
       const int pair = lower ? leg_pair_index(leg, j) : leg_pair_index(j, leg);
+      float best_phi = 1e30f;                 // two legs touch in ONE point: the deepest of the four capsule combinations (ties: lower type)
+      int best_type = -1;
 #pragma unroll
       for (int type = 0; type < 4; type++) {
         const int sa = (type >> 1) & 1, sbq = type & 1;                      // segment of body A / B: 0 lower leg, 1 thigh
@@ -916,9 +918,10 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
           const float ra = sa ? GO1_SELF_THIGH_RADIUS : GO1_SELF_LEG_RADIUS, rb = sbq ? GO1_SELF_THIGH_RADIUS : GO1_SELF_LEG_RADIUS;
           const bool hit = near && (lower ? capsule_contact(own_p[so], own_q[so], ra, par_p[sp], par_q[sp], rb, cd, c)
                                           : capsule_contact(par_p[sp], par_q[sp], ra, own_p[so], own_q[so], rb, cd, c));
-          if (hit) mybits |= 1u << (6 * type + pair);
+          if (hit && c.phi < best_phi) { best_phi = c.phi; best_type = type; }
         }
       }
+      if (best_type >= 0) mybits |= 1u << (6 * best_type + pair);
     }
     {
       const float ta = (float)(GO1_TRUNK_BOX_HALF[0] - GO1_TRUNK_BOX_HALF[1]);
@@ -927,20 +930,6 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         mybits |= 1u << (24 + leg);
     }
     smask = quad_or(mybits);
-    {   // at most MAXSB leg-leg pairs, in pid order
-      const unsigned legpairs = smask & 0xFFFFFFu;
-      if (__popc(legpairs) > MAXSB) {
-        unsigned keep = 0, cnt = 0;
-#pragma unroll 1
-        for (int pid = 0; pid < 24; pid++)
-          if (legpairs & (1u << pid)) { if (cnt < MAXSB) keep |= 1u << pid; cnt++; }
-        if (leg == 0) {
-          fault |= 1u << GO1_FAULT_CONTACT_DROPPED;
-          if (B.contact_drop_counts) atomicAdd(&B.contact_drop_counts[GO1_CC_SELF], (uint32_t)(cnt - MAXSB));
-        }
-        smask = keep | (smask & 0xF000000u);
-      }
-    }
     nS = __popc(smask);
   }
 
@@ -1004,11 +993,8 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     if (base_ofs > MAXC || drops[GO1_CC_TRUNK] > 0) {
       if (leg == 0) {
         fault |= 1u << GO1_FAULT_CONTACT_DROPPED;
-        if (B.contact_drop_counts) {
 #pragma unroll
-          for (int c = 0; c < GO1_CC_COUNT; c++)
-            if (drops[c] > 0) atomicAdd(&B.contact_drop_counts[c], (uint32_t)drops[c]);
-        }
+        for (int c = 0; c < GO1_CC_COUNT; c++) dropacc[c] += (uint32_t)drops[c];
       }
       sig1 |= 1u << 31;
     }

@@ -63,12 +63,31 @@ struct StepArgs {
 DEV void report_fault(BufRef B, int e, uint32_t fault) {
   fault |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)fault, 0xB1, 0xF, 0xF, false);
   fault |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)fault, 0x4E, 0xF, 0xF, false);
-  if ((threadIdx.x & 3) != 0) return;
-  if (fault == 0 || B.fault_flags == nullptr) return;
-  atomicOr(&B.fault_flags[e], fault);
+  const bool mine = (threadIdx.x & 3) == 0 && fault != 0 && B.fault_flags != nullptr;
+  if (__ballot(mine) == 0ull) return;
+  if (mine) atomicOr(&B.fault_flags[e], fault);
   if (B.fault_counts == nullptr) return;
-  for (int b = 0; b < GO1_FAULT_BITS; b++)
-    if (fault & (1u << b)) atomicAdd(&B.fault_counts[b], 1u);
+  // one atomic per wavefront and bit (under a learning policy hundreds of environments report the count-only bits in the same
+  // launch: per-environment atomics on ONE address serialise into milliseconds)
+  for (int b = 0; b < GO1_FAULT_BITS; b++) {
+    const unsigned long long m = __ballot(mine && (fault & (1u << b)));
+    if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&B.fault_counts[b], (uint32_t)__builtin_popcountll(m));
+  }
+}
+// contact points without a solver slot, per class: accumulated per environment over the substeps (leg-0 lanes), one atomic per
+// wavefront and class
+DEV void report_drops(BufRef B, const uint32_t (&drops)[GO1_CC_COUNT]) {
+  if (B.contact_drop_counts == nullptr) return;
+  uint32_t any = 0;
+#pragma unroll
+  for (int c = 0; c < GO1_CC_COUNT; c++) any |= drops[c];
+  if (__ballot(any != 0u) == 0ull) return;
+#pragma unroll
+  for (int c = 0; c < GO1_CC_COUNT; c++) {
+    uint32_t v = 0;                              // wave sum, bit plane by bit plane (an environment drops < 2^10 points per step)
+    for (int bit = 0; bit < 10; bit++) v += (uint32_t)__builtin_popcountll(__ballot((drops[c] >> bit) & 1u)) << bit;
+    if (v != 0u && (threadIdx.x & 63) == 0) atomicAdd(&B.contact_drop_counts[c], v);
+  }
 }
 
 // Workgroup = STEP_WAVES wavefronts for 16 environments.  Wavefront 0 (the "master") runs the step — four lanes per
@@ -131,6 +150,9 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   // it — possible aliasing — and expose one HBM round trip per group)
   load_state(B, leg, e, N, s, L);
   uint32_t fault = 0;
+  uint32_t drops[GO1_CC_COUNT];
+#pragma unroll
+  for (int c = 0; c < GO1_CC_COUNT; c++) drops[c] = 0u;
   float act_in[3], fv_in[3];
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) {
@@ -182,7 +204,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
     PROF(1);
     head = (head + 1) % nl;
 #ifndef GO1_ABLATE_PHYSICS
-    physics_substep<WALLS, SIG, PLANE>(cfg, B, Z, lane, nw, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault, deferred ? acth : nullptr, e, N, sub PROF_PASS);
+    physics_substep<WALLS, SIG, PLANE>(cfg, B, Z, lane, nw, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault, drops, deferred ? acth : nullptr, e, N, sub PROF_PASS);
 #endif
   }
   if (deferred) torque_stash_store(cfg, B, L, acth, lane, leg, e, N);
@@ -197,6 +219,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
     post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, grav, A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs PROF_PASS);
 #endif
   report_fault(B, e, fault);
+  report_drops(B, drops);
   PROF_FLUSH;
 }
 #define STEP_LDS \
