@@ -386,7 +386,7 @@ def main():
             valu = {"wave_instructions_per_launch": valu_insts, "lane_ops_per_s": lane_ops, "peak_lane_ops_per_s": 78.65e12,
                     "frac_of_fp32_vector_issue_peak": lane_ops / 78.65e12,
                     "note": "chip-wide; the step's serial spine runs on 256 of the 1024 SIMDs (one master wavefront per CU), the helper "
-                            "wavefronts fill the other SIMDs only during the actuator network and the Delassus build"}
+                            "wavefronts fill the other SIMDs only during the actuator network and the terrain-contact row emission"}
         faults = env.env.extras["sim_faults"].consume()
         bytes_per_launch = ALGORITHMIC_BYTES_PER_ENV_STEP * args.envs
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0

@@ -218,7 +218,9 @@ def test_graph_replay_update_equals_eager_update():
     N, T = 512, 8
     results = []
     for use_graphs in (False, True):
-        PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs, PPO_Args.use_fused_kernels = True, use_graphs, False
+        # "all": graphs for the autograd update are opt-in (exact at this size: 1024-row mini-batches, single-block reductions;
+        # PPO_Args.use_hip_graphs comment for why not at production sizes)
+        PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs, PPO_Args.use_fused_kernels = True, "all" if use_graphs else False, False
         torch.manual_seed(0)
         alg = PPO(ActorCritic(70, 2, 2100, 12), device="cuda:0")
         alg.init_storage(N, T, [70], [2], [2100], [12])
@@ -242,6 +244,29 @@ def test_graph_replay_update_equals_eager_update():
     assert lr0 == lr1
     np.testing.assert_allclose(l0, l1, rtol=1e-5)
     assert torch.equal(w0, w1)
+
+
+def test_autograd_update_is_not_captured_by_default():
+    """use_hip_graphs = True (the default) captures the fused update only: the autograd update (fp32 default configuration of the
+    reference, or use_fused_kernels = False) runs eagerly — its torch reductions do not replay reliably in HIP graphs at
+    production batch sizes (tools/debug/graph_vs_eager_lockstep.py, tools/probes/graph_reduce_repro.py)."""
+    from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
+    from go1_gym_learn.ppo_cse.ppo import PPO, PPO_Args
+    N, T = 256, 4
+    for bf16, fused_on, want in ((False, True, False), (True, False, False), (True, True, True)):
+        PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs, PPO_Args.use_fused_kernels = bf16, True, fused_on
+        torch.manual_seed(0)
+        alg = PPO(ActorCritic(70, 2, 2100, 12), device="cuda:0")
+        alg.init_storage(N, T, [70], [2], [2100], [12])
+        for it in range(2):
+            for t in range(T):
+                alg.act(torch.randn(N, 70, device="cuda"), torch.randn(N, 2, device="cuda"), torch.randn(N, 2100, device="cuda"))
+                alg.process_env_step(torch.randn(N, device="cuda"), torch.zeros(N, dtype=torch.uint8, device="cuda"),
+                                     {"env_bins": torch.zeros(N, device="cuda"), "time_outs": torch.zeros(N, dtype=torch.bool, device="cuda")})
+            alg.compute_returns(torch.randn(N, 2100, device="cuda"), torch.randn(N, 2, device="cuda"))
+            alg.update()
+        assert bool(alg._graphs) == want, (bf16, fused_on)
+    PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs, PPO_Args.use_fused_kernels = False, True, True
 
 
 def test_ppo_learns_on_the_hip_simulator(tmp_path):

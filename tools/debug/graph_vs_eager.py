@@ -36,6 +36,7 @@ def run(use_graphs, bf16, updates, N, T, inference_mode):
         torch.manual_seed(100 + it)
         losses = alg.update()
         out.append((alg.master.clone(), losses, alg.learning_rate, alg.master.grad.clone()))
+    run.alg = alg
     return out
 
 
@@ -55,6 +56,16 @@ def main():
         (w0, l0, lr0, g0), (w1, l1, lr1, g1), (w2, _, _, _) = a[u], b[u], a2[u]
         print(f"update {u}: eager-vs-eager {float((w0 - w2).abs().max()):.3e}   graph-vs-eager max|dw| {float((w0 - w1).abs().max()):.3e}  "
               f"lr {lr0:.3e} / {lr1:.3e}  losses eager {[round(x, 5) for x in l0[:3]]} graph {[round(x, 5) for x in l1[:3]]}", flush=True)
+        if float((w0 - w1).abs().max()) > 0:
+            alg = run.alg
+            n = alg.n_body
+            worst = []
+            for name, _ in alg.policy.blocks:
+                d = float((alg.policy._block(w0[:n], name) - alg.policy._block(w1[:n], name)).abs().max())
+                if d > 0:
+                    worst.append((d, name))
+            worst.sort(reverse=True)
+            print("    blocks:", ", ".join(f"{nm} {d:.2e}" for d, nm in worst[:12]), f"| std {float((w0[n:n + alg.n_std] - w1[n:n + alg.n_std]).abs().max()):.2e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -113,7 +113,7 @@ def main():
                 else:
                     totals[k] = totals.get(k, 0) + int(v)
             print(f"it {it:5d}  {it * T * args.envs / 1e6:7.1f} M env-steps  mean step reward {float(rew_acc) / cnt:8.5f}  lr {runner.alg.learning_rate:.2e}  "
-                  f"std {float(runner.alg.std.mean()):.3f}  sim faults fatal {faults['fatal']} dropped {faults.get('contact_dropped', 0)}  [{time.time() - t0:6.1f} s]", flush=True)
+                  f"std {float(runner.alg.std.detach().mean()):.3f}  sim faults fatal {faults['fatal']} dropped {faults.get('contact_dropped', 0)}  [{time.time() - t0:6.1f} s]", flush=True)
             rew_acc.zero_(); cnt = 0
         if it in eval_at:
             for vx in args.vx:

@@ -119,7 +119,7 @@ def main():
             a = acc.tolist()
             print(f"it {it + 1:4d}  mean step reward {a[0] / a[1]:8.5f}  mean ep len {float(ep_len_sum) / max(a[2], 1):7.1f}  "
                   f"time-outs/resets {a[3] / max(a[2], 1):5.3f}  lr {runner.alg.learning_rate:.2e}  value loss {losses[0]:.4f}  "
-                  f"surr {losses[1]:+.4f}  adapt {losses[2]:.4f}  std {float(runner.alg.std.mean()):.3f}  [{time.time() - t0:5.1f} s]{diag}", flush=True)
+                  f"surr {losses[1]:+.4f}  adapt {losses[2]:.4f}  std {float(runner.alg.std.detach().mean()):.3f}  [{time.time() - t0:5.1f} s]{diag}", flush=True)
             acc.zero_(); ep_len_sum.zero_()
 
 

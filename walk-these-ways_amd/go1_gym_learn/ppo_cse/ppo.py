@@ -54,7 +54,12 @@ class PPO_Args(PrefixProto):
     dp_zero1 = False                # PPO stage: reduce-scatter the gradient, every rank steps its 1/world slice of the flat
                                     # parameter (global norm / KL by two scalar-sized all-reduces), all-gather the result
     history_ring = True             # keep each observation once when init_storage(..., sliding_history=True) allows it
-    use_hip_graphs = True           # replay the mini-batch step as a HIP graph from the second update() on
+    # replay the mini-batch step as a HIP graph from the second update() on.  True: the fused update only (its kernels are this
+    # repo's own).  "all": the autograd update too — NOT safe at production batch sizes on ROCm 7.2: torch's multi-block
+    # reductions (bias / std gradients, column sums over 24576 rows) zero their semaphores with hipMemsetAsync, and that memset
+    # node does not replay reliably (wrong gradients from the first pure replay on; DESIGN.md "HIP graphs", tools/probes/
+    # graph_reduce_repro.py) — exact at the test sizes (<= 1024 rows, single-block reductions), hence still available for them.
+    use_hip_graphs = True
     use_fused_kernels = True        # bf16 policy on a GPU: hand-scheduled forward/backward with csrc/go1ppo.hip (fused.py)
     use_tuned_gemms = True          # PyTorch TunableOp with the gfx950 table shipped in walk-these-ways_amd/tuning/
 
@@ -627,7 +632,8 @@ class PPO:
             self.master.grad.zero_()          # once per update; afterwards the fused optimiser steps keep it clean (and the KL slot)
         indices = torch.randperm(nmb * mb, requires_grad=False, device=self.device)   # rollout_storage.py:103
         self._idx_all.copy_(indices.view(nmb, mb))
-        use_graphs = (self.on_gpu and A.use_hip_graphs and A.num_adaptation_module_substeps == 1)
+        use_graphs = bool(self.on_gpu and A.use_hip_graphs and A.num_adaptation_module_substeps == 1
+                          and (self.fused or A.use_hip_graphs == "all"))
         graph_mode = use_graphs and self._updates_done >= 1
         self._pregathered = bool(graph_mode and self.fused)
         if self._pregathered:
