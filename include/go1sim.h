@@ -53,8 +53,10 @@ enum Go1ContactClass {
   GO1_CC_WALL = 7,        /* trunk / calf / thigh against a vertical terrain face */
   GO1_CC_COUNT = 8
 };
-#define GO1_SIG_WORDS 4          /* per substep: [top-surface points | wall points | self pairs + legs with limit rows | geometry hash:
-                                    the height-field cell and the candidate point (corner / end) every listed terrain contact came from] */
+#define GO1_SIG_WORDS 4          /* per substep: [top-surface points | wall points | self pairs + legs with limit rows | hash of: the
+                                    height-field cell and candidate point (corner / end) every listed terrain contact came from, the
+                                    contacts that took the restitution branch, and the ACTIVE SET the solve ended in (pressing
+                                    contacts, contacts projected on the friction cone in the last sweep, limit rows with an impulse)] */
 #define GO1_SIG_MAX_SUBSTEPS 4
 
 /* canonical reward ids: one per `_reward_*` in go1_gym/envs/rewards/corl_rewards.py:15-202 */

@@ -711,6 +711,8 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
     for (int r = 0; r < 3; r++)
       for (int i = 0; i < NV; i++) v[i] += T[c][r][i] * lamc[c][r];
   }
+  int slid[GO1_MAX_CONTACTS];
+  for (int c = 0; c < nc; c++) slid[c] = 0;
   for (int it = 0; it < cfg->solver_iterations; it++) {
     for (int c = 0; c < nc; c++) {
       real un = 0;
@@ -726,6 +728,7 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
       /* Coulomb cone: a tangential impulse inside the static cone sticks, beyond it the contact slides on the dynamic cone
        * (PhysX: static / dynamic friction of the material pair) */
       real lim = cmu[c] * ln, nrm = sqrt(l1 * l1 + l2 * l2);
+      slid[c] = nrm > lim;
       if (nrm > lim) { real sc = (nrm > 0) ? cmud[c] * ln / nrm : 0; l1 *= sc; l2 *= sc; }
       real d1 = l1 - lamc[c][1], d2 = l2 - lamc[c][2];
       lamc[c][1] = l1; lamc[c][2] = l2;
@@ -742,6 +745,17 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
       lamj[j] = ln;
       for (int i = 0; i < NV; i++) v[i] += TJ[j][i] * dl;
     }
+  }
+  if (out && cfg->solver_iterations > 0) {
+    /* signature: the active set the solve ended in (pressing contacts, sliding contacts, limit rows carrying an impulse) */
+    uint32_t jm = 0;
+    for (int j = 0; j < 12; j++) if (jact[j] && lamj[j] != 0) jm |= 1u << j;
+    uint32_t ah = jm * 0x27D4EB2Fu;
+    for (int c = 0; c < nc; c++) {
+      if (lamc[c][0] > 0) ah += (uint32_t)(c + 1) * 0x85EBCA6Bu;
+      if (slid[c]) ah += (uint32_t)(c + 1) * 0xC2B2AE35u;
+    }
+    out->sig[3] += ah;
   }
   for (int b = 0; b < 17; b++) v3set(wl[b], 0, 0, 0);
   for (int c = 0; c < nc; c++)

@@ -344,19 +344,10 @@ def gen_heights(seed=9, N=24, name="heights.npz", border=2.0, hscale=0.1, vscale
     print("heights", h.shape, float(h.min()), float(h.max()))
 
 
-PPO_FUZZ = [dict(schedule="fixed", use_clipped_value_loss=False, clip_param=0.1, entropy_coef=0.0, num_learning_epochs=2, num_mini_batches=3,
-                 num_adaptation_module_substeps=2, max_grad_norm=0.3),
-            dict(schedule="adaptive", desired_kl=0.002, value_loss_coef=0.5, entropy_coef=0.03, num_learning_epochs=3, num_mini_batches=2,
-                 selective_adaptation_module_loss=True, gamma=0.97, lam=0.9),
-            dict(schedule="adaptive", desired_kl=0.05, learning_rate=3.e-4, adaptation_module_learning_rate=3.e-3, clip_param=0.3,
-                 num_learning_epochs=1, num_mini_batches=5, max_grad_norm=10.0),
-            dict(schedule="fixed", use_clipped_value_loss=True, value_loss_coef=2.0, num_learning_epochs=4, num_mini_batches=1,
-                 num_adaptation_module_substeps=3, selective_adaptation_module_loss=True, lam=1.0)]
-
-
 def gen_ppo_fuzz():
     """the same fixed-rollout update under four other settings of PPO_Args (ppo.py:11-31): fixed / adaptive schedule, plain value
     loss, several adaptation sub-steps, selective adaptation loss, other clip / entropy / value coefficients, epochs, batches"""
+    PPO_FUZZ = load_private("_wtw_variants_ppo", os.path.join(HERE, "variants.py")).PPO_FUZZ      # shared with tests/test_gpu_ppo_fused.py
     for k, over in enumerate(PPO_FUZZ):
         for m in [x for x in sys.modules if x.startswith("go1_gym")]:
             del sys.modules[m]

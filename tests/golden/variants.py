@@ -98,3 +98,15 @@ def apply_variant(Cfg, name):
         for k, v in values.items():
             setattr(target, k, v)
     return Cfg
+
+
+# PPO_Args settings of tests/golden/ppo_fuzz<k>.npz (reference ppo.py:11-31): fixed / adaptive schedule, plain value loss, several
+# adaptation sub-steps, selective adaptation loss, other clip / entropy / value coefficients, epochs, mini-batch counts
+PPO_FUZZ = [dict(schedule="fixed", use_clipped_value_loss=False, clip_param=0.1, entropy_coef=0.0, num_learning_epochs=2, num_mini_batches=3,
+                 num_adaptation_module_substeps=2, max_grad_norm=0.3),
+            dict(schedule="adaptive", desired_kl=0.002, value_loss_coef=0.5, entropy_coef=0.03, num_learning_epochs=3, num_mini_batches=2,
+                 selective_adaptation_module_loss=True, gamma=0.97, lam=0.9),
+            dict(schedule="adaptive", desired_kl=0.05, learning_rate=3.e-4, adaptation_module_learning_rate=3.e-3, clip_param=0.3,
+                 num_learning_epochs=1, num_mini_batches=5, max_grad_norm=10.0),
+            dict(schedule="fixed", use_clipped_value_loss=True, value_loss_coef=2.0, num_learning_epochs=4, num_mini_batches=1,
+                 num_adaptation_module_substeps=3, selective_adaptation_module_loss=True, lam=1.0)]

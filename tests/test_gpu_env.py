@@ -1,6 +1,7 @@
 """GPU tests of the env surface (LeggedRobot / VelocityTrackingEasyEnv / HistoryWrapper / Runner) and of the HIP
 tensor maps against the REFERENCE golden vectors (tests/golden/maps_*.npz, produced by the reference Python)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -304,6 +305,27 @@ def test_ppo_learns_on_the_hip_simulator(tmp_path):
     first, last = float(np.mean(rew[:40])), float(np.mean(rew[-40:]))
     assert last > 1.15 * first, (first, last)
     assert np.mean(adapt[-40:]) < 0.9 * np.mean(adapt[:40]), (np.mean(adapt[:40]), np.mean(adapt[-40:]))
+
+
+def test_play_eval_trained_policy_walks_the_play_commands():
+    """Task-level acceptance (tools/play_eval.py, profiles/r03_play_eval.txt): 1500 PPO iterations (147 M env-steps, ~40 s) with the
+    train.py configuration, then the policy is driven the way scripts/play.py drives it (reference play.py:89-139: 1.0 m/s, 3 Hz
+    trot, deterministic student actions, 250 steps) on 512 fresh environments.  Measured at 1500 iterations: |v_x - v_cmd| 0.164 m/s,
+    yaw drift 0.25 rad, gait-schedule match 0.914, no falls; the thresholds leave room for the run-to-run spread of early PPO."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(repo, "tools"))
+    import play_eval
+    lines = []
+    results, totals = play_eval.train_and_evaluate(1500, envs=4096, eval_envs=512, eval_at=[1500], vxs=(1.0,), log_every=500, out=lines.append)
+    r = results[1500][0]
+    report = "\n".join(lines)
+    assert r["fall_rate"] < 0.02, report
+    assert r["vel_err"] < 0.30, report
+    assert r["gait_match"] > 0.85, report
+    assert r["yaw_drift"] < 0.6, report
+    assert totals.get("fatal", 0) == 0, report
+    steps = 1500 * 24 * 4096
+    assert totals.get("contact_dropped", 0) < 1e-4 * steps, report
 
 
 def test_rough_terrain_env_end_to_end():

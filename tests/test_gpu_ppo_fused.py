@@ -565,6 +565,58 @@ def test_fused_update_tracks_autograd_update(use_graphs, engine, monkeypatch):
     assert moved > 0 and rel < 0.1, (rel, moved)
 
 
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_fused_update_tracks_autograd_update_under_ppo_fuzz_settings(k):
+    """GPU twins of tests/golden/ppo_fuzz<k>.npz: the four other PPO_Args settings the CPU fp32 path is pinned on against the
+    reference (tests/test_ppo.py; fixed schedule, plain value loss, 2-3 adaptation sub-steps, selective adaptation loss, other
+    clip / entropy / value coefficients, epochs, mini-batch counts, gamma / lambda) — here the bf16 fused update (own kernels: loss,
+    mse, wgrad, Adam, GAE) against the bf16 autograd update on identical rollouts, two update() calls each.  Same criteria as the
+    train.py-settings test above; graphs follow the default (captured when there is a single adaptation sub-step)."""
+    from golden.variants import PPO_FUZZ
+    from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    over = PPO_FUZZ[k]
+    saved_args = {name: getattr(PPO_Args, name) for name in over}
+    N, T = 480, 8                   # 3840 samples: mini-batches of 1280 / 1920 / 768 / 3840 rows
+    res, saved = [], {}
+    try:
+        for name, v in over.items():
+            setattr(PPO_Args, name, v)
+        for fused_on in (False, True):
+            alg = make_alg(fused_on, N, T)
+            w_init = alg.master.clone()
+            for it in range(2):
+                fill_storage(alg, N, T, seed=17 + it)      # (compute_returns inside: gamma / lam of this setting, GAE kernel vs torch)
+                fields = ("actions", "values", "mu", "sigma", "actions_log_prob", "observation_histories", "privileged_observations",
+                          "rewards", "dones")
+                if fused_on:
+                    for f in fields:
+                        getattr(alg.storage, f).copy_(saved[it][f])
+                    # the GAE + normalisation kernels under this setting's gamma / lambda against the torch scan
+                    alg.storage.compute_returns(saved[it]["last_values"].clone(), PPO_Args.gamma, PPO_Args.lam, fused_lib=alg._fused_lib)
+                    torch.testing.assert_close(alg.storage.returns, saved[it]["returns"], rtol=1e-5, atol=1e-5)
+                    torch.testing.assert_close(alg.storage.advantages, saved[it]["advantages"], rtol=1e-4, atol=1e-4)
+                    for f in ("advantages", "returns"):
+                        getattr(alg.storage, f).copy_(saved[it][f])
+                else:
+                    saved[it] = {f: getattr(alg.storage, f).clone() for f in fields + ("advantages", "returns")}
+                    saved[it]["last_values"] = alg._infer(alg._last_hist)[1].clone()
+                torch.manual_seed(100 + it)
+                losses = alg.update()
+            res.append((alg.master.clone(), losses, alg.learning_rate))
+    finally:
+        for name, v in saved_args.items():
+            setattr(PPO_Args, name, v)
+        PPO_Args.autocast_bf16, PPO_Args.use_fused_kernels, PPO_Args.use_hip_graphs = False, True, True
+    (w0, l0, lr0), (w1, l1, lr1) = res
+    assert lr1 == pytest.approx(lr0, rel=1e-5)
+    if over.get("schedule") == "fixed":
+        assert lr1 == pytest.approx(over.get("learning_rate", 1.e-3), rel=1e-6)
+    np.testing.assert_allclose(l1, l0, rtol=2e-2, atol=1e-6)
+    moved = float((w0 - w_init).norm())
+    rel = float((w1 - w0).norm()) / moved
+    assert moved > 0 and rel < 0.1, (rel, moved)
+
+
 def test_observation_ring_storage_is_bit_identical_to_the_history_block():
     """RolloutStorage(ring=True) — every observation stored once, (T + H - 1, N, 70) bf16 — against the reference layout
     (rollout_storage.py:36-38: every window stored, here (T, N, 2112) bf16): same sliding-window input stream

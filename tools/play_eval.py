@@ -70,6 +70,59 @@ def evaluate(runner, num_envs, vx, steps=250, seed=1):
                 mean_vx=float(base.base_lin_vel[:, 0][~fell].mean()) if bool((~fell).any()) else float("nan"))
 
 
+def train_and_evaluate(iters, envs=4096, eval_envs=512, eval_at=None, vxs=(1.0, 1.5), log_every=500, fp32=False, out=print):
+    """Train with scripts/train.py's configuration (bench.py's loop), evaluate at the iterations `eval_at`; returns
+    ({iteration: [evaluate() records]}, fault totals over the training)."""
+    from bench import build_env
+    from go1_gym_learn.ppo_cse import Runner, RunnerArgs
+    from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    saved = PPO_Args.autocast_bf16
+    PPO_Args.autocast_bf16 = not fp32
+    RunnerArgs.save_video_interval = 0
+    torch.manual_seed(0)
+    env, cfg = build_env(envs, 0, 0)
+    runner = Runner(env, device="cuda:0")
+    PPO_Args.autocast_bf16 = saved
+    T = runner.num_steps_per_env
+    env.episode_length_buf.copy_(torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length)))
+    obs_dict = env.get_observations()
+    n = env.num_train_envs
+    eval_at = sorted(set(eval_at or [iters]))
+    t0 = time.time()
+    rew_acc, cnt = torch.zeros((), device="cuda"), 0
+    totals, results = {}, {}
+    out(f"# train.py configuration, {envs} envs, ppo_cse, {'fp32' if fp32 else 'bf16'} policy; evaluation: {eval_envs} fresh environments, play.py commands")
+    for it in range(1, iters + 1):
+        with torch.inference_mode():
+            for _ in range(T):
+                obs_dict, _ = runner._rollout_step(obs_dict)
+                rew_acc += env.rew_buf.mean(); cnt += 1
+            runner.alg.compute_returns(obs_dict["obs_history"][:n], obs_dict["privileged_obs"][:n])
+        runner.alg.update()
+        if it % log_every == 0 or it == iters:
+            faults = env.env.extras["sim_faults"].consume()
+            for k, v in faults.items():
+                if isinstance(v, dict):
+                    for kk, vv in v.items():
+                        totals[f"{k}.{kk}"] = totals.get(f"{k}.{kk}", 0) + int(vv)
+                else:
+                    totals[k] = totals.get(k, 0) + int(v)
+            out(f"it {it:5d}  {it * T * envs / 1e6:7.1f} M env-steps  mean step reward {float(rew_acc) / max(cnt, 1):8.5f}  lr {runner.alg.learning_rate:.2e}  "
+                f"std {float(runner.alg.std.detach().mean()):.3f}  sim faults fatal {faults['fatal']} dropped {faults.get('contact_dropped', 0)}  [{time.time() - t0:6.1f} s]")
+            rew_acc.zero_(); cnt = 0
+        if it in eval_at:
+            results[it] = []
+            for vx in vxs:
+                r = evaluate(runner, eval_envs, vx)
+                results[it].append(r)
+                out(f"EVAL it {it:5d}  v_cmd {vx:.1f}: mean v_x {r['mean_vx']:.3f}  |v_x - v_cmd| {r['vel_err']:.3f} m/s  yaw drift {r['yaw_drift']:.3f} rad  "
+                    f"gait-schedule match {r['gait_match']:.3f}  fall rate {r['fall_rate']:.3f}")
+            runner.alg.actor_critic.train()
+    steps = iters * T * envs
+    out(f"FAULT SOAK over {steps / 1e6:.1f} M env-steps of training: " + "  ".join(f"{k} {v} ({v / steps:.2e}/env-step)" for k, v in sorted(totals.items())))
+    return results, totals
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5000)
@@ -80,49 +133,8 @@ def main():
     ap.add_argument("--log-every", type=int, default=500)
     ap.add_argument("--fp32", action="store_true", help="the autograd fp32 update instead of the bf16 fused one (bench.py's configuration)")
     args = ap.parse_args()
-    from bench import build_env
-    from go1_gym_learn.ppo_cse import Runner, RunnerArgs
-    from go1_gym_learn.ppo_cse.ppo import PPO_Args
-    PPO_Args.autocast_bf16 = not args.fp32
-    RunnerArgs.save_video_interval = 0
-    torch.manual_seed(0)
-    env, cfg = build_env(args.envs, 0, 0)
-    runner = Runner(env, device="cuda:0")
-    T = runner.num_steps_per_env
-    env.episode_length_buf.copy_(torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length)))
-    obs_dict = env.get_observations()
-    n = env.num_train_envs
-    eval_at = sorted(set(args.eval_at or [args.iters]))
-    t0 = time.time()
-    rew_acc, cnt = torch.zeros((), device="cuda"), 0
-    totals = {}
-    print(f"# train.py configuration, {args.envs} envs, ppo_cse, {'fp32' if args.fp32 else 'bf16'} policy; evaluation: {args.eval_envs} fresh environments, play.py commands", flush=True)
-    for it in range(1, args.iters + 1):
-        with torch.inference_mode():
-            for _ in range(T):
-                obs_dict, _ = runner._rollout_step(obs_dict)
-                rew_acc += env.rew_buf.mean(); cnt += 1
-            runner.alg.compute_returns(obs_dict["obs_history"][:n], obs_dict["privileged_obs"][:n])
-        runner.alg.update()
-        if it % args.log_every == 0:
-            faults = env.env.extras["sim_faults"].consume()
-            for k, v in faults.items():
-                if isinstance(v, dict):
-                    for kk, vv in v.items():
-                        totals[f"{k}.{kk}"] = totals.get(f"{k}.{kk}", 0) + int(vv)
-                else:
-                    totals[k] = totals.get(k, 0) + int(v)
-            print(f"it {it:5d}  {it * T * args.envs / 1e6:7.1f} M env-steps  mean step reward {float(rew_acc) / cnt:8.5f}  lr {runner.alg.learning_rate:.2e}  "
-                  f"std {float(runner.alg.std.detach().mean()):.3f}  sim faults fatal {faults['fatal']} dropped {faults.get('contact_dropped', 0)}  [{time.time() - t0:6.1f} s]", flush=True)
-            rew_acc.zero_(); cnt = 0
-        if it in eval_at:
-            for vx in args.vx:
-                r = evaluate(runner, args.eval_envs, vx)
-                print(f"EVAL it {it:5d}  v_cmd {vx:.1f}: mean v_x {r['mean_vx']:.3f}  |v_x - v_cmd| {r['vel_err']:.3f} m/s  yaw drift {r['yaw_drift']:.3f} rad  "
-                      f"gait-schedule match {r['gait_match']:.3f}  fall rate {r['fall_rate']:.3f}", flush=True)
-            runner.alg.actor_critic.train()
-    steps = args.iters * T * args.envs
-    print(f"FAULT SOAK over {steps / 1e6:.1f} M env-steps of training: " + "  ".join(f"{k} {v} ({v / steps:.2e}/env-step)" for k, v in sorted(totals.items())), flush=True)
+    train_and_evaluate(args.iters, args.envs, args.eval_envs, args.eval_at, args.vx, args.log_every, args.fp32,
+                       out=lambda m: print(m, flush=True))
 
 
 if __name__ == "__main__":

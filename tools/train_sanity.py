@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--every", type=int, default=20)
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="PPO_Args.use_hip_graphs = False")
+    ap.add_argument("--rough", action="store_true", help="BASELINE configs[2]: terrain-curriculum tile grid as a trimesh (vertical risers) + height scan")
     ap.add_argument("--check-finite", action="store_true", help="after every iteration: first non-finite tensor among "
                     "observations / rewards / actions / returns / parameters / gradients, then stop")
     args = ap.parse_args()
@@ -31,7 +32,7 @@ def main():
         PPO_Args.use_hip_graphs = False
     RunnerArgs.save_video_interval = 0
     torch.manual_seed(0)
-    env, cfg = build_env(args.envs, 0, 0)
+    env, cfg = build_env(args.envs, 0, 0, rough=args.rough)
     runner = Runner(env, device="cuda:0")
     T = runner.num_steps_per_env
     buf = env.episode_length_buf

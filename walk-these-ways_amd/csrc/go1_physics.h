@@ -1377,7 +1377,8 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         st.y01[1] = fmaf(Bq.u[0][1], m0, fmaf(Bq.u[1][1], m1, fmaf(Bq.u[2][1], m2, st.y01[1])));
         st.y2 = fmaf(Bq.u[0][2], m0, fmaf(Bq.u[1][2], m1, fmaf(Bq.u[2][2], m2, st.y2)));
       }
-      if (leg == 0) CRQ(k, 9) = (lf4){ln, l1, l2, 0.f};
+      // (SIG instances: the 4th word carries "this turn projected the friction impulse on the cone" for the test signature)
+      if (leg == 0) CRQ(k, 9) = (lf4){ln, l1, l2, SIG && nn > lim * lim ? 1.f : 0.f};
     };
 #pragma unroll 1
     for (int it = 0; it < cfg.solver_iterations; it++) {
@@ -1434,6 +1435,26 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
 #pragma unroll
       for (int i = 0; i < 3; i++) nf_acc = nonfinite_acc(nf_acc, lamj[i]);
       if (nf_acc != nf_acc) fault |= 1u << GO1_FAULT_LAMBDA;
+    }
+    if (SIG && B.contact_signature != nullptr && sub < GO1_SIG_MAX_SUBSTEPS) {
+      // tests only: the ACTIVE SET the solve ended in — which contacts press (lambda_n > 0), which slide (cone projection in the
+      // last sweep), which limit rows carry an impulse.  Same contact list + same active set = the same smooth map in oracle
+      // and kernel; anything else is a discrete flip (tests/test_gpu_parity.py Attribution).
+      LDS_PHASE();
+      unsigned jm = 0;
+#pragma unroll
+      for (int jj = 0; jj < 3; jj++) if (lamj[jj] != 0.f) jm |= 1u << (3 * leg + jj);
+      jm = quad_or(jm);
+      if (leg == 0) {
+        uint32_t ah = jm * 0x27D4EB2Fu;
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+          const lf4 q9 = CRQ(k, 9);
+          if (q9[0] > 0.f) ah += (uint32_t)(k + 1) * 0x85EBCA6Bu;
+          if (q9[3] != 0.f) ah += (uint32_t)(k + 1) * 0xC2B2AE35u;
+        }
+        AT(B.contact_signature, sub * GO1_SIG_WORDS + 3, e) += ah;
+      }
     }
   }
 #endif
