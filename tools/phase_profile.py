@@ -14,14 +14,14 @@ CSRC = os.path.join(PKG, "csrc")
 for p in (os.path.join(PKG, "shims"), PKG, REPO):
     sys.path.insert(0, p)
 
-PHASES = ["load state/actions/warm start", "torque model: publish (x4)", "torque pick-up (barrier wait) + ABA pass 2 (x4)",
-          "(unused)", "ABA pass 3 + limit-row bounds + hand-over packets + barrier (x4)", "PGS sweeps (x4)", "apply + integrate (x4)",
+PHASES = ["rest of the prologue (stash commit, input checks)", "torque model: barrier after the publish (x4)", "torque pick-up (barrier wait) + ABA pass 2 (x4)",
+          "prologue: the load batch lands + warm-start impulses into LDS", "ABA pass 3 + limit-row bounds + hand-over packets + barrier (x4)", "PGS sweeps (x4)", "apply + integrate (x4)",
           "store state/feet/forces", "post: derived + callbacks", "post: gait clock + push/dof-rand",
           "post: feet/heights/termination", "post: rewards", "post: reset", "post: observations", "post: privileged obs",
           "post: roll", "post: reward-input loads", "post: termination", "fault flags + sweep bounds (x4)",
           "kinematics + candidates + self-collision geometry + contact list (x4)", "post items into the records (x4)",
           "self-contacts + limit rows + barrier wait for the helpers' rows (x4)",
-          "(unused)", "PGS: warm-start state (x4)"]
+          "torque model: publish the input rows (x4)", "PGS: warm-start state (x4)"]
 
 
 def build(flags):

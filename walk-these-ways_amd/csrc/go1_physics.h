@@ -300,47 +300,64 @@ DEV void compute_torques(CfgRef cfg, BufRef B, Leg& L, int leg, int e, int N, in
 // ABA pass 1) does not need the torques.  So the master wavefront publishes the 192 input rows, the HELPER wavefronts
 // evaluate all 12 tiles while the master runs the kinematics, and the master picks the torques up right before ABA pass 2.
 // What compute_torques() keeps in global memory between substeps (actuator history, lagged targets) lives in a per-lane LDS
-// stash for the duration of the step: loaded by the prologue in one batch (torque_stash_load), written back once
+// stash for the duration of the step: loaded by the prologue in one batch (torque_stash_issue / _commit), written back once
 // (torque_stash_store).  Same arithmetic in the same order as compute_torques(): results are bit-identical.
 #define ACT_MAX_DEC 4
 enum { AH_E1 = 0, AH_E2 = 3, AH_V1 = 6, AH_V2 = 9, AH_MS = 12, AH_MO = 15, AH_TGT = 18, AH_END = AH_TGT + 3 * ACT_MAX_DEC };
 #define ACTH(k) acth[(k) * WAVE + lane]
 
-// act[jj]: the clipped action.  All loads of the lag buffer come before its stores (a substep reads the slot the NEXT
-// substep overwrites).
-DEV void torque_stash_load(CfgRef cfg, BufRef B, float* acth, int lane, int leg, int e, int N, int head, const float act[3]) {
+// Split in two so that the prologue has ONE batch of global loads: torque_stash_issue() only issues loads (nothing depends on
+// the actions), torque_stash_commit() — after the batch has landed — forms the targets, fills the stash and writes the lag
+// buffer.  All loads of the lag buffer come before its stores (a substep reads the slot the NEXT substep overwrites).
+struct StashIn { float lagv[ACT_MAX_DEC][3], e1[3], e2[3], v1[3], v2[3], ms[3], mo[3], dpos[3]; };
+DEV void torque_stash_issue(CfgRef cfg, BufRef B, int leg, int e, int N, int head, StashIn& in) {
   const int nl = cfg.lag_timesteps + 1;
-  float a[3], tg[ACT_MAX_DEC][3];
+#pragma unroll
+  for (int sb = 0; sb < ACT_MAX_DEC; sb++)
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      in.lagv[sb][jj] = 0.f;
+      if (cfg.use_lag && sb < cfg.decimation && sb + 1 < nl) in.lagv[sb][jj] = B.lag_buffer[((size_t)((head + sb + 1) % nl) * 12 + j) * N + e];
+    }
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+    const int j = 3 * leg + jj;
+    in.e1[jj] = AT(B.joint_pos_err_last, j, e);
+    in.e2[jj] = AT(B.joint_pos_err_last_last, j, e);
+    in.v1[jj] = AT(B.joint_vel_last, j, e);
+    in.v2[jj] = AT(B.joint_vel_last_last, j, e);
+    in.ms[jj] = AT(B.motor_strengths, j, e);
+    in.mo[jj] = AT(B.motor_offsets, j, e);
+    in.dpos[jj] = cfg.default_dof_pos[j];        // (indexed by the lane's leg: a vector load from the constant block)
+  }
+}
+// act[jj]: the clipped action
+DEV void torque_stash_commit(CfgRef cfg, BufRef B, float* acth, int lane, int leg, int e, int N, int head, const float act[3], const StashIn& in) {
+  const int nl = cfg.lag_timesteps + 1;
+  float a[3];
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) {
     a[jj] = act[jj] * cfg.action_scale;
     if (jj == 0) a[jj] *= cfg.hip_scale_reduction;
   }
 #pragma unroll
-  for (int sb = 0; sb < ACT_MAX_DEC; sb++)
-#pragma unroll
-    for (int jj = 0; jj < 3; jj++) {
-      const int j = 3 * leg + jj;
-      float t = a[jj];
-      if (cfg.use_lag && sb < cfg.decimation && sb + 1 < nl) t = B.lag_buffer[((size_t)((head + sb + 1) % nl) * 12 + j) * N + e];
-      tg[sb][jj] = t + cfg.default_dof_pos[j];
-    }
-#pragma unroll
   for (int jj = 0; jj < 3; jj++) {
-    const int j = 3 * leg + jj;
-    ACTH(AH_E1 + jj) = AT(B.joint_pos_err_last, j, e);
-    ACTH(AH_E2 + jj) = AT(B.joint_pos_err_last_last, j, e);
-    ACTH(AH_V1 + jj) = AT(B.joint_vel_last, j, e);
-    ACTH(AH_V2 + jj) = AT(B.joint_vel_last_last, j, e);
-    ACTH(AH_MS + jj) = AT(B.motor_strengths, j, e);
-    ACTH(AH_MO + jj) = AT(B.motor_offsets, j, e);
+    ACTH(AH_E1 + jj) = in.e1[jj];
+    ACTH(AH_E2 + jj) = in.e2[jj];
+    ACTH(AH_V1 + jj) = in.v1[jj];
+    ACTH(AH_V2 + jj) = in.v2[jj];
+    ACTH(AH_MS + jj) = in.ms[jj];
+    ACTH(AH_MO + jj) = in.mo[jj];
   }
 #pragma unroll
   for (int sb = 0; sb < ACT_MAX_DEC; sb++)
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) {
-      ACTH(AH_TGT + 3 * sb + jj) = tg[sb][jj];
-      if (cfg.use_lag && sb < cfg.decimation) B.lag_buffer[((size_t)((head + sb) % nl) * 12 + 3 * leg + jj) * N + e] = a[jj];
+      const int j = 3 * leg + jj;
+      const float t = (cfg.use_lag && sb < cfg.decimation && sb + 1 < nl) ? in.lagv[sb][jj] : a[jj];
+      ACTH(AH_TGT + 3 * sb + jj) = t + in.dpos[jj];
+      if (cfg.use_lag && sb < cfg.decimation) B.lag_buffer[((size_t)((head + sb) % nl) * 12 + j) * N + e] = a[jj];
     }
 }
 // input rows of substep `sub` into io[A_IN]; the history advances
@@ -1634,16 +1651,28 @@ DEV void store_state(BufRef B, int leg, int e, int N, const Base& s, const Leg& 
   for (int j = 0; j < 3; j++) { AT(B.dof_pos, 3 * leg + j, e) = L.q[j]; AT(B.dof_vel, 3 * leg + j, e) = L.qd[j]; }
 }
 // per-body impulses <-> contact force buffer; each lane moves its leg's 4 bodies, lane 0 also the trunk
-DEV void load_lambda(CfgRef cfg, BufRef B, float* lds, int lane, int e, int N, bool zero) {
+// Two halves, so that the loads join the prologue's single batch: the select on `zero` must not pull them into a branch (the
+// compiler then issues them one at a time with a full wait each — 15 exposed HBM round trips, measured), hence the pin.
+struct LambdaIn { float f[5][3]; };
+DEV void load_lambda_issue(BufRef B, int lane, int e, int N, LambdaIn& in) {
+  const int leg = lane & 3;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    const int b = (i == 4) ? 0 : 1 + 4 * leg + i;       // (the trunk's row is loaded by all four lanes: same address, one request)
+#pragma unroll
+    for (int c = 0; c < 3; c++) in.f[i][c] = AT(B.contact_forces, 3 * b + c, e);
+  }
+}
+DEV void load_lambda_commit(CfgRef cfg, float* lds, int lane, LambdaIn& in, bool zero) {
   const int leg = lane & 3, el = lane >> 2;
 #pragma unroll
   for (int i = 0; i < 5; i++) {
-    if (i == 4 && leg != 0) continue;
     const int b = (i == 4) ? 0 : 1 + 4 * leg + i;       // world force -> world impulse
 #pragma unroll
-    for (int c = 0; c < 3; c++) {          // unconditional load (joins the prologue's batch), then select
-      const float f = AT(B.contact_forces, 3 * b + c, e);
-      LDS(L_LAM + 3 * b + c) = zero ? 0.f : f * cfg.sim_dt;
+    for (int c = 0; c < 3; c++) {
+      VALUE_BARRIER(in.f[i][c]);
+      if (i == 4 && leg != 0) continue;
+      LDS(L_LAM + 3 * b + c) = zero ? 0.f : in.f[i][c] * cfg.sim_dt;
     }
   }
 }

@@ -149,6 +149,8 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   // every load of the prologue is issued before its first store (a store in between would pin the later loads behind
   // it — possible aliasing — and expose one HBM round trip per group)
   load_state(B, leg, e, N, s, L);
+  LambdaIn lam_in;
+  load_lambda_issue(B, lane, e, N, lam_in);
   uint32_t fault = 0;
   uint32_t drops[GO1_CC_COUNT];
 #pragma unroll
@@ -160,14 +162,20 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
     act_in[jj] = substep_only ? 0.f : A.actions[(size_t)e * 12 + j];
     fv_in[jj] = AT(B.foot_velocities, j, e);
   }
-  const bool warm = substep_only ? cfg.warm_start != 0 : (cfg.warm_start && B.episode_length_buf[e] > 0);
-  load_lambda(cfg, B, lds, lane, e, N, !warm);
-  LDS_PHASE();           // the trunk's warm-start impulse is read by all four lanes of the environment
+  int ep_len = B.episode_length_buf[e];
+  StashIn stash_in;
+  if (deferred) torque_stash_issue(cfg, B, leg, e, N, A.lag_head, stash_in);
+  // ---- (end of the prologue's load batch) ----
+  VALUE_BARRIER(ep_len);
+  const bool warm = substep_only ? cfg.warm_start != 0 : (cfg.warm_start && ep_len > 0);
+  load_lambda_commit(cfg, lds, lane, lam_in, !warm);
+  LDS_PHASE();
+  PROF(3);           // the trunk's warm-start impulse is read by all four lanes of the environment
   const V3 grav = gravity_at(cfg, A.counter);
   float act_clipped[3];
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) act_clipped[jj] = fminf(fmaxf(act_in[jj], -cfg.clip_actions), cfg.clip_actions);
-  if (deferred) torque_stash_load(cfg, B, acth, lane, leg, e, N, A.lag_head, act_clipped);
+  if (deferred) torque_stash_commit(cfg, B, acth, lane, leg, e, N, A.lag_head, act_clipped, stash_in);
   if (substep_only) {
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) L.tau[jj] = AT(B.torques, 3 * leg + jj, e);
@@ -198,6 +206,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
     if (substep_only) {
     } else if (deferred) {
       torque_publish(L, acth, Z.act_io(), lane, sub);
+      PROF(22);
       BLOCK_SYNC(nw);
     } else compute_torques(cfg, B, L, leg, e, N, head, act_lds, Z.act_io(), mfma_torque, nw, fault);
 #endif
@@ -226,7 +235,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   __shared__ float lds[L_END * EPW]; \
   __shared__ __attribute__((aligned(16))) lf4 ldsx[X_END]; \
   __shared__ __attribute__((aligned(16))) float act_lds[A_END]; \
-  __shared__ float acth[AH_END * WAVE];          /* per-lane stash of the deferred torque path (torque_stash_load) */
+  __shared__ float acth[AH_END * WAVE];          /* per-lane stash of the deferred torque path (torque_stash_issue / _commit) */
 // instances: terrain (plane | height field | height field with vertical faces) x (plain | contact signature recorded: parity tests)
 #define STEP_KERNEL(name, WALLS, SIG, PLANE) \
   extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) name(const StepArgs A) { STEP_LDS step_body<WALLS, SIG, PLANE>(A, lds, ldsx, act_lds, acth); }
@@ -264,6 +273,8 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   Base s;
   Leg L;
   load_state(B, leg, e, N, s, L);
+  LambdaIn lam_in;
+  load_lambda_issue(B, lane, e, N, lam_in);
   uint32_t fault = 0;
   if (A.mode == 1) {       // torques only (actions given as SoA)
 #pragma unroll
