@@ -2,7 +2,7 @@
 
 Tolerances are stated per quantity where they are applied (one physics substep from identical state: q, root 2e-4, qd 3e-3,
 contact forces 5e-2 N + 2e-3 rel; full step: q, root 1e-3, qd 2e-2, rewards 2e-4, observations 3e-3, torques 5e-3 — on the
-height-field relief: root 3e-3, observations 5e-3 — each with the relative part given next to it).  There is NO free outlier budget.  An environment may exceed a tolerance only if it is
+height-field relief: root 3e-3, observations 5e-3, torques 2e-2 — each with the relative part given next to it).  There is NO free outlier budget.  An environment may exceed a tolerance only if it is
 ATTRIBUTED, in one of three checkable ways, and even then its error stays below ATTRIBUTED_BOUND x the tolerance:
   (a) contact set: the contact points / self pairs / limit-row legs the solver listed in some substep, the height-field cell /
       corner a listed point came from, or the ACTIVE SET the solve ended in (pressing contacts, contacts on the friction cone,
@@ -14,10 +14,11 @@ ATTRIBUTED, in one of three checkable ways, and even then its error stays below 
       no bound applies — the kernel IS a valid fp32 evaluation of the restatement there;
   (b) precision: the fp32 build of the oracle (oracle/_build/libgo1oracle32.so, the same restatement with real = float), run on
       the same inputs beside the fp64 one, uses up a quarter of a tolerance itself in that environment-step (it typically
-      needs 1-3 %), or a tenth of it while coming within a factor 20 of the kernel's error (the kernel's v_rcp / v_rsq based
-      divides and square roots and its matrix-free summation order carry several times the rounding error of the correctly
-      rounded oracle arithmetic; finish() prints the measured bulk factor): the state is ill-conditioned in fp32 (deep
-      interpenetration with kilonewton impulses, a non-converged 20-contact solve), whoever computes it.
+      needs 1-3 %), or a tenth of it while coming within a factor 20 of the kernel's error: the state is ill-conditioned in
+      fp32 (deep interpenetration with kilonewton impulses, a non-converged 20-contact solve), whoever computes it.  (In bulk
+      the kernel's error equals the fp32 oracle's — finish() prints the ratio of the medians, 0.8-1.0 on the MI355X, and the
+      99 % quantiles coincide; in an ill-conditioned step the two are different draws from a heavy-tailed amplification of two
+      different rounding sequences, hence the factor.)
 tests/test_oracle_precision.py measures the rate at which the fp32 oracle alone leaves the tolerances: the same order.
 """
 import numpy as np
@@ -537,8 +538,11 @@ def test_full_step_on_height_field(walls):
         cpu_reset = Bc.reset_buf.bool()
         # (root 3e-3 here: on the relief the contact normals are the bilinear interpolant's gradient AT the contact point, so a
         #  round-off sized shift of the point tilts the whole contact frame — the flat-terrain tests keep 1e-3)
+        # (torques 2e-2: the actuator network's gain on the PREVIOUS substep's position error is 17 N m/rad on average, 23 at the
+        #  99 % quantile (finite differences of oracle/pyoracle.actuator_net), so a q inside its 1e-3 tolerance already moves the
+        #  torque by 2e-2 N m; the flat-terrain tests keep 5e-3 because q agrees to 1e-4 there)
         keys = (("root_states", 3e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
-                ("torques", 5e-3, 1e-3), ("foot_positions", 1e-3, 0), ("measured_heights", 1e-3, 0))
+                ("torques", 2e-2, 1e-3), ("foot_positions", 1e-3, 0), ("measured_heights", 1e-3, 0))
         # A scan point within round-off of a cell boundary reads the neighbouring sample in fp32 (legged_robot.py:1793-1806 floors
         # (x + border) / scale): environments whose ONLY differences are a few of the 187 scan heights (and their observation
         # columns) are attributed to that — the rest of their state, rewards and the 70 proprioceptive columns must agree
