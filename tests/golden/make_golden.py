@@ -1130,6 +1130,34 @@ def gen_callbacks(N=64, seed=51, sim_seed=999, step=200, x_offset_px=0, name="ca
     print(name, "teleported", moved, "pushed", len(push_ids), "re-randomised", len(rn))
 
 
+def gen_ref_adaptation_module():
+    """The reference's PRETRAINED adaptation module (runs/gait-conditioned-agility/pretrain-v0/train/025417.456545/checkpoints/
+    adaptation_module_latest.jit: 2100 -> 256 -> 128 -> 2, ELU; trained on Isaac Gym rollouts of its own policy) as plain
+    arrays (fp32) for tools/adaptation_probe.py (a sim-to-sim indicator: does it recover friction / restitution from THIS
+    simulator's observation histories?).  The run's parameters.pkl gives the observation layout it expects."""
+    import io
+    import pickle
+    run = os.path.join(REF, "runs", "gait-conditioned-agility", "pretrain-v0", "train", "025417.456545")
+    m = torch.jit.load(os.path.join(run, "checkpoints", "adaptation_module_latest.jit"), map_location="cpu")
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+
+    class U(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module == "torch.storage" and name == "_load_from_bytes":
+                return lambda b: torch.load(io.BytesIO(b), map_location="cpu", weights_only=False)
+            return super().find_class(module, name)
+    cfg = U(open(os.path.join(run, "parameters.pkl"), "rb")).load()["Cfg"]
+    x = torch.randn(64, 2100, generator=torch.Generator().manual_seed(0))
+    np.savez_compressed(os.path.join(HERE, "ref_adaptation_module.npz"),
+                        **{"w" + k.replace(".", "_"): v.astype(np.float32) for k, v in sd.items()},
+                        probe_in=x.numpy(), probe_out=m(x).detach().numpy(),
+                        num_observations=np.array(cfg["env"]["num_observations"]), history=np.array(cfg["env"]["num_observation_history"]),
+                        friction_range=np.array(cfg["domain_rand"]["friction_range"]), restitution_range=np.array(cfg["domain_rand"]["restitution_range"]),
+                        norm_friction_range=np.array(cfg["normalization"]["friction_range"]),
+                        norm_restitution_range=np.array(cfg["normalization"]["restitution_range"]))
+    print("ref adaptation module", {k: v.shape for k, v in sd.items()})
+
+
 if __name__ == "__main__":
     install_stubs()
     torch.manual_seed(0)
@@ -1173,6 +1201,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "torques":              # only torques_<variant>.npz of the named variant
         gen_torques(sys.argv[2])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ref_adaptation_module":
+        gen_ref_adaptation_module()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_fuzz":             # only ppo_fuzz<k>.npz
         gen_ppo_fuzz()

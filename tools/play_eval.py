@@ -70,9 +70,9 @@ def evaluate(runner, num_envs, vx, steps=250, seed=1):
                 mean_vx=float(base.base_lin_vel[:, 0][~fell].mean()) if bool((~fell).any()) else float("nan"))
 
 
-def train_and_evaluate(iters, envs=4096, eval_envs=512, eval_at=None, vxs=(1.0, 1.5), log_every=500, fp32=False, out=print):
+def train_and_evaluate(iters, envs=4096, eval_envs=512, eval_at=None, vxs=(1.0, 1.5), log_every=500, fp32=False, out=print, after=None):
     """Train with scripts/train.py's configuration (bench.py's loop), evaluate at the iterations `eval_at`; returns
-    ({iteration: [evaluate() records]}, fault totals over the training)."""
+    ({iteration: [evaluate() records]}, fault totals over the training).  `after(runner, env, obs_dict)`: called once the training is over."""
     from bench import build_env
     from go1_gym_learn.ppo_cse import Runner, RunnerArgs
     from go1_gym_learn.ppo_cse.ppo import PPO_Args
@@ -118,6 +118,8 @@ def train_and_evaluate(iters, envs=4096, eval_envs=512, eval_at=None, vxs=(1.0, 
                 out(f"EVAL it {it:5d}  v_cmd {vx:.1f}: mean v_x {r['mean_vx']:.3f}  |v_x - v_cmd| {r['vel_err']:.3f} m/s  yaw drift {r['yaw_drift']:.3f} rad  "
                     f"gait-schedule match {r['gait_match']:.3f}  fall rate {r['fall_rate']:.3f}")
             runner.alg.actor_critic.train()
+    if after is not None:
+        after(runner, env, obs_dict)
     steps = iters * T * envs
     out(f"FAULT SOAK over {steps / 1e6:.1f} M env-steps of training: " + "  ".join(f"{k} {v} ({v / steps:.2e}/env-step)" for k, v in sorted(totals.items())))
     return results, totals
