@@ -12,22 +12,22 @@ for p in (os.path.join(PKG, "shims"), PKG, REPO):
 import torch  # noqa: E402
 
 
-def run(use_graphs, bf16, updates, N, T, inference_mode):
+def run(use_graphs, bf16, updates, N, T, inference_mode, fused=False, no=70, H=30):
     from go1_gym_learn.ppo_cse.actor_critic import ActorCritic
     from go1_gym_learn.ppo_cse.ppo import PPO, PPO_Args
-    PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs, PPO_Args.use_fused_kernels = bf16, use_graphs, False
+    PPO_Args.autocast_bf16, PPO_Args.use_hip_graphs, PPO_Args.use_fused_kernels = bf16 or fused, ("all" if use_graphs else False), fused
     torch.manual_seed(0)
-    alg = PPO(ActorCritic(70, 2, 2100, 12), device="cuda:0")
-    alg.init_storage(N, T, [70], [2], [2100], [12])
+    alg = PPO(ActorCritic(no, 2, no * H, 12), device="cuda:0")
+    alg.init_storage(N, T, [no], [2], [no * H], [12])
     g = torch.Generator(device="cuda").manual_seed(1)
     out = []
     import contextlib
     for it in range(updates):
         with (torch.inference_mode() if inference_mode else contextlib.nullcontext()):
             for t in range(T):
-                obs = torch.randn(N, 70, device="cuda", generator=g)
+                obs = torch.randn(N, no, device="cuda", generator=g)
                 priv = torch.randn(N, 2, device="cuda", generator=g)
-                hist = torch.randn(N, 2100, device="cuda", generator=g)
+                hist = torch.randn(N, no * H, device="cuda", generator=g)
                 torch.manual_seed(10 * it + t)
                 alg.act(obs, priv, hist)
                 alg.process_env_step(torch.randn(N, device="cuda", generator=g), torch.zeros(N, dtype=torch.uint8, device="cuda"),
@@ -47,11 +47,15 @@ def main():
     ap.add_argument("--envs", type=int, default=512)
     ap.add_argument("--T", type=int, default=8)
     ap.add_argument("--no-inference-mode", action="store_true")
+    ap.add_argument("--fused", action="store_true", help="the bf16 fused update (atomics: eager vs eager is not bit-equal either; compare the sizes)")
+    ap.add_argument("--obs", type=int, default=70)
+    ap.add_argument("--hist", type=int, default=30)
     args = ap.parse_args()
     im = not args.no_inference_mode
-    a = run(False, args.bf16, args.updates, args.envs, args.T, im)
-    a2 = run(False, args.bf16, args.updates, args.envs, args.T, im)
-    b = run(True, args.bf16, args.updates, args.envs, args.T, im)
+    kw = dict(fused=args.fused, no=args.obs, H=args.hist)
+    a = run(False, args.bf16, args.updates, args.envs, args.T, im, **kw)
+    a2 = run(False, args.bf16, args.updates, args.envs, args.T, im, **kw)
+    b = run(True, args.bf16, args.updates, args.envs, args.T, im, **kw)
     for u in range(args.updates):
         (w0, l0, lr0, g0), (w1, l1, lr1, g1), (w2, _, _, _) = a[u], b[u], a2[u]
         print(f"update {u}: eager-vs-eager {float((w0 - w2).abs().max()):.3e}   graph-vs-eager max|dw| {float((w0 - w1).abs().max()):.3e}  "
