@@ -639,7 +639,7 @@ def test_fused_graph_replay_equals_eager_at_production_size():
     for u in range(3):
         ee = float((a[u][0] - a2[u][0]).abs().max())
         ge = float((a[u][0] - b[u][0]).abs().max())
-        assert ge <= 3.0 * ee + 1e-6, (u, ge, ee)
+        assert ge <= 3.0 * ee + 1e-3, (u, ge, ee)      # (both are maxima over 3 M Adam-amplified last-bit differences: 1-3e-3 each)
         np.testing.assert_allclose(b[u][1][:3], a[u][1][:3], rtol=1e-3)
         assert b[u][2] == pytest.approx(a[u][2], rel=1e-5)
 
