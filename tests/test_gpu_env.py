@@ -78,6 +78,49 @@ def test_hip_torque_model_matches_reference_golden(variant, n_env):
     assert int(Bg.fault_counts.sum()) == 0
 
 
+@pytest.mark.parametrize("variant", ["train", "act_nolag"])          # (the actuator-network variants: the deferred path)
+def test_deferred_torque_path_of_the_step_kernel_matches_reference_golden(variant):
+    """The torque path the PRODUCT runs — inside go1sim_step the actuator network is evaluated by the helper wavefronts
+    (`torque_publish` -> `actuator_tiles` -> `torque_collect`, csrc/go1sim.hip step_body `deferred`), not by the piecewise
+    `go1sim_compute_torques` entry point of the test above — pinned to the SAME reference fixtures at the SAME tolerance
+    (tests/golden/torques_*.npz: the reference's `_compute_torques` with the TorchScript network, legged_robot.py:907-946).
+    One full step per fixture row with `decimation = 1`: the step's only substep computes its torque from the fixture's
+    (q, qd, action) and the carried actuator history / lag buffer, and `torques` holds it afterwards.  The robots hang in the
+    air with the episode clock held at 0 so that no reset clears the carried state."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", f"torques_{variant}.npz"))
+    steps, n_env = d["actions"].shape[0], 16
+    cfg, S, meta, Bc = make_sim(variant, n_env, extra={"control": dict(decimation=1), "domain_rand": dict(randomize_gravity=False)})
+    assert S.decimation == 1 and S.control_type == 1
+    Bg = Bc.clone_to("cuda:0")
+    sim = H.Go1Sim(S, Bg, 0)
+    sim.reset_idx()                       # commands, gait clock, feet: everything the step's tensor maps read (the reset draws the motor
+    torch.cuda.synchronize()              # parameters too: the fixture's go in afterwards)
+    for k in ("motor_strengths", "motor_offsets", "Kp_factors", "Kd_factors"):
+        getattr(Bg, k).copy_(torch.from_numpy(d[k][:n_env]).t())
+    root0 = Bg.root_states.clone()
+    root0[2] = 3.0
+    root0[3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0], device=root0.device).unsqueeze(1)
+    root0[7:13] = 0.0
+    worst = 0.0
+    clip = float(S.clip_actions)
+    for s_ in range(steps):
+        Bg.dof_pos.copy_(torch.from_numpy(d["dof_pos"][s_][:n_env]).t())
+        Bg.dof_vel.copy_(torch.from_numpy(d["dof_vel"][s_][:n_env]).t())
+        Bg.root_states.copy_(root0)
+        Bg.episode_length_buf.zero_()
+        a = np.ascontiguousarray(d["actions"][s_][:n_env])
+        assert float(np.abs(a).max()) <= clip
+        sim.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        assert int(Bg.reset_buf.sum()) == 0, s_
+        tau = Bg.torques.t().cpu().numpy()
+        np.testing.assert_allclose(Bg.joint_pos_target.t().cpu().numpy(), d["joint_pos_target"][s_][:n_env], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(tau, d["torques"][s_][:n_env], rtol=1e-5, atol=2e-5)
+        worst = max(worst, float(np.abs(tau - d["torques"][s_][:n_env]).max()))
+    print(f"deferred torque path vs reference ({variant}): max abs error {worst:.2e} N m over {steps} steps")
+    assert int(Bg.fault_counts[:10].sum()) == 0
+
+
 def build_env(N=64):
     from go1_gym.envs.base.legged_robot_config import make_cfg
     from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv

@@ -3,7 +3,7 @@
 Tolerances are stated per quantity where they are applied (one physics substep from identical state: q, root 2e-4, qd 3e-3,
 contact forces 5e-2 N + 2e-3 rel; full step: q, root 1e-3, qd 2e-2, rewards 2e-4, observations 3e-3, torques 5e-3 — on the
 height-field relief: root 3e-3, observations 5e-3, torques 2e-2 — each with the relative part given next to it).  There is NO free outlier budget.  An environment may exceed a tolerance only if it is
-ATTRIBUTED, in one of three checkable ways, and even then its error stays below ATTRIBUTED_BOUND x the tolerance:
+ATTRIBUTED, in one of three checkable ways, and even then its error stays below ATTRIBUTED_BOUND (20) x the tolerance:
   (a) contact set: the contact points / self pairs / limit-row legs the solver listed in some substep, the height-field cell /
       corner a listed point came from, or the ACTIVE SET the solve ended in (pressing contacts, contacts on the friction cone,
       limit rows carrying an impulse) differ between kernel and oracle — both record them (include/go1sim.h
@@ -13,14 +13,22 @@ ATTRIBUTED, in one of three checkable ways, and even then its error stays below 
       decision both fp32 evaluations take the same way and fp64 the other, e.g. the termination threshold on the base height):
       no bound applies — the kernel IS a valid fp32 evaluation of the restatement there;
   (b) precision: the fp32 build of the oracle (oracle/_build/libgo1oracle32.so, the same restatement with real = float), run on
-      the same inputs beside the fp64 one, uses up a quarter of a tolerance itself in that environment-step (it typically
-      needs 1-3 %), or a tenth of it while coming within a factor 20 of the kernel's error: the state is ill-conditioned in
+      the same inputs beside the fp64 one, uses up a tenth of a tolerance itself in that environment-step (it typically
+      needs 1-3 %) AND comes within a factor 20 of the kernel's error: the state is ill-conditioned in
       fp32 (deep interpenetration with kilonewton impulses, a non-converged 20-contact solve), whoever computes it.  (In bulk
       the kernel's error equals the fp32 oracle's — finish() prints the ratio of the medians, 0.8-1.0 on the MI355X, and the
       99 % quantiles coincide; in an ill-conditioned step the two are different draws from a heavy-tailed amplification of two
       different rounding sequences, hence the factor.)
 tests/test_oracle_precision.py measures the rate at which the fp32 oracle alone leaves the tolerances: the same order.
+
+The kernels the PRODUCT launches carry no signature code (csrc/go1sim.hip: go1_step_kernel / _hf / _walls; the `_sig` twins are
+separate template instances).  test_product_instances_match_oracle runs those three at BASELINE's 4096 environments against the
+oracle with rules (b) / (c); rule (a) is admitted there only for an environment-step in which the product instance's outputs
+are BIT-IDENTICAL to its `_sig` twin's, stepped beside it from the same inputs — then, and only then, the twin's record
+describes what the product instance computed.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -61,10 +69,58 @@ class Shadow32:
         o.common_step_counter, o.lag_head, o.history_slot = c.common_step_counter, c.lag_head, c.history_slot
 
 
-def to_gpu(S, Bc):
+def to_gpu(S, Bc, product=False):
+    """product: WITHOUT the contact-signature buffer, so that go1sim_step launches the instances the product launches
+    (go1_step_kernel / _hf / _walls, csrc/go1sim.hip `launch`) instead of their `_sig` twins"""
     Bg = Bc.clone_to("cuda:0")
+    if product:
+        Bg.tensors["contact_signature"] = None
+        Bg.refresh_struct()
+        assert not Bg.struct.contact_signature
     sim = H.Go1Sim(S, Bg, 0)
     return Bg, sim
+
+
+ROW_MAJOR = ("obs_buf", "privileged_obs_buf", "obs_history")
+
+
+def identical_envs(Ba, Bb, N, keys):
+    """(N,) bool: every listed output of the environment is bit-identical in the two buffer sets"""
+    same = torch.ones(N, dtype=torch.bool)
+    for k in keys:
+        a, b = Ba.tensors[k], Bb.tensors[k]
+        ne = a != b
+        if a.is_floating_point():
+            ne = ne & ~(a.isnan() & b.isnan())
+        per_env = ne.reshape(N, -1).any(1) if k in ROW_MAJOR else ne.reshape(-1, N).any(0)
+        same &= ~per_env.cpu()
+    return same
+
+
+class ProductPair:
+    """a product instance of the step kernel (no signature buffer) and its `_sig` twin, stepped from the same inputs"""
+
+    def __init__(self, S, Bc, orc, keys):
+        self.Bc, self.orc, self.keys = Bc, orc, list(keys) + ["contact_forces", "reset_buf", "time_out_buf"]
+        self.Bg, self.sim = to_gpu(S, Bc, product=True)
+        self.Bt, self.sim_t = to_gpu(S, Bc)
+        self.env_steps = self.differ = 0
+
+    def step(self, a):
+        self.sim.step(a)
+        self.sim_t.step(a)
+        torch.cuda.synchronize()
+        same = identical_envs(self.Bg, self.Bt, self.Bc.root_states.shape[1], self.keys)
+        self.env_steps += same.numel()
+        self.differ += int((~same).sum())
+        return (self.Bt, same)
+
+    def sync(self):
+        sync_from(self.Bc, self.Bg, self.sim, self.orc)
+        sync_from(self.Bc, self.Bt, self.sim_t, self.orc)
+
+    def note(self):
+        return f"; product instance vs `_sig` twin: {self.differ} of {self.env_steps} env-steps not bit-identical"
 
 
 def sync_from(Bc, Bg, sim, orc):
@@ -74,7 +130,7 @@ def sync_from(Bc, Bg, sim, orc):
     sim.set_counters(orc.ctr.common_step_counter, orc.ctr.lag_head)
 
 
-ATTRIBUTED_BOUND = 50.0          # x tolerance: what a contact point entering / leaving the solver's list may change in one step
+ATTRIBUTED_BOUND = 20.0          # x tolerance: what a contact point entering / leaving the solver's list may change in one step (measured worst: x10.8)
 ATTRIBUTED_RATE = 5e-3           # fraction of environment-steps allowed to be attributed (flat terrain, measured: 0; robots thrown INTO a
                                  # staircase with kilonewton depenetration impulses: 2.4e-3; fp32-vs-fp64 oracle alone: 3e-5 .. 2e-3)
 
@@ -85,20 +141,28 @@ class Attribution:
     def __init__(self, N):
         self.N, self.env_steps, self.bad, self.attributed, self.worst_ratio, self.worst_unattr = N, 0, 0, 0, 0.0, 0.0
         self.r_all, self.r32_all = [], []
+        self.note = ""
 
     def ratio(self, a, b, atol, rtol=0.0, env_dim=-1):
-        a, b = a.double().cpu(), b.double().cpu()
+        dev = "cuda" if (a.is_cuda or b.is_cuda) else "cpu"          # (the arithmetic of the CHECK runs where the data is: 4096-env histories)
+        a, b = a.to(dev).double(), b.to(dev).double()
         r = (a - b).abs() / (atol + rtol * b.abs())
         r = torch.nan_to_num(r, nan=float("inf"))
         if env_dim == 0:
-            return r.reshape(self.N, -1).max(1).values
-        return r.reshape(-1, self.N).max(0).values
+            return r.reshape(self.N, -1).max(1).values.cpu()
+        return r.reshape(-1, self.N).max(0).values.cpu()
 
-    def step(self, ratio_fn, Bg, Bc, B32=None, reset_key=None, also_attributed=None):
+    def step(self, ratio_fn, Bg, Bc, B32=None, reset_key=None, also_attributed=None, twin=None):
         """ratio_fn(Bx, Bref) -> (N,) worst error / tolerance of every environment this step; B32: the fp32 oracle's buffers;
-        reset_key: a buffer whose mismatch (termination decided differently) puts the environment outside the tolerances."""
+        reset_key: a buffer whose mismatch (termination decided differently) puts the environment outside the tolerances;
+        twin = (Bt, identical): Bg carries no signature (a product instance) — rule (a) reads the record of the `_sig` twin Bt for
+        the environments whose outputs are bit-identical in the two (`identical`, (N,) bool)."""
         ratio = ratio_fn(Bg, Bc)
-        sig = (Bg.contact_signature.cpu() != Bc.contact_signature).any(0)
+        if twin is not None:
+            assert Bg.contact_signature is None
+            sig = (twin[0].contact_signature.cpu() != Bc.contact_signature).any(0) & twin[1]
+        else:
+            sig = (Bg.contact_signature.cpu() != Bc.contact_signature).any(0)
         bad = ratio > 1.0
         if reset_key is not None:
             bad = bad | (Bg.tensors[reset_key].cpu().bool() != Bc.tensors[reset_key].bool())
@@ -107,14 +171,14 @@ class Attribution:
             sig = sig | also_attributed
         if B32 is not None:
             # (b): ill-conditioned in fp32 — the fp32 oracle, whose error in a well-conditioned environment-step is 1-3 % of a
-            # tolerance (printed by finish()), uses up a quarter of it here, or a tenth while within a factor 20 of the kernel's error;
+            # tolerance (printed by finish()), uses up a tenth of it here AND is within a factor 20 of the kernel's error;
             # (c): the kernel REPRODUCES the fp32 oracle within the tolerances (a decision both fp32 evaluations take the same
             # way and fp64 the other — e.g. a termination threshold): no bound on how far that is from the fp64 result
             ratio32 = ratio_fn(B32, Bc)
             same32 = ratio_fn(Bg, B32) <= 1.0
             if reset_key is not None:
                 same32 = same32 & (Bg.tensors[reset_key].cpu().bool() == B32.tensors[reset_key].bool())
-            sig = sig | (ratio32 > 0.25) | ((ratio32 > 0.1) & (ratio32 > 0.05 * ratio)) | same32
+            sig = sig | ((ratio32 > 0.1) & (ratio <= 20.0 * ratio32)) | same32
             self.r32_all.append(ratio32.clone()); self.r_all.append(ratio.clone())
         un = bad & ~sig
         if bool(un.any()) and B32 is not None:
@@ -140,8 +204,12 @@ class Attribution:
             q = (f"; error / tolerance, median | 99 % | max: kernel {float(r.median()):.3f} | {float(r.quantile(0.99)):.3f} | {float(r.max()):.2f}, "
                  f"fp32 oracle {float(r32.median()):.3f} | {float(r32.quantile(0.99)):.3f} | {float(r32.max()):.2f}; "
                  f"bulk factor kernel / fp32 oracle (ratio of medians) {float(r.median()) / max(float(r32.median()), 1e-9):.1f}")
-        print(f"{what}: {self.env_steps} env-steps, {self.bad} outside the tolerances, all attributed "
-              f"(rate {rate:.2e}, worst x{self.worst_ratio:.1f} of the tolerance){q}")
+        line = (f"{what}: {self.env_steps} env-steps, {self.bad} outside the tolerances, all attributed "
+                f"(rate {rate:.2e}, worst x{self.worst_ratio:.1f} of the tolerance){q}{self.note}")
+        print(line)
+        if os.environ.get("GO1_PARITY_LOG"):            # the GPU run's summaries, committed as profiles/r04_parity_rates.txt
+            with open(os.environ["GO1_PARITY_LOG"], "a") as f:
+                f.write(line + "\n")
         assert rate <= ATTRIBUTED_RATE, rate
         assert self.worst_ratio <= ATTRIBUTED_BOUND, self.worst_ratio
 
@@ -249,18 +317,19 @@ FULL_STEP_TOL = (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 
 ROW_TOL = (("obs_buf", 3e-3, 1e-3), ("privileged_obs_buf", 1e-5, 0), ("obs_history", 3e-3, 1e-3))
 
 
-def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=None, what="full step"):
+def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=None, what="full step", product=False):
     """HIP step vs oracle step on identical state / action / RNG streams, re-synchronised after every step so that each
     step is compared on its own (a free-running pair diverges through contact-mode flips, as two fp32 PhysX runs
     would).  Every environment outside the per-quantity tolerances must be attributed (module docstring); returns the
     Attribution record and event counts."""
     cfg, S, meta, Bc, orc = gpu_pair(variant, N, seed=seed)
-    Bg, sim = to_gpu(S, Bc)
+    pp = ProductPair(S, Bc, orc, [k for k, _, _ in FULL_STEP_TOL + ROW_TOL]) if product else None
+    Bg, sim = (pp.Bg, pp.sim) if product else to_gpu(S, Bc)
     rng = np.random.default_rng(0)
     Bc.episode_length_buf[:] = torch.randint(0, S.max_episode_length, (N,), dtype=torch.int32, generator=torch.Generator().manual_seed(2))
     if prepare is not None:
         prepare(S, Bc)
-    sync_from(Bc, Bg, sim, orc)
+    pp.sync() if product else sync_from(Bc, Bg, sim, orc)
     sh = Shadow32(S, Bc, orc)
     resets = 0
     resamples = 0
@@ -275,11 +344,15 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
             watch(S, Bc, "before")
         orc.step(a)
         sh.o.step(a)
-        sim.step(torch.from_numpy(a).cuda())
-        torch.cuda.synchronize()
+        twin = None
+        if product:
+            twin = pp.step(torch.from_numpy(a).cuda())
+        else:
+            sim.step(torch.from_numpy(a).cuda())
+            torch.cuda.synchronize()
         cpu_reset = Bc.reset_buf.bool()
         np.testing.assert_array_equal(Bg.time_out_buf.cpu().numpy(), Bc.time_out_buf.numpy())
-        bad_env = att.step(make_ratio(att, FULL_STEP_TOL, ROW_TOL), Bg, Bc, sh.B, reset_key="reset_buf")
+        bad_env = att.step(make_ratio(att, FULL_STEP_TOL, ROW_TOL), Bg, Bc, sh.B, reset_key="reset_buf", twin=twin)
         timeouts += int(Bc.time_out_buf.sum())
         np.testing.assert_array_equal(Bg.env_command_bins.cpu().numpy()[~bad_env.numpy()], Bc.env_command_bins.numpy()[~bad_env.numpy()])
         np.testing.assert_allclose(Bg.curriculum_weights.cpu().numpy(), Bc.curriculum_weights.numpy(), atol=0.21 * float(bad_env.sum()) + 1e-6)
@@ -290,9 +363,10 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
             for k in ("payloads", "friction_coeffs", "restitutions", "com_displacements"):
                 bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], 1e-6)
                 assert not bool(bad[..., ~bad_env].any()), k
-        sync_from(Bc, Bg, sim, orc)
+        pp.sync() if product else sync_from(Bc, Bg, sim, orc)
         sh.sync()
     assert int(Bg.fault_counts[:10].sum()) == 0, Bg.fault_counts.tolist()
+    att.note = pp.note() if product else ""
     att.finish(f"{what} [{variant}, {N} envs x {steps} steps]")
     return att, resets, resamples, timeouts
 
@@ -500,11 +574,10 @@ def test_physics_substep_on_height_field(scenario, walls):
     assert wall_contacts == 0 if not walls else (wall_contacts > 0 or scenario == "standing"), wall_contacts       # the vertical faces were hit
 
 
-@pytest.mark.parametrize("walls", [False, True])
-def test_full_step_on_height_field(walls):
-    """40 full steps with the 187-point height scan in the observation, resets onto the field and the
-    height-relative termination test (legged_robot.py:160-178, 1793-1806); walls: as a `trimesh` terrain (vertical risers)."""
-    N = 256
+def run_height_field_comparison(walls, N=256, steps=40, product=False):
+    """full steps on the rough int16 height field of rough_field(): 187-point height scan in the observation, resets onto the
+    field, the height-relative termination test (legged_robot.py:160-178, 1793-1806); walls: as a `trimesh` terrain (vertical
+    risers).  product: the instance the product launches (no signature code) beside its `_sig` twin."""
     pts_x = [round(-0.8 + 0.1 * i, 1) for i in range(17)]
     pts_y = [round(-0.5 + 0.1 * i, 1) for i in range(11)]
     ex = {"terrain": dict(measure_heights=True, measured_points_x=pts_x, measured_points_y=pts_y),
@@ -523,26 +596,31 @@ def test_full_step_on_height_field(walls):
     Bc.env_origins[2] = torch.from_numpy(hs.astype(np.float32))[ix, iy] * vscale + 0.05
     orc = pyoracle.Oracle(S, Bc)
     orc.reset_idx()
-    Bg, sim = to_gpu(S, Bc)
-    sync_from(Bc, Bg, sim, orc)
+    # (root 3e-3 here: on the relief the contact normals are the bilinear interpolant's gradient AT the contact point, so a
+    #  round-off sized shift of the point tilts the whole contact frame — the flat-terrain tests keep 1e-3)
+    # (torques 2e-2: the actuator network's gain on the PREVIOUS substep's position error is 17 N m/rad on average, 23 at the
+    #  99 % quantile (finite differences of oracle/pyoracle.actuator_net), so a q inside its 1e-3 tolerance already moves the
+    #  torque by 2e-2 N m; the flat-terrain tests keep 5e-3 because q agrees to 1e-4 there)
+    keys = (("root_states", 3e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
+            ("torques", 2e-2, 1e-3), ("foot_positions", 1e-3, 0), ("measured_heights", 1e-3, 0))
+    pp = ProductPair(S, Bc, orc, [k for k, _, _ in keys] + ["obs_buf", "obs_history"]) if product else None
+    Bg, sim = (pp.Bg, pp.sim) if product else to_gpu(S, Bc)
+    pp.sync() if product else sync_from(Bc, Bg, sim, orc)
     sh = Shadow32(S, Bc, orc)
     rng = np.random.default_rng(0)
     resets = 0
     att = Attribution(N)
-    for step in range(40):
+    for step in range(steps):
         a = (rng.standard_normal((N, 12)) * (1.0 if step % 2 else 0.3)).astype(np.float32)
         orc.step(a)
         sh.o.step(a)
-        sim.step(torch.from_numpy(a).cuda())
-        torch.cuda.synchronize()
+        twin = None
+        if product:
+            twin = pp.step(torch.from_numpy(a).cuda())
+        else:
+            sim.step(torch.from_numpy(a).cuda())
+            torch.cuda.synchronize()
         cpu_reset = Bc.reset_buf.bool()
-        # (root 3e-3 here: on the relief the contact normals are the bilinear interpolant's gradient AT the contact point, so a
-        #  round-off sized shift of the point tilts the whole contact frame — the flat-terrain tests keep 1e-3)
-        # (torques 2e-2: the actuator network's gain on the PREVIOUS substep's position error is 17 N m/rad on average, 23 at the
-        #  99 % quantile (finite differences of oracle/pyoracle.actuator_net), so a q inside its 1e-3 tolerance already moves the
-        #  torque by 2e-2 N m; the flat-terrain tests keep 5e-3 because q agrees to 1e-4 there)
-        keys = (("root_states", 3e-3, 1e-3), ("dof_pos", 1e-3, 0), ("dof_vel", 2e-2, 1e-3), ("rew_buf", 2e-4, 1e-3),
-                ("torques", 2e-2, 1e-3), ("foot_positions", 1e-3, 0), ("measured_heights", 1e-3, 0))
         # A scan point within round-off of a cell boundary reads the neighbouring sample in fp32 (legged_robot.py:1793-1806 floors
         # (x + border) / scale): environments whose ONLY differences are a few of the 187 scan heights (and their observation
         # columns) are attributed to that — the rest of their state, rewards and the 70 proprioceptive columns must agree
@@ -550,13 +628,42 @@ def test_full_step_on_height_field(walls):
         core = make_ratio(att, keys[:-1])(Bg, Bc)
         prop = att.ratio(Bg.obs_buf[:, :70].contiguous(), Bc.obs_buf[:, :70].contiguous(), 5e-3, 1e-3, env_dim=0)
         scan_flip = (scan_pts > 0) & (scan_pts <= 4) & (core <= 1.0) & (prop <= 1.0)
-        att.step(make_ratio(att, keys, (("obs_buf", 5e-3, 1e-3),)), Bg, Bc, sh.B, reset_key="reset_buf", also_attributed=scan_flip)
+        att.step(make_ratio(att, keys, (("obs_buf", 5e-3, 1e-3),)), Bg, Bc, sh.B, reset_key="reset_buf", also_attributed=scan_flip, twin=twin)
         resets += int(cpu_reset.sum())
-        sync_from(Bc, Bg, sim, orc)
+        pp.sync() if product else sync_from(Bc, Bg, sim, orc)
         sh.sync()
-    att.finish(f"height-field full step (walls={walls})")
+    assert int(Bg.fault_counts[:10].sum()) == 0, Bg.fault_counts.tolist()
+    att.note = pp.note() if product else ""
+    att.finish(f"height-field full step (walls={walls}{', PRODUCT instance' if product else ''}) [{N} envs x {steps} steps]")
     assert Bc.obs_buf.shape[1] == 257 and float(Bc.obs_buf[:, 70:].abs().max()) > 0.1
-    assert resets > 5
+    assert resets > 5 or steps < 40
+    return att, pp
+
+
+@pytest.mark.parametrize("walls", [False, True])
+def test_full_step_on_height_field(walls):
+    """40 full steps with the 187-point height scan in the observation, resets onto the field and the
+    height-relative termination test (legged_robot.py:160-178, 1793-1806); walls: as a `trimesh` terrain (vertical risers)."""
+    run_height_field_comparison(walls)
+
+
+@pytest.mark.parametrize("instance", ["plane", "hf", "walls"])
+def test_product_instances_match_oracle(instance):
+    """The kernels the PRODUCT launches and bench.py times — go1_step_kernel (plane), go1_step_kernel_hf, go1_step_kernel_walls:
+    the template instances WITHOUT the contact-signature code (csrc/go1sim.hip `launch`: chosen when Go1SimBuffers.contact_signature
+    is NULL) — against the oracle at BASELINE configs[1] / [2]'s 4096 environments, 40 full steps re-synchronised every step
+    (reference legged_robot.py:60-88, 907-946), tolerances of FULL_STEP_TOL (relief: those of test_full_step_on_height_field).
+    Attribution by the fp32-oracle rules (b) / (c); rule (a) only for an environment-step whose outputs are bit-identical in
+    the product instance and in its `_sig` twin stepped beside it (module docstring) — the count of environment-steps in which
+    the two instances differ at all is part of the summary line."""
+    N = int(os.environ.get("GO1_PRODUCT_PARITY_ENVS", "4096"))        # (tools/dry_run_gpu_tests.py: the emulator needs a smaller count)
+    steps = 40 if N >= 4096 else 6
+    if instance == "plane":
+        att, resets, resamples, _ = run_full_step_comparison("train_noise", N, steps, what="PRODUCT instance, plane", product=True)
+        assert (resets > N // 64 and resamples > N // 64) or steps < 40
+    else:
+        att, pp = run_height_field_comparison(instance == "walls", N=N, steps=steps, product=True)
+    assert att.env_steps == N * steps
 
 
 def test_determinism_and_shard_independence():
@@ -713,6 +820,7 @@ def test_train_eval_split_matches_oracle():
     _, S_ev_full, _, _ = make_sim("dr", N, seed=5, extra=ev)
     S_eval = H.make_eval_sim_config(S, S_ev_full)
     randomize_dr(Bc, 5)
+    Bc.enable_contact_signature()
     Bc.episode_sums_eval.fill_(-1.0)
     orc = pyoracle.Oracle(S, Bc)
     orc.set_eval_config(S_eval, NT)
@@ -724,21 +832,22 @@ def test_train_eval_split_matches_oracle():
     with pytest.raises(RuntimeError):
         sim.set_eval_config(S_eval, 250)                    # not a multiple of 16
     sync_from(Bc, Bg, sim, orc)
+    sh = Shadow32(S, Bc, orc)
+    sh.o.set_eval_config(S_eval, NT)
     rng = np.random.default_rng(2)
-    bad_total, train_resets = 0.0, 0
+    train_resets = 0
+    att = Attribution(N)          # no free budget: an environment outside the tolerances must be attributed (module docstring)
+    keys = (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("friction_coeffs", 1e-6, 0), ("restitutions", 1e-6, 0),
+            ("payloads", 1e-6, 0), ("motor_strengths", 1e-6, 0), ("motor_offsets", 1e-6, 0), ("rew_buf", 2e-4, 1e-3),
+            ("commands", 1e-5, 0), ("episode_sums", 1e-3, 1e-3), ("episode_sums_eval", 1e-3, 1e-3))
     for step in range(40):
         a = (rng.standard_normal((N, 12)) * 0.5).astype(np.float32)
         Bg.episode_log.zero_()
         orc.step(a)
+        sh.o.step(a)
         sim.step(torch.from_numpy(a).cuda())
         torch.cuda.synchronize()
-        bad_env = Bg.reset_buf.cpu().bool() != Bc.reset_buf.bool()
-        for k, tol, rt in (("root_states", 1e-3, 1e-3), ("dof_pos", 1e-3, 0), ("friction_coeffs", 1e-6, 0), ("restitutions", 1e-6, 0),
-                           ("payloads", 1e-6, 0), ("motor_strengths", 1e-6, 0), ("motor_offsets", 1e-6, 0), ("rew_buf", 2e-4, 1e-3),
-                           ("commands", 1e-5, 0), ("episode_sums", 1e-3, 1e-3), ("episode_sums_eval", 1e-3, 1e-3)):
-            bad, _ = frac_bad(Bg.tensors[k], Bc.tensors[k], tol, rt)
-            bad_env |= bad.reshape(-1, N).any(0)
-        bad_total += float(bad_env.float().mean())
+        bad_env = att.step(make_ratio(att, keys), Bg, Bc, sh.B, reset_key="reset_buf")
         good = ~bad_env
         n_tr = int((Bc.reset_buf[:NT].bool() & good[:NT]).sum())
         if bool(good.all()):
@@ -746,7 +855,8 @@ def test_train_eval_split_matches_oracle():
             assert int(round(float(Bg.episode_log[-1]))) == int(Bc.reset_buf[:NT].sum())        # training resets only
         train_resets += n_tr
         sync_from(Bc, Bg, sim, orc)
-    assert bad_total / 40 <= 0.02, bad_total / 40
+        sh.sync()
+    att.finish("train / evaluation split [dr, 384 envs x 40 steps]")
     done = Bg.episode_sums_eval[-1].cpu() != -1.0
     assert int(done[NT:].sum()) > 50 and int(done[:NT].sum()) == 0 and train_resets > 50
     fr, ms, pl = Bg.friction_coeffs.cpu(), Bg.motor_strengths.cpu(), Bg.payloads.cpu()
