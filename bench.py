@@ -158,6 +158,44 @@ def time_iterations(runner, env, obs_dict, iters, rollout_only=False, warmup=2):
     return env.num_envs * T * iters / (time.perf_counter() - t0), obs_dict
 
 
+def dropin_default(args, device, iters=40):
+    """What the UNCHANGED scripts/train.py gets (train.py:207-216: Runner with the default PPO_Args, `runner.learn`): the caller sets
+    nothing on PPO_Args — the bf16 policy is selected by the environment variable GO1_POLICY_DTYPE=bf16 alone —
+    and the clock runs over `Runner.learn` itself: logging every iteration, checkpoint + TorchScript export at the end."""
+    import tempfile
+    from go1_gym_learn.ppo_cse import Runner, RunnerArgs
+    from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    from ml_logger import logger
+    keep = (PPO_Args.autocast_bf16, os.environ.get("GO1_POLICY_DTYPE"), os.getcwd(), RunnerArgs.save_video_interval)
+    tmp = tempfile.mkdtemp(prefix="go1_dropin_")
+    try:
+        PPO_Args.autocast_bf16 = False                          # the class default: what train.py leaves it at
+        os.environ["GO1_POLICY_DTYPE"] = "bf16"
+        RunnerArgs.save_video_interval = 0
+        logger.configure("bench_dropin", root=tmp)
+        logger.print_summary = False
+        os.chdir(tmp)
+        env, _ = build_env(args.envs, 0, args.seed)
+        runner = Runner(env, device=device)
+        runner.learn(num_learning_iterations=3, init_at_random_ep_len=True, eval_freq=100)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runner.learn(num_learning_iterations=iters, init_at_random_ep_len=False, eval_freq=100)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"env_steps_s": iters * runner.num_steps_per_env * env.num_envs / dt, "iterations": iters, "ms_per_iteration": 1e3 * dt / iters,
+                "how": "default PPO_Args + GO1_POLICY_DTYPE=bf16 in the environment, Runner.learn() timed as a whole (per-iteration "
+                       "logging, final checkpoint + TorchScript export included)"}
+    finally:
+        PPO_Args.autocast_bf16 = keep[0]
+        if keep[1] is None:
+            os.environ.pop("GO1_POLICY_DTYPE", None)
+        else:
+            os.environ["GO1_POLICY_DTYPE"] = keep[1]
+        os.chdir(keep[2])
+        RunnerArgs.save_video_interval = keep[3]
+
+
 def extra_records(args, env, runner, obs_dict, device):
     """The other measurements SURVEY 8(d) defines, in the same JSON line (rank 0, one GPU): the sim-only and
     sim + inference rates of the headline configuration, BASELINE configs[2] (rough terrain + height scan) and the
@@ -172,6 +210,10 @@ def extra_records(args, env, runner, obs_dict, device):
                         "note": "SURVEY 8(d) metrics 1 and 2 on the headline configuration; metric 3 is `value`"}
     except Exception as err:
         out["rates"] = {"error": f"{type(err).__name__}: {err}"}
+    try:
+        out["dropin_default"] = dropin_default(args, device)
+    except Exception as err:
+        out["dropin_default"] = {"error": f"{type(err).__name__}: {err}"}
     try:
         from torch.cuda import tunable
         if tunable.is_enabled():
@@ -231,6 +273,10 @@ def main():
     ap.add_argument("--zero1", action="store_true", help="N > 1: reduce-scatter + sharded optimiser step + all-gather (PPO_Args.dp_zero1)")
     ap.add_argument("--breakdown", action="store_true", help="diagnostic: print rollout/update split to stderr (adds syncs)")
     ap.add_argument("--headline-only", action="store_true", help="skip the extra single-GPU records (rates, height field, 8192 envs)")
+    ap.add_argument("--curriculum-interval", type=int, default=1,
+                    help="commands.curriculum_update_interval K: 1 = the reference's per-step curriculum update (curriculum.py) at EVERY rank count, so "
+                         "that the 1-GPU headline and the N-GPU scaling numbers run the same algorithm; K > 1 coalesces the sharded run's "
+                         "success-count all-reduce to one per K steps (samples inside the window see the weights from its start)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -285,9 +331,10 @@ def main():
     PPO_Args.dp_grad_dtype, PPO_Args.dp_zero1 = args.grad_dtype, bool(args.zero1)
     RunnerArgs.save_video_interval = 0
     torch.manual_seed(args.seed + rank)
-    # environments sharded over ranks: the command curriculum's success counts are exchanged once per rollout (T = 24 steps, one
-    # 170 KB all-reduce) instead of once per step; the 1-rank run keeps the reference's per-step cadence
-    env, cfg = build_env(args.envs, rank, args.seed, curriculum_update_interval=24 if use_dist else None)
+    # the command curriculum keeps the reference's per-step cadence at every rank count (sharded: one 7 KB int32 all-reduce of the
+    # success counts per step); --curriculum-interval 24 exchanges them once per rollout instead — a different sampling cadence,
+    # recorded in config.curriculum_update_interval
+    env, cfg = build_env(args.envs, rank, args.seed, curriculum_update_interval=args.curriculum_interval)
     device = f"cuda:{local_rank}"
     runner = Runner(env, device=device)
     sim = env.env.sim
@@ -398,7 +445,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Go1 flat terrain, 4096 envs/GPU, train.py config (actuator_net, lag 6, DR, gait "
                                    "curriculum), HIP sim + ppo_cse, 24 steps/iter, 5 epochs x 4 minibatches",
-                       "envs_per_gpu": args.envs, "policy_dtype": "fp32" if args.fp32 else "bf16 autocast (fp32 master)",
+                       "envs_per_gpu": args.envs, "curriculum_update_interval": int(args.curriculum_interval), "policy_dtype": "fp32" if args.fp32 else "bf16 autocast (fp32 master)",
                        "physics_dtype": "f32", "step": "one PPO iteration = 24 x envs env-steps + update",
                        "parallelism": (f"dp{world} (envs sharded, {args.backend} gradient "
                                        f"{'reduce-scatter + sharded step + all-gather' if args.zero1 else 'all-reduce'}, {args.grad_dtype})")

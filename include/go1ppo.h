@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define GO1PPO_ABI_VERSION 1
+#define GO1PPO_ABI_VERSION 2
 #define GO1PPO_MAX_ACTIONS 32
 
 /* y[r, c] = elu(y[r, c] + sum_i lat[r, i] * wz[c, i] (c < lat_cols)) in place.  lat/wz may be NULL (plain ELU).
@@ -182,10 +182,31 @@ int go1ppo_opt_prestep(const float* g, int64_t n, float gscale, float* partial, 
  * zero_grad != 0: every visited g[i] is cleared after it has been read (the following backward pass accumulates into a
  * clean gradient without a fill pass of its own); zero_slot (or NULL): one more float cleared — the KL accumulator that
  * rides in the gradient's padding. */
+/* extras (may be NULL):
+ *  - frozen columns: the elements [frozen_start + r * frozen_ld + c], r < frozen_rows, frozen_c0 <= c < frozen_c1, are
+ *    structurally zero weights — the privileged-observation columns of the adaptation module's and the actor's first-layer
+ *    rows in the augmented GEMM layout (those inputs are the critic's only, actor_critic.py:44-47, 58-61): whatever gradient
+ *    the GEMM left there is discarded (and cleared with zero_grad), the weight stays exactly 0;
+ *  - transposes: dst[c * rows + r] (bf16) <- the refreshed weight at [start + r * cols + c]: K-contiguous copies of the
+ *    layers whose input gradient runs on go1ppo_gemm_nt, kept current by the optimiser step itself. */
+#define GO1PPO_ADAM_MAX_TRANSPOSES 2
+typedef struct {
+  int64_t frozen_start;
+  int32_t frozen_rows, frozen_ld, frozen_c0, frozen_c1;
+  int32_t num_transposes, _pad;
+  struct { int64_t start; int32_t rows, cols; void* dst; } transpose[GO1PPO_ADAM_MAX_TRANSPOSES];
+} Go1PpoAdamExtras;
 int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t start0, int64_t count0, int64_t start1,
                     int64_t count1, float gscale, const float* partial, float max_norm, const float* step, const float* lr,
                     float beta1, float beta2, float eps, void* body, int64_t n_body, float* tail, int64_t n_tail, int zero_grad,
-                    float* zero_slot, void* stream);
+                    float* zero_slot, const Go1PpoAdamExtras* extras, void* stream);
+
+/* out[r][c] (fp32, rows x cols contiguous) = sum over b < count of partials[b * stride + r * cols + c] (bf16) — the row-chunk
+ * partial products of the first-layer weight gradient (a manual split-K over hipBLASLt's batched GEMM) summed into the flat
+ * gradient; the columns [zero_c0, zero_c1) of the first zero_rows rows are written as exact zeros (see Go1PpoAdamExtras:
+ * frozen columns).  cols, stride multiples of 8; 16-byte aligned. */
+int go1ppo_sum_partials(const void* partials, int count, int64_t stride, int64_t rows, int cols, float* out, int zero_rows,
+                        int zero_c0, int zero_c1, void* stream);
 
 /* ---- MLP-layer GEMM with fused epilogue (replaces torch.addmm + F.elu / the ELU-backward map around it) ---- */
 
@@ -196,8 +217,14 @@ int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t start0, int6
 typedef struct Go1PpoGemmArgs {
   const void* A; const void* B; void* C; const float* bias; const void* H;
   int32_t M, N, K, lda, ldb, ldc, ldh, epilogue, elu_c0, elu_c1;
+  int32_t elu_skip_c0, elu_skip_c1;      /* epilogue 1: columns [elu_skip_c0, elu_skip_c1) stay pre-activations (0, 0: none) */
 } Go1PpoGemmArgs;
 int go1ppo_gemm_nt(const Go1PpoGemmArgs* args, void* stream);
+
+/* The same product (epilogues 0 and 1) on 256 x 256 output tiles, one 8-wavefront workgroup per CU: the first layer of the
+ * update, X (24576 x 2112) W1^T (1280 x 2112) -> Y1 with nn.ELU (actor_critic.py:44-47, 58-61, 79-82) applied to the
+ * adaptation module's and the critic's column blocks on the way out (elu ranges multiples of 4). */
+int go1ppo_gemm_nt256(const Go1PpoGemmArgs* args, void* stream);
 
 /* the same weight gradients on 128 x 128 tiles (LDS-DMA staging, hardware transpose reads): what the first-layer
  * gradients (n = 256 .. 1280, k = 2112) and the batched tails use.  Same problem table as go1ppo_wgrad_plan /

@@ -7,7 +7,12 @@ tests/fake_sim.py (deterministic given the seeds), so the fixture pins the learn
 the storage receives, bootstrapping, advantage normalisation, mini-batch order, the two optimiser steps — end to end: the
 product's Runner must arrive at the same weights (tests/test_dropin_config.py).  It also shows that a user may keep the
 reference's own Runner on top of this environment.  Needs /root/reference; run by make_golden.py in its own process (the two
-`go1_gym_learn` packages cannot live in one interpreter)."""
+`go1_gym_learn` packages cannot live in one interpreter).
+
+Regeneration policy: the trajectories come from THIS repository's physics contract (oracle/go1_oracle.c through tests/fake_sim.py), so
+both fixtures are regenerated whenever that contract changes — last in round 3's physics commit (8893c20: 24-contact matrix-free
+solve, trunk corners, thigh capsules, static / dynamic cone), which moved the weights after two iterations by ~1e-4 without any
+change to this script.  A change of the learner's glue alone must NOT require regenerating them."""
 import os
 import sys
 

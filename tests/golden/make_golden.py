@@ -1141,10 +1141,20 @@ def gen_ref_adaptation_module():
     m = torch.jit.load(os.path.join(run, "checkpoints", "adaptation_module_latest.jit"), map_location="cpu")
     sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
 
+    # /root/reference is untrusted DATA: the pickle may only build plain containers, numpy arrays and torch tensors (an allow-list;
+    # any other global is refused instead of imported), embedded tensor blobs are read with weights_only=True
+    ALLOWED = {("builtins", n) for n in ("dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "complex", "slice")} | {
+        ("collections", "OrderedDict"), ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "_reconstruct"),
+        ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+        ("torch._utils", "_rebuild_tensor_v2"), ("torch", "FloatStorage"), ("torch", "LongStorage"), ("torch", "DoubleStorage"),
+        ("torch", "IntStorage"), ("torch", "BoolStorage")}
+
     class U(pickle.Unpickler):
         def find_class(self, module, name):
             if module == "torch.storage" and name == "_load_from_bytes":
-                return lambda b: torch.load(io.BytesIO(b), map_location="cpu", weights_only=False)
+                return lambda b: torch.load(io.BytesIO(b), map_location="cpu", weights_only=True)
+            if (module, name) not in ALLOWED:
+                raise pickle.UnpicklingError(f"refusing to import {module}.{name} from the reference's parameters.pkl")
             return super().find_class(module, name)
     cfg = U(open(os.path.join(run, "parameters.pkl"), "rb")).load()["Cfg"]
     x = torch.randn(64, 2100, generator=torch.Generator().manual_seed(0))

@@ -218,6 +218,43 @@ def test_runner_learns_and_exports(tmp_path):
     PPO_Args.autocast_bf16 = False
 
 
+def test_unchanged_train_script_configuration_clears_one_million_env_steps_per_second(tmp_path, monkeypatch):
+    """north_star: "scripts/train.py drops in unchanged" AND ">= 1 M env-steps/s at 4096 envs".  train.py:207-216 builds
+    `Runner(env, device=...)` with the DEFAULT `PPO_Args` and calls `runner.learn(...)`; the only thing a user adds is the
+    environment variable GO1_POLICY_DTYPE=bf16 — no edit of the script, no attribute set on PPO_Args.
+    Driven exactly so: default arguments, 4096 envs, `learn()` itself (logging, checkpoint + TorchScript export at the end
+    included in the clock), 3 warm-up iterations (graph capture, GEMM selection) + 40 timed."""
+    import time
+    from go1_gym_learn.ppo_cse import Runner, RunnerArgs
+    from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    from ml_logger import logger
+    assert PPO_Args.autocast_bf16 is False                    # the reference's own default surface: nothing set by the caller
+    monkeypatch.setenv("GO1_POLICY_DTYPE", "bf16")
+    logger.configure("run_dropin", root=str(tmp_path))
+    logger.print_summary = False
+    old = (RunnerArgs.save_interval, RunnerArgs.log_freq, RunnerArgs.save_video_interval)
+    RunnerArgs.save_video_interval = 0                        # (no viewer on the box; train.py's headless run records nothing either)
+    os.chdir(tmp_path)
+    try:
+        env, cfg = build_env(4096)
+        runner = Runner(env, device="cuda:0")
+        assert runner.alg.bf16 and runner.alg.fused
+        runner.learn(num_learning_iterations=3, init_at_random_ep_len=True, eval_freq=100)
+        torch.cuda.synchronize()
+        iters = 40
+        t0 = time.perf_counter()
+        runner.learn(num_learning_iterations=iters, init_at_random_ep_len=False, eval_freq=100)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rate = iters * 24 * 4096 / dt
+        print(f"unchanged train.py configuration + GO1_POLICY_DTYPE=bf16: {rate / 1e6:.2f} M env-steps/s over {iters} iterations of Runner.learn "
+              f"({1e3 * dt / iters:.1f} ms per iteration incl. logging and the final checkpoint / TorchScript export)")
+        assert rate >= 1.0e6, rate
+        assert torch.isfinite(runner.alg.flat_param).all()
+    finally:
+        RunnerArgs.save_interval, RunnerArgs.log_freq, RunnerArgs.save_video_interval = old
+
+
 def test_teacher_student_runner_on_the_hip_env(tmp_path):
     """the older go1_gym_learn.ppo runner (privileged-latent teacher + adaptation-module student, plain PyTorch) drives the
     same HIP environment: two iterations, checkpoint / TorchScript export under the reference's file names."""

@@ -215,6 +215,108 @@ def test_gemm_nt_matches_fp32_matmul(lib, M, N, K, epilogue):
     assert torch.all(err <= tol), f"max err {err.max().item()} at scale {ref.abs().max().item()}"
 
 
+@pytest.mark.parametrize("M,N,K", [(24576, 1280, 2112), (4096, 1280, 2112), (24576, 256, 2112), (1000, 388, 192), (130, 12, 64), (513, 260, 128)])
+@pytest.mark.parametrize("epilogue", ["plain", "elu", "elu_skip"])
+def test_gemm_nt256_matches_fp32_matmul(lib, M, N, K, epilogue):
+    """go1ppo_gemm_nt256 (256 x 256 tiles, the update's first-layer forward: reference actor_critic.py:44-47, 58-61, 79-82 = three
+    nn.Linear + nn.ELU over the same history) vs the fp32 matmul of the same bf16 operands; tolerance of test_gemm_nt_matches_fp32_matmul.
+    elu_skip: the production epilogue — ELU everywhere except a column block (the actor's, activated after the latent is known)."""
+    from go1_gym_learn.ppo_cse import fused
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + 1)
+    big_a = bf(torch.randn(M, K + 64, device="cuda", generator=g))
+    a = big_a[:, :K]
+    b = bf(torch.randn(N, K, device="cuda", generator=g) / K ** 0.5)
+    out_full = torch.full((M, N + 16), 7.0, device="cuda", dtype=torch.bfloat16)
+    c = out_full[:, :N]
+    pre = a.float() @ b.float().t()
+    if epilogue == "plain":
+        bias = torch.randn(N, device="cuda", generator=g)
+        pre = pre + bias
+        fused.gemm_nt256(lib, a, b, c, bias)
+        ref = pre
+    elif epilogue == "elu":
+        fused.gemm_nt256(lib, a, b, c, None, elu=True)
+        ref = torch.nn.functional.elu(pre)
+    else:
+        s0, s1 = (N // 5 // 4) * 4, (3 * N // 5 // 4) * 4
+        fused.gemm_nt256(lib, a, b, c, None, elu=True, elu_skip=(s0, s1))
+        ref = torch.nn.functional.elu(pre)
+        ref[:, s0:s1] = pre[:, s0:s1]
+    torch.cuda.synchronize()
+    assert torch.all(out_full[:, N:] == 7.0), "wrote outside the N columns"
+    err = (c.float() - ref).abs()
+    tol = 2 ** -8 * (ref.abs() + pre.abs().clamp(min=1.0)) + 1e-6
+    assert torch.all(err <= tol), f"max err {err.max().item()} at scale {ref.abs().max().item()}"
+    if (M, N, K) == (24576, 1280, 2112):          # the kernel writes every element exactly once: a second launch is bit-identical
+        c2 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        fused.gemm_nt256(lib, a, b, c2, None if epilogue != "plain" else bias, elu=None if epilogue == "plain" else True,
+                         elu_skip=(s0, s1) if epilogue == "elu_skip" else None)
+        torch.cuda.synchronize()
+        assert torch.equal(c2, c.contiguous())
+
+
+@pytest.mark.parametrize("count,rows,cols,zero", [(4, 1280, 2112, (768, 2101, 2103)), (1, 256, 2112, (256, 2101, 2103)), (3, 40, 64, (7, 13, 30)),
+                                                  (2, 16, 24, (0, 0, 0))])
+def test_sum_partials_matches_torch(lib, count, rows, cols, zero):
+    """go1ppo_sum_partials: fp32 sum of the bf16 row-chunk partial products of the first-layer weight gradient, with exact zeros on
+    the masked column block of the leading rows (what `param.grad` of the structurally absent inputs is in the reference: nothing)."""
+    g = torch.Generator(device="cuda").manual_seed(count + rows)
+    part = bf(torch.randn(count, rows + 3, cols, device="cuda", generator=g))      # batch stride larger than rows x cols
+    out = torch.full((rows + 1, cols), 5.0, device="cuda")
+    zr, c0, c1 = zero
+    assert lib.go1ppo_sum_partials(part.data_ptr(), count, part.stride(0), rows, cols, out.data_ptr(), zr, c0, c1, stream()) == 0
+    torch.cuda.synchronize()
+    ref = part[:, :rows].float().sum(0)
+    ref[:zr, c0:c1] = 0.0
+    torch.testing.assert_close(out[:rows], ref, rtol=1e-6, atol=1e-6)
+    assert bool((out[:zr, c0:c1] == 0).all()) and bool((out[rows] == 5.0).all())
+    assert lib.go1ppo_sum_partials(part.data_ptr(), count, part.stride(0), rows, cols + 4, out.data_ptr(), 0, 0, 0, stream()) == -1
+
+
+def test_adam_frozen_columns_and_transposed_copies(lib):
+    """Go1PpoAdamExtras: (i) the gradient of the structurally zero weights (a column block of the leading rows of one 2-D block of the
+    flat parameter) is discarded — those weights stay exactly 0, their moments stay 0, zero_grad clears the slot — everything
+    else steps like torch.optim.Adam; (ii) the K-contiguous bf16 copies equal body.view(rows, cols).t() after every step."""
+    from go1_gym_learn.ppo_cse import fused
+    g = torch.Generator(device="cuda").manual_seed(21)
+    blk0, rows, ld, c0, c1 = 384, 24, 40, 33, 35            # a (32 x 40) block at offset 384; frozen: rows < 24, columns 33..34
+    t0 = (2048, 16, 48)                                     # transposed copies of two blocks
+    t1 = (4096, 64, 8)
+    n_body, n_std = 6000, 12
+    n = n_body + 16
+    master = torch.randn(n, device="cuda", generator=g) * 0.1
+    master[n_body + n_std:] = 0
+    W = master[blk0:blk0 + 32 * ld].view(32, ld)
+    W[:rows, c0:c1] = 0.0
+    ref = master.clone().requires_grad_()
+    master.grad = torch.zeros_like(master)
+    body = torch.zeros(n_body, device="cuda", dtype=torch.bfloat16)
+    std = torch.zeros(n_std, device="cuda")
+    opt = fused.FusedAdam(lib, master, body, std, n_body, 1e-3, ranges=[(0, n_body + n_std)])
+    opt.set_frozen_columns(blk0, rows, ld, c0, c1)
+    d0 = torch.full((t0[2], t0[1]), 9.0, device="cuda", dtype=torch.bfloat16)
+    d1 = torch.full((t1[2], t1[1]), 9.0, device="cuda", dtype=torch.bfloat16)
+    opt.set_transposes([(t0[0], t0[1], t0[2], d0), (t1[0], t1[1], t1[2], d1)])
+    ref_opt = torch.optim.Adam([ref], lr=1e-3)
+    for it in range(4):
+        grad = torch.randn(n, device="cuda", generator=g)
+        grad[n_body + n_std:] = 0
+        master.grad.copy_(grad)
+        opt.step_(zero_grad=True)
+        gr = grad.clone()
+        gr[blk0:blk0 + 32 * ld].view(32, ld)[:rows, c0:c1] = 0.0
+        ref.grad = gr
+        ref_opt.step()
+        torch.cuda.synchronize()
+        torch.testing.assert_close(master, ref.detach(), rtol=2e-5, atol=2e-7)
+        assert bool((W[:rows, c0:c1] == 0).all()) and bool((master.grad[:n_body + n_std] == 0).all())
+        assert bool((opt.m[blk0:blk0 + 32 * ld].view(32, ld)[:rows, c0:c1] == 0).all())
+        assert float(W[rows:, c0:c1].abs().min()) > 0           # the rows behind the frozen ones (the critic's) do move
+        for (st, r, c), d in ((t0, d0), (t1, d1)):
+            assert torch.equal(d, body[st:st + r * c].view(r, c).t().contiguous())
+    torch.testing.assert_close(body.float(), bf(master[:n_body]).float(), rtol=0, atol=0)
+
+
 @pytest.mark.parametrize("M", [4096, 1000, 24576])
 def test_fused_tail_forward_matches_layerwise_torch(lib, M):
     """go1ppo_tail_fwd (three layers, activations on chip) vs addmm + ELU per layer in fp32 on the same bf16 data."""
@@ -715,13 +817,13 @@ def test_adam_slice_reaching_past_the_live_parameters_leaves_the_tail_copy_alone
     slot = torch.ones(1, device="cuda")
     p0 = p.clone()
     assert lib.go1ppo_opt_adam(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 500, tot - 500, 0, 0, 1.0, None, 0.0, step.data_ptr(),
-                               lr.data_ptr(), 0.9, 0.999, 1e-8, body.data_ptr(), n_body, arena.data_ptr(), n_tail, 0, slot.data_ptr(), stream()) == 0
+                               lr.data_ptr(), 0.9, 0.999, 1e-8, body.data_ptr(), n_body, arena.data_ptr(), n_tail, 0, slot.data_ptr(), None, stream()) == 0
     torch.cuda.synchronize()
     assert torch.equal(arena[:n_tail], p[n_body:n_body + n_tail]) and bool((arena[n_tail:] == 777.0).all())
     assert torch.equal(p[:500], p0[:500]) and not torch.equal(p[500:], p0[500:]) and float(slot) == 0.0
     slot.fill_(1.0)
     assert lib.go1ppo_opt_adam(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 0, 0, 0, 0, 1.0, None, 0.0, step.data_ptr(),
-                               lr.data_ptr(), 0.9, 0.999, 1e-8, body.data_ptr(), n_body, arena.data_ptr(), n_tail, 0, slot.data_ptr(), stream()) == 0
+                               lr.data_ptr(), 0.9, 0.999, 1e-8, body.data_ptr(), n_body, arena.data_ptr(), n_tail, 0, slot.data_ptr(), None, stream()) == 0
     torch.cuda.synchronize()
     assert float(slot) == 0.0
 

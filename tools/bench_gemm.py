@@ -40,6 +40,20 @@ def main():
     s = torch.cuda.current_stream().cuda_stream
     bf = dict(device="cuda", dtype=torch.bfloat16)
     R = 4                                            # rotating buffer sets
+    # ---- the 256-tile GEMM (go1ppo_gemm_nt256) on the first-layer shapes: update (24576 rows) and rollout inference (4096 rows)
+    import ctypes
+    print(f"{'256-tile GEMM, first layer':34s} {'ours us':>9s} {'TF/s':>7s} | {'torch us':>9s} {'TF/s':>7s} {'+elu us':>8s}")
+    for rows in (M, 4096):
+        A = [torch.randn(rows, 2112, **bf) for _ in range(R)]
+        B = torch.randn(1280, 2112, **bf) / 2112 ** 0.5
+        C = [torch.zeros(rows, 1280, **bf) for _ in range(R)]
+        ga = [fused.gemm_args(A[i], B, C[i], None, elu=True, elu_skip=(256, 768)) for i in range(R)]
+        ours = timeit([(lambda g=g: lib.go1ppo_gemm_nt256(ctypes.byref(g), s)) for g in ga])
+        tt = timeit([(lambda i=i: torch.mm(A[i], B.t(), out=C[i])) for i in range(R)])
+        te = timeit([(lambda i=i: lib.go1ppo_elu_fwd(C[i][:, 256:].data_ptr(), rows, 1024, 1280, None, 0, 0, None, 0, 0, s)) for i in range(R)])
+        te2 = timeit([(lambda i=i: lib.go1ppo_elu_fwd(C[i][:, 256:768].data_ptr(), rows, 512, 1280, None, 0, 0, None, 0, 0, s)) for i in range(R)])
+        gf = 2 * rows * 1280 * 2112 / 1e9
+        print(f"  {rows:6d} x 2112 -> 1280            {ours:9.1f} {gf / ours:7.0f} | {tt:9.1f} {gf / tt:7.0f} {te:8.1f}   (actor-block ELU alone: {te2:.1f} us)")
     print(f"rows = {M}\n{'shape':34s} {'ours us':>9s} {'TF/s':>7s} | {'torch us':>9s} {'TF/s':>7s} {'+elu us':>8s}")
     for name, N, K, lda, elu in (("first layer 2112 -> 1280", 1280, 2112, 2112, (0, 256)), ("adaptation 2112 -> 256", 256, 2112, 2112, True),
                                  ("tail 512 -> 256", 256, 512, 1280, True), ("tail 256 -> 128", 128, 256, 256, True),

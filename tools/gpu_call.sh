@@ -1,0 +1,21 @@
+#!/bin/bash
+# one gpurun call = several measurements; everything lands in gpurun_out/$TAG/ (scratch: copy what is to be judged into profiles/)
+TAG=${1:-call}; shift
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+run() { name=$1; shift; echo "=== $name: $*" | tee -a $OUT/index.txt; ( time timeout ${TMO:-600} "$@" ) > $OUT/$name.log 2>&1; echo "    rc=$? $(tail -n 3 $OUT/$name.log | tr '\n' ' ' | cut -c1-300)" | tee -a $OUT/index.txt; }
+for step in "$@"; do
+case $step in
+  parity) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt run parity python -m pytest tests/test_gpu_parity.py tests/test_gpu_env.py -q -x -s -k "product_instances or train_eval_split or deferred_torque" ;;
+  fusedtests) run fusedtests python -m pytest tests/test_gpu_ppo_fused.py -q -x ;;
+  gemm) run gemm python tools/bench_gemm.py ;;
+  bench) run bench python bench.py --steps 20 --warmup 5 --headline-only --no-cpu-baseline --breakdown ;;
+  bench_nogemm256) GO1_GEMM256=0 run bench_nogemm256 python bench.py --steps 20 --warmup 5 --headline-only --no-cpu-baseline --breakdown ;;
+  benchfull) TMO=900 run benchfull python bench.py ;;
+  prof) (cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -- python $OLDPWD/bench.py --steps 3 --warmup 2 --headline-only --no-cpu-baseline) > $OUT/prof.log 2>&1; find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \; ; find $OUT/prof -type f ! -name "*stats*" -delete; echo "=== prof rc=$?" | tee -a $OUT/index.txt ;;
+  gputests) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt TMO=1500 run gputests python -m pytest tests/ -x -q -m gpu ;;
+  dropin) run dropin python -m pytest tests/test_gpu_env.py -q -x -s -k "unchanged_train_script" ;;
+  *) echo "unknown step $step" ;;
+esac
+done
+cat $OUT/index.txt

@@ -15,9 +15,11 @@
 // bf16 activations, fp32 math, fp32 parameter gradients.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/go1ppo.h"
 
 typedef uint16_t bf16_t;
+static_assert(sizeof(Go1PpoAdamExtras) == 80 && sizeof(Go1PpoGemmArgs) == 88 && sizeof(Go1PpoWgradProblem) == 72, "ctypes mirrors (fused.py) assume these sizes");
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
@@ -546,7 +548,12 @@ __global__ __launch_bounds__(256) void prestep_kernel(const float* g, int64_t n,
   __shared__ float red[4];
   float s = 0.f;
   if (partial) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)OPT_BLOCKS * 256) {
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? n >> 2 : 0;      // 16-byte loads over the aligned bulk
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)OPT_BLOCKS * 256) {
+      const f32x4 x = reinterpret_cast<const f32x4*>(g)[i] * gscale;
+      s = fmaf(x[0], x[0], s); s = fmaf(x[1], x[1], s); s = fmaf(x[2], x[2], s); s = fmaf(x[3], x[3], s);
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)OPT_BLOCKS * 256) {
       float x = g[i] * gscale;
       s = fmaf(x, x, s);
     }
@@ -568,7 +575,8 @@ __global__ __launch_bounds__(256) void prestep_kernel(const float* g, int64_t n,
 __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m, float* v, int64_t start0, int64_t count0,
                                                    int64_t start1, int64_t count1, float gscale, const float* partial, float max_norm,
                                                    const float* step, const float* lr, float beta1, float beta2, float eps,
-                                                   bf16_t* body, int64_t n_body, float* tail, int64_t n_tail, int zero_grad, float* zero_slot) {
+                                                   bf16_t* body, int64_t n_body, float* tail, int64_t n_tail, int zero_grad, float* zero_slot,
+                                                   Go1PpoAdamExtras ex) {
   __shared__ float clip_s;
   if (threadIdx.x < 64) {
     float c = 1.f;
@@ -588,16 +596,40 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m,
   const int64_t total = count0 + count1;
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total; j += (int64_t)gridDim.x * 256) {
     const int64_t i = j < count0 ? start0 + j : start1 + (j - count0);
-    const float gi = g[i] * gs;
+    float gi = g[i] * gs;
     if (zero_grad) g[i] = 0.f;          // the next backward pass accumulates into a clean gradient: no separate fill pass
+    // structurally-zero weights (the privileged-observation columns of the adaptation module's and the actor's first-layer rows:
+    // the augmented GEMM rows carry those inputs for the critic only): their gradient is discarded here instead of by a fill pass
+    if (ex.frozen_rows > 0) {
+      const uint64_t off = (uint64_t)(i - ex.frozen_start);
+      if (off < (uint64_t)ex.frozen_rows * (uint64_t)ex.frozen_ld) {
+        const uint32_t col = (uint32_t)off % (uint32_t)ex.frozen_ld;
+        if (col >= (uint32_t)ex.frozen_c0 && col < (uint32_t)ex.frozen_c1) gi = 0.f;
+      }
+    }
     const float mi = beta1 * m[i] + (1.f - beta1) * gi;
     const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
     m[i] = mi;
     v[i] = vi;
     const float pi = p[i] - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
     p[i] = pi;
-    if (i < n_body) body[i] = f2bf(pi);
-    else if (tail && i - n_body < n_tail) tail[i - n_body] = pi;      // (slots behind the tail — KL, padding — have no compute copy)
+    if (i < n_body) {
+      const bf16_t pb = f2bf(pi);
+      body[i] = pb;
+      // K-contiguous (transposed) bf16 copies of the weights whose input gradient runs on go1ppo_gemm_nt: kept current here
+      // instead of by a transpose-copy launch per backward pass
+#pragma unroll
+      for (int t = 0; t < GO1PPO_ADAM_MAX_TRANSPOSES; t++) {
+        if (t < ex.num_transposes) {
+          const uint64_t off = (uint64_t)(i - ex.transpose[t].start);
+          const uint32_t rows = (uint32_t)ex.transpose[t].rows, cols = (uint32_t)ex.transpose[t].cols;
+          if (off < (uint64_t)rows * cols) {
+            const uint32_t r = (uint32_t)off / cols, c = (uint32_t)off % cols;
+            reinterpret_cast<bf16_t*>(ex.transpose[t].dst)[(size_t)c * rows + r] = pb;
+          }
+        }
+      }
+    } else if (tail && i - n_body < n_tail) tail[i - n_body] = pi;      // (slots behind the tail — KL, padding — have no compute copy)
   }
   if (zero_slot && blockIdx.x == 0 && threadIdx.x == 0) *zero_slot = 0.f;
 }
@@ -989,8 +1021,18 @@ extern "C" int go1ppo_opt_prestep(const float* g, int64_t n, float gscale, float
 extern "C" int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t start0, int64_t count0, int64_t start1,
                                int64_t count1, float gscale, const float* partial, float max_norm, const float* step, const float* lr,
                                float beta1, float beta2, float eps, void* body, int64_t n_body, float* tail, int64_t n_tail, int zero_grad,
-                               float* zero_slot, void* stream) {
+                               float* zero_slot, const Go1PpoAdamExtras* extras, void* stream) {
   if (!p || !g || !m || !v || !step || !lr || !body || count0 < 0 || count1 < 0 || n_tail < 0) return -1;
+  Go1PpoAdamExtras ex;
+  memset(&ex, 0, sizeof(ex));
+  if (extras) {
+    ex = *extras;
+    if (ex.num_transposes < 0 || ex.num_transposes > GO1PPO_ADAM_MAX_TRANSPOSES || ex.frozen_rows < 0 ||
+        (ex.frozen_rows > 0 && (ex.frozen_ld <= 0 || ex.frozen_c0 < 0 || ex.frozen_c1 > ex.frozen_ld || ex.frozen_c0 > ex.frozen_c1)))
+      return -2;
+    for (int t = 0; t < ex.num_transposes; t++)
+      if (!ex.transpose[t].dst || ex.transpose[t].rows <= 0 || ex.transpose[t].cols <= 0) return -2;
+  }
   if (count0 + count1 == 0) {           // an empty slice (a rank of a sharded step that owns padding only): just the slot
     if (zero_slot && hipMemsetAsync(zero_slot, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return -9;
     return 0;
@@ -999,7 +1041,47 @@ extern "C" int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t s
   int64_t blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   adam_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, start0, count0, start1, count1, gscale, partial,
-                                                                             max_norm, step, lr, beta1, beta2, eps, (bf16_t*)body, n_body, tail, n_tail, zero_grad, zero_slot);
+                                                                             max_norm, step, lr, beta1, beta2, eps, (bf16_t*)body, n_body, tail, n_tail, zero_grad, zero_slot, ex);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+// ---------------------------------------------------------------------------------------------- split-K partial sums
+// out[r][c] (fp32) = sum_b part[b][r][c] (bf16): the first-layer weight gradient leaves hipBLASLt as `count` row-chunk partial
+// products (a manual split-K, fused.py `_big_wgrad`); this pass sums them into the flat fp32 gradient — replacing the library
+// reduction — and writes exact zeros on the columns [zero_c0, zero_c1) of the first zero_rows rows (the privileged-observation
+// columns of the adaptation module's and the actor's rows, see adam_kernel) instead of a separate fill launch.
+__global__ __launch_bounds__(256) void sum_partials_kernel(const bf16_t* __restrict__ part, int count, int64_t stride, int64_t total8, int cols,
+                                                           float* __restrict__ out, int zero_rows, int zero_c0, int zero_c1) {
+  for (int64_t i8 = (int64_t)blockIdx.x * 256 + threadIdx.x; i8 < total8; i8 += (int64_t)gridDim.x * 256) {
+    const int64_t i = i8 << 3;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < count; b++) {
+      const Bf8 v = *reinterpret_cast<const Bf8*>(part + (int64_t)b * stride + i);
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[e] += bf2f(v.v[e]);
+    }
+    const int64_t row = i / cols;
+    const int c = (int)(i - row * cols);
+    if (row < zero_rows && c < zero_c1 && c + 8 > zero_c0) {
+#pragma unroll
+      for (int e = 0; e < 8; e++)
+        if (c + e >= zero_c0 && c + e < zero_c1) acc[e] = 0.f;
+    }
+    reinterpret_cast<f32x4*>(out + i)[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    reinterpret_cast<f32x4*>(out + i)[1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+  }
+}
+
+extern "C" int go1ppo_sum_partials(const void* partials, int count, int64_t stride, int64_t rows, int cols, float* out, int zero_rows,
+                                   int zero_c0, int zero_c1, void* stream) {
+  if (!partials || !out || count <= 0 || rows <= 0 || cols <= 0 || (cols & 7) || (stride & 7) || stride < rows * cols || !aligned16(partials) ||
+      !aligned16(out) || zero_rows < 0 || zero_c0 < 0 || zero_c1 < zero_c0 || zero_c1 > cols)
+    return -1;
+  const int64_t total8 = rows * cols / 8;
+  int64_t blocks = (total8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  sum_partials_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)partials, count, stride, total8, cols, out,
+                                                                                   zero_rows, zero_c0, zero_c1);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
@@ -1049,4 +1131,4 @@ extern "C" int go1ppo_wgrad_batched(const Go1PpoWgradProblem* device_probs, int 
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
-extern "C" const char* go1ppo_version(void) { return "go1ppo 0.1 (gfx950, abi 1)"; }
+extern "C" const char* go1ppo_version(void) { return "go1ppo 0.2 (gfx950, abi 2)"; }

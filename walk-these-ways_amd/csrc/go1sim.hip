@@ -438,6 +438,10 @@ extern "C" int go1sim_set_config(Go1Sim* s, const Go1SimConfig* cfg) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (cfg->num_envs != s->cfg.num_envs) return -6;
+  // curriculum_success was allocated by the caller as [K][categories][bins] for the creation-time K: a larger K would index past it
+  if (cfg->curriculum_update_interval != s->cfg.curriculum_update_interval || cfg->num_categories != s->cfg.num_categories ||
+      cfg->num_bins != s->cfg.num_bins)
+    return -6;
   s->cfg = *cfg;
   return upload_const(s);      // blocking copy: configuration changes are rare and never on the step path
 }
@@ -450,6 +454,7 @@ extern "C" int go1sim_set_eval_config(Go1Sim* s, const Go1SimConfig* cfg, int32_
       cfg->num_obs_history != t.num_obs_history || cfg->num_rewards != t.num_rewards || cfg->decimation != t.decimation ||
       cfg->lag_timesteps != t.lag_timesteps || cfg->control_type != t.control_type || cfg->num_commands != t.num_commands ||
       cfg->num_bins != t.num_bins || cfg->num_categories != t.num_categories || cfg->terrain_type != t.terrain_type ||
+      cfg->curriculum_update_interval != t.curriculum_update_interval ||
       cfg->seed != t.seed || cfg->env_id_offset != t.env_id_offset)
     return -6;
   if (num_train_envs <= 0 || num_train_envs > t.num_envs || (num_train_envs < t.num_envs && (num_train_envs % EPW) != 0)) return -3;

@@ -207,7 +207,7 @@ class LeggedRobot(BaseTask):
         # Environments sharded over ranks (one process per GPU): the command curriculum stays ONE global curriculum — every
         # rank adds up the per-bin success counts of all shards before the weight update, so weights, CDFs and therefore
         # the sampled commands are those of a single-GPU run over the concatenated shards (RNG streams are
-        # keyed by global env id).  7 KB int32 all-reduce per env step; `Cfg.commands.global_curriculum = False` keeps
+        # keyed by global env id).  one int32 all-reduce of the K x 4 x 441 success counts every K = commands.curriculum_update_interval env steps (7 KB per step at the default K = 1); `Cfg.commands.global_curriculum = False` keeps
         # per-rank curricula instead.
         import torch.distributed as dist
         self._curriculum_sync = bool(dist.is_available() and dist.is_initialized()
@@ -222,8 +222,7 @@ class LeggedRobot(BaseTask):
             defer_curriculum_update=self._curriculum_sync)
         self.buffers = B = H.SimBuffers(self.sim_config, self.sim_meta, self.device)
         if mesh_type in ('heightfield', 'trimesh'):
-            # both mesh types are simulated on the height field's bilinear surface (utils/terrain.py docstring)
-            # 'heightfield': the bilinear surface.  'trimesh': the reference corrects faces steeper than slope_treshold into vertical
+            # 'heightfield': the height field's bilinear surface.  'trimesh': the reference corrects faces steeper than slope_treshold into vertical
             # walls (terrain.py:33-36, convert_heightfield_to_trimesh) — simulated as vertical contact faces on the same height
             # field (include/go1sim.h hf_wall_units)
             H.bind_height_field(self.sim_config, B, self.terrain.heightsamples, cfg.terrain.horizontal_scale,

@@ -77,10 +77,20 @@ MLP2_DIMS = (256, 128, 64)
 class GemmArgs(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
                 ("H", ctypes.c_void_p)] + [(n, ctypes.c_int32) for n in
-                                           ("M", "N", "K", "lda", "ldb", "ldc", "ldh", "epilogue", "elu_c0", "elu_c1")]
+                                           ("M", "N", "K", "lda", "ldb", "ldc", "ldh", "epilogue", "elu_c0", "elu_c1", "elu_skip_c0", "elu_skip_c1")]
 
 
-EXPORTED_SYMBOLS = ["go1ppo_mlp2_fwd", "go1ppo_mlp2_bwd", "go1ppo_gemm_nt", "go1ppo_wgrad_tn_plan", "go1ppo_wgrad_tn_batched", "go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
+class _AdamTranspose(ctypes.Structure):
+    _fields_ = [("start", ctypes.c_int64), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("dst", ctypes.c_void_p)]
+
+
+class AdamExtras(ctypes.Structure):
+    _fields_ = [("frozen_start", ctypes.c_int64), ("frozen_rows", ctypes.c_int32), ("frozen_ld", ctypes.c_int32),
+                ("frozen_c0", ctypes.c_int32), ("frozen_c1", ctypes.c_int32), ("num_transposes", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("transpose", _AdamTranspose * 2)]
+
+
+EXPORTED_SYMBOLS = ["go1ppo_mlp2_fwd", "go1ppo_mlp2_bwd", "go1ppo_gemm_nt", "go1ppo_gemm_nt256", "go1ppo_sum_partials", "go1ppo_wgrad_tn_plan", "go1ppo_wgrad_tn_batched", "go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
                     "go1ppo_wgrad_batched", "go1ppo_act",
                     "go1ppo_store_step", "go1ppo_ring_snapshot", "go1ppo_ring_step", "go1ppo_ring_gather", "go1ppo_gae", "go1ppo_normalize", "go1ppo_opt_partials", "go1ppo_opt_prestep",
                     "go1ppo_opt_adam", "go1ppo_version"]
@@ -105,6 +115,8 @@ def load_library(path=None):
     L.go1ppo_wgrad_plan.argtypes = [ctypes.POINTER(WgradProblem), i32]
     L.go1ppo_tail_fwd.argtypes = [ctypes.POINTER(TailArgs), vp]
     L.go1ppo_gemm_nt.argtypes = [ctypes.POINTER(GemmArgs), vp]
+    L.go1ppo_gemm_nt256.argtypes = [ctypes.POINTER(GemmArgs), vp]
+    L.go1ppo_sum_partials.argtypes = [vp, i32, i64, i64, i32, vp, i32, i32, i32, vp]
     L.go1ppo_mlp2_fwd.argtypes = [ctypes.POINTER(Mlp2Fwd), i32, vp]
     L.go1ppo_mlp2_bwd.argtypes = [ctypes.POINTER(Mlp2Bwd), i32, vp]
     L.go1ppo_wgrad_batched.argtypes = [vp, i32, i32, vp]
@@ -120,7 +132,8 @@ def load_library(path=None):
     L.go1ppo_normalize.argtypes = [vp, i64, vp, vp]
     L.go1ppo_opt_partials.argtypes = []
     L.go1ppo_opt_prestep.argtypes = [vp, i64, f32, vp, vp, vp, vp, f32, f32, f32, f32, vp]
-    L.go1ppo_opt_adam.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, f32, vp, f32, vp, vp, f32, f32, f32, vp, i64, vp, i64, i32, vp, vp]
+    L.go1ppo_opt_adam.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, f32, vp, f32, vp, vp, f32, f32, f32, vp, i64, vp, i64, i32, vp,
+                                  ctypes.POINTER(AdamExtras), vp]
     for name in EXPORTED_SYMBOLS[:-1]:
         getattr(L, name).restype = ctypes.c_int
     L.go1ppo_version.restype = ctypes.c_char_p
@@ -147,9 +160,9 @@ def _ld(t):
     return t.stride(0)
 
 
-def gemm_args(a, b, c, bias=None, elu=None, elu_bwd_of=None):
-    """Go1PpoGemmArgs for c = epilogue(a @ b.T + bias): `elu` = (c0, c1) column range to activate (True: all columns),
-    `elu_bwd_of` = post-ELU activations H, the result is multiplied by elu'(H)."""
+def gemm_args(a, b, c, bias=None, elu=None, elu_bwd_of=None, elu_skip=None):
+    """Go1PpoGemmArgs for c = epilogue(a @ b.T + bias): `elu` = (c0, c1) column range to activate (True: all columns) except the
+    columns `elu_skip` = (s0, s1); `elu_bwd_of` = post-ELU activations H, the result is multiplied by elu'(H)."""
     g = GemmArgs()
     g.A, g.B, g.C, g.bias, g.H = a.data_ptr(), b.data_ptr(), c.data_ptr(), _ptr(bias), _ptr(elu_bwd_of)
     g.M, g.N, g.K, g.lda, g.ldb, g.ldc = a.shape[0], b.shape[0], a.shape[1], _ld(a), _ld(b), _ld(c)
@@ -161,12 +174,21 @@ def gemm_args(a, b, c, bias=None, elu=None, elu_bwd_of=None):
     elif elu is not None:
         g.epilogue = 1
         g.elu_c0, g.elu_c1 = (0, g.N) if elu is True else elu
+        if elu_skip is not None:
+            g.elu_skip_c0, g.elu_skip_c1 = elu_skip
     return g
 
 
 def gemm_nt(lib, a, b, c, bias=None, elu=None, elu_bwd_of=None):
     g = gemm_args(a, b, c, bias, elu, elu_bwd_of)
     _chk(lib.go1ppo_gemm_nt(ctypes.byref(g), _stream()), "go1ppo_gemm_nt")
+    return c
+
+
+def gemm_nt256(lib, a, b, c, bias=None, elu=None, elu_skip=None):
+    """c = epilogue(a @ b.T + bias) on 256 x 256 tiles (go1ppo_gemm_nt256)"""
+    g = gemm_args(a, b, c, bias, elu, elu_skip=elu_skip)
+    _chk(lib.go1ppo_gemm_nt256(ctypes.byref(g), _stream()), "go1ppo_gemm_nt256")
     return c
 
 
@@ -245,6 +267,15 @@ class FusedNet:
             self._dgrad_nt = os.environ.get("GO1_DGRAD_NT", "1") == "1" and self._mlp2
             self._WT = {n: torch.zeros(self.P[f"{n}.1.W"].shape[1], self.P[f"{n}.1.W"].shape[0], **bf) for n in ("actor", "critic")} \
                 if self._dgrad_nt else None
+            # the K-contiguous copies are refreshed per backward pass (two transpose-copy launches) until an optimiser takes them
+            # over (`adam_transposes()` -> FusedAdam.set_transposes: the step that changes the weights rewrites the copies)
+            self._wt_by_optimizer = False
+            # first-layer forward on this repository's 256-tile GEMM with the ELU of the adaptation module's and the critic's blocks
+            # in its epilogue (the separate activation pass then only covers the actor's block, which waits for the latent);
+            # GO1_GEMM256=0: hipBLASLt + the full activation pass
+            self._gemm256 = os.environ.get("GO1_GEMM256", "1") == "1" and self._mlp2 and policy.Kp % 64 == 0
+            # privileged-observation columns of the adaptation module's and the actor's first-layer rows: structurally zero weights
+            self.priv_mask = (self.nd + self.na, policy.K + 1, policy.K + 1 + policy.npv)
 
     # ---- kernels -----------------------------------------------------------------------------------------
     def _elu(self, y, lat=None, lat_cols=0):
@@ -337,16 +368,17 @@ class FusedNet:
         return mean, value, latent
 
     # ---- LDS-resident 256 -> 128 -> 64 ends ------------------------------------------------------------------------
-    def _mlp2_fwd(self, key, items):
-        """items: [(net, x)] with x the 256-wide PRE-activation in front of the net's last two layers (activated in place)."""
-        key = ("fwd", key)
+    def _mlp2_fwd(self, key, items, elu_input=1):
+        """items: [(net, x)] with x the 256-wide PRE-activation in front of the net's last two layers (activated in place);
+        elu_input=0: x is already activated."""
+        key = ("fwd", key, elu_input)
         if key not in self._mlp2_cache:
             arr = (Mlp2Fwd * len(items))()
             for a, (net, x) in zip(arr, items):
                 d = self.depth[net]
                 W2, W3, z2, out = self.P[f"{net}.{d - 2}.W"], self.P[f"{net}.{d - 1}.W"], self.Z[net][d - 2], self.Z[net][d - 1]
                 a.x, a.W2, a.b2, a.W3, a.b3 = x.data_ptr(), W2.data_ptr(), self.P[f"{net}.{d - 2}.b"].data_ptr(), W3.data_ptr(), self.P[f"{net}.{d - 1}.b"].data_ptr()
-                a.z2, a.out, a.rows, a.ld_x, a.ld_z2, a.ld_out, a.elu_input = z2.data_ptr(), out.data_ptr(), x.shape[0], _ld(x), _ld(z2), _ld(out), 1
+                a.z2, a.out, a.rows, a.ld_x, a.ld_z2, a.ld_out, a.elu_input = z2.data_ptr(), out.data_ptr(), x.shape[0], _ld(x), _ld(z2), _ld(out), int(elu_input)
             self._mlp2_cache[key] = (arr, len(items))
         arr, n = self._mlp2_cache[key]
         _chk(self.lib.go1ppo_mlp2_fwd(arr, n, _stream()), "go1ppo_mlp2_fwd")
@@ -369,10 +401,17 @@ class FusedNet:
 
     def _forward_mlp2(self, x):
         P, Z, nd, na = self.P, self.Z, self.nd, self.na
-        torch.mm(x, P["W1"].t(), out=self.Y1)
-        self._mlp2_fwd("adaptation", [("adaptation", self.Y1[:, :nd])])
-        latent = Z["adaptation"][2]
-        self._elu(self.Y1[:, nd:], latent, na)
+        if self._gemm256:
+            # ELU of the adaptation / critic blocks in the GEMM's epilogue; the actor's block stays a pre-activation until the latent exists
+            gemm_nt256(self.lib, x, P["W1"], self.Y1, elu=True, elu_skip=(nd, nd + na))
+            self._mlp2_fwd("adaptation", [("adaptation", self.Y1[:, :nd])], elu_input=0)
+            latent = Z["adaptation"][2]
+            self._elu(self.Y1[:, nd:nd + na], latent, na)
+        else:
+            torch.mm(x, P["W1"].t(), out=self.Y1)
+            self._mlp2_fwd("adaptation", [("adaptation", self.Y1[:, :nd])])
+            latent = Z["adaptation"][2]
+            self._elu(self.Y1[:, nd:], latent, na)
         with self._branch():
             torch.addmm(P["critic.1.b"], self.Y1[:, nd + na:], P["critic.1.W"].t(), out=Z["critic"][1])
         torch.addmm(P["actor.1.b"], self.Y1[:, nd:nd + na], P["actor.1.W"].t(), out=Z["actor"][1])
@@ -394,9 +433,11 @@ class FusedNet:
             # epilogue (go1ppo_gemm_nt, epilogue 2): dY1 = (dz1 W) * elu'(h1) in one pass per net instead of a hipBLASLt GEMM
             # + an element-wise pass over (M x 512).  The kernel wants the weight K-contiguous: W^T, refreshed here (256 KB).
             with self._branch():
-                self._WT["critic"].copy_(P["critic.1.W"].t())
+                if not self._wt_by_optimizer:
+                    self._WT["critic"].copy_(P["critic.1.W"].t())
                 gemm_nt(self.lib, dZ["critic"][1], self._WT["critic"], dY1[:, cols["critic"]], elu_bwd_of=Y1[:, cols["critic"]])
-            self._WT["actor"].copy_(P["actor.1.W"].t())
+            if not self._wt_by_optimizer:
+                self._WT["actor"].copy_(P["actor.1.W"].t())
             gemm_nt(self.lib, dZ["actor"][1], self._WT["actor"], dY1[:, cols["actor"]], elu_bwd_of=Y1[:, cols["actor"]])
         else:
             with self._branch():
@@ -426,6 +467,25 @@ class FusedNet:
         self._wgrad(dZ["adaptation"][2], Z["adaptation"][1], G["adaptation.2.W"], None)     # head bias: the MSE kernel's
         self._wgrad(dZ["adaptation"][1], self.Y1d, G["adaptation.1.W"], G["adaptation.1.b"])
         self._big_wgrad(d, x, G["W1"][:nd], self._w1_tmp[:, :nd], self._w1_tn[1])
+
+    # ---- K-contiguous weight copies kept by the optimiser ------------------------------------------------------------
+    def adam_transposes(self):
+        """[(start element in the flat parameter, rows, cols, destination tensor)] of the transposed copies the backward pass reads;
+        after FusedAdam.set_transposes(...) took them over the per-pass transpose-copy launches are dropped."""
+        if not getattr(self, "_dgrad_nt", False):
+            return []
+        out = []
+        for n in ("actor", "critic"):
+            i = self.pol.index[f"{n}.1.W"]
+            rows, cols = self.pol.blocks[i][1]
+            out.append((self.pol.offsets[i], rows, cols, self._WT[n]))
+        return out
+
+    def refresh_transposes(self):
+        """after the compute copy was rewritten from outside the optimiser (initial push, resume, sharded step's all-gather)"""
+        if getattr(self, "_dgrad_nt", False):
+            for n in ("actor", "critic"):
+                self._WT[n].copy_(self.P[f"{n}.1.W"].t())
 
     # ---- two-stream helpers ------------------------------------------------------------------------------------
     def _branch(self):
@@ -474,12 +534,19 @@ class FusedNet:
             self._wgrad(dY, x, gW)
             return
         b = tmp.shape[0]
+        # the partial products are summed into the fp32 gradient by go1ppo_sum_partials, which also writes the structural zeros
+        # of the privileged-observation columns (rows of the adaptation module and the actor: gW starts at row 0 of W1)
+        zr, zc0, zc1 = self.priv_mask
+        zr = min(zr, gW.shape[0])
         if b == 1 or not tmp.is_contiguous():
             torch.mm(dY.t(), x, out=tmp[0])
-            gW.copy_(tmp[0])
+            part, count, stride = tmp[0], 1, gW.numel()
         else:
             torch.bmm(dY.view(b, dY.shape[0] // b, dY.shape[1]).transpose(1, 2), x.view(b, x.shape[0] // b, x.shape[1]), out=tmp)
-            torch.sum(tmp, dim=0, dtype=torch.float32, out=gW)
+            part, count, stride = tmp, b, tmp.stride(0)
+        assert gW.is_contiguous() and part.stride(-1) == 1 and part.stride(-2) == gW.shape[1]
+        _chk(self.lib.go1ppo_sum_partials(part.data_ptr(), count, stride, gW.shape[0], gW.shape[1], gW.data_ptr(), zr, zc0, zc1, _stream()),
+             "go1ppo_sum_partials")
 
     def _run_planned(self, key, fn):
         """first call: run `fn` recording its weight-gradient problems (nothing launched for them), build the device
@@ -677,6 +744,23 @@ class FusedAdam:
         r = list(ranges or [(0, master.numel())]) + [(0, 0)]
         self.r0, self.r1 = r[0], r[1]
         self.n_norm = max(a + b for a, b in r)          # elements the global norm runs over (padding slots excluded)
+        self.extras = AdamExtras()
+        self._keep = []
+
+    def set_frozen_columns(self, start, rows, ld, c0, c1):
+        """elements [start + r * ld + c], r < rows, c0 <= c < c1: structurally zero weights (gradient discarded in the step)"""
+        e = self.extras
+        e.frozen_start, e.frozen_rows, e.frozen_ld, e.frozen_c0, e.frozen_c1 = int(start), int(rows), int(ld), int(c0), int(c1)
+
+    def set_transposes(self, items):
+        """items: [(start, rows, cols, dst bf16 (cols x rows) tensor)] — dst is rewritten whenever its weights are stepped"""
+        e = self.extras
+        assert len(items) <= 2
+        e.num_transposes = len(items)
+        self._keep = [t for *_, t in items]
+        for T, (start, rows, cols, dst) in zip(e.transpose, items):
+            assert dst.is_contiguous() and dst.dtype == torch.bfloat16 and tuple(dst.shape) == (cols, rows)
+            T.start, T.rows, T.cols, T.dst = int(start), int(rows), int(cols), dst.data_ptr()
 
     def set_ranges(self, ranges):
         """restrict the step to these (start, count) element ranges (at most two) — e.g. one rank's slice of a sharded step"""
@@ -699,5 +783,5 @@ class FusedAdam:
                                       self.r1[0], self.r1[1], gscale, self.partial.data_ptr() if clip else None,
                                       float(max_norm) if clip else 0.0, self.step.data_ptr(), self.lr.data_ptr(), self.betas[0],
                                       self.betas[1], self.eps, self.body.data_ptr(), self.n_body, self.std.data_ptr(), self.std.numel(), int(zero_grad),
-                                      _ptr(zero_slot), _stream()),
+                                      _ptr(zero_slot), ctypes.byref(self.extras), _stream()),
              "go1ppo_opt_adam")

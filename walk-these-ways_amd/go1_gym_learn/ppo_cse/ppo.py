@@ -86,6 +86,21 @@ def _enable_tuned_gemms():
         print(f"[ppo] TunableOp not enabled ({type(err).__name__}: {err})", file=sys.stderr)
 
 
+def policy_dtype_is_bf16():
+    """bf16 policy (fp32 master + bf16 compute copy, the fused update) or the fp32 autograd path?  `PPO_Args.autocast_bf16` decides,
+    unless the environment variable GO1_POLICY_DTYPE (= bf16 | fp32) is set: the switch for the UNCHANGED reference scripts
+    (scripts/train.py constructs Runner with the default PPO_Args, train.py:207-216) — `GO1_POLICY_DTYPE=bf16 python scripts/train.py`
+    selects BASELINE configs[1]'s bf16 policy without editing the script."""
+    v = os.environ.get("GO1_POLICY_DTYPE", "").strip().lower()
+    if v in ("bf16", "bfloat16"):
+        return True
+    if v in ("fp32", "f32", "float32"):
+        return False
+    if v:
+        raise ValueError(f"GO1_POLICY_DTYPE={v!r}: expected bf16 or fp32")
+    return bool(PPO_Args.autocast_bf16)
+
+
 def _force_dp():
     return os.environ.get("GO1_FORCE_DP", "0") not in ("", "0")
 
@@ -113,7 +128,7 @@ class PPO:
         self.actor_critic = actor_critic          # public / checkpoint format; refreshed by sync_module()
         self.actor_critic.to(device)
         self.on_gpu = torch.device(device).type == "cuda"
-        self.bf16 = bool(PPO_Args.autocast_bf16 and self.on_gpu)
+        self.bf16 = bool(policy_dtype_is_bf16() and self.on_gpu)
         self.storage = None
         ac = self.actor_critic
         self.policy = FlatPolicy(ac)
@@ -169,6 +184,11 @@ class PPO:
                                            ranges=[(0, pol.adaptation_numel)])
             self._lr = self._opt.lr
             self._ad_grad_views = [self.master.grad[:pol.adaptation_numel]]
+            # the privileged-observation columns of the adaptation module's and the actor's first-layer rows are structurally zero
+            # weights: both optimiser steps discard whatever gradient the augmented GEMM rows left there (no fill launches)
+            w1 = pol.offsets[pol.index["W1"]]
+            for o in (self._opt, self._opt_ad):
+                o.set_frozen_columns(w1, pol.first[0] + pol.first[1], pol.Kp, pol.K + 1, pol.K + 1 + pol.npv)
         if self.dp:                              # identical initial weights on every rank
             dist.broadcast(self.master, src=0)
         self._dp_lowp = self._dp_shard = None
@@ -203,6 +223,8 @@ class PPO:
         with torch.no_grad():
             self.body.copy_(self.master[:self.n_body])
             self.std.copy_(self.master[self.n_body:self.n_body + self.n_std])
+            if self._train_net is not None:
+                self._train_net.refresh_transposes()
 
     def _pull_grads(self):
         """compute-copy gradients -> fp32 master gradient."""
@@ -409,7 +431,10 @@ class PPO:
             net.forward(net.X)
             net.ppo_loss(self.storage, idx, self.std, self.master.grad[n:n + self.n_std], PPO_Args, self._kl, self._acc)
             net.backward(net.X)
-            self._priv_cols_grad.zero_()
+            # (privileged-observation columns of the adaptation / actor rows: zeroed by go1ppo_sum_partials on the hipBLASLt path —
+            #  before the norm of the clip sees them —, discarded by the optimiser step in any case)
+            if net._w1_tn[0] or not net._mlp2:
+                self._priv_cols_grad.zero_()
 
     def _gather_rows(self, idx, out):
         """augmented history rows of the storage entries idx into the (len(idx), Kp) buffer `out`"""
@@ -426,7 +451,7 @@ class PPO:
             net.forward_adaptation(net.X)
             net.adaptation_loss(self.storage, idx, num_train, PPO_Args.selective_adaptation_module_loss, self._acc)
             net.backward_adaptation(net.X)
-            self._priv_cols_grad.zero_()
+            # (no clip in this stage: the optimiser step discards the gradient of the privileged-observation columns, __init__)
 
     def _stage_ppo_backward(self, idx):
         """PPO loss forward + backward into the fp32 master gradient (reference ppo.py:112-155)."""
@@ -624,6 +649,13 @@ class PPO:
             if self.fused:
                 from go1_gym_learn.ppo_cse.fused import FusedNet
                 self._train_net = FusedNet(self.policy, self.body, self.master.grad[:self.n_body], mb, self._fused_lib, with_grad=True)
+                # the optimiser step that changes actor.1 / critic.1 also rewrites their K-contiguous copies (the input-gradient GEMM's
+                # operand): no transpose-copy launches in the backward pass.  Not with the sharded step, whose ranks step slices only.
+                tr = self._train_net.adam_transposes()
+                if tr and self._dp_shard is None:
+                    self._train_net.refresh_transposes()
+                    self._opt.set_transposes(tr)
+                    self._train_net._wt_by_optimizer = True
                 # one row block per mini-batch: the same nmb index sets are visited in every epoch, so in graph mode
                 # their history rows are gathered once per update() (nmb gathers instead of epochs x nmb)
                 self._Xall = torch.zeros(nmb, mb, self.policy.Kp, device=self.device, dtype=self.body.dtype)
