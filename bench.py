@@ -39,7 +39,7 @@ ALGORITHMIC_BYTES_PER_ENV_STEP = 3444      # 1,332 B read + 1,
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def build_env(num_envs, rank, seed, rough=False, curriculum_update_interval=None):
+def build_env(num_envs, rank, seed, rough=False, curriculum_update_interval=None, spawn=None):
     """train.py configuration (BASELINE configs[1]); rough=True: configs[2] — the terrain curriculum's tile grid
     (slopes / rough slopes / stairs / obstacles, cfg:64-102 defaults) as a trimesh terrain (vertical risers) + the 187-point
     height scan appended to the observation (70 + 187 = 257)."""
@@ -58,6 +58,8 @@ def build_env(num_envs, rank, seed, rough=False, curriculum_update_interval=None
         t.mesh_type, t.terrain_proportions, t.curriculum = "trimesh", [0.1, 0.1, 0.35, 0.25, 0.2], True
         t.num_rows, t.num_cols, t.terrain_length, t.terrain_width, t.border_size, t.center_robots = 10, 20, 8.0, 8.0, 25.0, False
         t.measure_heights = True
+        if spawn is not None:                    # non-reference diagnostic switch (go1_gym/utils/terrain.py add_terrain_to_map)
+            t.origin_height_source = spawn
         cfg.env.observe_heights = True
         cfg.env.num_observations = cfg.env.num_scalar_observations = 70 + 187
     env = VelocityTrackingEasyEnv(sim_device=f"cuda:{torch.cuda.current_device()}", headless=True, cfg=cfg)

@@ -119,7 +119,10 @@ typedef struct {
   int64_t rows;
   int32_t ld_dz, ld_h, n, k, ldw;
   int32_t chunk_rows, wg_offset;      /* filled by go1ppo_wgrad_plan */
-  int32_t _pad;
+  /* structural zeros: dW[r][c] for r < zero_n, zero_k0 <= c < zero_k1 receives nothing (zero_n = 0: no mask).  The augmented
+   * first-layer rows carry the privileged observations for the critic only (actor_critic.py:44-47, 58-61): the adaptation
+   * module's and the actor's rows of W1 have no weight — hence no gradient — on those columns. */
+  int32_t zero_n, zero_k0, zero_k1;
 } Go1PpoWgradProblem;
 
 int go1ppo_wgrad_plan(Go1PpoWgradProblem* host_problems, int count);
@@ -182,17 +185,11 @@ int go1ppo_opt_prestep(const float* g, int64_t n, float gscale, float* partial, 
  * zero_grad != 0: every visited g[i] is cleared after it has been read (the following backward pass accumulates into a
  * clean gradient without a fill pass of its own); zero_slot (or NULL): one more float cleared — the KL accumulator that
  * rides in the gradient's padding. */
-/* extras (may be NULL):
- *  - frozen columns: the elements [frozen_start + r * frozen_ld + c], r < frozen_rows, frozen_c0 <= c < frozen_c1, are
- *    structurally zero weights — the privileged-observation columns of the adaptation module's and the actor's first-layer
- *    rows in the augmented GEMM layout (those inputs are the critic's only, actor_critic.py:44-47, 58-61): whatever gradient
- *    the GEMM left there is discarded (and cleared with zero_grad), the weight stays exactly 0;
- *  - transposes: dst[c * rows + r] (bf16) <- the refreshed weight at [start + r * cols + c]: K-contiguous copies of the
- *    layers whose input gradient runs on go1ppo_gemm_nt, kept current by the optimiser step itself. */
+/* extras (may be NULL): transposes — dst[c * rows + r] (bf16) <- the refreshed weight at [start + r * cols + c]: K-contiguous
+ * copies of the layers whose input gradient runs on go1ppo_gemm_nt, kept current by the optimiser step itself instead of by a
+ * transpose-copy launch per backward pass. */
 #define GO1PPO_ADAM_MAX_TRANSPOSES 2
 typedef struct {
-  int64_t frozen_start;
-  int32_t frozen_rows, frozen_ld, frozen_c0, frozen_c1;
   int32_t num_transposes, _pad;
   struct { int64_t start; int32_t rows, cols; void* dst; } transpose[GO1PPO_ADAM_MAX_TRANSPOSES];
 } Go1PpoAdamExtras;
@@ -203,8 +200,8 @@ int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t start0, int6
 
 /* out[r][c] (fp32, rows x cols contiguous) = sum over b < count of partials[b * stride + r * cols + c] (bf16) — the row-chunk
  * partial products of the first-layer weight gradient (a manual split-K over hipBLASLt's batched GEMM) summed into the flat
- * gradient; the columns [zero_c0, zero_c1) of the first zero_rows rows are written as exact zeros (see Go1PpoAdamExtras:
- * frozen columns).  cols, stride multiples of 8; 16-byte aligned. */
+ * gradient; the columns [zero_c0, zero_c1) of the first zero_rows rows are written as exact zeros (the structural zeros of
+ * Go1PpoWgradProblem).  cols, stride multiples of 8; 16-byte aligned. */
 int go1ppo_sum_partials(const void* partials, int count, int64_t stride, int64_t rows, int cols, float* out, int zero_rows,
                         int zero_c0, int zero_c1, void* stream);
 
@@ -213,11 +210,13 @@ int go1ppo_sum_partials(const void* partials, int count, int64_t stride, int64_t
 /* C (M x N, bf16, row stride ldc) = epilogue(A (M x K, bf16, lda) * B^T (B: N x K, bf16, ldb) + bias (fp32[N] or NULL)).
  * epilogue 0: nothing more; 1: ELU on the columns [elu_c0, elu_c1); 2: multiplied element-wise by elu'(H[m][n])
  * (H: the layer's post-ELU activations, bf16, ldh) — the input gradient of a hidden layer, B being the transposed
- * weight.  K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0, ldc/ldh % 4 == 0, A/B 16-byte and C/H 8-byte aligned. */
+ * weight.  K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0, ldc/ldh % 4 == 0, A/B 16-byte and C/H 8-byte aligned; bias 16-byte
+ * (fp32) or 8-byte (bf16) aligned. */
 typedef struct Go1PpoGemmArgs {
   const void* A; const void* B; void* C; const float* bias; const void* H;
   int32_t M, N, K, lda, ldb, ldc, ldh, epilogue, elu_c0, elu_c1;
   int32_t elu_skip_c0, elu_skip_c1;      /* epilogue 1: columns [elu_skip_c0, elu_skip_c1) stay pre-activations (0, 0: none) */
+  int32_t bias_bf16, _pad;               /* bias_bf16 != 0: `bias` points to bf16 values (the compute copy of the parameters) */
 } Go1PpoGemmArgs;
 int go1ppo_gemm_nt(const Go1PpoGemmArgs* args, void* stream);
 

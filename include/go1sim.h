@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GO1SIM_ABI_VERSION 5
+#define GO1SIM_ABI_VERSION 6
 
 #define GO1_NUM_DOF 12
 #define GO1_NUM_BODIES 17        /* base, then FL,FR,RL,RR x (hip, thigh, calf, foot) */
@@ -55,8 +55,8 @@ enum Go1ContactClass {
 };
 #define GO1_SIG_WORDS 4          /* per substep: [top-surface points | wall points | self pairs + legs with limit rows | hash of: the
                                     height-field cell and candidate point (corner / end) every listed terrain contact came from, the
-                                    contacts that took the restitution branch, and the ACTIVE SET the solve ended in (pressing
-                                    contacts, contacts projected on the friction cone in the last sweep, limit rows with an impulse)] */
+                                    contacts that took the restitution branch, and the ACTIVE SET after every solver sweep (pressing
+                                    contacts, contacts projected on the friction cone in that sweep, limit rows with an impulse)] */
 #define GO1_SIG_MAX_SUBSTEPS 4
 
 /* canonical reward ids: one per `_reward_*` in go1_gym/envs/rewards/corl_rewards.py:15-202 */
@@ -231,6 +231,12 @@ typedef struct Go1SimConfig {
   float dt;                        /* policy dt = decimation * sim_dt */
   float tracking_sigma, tracking_sigma_yaw, base_height_target, max_contact_force;
   float kappa_gait_probs, gait_force_sigma, gait_vel_sigma;
+  int32_t reward_heights_above_terrain;  /* 0 (reference): _reward_feet_clearance_cmd_linear / _reward_feet_contact_vel / _reward_jump read WORLD
+                                      z (corl_rewards.py:129 `# - reference_heights`, :100, :52-53: written for the flat z = 0 ground of
+                                      scripts/train.py).  1 (NOT in the reference; Cfg.rewards.heights_above_terrain): foot heights above the
+                                      terrain sample under the foot, base height above the mean of the height scan (or the sample under the
+                                      base) — sample convention of _get_heights, legged_robot.py:1793-1806.  What BASELINE configs[2] needs to
+                                      have a non-zero reward off the z = 0 tiles. */
 
   /* --- commands / curriculum: legged_robot.py:710-824, curriculum.py --- */
   int32_t device_curriculum;       /* 1: in-kernel sampling; 0: kernel only raises resample flags */

@@ -745,17 +745,19 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
       lamj[j] = ln;
       for (int i = 0; i < NV; i++) v[i] += TJ[j][i] * dl;
     }
-  }
-  if (out && cfg->solver_iterations > 0) {
-    /* signature: the active set the solve ended in (pressing contacts, sliding contacts, limit rows carrying an impulse) */
-    uint32_t jm = 0;
-    for (int j = 0; j < 12; j++) if (jact[j] && lamj[j] != 0) jm |= 1u << j;
-    uint32_t ah = jm * 0x27D4EB2Fu;
-    for (int c = 0; c < nc; c++) {
-      if (lamc[c][0] > 0) ah += (uint32_t)(c + 1) * 0x85EBCA6Bu;
-      if (slid[c]) ah += (uint32_t)(c + 1) * 0xC2B2AE35u;
+    if (out) {
+      /* signature: the active set after EVERY sweep (pressing contacts, contacts projected on the cone in this sweep, limit rows
+       * carrying an impulse), weighted by the sweep: a projection that flips in an intermediate sweep sends the unconverged
+       * 4-sweep iterate down another path even when the final active sets coincide */
+      uint32_t jm = 0;
+      for (int j = 0; j < 12; j++) if (jact[j] && lamj[j] != 0) jm |= 1u << j;
+      uint32_t ah = jm * 0x27D4EB2Fu;
+      for (int c = 0; c < nc; c++) {
+        if (lamc[c][0] > 0) ah += (uint32_t)(c + 1) * 0x85EBCA6Bu;
+        if (slid[c]) ah += (uint32_t)(c + 1) * 0xC2B2AE35u;
+      }
+      out->sig[3] += ah * (uint32_t)(2 * it + 1);
     }
-    out->sig[3] += ah;
   }
   for (int b = 0; b < 17; b++) v3set(wl[b], 0, 0, 0);
   for (int c = 0; c < nc; c++)
@@ -1180,7 +1182,23 @@ typedef struct {
   real base_pos[3], base_quat[4], base_lin_vel[3], base_ang_vel[3], proj_g[3], gvec[3];
   real q[12], qd[12];
   real fpos[4][3], fvel[4][3], cf[17][3];
+  real base_hz, fhz[4];      /* heights the reward terms read: world z (reference) or above the terrain (reward_heights_above_terrain) */
 } Derived;
+
+/* terrain height at world (x, y), sample convention of _get_heights (legged_robot.py:1793-1806): fp32 quotient truncated, the lowest
+ * of the sample and its +x / +y neighbours */
+static float hf_sample_min3(const Go1SimConfig* cfg, const int16_t* hs, float x, float y) {
+  if (cfg->terrain_type == 0 || !hs) return 0;
+  float fx = (x + cfg->hf_border) / cfg->hf_hscale, fy = (y + cfg->hf_border) / cfg->hf_hscale;
+  long px = (long)fx, py = (long)fy;
+  if (px < 0) px = 0; if (py < 0) py = 0;
+  if (px > cfg->hf_rows - 2) px = cfg->hf_rows - 2;
+  if (py > cfg->hf_cols - 2) py = cfg->hf_cols - 2;
+  int16_t h1 = hs[px * cfg->hf_cols + py], h2 = hs[(px + 1) * cfg->hf_cols + py], h3 = hs[px * cfg->hf_cols + py + 1];
+  int16_t hm = h1 < h2 ? h1 : h2;
+  hm = hm < h3 ? hm : h3;
+  return hm * cfg->hf_vscale;
+}
 
 static real reward_term(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, int id, const Derived* d) {
   const int N = cfg->num_envs;
@@ -1210,7 +1228,7 @@ static real reward_term(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, 
       }
       return r;
     case GO1_REW_JUMP: {
-      real t = d->base_pos[2] - ((real)AT(B->commands, 3, e) + (real)cfg->base_height_target);
+      real t = d->base_hz - ((real)AT(B->commands, 3, e) + (real)cfg->base_height_target);
       return -t * t;
     }
     case GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE:
@@ -1248,7 +1266,7 @@ static real reward_term(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, 
       }
       return r;
     case GO1_REW_FEET_CONTACT_VEL:
-      for (int f = 0; f < 4; f++) r += (d->fpos[f][2] < 0.03 ? 1 : 0) * v3dot(d->fvel[f], d->fvel[f]);
+      for (int f = 0; f < 4; f++) r += (d->fhz[f] < 0.03 ? 1 : 0) * v3dot(d->fvel[f], d->fvel[f]);
       return r;
     case GO1_REW_FEET_CONTACT_FORCES:
       for (int f = 0; f < 4; f++) { real x = v3norm(d->cf[4 + 4 * f]) - (real)cfg->max_contact_force; r += x > 0 ? x : 0; }
@@ -1259,7 +1277,7 @@ static real reward_term(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e, 
         real cl = fi * 2.0 - 1.0; cl = cl < 0 ? 0 : (cl > 1 ? 1 : cl);
         real ph = 1 - fabs(1.0 - cl * 2.0);
         real target = (real)AT(B->commands, 9, e) * ph + 0.02;
-        real df = target - d->fpos[f][2];
+        real df = target - d->fhz[f];
         r += df * df * (1 - (real)AT(B->desired_contact_states, f, e));
       }
       return r;
@@ -1404,6 +1422,13 @@ static void post_physics(const Go1SimConfig* cfg, const Go1SimBuffers* B, int e,
     mean_height /= np;
   }
 
+  d.base_hz = d.base_pos[2];
+  for (int f = 0; f < 4; f++) d.fhz[f] = d.fpos[f][2];
+  if (cfg->reward_heights_above_terrain) {          /* NOT in the reference (go1sim.h) */
+    for (int f = 0; f < 4; f++) d.fhz[f] -= (real)hf_sample_min3(cfg, B->height_samples, AT(B->foot_positions, 3 * f, e), AT(B->foot_positions, 3 * f + 1, e));
+    d.base_hz -= (cfg->measure_heights && B->measured_heights) ? mean_height
+                                                               : (real)hf_sample_min3(cfg, B->height_samples, AT(B->root_states, 0, e), AT(B->root_states, 1, e));
+  }
   /* ---- check_termination (:138-148) ---- */
   int reset = 0;
   for (int b = 0; b < 17; b++) if ((cfg->termination_body_mask & (1u << b)) && v3norm(d.cf[b]) > 1.0) reset = 1;

@@ -102,10 +102,10 @@ def test_ppo_wgrad_problem_mirror_matches_header():
         if decl:
             names += [n.strip().lstrip("*") for n in re.sub(r"^(const\s+)?\w+\s*\*?", "", decl, count=1).split(",")]
     assert names == [f[0] for f in fused.WgradProblem._fields_]
-    assert C.sizeof(fused.WgradProblem) == 72
+    assert C.sizeof(fused.WgradProblem) == 80
 
 
-@pytest.mark.parametrize("cname,mirror,size", [("Go1PpoGemmArgs", "GemmArgs", 88), ("Go1PpoMlp2Fwd", "Mlp2Fwd", 80), ("Go1PpoMlp2Bwd", "Mlp2Bwd", 88)])
+@pytest.mark.parametrize("cname,mirror,size", [("Go1PpoGemmArgs", "GemmArgs", 96), ("Go1PpoMlp2Fwd", "Mlp2Fwd", 80), ("Go1PpoMlp2Bwd", "Mlp2Bwd", 88)])
 def test_ppo_new_struct_mirrors_match_header(cname, mirror, size):
     """field order and size of the ctypes mirrors of the GEMM / LDS-resident MLP argument structs."""
     import ctypes as C
@@ -122,12 +122,12 @@ def test_ppo_new_struct_mirrors_match_header(cname, mirror, size):
 
 
 def test_ppo_adam_extras_mirror_size():
-    """Go1PpoAdamExtras (frozen columns + transposed copies of the optimiser step): the ctypes mirror has the size the library
-    asserts at compile time (csrc/go1ppo.hip static_assert: 80 bytes)."""
+    """Go1PpoAdamExtras (transposed weight copies kept by the optimiser step): the ctypes mirror has the size the library asserts at
+    compile time (csrc/go1ppo.hip static_assert: 56 bytes)."""
     import ctypes as C
     from go1_gym_learn.ppo_cse import fused
-    assert C.sizeof(fused.AdamExtras) == 80 and C.sizeof(fused._AdamTranspose) == 24
-    assert [f[0] for f in fused.AdamExtras._fields_][:6] == ["frozen_start", "frozen_rows", "frozen_ld", "frozen_c0", "frozen_c1", "num_transposes"]
+    assert C.sizeof(fused.AdamExtras) == 56 and C.sizeof(fused._AdamTranspose) == 24
+    assert [f[0] for f in fused.AdamExtras._fields_] == ["num_transposes", "_pad", "transpose"]
 
 
 def test_fused_update_fails_loudly_without_library(tmp_path):

@@ -421,20 +421,24 @@ def test_emulated_full_step_in_the_contact_heavy_regime(oracle_lib, emu, seed):
     assert int(Be.fault_counts[:10].sum()) == 0 and int(Be.contact_drop_counts.sum()) == int(Bc.contact_drop_counts.sum())
 
 
-@pytest.mark.parametrize("walls", [False, True])
-def test_emulated_full_step_on_a_height_field(oracle_lib, emu, walls):
+@pytest.mark.parametrize("walls,above", [(False, False), (True, False), (False, True)])
+def test_emulated_full_step_on_a_height_field(oracle_lib, emu, walls, above):
     """BASELINE config 3 through the emulated step kernel: rough int16 height field with a staircase strip (bilinear height,
     tilted contact normals), the 187-point height scan in the observation (257 columns), resets onto the field — against
     the oracle, re-synchronised every step (the GPU counterpart: tests/test_gpu_parity.py::test_full_step_on_height_field).
     walls: the same field as a `trimesh` terrain — the strip's 0.1 m risers are vertical faces (the kernel's WALLS instances);
-    half of the robots start on the strip."""
+    half of the robots start on the strip.  above: the non-reference `rewards.heights_above_terrain` switch (foot / base heights of the
+    reward terms measured above the ground, include/go1sim.h reward_heights_above_terrain)."""
     N = 32
     pts_x = [round(-0.8 + 0.1 * i, 1) for i in range(17)]
     pts_y = [round(-0.5 + 0.1 * i, 1) for i in range(11)]
     ex = {"terrain": dict(measure_heights=True, measured_points_x=pts_x, measured_points_y=pts_y),
           "env": dict(observe_heights=True, num_observations=70 + 187),
           "domain_rand": dict(randomize_gravity=False)}
+    if above:
+        ex["rewards"] = dict(heights_above_terrain=True)
     cfg, S, meta, Bc = make_sim("train_noise", N, seed=13, extra=ex)
+    assert bool(S.reward_heights_above_terrain) == above
     rng = np.random.default_rng(2)
     z = rng.uniform(-1, 1, (62, 62))
     z = np.kron(z, np.ones((4, 4)))[:240, :240]

@@ -273,27 +273,22 @@ def test_sum_partials_matches_torch(lib, count, rows, cols, zero):
     assert lib.go1ppo_sum_partials(part.data_ptr(), count, part.stride(0), rows, cols + 4, out.data_ptr(), 0, 0, 0, stream()) == -1
 
 
-def test_adam_frozen_columns_and_transposed_copies(lib):
-    """Go1PpoAdamExtras: (i) the gradient of the structurally zero weights (a column block of the leading rows of one 2-D block of the
-    flat parameter) is discarded — those weights stay exactly 0, their moments stay 0, zero_grad clears the slot — everything
-    else steps like torch.optim.Adam; (ii) the K-contiguous bf16 copies equal body.view(rows, cols).t() after every step."""
+def test_adam_keeps_transposed_copies(lib):
+    """Go1PpoAdamExtras: the K-contiguous bf16 copies equal body.view(rows, cols).t() after every step that visits their weights, the
+    step itself is torch.optim.Adam's; a range-restricted step that does not visit them leaves them alone."""
     from go1_gym_learn.ppo_cse import fused
     g = torch.Generator(device="cuda").manual_seed(21)
-    blk0, rows, ld, c0, c1 = 384, 24, 40, 33, 35            # a (32 x 40) block at offset 384; frozen: rows < 24, columns 33..34
-    t0 = (2048, 16, 48)                                     # transposed copies of two blocks
+    t0 = (2048, 16, 48)
     t1 = (4096, 64, 8)
     n_body, n_std = 6000, 12
     n = n_body + 16
     master = torch.randn(n, device="cuda", generator=g) * 0.1
     master[n_body + n_std:] = 0
-    W = master[blk0:blk0 + 32 * ld].view(32, ld)
-    W[:rows, c0:c1] = 0.0
     ref = master.clone().requires_grad_()
     master.grad = torch.zeros_like(master)
     body = torch.zeros(n_body, device="cuda", dtype=torch.bfloat16)
     std = torch.zeros(n_std, device="cuda")
     opt = fused.FusedAdam(lib, master, body, std, n_body, 1e-3, ranges=[(0, n_body + n_std)])
-    opt.set_frozen_columns(blk0, rows, ld, c0, c1)
     d0 = torch.full((t0[2], t0[1]), 9.0, device="cuda", dtype=torch.bfloat16)
     d1 = torch.full((t1[2], t1[1]), 9.0, device="cuda", dtype=torch.bfloat16)
     opt.set_transposes([(t0[0], t0[1], t0[2], d0), (t1[0], t1[1], t1[2], d1)])
@@ -303,18 +298,50 @@ def test_adam_frozen_columns_and_transposed_copies(lib):
         grad[n_body + n_std:] = 0
         master.grad.copy_(grad)
         opt.step_(zero_grad=True)
-        gr = grad.clone()
-        gr[blk0:blk0 + 32 * ld].view(32, ld)[:rows, c0:c1] = 0.0
-        ref.grad = gr
+        ref.grad = grad.clone()
         ref_opt.step()
         torch.cuda.synchronize()
         torch.testing.assert_close(master, ref.detach(), rtol=2e-5, atol=2e-7)
-        assert bool((W[:rows, c0:c1] == 0).all()) and bool((master.grad[:n_body + n_std] == 0).all())
-        assert bool((opt.m[blk0:blk0 + 32 * ld].view(32, ld)[:rows, c0:c1] == 0).all())
-        assert float(W[rows:, c0:c1].abs().min()) > 0           # the rows behind the frozen ones (the critic's) do move
+        assert bool((master.grad[:n_body + n_std] == 0).all())
         for (st, r, c), d in ((t0, d0), (t1, d1)):
             assert torch.equal(d, body[st:st + r * c].view(r, c).t().contiguous())
     torch.testing.assert_close(body.float(), bf(master[:n_body]).float(), rtol=0, atol=0)
+    keep = d0.clone()
+    sub = fused.FusedAdam(lib, master, body, std, n_body, 1e-3, ranges=[(0, 1000)])
+    sub.set_transposes([(t0[0], t0[1], t0[2], d0)])
+    master.grad.normal_(generator=g)
+    sub.step_()
+    torch.cuda.synchronize()
+    assert torch.equal(d0, keep)
+
+
+@pytest.mark.parametrize("tn", [True, False])
+def test_batched_weight_gradient_structural_zeros(lib, tn):
+    """Go1PpoWgradProblem.zero_*: the masked block of dW receives NOTHING (it keeps the value the buffer held), every other element is the
+    plain product — on both batched kernels (128-tile LDS-DMA kernel / 64-tile fallback)."""
+    from go1_gym_learn.ppo_cse import fused
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, n, k = 4096, 256, 192
+    dz = bf(torch.randn(M, n, device="cuda", generator=g))
+    h = bf(torch.randn(M, k, device="cuda", generator=g))
+    out = torch.zeros(n, k, device="cuda")
+    zn, z0, z1 = 200, 130, 133
+    out[:zn, z0:z1] = 42.0
+    tab = (fused.WgradProblem * 1)()
+    P = tab[0]
+    P.dz, P.h, P.dW, P.bias_grad = dz.data_ptr(), h.data_ptr(), out.data_ptr(), None
+    P.rows, P.ld_dz, P.ld_h, P.n, P.k, P.ldw = M, n, k, n, k, k
+    P.zero_n, P.zero_k0, P.zero_k1 = zn, z0, z1
+    total = (lib.go1ppo_wgrad_tn_plan if tn else lib.go1ppo_wgrad_plan)(tab, 1)
+    assert total > 0
+    dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).cuda()
+    assert (lib.go1ppo_wgrad_tn_batched if tn else lib.go1ppo_wgrad_batched)(dev.data_ptr(), 1, total, stream()) == 0
+    torch.cuda.synchronize()
+    ref = dz.float().t() @ h.float()
+    mask = torch.zeros(n, k, dtype=torch.bool, device="cuda")
+    mask[:zn, z0:z1] = True
+    assert bool((out[mask] == 42.0).all())
+    torch.testing.assert_close(out[~mask], ref[~mask], rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("M", [4096, 1000, 24576])

@@ -173,3 +173,33 @@ def test_incline_friction_holds_or_slides(oracle_lib, slope, mu_robot, holds):
         F = B.contact_forces.view(17, 3, N).sum(0).numpy()
         np.testing.assert_allclose(F[0] / F[2], -slope, atol=0.01)       # along the slope normal (-slope, 0, 1)/|.|
         np.testing.assert_allclose(np.linalg.norm(F, axis=0), mg * np.cos(th), rtol=0.03)
+
+
+def test_heights_above_terrain_makes_the_reward_independent_of_the_ground_elevation(oracle_lib):
+    """`rewards.heights_above_terrain` (NOT a reference switch; include/go1sim.h reward_heights_above_terrain): the reference's
+    _reward_feet_clearance_cmd_linear / _reward_feet_contact_vel / _reward_jump read world z (corl_rewards.py:129 `# - reference_heights`,
+    :100, :52-53), so lifting the whole scene by 1 m changes the reward; with the switch the same robots on the lifted ground get the
+    reward they got at z = 0 — which is what a terrain-curriculum tile grid needs (BASELINE configs[2])."""
+    import pyoracle
+    N = 16
+    rews = {}
+    for above in (False, True):
+        for lift in (0.0, 1.0):
+            ex = {"domain_rand": dict(randomize_gravity=False), "rewards": dict(heights_above_terrain=above)}
+            cfg, S, meta, B = make_sim("train_noise", N, seed=3, extra=ex)
+            hs = np.full((240, 240), int(round(lift / 0.005)), dtype=np.int16)
+            H.bind_height_field(S, B, hs, 0.1, 0.005, 0.0)
+            B.env_origins[0].uniform_(5.0, 18.0, generator=torch.Generator().manual_seed(1))
+            B.env_origins[1].uniform_(5.0, 18.0, generator=torch.Generator().manual_seed(2))
+            B.env_origins[2] = lift
+            orc = pyoracle.Oracle(S, B)
+            orc.reset_idx()
+            rng = np.random.default_rng(0)
+            tot = np.zeros(N)
+            for _ in range(5):
+                orc.step((0.3 * rng.standard_normal((N, 12))).astype(np.float32))
+                tot += B.rew_buf.numpy()
+            rews[(above, lift)] = tot
+    np.testing.assert_allclose(rews[(True, 1.0)], rews[(True, 0.0)], rtol=1e-4, atol=1e-6)       # (fp32 state at z ~ 1.3 instead of 0.3)
+    np.testing.assert_allclose(rews[(True, 0.0)], rews[(False, 0.0)], rtol=1e-6, atol=1e-8)      # on the z = 0 ground the switch changes nothing
+    assert np.abs(rews[(False, 1.0)] - rews[(False, 0.0)]).max() > 1e-3                           # the reference terms do depend on the elevation

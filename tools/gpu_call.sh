@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 run() { name=$1; shift; echo "=== $name: $*" | tee -a $OUT/index.txt; ( time timeout ${TMO:-600} "$@" ) > $OUT/$name.log 2>&1; echo "    rc=$? $(tail -n 3 $OUT/$name.log | tr '\n' ' ' | cut -c1-300)" | tee -a $OUT/index.txt; }
 for step in "$@"; do
 case $step in
-  parity) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt run parity python -m pytest tests/test_gpu_parity.py tests/test_gpu_env.py -q -x -s -k "product_instances or train_eval_split or deferred_torque" ;;
+  parity) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt run parity python -m pytest tests/test_gpu_parity.py tests/test_gpu_env.py -q -s -k "product_instances or train_eval_split or deferred_torque" ;;
   fusedtests) run fusedtests python -m pytest tests/test_gpu_ppo_fused.py -q -x ;;
   gemm) run gemm python tools/bench_gemm.py ;;
   bench) run bench python bench.py --steps 20 --warmup 5 --headline-only --no-cpu-baseline --breakdown ;;

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="PPO_Args.use_hip_graphs = False")
     ap.add_argument("--rough", action="store_true", help="BASELINE configs[2]: terrain-curriculum tile grid as a trimesh (vertical risers) + height scan")
+    ap.add_argument("--spawn", default=None, choices=["tile_max", "centre_patch"], help="with --rough: spawn height of a tile (tile_max = the reference's rule)")
     ap.add_argument("--check-finite", action="store_true", help="after every iteration: first non-finite tensor among "
                     "observations / rewards / actions / returns / parameters / gradients, then stop")
     args = ap.parse_args()
@@ -32,7 +33,30 @@ def main():
         PPO_Args.use_hip_graphs = False
     RunnerArgs.save_video_interval = 0
     torch.manual_seed(0)
-    env, cfg = build_env(args.envs, 0, 0, rough=args.rough)
+    env, cfg = build_env(args.envs, 0, 0, rough=args.rough, spawn=args.spawn)
+    per_class = None
+    if args.rough:
+        # terrain class of every environment's tile column (terrain.py make_terrain: choice = column / num_cols + 0.001 against the
+        # cumulative proportions): which tile classes end episodes by falling
+        base0 = env
+        while not hasattr(base0, "terrain_types"):
+            base0 = base0.env
+        t = cfg.terrain
+        cum = [sum(t.terrain_proportions[:i + 1]) for i in range(len(t.terrain_proportions))]
+        names = ["slope (inverted: pit)", "slope", "rough slope", "stairs down (pit)", "stairs up", "obstacles"]
+
+        def klass(col):
+            c = col / t.num_cols + 0.001
+            if c < cum[0]:
+                return 0 if c < cum[0] / 2 else 1
+            if c < cum[1]:
+                return 2
+            if c < cum[3]:
+                return 3 if c < cum[2] else 4
+            return 5
+        cls = torch.tensor([klass(int(c)) for c in base0.terrain_types.tolist()], device="cuda")
+        per_class = dict(names=names, cls=cls, stats=torch.zeros(len(names), 4, device="cuda"))      # episodes, time-outs, length sum, envs
+        per_class["stats"][:, 3] = torch.bincount(cls, minlength=len(names)).float()
     runner = Runner(env, device="cuda:0")
     T = runner.num_steps_per_env
     buf = env.episode_length_buf
@@ -73,6 +97,11 @@ def main():
                 acc[0] += env.rew_buf.sum(); acc[1] += n
                 acc[2] += done.sum(); acc[3] += (done & env.time_out_buf).sum()
                 ep_len_sum += (ep_before[done] + 1).sum()
+                if per_class is not None and it >= args.iters - 100:          # the last 100 iterations
+                    c, S = per_class["cls"][:n], per_class["stats"]
+                    S[:, 0].index_add_(0, c, done[:n].float())
+                    S[:, 1].index_add_(0, c, (done & env.time_out_buf)[:n].float())
+                    S[:, 2].index_add_(0, c, torch.where(done[:n], (ep_before[:n] + 1).float(), torch.zeros(n, device="cuda")))
             runner.alg.compute_returns(obs_dict["obs_history"][:n], obs_dict["privileged_obs"][:n])
         if args.check_finite:
             st = runner.alg.storage
@@ -122,6 +151,21 @@ def main():
                   f"time-outs/resets {a[3] / max(a[2], 1):5.3f}  lr {runner.alg.learning_rate:.2e}  value loss {losses[0]:.4f}  "
                   f"surr {losses[1]:+.4f}  adapt {losses[2]:.4f}  std {float(runner.alg.std.detach().mean()):.3f}  [{time.time() - t0:5.1f} s]{diag}", flush=True)
             acc.zero_(); ep_len_sum.zero_()
+    # per-term episode sums of the episodes finished since the last print (reference extras["train/episode"], legged_robot.py:181-227):
+    # which terms make up train.py's reward = positive part x exp(negative part / sigma_rew_neg)
+    base = env
+    while not hasattr(base, "buffers"):
+        base = base.env
+    terms = {k: v for k, v in base.extras["train/episode"].consume().items() if k.startswith("rew_")}
+    print("mean per-episode reward terms (finished episodes since the last print), most negative first:")
+    for k, v in sorted(terms.items(), key=lambda kv: kv[1])[:8]:
+        print(f"    {k:44s} {v:12.4f}")
+    for k, v in sorted(terms.items(), key=lambda kv: -kv[1])[:4]:
+        print(f"    {k:44s} {v:12.4f}")
+    if per_class is not None:
+        print("per terrain class, last 100 iterations: envs | episodes ended | time-outs among them | mean episode length [steps]")
+        for name, (ep, to, ln, ne) in zip(per_class["names"], per_class["stats"].tolist()):
+            print(f"  {name:24s} {int(ne):5d} | {int(ep):7d} | {to / max(ep, 1):5.3f} | {ln / max(ep, 1):7.1f}")
 
 
 if __name__ == "__main__":

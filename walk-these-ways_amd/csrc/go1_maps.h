@@ -220,12 +220,26 @@ DEV void reset_env(CfgRef cfg, BufRef B, int e, int N, int64_t step, bool is_eva
 struct Derived {
   V3 base_pos, blv, bav, pg, gvec;
   float qx, qy, qz, qw;
+  float base_hz;            // base height the reward terms read: world z (reference) or above the terrain (reward_heights_above_terrain)
 };
 struct FootCtx {            // the calling lane's foot
   V3 pos, vel, force;
   float fnorm;
   float foot_index, desired_contact;
+  float hz;                 // foot height the reward terms read: world z (reference) or above the terrain sample under the foot
 };
+// terrain height at world (x, y) with the sample convention of _get_heights (reference legged_robot.py:1793-1806): truncated
+// index, the lowest of the sample and its +x / +y neighbours
+DEV float hf_sample_min3(CfgRef cfg, const int16_t* __restrict__ hs, float x, float y) {
+  if (cfg.terrain_type == 0 || hs == nullptr) return 0.f;
+  long px = (long)((x + cfg.hf_border) / cfg.hf_hscale), py = (long)((y + cfg.hf_border) / cfg.hf_hscale);
+  px = px < 0 ? 0 : (px > cfg.hf_rows - 2 ? cfg.hf_rows - 2 : px);
+  py = py < 0 ? 0 : (py > cfg.hf_cols - 2 ? cfg.hf_cols - 2 : py);
+  const int16_t* q = hs + px * cfg.hf_cols + py;
+  int16_t hm = q[0] < q[cfg.hf_cols] ? q[0] : q[cfg.hf_cols];
+  hm = hm < q[1] ? hm : q[1];
+  return hm * cfg.hf_vscale;
+}
 
 DEV float cf_norm(BufRef B, int b, int e, int N) {
   float x = AT(B.contact_forces, 3 * b, e), y = AT(B.contact_forces, 3 * b + 1, e), z = AT(B.contact_forces, 3 * b + 2, e);
@@ -307,7 +321,7 @@ DEV float reward_partial(CfgRef cfg, BufRef B, int e, int N, int id, const Deriv
       }
       return r;
     case GO1_REW_JUMP: {
-      float t = d.base_pos.z - (in.cmd[3] + cfg.base_height_target);
+      float t = d.base_hz - (in.cmd[3] + cfg.base_height_target);
       return is0 ? -t * t : 0.f;
     }
     case GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE:
@@ -342,13 +356,13 @@ DEV float reward_partial(CfgRef cfg, BufRef B, int e, int N, int id, const Deriv
       AT(B.last_contacts, leg, e) = (uint8_t)contact;
       return filt ? (F.vel.x * F.vel.x + F.vel.y * F.vel.y) : 0.f;
     }
-    case GO1_REW_FEET_CONTACT_VEL: return (F.pos.z < 0.03f) ? dot(F.vel, F.vel) : 0.f;
+    case GO1_REW_FEET_CONTACT_VEL: return (F.hz < 0.03f) ? dot(F.vel, F.vel) : 0.f;
     case GO1_REW_FEET_CONTACT_FORCES: return fmaxf(F.fnorm - cfg.max_contact_force, 0.f);
     case GO1_REW_FEET_CLEARANCE_CMD_LINEAR: {
       float cl = fminf(fmaxf(F.foot_index * 2.0f - 1.0f, 0.f), 1.f);
       float ph = 1.f - fabsf(1.0f - cl * 2.0f);
       float target = in.cmd[9] * ph + 0.02f;
-      float df = target - F.pos.z;
+      float df = target - F.hz;
       return df * df * (1.f - F.desired_contact);
     }
     case GO1_REW_FEET_IMPACT_VEL: {
@@ -512,6 +526,13 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
       sum += hgt;
     }
     mean_height = quad_sum(sum) / np;
+  }
+  // heights the reward terms read (reference: world z; reward_heights_above_terrain: above the ground — go1sim.h)
+  F.hz = F.pos.z;
+  d.base_hz = d.base_pos.z;
+  if (cfg.reward_heights_above_terrain) {
+    F.hz -= hf_sample_min3(cfg, B.height_samples, F.pos.x, F.pos.y);
+    d.base_hz -= (cfg.measure_heights && B.measured_heights) ? mean_height : hf_sample_min3(cfg, B.height_samples, d.base_pos.x, d.base_pos.y);
   }
   // ---- check_termination ---------------------------------------------------------------------------
   PROF(10);

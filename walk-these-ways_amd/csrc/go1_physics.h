@@ -1397,6 +1397,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       // (SIG instances: the 4th word carries "this turn projected the friction impulse on the cone" for the test signature)
       if (leg == 0) CRQ(k, 9) = (lf4){ln, l1, l2, SIG && nn > lim * lim ? 1.f : 0.f};
     };
+    uint32_t sig_active = 0u;
 #pragma unroll 1
     for (int it = 0; it < cfg.solver_iterations; it++) {
       // two records in flight: the next contact's ten slots are requested before the current contact's arithmetic starts
@@ -1443,6 +1444,26 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         }
       }
       LDS_PHASE();          // the next sweep re-reads the impulses the leg-0 lanes stored in this one
+      if (SIG && B.contact_signature != nullptr && sub < GO1_SIG_MAX_SUBSTEPS) {
+        // tests only: the ACTIVE SET after every sweep — which contacts press (lambda_n > 0), which were projected on the cone in this
+        // sweep, which limit rows carry an impulse —, weighted by the sweep.  Same contact list + same active sets = the same
+        // smooth map in oracle and kernel; anything else is a discrete flip (tests/test_gpu_parity.py Attribution): a projection
+        // that flips in an intermediate sweep sends the unconverged iterate down another path even when the final sets coincide.
+        unsigned jm = 0;
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) if (lamj[jj] != 0.f) jm |= 1u << (3 * leg + jj);
+        jm = quad_or(jm);
+        if (leg == 0) {
+          uint32_t ah = jm * 0x27D4EB2Fu;
+#pragma unroll 1
+          for (int k = 0; k < K; k++) {
+            const lf4 q9 = CRQ(k, 9);
+            if (q9[0] > 0.f) ah += (uint32_t)(k + 1) * 0x85EBCA6Bu;
+            if (q9[3] != 0.f) ah += (uint32_t)(k + 1) * 0xC2B2AE35u;
+          }
+          sig_active += ah * (uint32_t)(2 * it + 1);
+        }
+      }
     }
     {
       float nf_acc = 0.f;
@@ -1453,26 +1474,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       for (int i = 0; i < 3; i++) nf_acc = nonfinite_acc(nf_acc, lamj[i]);
       if (nf_acc != nf_acc) fault |= 1u << GO1_FAULT_LAMBDA;
     }
-    if (SIG && B.contact_signature != nullptr && sub < GO1_SIG_MAX_SUBSTEPS) {
-      // tests only: the ACTIVE SET the solve ended in — which contacts press (lambda_n > 0), which slide (cone projection in the
-      // last sweep), which limit rows carry an impulse.  Same contact list + same active set = the same smooth map in oracle
-      // and kernel; anything else is a discrete flip (tests/test_gpu_parity.py Attribution).
-      LDS_PHASE();
-      unsigned jm = 0;
-#pragma unroll
-      for (int jj = 0; jj < 3; jj++) if (lamj[jj] != 0.f) jm |= 1u << (3 * leg + jj);
-      jm = quad_or(jm);
-      if (leg == 0) {
-        uint32_t ah = jm * 0x27D4EB2Fu;
-#pragma unroll 1
-        for (int k = 0; k < K; k++) {
-          const lf4 q9 = CRQ(k, 9);
-          if (q9[0] > 0.f) ah += (uint32_t)(k + 1) * 0x85EBCA6Bu;
-          if (q9[3] != 0.f) ah += (uint32_t)(k + 1) * 0xC2B2AE35u;
-        }
-        AT(B.contact_signature, sub * GO1_SIG_WORDS + 3, e) += ah;
-      }
-    }
+    if (SIG && B.contact_signature != nullptr && sub < GO1_SIG_MAX_SUBSTEPS && leg == 0) AT(B.contact_signature, sub * GO1_SIG_WORDS + 3, e) += sig_active;
   }
 #endif
 

@@ -19,7 +19,7 @@
 #include "../../include/go1ppo.h"
 
 typedef uint16_t bf16_t;
-static_assert(sizeof(Go1PpoAdamExtras) == 80 && sizeof(Go1PpoGemmArgs) == 88 && sizeof(Go1PpoWgradProblem) == 72, "ctypes mirrors (fused.py) assume these sizes");
+static_assert(sizeof(Go1PpoAdamExtras) == 56 && sizeof(Go1PpoGemmArgs) == 96 && sizeof(Go1PpoWgradProblem) == 80, "ctypes mirrors (fused.py) assume these sizes");
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
@@ -357,7 +357,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 #define WG2_LDM 72
 __device__ __forceinline__ void wgrad2_body(const bf16_t* dz, int ld_dz, const bf16_t* h, int ld_h, int64_t m_begin, int64_t m_end,
                                             float* dW, int ldw, float* bias_grad, int n0, int k0, bool do_bias,
-                                            bf16_t (*T)[2][64][WG2_LDM]) {
+                                            bf16_t (*T)[2][64][WG2_LDM], int zero_n = 0, int zero_k0 = 0, int zero_k1 = 0) {
   const int t = threadIdx.x, op = t >> 7, rq = (t & 127) >> 3, cg = t & 7, wave = t >> 6, lane = t & 63;
   const bf16_t* src = op ? h + k0 + 8 * cg : dz + n0 + 8 * cg;
   const int ld = op ? ld_h : ld_dz;
@@ -421,7 +421,7 @@ __device__ __forceinline__ void wgrad2_body(const bf16_t* dz, int ld_dz, const b
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       int row = n0 + 16 * wave + (lane >> 4) * 4 + q, col = k0 + 16 * j + (lane & 15);
-      atomicAdd(dW + (int64_t)row * ldw + col, acc[j][q]);
+      if (!(row < zero_n && col >= zero_k0 && col < zero_k1)) atomicAdd(dW + (int64_t)row * ldw + col, acc[j][q]);
     }
   if (do_bias) {
     bsum += __shfl_xor(bsum, 1, 64);
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void wgrad_batched_kernel(const Go1PpoWgradPro
   const int64_t m_begin = (int64_t)split * P.chunk_rows;
   const int64_t m_end = m_begin + P.chunk_rows < P.rows ? m_begin + P.chunk_rows : P.rows;
   wgrad2_body((const bf16_t*)P.dz, P.ld_dz, (const bf16_t*)P.h, P.ld_h, m_begin, m_end, P.dW, P.ldw, P.bias_grad, n0, k0,
-              P.bias_grad && k0 == 0, T);
+              P.bias_grad && k0 == 0, T, P.zero_n, P.zero_k0, P.zero_k1);
 }
 
 // ---------------------------------------------------------------------------------------------- rollout glue
@@ -596,17 +596,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m,
   const int64_t total = count0 + count1;
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total; j += (int64_t)gridDim.x * 256) {
     const int64_t i = j < count0 ? start0 + j : start1 + (j - count0);
-    float gi = g[i] * gs;
+    const float gi = g[i] * gs;
     if (zero_grad) g[i] = 0.f;          // the next backward pass accumulates into a clean gradient: no separate fill pass
-    // structurally-zero weights (the privileged-observation columns of the adaptation module's and the actor's first-layer rows:
-    // the augmented GEMM rows carry those inputs for the critic only): their gradient is discarded here instead of by a fill pass
-    if (ex.frozen_rows > 0) {
-      const uint64_t off = (uint64_t)(i - ex.frozen_start);
-      if (off < (uint64_t)ex.frozen_rows * (uint64_t)ex.frozen_ld) {
-        const uint32_t col = (uint32_t)off % (uint32_t)ex.frozen_ld;
-        if (col >= (uint32_t)ex.frozen_c0 && col < (uint32_t)ex.frozen_c1) gi = 0.f;
-      }
-    }
+
     const float mi = beta1 * m[i] + (1.f - beta1) * gi;
     const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
     m[i] = mi;
@@ -1027,9 +1019,7 @@ extern "C" int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t s
   memset(&ex, 0, sizeof(ex));
   if (extras) {
     ex = *extras;
-    if (ex.num_transposes < 0 || ex.num_transposes > GO1PPO_ADAM_MAX_TRANSPOSES || ex.frozen_rows < 0 ||
-        (ex.frozen_rows > 0 && (ex.frozen_ld <= 0 || ex.frozen_c0 < 0 || ex.frozen_c1 > ex.frozen_ld || ex.frozen_c0 > ex.frozen_c1)))
-      return -2;
+    if (ex.num_transposes < 0 || ex.num_transposes > GO1PPO_ADAM_MAX_TRANSPOSES) return -2;
     for (int t = 0; t < ex.num_transposes; t++)
       if (!ex.transpose[t].dst || ex.transpose[t].rows <= 0 || ex.transpose[t].cols <= 0) return -2;
   }

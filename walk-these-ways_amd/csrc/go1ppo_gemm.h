@@ -116,7 +116,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(Go1PpoGemmArgs a) {
   for (int j = 0; j < 4; j++) {
     const int n = n0 + wn * 64 + j * 16 + fg * 4;
     if (n >= a.N) continue;                                     // N % 4 == 0: a 4-column group is in or out as a whole
-    f32x4 bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+      if (a.bias_bf16) {
+        const uint2 braw = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.bias) + n);
+        bias = f32x4{__uint_as_float(braw.x << 16), __uint_as_float(braw.x & 0xffff0000u), __uint_as_float(braw.y << 16),
+                     __uint_as_float(braw.y & 0xffff0000u)};
+      } else bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int m = m0 + wm * 64 + i * 16 + fr;
@@ -151,7 +158,7 @@ extern "C" int go1ppo_gemm_nt(const Go1PpoGemmArgs* a, void* stream) {
       ((uintptr_t)a->C & 7))
     return -2;
   if (a->epilogue == 2 && (!a->H || (a->ldh & 3) || ((uintptr_t)a->H & 7))) return -3;
-  if (a->bias && ((uintptr_t)a->bias & 15)) return -4;
+  if (a->bias && ((uintptr_t)a->bias & (a->bias_bf16 ? 7 : 15))) return -4;
   int64_t tiles = (int64_t)((a->M + GEMM_BM - 1) / GEMM_BM) * ((a->N + GEMM_BN - 1) / GEMM_BN);
   if (tiles > INT32_MAX) return -5;
   dim3 grid((unsigned)tiles), block(256);
@@ -176,9 +183,13 @@ extern "C" int go1ppo_gemm_nt(const Go1PpoGemmArgs* a, void* stream) {
 // Epilogue 1: ELU on the columns [elu_c0, elu_c1) except [elu_skip_c0, elu_skip_c1) — the actor's first-layer block, whose
 // activation needs the adaptation module's latent first (go1ppo_elu_fwd applies it afterwards).
 #define G256_T 256
+#define G256_OUT_LD 528            // bytes per row of the epilogue's LDS image of the tile (512 + 16: conflict-free 8-byte writes)
 template <int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Go1PpoGemmArgs a) {
-  __shared__ __attribute__((aligned(1024))) bf16_t lds[2][2][G256_T * GEMM_BK];   // [buffer][A|B][row][64]: 128 KB
+  // one LDS array (a second __shared__ object would make hipcc drain the LDS-DMA queue before every fragment read): the two
+  // operand buffers [buffer][A|B][row][64] (128 KB) during the main loop, the output tile's bf16 image in the epilogue
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[G256_T * G256_OUT_LD];
+  bf16_t (*lds)[2][G256_T * GEMM_BK] = reinterpret_cast<bf16_t (*)[2][G256_T * GEMM_BK]>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwg = gridDim.x, orig = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
@@ -242,11 +253,51 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Go1PpoGemmArgs a) {
   }
 
   // ---- epilogue: lane holds D[n = 4*fg + e][m = fr] of each 16 x 16 fragment
+  const bool interior = m0 + G256_T <= a.M && n0 + G256_T <= a.N && !a.bias && (a.ldc & 7) == 0 && ((uintptr_t)a.C & 15) == 0;
+  if (interior) {
+    // whole tile, no bias: the activated bf16 tile goes through LDS and leaves as 16-byte stores of whole 512-byte row segments
+    // (measured, tools/probes/gemm256_probe.hip: 8-byte stores from the fragment layout cost 25 us of the 24576 x 1280 product,
+    // and a per-fragment bounds check / bias select serialises them behind vmcnt(0) waits)
+    __syncthreads();                                            // every wave is done with the operand buffers
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int nl = wn * 64 + j * 16 + fg * 4, n = n0 + nl;
+      const bool act = EPI == 1 && n >= a.elu_c0 && n < a.elu_c1 && !(n >= a.elu_skip_c0 && n < a.elu_skip_c1);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const float x = acc[j][i][e]; v[e] = act ? elu1(x) : x; }
+        f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+        uint2 o;
+        o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2_t));
+        o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2_t));
+        *reinterpret_cast<uint2*>(smem + (wm * 128 + i * 16 + fr) * G256_OUT_LD + nl * 2) = o;
+      }
+    }
+    __syncthreads();
+    // a wave instruction moves two rows (32 lanes x 16 B each); wave w takes rows 32w .. 32w+31
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const int row = wave * 32 + t * 2 + (lane >> 5), c16 = lane & 31;
+      const uint4 v = *reinterpret_cast<const uint4*>(smem + row * G256_OUT_LD + c16 * 16);
+      *reinterpret_cast<uint4*>((bf16_t*)a.C + (int64_t)(m0 + row) * a.ldc + n0 + c16 * 8) = v;
+    }
+    return;
+  }
+  // edge tiles / bias: 8-byte stores straight from the fragments, rows and column groups masked
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int n = n0 + wn * 64 + j * 16 + fg * 4;
     if (n >= a.N) continue;                                     // N % 4 == 0: a 4-column group is in or out as a whole
-    const f32x4 bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+      if (a.bias_bf16) {
+        const uint2 braw = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.bias) + n);
+        bias = f32x4{__uint_as_float(braw.x << 16), __uint_as_float(braw.x & 0xffff0000u), __uint_as_float(braw.y << 16),
+                     __uint_as_float(braw.y & 0xffff0000u)};
+      } else bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+    }
     const bool act = EPI == 1 && n >= a.elu_c0 && n < a.elu_c1 && !(n >= a.elu_skip_c0 && n < a.elu_skip_c1);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -273,7 +324,7 @@ extern "C" int go1ppo_gemm_nt256(const Go1PpoGemmArgs* a, void* stream) {
   if ((a->K % GEMM_BK) || (a->N & 3) || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 3) || !aligned16(a->A) || !aligned16(a->B) ||
       ((uintptr_t)a->C & 7))
     return -2;
-  if (a->bias && ((uintptr_t)a->bias & 15)) return -4;
+  if (a->bias && ((uintptr_t)a->bias & (a->bias_bf16 ? 7 : 15))) return -4;
   if (a->epilogue == 1 && ((a->elu_c0 | a->elu_c1 | a->elu_skip_c0 | a->elu_skip_c1) & 3)) return -3;
   int64_t tiles = (int64_t)((a->M + G256_T - 1) / G256_T) * ((a->N + G256_T - 1) / G256_T);
   if (tiles > INT32_MAX) return -5;
@@ -351,7 +402,7 @@ __device__ __forceinline__ bf16x8_t tn_operand(const TnFrags& f, int i) {
 
 __device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf16_t* Q, int ldq, int64_t m_begin, int steps,
                                               float* C, int ldc, float* bias_grad, int N, int K, int n0, int k0,
-                                              bf16_t (*lds)[2][WTN_STEP * WTN_T]) {
+                                              bf16_t (*lds)[2][WTN_STEP * WTN_T], int zero_n, int zero_k0, int zero_k1) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // ---- staging: wave w moves row blocks (4 rows of 256 B each) 2w, 2w+1 of both operand tiles
   const bf16_t* gp[2];
@@ -456,7 +507,7 @@ __device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf
 #pragma unroll
       for (int b = 0; b < 2; b++) {
         const int k = k0 + wk * 32 + b * 16 + i16;
-        if (k < K) atomicAdd(C + (int64_t)n * ldc + k, acc[a][b][e]);
+        if (k < K && !(n < zero_n && k >= zero_k0 && k < zero_k1)) atomicAdd(C + (int64_t)n * ldc + k, acc[a][b][e]);
       }
       if (do_bias && i16 == 0) atomicAdd(bias_grad + n, bacc[a][e]);
     }
@@ -481,7 +532,7 @@ __global__ __launch_bounds__(WTN_THREADS, 1) void wgrad_tn_batched_kernel(const 
   const int64_t m_begin = (int64_t)split * P.chunk_rows;
   const int64_t m_end = m_begin + P.chunk_rows < P.rows ? m_begin + P.chunk_rows : P.rows;
   wgrad_tn_body((const bf16_t*)P.dz, P.ld_dz, (const bf16_t*)P.h, P.ld_h, m_begin, (int)((m_end - m_begin) / WTN_STEP), P.dW, P.ldw,
-                P.bias_grad, P.n, P.k, (tile / tiles_k) * WTN_T, (tile % tiles_k) * WTN_T, lds);
+                P.bias_grad, P.n, P.k, (tile / tiles_k) * WTN_T, (tile % tiles_k) * WTN_T, lds, P.zero_n, P.zero_k0, P.zero_k1);
 }
 
 extern "C" int go1ppo_wgrad_tn_plan(Go1PpoWgradProblem* probs, int count) {
@@ -490,7 +541,7 @@ extern "C" int go1ppo_wgrad_tn_plan(Go1PpoWgradProblem* probs, int count) {
   for (int i = 0; i < count; i++) {
     Go1PpoWgradProblem& P = probs[i];
     if (!P.dz || !P.h || !P.dW || P.rows <= 0 || (P.rows % WTN_STEP) || P.n < 8 || P.k < 8 || (P.n & 7) || (P.k & 7) ||
-        (P.ld_dz & 7) || (P.ld_h & 7) || !aligned16(P.dz) || !aligned16(P.h))
+        (P.ld_dz & 7) || (P.ld_h & 7) || !aligned16(P.dz) || !aligned16(P.h) || P.zero_n < 0 || P.zero_k0 < 0 || P.zero_k1 < P.zero_k0)
       return -1;
     const int64_t t = (int64_t)((P.n + WTN_T - 1) / WTN_T) * ((P.k + WTN_T - 1) / WTN_T);
     tiles += t;

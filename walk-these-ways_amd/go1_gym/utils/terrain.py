@@ -244,6 +244,16 @@ class Terrain:
         sx = cfg.border + row * cfg.length_per_env_pixels + cfg.x_offset
         sy = cfg.border + col * cfg.width_per_env_pixels
         self.height_field_raw[sx:sx + cfg.length_per_env_pixels, sy:sy + cfg.width_per_env_pixels] = terrain.height_field_raw
-        z = np.max(self.height_field_raw[sx:sx + cfg.length_per_env_pixels, sy:sy + cfg.width_per_env_pixels]) * terrain.vertical_scale
+        # spawn height of the tile.  Reference terrain.py:177: the maximum over the WHOLE tile — the 2 x 2 m centre patch of
+        # legged_gym is computed at :173-176 and left unused, so on a pit-shaped tile (inverted slope, descending stairs) a reset
+        # drops the robot from the rim's height onto the centre platform.  Mirrored as the default; the non-reference switch
+        # `terrain.origin_height_source = "centre_patch"` takes the patch instead (profiles/r04_rough_train_sanity.txt uses it to
+        # separate this spawn rule from the simulator in BASELINE configs[2]'s learning curve).
+        if getattr(cfg, "origin_height_source", "tile_max") == "centre_patch":
+            cx, cy = sx + cfg.length_per_env_pixels // 2, sy + cfg.width_per_env_pixels // 2
+            hx = max(1, int(1.0 / terrain.horizontal_scale))
+            z = np.max(self.height_field_raw[cx - hx:cx + hx, cy - hx:cy + hx]) * terrain.vertical_scale
+        else:
+            z = np.max(self.height_field_raw[sx:sx + cfg.length_per_env_pixels, sy:sy + cfg.width_per_env_pixels]) * terrain.vertical_scale
         cfg.env_origins[row, col] = [(row + 0.5) * cfg.terrain_length + cfg.x_offset * terrain.horizontal_scale,
                                      (col + 0.5) * cfg.terrain_width, z]

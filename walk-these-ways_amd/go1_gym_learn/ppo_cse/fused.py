@@ -42,7 +42,7 @@ class WgradProblem(ctypes.Structure):
     _fields_ = [("dz", ctypes.c_void_p), ("h", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("bias_grad", ctypes.c_void_p),
                 ("rows", ctypes.c_int64), ("ld_dz", ctypes.c_int32), ("ld_h", ctypes.c_int32), ("n", ctypes.c_int32),
                 ("k", ctypes.c_int32), ("ldw", ctypes.c_int32), ("chunk_rows", ctypes.c_int32), ("wg_offset", ctypes.c_int32),
-                ("_pad", ctypes.c_int32)]
+                ("zero_n", ctypes.c_int32), ("zero_k0", ctypes.c_int32), ("zero_k1", ctypes.c_int32)]
 
 
 class TailLayer(ctypes.Structure):
@@ -77,7 +77,7 @@ MLP2_DIMS = (256, 128, 64)
 class GemmArgs(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
                 ("H", ctypes.c_void_p)] + [(n, ctypes.c_int32) for n in
-                                           ("M", "N", "K", "lda", "ldb", "ldc", "ldh", "epilogue", "elu_c0", "elu_c1", "elu_skip_c0", "elu_skip_c1")]
+                                           ("M", "N", "K", "lda", "ldb", "ldc", "ldh", "epilogue", "elu_c0", "elu_c1", "elu_skip_c0", "elu_skip_c1", "bias_bf16", "_pad")]
 
 
 class _AdamTranspose(ctypes.Structure):
@@ -85,9 +85,7 @@ class _AdamTranspose(ctypes.Structure):
 
 
 class AdamExtras(ctypes.Structure):
-    _fields_ = [("frozen_start", ctypes.c_int64), ("frozen_rows", ctypes.c_int32), ("frozen_ld", ctypes.c_int32),
-                ("frozen_c0", ctypes.c_int32), ("frozen_c1", ctypes.c_int32), ("num_transposes", ctypes.c_int32), ("_pad", ctypes.c_int32),
-                ("transpose", _AdamTranspose * 2)]
+    _fields_ = [("num_transposes", ctypes.c_int32), ("_pad", ctypes.c_int32), ("transpose", _AdamTranspose * 2)]
 
 
 EXPORTED_SYMBOLS = ["go1ppo_mlp2_fwd", "go1ppo_mlp2_bwd", "go1ppo_gemm_nt", "go1ppo_gemm_nt256", "go1ppo_sum_partials", "go1ppo_wgrad_tn_plan", "go1ppo_wgrad_tn_batched", "go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
@@ -167,7 +165,8 @@ def gemm_args(a, b, c, bias=None, elu=None, elu_bwd_of=None, elu_skip=None):
     g.A, g.B, g.C, g.bias, g.H = a.data_ptr(), b.data_ptr(), c.data_ptr(), _ptr(bias), _ptr(elu_bwd_of)
     g.M, g.N, g.K, g.lda, g.ldb, g.ldc = a.shape[0], b.shape[0], a.shape[1], _ld(a), _ld(b), _ld(c)
     assert b.shape[1] == g.K and tuple(c.shape) == (g.M, g.N) and (elu is None or elu_bwd_of is None)
-    assert a.dtype == b.dtype == c.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.float32)
+    assert a.dtype == b.dtype == c.dtype == torch.bfloat16 and (bias is None or bias.dtype in (torch.float32, torch.bfloat16))
+    g.bias_bf16 = int(bias is not None and bias.dtype == torch.bfloat16)
     if elu_bwd_of is not None:
         assert elu_bwd_of.shape == c.shape and elu_bwd_of.dtype == torch.bfloat16
         g.epilogue, g.ldh = 2, _ld(elu_bwd_of)
@@ -242,6 +241,11 @@ class FusedNet:
                           and tuple(self.P[f"{n}.{self.depth[n] - 1}.W"].shape) == (MLP2_DIMS[2], MLP2_DIMS[1]) for n in self.depth)
                       and self.depth["adaptation"] == 3 and self.depth["actor"] == 4 and self.depth["critic"] == 4)
         self._mlp2_cache = {}
+        # first-layer forward on this repository's 256-tile GEMM with the ELU of the adaptation module's and the critic's blocks
+        # in its epilogue (the separate activation pass then only covers the actor's block, which waits for the latent);
+        # GO1_GEMM256=0: hipBLASLt + the full activation pass
+        self._gemm256 = os.environ.get("GO1_GEMM256", "0") == "1" and self._mlp2 and policy.Kp % 64 == 0
+        self._l1_nt = os.environ.get("GO1_L1_NT", "1") == "1"
         # the critic's tail is independent of the actor / adaptation chain: it runs on a side stream (forked from and
         # joined back into the caller's stream, so HIP-graph capture records it as a parallel branch)
         self._side = torch.cuda.Stream(device=dev) if two_streams else None
@@ -270,10 +274,6 @@ class FusedNet:
             # the K-contiguous copies are refreshed per backward pass (two transpose-copy launches) until an optimiser takes them
             # over (`adam_transposes()` -> FusedAdam.set_transposes: the step that changes the weights rewrites the copies)
             self._wt_by_optimizer = False
-            # first-layer forward on this repository's 256-tile GEMM with the ELU of the adaptation module's and the critic's blocks
-            # in its epilogue (the separate activation pass then only covers the actor's block, which waits for the latent);
-            # GO1_GEMM256=0: hipBLASLt + the full activation pass
-            self._gemm256 = os.environ.get("GO1_GEMM256", "1") == "1" and self._mlp2 and policy.Kp % 64 == 0
             # privileged-observation columns of the adaptation module's and the actor's first-layer rows: structurally zero weights
             self.priv_mask = (self.nd + self.na, policy.K + 1, policy.K + 1 + policy.npv)
 
@@ -288,16 +288,18 @@ class FusedNet:
         _chk(self.lib.go1ppo_elu_bwd(d.data_ptr(), _ld(d), _ptr(h), _ld(h) if h is not None else 0, d.shape[0], d.shape[1],
                                      _ptr(bias_grad), out.data_ptr(), _ld(out), _stream()), "go1ppo_elu_bwd")
 
-    def _wgrad(self, dz, h, gW, gb=None):
+    def _wgrad(self, dz, h, gW, gb=None, zero=None):
         """weight (+ bias) gradient of one layer.  All operands are static buffers, so the calls of a backward pass are
-        recorded once (`_plan`) and afterwards executed together as ONE batched launch at the end of the pass."""
+        recorded once (`_plan`) and afterwards executed together as ONE batched launch at the end of the pass.
+        zero = (rows, c0, c1): structural zeros of gW (Go1PpoWgradProblem) — batched launches only."""
         n, k = dz.shape[1], h.shape[1]
         assert gW.shape == (n, k) and gW.is_contiguous()
         if self._recording is not None:
-            self._recording.append((dz, h, gW, gb))
+            self._recording.append((dz, h, gW, gb, zero))
             return
         if self._batched:
             return
+        assert zero is None or zero[0] == 0, "the structural zeros are applied by the batched launch"
         _chk(self.lib.go1ppo_wgrad(dz.data_ptr(), _ld(dz), h.data_ptr(), _ld(h), dz.shape[0], n, k, gW.data_ptr(), k, _ptr(gb),
                                    _stream()), "go1ppo_wgrad")
 
@@ -412,9 +414,15 @@ class FusedNet:
             self._mlp2_fwd("adaptation", [("adaptation", self.Y1[:, :nd])])
             latent = Z["adaptation"][2]
             self._elu(self.Y1[:, nd:], latent, na)
-        with self._branch():
-            torch.addmm(P["critic.1.b"], self.Y1[:, nd + na:], P["critic.1.W"].t(), out=Z["critic"][1])
-        torch.addmm(P["actor.1.b"], self.Y1[:, nd:nd + na], P["actor.1.W"].t(), out=Z["actor"][1])
+        if self._l1_nt:
+            # the 512 -> 256 layers on go1ppo_gemm_nt (bias in the epilogue; measured 16 us against hipBLASLt's 31 at 24576 rows)
+            with self._branch():
+                gemm_nt(self.lib, self.Y1[:, nd + na:], P["critic.1.W"], Z["critic"][1], P["critic.1.b"])
+            gemm_nt(self.lib, self.Y1[:, nd:nd + na], P["actor.1.W"], Z["actor"][1], P["actor.1.b"])
+        else:
+            with self._branch():
+                torch.addmm(P["critic.1.b"], self.Y1[:, nd + na:], P["critic.1.W"].t(), out=Z["critic"][1])
+            torch.addmm(P["actor.1.b"], self.Y1[:, nd:nd + na], P["actor.1.W"].t(), out=Z["actor"][1])
         self._join()
         self._mlp2_fwd("ac", [("actor", Z["actor"][1]), ("critic", Z["critic"][1])])
         return Z["actor"][3], Z["critic"][3], latent
@@ -530,14 +538,14 @@ class FusedNet:
         """first-layer weight gradient.  own_kernel: one more problem of the batched 128-tile launch (accumulates straight
         into the fp32 gradient); otherwise one (rows x M) @ (M x Kp) bf16 hipBLASLt GEMM (the fp32-output variants it
         offers for this shape are 3x slower) and one cast into the fp32 gradient."""
+        zr, zc0, zc1 = self.priv_mask           # (gW starts at row 0 of W1: rows of the adaptation module, then the actor's)
+        zr = min(zr, gW.shape[0])
         if own_kernel:
-            self._wgrad(dY, x, gW)
+            self._wgrad(dY, x, gW, zero=(zr, zc0, zc1))
             return
         b = tmp.shape[0]
         # the partial products are summed into the fp32 gradient by go1ppo_sum_partials, which also writes the structural zeros
-        # of the privileged-observation columns (rows of the adaptation module and the actor: gW starts at row 0 of W1)
-        zr, zc0, zc1 = self.priv_mask
-        zr = min(zr, gW.shape[0])
+        # of the privileged-observation columns
         if b == 1 or not tmp.is_contiguous():
             torch.mm(dY.t(), x, out=tmp[0])
             part, count, stride = tmp[0], 1, gW.numel()
@@ -556,8 +564,10 @@ class FusedNet:
             fn()
             rec, self._recording = self._recording, None
             tab = (WgradProblem * len(rec))()
-            for P, (dz, h, gW, gb) in zip(tab, rec):
+            for P, (dz, h, gW, gb, zero) in zip(tab, rec):
                 P.dz, P.h, P.dW, P.bias_grad = dz.data_ptr(), h.data_ptr(), gW.data_ptr(), _ptr(gb)
+                if zero is not None:
+                    P.zero_n, P.zero_k0, P.zero_k1 = zero
                 P.rows, P.ld_dz, P.ld_h, P.n, P.k, P.ldw = dz.shape[0], _ld(dz), _ld(h), dz.shape[1], h.shape[1], gW.shape[1]
             tn = self._wgrad_tn and all(P.rows % 64 == 0 and P.n % 8 == 0 and P.k % 8 == 0 for P in tab)
             total = (self.lib.go1ppo_wgrad_tn_plan if tn else self.lib.go1ppo_wgrad_plan)(tab, len(rec))
@@ -746,11 +756,6 @@ class FusedAdam:
         self.n_norm = max(a + b for a, b in r)          # elements the global norm runs over (padding slots excluded)
         self.extras = AdamExtras()
         self._keep = []
-
-    def set_frozen_columns(self, start, rows, ld, c0, c1):
-        """elements [start + r * ld + c], r < rows, c0 <= c < c1: structurally zero weights (gradient discarded in the step)"""
-        e = self.extras
-        e.frozen_start, e.frozen_rows, e.frozen_ld, e.frozen_c0, e.frozen_c1 = int(start), int(rows), int(ld), int(c0), int(c1)
 
     def set_transposes(self, items):
         """items: [(start, rows, cols, dst bf16 (cols x rows) tensor)] — dst is rewritten whenever its weights are stepped"""

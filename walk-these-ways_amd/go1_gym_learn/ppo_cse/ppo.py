@@ -184,11 +184,6 @@ class PPO:
                                            ranges=[(0, pol.adaptation_numel)])
             self._lr = self._opt.lr
             self._ad_grad_views = [self.master.grad[:pol.adaptation_numel]]
-            # the privileged-observation columns of the adaptation module's and the actor's first-layer rows are structurally zero
-            # weights: both optimiser steps discard whatever gradient the augmented GEMM rows left there (no fill launches)
-            w1 = pol.offsets[pol.index["W1"]]
-            for o in (self._opt, self._opt_ad):
-                o.set_frozen_columns(w1, pol.first[0] + pol.first[1], pol.Kp, pol.K + 1, pol.K + 1 + pol.npv)
         if self.dp:                              # identical initial weights on every rank
             dist.broadcast(self.master, src=0)
         self._dp_lowp = self._dp_shard = None
@@ -431,10 +426,8 @@ class PPO:
             net.forward(net.X)
             net.ppo_loss(self.storage, idx, self.std, self.master.grad[n:n + self.n_std], PPO_Args, self._kl, self._acc)
             net.backward(net.X)
-            # (privileged-observation columns of the adaptation / actor rows: zeroed by go1ppo_sum_partials on the hipBLASLt path —
-            #  before the norm of the clip sees them —, discarded by the optimiser step in any case)
-            if net._w1_tn[0] or not net._mlp2:
-                self._priv_cols_grad.zero_()
+            # (the privileged-observation columns of the adaptation module's and the actor's first-layer rows — structurally zero
+            #  weights — receive no gradient: masked by go1ppo_sum_partials / the batched weight-gradient launch, no fill pass)
 
     def _gather_rows(self, idx, out):
         """augmented history rows of the storage entries idx into the (len(idx), Kp) buffer `out`"""
@@ -451,7 +444,6 @@ class PPO:
             net.forward_adaptation(net.X)
             net.adaptation_loss(self.storage, idx, num_train, PPO_Args.selective_adaptation_module_loss, self._acc)
             net.backward_adaptation(net.X)
-            # (no clip in this stage: the optimiser step discards the gradient of the privileged-observation columns, __init__)
 
     def _stage_ppo_backward(self, idx):
         """PPO loss forward + backward into the fp32 master gradient (reference ppo.py:112-155)."""

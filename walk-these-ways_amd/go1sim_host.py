@@ -289,6 +289,8 @@ def build_sim_config(cfg, num_envs=None, seed=0, env_id_offset=0, device_curricu
     S.tracking_sigma, S.tracking_sigma_yaw = rw.tracking_sigma, rw.tracking_sigma_yaw
     S.base_height_target, S.max_contact_force = rw.base_height_target, rw.max_contact_force
     S.kappa_gait_probs, S.gait_force_sigma, S.gait_vel_sigma = rw.kappa_gait_probs, rw.gait_force_sigma, rw.gait_vel_sigma
+    # NOT a reference field (absent = the reference's world-z reward terms): include/go1sim.h reward_heights_above_terrain
+    S.reward_heights_above_terrain = int(bool(getattr(rw, "heights_above_terrain", False)))
 
     cm = cfg.commands
     S.device_curriculum = int(device_curriculum)
