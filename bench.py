@@ -39,7 +39,7 @@ ALGORITHMIC_BYTES_PER_ENV_STEP = 3444      # 1,332 B read + 1,
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def build_env(num_envs, rank, seed, rough=False, curriculum_update_interval=None, spawn=None):
+def build_env(num_envs, rank, seed, rough=False, curriculum_update_interval=None, spawn=None, heights_above_terrain=False, sigma_rew_neg=None):
     """train.py configuration (BASELINE configs[1]); rough=True: configs[2] — the terrain curriculum's tile grid
     (slopes / rough slopes / stairs / obstacles, cfg:64-102 defaults) as a trimesh terrain (vertical risers) + the 187-point
     height scan appended to the observation (70 + 187 = 257)."""
@@ -52,6 +52,8 @@ def build_env(num_envs, rank, seed, rough=False, curriculum_update_interval=None
     cfg.env.env_id_offset = rank * num_envs
     if curriculum_update_interval is not None:
         cfg.commands.curriculum_update_interval = int(curriculum_update_interval)
+    if sigma_rew_neg is not None:                # diagnostic (tools/train_sanity.py): train.py's value is 0.02
+        cfg.rewards.sigma_rew_neg = float(sigma_rew_neg)
     if rough:
         t = cfg.terrain
         # 'trimesh' with the default slope_treshold 0.75: stair risers / obstacle sides are VERTICAL faces (terrain.py:33-36)
@@ -60,6 +62,8 @@ def build_env(num_envs, rank, seed, rough=False, curriculum_update_interval=None
         t.measure_heights = True
         if spawn is not None:                    # non-reference diagnostic switch (go1_gym/utils/terrain.py add_terrain_to_map)
             t.origin_height_source = spawn
+        if heights_above_terrain:                # non-reference: include/go1sim.h reward_heights_above_terrain
+            cfg.rewards.heights_above_terrain = True
         cfg.env.observe_heights = True
         cfg.env.num_observations = cfg.env.num_scalar_observations = 70 + 187
     env = VelocityTrackingEasyEnv(sim_device=f"cuda:{torch.cuda.current_device()}", headless=True, cfg=cfg)

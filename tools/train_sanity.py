@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="PPO_Args.use_hip_graphs = False")
     ap.add_argument("--rough", action="store_true", help="BASELINE configs[2]: terrain-curriculum tile grid as a trimesh (vertical risers) + height scan")
     ap.add_argument("--spawn", default=None, choices=["tile_max", "centre_patch"], help="with --rough: spawn height of a tile (tile_max = the reference's rule)")
+    ap.add_argument("--above-terrain", action="store_true", help="with --rough: rewards.heights_above_terrain (non-reference: foot / base heights of the reward terms above the ground)")
+    ap.add_argument("--sigma-rew-neg", type=float, default=None, help="rewards.sigma_rew_neg (train.py: 0.02): reward = positive part x exp(negative part / sigma)")
+    ap.add_argument("--save", default=None, help="write the policy (flat fp32 master parameter) to this file at the end")
     ap.add_argument("--check-finite", action="store_true", help="after every iteration: first non-finite tensor among "
                     "observations / rewards / actions / returns / parameters / gradients, then stop")
     args = ap.parse_args()
@@ -33,7 +36,7 @@ def main():
         PPO_Args.use_hip_graphs = False
     RunnerArgs.save_video_interval = 0
     torch.manual_seed(0)
-    env, cfg = build_env(args.envs, 0, 0, rough=args.rough, spawn=args.spawn)
+    env, cfg = build_env(args.envs, 0, 0, rough=args.rough, spawn=args.spawn, heights_above_terrain=args.above_terrain, sigma_rew_neg=args.sigma_rew_neg)
     per_class = None
     if args.rough:
         # terrain class of every environment's tile column (terrain.py make_terrain: choice = column / num_cols + 0.001 against the
@@ -162,6 +165,8 @@ def main():
         print(f"    {k:44s} {v:12.4f}")
     for k, v in sorted(terms.items(), key=lambda kv: -kv[1])[:4]:
         print(f"    {k:44s} {v:12.4f}")
+    if args.save:
+        torch.save(runner.alg.sync_module().state_dict(), args.save)
     if per_class is not None:
         print("per terrain class, last 100 iterations: envs | episodes ended | time-outs among them | mean episode length [steps]")
         for name, (ep, to, ln, ne) in zip(per_class["names"], per_class["stats"].tolist()):

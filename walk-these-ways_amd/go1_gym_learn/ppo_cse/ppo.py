@@ -60,6 +60,9 @@ class PPO_Args(PrefixProto):
     # node does not replay reliably (wrong gradients from the first pure replay on; DESIGN.md "HIP graphs", tools/probes/
     # graph_reduce_repro.py) — exact at the test sizes (<= 1024 rows, single-block reductions), hence still available for them.
     use_hip_graphs = True
+    dp_graph_collectives = True     # data parallel: record the RCCL collectives of a mini-batch INSIDE its HIP graph (one replay per
+                                    # mini-batch, no eager launches between graphs); if the capture fails the three-graph scheme with
+                                    # eager collectives between the graphs is used instead
     use_fused_kernels = True        # bf16 policy on a GPU: hand-scheduled forward/backward with csrc/go1ppo.hip (fused.py)
     use_tuned_gemms = True          # PyTorch TunableOp with the gfx950 table shipped in walk-these-ways_amd/tuning/
 
@@ -153,6 +156,7 @@ class PPO:
         kw = dict(fused=True, capturable=True) if self.on_gpu else {}
         self._acc = torch.zeros(4, device=device)        # value, surrogate, adaptation, adaptation-test losses
         self._idx_all, self._graphs, self._updates_done = None, {}, 0
+        self._collectives_capturable = None      # unknown until the first data-parallel capture (True / False afterwards)
         self._pregathered, self._Xall = False, None
         lr = torch.tensor(PPO_Args.learning_rate, device=device) if self.on_gpu else PPO_Args.learning_rate
         self.optimizer = optim.Adam([self.master], lr=lr, **kw)
@@ -595,6 +599,22 @@ class PPO:
         single = not self.dp and PPO_Args.num_adaptation_module_substeps == 1
         pool = None
         graphs = []
+        if self.dp and PPO_Args.dp_graph_collectives and PPO_Args.num_adaptation_module_substeps == 1 and self._collectives_capturable is not False \
+                and dist.get_backend() == "nccl":          # (RCCL records into a capturing stream; gloo stages through the host and cannot)
+            # the whole mini-batch — stages AND collectives — as one graph.  Tried once: a backend that cannot record its
+            # collectives (gloo in the CPU dry runs; an RCCL build without capture support) raises here and the scheme below takes over
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._minibatch_eager(idx)
+                self._collectives_capturable = True
+                return [g]
+            except Exception as err:
+                if self._collectives_capturable is None:
+                    print(f"[ppo] collectives not capturable ({type(err).__name__}: {str(err)[:120]}); eager collectives between graphs", file=sys.stderr)
+                self._collectives_capturable = False
+                torch.cuda.synchronize()
+                self.master.grad.zero_()
 
         def rec(fn):
             nonlocal pool
