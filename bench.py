@@ -125,6 +125,39 @@ def cpu_baseline(num_envs, target_seconds=15.0):
                       f"(oracle/go1_oracle.c, OpenMP over envs, {cores} threads = cgroup CPU quota), N(0,1) actions, {dt:.1f} s"}
 
 
+def measure_step_kernel_traffic(envs, timeout=150):
+    """HBM bytes per launch of the step kernel from THIS box's counters: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE: they do
+    not fit one pass, MI355X_MICROARCH.md) over a short `bench.py --sim-only` child; units KB, factor 1.00 for this kernel's 64-byte SoA
+    segments (calibration in profiles/r03_step_kernel_pmc.json).  Returns (bytes, description) or (None, reason): the caller falls back
+    to the committed passes."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="go1_pmc_")
+        cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+               "--sim-only", "--steps", "2", "--warmup", "1", "--envs", str(envs), "--no-cpu-baseline", "--no-traffic"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            rows = [r for f in files for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("go1_step_kernel") and r["Counter_Name"] == ctr]
+            if not rows:
+                return None, f"no {ctr} rows for go1_step_kernel"
+            vals[ctr] = sum(float(r["Counter_Value"]) for r in rows) / len(rows)
+        except Exception as err:
+            return None, f"{ctr} pass failed: {type(err).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(round((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)), (f"measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --sim-only` "
+                                                                       f"({vals['FETCH_SIZE']:.0f} + {vals['WRITE_SIZE']:.0f} KB per launch)")
+
+
 def time_sim_only(env, sim, envs, policy_steps, device, warmup=48):
     """SURVEY 8(d) metric 1: env.step alone with pre-generated N(0,1) actions; returns (env-steps/s, mean launch ms)."""
     acts = torch.randn(24, envs, 12, device=device)
@@ -222,8 +255,8 @@ def extra_records(args, env, runner, obs_dict, device):
         out["dropin_default"] = {"error": f"{type(err).__name__}: {err}"}
     try:
         from torch.cuda import tunable
-        if tunable.is_enabled():
-            tunable.tuning_enable(False)         # the 7710-wide history's GEMM shapes are not in the shipped table: hipBLASLt's default pick
+        if tunable.is_enabled() and not os.environ.get("GO1_TUNE_ALL"):
+            tunable.tuning_enable(False)         # shapes missing from the shipped table run on hipBLASLt's default pick (GO1_TUNE_ALL=1: tools/tune_gemms.sh)
         env3, _ = build_env(args.envs, 0, args.seed, rough=True)
         runner3 = Runner(env3, device=device)
         env3.episode_length_buf.copy_(torch.randint_like(env3.episode_length_buf, high=int(env3.max_episode_length)))
@@ -237,23 +270,24 @@ def extra_records(args, env, runner, obs_dict, device):
                                 "sim_ppo_env_steps_s": full, "sim_only_env_steps_s": so, "step_kernel_launch_ms": ms,
                                 "wall_instance": bool(env3.env.sim_config.hf_wall_units > 0),
                                 "guard_activations": {k: v for k, v in f3.items() if v},
-                                "note": "sim+PPO: 5 timed PPO iterations (live policy), GEMM selections untuned for the 7744-wide first layer; "
-                                        "sim only: N(0,1) actions"}
+                                "note": "sim+PPO: 5 timed PPO iterations (live policy), first-layer GEMM selections for the 7744-wide history from the "
+                                        "shipped TunableOp table (1.17 TFLOP of first-layer products per mini-batch step: the update is FLOP-bound, "
+                                        "DESIGN.md section 9); sim only: N(0,1) actions"}
         del runner3, env3
     except Exception as err:
         out["rough_trimesh"] = {"error": f"{type(err).__name__}: {err}"}
     try:
         from torch.cuda import tunable
-        if tunable.is_enabled():
-            tunable.tuning_enable(False)         # shapes of this size are not in the shipped table: use hipBLASLt's default pick
+        if tunable.is_enabled() and not os.environ.get("GO1_TUNE_ALL"):
+            tunable.tuning_enable(False)         # shapes missing from the shipped table run on hipBLASLt's default pick
         env8, _ = build_env(8192, 0, args.seed)
         runner8 = Runner(env8, device=device)
         env8.episode_length_buf.copy_(torch.randint_like(env8.episode_length_buf, high=int(env8.max_episode_length)))
         od8 = env8.get_observations()
         full, od8 = time_iterations(runner8, env8, od8, 5, warmup=3)
         so, ms = time_sim_only(env8, env8.env.sim, 8192, 240, device)
-        out["envs_8192"] = {"workload": "per-GPU size of BASELINE configs[4]: 8192 envs, train.py configuration, one GPU; GEMM "
-                                        "selections untuned for this batch size", "env_steps_s": full, "sim_only_env_steps_s": so,
+        out["envs_8192"] = {"workload": "per-GPU size of BASELINE configs[4]: 8192 envs, train.py configuration, one GPU; first-layer GEMM "
+                                        "selections from the shipped TunableOp table", "env_steps_s": full, "sim_only_env_steps_s": so,
                             "step_kernel_launch_ms": ms}
         del runner8, env8
     except Exception as err:
@@ -279,6 +313,8 @@ def main():
     ap.add_argument("--zero1", action="store_true", help="N > 1: reduce-scatter + sharded optimiser step + all-gather (PPO_Args.dp_zero1)")
     ap.add_argument("--breakdown", action="store_true", help="diagnostic: print rollout/update split to stderr (adds syncs)")
     ap.add_argument("--headline-only", action="store_true", help="skip the extra single-GPU records (rates, height field, 8192 envs)")
+    ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the step kernel's HBM traffic "
+                                                              "(roofline.traffic then comes from the committed passes in profiles/)")
     ap.add_argument("--curriculum-interval", type=int, default=1,
                     help="commands.curriculum_update_interval K: 1 = the reference's per-step curriculum update (curriculum.py) at EVERY rank count, so "
                          "that the 1-GPU headline and the N-GPU scaling numbers run the same algorithm; K > 1 coalesces the sharded run's "
@@ -419,7 +455,7 @@ def main():
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         valu_insts = None
         traffic, traffic_src = None, None   # HBM bytes per launch: NOT measured by this run — read from the committed PMC passes
-        for name in ("r03_step_kernel_pmc.json", "r02_step_kernel_pmc.json", "r01_step_kernel_pmc.json"):
+        for name in ("r04_step_kernel_pmc.json", "r03_step_kernel_pmc.json", "r02_step_kernel_pmc.json", "r01_step_kernel_pmc.json"):
             try:
                 with open(os.path.join(REPO, "profiles", name)) as f:
                     pmc = json.load(f)
@@ -430,6 +466,12 @@ def main():
                 break
             except (OSError, KeyError, ValueError):
                 continue
+        if world == 1 and not args.no_traffic and not args.headline_only and not (args.sim_only or args.rollout_only) and args.envs == 4096:
+            measured, how = measure_step_kernel_traffic(args.envs)
+            if measured is not None:
+                traffic, traffic_src = measured, how
+            else:
+                traffic_src = f"{traffic_src}; live measurement unavailable ({how})"
         # what the kernel IS bound by: vector-ALU issue of the master wavefronts.  Wave-level VALU instructions (committed PMC pass)
         # x 64 lanes over this run's launch time, against the fp32 vector rate (157.3 TFLOP/s = 78.6 T lane-FMAs/s,
         # MI355X_MICROARCH.md) — an issue-slot fraction, not a FLOP count (moves, compares and selects occupy slots too)

@@ -198,6 +198,11 @@ int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t start0, int6
                     float beta1, float beta2, float eps, void* body, int64_t n_body, float* tail, int64_t n_tail, int zero_grad,
                     float* zero_slot, const Go1PpoAdamExtras* extras, void* stream);
 
+/* out[r][q] (bf16, row stride ld_out; the columns >= npv are not touched) = sum_n d[r][n] * wz[n][q], q < npv <= 8: gradient w.r.t. the
+ * latent that enters the actor's first layer beside the history (actor_critic.py:58-61).  n % 8 == 0, d 16-byte aligned. */
+int go1ppo_latent_dgrad(const void* d, int ld_d, int64_t rows, int n, const void* wz, int wz_ld, int npv, void* out, int ld_out,
+                        void* stream);
+
 /* out[r][c] (fp32, rows x cols contiguous) = sum over b < count of partials[b * stride + r * cols + c] (bf16) — the row-chunk
  * partial products of the first-layer weight gradient (a manual split-K over hipBLASLt's batched GEMM) summed into the flat
  * gradient; the columns [zero_c0, zero_c1) of the first zero_rows rows are written as exact zeros (the structural zeros of

@@ -315,6 +315,24 @@ def test_adam_keeps_transposed_copies(lib):
     assert torch.equal(d0, keep)
 
 
+@pytest.mark.parametrize("rows,n,npv", [(24576, 512, 2), (1001, 512, 2), (300, 1024, 5), (7, 64, 1)])
+def test_latent_dgrad_matches_fp32_matmul(lib, rows, n, npv):
+    """go1ppo_latent_dgrad: d (rows x n, a column block of a wider matrix) times the first npv columns of wz — the autograd gradient of
+    `torch.cat((obs_history, latent))`'s latent part through actor_body[0] (actor_critic.py:58-61) — vs the fp32 product, 1 bf16 ulp;
+    the columns behind npv keep what they held."""
+    g = torch.Generator(device="cuda").manual_seed(rows + n)
+    wide = bf(torch.randn(rows, n + 256, device="cuda", generator=g))
+    d = wide[:, 128:128 + n]
+    wz = bf(torch.randn(n, 64, device="cuda", generator=g) / n ** 0.5)
+    out = torch.full((rows, 64), 3.0, device="cuda", dtype=torch.bfloat16)
+    assert lib.go1ppo_latent_dgrad(d.data_ptr(), d.stride(0), rows, n, wz.data_ptr(), 64, npv, out.data_ptr(), 64, stream()) == 0
+    torch.cuda.synchronize()
+    ref = d.float() @ wz[:, :npv].float()
+    assert bool((out[:, npv:] == 3.0).all())
+    err = (out[:, :npv].float() - ref).abs()
+    assert bool((err <= 2 ** -8 * ref.abs() + 2e-3).all()), float(err.max())
+
+
 @pytest.mark.parametrize("tn", [True, False])
 def test_batched_weight_gradient_structural_zeros(lib, tn):
     """Go1PpoWgradProblem.zero_*: the masked block of dW receives NOTHING (it keeps the value the buffer held), every other element is the
@@ -769,7 +787,9 @@ def test_fused_graph_replay_equals_eager_at_production_size():
         ee = float((a[u][0] - a2[u][0]).abs().max())
         ge = float((a[u][0] - b[u][0]).abs().max())
         assert ge <= 3.0 * ee + 1e-3, (u, ge, ee)      # (both are maxima over 3 M Adam-amplified last-bit differences: 1-3e-3 each)
-        np.testing.assert_allclose(b[u][1][:3], a[u][1][:3], rtol=1e-3)
+        # (losses: the surrogate is a difference of O(1) terms around -0.04 — two EAGER runs differ by ~4e-5 there, the atomics' order)
+        spread = np.abs(np.asarray(a[u][1][:3]) - np.asarray(a2[u][1][:3]))
+        np.testing.assert_allclose(b[u][1][:3], a[u][1][:3], rtol=1e-3, atol=float(3.0 * spread.max() + 1e-4))
         assert b[u][2] == pytest.approx(a[u][2], rel=1e-5)
 
 

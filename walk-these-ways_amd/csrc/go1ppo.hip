@@ -213,6 +213,9 @@ __device__ __forceinline__ void block_reduce_atomic(float (&v)[NV], float* const
 __global__ __launch_bounds__(256) void loss_kernel(Go1PpoLossArgs a) {
   __shared__ float lds[4 * (4 + 2 * GO1PPO_MAX_ACTIONS)];
   const int A = a.num_actions;
+  const bool vec4 = (A & 3) == 0 && (a.head_ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.actions) | reinterpret_cast<uintptr_t>(a.old_mu) |
+                                                              reinterpret_cast<uintptr_t>(a.old_sigma)) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.mean) & 7) == 0;
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool on = r < a.rows;
   float invM = 1.f / (float)a.rows;
@@ -224,17 +227,39 @@ __global__ __launch_bounds__(256) void loss_kernel(Go1PpoLossArgs a) {
     int64_t s = a.idx[r];
     const bf16_t* mrow = reinterpret_cast<const bf16_t*>(a.mean) + r * a.head_ld;
     float mu[GO1PPO_MAX_ACTIONS], z[GO1PPO_MAX_ACTIONS], isg[GO1PPO_MAX_ACTIONS];
+    float act[GO1PPO_MAX_ACTIONS], omu[GO1PPO_MAX_ACTIONS], osg[GO1PPO_MAX_ACTIONS];
     float logp = 0.f;
     const float HALF_LOG_2PI = 0.9189385332046727f;
+    if (vec4) {
+      // the storage rows of a sample (A fp32 each, A % 4 == 0: 16-byte aligned) and its bf16 head row as 16 / 8-byte gathers: a wave's
+      // 64 samples are 64 different cache lines per load instruction, so the instruction COUNT (4 per element-wise load) is what the
+      // texture path's time goes with
+#pragma unroll
+      for (int j = 0; j < GO1PPO_MAX_ACTIONS; j += 4) {
+        if (j < A) {
+          const f32x4 va = *reinterpret_cast<const f32x4*>(a.actions + s * A + j), vm = *reinterpret_cast<const f32x4*>(a.old_mu + s * A + j),
+                      vs = *reinterpret_cast<const f32x4*>(a.old_sigma + s * A + j);
+          const uint2 mr = *reinterpret_cast<const uint2*>(mrow + j);
+          mu[j] = __uint_as_float(mr.x << 16); mu[j + 1] = __uint_as_float(mr.x & 0xffff0000u);
+          mu[j + 2] = __uint_as_float(mr.y << 16); mu[j + 3] = __uint_as_float(mr.y & 0xffff0000u);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { act[j + e] = va[e]; omu[j + e] = vm[e]; osg[j + e] = vs[e]; }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < GO1PPO_MAX_ACTIONS; j++) {
+        if (j < A) { mu[j] = bf2f(mrow[j]); act[j] = a.actions[s * A + j]; omu[j] = a.old_mu[s * A + j]; osg[j] = a.old_sigma[s * A + j]; }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < GO1PPO_MAX_ACTIONS; j++) {
       if (j < A) {
         float sg = a.std[j];
-        mu[j] = bf2f(mrow[j]);
         isg[j] = 1.f / sg;
-        z[j] = (a.actions[s * A + j] - mu[j]) * isg[j];
+        z[j] = (act[j] - mu[j]) * isg[j];
         logp += -0.5f * z[j] * z[j] - logf(sg) - HALF_LOG_2PI;
-        float so = a.old_sigma[s * A + j], dm = a.old_mu[s * A + j] - mu[j];
+        float so = osg[j], dm = omu[j] - mu[j];
         kl += logf(sg / so + 1.e-5f) + (so * so + dm * dm) / (2.f * sg * sg) - 0.5f;
       }
     }
@@ -596,6 +621,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m,
   const int64_t total = count0 + count1;
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total; j += (int64_t)gridDim.x * 256) {
     const int64_t i = j < count0 ? start0 + j : start1 + (j - count0);
+    // (block-uniform) can any element of this 256-element chunk belong to a transposed block?  first / last element index of the chunk
+    const int64_t j0 = j - threadIdx.x, j1 = j0 + 255 < total ? j0 + 255 : total - 1;
+    const int64_t i0 = j0 < count0 ? start0 + j0 : start1 + (j0 - count0), i1 = j1 < count0 ? start0 + j1 : start1 + (j1 - count0);
+    bool tr_chunk = false;
+#pragma unroll
+    for (int t = 0; t < GO1PPO_ADAM_MAX_TRANSPOSES; t++)
+      if (t < ex.num_transposes) {
+        const int64_t ts = ex.transpose[t].start, te = ts + (int64_t)ex.transpose[t].rows * ex.transpose[t].cols;
+        tr_chunk = tr_chunk || (j0 < count0) != (j1 < count0) || (i0 < te && i1 >= ts);
+      }
     const float gi = g[i] * gs;
     if (zero_grad) g[i] = 0.f;          // the next backward pass accumulates into a clean gradient: no separate fill pass
 
@@ -612,7 +647,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m,
       // instead of by a transpose-copy launch per backward pass
 #pragma unroll
       for (int t = 0; t < GO1PPO_ADAM_MAX_TRANSPOSES; t++) {
-        if (t < ex.num_transposes) {
+        if (tr_chunk && t < ex.num_transposes) {
           const uint64_t off = (uint64_t)(i - ex.transpose[t].start);
           const uint32_t rows = (uint32_t)ex.transpose[t].rows, cols = (uint32_t)ex.transpose[t].cols;
           if (off < (uint64_t)rows * cols) {
@@ -1032,6 +1067,56 @@ extern "C" int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t s
   if (blocks > 2048) blocks = 2048;
   adam_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, start0, count0, start1, count1, gscale, partial,
                                                                              max_norm, step, lr, beta1, beta2, eps, (bf16_t*)body, n_body, tail, n_tail, zero_grad, zero_slot, ex);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+// ---------------------------------------------------------------------------------------------- latent input gradient
+// out[r][q] (bf16) = sum_n d[r][n] * wz[n][q], q < npv <= 8: the gradient w.r.t. the latent the actor's first layer received beside the
+// history (actor_critic.py:58-61: actor_body(cat(obs_history, latent))): a (rows x n) x (n x npv) product with npv = 2 — one pass over
+// d at streaming rate instead of a 64-column padded GEMM.  One wavefront per row: lane l holds the columns 8 l + 512 c.
+__global__ __launch_bounds__(256) void latent_dgrad_kernel(const bf16_t* __restrict__ d, int ld_d, int64_t rows, int n, const bf16_t* __restrict__ wz,
+                                                           int wz_ld, int npv, bf16_t* __restrict__ out, int ld_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = wave * 4; r0 < rows; r0 += nwaves * 4) {            // four rows per turn: four independent loads in flight
+    float acc[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int q = 0; q < 8; q++) acc[u][q] = 0.f;
+    for (int c0 = lane * 8; c0 < n; c0 += 512) {
+      Bf8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (r0 + u < rows) v[u] = *reinterpret_cast<const Bf8*>(d + (r0 + u) * ld_d + c0);
+      for (int q = 0; q < npv; q++) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float w = bf2f(wz[(int64_t)(c0 + e) * wz_ld + q]);
+#pragma unroll
+          for (int u = 0; u < 4; u++) acc[u][q] = fmaf(bf2f(v[u].v[e]), w, acc[u][q]);
+        }
+      }
+    }
+    for (int q = 0; q < npv; q++) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        float s = acc[u][q];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0 && r0 + u < rows) out[(r0 + u) * ld_out + q] = f2bf(s);
+      }
+    }
+  }
+}
+
+extern "C" int go1ppo_latent_dgrad(const void* d, int ld_d, int64_t rows, int n, const void* wz, int wz_ld, int npv, void* out, int ld_out,
+                                   void* stream) {
+  if (!d || !wz || !out || rows <= 0 || n <= 0 || (n & 7) || (ld_d & 7) || npv <= 0 || npv > 8 || wz_ld < npv || ld_out < npv || !aligned16(d))
+    return -1;
+  int64_t blocks = (rows + 15) / 16;
+  if (blocks > 2048) blocks = 2048;
+  latent_dgrad_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)d, ld_d, rows, n, (const bf16_t*)wz, wz_ld, npv,
+                                                                                   (bf16_t*)out, ld_out);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 

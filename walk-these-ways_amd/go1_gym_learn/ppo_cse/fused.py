@@ -88,7 +88,7 @@ class AdamExtras(ctypes.Structure):
     _fields_ = [("num_transposes", ctypes.c_int32), ("_pad", ctypes.c_int32), ("transpose", _AdamTranspose * 2)]
 
 
-EXPORTED_SYMBOLS = ["go1ppo_mlp2_fwd", "go1ppo_mlp2_bwd", "go1ppo_gemm_nt", "go1ppo_gemm_nt256", "go1ppo_sum_partials", "go1ppo_wgrad_tn_plan", "go1ppo_wgrad_tn_batched", "go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
+EXPORTED_SYMBOLS = ["go1ppo_mlp2_fwd", "go1ppo_mlp2_bwd", "go1ppo_gemm_nt", "go1ppo_gemm_nt256", "go1ppo_sum_partials", "go1ppo_latent_dgrad", "go1ppo_wgrad_tn_plan", "go1ppo_wgrad_tn_batched", "go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
                     "go1ppo_wgrad_batched", "go1ppo_act",
                     "go1ppo_store_step", "go1ppo_ring_snapshot", "go1ppo_ring_step", "go1ppo_ring_gather", "go1ppo_gae", "go1ppo_normalize", "go1ppo_opt_partials", "go1ppo_opt_prestep",
                     "go1ppo_opt_adam", "go1ppo_version"]
@@ -115,6 +115,7 @@ def load_library(path=None):
     L.go1ppo_gemm_nt.argtypes = [ctypes.POINTER(GemmArgs), vp]
     L.go1ppo_gemm_nt256.argtypes = [ctypes.POINTER(GemmArgs), vp]
     L.go1ppo_sum_partials.argtypes = [vp, i32, i64, i64, i32, vp, i32, i32, i32, vp]
+    L.go1ppo_latent_dgrad.argtypes = [vp, i32, i64, i32, vp, i32, i32, vp, i32, vp]
     L.go1ppo_mlp2_fwd.argtypes = [ctypes.POINTER(Mlp2Fwd), i32, vp]
     L.go1ppo_mlp2_bwd.argtypes = [ctypes.POINTER(Mlp2Bwd), i32, vp]
     L.go1ppo_wgrad_batched.argtypes = [vp, i32, i32, vp]
@@ -457,7 +458,9 @@ class FusedNet:
         latent, dlat = Z["adaptation"][2], dZ["adaptation"][2]
         dA1 = dY1[:, cols["actor"]]
         self._wgrad(dA1, latent, G["Wz"])
-        torch.mm(dA1, P["Wz"], out=dlat)
+        # dlat = dA1 Wz: two useful columns — one streaming pass instead of a 64-column padded GEMM (the other columns of dlat stay 0)
+        _chk(self.lib.go1ppo_latent_dgrad(dA1.data_ptr(), _ld(dA1), dA1.shape[0], dA1.shape[1], P["Wz"].data_ptr(), HEAD, self.pol.npv,
+                                          dlat.data_ptr(), _ld(dlat), _stream()), "go1ppo_latent_dgrad")
         self._mlp2_bwd("adaptation", [("adaptation", Y1[:, :nd], dY1[:, :nd])])
         self._wgrad(dlat, Z["adaptation"][1], G["adaptation.2.W"], G["adaptation.2.b"])
         self._wgrad(dZ["adaptation"][1], Y1[:, :nd], G["adaptation.1.W"], G["adaptation.1.b"])
