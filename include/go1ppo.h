@@ -198,11 +198,6 @@ int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t start0, int6
                     float beta1, float beta2, float eps, void* body, int64_t n_body, float* tail, int64_t n_tail, int zero_grad,
                     float* zero_slot, const Go1PpoAdamExtras* extras, void* stream);
 
-/* out[r][q] (bf16, row stride ld_out; the columns >= npv are not touched) = sum_n d[r][n] * wz[n][q], q < npv <= 8: gradient w.r.t. the
- * latent that enters the actor's first layer beside the history (actor_critic.py:58-61).  n % 8 == 0, d 16-byte aligned. */
-int go1ppo_latent_dgrad(const void* d, int ld_d, int64_t rows, int n, const void* wz, int wz_ld, int npv, void* out, int ld_out,
-                        void* stream);
-
 /* out[r][c] (fp32, rows x cols contiguous) = sum over b < count of partials[b * stride + r * cols + c] (bf16) — the row-chunk
  * partial products of the first-layer weight gradient (a manual split-K over hipBLASLt's batched GEMM) summed into the flat
  * gradient; the columns [zero_c0, zero_c1) of the first zero_rows rows are written as exact zeros (the structural zeros of
@@ -224,11 +219,6 @@ typedef struct Go1PpoGemmArgs {
   int32_t bias_bf16, _pad;               /* bias_bf16 != 0: `bias` points to bf16 values (the compute copy of the parameters) */
 } Go1PpoGemmArgs;
 int go1ppo_gemm_nt(const Go1PpoGemmArgs* args, void* stream);
-
-/* The same product (epilogues 0 and 1) on 256 x 256 output tiles, one 8-wavefront workgroup per CU: the first layer of the
- * update, X (24576 x 2112) W1^T (1280 x 2112) -> Y1 with nn.ELU (actor_critic.py:44-47, 58-61, 79-82) applied to the
- * adaptation module's and the critic's column blocks on the way out (elu ranges multiples of 4). */
-int go1ppo_gemm_nt256(const Go1PpoGemmArgs* args, void* stream);
 
 /* the same weight gradients on 128 x 128 tiles (LDS-DMA staging, hardware transpose reads): what the first-layer
  * gradients (n = 256 .. 1280, k = 2112) and the batched tails use.  Same problem table as go1ppo_wgrad_plan /

@@ -32,7 +32,7 @@ _RUN_LATE = ("test_two_rank", "test_ppo_learns_on_the_hip_simulator", "test_free
 # cases added after the last run on hardware (validated through the emulated kernel only) go behind everything proven.  Round 3: every
 # `-m gpu` test has passed on an MI355X (145 tests, gpurun calls 18-20); what stays last is the longest statistical one
 # (2500 PPO iterations + a play-flow evaluation, ~75 s)
-_RUN_LAST = ("test_play_eval",)
+_RUN_LAST = ("test_play_eval", "test_rough_terrain_training", "test_unchanged_train_script")
 
 
 def _rank(nodeid):

@@ -255,6 +255,32 @@ def test_unchanged_train_script_configuration_clears_one_million_env_steps_per_s
         RunnerArgs.save_interval, RunnerArgs.log_freq, RunnerArgs.save_video_interval = old
 
 
+def test_rough_terrain_training_survives_once_the_flat_ground_assumptions_are_lifted():
+    """BASELINE configs[2] (terrain-curriculum tile grid as a `trimesh` terrain + 187-point height scan) under scripts/train.py's reward
+    set does not learn — in the reference either, for three reasons that are the REFERENCE's, not the simulator's (DESIGN.md section 9,
+    profiles/r04_rough_train_sanity.txt): tiles spawn at their rim height (terrain.py:177), the foot-clearance / jump / contact-velocity
+    terms read world z (corl_rewards.py:129 `# - reference_heights`), and reward = positive x exp(negative / 0.02) is identically 0
+    while robots still fall.  With the three lifted by flagged, non-default switches (centre-patch spawn, heights above the terrain,
+    sigma_rew_neg = 1) 500 PPO iterations on the WALLS instance of the step kernel must show what the simulator owes: robots that stay
+    up on every tile class — time-outs instead of falls —, a non-zero reward, and no simulator fault."""
+    import re
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "tools", "train_sanity.py"), "--rough", "--spawn", "centre_patch", "--above-terrain",
+                          "--sigma-rew-neg", "1.0", "--iters", "500", "--every", "100"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [l for l in out.stdout.splitlines() if l.startswith("it ")]
+    assert len(rows) == 5, out.stdout[-2000:]
+    last = rows[-1]
+    rew = float(re.search(r"mean step reward\s+([-\d.]+)", last).group(1))
+    to = float(re.search(r"time-outs/resets\s+([\d.]+)", last).group(1))
+    ep = float(re.search(r"mean ep len\s+([\d.]+)", last).group(1))
+    fatal = sum(int(re.search(r"fatal (\d+)", l).group(1)) for l in rows)
+    print(last)
+    # measured (r4c12): reward 0.0059, time-outs / resets 0.42, mean episode length 579 at iteration 500; reference settings: 0.0000 / 0.03 / 117
+    assert rew > 0.003 and to > 0.25 and ep > 350 and fatal == 0, last
+
+
 def test_teacher_student_runner_on_the_hip_env(tmp_path):
     """the older go1_gym_learn.ppo runner (privileged-latent teacher + adaptation-module student, plain PyTorch) drives the
     same HIP environment: two iterations, checkpoint / TorchScript export under the reference's file names."""

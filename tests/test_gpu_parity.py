@@ -12,9 +12,10 @@ ATTRIBUTED, in one of three checkable ways (a step attributed to precision alone
   (c) the kernel reproduces, within the tolerances, the fp32 BUILD OF THE ORACLE run beside the fp64 one on the same inputs (a
       decision both fp32 evaluations take the same way and fp64 the other, e.g. the termination threshold on the base height):
       no bound applies — the kernel IS a valid fp32 evaluation of the restatement there;
-  (b) precision: the fp32 build of the oracle (oracle/_build/libgo1oracle32.so, the same restatement with real = float), run on
-      the same inputs beside the fp64 one, uses up a twentieth of a tolerance itself in that environment-step (its median is
-      0.3 %) AND comes within a factor 25 of the kernel's error (RULE_B_*, with the measurements they come from): the state is ill-conditioned in
+  (b) precision: the CONDITIONING of the environment-step — the larger of (i) the error of the fp32 build of the oracle
+      (oracle/_build/libgo1oracle32.so, the same restatement with real = float) run beside the fp64 one and (ii), in the full-step runs,
+      what perturbing the fp64 oracle's inputs by one fp32 ulp does to its own result (ShadowPert, three draws) — uses up a twentieth of a
+      tolerance (the median of (i) is 0.3 %) AND comes within a factor 25 of the kernel's error (RULE_B_*): the state is ill-conditioned in
       fp32 (deep interpenetration with kilonewton impulses, a non-converged 20-contact solve), whoever computes it.  (In bulk
       the kernel's error equals the fp32 oracle's — finish() prints the ratio of the medians, 0.8-1.0 on the MI355X, and the
       99 % quantiles coincide; in an ill-conditioned step the two are different draws from a heavy-tailed amplification of two
@@ -67,6 +68,42 @@ class Shadow32:
                 self.B.tensors[k].copy_(t)
         c, o = self.orc.ctr, self.o.ctr
         o.common_step_counter, o.lag_head, o.history_slot = c.common_step_counter, c.lag_head, c.history_slot
+
+
+class ShadowPert:
+    """Conditioning probe: K copies of the fp64 oracle stepping from the same (re-synchronised) inputs PERTURBED BY ONE FP32 ULP
+    (root state, joint positions and rates times 1 + 2^-23 U(-1, 1), fixed seeds).  In a well-conditioned environment-step the outputs move
+    by 1e-5 (1e-3 of a tolerance); where the step hides a discrete decision — a leg-leg contact between nearly parallel capsules, an
+    impact on a speculative contact — they move by whole tolerances, whatever arithmetic evaluates it: measured on the two states the
+    hardware kernel left a tolerance in with identical contact and active sets while the fp32 oracle stayed inside (hf run, env 2413
+    step 12: 0.08 rad/s = x4 the joint-rate tolerance; env 2320 step 25: 0.011 rad/s base rate = x3.5), 2e-5 on an ordinary state."""
+
+    def __init__(self, S, Bc, orc, draws=3, seed=77):
+        import pyoracle
+        self.Bc, self.orc = Bc, orc
+        self.B = [Bc.clone_to("cpu") for _ in range(draws)]
+        self.o = [pyoracle.Oracle(S, B) for B in self.B]
+        self.g = torch.Generator().manual_seed(seed)
+        self.sync()
+
+    def set_eval_config(self, S_eval, num_train):
+        for o in self.o:
+            o.set_eval_config(S_eval, num_train)
+
+    def sync(self):
+        for B, o in zip(self.B, self.o):
+            for k, t in self.Bc.tensors.items():
+                if t is not None and B.tensors.get(k) is not None:
+                    B.tensors[k].copy_(t)
+            for k in ("root_states", "dof_pos", "dof_vel"):
+                t = B.tensors[k]
+                t.mul_(1.0 + (torch.rand(t.shape, generator=self.g) * 2.0 - 1.0) * 2.0 ** -23)
+            c = self.orc.ctr
+            o.ctr.common_step_counter, o.ctr.lag_head, o.ctr.history_slot = c.common_step_counter, c.lag_head, c.history_slot
+
+    def step(self, a):
+        for o in self.o:
+            o.step(a)
 
 
 def to_gpu(S, Bc, product=False):
@@ -147,8 +184,8 @@ class Attribution:
 
     def __init__(self, N, residual=(0, 0.0)):
         """residual = (count, bound): at most `count` environment-steps of the whole run may stay UNEXPLAINED — outside a tolerance by at
-        most `bound` x, none of the rules applying — instead of failing at the first one.  (0, 0) everywhere except the 4096-environment
-        relief runs of test_product_instances_match_oracle, whose docstring states the measurement behind its (3, 3.0)."""
+        most `bound` x, none of the rules applying — instead of failing at the first one.  (0, 0) in every test of this file: nothing
+        unexplained is admitted (the mechanism exists for investigations: tools/debug/hf_env_replay.py grew out of one)."""
         self.N, self.env_steps, self.bad, self.attributed, self.worst_ratio, self.worst_unattr = N, 0, 0, 0, 0.0, 0.0
         self.r_all, self.r32_all = [], []
         self.note = ""
@@ -163,7 +200,7 @@ class Attribution:
             return r.reshape(self.N, -1).max(1).values.cpu()
         return r.reshape(-1, self.N).max(0).values.cpu()
 
-    def step(self, ratio_fn, Bg, Bc, B32=None, reset_key=None, also_attributed=None, twin=None):
+    def step(self, ratio_fn, Bg, Bc, B32=None, reset_key=None, also_attributed=None, twin=None, pert=None):
         """ratio_fn(Bx, Bref) -> (N,) worst error / tolerance of every environment this step; B32: the fp32 oracle's buffers;
         reset_key: a buffer whose mismatch (termination decided differently) puts the environment outside the tolerances;
         twin = (Bt, identical): Bg carries no signature (a product instance) — rule (a) reads the record of the `_sig` twin Bt for
@@ -187,6 +224,12 @@ class Attribution:
             # (c): the kernel REPRODUCES the fp32 oracle within the tolerances (a decision both fp32 evaluations take the same
             # way and fp64 the other — e.g. a termination threshold): no bound on how far that is from the fp64 result
             ratio32 = ratio_fn(B32, Bc)
+            if pert is not None:                   # conditioning of the step itself (ShadowPert): the larger of the fp32 oracle's error and of
+                for Bp in pert.B:                  # what one-ulp input perturbations do to the fp64 oracle's own result
+                    rp = ratio_fn(Bp, Bc)
+                    if reset_key is not None:      # (a termination decided differently under the perturbation: a threshold sits here)
+                        rp = torch.where(Bp.tensors[reset_key].bool() != Bc.tensors[reset_key].bool(), torch.full_like(rp, 1e3), rp)
+                    ratio32 = torch.maximum(ratio32, rp)
             same32 = ratio_fn(Bg, B32) <= 1.0
             if reset_key is not None:
                 same32 = same32 & (Bg.tensors[reset_key].cpu().bool() == B32.tensors[reset_key].bool())
@@ -365,6 +408,7 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
         prepare(S, Bc)
     pp.sync() if product else sync_from(Bc, Bg, sim, orc)
     sh = Shadow32(S, Bc, orc)
+    sp = ShadowPert(S, Bc, orc)
     resets = 0
     resamples = 0
     timeouts = 0
@@ -378,6 +422,7 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
             watch(S, Bc, "before")
         orc.step(a)
         sh.o.step(a)
+        sp.step(a)
         twin = None
         if product:
             twin = pp.step(torch.from_numpy(a).cuda())
@@ -386,7 +431,7 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
             torch.cuda.synchronize()
         cpu_reset = Bc.reset_buf.bool()
         np.testing.assert_array_equal(Bg.time_out_buf.cpu().numpy(), Bc.time_out_buf.numpy())
-        bad_env = att.step(make_ratio(att, FULL_STEP_TOL, ROW_TOL), Bg, Bc, sh.B, reset_key="reset_buf", twin=twin)
+        bad_env = att.step(make_ratio(att, FULL_STEP_TOL, ROW_TOL), Bg, Bc, sh.B, reset_key="reset_buf", twin=twin, pert=sp)
         timeouts += int(Bc.time_out_buf.sum())
         np.testing.assert_array_equal(Bg.env_command_bins.cpu().numpy()[~bad_env.numpy()], Bc.env_command_bins.numpy()[~bad_env.numpy()])
         np.testing.assert_allclose(Bg.curriculum_weights.cpu().numpy(), Bc.curriculum_weights.numpy(), atol=0.21 * float(bad_env.sum()) + 1e-6)
@@ -399,6 +444,7 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
                 assert not bool(bad[..., ~bad_env].any()), k
         pp.sync() if product else sync_from(Bc, Bg, sim, orc)
         sh.sync()
+        sp.sync()
     assert int(Bg.fault_counts[:10].sum()) == 0, Bg.fault_counts.tolist()
     att.note = pp.note() if product else ""
     att.finish(f"{what} [{variant}, {N} envs x {steps} steps]")
@@ -641,6 +687,7 @@ def run_height_field_comparison(walls, N=256, steps=40, product=False, residual=
     Bg, sim = (pp.Bg, pp.sim) if product else to_gpu(S, Bc)
     pp.sync() if product else sync_from(Bc, Bg, sim, orc)
     sh = Shadow32(S, Bc, orc)
+    sp = ShadowPert(S, Bc, orc)
     rng = np.random.default_rng(0)
     resets = 0
     att = Attribution(N, residual)
@@ -648,6 +695,7 @@ def run_height_field_comparison(walls, N=256, steps=40, product=False, residual=
         a = (rng.standard_normal((N, 12)) * (1.0 if step % 2 else 0.3)).astype(np.float32)
         orc.step(a)
         sh.o.step(a)
+        sp.step(a)
         twin = None
         if product:
             twin = pp.step(torch.from_numpy(a).cuda())
@@ -662,10 +710,11 @@ def run_height_field_comparison(walls, N=256, steps=40, product=False, residual=
         core = make_ratio(att, keys[:-1])(Bg, Bc)
         prop = att.ratio(Bg.obs_buf[:, :70].contiguous(), Bc.obs_buf[:, :70].contiguous(), 5e-3, 1e-3, env_dim=0)
         scan_flip = (scan_pts > 0) & (scan_pts <= 4) & (core <= 1.0) & (prop <= 1.0)
-        att.step(make_ratio(att, keys, (("obs_buf", 5e-3, 1e-3),)), Bg, Bc, sh.B, reset_key="reset_buf", also_attributed=scan_flip, twin=twin)
+        att.step(make_ratio(att, keys, (("obs_buf", 5e-3, 1e-3),)), Bg, Bc, sh.B, reset_key="reset_buf", also_attributed=scan_flip, twin=twin, pert=sp)
         resets += int(cpu_reset.sum())
         pp.sync() if product else sync_from(Bc, Bg, sim, orc)
         sh.sync()
+        sp.sync()
     assert int(Bg.fault_counts[:10].sum()) == 0, Bg.fault_counts.tolist()
     att.note = pp.note() if product else ""
     att.finish(f"height-field full step (walls={walls}{', PRODUCT instance' if product else ''}) [{N} envs x {steps} steps]")
@@ -691,24 +740,21 @@ def test_product_instances_match_oracle(instance):
     the product instance and in its `_sig` twin stepped beside it (module docstring) — the count of environment-steps in which
     the two instances differ at all is part of the summary line.
 
-    Residual on the relief (hf, walls): at this size — 16 x the environment-steps of test_full_step_on_height_field — the hardware
-    leaves 1-2 environment-steps of 163,840 outside the tolerances by x1.8 (joint rates of one leg 0.01-0.04 rad/s, base angular rate
-    0.007 rad/s off) that NO rule explains: identical contact lists and per-sweep active sets, the fp32 oracle within 0.06-0.09 of the
-    tolerance, and the same kernel SOURCE executed in plain fp32 by the SIMT emulator agrees with the oracle to 1e-4 on exactly these
-    states.  Replayed on the MI355X (tools/debug/hf_env_replay.py ENV STEP, states regenerated from the seeds) the deviation is
-    deterministic, identical for one environment alone and in a full wavefront (neither the MFMA torque path nor the helper
-    wavefronts), and unchanged by -O1 and -ffp-contract=off; one of the two cases (env 2413, step 12) disappeared with correctly
-    rounded fp32 divide / sqrt (now the product build, __graft_entry__.py), the other (env 2320, step 25) did not.  Calf / thigh
-    contacts on the relief in both.  Cause not found.  They are admitted HERE ONLY, counted and bounded — at most 3 per run (1.8e-5
-    of the environment-steps), at most 3 x a tolerance — and reported in the summary line (profiles/r04_parity_rates.txt)
-    instead of being hidden behind a rate; on flat terrain the count is 0 of 163,840."""
+    At this size — 16 x the environment-steps of test_full_step_on_height_field — the relief runs meet states the 256-environment runs never
+    did: twice in 163,840 environment-steps the hardware kernel left a tolerance by x1.8 with identical contact lists and per-sweep active
+    sets while the fp32 oracle stayed at 0.06-0.09 of it.  Replayed (tools/debug/hf_env_replay.py, hf_env_substeps.py: deterministic, the same
+    for one environment alone and in a full wavefront, unchanged by -O1 / -ffp-contract=off) both turned out to be ILL-CONDITIONED states — a
+    leg-leg contact of 85 N appearing in the step's last substep, an impact on a calf — in which the fp64 oracle's OWN result moves by
+    0.011-0.08 rad/s when its inputs are perturbed by one fp32 ulp (ShadowPert above; 2e-5 on an ordinary state): the fp32 oracle's small
+    error there was one lucky draw.  Rule (b) therefore takes the conditioning from the larger of the fp32 oracle's error and of that
+    perturbation probe; with it every environment-step of the three runs is attributed (no residual category)."""
     N = int(os.environ.get("GO1_PRODUCT_PARITY_ENVS", "4096"))        # (tools/dry_run_gpu_tests.py: the emulator needs a smaller count)
     steps = 40 if N >= 4096 else 6
     if instance == "plane":
         att, resets, resamples, _ = run_full_step_comparison("train_noise", N, steps, what="PRODUCT instance, plane", product=True)
         assert (resets > N // 64 and resamples > N // 64) or steps < 40
     else:
-        att, pp = run_height_field_comparison(instance == "walls", N=N, steps=steps, product=True, residual=(3, 3.0))
+        att, pp = run_height_field_comparison(instance == "walls", N=N, steps=steps, product=True)
     assert att.env_steps == N * steps
 
 

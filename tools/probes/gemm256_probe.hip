@@ -1,7 +1,12 @@
-// gemm256_probe.hip — where does go1ppo_gemm_nt256 spend its time?  Ablations of the kernel on the production shape
+// gemm256_probe.hip — a 256 x 256-tile LDS-DMA NT GEMM for the update's first-layer forward (X (24576 x 2112) W1^T (1280 x 2112), ELU in the
+// epilogue): where does it spend its time, and can it beat hipBLASLt's 96 us?  It cannot (round 4; withdrawn from the product): the main loop
+// is bound by the L2 -> LDS staging rate (~10.5 TB/s chip-wide: 1.01 GB staged per launch in 96 us with the MFMAs removed), 117 us with the MFMAs,
+// + 17 us epilogue (LDS-staged full-line stores; 8-byte stores from the fragment layout cost 25 us, a per-fragment bounds check serialises them).
+// Ablations of the kernel on the production shape
 // (24576 x 2112 -> 1280), random bf16 operands, rotating buffers (operands come from HBM / the Infinity Cache, not a hot L2).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -o gemm256_probe tools/probes/gemm256_probe.hip && ./gemm256_probe
 #include "../../walk-these-ways_amd/csrc/go1ppo.hip"
+#define G256_T 256
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -261,7 +266,6 @@ int main(int argc, char** argv) {
   const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
   printf("M %d N %d K %d: %d tiles of 256x256, %.1f GFLOP\n", M, N, K, tiles, gf);
   auto rep = [&](const char* name, float us) { printf("%-58s %8.1f us  %7.0f TF/s\n", name, us, gf / us * 1e-3 * 1e3); };
-  rep("go1ppo_gemm_nt256 (production, ELU epilogue)", time_us([&](int i) { go1ppo_gemm_nt256(&g[i % R], 0); }));
   rep("go1ppo_gemm_nt (128 tile, ELU epilogue)", time_us([&](int i) { go1ppo_gemm_nt(&g[i % R], 0); }));
   rep("probe <loads, mfma, store>", time_us([&](int i) { probe_kernel<1, 1, 1><<<tiles, 512>>>(g[i % R]); }));
   rep("probe <loads, mfma, NO store>", time_us([&](int i) { probe_kernel<1, 1, 0><<<tiles, 512>>>(g[i % R]); }));
@@ -271,14 +275,14 @@ int main(int argc, char** argv) {
   rep("probe <NO loads, mfma, store>", time_us([&](int i) { probe_kernel<0, 1, 1><<<tiles, 512>>>(g[i % R]); }));
   rep("probe2 <EP 1: branch-free direct stores + ELU>", time_us([&](int i) { probe2_kernel<1><<<tiles, 512>>>(g[i % R]); }));
   rep("probe2 <EP 2: LDS-staged full-line stores + ELU>", time_us([&](int i) { probe2_kernel<2><<<tiles, 512>>>(g[i % R]); }));
-  {   // the two epilogues agree with the production kernel bit for bit
+  {   // the two epilogues agree with the 128-tile product kernel bit for bit
     std::vector<bf16_t> h0((size_t)M * N), h1((size_t)M * N), h2((size_t)M * N);
-    go1ppo_gemm_nt256(&g[0], 0); CK(hipDeviceSynchronize()); CK(hipMemcpy(h0.data(), C[0], h0.size() * 2, hipMemcpyDeviceToHost));
+    go1ppo_gemm_nt(&g[0], 0); CK(hipDeviceSynchronize()); CK(hipMemcpy(h0.data(), C[0], h0.size() * 2, hipMemcpyDeviceToHost));
     probe2_kernel<1><<<tiles, 512>>>(g[0]); CK(hipDeviceSynchronize()); CK(hipMemcpy(h1.data(), C[0], h1.size() * 2, hipMemcpyDeviceToHost));
     probe2_kernel<2><<<tiles, 512>>>(g[0]); CK(hipDeviceSynchronize()); CK(hipMemcpy(h2.data(), C[0], h2.size() * 2, hipMemcpyDeviceToHost));
     size_t d1 = 0, d2 = 0;
     for (size_t i = 0; i < h0.size(); i++) { d1 += h0[i] != h1[i]; d2 += h0[i] != h2[i]; }
-    printf("elements differing from the production kernel: EP1 %zu, EP2 %zu of %zu\n", d1, d2, h0.size());
+    printf("elements differing from the 128-tile product kernel (go1ppo_gemm_nt): EP1 %zu, EP2 %zu of %zu\n", d1, d2, h0.size());
   }
   // same kernel on exactly one round of tiles (256) and on a single tile: per-tile latency
   for (int i = 0; i < R; i++) g[i].M = 256 * 256 / 5 / 256 * 256;      // 51 row blocks x 5 = 255 tiles

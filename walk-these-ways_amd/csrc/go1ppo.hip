@@ -1070,56 +1070,6 @@ extern "C" int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t s
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
-// ---------------------------------------------------------------------------------------------- latent input gradient
-// out[r][q] (bf16) = sum_n d[r][n] * wz[n][q], q < npv <= 8: the gradient w.r.t. the latent the actor's first layer received beside the
-// history (actor_critic.py:58-61: actor_body(cat(obs_history, latent))): a (rows x n) x (n x npv) product with npv = 2 — one pass over
-// d at streaming rate instead of a 64-column padded GEMM.  One wavefront per row: lane l holds the columns 8 l + 512 c.
-__global__ __launch_bounds__(256) void latent_dgrad_kernel(const bf16_t* __restrict__ d, int ld_d, int64_t rows, int n, const bf16_t* __restrict__ wz,
-                                                           int wz_ld, int npv, bf16_t* __restrict__ out, int ld_out) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-  for (int64_t r0 = wave * 4; r0 < rows; r0 += nwaves * 4) {            // four rows per turn: four independent loads in flight
-    float acc[4][8];
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-#pragma unroll
-      for (int q = 0; q < 8; q++) acc[u][q] = 0.f;
-    for (int c0 = lane * 8; c0 < n; c0 += 512) {
-      Bf8 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (r0 + u < rows) v[u] = *reinterpret_cast<const Bf8*>(d + (r0 + u) * ld_d + c0);
-      for (int q = 0; q < npv; q++) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const float w = bf2f(wz[(int64_t)(c0 + e) * wz_ld + q]);
-#pragma unroll
-          for (int u = 0; u < 4; u++) acc[u][q] = fmaf(bf2f(v[u].v[e]), w, acc[u][q]);
-        }
-      }
-    }
-    for (int q = 0; q < npv; q++) {
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        float s = acc[u][q];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0 && r0 + u < rows) out[(r0 + u) * ld_out + q] = f2bf(s);
-      }
-    }
-  }
-}
-
-extern "C" int go1ppo_latent_dgrad(const void* d, int ld_d, int64_t rows, int n, const void* wz, int wz_ld, int npv, void* out, int ld_out,
-                                   void* stream) {
-  if (!d || !wz || !out || rows <= 0 || n <= 0 || (n & 7) || (ld_d & 7) || npv <= 0 || npv > 8 || wz_ld < npv || ld_out < npv || !aligned16(d))
-    return -1;
-  int64_t blocks = (rows + 15) / 16;
-  if (blocks > 2048) blocks = 2048;
-  latent_dgrad_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)d, ld_d, rows, n, (const bf16_t*)wz, wz_ld, npv,
-                                                                                   (bf16_t*)out, ld_out);
-  return hipGetLastError() == hipSuccess ? 0 : -9;
-}
-
 // ---------------------------------------------------------------------------------------------- split-K partial sums
 // out[r][c] (fp32) = sum_b part[b][r][c] (bf16): the first-layer weight gradient leaves hipBLASLt as `count` row-chunk partial
 // products (a manual split-K, fused.py `_big_wgrad`); this pass sums them into the flat fp32 gradient — replacing the library

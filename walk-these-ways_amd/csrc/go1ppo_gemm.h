@@ -172,172 +172,6 @@ extern "C" int go1ppo_gemm_nt(const Go1PpoGemmArgs* a, void* stream) {
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
-// ================================================================================================ 256 x 256 tile
-// The same NT product on a 256 x 256 output tile per 8-wavefront workgroup (one workgroup per CU: 128 KB of LDS), for the
-// first layer of the update (M = 24576 rows, K = 2112, N = 1280: 96 x 5 = 480 tiles): twice the operand reuse of the 128-tile
-// kernel per byte staged and per byte read from LDS (wave sub-tile 128 (m) x 64 (n): 8 x 4 accumulators, 24.6 KB of fragment
-// reads per 1.05 MFLOP instead of 16 KB per 0.52).  Staging, swizzle and fragment addressing are those of gemm_nt_kernel
-// (row blocks of 8 x 128 B by LDS-DMA, 16-B chunk index XOR-ed by (row >> 1) & 7 on the source address).  The workgroup -> tile
-// map walks the column tiles of one row block on ONE XCD back to back: the 256-row A block (1.08 MB) is fetched from HBM once
-// and re-read from that XCD's L2 by the other column tiles.
-// Epilogue 1: ELU on the columns [elu_c0, elu_c1) except [elu_skip_c0, elu_skip_c1) — the actor's first-layer block, whose
-// activation needs the adaptation module's latent first (go1ppo_elu_fwd applies it afterwards).
-#define G256_T 256
-#define G256_OUT_LD 528            // bytes per row of the epilogue's LDS image of the tile (512 + 16: conflict-free 8-byte writes)
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Go1PpoGemmArgs a) {
-  // one LDS array (a second __shared__ object would make hipcc drain the LDS-DMA queue before every fragment read): the two
-  // operand buffers [buffer][A|B][row][64] (128 KB) during the main loop, the output tile's bf16 image in the epilogue
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[G256_T * G256_OUT_LD];
-  bf16_t (*lds)[2][G256_T * GEMM_BK] = reinterpret_cast<bf16_t (*)[2][G256_T * GEMM_BK]>(smem);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nwg = gridDim.x, orig = blockIdx.x;
-  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  const int tiles_n = (a.N + G256_T - 1) / G256_T;
-  const int m0 = (logical / tiles_n) * G256_T, n0 = (logical % tiles_n) * G256_T;
-
-  // ---- staging: wave w moves the row blocks (8 rows each) 4w .. 4w+3 of both tiles: 8 LDS-DMA instructions per K-step
-  const int srow = lane >> 3;
-  const bf16_t* ga[4];
-  const bf16_t* gb[4];
-#pragma unroll
-  for (int p = 0; p < 4; p++) {
-    const int R = (wave * 4 + p) * 8 + srow;
-    const int chunk = (lane & 7) ^ ((R >> 1) & 7);
-    const int ra = m0 + R < a.M ? m0 + R : a.M - 1;
-    const int rb = n0 + R < a.N ? n0 + R : a.N - 1;
-    ga[p] = (const bf16_t*)a.A + (int64_t)ra * a.lda + chunk * 8;
-    gb[p] = (const bf16_t*)a.B + (int64_t)rb * a.ldb + chunk * 8;
-  }
-  auto stage = [&](int buf, int k0) {
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      glds16(ga[p] + k0, &lds[buf][0][(wave * 4 + p) * 8 * GEMM_BK]);
-      glds16(gb[p] + k0, &lds[buf][1][(wave * 4 + p) * 8 * GEMM_BK]);
-    }
-  };
-  const int fr = lane & 15, fg = lane >> 4;
-  int foff[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; kk++) foff[kk] = fr * GEMM_BK + (((kk * 4 + fg) ^ (fr >> 1)) << 3);
-  const int wm = wave >> 2, wn = wave & 3;                      // the wave's 128 (m) x 64 (n) sub-tile
-
-  f32x4 acc[4][8];                                              // [n fragment][m fragment]
-#pragma unroll
-  for (int j = 0; j < 4; j++)
-#pragma unroll
-    for (int i = 0; i < 8; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int KT = a.K / GEMM_BK;
-  stage(0, 0);
-  for (int kt = 0; kt < KT; kt++) {
-    const int buf = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                            // step kt landed; everyone is done with buffer buf^1
-    if (kt + 1 < KT) stage(buf ^ 1, (kt + 1) * GEMM_BK);
-    const bf16_t* la = &lds[buf][0][wm * 128 * GEMM_BK];
-    const bf16_t* lb = &lds[buf][1][wn * 64 * GEMM_BK];
-#pragma unroll
-    for (int kk = 0; kk < 2; kk++) {
-      bf16x8_t xa[8], wb[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) wb[j] = *reinterpret_cast<const bf16x8_t*>(lb + j * 16 * GEMM_BK + foff[kk]);
-#pragma unroll
-      for (int i = 0; i < 8; i++) xa[i] = *reinterpret_cast<const bf16x8_t*>(la + i * 16 * GEMM_BK + foff[kk]);
-#pragma unroll
-      for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[j][i], 0, 0, 0);
-    }
-  }
-
-  // ---- epilogue: lane holds D[n = 4*fg + e][m = fr] of each 16 x 16 fragment
-  const bool interior = m0 + G256_T <= a.M && n0 + G256_T <= a.N && !a.bias && (a.ldc & 7) == 0 && ((uintptr_t)a.C & 15) == 0;
-  if (interior) {
-    // whole tile, no bias: the activated bf16 tile goes through LDS and leaves as 16-byte stores of whole 512-byte row segments
-    // (measured, tools/probes/gemm256_probe.hip: 8-byte stores from the fragment layout cost 25 us of the 24576 x 1280 product,
-    // and a per-fragment bounds check / bias select serialises them behind vmcnt(0) waits)
-    __syncthreads();                                            // every wave is done with the operand buffers
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int nl = wn * 64 + j * 16 + fg * 4, n = n0 + nl;
-      const bool act = EPI == 1 && n >= a.elu_c0 && n < a.elu_c1 && !(n >= a.elu_skip_c0 && n < a.elu_skip_c1);
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) { const float x = acc[j][i][e]; v[e] = act ? elu1(x) : x; }
-        f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
-        uint2 o;
-        o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2_t));
-        o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2_t));
-        *reinterpret_cast<uint2*>(smem + (wm * 128 + i * 16 + fr) * G256_OUT_LD + nl * 2) = o;
-      }
-    }
-    __syncthreads();
-    // a wave instruction moves two rows (32 lanes x 16 B each); wave w takes rows 32w .. 32w+31
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-      const int row = wave * 32 + t * 2 + (lane >> 5), c16 = lane & 31;
-      const uint4 v = *reinterpret_cast<const uint4*>(smem + row * G256_OUT_LD + c16 * 16);
-      *reinterpret_cast<uint4*>((bf16_t*)a.C + (int64_t)(m0 + row) * a.ldc + n0 + c16 * 8) = v;
-    }
-    return;
-  }
-  // edge tiles / bias: 8-byte stores straight from the fragments, rows and column groups masked
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int n = n0 + wn * 64 + j * 16 + fg * 4;
-    if (n >= a.N) continue;                                     // N % 4 == 0: a 4-column group is in or out as a whole
-    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (a.bias) {
-      if (a.bias_bf16) {
-        const uint2 braw = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.bias) + n);
-        bias = f32x4{__uint_as_float(braw.x << 16), __uint_as_float(braw.x & 0xffff0000u), __uint_as_float(braw.y << 16),
-                     __uint_as_float(braw.y & 0xffff0000u)};
-      } else bias = *reinterpret_cast<const f32x4*>(a.bias + n);
-    }
-    const bool act = EPI == 1 && n >= a.elu_c0 && n < a.elu_c1 && !(n >= a.elu_skip_c0 && n < a.elu_skip_c1);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int m = m0 + wm * 128 + i * 16 + fr;
-      if (m >= a.M) continue;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) v[e] = acc[j][i][e] + bias[e];
-      if (act) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = elu1(v[e]);
-      }
-      f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
-      uint2 o;
-      o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2_t));
-      o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2_t));
-      *reinterpret_cast<uint2*>((bf16_t*)a.C + (int64_t)m * a.ldc + n) = o;
-    }
-  }
-}
-
-extern "C" int go1ppo_gemm_nt256(const Go1PpoGemmArgs* a, void* stream) {
-  if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return -1;
-  if ((a->K % GEMM_BK) || (a->N & 3) || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 3) || !aligned16(a->A) || !aligned16(a->B) ||
-      ((uintptr_t)a->C & 7))
-    return -2;
-  if (a->bias && ((uintptr_t)a->bias & (a->bias_bf16 ? 7 : 15))) return -4;
-  if (a->epilogue == 1 && ((a->elu_c0 | a->elu_c1 | a->elu_skip_c0 | a->elu_skip_c1) & 3)) return -3;
-  int64_t tiles = (int64_t)((a->M + G256_T - 1) / G256_T) * ((a->N + G256_T - 1) / G256_T);
-  if (tiles > INT32_MAX) return -5;
-  dim3 grid((unsigned)tiles), block(512);
-  hipStream_t s = (hipStream_t)stream;
-  switch (a->epilogue) {
-    case 0: gemm_nt256_kernel<0><<<grid, block, 0, s>>>(*a); break;
-    case 1: gemm_nt256_kernel<1><<<grid, block, 0, s>>>(*a); break;
-    default: return -6;
-  }
-  return hipGetLastError() == hipSuccess ? 0 : -9;
-}
-
 // ================================================================================================ weight gradients
 // dW[n][k] += sum_m dZ[m][n] H[m][k] ("TN": both operands are m-major, the reduction runs over the slow index).
 // One workgroup = 8 wavefronts = one 128 x 128 output tile over a chunk of rows, 64 reduction rows per step:

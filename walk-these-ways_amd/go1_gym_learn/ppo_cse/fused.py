@@ -88,7 +88,7 @@ class AdamExtras(ctypes.Structure):
     _fields_ = [("num_transposes", ctypes.c_int32), ("_pad", ctypes.c_int32), ("transpose", _AdamTranspose * 2)]
 
 
-EXPORTED_SYMBOLS = ["go1ppo_mlp2_fwd", "go1ppo_mlp2_bwd", "go1ppo_gemm_nt", "go1ppo_gemm_nt256", "go1ppo_sum_partials", "go1ppo_latent_dgrad", "go1ppo_wgrad_tn_plan", "go1ppo_wgrad_tn_batched", "go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
+EXPORTED_SYMBOLS = ["go1ppo_mlp2_fwd", "go1ppo_mlp2_bwd", "go1ppo_gemm_nt", "go1ppo_sum_partials", "go1ppo_wgrad_tn_plan", "go1ppo_wgrad_tn_batched", "go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
                     "go1ppo_wgrad_batched", "go1ppo_act",
                     "go1ppo_store_step", "go1ppo_ring_snapshot", "go1ppo_ring_step", "go1ppo_ring_gather", "go1ppo_gae", "go1ppo_normalize", "go1ppo_opt_partials", "go1ppo_opt_prestep",
                     "go1ppo_opt_adam", "go1ppo_version"]
@@ -113,9 +113,7 @@ def load_library(path=None):
     L.go1ppo_wgrad_plan.argtypes = [ctypes.POINTER(WgradProblem), i32]
     L.go1ppo_tail_fwd.argtypes = [ctypes.POINTER(TailArgs), vp]
     L.go1ppo_gemm_nt.argtypes = [ctypes.POINTER(GemmArgs), vp]
-    L.go1ppo_gemm_nt256.argtypes = [ctypes.POINTER(GemmArgs), vp]
     L.go1ppo_sum_partials.argtypes = [vp, i32, i64, i64, i32, vp, i32, i32, i32, vp]
-    L.go1ppo_latent_dgrad.argtypes = [vp, i32, i64, i32, vp, i32, i32, vp, i32, vp]
     L.go1ppo_mlp2_fwd.argtypes = [ctypes.POINTER(Mlp2Fwd), i32, vp]
     L.go1ppo_mlp2_bwd.argtypes = [ctypes.POINTER(Mlp2Bwd), i32, vp]
     L.go1ppo_wgrad_batched.argtypes = [vp, i32, i32, vp]
@@ -185,13 +183,6 @@ def gemm_nt(lib, a, b, c, bias=None, elu=None, elu_bwd_of=None):
     return c
 
 
-def gemm_nt256(lib, a, b, c, bias=None, elu=None, elu_skip=None):
-    """c = epilogue(a @ b.T + bias) on 256 x 256 tiles (go1ppo_gemm_nt256)"""
-    g = gemm_args(a, b, c, bias, elu, elu_skip=elu_skip)
-    _chk(lib.go1ppo_gemm_nt256(ctypes.byref(g), _stream()), "go1ppo_gemm_nt256")
-    return c
-
-
 class FusedNet:
     """Static-buffer forward (and optionally backward) of the three MLPs for a fixed row count M.
 
@@ -242,10 +233,9 @@ class FusedNet:
                           and tuple(self.P[f"{n}.{self.depth[n] - 1}.W"].shape) == (MLP2_DIMS[2], MLP2_DIMS[1]) for n in self.depth)
                       and self.depth["adaptation"] == 3 and self.depth["actor"] == 4 and self.depth["critic"] == 4)
         self._mlp2_cache = {}
-        # first-layer forward on this repository's 256-tile GEMM with the ELU of the adaptation module's and the critic's blocks
-        # in its epilogue (the separate activation pass then only covers the actor's block, which waits for the latent);
-        # GO1_GEMM256=0: hipBLASLt + the full activation pass
-        self._gemm256 = os.environ.get("GO1_GEMM256", "0") == "1" and self._mlp2 and policy.Kp % 64 == 0
+        # (the first-layer forward stays on hipBLASLt: 96 us = 1.39 PFLOP/s in situ.  A 256-tile LDS-DMA GEMM of this repository with the ELU in
+        #  its epilogue measured 135-140 us — bound by the L2 -> LDS staging rate of ~10.5 TB/s chip-wide, tools/probes/gemm256_probe.hip,
+        #  DESIGN.md section 7 — and was withdrawn)
         self._l1_nt = os.environ.get("GO1_L1_NT", "1") == "1"
         # the critic's tail is independent of the actor / adaptation chain: it runs on a side stream (forked from and
         # joined back into the caller's stream, so HIP-graph capture records it as a parallel branch)
@@ -404,17 +394,10 @@ class FusedNet:
 
     def _forward_mlp2(self, x):
         P, Z, nd, na = self.P, self.Z, self.nd, self.na
-        if self._gemm256:
-            # ELU of the adaptation / critic blocks in the GEMM's epilogue; the actor's block stays a pre-activation until the latent exists
-            gemm_nt256(self.lib, x, P["W1"], self.Y1, elu=True, elu_skip=(nd, nd + na))
-            self._mlp2_fwd("adaptation", [("adaptation", self.Y1[:, :nd])], elu_input=0)
-            latent = Z["adaptation"][2]
-            self._elu(self.Y1[:, nd:nd + na], latent, na)
-        else:
-            torch.mm(x, P["W1"].t(), out=self.Y1)
-            self._mlp2_fwd("adaptation", [("adaptation", self.Y1[:, :nd])])
-            latent = Z["adaptation"][2]
-            self._elu(self.Y1[:, nd:], latent, na)
+        torch.mm(x, P["W1"].t(), out=self.Y1)
+        self._mlp2_fwd("adaptation", [("adaptation", self.Y1[:, :nd])])
+        latent = Z["adaptation"][2]
+        self._elu(self.Y1[:, nd:], latent, na)
         if self._l1_nt:
             # the 512 -> 256 layers on go1ppo_gemm_nt (bias in the epilogue; measured 16 us against hipBLASLt's 31 at 24576 rows)
             with self._branch():
@@ -458,9 +441,7 @@ class FusedNet:
         latent, dlat = Z["adaptation"][2], dZ["adaptation"][2]
         dA1 = dY1[:, cols["actor"]]
         self._wgrad(dA1, latent, G["Wz"])
-        # dlat = dA1 Wz: two useful columns — one streaming pass instead of a 64-column padded GEMM (the other columns of dlat stay 0)
-        _chk(self.lib.go1ppo_latent_dgrad(dA1.data_ptr(), _ld(dA1), dA1.shape[0], dA1.shape[1], P["Wz"].data_ptr(), HEAD, self.pol.npv,
-                                          dlat.data_ptr(), _ld(dlat), _stream()), "go1ppo_latent_dgrad")
+        torch.mm(dA1, P["Wz"], out=dlat)          # (13 us on hipBLASLt; a dedicated streaming kernel for the two useful columns measured 19)
         self._mlp2_bwd("adaptation", [("adaptation", Y1[:, :nd], dY1[:, :nd])])
         self._wgrad(dlat, Z["adaptation"][1], G["adaptation.2.W"], G["adaptation.2.b"])
         self._wgrad(dZ["adaptation"][1], Y1[:, :nd], G["adaptation.1.W"], G["adaptation.1.b"])
