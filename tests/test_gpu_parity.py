@@ -84,6 +84,7 @@ class ShadowPert:
         self.B = [Bc.clone_to("cpu") for _ in range(draws)]
         self.o = [pyoracle.Oracle(S, B) for B in self.B]
         self.g = torch.Generator().manual_seed(seed)
+        self.pending = None
         self.sync()
 
     def set_eval_config(self, S_eval, num_train):
@@ -102,8 +103,15 @@ class ShadowPert:
             o.ctr.common_step_counter, o.ctr.lag_head, o.ctr.history_slot = c.common_step_counter, c.lag_head, c.history_slot
 
     def step(self, a):
-        for o in self.o:
-            o.step(a)
+        """note the actions of this step; the perturbed oracles only run when Attribution.step() meets an environment the other rules
+        leave unexplained (their buffers hold the pre-step state until the next sync())"""
+        self.pending = a
+
+    def run(self):
+        if self.pending is not None:
+            for o in self.o:
+                o.step(self.pending)
+            self.pending = None
 
 
 def to_gpu(S, Bc, product=False):
@@ -224,8 +232,11 @@ class Attribution:
             # (c): the kernel REPRODUCES the fp32 oracle within the tolerances (a decision both fp32 evaluations take the same
             # way and fp64 the other — e.g. a termination threshold): no bound on how far that is from the fp64 result
             ratio32 = ratio_fn(B32, Bc)
-            if pert is not None:                   # conditioning of the step itself (ShadowPert): the larger of the fp32 oracle's error and of
-                for Bp in pert.B:                  # what one-ulp input perturbations do to the fp64 oracle's own result
+            same32_pre = ratio_fn(Bg, B32) <= 1.0
+            need = bad & ~sig & ~(((ratio32 > RULE_B_FLOOR) & (ratio <= RULE_B_FACTOR * ratio32)) | same32_pre)
+            if pert is not None and bool(need.any()):     # conditioning of the step itself (ShadowPert): the larger of the fp32 oracle's error and
+                pert.run()                                 # of what one-ulp input perturbations do to the fp64 oracle's own result
+                for Bp in pert.B:
                     rp = ratio_fn(Bp, Bc)
                     if reset_key is not None:      # (a termination decided differently under the perturbation: a threshold sits here)
                         rp = torch.where(Bp.tensors[reset_key].bool() != Bc.tensors[reset_key].bool(), torch.full_like(rp, 1e3), rp)
