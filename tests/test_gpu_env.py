@@ -261,24 +261,25 @@ def test_rough_terrain_training_survives_once_the_flat_ground_assumptions_are_li
     profiles/r04_rough_train_sanity.txt): tiles spawn at their rim height (terrain.py:177), the foot-clearance / jump / contact-velocity
     terms read world z (corl_rewards.py:129 `# - reference_heights`), and reward = positive x exp(negative / 0.02) is identically 0
     while robots still fall.  With the three lifted by flagged, non-default switches (centre-patch spawn, heights above the terrain,
-    sigma_rew_neg = 1) 500 PPO iterations on the WALLS instance of the step kernel must show what the simulator owes: robots that stay
+    sigma_rew_neg = 1) 300 PPO iterations on the WALLS instance of the step kernel must show what the simulator owes: robots that stay
     up on every tile class — time-outs instead of falls —, a non-zero reward, and no simulator fault."""
     import re
     import subprocess
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(repo, "tools", "train_sanity.py"), "--rough", "--spawn", "centre_patch", "--above-terrain",
-                          "--sigma-rew-neg", "1.0", "--iters", "500", "--every", "100"], capture_output=True, text=True, timeout=600)
+                          "--sigma-rew-neg", "1.0", "--iters", "300", "--every", "100"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = [l for l in out.stdout.splitlines() if l.startswith("it ")]
-    assert len(rows) == 5, out.stdout[-2000:]
+    assert len(rows) == 3, out.stdout[-2000:]
     last = rows[-1]
     rew = float(re.search(r"mean step reward\s+([-\d.]+)", last).group(1))
     to = float(re.search(r"time-outs/resets\s+([\d.]+)", last).group(1))
     ep = float(re.search(r"mean ep len\s+([\d.]+)", last).group(1))
     fatal = sum(int(re.search(r"fatal (\d+)", l).group(1)) for l in rows)
     print(last)
-    # measured (r4c12): reward 0.0059, time-outs / resets 0.42, mean episode length 579 at iteration 500; reference settings: 0.0000 / 0.03 / 117
-    assert rew > 0.003 and to > 0.25 and ep > 350 and fatal == 0, last
+    # measured (r4c12): reward 0.0058, time-outs / resets 0.39, mean episode length 508 at iteration 300 (0.0061 / 0.64 / 790 at 1500);
+    # reference settings: 0.0000 / 0.03 / 117
+    assert rew > 0.003 and to > 0.2 and ep > 300 and fatal == 0, last
 
 
 def test_teacher_student_runner_on_the_hip_env(tmp_path):

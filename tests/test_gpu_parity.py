@@ -80,11 +80,12 @@ class ShadowPert:
 
     def __init__(self, S, Bc, orc, draws=3, seed=77):
         import pyoracle
-        self.Bc, self.orc = Bc, orc
+        self.Bc, self.orc, self.draws = Bc, orc, draws
+        self.snap = Bc.clone_to("cpu")              # the pre-step state (ONE copy per step; the perturbed copies are made on demand)
         self.B = [Bc.clone_to("cpu") for _ in range(draws)]
         self.o = [pyoracle.Oracle(S, B) for B in self.B]
         self.g = torch.Generator().manual_seed(seed)
-        self.pending = None
+        self.pending, self.eval_cfg = None, None
         self.sync()
 
     def set_eval_config(self, S_eval, num_train):
@@ -92,26 +93,30 @@ class ShadowPert:
             o.set_eval_config(S_eval, num_train)
 
     def sync(self):
+        for k, t in self.Bc.tensors.items():
+            if t is not None and self.snap.tensors.get(k) is not None:
+                self.snap.tensors[k].copy_(t)
+        c = self.orc.ctr
+        self.ctr = (c.common_step_counter, c.lag_head, c.history_slot)
+
+    def step(self, a):
+        """note the actions of this step; the perturbed oracles only run when Attribution.step() meets an environment the other rules
+        leave unexplained"""
+        self.pending = a
+
+    def run(self):
+        if self.pending is None:
+            return
         for B, o in zip(self.B, self.o):
-            for k, t in self.Bc.tensors.items():
+            for k, t in self.snap.tensors.items():
                 if t is not None and B.tensors.get(k) is not None:
                     B.tensors[k].copy_(t)
             for k in ("root_states", "dof_pos", "dof_vel"):
                 t = B.tensors[k]
                 t.mul_(1.0 + (torch.rand(t.shape, generator=self.g) * 2.0 - 1.0) * 2.0 ** -23)
-            c = self.orc.ctr
-            o.ctr.common_step_counter, o.ctr.lag_head, o.ctr.history_slot = c.common_step_counter, c.lag_head, c.history_slot
-
-    def step(self, a):
-        """note the actions of this step; the perturbed oracles only run when Attribution.step() meets an environment the other rules
-        leave unexplained (their buffers hold the pre-step state until the next sync())"""
-        self.pending = a
-
-    def run(self):
-        if self.pending is not None:
-            for o in self.o:
-                o.step(self.pending)
-            self.pending = None
+            o.ctr.common_step_counter, o.ctr.lag_head, o.ctr.history_slot = self.ctr
+            o.step(self.pending)
+        self.pending = None
 
 
 def to_gpu(S, Bc, product=False):
@@ -419,7 +424,7 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
         prepare(S, Bc)
     pp.sync() if product else sync_from(Bc, Bg, sim, orc)
     sh = Shadow32(S, Bc, orc)
-    sp = ShadowPert(S, Bc, orc)
+    sp = ShadowPert(S, Bc, orc) if product else None         # (the conditioning probe: the 4096-environment runs and the relief)
     resets = 0
     resamples = 0
     timeouts = 0
@@ -433,7 +438,8 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
             watch(S, Bc, "before")
         orc.step(a)
         sh.o.step(a)
-        sp.step(a)
+        if sp is not None:
+            sp.step(a)
         twin = None
         if product:
             twin = pp.step(torch.from_numpy(a).cuda())
@@ -455,7 +461,8 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
                 assert not bool(bad[..., ~bad_env].any()), k
         pp.sync() if product else sync_from(Bc, Bg, sim, orc)
         sh.sync()
-        sp.sync()
+        if sp is not None:
+            sp.sync()
     assert int(Bg.fault_counts[:10].sum()) == 0, Bg.fault_counts.tolist()
     att.note = pp.note() if product else ""
     att.finish(f"{what} [{variant}, {N} envs x {steps} steps]")

@@ -36,7 +36,7 @@ def main():
         from go1_gym_learn.ppo_cse.ppo import _enable_tuned_gemms
         _enable_tuned_gemms()
     M = args.rows
-    lib = fused.load_library()
+    lib = fused.load_library(os.environ.get("GO1PPO_LIB"))          # (GO1PPO_LIB: a variant build for A/B runs)
     s = torch.cuda.current_stream().cuda_stream
     bf = dict(device="cuda", dtype=torch.bfloat16)
     R = 4                                            # rotating buffer sets

@@ -341,7 +341,11 @@ __device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf
 #pragma unroll
       for (int b = 0; b < 2; b++) {
         const int k = k0 + wk * 32 + b * 16 + i16;
+#ifdef WTN_PROBE_PLAIN_STORES          /* timing probe only (tools/bench_gemm.py with GO1PPO_LIB): what the fp32 atomics of the partial tiles cost */
+        if (k < K && !(n < zero_n && k >= zero_k0 && k < zero_k1)) C[(int64_t)n * ldc + k] = acc[a][b][e];
+#else
         if (k < K && !(n < zero_n && k >= zero_k0 && k < zero_k1)) atomicAdd(C + (int64_t)n * ldc + k, acc[a][b][e]);
+#endif
       }
       if (do_bias && i16 == 0) atomicAdd(bias_grad + n, bacc[a][e]);
     }
