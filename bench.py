@@ -39,7 +39,7 @@ ALGORITHMIC_BYTES_PER_ENV_STEP = 3444      # 1,332 B read + 1,
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def build_env(num_envs, rank, seed, rough=False, curriculum_update_interval=None, spawn=None, heights_above_terrain=False, sigma_rew_neg=None):
+def build_env(num_envs, rank, seed, rough=False, curriculum_update_interval=None, spawn=None, heights_above_terrain=False, sigma_rew_neg=None, solver_sweeps=None):
     """train.py configuration (BASELINE configs[1]); rough=True: configs[2] — the terrain curriculum's tile grid
     (slopes / rough slopes / stairs / obstacles, cfg:64-102 defaults) as a trimesh terrain (vertical risers) + the 187-point
     height scan appended to the observation (70 + 187 = 257)."""
@@ -52,6 +52,8 @@ def build_env(num_envs, rank, seed, rough=False, curriculum_update_interval=None
     cfg.env.env_id_offset = rank * num_envs
     if curriculum_update_interval is not None:
         cfg.commands.curriculum_update_interval = int(curriculum_update_interval)
+    if solver_sweeps is not None:                # diagnostic (tools/play_eval.py --sweeps): the reference's PhysX setting is 4
+        cfg.sim.physx.num_solver_sweeps = int(solver_sweeps)
     if sigma_rew_neg is not None:                # diagnostic (tools/train_sanity.py): train.py's value is 0.02
         cfg.rewards.sigma_rew_neg = float(sigma_rew_neg)
     if rough:

@@ -40,20 +40,7 @@ def main():
     s = torch.cuda.current_stream().cuda_stream
     bf = dict(device="cuda", dtype=torch.bfloat16)
     R = 4                                            # rotating buffer sets
-    # ---- the 256-tile GEMM (go1ppo_gemm_nt256) on the first-layer shapes: update (24576 rows) and rollout inference (4096 rows)
     import ctypes
-    print(f"{'256-tile GEMM, first layer':34s} {'ours us':>9s} {'TF/s':>7s} | {'torch us':>9s} {'TF/s':>7s} {'+elu us':>8s}")
-    for rows in (M, 4096):
-        A = [torch.randn(rows, 2112, **bf) for _ in range(R)]
-        B = torch.randn(1280, 2112, **bf) / 2112 ** 0.5
-        C = [torch.zeros(rows, 1280, **bf) for _ in range(R)]
-        ga = [fused.gemm_args(A[i], B, C[i], None, elu=True, elu_skip=(256, 768)) for i in range(R)]
-        ours = timeit([(lambda g=g: lib.go1ppo_gemm_nt256(ctypes.byref(g), s)) for g in ga])
-        tt = timeit([(lambda i=i: torch.mm(A[i], B.t(), out=C[i])) for i in range(R)])
-        te = timeit([(lambda i=i: lib.go1ppo_elu_fwd(C[i][:, 256:].data_ptr(), rows, 1024, 1280, None, 0, 0, None, 0, 0, s)) for i in range(R)])
-        te2 = timeit([(lambda i=i: lib.go1ppo_elu_fwd(C[i][:, 256:768].data_ptr(), rows, 512, 1280, None, 0, 0, None, 0, 0, s)) for i in range(R)])
-        gf = 2 * rows * 1280 * 2112 / 1e9
-        print(f"  {rows:6d} x 2112 -> 1280            {ours:9.1f} {gf / ours:7.0f} | {tt:9.1f} {gf / tt:7.0f} {te:8.1f}   (actor-block ELU alone: {te2:.1f} us)")
     print(f"rows = {M}\n{'shape':34s} {'ours us':>9s} {'TF/s':>7s} | {'torch us':>9s} {'TF/s':>7s} {'+elu us':>8s}")
     for name, N, K, lda, elu in (("first layer 2112 -> 1280", 1280, 2112, 2112, (0, 256)), ("adaptation 2112 -> 256", 256, 2112, 2112, True),
                                  ("tail 512 -> 256", 256, 512, 1280, True), ("tail 256 -> 128", 128, 256, 256, True),
@@ -105,6 +92,23 @@ def main():
     for n, k, ld_dz, ld_h in ((1280, 2112, 1280, 2112), (256, 2112, 256, 2112), (256, 512, 256, 1280), (128, 256, 128, 256),
                               (64, 128, 64, 128), (512, 64, 1280, 64)):
         one(n, k, ld_dz, ld_h)
+    # the PPO pass's batched launch: every small weight gradient of one backward pass in one go1ppo_wgrad_tn_batched call
+    shapes = [(64, 128, 64, 128), (128, 256, 128, 256), (256, 512, 256, 1280)] * 2 + [(512, 64, 1280, 64), (64, 128, 64, 128), (128, 256, 128, 1280)]
+    sets = []
+    for _ in range(R):
+        tab = (fused.WgradProblem * len(shapes))()
+        keep = []
+        for P, (n, k, ld_dz, ld_h) in zip(tab, shapes):
+            dz, h, out, bg = torch.randn(M, ld_dz, **bf), torch.randn(M, ld_h, **bf), torch.zeros(n, k, device="cuda"), torch.zeros(n, device="cuda")
+            keep.append((dz, h, out, bg))
+            P.dz, P.h, P.dW, P.bias_grad = dz.data_ptr(), h.data_ptr(), out.data_ptr(), bg.data_ptr()
+            P.rows, P.ld_dz, P.ld_h, P.n, P.k, P.ldw = M, ld_dz, ld_h, n, k, k
+        total = lib.go1ppo_wgrad_tn_plan(tab, len(shapes))
+        sets.append((torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).cuda(), total, keep))
+    t_set = timeit([(lambda t=t: lib.go1ppo_wgrad_tn_batched(t[0].data_ptr(), len(shapes), t[1], s)) for t in sets])
+    gf = sum(2 * M * n * k for n, k, _, _ in shapes) / 1e9
+    print(f"batched PPO-pass set ({len(shapes)} problems, wgs {sets[0][1]}): {t_set:7.1f} us  {gf / t_set:6.0f} TF/s")
+    del sets
     print("\nLDS-resident 256 -> 128 -> 64 tails (us per launch)")
     for nets in (1, 2, 3):
         sets = []

@@ -30,11 +30,11 @@ def yaw_of(quat_xyzw):
     return torch.atan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))
 
 
-def evaluate(runner, num_envs, vx, steps=250, seed=1):
+def evaluate(runner, num_envs, vx, steps=250, seed=1, solver_sweeps=None):
     """a FRESH evaluation environment (play.py builds its own): DR ranges of the training configuration, commands written
     every step, deterministic policy (actor mean on the adaptation module's latent: act_student's inference path)"""
     from bench import build_env
-    env, cfg = build_env(num_envs, 0, seed)
+    env, cfg = build_env(num_envs, 0, seed, solver_sweeps=solver_sweeps)
     base = env.env
     alg = runner.alg
     policy = alg.actor_critic
@@ -70,7 +70,8 @@ def evaluate(runner, num_envs, vx, steps=250, seed=1):
                 mean_vx=float(base.base_lin_vel[:, 0][~fell].mean()) if bool((~fell).any()) else float("nan"))
 
 
-def train_and_evaluate(iters, envs=4096, eval_envs=512, eval_at=None, vxs=(1.0, 1.5), log_every=500, fp32=False, out=print, after=None):
+def train_and_evaluate(iters, envs=4096, eval_envs=512, eval_at=None, vxs=(1.0, 1.5), log_every=500, fp32=False, out=print, after=None,
+                       sweeps=None, eval_sweeps=(None,)):
     """Train with scripts/train.py's configuration (bench.py's loop), evaluate at the iterations `eval_at`; returns
     ({iteration: [evaluate() records]}, fault totals over the training).  `after(runner, env, obs_dict)`: called once the training is over."""
     from bench import build_env
@@ -80,7 +81,7 @@ def train_and_evaluate(iters, envs=4096, eval_envs=512, eval_at=None, vxs=(1.0, 
     PPO_Args.autocast_bf16 = not fp32
     RunnerArgs.save_video_interval = 0
     torch.manual_seed(0)
-    env, cfg = build_env(envs, 0, 0)
+    env, cfg = build_env(envs, 0, 0, solver_sweeps=sweeps)
     runner = Runner(env, device="cuda:0")
     PPO_Args.autocast_bf16 = saved
     T = runner.num_steps_per_env
@@ -112,10 +113,11 @@ def train_and_evaluate(iters, envs=4096, eval_envs=512, eval_at=None, vxs=(1.0, 
             rew_acc.zero_(); cnt = 0
         if it in eval_at:
             results[it] = []
-            for vx in vxs:
-                r = evaluate(runner, eval_envs, vx)
+            for vx, es in [(v, e) for e in eval_sweeps for v in vxs]:
+                r = evaluate(runner, eval_envs, vx, solver_sweeps=es)
+                r["solver_sweeps"] = es
                 results[it].append(r)
-                out(f"EVAL it {it:5d}  v_cmd {vx:.1f}: mean v_x {r['mean_vx']:.3f}  |v_x - v_cmd| {r['vel_err']:.3f} m/s  yaw drift {r['yaw_drift']:.3f} rad  "
+                out(f"EVAL it {it:5d}  {'' if es is None else f'[{es} solver sweeps] '}v_cmd {vx:.1f}: mean v_x {r['mean_vx']:.3f}  |v_x - v_cmd| {r['vel_err']:.3f} m/s  yaw drift {r['yaw_drift']:.3f} rad  "
                     f"gait-schedule match {r['gait_match']:.3f}  fall rate {r['fall_rate']:.3f}")
             runner.alg.actor_critic.train()
     if after is not None:
@@ -134,9 +136,14 @@ def main():
     ap.add_argument("--vx", type=float, nargs="*", default=[1.0, 1.5])
     ap.add_argument("--log-every", type=int, default=500)
     ap.add_argument("--fp32", action="store_true", help="the autograd fp32 update instead of the bf16 fused one (bench.py's configuration)")
+    ap.add_argument("--sweeps", type=int, default=None, help="PGS sweeps per substep of the TRAINING simulator (default: the reference's 4)")
+    ap.add_argument("--eval-sweeps", type=int, nargs="*", default=None,
+                    help="evaluate the same policy on simulators with these sweep counts (solver-convergence sensitivity of the task metrics)")
     args = ap.parse_args()
+    if args.sweeps is not None:
+        print(f"# training simulator: {args.sweeps} solver sweeps per substep", flush=True)
     train_and_evaluate(args.iters, args.envs, args.eval_envs, args.eval_at, args.vx, args.log_every, args.fp32,
-                       out=lambda m: print(m, flush=True))
+                       out=lambda m: print(m, flush=True), sweeps=args.sweeps, eval_sweeps=tuple(args.eval_sweeps or (None,)))
 
 
 if __name__ == "__main__":
