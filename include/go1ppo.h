@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define GO1PPO_ABI_VERSION 2
+#define GO1PPO_ABI_VERSION 3
 #define GO1PPO_MAX_ACTIONS 32
 
 /* y[r, c] = elu(y[r, c] + sum_i lat[r, i] * wz[c, i] (c < lat_cols)) in place.  lat/wz may be NULL (plain ELU).
@@ -123,6 +123,13 @@ typedef struct {
    * first-layer rows carry the privileged observations for the critic only (actor_critic.py:44-47, 58-61): the adaptation
    * module's and the actor's rows of W1 have no weight — hence no gradient — on those columns. */
   int32_t zero_n, zero_k0, zero_k1;
+  /* go1ppo_wgrad_tn_batched only (NULL for the 64-tile kernels).  partials != NULL: the workgroup of row chunk s STORES its partial
+   * tile into the slab partials[s * partial_stride + r * ldw + c] (fp32, plain stores; structural zeros are skipped, so a slab
+   * buffer allocated as zeros keeps them) instead of adding it to dW with fp32 atomics; the slabs — ceil(rows / chunk_rows) of
+   * them — are summed in a fixed order by go1ppo_grad_reduce or by the optimiser's norm pass (Go1PpoGradPiece).  Measured on
+   * MI355X: the atomics of the 9-problem PPO-pass set cost 15.6 of its 64.5 us (profiles/r04_wgrad_atomics_probe.txt). */
+  float* partials;
+  int64_t partial_stride;
 } Go1PpoWgradProblem;
 
 int go1ppo_wgrad_plan(Go1PpoWgradProblem* host_problems, int count);
@@ -177,6 +184,28 @@ int go1ppo_opt_partials(void);
 int go1ppo_opt_prestep(const float* g, int64_t n, float gscale, float* partial, float* step, float* lr, const float* kl,
                        float kl_scale, float desired_kl, float lr_min, float lr_max, void* stream);
 
+/* The flat gradient as a list of pieces, ascending and disjoint (elements outside every piece are plain):
+ *   kind 0: g[begin, begin + count) is final as it stands;
+ *   kind 1: g[begin + i] <- sum over b < slabs of ((const float*)src)[b * stride + i]   (Go1PpoWgradProblem.partials);
+ *   kind 2: the same with bf16 slabs (the row-chunk partial products of go1ppo_sum_partials' caller).
+ * zero_rows > 0: the elements of the first zero_rows rows (rows of `cols` elements, counted from `begin`) on the columns
+ * [zero_c0, zero_c1) are written as exact zeros.  begin, count multiples of 8 for kinds 1 / 2 (stride too); src 16-byte aligned. */
+typedef struct {
+  int64_t begin, count;
+  const void* src;
+  int64_t stride;
+  int32_t kind, slabs, cols, zero_rows, zero_c0, zero_c1;
+} Go1PpoGradPiece;
+/* materialise the slab pieces (kinds 1, 2) into g: what a consumer other than go1ppo_opt_prestep_pieces needs — the data-parallel
+ * all-reduce of the gradient, a torch optimiser. `device_pieces`: the table in device memory. */
+int go1ppo_grad_reduce(float* g, const Go1PpoGradPiece* device_pieces, int num_pieces, void* stream);
+/* go1ppo_opt_prestep over [0, n) with the slab pieces summed on the way: g receives the sums (so go1ppo_opt_adam reads a plain
+ * gradient) and the norm partials are taken from them — one pass instead of a reduction launch + the norm pass.  Elements of
+ * [0, n) outside every piece count as plain.  partial must not be NULL. */
+int go1ppo_opt_prestep_pieces(float* g, int64_t n, const Go1PpoGradPiece* device_pieces, int num_pieces, float gscale, float* partial,
+                              float* step, float* lr, const float* kl, float kl_scale, float desired_kl, float lr_min, float lr_max,
+                              void* stream);
+
 /* Adam (no weight decay, no amsgrad) on the elements [start0, start0+count0) U [start1, start1+count1) of the flat
  * parameter p with gradient g * gscale * clip, clip = min(1, max_norm / (sqrt(sum partial) + 1e-6)) (partial == NULL:
  * no clipping).  Refreshes the compute copies of the touched elements: body[i] (bf16) for i < n_body, tail[i - n_body]
@@ -219,6 +248,8 @@ typedef struct Go1PpoGemmArgs {
   int32_t bias_bf16, _pad;               /* bias_bf16 != 0: `bias` points to bf16 values (the compute copy of the parameters) */
 } Go1PpoGemmArgs;
 int go1ppo_gemm_nt(const Go1PpoGemmArgs* args, void* stream);
+/* two independent problems with equal tile grids (ceil(M / 128) * ceil(N / 128)) and the same epilogue in one launch */
+int go1ppo_gemm_nt_pair(const Go1PpoGemmArgs* a, const Go1PpoGemmArgs* b, void* stream);
 
 /* the same weight gradients on 128 x 128 tiles (LDS-DMA staging, hardware transpose reads): what the first-layer
  * gradients (n = 256 .. 1280, k = 2112) and the batched tails use.  Same problem table as go1ppo_wgrad_plan /

@@ -76,6 +76,8 @@ def test_ppo_library_exports_every_declared_symbol():
     # argument validation happens before any launch: callable without a GPU
     assert lib.go1ppo_wgrad(None, 0, None, 0, 0, 0, 0, None, 0, None, None) == -1
     assert lib.go1ppo_elu_fwd(None, 0, 0, 0, None, 0, 0, None, 0, 0, None) == -1
+    assert lib.go1ppo_grad_reduce(None, None, 0, None) == -1
+    assert lib.go1ppo_opt_prestep_pieces(None, 0, None, 0, 1.0, None, None, None, None, 1.0, 0.01, 1e-5, 1e-2, None) == -1
 
 
 def test_ppo_loss_args_mirror_matches_header():
@@ -102,10 +104,11 @@ def test_ppo_wgrad_problem_mirror_matches_header():
         if decl:
             names += [n.strip().lstrip("*") for n in re.sub(r"^(const\s+)?\w+\s*\*?", "", decl, count=1).split(",")]
     assert names == [f[0] for f in fused.WgradProblem._fields_]
-    assert C.sizeof(fused.WgradProblem) == 80
+    assert C.sizeof(fused.WgradProblem) == 96
 
 
-@pytest.mark.parametrize("cname,mirror,size", [("Go1PpoGemmArgs", "GemmArgs", 96), ("Go1PpoMlp2Fwd", "Mlp2Fwd", 80), ("Go1PpoMlp2Bwd", "Mlp2Bwd", 88)])
+@pytest.mark.parametrize("cname,mirror,size", [("Go1PpoGemmArgs", "GemmArgs", 96), ("Go1PpoMlp2Fwd", "Mlp2Fwd", 80), ("Go1PpoMlp2Bwd", "Mlp2Bwd", 88),
+                                                ("Go1PpoGradPiece", "GradPiece", 56)])
 def test_ppo_new_struct_mirrors_match_header(cname, mirror, size):
     """field order and size of the ctypes mirrors of the GEMM / LDS-resident MLP argument structs."""
     import ctypes as C

@@ -315,6 +315,110 @@ def test_batched_weight_gradient_structural_zeros(lib, tn):
     torch.testing.assert_close(out[~mask], ref[~mask], rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
 
 
+def test_weight_gradient_slabs_and_their_reduction(lib):
+    """Go1PpoWgradProblem.partials: every row chunk's partial tile goes into its slab with plain stores; go1ppo_grad_reduce sums the
+    slabs (fp32, fixed order: two runs are bit-identical) and the bf16 row-chunk products of a library GEMM into the flat gradient,
+    with the structural zeros; go1ppo_opt_prestep_pieces does the same inside the norm pass — the partials it leaves add up to the
+    squared norm of the WHOLE gradient (summed pieces and plain elements alike)."""
+    from go1_gym_learn.ppo_cse import fused
+    g = torch.Generator(device="cuda").manual_seed(31)
+    M = 8192
+    flat = torch.zeros(200000, device="cuda")
+    plain = torch.randn(flat.numel(), device="cuda", generator=g)
+    shapes = [(256, 192, 1024, (200, 130, 133)), (64, 128, 66560, (0, 0, 0)), (24, 40, 120000, (0, 0, 0))]      # (n, k, offset in the flat gradient, mask)
+    tab = (fused.WgradProblem * len(shapes))()
+    keep, refs = [], []
+    for P, (n, k, off, zero) in zip(tab, shapes):
+        dz, h = bf(torch.randn(M, n, device="cuda", generator=g)), bf(torch.randn(M, k, device="cuda", generator=g))
+        keep.append((dz, h))
+        P.dz, P.h, P.dW, P.bias_grad = dz.data_ptr(), h.data_ptr(), flat[off:].data_ptr(), None
+        P.rows, P.ld_dz, P.ld_h, P.n, P.k, P.ldw = M, n, k, n, k, k
+        P.zero_n, P.zero_k0, P.zero_k1 = zero
+        ref = dz.float().t() @ h.float()
+        ref[:zero[0], zero[1]:zero[2]] = 0
+        refs.append(ref)
+    total = lib.go1ppo_wgrad_tn_plan(tab, len(shapes))
+    assert total > 0
+    pieces = []
+    for P, (n, k, off, zero) in zip(tab, shapes):
+        S = -(-P.rows // P.chunk_rows)
+        ws = torch.zeros(S, n * k, device="cuda")
+        keep.append(ws)
+        P.partials, P.partial_stride = ws.data_ptr(), n * k
+        pieces.append((off, n * k, ws.data_ptr(), n * k, 1, S, k, (0, 0, 0)))
+    assert lib.go1ppo_wgrad_tn_plan(tab, len(shapes)) == total
+    # a bf16 piece: 3 row-chunk products of a (40 x 64) block, structural zeros on rows < 7, columns [13, 30)
+    part = bf(torch.randn(3, 40, 64, device="cuda", generator=g))
+    pieces.append((150000, 40 * 64, part.data_ptr(), 40 * 64, 2, 3, 64, (7, 13, 30)))
+    ref_b = part.float().sum(0)
+    ref_b[:7, 13:30] = 0
+    pieces.sort()
+    arr = (fused.GradPiece * len(pieces))()
+    for A, (begin, count, src, stride, kind, slabs, cols, zero) in zip(arr, pieces):
+        A.begin, A.count, A.src, A.stride, A.kind, A.slabs, A.cols = begin, count, src, stride, kind, slabs, cols
+        A.zero_rows, A.zero_c0, A.zero_c1 = zero
+    dev_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).cuda()
+    dev_pieces = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    in_piece = torch.zeros(flat.numel(), dtype=torch.bool, device="cuda")
+    for begin, count, *_ in pieces:
+        in_piece[begin:begin + count] = True
+
+    def run(reduce):
+        flat.copy_(plain)
+        assert lib.go1ppo_wgrad_tn_batched(dev_tab.data_ptr(), len(shapes), total, stream()) == 0
+        reduce()
+        torch.cuda.synchronize()
+        return flat.clone()
+    a = run(lambda: lib.go1ppo_grad_reduce(flat.data_ptr(), dev_pieces.data_ptr(), len(pieces), stream()))
+    a2 = run(lambda: lib.go1ppo_grad_reduce(flat.data_ptr(), dev_pieces.data_ptr(), len(pieces), stream()))
+    assert torch.equal(a, a2)                                    # fixed summation order
+    assert torch.equal(a[~in_piece], plain[~in_piece])           # nothing outside the pieces is touched
+    for (n, k, off, zero), ref in zip(shapes, refs):
+        got = a[off:off + n * k].view(n, k)
+        torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+        assert bool((got[:zero[0], zero[1]:zero[2]] == 0).all())
+    torch.testing.assert_close(a[150000:150000 + 40 * 64].view(40, 64), ref_b, rtol=1e-6, atol=1e-6)
+    # the same sums inside the optimiser's norm pass (n_norm in front of the last plain elements: they are not counted)
+    n_norm, gscale = 190001, 0.5
+    partial = torch.zeros(lib.go1ppo_opt_partials(), device="cuda")
+    step, lr = torch.zeros(1, device="cuda"), torch.full((1,), 1e-3, device="cuda")
+    b = run(lambda: lib.go1ppo_opt_prestep_pieces(flat.data_ptr(), n_norm, dev_pieces.data_ptr(), len(pieces), gscale, partial.data_ptr(),
+                                                  step.data_ptr(), lr.data_ptr(), None, 1.0, 0.01, 1e-5, 1e-2, stream()))
+    assert torch.equal(a, b)
+    want = float((a[:n_norm].double() * gscale).square().sum())
+    assert abs(float(partial.double().sum()) - want) <= 1e-5 * want
+    assert float(step) == 1.0
+
+
+def test_adam_vector_path_is_the_scalar_path(lib):
+    """go1ppo_opt_adam takes four elements per lane when both ranges start and end on multiples of four; the same step through the
+    general one-element path (ranges cut off the four-element grid) gives the same parameters, moments, compute copies, fp32 tail
+    and transposed copies (to the last bits: rtol 2e-6) — including a body end and a transposed block that are not multiples of four."""
+    from go1_gym_learn.ppo_cse import fused
+    g = torch.Generator(device="cuda").manual_seed(77)
+    n_body, n_std, n = 9998, 12, 10016
+    tr = (4002, 50, 27)
+    results = []
+    for ranges in ([(0, 6000), (6000, 4012)], [(0, 6001), (6001, 4011)]):          # vector path / scalar path over the same elements
+        gg = torch.Generator(device="cuda").manual_seed(78)
+        master = torch.randn(n, device="cuda", generator=gg) * 0.1
+        master.grad = torch.zeros_like(master)
+        body = torch.zeros(n_body, device="cuda", dtype=torch.bfloat16)
+        std = torch.zeros(n_std, device="cuda")
+        opt = fused.FusedAdam(lib, master, body, std, n_body, 1e-3, ranges=ranges)
+        d = torch.full((tr[2], tr[1]), 9.0, device="cuda", dtype=torch.bfloat16)
+        opt.set_transposes([(tr[0], tr[1], tr[2], d)])
+        for it in range(3):
+            master.grad.normal_(generator=gg)
+            opt.step_(max_norm=1.0, zero_grad=True)
+        torch.cuda.synchronize()
+        assert torch.equal(d, body[tr[0]:tr[0] + tr[1] * tr[2]].view(tr[1], tr[2]).t().contiguous())
+        assert bool((master.grad[:n_body + n_std + 2] == 0).all())
+        results.append((master.clone(), opt.m.clone(), opt.v.clone(), body.clone(), std.clone(), d.clone()))
+    for x, y in zip(*results):           # (not bit-identical: the compiler contracts the two instantiations' multiply-adds differently)
+        torch.testing.assert_close(x.float(), y.float(), rtol=2e-6, atol=1e-9)
+
+
 @pytest.mark.parametrize("M", [4096, 1000, 24576])
 def test_fused_tail_forward_matches_layerwise_torch(lib, M):
     """go1ppo_tail_fwd (three layers, activations on chip) vs addmm + ELU per layer in fp32 on the same bf16 data."""

@@ -1,7 +1,13 @@
-"""Probe: which operand layout lets hipBLASLt / rocBLAS run the first-layer weight gradient dW(1280 x 2112) = dY^T X
-(24576 rows) fastest?  TunableOp tunes every variant; buffers rotate so operands come from HBM.  GPU box only."""
+"""Probe: would the first-layer weight gradient dW1 = dY1^T X run faster on hipBLASLt with K-contiguous operands (dY1^T (1280 x M) and
+X^T (2112 x M): the forward GEMM's "Alik_Bljk" layout, 1.39 PFLOP/s in situ) than with the M-major operands it has now ("Ailk_Bjlk",
+0.93 PFLOP/s)?  X^T could be made once per update (the mini-batch blocks are gathered once), dY1^T would cost a transposed store or a
+transpose pass per mini-batch.  Batched over row chunks (manual split-K) and as one GEMM.  GPU box only."""
 import os
 import sys
+R_ = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+P_ = os.path.join(R_, "walk-these-ways_amd")
+for p in (os.path.join(P_, "shims"), P_, R_):
+    sys.path.insert(0, p)
 import torch
 from torch.cuda import tunable
 
@@ -10,20 +16,16 @@ tunable.tuning_enable(True)
 tunable.set_filename("/tmp/wgrad_layouts.csv", insert_device_ordinal=False)
 tunable.set_max_tuning_duration(60)
 tunable.set_rotating_buffer_size(512)
-
-M, N, K = 24576, 1280, 2112
+M, K, N = 24576, 2112, 1280
 bf = dict(device="cuda", dtype=torch.bfloat16)
-R = 4
+R = 3
 dY = [torch.randn(M, N, **bf) for _ in range(R)]
 X = [torch.randn(M, K, **bf) for _ in range(R)]
-dYt = [d.t().contiguous() for d in dY]
-Xt = [x.t().contiguous() for x in X]
-out_nk = torch.zeros(N, K, **bf)
-out_kn = torch.zeros(K, N, **bf)
-out32 = torch.zeros(N, K, device="cuda")
+dYT = [d.t().contiguous() for d in dY]
+XT = [x.t().contiguous() for x in X]
 
 
-def timeit(fns, iters=40, warm=8):
+def timeit(fns, iters=30, warm=6):
     for i in range(warm):
         fns[i % len(fns)]()
     torch.cuda.synchronize()
@@ -37,18 +39,18 @@ def timeit(fns, iters=40, warm=8):
 
 
 gf = 2 * M * N * K / 1e9
-cases = {
-    "dY^T X          (row-strided both, out n x k)": [lambda i=i: torch.mm(dY[i].t(), X[i], out=out_nk) for i in range(R)],
-    "X^T dY          (row-strided both, out k x n)": [lambda i=i: torch.mm(X[i].t(), dY[i], out=out_kn) for i in range(R)],
-    "dYt Xt^T        (K-contiguous both, out n x k)": [lambda i=i: torch.mm(dYt[i], Xt[i].t(), out=out_nk) for i in range(R)],
-    "Xt dYt^T        (K-contiguous both, out k x n)": [lambda i=i: torch.mm(Xt[i], dYt[i].t(), out=out_kn) for i in range(R)],
-    "dYt X           (A K-contiguous, B strided)": [lambda i=i: torch.mm(dYt[i], X[i], out=out_nk) for i in range(R)],
-    "dY^T Xt^T       (A strided, B K-contiguous)": [lambda i=i: torch.mm(dY[i].t(), Xt[i].t(), out=out_nk) for i in range(R)],
-}
-for name, fns in cases.items():
-    t = timeit(fns)
-    print(f"{name:50s} {t:8.1f} us  {gf / t:7.0f} TF/s", flush=True)
-t = timeit([lambda i=i: torch.transpose_copy(dY[i], 0, 1, out=dYt[i]) for i in range(R)])
-print(f"transpose dY (24576 x 1280 bf16)                   {t:8.1f} us")
+for b in (1, 2, 4, 6, 8):
+    m = M // b
+    out = torch.zeros(b, N, K, **bf)
+    cur = [lambda i=i: torch.bmm(dY[i].view(b, m, N).transpose(1, 2), X[i].view(b, m, K), out=out) for i in range(R)]
+    # K-contiguous: A_b = dYT[:, b*m:(b+1)*m] (N x m, row stride M), B_b = XT[:, chunk]^T (m x K given as the transpose of a K-contiguous block)
+    nt = [lambda i=i: torch.bmm(dYT[i].view(N, b, m).permute(1, 0, 2), XT[i].view(K, b, m).permute(1, 2, 0), out=out) for i in range(R)]
+    t0, t1 = timeit(cur), timeit(nt)
+    ref = torch.bmm(dY[0].view(b, m, N).transpose(1, 2).float(), X[0].view(b, m, K).float()).sum(0)
+    nt[0]()
+    err = float((out.float().sum(0) - ref).abs().max() / ref.abs().max())
+    print(f"chunks {b}: M-major operands {t0:7.1f} us ({gf / t0:5.0f} TF/s) | K-contiguous operands {t1:7.1f} us ({gf / t1:5.0f} TF/s)   [check {err:.1e}]", flush=True)
+tr = timeit([lambda i=i: dYT[i].copy_(dY[i].t()) for i in range(R)])
+print(f"transpose pass of dY1 (torch copy_ of a (24576 x 1280) bf16 view): {tr:.1f} us")
 for r in tunable.get_results():
     print(r)

@@ -19,7 +19,7 @@
 #include "../../include/go1ppo.h"
 
 typedef uint16_t bf16_t;
-static_assert(sizeof(Go1PpoAdamExtras) == 56 && sizeof(Go1PpoGemmArgs) == 96 && sizeof(Go1PpoWgradProblem) == 80, "ctypes mirrors (fused.py) assume these sizes");
+static_assert(sizeof(Go1PpoAdamExtras) == 56 && sizeof(Go1PpoGemmArgs) == 96 && sizeof(Go1PpoWgradProblem) == 96 && sizeof(Go1PpoGradPiece) == 56, "ctypes mirrors (fused.py) assume these sizes");
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
@@ -567,12 +567,115 @@ __global__ __launch_bounds__(256) void normalize_kernel(float* adv, int64_t n, c
 //            that the second kernel only reads: step += 1, lr <- schedule(kl, lr).
 //   adam:    p, m, v update over up to two element ranges with the clip factor from the partials; writes the bf16
 //            copy of the updated parameters (and the fp32 tail, the action std) on the way.
-#define OPT_BLOCKS 512
+#define OPT_BLOCKS 2048
+// ---- the flat gradient as pieces (include/go1ppo.h Go1PpoGradPiece): slab pieces are summed in a fixed order (slab 0, 1, ...) into g;
+// NORM: the squared norm of (g * gscale) over [0, n) — plain elements and the fresh sums alike — is returned per thread
+__device__ __forceinline__ float plain_sq(const float* g, int64_t lo, int64_t hi, float gscale, int64_t tid, int64_t nth) {
+  float s = 0.f;
+  if (hi <= lo) return s;
+  int64_t head = ((lo + 3) & ~(int64_t)3);                        // 16-byte loads over the aligned bulk (g itself is 16-byte aligned)
+  if (head > hi) head = hi;
+  const int64_t body4 = (hi - head) >> 2;
+  for (int64_t i = lo + tid; i < head; i += nth) { const float x = g[i] * gscale; s = fmaf(x, x, s); }
+  for (int64_t i = tid; i < body4; i += nth) {
+    const f32x4 x = reinterpret_cast<const f32x4*>(g + head)[i] * gscale;
+    s = fmaf(x[0], x[0], s); s = fmaf(x[1], x[1], s); s = fmaf(x[2], x[2], s); s = fmaf(x[3], x[3], s);
+  }
+  for (int64_t i = head + 4 * body4 + tid; i < hi; i += nth) { const float x = g[i] * gscale; s = fmaf(x, x, s); }
+  return s;
+}
+template <bool NORM>
+__device__ __forceinline__ float grad_pieces_pass(float* g, int64_t n, const Go1PpoGradPiece* __restrict__ pieces, int num_pieces, float gscale) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  float s = 0.f;
+  int64_t cur = 0;
+  for (int q = 0; q <= num_pieces; q++) {
+    const int64_t pb = q < num_pieces ? pieces[q].begin : n;
+    if (NORM) s += plain_sq(g, cur, pb < n ? pb : n, gscale, tid, nth);
+    if (q == num_pieces) break;
+    const Go1PpoGradPiece P = pieces[q];
+    cur = P.begin + P.count;
+    if (P.kind == 0) {
+      if (NORM) s += plain_sq(g, P.begin, cur, gscale, tid, nth);
+      continue;
+    }
+    float* out = g + P.begin;
+    for (int64_t i8 = tid; i8 < (P.count >> 3); i8 += nth) {
+      const int64_t i = i8 << 3;
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (P.kind == 1) {
+        const float* src = (const float*)P.src + i;
+        int b = 0;
+        for (; b + 4 <= P.slabs; b += 4) {                        // four slabs' loads in flight (the sums stay in slab order)
+          f32x4 lo[4], hi[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            lo[u] = reinterpret_cast<const f32x4*>(src + (int64_t)(b + u) * P.stride)[0];
+            hi[u] = reinterpret_cast<const f32x4*>(src + (int64_t)(b + u) * P.stride)[1];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) { acc[e] += lo[u][e]; acc[4 + e] += hi[u][e]; }
+        }
+        for (; b < P.slabs; b++) {
+          const f32x4 lo = reinterpret_cast<const f32x4*>(src + (int64_t)b * P.stride)[0], hi = reinterpret_cast<const f32x4*>(src + (int64_t)b * P.stride)[1];
+#pragma unroll
+          for (int e = 0; e < 4; e++) { acc[e] += lo[e]; acc[4 + e] += hi[e]; }
+        }
+      } else {
+        const bf16_t* src = (const bf16_t*)P.src + i;
+        int b = 0;
+        for (; b + 4 <= P.slabs; b += 4) {
+          Bf8 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const Bf8*>(src + (int64_t)(b + u) * P.stride);
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] += bf2f(v[u].v[e]);
+        }
+        for (; b < P.slabs; b++) {
+          const Bf8 v = *reinterpret_cast<const Bf8*>(src + (int64_t)b * P.stride);
+#pragma unroll
+          for (int e = 0; e < 8; e++) acc[e] += bf2f(v.v[e]);
+        }
+      }
+      if (P.zero_rows > 0) {
+        const int64_t row = i / P.cols;
+        const int c = (int)(i - row * P.cols);
+        if (row < P.zero_rows && c < P.zero_c1 && c + 8 > P.zero_c0) {
+#pragma unroll
+          for (int e = 0; e < 8; e++)
+            if (c + e >= P.zero_c0 && c + e < P.zero_c1) acc[e] = 0.f;
+        }
+      }
+      reinterpret_cast<f32x4*>(out + i)[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+      reinterpret_cast<f32x4*>(out + i)[1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+      if (NORM) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const float x = acc[e] * gscale; s = fmaf(x, x, s); }
+      }
+    }
+  }
+  return s;
+}
+__global__ __launch_bounds__(256) void grad_reduce_kernel(float* g, const Go1PpoGradPiece* __restrict__ pieces, int num_pieces) {
+  grad_pieces_pass<false>(g, 0, pieces, num_pieces, 1.f);
+}
+
 __global__ __launch_bounds__(256) void prestep_kernel(const float* g, int64_t n, float gscale, float* partial, float* step, float* lr,
-                                                      const float* kl, float kl_scale, float desired_kl, float lr_min, float lr_max) {
+                                                      const float* kl, float kl_scale, float desired_kl, float lr_min, float lr_max,
+                                                      const Go1PpoGradPiece* __restrict__ pieces, int num_pieces) {
   __shared__ float red[4];
   float s = 0.f;
-  if (partial) {
+  if (partial && pieces) {
+    s = grad_pieces_pass<true>(const_cast<float*>(g), n, pieces, num_pieces, gscale);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  } else if (partial) {
     const int64_t n4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? n >> 2 : 0;      // 16-byte loads over the aligned bulk
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)OPT_BLOCKS * 256) {
       const f32x4 x = reinterpret_cast<const f32x4*>(g)[i] * gscale;
@@ -597,6 +700,10 @@ __global__ __launch_bounds__(256) void prestep_kernel(const float* g, int64_t n,
   }
 }
 
+// V = 4: four consecutive elements per lane and pass (16-byte loads / stores of p, g, m, v, one 8-byte store of the bf16 copy) — the host picks it when
+// both ranges start and end on multiples of 4 elements and the buffers are 16-byte aligned; V = 1 is the general path.
+// (Measured on MI355X, 3.2 M elements: 34 us with V = 1 — 2.8 TB/s of the 96 MB it moves — see DESIGN.md section 7 for V = 4.)
+template <int V>
 __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m, float* v, int64_t start0, int64_t count0,
                                                    int64_t start1, int64_t count1, float gscale, const float* partial, float max_norm,
                                                    const float* step, const float* lr, float beta1, float beta2, float eps,
@@ -619,10 +726,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m,
   const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
   const float step_size = l / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
   const int64_t total = count0 + count1;
-  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total; j += (int64_t)gridDim.x * 256) {
+  constexpr int64_t CH = 256 * V;                                          // elements per block and pass
+  for (int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V; j < total; j += (int64_t)gridDim.x * CH) {
     const int64_t i = j < count0 ? start0 + j : start1 + (j - count0);
-    // (block-uniform) can any element of this 256-element chunk belong to a transposed block?  first / last element index of the chunk
-    const int64_t j0 = j - threadIdx.x, j1 = j0 + 255 < total ? j0 + 255 : total - 1;
+    // (block-uniform) can any element of this chunk belong to a transposed block?  first / last element index of the chunk
+    const int64_t j0 = j - (int64_t)threadIdx.x * V, j1 = j0 + CH - 1 < total ? j0 + CH - 1 : total - 1;
     const int64_t i0 = j0 < count0 ? start0 + j0 : start1 + (j0 - count0), i1 = j1 < count0 ? start0 + j1 : start1 + (j1 - count0);
     bool tr_chunk = false;
 #pragma unroll
@@ -631,32 +739,62 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m,
         const int64_t ts = ex.transpose[t].start, te = ts + (int64_t)ex.transpose[t].rows * ex.transpose[t].cols;
         tr_chunk = tr_chunk || (j0 < count0) != (j1 < count0) || (i0 < te && i1 >= ts);
       }
-    const float gi = g[i] * gs;
-    if (zero_grad) g[i] = 0.f;          // the next backward pass accumulates into a clean gradient: no separate fill pass
-
-    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float pi = p[i] - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
-    p[i] = pi;
-    if (i < n_body) {
-      const bf16_t pb = f2bf(pi);
-      body[i] = pb;
-      // K-contiguous (transposed) bf16 copies of the weights whose input gradient runs on go1ppo_gemm_nt: kept current here
-      // instead of by a transpose-copy launch per backward pass
+    float gi[V], mi[V], vi[V], pi[V];
+    if constexpr (V == 4) {
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + i), m4 = *reinterpret_cast<const f32x4*>(m + i);
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(v + i), p4 = *reinterpret_cast<const f32x4*>(p + i);
+#pragma unroll
+      for (int e = 0; e < 4; e++) { gi[e] = g4[e]; mi[e] = m4[e]; vi[e] = v4[e]; pi[e] = p4[e]; }
+    } else {
+      gi[0] = g[i]; mi[0] = m[i]; vi[0] = v[i]; pi[0] = p[i];
+    }
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      const float ge = gi[e] * gs;
+      mi[e] = beta1 * mi[e] + (1.f - beta1) * ge;
+      vi[e] = beta2 * vi[e] + (1.f - beta2) * ge * ge;
+      pi[e] = pi[e] - step_size * mi[e] / (sqrtf(vi[e]) * inv_sqrt_bc2 + eps);
+    }
+    if constexpr (V == 4) {
+      if (zero_grad) *reinterpret_cast<f32x4*>(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};      // the next backward pass accumulates into a clean gradient: no separate fill pass
+      *reinterpret_cast<f32x4*>(m + i) = f32x4{mi[0], mi[1], mi[2], mi[3]};
+      *reinterpret_cast<f32x4*>(v + i) = f32x4{vi[0], vi[1], vi[2], vi[3]};
+      *reinterpret_cast<f32x4*>(p + i) = f32x4{pi[0], pi[1], pi[2], pi[3]};
+    } else {
+      if (zero_grad) g[i] = 0.f;
+      m[i] = mi[0]; v[i] = vi[0]; p[i] = pi[0];
+    }
+    bf16_t pb[V];
+#pragma unroll
+    for (int e = 0; e < V; e++) pb[e] = f2bf(pi[e]);
+    if (V == 4 && i + 4 <= n_body) {
+      typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+      *reinterpret_cast<us4_t*>(body + i) = us4_t{pb[0], pb[V > 1 ? 1 : 0], pb[V > 2 ? 2 : 0], pb[V > 3 ? 3 : 0]};
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; e++) {
+        if (i + e < n_body) body[i + e] = pb[e];
+        else if (tail && i + e - n_body < n_tail) tail[i + e - n_body] = pi[e];      // (slots behind the tail — KL, padding — have no compute copy)
+      }
+    }
+    // K-contiguous (transposed) bf16 copies of the weights whose input gradient runs on go1ppo_gemm_nt: kept current here
+    // instead of by a transpose-copy launch per backward pass
+    if (tr_chunk) {
 #pragma unroll
       for (int t = 0; t < GO1PPO_ADAM_MAX_TRANSPOSES; t++) {
-        if (tr_chunk && t < ex.num_transposes) {
-          const uint64_t off = (uint64_t)(i - ex.transpose[t].start);
+        if (t < ex.num_transposes) {
           const uint32_t rows = (uint32_t)ex.transpose[t].rows, cols = (uint32_t)ex.transpose[t].cols;
-          if (off < (uint64_t)rows * cols) {
-            const uint32_t r = (uint32_t)off / cols, c = (uint32_t)off % cols;
-            reinterpret_cast<bf16_t*>(ex.transpose[t].dst)[(size_t)c * rows + r] = pb;
+#pragma unroll
+          for (int e = 0; e < V; e++) {
+            const uint64_t off = (uint64_t)(i + e - ex.transpose[t].start);
+            if (i + e < n_body && off < (uint64_t)rows * cols) {
+              const uint32_t r = (uint32_t)off / cols, c = (uint32_t)off % cols;
+              reinterpret_cast<bf16_t*>(ex.transpose[t].dst)[(size_t)c * rows + r] = pb[e];
+            }
           }
         }
       }
-    } else if (tail && i - n_body < n_tail) tail[i - n_body] = pi;      // (slots behind the tail — KL, padding — have no compute copy)
+    }
   }
   if (zero_slot && blockIdx.x == 0 && threadIdx.x == 0) *zero_slot = 0.f;
 }
@@ -1041,7 +1179,22 @@ extern "C" int go1ppo_opt_prestep(const float* g, int64_t n, float gscale, float
                                   float kl_scale, float desired_kl, float lr_min, float lr_max, void* stream) {
   if (!step || (partial && (!g || n <= 0)) || (kl && !lr)) return -1;
   prestep_kernel<<<dim3(partial ? OPT_BLOCKS : 1), dim3(256), 0, (hipStream_t)stream>>>(g, n, gscale, partial, step, lr, kl, kl_scale,
-                                                                                       desired_kl, lr_min, lr_max);
+                                                                                       desired_kl, lr_min, lr_max, nullptr, 0);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_opt_prestep_pieces(float* g, int64_t n, const Go1PpoGradPiece* device_pieces, int num_pieces, float gscale, float* partial,
+                                         float* step, float* lr, const float* kl, float kl_scale, float desired_kl, float lr_min, float lr_max,
+                                         void* stream) {
+  if (!step || !partial || !g || n <= 0 || (kl && !lr) || !device_pieces || num_pieces <= 0 || !aligned16(g)) return -1;
+  prestep_kernel<<<dim3(OPT_BLOCKS), dim3(256), 0, (hipStream_t)stream>>>(g, n, gscale, partial, step, lr, kl, kl_scale, desired_kl, lr_min, lr_max,
+                                                                         device_pieces, num_pieces);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_grad_reduce(float* g, const Go1PpoGradPiece* device_pieces, int num_pieces, void* stream) {
+  if (!g || !device_pieces || num_pieces <= 0 || !aligned16(g)) return -1;
+  grad_reduce_kernel<<<dim3(OPT_BLOCKS), dim3(256), 0, (hipStream_t)stream>>>(g, device_pieces, num_pieces);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
@@ -1063,10 +1216,18 @@ extern "C" int go1ppo_opt_adam(float* p, float* g, float* m, float* v, int64_t s
     return 0;
   }
   int64_t total = count0 + count1;
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  adam_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, start0, count0, start1, count1, gscale, partial,
-                                                                             max_norm, step, lr, beta1, beta2, eps, (bf16_t*)body, n_body, tail, n_tail, zero_grad, zero_slot, ex);
+  const bool vec = !((start0 | count0 | start1 | count1) & 3) && aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && aligned16(body);
+  if (vec) {
+    int64_t blocks = (total / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    adam_kernel<4><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, start0, count0, start1, count1, gscale, partial, max_norm, step, lr,
+                                                                                  beta1, beta2, eps, (bf16_t*)body, n_body, tail, n_tail, zero_grad, zero_slot, ex);
+  } else {
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    adam_kernel<1><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, start0, count0, start1, count1, gscale, partial, max_norm, step, lr,
+                                                                                  beta1, beta2, eps, (bf16_t*)body, n_body, tail, n_tail, zero_grad, zero_slot, ex);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
@@ -1138,7 +1299,7 @@ extern "C" int go1ppo_wgrad_plan(Go1PpoWgradProblem* probs, int count) {
   int total = 0;
   for (int i = 0; i < count; i++) {
     Go1PpoWgradProblem& P = probs[i];
-    if (!P.dz || !P.h || !P.dW || P.rows <= 0 || P.n <= 0 || P.k <= 0 || (P.n & 63) || (P.k & 63) || (P.ld_dz & 7) || (P.ld_h & 7) ||
+    if (!P.dz || !P.h || !P.dW || P.partials || P.rows <= 0 || P.n <= 0 || P.k <= 0 || (P.n & 63) || (P.k & 63) || (P.ld_dz & 7) || (P.ld_h & 7) ||
         !aligned16(P.dz) || !aligned16(P.h))
       return -1;
     int64_t S, chunk_steps;
@@ -1156,4 +1317,4 @@ extern "C" int go1ppo_wgrad_batched(const Go1PpoWgradProblem* device_probs, int 
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
-extern "C" const char* go1ppo_version(void) { return "go1ppo 0.2 (gfx950, abi 2)"; }
+extern "C" const char* go1ppo_version(void) { return "go1ppo 0.3 (gfx950, abi 3)"; }

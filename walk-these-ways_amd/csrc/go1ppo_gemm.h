@@ -27,8 +27,7 @@ __device__ __forceinline__ void glds16(const bf16_t* g, bf16_t* lds_wave_base) {
 }
 
 template <int EPI>   // 0: bias only, 1: bias + ELU on [elu_c0, elu_c1), 2: times elu'(H)
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(Go1PpoGemmArgs a) {
-  __shared__ __attribute__((aligned(1024))) bf16_t lds[2][2][GEMM_BM * GEMM_BK];   // [buffer][A|B][row][64]
+__device__ __forceinline__ void gemm_nt_body(const Go1PpoGemmArgs& a, bf16_t (*lds)[2][GEMM_BM * GEMM_BK]) {   // lds: [buffer][A|B][row][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // ---- XCD-aware tile index (bijective for any grid size)
   const int nwg = gridDim.x, orig = blockIdx.x;
@@ -152,13 +151,51 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(Go1PpoGemmArgs a) {
   }
 }
 
-extern "C" int go1ppo_gemm_nt(const Go1PpoGemmArgs* a, void* stream) {
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(Go1PpoGemmArgs a) {
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[2][2][GEMM_BM * GEMM_BK];
+  gemm_nt_body<EPI>(a, lds);
+}
+// two independent problems with the same tile grid in ONE launch (blockIdx.y picks the problem): the actor's and the critic's
+// 512 -> 256 layers.  As two launches on two streams they cost a graph fork and a join (5-10 us of idle device each, tools/timeline.py)
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_pair_kernel(Go1PpoGemmArgs a, Go1PpoGemmArgs b) {
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[2][2][GEMM_BM * GEMM_BK];
+  gemm_nt_body<EPI>(blockIdx.y == 0 ? a : b, lds);
+}
+
+static int gemm_nt_check(const Go1PpoGemmArgs* a) {
   if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return -1;
   if ((a->K % GEMM_BK) || (a->N & 3) || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 3) || !aligned16(a->A) || !aligned16(a->B) ||
       ((uintptr_t)a->C & 7))
     return -2;
   if (a->epilogue == 2 && (!a->H || (a->ldh & 3) || ((uintptr_t)a->H & 7))) return -3;
   if (a->bias && ((uintptr_t)a->bias & (a->bias_bf16 ? 7 : 15))) return -4;
+  return 0;
+}
+
+extern "C" int go1ppo_gemm_nt_pair(const Go1PpoGemmArgs* a, const Go1PpoGemmArgs* b, void* stream) {
+  int rc = gemm_nt_check(a);
+  if (rc == 0) rc = gemm_nt_check(b);
+  if (rc) return rc;
+  const int64_t tiles = (int64_t)((a->M + GEMM_BM - 1) / GEMM_BM) * ((a->N + GEMM_BN - 1) / GEMM_BN);
+  const int64_t tiles_b = (int64_t)((b->M + GEMM_BM - 1) / GEMM_BM) * ((b->N + GEMM_BN - 1) / GEMM_BN);
+  if (tiles > INT32_MAX) return -5;
+  if (tiles != tiles_b || a->epilogue != b->epilogue) return -7;      // same tile grid, same epilogue
+  dim3 grid((unsigned)tiles, 2), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (a->epilogue) {
+    case 0: gemm_nt_pair_kernel<0><<<grid, block, 0, s>>>(*a, *b); break;
+    case 1: gemm_nt_pair_kernel<1><<<grid, block, 0, s>>>(*a, *b); break;
+    case 2: gemm_nt_pair_kernel<2><<<grid, block, 0, s>>>(*a, *b); break;
+    default: return -6;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
+extern "C" int go1ppo_gemm_nt(const Go1PpoGemmArgs* a, void* stream) {
+  const int rc = gemm_nt_check(a);
+  if (rc) return rc;
   int64_t tiles = (int64_t)((a->M + GEMM_BM - 1) / GEMM_BM) * ((a->N + GEMM_BN - 1) / GEMM_BN);
   if (tiles > INT32_MAX) return -5;
   dim3 grid((unsigned)tiles), block(256);
@@ -236,7 +273,7 @@ __device__ __forceinline__ bf16x8_t tn_operand(const TnFrags& f, int i) {
 
 __device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf16_t* Q, int ldq, int64_t m_begin, int steps,
                                               float* C, int ldc, float* bias_grad, int N, int K, int n0, int k0,
-                                              bf16_t (*lds)[2][WTN_STEP * WTN_T], int zero_n, int zero_k0, int zero_k1) {
+                                              bf16_t (*lds)[2][WTN_STEP * WTN_T], int zero_n, int zero_k0, int zero_k1, bool slab) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // ---- staging: wave w moves row blocks (4 rows of 256 B each) 2w, 2w+1 of both operand tiles
   const bf16_t* gp[2];
@@ -341,11 +378,10 @@ __device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf
 #pragma unroll
       for (int b = 0; b < 2; b++) {
         const int k = k0 + wk * 32 + b * 16 + i16;
-#ifdef WTN_PROBE_PLAIN_STORES          /* timing probe only (tools/bench_gemm.py with GO1PPO_LIB): what the fp32 atomics of the partial tiles cost */
-        if (k < K && !(n < zero_n && k >= zero_k0 && k < zero_k1)) C[(int64_t)n * ldc + k] = acc[a][b][e];
-#else
-        if (k < K && !(n < zero_n && k >= zero_k0 && k < zero_k1)) atomicAdd(C + (int64_t)n * ldc + k, acc[a][b][e]);
-#endif
+        if (k < K && !(n < zero_n && k >= zero_k0 && k < zero_k1)) {
+          if (slab) C[(int64_t)n * ldc + k] = acc[a][b][e];           // this row chunk's slab (Go1PpoWgradProblem.partials): summed by the reduction pass
+          else atomicAdd(C + (int64_t)n * ldc + k, acc[a][b][e]);
+        }
       }
       if (do_bias && i16 == 0) atomicAdd(bias_grad + n, bacc[a][e]);
     }
@@ -369,8 +405,10 @@ __global__ __launch_bounds__(WTN_THREADS, 1) void wgrad_tn_batched_kernel(const 
   const int tile = local % tiles, split = local / tiles;
   const int64_t m_begin = (int64_t)split * P.chunk_rows;
   const int64_t m_end = m_begin + P.chunk_rows < P.rows ? m_begin + P.chunk_rows : P.rows;
-  wgrad_tn_body((const bf16_t*)P.dz, P.ld_dz, (const bf16_t*)P.h, P.ld_h, m_begin, (int)((m_end - m_begin) / WTN_STEP), P.dW, P.ldw,
-                P.bias_grad, P.n, P.k, (tile / tiles_k) * WTN_T, (tile % tiles_k) * WTN_T, lds, P.zero_n, P.zero_k0, P.zero_k1);
+  const bool slab = P.partials != nullptr;
+  wgrad_tn_body((const bf16_t*)P.dz, P.ld_dz, (const bf16_t*)P.h, P.ld_h, m_begin, (int)((m_end - m_begin) / WTN_STEP),
+                slab ? P.partials + (int64_t)split * P.partial_stride : P.dW, P.ldw, P.bias_grad, P.n, P.k, (tile / tiles_k) * WTN_T,
+                (tile % tiles_k) * WTN_T, lds, P.zero_n, P.zero_k0, P.zero_k1, slab);
 }
 
 extern "C" int go1ppo_wgrad_tn_plan(Go1PpoWgradProblem* probs, int count) {
@@ -378,7 +416,7 @@ extern "C" int go1ppo_wgrad_tn_plan(Go1PpoWgradProblem* probs, int count) {
   int64_t tile_steps = 0, tiles = 0;
   for (int i = 0; i < count; i++) {
     Go1PpoWgradProblem& P = probs[i];
-    if (!P.dz || !P.h || !P.dW || P.rows <= 0 || (P.rows % WTN_STEP) || P.n < 8 || P.k < 8 || (P.n & 7) || (P.k & 7) ||
+    if (!P.dz || !P.h || (!P.dW && !P.partials) || (P.partials && P.partial_stride < (int64_t)P.n * P.ldw) || P.rows <= 0 || (P.rows % WTN_STEP) || P.n < 8 || P.k < 8 || (P.n & 7) || (P.k & 7) ||
         (P.ld_dz & 7) || (P.ld_h & 7) || !aligned16(P.dz) || !aligned16(P.h) || P.zero_n < 0 || P.zero_k0 < 0 || P.zero_k1 < P.zero_k0)
       return -1;
     const int64_t t = (int64_t)((P.n + WTN_T - 1) / WTN_T) * ((P.k + WTN_T - 1) / WTN_T);

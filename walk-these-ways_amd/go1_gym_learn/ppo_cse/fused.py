@@ -42,7 +42,14 @@ class WgradProblem(ctypes.Structure):
     _fields_ = [("dz", ctypes.c_void_p), ("h", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("bias_grad", ctypes.c_void_p),
                 ("rows", ctypes.c_int64), ("ld_dz", ctypes.c_int32), ("ld_h", ctypes.c_int32), ("n", ctypes.c_int32),
                 ("k", ctypes.c_int32), ("ldw", ctypes.c_int32), ("chunk_rows", ctypes.c_int32), ("wg_offset", ctypes.c_int32),
-                ("zero_n", ctypes.c_int32), ("zero_k0", ctypes.c_int32), ("zero_k1", ctypes.c_int32)]
+                ("zero_n", ctypes.c_int32), ("zero_k0", ctypes.c_int32), ("zero_k1", ctypes.c_int32),
+                ("partials", ctypes.c_void_p), ("partial_stride", ctypes.c_int64)]
+
+
+class GradPiece(ctypes.Structure):
+    _fields_ = [("begin", ctypes.c_int64), ("count", ctypes.c_int64), ("src", ctypes.c_void_p), ("stride", ctypes.c_int64),
+                ("kind", ctypes.c_int32), ("slabs", ctypes.c_int32), ("cols", ctypes.c_int32), ("zero_rows", ctypes.c_int32),
+                ("zero_c0", ctypes.c_int32), ("zero_c1", ctypes.c_int32)]
 
 
 class TailLayer(ctypes.Structure):
@@ -88,10 +95,10 @@ class AdamExtras(ctypes.Structure):
     _fields_ = [("num_transposes", ctypes.c_int32), ("_pad", ctypes.c_int32), ("transpose", _AdamTranspose * 2)]
 
 
-EXPORTED_SYMBOLS = ["go1ppo_mlp2_fwd", "go1ppo_mlp2_bwd", "go1ppo_gemm_nt", "go1ppo_sum_partials", "go1ppo_wgrad_tn_plan", "go1ppo_wgrad_tn_batched", "go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
+EXPORTED_SYMBOLS = ["go1ppo_mlp2_fwd", "go1ppo_mlp2_bwd", "go1ppo_gemm_nt", "go1ppo_gemm_nt_pair", "go1ppo_sum_partials", "go1ppo_wgrad_tn_plan", "go1ppo_wgrad_tn_batched", "go1ppo_tail_fwd", "go1ppo_elu_fwd", "go1ppo_elu_bwd", "go1ppo_loss", "go1ppo_mse", "go1ppo_wgrad", "go1ppo_wgrad_plan",
                     "go1ppo_wgrad_batched", "go1ppo_act",
                     "go1ppo_store_step", "go1ppo_ring_snapshot", "go1ppo_ring_step", "go1ppo_ring_gather", "go1ppo_gae", "go1ppo_normalize", "go1ppo_opt_partials", "go1ppo_opt_prestep",
-                    "go1ppo_opt_adam", "go1ppo_version"]
+                    "go1ppo_opt_prestep_pieces", "go1ppo_grad_reduce", "go1ppo_opt_adam", "go1ppo_version"]
 
 
 def load_library(path=None):
@@ -113,6 +120,7 @@ def load_library(path=None):
     L.go1ppo_wgrad_plan.argtypes = [ctypes.POINTER(WgradProblem), i32]
     L.go1ppo_tail_fwd.argtypes = [ctypes.POINTER(TailArgs), vp]
     L.go1ppo_gemm_nt.argtypes = [ctypes.POINTER(GemmArgs), vp]
+    L.go1ppo_gemm_nt_pair.argtypes = [ctypes.POINTER(GemmArgs), ctypes.POINTER(GemmArgs), vp]
     L.go1ppo_sum_partials.argtypes = [vp, i32, i64, i64, i32, vp, i32, i32, i32, vp]
     L.go1ppo_mlp2_fwd.argtypes = [ctypes.POINTER(Mlp2Fwd), i32, vp]
     L.go1ppo_mlp2_bwd.argtypes = [ctypes.POINTER(Mlp2Bwd), i32, vp]
@@ -129,6 +137,8 @@ def load_library(path=None):
     L.go1ppo_normalize.argtypes = [vp, i64, vp, vp]
     L.go1ppo_opt_partials.argtypes = []
     L.go1ppo_opt_prestep.argtypes = [vp, i64, f32, vp, vp, vp, vp, f32, f32, f32, f32, vp]
+    L.go1ppo_opt_prestep_pieces.argtypes = [vp, i64, vp, i32, f32, vp, vp, vp, vp, f32, f32, f32, f32, vp]
+    L.go1ppo_grad_reduce.argtypes = [vp, vp, i32, vp]
     L.go1ppo_opt_adam.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, f32, vp, f32, vp, vp, f32, f32, f32, vp, i64, vp, i64, i32, vp,
                                   ctypes.POINTER(AdamExtras), vp]
     for name in EXPORTED_SYMBOLS[:-1]:
@@ -183,6 +193,12 @@ def gemm_nt(lib, a, b, c, bias=None, elu=None, elu_bwd_of=None):
     return c
 
 
+def gemm_nt_pair(lib, first, second):
+    """two go1ppo_gemm_nt problems with the same tile grid and epilogue in one launch; first / second: keyword dicts of gemm_args"""
+    ga, gb = gemm_args(**first), gemm_args(**second)
+    _chk(lib.go1ppo_gemm_nt_pair(ctypes.byref(ga), ctypes.byref(gb), _stream()), "go1ppo_gemm_nt_pair")
+
+
 class FusedNet:
     """Static-buffer forward (and optionally backward) of the three MLPs for a fixed row count M.
 
@@ -205,6 +221,14 @@ class FusedNet:
                   for n, d in self.depth.items()}
         assert policy.npv <= HEAD and self.P["Wz"].shape == (self.na, HEAD)
         self._recording, self._batched, self._plans = None, False, {}
+        # weight gradients as per-row-chunk SLABS (plain stores) summed in a fixed order by one pass — the optimiser's norm pass when
+        # `defer_grad_sum` is set by the owner (FusedAdam.step_(pieces=...)), go1ppo_grad_reduce at the end of the backward pass
+        # otherwise — instead of fp32 atomics into the flat gradient (15.6 of the 64.5 us of the PPO pass's batched launch on MI355X,
+        # profiles/r04_wgrad_atomics_probe.txt; and run-to-run reproducible).  GO1_WGRAD_SLABS=0: the atomics.
+        self._grad = grad
+        self._slabs = grad is not None and os.environ.get("GO1_WGRAD_SLABS", "1") == "1"
+        self.defer_grad_sum = False
+        self._rec_pieces, self._slab_ws, self._last_pieces = None, {}, {}
         # weight gradients: 128-tile kernel for the batched tails; first layer (PPO pass, adaptation pass) on it or on
         # hipBLASLt.  GO1_WGRAD = "<tails><ppo W1><adaptation W1>" digits for A/B runs (tools/), default below.
         knob = os.environ.get("GO1_WGRAD", "101")
@@ -237,6 +261,9 @@ class FusedNet:
         #  its epilogue measured 135-140 us — bound by the L2 -> LDS staging rate of ~10.5 TB/s chip-wide, tools/probes/gemm256_probe.hip,
         #  DESIGN.md section 7 — and was withdrawn)
         self._l1_nt = os.environ.get("GO1_L1_NT", "1") == "1"
+        # the actor's and the critic's 512 -> 256 GEMMs (forward, input gradient) as one launch each instead of two launches on two
+        # streams: tools/timeline.py showed 5-10 us of idle device at every graph fork and join (GO1_GEMM_PAIR=0: the two streams)
+        self._pair = os.environ.get("GO1_GEMM_PAIR", "1") == "1"
         # the critic's tail is independent of the actor / adaptation chain: it runs on a side stream (forked from and
         # joined back into the caller's stream, so HIP-graph capture records it as a parallel branch)
         self._side = torch.cuda.Stream(device=dev) if two_streams else None
@@ -398,7 +425,11 @@ class FusedNet:
         self._mlp2_fwd("adaptation", [("adaptation", self.Y1[:, :nd])])
         latent = Z["adaptation"][2]
         self._elu(self.Y1[:, nd:], latent, na)
-        if self._l1_nt:
+        if self._l1_nt and self._pair:
+            # actor's and critic's 512 -> 256 layers as ONE launch: no graph fork / join around them
+            gemm_nt_pair(self.lib, dict(a=self.Y1[:, nd:nd + na], b=P["actor.1.W"], c=Z["actor"][1], bias=P["actor.1.b"]),
+                         dict(a=self.Y1[:, nd + na:], b=P["critic.1.W"], c=Z["critic"][1], bias=P["critic.1.b"]))
+        elif self._l1_nt:
             # the 512 -> 256 layers on go1ppo_gemm_nt (bias in the epilogue; measured 16 us against hipBLASLt's 31 at 24576 rows)
             with self._branch():
                 gemm_nt(self.lib, self.Y1[:, nd + na:], P["critic.1.W"], Z["critic"][1], P["critic.1.b"])
@@ -420,7 +451,10 @@ class FusedNet:
             self._wgrad(dZ[net][3], Z[net][2], G[f"{net}.3.W"], None)
             self._wgrad(dZ[net][2], Z[net][1], G[f"{net}.2.W"], G[f"{net}.2.b"])
             self._wgrad(dZ[net][1], Y1[:, cols[net]], G[f"{net}.1.W"], G[f"{net}.1.b"])
-        if self._dgrad_nt:
+        if self._dgrad_nt and self._pair and self._wt_by_optimizer:
+            gemm_nt_pair(self.lib, dict(a=dZ["actor"][1], b=self._WT["actor"], c=dY1[:, cols["actor"]], elu_bwd_of=Y1[:, cols["actor"]]),
+                         dict(a=dZ["critic"][1], b=self._WT["critic"], c=dY1[:, cols["critic"]], elu_bwd_of=Y1[:, cols["critic"]]))
+        elif self._dgrad_nt:
             # input gradient of the 512 -> 256 layers with the ELU-backward factor of the first layer folded into the GEMM's
             # epilogue (go1ppo_gemm_nt, epilogue 2): dY1 = (dz1 W) * elu'(h1) in one pass per net instead of a hipBLASLt GEMM
             # + an element-wise pass over (M x 512).  The kernel wants the weight K-contiguous: W^T, refreshed here (256 KB).
@@ -486,11 +520,13 @@ class FusedNet:
             import contextlib
             return contextlib.nullcontext()
         self._side.wait_stream(torch.cuda.current_stream())
+        self._forked = True
         return torch.cuda.stream(self._side)
 
     def _join(self):
-        if self._side is not None:
+        if self._side is not None and getattr(self, "_forked", False):      # (nothing to wait for when no branch was opened since the last join)
             torch.cuda.current_stream().wait_stream(self._side)
+            self._forked = False
 
     def forward_adaptation(self, x):
         if self._mlp2:
@@ -537,16 +573,32 @@ class FusedNet:
             torch.bmm(dY.view(b, dY.shape[0] // b, dY.shape[1]).transpose(1, 2), x.view(b, x.shape[0] // b, x.shape[1]), out=tmp)
             part, count, stride = tmp, b, tmp.stride(0)
         assert gW.is_contiguous() and part.stride(-1) == 1 and part.stride(-2) == gW.shape[1]
+        if self._slabs and (self._recording is not None or self._batched):      # summed with the other slab pieces of the pass
+            if self._rec_pieces is not None:
+                self._rec_pieces.append(dict(begin=self._grad_offset(gW), count=gW.numel(), src=part, stride=stride, kind=2, slabs=count,
+                                             cols=gW.shape[1], zero=(zr, zc0, zc1)))
+            return
         _chk(self.lib.go1ppo_sum_partials(part.data_ptr(), count, stride, gW.shape[0], gW.shape[1], gW.data_ptr(), zr, zc0, zc1, _stream()),
              "go1ppo_sum_partials")
+
+    def _grad_offset(self, view):
+        off = (view.data_ptr() - self._grad.data_ptr()) // 4
+        assert view.dtype == torch.float32 and view.is_contiguous() and 0 <= off and off + view.numel() <= self._grad.numel()
+        return int(off)
+
+    def last_pieces(self, kind):
+        """(device table, count) of the slab pieces the last backward pass of this kind ("ppo" / "adaptation") left unsummed
+        (defer_grad_sum), or None"""
+        return self._last_pieces.get(kind)
 
     def _run_planned(self, key, fn):
         """first call: run `fn` recording its weight-gradient problems (nothing launched for them), build the device
         table; every call: run `fn` with the per-layer launches suppressed, then the one batched launch."""
         if key not in self._plans:
-            self._recording = []
+            self._recording, self._rec_pieces = [], []
             fn()
             rec, self._recording = self._recording, None
+            pieces, self._rec_pieces = self._rec_pieces, None
             tab = (WgradProblem * len(rec))()
             for P, (dz, h, gW, gb, zero) in zip(tab, rec):
                 P.dz, P.h, P.dW, P.bias_grad = dz.data_ptr(), h.data_ptr(), gW.data_ptr(), _ptr(gb)
@@ -554,11 +606,36 @@ class FusedNet:
                     P.zero_n, P.zero_k0, P.zero_k1 = zero
                 P.rows, P.ld_dz, P.ld_h, P.n, P.k, P.ldw = dz.shape[0], _ld(dz), _ld(h), dz.shape[1], h.shape[1], gW.shape[1]
             tn = self._wgrad_tn and all(P.rows % 64 == 0 and P.n % 8 == 0 and P.k % 8 == 0 for P in tab)
-            total = (self.lib.go1ppo_wgrad_tn_plan if tn else self.lib.go1ppo_wgrad_plan)(tab, len(rec))
+            plan = self.lib.go1ppo_wgrad_tn_plan if tn else self.lib.go1ppo_wgrad_plan
+            total = plan(tab, len(rec))
             if total <= 0:
                 raise RuntimeError(f"go1ppo_wgrad_plan failed with code {total}")
+            if tn and self._slabs:
+                # one fp32 slab per row chunk and problem (shared by the plans of the same pass: graph mode keeps one plan per
+                # pre-gathered input block); zero-initialised and never written on the structural zeros
+                for j, (P, (dz, h, gW, gb, zero)) in enumerate(zip(tab, rec)):
+                    S = -(-P.rows // P.chunk_rows)
+                    ws = self._slab_ws.get((key[0], j))
+                    if ws is None or tuple(ws.shape) != (S, gW.numel()):
+                        ws = self._slab_ws[(key[0], j)] = torch.zeros(S, gW.numel(), device=gW.device, dtype=torch.float32)
+                    P.partials, P.partial_stride = ws.data_ptr(), gW.numel()
+                    pieces.append(dict(begin=self._grad_offset(gW), count=gW.numel(), src=ws, stride=gW.numel(), kind=1, slabs=S, cols=gW.shape[1],
+                                       zero=(0, 0, 0)))
+                if plan(tab, len(rec)) != total:
+                    raise RuntimeError("go1ppo_wgrad_tn_plan: the plan changed with the slab buffers attached")
             dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.Y1.device)
-            self._plans[key] = (dev, len(rec), total, rec, tn)
+            ptab = None
+            if pieces:
+                pieces.sort(key=lambda q: q["begin"])
+                arr = (GradPiece * len(pieces))()
+                end = 0
+                for A, q in zip(arr, pieces):
+                    assert q["begin"] >= end and q["begin"] % 8 == 0 and q["count"] % 8 == 0 and q["stride"] % 8 == 0, "slab pieces: ascending, disjoint, multiples of 8"
+                    end = q["begin"] + q["count"]
+                    A.begin, A.count, A.src, A.stride, A.kind, A.slabs, A.cols = q["begin"], q["count"], q["src"].data_ptr(), q["stride"], q["kind"], q["slabs"], q["cols"]
+                    A.zero_rows, A.zero_c0, A.zero_c1 = q["zero"]
+                ptab = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.Y1.device), len(pieces), [q["src"] for q in pieces])
+            self._plans[key] = (dev, len(rec), total, rec, tn, ptab)
             # the recording pass skipped the launches AND ran the rest of fn: its dgrad results are valid, only the
             # weight gradients are missing -> fall through to the batched launch
         else:
@@ -568,11 +645,23 @@ class FusedNet:
             finally:
                 self._batched, self._plan_key = False, None
             if self._plan_launched:          # fn() put the batched launch on the side stream next to the first-layer GEMM
+                self._finish_pieces(key)
                 return
         self._launch_plan(key)
+        self._finish_pieces(key)
+
+    def _finish_pieces(self, key):
+        ptab = self._plans[key][5]
+        self._last_pieces[key[0]] = None
+        if ptab is None:
+            return
+        if self.defer_grad_sum:
+            self._last_pieces[key[0]] = ptab[:2]
+        else:
+            _chk(self.lib.go1ppo_grad_reduce(self._grad.data_ptr(), ptab[0].data_ptr(), ptab[1], _stream()), "go1ppo_grad_reduce")
 
     def _launch_plan(self, key):
-        dev, count, total, _, tn = self._plans[key]
+        dev, count, total, _, tn, _ = self._plans[key]
         launch = self.lib.go1ppo_wgrad_tn_batched if tn else self.lib.go1ppo_wgrad_batched
         _chk(launch(dev.data_ptr(), count, total, _stream()), "go1ppo_wgrad_batched")
 
@@ -757,15 +846,21 @@ class FusedAdam:
         self.r0, self.r1 = r[0], r[1]
 
     def step_(self, gscale=1.0, max_norm=None, kl=None, kl_scale=1.0, desired_kl=0.01, lr_min=1e-5, lr_max=1e-2, zero_grad=False,
-              zero_slot=None, between=None):
+              zero_slot=None, between=None, pieces=None):
         """zero_grad: clear the visited gradient elements (and `zero_slot`, a one-element tensor) inside the Adam kernel.
         between: called between the two kernels with the per-block partial sums of the squared gradient norm — a sharded
         step all-reduces them there, so that every rank clips by the GLOBAL norm."""
         g = self.master.grad
         clip = max_norm is not None
-        _chk(self.lib.go1ppo_opt_prestep(g.data_ptr(), self.n_norm, gscale, self.partial.data_ptr() if clip else None,
-                                         self.step.data_ptr(), self.lr.data_ptr(), _ptr(kl), kl_scale, desired_kl, lr_min, lr_max,
-                                         _stream()), "go1ppo_opt_prestep")
+        if pieces is not None:
+            # pieces = FusedNet.last_pieces(kind): weight-gradient slabs the backward pass left unsummed — summed into g by the norm pass
+            _chk(self.lib.go1ppo_opt_prestep_pieces(g.data_ptr(), self.n_norm, pieces[0].data_ptr(), pieces[1], gscale, self.partial.data_ptr(),
+                                                    self.step.data_ptr(), self.lr.data_ptr(), _ptr(kl), kl_scale, desired_kl, lr_min, lr_max,
+                                                    _stream()), "go1ppo_opt_prestep_pieces")
+        else:
+            _chk(self.lib.go1ppo_opt_prestep(g.data_ptr(), self.n_norm, gscale, self.partial.data_ptr() if clip else None,
+                                             self.step.data_ptr(), self.lr.data_ptr(), _ptr(kl), kl_scale, desired_kl, lr_min, lr_max,
+                                             _stream()), "go1ppo_opt_prestep")
         if between is not None:
             between(self.partial)
         _chk(self.lib.go1ppo_opt_adam(self.master.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.r0[0], self.r0[1],

@@ -487,7 +487,8 @@ class PPO:
             w = float(_world()) if self.dp else 1.0
             self._opt.step_(gscale=1.0 / w, max_norm=A.max_grad_norm, kl=self._kl if adaptive else None, kl_scale=1.0 / w,
                             desired_kl=A.desired_kl if adaptive else 0.0, zero_grad=True, zero_slot=self._kl,
-                            between=(lambda partial: dist.all_reduce(partial)) if sharded else None)
+                            between=(lambda partial: dist.all_reduce(partial)) if sharded else None,
+                            pieces=self._train_net.last_pieces("ppo") if self._train_net is not None else None)
             if sharded:
                 self._dp_gather_params()
             return
@@ -530,7 +531,8 @@ class PPO:
 
     def _stage_adapt_step(self):
         if self._opt_ad is not None:
-            self._opt_ad.step_(gscale=1.0 / float(_world()) if self.dp else 1.0, zero_grad=True)
+            self._opt_ad.step_(gscale=1.0 / float(_world()) if self.dp else 1.0, zero_grad=True,
+                               pieces=self._train_net.last_pieces("adaptation") if self._train_net is not None else None)
             return
         if self.dp:
             self.master.grad.div_(_world())
@@ -661,6 +663,9 @@ class PPO:
             if self.fused:
                 from go1_gym_learn.ppo_cse.fused import FusedNet
                 self._train_net = FusedNet(self.policy, self.body, self.master.grad[:self.n_body], mb, self._fused_lib, with_grad=True)
+                # single process: the weight-gradient slabs of a backward pass are summed by the optimiser's norm pass (no reduction
+                # launch); data parallel: the all-reduce between the two needs the finished gradient
+                self._train_net.defer_grad_sum = not self.dp
                 # the optimiser step that changes actor.1 / critic.1 also rewrites their K-contiguous copies (the input-gradient GEMM's
                 # operand): no transpose-copy launches in the backward pass.  Not with the sharded step, whose ranks step slices only.
                 tr = self._train_net.adam_transposes()
