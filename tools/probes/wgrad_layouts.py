@@ -22,7 +22,6 @@ R = 3
 dY = [torch.randn(M, N, **bf) for _ in range(R)]
 X = [torch.randn(M, K, **bf) for _ in range(R)]
 dYT = [d.t().contiguous() for d in dY]
-XT = [x.t().contiguous() for x in X]
 
 
 def timeit(fns, iters=30, warm=6):
@@ -38,18 +37,22 @@ def timeit(fns, iters=30, warm=6):
     return a.elapsed_time(b) / iters * 1e3
 
 
-gf = 2 * M * N * K / 1e9
+gf = 2 * M * N * K / 1e3        # -> TFLOP/s with microseconds
 for b in (1, 2, 4, 6, 8):
     m = M // b
     out = torch.zeros(b, N, K, **bf)
     cur = [lambda i=i: torch.bmm(dY[i].view(b, m, N).transpose(1, 2), X[i].view(b, m, K), out=out) for i in range(R)]
-    # K-contiguous: A_b = dYT[:, b*m:(b+1)*m] (N x m, row stride M), B_b = XT[:, chunk]^T (m x K given as the transpose of a K-contiguous block)
-    nt = [lambda i=i: torch.bmm(dYT[i].view(N, b, m).permute(1, 0, 2), XT[i].view(K, b, m).permute(1, 2, 0), out=out) for i in range(R)]
+    # K-contiguous, chunk-major: dYT_b (b, N, m) and XT_b (b, K, m), both contiguous (what a transposing producer would write)
+    dYTb = [d.view(b, m, N).transpose(1, 2).contiguous() for d in dY]
+    XTb = [x.view(b, m, K).transpose(1, 2).contiguous() for x in X]
+    nt = [lambda i=i: torch.bmm(dYTb[i], XTb[i].transpose(1, 2), out=out) for i in range(R)]
     t0, t1 = timeit(cur), timeit(nt)
     ref = torch.bmm(dY[0].view(b, m, N).transpose(1, 2).float(), X[0].view(b, m, K).float()).sum(0)
     nt[0]()
+    torch.cuda.synchronize()
     err = float((out.float().sum(0) - ref).abs().max() / ref.abs().max())
     print(f"chunks {b}: M-major operands {t0:7.1f} us ({gf / t0:5.0f} TF/s) | K-contiguous operands {t1:7.1f} us ({gf / t1:5.0f} TF/s)   [check {err:.1e}]", flush=True)
+    del dYTb, XTb
 tr = timeit([lambda i=i: dYT[i].copy_(dY[i].t()) for i in range(R)])
 print(f"transpose pass of dY1 (torch copy_ of a (24576 x 1280) bf16 view): {tr:.1f} us")
 for r in tunable.get_results():

@@ -709,19 +709,20 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m,
                                                    const float* step, const float* lr, float beta1, float beta2, float eps,
                                                    bf16_t* body, int64_t n_body, float* tail, int64_t n_tail, int zero_grad, float* zero_slot,
                                                    Go1PpoAdamExtras ex) {
-  __shared__ float clip_s;
-  if (threadIdx.x < 64) {
-    float c = 1.f;
-    if (partial) {
-      float s = 0.f;
-      for (int i = threadIdx.x; i < OPT_BLOCKS; i += 64) s += partial[i];
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      c = fminf(1.f, max_norm / (sqrtf(s) + 1e-6f));
-    }
-    if (threadIdx.x == 0) clip_s = c;
+  // clip factor from the norm pass's per-block partials: all 256 lanes load their OPT_BLOCKS / 256 values at once (one memory round
+  // trip; a 64-lane loop of 32 dependent loads cost ~10 us in front of every block's single pass)
+  __shared__ float clip_red[4];
+  float clip = 1.f;
+  if (partial) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < OPT_BLOCKS / 256; u++) s += partial[threadIdx.x + 256 * u];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) clip_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    clip = fminf(1.f, max_norm / (sqrtf((clip_red[0] + clip_red[1]) + (clip_red[2] + clip_red[3])) + 1e-6f));
   }
-  __syncthreads();
-  const float gs = gscale * clip_s;
+  const float gs = gscale * clip;
   const float t = step[0], l = lr[0];
   const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
   const float step_size = l / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
@@ -1004,6 +1005,7 @@ extern "C" int go1ppo_elu_bwd(const void* d, int ld_d, const void* h, int ld_h, 
 extern "C" int go1ppo_loss(const Go1PpoLossArgs* a, void* stream) {
   if (!a || a->rows <= 0 || a->num_actions <= 0 || a->num_actions > GO1PPO_MAX_ACTIONS || a->head_ld < a->num_actions) return -1;
   // (measured: 64-thread workgroups — 384 instead of 96 — are slower, 33 vs 26 us: four times the atomics on the same 28 words)
+  // (one wavefront per workgroup — 384 workgroups instead of 96 — measured 32 us against 22: four times the same-address atomics of the reductions)
   loss_kernel<<<dim3((unsigned)((a->rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(*a);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
