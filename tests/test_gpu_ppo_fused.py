@@ -226,6 +226,39 @@ def test_gemm_nt_matches_fp32_matmul(lib, M, N, K, epilogue):
     assert torch.all(err <= tol), f"max err {err.max().item()} at scale {ref.abs().max().item()}"
 
 
+@pytest.mark.parametrize("epilogue", ["bias_bf16", "elu_bwd"])
+def test_gemm_nt_pair_is_two_gemm_nt_launches(lib, epilogue):
+    """go1ppo_gemm_nt_pair (blockIdx.y picks the problem): bit-identical to the two single launches, on the update's shapes — the
+    actor's and critic's 512 -> 256 forward (column blocks of the shared first-layer buffer) and their 256 -> 512 input gradients."""
+    from go1_gym_learn.ppo_cse import fused
+    g = torch.Generator(device="cuda").manual_seed(8)
+    M = 24576
+    if epilogue == "bias_bf16":
+        y1 = bf(torch.randn(M, 1280, device="cuda", generator=g))
+        probs = [dict(a=y1[:, 256 + 512 * i:768 + 512 * i], b=bf(torch.randn(256, 512, device="cuda", generator=g) / 22),
+                      bias=bf(torch.randn(256, device="cuda", generator=g))) for i in range(2)]
+        shape = (M, 256)
+    else:
+        h = bf(torch.nn.functional.elu(torch.randn(M, 1280, device="cuda", generator=g)))
+        probs = [dict(a=bf(torch.randn(M, 256, device="cuda", generator=g)), b=bf(torch.randn(512, 256, device="cuda", generator=g) / 16),
+                      elu_bwd_of=h[:, 256 + 512 * i:768 + 512 * i]) for i in range(2)]
+        shape = (M, 512)
+    single = [torch.zeros(shape, device="cuda", dtype=torch.bfloat16) for _ in range(2)]
+    paired = [torch.zeros(shape, device="cuda", dtype=torch.bfloat16) for _ in range(2)]
+    for q, c in zip(probs, single):
+        fused.gemm_nt(lib, q["a"], q["b"], c, q.get("bias"), elu_bwd_of=q.get("elu_bwd_of"))
+    fused.gemm_nt_pair(lib, dict(c=paired[0], **probs[0]), dict(c=paired[1], **probs[1]))
+    torch.cuda.synchronize()
+    for s_, p_ in zip(single, paired):
+        assert torch.equal(s_, p_) and float(s_.float().abs().max()) > 0.1
+    # different tile grids are refused
+    import ctypes
+    ga = fused.gemm_args(c=paired[0], **probs[0])
+    gb = fused.gemm_args(a=probs[1]["a"][:4096], b=probs[1]["b"], c=paired[1][:4096], bias=probs[1].get("bias"),
+                         elu_bwd_of=None if probs[1].get("elu_bwd_of") is None else probs[1]["elu_bwd_of"][:4096])
+    assert lib.go1ppo_gemm_nt_pair(ctypes.byref(ga), ctypes.byref(gb), stream()) == -7
+
+
 @pytest.mark.parametrize("count,rows,cols,zero", [(4, 1280, 2112, (768, 2101, 2103)), (1, 256, 2112, (256, 2101, 2103)), (3, 40, 64, (7, 13, 30)),
                                                   (2, 16, 24, (0, 0, 0))])
 def test_sum_partials_matches_torch(lib, count, rows, cols, zero):

@@ -73,8 +73,23 @@ __device__ __forceinline__ void gemm_nt_body(const Go1PpoGemmArgs& a, bf16_t (*l
   // epilogue 2 multiplies by elu'(H): its 16 H fragments are requested NOW — a load issued in the epilogue is waited for right
   // there (an HBM round trip per fragment with nothing to hide it: 19 such waits made this variant slower than GEMM + a
   // separate element-wise pass)
+  // wide epilogue (N, ldc [, ldh] multiples of 8 and 16-byte aligned C [, H]): the finished tile goes through LDS (fp32, the 64 KB the
+  // staging buffers occupied) and leaves as whole 256-byte row pieces — 16 lanes x 16 B — instead of fragment-shaped 8-byte stores
+  // (16 rows x 32 B per instruction: the stores, and epilogue 2's H reads, were what the 512 <-> 256 layers' time went with);
+  // epilogue 2's H row pieces are requested here in that same coalesced shape
+  const bool wide = !(a.N & 7) && !(a.ldc & 7) && !((uintptr_t)a.C & 15) && (EPI != 2 || (!(a.ldh & 7) && !((uintptr_t)a.H & 15)));
+  uint4 hrow[8];
+  if (EPI == 2 && wide) {
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      int m = m0 + (int)(threadIdx.x >> 4) + 16 * it, n = n0 + (int)(threadIdx.x & 15) * 8;
+      m = m < a.M ? m : a.M - 1;
+      n = n < a.N ? n : a.N - 8;
+      hrow[it] = *reinterpret_cast<const uint4*>((const bf16_t*)a.H + (int64_t)m * a.ldh + n);
+    }
+  }
   uint2 hpre[4][4];
-  if (EPI == 2) {
+  if (EPI == 2 && !wide) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       int n = n0 + wn * 64 + j * 16 + fg * 4;
@@ -111,6 +126,63 @@ __device__ __forceinline__ void gemm_nt_body(const Go1PpoGemmArgs& a, bf16_t (*l
   }
 
   // ---- epilogue: lane holds D[n = 4*fg + e][m = fr] of each 16 x 16 fragment
+  if (wide) {
+    __syncthreads();                                            // every wave is done with the staging buffers
+    float* img = reinterpret_cast<float*>(&lds[0][0][0]);       // [128 rows][128 columns] fp32, 16-byte chunk index XOR-ed with (row & 15)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int nl = wn * 64 + j * 16 + fg * 4, n = n0 + nl;
+      f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.bias && n < a.N) {
+        if (a.bias_bf16) {
+          const uint2 braw = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.bias) + n);
+          bias = f32x4{__uint_as_float(braw.x << 16), __uint_as_float(braw.x & 0xffff0000u), __uint_as_float(braw.y << 16),
+                       __uint_as_float(braw.y & 0xffff0000u)};
+        } else bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+      }
+      const bool act = EPI == 1 && n >= a.elu_c0 && n < a.elu_c1 && !(n >= a.elu_skip_c0 && n < a.elu_skip_c1);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int row = wm * 64 + i * 16 + fr;
+        f32x4 v = acc[j][i] + bias;
+        if (act) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = elu1(v[e]);
+        }
+        *reinterpret_cast<f32x4*>(img + row * 128 + ((((nl >> 2)) ^ (row & 15)) << 2)) = v;
+      }
+    }
+    __syncthreads();
+    const int c8 = (int)(threadIdx.x & 15);
+    const int n = n0 + c8 * 8;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = (int)(threadIdx.x >> 4) + 16 * it, m = m0 + row;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(img + row * 128 + (((2 * c8) ^ (row & 15)) << 2));
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(img + row * 128 + (((2 * c8 + 1) ^ (row & 15)) << 2));
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (EPI == 2) {
+        const uint32_t hw[4] = {hrow[it].x, hrow[it].y, hrow[it].z, hrow[it].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float h0 = __uint_as_float(hw[e] << 16), h1 = __uint_as_float(hw[e] & 0xffff0000u);
+          v[2 * e] *= h0 > 0.f ? 1.f : h0 + 1.f;
+          v[2 * e + 1] *= h1 > 0.f ? 1.f : h1 + 1.f;
+        }
+      }
+      if (m < a.M && n < a.N) {
+        uint4 o;
+        uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          f32x2 p2 = {v[2 * e], v[2 * e + 1]};
+          ow[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p2, bf16x2_t));
+        }
+        *reinterpret_cast<uint4*>((bf16_t*)a.C + (int64_t)m * a.ldc + n) = o;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int n = n0 + wn * 64 + j * 16 + fg * 4;
