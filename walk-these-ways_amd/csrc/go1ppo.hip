@@ -1289,7 +1289,8 @@ extern "C" int go1ppo_tail_fwd(const Go1PpoTailArgs* args, void* stream) {
     }
     if (N.rows > max_rows) max_rows = N.rows;
   }
-  if (false)
+  static const bool bm64 = getenv("GO1PPO_TAIL_BM64") != nullptr;      // probe switch (tools/probes/tail_first_layer.py)
+  if (bm64)
     tail_fwd_kernel<64><<<dim3((unsigned)((max_rows + 63) / 64), args->num_nets), dim3(256), 0, (hipStream_t)stream>>>(*args);
   else
     tail_fwd_kernel<32><<<dim3((unsigned)((max_rows + 31) / 32), args->num_nets), dim3(256), 0, (hipStream_t)stream>>>(*args);

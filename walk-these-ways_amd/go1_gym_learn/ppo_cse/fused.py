@@ -235,10 +235,11 @@ class FusedNet:
         self._wgrad_tn = knob[0] == "1" and M % 64 == 0
         self._w1_tn = (self._wgrad_tn and knob[1] == "1", self._wgrad_tn and knob[2] == "1")
         self._tails = self._tails_ad = None
-        # measured on MI355X: one fused launch per dependency level beats 8 GEMMs + 5 ELU kernels 3.5x at M = 4096
-        # (rollout inference: 32 vs 110 us) but only ties hipBLASLt + the two-stream schedule at M = 24576
+        # measured on MI355X: one fused launch per dependency level beats 8 GEMMs + 5 ELU kernels 3.5x at M = 4096 (32 vs 110 us) — but the
+        # engine below (ELU pass, paired 512 -> 256 GEMM, LDS-resident MLP ends) beats it at the rollout's 4096 rows since round 4
+        # (rollout 6.8 vs 7.0 ms per iteration, same-box alternating runs) and at the update's 24576: the fused kernel keeps the small batches
         if fused_tails is None:
-            fused_tails = M <= int(os.environ.get("GO1_FUSED_TAILS_MAX_ROWS", "8192"))     # (tests lower it to reach the other engine)
+            fused_tails = M <= int(os.environ.get("GO1_FUSED_TAILS_MAX_ROWS", "2048"))     # (tests lower it to reach the other engine)
         # inference-only engines: the first layer's ELU (+ the actor's latent columns) is applied by the tail kernel while it
         # stages its input rows — two element-wise launches per rollout step less; an engine with a backward pass keeps the
         # separate pass, which leaves the activated first layer in memory for the weight gradients
