@@ -350,20 +350,23 @@ __device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf
   // ---- staging: wave w moves row blocks (4 rows of 256 B each) 2w, 2w+1 of both operand tiles
   const bf16_t* gp[2];
   const bf16_t* gq[2];
+  bool vp[2], vq[2];
 #pragma unroll
   for (int p = 0; p < 2; p++) {
     const int row = (wave * 2 + p) * 4 + (lane >> 4);
     const int chunk = (lane & 15) ^ (2 * ((row & 3) | (((row >> 3) & 1) << 2)));
-    int cn = n0 + chunk * 8, ck = k0 + chunk * 8;
-    cn = cn < N ? cn : N - 8;                                    // columns past the matrix: any legal address will do
-    ck = ck < K ? ck : K - 8;
-    gp[p] = P + (m_begin + row) * ldp + cn;
-    gq[p] = Q + (m_begin + row) * ldq + ck;
+    const int cn = n0 + chunk * 8, ck = k0 + chunk * 8;
+    // columns past the matrix (n = 64 or k = 64 problems on the 128-wide tile): the lane sits the DMA out — its LDS slot keeps whatever it
+    // held, which only ever reaches output elements that are not stored — instead of moving bytes nobody uses through the L2 -> LDS path
+    vp[p] = cn < N;
+    vq[p] = ck < K;
+    gp[p] = P + (m_begin + row) * ldp + (vp[p] ? cn : 0);
+    gq[p] = Q + (m_begin + row) * ldq + (vq[p] ? ck : 0);
   }
   auto stage_piece = [&](int step, int p, int op) {              // one of the wave's 4 DMA instructions of a step
     const int buf = step & (WTN_BUFS - 1);
-    if (op == 0) glds16(gp[p] + (int64_t)step * WTN_STEP * ldp, &lds[buf][0][(wave * 2 + p) * 4 * WTN_T]);
-    else glds16(gq[p] + (int64_t)step * WTN_STEP * ldq, &lds[buf][1][(wave * 2 + p) * 4 * WTN_T]);
+    if (op == 0) { if (vp[p]) glds16(gp[p] + (int64_t)step * WTN_STEP * ldp, &lds[buf][0][(wave * 2 + p) * 4 * WTN_T]); }
+    else { if (vq[p]) glds16(gq[p] + (int64_t)step * WTN_STEP * ldq, &lds[buf][1][(wave * 2 + p) * 4 * WTN_T]); }
   };
   auto stage = [&](int step) {
     stage_piece(step, 0, 0); stage_piece(step, 0, 1); stage_piece(step, 1, 0); stage_piece(step, 1, 1);
