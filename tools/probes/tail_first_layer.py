@@ -12,7 +12,7 @@ for p in (os.path.join(P_, "shims"), P_, R_):
 import torch
 from go1_gym_learn.ppo_cse import fused
 
-lib = fused.load_library()
+lib = fused.load_library(os.environ.get("GO1PPO_LIB"))
 s = torch.cuda.current_stream().cuda_stream
 M = int(os.environ.get("ROWS", "24576"))
 bf = dict(device="cuda", dtype=torch.bfloat16)

@@ -50,7 +50,9 @@ __device__ __forceinline__ Bf8 pack_bf8(const float (&x)[8]) {
 
 // ---------------------------------------------------------------------------------------------- elu_fwd
 // block = 16 column groups (8 columns each) x 16 row lanes, ELU_ROWS rows per lane: a 128-column x 64-row tile.
+#ifndef ELU_ROWS
 #define ELU_ROWS 4
+#endif
 template <bool LAT>
 __global__ __launch_bounds__(256) void elu_fwd_kernel(bf16_t* y, int rows, int cols, int ld, const bf16_t* lat, int lat_ld,
                                                       int npv, const bf16_t* wz, int wz_ld, int lat_cols) {

@@ -463,6 +463,153 @@ __device__ __forceinline__ void wgrad_tn_body(const bf16_t* P, int ldp, const bf
   }
 }
 
+// ---- 256 (n) x 128 (k) tiles for problems whose n is a multiple of 256 (the 256-row first-layer block of the adaptation pass, the
+// 512 -> 256 layers, Wz): the H / X operand of a step is staged once for 256 output rows instead of once per 128 — the kernel is bound by the
+// L2 -> LDS staging rate, and this tile moves 48 KB per 1 M multiply-adds instead of 64.  Per step and buffer:
+// [dZ image, columns 0..127 | dZ image, columns 128..255 | H image], 16 KB each, the images exactly those of the 128-tile body;
+// three buffers (two steps in flight: the same 96 KB in flight per workgroup); each wave owns 64 (n) x 64 (k): 4 x 4 accumulators.
+#define WTW_BUF_BYTES (3 * WTN_STEP * WTN_T * 2)
+#define WTW_BUFS 3
+struct TnFragsW { s16x4_t lo[8], hi[8]; };                       // 4 dZ fragments + 4 H fragments
+template <int KK>
+__device__ __forceinline__ void tnw_read(TnFragsW& f, const uint32_t (&aa)[4], const uint32_t (&ab)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    f.lo[i] = lds_tr<KK * 32 * 256>(aa[i]);
+    f.hi[i] = lds_tr<KK * 32 * 256 + 4 * 256>(aa[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    f.lo[4 + i] = lds_tr<KK * 32 * 256>(ab[i]);
+    f.hi[4 + i] = lds_tr<KK * 32 * 256 + 4 * 256>(ab[i]);
+  }
+}
+__device__ __forceinline__ void ldsw_wait_all(TnFragsW& f) {       // (two statements: an asm takes at most 30 operands; volatile asms keep their order)
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f.lo[0]), "+v"(f.lo[1]), "+v"(f.lo[2]), "+v"(f.lo[3]), "+v"(f.lo[4]), "+v"(f.lo[5]), "+v"(f.lo[6]), "+v"(f.lo[7]));
+  asm volatile("" : "+v"(f.hi[0]), "+v"(f.hi[1]), "+v"(f.hi[2]), "+v"(f.hi[3]), "+v"(f.hi[4]), "+v"(f.hi[5]), "+v"(f.hi[6]), "+v"(f.hi[7]));
+}
+__device__ __forceinline__ bf16x8_t tnw_operand(const TnFragsW& f, int i) {
+  s16x8_t v = __builtin_shufflevector(f.lo[i], f.hi[i], 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ void wgrad_tn_body_wide(const bf16_t* P, int ldp, const bf16_t* Q, int ldq, int64_t m_begin, int steps,
+                                                   float* C, int ldc, float* bias_grad, int N, int K, int n0, int k0, char* lds,
+                                                   int zero_n, int zero_k0, int zero_k1, bool slab) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // ---- staging: 32 row blocks (4 rows of 256 B) of the two dZ images + 16 of the H image per step; wave w moves dZ blocks 4w .. 4w+3
+  // (image = block >> 4) and H blocks 2w, 2w+1
+  const bf16_t* src[6];
+  bool ok[6];
+  int dst[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    const int id = q < 4 ? wave * 4 + q : wave * 2 + (q - 4);
+    const int img = q < 4 ? id >> 4 : 2, rb = q < 4 ? id & 15 : id;
+    const int row = rb * 4 + (lane >> 4);
+    const int chunk = (lane & 15) ^ (2 * ((row & 3) | (((row >> 3) & 1) << 2)));
+    const int col = (q < 4 ? n0 + img * 128 : k0) + chunk * 8;
+    ok[q] = col < (q < 4 ? N : K);                              // (n % 256 == 0 and k0 < K: every instruction keeps active lanes — the vmcnt bookkeeping relies on it)
+    src[q] = (q < 4 ? P + (m_begin + row) * ldp : Q + (m_begin + row) * ldq) + (ok[q] ? col : 0);
+    dst[q] = img * (WTN_STEP * WTN_T * 2) + rb * 4 * WTN_T * 2;
+  }
+  auto stage_piece = [&](int step, int buf, int q) {
+    if (ok[q]) glds16(src[q] + (int64_t)step * WTN_STEP * (q < 4 ? ldp : ldq), (bf16_t*)(lds + buf * WTW_BUF_BYTES + dst[q]));
+  };
+  const int g = lane >> 4, i16 = lane & 15;
+  const int rowoff = (g * 8 + (i16 >> 2)) * 256 + ((i16 & 3) >> 1) * 16 + (i16 & 1) * 8;
+  const int swb = 32 * ((i16 >> 2) | ((g & 1) << 2));
+  const int wn = wave >> 1, wk = wave & 1;                        // 64 (n) x 64 (k) per wave
+  int fa[4], fb[4];
+#pragma unroll
+  for (int f = 0; f < 4; f++) {
+    fa[f] = (wn >> 1) * (WTN_STEP * WTN_T * 2) + rowoff + ((((wn & 1) * 64 + f * 16) * 2) ^ swb);
+    fb[f] = 2 * (WTN_STEP * WTN_T * 2) + rowoff + (((wk * 64 + f * 16) * 2) ^ swb);
+  }
+  f32x4 acc[4][4], bacc[4];
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    bacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = bias_grad && k0 == 0 && wk == 0;
+  const s16x8_t ones_bits = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_bits);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)lds;
+#pragma unroll
+  for (int s = 0; s < WTW_BUFS - 1; s++)
+    if (s < steps) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) stage_piece(s, s, q);
+    }
+  int buf = 0;
+  for (int s = 0; s < steps; s++) {
+    // step s has landed once at most the 6 DMAs of step s+1 are outstanding
+    if (s + 1 < steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                // everyone's part of step s is in LDS, step s-1 is consumed
+    asm volatile("" ::: "memory");
+    const bool more = s + WTW_BUFS - 1 < steps;                  // the DMA of step s+2 goes into the buffer step s-1 used
+    const int nxt = s + WTW_BUFS - 1, nbuf = buf == 0 ? WTW_BUFS - 1 : buf - 1;
+    const uint32_t base = lds0 + (uint32_t)buf * WTW_BUF_BYTES;
+    uint32_t aa[4], ab[4];
+#pragma unroll
+    for (int f = 0; f < 4; f++) { aa[f] = base + fa[f]; ab[f] = base + fb[f]; }
+    TnFragsW f0, f1;
+    tnw_read<0>(f0, aa, ab);
+    if (more) { stage_piece(nxt, nbuf, 0); stage_piece(nxt, nbuf, 1); stage_piece(nxt, nbuf, 4); }
+    ldsw_wait_all(f0);
+    tnw_read<1>(f1, aa, ab);
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tnw_operand(f0, a), tnw_operand(f0, 4 + b), acc[a][b], 0, 0, 0);
+      if (more && a < 3) stage_piece(nxt, nbuf, a == 0 ? 2 : (a == 1 ? 3 : 5));
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int a = 0; a < 4; a++) bacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tnw_operand(f0, a), ones, bacc[a], 0, 0, 0);
+    }
+    ldsw_wait_all(f1);
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tnw_operand(f1, a), tnw_operand(f1, 4 + b), acc[a][b], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+      for (int a = 0; a < 4; a++) bacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tnw_operand(f1, a), ones, bacc[a], 0, 0, 0);
+    }
+    buf = buf + 1 == WTW_BUFS ? 0 : buf + 1;
+  }
+  // ---- lane holds D[n = 4g + e][k = i16] of each fragment pair
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int n = n0 + wn * 64 + a * 16 + 4 * g + e;
+      if (n >= N) continue;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int k = k0 + wk * 64 + b * 16 + i16;
+        if (k < K && !(n < zero_n && k >= zero_k0 && k < zero_k1)) {
+          if (slab) C[(int64_t)n * ldc + k] = acc[a][b][e];
+          else atomicAdd(C + (int64_t)n * ldc + k, acc[a][b][e]);
+        }
+      }
+      if (do_bias && i16 == 0) atomicAdd(bias_grad + n, bacc[a][e]);
+    }
+  }
+}
+// the tile shape of a problem: 256 x 128 when n is a multiple of 256 AND the partial tiles go to slabs, 128 x 128 otherwise (kernel and
+// planner agree through these).  With atomics the wide tile loses: the same number of workgroups means twice the row chunks per output
+// element, i.e. twice the atomics (measured: 256 x 512 alone 53 us against 34).
+__host__ __device__ __forceinline__ bool wtn_wide(const Go1PpoWgradProblem& P) { return (P.n & 255) == 0 && P.partials != nullptr; }
+__host__ __device__ __forceinline__ int wtn_tiles_n(const Go1PpoWgradProblem& P) { return wtn_wide(P) ? P.n >> 8 : (P.n + WTN_T - 1) / WTN_T; }
+
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
@@ -470,20 +617,28 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 
 // every weight gradient of a backward pass in ONE launch (problem table built by go1ppo_wgrad_tn_plan)
 __global__ __launch_bounds__(WTN_THREADS, 1) void wgrad_tn_batched_kernel(const Go1PpoWgradProblem* __restrict__ probs, int count) {
-  __shared__ __attribute__((aligned(1024))) bf16_t lds[WTN_BUFS][2][WTN_STEP * WTN_T];
+  __shared__ __attribute__((aligned(1024))) char lds_raw[WTW_BUFS * WTW_BUF_BYTES];      // 144 KB (the 128-tile body uses the first 128 KB)
+  static_assert(WTW_BUFS * WTW_BUF_BYTES >= WTN_BUFS * 2 * WTN_STEP * WTN_T * 2, "one LDS block for both tile shapes");
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   int p = 0;
   while (p + 1 < count && wg >= probs[p + 1].wg_offset) p++;
   const Go1PpoWgradProblem P = probs[p];
   const int local = wg - P.wg_offset;
-  const int tiles_k = (P.k + WTN_T - 1) / WTN_T, tiles = ((P.n + WTN_T - 1) / WTN_T) * tiles_k;
+  const bool wide = wtn_wide(P);
+  const int tiles_k = (P.k + WTN_T - 1) / WTN_T, tiles = wtn_tiles_n(P) * tiles_k;
   const int tile = local % tiles, split = local / tiles;
   const int64_t m_begin = (int64_t)split * P.chunk_rows;
   const int64_t m_end = m_begin + P.chunk_rows < P.rows ? m_begin + P.chunk_rows : P.rows;
   const bool slab = P.partials != nullptr;
-  wgrad_tn_body((const bf16_t*)P.dz, P.ld_dz, (const bf16_t*)P.h, P.ld_h, m_begin, (int)((m_end - m_begin) / WTN_STEP),
-                slab ? P.partials + (int64_t)split * P.partial_stride : P.dW, P.ldw, P.bias_grad, P.n, P.k, (tile / tiles_k) * WTN_T,
-                (tile % tiles_k) * WTN_T, lds, P.zero_n, P.zero_k0, P.zero_k1, slab);
+  float* C = slab ? P.partials + (int64_t)split * P.partial_stride : P.dW;
+  const int steps = (int)((m_end - m_begin) / WTN_STEP);
+  if (wide)
+    wgrad_tn_body_wide((const bf16_t*)P.dz, P.ld_dz, (const bf16_t*)P.h, P.ld_h, m_begin, steps, C, P.ldw, P.bias_grad, P.n, P.k,
+                       (tile / tiles_k) * 2 * WTN_T, (tile % tiles_k) * WTN_T, lds_raw, P.zero_n, P.zero_k0, P.zero_k1, slab);
+  else
+    wgrad_tn_body((const bf16_t*)P.dz, P.ld_dz, (const bf16_t*)P.h, P.ld_h, m_begin, steps, C, P.ldw, P.bias_grad, P.n, P.k,
+                  (tile / tiles_k) * WTN_T, (tile % tiles_k) * WTN_T, reinterpret_cast<bf16_t (*)[2][WTN_STEP * WTN_T]>(lds_raw), P.zero_n, P.zero_k0,
+                  P.zero_k1, slab);
 }
 
 extern "C" int go1ppo_wgrad_tn_plan(Go1PpoWgradProblem* probs, int count) {
@@ -494,9 +649,10 @@ extern "C" int go1ppo_wgrad_tn_plan(Go1PpoWgradProblem* probs, int count) {
     if (!P.dz || !P.h || (!P.dW && !P.partials) || (P.partials && P.partial_stride < (int64_t)P.n * P.ldw) || P.rows <= 0 || (P.rows % WTN_STEP) || P.n < 8 || P.k < 8 || (P.n & 7) || (P.k & 7) ||
         (P.ld_dz & 7) || (P.ld_h & 7) || !aligned16(P.dz) || !aligned16(P.h) || P.zero_n < 0 || P.zero_k0 < 0 || P.zero_k1 < P.zero_k0)
       return -1;
-    const int64_t t = (int64_t)((P.n + WTN_T - 1) / WTN_T) * ((P.k + WTN_T - 1) / WTN_T);
+    // (a step of a 256 x 128 tile stages 48 KB instead of 32: it counts 1.5 steps, and its chunks are shorter by that factor)
+    const int64_t t = (int64_t)wtn_tiles_n(P) * ((P.k + WTN_T - 1) / WTN_T);
     tiles += t;
-    tile_steps += t * (P.rows / WTN_STEP);
+    tile_steps += t * (P.rows / WTN_STEP) * (wtn_wide(P) ? 3 : 2) / 2;
   }
   // every partial tile costs 16384 fp32 atomics, so chunks are long: one workgroup per CU and round, as few rounds as
   // give each workgroup <= 96 steps (the atomics of one round hide behind the MFMAs of the next)
@@ -510,11 +666,13 @@ extern "C" int go1ppo_wgrad_tn_plan(Go1PpoWgradProblem* probs, int count) {
     for (int i = 0; i < count; i++) {
       Go1PpoWgradProblem& P = probs[i];
       const int64_t steps = P.rows / WTN_STEP;
-      const int64_t S0 = (steps + chunk_steps - 1) / chunk_steps;  // splits, then equalise the chunks
+      int64_t want = wtn_wide(P) ? chunk_steps * 2 / 3 : chunk_steps;
+      if (want < 4) want = 4;
+      const int64_t S0 = (steps + want - 1) / want;               // splits, then equalise the chunks
       const int64_t cs = (steps + S0 - 1) / S0;
       P.chunk_rows = (int32_t)(cs * WTN_STEP);
       P.wg_offset = total;
-      total += (int)((steps + cs - 1) / cs) * ((P.n + WTN_T - 1) / WTN_T) * ((P.k + WTN_T - 1) / WTN_T);
+      total += (int)((steps + cs - 1) / cs) * wtn_tiles_n(P) * ((P.k + WTN_T - 1) / WTN_T);
     }
     if (total <= cus * rounds || chunk_steps >= 4096) return total;
   }

@@ -608,6 +608,9 @@ class FusedNet:
                 P.rows, P.ld_dz, P.ld_h, P.n, P.k, P.ldw = dz.shape[0], _ld(dz), _ld(h), dz.shape[1], h.shape[1], gW.shape[1]
             tn = self._wgrad_tn and all(P.rows % 64 == 0 and P.n % 8 == 0 and P.k % 8 == 0 for P in tab)
             plan = self.lib.go1ppo_wgrad_tn_plan if tn else self.lib.go1ppo_wgrad_plan
+            if tn and self._slabs:       # the plan depends on WHETHER a problem has slabs (tile shape), not on where they are: a placeholder until they are allocated
+                for P, (dz, h, gW, gb, zero) in zip(tab, rec):
+                    P.partials, P.partial_stride = 16, gW.numel()
             total = plan(tab, len(rec))
             if total <= 0:
                 raise RuntimeError(f"go1ppo_wgrad_plan failed with code {total}")
