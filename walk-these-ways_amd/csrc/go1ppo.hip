@@ -572,98 +572,107 @@ __global__ __launch_bounds__(256) void normalize_kernel(float* adv, int64_t n, c
 #define OPT_BLOCKS 2048
 // ---- the flat gradient as pieces (include/go1ppo.h Go1PpoGradPiece): slab pieces are summed in a fixed order (slab 0, 1, ...) into g;
 // NORM: the squared norm of (g * gscale) over [0, n) — plain elements and the fresh sums alike — is returned per thread
-__device__ __forceinline__ float plain_sq(const float* g, int64_t lo, int64_t hi, float gscale, int64_t tid, int64_t nth) {
-  float s = 0.f;
-  if (hi <= lo) return s;
-  int64_t head = ((lo + 3) & ~(int64_t)3);                        // 16-byte loads over the aligned bulk (g itself is 16-byte aligned)
-  if (head > hi) head = hi;
-  const int64_t body4 = (hi - head) >> 2;
-  for (int64_t i = lo + tid; i < head; i += nth) { const float x = g[i] * gscale; s = fmaf(x, x, s); }
-  for (int64_t i = tid; i < body4; i += nth) {
-    const f32x4 x = reinterpret_cast<const f32x4*>(g + head)[i] * gscale;
-    s = fmaf(x[0], x[0], s); s = fmaf(x[1], x[1], s); s = fmaf(x[2], x[2], s); s = fmaf(x[3], x[3], s);
-  }
-  for (int64_t i = head + 4 * body4 + tid; i < hi; i += nth) { const float x = g[i] * gscale; s = fmaf(x, x, s); }
-  return s;
-}
+// One flat index space of 8-element groups over all segments (plain gap, piece, plain gap, ...): a lane's group lies in exactly one segment, so a
+// wave makes ONE memory round trip — with a loop per segment the first blocks walked through all ~20 segments one after the other (22 us for 51 MB).
 template <bool NORM>
 __device__ __forceinline__ float grad_pieces_pass(float* g, int64_t n, const Go1PpoGradPiece* __restrict__ pieces, int num_pieces, float gscale) {
-  const int64_t tid0 = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
-  // every segment (piece, plain gap) starts at a different block: most pieces are far smaller than the grid, and with one common start the
-  // first few blocks would walk through ALL of them one after the other (measured: 22 us for 51 MB, the serial chain of ~10 small segments)
-  const int64_t rot = (((int64_t)gridDim.x / (2 * num_pieces + 2)) > 0 ? ((int64_t)gridDim.x / (2 * num_pieces + 2)) : 1) * 256;
-  int seg = 0;
-  auto start = [&]() { const int64_t t = (tid0 + (int64_t)(seg++) * rot) % nth; return t; };
-  float s = 0.f;
-  int64_t cur = 0;
-  for (int q = 0; q <= num_pieces; q++) {
-    const int64_t pb = q < num_pieces ? pieces[q].begin : n;
-    if (NORM) s += plain_sq(g, cur, pb < n ? pb : n, gscale, start(), nth);
-    if (q == num_pieces) break;
-    const Go1PpoGradPiece P = pieces[q];
-    cur = P.begin + P.count;
-    if (P.kind == 0) {
-      if (NORM) s += plain_sq(g, P.begin, cur, gscale, start(), nth);
-      continue;
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  auto gap_groups = [&](int64_t lo, int64_t hi) -> int64_t { return NORM && hi > lo ? (hi - lo + 7) >> 3 : 0; };
+  auto piece_groups = [&](const Go1PpoGradPiece& P) -> int64_t { return P.kind == 0 ? gap_groups(P.begin, P.begin + P.count) : P.count >> 3; };
+  int64_t total = 0;
+  {
+    int64_t cur = 0;
+    for (int q = 0; q <= num_pieces; q++) {
+      const int64_t pb = q < num_pieces ? pieces[q].begin : n;
+      total += gap_groups(cur, pb < n ? pb : n);
+      if (q == num_pieces) break;
+      total += piece_groups(pieces[q]);
+      cur = pieces[q].begin + pieces[q].count;
     }
-    float* out = g + P.begin;
-    const int64_t tid = start();
-    for (int64_t i8 = tid; i8 < (P.count >> 3); i8 += nth) {
-      const int64_t i = i8 << 3;
-      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (P.kind == 1) {
-        const float* src = (const float*)P.src + i;
-        int b = 0;
-        for (; b + 4 <= P.slabs; b += 4) {                        // four slabs' loads in flight (the sums stay in slab order)
-          f32x4 lo[4], hi[4];
+  }
+  float s = 0.f;
+  auto plain8 = [&](int64_t i, int64_t hi) {                      // g[i, min(i + 8, hi)) into the norm; i is a multiple of 8
+    if (i + 8 <= hi) {
+      const f32x4 a = reinterpret_cast<const f32x4*>(g + i)[0] * gscale, b = reinterpret_cast<const f32x4*>(g + i)[1] * gscale;
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            lo[u] = reinterpret_cast<const f32x4*>(src + (int64_t)(b + u) * P.stride)[0];
-            hi[u] = reinterpret_cast<const f32x4*>(src + (int64_t)(b + u) * P.stride)[1];
+      for (int e = 0; e < 4; e++) { s = fmaf(a[e], a[e], s); s = fmaf(b[e], b[e], s); }
+    } else {
+      for (int64_t j = i; j < hi; j++) { const float x = g[j] * gscale; s = fmaf(x, x, s); }
+    }
+  };
+  for (int64_t f = tid; f < total; f += nth) {
+    int64_t cum = 0, cur = 0;
+    for (int q = 0; q <= num_pieces; q++) {
+      const int64_t pb = q < num_pieces ? pieces[q].begin : n, ge = pb < n ? pb : n;
+      const int64_t gg = gap_groups(cur, ge);
+      if (f >= cum && f < cum + gg) plain8(cur + ((f - cum) << 3), ge);
+      cum += gg;
+      if (q == num_pieces) break;
+      const Go1PpoGradPiece P = pieces[q];
+      const int64_t pg = piece_groups(P);
+      cur = P.begin + P.count;
+      if (f >= cum && f < cum + pg) {
+        const int64_t i = (f - cum) << 3;
+        if (P.kind == 0) plain8(P.begin + i, cur);
+        else {
+          float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (P.kind == 1) {
+            const float* src = (const float*)P.src + i;
+            int b = 0;
+            for (; b + 4 <= P.slabs; b += 4) {                        // four slabs' loads in flight (the sums stay in slab order)
+              f32x4 lo[4], hi[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                lo[u] = reinterpret_cast<const f32x4*>(src + (int64_t)(b + u) * P.stride)[0];
+                hi[u] = reinterpret_cast<const f32x4*>(src + (int64_t)(b + u) * P.stride)[1];
+              }
+#pragma unroll
+              for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) { acc[e] += lo[u][e]; acc[4 + e] += hi[u][e]; }
+            }
+            for (; b < P.slabs; b++) {
+              const f32x4 lo = reinterpret_cast<const f32x4*>(src + (int64_t)b * P.stride)[0], hi = reinterpret_cast<const f32x4*>(src + (int64_t)b * P.stride)[1];
+#pragma unroll
+              for (int e = 0; e < 4; e++) { acc[e] += lo[e]; acc[4 + e] += hi[e]; }
+            }
+          } else {
+            const bf16_t* src = (const bf16_t*)P.src + i;
+            int b = 0;
+            for (; b + 4 <= P.slabs; b += 4) {
+              Bf8 v[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const Bf8*>(src + (int64_t)(b + u) * P.stride);
+#pragma unroll
+              for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[e] += bf2f(v[u].v[e]);
+            }
+            for (; b < P.slabs; b++) {
+              const Bf8 v = *reinterpret_cast<const Bf8*>(src + (int64_t)b * P.stride);
+#pragma unroll
+              for (int e = 0; e < 8; e++) acc[e] += bf2f(v.v[e]);
+            }
           }
+          if (P.zero_rows > 0) {
+            const int64_t row = i / P.cols;
+            const int c = (int)(i - row * P.cols);
+            if (row < P.zero_rows && c < P.zero_c1 && c + 8 > P.zero_c0) {
 #pragma unroll
-          for (int u = 0; u < 4; u++)
+              for (int e = 0; e < 8; e++)
+                if (c + e >= P.zero_c0 && c + e < P.zero_c1) acc[e] = 0.f;
+            }
+          }
+          float* out = g + P.begin + i;
+          reinterpret_cast<f32x4*>(out)[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+          reinterpret_cast<f32x4*>(out)[1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+          if (NORM) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) { acc[e] += lo[u][e]; acc[4 + e] += hi[u][e]; }
-        }
-        for (; b < P.slabs; b++) {
-          const f32x4 lo = reinterpret_cast<const f32x4*>(src + (int64_t)b * P.stride)[0], hi = reinterpret_cast<const f32x4*>(src + (int64_t)b * P.stride)[1];
-#pragma unroll
-          for (int e = 0; e < 4; e++) { acc[e] += lo[e]; acc[4 + e] += hi[e]; }
-        }
-      } else {
-        const bf16_t* src = (const bf16_t*)P.src + i;
-        int b = 0;
-        for (; b + 4 <= P.slabs; b += 4) {
-          Bf8 v[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const Bf8*>(src + (int64_t)(b + u) * P.stride);
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) acc[e] += bf2f(v[u].v[e]);
-        }
-        for (; b < P.slabs; b++) {
-          const Bf8 v = *reinterpret_cast<const Bf8*>(src + (int64_t)b * P.stride);
-#pragma unroll
-          for (int e = 0; e < 8; e++) acc[e] += bf2f(v.v[e]);
+            for (int e = 0; e < 8; e++) { const float x = acc[e] * gscale; s = fmaf(x, x, s); }
+          }
         }
       }
-      if (P.zero_rows > 0) {
-        const int64_t row = i / P.cols;
-        const int c = (int)(i - row * P.cols);
-        if (row < P.zero_rows && c < P.zero_c1 && c + 8 > P.zero_c0) {
-#pragma unroll
-          for (int e = 0; e < 8; e++)
-            if (c + e >= P.zero_c0 && c + e < P.zero_c1) acc[e] = 0.f;
-        }
-      }
-      reinterpret_cast<f32x4*>(out + i)[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
-      reinterpret_cast<f32x4*>(out + i)[1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
-      if (NORM) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) { const float x = acc[e] * gscale; s = fmaf(x, x, s); }
-      }
+      cum += pg;
     }
   }
   return s;
