@@ -295,10 +295,11 @@ extern "C" int go1ppo_gemm_nt(const Go1PpoGemmArgs* a, void* stream) {
 //     with 2 * ((m & 3) | ((m >> 3) & 1) << 2) on the DMA source address, which spreads them over 8 distinct 32-B
 //     slots (tools/probes/tr_bank_probe.hip: same rate as a contiguous image);
 //   * each wave owns 64 (n) x 32 (k): 4 x 2 accumulators of v_mfma_f32_16x16x32_bf16;
-//   * the reduction is split over row chunks (the output has only (n/128)(k/128) tiles); partial tiles meet in fp32
-//     atomics on the gradient buffer itself (~200 G atomic adds/s chip-wide, which is why chunks are as long as filling
-//     the machine once allows); the bias gradient (column sums of dZ) is one more MFMA per fragment against a fragment
-//     of ones, in the workgroups of the first column tile.
+//   * the reduction is split over row chunks (the output has only (n/128)(k/128) tiles).  The partial tiles go to per-chunk fp32 SLABS
+//     (Go1PpoWgradProblem.partials, plain stores; summed in a fixed order by the optimiser's norm pass or go1ppo_grad_reduce) — or, without
+//     slabs, meet in fp32 atomics on the gradient buffer itself (~200 G atomic adds/s chip-wide: 15.6 of the 64.5 us of the PPO pass's
+//     launch, which is why the product path uses slabs); the bias gradient (column sums of dZ) is one more MFMA per fragment against a
+//     fragment of ones, in the workgroups of the first column tile (atomics in both modes: n values per workgroup).
 // rows % 64 == 0, n % 8 == 0, k % 8 == 0.
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
@@ -654,8 +655,8 @@ extern "C" int go1ppo_wgrad_tn_plan(Go1PpoWgradProblem* probs, int count) {
     tiles += t;
     tile_steps += t * (P.rows / WTN_STEP) * (wtn_wide(P) ? 3 : 2) / 2;
   }
-  // every partial tile costs 16384 fp32 atomics, so chunks are long: one workgroup per CU and round, as few rounds as
-  // give each workgroup <= 96 steps (the atomics of one round hide behind the MFMAs of the next)
+  // every partial tile costs a 64 KB slab write (or 16384 fp32 atomics), so chunks are long: one workgroup per CU and round, as few
+  // rounds as give each workgroup <= 96 steps
   const int64_t cus = 256;
   int64_t rounds = (tile_steps + cus * 96 - 1) / (cus * 96);
   if (rounds < 1) rounds = 1;

@@ -556,7 +556,7 @@ class FusedNet:
                 self._elu_bwd(out, h_in, None)
 
     def _big_wgrad(self, dY, x, gW, tmp, own_kernel):
-        """first-layer weight gradient.  own_kernel: one more problem of the batched 128-tile launch (accumulates straight
+        """first-layer weight gradient.  own_kernel: one more problem of the batched 128-tile launch (slabs, or atomics straight
         into the fp32 gradient); otherwise one (rows x M) @ (M x Kp) bf16 hipBLASLt GEMM (the fp32-output variants it
         offers for this shape are 3x slower) and one cast into the fp32 gradient."""
         zr, zc0, zc1 = self.priv_mask           # (gW starts at row 0 of W1: rows of the adaptation module, then the actor's)
@@ -691,7 +691,9 @@ class FusedNet:
 
     def _backward(self, x):
         """After forward(x) and a loss kernel that filled dZ[actor][last], dZ[critic][last] (+ their bias / std
-        gradients): everything else.  Gradients are ACCUMULATED into the (pre-zeroed) flat gradient."""
+        gradients): everything else.  Bias gradients are ACCUMULATED into the (pre-zeroed) flat gradient; weight gradients too without
+        slabs (`_slabs` off) — with slabs they are WRITTEN: by go1ppo_grad_reduce at the end of the pass, or by the optimiser's norm pass
+        (`defer_grad_sum`), see `_run_planned`."""
         nd, na = self.nd, self.na
         G, Y1, dY1, dH1 = self.G, self.Y1, self.dY1, self.dH1
         cols = {"adaptation": slice(0, nd), "actor": slice(nd, nd + na), "critic": slice(nd + na, self.n1)}
