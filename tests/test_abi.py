@@ -137,3 +137,29 @@ def test_fused_update_fails_loudly_without_library(tmp_path):
     from go1_gym_learn.ppo_cse import fused
     with pytest.raises(fused.Go1PpoLibraryMissing):
         fused.load_library(str(tmp_path / "missing.so"))
+
+
+def test_product_package_never_touches_the_oracle():
+    """oracle/ is test infrastructure: no Python source of the product package imports it, loads its libraries or names its build directory
+    (comments may mention it); the only users outside tests/ are __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+    import ast
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "walk-these-ways_amd")
+    offenders = []
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            path = os.path.join(root, f)
+            tree = ast.parse(open(path).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                elif isinstance(node, ast.Constant) and isinstance(node.value, str) and not isinstance(getattr(node, "parent", None), ast.Expr):
+                    if "pyoracle" in node.value or "oracle/_build" in node.value or "libgo1oracle" in node.value:
+                        offenders.append((path, node.lineno, node.value[:60]))
+                if any(n.split(".")[0] in ("oracle", "pyoracle") for n in names):
+                    offenders.append((path, node.lineno, names))
+    assert not offenders, offenders
