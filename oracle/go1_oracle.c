@@ -607,6 +607,10 @@ static void jac_row(const Kin* k, int dynb, const real* x, const real* d, real* 
   }
 }
 
+/* study switch (tools/solver_order_study.py): 0 = the contract (contacts in list order), 1 = legs side by side */
+static int g_solver_legs_parallel = 0;
+void go1_oracle_set_solver_order(int legs_parallel) { g_solver_legs_parallel = legs_parallel; }
+
 /* ------------------------------------------------------------------ one physics substep (replaces gym.simulate) */
 typedef struct { real force[17][3]; int dropped[GO1_CC_COUNT]; uint32_t sig[GO1_SIG_WORDS]; } ContactOut;
 
@@ -714,26 +718,48 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
   int slid[GO1_MAX_CONTACTS];
   for (int c = 0; c < nc; c++) slid[c] = 0;
   for (int it = 0; it < cfg->solver_iterations; it++) {
-    for (int c = 0; c < nc; c++) {
-      real un = 0;
-      for (int i = 0; i < NV; i++) un += J[c][0][i] * v[i];
-      real ln = lamc[c][0] - (un - vstar[c]) / A[c][0];
-      if (ln < 0) ln = 0;
-      real dl = ln - lamc[c][0];
-      lamc[c][0] = ln;
-      for (int i = 0; i < NV; i++) v[i] += T[c][0][i] * dl;
-      real u1 = 0, u2 = 0;
-      for (int i = 0; i < NV; i++) { u1 += J[c][1][i] * v[i]; u2 += J[c][2][i] * v[i]; }
-      real l1 = lamc[c][1] - u1 / A[c][1], l2 = lamc[c][2] - u2 / A[c][2];
-      /* Coulomb cone: a tangential impulse inside the static cone sticks, beyond it the contact slides on the dynamic cone
-       * (PhysX: static / dynamic friction of the material pair) */
-      real lim = cmu[c] * ln, nrm = sqrt(l1 * l1 + l2 * l2);
-      slid[c] = nrm > lim;
-      if (nrm > lim) { real sc = (nrm > 0) ? cmud[c] * ln / nrm : 0; l1 *= sc; l2 *= sc; }
-      real d1 = l1 - lamc[c][1], d2 = l2 - lamc[c][2];
-      lamc[c][1] = l1; lamc[c][2] = l2;
-      for (int i = 0; i < NV; i++) v[i] += T[c][1][i] * d1 + T[c][2][i] * d2;
+    /* one contact's update on the velocity vector vv (projected Gauss-Seidel step: normal row, then the two tangent rows on the cone) */
+#define CONTACT_UPDATE(c, vv) do { \
+      real un = 0; \
+      for (int i = 0; i < NV; i++) un += J[c][0][i] * (vv)[i]; \
+      real ln = lamc[c][0] - (un - vstar[c]) / A[c][0]; \
+      if (ln < 0) ln = 0; \
+      real dl = ln - lamc[c][0]; \
+      lamc[c][0] = ln; \
+      for (int i = 0; i < NV; i++) (vv)[i] += T[c][0][i] * dl; \
+      real u1 = 0, u2 = 0; \
+      for (int i = 0; i < NV; i++) { u1 += J[c][1][i] * (vv)[i]; u2 += J[c][2][i] * (vv)[i]; } \
+      real l1 = lamc[c][1] - u1 / A[c][1], l2 = lamc[c][2] - u2 / A[c][2]; \
+      /* Coulomb cone: a tangential impulse inside the static cone sticks, beyond it the contact slides on the dynamic cone \
+       * (PhysX: static / dynamic friction of the material pair) */ \
+      real lim = cmu[c] * ln, nrm = sqrt(l1 * l1 + l2 * l2); \
+      slid[c] = nrm > lim; \
+      if (nrm > lim) { real sc = (nrm > 0) ? cmud[c] * ln / nrm : 0; l1 *= sc; l2 *= sc; } \
+      real d1 = l1 - lamc[c][1], d2 = l2 - lamc[c][2]; \
+      lamc[c][1] = l1; lamc[c][2] = l2; \
+      for (int i = 0; i < NV; i++) (vv)[i] += T[c][1][i] * d1 + T[c][2][i] * d2; \
+    } while (0)
+    if (!g_solver_legs_parallel) {
+      for (int c = 0; c < nc; c++) CONTACT_UPDATE(c, v);
+    } else {
+      /* STUDY ORDER (tools/solver_order_study.py; never the contract the kernel is checked against): trunk and body-body contacts in
+       * list order, then the terrain contacts of the four legs SIDE BY SIDE — Gauss-Seidel inside a leg, every leg starting from the
+       * same velocity, the legs' velocity changes added up (block Jacobi over legs: what a lane-per-leg kernel could run concurrently) */
+      for (int c = 0; c < nc; c++)
+        if (C[c].dynA == 0 || C[c].dynB >= 0) CONTACT_UPDATE(c, v);
+      real v0[NV], dv[NV];
+      memcpy(v0, v, sizeof v0);
+      for (int i = 0; i < NV; i++) dv[i] = 0;
+      for (int leg = 0; leg < 4; leg++) {
+        real vl[NV];
+        memcpy(vl, v0, sizeof vl);
+        for (int c = 0; c < nc; c++)
+          if (C[c].dynB < 0 && C[c].dynA > 0 && (C[c].dynA - 1) / 3 == leg) CONTACT_UPDATE(c, vl);
+        for (int i = 0; i < NV; i++) dv[i] += vl[i] - v0[i];
+      }
+      for (int i = 0; i < NV; i++) v[i] = v0[i] + dv[i];
     }
+#undef CONTACT_UPDATE
     /* joint rows, plain Gauss-Seidel in joint order.  (Running the four legs side by side — block Jacobi — was tried and
      * does NOT converge: with the robot in the air the legs couple strongly through the light base.) */
     for (int j = 0; j < 12; j++) {

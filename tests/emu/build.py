@@ -11,16 +11,18 @@ OUT = os.path.join(HERE, "_build", "libgo1sim_emu.so")
 CLANG = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 
-def build(force=False):
+def build(force=False, defines=(), tag=""):
+    """defines / tag: a study build of the same sources (e.g. ("GO1_PGS_LEGS",), "_legs") next to the product's"""
+    out = OUT.replace(".so", tag + ".so")
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
     deps += [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "emu_runtime.cpp"), os.path.join(REPO, "include", "go1sim.h")]
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps):
-        return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-Wno-everything",
-           "-I", HERE, "-o", OUT, os.path.join(CSRC, "go1sim.hip"), os.path.join(HERE, "emu_runtime.cpp")]
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-Wno-everything"] + \
+          ["-D" + d for d in defines] + ["-I", HERE, "-o", out, os.path.join(CSRC, "go1sim.hip"), os.path.join(HERE, "emu_runtime.cpp")]
     subprocess.check_call(cmd, cwd=CSRC)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -21,10 +21,20 @@ def lib():
     return _lib
 
 
+_study_libs = {}
+
+
+def study_lib(defines, tag):
+    """a study build of the kernel sources (tests/emu/build.py): e.g. (("GO1_PGS_LEGS",), "_legs")"""
+    if tag not in _study_libs:
+        _study_libs[tag] = H.bind_library(ctypes.CDLL(emu_build.build(defines=defines, tag=tag)))
+    return _study_libs[tag]
+
+
 class EmuSim(H.Go1Sim):
-    def __init__(self, S, buffers, device_index=0):
+    def __init__(self, S, buffers, device_index=0, library=None):
         assert buffers.device.type == "cpu"
-        super().__init__(S, buffers, device_index, lib=lib())
+        super().__init__(S, buffers, device_index, lib=library if library is not None else lib())
 
     def _stream(self):
         return ctypes.c_void_p(0)

@@ -1,0 +1,46 @@
+"""A/B of step-kernel builds on the sim-only rate (4096 envs, train.py configuration): the product library and variant builds of the same
+sources (e.g. -DGO1_PGS_LEGS), each under N(0, 1) actions (robots falling and tangling: the bench's regime) and under zero actions (standing on
+four feet: one contact per leg).  Timing only — a variant's results are validated on the CPU (tests/test_emu_parity.py), not here.
+
+    python tools/probes/step_variant_ab.py [variant.so ...]"""
+import os
+import sys
+import time
+
+R_ = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+P_ = os.path.join(R_, "walk-these-ways_amd")
+for p in (os.path.join(P_, "shims"), P_, R_):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+import go1sim_host as H  # noqa: E402
+
+
+def rate(lib_path, zero_actions, envs=4096, steps=240):
+    if lib_path:
+        H.LIB_PATH, H._lib = os.path.abspath(lib_path), None
+    from bench import build_env
+    env, cfg = build_env(envs, 0, 0)
+    env.reset()
+    acts = (torch.zeros if zero_actions else torch.randn)(24, envs, 12, device="cuda")
+    for i in range(48):
+        env.step(acts[i % 24])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        env.step(acts[i % 24])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = env.env.sim.read_timings() if hasattr(env.env.sim, "read_timings") else None
+    return envs * steps / dt, 1e3 * dt / steps
+
+
+def main():
+    default = H.LIB_PATH
+    for path in [None] + sys.argv[1:]:
+        for zero in (False, True):
+            r, ms = rate(path or default, zero)
+            print(f"{os.path.basename(path or default):28s} {'zero actions (standing)' if zero else 'N(0,1) actions':24s}: {r / 1e6:6.2f} M env-steps/s, {ms:.3f} ms per env.step", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1354,7 +1354,13 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     }
     PROF(23);
     // one contact's turn (its record already in registers)
+    // (study build: `on` = this environment takes part; the others run the same instructions — the turn holds wave-level operations — on their
+    //  record k with their changes gated to zero)
+#ifdef GO1_PGS_LEGS
+    auto contact_turn = [&](int k, const SweepRec& R, bool on) {
+#else
     auto contact_turn = [&](int k, const SweepRec& R) {
+#endif
       const int fl = (int)R.q[8][3];
       const int legA = fl & 7, sb1 = fl >> 4;
       const bool self = (fl & 8) != 0;
@@ -1386,20 +1392,96 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       float l2 = R.q[9][2] - u2 * R.q[8][2];
       const float lim = (self ? s.mu : mu_s) * ln, nn = l1 * l1 + l2 * l2;      // robot-robot: the robot's own material
       if (nn > lim * lim) { const float sc = (self ? s.mu : mu_d) * ln * __builtin_amdgcn_rsqf(nn); l1 *= sc; l2 *= sc; }
-      const float e1 = l1 - R.q[9][1], e2 = l2 - R.q[9][2];
-      sweep_add_rows(R, st, m, dln, e1, e2);
+      float dq = dln, e1 = l1 - R.q[9][1], e2 = l2 - R.q[9][2];
+#ifdef GO1_PGS_LEGS
+      if (!on) dq = e1 = e2 = 0.f;
+#endif
+      sweep_add_rows(R, st, m, dq, e1, e2);
       if (anyB) {
-        const float m0 = mB * dln, m1 = mB * e1, m2 = mB * e2;
+        const float m0 = mB * dq, m1 = mB * e1, m2 = mB * e2;
         st.y01[0] = fmaf(Bq.u[0][0], m0, fmaf(Bq.u[1][0], m1, fmaf(Bq.u[2][0], m2, st.y01[0])));
         st.y01[1] = fmaf(Bq.u[0][1], m0, fmaf(Bq.u[1][1], m1, fmaf(Bq.u[2][1], m2, st.y01[1])));
         st.y2 = fmaf(Bq.u[0][2], m0, fmaf(Bq.u[1][2], m1, fmaf(Bq.u[2][2], m2, st.y2)));
       }
       // (SIG instances: the 4th word carries "this turn projected the friction impulse on the cone" for the test signature)
+#ifdef GO1_PGS_LEGS
+      if (leg == 0 && on) CRQ(k, 9) = (lf4){ln, l1, l2, SIG && nn > lim * lim ? 1.f : 0.f};
+#else
       if (leg == 0) CRQ(k, 9) = (lf4){ln, l1, l2, SIG && nn > lim * lim ? 1.f : 0.f};
+#endif
     };
     uint32_t sig_active = 0u;
+#ifdef GO1_PGS_LEGS
+    // STUDY BUILD (round 4; -DGO1_PGS_LEGS, not the product: the oracle follows it with go1_oracle_set_solver_order(1), tests/test_emu_parity.py,
+    // tools/solver_order_study.py): per sweep, trunk and body-body contacts in list order as below, then the terrain contacts of the four legs SIDE
+    // BY SIDE — every lane walks through the contacts of ITS leg (Gauss-Seidel inside the leg) on a private copy of the base state, the legs'
+    // base changes are added up once per sweep (block Jacobi over legs).  The serial length of a sweep is then the trunk / body-body count + the
+    // largest count on one leg instead of the environment's total.
+    uint32_t mine = 0u, coop = 0u;                               // contact indices: own leg's terrain contacts / the cooperative ones of the environment
+#pragma unroll 1
+    for (int k = 0; k < Kw; k++) {
+      const int fl = (int)CRQ(k, 8)[3];
+      if (k < K) {
+        if ((fl & 8) != 0 || (fl & 7) >= 4) coop |= 1u << k;
+        else if ((fl & 7) == leg) mine |= 1u << k;
+      }
+    }
+    uint32_t coop_w = 0u;                                          // wave-uniform: indices some environment of the wavefront treats cooperatively
+#pragma unroll 1
+    for (int k = 0; k < Kw; k++)
+      if (__ballot((coop >> k) & 1u) != 0ull) coop_w |= 1u << k;
+    int turns = 0;                                                 // wave-uniform: the largest number of contacts on one leg
+    {
+      const int cnt = __builtin_popcount(mine);
+#pragma unroll 1
+      for (int tt = 1; tt <= MAXC; tt++) { if (__ballot(cnt >= tt) == 0ull) break; turns = tt; }
+    }
+#endif
 #pragma unroll 1
     for (int it = 0; it < cfg.solver_iterations; it++) {
+#ifdef GO1_PGS_LEGS
+      for (uint32_t rest = coop_w; rest != 0u; rest &= rest - 1u) {
+        const int k = __builtin_ctz(rest);
+        SweepRec R;
+        sweep_rec_load(crl, el, k, R);
+        contact_turn(k, R, ((coop >> k) & 1u) != 0u);
+      }
+      {
+        SweepState sp = st;                                        // private copy: base state as the leg phase found it + the own contacts' changes
+        uint32_t rem = mine;
+#pragma unroll 1
+        for (int tt = 0; tt < turns; tt++) {
+          if (rem != 0u) {
+            const int k = __builtin_ctz(rem);
+            rem &= rem - 1u;
+            SweepRec R;
+            sweep_rec_load(crl, el, k, R);
+            float dn, d1, d2, pn, p1, p2;
+            sweep_row_dot(R, 0, sp, dn, pn);
+            sweep_row_dot(R, 1, sp, d1, p1);
+            sweep_row_dot(R, 2, sp, d2, p2);
+            const float un = R.q[2][1] + dn + pn;                  // = u_n - v*
+            float u1 = R.q[5][1] + d1 + p1, u2 = R.q[8][1] + d2 + p2;
+            const float ln_old = R.q[9][0];
+            const float ln = fmaxf(0.f, ln_old - un * R.q[2][2]);
+            const float dln = ln - ln_old;
+            u1 = fmaf(R.q[2][3], dln, u1);
+            u2 = fmaf(R.q[5][3], dln, u2);
+            float l1 = R.q[9][1] - u1 * R.q[5][2];
+            float l2 = R.q[9][2] - u2 * R.q[8][2];
+            const float lim = mu_s * ln, nn = l1 * l1 + l2 * l2;
+            if (nn > lim * lim) { const float sc = mu_d * ln * __builtin_amdgcn_rsqf(nn); l1 *= sc; l2 *= sc; }
+            sweep_add_rows(R, sp, 1.f, dln, l1 - R.q[9][1], l2 - R.q[9][2]);
+            CRQ(k, 9) = (lf4){ln, l1, l2, SIG && nn > lim * lim ? 1.f : 0.f};
+          }
+        }
+        // the legs' base changes meet; the own leg's part is already final
+        st.z01[0] += quad_sum(sp.z01[0] - st.z01[0]); st.z01[1] += quad_sum(sp.z01[1] - st.z01[1]);
+        st.z23[0] += quad_sum(sp.z23[0] - st.z23[0]); st.z23[1] += quad_sum(sp.z23[1] - st.z23[1]);
+        st.z45[0] += quad_sum(sp.z45[0] - st.z45[0]); st.z45[1] += quad_sum(sp.z45[1] - st.z45[1]);
+        st.y01 = sp.y01; st.y2 = sp.y2;
+      }
+#else
       // two records in flight: the next contact's ten slots are requested before the current contact's arithmetic starts
       // (one wavefront per SIMD: nothing else hides the LDS round trip)
       SweepRec RA, RB;
@@ -1413,6 +1495,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
           contact_turn(k + 1, RB);
         }
       }
+#endif
       // limit rows in joint order: the rate without the row's own impulse is projected on [lower, upper]
 #pragma unroll
       for (int lgi = 0; lgi < 4; lgi++) {
