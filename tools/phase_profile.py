@@ -25,8 +25,7 @@ PHASES = ["rest of the prologue (stash commit, input checks)", "torque model: ba
 
 
 def build(flags):
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"] + flags + \
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"] + flags + \
           ["-o", os.path.join(CSRC, "libgo1sim.so"), os.path.join(CSRC, "go1sim.hip")]
     subprocess.check_call(cmd, cwd=CSRC)
 
@@ -35,11 +34,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--lib", default=None, help="a library prebuilt with -DGO1_PROFILE (no rebuild on the GPU box, csrc/libgo1sim.so untouched)")
+    ap.add_argument("--zero-actions", action="store_true", help="robots standing on four feet instead of N(0,1) actions")
     args, extra = ap.parse_known_args()
-    build(["-DGO1_PROFILE"] + extra)
+    if args.lib is None:
+        build(["-DGO1_PROFILE"] + extra)
     try:
         import torch
         import go1sim_host as H
+        if args.lib is not None:
+            H.LIB_PATH, H._lib = os.path.abspath(args.lib), None
         from go1_gym.envs.base.legged_robot_config import make_cfg
         from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
         from scripts.train_config import apply_train_config
@@ -48,7 +52,7 @@ def main():
         lib = H.load_library()
         lib.go1sim_debug_read_profile.argtypes = [ctypes.c_void_p]
         buf = (ctypes.c_uint64 * 64)()
-        acts = torch.randn(args.steps, args.envs, 12, device="cuda")
+        acts = (torch.zeros if args.zero_actions else torch.randn)(args.steps, args.envs, 12, device="cuda")
         for t in range(10):
             env.step(acts[t])
         torch.cuda.synchronize()
@@ -62,7 +66,8 @@ def main():
         for i, name in enumerate(PHASES):
             print(f"  {i:2d} {name:42s} {buf[i] / args.steps:10.0f}  {100.0 * buf[i] / tot:5.1f} %")
     finally:
-        build([])
+        if args.lib is None:
+            build([])
 
 
 if __name__ == "__main__":

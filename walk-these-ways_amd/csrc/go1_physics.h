@@ -1345,6 +1345,36 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       Bq.u[2][0] = b6[0]; Bq.u[2][1] = b6[1]; Bq.u[2][2] = b6[2];
       Bq.legB = (int)b6[3];
     };
+#ifdef GO1_PGS_LEGS
+    // STUDY BUILD (round 4; -DGO1_PGS_LEGS, not the product: the oracle follows it with go1_oracle_set_solver_order(1), tests/test_emu_parity.py,
+    // tools/solver_order_study.py): per sweep, trunk and body-body contacts in list order as below, then the terrain contacts of the four legs SIDE
+    // BY SIDE — every lane walks through the contacts of ITS leg (Gauss-Seidel inside the leg) on a private copy of the base state, the legs'
+    // base changes are added up once per sweep (block Jacobi over legs).  The serial length of a sweep is then the trunk / body-body count + the
+    // largest count on one leg instead of the environment's total.
+    // contact indices: own leg's terrain contacts / the cooperative ones of the environment — straight from the slots the list gave out
+    uint32_t mine = 0u, coop = 0u;
+    {
+      const int leg_items[10] = {IT_FOOT, IT_FOOTW, IT_CALF1, IT_CALFW, IT_CALF2, IT_THIGH1, IT_THIGHW, IT_THIGH2, IT_HIP1, IT_HIP2};
+#pragma unroll
+      for (int i = 0; i < 10; i++) if (slot[leg_items[i]] >= 0) mine |= 1u << slot[leg_items[i]];
+      uint32_t tr = 0u;
+      if (slot[IT_TR0] >= 0) tr |= 1u << slot[IT_TR0];
+      if (slot[IT_TR1] >= 0) tr |= 1u << slot[IT_TR1];
+      if (slot[IT_TRW] >= 0) tr |= 1u << slot[IT_TRW];
+      const int s1 = nF + nS < K ? nF + nS : K;                      // body-body contacts: [nF, nF + nS) as far as they were listed
+      coop = quad_or(tr) | (s1 > nF ? ((1u << s1) - 1u) & ~((1u << nF) - 1u) : 0u);
+    }
+    uint32_t coop_w = 0u;                                          // wave-uniform: indices some environment of the wavefront treats cooperatively
+#pragma unroll 1
+    for (int k = 0; k < Kw; k++)
+      if (__ballot((coop >> k) & 1u) != 0ull) coop_w |= 1u << k;
+    int turns = 0;                                                 // wave-uniform: the largest number of contacts on one leg
+    {
+      const int cnt = __builtin_popcount(mine);
+#pragma unroll 1
+      for (int tt = 1; tt <= MAXC; tt++) { if (__ballot(cnt >= tt) == 0ull) break; turns = tt; }
+    }
+#endif
     // warm start: the state of the starting impulses (self-contacts and limit rows start from zero)
 #pragma unroll 1
     for (int k = 0; k < Kw; k++) {
@@ -1352,6 +1382,9 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       sweep_rec_load(crl, el, k, R);
       sweep_add_rows(R, st, (((int)R.q[8][3]) & 7) == leg ? 1.f : 0.f, R.q[9][0], R.q[9][1], R.q[9][2]);
     }
+#ifdef GO1_PGS_LEGS
+    LDS_PHASE();            // every lane has read every contact's starting impulse before a lane overwrites its own contacts' (lock step on the hardware)
+#endif
     PROF(23);
     // one contact's turn (its record already in registers)
     // (study build: `on` = this environment takes part; the others run the same instructions — the turn holds wave-level operations — on their
@@ -1411,32 +1444,6 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
 #endif
     };
     uint32_t sig_active = 0u;
-#ifdef GO1_PGS_LEGS
-    // STUDY BUILD (round 4; -DGO1_PGS_LEGS, not the product: the oracle follows it with go1_oracle_set_solver_order(1), tests/test_emu_parity.py,
-    // tools/solver_order_study.py): per sweep, trunk and body-body contacts in list order as below, then the terrain contacts of the four legs SIDE
-    // BY SIDE — every lane walks through the contacts of ITS leg (Gauss-Seidel inside the leg) on a private copy of the base state, the legs'
-    // base changes are added up once per sweep (block Jacobi over legs).  The serial length of a sweep is then the trunk / body-body count + the
-    // largest count on one leg instead of the environment's total.
-    uint32_t mine = 0u, coop = 0u;                               // contact indices: own leg's terrain contacts / the cooperative ones of the environment
-#pragma unroll 1
-    for (int k = 0; k < Kw; k++) {
-      const int fl = (int)CRQ(k, 8)[3];
-      if (k < K) {
-        if ((fl & 8) != 0 || (fl & 7) >= 4) coop |= 1u << k;
-        else if ((fl & 7) == leg) mine |= 1u << k;
-      }
-    }
-    uint32_t coop_w = 0u;                                          // wave-uniform: indices some environment of the wavefront treats cooperatively
-#pragma unroll 1
-    for (int k = 0; k < Kw; k++)
-      if (__ballot((coop >> k) & 1u) != 0ull) coop_w |= 1u << k;
-    int turns = 0;                                                 // wave-uniform: the largest number of contacts on one leg
-    {
-      const int cnt = __builtin_popcount(mine);
-#pragma unroll 1
-      for (int tt = 1; tt <= MAXC; tt++) { if (__ballot(cnt >= tt) == 0ull) break; turns = tt; }
-    }
-#endif
 #pragma unroll 1
     for (int it = 0; it < cfg.solver_iterations; it++) {
 #ifdef GO1_PGS_LEGS
