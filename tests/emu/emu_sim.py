@@ -17,7 +17,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = H.bind_library(ctypes.CDLL(emu_build.build()))
+        if os.environ.get("GO1_TEST_SOLVER_ORDER") == "legs":      # rehearsal of the study order (tests/conftest.py oracle_lib)
+            _lib = H.bind_library(ctypes.CDLL(emu_build.build(defines=("GO1_PGS_LEGS",), tag="_legs")))
+        else:
+            _lib = H.bind_library(ctypes.CDLL(emu_build.build()))
     return _lib
 
 
