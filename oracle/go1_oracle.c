@@ -607,8 +607,12 @@ static void jac_row(const Kin* k, int dynb, const real* x, const real* d, real* 
   }
 }
 
-/* study switch (tools/solver_order_study.py): 0 = the contract (contacts in list order), 1 = legs side by side */
-static int g_solver_legs_parallel = 0;
+/* sweep order.  2 = THE CONTRACT since round 5: trunk, hip, thigh and body-body contacts in list order, then the LOWER-LEG contacts (foot sphere,
+ * calf capsule) of the four legs side by side — what the kernel runs (csrc/go1_physics.h "SWEEP ORDER").  Comparison arms of
+ * tools/solver_order_study.py and tests/test_emu_parity.py::test_sweep_orders_converge_to_the_same_solve: 0 = every contact in list order (the
+ * contract of rounds 1-4); 1 = ALL terrain contacts of a leg side by side (round 4's study build: block Jacobi over hip / thigh contacts, which
+ * couple to the base through one or two joints, does not settle on a robot lying on its side — profiles/r05_solver_order_study.txt) */
+static int g_solver_legs_parallel = 2;
 void go1_oracle_set_solver_order(int legs_parallel) { g_solver_legs_parallel = legs_parallel; }
 
 /* ------------------------------------------------------------------ one physics substep (replaces gym.simulate) */
@@ -742,11 +746,12 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
     if (!g_solver_legs_parallel) {
       for (int c = 0; c < nc; c++) CONTACT_UPDATE(c, v);
     } else {
-      /* STUDY ORDER (tools/solver_order_study.py; never the contract the kernel is checked against): trunk and body-body contacts in
-       * list order, then the terrain contacts of the four legs SIDE BY SIDE — Gauss-Seidel inside a leg, every leg starting from the
-       * same velocity, the legs' velocity changes added up (block Jacobi over legs: what a lane-per-leg kernel could run concurrently) */
+      /* the contract (order 2): trunk, hip, thigh and body-body contacts in list order, then the lower-leg contacts of the four legs SIDE BY
+       * SIDE — Gauss-Seidel inside a leg, every leg starting from the same velocity, the legs' velocity changes added up (block Jacobi over
+       * legs: what a lane-per-leg kernel runs concurrently; convergence against the list order: profiles/r05_solver_order_study.txt) */
+#define LEG_PARALLEL(c) (C[c].dynB < 0 && C[c].dynA > 0 && (g_solver_legs_parallel == 1 || (C[c].dynA - 1) % 3 == 2))
       for (int c = 0; c < nc; c++)
-        if (C[c].dynA == 0 || C[c].dynB >= 0) CONTACT_UPDATE(c, v);
+        if (!LEG_PARALLEL(c)) CONTACT_UPDATE(c, v);
       real v0[NV], dv[NV];
       memcpy(v0, v, sizeof v0);
       for (int i = 0; i < NV; i++) dv[i] = 0;
@@ -754,7 +759,7 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
         real vl[NV];
         memcpy(vl, v0, sizeof vl);
         for (int c = 0; c < nc; c++)
-          if (C[c].dynB < 0 && C[c].dynA > 0 && (C[c].dynA - 1) / 3 == leg) CONTACT_UPDATE(c, vl);
+          if (LEG_PARALLEL(c) && (C[c].dynA - 1) / 3 == leg) CONTACT_UPDATE(c, vl);
         for (int i = 0; i < NV; i++) dv[i] += vl[i] - v0[i];
       }
       for (int i = 0; i < NV; i++) v[i] = v0[i] + dv[i];

@@ -21,11 +21,6 @@ def pytest_configure(config):
 def oracle_lib():
     import pyoracle
     pyoracle.build()
-    if os.environ.get("GO1_TEST_SOLVER_ORDER") == "legs":
-        # rehearsal of the study order as the contract: the whole CPU parity suite with the oracle in that order and
-        # the emulator on the -DGO1_PGS_LEGS build (tests/emu/emu_sim.lib honours the same variable)
-        for fp32 in (False, True):
-            pyoracle.lib(fp32).go1_oracle_set_solver_order(1)
     return pyoracle
 
 

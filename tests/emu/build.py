@@ -12,7 +12,7 @@ CLANG = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 
 def build(force=False, defines=(), tag=""):
-    """defines / tag: a study build of the same sources (e.g. ("GO1_PGS_LEGS",), "_legs") next to the product's"""
+    """defines / tag: a study build of the same sources (e.g. ("GO1_PROFILE",), "_prof") next to the product's"""
     out = OUT.replace(".so", tag + ".so")
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
     deps += [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "emu_runtime.cpp"), os.path.join(REPO, "include", "go1sim.h")]

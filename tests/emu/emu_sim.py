@@ -17,10 +17,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if os.environ.get("GO1_TEST_SOLVER_ORDER") == "legs":      # rehearsal of the study order (tests/conftest.py oracle_lib)
-            _lib = H.bind_library(ctypes.CDLL(emu_build.build(defines=("GO1_PGS_LEGS",), tag="_legs")))
-        else:
-            _lib = H.bind_library(ctypes.CDLL(emu_build.build()))
+        _lib = H.bind_library(ctypes.CDLL(emu_build.build()))
     return _lib
 
 
@@ -28,7 +25,7 @@ _study_libs = {}
 
 
 def study_lib(defines, tag):
-    """a study build of the kernel sources (tests/emu/build.py): e.g. (("GO1_PGS_LEGS",), "_legs")"""
+    """a study build of the kernel sources (tests/emu/build.py): e.g. (("GO1_PROFILE",), "_prof")"""
     if tag not in _study_libs:
         _study_libs[tag] = H.bind_library(ctypes.CDLL(emu_build.build(defines=defines, tag=tag)))
     return _study_libs[tag]

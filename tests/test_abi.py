@@ -30,6 +30,23 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     lib.go1sim_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.go1sim_version()
+    # stale-binary guard: the library carries the hash of the sources it was built from, and build() keys on it (content, not mtimes)
+    want = g.source_hash(g.sim_sources(), g.SIM_FLAGS)
+    assert g.library_stamp(H.LIB_PATH) == want and want.encode() in lib.go1sim_version()
+
+
+def test_build_rebuilds_a_library_whose_stamp_does_not_match_the_sources(tmp_path, monkeypatch):
+    """a library built from other sources (here: a copy with its stamp overwritten) is not accepted by the up-to-date check"""
+    import __graft_entry__ as g
+    g.build_ppo_hip()
+    path = os.path.join(g.CSRC, "libgo1ppo.so")
+    want = g.source_hash(g.ppo_sources(), g.PPO_FLAGS)
+    assert g.library_stamp(path) == want
+    stale = tmp_path / "libstale.so"
+    blob = open(path, "rb").read()
+    stale.write_bytes(blob.replace(g.STAMP + want.encode(), g.STAMP + b"0" * 16))
+    assert g.library_stamp(str(stale)) == "0" * 16 != want
+    assert g.library_stamp(str(tmp_path / "absent.so")) is None
 
 
 def test_struct_sizes_match_oracle_build(oracle_lib):

@@ -11,6 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
 import go1sim_host as H  # noqa: E402
+from test_gpu_parity import ATTRIBUTED_BOUND, RULE_B_FACTOR, RULE_B_FLOOR  # noqa: E402  (constants only: that module's tests need the GPU)
 from golden.variants import FUZZ_VARIANTS, random_switches  # noqa: E402
 from util import (GOLDEN, RESAMPLE_MODES, check_resample_against_reference, load_maps_fixture, load_resample_fixture, maps_fixture_stream, maps_keep,  # noqa: E402
                   make_sim, randomize_dr, standing_state)
@@ -73,9 +74,11 @@ def env_ratio(Bx, Bc, tols, N):
 def assert_attributed(Be, Bc, B32, tols, N, where):
     r, r32 = env_ratio(Be, Bc, tols, N), env_ratio(B32, Bc, tols, N)
     bad = r > 1.0
-    ok = (Be.contact_signature != Bc.contact_signature).any(0) | (r32 > 0.5 * r)
+    # rule (b) of tests/test_gpu_parity.py with ITS frozen constants (until round 5 this file had a private `r32 > 0.5 r`; the hardware suite's
+    # rule is the one that was measured — 4096 envs x 40 steps x 3 instances — and one rule set is easier to audit than two)
+    ok = (Be.contact_signature != Bc.contact_signature).any(0) | ((r32 > RULE_B_FLOOR) & (r <= RULE_B_FACTOR * r32))
     assert not bool((bad & ~ok).any()), (where, (bad & ~ok).nonzero().flatten().tolist(), r[bad & ~ok].tolist())
-    assert float(r.max()) < 50.0, (where, float(r.max()))
+    assert float(r.max()) < ATTRIBUTED_BOUND, (where, float(r.max()))
     return int(bad.sum())
 
 
@@ -508,26 +511,16 @@ def test_emulated_kernel_under_random_configurations(oracle_lib, emu, case):
         resync(Bc, Be, sim, orc)
 
 
-# ---- study build: the legs' terrain contacts side by side (-DGO1_PGS_LEGS; oracle: go1_oracle_set_solver_order(1)) -------------------------
-@pytest.fixture()
-def legs_order(oracle_lib, emu):
-    """(emulator library of the study build, the oracle libraries switched to the study order for the duration of the test)"""
-    library = emu.study_lib(("GO1_PGS_LEGS",), "_legs")
-    libs = [oracle_lib.lib(False), oracle_lib.lib(True)]
-    for L in libs:
-        L.go1_oracle_set_solver_order(1)
-    yield library
-    for L in libs:
-        L.go1_oracle_set_solver_order(0)
-
-
-def test_study_order_differs_from_the_contract_and_converges_to_the_same_solve(oracle_lib, legs_order):
-    """the switch is live (4 sweeps in the two orders differ beyond round-off) and on robots standing on their feet under random joint
-    rates and torques both orders approach the same converged solve: 64 sweeps agree within 2e-3 rad/s, while 4 sweeps of EITHER order
-    are 0.17 rad/s away from it (measured) — the order costs nothing in convergence there (tools/solver_order_study.py for the statistics)"""
+# ---- sweep order: the legs' terrain contacts side by side (the contract) against the list order (oracle switch only) ----------------------
+def test_sweep_orders_converge_to_the_same_solve(oracle_lib):
+    """the oracle's order switch (2 = the contract: lower-leg contacts side by side; 1 = all of a leg's terrain contacts side by side, round 4's
+    study order; 0 = list order, the contract of rounds 1-4) is live (4 sweeps in list order and side by side differ beyond round-off) and on
+    robots standing on their feet under random joint rates and torques the orders approach the same converged solve: 64 sweeps agree within
+    2e-3 rad/s, while 4 sweeps of EITHER order are 0.17 rad/s away from it (measured) — the order costs nothing in convergence there
+    (tools/solver_order_study.py for the statistics; on its feet a robot has no hip / thigh contacts: orders 1 and 2 coincide)"""
     N = 16
     out = {}
-    for order in (0, 1):
+    for order in (0, 1, 2):
         for sweeps in (4, 64):
             cfg, S, meta, B = make_sim("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
             g = torch.Generator().manual_seed(2)
@@ -538,82 +531,40 @@ def test_study_order_differs_from_the_contract_and_converges_to_the_same_solve(o
             S.solver_iterations = sweeps
             orc = oracle_lib.Oracle(S, B)
             orc.L.go1_oracle_set_solver_order(order)
-            for _ in range(3):
-                orc.physics_substep()
+            try:
+                for _ in range(3):
+                    orc.physics_substep()
+            finally:
+                orc.L.go1_oracle_set_solver_order(2)
             out[(order, sweeps)] = torch.cat([B.root_states[7:13], B.dof_vel]).clone()
-    assert float((out[(0, 4)] - out[(1, 4)]).abs().max()) > 1e-4
-    assert float((out[(0, 64)] - out[(1, 64)]).abs().max()) < 2e-3
-    for order in (0, 1):
+    assert float((out[(0, 4)] - out[(2, 4)]).abs().max()) > 1e-4
+    assert torch.equal(out[(1, 4)], out[(2, 4)])
+    assert float((out[(0, 64)] - out[(2, 64)]).abs().max()) < 2e-3
+    for order in (0, 2):
         assert 0.05 < float((out[(order, 4)] - out[(0, 64)]).abs().max()) < 0.5
 
 
-@pytest.mark.parametrize("scenario", ["standing", "dropped", "tumbling"])
-def test_study_build_physics_substep_matches_oracle_in_the_study_order(oracle_lib, emu, legs_order, scenario):
-    """test_emulated_physics_substep_matches_oracle for the study build: kernel and oracle both solve the legs side by side"""
-    N = 32
-    cfg, S, meta, Bc = make_sim("train", N, seed=3, extra={"domain_rand": dict(randomize_gravity=False)})
-    randomize_dr(Bc, 3)
-    orc = oracle_lib.Oracle(S, Bc)
-    orc.reset_idx()
-    Be = Bc.clone_to("cpu")
-    sim = emu.EmuSim(S, Be, library=legs_order)
-    g = torch.Generator().manual_seed(1)
-    if scenario == "standing":
-        standing_state(S, Bc, z=0.28)
-    elif scenario == "dropped":
-        Bc.root_states[2].uniform_(0.05, 0.3, generator=g)
-        Bc.root_states[9] = -1.5
-    else:
-        q = torch.randn(4, N, generator=g)
-        Bc.root_states[3:7] = q / q.norm(dim=0, keepdim=True)
-        Bc.root_states[2].uniform_(0.08, 0.35, generator=g)
-        Bc.root_states[7:13].uniform_(-2, 2, generator=g)
-        Bc.dof_vel.uniform_(-5, 5, generator=g)
-    Bc.torques.uniform_(-20, 20, generator=g)
-    resync(Bc, Be, sim, orc)
-    bad = torch.zeros(N, dtype=torch.bool)
-    for it in range(5):
-        orc.physics_substep()
-        sim.physics_substep()
-        for k, tol in (("root_states", 2e-4), ("dof_pos", 2e-5), ("dof_vel", 3e-3)):
-            bad |= ((Be.tensors[k] - Bc.tensors[k]).abs() > tol).any(0)
-        bad |= ((Be.contact_forces - Bc.contact_forces).abs() > 5e-2 + 2e-3 * Bc.contact_forces.abs()).any(0)
-        resync(Bc, Be, sim, orc)
-    assert int(bad.sum()) <= (0 if scenario == "standing" else 1), int(bad.sum())
-    assert float(Bc.contact_forces.abs().max()) > 1.0
-
-
-def test_study_build_full_step_in_the_contact_heavy_regime(oracle_lib, emu, legs_order):
-    """test_emulated_full_step_in_the_contact_heavy_regime for the study build (trunk + body-body contacts cooperative, the legs' lists side by side)"""
-    N, seed = 32, 4
-    cfg, S, meta, Bc = make_sim("train", N, seed=3, extra={"domain_rand": dict(randomize_gravity=False)})
-    randomize_dr(Bc, 3)
-    Bc.enable_contact_signature()
-    orc = oracle_lib.Oracle(S, Bc)
-    orc.reset_idx()
-    Be = Bc.clone_to("cpu")
-    sim = emu.EmuSim(S, Be, library=legs_order)
-    g = torch.Generator().manual_seed(seed)
-    q = torch.randn(4, N, generator=g)
-    Bc.root_states[3:7] = q / q.norm(dim=0, keepdim=True)
-    Bc.root_states[2].uniform_(0.06, 0.25, generator=g)
-    Bc.root_states[7:13].uniform_(-1.5, 1.5, generator=g)
-    lo = torch.tensor([-0.86, -0.68, -2.81] * 4).unsqueeze(1)
-    hi = torch.tensor([0.86, 4.50, -0.89] * 4).unsqueeze(1)
-    Bc.dof_pos[:] = lo + (hi - lo) * torch.rand(12, N, generator=g)
-    Bc.dof_vel.uniform_(-4, 4, generator=g)
-    Bc.episode_length_buf[:] = 5
-    resync(Bc, Be, sim, orc)
-    sh = Shadow32(oracle_lib, S, Bc, orc)
-    rng = np.random.default_rng(seed + 1)
-    tols = (("root_states", 1e-3, 1e-3), ("dof_pos", 2e-4, 0), ("dof_vel", 1e-2, 1e-3), ("torques", 5e-3, 0), ("rew_buf", 1e-4, 0), ("contact_forces", 1e-1, 5e-3))
-    for step in range(6):
-        a = (rng.standard_normal((N, 12)) * 1.5).astype(np.float32)
-        orc.step(a)
-        sh.o.step(a)
-        sim.step(torch.from_numpy(a))
-        assert torch.equal(Be.reset_buf, Bc.reset_buf), step
-        assert_attributed(Be, Bc, sh.B, tols, N, step)
-        resync(Bc, Be, sim, orc)
-        sh.sync()
-    assert int(Be.fault_counts[:10].sum()) == 0 and int(Be.contact_drop_counts.sum()) == int(Bc.contact_drop_counts.sum())
+def test_hip_and_thigh_contacts_stay_in_list_order_for_a_reason(oracle_lib):
+    """why the contract is order 2 and not round 4's study order 1: a limp robot lying on its side (hips, thighs, calves and a trunk edge on the
+    ground) comes to rest under the list order and under order 2, and keeps creeping at > 1 cm/s when block Jacobi runs over the hip and thigh
+    contacts as well (they couple to the base through one or two joints: every leg stops the WHOLE base) — with 8 sweeps too."""
+    creep = {}
+    for order in (0, 1, 2):
+        cfg, S, meta, B = make_sim("train", 1, extra={"domain_rand": dict(randomize_gravity=False)})
+        S.solver_iterations = 8
+        standing_state(S, B, 0.30)
+        B.root_states[2, 0] = 0.12; B.root_states[3, 0] = np.sin(np.pi / 4); B.root_states[6, 0] = np.cos(np.pi / 4)
+        orc = oracle_lib.Oracle(S, B)
+        orc.L.go1_oracle_set_solver_order(order)
+        B.torques.zero_()
+        try:
+            for _ in range(800):
+                orc.physics_substep()
+            v = 0.0
+            for _ in range(40):
+                orc.physics_substep()
+                v = max(v, float(B.root_states[7:10].norm()))
+        finally:
+            orc.L.go1_oracle_set_solver_order(2)
+        creep[order] = v
+    assert creep[0] < 1e-3 and creep[2] < 1e-3 and creep[1] > 5e-3, creep

@@ -1,12 +1,17 @@
 """Would a lane-per-leg kernel that solves the four legs' terrain contacts SIDE BY SIDE (Gauss-Seidel inside a leg, the legs' velocity changes
 added up: block Jacobi over legs) still converge like the contract's sweep over the contact list?  The sweeps are 32 % of the step kernel's serial
 spine and their length is the contact COUNT of the slowest environment of a wavefront; side by side it would be the largest count of one LEG.
-CPU study on the fp64 oracle (`go1_oracle_set_solver_order`, a study switch — the contract is unchanged): at states taken from rollouts, one
+CPU study on the fp64 oracle (`go1_oracle_set_solver_order`: 1 = legs side by side, the contract since round 5; 0 = list order, rounds 1-4): at states taken from rollouts, one
 physics substep is solved with 64 list-order sweeps (the converged reference of the same contact model) and with 2 / 4 / 8 sweeps in both orders;
 reported is the distance of the resulting generalised velocity from the converged one, in units of the parity suite's tolerances
 (base 2e-3 m/s, 1e-2 rad/s; joints 2e-2 rad/s).
 
-    python tools/solver_order_study.py > profiles/r04_solver_order_study.txt
+    python tools/solver_order_study.py > profiles/r05_solver_order_study.txt       (round 4's record: profiles/r04_solver_order_study.txt)
+
+Round 5 added the third order — only the contacts of the LOWER LEG (foot sphere, calf capsule) side by side, hip and thigh contacts with the
+trunk's in list order — and the regime that separates the three: robots lying at rest on hips / thighs / trunk.  A hip or thigh contact couples
+to the base through one or two joints only; block Jacobi over such contacts over-corrects the base (every leg stops the WHOLE base) and leaves
+a creep that more sweeps do not remove.  Order 2 is the contract (oracle/go1_oracle.c g_solver_legs_parallel = 2, csrc/go1_physics.h).
 """
 import os
 import sys
@@ -22,6 +27,7 @@ import pyoracle  # noqa: E402
 from util import make_sim, standing_state  # noqa: E402
 
 N = 64
+ORDER_NAMES = {0: 'list order (rounds 1-4)', 1: 'all leg contacts side by side', 2: 'feet + calves side by side (contract)'}
 TOL = np.concatenate([np.full(3, 2e-3), np.full(3, 1e-2), np.full(12, 2e-2)])[:, None]      # v_lin, v_ang, joint rates
 
 
@@ -50,7 +56,7 @@ def study(name, action_std, steps, every, S, B, orc, rng):
     counts, legmax = [], []
     for t in range(steps):
         a = (rng.standard_normal((N, 12)) * action_std).astype(np.float32)
-        L.go1_oracle_set_solver_order(0)
+        L.go1_oracle_set_solver_order(2)
         S.solver_iterations = 4
         orc.step(a)
         if t % every:
@@ -61,7 +67,7 @@ def study(name, action_std, steps, every, S, B, orc, rng):
         ref = velocity(B)
         c, lm = contacts_per_leg(B)
         counts.append(c); legmax.append(lm)
-        for order in (0, 1):
+        for order in (0, 1, 2):
             for sweeps in (2, 4, 8):
                 restore(B, snap)
                 L.go1_oracle_set_solver_order(order)
@@ -69,7 +75,7 @@ def study(name, action_std, steps, every, S, B, orc, rng):
                 orc.physics_substep()
                 e = np.abs(velocity(B) - ref) / TOL
                 errs.setdefault((order, sweeps), []).append(e.max(0))
-        L.go1_oracle_set_solver_order(0)
+        L.go1_oracle_set_solver_order(2)
         S.solver_iterations = 4
         restore(B, snap)
     counts, legmax = np.concatenate(counts), np.concatenate(legmax)
@@ -79,7 +85,7 @@ def study(name, action_std, steps, every, S, B, orc, rng):
     for (order, sweeps), e in sorted(errs.items()):
         e = np.concatenate(e)
         q = np.quantile(e, [0.5, 0.9, 0.99])
-        print(f"  {'legs side by side' if order else 'list order (contract)':22s} {sweeps:2d} sweeps        {q[0]:10.3f} {q[1]:10.3f} {q[2]:10.3f} {e.max():10.2f} {100 * (e > 1).mean():9.1f} %")
+        print(f"  {ORDER_NAMES[order]:34s} {sweeps:2d} sweeps        {q[0]:10.3f} {q[1]:10.3f} {q[2]:10.3f} {e.max():10.2f} {100 * (e > 1).mean():9.1f} %")
     return errs
 
 
@@ -96,13 +102,47 @@ def closed_loop(order, sweeps, action_std, steps, seed):
         resets += int(B.reset_buf.sum())
         zsum += float(B.root_states[2].mean())
         wmax = max(wmax, float(B.root_states[10:13].norm(dim=0).max()))
-    orc.L.go1_oracle_set_solver_order(0)
+    orc.L.go1_oracle_set_solver_order(2)
     finite = bool(torch.isfinite(B.root_states).all() and torch.isfinite(B.dof_vel).all())
     return resets, zsum / steps, wmax, finite
 
 
+def fallen_at_rest(order, sweeps, seed=3, n=64):
+    """limp robots dropped in random orientations; after 3 s: the largest base |v| and |omega| over 40 substeps, per environment (a robot at rest
+    on hips / thighs / trunk is what the rollouts above never hold: the training configuration ends an episode soon after a fall)"""
+    cfg, S, meta, B = make_sim("train", n, extra={"domain_rand": dict(randomize_gravity=False)})
+    g = torch.Generator().manual_seed(seed)
+    standing_state(S, B, 0.30)
+    q = torch.randn(4, n, generator=g)
+    B.root_states[3:7] = q / q.norm(dim=0, keepdim=True)
+    lo = torch.tensor([-0.86, -0.68, -2.81] * 4).unsqueeze(1)
+    hi = torch.tensor([0.86, 4.50, -0.89] * 4).unsqueeze(1)
+    B.dof_pos[:] = lo + (hi - lo) * torch.rand(12, n, generator=g)
+    S.solver_iterations = sweeps
+    orc = pyoracle.Oracle(S, B)
+    orc.L.go1_oracle_set_solver_order(order)
+    B.torques.zero_()
+    for _ in range(600):
+        orc.physics_substep()
+    wmax, vmax = torch.zeros(n), torch.zeros(n)
+    for _ in range(40):
+        orc.physics_substep()
+        wmax = torch.maximum(wmax, B.root_states[10:13].norm(dim=0))
+        vmax = torch.maximum(vmax, B.root_states[7:10].norm(dim=0))
+    orc.L.go1_oracle_set_solver_order(2)
+    ncont = (B.contact_forces.view(17, 3, -1).norm(dim=1) > 0).sum(0).float()
+    return wmax.numpy(), vmax.numpy(), float(ncont.mean())
+
+
 def main():
     print(__doc__.split("\n\n")[0])
+    print("\nLimp robots dropped in random orientations and joint angles, 64 environments, 3 s of settling, then 40 substeps: base creep at rest")
+    print("  order                              sweeps   bodies in contact   |v| median / 90 % / max [m/s]      |omega| median / 90 % / max [rad/s]")
+    for order in (0, 1, 2):
+        for sweeps in (4, 8):
+            w, v, nc = fallen_at_rest(order, sweeps)
+            print(f"  {ORDER_NAMES[order]:34s} {sweeps:4d} {nc:12.1f}          {np.median(v):.4f} / {np.quantile(v, 0.9):.4f} / {v.max():.4f}"
+                  f"            {np.median(w):.4f} / {np.quantile(w, 0.9):.4f} / {w.max():.4f}")
     for name, std, steps, every in (("standing / shuffling (actions N(0, 0.1))", 0.1, 60, 6), ("walking-scale actions N(0, 0.5)", 0.5, 60, 6),
                                     ("falling and tangling (actions N(0, 1): the parity suite's regime)", 1.0, 90, 6)):
         cfg, S, meta, B = make_sim("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
@@ -111,9 +151,9 @@ def main():
         study(name, std, steps, every, S, B, orc, np.random.default_rng(11))
     print("\nClosed loop, 300 policy steps (1200 substeps) of N(0, 0.5) actions from standing, same action stream; episodes ended (falls + time-outs),")
     print("mean base height, largest base angular velocity, all state finite:")
-    for order, sweeps in ((0, 4), (1, 4), (1, 8)):
+    for order, sweeps in ((0, 4), (1, 4), (1, 8), (2, 4), (2, 8)):
         r, z, w, fin = closed_loop(order, sweeps, 0.5, 300, 5)
-        print(f"  {'legs side by side' if order else 'list order (contract)':22s} {sweeps} sweeps: {r:4d} episodes ended, mean height {z:.3f} m, max |omega| {w:6.2f} rad/s, finite {fin}")
+        print(f"  {ORDER_NAMES[order]:34s} {sweeps} sweeps: {r:4d} episodes ended, mean height {z:.3f} m, max |omega| {w:6.2f} rad/s, finite {fin}")
 
 
 if __name__ == "__main__":

@@ -23,6 +23,9 @@
 #define EPW 16                       // environments per wavefront
 #define MAXC GO1_MAX_CONTACTS        // solver contacts per env (24; oracle: the same constant of include/go1sim.h)
 #define NRJ 12                       // joint-limit rows: joint j
+#ifndef PGS_SIDE_BY_SIDE_ITEMS
+#define PGS_SIDE_BY_SIDE_ITEMS 5     // of a leg's 10 terrain items (foot, foot-wall, calf x3 | thigh x3, hip x2) the first 5 — the lower leg's — are solved side by side
+#endif                               // (10 = round 4's study order, for tools/probes/step_variant_ab.py only: does not settle on a side-lying robot)
 #define MAXSB 6                      // leg-leg self-contacts per env: one per pair of legs (the deepest of its four capsule combinations)
 #define MAXTR 4                      // trunk corners per env (oracle: GO1_MAX_TRUNK_POINTS)
 #define GO1_LIMIT_RECOVERY_RATE 10.0f   // rad/s: a joint found beyond a stop is brought back at a bounded rate
@@ -1345,19 +1348,21 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       Bq.u[2][0] = b6[0]; Bq.u[2][1] = b6[1]; Bq.u[2][2] = b6[2];
       Bq.legB = (int)b6[3];
     };
-#ifdef GO1_PGS_LEGS
-    // STUDY BUILD (round 4; -DGO1_PGS_LEGS, not the product: the oracle follows it with go1_oracle_set_solver_order(1), tests/test_emu_parity.py,
-    // tools/solver_order_study.py): per sweep, trunk and body-body contacts in list order as below, then the terrain contacts of the four legs SIDE
-    // BY SIDE — every lane walks through the contacts of ITS leg (Gauss-Seidel inside the leg) on a private copy of the base state, the legs'
-    // base changes are added up once per sweep (block Jacobi over legs).  The serial length of a sweep is then the trunk / body-body count + the
-    // largest count on one leg instead of the environment's total.
-    // contact indices: own leg's terrain contacts / the cooperative ones of the environment — straight from the slots the list gave out
+    // SWEEP ORDER (the contract since round 5; oracle: physics_substep's sweep in oracle/go1_oracle.c, measured against the list order in
+    // profiles/r05_solver_order_study.txt): per sweep, trunk, hip, thigh and body-body contacts in list order ("cooperative" turns: the quad
+    // works on one contact), then the LOWER-LEG terrain contacts (foot sphere, calf capsule) of the four legs SIDE BY SIDE — every lane walks
+    // through the contacts of ITS leg (Gauss-Seidel inside the leg) on a private copy of the base state, the legs' base changes are added up
+    // once per sweep (block Jacobi over legs).  The serial length of a sweep is then the cooperative count + the largest lower-leg count on one
+    // leg instead of the environment's total.  Hip and thigh contacts stay cooperative: they couple to the base through one or two joints, and
+    // block Jacobi over them over-corrects the base (a robot lying on its side creeps; more sweeps do not cure it).
+    // contact indices: own leg's side-by-side contacts / the cooperative ones of the environment — straight from the slots the list gave out
     uint32_t mine = 0u, coop = 0u;
     {
       const int leg_items[10] = {IT_FOOT, IT_FOOTW, IT_CALF1, IT_CALFW, IT_CALF2, IT_THIGH1, IT_THIGHW, IT_THIGH2, IT_HIP1, IT_HIP2};
-#pragma unroll
-      for (int i = 0; i < 10; i++) if (slot[leg_items[i]] >= 0) mine |= 1u << slot[leg_items[i]];
       uint32_t tr = 0u;
+#pragma unroll
+      for (int i = 0; i < 10; i++)
+        if (slot[leg_items[i]] >= 0) { if (i < PGS_SIDE_BY_SIDE_ITEMS) mine |= 1u << slot[leg_items[i]]; else tr |= 1u << slot[leg_items[i]]; }
       if (slot[IT_TR0] >= 0) tr |= 1u << slot[IT_TR0];
       if (slot[IT_TR1] >= 0) tr |= 1u << slot[IT_TR1];
       if (slot[IT_TRW] >= 0) tr |= 1u << slot[IT_TRW];
@@ -1374,7 +1379,6 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
 #pragma unroll 1
       for (int tt = 1; tt <= MAXC; tt++) { if (__ballot(cnt >= tt) == 0ull) break; turns = tt; }
     }
-#endif
     // warm start: the state of the starting impulses (self-contacts and limit rows start from zero)
 #pragma unroll 1
     for (int k = 0; k < Kw; k++) {
@@ -1382,18 +1386,11 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       sweep_rec_load(crl, el, k, R);
       sweep_add_rows(R, st, (((int)R.q[8][3]) & 7) == leg ? 1.f : 0.f, R.q[9][0], R.q[9][1], R.q[9][2]);
     }
-#ifdef GO1_PGS_LEGS
     LDS_PHASE();            // every lane has read every contact's starting impulse before a lane overwrites its own contacts' (lock step on the hardware)
-#endif
     PROF(23);
-    // one contact's turn (its record already in registers)
-    // (study build: `on` = this environment takes part; the others run the same instructions — the turn holds wave-level operations — on their
-    //  record k with their changes gated to zero)
-#ifdef GO1_PGS_LEGS
+    // one cooperative contact's turn (its record already in registers).  `on` = this environment takes part; the others run the same
+    // instructions — the turn holds wave-level operations — on their record k with their changes gated to zero
     auto contact_turn = [&](int k, const SweepRec& R, bool on) {
-#else
-    auto contact_turn = [&](int k, const SweepRec& R) {
-#endif
       const int fl = (int)R.q[8][3];
       const int legA = fl & 7, sb1 = fl >> 4;
       const bool self = (fl & 8) != 0;
@@ -1426,9 +1423,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       const float lim = (self ? s.mu : mu_s) * ln, nn = l1 * l1 + l2 * l2;      // robot-robot: the robot's own material
       if (nn > lim * lim) { const float sc = (self ? s.mu : mu_d) * ln * __builtin_amdgcn_rsqf(nn); l1 *= sc; l2 *= sc; }
       float dq = dln, e1 = l1 - R.q[9][1], e2 = l2 - R.q[9][2];
-#ifdef GO1_PGS_LEGS
       if (!on) dq = e1 = e2 = 0.f;
-#endif
       sweep_add_rows(R, st, m, dq, e1, e2);
       if (anyB) {
         const float m0 = mB * dq, m1 = mB * e1, m2 = mB * e2;
@@ -1437,16 +1432,11 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         st.y2 = fmaf(Bq.u[0][2], m0, fmaf(Bq.u[1][2], m1, fmaf(Bq.u[2][2], m2, st.y2)));
       }
       // (SIG instances: the 4th word carries "this turn projected the friction impulse on the cone" for the test signature)
-#ifdef GO1_PGS_LEGS
       if (leg == 0 && on) CRQ(k, 9) = (lf4){ln, l1, l2, SIG && nn > lim * lim ? 1.f : 0.f};
-#else
-      if (leg == 0) CRQ(k, 9) = (lf4){ln, l1, l2, SIG && nn > lim * lim ? 1.f : 0.f};
-#endif
     };
     uint32_t sig_active = 0u;
 #pragma unroll 1
     for (int it = 0; it < cfg.solver_iterations; it++) {
-#ifdef GO1_PGS_LEGS
       for (uint32_t rest = coop_w; rest != 0u; rest &= rest - 1u) {
         const int k = __builtin_ctz(rest);
         SweepRec R;
@@ -1488,21 +1478,6 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         st.z45[0] += quad_sum(sp.z45[0] - st.z45[0]); st.z45[1] += quad_sum(sp.z45[1] - st.z45[1]);
         st.y01 = sp.y01; st.y2 = sp.y2;
       }
-#else
-      // two records in flight: the next contact's ten slots are requested before the current contact's arithmetic starts
-      // (one wavefront per SIMD: nothing else hides the LDS round trip)
-      SweepRec RA, RB;
-      if (Kw > 0) sweep_rec_load(crl, el, 0, RA);
-#pragma unroll 1
-      for (int k = 0; k < Kw; k += 2) {
-        if (k + 1 < Kw) sweep_rec_load(crl, el, k + 1, RB);
-        contact_turn(k, RA);
-        if (k + 1 < Kw) {
-          if (k + 2 < Kw) sweep_rec_load(crl, el, k + 2, RA);
-          contact_turn(k + 1, RB);
-        }
-      }
-#endif
       // limit rows in joint order: the rate without the row's own impulse is projected on [lower, upper]
 #pragma unroll
       for (int lgi = 0; lgi < 4; lgi++) {

@@ -1337,4 +1337,7 @@ extern "C" int go1ppo_wgrad_batched(const Go1PpoWgradProblem* device_probs, int 
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
 
-extern "C" const char* go1ppo_version(void) { return "go1ppo 0.3 (gfx950, abi 3)"; }
+#ifndef GO1_SOURCE_HASH
+#define GO1_SOURCE_HASH "unstamped"      // __graft_entry__.build_ppo_hip passes the sha256 of the sources + flags
+#endif
+extern "C" const char* go1ppo_version(void) { return "go1ppo 0.3 (gfx950, abi 3) go1-src:" GO1_SOURCE_HASH; }

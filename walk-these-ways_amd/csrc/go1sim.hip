@@ -579,7 +579,10 @@ extern "C" int go1sim_read_timings(Go1Sim* s, float* ms, int32_t max, int32_t* c
   *count = (int32_t)have;
   return 0;
 }
-extern "C" const char* go1sim_version(void) { return "go1sim 0.5 (gfx950, abi " GO1SIM_STR(GO1SIM_ABI_VERSION) ", 4 lanes/env)"; }
+#ifndef GO1_SOURCE_HASH
+#define GO1_SOURCE_HASH "unstamped"      // __graft_entry__.build_hip passes the sha256 of the sources + flags; smoke() / tests/test_abi.py compare
+#endif
+extern "C" const char* go1sim_version(void) { return "go1sim 0.6 (gfx950, abi " GO1SIM_STR(GO1SIM_ABI_VERSION) ", 4 lanes/env) go1-src:" GO1_SOURCE_HASH; }
 
 #ifdef GO1_PROFILE
 // debug build only (tools/phase_profile.py): read and clear the per-phase cycle accumulators of workgroup 0, lane 0
