@@ -607,12 +607,15 @@ static void jac_row(const Kin* k, int dynb, const real* x, const real* d, real* 
   }
 }
 
-/* sweep order.  2 = THE CONTRACT since round 5: trunk, hip, thigh and body-body contacts in list order, then the LOWER-LEG contacts (foot sphere,
- * calf capsule) of the four legs side by side — what the kernel runs (csrc/go1_physics.h "SWEEP ORDER").  Comparison arms of
- * tools/solver_order_study.py and tests/test_emu_parity.py::test_sweep_orders_converge_to_the_same_solve: 0 = every contact in list order (the
- * contract of rounds 1-4); 1 = ALL terrain contacts of a leg side by side (round 4's study build: block Jacobi over hip / thigh contacts, which
- * couple to the base through one or two joints, does not settle on a robot lying on its side — profiles/r05_solver_order_study.txt) */
-static int g_solver_legs_parallel = 2;
+/* sweep order.  3 = THE CONTRACT since round 5: trunk and body-body contacts in list order, then the terrain contacts of the four legs SIDE BY
+ * SIDE (Gauss-Seidel inside a leg, block Jacobi over legs), the hip and thigh rows with MASS SPLITTING — what the kernel runs
+ * (csrc/go1_physics.h "SWEEP ORDER").  Comparison arms of tools/solver_order_study.py and tests/test_emu_parity.py: 0 = every contact in list
+ * order (the contract of rounds 1-4); 1 = side by side without splitting (round 4's study build: block Jacobi over hip / thigh contacts, which
+ * couple to the base through one or two joints, does not settle on a robot lying on its side); 2 = only the lower-leg contacts side by side,
+ * hip / thigh in list order (settles, but no faster than the list order on the hardware: every wavefront holds a fallen robot whose
+ * cooperative turns the other fifteen wait for); 4 = every row split (slows the convergence of walking robots).
+ * Numbers: profiles/r05_solver_order_study.txt */
+static int g_solver_legs_parallel = 3;
 void go1_oracle_set_solver_order(int legs_parallel) { g_solver_legs_parallel = legs_parallel; }
 
 /* ------------------------------------------------------------------ one physics substep (replaces gym.simulate) */
@@ -682,6 +685,14 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
   }
   real J[GO1_MAX_CONTACTS][3][NV], T[GO1_MAX_CONTACTS][3][NV], A[GO1_MAX_CONTACTS][3], vstar[GO1_MAX_CONTACTS], cmu[GO1_MAX_CONTACTS], cmud[GO1_MAX_CONTACTS];
   real lamc[GO1_MAX_CONTACTS][3];
+  /* orders 3 / 4 (mass splitting): TL = response of the own leg's joints with the base held, TS / AS = the split response / diagonal */
+  static real TL[GO1_MAX_CONTACTS][3][NV], TS[GO1_MAX_CONTACTS][3][NV], AS[GO1_MAX_CONTACTS][3];
+#pragma omp threadprivate(TL, TS, AS)
+  real Lll[12 * 12];
+  if (g_solver_legs_parallel >= 3) {
+    for (int r = 0; r < 12; r++) for (int cc = 0; cc < 12; cc++) Lll[r * 12 + cc] = M[(6 + r) * NV + 6 + cc];
+    cholesky(Lll, 12);
+  }
   for (int c = 0; c < nc; c++) {
     const real* dirs[3] = {C[c].n, C[c].t1, C[c].t2};
     for (int r = 0; r < 3; r++) {
@@ -696,6 +707,13 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
       real a = 0;
       for (int i = 0; i < NV; i++) a += J[c][r][i] * T[c][r][i];
       A[c][r] = a;
+      if (g_solver_legs_parallel >= 3) {
+        real x[12];
+        for (int i = 0; i < 12; i++) x[i] = J[c][r][6 + i];
+        chol_solve(Lll, 12, x);
+        for (int i = 0; i < 6; i++) TL[c][r][i] = 0;
+        for (int i = 0; i < 12; i++) TL[c][r][6 + i] = x[i];
+      }
     }
     /* PhysX default combine mode: average of the two materials (robot-robot: the robot's own) */
     const int self = C[c].repB >= 0;
@@ -723,7 +741,8 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
   for (int c = 0; c < nc; c++) slid[c] = 0;
   for (int it = 0; it < cfg->solver_iterations; it++) {
     /* one contact's update on the velocity vector vv (projected Gauss-Seidel step: normal row, then the two tangent rows on the cone) */
-#define CONTACT_UPDATE(c, vv) do { \
+#define CONTACT_UPDATE(c, vv) CONTACT_UPDATE_X(c, vv, T, A)
+#define CONTACT_UPDATE_X(c, vv, T, A) do { \
       real un = 0; \
       for (int i = 0; i < NV; i++) un += J[c][0][i] * (vv)[i]; \
       real ln = lamc[c][0] - (un - vstar[c]) / A[c][0]; \
@@ -745,10 +764,49 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
     } while (0)
     if (!g_solver_legs_parallel) {
       for (int c = 0; c < nc; c++) CONTACT_UPDATE(c, v);
+    } else if (g_solver_legs_parallel >= 3) {
+      /* THE CONTRACT (order 3): all terrain contacts of a leg side by side with MASS SPLITTING — in the leg phase the base answers a split
+       * row's impulse n times as strongly as it really does (n sub-bodies of 1/n of its articulated inertia, one per leg that holds split
+       * rows), which makes block Jacobi over legs convergent whatever the coupling; the true response of all impulse changes is applied
+       * when the legs meet.  3: the hip / thigh rows are split (lower-leg rows plain Jacobi); 4 (study): every row */
+      for (int c = 0; c < nc; c++)
+        if (C[c].dynA == 0 || C[c].dynB >= 0) CONTACT_UPDATE(c, v);
+      int legs_on = 0;
+      for (int leg = 0; leg < 4; leg++) {
+        int any = 0;
+        for (int c = 0; c < nc; c++)
+          if (C[c].dynB < 0 && C[c].dynA > 0 && (C[c].dynA - 1) / 3 == leg && (g_solver_legs_parallel == 4 || (C[c].dynA - 1) % 3 < 2)) any = 1;
+        legs_on += any;
+      }
+      const real nsplit = legs_on > 1 ? legs_on : 1;
+      for (int c = 0; c < nc; c++) {
+        if (!(C[c].dynB < 0 && C[c].dynA > 0)) continue;
+        const int split = g_solver_legs_parallel == 4 || (C[c].dynA - 1) % 3 < 2;
+        for (int r = 0; r < 3; r++) {
+          real a = 0;
+          for (int i = 0; i < NV; i++) {
+            TS[c][r][i] = split ? TL[c][r][i] + nsplit * (T[c][r][i] - TL[c][r][i]) : T[c][r][i];
+            a += J[c][r][i] * TS[c][r][i];
+          }
+          AS[c][r] = a;
+        }
+      }
+      real v0[NV], lam0[GO1_MAX_CONTACTS][3];
+      memcpy(v0, v, sizeof v0);
+      memcpy(lam0, lamc, sizeof lam0);
+      for (int leg = 0; leg < 4; leg++) {
+        real vl[NV];
+        memcpy(vl, v0, sizeof vl);
+        for (int c = 0; c < nc; c++)
+          if (C[c].dynB < 0 && C[c].dynA > 0 && (C[c].dynA - 1) / 3 == leg) CONTACT_UPDATE_X(c, vl, TS, AS);
+      }
+      for (int c = 0; c < nc; c++)
+        if (C[c].dynB < 0 && C[c].dynA > 0)
+          for (int r = 0; r < 3; r++)
+            for (int i = 0; i < NV; i++) v[i] += T[c][r][i] * (lamc[c][r] - lam0[c][r]);
     } else {
-      /* the contract (order 2): trunk, hip, thigh and body-body contacts in list order, then the lower-leg contacts of the four legs SIDE BY
-       * SIDE — Gauss-Seidel inside a leg, every leg starting from the same velocity, the legs' velocity changes added up (block Jacobi over
-       * legs: what a lane-per-leg kernel runs concurrently; convergence against the list order: profiles/r05_solver_order_study.txt) */
+      /* study orders 1 / 2: (2: trunk, hip, thigh and) body-body contacts in list order, then the (2: lower-leg) contacts of the four legs
+       * SIDE BY SIDE — Gauss-Seidel inside a leg, every leg starting from the same velocity, the legs' velocity changes added up */
 #define LEG_PARALLEL(c) (C[c].dynB < 0 && C[c].dynA > 0 && (g_solver_legs_parallel == 1 || (C[c].dynA - 1) % 3 == 2))
       for (int c = 0; c < nc; c++)
         if (!LEG_PARALLEL(c)) CONTACT_UPDATE(c, v);

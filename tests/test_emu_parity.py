@@ -402,7 +402,7 @@ def test_emulated_full_step_in_the_contact_heavy_regime(oracle_lib, emu, seed):
     resync(Bc, Be, sim, orc)
     sh = Shadow32(oracle_lib, S, Bc, orc)
     rng = np.random.default_rng(seed + 1)
-    peak_listed, self_pairs = 0, 0
+    peak_listed, self_pairs, split_substeps = 0, 0, 0
     # (a full step = 4 substeps without re-synchronisation, joints at their 28 rad/s rate limits: a rate error inside its own
     #  tolerance moves a joint by 5e-5 rad per substep)
     tols = (("root_states", 1e-3, 1e-3), ("dof_pos", 2e-4, 0), ("dof_vel", 1e-2, 1e-3), ("torques", 5e-3, 0), ("rew_buf", 1e-4, 0), ("contact_forces", 1e-1, 5e-3))
@@ -418,9 +418,14 @@ def test_emulated_full_step_in_the_contact_heavy_regime(oracle_lib, emu, seed):
                             for e in range(N)] for sb in range(4)])
         peak_listed = max(peak_listed, int(listed.max()))
         self_pairs += int((sig[:, 2] & 0xFFFFFFF != 0).sum())
+        # legs holding hip / thigh rows (word 0 bits 20..27: thigh ends, word 1 bits 9..12: thigh walls, 13..20: hip ends): with two or more
+        # of them the leg phase of the sweep splits the base (csrc/go1_physics.h "MASS SPLITTING")
+        legs_split = sum((((sig[:, 0] >> (20 + 2 * leg)) & 3) | ((sig[:, 1] >> (13 + 2 * leg)) & 3) | ((sig[:, 1] >> (9 + leg)) & 1)) != 0 for leg in range(4))
+        split_substeps += int((legs_split >= 2).sum())
         resync(Bc, Be, sim, orc)
         sh.sync()
     assert peak_listed > 8, peak_listed                               # beyond what round 2 could solve
+    assert split_substeps > 50, split_substeps                        # the mass-split leg phase ran (two or more legs with hip / thigh rows)
     assert int(Be.fault_counts[:10].sum()) == 0 and int(Be.contact_drop_counts.sum()) == int(Bc.contact_drop_counts.sum())
 
 
@@ -513,14 +518,15 @@ def test_emulated_kernel_under_random_configurations(oracle_lib, emu, case):
 
 # ---- sweep order: the legs' terrain contacts side by side (the contract) against the list order (oracle switch only) ----------------------
 def test_sweep_orders_converge_to_the_same_solve(oracle_lib):
-    """the oracle's order switch (2 = the contract: lower-leg contacts side by side; 1 = all of a leg's terrain contacts side by side, round 4's
-    study order; 0 = list order, the contract of rounds 1-4) is live (4 sweeps in list order and side by side differ beyond round-off) and on
-    robots standing on their feet under random joint rates and torques the orders approach the same converged solve: 64 sweeps agree within
-    2e-3 rad/s, while 4 sweeps of EITHER order are 0.17 rad/s away from it (measured) — the order costs nothing in convergence there
-    (tools/solver_order_study.py for the statistics; on its feet a robot has no hip / thigh contacts: orders 1 and 2 coincide)"""
+    """the oracle's order switch (3 = the contract: a leg's terrain contacts side by side, hip / thigh rows mass-split; 1 = the same without
+    splitting, round 4's study order; 0 = list order, the contract of rounds 1-4) is live (4 sweeps in list order and side by side differ
+    beyond round-off) and on robots standing on their feet under random joint rates and torques the orders approach the same converged
+    solve: 64 sweeps agree within 2e-3 rad/s, while 4 sweeps of EITHER order are 0.17 rad/s away from it (measured) — the order costs
+    nothing in convergence there (tools/solver_order_study.py for the statistics; on its feet a robot has no hip / thigh contacts:
+    orders 1 and 3 coincide)"""
     N = 16
     out = {}
-    for order in (0, 1, 2):
+    for order in (0, 1, 3):
         for sweeps in (4, 64):
             cfg, S, meta, B = make_sim("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
             g = torch.Generator().manual_seed(2)
@@ -535,21 +541,21 @@ def test_sweep_orders_converge_to_the_same_solve(oracle_lib):
                 for _ in range(3):
                     orc.physics_substep()
             finally:
-                orc.L.go1_oracle_set_solver_order(2)
+                orc.L.go1_oracle_set_solver_order(3)
             out[(order, sweeps)] = torch.cat([B.root_states[7:13], B.dof_vel]).clone()
-    assert float((out[(0, 4)] - out[(2, 4)]).abs().max()) > 1e-4
-    assert torch.equal(out[(1, 4)], out[(2, 4)])
-    assert float((out[(0, 64)] - out[(2, 64)]).abs().max()) < 2e-3
-    for order in (0, 2):
+    assert float((out[(0, 4)] - out[(3, 4)]).abs().max()) > 1e-4
+    assert float((out[(1, 4)] - out[(3, 4)]).abs().max()) < 1e-9
+    assert float((out[(0, 64)] - out[(3, 64)]).abs().max()) < 2e-3
+    for order in (0, 3):
         assert 0.05 < float((out[(order, 4)] - out[(0, 64)]).abs().max()) < 0.5
 
 
-def test_hip_and_thigh_contacts_stay_in_list_order_for_a_reason(oracle_lib):
-    """why the contract is order 2 and not round 4's study order 1: a limp robot lying on its side (hips, thighs, calves and a trunk edge on the
-    ground) comes to rest under the list order and under order 2, and keeps creeping at > 1 cm/s when block Jacobi runs over the hip and thigh
-    contacts as well (they couple to the base through one or two joints: every leg stops the WHOLE base) — with 8 sweeps too."""
+def test_hip_and_thigh_rows_are_mass_split_for_a_reason(oracle_lib):
+    """why the contract splits the base for hip / thigh rows (order 3) instead of running plain block Jacobi over them (round 4's study
+    order 1): a limp robot lying on its side (hips, thighs, calves and a trunk edge on the ground) comes to rest under the list order and
+    under order 3, and keeps creeping at > 5 mm/s under order 1 — with 8 sweeps too (every leg stops the WHOLE base)."""
     creep = {}
-    for order in (0, 1, 2):
+    for order in (0, 1, 3):
         cfg, S, meta, B = make_sim("train", 1, extra={"domain_rand": dict(randomize_gravity=False)})
         S.solver_iterations = 8
         standing_state(S, B, 0.30)
@@ -565,6 +571,6 @@ def test_hip_and_thigh_contacts_stay_in_list_order_for_a_reason(oracle_lib):
                 orc.physics_substep()
                 v = max(v, float(B.root_states[7:10].norm()))
         finally:
-            orc.L.go1_oracle_set_solver_order(2)
+            orc.L.go1_oracle_set_solver_order(3)
         creep[order] = v
-    assert creep[0] < 1e-3 and creep[2] < 1e-3 and creep[1] > 5e-3, creep
+    assert creep[0] < 1e-3 and creep[3] < 1e-3 and creep[1] > 5e-3, creep

@@ -81,7 +81,7 @@ def test_hip_torque_model_matches_reference_golden(variant, n_env):
 @pytest.mark.parametrize("variant", ["train", "act_nolag"])          # (the actuator-network variants: the deferred path)
 def test_deferred_torque_path_of_the_step_kernel_matches_reference_golden(variant):
     """The torque path the PRODUCT runs — inside go1sim_step the actuator network is evaluated by the helper wavefronts
-    (`torque_publish` -> `actuator_tiles` -> `torque_collect`, csrc/go1sim.hip step_body `deferred`), not by the piecewise
+    (`torque_post_state` -> `torque_build_row` -> `actuator_tiles` -> `torque_collect`, csrc/go1sim.hip step_body `deferred`), not by the piecewise
     `go1sim_compute_torques` entry point of the test above — pinned to the SAME reference fixtures at the SAME tolerance
     (tests/golden/torques_*.npz: the reference's `_compute_torques` with the TorchScript network, legged_robot.py:907-946).
     One full step per fixture row with `decimation = 1`: the step's only substep computes its torque from the fixture's

@@ -6,7 +6,7 @@
 cd "$(dirname "$0")/.."
 C=walk-these-ways_amd/csrc
 mkdir -p $C/variants
-BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -Iinclude"
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -Iinclude"
 build() {
   /opt/rocm/bin/hipcc $BASE $2 -o $C/variants/$1.so $C/go1sim.hip && echo "built $1 ($2)"
 }

@@ -15,7 +15,7 @@ import torch  # noqa: E402
 import go1sim_host as H  # noqa: E402
 
 
-def rate(lib_path, zero_actions, envs=4096, steps=240):
+def rate(lib_path, zero_actions, envs=4096, steps=480):
     if lib_path:
         H.LIB_PATH, H._lib = os.path.abspath(lib_path), None
     from bench import build_env
@@ -35,11 +35,24 @@ def rate(lib_path, zero_actions, envs=4096, steps=240):
 
 
 def main():
+    """every library in turn, REPS times round-robin (the first measurement of a process runs on a GPU that is still ramping its clocks: round 5's
+    first A/B had the product library first and read 8 % slow); the table prints every repetition and the median"""
     default = H.LIB_PATH
-    for path in [None] + sys.argv[1:]:
+    reps = int(os.environ.get("AB_REPS", "4"))
+    libs = [None] + sys.argv[1:]
+    rate(default, False, steps=1500)                       # warm the clocks
+    res = {}
+    for rep in range(reps):
+        for path in libs:
+            for zero in (False, True):
+                r, ms = rate(path or default, zero)
+                res.setdefault((path, zero), []).append(ms)
+    for path in libs:
         for zero in (False, True):
-            r, ms = rate(path or default, zero)
-            print(f"{os.path.basename(path or default):28s} {'zero actions (standing)' if zero else 'N(0,1) actions':24s}: {r / 1e6:6.2f} M env-steps/s, {ms:.3f} ms per env.step", flush=True)
+            v = sorted(res[(path, zero)])
+            med = 0.5 * (v[(len(v) - 1) // 2] + v[len(v) // 2])
+            print(f"{os.path.basename(path or default):28s} {'zero actions (standing)' if zero else 'N(0,1) actions':24s}: median {med:.4f} ms per env.step "
+                  f"({4096 / med / 1e3:6.2f} M env-steps/s); runs {' '.join(f'{x:.4f}' for x in res[(path, zero)])}", flush=True)
 
 
 if __name__ == "__main__":

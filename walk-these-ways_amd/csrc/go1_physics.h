@@ -23,9 +23,6 @@
 #define EPW 16                       // environments per wavefront
 #define MAXC GO1_MAX_CONTACTS        // solver contacts per env (24; oracle: the same constant of include/go1sim.h)
 #define NRJ 12                       // joint-limit rows: joint j
-#ifndef PGS_SIDE_BY_SIDE_ITEMS
-#define PGS_SIDE_BY_SIDE_ITEMS 5     // of a leg's 10 terrain items (foot, foot-wall, calf x3 | thigh x3, hip x2) the first 5 — the lower leg's — are solved side by side
-#endif                               // (10 = round 4's study order, for tools/probes/step_variant_ab.py only: does not settle on a side-lying robot)
 #define MAXSB 6                      // leg-leg self-contacts per env: one per pair of legs (the deepest of its four capsule combinations)
 #define MAXTR 4                      // trunk corners per env (oracle: GO1_MAX_TRUNK_POINTS)
 #define GO1_LIMIT_RECOVERY_RATE 10.0f   // rad/s: a joint found beyond a stop is brought back at a bounded rate
@@ -167,7 +164,8 @@ DEV void actuator_lds_init(float* a, int lane) {          // once per launch, al
 
 // The 12 row tiles of a substep are split over wavefronts: `actuator_tiles` evaluates tiles t = t0, t0 + ts, ... from the
 // 192 input rows in io[A_IN] and leaves the four partial sums of every row in io[A_OUT].
-DEV void actuator_tiles(const float* a, float* io, int lane, int t0, int ts) {
+// (t1: one past the last tile; ts: stride)
+DEV void actuator_tiles(const float* a, float* io, int lane, int t0, int ts, int t1 = 12) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   const int c = lane & 15, g = lane >> 4;
   float w0[8][7];
@@ -188,7 +186,7 @@ DEV void actuator_tiles(const float* a, float* io, int lane, int t0, int ts) {
     for (int q = 0; q < 4; q++) { b1v[4 * i + q] = bb[q]; w2v[4 * i + q] = ww[q]; }
   }
 #pragma unroll 1
-  for (int t = t0; t < 12; t += ts) {
+  for (int t = t0; t < t1; t += ts) {
     const f4* pin = reinterpret_cast<const f4*>(io + A_IN + (16 * t + c) * 8);
     const f4 x0 = pin[0], x1 = pin[1];
     act_f16x8 bhi, blo;
@@ -363,17 +361,33 @@ DEV void torque_stash_commit(CfgRef cfg, BufRef B, float* acth, int lane, int le
       if (cfg.use_lag && sb < cfg.decimation) B.lag_buffer[((size_t)((head + sb) % nl) * 12 + j) * N + e] = a[jj];
     }
 }
-// input rows of substep `sub` into io[A_IN]; the history advances
-DEV void torque_publish(const Leg& L, float* acth, float* io, int lane, int sub) {
-  float in[3][6];
+// Input rows of substep `sub`.  The MASTER only posts q and qd of its three joints into the row slots they belong to (6 LDS stores);
+// the row itself — position error against the lagged target, the two-deep histories — is built by the HELPER lane that owns the row
+// (192 rows = 3 helper wavefronts x 64 lanes: one row per lane), which also advances the histories in the stash.  Until round 5 the
+// master did all of it (15 stash reads, 12 stash writes, 6 row stores and their waits on the critical path, four times a step).
+// Same arithmetic in the same order as compute_torques(): results are bit-identical.
+DEV void torque_post_state(const Leg& L, float* io, int lane) {
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) {
-    const float err = L.q[jj] - ACTH(AH_TGT + 3 * sub + jj) + ACTH(AH_MO + jj);
-    const float e1 = ACTH(AH_E1 + jj), e2 = ACTH(AH_E2 + jj), v1 = ACTH(AH_V1 + jj), v2 = ACTH(AH_V2 + jj);
-    in[jj][0] = err; in[jj][1] = e1; in[jj][2] = e2; in[jj][3] = L.qd[jj]; in[jj][4] = v1; in[jj][5] = v2;
-    ACTH(AH_E2 + jj) = e1; ACTH(AH_E1 + jj) = err; ACTH(AH_V2 + jj) = v1; ACTH(AH_V1 + jj) = L.qd[jj];
+    float* row = io + A_IN + (3 * lane + jj) * 8;
+    row[0] = L.q[jj];
+    row[3] = L.qd[jj];
   }
-  actuator_publish(io, lane, in);
+}
+// helper lane `hl` in [0, 192): row hl = joint jj = hl % 3 of master lane ml = hl / 3
+DEV void torque_build_row(float* acth_, float* io, int hl, int sub) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const int ml = hl / 3, jj = hl - 3 * ml;
+  float* acth = acth_;
+  const int lane = ml;                                   // (ACTH indexes the master lane's stash column)
+  float* row = io + A_IN + hl * 8;
+  const float q = row[0], qd = row[3];
+  const float err = q - ACTH(AH_TGT + 3 * sub + jj) + ACTH(AH_MO + jj);
+  const float e1 = ACTH(AH_E1 + jj), e2 = ACTH(AH_E2 + jj), v1 = ACTH(AH_V1 + jj), v2 = ACTH(AH_V2 + jj);
+  f4* p = reinterpret_cast<f4*>(row);
+  p[0] = (f4){err, e1, e2, qd};
+  p[1] = (f4){v1, v2, 1.f, 0.f};
+  ACTH(AH_E2 + jj) = e1; ACTH(AH_E1 + jj) = err; ACTH(AH_V2 + jj) = v1; ACTH(AH_V1 + jj) = qd;
 }
 DEV void torque_collect(CfgRef cfg, Leg& L, const float* acth, const float* io, int lane, int leg, uint32_t& fault) {
   float tq[3];
@@ -761,7 +775,7 @@ DEV SolveBounds solve_bounds(int K, bool legact) {
 // pair index of the legs lo < hi in the order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
 DEV int leg_pair_index(int lo, int hi) { return lo == 0 ? hi - 1 : lo == 1 ? hi + 1 : 5; }
 
-// acth != nullptr: the torques of this substep are being evaluated by the helper wavefronts (torque_publish was called, the
+// acth != nullptr: the torques of this substep are being evaluated by the helper wavefronts (torque_post_state was called, the
 // workgroup barrier behind it passed): they are picked up right before ABA pass 2.
 // The helper wavefronts (nw > 1, always) run emit_terrain_contacts() between the two workgroup barriers of the emission hand-over.
 // PLANE: the terrain is the plane z = 0 (terrain_type 0; never with WALLS): no height samples, and the deepest corner of a box end
@@ -1348,27 +1362,35 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       Bq.u[2][0] = b6[0]; Bq.u[2][1] = b6[1]; Bq.u[2][2] = b6[2];
       Bq.legB = (int)b6[3];
     };
-    // SWEEP ORDER (the contract since round 5; oracle: physics_substep's sweep in oracle/go1_oracle.c, measured against the list order in
-    // profiles/r05_solver_order_study.txt): per sweep, trunk, hip, thigh and body-body contacts in list order ("cooperative" turns: the quad
-    // works on one contact), then the LOWER-LEG terrain contacts (foot sphere, calf capsule) of the four legs SIDE BY SIDE — every lane walks
-    // through the contacts of ITS leg (Gauss-Seidel inside the leg) on a private copy of the base state, the legs' base changes are added up
-    // once per sweep (block Jacobi over legs).  The serial length of a sweep is then the cooperative count + the largest lower-leg count on one
-    // leg instead of the environment's total.  Hip and thigh contacts stay cooperative: they couple to the base through one or two joints, and
-    // block Jacobi over them over-corrects the base (a robot lying on its side creeps; more sweeps do not cure it).
-    // contact indices: own leg's side-by-side contacts / the cooperative ones of the environment — straight from the slots the list gave out
-    uint32_t mine = 0u, coop = 0u;
+    // SWEEP ORDER (the contract since round 5; oracle: physics_substep's sweep in oracle/go1_oracle.c, order 3; measured against the list order
+    // in profiles/r05_solver_order_study.txt): per sweep, trunk and body-body contacts in list order ("cooperative" turns: the quad works on
+    // one contact), then the terrain contacts of the four legs SIDE BY SIDE — every lane walks through the contacts of ITS leg (Gauss-Seidel
+    // inside the leg) on a private copy of the base state, the legs' base changes are added up once per sweep (block Jacobi over legs).  The
+    // serial length of a sweep is then the cooperative count + the largest count on one leg instead of the environment's total.
+    // MASS SPLITTING for hip and thigh contacts: they couple to the base through one or two joints, and plain block Jacobi over them
+    // over-corrects the base (every leg stops the WHOLE base: a robot lying on its side creeps, more sweeps do not cure it).  In the leg
+    // phase the base therefore answers a hip / thigh row's impulse n times as strongly as it really does — n = the legs of the environment
+    // holding such rows; the base as n sub-bodies of 1 / n of its articulated inertia, one per leg — which makes the iteration convergent
+    // whatever the coupling; when the legs meet, the TRUE response of the impulse changes is what enters the base state.  Lower-leg rows
+    // (foot, calf: three joints away from the base) are not split: walking robots solve exactly as under plain block Jacobi.
+    // contact indices: own leg's contacts (all / the hip and thigh ones) and the cooperative ones of the environment — straight from the slots
+    // the list gave out
+    uint32_t mine = 0u, mine_split = 0u, coop = 0u;
     {
       const int leg_items[10] = {IT_FOOT, IT_FOOTW, IT_CALF1, IT_CALFW, IT_CALF2, IT_THIGH1, IT_THIGHW, IT_THIGH2, IT_HIP1, IT_HIP2};
-      uint32_t tr = 0u;
 #pragma unroll
       for (int i = 0; i < 10; i++)
-        if (slot[leg_items[i]] >= 0) { if (i < PGS_SIDE_BY_SIDE_ITEMS) mine |= 1u << slot[leg_items[i]]; else tr |= 1u << slot[leg_items[i]]; }
+        if (slot[leg_items[i]] >= 0) { mine |= 1u << slot[leg_items[i]]; if (i >= 5) mine_split |= 1u << slot[leg_items[i]]; }
+      uint32_t tr = 0u;
       if (slot[IT_TR0] >= 0) tr |= 1u << slot[IT_TR0];
       if (slot[IT_TR1] >= 0) tr |= 1u << slot[IT_TR1];
       if (slot[IT_TRW] >= 0) tr |= 1u << slot[IT_TRW];
       const int s1 = nF + nS < K ? nF + nS : K;                      // body-body contacts: [nF, nF + nS) as far as they were listed
       coop = quad_or(tr) | (s1 > nF ? ((1u << s1) - 1u) & ~((1u << nF) - 1u) : 0u);
     }
+    const int nsplit_legs = __popc(quad_ballot(mine_split != 0u, lane));
+    const float nsm1 = nsplit_legs > 1 ? (float)(nsplit_legs - 1) : 0.f;      // n - 1 (0: a single leg holds split rows — nothing to split)
+    const bool split_w = __ballot(mine_split != 0u && nsm1 > 0.f) != 0ull;     // wave-uniform: some environment of the wavefront splits
     uint32_t coop_w = 0u;                                          // wave-uniform: indices some environment of the wavefront treats cooperatively
 #pragma unroll 1
     for (int k = 0; k < Kw; k++)
@@ -1445,34 +1467,65 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       }
       {
         SweepState sp = st;                                        // private copy: base state as the leg phase found it + the own contacts' changes
+        f2 ds01 = splat2(0.f), ds23 = splat2(0.f), ds45 = splat2(0.f);      // sum of a_z dlambda over the own SPLIT rows (unscaled)
         uint32_t rem = mine;
 #pragma unroll 1
         for (int tt = 0; tt < turns; tt++) {
-          if (rem != 0u) {
-            const int k = __builtin_ctz(rem);
-            rem &= rem - 1u;
+          const int k = rem != 0u ? __builtin_ctz(rem) : 0;
+          const bool on = rem != 0u;
+          rem &= rem - 1u;
+          const bool split = on && ((mine_split >> k) & 1u) != 0u && nsm1 > 0.f;
+          const bool any_split = split_w && __ballot(split) != 0ull;      // (wave-uniform: the split arithmetic sits behind a scalar branch)
+          if (on) {
             SweepRec R;
             sweep_rec_load(crl, el, k, R);
             float dn, d1, d2, pn, p1, p2;
             sweep_row_dot(R, 0, sp, dn, pn);
             sweep_row_dot(R, 1, sp, d1, p1);
             sweep_row_dot(R, 2, sp, d2, p2);
+            // 1 / W of the three rows and the normal's weight in the tangent rows; split rows: W + (n - 1) a_z . a_z
+            float iwn = R.q[2][2], iw1 = R.q[5][2], iw2 = R.q[8][2], w1n = R.q[2][3], w2n = R.q[5][3];
+            if (any_split) {
+              auto zdot = [&](int a, int b) {
+                f2 acc = lo2(R.q[3 * a]) * lo2(R.q[3 * b]);
+                acc = fma2(hi2(R.q[3 * a]), hi2(R.q[3 * b]), acc);
+                acc = fma2(lo2(R.q[3 * a + 1]), lo2(R.q[3 * b + 1]), acc);
+                return acc[0] + acc[1];
+              };
+              const float f = split ? nsm1 : 0.f;
+              iwn = iwn / fmaf(f * zdot(0, 0), iwn, 1.f);
+              iw1 = iw1 / fmaf(f * zdot(1, 1), iw1, 1.f);
+              iw2 = iw2 / fmaf(f * zdot(2, 2), iw2, 1.f);
+              w1n = fmaf(f, zdot(1, 0), w1n);
+              w2n = fmaf(f, zdot(2, 0), w2n);
+            }
             const float un = R.q[2][1] + dn + pn;                  // = u_n - v*
             float u1 = R.q[5][1] + d1 + p1, u2 = R.q[8][1] + d2 + p2;
             const float ln_old = R.q[9][0];
-            const float ln = fmaxf(0.f, ln_old - un * R.q[2][2]);
+            const float ln = fmaxf(0.f, ln_old - un * iwn);
             const float dln = ln - ln_old;
-            u1 = fmaf(R.q[2][3], dln, u1);
-            u2 = fmaf(R.q[5][3], dln, u2);
-            float l1 = R.q[9][1] - u1 * R.q[5][2];
-            float l2 = R.q[9][2] - u2 * R.q[8][2];
+            u1 = fmaf(w1n, dln, u1);
+            u2 = fmaf(w2n, dln, u2);
+            float l1 = R.q[9][1] - u1 * iw1;
+            float l2 = R.q[9][2] - u2 * iw2;
             const float lim = mu_s * ln, nn = l1 * l1 + l2 * l2;
             if (nn > lim * lim) { const float sc = mu_d * ln * __builtin_amdgcn_rsqf(nn); l1 *= sc; l2 *= sc; }
-            sweep_add_rows(R, sp, 1.f, dln, l1 - R.q[9][1], l2 - R.q[9][2]);
+            const float g0 = dln, g1 = l1 - R.q[9][1], g2 = l2 - R.q[9][2];
+            sweep_add_rows(R, sp, 1.f, g0, g1, g2);
+            if (any_split) {                                       // the base part once more, n - 1 times, on the private copy; remembered for the merge
+              const float f = split ? nsm1 : 0.f;
+              const f2 s0 = splat2(f * g0), s1 = splat2(f * g1), s2 = splat2(f * g2);
+              const f2 a01 = fma2(lo2(R.q[0]), s0, fma2(lo2(R.q[3]), s1, lo2(R.q[6]) * s2));
+              const f2 a23 = fma2(hi2(R.q[0]), s0, fma2(hi2(R.q[3]), s1, hi2(R.q[6]) * s2));
+              const f2 a45 = fma2(lo2(R.q[1]), s0, fma2(lo2(R.q[4]), s1, lo2(R.q[7]) * s2));
+              sp.z01 += a01; sp.z23 += a23; sp.z45 += a45;
+              ds01 += a01; ds23 += a23; ds45 += a45;
+            }
             CRQ(k, 9) = (lf4){ln, l1, l2, SIG && nn > lim * lim ? 1.f : 0.f};
           }
         }
-        // the legs' base changes meet; the own leg's part is already final
+        // the legs' base changes meet (split rows: without the n - 1 extra shares); the own leg's part is already final
+        if (split_w) { sp.z01 -= ds01; sp.z23 -= ds23; sp.z45 -= ds45; }
         st.z01[0] += quad_sum(sp.z01[0] - st.z01[0]); st.z01[1] += quad_sum(sp.z01[1] - st.z01[1]);
         st.z23[0] += quad_sum(sp.z23[0] - st.z23[0]); st.z23[1] += quad_sum(sp.z23[1] - st.z23[1]);
         st.z45[0] += quad_sum(sp.z45[0] - st.z45[0]); st.z45[1] += quad_sum(sp.z45[1] - st.z45[1]);

@@ -116,7 +116,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
 #if defined(GO1_ABLATE_TORQUE) || defined(GO1_ABLATE_PHYSICS) || defined(GO1_NO_DEFERRED_TORQUE)
   const bool deferred = false;
 #else
-  const bool deferred = mfma_torque && nw > 1 && cfg.decimation <= ACT_MAX_DEC;      // torque model entirely on the helper wavefronts
+  const bool deferred = mfma_torque && nw == 4 && cfg.decimation <= ACT_MAX_DEC;     // torque model entirely on the helper wavefronts (3 x 64 lanes = the 192 rows)
 #endif
   if (mfma_torque && wv == 0) actuator_lds_init(act_lds, lane);
   PROF_INIT
@@ -129,8 +129,10 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
 #ifndef GO1_ABLATE_TORQUE
       if (substep_only) {
       } else if (deferred) {
-        BLOCK_SYNC(nw);                                   // the master's input rows are in LDS
-        actuator_tiles(act_lds, Z.act_io(), lane, wv - 1, nw - 1);
+        BLOCK_SYNC(nw);                                   // the master's q, qd are in the row slots
+        torque_build_row(acth, Z.act_io(), 64 * (wv - 1) + lane, sub);
+        LDS_PHASE();                                      // rows 64 (wv - 1) .. + 63 = tiles 4 (wv - 1) .. + 3: built and consumed by this wavefront
+        actuator_tiles(act_lds, Z.act_io(), lane, 4 * (wv - 1), 1, 4 * wv);
         BLOCK_SYNC(nw);                                   // (the master arrives here when it needs the torques)
       } else if (mfma_torque) actuator_net_mfma(act_lds, Z.act_io(), lane, wv, nw, false, nullptr, nullptr);
 #endif
@@ -205,7 +207,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
 #ifndef GO1_ABLATE_TORQUE
     if (substep_only) {
     } else if (deferred) {
-      torque_publish(L, acth, Z.act_io(), lane, sub);
+      torque_post_state(L, Z.act_io(), lane);
       PROF(22);
       BLOCK_SYNC(nw);
     } else compute_torques(cfg, B, L, leg, e, N, head, act_lds, Z.act_io(), mfma_torque, nw, fault);
