@@ -21,7 +21,8 @@ PHASES = ["rest of the prologue (stash commit, input checks)", "torque model: ba
           "post: roll", "post: reward-input loads", "post: termination", "fault flags + sweep bounds (x4)",
           "kinematics + candidates + self-collision geometry + contact list (x4)", "post items into the records (x4)",
           "self-contacts + limit rows + barrier wait for the helpers' rows (x4)",
-          "torque model: publish the input rows (x4)", "PGS: warm-start state (x4)"]
+          "torque model: post q, qd for the helpers' rows (x4)", "PGS: warm-start state (x4)",
+          "loop edge after the pose update (x4)", "kinematics + terrain candidates (x4; 19 = the contact list alone)", "self-collision geometry (x4)"]
 
 
 def build(flags):

@@ -7,13 +7,14 @@
 // accumulates s_memtime deltas per phase into g_prof[]; everything compiles away otherwise ------------------
 #ifdef GO1_PROFILE
 __device__ unsigned long long g_prof[64];
-__shared__ unsigned long long s_prof[24];          // accumulated with fire-and-forget LDS adds: no memory stall per marker
+__shared__ unsigned long long s_prof[32];          // accumulated with fire-and-forget LDS adds: no memory stall per marker
 #define PROF_PARAM , unsigned long long& prof_t
 #define PROF_PASS , prof_t
-#define PROF_INIT if (threadIdx.x < 24) s_prof[threadIdx.x] = 0; __syncthreads();
+#define PROF_INIT if (threadIdx.x < 32) s_prof[threadIdx.x] = 0; __syncthreads();
 #define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter();
-#define PROF(i) do { unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&s_prof[i], now_ - prof_t); prof_t = now_; } while (0)
-#define PROF_FLUSH do { LDS_PHASE(); if (blockIdx.x == 0 && threadIdx.x < 24) g_prof[threadIdx.x] += s_prof[threadIdx.x]; } while (0)
+// (sched_barrier: the counter read is a scheduling fence — without it the compiler sinks a phase's tail, e.g. the pose update's sincos, past the marker)
+#define PROF(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) atomicAdd(&s_prof[i], now_ - prof_t); prof_t = now_; } while (0)
+#define PROF_FLUSH do { LDS_PHASE(); if (blockIdx.x == 0 && threadIdx.x < 32) g_prof[threadIdx.x] += s_prof[threadIdx.x]; } while (0)
 #else
 #define PROF_PARAM
 #define PROF_PASS
@@ -246,5 +247,15 @@ DEV unsigned quad_or(unsigned x) {
   x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
   x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);
   return x;
+}
+// value of the lane `rot` (1..3) places further round the quad (quad_perm rotations): lane leg reads lane (leg + rot) & 3
+DEV float quad_rot(float x, int rot) {
+  const int v = __float_as_int(x);
+  switch (rot & 3) {
+    case 1: return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x39, 0xF, 0xF, false));      // [1, 2, 3, 0]
+    case 2: return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));      // [2, 3, 0, 1]
+    case 3: return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x93, 0xF, 0xF, false));      // [3, 0, 1, 2]
+    default: return x;
+  }
 }
 DEV unsigned quad_ballot(bool p, int lane) { return (unsigned)((__ballot(p) >> (lane & ~3)) & 0xFull); }

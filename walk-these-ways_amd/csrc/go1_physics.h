@@ -717,7 +717,8 @@ DEV void emit_terrain_contact(CfgRef cfg, const SolverLds& Z, int el, int k, flo
   const lf4 i0 = CRQ(k, 9), i1 = CRQ(k, 10), i2 = CRQ(k, 11);
   const float phi = i0[0], un_pre = i1[0], share = i2[3];
   const V3 x = v3(i0[1], i0[2], i0[3]), n = v3(i1[1], i1[2], i1[3]);
-  const int depth = (int)i2[0], leg = (int)i2[1], body = (int)i2[2];
+  const int depth = (int)i2[0], legc = (int)i2[1], leg = legc & 3, body = (int)i2[2];
+  const float fsplit = (float)(legc >> 2);            // mass splitting (the sweep's leg phase): n - 1 for a hip / thigh row of an environment with n > 1 such legs
   EnvPk E;
   envpk_load(Z.pke(), el, E);
   LegFac F;
@@ -744,8 +745,14 @@ DEV void emit_terrain_contact(CfgRef cfg, const SolverLds& Z, int el, int k, flo
     row_propagate(F, depth, -sv(cross(x, d), d), g, uj);
     row_finish(E.Li, g, uj, F.sD, a[r]);
   }
+  // the record's W entries of a split row are those of the split system: W + (n - 1) a_z . a_z (base part once more per extra sub-body)
+  auto zdot = [](const Row& p, const Row& q) {
+    return fmaf(p.g[0], q.g[0], fmaf(p.g[1], q.g[1], fmaf(p.g[2], q.g[2], fmaf(p.g[3], q.g[3], fmaf(p.g[4], q.g[4], p.g[5] * q.g[5])))));
+  };
   contact_record_store(crl, el, k, a[0], a[1], a[2], cr_flags(depth < 0 ? 4 : leg, false, 0), dot(n, vp) - vs, dot(t1, vp), dot(t2, vp),
-                       row_dot(a[0], a[0]), row_dot(a[1], a[1]), row_dot(a[2], a[2]), row_dot(a[1], a[0]), row_dot(a[2], a[0]), lam, x, n, bounce, fault);
+                       fmaf(fsplit, zdot(a[0], a[0]), row_dot(a[0], a[0])), fmaf(fsplit, zdot(a[1], a[1]), row_dot(a[1], a[1])),
+                       fmaf(fsplit, zdot(a[2], a[2]), row_dot(a[2], a[2])), fmaf(fsplit, zdot(a[1], a[0]), row_dot(a[1], a[0])),
+                       fmaf(fsplit, zdot(a[2], a[0]), row_dot(a[2], a[0])), lam, x, n, bounce, fault);
 }
 // terrain contacts k = k0, k0 + kstride, ... of environment el (K listed, nF .. nF + nS - 1 are self-contacts: the master's)
 DEV void emit_terrain_contacts(CfgRef cfg, const SolverLds& Z, int el, int k0, int kstride, float h) {
@@ -912,6 +919,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     }
   }
 
+  PROF(25);
   // ---- self-collision, geometry (asset self_collisions = 0: enabled): capsules — lower leg (knee -> foot centre, radius of
   // the foot sphere), thigh (thigh joint -> knee) — of DIFFERENT legs against each other and lower legs against the trunk's
   // capsule.  Every lane publishes its two segments and the two bodies' twists, tests the pairs it is part of in the
@@ -930,11 +938,27 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     LDS_PHASE();
     unsigned mybits = 0;
     const V3 own_p[2] = {pknee, pthigh}, own_q[2] = {pfoot, pknee};
-    // broad phase: the two segments' midpoints further apart than both half lengths + radii + contact distance
+    // Broad phase 1 (round 5; the capsule tests below were 14 % of the step for pairs that almost never touch): SEPARATING AXES.  The leg's
+    // three points (thigh joint, knee, foot centre) span both of its capsules; their extents along the base's x and y axes are exchanged
+    // in the quad (DPP rotations, no LDS), and two legs whose extents are further apart along either axis than the largest radii sum +
+    // the contact distance cannot touch in any of the four capsule combinations.  Conservative (an axis test never rejects a contact), so
+    // the listed pairs — and everything downstream — are exactly those of the full test.  Walking robots: every pair is rejected here.
+    const float sep = 2.f * GO1_SELF_LEG_RADIUS + cd + 1e-4f;            // (lower-leg radius >= thigh radius)
+    float ex0, ex1, ey0, ey1;
+    {
+      const float tx = dot(pthigh, R0.c0), kx = dot(pknee, R0.c0), fx = dot(pfoot, R0.c0);
+      const float ty = dot(pthigh, R0.c1), ky = dot(pknee, R0.c1), fy = dot(pfoot, R0.c1);
+      ex0 = fminf(tx, fminf(kx, fx)); ex1 = fmaxf(tx, fmaxf(kx, fx));
+      ey0 = fminf(ty, fminf(ky, fy)); ey1 = fmaxf(ty, fmaxf(ky, fy));
+    }
+    // broad phase 2: the two segments' midpoints further apart than both half lengths + radii + contact distance
     const float reach = 2.f * 0.1065f + 2.f * GO1_SELF_LEG_RADIUS + cd + 0.01f;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       const int j = (leg + 1 + i) & 3, lj = (lane & ~3) | j;
+      const float px0 = quad_rot(ex0, i + 1), px1 = quad_rot(ex1, i + 1), py0 = quad_rot(ey0, i + 1), py1 = quad_rot(ey1, i + 1);
+      const bool apart = ex0 - px1 > sep || px0 - ex1 > sep || ey0 - py1 > sep || py0 - ey1 > sep;
+      if (__ballot(!apart) == 0ull) continue;
       const lf4 a0 = seg[0 * WAVE + lj], a1 = seg[1 * WAVE + lj], a2 = seg[2 * WAVE + lj];
       const V3 par_p[2] = {v3(a0[0], a0[1], a0[2]), v3(a1[2], a1[3], a2[0])}, par_q[2] = {v3(a0[3], a1[0], a1[1]), v3(a0[0], a0[1], a0[2])};
       const bool lower = leg < j;
@@ -946,7 +970,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         const int sa = (type >> 1) & 1, sbq = type & 1;                      // segment of body A / B: 0 lower leg, 1 thigh
         const int so = lower ? sa : sbq, sp = lower ? sbq : sa;               // own / partner segment
         const V3 mo = 0.5f * (own_p[so] + own_q[so]), mp = 0.5f * (par_p[sp] + par_q[sp]), dm = mo - mp;
-        const bool near = dot(dm, dm) < reach * reach;
+        const bool near = !apart && dot(dm, dm) < reach * reach;
         if (__ballot(near) != 0ull) {
           Cand c;
           const float ra = sa ? GO1_SELF_THIGH_RADIUS : GO1_SELF_LEG_RADIUS, rb = sbq ? GO1_SELF_THIGH_RADIUS : GO1_SELF_LEG_RADIUS;
@@ -958,15 +982,22 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       if (best_type >= 0) mybits |= 1u << (6 * best_type + pair);
     }
     {
+      // lower leg against the trunk's capsule (axis = the base's x axis through the origin): apart along the base's y or z axis?
       const float ta = (float)(GO1_TRUNK_BOX_HALF[0] - GO1_TRUNK_BOX_HALF[1]);
-      Cand c;
-      if (capsule_contact(pknee, pfoot, GO1_SELF_LEG_RADIUS, mul(R0, v3(-ta, 0.f, 0.f)), mul(R0, v3(ta, 0.f, 0.f)), (float)GO1_TRUNK_BOX_HALF[1], cd, c))
-        mybits |= 1u << (24 + leg);
+      const float sept = (float)GO1_TRUNK_BOX_HALF[1] + GO1_SELF_LEG_RADIUS + cd + 1e-4f;
+      const float ky = dot(pknee, R0.c1), fy = dot(pfoot, R0.c1), kz = dot(pknee, R0.c2), fz = dot(pfoot, R0.c2);
+      const bool apart = fminf(ky, fy) > sept || fmaxf(ky, fy) < -sept || fminf(kz, fz) > sept || fmaxf(kz, fz) < -sept;
+      if (__ballot(!apart) != 0ull) {
+        Cand c;
+        if (!apart && capsule_contact(pknee, pfoot, GO1_SELF_LEG_RADIUS, mul(R0, v3(-ta, 0.f, 0.f)), mul(R0, v3(ta, 0.f, 0.f)), (float)GO1_TRUNK_BOX_HALF[1], cd, c))
+          mybits |= 1u << (24 + leg);
+      }
     }
     smask = quad_or(mybits);
     nS = __popc(smask);
   }
 
+  PROF(26);
   // ---- solver contact list (oracle detect_contacts()): slots in the priority order feet, foot walls, self-contacts, trunk
   // corners, trunk wall, calves (first points, walls, second points), thighs (same), hips; at most MAXC, the rest is dropped
   // and counted per class ---------------------------------------------------------------------------------------------------
@@ -1072,6 +1103,10 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
   PROF(19);
   // ---- post the listed terrain points as items into their records (q9 .. q11), invalidate the records the previous
   // substep used beyond this one's count (their impulses and inverse diagonals: the sweep then leaves them at zero) ----------
+  // mass splitting of the sweep's leg phase (see "SWEEP ORDER" below): n = the legs of the environment that hold hip / thigh rows
+  const bool has_split = slot[IT_THIGH1] >= 0 || slot[IT_THIGHW] >= 0 || slot[IT_THIGH2] >= 0 || slot[IT_HIP1] >= 0 || slot[IT_HIP2] >= 0;
+  const int nsplit_legs = __popc(quad_ballot(has_split, lane));
+  const int nsm1i = nsplit_legs > 1 ? nsplit_legs - 1 : 0;            // n - 1 (0: a single leg holds such rows — nothing to split)
   {
     // warm start: a body's previous impulse is shared equally by its listed top-surface points; wall points start from zero
     const float share_k = (slot[IT_CALF1] >= 0 && slot[IT_CALF2] >= 0) ? 0.5f : 1.f, share_t = (slot[IT_THIGH1] >= 0 && slot[IT_THIGH2] >= 0) ? 0.5f : 1.f,
@@ -1081,7 +1116,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     auto post = [&](int k, const Cand& c, int depth, int body, float share) {
       CRQ(k, 9) = (lf4){c.phi, c.x, c.y, c.z};
       CRQ(k, 10) = (lf4){c.un, c.nx, c.ny, c.nz};
-      CRQ(k, 11) = (lf4){(float)depth, (float)leg, (float)body, share};
+      CRQ(k, 11) = (lf4){(float)depth, (float)(leg + ((depth == 0 || depth == 1) ? 4 * nsm1i : 0)), (float)body, share};      // (leg + 4 (n - 1): emit_terrain_contact)
     };
     if (slot[IT_FOOT] >= 0) post(slot[IT_FOOT], cf, 2, 4 + 4 * leg, 1.f);
     if (WALLS && slot[IT_FOOTW] >= 0) post(slot[IT_FOOTW], cwf, 2, 4 + 4 * leg, 0.f);
@@ -1388,8 +1423,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       const int s1 = nF + nS < K ? nF + nS : K;                      // body-body contacts: [nF, nF + nS) as far as they were listed
       coop = quad_or(tr) | (s1 > nF ? ((1u << s1) - 1u) & ~((1u << nF) - 1u) : 0u);
     }
-    const int nsplit_legs = __popc(quad_ballot(mine_split != 0u, lane));
-    const float nsm1 = nsplit_legs > 1 ? (float)(nsplit_legs - 1) : 0.f;      // n - 1 (0: a single leg holds split rows — nothing to split)
+    const float nsm1 = (float)nsm1i;
     const bool split_w = __ballot(mine_split != 0u && nsm1 > 0.f) != 0ull;     // wave-uniform: some environment of the wavefront splits
     uint32_t coop_w = 0u;                                          // wave-uniform: indices some environment of the wavefront treats cooperatively
 #pragma unroll 1
@@ -1401,12 +1435,36 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
 #pragma unroll 1
       for (int tt = 1; tt <= MAXC; tt++) { if (__ballot(cnt >= tt) == 0ull) break; turns = tt; }
     }
-    // warm start: the state of the starting impulses (self-contacts and limit rows start from zero)
+    // warm start: the state of the starting impulses (self-contacts and limit rows start from zero).  Like the sweep: the cooperative
+    // contacts by the whole quad, the own leg's contacts by their lane — base parts summed over the quad once — instead of every lane
+    // walking through every record of the environment (round 4: 6.6 % of the step)
 #pragma unroll 1
-    for (int k = 0; k < Kw; k++) {
+    for (uint32_t rest = coop_w; rest != 0u; rest &= rest - 1u) {
+      const int k = __builtin_ctz(rest);
       SweepRec R;
       sweep_rec_load(crl, el, k, R);
-      sweep_add_rows(R, st, (((int)R.q[8][3]) & 7) == leg ? 1.f : 0.f, R.q[9][0], R.q[9][1], R.q[9][2]);
+      const float g = ((coop >> k) & 1u) ? 1.f : 0.f;
+      sweep_add_rows(R, st, (((int)R.q[8][3]) & 7) == leg ? 1.f : 0.f, g * R.q[9][0], g * R.q[9][1], g * R.q[9][2]);
+    }
+    {
+      SweepState so;
+      so.z01 = so.z23 = so.z45 = so.y01 = splat2(0.f);
+      so.y2 = 0.f;
+      uint32_t rem = mine;
+#pragma unroll 1
+      for (int tt = 0; tt < turns; tt++) {
+        if (rem != 0u) {
+          const int k = __builtin_ctz(rem);
+          rem &= rem - 1u;
+          SweepRec R;
+          sweep_rec_load(crl, el, k, R);
+          sweep_add_rows(R, so, 1.f, R.q[9][0], R.q[9][1], R.q[9][2]);
+        }
+      }
+      st.z01[0] += quad_sum(so.z01[0]); st.z01[1] += quad_sum(so.z01[1]);
+      st.z23[0] += quad_sum(so.z23[0]); st.z23[1] += quad_sum(so.z23[1]);
+      st.z45[0] += quad_sum(so.z45[0]); st.z45[1] += quad_sum(so.z45[1]);
+      st.y01 += so.y01; st.y2 += so.y2;
     }
     LDS_PHASE();            // every lane has read every contact's starting impulse before a lane overwrites its own contacts' (lock step on the hardware)
     PROF(23);
@@ -1483,22 +1541,8 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
             sweep_row_dot(R, 0, sp, dn, pn);
             sweep_row_dot(R, 1, sp, d1, p1);
             sweep_row_dot(R, 2, sp, d2, p2);
-            // 1 / W of the three rows and the normal's weight in the tangent rows; split rows: W + (n - 1) a_z . a_z
-            float iwn = R.q[2][2], iw1 = R.q[5][2], iw2 = R.q[8][2], w1n = R.q[2][3], w2n = R.q[5][3];
-            if (any_split) {
-              auto zdot = [&](int a, int b) {
-                f2 acc = lo2(R.q[3 * a]) * lo2(R.q[3 * b]);
-                acc = fma2(hi2(R.q[3 * a]), hi2(R.q[3 * b]), acc);
-                acc = fma2(lo2(R.q[3 * a + 1]), lo2(R.q[3 * b + 1]), acc);
-                return acc[0] + acc[1];
-              };
-              const float f = split ? nsm1 : 0.f;
-              iwn = iwn / fmaf(f * zdot(0, 0), iwn, 1.f);
-              iw1 = iw1 / fmaf(f * zdot(1, 1), iw1, 1.f);
-              iw2 = iw2 / fmaf(f * zdot(2, 2), iw2, 1.f);
-              w1n = fmaf(f, zdot(1, 0), w1n);
-              w2n = fmaf(f, zdot(2, 0), w2n);
-            }
+            // (1 / W of the three rows and the normal's weight in the tangent rows are those of the SPLIT system for a split row: emit_terrain_contact)
+            const float iwn = R.q[2][2], iw1 = R.q[5][2], iw2 = R.q[8][2], w1n = R.q[2][3], w2n = R.q[5][3];
             const float un = R.q[2][1] + dn + pn;                  // = u_n - v*
             float u1 = R.q[5][1] + d1 + p1, u2 = R.q[8][1] + d2 + p2;
             const float ln_old = R.q[9][0];

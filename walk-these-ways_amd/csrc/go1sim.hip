@@ -204,6 +204,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   PROF(0);
 #pragma unroll 1
   for (int sub = 0; sub < nsub; sub++) {
+    PROF(24);
 #ifndef GO1_ABLATE_TORQUE
     if (substep_only) {
     } else if (deferred) {
