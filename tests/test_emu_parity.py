@@ -242,6 +242,36 @@ def test_emulated_failed_state_is_contained(oracle_lib, emu):
     assert int(Be.fault_flags[others].abs().sum()) == 0
 
 
+def test_emulated_reward_guard_with_the_observations_on_the_helper(oracle_lib, emu):
+    """tests/test_gpu_parity.py::test_failed_simulation_guard through the emulated kernel: a NaN in one environment's previous joint rate
+    turns the dof_acc reward term non-finite — the only way an environment can reset AFTER the helper wavefront was sent off with the
+    observations (csrc/go1_maps.h post_physics: S1 / S2).  The victim is re-initialised and observed again by the master, everything it
+    leaves is finite, and the other environments (same workgroup, observed by the helper) are bit-identical to an undisturbed run."""
+    N = 32
+    S, Bc, orc, Be, sim = pair(oracle_lib, emu, "train_noise", N, seed=21)
+    Br = Be.clone_to("cpu")
+    ref = emu.EmuSim(S, Br)
+    ref.set_counters(orc.ctr.common_step_counter, orc.ctr.lag_head)
+    sim.set_counters(orc.ctr.common_step_counter, orc.ctr.lag_head)
+    victim = 5
+    Be.last_dof_vel[4, victim] = float("nan")
+    z = torch.zeros(N, 12)
+    sim.step(z)
+    ref.step(z)
+    for k in ("rew_buf", "episode_sums", "obs_buf", "obs_history", "privileged_obs_buf", "last_actions", "last_dof_vel"):
+        assert torch.isfinite(Be.tensors[k]).all(), k
+    assert int(Be.reset_buf[victim]) == 1 and int(Be.time_out_buf[victim]) == 0 and int(Be.episode_length_buf[victim]) == 0
+    assert int(Be.fault_flags[victim]) & H.FAULT_FATAL_MASK == 1 << H.abi.GO1_FAULT_REWARD
+    others = torch.arange(N) != victim
+    assert int((Be.fault_flags[others] & H.FAULT_FATAL_MASK).sum()) == 0
+    for k in ("rew_buf", "reset_buf", "obs_buf", "privileged_obs_buf", "last_actions", "last_last_actions", "last_dof_vel", "last_joint_pos_target"):
+        a, b = Be.tensors[k], Br.tensors[k]
+        per_env_first = a.shape[0] == N and k in ("obs_buf", "privileged_obs_buf")
+        assert torch.equal(a[others] if (per_env_first or a.dim() == 1) else a[..., others], b[others] if (per_env_first or b.dim() == 1) else b[..., others]), k
+    # the victim's observation is that of the re-initialised environment: its joint-velocity columns are those of the reset state
+    assert torch.isfinite(Be.obs_buf[victim]).all() and not torch.equal(Be.obs_buf[victim], Br.obs_buf[victim])
+
+
 def test_emulated_self_collision_matches_oracle(oracle_lib, emu):
     """Self-collision through the KERNEL code: in free flight the hips swing the lower legs into each other (left-right and,
     with the thighs, front-rear) and fold the feet against the trunk; leg-leg rows carry two leg parts, trunk-leg rows one.

@@ -7,6 +7,7 @@ run() { name=$1; shift; echo "=== $name: $*" | tee -a $OUT/index.txt; ( time tim
 for step in "$@"; do
 case $step in
   parity) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt run parity python -m pytest tests/test_gpu_parity.py tests/test_gpu_env.py -q -s -k "product_instances or train_eval_split or deferred_torque" ;;
+  quick) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt run quick python -m pytest tests/test_gpu_parity.py tests/test_gpu_env.py tests/test_gpu_ppo_reference.py -q -k "product_instances or failed or full_step_matches or ragged or deferred_torque or gpu_fp32_update or history" ;;
   fusedtests) run fusedtests python -m pytest tests/test_gpu_ppo_fused.py -q -x ;;
   gemm) run gemm python tools/bench_gemm.py ;;
   bench) run bench python bench.py --steps 20 --warmup 5 --headline-only --no-cpu-baseline --breakdown ;;
@@ -17,6 +18,7 @@ case $step in
   gputests) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt TMO=1500 run gputests python -m pytest tests/ -x -q -m gpu --durations=30 ;;
   dropin) run dropin python -m pytest tests/test_gpu_env.py -q -x -s -k "unchanged_train_script" ;;
   ab) run ab python tools/probes/step_variant_ab.py $(ls walk-these-ways_amd/csrc/variants/*.so | grep -v prof) ;;
+  sweep) AB_ENVS=64,256,1024,2048,4096,8192 run sweep python tools/probes/step_variant_ab.py ;;
   phases) run phases python tools/phase_profile.py --lib walk-these-ways_amd/csrc/variants/prof.so --steps 32; run phases_standing python tools/phase_profile.py --lib walk-these-ways_amd/csrc/variants/prof.so --steps 32 --zero-actions ;;
   *) echo "unknown step $step" ;;
 esac

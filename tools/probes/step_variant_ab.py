@@ -34,6 +34,17 @@ def rate(lib_path, zero_actions, envs=4096, steps=480):
     return envs * steps / dt, 1e3 * dt / steps
 
 
+def envs_sweep():
+    """AB_ENVS="256,1024,2048,4096,8192": per-step time of the default library against the number of environments (= workgroups of 16): how much
+    of the 4096-environment time is contention between workgroups (two CUs share an instruction cache; the step kernel's loop body is ~240 KB
+    of code) and how much is the one workgroup's own serial spine"""
+    rate(H.LIB_PATH, False, steps=1500)
+    for envs in [int(x) for x in os.environ["AB_ENVS"].split(",")]:
+        for zero in (False, True):
+            v = sorted(rate(H.LIB_PATH, zero, envs=envs)[1] for _ in range(3))
+            print(f"{envs:6d} envs ({envs // 16:4d} workgroups) {'zero actions (standing)' if zero else 'N(0,1) actions':24s}: median {v[1]:.4f} ms per env.step", flush=True)
+
+
 def main():
     """every library in turn, REPS times round-robin (the first measurement of a process runs on a GPU that is still ramping its clocks: round 5's
     first A/B had the product library first and read 8 % slow); the table prints every repetition and the median"""
@@ -56,4 +67,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    envs_sweep() if os.environ.get("AB_ENVS") else main()

@@ -409,16 +409,180 @@ DEV int reward_raw_sign(int id) {
   return (id == GO1_REW_JUMP || id == GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE || id == GO1_REW_TRACKING_CONTACTS_SHAPED_VEL) ? -1 : 1;
 }
 
+#define QUAD_SYNC() do { __threadfence_block(); LDS_PHASE(); } while (0)      // (one wavefront: memory fence + ordering, no s_barrier)
+// ---- compute_observations + privileged observations + the roll of the "last_*" buffers (reference legged_robot.py:302-491, 120-133) --------
+// Reads the post-callback / post-reset state from the buffers; pg (projected gravity), clock_own (the own foot's clock input) and force_z
+// (the own foot's vertical contact force) are the three values post_physics() holds in registers — a caller that does not have them
+// (the helper wavefront of the step kernel) loads them from projected_gravity / clock_inputs / contact_forces, where post_physics() stored
+// them.  Four lanes per environment, must be called by all four.
+DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int e, int N, int64_t counter_post, V3 grav, int history_slot,
+                           uint32_t& fault, V3 pg, float clock_own, float force_z PROF_PARAM) {
+  const int leg = lane & 3;
+  const bool is0 = leg == 0;
+  const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
+    float* obs_row = B.obs_buf + (size_t)e * cfg.num_obs;
+    const int R = cfg.num_obs_history + 1;     // ring slots (one spare keeps the previous window intact)
+    float* h0 = B.obs_history ? B.obs_history + (size_t)e * 2 * R * cfg.num_obs + (size_t)history_slot * cfg.num_obs : nullptr;
+    float* h1 = h0 ? h0 + (size_t)R * cfg.num_obs : nullptr;
+    // Two passes.  (1) every lane stages the raw values of "its" columns in an LDS row; (2) the row is finished in
+    // blocks of 4 columns, block b by lane b & 3: ONE Philox4x32 call yields the noise of all 4 columns (drawing per
+    // column would run the generator 4x for the same counter), then clip and the three stores (obs, history x2).
+    float* orow = obs_stage + (lane >> 2) * GO1_MAX_OBS;
+    auto emit = [&](int n, float v) { orow[n] = v; };
+    // everything the default observation and the history roll read, as ONE batch of loads (post-reset values)
+    float o_q[3], o_qd[3], o_act[3], o_lact[3], o_jpt[3], o_ljpt[3], o_cmd[4];
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      o_q[jj] = AT(B.dof_pos, j, e); o_qd[jj] = AT(B.dof_vel, j, e); o_act[jj] = AT(B.actions, j, e);
+      o_lact[jj] = AT(B.last_actions, j, e); o_jpt[jj] = AT(B.joint_pos_target, j, e); o_ljpt[jj] = AT(B.last_joint_pos_target, j, e);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) o_cmd[i] = (leg + 4 * i < cfg.num_commands) ? AT(B.commands, leg + 4 * i, e) : 0.f;
+    const float o_gait = B.gait_indices[e];
+    int n = 0;                // running column (identical on all lanes)
+    if (cfg.observe_only_lin_vel) { if (is0) for (int i = 0; i < 3; i++) emit(n + i, AT(B.base_lin_vel, i, e) * cfg.obs_scale_lin_vel); n += 3; }
+    if (cfg.observe_only_ang_vel) { if (is0) for (int i = 0; i < 3; i++) emit(n + i, AT(B.base_ang_vel, i, e) * cfg.obs_scale_ang_vel); n += 3; }
+    if (cfg.observe_vel) {
+      if (is0) {
+        for (int i = 0; i < 3; i++) emit(n + i, (cfg.global_reference ? AT(B.root_states, 7 + i, e) : AT(B.base_lin_vel, i, e)) * cfg.obs_scale_lin_vel);
+        for (int i = 0; i < 3; i++) emit(n + 3 + i, AT(B.base_ang_vel, i, e) * cfg.obs_scale_ang_vel);
+      }
+      n += 6;
+    }
+    if (is0) { emit(n, pg.x); emit(n + 1, pg.y); emit(n + 2, pg.z); }
+    n += 3;
+    if (cfg.observe_command) {
+      // 15 command columns: spread over the quad
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int kx = leg + 4 * i;
+        if (kx < cfg.num_commands) emit(n + kx, o_cmd[i] * cfg.commands_scale[kx]);
+      }
+      n += cfg.num_commands;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      emit(n + j, (o_q[jj] - cfg.default_dof_pos[j]) * cfg.obs_scale_dof_pos);
+      emit(n + 12 + j, o_qd[jj] * cfg.obs_scale_dof_vel);
+      emit(n + 24 + j, o_act[jj]);
+      if (cfg.observe_two_prev_actions) emit(n + 36 + j, o_lact[jj]);
+    }
+    n += cfg.observe_two_prev_actions ? 48 : 36;
+    if (cfg.observe_timing_parameter) { if (is0) emit(n, o_gait); n += 1; }
+    if (cfg.observe_clock_inputs) { emit(n + leg, clock_own); n += 4; }
+    if (cfg.observe_yaw) {
+      if (is0) {
+        V3 fw = quat_rotate(AT(B.root_states, 3, e), AT(B.root_states, 4, e), AT(B.root_states, 5, e), AT(B.root_states, 6, e), v3(1.f, 0.f, 0.f));
+        emit(n, atan2f(fw.y, fw.x));
+      }
+      n += 1;
+    }
+    if (cfg.observe_contact_states) { emit(n + leg, force_z > 1.0f ? 1.0f : 0.0f); n += 4; }
+    {
+      const int n_def = n;                      // columns staged so far
+      QUAD_SYNC();
+#pragma unroll 1
+      for (int b = leg; 4 * b < n_def; b += 4) {
+        float v[4], sc[4];
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int c = 4 * b + i;
+          v[i] = c < n_def ? orow[c] : 0.f;
+          sc[i] = (cfg.add_noise && c < n_def) ? cfg.noise_scale_vec[c] : 0.f;
+          any = any || sc[i] != 0.f;
+        }
+        if (any) {
+          uint32_t out[4];
+          philox4x32_10(eg, (uint32_t)counter_post, P_NOISE, (uint32_t)b, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), out);
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (sc[i] != 0.f) v[i] += (2 * u32_to_unit(out[i]) - 1) * sc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int c = 4 * b + i;
+          if (c < n_def) {
+            float x = fminf(fmaxf(v[i], -cfg.clip_observations), cfg.clip_observations);
+            if (!(v[i] == v[i])) { x = 0.f; fault |= 1u << GO1_FAULT_OBS; }
+            obs_row[c] = x;
+            if (h0) { h0[c] = x; h1[c] = x; }
+          }
+        }
+      }
+    }
+    if (cfg.observe_heights && cfg.measure_heights && B.measured_heights) {      // legacy legged_gym height block (BASELINE config 3)
+      const int np = cfg.num_height_x * cfg.num_height_y;
+      const float z = AT(B.root_states, 2, e);
+#pragma unroll 1
+      for (int p = leg; p < np; p += 4) {
+        float v = fminf(fmaxf(z - 0.5f - AT(B.measured_heights, p, e), -1.f), 1.f) * cfg.obs_scale_height;
+        if (cfg.add_noise && cfg.height_noise_scale != 0.f) v += (2 * rng_uniform(cfg, eg, counter_post, P_NOISE, n + p) - 1) * cfg.height_noise_scale;
+        v = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations);
+        obs_row[n + p] = v;
+        if (h0) { h0[n + p] = v; h1[n + p] = v; }
+      }
+      n += np;
+    }
+
+    PROF(13);
+    if (is0) {
+      float* pv = B.privileged_obs_buf + (size_t)e * cfg.num_privileged_obs;
+      int np = 0;
+      auto priv = [&](int idx, float val) {
+        float v = (val - cfg.priv_shift[idx]) * cfg.priv_scale[idx];
+        pv[np++] = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations);
+      };
+      auto privraw = [&](float v) { pv[np++] = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations); };
+      if (cfg.priv_enabled[GO1_PRIV_FRICTION]) priv(GO1_PRIV_FRICTION, B.friction_coeffs[e]);
+      if (cfg.priv_enabled[GO1_PRIV_RESTITUTION]) priv(GO1_PRIV_RESTITUTION, B.restitutions[e]);
+      if (cfg.priv_enabled[GO1_PRIV_BASE_MASS]) priv(GO1_PRIV_BASE_MASS, B.payloads[e]);
+      if (cfg.priv_enabled[GO1_PRIV_COM_DISPLACEMENT]) for (int i = 0; i < 3; i++) priv(GO1_PRIV_COM_DISPLACEMENT, AT(B.com_displacements, i, e));
+      if (cfg.priv_enabled[GO1_PRIV_MOTOR_STRENGTH])
+#pragma unroll 1
+        for (int j = 0; j < 12; j++) priv(GO1_PRIV_MOTOR_STRENGTH, AT(B.motor_strengths, j, e));
+      if (cfg.priv_enabled[GO1_PRIV_MOTOR_OFFSET])
+#pragma unroll 1
+        for (int j = 0; j < 12; j++) priv(GO1_PRIV_MOTOR_OFFSET, AT(B.motor_offsets, j, e));
+      if (cfg.priv_enabled[GO1_PRIV_BODY_HEIGHT]) priv(GO1_PRIV_BODY_HEIGHT, AT(B.root_states, 2, e));
+      if (cfg.priv_enabled[GO1_PRIV_BODY_VELOCITY]) for (int i = 0; i < 3; i++) priv(GO1_PRIV_BODY_VELOCITY, AT(B.base_lin_vel, i, e));
+      if (cfg.priv_enabled[GO1_PRIV_GRAVITY]) {
+        privraw(((grav.x - cfg.gravity[0]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
+        privraw(((grav.y - cfg.gravity[1]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
+        privraw(((grav.z - cfg.gravity[2]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
+      }
+      if (cfg.priv_enabled[GO1_PRIV_CLOCK_INPUTS]) for (int f = 0; f < 4; f++) privraw(AT(B.clock_inputs, f, e));
+      if (cfg.priv_enabled[GO1_PRIV_DESIRED_CONTACT]) for (int f = 0; f < 4; f++) privraw(AT(B.desired_contact_states, f, e));
+    }
+    // ---- roll (own joints): from the values fetched above -------------------------------------------------
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      AT(B.last_last_actions, j, e) = o_lact[jj];
+      AT(B.last_actions, j, e) = o_act[jj];
+      AT(B.last_last_joint_pos_target, j, e) = o_ljpt[jj];
+      AT(B.last_joint_pos_target, j, e) = o_jpt[jj];
+      AT(B.last_dof_vel, j, e) = o_qd[jj];
+    }
+}
+
 // ================================================================================================
 // post-physics maps (reference legged_robot.py:90-136), FOUR lanes per environment (lane = leg).
 // Per-leg work (gait clock of the own foot, reward partials, own joints' observation columns, history roll) runs
 // on every lane; per-environment scalar work on the leg-0 lane; `__syncthreads()` (one-wave workgroup) orders the
 // hand-overs through HBM/L2.  Must be called by all four lanes of the environment.
 // ================================================================================================
-#define QUAD_SYNC() do { __threadfence_block(); LDS_PHASE(); } while (0)      // (one wavefront: memory fence + ordering, no s_barrier)
 
+// helper_flag != nullptr (step kernel, workgroups of nw wavefronts): the observations are taken OFF the master's serial spine — once the
+// callbacks and the termination test are through, a helper wavefront runs post_observations() (from the buffers) while the master evaluates
+// the rewards.  Two workgroup barriers: S1 (the state the observations read is stored, *helper_flag says whether the helper goes) and S2 (the
+// helper is through).  The helper does NOT go when an environment of the wavefront resets (the observations then read the re-initialised
+// state, which exists only after the rewards: master as before).  A reset that only the rewards bring about (a non-finite term: the
+// failed-simulation guard) is met after S2 by evaluating the observations of that environment again.
 DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int lane, int e, int N, int64_t counter_post, V3 grav,
-                      int history_slot, uint32_t& fault, bool is_eval PROF_PARAM) {
+                      int history_slot, uint32_t& fault, bool is_eval, float* helper_flag, int nw PROF_PARAM) {
   const int leg = lane & 3;
   const bool is0 = leg == 0;
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
@@ -553,12 +717,19 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
   if (is0) { B.time_out_buf[e] = (uint8_t)time_out; B.reset_buf[e] = (uint8_t)reset; }
 
   PROF(17);
+  bool sim_failed = quad_sum((fault & GO1_FAULT_FATAL_MASK) ? 1.f : 0.f) > 0.f;
+  bool helper_obs = false;
+  if (helper_flag != nullptr) {
+    helper_obs = __ballot(reset || sim_failed) == 0ull;
+    if (lane == 0) *helper_flag = helper_obs ? 1.f : 0.f;
+    __threadfence_block();
+    BLOCK_SYNC(nw);             // S1
+  }
   // ---- compute_reward ----------------------------------------------------------------------------------
   // Failed-simulation containment: a fault raised by the physics of this step (go1sim.h Go1FaultBit), or a reward term
   // that is not finite, ends the episode and counts as reward 0 instead of poisoning the running sums, the curriculum
   // statistics and, through the advantage normalisation, every other environment's gradient.  Every activation is
   // reported through fault_flags / fault_counts.
-  bool sim_failed = quad_sum((fault & GO1_FAULT_FATAL_MASK) ? 1.f : 0.f) > 0.f;
   float rew = 0.f, pos = 0.f, neg = 0.f;
 #pragma unroll
   for (int id = 0; id < GO1_REW_COUNT; id++) {
@@ -622,154 +793,14 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
   QUAD_SYNC();                // the observation sees the post-reset state, as in the reference
   PROF(12);
 
-  // ---- compute_observations ---------------------------------------------------------------------------
-  {
-    float* obs_row = B.obs_buf + (size_t)e * cfg.num_obs;
-    const int R = cfg.num_obs_history + 1;     // ring slots (one spare keeps the previous window intact)
-    float* h0 = B.obs_history ? B.obs_history + (size_t)e * 2 * R * cfg.num_obs + (size_t)history_slot * cfg.num_obs : nullptr;
-    float* h1 = h0 ? h0 + (size_t)R * cfg.num_obs : nullptr;
-    // Two passes.  (1) every lane stages the raw values of "its" columns in an LDS row; (2) the row is finished in
-    // blocks of 4 columns, block b by lane b & 3: ONE Philox4x32 call yields the noise of all 4 columns (drawing per
-    // column would run the generator 4x for the same counter), then clip and the three stores (obs, history x2).
-    float* orow = obs_stage + (lane >> 2) * GO1_MAX_OBS;
-    auto emit = [&](int n, float v) { orow[n] = v; };
-    // everything the default observation and the history roll read, as ONE batch of loads (post-reset values)
-    float o_q[3], o_qd[3], o_act[3], o_lact[3], o_jpt[3], o_ljpt[3], o_cmd[4];
-#pragma unroll
-    for (int jj = 0; jj < 3; jj++) {
-      const int j = 3 * leg + jj;
-      o_q[jj] = AT(B.dof_pos, j, e); o_qd[jj] = AT(B.dof_vel, j, e); o_act[jj] = AT(B.actions, j, e);
-      o_lact[jj] = AT(B.last_actions, j, e); o_jpt[jj] = AT(B.joint_pos_target, j, e); o_ljpt[jj] = AT(B.last_joint_pos_target, j, e);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) o_cmd[i] = (leg + 4 * i < cfg.num_commands) ? AT(B.commands, leg + 4 * i, e) : 0.f;
-    const float o_gait = B.gait_indices[e];
-    int n = 0;                // running column (identical on all lanes)
-    if (cfg.observe_only_lin_vel) { if (is0) for (int i = 0; i < 3; i++) emit(n + i, AT(B.base_lin_vel, i, e) * cfg.obs_scale_lin_vel); n += 3; }
-    if (cfg.observe_only_ang_vel) { if (is0) for (int i = 0; i < 3; i++) emit(n + i, AT(B.base_ang_vel, i, e) * cfg.obs_scale_ang_vel); n += 3; }
-    if (cfg.observe_vel) {
-      if (is0) {
-        for (int i = 0; i < 3; i++) emit(n + i, (cfg.global_reference ? AT(B.root_states, 7 + i, e) : AT(B.base_lin_vel, i, e)) * cfg.obs_scale_lin_vel);
-        for (int i = 0; i < 3; i++) emit(n + 3 + i, AT(B.base_ang_vel, i, e) * cfg.obs_scale_ang_vel);
-      }
-      n += 6;
-    }
-    if (is0) { emit(n, d.pg.x); emit(n + 1, d.pg.y); emit(n + 2, d.pg.z); }
-    n += 3;
-    if (cfg.observe_command) {
-      // 15 command columns: spread over the quad
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int kx = leg + 4 * i;
-        if (kx < cfg.num_commands) emit(n + kx, o_cmd[i] * cfg.commands_scale[kx]);
-      }
-      n += cfg.num_commands;
-    }
-#pragma unroll
-    for (int jj = 0; jj < 3; jj++) {
-      const int j = 3 * leg + jj;
-      emit(n + j, (o_q[jj] - cfg.default_dof_pos[j]) * cfg.obs_scale_dof_pos);
-      emit(n + 12 + j, o_qd[jj] * cfg.obs_scale_dof_vel);
-      emit(n + 24 + j, o_act[jj]);
-      if (cfg.observe_two_prev_actions) emit(n + 36 + j, o_lact[jj]);
-    }
-    n += cfg.observe_two_prev_actions ? 48 : 36;
-    if (cfg.observe_timing_parameter) { if (is0) emit(n, o_gait); n += 1; }
-    if (cfg.observe_clock_inputs) { emit(n + leg, clock_own); n += 4; }
-    if (cfg.observe_yaw) {
-      if (is0) {
-        V3 fw = quat_rotate(AT(B.root_states, 3, e), AT(B.root_states, 4, e), AT(B.root_states, 5, e), AT(B.root_states, 6, e), v3(1.f, 0.f, 0.f));
-        emit(n, atan2f(fw.y, fw.x));
-      }
-      n += 1;
-    }
-    if (cfg.observe_contact_states) { emit(n + leg, F.force.z > 1.0f ? 1.0f : 0.0f); n += 4; }
-    {
-      const int n_def = n;                      // columns staged so far
-      QUAD_SYNC();
-#pragma unroll 1
-      for (int b = leg; 4 * b < n_def; b += 4) {
-        float v[4], sc[4];
-        bool any = false;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int c = 4 * b + i;
-          v[i] = c < n_def ? orow[c] : 0.f;
-          sc[i] = (cfg.add_noise && c < n_def) ? cfg.noise_scale_vec[c] : 0.f;
-          any = any || sc[i] != 0.f;
-        }
-        if (any) {
-          uint32_t out[4];
-          philox4x32_10(eg, (uint32_t)counter_post, P_NOISE, (uint32_t)b, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), out);
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-            if (sc[i] != 0.f) v[i] += (2 * u32_to_unit(out[i]) - 1) * sc[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int c = 4 * b + i;
-          if (c < n_def) {
-            float x = fminf(fmaxf(v[i], -cfg.clip_observations), cfg.clip_observations);
-            if (!(v[i] == v[i])) { x = 0.f; fault |= 1u << GO1_FAULT_OBS; }
-            obs_row[c] = x;
-            if (h0) { h0[c] = x; h1[c] = x; }
-          }
-        }
-      }
-    }
-    if (cfg.observe_heights && cfg.measure_heights && B.measured_heights) {      // legacy legged_gym height block (BASELINE config 3)
-      const int np = cfg.num_height_x * cfg.num_height_y;
-      const float z = AT(B.root_states, 2, e);
-#pragma unroll 1
-      for (int p = leg; p < np; p += 4) {
-        float v = fminf(fmaxf(z - 0.5f - AT(B.measured_heights, p, e), -1.f), 1.f) * cfg.obs_scale_height;
-        if (cfg.add_noise && cfg.height_noise_scale != 0.f) v += (2 * rng_uniform(cfg, eg, counter_post, P_NOISE, n + p) - 1) * cfg.height_noise_scale;
-        v = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations);
-        obs_row[n + p] = v;
-        if (h0) { h0[n + p] = v; h1[n + p] = v; }
-      }
-      n += np;
-    }
-
-    PROF(13);
-    if (is0) {
-      float* pv = B.privileged_obs_buf + (size_t)e * cfg.num_privileged_obs;
-      int np = 0;
-      auto priv = [&](int idx, float val) {
-        float v = (val - cfg.priv_shift[idx]) * cfg.priv_scale[idx];
-        pv[np++] = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations);
-      };
-      auto privraw = [&](float v) { pv[np++] = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations); };
-      if (cfg.priv_enabled[GO1_PRIV_FRICTION]) priv(GO1_PRIV_FRICTION, B.friction_coeffs[e]);
-      if (cfg.priv_enabled[GO1_PRIV_RESTITUTION]) priv(GO1_PRIV_RESTITUTION, B.restitutions[e]);
-      if (cfg.priv_enabled[GO1_PRIV_BASE_MASS]) priv(GO1_PRIV_BASE_MASS, B.payloads[e]);
-      if (cfg.priv_enabled[GO1_PRIV_COM_DISPLACEMENT]) for (int i = 0; i < 3; i++) priv(GO1_PRIV_COM_DISPLACEMENT, AT(B.com_displacements, i, e));
-      if (cfg.priv_enabled[GO1_PRIV_MOTOR_STRENGTH])
-#pragma unroll 1
-        for (int j = 0; j < 12; j++) priv(GO1_PRIV_MOTOR_STRENGTH, AT(B.motor_strengths, j, e));
-      if (cfg.priv_enabled[GO1_PRIV_MOTOR_OFFSET])
-#pragma unroll 1
-        for (int j = 0; j < 12; j++) priv(GO1_PRIV_MOTOR_OFFSET, AT(B.motor_offsets, j, e));
-      if (cfg.priv_enabled[GO1_PRIV_BODY_HEIGHT]) priv(GO1_PRIV_BODY_HEIGHT, AT(B.root_states, 2, e));
-      if (cfg.priv_enabled[GO1_PRIV_BODY_VELOCITY]) for (int i = 0; i < 3; i++) priv(GO1_PRIV_BODY_VELOCITY, AT(B.base_lin_vel, i, e));
-      if (cfg.priv_enabled[GO1_PRIV_GRAVITY]) {
-        privraw(((grav.x - cfg.gravity[0]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
-        privraw(((grav.y - cfg.gravity[1]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
-        privraw(((grav.z - cfg.gravity[2]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
-      }
-      if (cfg.priv_enabled[GO1_PRIV_CLOCK_INPUTS]) for (int f = 0; f < 4; f++) privraw(AT(B.clock_inputs, f, e));
-      if (cfg.priv_enabled[GO1_PRIV_DESIRED_CONTACT]) for (int f = 0; f < 4; f++) privraw(AT(B.desired_contact_states, f, e));
-    }
-    // ---- roll (own joints): from the values fetched above -------------------------------------------------
-#pragma unroll
-    for (int jj = 0; jj < 3; jj++) {
-      const int j = 3 * leg + jj;
-      AT(B.last_last_actions, j, e) = o_lact[jj];
-      AT(B.last_actions, j, e) = o_act[jj];
-      AT(B.last_last_joint_pos_target, j, e) = o_ljpt[jj];
-      AT(B.last_joint_pos_target, j, e) = o_jpt[jj];
-      AT(B.last_dof_vel, j, e) = o_qd[jj];
-    }
+  // ---- compute_observations (+ privileged observations, roll): post_observations() -------------------------------------------
+  if (!helper_obs) {
+    post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z PROF_PASS);
+    if (helper_flag != nullptr) BLOCK_SYNC(nw);       // S2 (the helper had nothing to do)
+  } else {
+    BLOCK_SYNC(nw);                                   // S2: the helper's observations are written
+    if (reset)                                        // only through the failed-simulation guard above: this environment once more, re-initialised
+      post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z PROF_PASS);
   }
   PROF(14);
   PROF(15);

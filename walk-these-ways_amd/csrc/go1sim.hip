@@ -142,6 +142,21 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
       BLOCK_SYNC(nw);
 #endif
     }
+#ifndef GO1_ABLATE_POST
+    if (!substep_only) {       // post_physics(): the observations on helper 1 while the master evaluates the rewards (go1_maps.h)
+      BLOCK_SYNC(nw);          // S1
+      if (wv == 1 && acth[0] != 0.f) {
+        PROF_DECL
+        const int leg_ = lane & 3;
+        const V3 pg = v3(AT(B.projected_gravity, 0, e), AT(B.projected_gravity, 1, e), AT(B.projected_gravity, 2, e));
+        const float clock_own = AT(B.clock_inputs, leg_, e), force_z = AT(B.contact_forces, 3 * (4 + 4 * leg_) + 2, e);
+        uint32_t fault_h = 0;
+        post_observations(cfg, B, lds, lane, e, N, A.counter + 1, gravity_at(cfg, A.counter), A.history_slot, fault_h, pg, clock_own, force_z PROF_PASS);
+        report_fault(B, e, fault_h);
+      }
+      BLOCK_SYNC(nw);          // S2
+    }
+#endif
     return;
   }
   const float h = cfg.sim_dt;
@@ -228,7 +243,8 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   PROF(7);
 #ifndef GO1_ABLATE_POST
   if (!substep_only)
-    post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, grav, A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs PROF_PASS);
+    post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, grav, A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs,
+                 nw > 1 ? acth : nullptr, nw PROF_PASS);
 #endif
   report_fault(B, e, fault);
   report_drops(B, drops);
@@ -269,7 +285,8 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   if (A.mode == 4) {       // tensor maps only
     PROF_DECL
     uint32_t fault = 0;
-    post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs PROF_PASS);
+    post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs,
+                 nullptr, 1 PROF_PASS);
     report_fault(B, e, fault);
     return;
   }
