@@ -371,8 +371,10 @@ static void terrain_sample(const Terrain* t, real x, real y, real* h, real* n, W
  * Self-collision (asset self_collisions = 0: nothing filtered, go1_config.py:44, legged_robot.py:1563-1564): capsules —
  * lower leg (knee -> foot centre, radius of the foot sphere), thigh (thigh joint -> knee, GO1_SELF_THIGH_RADIUS), trunk (the
  * box's long axis, radius = its half width) — lower legs and thighs of DIFFERENT legs against each other (24 pairs) and
- * lower legs against the trunk (4); closest points of the two segments; two legs touch in ONE point (the deepest of their four
- * capsule combinations).  Not modelled: pairs within one leg and the hip capsules (mechanically out of reach within the joint limits).
+ * lower legs against the trunk (4), and since round 5 the hip capsules against the OTHER legs' lower legs (12: the one combination with a
+ * hip capsule the joint limits let touch); closest points of the two segments; two legs touch in ONE point (the deepest of their six
+ * capsule combinations).  Not modelled: pairs within one leg, hip capsules against thighs / each other, trunk against thighs —
+ * out of reach within the joint limits (tests/test_self_collision_reach.py samples the limit box).
  * Solver list: at most GO1_MAX_CONTACTS, in the priority order feet, foot walls, self-contacts (at most 6 leg-leg), trunk, trunk wall, calves (first points, walls, second points), thighs (same), hips; what does not fit is dropped
  * and counted per class. */
 typedef struct { real phi, x[3], n[3]; int valid; uint32_t tag; } Cand;   /* tag: 16 * height-field cell + candidate point index */
@@ -445,6 +447,7 @@ static void seg_seg(const real* p1, const real* q1, const real* p2, const real* 
   for (int i = 0; i < 3; i++) { c1[i] = p1[i] + sN * d1[i]; c2[i] = p2[i] + tN * d2[i]; }
 }
 
+#define GO1_SELF_TYPES 6                /* capsule combinations of a pair of legs (detect_contacts) */
 #define GO1_SELF_LEG_RADIUS GO1_FOOT_RADIUS
 #define GO1_SELF_THIGH_RADIUS 0.017    /* half of the thigh box's larger cross-section side (urdf: 0.0245 x 0.034) */
 #define GO1_MAX_TRUNK_POINTS 4
@@ -454,13 +457,13 @@ static void seg_seg(const real* p1, const real* q1, const real* p2, const real* 
 
 typedef struct { int n; int dropped[GO1_CC_COUNT]; uint32_t sig[GO1_SIG_WORDS]; } ContactList;
 
-/* sigw: signature word (0 top surface, 1 walls, 2 self pairs), sigb: bit */
+/* sigw: signature word (0 top surface, 1 walls, 2 self pairs), sigb: bit (< 0: the caller records it) */
 static void add_contact(Contact* list, ContactList* L, const Contact* c, int sigw, int sigb) {
   if (L->n >= GO1_MAX_CONTACTS) { L->dropped[c->cls]++; L->sig[1] |= 1u << 31; return; }
   list[L->n] = *c;
   contact_frame(&list[L->n]);
   L->n++;
-  L->sig[sigw] |= 1u << sigb;
+  if (sigb >= 0) L->sig[sigw] |= 1u << sigb;
 }
 /* item: the kernel's item index of the point (go1_physics.h IT_*): its weight in the geometry hash */
 enum { IT_FOOT = 0, IT_FOOTW, IT_CALF1, IT_CALFW, IT_CALF2, IT_THIGH1, IT_THIGHW, IT_THIGH2, IT_HIP1, IT_HIP2, IT_TR0, IT_TR1, IT_TRW };
@@ -509,8 +512,8 @@ static ContactList detect_contacts(const Go1SimConfig* cfg, const Terrain* ter, 
   memset(&L, 0, sizeof L);
   for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &foot[leg], 4 + 4 * leg, 3 * leg + 3, GO1_CC_FOOT, 1, 0, leg, IT_FOOT);
   for (int leg = 0; leg < 4; leg++) add_terrain(list, &L, cd, &footw[leg], 4 + 4 * leg, 3 * leg + 3, GO1_CC_FOOT_WALL, 0, 1, leg, IT_FOOTW);
-  /* self-collision: segments of the lower legs [0] and thighs [1], trunk axis */
-  real P[4][2][3], Q[4][2][3], TA[3], TB[3];
+  /* self-collision: segments of the lower legs [0], thighs [1] and hip capsules [2], trunk axis */
+  real P[4][3][3], Q[4][3][3], TA[3], TB[3];
   for (int leg = 0; leg < 4; leg++) {
     real fo[3] = {GO1_FOOT_OFFSET[leg][0], GO1_FOOT_OFFSET[leg][1], GO1_FOOT_OFFSET[leg][2]}, w[3];
     v3cpy(P[leg][0], k->p[3 * leg + 3]);
@@ -518,26 +521,35 @@ static ContactList detect_contacts(const Go1SimConfig* cfg, const Terrain* ter, 
     v3add(Q[leg][0], P[leg][0], w);
     v3cpy(P[leg][1], k->p[3 * leg + 2]);
     v3cpy(Q[leg][1], k->p[3 * leg + 3]);
+    for (int m = 0; m < 2; m++) {           /* hip capsule: along the hip body's y axis (the collision shape the terrain sees too) */
+      real l[3] = {GO1_HIP_CAPSULE_CENTER[leg][0], GO1_HIP_CAPSULE_CENTER[leg][1] + (m ? 1 : -1) * GO1_HIP_CAPSULE_HALF, GO1_HIP_CAPSULE_CENTER[leg][2]};
+      m3v(w, k->R[3 * leg + 1], l);
+      v3add(m ? Q[leg][2] : P[leg][2], k->p[3 * leg + 1], w);
+    }
   }
   {
     real a = GO1_TRUNK_BOX_HALF[0] - GO1_TRUNK_BOX_HALF[1], la[3] = {-a, 0, 0}, lb[3] = {a, 0, 0};
     m3v(TA, k->R[0], la); m3v(TB, k->R[0], lb);
   }
-  /* pid = 6 * type + pair for the leg-leg pairs: type 0 lower-lower, 1 lower(i)-thigh(j), 2 thigh(i)-lower(j), 3 thigh-thigh,
-   * pair (i, j) in the order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); pid 24 + leg: lower leg against the trunk.  Two legs touch in ONE
-   * point: of the four capsule combinations of a pair of legs only the deepest is a contact (ties: the lower type), so at most six
-   * leg-leg contacts exist and none is ever dropped for lack of a slot of its own. */
+  /* pid = 6 * type + pair for the leg-leg pairs — type 0 lower-lower, 1 lower(i)-thigh(j), 2 thigh(i)-lower(j), 3 thigh-thigh, 4 hip(i)-lower(j),
+   * 5 lower(i)-hip(j) (round 5: the one reachable combination with a hip capsule, tests/test_self_collision_reach.py) — pair (i, j) in
+   * the order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); pid 36 + leg: lower leg against the trunk.  Two legs touch in ONE point: of the six
+   * capsule combinations of a pair of legs only the deepest is a contact (ties: the lower type), so at most six leg-leg contacts exist and
+   * none is ever dropped for lack of a slot of its own.  Signature word 2: 3 bits per pair (type + 1; bits 0..17), trunk pairs at 18 + leg. */
   static const int PI_[6] = {0, 0, 0, 1, 1, 2}, PJ_[6] = {1, 2, 3, 2, 3, 3};
+  static const int SEG_A[GO1_SELF_TYPES] = {0, 0, 1, 1, 2, 0}, SEG_B[GO1_SELF_TYPES] = {0, 1, 0, 1, 0, 2};
+  const real SEG_R[3] = {(real)GO1_SELF_LEG_RADIUS, (real)GO1_SELF_THIGH_RADIUS, (real)GO1_HIP_CAPSULE_RADIUS};
   int best_type[6];
-  Contact pairc[28];
-  int pair_on[28] = {0};
+  Contact pairc[6 * GO1_SELF_TYPES + 4];
+  int pair_on[6 * GO1_SELF_TYPES + 4] = {0};
   for (int pr = 0; pr < 6; pr++) best_type[pr] = -1;
-  for (int pid = 0; pid < (cfg->self_collision ? 28 : 0); pid++) {
-    const int type = pid < 24 ? pid / 6 : 0, i = pid < 24 ? PI_[pid % 6] : pid - 24, j = pid < 24 ? PJ_[pid % 6] : -1;
-    const int sa = (type >> 1) & 1, sb = type & 1;          /* segment of body A / B: 0 lower leg, 1 thigh */
+  for (int pid = 0; pid < (cfg->self_collision ? 6 * GO1_SELF_TYPES + 4 : 0); pid++) {
+    const int leglegs = 6 * GO1_SELF_TYPES;
+    const int type = pid < leglegs ? pid / 6 : 0, i = pid < leglegs ? PI_[pid % 6] : pid - leglegs, j = pid < leglegs ? PJ_[pid % 6] : -1;
+    const int sa = SEG_A[type], sb = SEG_B[type];          /* segment of body A / B: 0 lower leg, 1 thigh, 2 hip capsule */
     real c1[3], c2[3], d[3];
-    const real ra = sa ? (real)GO1_SELF_THIGH_RADIUS : (real)GO1_SELF_LEG_RADIUS;
-    const real rb = j >= 0 ? (sb ? (real)GO1_SELF_THIGH_RADIUS : (real)GO1_SELF_LEG_RADIUS) : (real)GO1_TRUNK_BOX_HALF[1];
+    const real ra = SEG_R[sa];
+    const real rb = j >= 0 ? SEG_R[sb] : (real)GO1_TRUNK_BOX_HALF[1];
     if (j >= 0) seg_seg(P[i][sa], Q[i][sa], P[j][sb], Q[j][sb], c1, c2); else seg_seg(P[i][0], Q[i][0], TA, TB, c1, c2);
     v3sub(d, c1, c2);
     real dist = v3norm(d);
@@ -545,8 +557,8 @@ static ContactList detect_contacts(const Go1SimConfig* cfg, const Terrain* ter, 
     real phi = dist - ra - rb;
     if (!(phi < cd)) continue;
     Contact t;
-    t.repA = 1 + 4 * i + (sa ? 1 : 2); t.dynA = 3 * i + (sa ? 2 : 3);
-    t.repB = j >= 0 ? 1 + 4 * j + (sb ? 1 : 2) : 0; t.dynB = j >= 0 ? 3 * j + (sb ? 2 : 3) : 0;
+    t.repA = 1 + 4 * i + (2 - sa); t.dynA = 3 * i + (3 - sa);
+    t.repB = j >= 0 ? 1 + 4 * j + (2 - sb) : 0; t.dynB = j >= 0 ? 3 * j + (3 - sb) : 0;
     t.phi = phi; t.share = 0; t.cls = GO1_CC_SELF; t.top = 0;
     for (int q = 0; q < 3; q++) { t.n[q] = d[q] / dist; t.x[q] = c2[q] + t.n[q] * (rb + (real)0.5 * phi); }
     pairc[pid] = t;
@@ -558,8 +570,12 @@ static ContactList detect_contacts(const Go1SimConfig* cfg, const Terrain* ter, 
       pair_on[pid] = 1;
     }
   }
-  for (int pid = 0; pid < 28; pid++)
-    if (pair_on[pid]) add_contact(list, &L, &pairc[pid], 2, pid);
+  for (int pid = 0; pid < 6 * GO1_SELF_TYPES + 4; pid++)
+    if (pair_on[pid]) {
+      const int before = L.n;
+      add_contact(list, &L, &pairc[pid], 2, -1);
+      if (L.n > before) L.sig[2] |= pid < 6 * GO1_SELF_TYPES ? (uint32_t)(pid / 6 + 1) << (3 * (pid % 6)) : 1u << (18 + pid - 6 * GO1_SELF_TYPES);
+    }
   /* remaining shapes */
 #define FIRST(c) (((c)[1].valid && (!(c)[0].valid || (c)[1].phi < (c)[0].phi)) ? 1 : 0)
   {

@@ -14,6 +14,7 @@ import go1sim_host as H  # noqa: E402
 from test_gpu_parity import ATTRIBUTED_BOUND, RULE_B_FACTOR, RULE_B_FLOOR  # noqa: E402  (constants only: that module's tests need the GPU)
 from golden.variants import FUZZ_VARIANTS, random_switches  # noqa: E402
 from util import (GOLDEN, RESAMPLE_MODES, check_resample_against_reference, load_maps_fixture, load_resample_fixture, maps_fixture_stream, maps_keep,  # noqa: E402
+                  self_contacts_listed, self_pair_codes,
                   make_sim, randomize_dr, standing_state)
 
 
@@ -341,9 +342,54 @@ def test_emulated_thigh_capsules_match_oracle(oracle_lib, emu):
         for k, tol in (("root_states", 5e-4), ("dof_pos", 1e-4), ("dof_vel", 2e-2)):
             assert diff(Be, Bc, k) <= tol, (it, k, diff(Be, Bc, k))
         assert not bool(((Be.contact_forces - Bc.contact_forces).abs() > 5e-2 + 5e-3 * Bc.contact_forces.abs()).any()), it
-        thigh_pairs += int(((Bc.contact_signature[2] & 0xFFFFFF) >> 6 != 0).sum())
+        thigh_pairs += sum(any(c in (2, 3, 4) for c in self_pair_codes(w)[0]) for w in Bc.contact_signature[2].tolist())
         resync(Bc, Be, sim, orc)
     assert thigh_pairs > 50, thigh_pairs
+    assert int(Be.fault_counts[:10].sum()) == 0
+
+
+def test_emulated_hip_capsules_match_oracle(oracle_lib, emu):
+    """Hip capsules in the self-collision (round 5: types 4 / 5 of a pair of legs, hip - the other leg's lower leg) through the KERNEL code: in
+    free flight a fore lower leg (knee stretched) is swung back into the hind hip of its side (environments 0-7: left side, the lower-numbered
+    leg carries the lower leg = type 5; environments 8-15: the hind lower leg swung FORWARD into the fore hip = type 4), every joint held by
+    a PD torque; kernel and oracle list the same pairs and agree to round-off on every substep, and both types do fire."""
+    N = 16
+    cfg, S, meta, Bc = make_sim("train", N, extra={"domain_rand": dict(randomize_gravity=False)})
+    S.gravity[0] = S.gravity[1] = S.gravity[2] = 0.0
+    standing_state(S, Bc, z=3.0)
+    g = torch.Generator().manual_seed(9)
+    back = torch.tensor([-0.4, 1.5, -0.98, -0.1, 0.8, -1.5, -0.43, 2.3, -2.5, -0.1, 1.0, -1.5])       # FL lower leg -> RL hip (tests/test_oracle_physics.py)
+    fwd = torch.tensor([0.3, 0.0, -1.5, -0.1, 0.8, -1.5, 0.58, -0.4, -1.0, -0.1, 1.0, -1.5])          # RL lower leg -> FL hip (thigh angle < 0: forward)
+    Bc.dof_pos[:, :8] = back.unsqueeze(1)
+    Bc.dof_pos[:, 8:] = fwd.unsqueeze(1)
+    Bc.dof_pos[[0, 6]] += torch.empty(2, N).uniform_(-0.15, 0.15, generator=g)
+    q_hold = Bc.dof_pos.clone()
+    drive = torch.empty(N).uniform_(1.0, 2.5, generator=g)
+    Bc.enable_contact_signature()
+    orc = oracle_lib.Oracle(S, Bc)
+    Be = Bc.clone_to("cpu")
+    sim = emu.EmuSim(S, Be)
+    seen = {5: 0, 6: 0}
+    for it in range(120):
+        tau = 30.0 * (q_hold - Bc.dof_pos) - 1.0 * Bc.dof_vel
+        tau[1, :8] = drive[:8] - 0.5 * Bc.dof_vel[1, :8]           # FL thigh backwards
+        tau[7, 8:] = -drive[8:] - 0.5 * Bc.dof_vel[7, 8:]          # RL thigh forwards
+        Bc.torques.copy_(tau)
+        Be.torques.copy_(tau)
+        orc.physics_substep()
+        sim.physics_substep()
+        assert torch.equal(Be.contact_signature[:3], Bc.contact_signature[:3]), it
+        for k, tol in (("root_states", 5e-4), ("dof_pos", 1e-4), ("dof_vel", 2e-2)):
+            assert diff(Be, Bc, k) <= tol, (it, k, diff(Be, Bc, k))
+        assert not bool(((Be.contact_forces - Bc.contact_forces).abs() > 5e-2 + 5e-3 * Bc.contact_forces.abs()).any()), it
+        for w in Bc.contact_signature[2].tolist():
+            c = self_pair_codes(w)[0][1]                           # pair (0, 2): FL - RL
+            if c in seen:
+                seen[c] += 1
+        resync(Bc, Be, sim, orc)
+    assert seen[5] > 50 and seen[6] > 50, seen
+    hipf = Bc.contact_forces.view(17, 3, N)[[1, 9]].norm(dim=1)   # FL hip, RL hip: the forces are booked on the hip bodies
+    assert float(hipf.max()) > 1.0
     assert int(Be.fault_counts[:10].sum()) == 0
 
 
@@ -444,7 +490,7 @@ def test_emulated_full_step_in_the_contact_heavy_regime(oracle_lib, emu, seed):
         assert torch.equal(Be.reset_buf, Bc.reset_buf), step
         assert_attributed(Be, Bc, sh.B, tols, N, step)
         sig = Bc.contact_signature.view(4, 4, N).numpy().astype(np.uint32)
-        listed = np.array([[bin(int(sig[sb, 0, e])).count("1") + bin(int(sig[sb, 1, e]) & 0x7FFFFFFF).count("1") + bin(int(sig[sb, 2, e]) & 0xFFFFFFF).count("1")
+        listed = np.array([[bin(int(sig[sb, 0, e])).count("1") + bin(int(sig[sb, 1, e]) & 0x7FFFFFFF).count("1") + self_contacts_listed(sig[sb, 2, e])
                             for e in range(N)] for sb in range(4)])
         peak_listed = max(peak_listed, int(listed.max()))
         self_pairs += int((sig[:, 2] & 0xFFFFFFF != 0).sum())

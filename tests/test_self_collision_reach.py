@@ -1,5 +1,6 @@
 """Which body pairs can touch inside the joint-limit box?  (the step lists lower legs and thighs of DIFFERENT legs
-against each other and lower legs against the trunk; pairs within one leg and the hip capsules are NOT modelled.)  The reference enables
+against each other, hip capsules against the other legs' lower legs, and lower legs against the trunk; the remaining non-adjacent pairs
+are NOT modelled — this file shows that they are out of reach.)  The reference enables
 all self-collisions (go1_config.py:44 `self_collisions = 0` = no pair filtered, legged_robot.py:1562-1563); PhysX articulations skip
 parent-child pairs only.  Sampled here over the whole joint-limit box with the model's own numbers (csrc/go1_model_data.h, generated from
 the reference URDF): forward kinematics of the legs, capsule / sphere-swept segments as the oracle uses them (lower leg: knee -> foot
@@ -100,11 +101,15 @@ def test_unlisted_body_pairs_over_the_joint_limit_box():
         print(f"  {k:30s}: minimum clearance {v.min() * 1e3:7.1f} mm, touching in {100.0 * (v < 0).mean():6.3f} % of the joint-limit box")
     # what the sampling finds (pinned; DESIGN.md section 2 quotes these numbers):
     frac = {k: float((v < 0).mean()) for k, v in out.items()}
-    # never closer than 2 cm anywhere in the limit box: "out of reach" holds for the pairs WITHIN a leg, for the trunk against the thighs,
-    # for the hips among themselves and against the other legs' thighs
-    for k in ("hip - own lower leg", "trunk - thigh", "hip - hip", "hip - other leg's thigh"):
+    # Every pair that can touch inside the limit box must be one the solver lists.  NOT listed (oracle/go1_oracle.c detect_contacts,
+    # csrc/go1_physics.h self-collision geometry): pairs within a leg, trunk - thigh, hip - hip, hip - another leg's thigh — never closer
+    # than 2 cm anywhere in the box:
+    not_listed = ("hip - own lower leg", "trunk - thigh", "hip - hip", "hip - other leg's thigh")
+    for k in not_listed:
         assert out[k].min() > 0.02, k
-    # ... but NOT for a hip capsule (r = 4.6 cm, the fattest shape of a leg) against ANOTHER leg's LOWER leg: the hind leg of a side swung
-    # forward with the knee stretched reaches the fore hip of that side (and vice versa) in ~5 % of the box (up to 5 cm deep); the
-    # reference lists these pairs (PhysX, self_collisions = 0), this simulator does not — a stated deviation
+    # ... and the one reachable combination with a hip capsule (r = 4.6 cm, the fattest shape of a leg) — against ANOTHER leg's LOWER leg:
+    # the hind leg of a side swung forward with the knee stretched reaches the fore hip of that side (and vice versa) in ~5 % of the box,
+    # up to 5 cm deep — IS listed since round 5 (types 4 / 5 of a pair of legs; tests/test_oracle_physics.py
+    # test_fore_lower_leg_swung_into_the_hind_hip_is_pushed_out, tests/test_emu_parity.py test_emulated_hip_capsules_match_oracle)
     assert 0.02 < frac["hip - other leg's lower leg"] < 0.08
+    assert set(out) - set(not_listed) == {"hip - other leg's lower leg"}

@@ -156,3 +156,16 @@ def check_exported_policy_layout(ckpt_dir):
     weights = torch.load(os.path.join(ckpt_dir, "ac_weights_last.pt"), map_location="cpu")
     groups = {k.split(".")[0] for k in weights}
     assert groups == {"std", "adaptation_module", "actor_body", "critic_body"}, groups      # ppo_cse/__init__.py:231-251 consumers
+
+
+def self_pair_codes(w2):
+    """contact signature word 2 (include/go1sim.h): bits 3 p .. 3 p + 2 = 1 + type of the leg-leg self-contact listed for pair p of
+    (0,1) (0,2) (0,3) (1,2) (1,3) (2,3) — type 0 lower-lower, 1 lower-thigh, 2 thigh-lower, 3 thigh-thigh, 4 hip-lower, 5 lower-hip; 0: none —,
+    bits 18..21: lower leg of leg 0..3 against the trunk, bits 28..31: legs with limit rows.  Returns (six codes, trunk mask)."""
+    w2 = int(w2) & 0xFFFFFFFF
+    return [(w2 >> (3 * p)) & 7 for p in range(6)], (w2 >> 18) & 0xF
+
+
+def self_contacts_listed(w2):
+    codes, trunk = self_pair_codes(w2)
+    return sum(c != 0 for c in codes) + bin(trunk).count("1")

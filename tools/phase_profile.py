@@ -22,7 +22,8 @@ PHASES = ["rest of the prologue (stash commit, input checks)", "torque model: ba
           "kinematics + candidates + self-collision geometry + contact list (x4)", "post items into the records (x4)",
           "self-contacts + limit rows + barrier wait for the helpers' rows (x4)",
           "torque model: post q, qd for the helpers' rows (x4)", "PGS: warm-start state (x4)",
-          "loop edge after the pose update (x4)", "kinematics + terrain candidates (x4; 19 = the contact list alone)", "self-collision geometry (x4)"]
+          "loop edge after the pose update (x4)", "kinematics + terrain candidates (x4; 19 = the contact list alone)", "self-collision geometry (x4)",
+          "apply: impulses of the listed contacts from LDS (x4; 6 = the rest)", "apply: back-substitution + base twist (x4)", "integrate the joints (x4)"]
 
 
 def build(flags):
@@ -58,14 +59,35 @@ def main():
             env.step(acts[t])
         torch.cuda.synchronize()
         lib.go1sim_debug_read_profile(buf)            # clear
+        wg = (ctypes.c_uint64 * 1152)()
+        lib.go1sim_debug_read_wg_times.argtypes = [ctypes.c_void_p]
+        lib.go1sim_debug_read_wg_times(wg)
+        wp = (ctypes.c_uint64 * (1024 * 32))()
+        lib.go1sim_debug_read_wg_phases.argtypes = [ctypes.c_void_p]
+        lib.go1sim_debug_read_wg_phases(wp)
         for t in range(args.steps):
             env.step(acts[t])
         torch.cuda.synchronize()
         assert lib.go1sim_debug_read_profile(buf) == 0
+        assert lib.go1sim_debug_read_wg_times(wg) == 0
+        import numpy as np
+        w = np.array(wg[:args.envs // 16], dtype=np.float64) / args.steps
+        print(f"master wavefront's cycles per step over the {len(w)} workgroups: mean {w.mean():.0f}, median {np.median(w):.0f}, 90 % {np.quantile(w, 0.9):.0f}, "
+              f"99 % {np.quantile(w, 0.99):.0f}, max {w.max():.0f} (the launch lasts as long as its slowest workgroup: max / mean = {w.max() / w.mean():.2f})")
+        nwg = args.envs // 16
+        lmax, lsum = np.array(wg[1024:1088], dtype=np.float64), np.array(wg[1088:1152], dtype=np.float64)
+        used = lmax > 0
+        print(f"per launch ({int(used.sum())} launches): mean over workgroups {np.mean(lsum[used] / nwg):.0f} cycles, slowest workgroup {np.mean(lmax[used]):.0f} "
+              f"(ratio {np.mean(lmax[used] / (lsum[used] / nwg)):.2f}: what perfectly even workgroups would save)")
         tot = sum(buf[:len(PHASES)])
         print(f"cycles per step (wave 0 lane 0, s_memtime ticks): {tot / args.steps:.0f}")
+        assert lib.go1sim_debug_read_wg_phases(wp) == 0
+        P = np.array(wp[:], dtype=np.float64).reshape(1024, 32)[:nwg, :len(PHASES)] / args.steps
+        order = np.argsort(P.sum(1))
+        slow, fast = P[order[-max(nwg // 10, 1):]].mean(0), P[order[:max(nwg // 10, 1)]].mean(0)
+        print(f"  phase                                      workgroup 0    mean of all   slowest 10 %   fastest 10 %   (cycles per step)")
         for i, name in enumerate(PHASES):
-            print(f"  {i:2d} {name:42s} {buf[i] / args.steps:10.0f}  {100.0 * buf[i] / tot:5.1f} %")
+            print(f"  {i:2d} {name[:40]:40s} {buf[i] / args.steps:10.0f} {P[:, i].mean():12.0f} {slow[i]:14.0f} {fast[i]:14.0f}")
     finally:
         if args.lib is None:
             build([])

@@ -414,12 +414,14 @@ DEV int reward_raw_sign(int id) {
 // Reads the post-callback / post-reset state from the buffers; pg (projected gravity), clock_own (the own foot's clock input) and force_z
 // (the own foot's vertical contact force) are the three values post_physics() holds in registers — a caller that does not have them
 // (the helper wavefront of the step kernel) loads them from projected_gravity / clock_inputs / contact_forces, where post_physics() stored
-// them.  Four lanes per environment, must be called by all four.
+// them.  parts: 1 = observations + roll, 2 = privileged observations (the step kernel gives 1 to the helper and keeps 2 on the master: the
+// helper's share then takes as long as the master's rewards).  Four lanes per environment, must be called by all four.
 DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int e, int N, int64_t counter_post, V3 grav, int history_slot,
-                           uint32_t& fault, V3 pg, float clock_own, float force_z PROF_PARAM) {
+                           uint32_t& fault, V3 pg, float clock_own, float force_z, int parts PROF_PARAM) {
   const int leg = lane & 3;
   const bool is0 = leg == 0;
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
+  if (parts & 1) {         // observations (+ history ring) and the roll of the own joints' "last_*" values
     float* obs_row = B.obs_buf + (size_t)e * cfg.num_obs;
     const int R = cfg.num_obs_history + 1;     // ring slots (one spare keeps the previous window intact)
     float* h0 = B.obs_history ? B.obs_history + (size_t)e * 2 * R * cfg.num_obs + (size_t)history_slot * cfg.num_obs : nullptr;
@@ -527,7 +529,19 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
       n += np;
     }
 
+    // ---- roll (own joints): from the values fetched above -------------------------------------------------
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
+      AT(B.last_last_actions, j, e) = o_lact[jj];
+      AT(B.last_actions, j, e) = o_act[jj];
+      AT(B.last_last_joint_pos_target, j, e) = o_ljpt[jj];
+      AT(B.last_joint_pos_target, j, e) = o_jpt[jj];
+      AT(B.last_dof_vel, j, e) = o_qd[jj];
+    }
+  }
     PROF(13);
+  if (parts & 2) {         // privileged observations (leg-0 lane)
     if (is0) {
       float* pv = B.privileged_obs_buf + (size_t)e * cfg.num_privileged_obs;
       int np = 0;
@@ -556,16 +570,7 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
       if (cfg.priv_enabled[GO1_PRIV_CLOCK_INPUTS]) for (int f = 0; f < 4; f++) privraw(AT(B.clock_inputs, f, e));
       if (cfg.priv_enabled[GO1_PRIV_DESIRED_CONTACT]) for (int f = 0; f < 4; f++) privraw(AT(B.desired_contact_states, f, e));
     }
-    // ---- roll (own joints): from the values fetched above -------------------------------------------------
-#pragma unroll
-    for (int jj = 0; jj < 3; jj++) {
-      const int j = 3 * leg + jj;
-      AT(B.last_last_actions, j, e) = o_lact[jj];
-      AT(B.last_actions, j, e) = o_act[jj];
-      AT(B.last_last_joint_pos_target, j, e) = o_ljpt[jj];
-      AT(B.last_joint_pos_target, j, e) = o_jpt[jj];
-      AT(B.last_dof_vel, j, e) = o_qd[jj];
-    }
+  }
 }
 
 // ================================================================================================
@@ -795,12 +800,13 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
 
   // ---- compute_observations (+ privileged observations, roll): post_observations() -------------------------------------------
   if (!helper_obs) {
-    post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z PROF_PASS);
+    post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, 3 PROF_PASS);
     if (helper_flag != nullptr) BLOCK_SYNC(nw);       // S2 (the helper had nothing to do)
   } else {
+    if (__ballot(reset) == 0ull) post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, 2 PROF_PASS);
     BLOCK_SYNC(nw);                                   // S2: the helper's observations are written
-    if (reset)                                        // only through the failed-simulation guard above: this environment once more, re-initialised
-      post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z PROF_PASS);
+    if (__ballot(reset) != 0ull)                      // only through the failed-simulation guard above: this environment once more, re-initialised
+      post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, reset ? 3 : 2 PROF_PASS);
   }
   PROF(14);
   PROF(15);

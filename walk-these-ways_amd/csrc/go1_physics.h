@@ -23,6 +23,8 @@
 #define EPW 16                       // environments per wavefront
 #define MAXC GO1_MAX_CONTACTS        // solver contacts per env (24; oracle: the same constant of include/go1sim.h)
 #define NRJ 12                       // joint-limit rows: joint j
+#define SELF_TYPES 6                  // capsule combinations of a pair of legs (oracle: GO1_SELF_TYPES)
+#define SELF_LEGLEG (6 * SELF_TYPES)  // leg-leg pair ids [0, 36); 36 + leg: lower leg against the trunk
 #define MAXSB 6                      // leg-leg self-contacts per env: one per pair of legs (the deepest of its four capsule combinations)
 #define MAXTR 4                      // trunk corners per env (oracle: GO1_MAX_TRUNK_POINTS)
 #define GO1_LIMIT_RECOVERY_RATE 10.0f   // rad/s: a joint found beyond a stop is brought back at a bounded rate
@@ -781,6 +783,11 @@ DEV SolveBounds solve_bounds(int K, bool legact) {
 }
 // pair index of the legs lo < hi in the order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
 DEV int leg_pair_index(int lo, int hi) { return lo == 0 ? hi - 1 : lo == 1 ? hi + 1 : 5; }
+// capsule combination `type` of a pair of legs: the segments of body A / B (0 lower leg, 1 thigh, 2 hip capsule), a segment's radius and the
+// joint its body hangs on (= the depth of the impulse propagation: lower leg 2, thigh 1, hip 0)
+DEV int self_seg_a(int type) { return type == 2 || type == 3 ? 1 : type == 4 ? 2 : 0; }
+DEV int self_seg_b(int type) { return type == 1 || type == 3 ? 1 : type == 5 ? 2 : 0; }
+DEV float self_seg_radius(int seg) { return seg == 0 ? GO1_SELF_LEG_RADIUS : seg == 1 ? GO1_SELF_THIGH_RADIUS : (float)GO1_HIP_CAPSULE_RADIUS; }
 
 // acth != nullptr: the torques of this substep are being evaluated by the helper wavefronts (torque_post_state was called, the
 // workgroup barrier behind it passed): they are picked up right before ABA pass 2.
@@ -832,8 +839,8 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
   float uu[3];
   SV cj[3];
   Cand ch[2], ct[2], ck[2], cf, cwt, cwk, cwf;      // hip, thigh, calf: one candidate per end; foot; wall candidates of thigh, calf, foot
-  V3 pthigh, pknee, pfoot;            // own thigh / lower-leg segments for the self-collision test (rel. base origin)
-  SV vthigh, vlow;                    //   and the two bodies' twists before the step
+  V3 pthigh, pknee, pfoot, phipa, phipb;      // own thigh / lower-leg segments and hip capsule for the self-collision test (rel. base origin)
+  SV vthigh, vlow, vhip;                      //   and the three bodies' twists before the step
   SV pA[3];
   Sym6 IA[3];
   {
@@ -915,71 +922,82 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
 #endif
       cand_try<WALLS, WALLS, PLANE>(cfg, hs, cf, cwf, p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2], 0);
       pthigh = p[1]; pknee = p[2]; pfoot = p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg));
-      vthigh = v[1]; vlow = v[2];
+      vthigh = v[1]; vlow = v[2]; vhip = v[0];
+      {
+        const V3 hc = model_v3(GO1_HIP_CAPSULE_CENTER, leg);
+        phipa = p[0] + mul(R[0], v3(hc.x, hc.y - (float)GO1_HIP_CAPSULE_HALF, hc.z));
+        phipb = p[0] + mul(R[0], v3(hc.x, hc.y + (float)GO1_HIP_CAPSULE_HALF, hc.z));
+      }
     }
   }
 
   PROF(25);
   // ---- self-collision, geometry (asset self_collisions = 0: enabled): capsules — lower leg (knee -> foot centre, radius of
-  // the foot sphere), thigh (thigh joint -> knee) — of DIFFERENT legs against each other and lower legs against the trunk's
-  // capsule.  Every lane publishes its two segments and the two bodies' twists, tests the pairs it is part of in the
-  // canonical order (body A on the lower-numbered leg), and the environment's pair mask is the OR over the quad.
-  // pid = 6 type + pair (type 0 lower-lower, 1 lower(A)-thigh(B), 2 thigh(A)-lower(B), 3 thigh-thigh); 24 + leg: lower leg - trunk.
-  unsigned smask = 0;              // listed pairs of the environment
+  // the foot sphere), thigh (thigh joint -> knee), hip (the URDF cylinder as a capsule, the shape the terrain sees too) — of DIFFERENT
+  // legs against each other and lower legs against the trunk's capsule.  Every lane publishes its segments and the bodies' twists, tests
+  // the pairs it is part of in the canonical order (body A on the lower-numbered leg), and the environment's pair mask is the OR over the quad.
+  // pid = 6 type + pair, type 0 lower-lower, 1 lower(A)-thigh(B), 2 thigh(A)-lower(B), 3 thigh-thigh, 4 hip(A)-lower(B), 5 lower(A)-hip(B)
+  // (round 5: the one combination with a hip capsule the joint limits let touch); 36 + leg: lower leg - trunk.
+  unsigned long long smask = 0;    // listed pairs of the environment
   int nS = 0;
   if (cfg.self_collision) {
     lf4* seg = Z.seg();
+    lf4* twx = Z.tw();             // (slot 5 of the free-twist block: not used otherwise, dedicated memory — a failed environment's non-finite
+                                   //  values must not reach slots other environments read, tests/test_emu_parity.py failed_state)
     seg[0 * WAVE + lane] = (lf4){pknee.x, pknee.y, pknee.z, pfoot.x};
     seg[1 * WAVE + lane] = (lf4){pfoot.y, pfoot.z, pthigh.x, pthigh.y};
     seg[2 * WAVE + lane] = (lf4){pthigh.z, vlow.a.x, vlow.a.y, vlow.a.z};
     seg[3 * WAVE + lane] = (lf4){vlow.l.x, vlow.l.y, vlow.l.z, vthigh.a.x};
     seg[4 * WAVE + lane] = (lf4){vthigh.a.y, vthigh.a.z, vthigh.l.x, vthigh.l.y};
-    seg[5 * WAVE + lane] = (lf4){vthigh.l.z, 0.f, 0.f, 0.f};
+    seg[5 * WAVE + lane] = (lf4){vthigh.l.z, phipa.x, phipa.y, phipa.z};      // hip capsule: its ends, and the hip joint's rate (the hip body's
+    twx[5 * WAVE + lane] = (lf4){phipb.x, phipb.y, phipb.z, L.qd[0]};           //  twist = base twist + rate x the joint's motion subspace)
     LDS_PHASE();
-    unsigned mybits = 0;
-    const V3 own_p[2] = {pknee, pthigh}, own_q[2] = {pfoot, pknee};
+    unsigned long long mybits = 0;
+    const V3 own_p[3] = {pknee, pthigh, phipa}, own_q[3] = {pfoot, pknee, phipb};
     // Broad phase 1 (round 5; the capsule tests below were 14 % of the step for pairs that almost never touch): SEPARATING AXES.  The leg's
-    // three points (thigh joint, knee, foot centre) span both of its capsules; their extents along the base's x and y axes are exchanged
-    // in the quad (DPP rotations, no LDS), and two legs whose extents are further apart along either axis than the largest radii sum +
-    // the contact distance cannot touch in any of the four capsule combinations.  Conservative (an axis test never rejects a contact), so
-    // the listed pairs — and everything downstream — are exactly those of the full test.  Walking robots: every pair is rejected here.
-    const float sep = 2.f * GO1_SELF_LEG_RADIUS + cd + 1e-4f;            // (lower-leg radius >= thigh radius)
+    // five points (hip capsule ends, thigh joint, knee, foot centre) span all of its capsules; their extents along the base's x and y axes
+    // are exchanged in the quad (DPP rotations, no LDS), and two legs whose extents are further apart along either axis than the largest
+    // radii sum + the contact distance cannot touch in any of the six capsule combinations.  Conservative (an axis test never rejects a
+    // contact), so the listed pairs — and everything downstream — are exactly those of the full test.  Walking robots: every pair is
+    // rejected here.
+    const float sep = (float)GO1_HIP_CAPSULE_RADIUS + GO1_SELF_LEG_RADIUS + cd + 1e-4f;      // (hip - lower leg: the largest radii sum of a listed combination)
     float ex0, ex1, ey0, ey1;
     {
-      const float tx = dot(pthigh, R0.c0), kx = dot(pknee, R0.c0), fx = dot(pfoot, R0.c0);
-      const float ty = dot(pthigh, R0.c1), ky = dot(pknee, R0.c1), fy = dot(pfoot, R0.c1);
-      ex0 = fminf(tx, fminf(kx, fx)); ex1 = fmaxf(tx, fmaxf(kx, fx));
-      ey0 = fminf(ty, fminf(ky, fy)); ey1 = fmaxf(ty, fmaxf(ky, fy));
+      const float tx = dot(pthigh, R0.c0), kx = dot(pknee, R0.c0), fx = dot(pfoot, R0.c0), ax = dot(phipa, R0.c0), bx = dot(phipb, R0.c0);
+      const float ty = dot(pthigh, R0.c1), ky = dot(pknee, R0.c1), fy = dot(pfoot, R0.c1), ay = dot(phipa, R0.c1), by = dot(phipb, R0.c1);
+      ex0 = fminf(fminf(tx, fminf(kx, fx)), fminf(ax, bx)); ex1 = fmaxf(fmaxf(tx, fmaxf(kx, fx)), fmaxf(ax, bx));
+      ey0 = fminf(fminf(ty, fminf(ky, fy)), fminf(ay, by)); ey1 = fmaxf(fmaxf(ty, fmaxf(ky, fy)), fmaxf(ay, by));
     }
     // broad phase 2: the two segments' midpoints further apart than both half lengths + radii + contact distance
-    const float reach = 2.f * 0.1065f + 2.f * GO1_SELF_LEG_RADIUS + cd + 0.01f;
+    const float reach = 2.f * 0.1065f + (float)GO1_HIP_CAPSULE_RADIUS + GO1_SELF_LEG_RADIUS + cd + 0.01f;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       const int j = (leg + 1 + i) & 3, lj = (lane & ~3) | j;
       const float px0 = quad_rot(ex0, i + 1), px1 = quad_rot(ex1, i + 1), py0 = quad_rot(ey0, i + 1), py1 = quad_rot(ey1, i + 1);
       const bool apart = ex0 - px1 > sep || px0 - ex1 > sep || ey0 - py1 > sep || py0 - ey1 > sep;
       if (__ballot(!apart) == 0ull) continue;
-      const lf4 a0 = seg[0 * WAVE + lj], a1 = seg[1 * WAVE + lj], a2 = seg[2 * WAVE + lj];
-      const V3 par_p[2] = {v3(a0[0], a0[1], a0[2]), v3(a1[2], a1[3], a2[0])}, par_q[2] = {v3(a0[3], a1[0], a1[1]), v3(a0[0], a0[1], a0[2])};
+      const lf4 a0 = seg[0 * WAVE + lj], a1 = seg[1 * WAVE + lj], a2 = seg[2 * WAVE + lj], h0 = seg[5 * WAVE + lj], h1 = twx[5 * WAVE + lj];
+      const V3 par_p[3] = {v3(a0[0], a0[1], a0[2]), v3(a1[2], a1[3], a2[0]), v3(h0[1], h0[2], h0[3])};
+      const V3 par_q[3] = {v3(a0[3], a1[0], a1[1]), v3(a0[0], a0[1], a0[2]), v3(h1[0], h1[1], h1[2])};
       const bool lower = leg < j;
       const int pair = lower ? leg_pair_index(leg, j) : leg_pair_index(j, leg);
-      float best_phi = 1e30f;                 // two legs touch in ONE point: the deepest of the four capsule combinations (ties: lower type)
+      float best_phi = 1e30f;                 // two legs touch in ONE point: the deepest of the six capsule combinations (ties: lower type)
       int best_type = -1;
 #pragma unroll
-      for (int type = 0; type < 4; type++) {
-        const int sa = (type >> 1) & 1, sbq = type & 1;                      // segment of body A / B: 0 lower leg, 1 thigh
+      for (int type = 0; type < SELF_TYPES; type++) {
+        const int sa = self_seg_a(type), sbq = self_seg_b(type);             // segment of body A / B: 0 lower leg, 1 thigh, 2 hip capsule
         const int so = lower ? sa : sbq, sp = lower ? sbq : sa;               // own / partner segment
         const V3 mo = 0.5f * (own_p[so] + own_q[so]), mp = 0.5f * (par_p[sp] + par_q[sp]), dm = mo - mp;
         const bool near = !apart && dot(dm, dm) < reach * reach;
         if (__ballot(near) != 0ull) {
           Cand c;
-          const float ra = sa ? GO1_SELF_THIGH_RADIUS : GO1_SELF_LEG_RADIUS, rb = sbq ? GO1_SELF_THIGH_RADIUS : GO1_SELF_LEG_RADIUS;
+          const float ra = self_seg_radius(sa), rb = self_seg_radius(sbq);
           const bool hit = near && (lower ? capsule_contact(own_p[so], own_q[so], ra, par_p[sp], par_q[sp], rb, cd, c)
                                           : capsule_contact(par_p[sp], par_q[sp], ra, own_p[so], own_q[so], rb, cd, c));
           if (hit && c.phi < best_phi) { best_phi = c.phi; best_type = type; }
         }
       }
-      if (best_type >= 0) mybits |= 1u << (6 * best_type + pair);
+      if (best_type >= 0) mybits |= 1ull << (6 * best_type + pair);
     }
     {
       // lower leg against the trunk's capsule (axis = the base's x axis through the origin): apart along the base's y or z axis?
@@ -990,11 +1008,11 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       if (__ballot(!apart) != 0ull) {
         Cand c;
         if (!apart && capsule_contact(pknee, pfoot, GO1_SELF_LEG_RADIUS, mul(R0, v3(-ta, 0.f, 0.f)), mul(R0, v3(ta, 0.f, 0.f)), (float)GO1_TRUNK_BOX_HALF[1], cd, c))
-          mybits |= 1u << (24 + leg);
+          mybits |= 1ull << (SELF_LEGLEG + leg);
       }
     }
-    smask = quad_or(mybits);
-    nS = __popc(smask);
+    smask = quad_or64(mybits);
+    nS = __builtin_popcountll(smask);
   }
 
   PROF(26);
@@ -1077,10 +1095,13 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       if (slot[IT_THIGHW] >= 0) sig1 |= 1u << (9 + leg);
       if (slot[IT_HIP1] >= 0) sig1 |= 1u << (13 + 2 * leg + fh);
       if (slot[IT_HIP2] >= 0) sig1 |= 1u << (13 + 2 * leg + 1 - fh);
-      unsigned sself = 0, pos = nF;          // self pairs that found a slot
+      unsigned sself = 0, pos = nF;          // self pairs that found a slot: 3 bits per pair of legs (1 + type), trunk pairs at 18 + leg
 #pragma unroll 1
-      for (int pid = 0; pid < 28; pid++)
-        if (smask & (1u << pid)) { if ((int)pos < MAXC) sself |= 1u << pid; pos++; }
+      for (int pid = 0; pid < SELF_LEGLEG + 4; pid++)
+        if (smask & (1ull << pid)) {
+          if ((int)pos < MAXC) sself |= pid < SELF_LEGLEG ? (unsigned)(pid / 6 + 1) << (3 * (pid % 6)) : 1u << (18 + pid - SELF_LEGLEG);
+          pos++;
+        }
       sig0 = quad_or(sig0); sig1 = quad_or(sig1);
       // geometry hash: the cell and candidate point of every listed terrain contact, weighted by its item index
       uint32_t gh = 0;
@@ -1215,7 +1236,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
   // wavefronts (nw > 1) while this one emits the self-contacts and the limit rows --------------------------------------------
   legfac_store(Z.pkl(), lane, F);
   if (leg == 0) { envpk_store(Z.pke(), el, E); LDS(L_KL + 1) = (float)lact; }
-  if (cfg.self_collision && __ballot(smask != 0u) != 0ull) {          // free twists of the own lower leg / thigh for the partners
+  if (cfg.self_collision && __ballot(smask != 0ull) != 0ull) {        // free twists of the own lower leg / thigh / hip for the partners
     SV fl = sv(w_free, v_free), ft_;
 #pragma unroll
     for (int j = 0; j < 3; j++) { fl = fl + F.qdf[j] * F.S[j]; if (j == 1) ft_ = fl; }
@@ -1223,6 +1244,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     tw[0 * WAVE + lane] = (lf4){fl.a.x, fl.a.y, fl.a.z, fl.l.x};
     tw[1 * WAVE + lane] = (lf4){fl.l.y, fl.l.z, ft_.a.x, ft_.a.y};
     tw[2 * WAVE + lane] = (lf4){ft_.a.z, ft_.l.x, ft_.l.y, ft_.l.z};
+    tw[3 * WAVE + lane] = (lf4){F.qdf[0], 0.f, 0.f, 0.f};                       // (hip body: free rate of the hip joint; see the geometry block)
   }
   BLOCK_SYNC(nw);
   PROF(4);
@@ -1230,22 +1252,22 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
   // lane of body A (the lower-numbered leg; the leg of a trunk pair) owns the record; for a leg-leg pair the lane of body B
   // hands its side over through the pair's SB slots.
   int sslot[MAXSB + 1];            // slots of the (at most MAXSB + 1) listed pairs this lane is body A or B of ...
-  int sdepth[MAXSB + 1];           // ... own body's depth (1 thigh, 2 lower leg) ...
+  int sdepth[MAXSB + 1];           // ... own body's depth (0 hip, 1 thigh, 2 lower leg) ...
   float ssign[MAXSB + 1];          // ... and the sign of the impulse it receives (+1 body A, -1 body B)
   int nown = 0;
 #pragma unroll
   for (int i = 0; i <= MAXSB; i++) { sslot[i] = -1; sdepth[i] = 2; ssign[i] = 0.f; }
-  if (cfg.self_collision && __ballot(smask != 0u) != 0ull) {
+  if (cfg.self_collision && __ballot(smask != 0ull) != 0ull) {
     const lf4* seg = Z.seg();
     const lf4* tw = Z.tw();
     int rank = 0, sbi = 0;         // rank among the listed pairs / among the listed leg-leg pairs (wave-uniform loop, per-lane counters)
 #pragma unroll 1
-    for (int pid = 0; pid < 28; pid++) {
-      const bool on = (smask & (1u << pid)) != 0u;
+    for (int pid = 0; pid < SELF_LEGLEG + 4; pid++) {
+      const bool on = (smask & (1ull << pid)) != 0ull;
       if (__ballot(on) == 0ull) continue;
-      const int type = pid < 24 ? pid / 6 : 0, pr = pid % 6;
-      const int lo_ = pid < 24 ? (pr < 3 ? 0 : pr < 5 ? 1 : 2) : pid - 24, hi_ = pid < 24 ? (pr < 3 ? pr + 1 : pr < 5 ? pr - 1 : 3) : -1;
-      const int sa = (type >> 1) & 1, sbq = type & 1;
+      const int type = pid < SELF_LEGLEG ? pid / 6 : 0, pr = pid % 6;
+      const int lo_ = pid < SELF_LEGLEG ? (pr < 3 ? 0 : pr < 5 ? 1 : 2) : pid - SELF_LEGLEG, hi_ = pid < SELF_LEGLEG ? (pr < 3 ? pr + 1 : pr < 5 ? pr - 1 : 3) : -1;
+      const int sa = self_seg_a(type), sbq = self_seg_b(type);
       const int k = nF + rank;
       const bool isA = on && leg == lo_ && k < MAXC, isB = on && leg == hi_ && k < MAXC;
       Cand c;
@@ -1256,22 +1278,23 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       int depth = 2;
       const int lj = (lane & ~3) | (isA ? (hi_ < 0 ? leg : hi_) : (lo_ & 3));       // partner lane (trunk pair: unused)
       if (isA || isB) {
-        const lf4 a0 = seg[0 * WAVE + lj], a1 = seg[1 * WAVE + lj], a2 = seg[2 * WAVE + lj];
-        const V3 par_p[2] = {v3(a0[0], a0[1], a0[2]), v3(a1[2], a1[3], a2[0])}, par_q[2] = {v3(a0[3], a1[0], a1[1]), v3(a0[0], a0[1], a0[2])};
-        const V3 own_p[2] = {pknee, pthigh}, own_q[2] = {pfoot, pknee};
+        const lf4 a0 = seg[0 * WAVE + lj], a1 = seg[1 * WAVE + lj], a2 = seg[2 * WAVE + lj], h0 = seg[5 * WAVE + lj], h1 = tw[5 * WAVE + lj];
+        const V3 par_p[3] = {v3(a0[0], a0[1], a0[2]), v3(a1[2], a1[3], a2[0]), v3(h0[1], h0[2], h0[3])};
+        const V3 par_q[3] = {v3(a0[3], a1[0], a1[1]), v3(a0[0], a0[1], a0[2]), v3(h1[0], h1[1], h1[2])};
+        const V3 own_p[3] = {pknee, pthigh, phipa}, own_q[3] = {pfoot, pknee, phipb};
         const int so = isA ? sa : sbq, sp = isA ? sbq : sa;
-        const float ra = sa ? GO1_SELF_THIGH_RADIUS : GO1_SELF_LEG_RADIUS;
+        const float ra = self_seg_radius(sa);
         if (hi_ < 0) {
           const float ta = (float)(GO1_TRUNK_BOX_HALF[0] - GO1_TRUNK_BOX_HALF[1]);
           capsule_contact(pknee, pfoot, ra, mul(R0, v3(-ta, 0.f, 0.f)), mul(R0, v3(ta, 0.f, 0.f)), (float)GO1_TRUNK_BOX_HALF[1], cd, c);
         } else {
-          const float rb = sbq ? GO1_SELF_THIGH_RADIUS : GO1_SELF_LEG_RADIUS;
+          const float rb = self_seg_radius(sbq);
           if (isA) capsule_contact(own_p[so], own_q[so], ra, par_p[sp], par_q[sp], rb, cd, c);
           else capsule_contact(par_p[sp], par_q[sp], ra, own_p[so], own_q[so], rb, cd, c);
         }
         n = v3(c.nx, c.ny, c.nz); x = v3(c.x, c.y, c.z);
         contact_frame(n, t1, t2, fault);
-        depth = so ? 1 : 2;
+        depth = 2 - so;
         if (nown <= MAXSB) {
 #pragma unroll
           for (int i = 0; i <= MAXSB; i++) if (i == nown) { sslot[i] = k; sdepth[i] = depth; ssign[i] = isA ? 1.f : -1.f; }
@@ -1302,9 +1325,15 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         const lf4 f0 = tw[0 * WAVE + lj], f1 = tw[1 * WAVE + lj], f2 = tw[2 * WAVE + lj];
         SV preB, freeB;
         if (hi_ < 0) { preB = v0; freeB = sv(w_free, v_free); }
-        else if (sbq) { preB = sv(v3(s3[3], s4[0], s4[1]), v3(s4[2], s4[3], s5[0])); freeB = sv(v3(f1[2], f1[3], f2[0]), v3(f2[1], f2[2], f2[3])); }
+        else if (sbq == 2) {         // partner's hip body: base twist + hip rate x the hip joint's motion subspace (axis = the base's x axis)
+          const V3 p0 = mul(R0, model_v3(GO1_JOINT_ORIGIN, 3 * (lj & 3)));
+          const SV S0 = sv(R0.c0, cross(p0, R0.c0));
+          preB = v0 + tw[5 * WAVE + lj][3] * S0;
+          freeB = sv(w_free, v_free) + tw[3 * WAVE + lj][0] * S0;
+        }
+        else if (sbq == 1) { preB = sv(v3(s3[3], s4[0], s4[1]), v3(s4[2], s4[3], s5[0])); freeB = sv(v3(f1[2], f1[3], f2[0]), v3(f2[1], f2[2], f2[3])); }
         else { preB = sv(v3(s2[1], s2[2], s2[3]), v3(s3[0], s3[1], s3[2])); freeB = sv(v3(f0[0], f0[1], f0[2]), v3(f0[3], f1[0], f1[1])); }
-        const SV preA = sa ? vthigh : vlow;
+        const SV preA = sa == 2 ? vhip : sa == 1 ? vthigh : vlow;
         SV freeA = sv(w_free, v_free);
 #pragma unroll
         for (int j = 0; j < 3; j++) if (j <= depth) freeA = freeA + F.qdf[j] * F.S[j];
@@ -1332,7 +1361,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
                              row_dot(a[0], a[0]) + wB[0], row_dot(a[1], a[1]) + wB[1], row_dot(a[2], a[2]) + wB[2],
                              row_dot(a[1], a[0]) + wB[3], row_dot(a[2], a[0]) + wB[4], v3(0.f, 0.f, 0.f), x, n, bounce, fault);
       }
-      if (on) { rank++; if (pid < 24) sbi++; }
+      if (on) { rank++; if (pid < SELF_LEGLEG) sbi++; }
     }
   }
   if (legact) {
@@ -1686,8 +1715,9 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         V3 x;
         const V3 f = ssign[i] * take(sslot[i], x);              // body B receives the opposite impulse
         const SV ff = sv(cross(x, f), f);
-        if (sdepth[i] == 1) { pAq[1] = pAq[1] - ff; fbody[1] = fbody[1] + f; }        // booked on the thigh / the calf (penalised bodies:
-        else { pAq[2] = pAq[2] - ff; fbody[2] = fbody[2] + f; }                        //  the collision reward sees it, corl_rewards.py:49-52)
+        if (sdepth[i] == 0) { pAq[0] = pAq[0] - ff; fbody[0] = fbody[0] + f; }        // booked on the hip / the thigh / the calf (penalised
+        else if (sdepth[i] == 1) { pAq[1] = pAq[1] - ff; fbody[1] = fbody[1] + f; }   //  bodies: the collision reward sees it,
+        else { pAq[2] = pAq[2] - ff; fbody[2] = fbody[2] + f; }                        //  corl_rewards.py:49-52)
         const bool trunk_pair = (((int)CRQ(sslot[i], 8)[3]) & 0x78) == 8;              // self, no B record: the trunk is body B
         if (trunk_pair) { contrib = contrib + ff; ftrunk = ftrunk - f; }
       }
@@ -1698,6 +1728,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     const int b = 1 + 4 * leg + i;
     LDS(L_LAM + 3 * b) = fbody[i].x; LDS(L_LAM + 3 * b + 1) = fbody[i].y; LDS(L_LAM + 3 * b + 2) = fbody[i].z;      // listed: impulse, else 0
   }
+  PROF(27);
   float du[3];
 #pragma unroll
   for (int j = 2; j >= 0; j--) {
@@ -1716,6 +1747,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     if (wn2 > cfg.max_angular_velocity * cfg.max_angular_velocity) s.w = (cfg.max_angular_velocity * rsqrtf(wn2)) * s.w;
     if (vn2 > cfg.max_linear_velocity * cfg.max_linear_velocity) s.v = (cfg.max_linear_velocity * rsqrtf(vn2)) * s.v;
   }
+  PROF(28);
   {
     SV a = dv0;
 #pragma unroll
@@ -1736,6 +1768,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       L.qd[j] = qd;
     }
   }
+  PROF(29);
   // base pose
   s.pos = s.pos + h * s.v;
   float wn = norm(s.w);

@@ -151,7 +151,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
         const V3 pg = v3(AT(B.projected_gravity, 0, e), AT(B.projected_gravity, 1, e), AT(B.projected_gravity, 2, e));
         const float clock_own = AT(B.clock_inputs, leg_, e), force_z = AT(B.contact_forces, 3 * (4 + 4 * leg_) + 2, e);
         uint32_t fault_h = 0;
-        post_observations(cfg, B, lds, lane, e, N, A.counter + 1, gravity_at(cfg, A.counter), A.history_slot, fault_h, pg, clock_own, force_z PROF_PASS);
+        post_observations(cfg, B, lds, lane, e, N, A.counter + 1, gravity_at(cfg, A.counter), A.history_slot, fault_h, pg, clock_own, force_z, 1 PROF_PASS);
         report_fault(B, e, fault_h);
       }
       BLOCK_SYNC(nw);          // S2
@@ -217,7 +217,10 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   const int nl = cfg.lag_timesteps + 1;
   int head = A.lag_head;
   PROF(0);
-#pragma unroll 1
+#ifndef GO1_SUBSTEP_UNROLL
+#define GO1_SUBSTEP_UNROLL 1          // (probe: tools/build_variants.sh unroll2 "-DGO1_SUBSTEP_UNROLL=2")
+#endif
+#pragma unroll GO1_SUBSTEP_UNROLL
   for (int sub = 0; sub < nsub; sub++) {
     PROF(24);
 #ifndef GO1_ABLATE_TORQUE
@@ -248,7 +251,9 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
 #endif
   report_fault(B, e, fault);
   report_drops(B, drops);
+#define PROF_LAUNCH ((unsigned)A.counter)
   PROF_FLUSH;
+#undef PROF_LAUNCH
 }
 #define STEP_LDS \
   __shared__ float lds[L_END * EPW]; \
@@ -610,5 +615,20 @@ extern "C" int go1sim_debug_read_profile(unsigned long long* out64) {
   unsigned long long z[64] = {0};
   if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(z)) != hipSuccess) return -1;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+// the phase accumulators of every workgroup, [1024][32] (read and clear)
+extern "C" int go1sim_debug_read_wg_phases(unsigned long long* out) {
+  static unsigned long long z[1024 * 32];
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_profw), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_profw), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+// per-workgroup totals of the master wavefront [0, 1024), per-launch maxima [1024, 1088) and sums [1088, 1152) (read and clear)
+extern "C" int go1sim_debug_read_wg_times(unsigned long long* out1152) {
+  static unsigned long long z[1024];
+  if (hipMemcpyFromSymbol(out1152, HIP_SYMBOL(g_wgt), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out1152 + 1024, HIP_SYMBOL(g_lmax), 64 * 8) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out1152 + 1088, HIP_SYMBOL(g_lsum), 64 * 8) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_lmax), z, 64 * 8) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_lsum), z, 64 * 8) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_wgt), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
