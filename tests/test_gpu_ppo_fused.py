@@ -877,7 +877,12 @@ def test_fused_graph_replay_equals_eager_at_production_size():
     for u in range(3):
         ee = float((a[u][0] - a2[u][0]).abs().max())
         ge = float((a[u][0] - b[u][0]).abs().max())
-        assert ge <= 3.0 * ee + 1e-3, (u, ge, ee)      # (both are maxima over 3 M Adam-amplified last-bit differences: 1-3e-3 each)
+        # Both are maxima over 3 M Adam-amplified last-bit differences.  Round 4 (fp32 atomics in the weight-gradient kernels): 1-3e-3 each, so
+        # "3 x eager-vs-eager + 1e-3" held.  Since the slabs replaced the atomics two EAGER runs are bit-reproducible (ee ~ 1e-8) while the
+        # replay still takes its GEMMs through another hipBLASLt dispatch (pre-gathered operands): 1.3e-3 after three updates on one box of the
+        # pool (gpurun call r5j), which the old floor of 1e-3 flagged.  An element whose gradient sits at a rounding boundary moves by one
+        # learning rate per optimiser step the two runs round it differently: the floor is 4 learning rates (lr <= 1e-3 here).
+        assert ge <= 3.0 * ee + 4e-3, (u, ge, ee)
         # (losses: the surrogate is a difference of O(1) terms around -0.04 — two EAGER runs differ by ~4e-5 there, the atomics' order)
         spread = np.abs(np.asarray(a[u][1][:3]) - np.asarray(a2[u][1][:3]))
         np.testing.assert_allclose(b[u][1][:3], a[u][1][:3], rtol=1e-3, atol=float(3.0 * spread.max() + 1e-4))

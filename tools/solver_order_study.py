@@ -1,17 +1,21 @@
-"""Would a lane-per-leg kernel that solves the four legs' terrain contacts SIDE BY SIDE (Gauss-Seidel inside a leg, the legs' velocity changes
-added up: block Jacobi over legs) still converge like the contract's sweep over the contact list?  The sweeps are 32 % of the step kernel's serial
-spine and their length is the contact COUNT of the slowest environment of a wavefront; side by side it would be the largest count of one LEG.
-CPU study on the fp64 oracle (`go1_oracle_set_solver_order`: 1 = legs side by side, the contract since round 5; 0 = list order, rounds 1-4): at states taken from rollouts, one
-physics substep is solved with 64 list-order sweeps (the converged reference of the same contact model) and with 2 / 4 / 8 sweeps in both orders;
-reported is the distance of the resulting generalised velocity from the converged one, in units of the parity suite's tolerances
-(base 2e-3 m/s, 1e-2 rad/s; joints 2e-2 rad/s).
+"""In which ORDER may the contacts of a substep be swept?  The sweeps are the largest single piece of the step kernel's serial spine and their length
+is the contact count of the slowest environment of a wavefront; with the four legs' contacts solved SIDE BY SIDE (Gauss-Seidel inside a leg,
+block Jacobi over legs) it is the cooperative (trunk, body-body) count + the largest count on one leg.  CPU study on the fp64 oracle
+(`go1_oracle_set_solver_order`):
+    0  every contact in list order (the contract of rounds 1-4)
+    1  all terrain contacts of a leg side by side (round 4's study build)
+    2  only the lower-leg contacts (foot, calf) side by side, hip / thigh in list order
+    3  THE CONTRACT since round 5: all of a leg's contacts side by side, hip and thigh rows with MASS SPLITTING (the base answers such a row
+       n times as strongly in the leg phase, n = legs holding such rows; the true response enters when the legs meet)
+    4  every row split
+Regimes: (i) limp robots at rest on hips / thighs / trunk after a fall — what separates the orders: plain block Jacobi over hip / thigh rows
+(1) does not settle, more sweeps do not cure it; (ii) states from rollouts under N(0, 0.1) / N(0, 0.5) / N(0, 1) actions: one substep solved
+with 64 list-order sweeps (the converged reference) and with 2 / 4 / 8 sweeps in every order, distance of the generalised velocity from the
+converged one in units of the parity suite's tolerances (base 2e-3 m/s, 1e-2 rad/s; joints 2e-2 rad/s); (iii) closed loop.
+Hardware cost of the orders (tools/probes/step_variant_ab.py, gpurun calls r5a-r5f): 2 is no faster than 0 (every wavefront holds a fallen
+robot whose cooperative turns the other fifteen environments wait for), 1 and 3 are 8-14 % faster per env.step.
 
     python tools/solver_order_study.py > profiles/r05_solver_order_study.txt       (round 4's record: profiles/r04_solver_order_study.txt)
-
-Round 5 added the third order — only the contacts of the LOWER LEG (foot sphere, calf capsule) side by side, hip and thigh contacts with the
-trunk's in list order — and the regime that separates the three: robots lying at rest on hips / thighs / trunk.  A hip or thigh contact couples
-to the base through one or two joints only; block Jacobi over such contacts over-corrects the base (every leg stops the WHOLE base) and leaves
-a creep that more sweeps do not remove.  Order 2 is the contract (oracle/go1_oracle.c g_solver_legs_parallel = 2, csrc/go1_physics.h).
 """
 import os
 import sys
@@ -135,7 +139,7 @@ def fallen_at_rest(order, sweeps, seed=3, n=64):
 
 
 def main():
-    print(__doc__.split("\n\n")[0])
+    print(__doc__.rsplit("\n\n", 1)[0])
     print("\nLimp robots dropped in random orientations and joint angles, 64 environments, 3 s of settling, then 40 substeps: base creep at rest")
     print("  order                              sweeps   bodies in contact   |v| median / 90 % / max [m/s]      |omega| median / 90 % / max [rad/s]")
     for order in (0, 1, 2, 3, 4):
