@@ -23,7 +23,8 @@ PHASES = ["rest of the prologue (stash commit, input checks)", "torque model: ba
           "self-contacts + limit rows + barrier wait for the helpers' rows (x4)",
           "torque model: post q, qd for the helpers' rows (x4)", "PGS: warm-start state (x4)",
           "loop edge after the pose update (x4)", "kinematics + terrain candidates (x4; 19 = the contact list alone)", "self-collision geometry (x4)",
-          "apply: impulses of the listed contacts from LDS (x4; 6 = the rest)", "apply: back-substitution + base twist (x4)", "integrate the joints (x4)"]
+          "apply: impulses of the listed contacts from LDS (x4; 6 = the rest)", "apply: back-substitution + base twist (x4)", "integrate the joints (x4)",
+          "what the compiler sank behind the substep's last marker (x4; 24 = the loop's back edge alone)"]
 
 
 def build(flags):

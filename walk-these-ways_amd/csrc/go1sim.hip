@@ -233,6 +233,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
 #ifndef GO1_ABLATE_PHYSICS
     physics_substep<WALLS, SIG, PLANE>(cfg, B, Z, lane, nw, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault, drops, deferred ? acth : nullptr, e, N, sub PROF_PASS);
 #endif
+    PROF(30);
   }
   if (deferred) torque_stash_store(cfg, B, L, acth, lane, leg, e, N);
   store_state(B, leg, e, N, s, L);

@@ -261,10 +261,16 @@ class FusedNet:
         # (the first-layer forward stays on hipBLASLt: 96 us = 1.39 PFLOP/s in situ.  A 256-tile LDS-DMA GEMM of this repository with the ELU in
         #  its epilogue measured 135-140 us — bound by the L2 -> LDS staging rate of ~10.5 TB/s chip-wide, tools/probes/gemm256_probe.hip,
         #  DESIGN.md section 7 — and was withdrawn)
-        self._l1_nt = os.environ.get("GO1_L1_NT", "1") == "1"
+        # go1ppo_gemm_nt wants 64-column tiles and 16-byte aligned rows / biases, the paired launch equal tile grids for its two problems:
+        # other widths (an actor / critic first hidden width that is not a multiple of 64, or that differ) take torch.addmm / two launches
+        na1, nc1 = int(self.P["actor.1.W"].shape[0]), int(self.P["critic.1.W"].shape[0])
+        nt_ok = all(v % 64 == 0 for v in (na1, nc1, self.na, self.n1 - self.nd - self.na)) and \
+            all(self.P[k].data_ptr() % 16 == 0 for k in ("actor.1.b", "critic.1.b", "actor.1.W", "critic.1.W"))
+        pair_ok = nt_ok and na1 == nc1 and self.na == self.n1 - self.nd - self.na
+        self._l1_nt = os.environ.get("GO1_L1_NT", "1") == "1" and nt_ok
         # the actor's and the critic's 512 -> 256 GEMMs (forward, input gradient) as one launch each instead of two launches on two
         # streams: tools/timeline.py showed 5-10 us of idle device at every graph fork and join (GO1_GEMM_PAIR=0: the two streams)
-        self._pair = os.environ.get("GO1_GEMM_PAIR", "1") == "1"
+        self._pair = os.environ.get("GO1_GEMM_PAIR", "1") == "1" and pair_ok
         # the critic's tail is independent of the actor / adaptation chain: it runs on a side stream (forked from and
         # joined back into the caller's stream, so HIP-graph capture records it as a parallel branch)
         self._side = torch.cuda.Stream(device=dev) if two_streams else None
@@ -287,7 +293,7 @@ class FusedNet:
             # GO1_DGRAD_NT: the 512 -> 256 input gradients on go1ppo_gemm_nt with the ELU' epilogue instead of hipBLASLt + the
             # element-wise pass.  In situ A/B on one box: 23.30 vs 23.43 ms per iteration (it was 0.6 ms SLOWER while the
             # epilogue still loaded its ELU' operand where it used it: 19 exposed HBM round trips per workgroup)
-            self._dgrad_nt = os.environ.get("GO1_DGRAD_NT", "1") == "1" and self._mlp2
+            self._dgrad_nt = os.environ.get("GO1_DGRAD_NT", "1") == "1" and self._mlp2 and nt_ok
             self._WT = {n: torch.zeros(self.P[f"{n}.1.W"].shape[1], self.P[f"{n}.1.W"].shape[0], **bf) for n in ("actor", "critic")} \
                 if self._dgrad_nt else None
             # the K-contiguous copies are refreshed per backward pass (two transpose-copy launches) until an optimiser takes them

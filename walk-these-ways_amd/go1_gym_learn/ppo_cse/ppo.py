@@ -89,18 +89,25 @@ def _enable_tuned_gemms():
         print(f"[ppo] TunableOp not enabled ({type(err).__name__}: {err})", file=sys.stderr)
 
 
+_AUTOCAST_DEFAULT = bool(PPO_Args.autocast_bf16)          # the class default, before any caller touched it
+
+
 def policy_dtype_is_bf16():
     """bf16 policy (fp32 master + bf16 compute copy, the fused update) or the fp32 autograd path?  `PPO_Args.autocast_bf16` decides,
     unless the environment variable GO1_POLICY_DTYPE (= bf16 | fp32) is set: the switch for the UNCHANGED reference scripts
     (scripts/train.py constructs Runner with the default PPO_Args, train.py:207-216) — `GO1_POLICY_DTYPE=bf16 python scripts/train.py`
     selects BASELINE configs[1]'s bf16 policy without editing the script."""
     v = os.environ.get("GO1_POLICY_DTYPE", "").strip().lower()
-    if v in ("bf16", "bfloat16"):
-        return True
-    if v in ("fp32", "f32", "float32"):
-        return False
-    if v:
+    if v and v not in ("bf16", "bfloat16", "fp32", "f32", "float32"):
         raise ValueError(f"GO1_POLICY_DTYPE={v!r}: expected bf16 or fp32")
+    if v:
+        want = v in ("bf16", "bfloat16")
+        # the variable speaks for scripts that leave PPO_Args at its class default; a caller that SET autocast_bf16 (bench.py --fp32, a test)
+        # and meets a contradicting variable gets an error instead of a silently different dtype
+        explicit = bool(PPO_Args.autocast_bf16) != _AUTOCAST_DEFAULT
+        if explicit and bool(PPO_Args.autocast_bf16) != want:
+            raise ValueError(f"GO1_POLICY_DTYPE={v} contradicts PPO_Args.autocast_bf16={PPO_Args.autocast_bf16}")
+        return want
     return bool(PPO_Args.autocast_bf16)
 
 
@@ -612,8 +619,11 @@ class PPO:
                 self._collectives_capturable = True
                 return [g]
             except Exception as err:
+                # every rank takes the SAME scheme: the outcome is agreed on below.  The full error is logged once per rank — a failed plan-table
+                # copy or an out-of-memory during capture ends up here too and must not hide behind "not capturable"
                 if self._collectives_capturable is None:
-                    print(f"[ppo] collectives not capturable ({type(err).__name__}: {str(err)[:120]}); eager collectives between graphs", file=sys.stderr)
+                    print(f"[ppo] rank {dist.get_rank()}: one-graph capture of stages + collectives failed ({type(err).__name__}: {err}); "
+                          f"eager collectives between graphs", file=sys.stderr)
                 self._collectives_capturable = False
                 torch.cuda.synchronize()
                 self.master.grad.zero_()
