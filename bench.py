@@ -372,6 +372,9 @@ def main():
     from go1_gym_learn.ppo_cse import Runner, RunnerArgs
     from go1_gym_learn.ppo_cse.ppo import PPO_Args
     PPO_Args.autocast_bf16 = not args.fp32
+    env_dtype = os.environ.get("GO1_POLICY_DTYPE", "").strip().lower()
+    if env_dtype and (env_dtype in ("bf16", "bfloat16")) == bool(args.fp32):      # the variable would override what this line is labelled with
+        raise SystemExit(f"GO1_POLICY_DTYPE={env_dtype} contradicts {'--fp32' if args.fp32 else 'the bf16 default'}: unset it")
     PPO_Args.dp_grad_dtype, PPO_Args.dp_zero1 = args.grad_dtype, bool(args.zero1)
     RunnerArgs.save_video_interval = 0
     torch.manual_seed(args.seed + rank)
