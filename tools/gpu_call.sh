@@ -8,6 +8,7 @@ for step in "$@"; do
 case $step in
   parity) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt run parity python -m pytest tests/test_gpu_parity.py tests/test_gpu_env.py -q -s -k "product_instances or train_eval_split or deferred_torque" ;;
   altseed) GO1_PARITY_ALT=1 GO1_PARITY_LOG=$PWD/$OUT/parity_rates_alt_seed.txt run altseed python -m pytest tests/test_gpu_parity.py -q -s -k "product_instances" ;;
+  pmc) GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD} run pmc bash tools/pmc.sh $TAG ;;
   quick) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt run quick python -m pytest tests/test_gpu_parity.py tests/test_gpu_env.py tests/test_gpu_ppo_reference.py -q -k "product_instances or failed or full_step_matches or ragged or deferred_torque or gpu_fp32_update or history" ;;
   fusedtests) run fusedtests python -m pytest tests/test_gpu_ppo_fused.py -q -x ;;
   gemm) run gemm python tools/bench_gemm.py ;;
