@@ -460,7 +460,7 @@ def main():
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         valu_insts = None
         traffic, traffic_src = None, None   # HBM bytes per launch: NOT measured by this run — read from the committed PMC passes
-        for name in ("r04_step_kernel_pmc.json", "r03_step_kernel_pmc.json", "r02_step_kernel_pmc.json", "r01_step_kernel_pmc.json"):
+        for name in ("r05_step_kernel_pmc.json", "r04_step_kernel_pmc.json", "r03_step_kernel_pmc.json", "r02_step_kernel_pmc.json", "r01_step_kernel_pmc.json"):
             try:
                 with open(os.path.join(REPO, "profiles", name)) as f:
                     pmc = json.load(f)
