@@ -53,7 +53,9 @@ enum Go1ContactClass {
   GO1_CC_WALL = 7,        /* trunk / calf / thigh against a vertical terrain face */
   GO1_CC_COUNT = 8
 };
-#define GO1_SIG_WORDS 4          /* per substep: [top-surface points | wall points | self pairs + legs with limit rows | hash of: the
+#define GO1_SIG_WORDS 4          /* per substep: [top-surface points | wall + hip points | self pairs (3 bits per pair of legs: 1 + type of the
+                                    listed capsule combination, pairs (0,1) (0,2) (0,3) (1,2) (1,3) (2,3) in bits 0..17; lower leg - trunk at
+                                    bit 18 + leg; round 5: types 4 / 5 = hip capsule - lower leg) + legs with limit rows (bits 28..31) | hash of: the
                                     height-field cell and candidate point (corner / end) every listed terrain contact came from, the
                                     contacts that took the restitution branch, and the ACTIVE SET after every solver sweep (pressing
                                     contacts, contacts projected on the friction cone in that sweep, limit rows with an impulse)] */
