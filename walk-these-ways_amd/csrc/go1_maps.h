@@ -617,7 +617,7 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
       if (y > cfg.terrain_width * cfg.terrain_num_cols - th) y -= cfg.terrain_width * (cfg.terrain_num_cols - 1);
       AT(B.root_states, 0, e) = x; AT(B.root_states, 1, e) = y;
     }
-    if (ep_len % cfg.resample_interval == 0) resample_commands(cfg, B, e, N, counter_post, P_CMD_CB, counter_post - 1);
+    if (GO1_RARE(ep_len % cfg.resample_interval == 0)) resample_commands(cfg, B, e, N, counter_post, P_CMD_CB, counter_post - 1);
   }
   QUAD_SYNC();                // commands / command_sums of this step are final
   PROF(8);
@@ -649,11 +649,11 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
     AT(B.desired_contact_states, leg, e) = sm;
   }
   if (is0) {
-    if (cfg.push_robots && ep_len % cfg.push_interval == 0) {
+    if (GO1_RARE(cfg.push_robots && ep_len % cfg.push_interval == 0)) {
       AT(B.root_states, 7, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, 0) - 1) * cfg.max_push_vel_xy;
       AT(B.root_states, 8, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, 1) - 1) * cfg.max_push_vel_xy;
     }
-    if (ep_len % cfg.rand_interval == 0) {
+    if (GO1_RARE(ep_len % cfg.rand_interval == 0)) {
       randomize_dof_props(cfg, B, e, N, counter_post, P_DOFPROPS_CB);
       if (cfg.randomize_rigids_after_start) randomize_rigid_props(cfg, B, e, N, counter_post, P_RIGID);
     }
@@ -756,7 +756,7 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
   if (cfg.only_positive_rewards) rew = fmaxf(rew, 0.f);
   else if (cfg.only_positive_rewards_ji22_style) rew = pos * expf(neg / cfg.sigma_rew_neg);
   if (!(fabsf(rew) <= 3.0e38f)) { rew = 0.f; sim_failed = true; fault |= 1u << GO1_FAULT_REWARD; }
-  if (sim_failed) {
+  if (GO1_RARE(sim_failed)) {
     rew = 0.f;
     reset = true;
     if (is0) B.reset_buf[e] = 1;
@@ -794,7 +794,7 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
   PROF(11);
   QUAD_SYNC();                // running sums complete before a reset logs / clears them
   // ---- reset ----------------------------------------------------------------------------------------
-  if (reset && is0) reset_env(cfg, B, e, N, counter_post, is_eval, counter_post - 1);
+  if (GO1_RARE(reset && is0)) reset_env(cfg, B, e, N, counter_post, is_eval, counter_post - 1);
   QUAD_SYNC();                // the observation sees the post-reset state, as in the reference
   PROF(12);
 

@@ -31,6 +31,14 @@ __shared__ unsigned long long s_prof[32];          // accumulated with fire-and-
 #include <stdint.h>
 
 #define DEV __device__ __forceinline__
+// A branch into a large, rarely executed block (a reset, a command resampling, the self-contact rows): the hint moves the block out of the
+// fall-through path, so that the common path runs straight through its code.  With ONE wavefront per SIMD a taken branch to a cold line of
+// the 240 KB kernel is an exposed instruction fetch (csrc/go1sim.hip: the substep loop written out).  GO1_NO_RARE_HINTS: the probe without.
+#ifndef GO1_NO_RARE_HINTS
+#define GO1_RARE(x) __builtin_expect(!!(x), 0)
+#else
+#define GO1_RARE(x) (x)
+#endif
 // Marks a point where the lanes of the wavefront hand data to each other through LDS.  The hardware executes one wave's
 // LDS operations in issue order, so no instruction is needed — only the compiler must not move LDS accesses across it.
 // (The SIMT emulator of tests/emu defines it as a real barrier: there the lanes do not run in lock step.)

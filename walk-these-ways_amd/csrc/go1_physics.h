@@ -1236,7 +1236,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
   // wavefronts (nw > 1) while this one emits the self-contacts and the limit rows --------------------------------------------
   legfac_store(Z.pkl(), lane, F);
   if (leg == 0) { envpk_store(Z.pke(), el, E); LDS(L_KL + 1) = (float)lact; }
-  if (cfg.self_collision && __ballot(smask != 0ull) != 0ull) {        // free twists of the own lower leg / thigh / hip for the partners
+  if (GO1_RARE(cfg.self_collision && __ballot(smask != 0ull) != 0ull)) {        // free twists of the own lower leg / thigh / hip for the partners
     SV fl = sv(w_free, v_free), ft_;
 #pragma unroll
     for (int j = 0; j < 3; j++) { fl = fl + F.qdf[j] * F.S[j]; if (j == 1) ft_ = fl; }
@@ -1257,7 +1257,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
   int nown = 0;
 #pragma unroll
   for (int i = 0; i <= MAXSB; i++) { sslot[i] = -1; sdepth[i] = 2; ssign[i] = 0.f; }
-  if (cfg.self_collision && __ballot(smask != 0ull) != 0ull) {
+  if (GO1_RARE(cfg.self_collision && __ballot(smask != 0ull) != 0ull)) {
     const lf4* seg = Z.seg();
     const lf4* tw = Z.tw();
     int rank = 0, sbi = 0;         // rank among the listed pairs / among the listed leg-leg pairs (wave-uniform loop, per-lane counters)

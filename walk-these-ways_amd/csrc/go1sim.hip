@@ -217,8 +217,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   const int nl = cfg.lag_timesteps + 1;
   int head = A.lag_head;
   PROF(0);
-#pragma unroll 1          // (unrolled by 2 / 4 the step takes the same time: gpurun call r5j, 0.1690 / 0.1698 against 0.1696 ms)
-  for (int sub = 0; sub < nsub; sub++) {
+  auto substep = [&](int sub) __attribute__((always_inline)) {
     PROF(24);
 #ifndef GO1_ABLATE_TORQUE
     if (substep_only) {
@@ -234,7 +233,17 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
     physics_substep<WALLS, SIG, PLANE>(cfg, B, Z, lane, nw, s, L, grav, warm || (cfg.warm_start && sub > 0), h, fault, drops, deferred ? acth : nullptr, e, N, sub PROF_PASS);
 #endif
     PROF(30);
-  }
+  };
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GO1_SUBSTEP_LOOP)
+  // The reference's decimation of 4 with the body written out four times (`#pragma unroll` is refused by the optimizer for this loop): no
+  // far backward branch at the end of a substep, and `sub` folds into each copy.  Same-box A/B against the loop (gpurun call r5o): 0.1583 /
+  // 0.1231 against 0.1626 / 0.1292 ms per env.step (-2.6 % / -4.7 %); code size x 4 (the 16-384 KB probe shows no instruction-cache cliff,
+  // profiles/r05_icache_probe.txt).  Other decimations — and the host build of the SIMT emulator — take the loop.
+  if (nsub == 4) { substep(0); substep(1); substep(2); substep(3); }
+  else
+#endif
+#pragma unroll 1
+  for (int sub = 0; sub < nsub; sub++) substep(sub);
   if (deferred) torque_stash_store(cfg, B, L, acth, lane, leg, e, N);
   store_state(B, leg, e, N, s, L);
   foot_state(s, L, leg, B, e, N);
