@@ -24,7 +24,8 @@ PHASES = ["rest of the prologue (stash commit, input checks)", "torque model: ba
           "torque model: post q, qd for the helpers' rows (x4)", "PGS: warm-start state (x4)",
           "loop edge after the pose update (x4)", "kinematics + terrain candidates (x4; 19 = the contact list alone)", "self-collision geometry (x4)",
           "apply: impulses of the listed contacts from LDS (x4; 6 = the rest)", "apply: back-substitution + base twist (x4)", "integrate the joints (x4)",
-          "what the compiler sank behind the substep's last marker (x4; 24 = the loop's back edge alone)"]
+          "what the compiler sank behind the substep's last marker (x4; 24 = the loop's back edge alone)",
+          "sweep: cooperative turns (x16; 5 = the sweep's rest: signature, phase marker)", "sweep: the legs' turns + merge (x16)", "sweep: limit rows (x16)"]
 
 
 def build(flags):
@@ -63,7 +64,7 @@ def main():
         wg = (ctypes.c_uint64 * 1152)()
         lib.go1sim_debug_read_wg_times.argtypes = [ctypes.c_void_p]
         lib.go1sim_debug_read_wg_times(wg)
-        wp = (ctypes.c_uint64 * (1024 * 32))()
+        wp = (ctypes.c_uint64 * (1024 * 40))()
         lib.go1sim_debug_read_wg_phases.argtypes = [ctypes.c_void_p]
         lib.go1sim_debug_read_wg_phases(wp)
         for t in range(args.steps):
@@ -83,7 +84,7 @@ def main():
         tot = sum(buf[:len(PHASES)])
         print(f"cycles per step (wave 0 lane 0, s_memtime ticks): {tot / args.steps:.0f}")
         assert lib.go1sim_debug_read_wg_phases(wp) == 0
-        P = np.array(wp[:], dtype=np.float64).reshape(1024, 32)[:nwg, :len(PHASES)] / args.steps
+        P = np.array(wp[:], dtype=np.float64).reshape(1024, 40)[:nwg, :len(PHASES)] / args.steps
         order = np.argsort(P.sum(1))
         slow, fast = P[order[-max(nwg // 10, 1):]].mean(0), P[order[:max(nwg // 10, 1)]].mean(0)
         print(f"  phase                                      workgroup 0    mean of all   slowest 10 %   fastest 10 %   (cycles per step)")

@@ -8,16 +8,16 @@
 #ifdef GO1_PROFILE
 __device__ unsigned long long g_prof[64];
 __device__ unsigned long long g_lmax[64], g_lsum[64];   // per launch (slot = step counter & 63): the slowest workgroup's / all workgroups' master cycles
-__device__ unsigned long long g_profw[1024 * 32];       // the phase accumulators of EVERY workgroup (which phases make the slowest workgroups slow)
+__device__ unsigned long long g_profw[1024 * 40];       // the phase accumulators of EVERY workgroup (which phases make the slowest workgroups slow)
 __device__ unsigned long long g_wgt[1024];          // per workgroup: the master wavefront's cycles, accumulated over the launches (spread between workgroups)
-__shared__ unsigned long long s_prof[32];          // accumulated with fire-and-forget LDS adds: no memory stall per marker
+__shared__ unsigned long long s_prof[40];          // accumulated with fire-and-forget LDS adds: no memory stall per marker
 #define PROF_PARAM , unsigned long long& prof_t
 #define PROF_PASS , prof_t
-#define PROF_INIT if (threadIdx.x < 32) s_prof[threadIdx.x] = 0; __syncthreads();
+#define PROF_INIT if (threadIdx.x < 40) s_prof[threadIdx.x] = 0; __syncthreads();
 #define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(); const unsigned long long prof_t0 = prof_t;
 // (sched_barrier: the counter read is a scheduling fence — without it the compiler sinks a phase's tail, e.g. the pose update's sincos, past the marker)
 #define PROF(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) atomicAdd(&s_prof[i], now_ - prof_t); prof_t = now_; } while (0)
-#define PROF_FLUSH do { LDS_PHASE(); if (blockIdx.x == 0 && threadIdx.x < 32) g_prof[threadIdx.x] += s_prof[threadIdx.x]; if (blockIdx.x < 1024 && threadIdx.x < 32) g_profw[blockIdx.x * 32 + threadIdx.x] += s_prof[threadIdx.x]; if (threadIdx.x == 0 && blockIdx.x < 1024) { const unsigned long long dt_ = __builtin_readcyclecounter() - prof_t0; g_wgt[blockIdx.x] += dt_; atomicMax(&g_lmax[PROF_LAUNCH & 63], dt_); atomicAdd(&g_lsum[PROF_LAUNCH & 63], dt_); } } while (0)
+#define PROF_FLUSH do { LDS_PHASE(); if (blockIdx.x == 0 && threadIdx.x < 40) g_prof[threadIdx.x] += s_prof[threadIdx.x]; if (blockIdx.x < 1024 && threadIdx.x < 40) g_profw[blockIdx.x * 40 + threadIdx.x] += s_prof[threadIdx.x]; if (threadIdx.x == 0 && blockIdx.x < 1024) { const unsigned long long dt_ = __builtin_readcyclecounter() - prof_t0; g_wgt[blockIdx.x] += dt_; atomicMax(&g_lmax[PROF_LAUNCH & 63], dt_); atomicAdd(&g_lsum[PROF_LAUNCH & 63], dt_); } } while (0)
 #else
 #define PROF_PARAM
 #define PROF_PASS

@@ -1552,6 +1552,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         sweep_rec_load(crl, el, k, R);
         contact_turn(k, R, ((coop >> k) & 1u) != 0u);
       }
+      PROF(31);
       {
         SweepState sp = st;                                        // private copy: base state as the leg phase found it + the own contacts' changes
         f2 ds01 = splat2(0.f), ds23 = splat2(0.f), ds45 = splat2(0.f);      // sum of a_z dlambda over the own SPLIT rows (unscaled)
@@ -1604,6 +1605,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         st.z45[0] += quad_sum(sp.z45[0] - st.z45[0]); st.z45[1] += quad_sum(sp.z45[1] - st.z45[1]);
         st.y01 = sp.y01; st.y2 = sp.y2;
       }
+      PROF(32);
       // limit rows in joint order: the rate without the row's own impulse is projected on [lower, upper]
 #pragma unroll
       for (int lgi = 0; lgi < 4; lgi++) {
@@ -1634,6 +1636,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
           }
         }
       }
+      PROF(33);
       LDS_PHASE();          // the next sweep re-reads the impulses the leg-0 lanes stored in this one
       if (SIG && B.contact_signature != nullptr && sub < GO1_SIG_MAX_SUBSTEPS) {
         // tests only: the ACTIVE SET after every sweep — which contacts press (lambda_n > 0), which were projected on the cone in this

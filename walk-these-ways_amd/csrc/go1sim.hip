@@ -238,7 +238,8 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   // The reference's decimation of 4 with the body written out four times (`#pragma unroll` is refused by the optimizer for this loop): no
   // far backward branch at the end of a substep, and `sub` folds into each copy.  Same-box A/B against the loop (gpurun call r5o): 0.1583 /
   // 0.1231 against 0.1626 / 0.1292 ms per env.step (-2.6 % / -4.7 %); code size x 4 (the 16-384 KB probe shows no instruction-cache cliff,
-  // profiles/r05_icache_probe.txt).  Other decimations — and the host build of the SIMT emulator — take the loop.
+  // profiles/r05_icache_probe.txt).  Price: 352 bytes of scratch per lane instead of 144 (+3 MB of HBM traffic per launch); a loop of two
+  // written-out pairs needs 720.  Other decimations — and the host build of the SIMT emulator — take the loop.
   if (nsub == 4) { substep(0); substep(1); substep(2); substep(3); }
   else
 #endif
@@ -623,9 +624,9 @@ extern "C" int go1sim_debug_read_profile(unsigned long long* out64) {
   if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(z)) != hipSuccess) return -1;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
-// the phase accumulators of every workgroup, [1024][32] (read and clear)
+// the phase accumulators of every workgroup, [1024][40] (read and clear)
 extern "C" int go1sim_debug_read_wg_phases(unsigned long long* out) {
-  static unsigned long long z[1024 * 32];
+  static unsigned long long z[1024 * 40];
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_profw), sizeof(z)) != hipSuccess) return -1;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_profw), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
