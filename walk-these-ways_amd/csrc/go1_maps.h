@@ -405,6 +405,11 @@ struct RewardPlan {
   float scale_by_id[GO1_REW_COUNT];
 };
 typedef const GO1_CONSTANT RewardPlan& PlanRef;
+// the plan as 2 x GO1_REW_COUNT words in LDS (row indices, then the scales' bits): called by the first 48 threads of a workgroup at kernel start
+DEV void reward_plan_to_lds(PlanRef plan, int* plan_lds, int t) {
+  if (t < GO1_REW_COUNT) plan_lds[t] = plan.kx_by_id[t];
+  else if (t < 2 * GO1_REW_COUNT) plan_lds[t] = __float_as_int(plan.scale_by_id[t - GO1_REW_COUNT]);
+}
 DEV int reward_raw_sign(int id) {
   return (id == GO1_REW_JUMP || id == GO1_REW_TRACKING_CONTACTS_SHAPED_FORCE || id == GO1_REW_TRACKING_CONTACTS_SHAPED_VEL) ? -1 : 1;
 }
@@ -421,11 +426,25 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
   const int leg = lane & 3;
   const bool is0 = leg == 0;
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
+  // The configuration's switches and scales this function branches on, fetched as ONE batch: a mask built from all of them forces every
+  // scalar load to be issued before the first branch.  Read where they were used, each `if (cfg.x)` was a load - wait - branch round trip
+  // through the constant cache, fifteen in a row (round 5: found in the ISA; the helper wavefront's observations had become the longer side
+  // of the post-physics phase).
+  enum { O_LIN = 1, O_ANG = 2, O_VEL = 4, O_GLOBAL = 8, O_CMD = 16, O_TWO = 32, O_TIMING = 64, O_CLOCK = 128, O_YAW = 256, O_CONTACT = 512,
+         O_NOISE = 1024, O_HEIGHTS = 2048 };
+  const unsigned om = (cfg.observe_only_lin_vel ? O_LIN : 0) | (cfg.observe_only_ang_vel ? O_ANG : 0) | (cfg.observe_vel ? O_VEL : 0) |
+                      (cfg.global_reference ? O_GLOBAL : 0) | (cfg.observe_command ? O_CMD : 0) | (cfg.observe_two_prev_actions ? O_TWO : 0) |
+                      (cfg.observe_timing_parameter ? O_TIMING : 0) | (cfg.observe_clock_inputs ? O_CLOCK : 0) | (cfg.observe_yaw ? O_YAW : 0) |
+                      (cfg.observe_contact_states ? O_CONTACT : 0) | (cfg.add_noise ? O_NOISE : 0) |
+                      ((cfg.observe_heights && cfg.measure_heights) ? O_HEIGHTS : 0);
+  const int o_num_obs = cfg.num_obs, o_num_cmd = cfg.num_commands, o_hist = cfg.num_obs_history;
+  const float o_s_lin = cfg.obs_scale_lin_vel, o_s_ang = cfg.obs_scale_ang_vel, o_s_q = cfg.obs_scale_dof_pos, o_s_qd = cfg.obs_scale_dof_vel,
+              o_clip = cfg.clip_observations;
   if (parts & 1) {         // observations (+ history ring) and the roll of the own joints' "last_*" values
-    float* obs_row = B.obs_buf + (size_t)e * cfg.num_obs;
-    const int R = cfg.num_obs_history + 1;     // ring slots (one spare keeps the previous window intact)
-    float* h0 = B.obs_history ? B.obs_history + (size_t)e * 2 * R * cfg.num_obs + (size_t)history_slot * cfg.num_obs : nullptr;
-    float* h1 = h0 ? h0 + (size_t)R * cfg.num_obs : nullptr;
+    float* obs_row = B.obs_buf + (size_t)e * o_num_obs;
+    const int R = o_hist + 1;     // ring slots (one spare keeps the previous window intact)
+    float* h0 = B.obs_history ? B.obs_history + (size_t)e * 2 * R * o_num_obs + (size_t)history_slot * o_num_obs : nullptr;
+    float* h1 = h0 ? h0 + (size_t)R * o_num_obs : nullptr;
     // Two passes.  (1) every lane stages the raw values of "its" columns in an LDS row; (2) the row is finished in
     // blocks of 4 columns, block b by lane b & 3: ONE Philox4x32 call yields the noise of all 4 columns (drawing per
     // column would run the generator 4x for the same counter), then clip and the three stores (obs, history x2).
@@ -440,48 +459,48 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
       o_lact[jj] = AT(B.last_actions, j, e); o_jpt[jj] = AT(B.joint_pos_target, j, e); o_ljpt[jj] = AT(B.last_joint_pos_target, j, e);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) o_cmd[i] = (leg + 4 * i < cfg.num_commands) ? AT(B.commands, leg + 4 * i, e) : 0.f;
+    for (int i = 0; i < 4; i++) o_cmd[i] = (leg + 4 * i < o_num_cmd) ? AT(B.commands, leg + 4 * i, e) : 0.f;
     const float o_gait = B.gait_indices[e];
     int n = 0;                // running column (identical on all lanes)
-    if (cfg.observe_only_lin_vel) { if (is0) for (int i = 0; i < 3; i++) emit(n + i, AT(B.base_lin_vel, i, e) * cfg.obs_scale_lin_vel); n += 3; }
-    if (cfg.observe_only_ang_vel) { if (is0) for (int i = 0; i < 3; i++) emit(n + i, AT(B.base_ang_vel, i, e) * cfg.obs_scale_ang_vel); n += 3; }
-    if (cfg.observe_vel) {
+    if ((om & O_LIN)) { if (is0) for (int i = 0; i < 3; i++) emit(n + i, AT(B.base_lin_vel, i, e) * o_s_lin); n += 3; }
+    if ((om & O_ANG)) { if (is0) for (int i = 0; i < 3; i++) emit(n + i, AT(B.base_ang_vel, i, e) * o_s_ang); n += 3; }
+    if ((om & O_VEL)) {
       if (is0) {
-        for (int i = 0; i < 3; i++) emit(n + i, (cfg.global_reference ? AT(B.root_states, 7 + i, e) : AT(B.base_lin_vel, i, e)) * cfg.obs_scale_lin_vel);
-        for (int i = 0; i < 3; i++) emit(n + 3 + i, AT(B.base_ang_vel, i, e) * cfg.obs_scale_ang_vel);
+        for (int i = 0; i < 3; i++) emit(n + i, ((om & O_GLOBAL) ? AT(B.root_states, 7 + i, e) : AT(B.base_lin_vel, i, e)) * o_s_lin);
+        for (int i = 0; i < 3; i++) emit(n + 3 + i, AT(B.base_ang_vel, i, e) * o_s_ang);
       }
       n += 6;
     }
     if (is0) { emit(n, pg.x); emit(n + 1, pg.y); emit(n + 2, pg.z); }
     n += 3;
-    if (cfg.observe_command) {
+    if ((om & O_CMD)) {
       // 15 command columns: spread over the quad
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int kx = leg + 4 * i;
-        if (kx < cfg.num_commands) emit(n + kx, o_cmd[i] * cfg.commands_scale[kx]);
+        if (kx < o_num_cmd) emit(n + kx, o_cmd[i] * cfg.commands_scale[kx]);
       }
-      n += cfg.num_commands;
+      n += o_num_cmd;
     }
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) {
       const int j = 3 * leg + jj;
-      emit(n + j, (o_q[jj] - cfg.default_dof_pos[j]) * cfg.obs_scale_dof_pos);
-      emit(n + 12 + j, o_qd[jj] * cfg.obs_scale_dof_vel);
+      emit(n + j, (o_q[jj] - cfg.default_dof_pos[j]) * o_s_q);
+      emit(n + 12 + j, o_qd[jj] * o_s_qd);
       emit(n + 24 + j, o_act[jj]);
-      if (cfg.observe_two_prev_actions) emit(n + 36 + j, o_lact[jj]);
+      if ((om & O_TWO)) emit(n + 36 + j, o_lact[jj]);
     }
-    n += cfg.observe_two_prev_actions ? 48 : 36;
-    if (cfg.observe_timing_parameter) { if (is0) emit(n, o_gait); n += 1; }
-    if (cfg.observe_clock_inputs) { emit(n + leg, clock_own); n += 4; }
-    if (cfg.observe_yaw) {
+    n += (om & O_TWO) ? 48 : 36;
+    if ((om & O_TIMING)) { if (is0) emit(n, o_gait); n += 1; }
+    if ((om & O_CLOCK)) { emit(n + leg, clock_own); n += 4; }
+    if ((om & O_YAW)) {
       if (is0) {
         V3 fw = quat_rotate(AT(B.root_states, 3, e), AT(B.root_states, 4, e), AT(B.root_states, 5, e), AT(B.root_states, 6, e), v3(1.f, 0.f, 0.f));
         emit(n, atan2f(fw.y, fw.x));
       }
       n += 1;
     }
-    if (cfg.observe_contact_states) { emit(n + leg, force_z > 1.0f ? 1.0f : 0.0f); n += 4; }
+    if ((om & O_CONTACT)) { emit(n + leg, force_z > 1.0f ? 1.0f : 0.0f); n += 4; }
     {
       const int n_def = n;                      // columns staged so far
       QUAD_SYNC();
@@ -493,7 +512,7 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
         for (int i = 0; i < 4; i++) {
           const int c = 4 * b + i;
           v[i] = c < n_def ? orow[c] : 0.f;
-          sc[i] = (cfg.add_noise && c < n_def) ? cfg.noise_scale_vec[c] : 0.f;
+          sc[i] = ((om & O_NOISE) && c < n_def) ? cfg.noise_scale_vec[c] : 0.f;
           any = any || sc[i] != 0.f;
         }
         if (any) {
@@ -507,7 +526,7 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
         for (int i = 0; i < 4; i++) {
           const int c = 4 * b + i;
           if (c < n_def) {
-            float x = fminf(fmaxf(v[i], -cfg.clip_observations), cfg.clip_observations);
+            float x = fminf(fmaxf(v[i], -o_clip), o_clip);
             if (!(v[i] == v[i])) { x = 0.f; fault |= 1u << GO1_FAULT_OBS; }
             obs_row[c] = x;
             if (h0) { h0[c] = x; h1[c] = x; }
@@ -515,14 +534,14 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
         }
       }
     }
-    if (cfg.observe_heights && cfg.measure_heights && B.measured_heights) {      // legacy legged_gym height block (BASELINE config 3)
+    if ((om & O_HEIGHTS) && B.measured_heights) {      // legacy legged_gym height block (BASELINE config 3)
       const int np = cfg.num_height_x * cfg.num_height_y;
       const float z = AT(B.root_states, 2, e);
 #pragma unroll 1
       for (int p = leg; p < np; p += 4) {
         float v = fminf(fmaxf(z - 0.5f - AT(B.measured_heights, p, e), -1.f), 1.f) * cfg.obs_scale_height;
-        if (cfg.add_noise && cfg.height_noise_scale != 0.f) v += (2 * rng_uniform(cfg, eg, counter_post, P_NOISE, n + p) - 1) * cfg.height_noise_scale;
-        v = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations);
+        if ((om & O_NOISE) && cfg.height_noise_scale != 0.f) v += (2 * rng_uniform(cfg, eg, counter_post, P_NOISE, n + p) - 1) * cfg.height_noise_scale;
+        v = fminf(fmaxf(v, -o_clip), o_clip);
         obs_row[n + p] = v;
         if (h0) { h0[n + p] = v; h1[n + p] = v; }
       }
@@ -542,6 +561,10 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
   }
     PROF(13);
   if (parts & 2) {         // privileged observations (leg-0 lane)
+    // (the eleven `priv_enabled` switches as one mask: one batch of scalar loads instead of eleven load - wait - branch round trips)
+    unsigned pm = 0;
+#pragma unroll
+    for (int i = 0; i <= GO1_PRIV_DESIRED_CONTACT; i++) pm |= cfg.priv_enabled[i] ? 1u << i : 0u;
     if (is0) {
       float* pv = B.privileged_obs_buf + (size_t)e * cfg.num_privileged_obs;
       int np = 0;
@@ -550,25 +573,25 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
         pv[np++] = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations);
       };
       auto privraw = [&](float v) { pv[np++] = fminf(fmaxf(v, -cfg.clip_observations), cfg.clip_observations); };
-      if (cfg.priv_enabled[GO1_PRIV_FRICTION]) priv(GO1_PRIV_FRICTION, B.friction_coeffs[e]);
-      if (cfg.priv_enabled[GO1_PRIV_RESTITUTION]) priv(GO1_PRIV_RESTITUTION, B.restitutions[e]);
-      if (cfg.priv_enabled[GO1_PRIV_BASE_MASS]) priv(GO1_PRIV_BASE_MASS, B.payloads[e]);
-      if (cfg.priv_enabled[GO1_PRIV_COM_DISPLACEMENT]) for (int i = 0; i < 3; i++) priv(GO1_PRIV_COM_DISPLACEMENT, AT(B.com_displacements, i, e));
-      if (cfg.priv_enabled[GO1_PRIV_MOTOR_STRENGTH])
+      if ((pm & (1u << GO1_PRIV_FRICTION))) priv(GO1_PRIV_FRICTION, B.friction_coeffs[e]);
+      if ((pm & (1u << GO1_PRIV_RESTITUTION))) priv(GO1_PRIV_RESTITUTION, B.restitutions[e]);
+      if ((pm & (1u << GO1_PRIV_BASE_MASS))) priv(GO1_PRIV_BASE_MASS, B.payloads[e]);
+      if ((pm & (1u << GO1_PRIV_COM_DISPLACEMENT))) for (int i = 0; i < 3; i++) priv(GO1_PRIV_COM_DISPLACEMENT, AT(B.com_displacements, i, e));
+      if ((pm & (1u << GO1_PRIV_MOTOR_STRENGTH)))
 #pragma unroll 1
         for (int j = 0; j < 12; j++) priv(GO1_PRIV_MOTOR_STRENGTH, AT(B.motor_strengths, j, e));
-      if (cfg.priv_enabled[GO1_PRIV_MOTOR_OFFSET])
+      if ((pm & (1u << GO1_PRIV_MOTOR_OFFSET)))
 #pragma unroll 1
         for (int j = 0; j < 12; j++) priv(GO1_PRIV_MOTOR_OFFSET, AT(B.motor_offsets, j, e));
-      if (cfg.priv_enabled[GO1_PRIV_BODY_HEIGHT]) priv(GO1_PRIV_BODY_HEIGHT, AT(B.root_states, 2, e));
-      if (cfg.priv_enabled[GO1_PRIV_BODY_VELOCITY]) for (int i = 0; i < 3; i++) priv(GO1_PRIV_BODY_VELOCITY, AT(B.base_lin_vel, i, e));
-      if (cfg.priv_enabled[GO1_PRIV_GRAVITY]) {
+      if ((pm & (1u << GO1_PRIV_BODY_HEIGHT))) priv(GO1_PRIV_BODY_HEIGHT, AT(B.root_states, 2, e));
+      if ((pm & (1u << GO1_PRIV_BODY_VELOCITY))) for (int i = 0; i < 3; i++) priv(GO1_PRIV_BODY_VELOCITY, AT(B.base_lin_vel, i, e));
+      if ((pm & (1u << GO1_PRIV_GRAVITY))) {
         privraw(((grav.x - cfg.gravity[0]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
         privraw(((grav.y - cfg.gravity[1]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
         privraw(((grav.z - cfg.gravity[2]) - cfg.priv_shift[GO1_PRIV_GRAVITY]) / cfg.priv_scale[GO1_PRIV_GRAVITY]);
       }
-      if (cfg.priv_enabled[GO1_PRIV_CLOCK_INPUTS]) for (int f = 0; f < 4; f++) privraw(AT(B.clock_inputs, f, e));
-      if (cfg.priv_enabled[GO1_PRIV_DESIRED_CONTACT]) for (int f = 0; f < 4; f++) privraw(AT(B.desired_contact_states, f, e));
+      if ((pm & (1u << GO1_PRIV_CLOCK_INPUTS))) for (int f = 0; f < 4; f++) privraw(AT(B.clock_inputs, f, e));
+      if ((pm & (1u << GO1_PRIV_DESIRED_CONTACT))) for (int f = 0; f < 4; f++) privraw(AT(B.desired_contact_states, f, e));
     }
   }
 }
@@ -586,11 +609,17 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
 // helper is through).  The helper does NOT go when an environment of the wavefront resets (the observations then read the re-initialised
 // state, which exists only after the rewards: master as before).  A reset that only the rewards bring about (a non-finite term: the
 // failed-simulation guard) is met after S2 by evaluating the observations of that environment again.
-DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int lane, int e, int N, int64_t counter_post, V3 grav,
+DEV void post_physics(CfgRef cfg, BufRef B, const int* plan_lds, float* obs_stage, int lane, int e, int N, int64_t counter_post, V3 grav,
                       int history_slot, uint32_t& fault, bool is_eval, float* helper_flag, int nw PROF_PARAM) {
   const int leg = lane & 3;
   const bool is0 = leg == 0;
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
+  // (the switches and intervals the callbacks branch on as one batch of scalar loads: see post_observations)
+  enum { F_TELE = 1, F_GAIT = 2, F_PUSH = 4, F_MEAS = 8, F_ABOVE = 16, F_TERMH = 32, F_PACING = 64, F_RIGID = 128 };
+  const unsigned fm = (cfg.teleport_robots ? F_TELE : 0) | (cfg.observe_gait_commands ? F_GAIT : 0) | (cfg.push_robots ? F_PUSH : 0) |
+                      (cfg.measure_heights ? F_MEAS : 0) | (cfg.reward_heights_above_terrain ? F_ABOVE : 0) |
+                      (cfg.use_terminal_body_height ? F_TERMH : 0) | (cfg.pacing_offset ? F_PACING : 0) | (cfg.randomize_rigids_after_start ? F_RIGID : 0);
+  const int c_resample = cfg.resample_interval, c_push = cfg.push_interval, c_rand = cfg.rand_interval, c_maxlen = cfg.max_episode_length;
   Derived d;
   const int ep_len = B.episode_length_buf[e] + 1;
   d.base_pos = v3(AT(B.root_states, 0, e), AT(B.root_states, 1, e), AT(B.root_states, 2, e));
@@ -609,7 +638,7 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
     AT(B.base_ang_vel, 0, e) = d.bav.x; AT(B.base_ang_vel, 1, e) = d.bav.y; AT(B.base_ang_vel, 2, e) = d.bav.z;
     AT(B.projected_gravity, 0, e) = d.pg.x; AT(B.projected_gravity, 1, e) = d.pg.y; AT(B.projected_gravity, 2, e) = d.pg.z;
     // ---- _post_physics_step_callback: teleport, interval command resampling ----------------------
-    if (cfg.teleport_robots) {
+    if ((fm & F_TELE)) {
       float x = AT(B.root_states, 0, e), y = AT(B.root_states, 1, e), th = cfg.teleport_thresh, xo = cfg.teleport_x_offset;
       if (x < th + xo) x += cfg.terrain_length * (cfg.terrain_num_rows - 1);
       if (x > cfg.terrain_length * cfg.terrain_num_rows - th + xo) x -= cfg.terrain_length * (cfg.terrain_num_rows - 1);
@@ -617,7 +646,7 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
       if (y > cfg.terrain_width * cfg.terrain_num_cols - th) y -= cfg.terrain_width * (cfg.terrain_num_cols - 1);
       AT(B.root_states, 0, e) = x; AT(B.root_states, 1, e) = y;
     }
-    if (GO1_RARE(ep_len % cfg.resample_interval == 0)) resample_commands(cfg, B, e, N, counter_post, P_CMD_CB, counter_post - 1);
+    if (GO1_RARE(ep_len % c_resample == 0)) resample_commands(cfg, B, e, N, counter_post, P_CMD_CB, counter_post - 1);
   }
   QUAD_SYNC();                // commands / command_sums of this step are final
   PROF(8);
@@ -626,12 +655,12 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
   F.foot_index = AT(B.foot_indices, leg, e);
   F.desired_contact = AT(B.desired_contact_states, leg, e);
   float clock_own = AT(B.clock_inputs, leg, e);
-  if (cfg.observe_gait_commands) {
+  if ((fm & F_GAIT)) {
     float freq = AT(B.commands, 4, e), phase = AT(B.commands, 5, e), offset = AT(B.commands, 6, e), bound = AT(B.commands, 7, e), dur = AT(B.commands, 8, e);
     float gi = fmod1(B.gait_indices[e] + cfg.dt * freq);
     float f0 = gi + phase + offset + bound, f3 = gi + phase;
-    float f1 = cfg.pacing_offset ? gi + bound : gi + offset;
-    float f2 = cfg.pacing_offset ? gi + offset : gi + bound;
+    float f1 = (fm & F_PACING) ? gi + bound : gi + offset;
+    float f2 = (fm & F_PACING) ? gi + offset : gi + bound;
     float fi = leg == 0 ? f0 : leg == 1 ? f1 : leg == 2 ? f2 : f3;
     float rem = fmod1(fi);
     float idx = fi;
@@ -649,13 +678,13 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
     AT(B.desired_contact_states, leg, e) = sm;
   }
   if (is0) {
-    if (GO1_RARE(cfg.push_robots && ep_len % cfg.push_interval == 0)) {
+    if (GO1_RARE((fm & F_PUSH) && ep_len % c_push == 0)) {
       AT(B.root_states, 7, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, 0) - 1) * cfg.max_push_vel_xy;
       AT(B.root_states, 8, e) = (2 * rng_uniform(cfg, eg, counter_post, P_PUSH, 1) - 1) * cfg.max_push_vel_xy;
     }
-    if (GO1_RARE(ep_len % cfg.rand_interval == 0)) {
+    if (GO1_RARE(ep_len % c_rand == 0)) {
       randomize_dof_props(cfg, B, e, N, counter_post, P_DOFPROPS_CB);
-      if (cfg.randomize_rigids_after_start) randomize_rigid_props(cfg, B, e, N, counter_post, P_RIGID);
+      if ((fm & F_RIGID)) randomize_rigid_props(cfg, B, e, N, counter_post, P_RIGID);
     }
   }
   PROF(9);
@@ -669,7 +698,7 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
   }
   // ---- measured terrain heights (_get_heights, reference legged_robot.py:1772-1806): 187 points over the quad ----
   float mean_height = 0.f;
-  if (cfg.measure_heights && B.measured_heights) {
+  if ((fm & F_MEAS) && B.measured_heights) {
     const int np = cfg.num_height_x * cfg.num_height_y;
     const float l = rsqrtf(d.qz * d.qz + d.qw * d.qw);       // quat_apply_yaw: yaw-only rotation of the scan pattern
     const float yz = d.qz * l, yw = d.qw * l;
@@ -699,9 +728,9 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
   // heights the reward terms read (reference: world z; reward_heights_above_terrain: above the ground — go1sim.h)
   F.hz = F.pos.z;
   d.base_hz = d.base_pos.z;
-  if (cfg.reward_heights_above_terrain) {
+  if ((fm & F_ABOVE)) {
     F.hz -= hf_sample_min3(cfg, B.height_samples, F.pos.x, F.pos.y);
-    d.base_hz -= (cfg.measure_heights && B.measured_heights) ? mean_height : hf_sample_min3(cfg, B.height_samples, d.base_pos.x, d.base_pos.y);
+    d.base_hz -= ((fm & F_MEAS) && B.measured_heights) ? mean_height : hf_sample_min3(cfg, B.height_samples, d.base_pos.x, d.base_pos.y);
   }
   // ---- check_termination ---------------------------------------------------------------------------
   PROF(10);
@@ -716,9 +745,9 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
   }
   if (is0 && (cfg.termination_body_mask & 1u) && !(rin.cfn_base <= 1.0f)) term = 1.f;
   bool reset = quad_sum(term) > 0.f;
-  const bool time_out = ep_len > cfg.max_episode_length;
+  const bool time_out = ep_len > c_maxlen;
   reset = reset || time_out;
-  if (cfg.use_terminal_body_height && root_z - mean_height < cfg.terminal_body_height) reset = true;
+  if ((fm & F_TERMH) && root_z - mean_height < cfg.terminal_body_height) reset = true;
   if (is0) { B.time_out_buf[e] = (uint8_t)time_out; B.reset_buf[e] = (uint8_t)reset; }
 
   PROF(17);
@@ -736,11 +765,17 @@ DEV void post_physics(CfgRef cfg, BufRef B, PlanRef plan, float* obs_stage, int 
   // statistics and, through the advantage normalisation, every other environment's gradient.  Every activation is
   // reported through fault_flags / fault_counts.
   float rew = 0.f, pos = 0.f, neg = 0.f;
+  // The plan's 2 x 24 scalars come from LDS (reward_plan_to_lds at kernel start) as ONE batch of broadcast reads.  As scalar loads from the
+  // constant block inside the term loop they were 48 DEPENDENT round trips — load, wait, branch, load, wait — which was most of this phase
+  // (round 5: found in the ISA).  The same bits arrive: results are unchanged.
+  int plan_kx[GO1_REW_COUNT], plan_sc[GO1_REW_COUNT];
+#pragma unroll
+  for (int id = 0; id < GO1_REW_COUNT; id++) { plan_kx[id] = plan_lds[id]; plan_sc[id] = plan_lds[GO1_REW_COUNT + id]; }
 #pragma unroll
   for (int id = 0; id < GO1_REW_COUNT; id++) {
-    const int kx = plan.kx_by_id[id];
+    const int kx = WAVE_UNIFORM(plan_kx[id]);
     if (kx >= 0) {                  // wave-uniform
-      const float sc = plan.scale_by_id[id];
+      const float sc = __int_as_float(WAVE_UNIFORM(plan_sc[id]));
       float r = quad_sum(reward_partial(cfg, B, e, N, id, d, F, leg, rin)) * sc;
       if (!(fabsf(r) <= 3.0e38f)) { r = 0.f; sim_failed = true; fault |= 1u << GO1_FAULT_REWARD; }
       rew += r;

@@ -99,7 +99,7 @@ DEV void report_drops(BufRef B, const uint32_t (&drops)[GO1_CC_COUNT]) {
 #define STEP_WAVES 4
 #endif
 template <bool WALLS, bool SIG, bool PLANE>
-DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, float* acth) {
+DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, float* acth, int* plan_lds) {
   const int nw = STEP_WAVES, wv = WAVE_UNIFORM((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63, leg = lane & 3;
   for (int i = threadIdx.x; i < L_END * EPW; i += WAVE * STEP_WAVES) lds[i] = 0.f;
   for (int i = threadIdx.x; i < X_END; i += WAVE * STEP_WAVES) ldsx[i] = (lf4){0.f, 0.f, 0.f, 0.f};      // finite everywhere: stale records are read (with zero weight)
@@ -119,6 +119,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   const bool deferred = mfma_torque && nw == 4 && cfg.decimation <= ACT_MAX_DEC;     // torque model entirely on the helper wavefronts (3 x 64 lanes = the 192 rows)
 #endif
   if (mfma_torque && wv == 0) actuator_lds_init(act_lds, lane);
+  reward_plan_to_lds(csc->rew, plan_lds, (int)threadIdx.x);
   PROF_INIT
   __syncthreads();
   if (e >= N) return;
@@ -254,7 +255,7 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   PROF(7);
 #ifndef GO1_ABLATE_POST
   if (!substep_only)
-    post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, grav, A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs,
+    post_physics(cfg, B, plan_lds, lds, lane, e, N, A.counter + 1, grav, A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs,
                  nw > 1 ? acth : nullptr, nw PROF_PASS);
 #endif
   report_fault(B, e, fault);
@@ -267,10 +268,11 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   __shared__ float lds[L_END * EPW]; \
   __shared__ __attribute__((aligned(16))) lf4 ldsx[X_END]; \
   __shared__ __attribute__((aligned(16))) float act_lds[A_END]; \
-  __shared__ float acth[AH_END * WAVE];          /* per-lane stash of the deferred torque path (torque_stash_issue / _commit) */
+  __shared__ float acth[AH_END * WAVE];          /* per-lane stash of the deferred torque path (torque_stash_issue / _commit) */ \
+  __shared__ int plan_lds[2 * GO1_REW_COUNT];    /* the reward plan (go1_maps.h reward_plan_to_lds) */
 // instances: terrain (plane | height field | height field with vertical faces) x (plain | contact signature recorded: parity tests)
 #define STEP_KERNEL(name, WALLS, SIG, PLANE) \
-  extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) name(const StepArgs A) { STEP_LDS step_body<WALLS, SIG, PLANE>(A, lds, ldsx, act_lds, acth); }
+  extern "C" __global__ void __launch_bounds__(WAVE * STEP_WAVES) name(const StepArgs A) { STEP_LDS step_body<WALLS, SIG, PLANE>(A, lds, ldsx, act_lds, acth, plan_lds); }
 STEP_KERNEL(go1_step_kernel, false, false, true)
 STEP_KERNEL(go1_step_kernel_hf, false, false, false)
 STEP_KERNEL(go1_step_kernel_walls, true, false, false)
@@ -284,9 +286,11 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   __shared__ float lds[L_END * EPW];
   __shared__ __attribute__((aligned(16))) float act_io[A_IO_END];
   __shared__ __attribute__((aligned(16))) float act_lds[A_END];
+  __shared__ int plan_lds[2 * GO1_REW_COUNT];
   for (int i = threadIdx.x; i < L_END * EPW; i += WAVE) lds[i] = 0.f;
-  LDS_PHASE();
   const GO1_CONSTANT SimConst* csc = (const GO1_CONSTANT SimConst*)(uintptr_t)A.sc;
+  reward_plan_to_lds(csc->rew, plan_lds, (int)threadIdx.x);
+  LDS_PHASE();
   CfgRef cfg = WAVE_CFG(csc, (int)blockIdx.x * EPW);
   BufRef B = csc->buf;
   const int N = cfg.num_envs;
@@ -298,7 +302,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) go1_aux_kernel(const StepArgs
   if (A.mode == 4) {       // tensor maps only
     PROF_DECL
     uint32_t fault = 0;
-    post_physics(cfg, B, csc->rew, lds, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs,
+    post_physics(cfg, B, plan_lds, lds, lane, e, N, A.counter + 1, v3(A.gravity_override[0], A.gravity_override[1], A.gravity_override[2]), A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs,
                  nullptr, 1 PROF_PASS);
     report_fault(B, e, fault);
     return;
