@@ -9,14 +9,19 @@
 // 4-wide on the master.
 //
 // Physics per substep (replaces gym.simulate, reference legged_robot.py:76-80; contract: DESIGN.md §2, oracle/go1_oracle.c):
-//   1. torque model: the helpers evaluate the actuator network (hidden layer on MFMA, fp16 hi/lo split) while the master runs
+//   1. torque model: the helpers build the actuator network's input rows (one row per helper lane) from the q, qd the master posts and
+//      evaluate the network (hidden layer on MFMA, fp16 hi/lo split) while the master runs
 //   2. forward kinematics + contact candidates (terrain top surface, vertical faces of a trimesh terrain, self-collision
 //      capsules), the solver's contact list (<= 24 contacts, priority order, overflow counted per class)
 //   3. Featherstone articulated-body algorithm, world-aligned frame at the base origin; base terms quad-reduced
 //   4. the rows of the solve in factorised coordinates (M^-1 = A A^T from the ABA factors): terrain contacts finished by the
 //      helpers, self-contacts and joint-limit rows by the master
-//   5. matrix-free projected Gauss-Seidel on (normal, 2 tangents | limit rows), static / dynamic Coulomb cone
+//   5. matrix-free projected Gauss-Seidel on (normal, 2 tangents | limit rows), static / dynamic Coulomb cone: trunk and body-body
+//      contacts in list order, then the four legs' contacts side by side (a lane walks through ITS leg's contacts; hip / thigh rows with
+//      mass splitting), then the limit rows
 //   6. one more impulse propagation applies all impulses; semi-implicit Euler
+// After the last substep the master runs the post-physics maps; once the callbacks and the termination test are through, helper 1 takes the
+// observations (+ history ring, roll) while the master evaluates the rewards (go1_maps.h post_physics / post_observations).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
