@@ -21,6 +21,7 @@ case $step in
   dropin) run dropin python -m pytest tests/test_gpu_env.py -q -x -s -k "unchanged_train_script" ;;
   ab) run ab python tools/probes/step_variant_ab.py $(ls walk-these-ways_amd/csrc/variants/*.so | grep -v prof) ;;
   icache) run icache tools/probes/icache_probe ;;
+  phases_rough) run phases_rough python tools/phase_profile.py --lib walk-these-ways_amd/csrc/variants/prof.so --steps 32 --rough ;;
   sweep) AB_ENVS=64,256,1024,2048,4096,8192 run sweep python tools/probes/step_variant_ab.py ;;
   phases) run phases python tools/phase_profile.py --lib walk-these-ways_amd/csrc/variants/prof.so --steps 32; run phases_standing python tools/phase_profile.py --lib walk-these-ways_amd/csrc/variants/prof.so --steps 32 --zero-actions ;;
   *) echo "unknown step $step" ;;

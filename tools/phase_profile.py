@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--lib", default=None, help="a library prebuilt with -DGO1_PROFILE (no rebuild on the GPU box, csrc/libgo1sim.so untouched)")
     ap.add_argument("--zero-actions", action="store_true", help="robots standing on four feet instead of N(0,1) actions")
+    ap.add_argument("--rough", action="store_true", help="BASELINE configs[2]: the terrain-curriculum tile grid as a trimesh terrain + height scan "
+                                                         "(go1_step_kernel_walls; the markers of workgroup 0 and the per-workgroup statistics)")
     args, extra = ap.parse_known_args()
     if args.lib is None:
         build(["-DGO1_PROFILE"] + extra)
@@ -51,8 +53,15 @@ def main():
         from go1_gym.envs.base.legged_robot_config import make_cfg
         from go1_gym.envs.go1.velocity_tracking import VelocityTrackingEasyEnv
         from scripts.train_config import apply_train_config
-        cfg = apply_train_config(make_cfg(), num_envs=args.envs)
-        env = VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg)
+        if args.rough:
+            sys.path.insert(0, REPO)
+            from bench import build_env
+            wrapped, cfg = build_env(args.envs, 0, 0, rough=True)
+            env = wrapped.env if hasattr(wrapped, "env") else wrapped
+            env.reset()
+        else:
+            cfg = apply_train_config(make_cfg(), num_envs=args.envs)
+            env = VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg)
         lib = H.load_library()
         lib.go1sim_debug_read_profile.argtypes = [ctypes.c_void_p]
         buf = (ctypes.c_uint64 * 64)()

@@ -704,15 +704,21 @@ DEV void post_physics(CfgRef cfg, BufRef B, const int* plan_lds, float* obs_stag
     const float yz = d.qz * l, yw = d.qw * l;
     const float bx = AT(B.root_states, 0, e), by = AT(B.root_states, 1, e);
     float sum = 0.f;
-#pragma unroll 1
+    const int ny = cfg.num_height_y;
+    int ix = leg / ny, iy = leg % ny;          // p = ix * ny + iy, advanced by 4 per turn (a divide and a remainder per point otherwise)
+#pragma unroll 2
     for (int p = leg; p < np; p += 4) {
-      V3 w = quat_rotate(0.f, 0.f, yz, yw, v3(cfg.height_points_x[p / cfg.num_height_y], cfg.height_points_y[p % cfg.num_height_y], 0.f));
+      V3 w = quat_rotate(0.f, 0.f, yz, yw, v3(cfg.height_points_x[ix], cfg.height_points_y[iy], 0.f));
+      iy += 4;
+      while (iy >= ny) { iy -= ny; ix++; }
       float hgt = 0.f;
       if (cfg.terrain_type != 0 && B.height_samples) {
-        // the sample index is the reference's fp32 quotient truncated (legged_robot.py:1795-1797): the library is built
-        // with approximate fp32 division, so form the correctly rounded quotient through fp64 (exact: 53 >= 2*24+2 bits)
-        long px = (long)(float)((double)(w.x + bx + cfg.hf_border) / (double)cfg.hf_hscale);
-        long py = (long)(float)((double)(w.y + by + cfg.hf_border) / (double)cfg.hf_hscale);
+        // the sample index is the reference's fp32 quotient truncated (legged_robot.py:1795-1797).  The library is built with correctly
+        // rounded fp32 division since round 4 (__graft_entry__.py SIM_FLAGS), so the plain quotient IS that value; rounds 1-3 built with the
+        // approximate divide and formed it through fp64 (53 >= 2 * 24 + 2 bits: the same number) — 2 x 187 fp64 divisions per environment-step,
+        // most of the 49 k cycles this block cost on the rough terrain (profiles/r05_step_kernel_phases_rough.txt)
+        long px = (long)((w.x + bx + cfg.hf_border) / cfg.hf_hscale);
+        long py = (long)((w.y + by + cfg.hf_border) / cfg.hf_hscale);
         px = px < 0 ? 0 : (px > cfg.hf_rows - 2 ? cfg.hf_rows - 2 : px);
         py = py < 0 ? 0 : (py > cfg.hf_cols - 2 ? cfg.hf_cols - 2 : py);
         const int16_t* q = B.height_samples + px * cfg.hf_cols + py;
