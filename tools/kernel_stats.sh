@@ -4,7 +4,7 @@ set -e
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-/tmp/go1sim_isa}
 mkdir -p "$OUT" && cd "$OUT"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize ${EXTRA_FLAGS} -c --cuda-device-only -save-temps=obj \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize ${EXTRA_FLAGS} -c --cuda-device-only -save-temps=obj \
   -o go1sim.o "$REPO/walk-these-ways_amd/csrc/go1sim.hip" 2>&1 | grep -v warning | head -5
 S=go1sim-hip-amdgcn-amd-amdhsa-gfx950.s
 for k in go1_step_kernel go1_aux_kernel; do

@@ -19,7 +19,7 @@ def rate(lib_path, zero_actions, envs=4096, steps=480):
     if lib_path:
         H.LIB_PATH, H._lib = os.path.abspath(lib_path), None
     from bench import build_env
-    env, cfg = build_env(envs, 0, 0)
+    env, cfg = build_env(envs, 0, 0, rough=bool(os.environ.get("AB_ROUGH")))      # AB_ROUGH=1: BASELINE configs[2] (height field with walls, 257 observations)
     env.reset()
     acts = (torch.zeros if zero_actions else torch.randn)(24, envs, 12, device="cuda")
     for i in range(48):
@@ -30,7 +30,6 @@ def rate(lib_path, zero_actions, envs=4096, steps=480):
         env.step(acts[i % 24])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ms = env.env.sim.read_timings() if hasattr(env.env.sim, "read_timings") else None
     return envs * steps / dt, 1e3 * dt / steps
 
 

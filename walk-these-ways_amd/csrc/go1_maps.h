@@ -422,7 +422,7 @@ DEV int reward_raw_sign(int id) {
 // them.  parts: 1 = observations + roll, 2 = privileged observations (the step kernel gives 1 to the helper and keeps 2 on the master: the
 // helper's share then takes as long as the master's rewards).  Four lanes per environment, must be called by all four.
 DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int e, int N, int64_t counter_post, V3 grav, int history_slot,
-                           uint32_t& fault, V3 pg, float clock_own, float force_z, int parts PROF_PARAM) {
+                           uint32_t& fault, V3 pg, float clock_own, float force_z, int parts, int hpart, int hparts PROF_PARAM) {
   const int leg = lane & 3;
   const bool is0 = leg == 0;
   const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
@@ -534,19 +534,6 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
         }
       }
     }
-    if ((om & O_HEIGHTS) && B.measured_heights) {      // legacy legged_gym height block (BASELINE config 3)
-      const int np = cfg.num_height_x * cfg.num_height_y;
-      const float z = AT(B.root_states, 2, e);
-#pragma unroll 1
-      for (int p = leg; p < np; p += 4) {
-        float v = fminf(fmaxf(z - 0.5f - AT(B.measured_heights, p, e), -1.f), 1.f) * cfg.obs_scale_height;
-        if ((om & O_NOISE) && cfg.height_noise_scale != 0.f) v += (2 * rng_uniform(cfg, eg, counter_post, P_NOISE, n + p) - 1) * cfg.height_noise_scale;
-        v = fminf(fmaxf(v, -o_clip), o_clip);
-        obs_row[n + p] = v;
-        if (h0) { h0[n + p] = v; h1[n + p] = v; }
-      }
-      n += np;
-    }
 
     // ---- roll (own joints): from the values fetched above -------------------------------------------------
 #pragma unroll
@@ -557,6 +544,30 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
       AT(B.last_last_joint_pos_target, j, e) = o_ljpt[jj];
       AT(B.last_joint_pos_target, j, e) = o_jpt[jj];
       AT(B.last_dof_vel, j, e) = o_qd[jj];
+    }
+  }
+  if ((parts & 5) && (om & O_HEIGHTS) && B.measured_heights) {      // legacy legged_gym height block (BASELINE config 3): the LAST columns
+    // Share hpart of hparts (points leg + 4 hpart, + 4 hparts, ...): the step kernel spreads the block over its three helper wavefronts — one
+    // generator call per point (the noise stream is indexed by the column), 47 calls per lane on one wavefront were the longest stretch of the
+    // rough-terrain step's post-physics phase (profiles/r05_step_kernel_phases_rough.txt)
+    float* obs_row = B.obs_buf + (size_t)e * o_num_obs;
+    const int R = o_hist + 1;
+    float* h0 = B.obs_history ? B.obs_history + (size_t)e * 2 * R * o_num_obs + (size_t)history_slot * o_num_obs : nullptr;
+    float* h1 = h0 ? h0 + (size_t)R * o_num_obs : nullptr;
+    const int n = ((om & O_LIN) ? 3 : 0) + ((om & O_ANG) ? 3 : 0) + ((om & O_VEL) ? 6 : 0) + 3 + ((om & O_CMD) ? o_num_cmd : 0) +
+                  ((om & O_TWO) ? 48 : 36) + ((om & O_TIMING) ? 1 : 0) + ((om & O_CLOCK) ? 4 : 0) + ((om & O_YAW) ? 1 : 0) +
+                  ((om & O_CONTACT) ? 4 : 0);                         // the columns staged before it (the running column of the block above)
+    const int np = cfg.num_height_x * cfg.num_height_y;
+    const float z = AT(B.root_states, 2, e);
+    const bool noisy = (om & O_NOISE) && cfg.height_noise_scale != 0.f;
+    const float o_s_h = cfg.obs_scale_height, o_hn = cfg.height_noise_scale;
+#pragma unroll 2
+    for (int p = leg + 4 * hpart; p < np; p += 4 * hparts) {
+      float v = fminf(fmaxf(z - 0.5f - AT(B.measured_heights, p, e), -1.f), 1.f) * o_s_h;
+      if (noisy) v += (2 * rng_uniform(cfg, eg, counter_post, P_NOISE, n + p) - 1) * o_hn;
+      v = fminf(fmaxf(v, -o_clip), o_clip);
+      obs_row[n + p] = v;
+      if (h0) { h0[n + p] = v; h1[n + p] = v; }
     }
   }
     PROF(13);
@@ -705,29 +716,54 @@ DEV void post_physics(CfgRef cfg, BufRef B, const int* plan_lds, float* obs_stag
     const float bx = AT(B.root_states, 0, e), by = AT(B.root_states, 1, e);
     float sum = 0.f;
     const int ny = cfg.num_height_y;
-    int ix = leg / ny, iy = leg % ny;          // p = ix * ny + iy, advanced by 4 per turn (a divide and a remainder per point otherwise)
-#pragma unroll 2
-    for (int p = leg; p < np; p += 4) {
-      V3 w = quat_rotate(0.f, 0.f, yz, yw, v3(cfg.height_points_x[ix], cfg.height_points_y[iy], 0.f));
-      iy += 4;
-      while (iy >= ny) { iy -= ny; ix++; }
-      float hgt = 0.f;
-      if (cfg.terrain_type != 0 && B.height_samples) {
-        // the sample index is the reference's fp32 quotient truncated (legged_robot.py:1795-1797).  The library is built with correctly
-        // rounded fp32 division since round 4 (__graft_entry__.py SIM_FLAGS), so the plain quotient IS that value; rounds 1-3 built with the
-        // approximate divide and formed it through fp64 (53 >= 2 * 24 + 2 bits: the same number) — 2 x 187 fp64 divisions per environment-step,
-        // most of the 49 k cycles this block cost on the rough terrain (profiles/r05_step_kernel_phases_rough.txt)
-        long px = (long)((w.x + bx + cfg.hf_border) / cfg.hf_hscale);
-        long py = (long)((w.y + by + cfg.hf_border) / cfg.hf_hscale);
-        px = px < 0 ? 0 : (px > cfg.hf_rows - 2 ? cfg.hf_rows - 2 : px);
-        py = py < 0 ? 0 : (py > cfg.hf_cols - 2 ? cfg.hf_cols - 2 : py);
-        const int16_t* q = B.height_samples + px * cfg.hf_cols + py;
-        int16_t hm = q[0] < q[cfg.hf_cols] ? q[0] : q[cfg.hf_cols];
-        hm = hm < q[1] ? hm : q[1];
-        hgt = hm * cfg.hf_vscale;
+    int ix = leg / ny, iy = leg % ny;          // p = ix * ny + iy, advanced by 4 per point (a divide and a remainder per point otherwise)
+    if (cfg.terrain_type != 0 && B.height_samples) {
+      // HB points per turn: all their sample loads are issued before the first is used.  One point per turn was a chain of 47 dependent
+      // round trips to L2 per lane — 49 k cycles of the rough-terrain step (profiles/r05_step_kernel_phases_rough.txt), none of it arithmetic.
+      // The sample index is the reference's fp32 quotient truncated (legged_robot.py:1795-1797); the library is built with correctly rounded
+      // fp32 division since round 4 (__graft_entry__.py SIM_FLAGS), so the plain quotient IS that value (rounds 1-3 formed it through fp64).
+      constexpr int HB = 8;
+      const long rmax = cfg.hf_rows - 2, cmax = cfg.hf_cols - 2;
+      const int cols = cfg.hf_cols;
+      const float border = cfg.hf_border, hscale = cfg.hf_hscale, vscale = cfg.hf_vscale;
+      const int16_t* __restrict__ hs = B.height_samples;
+#pragma unroll 1
+      for (int p0 = leg; p0 < np; p0 += 4 * HB) {
+        int s00[HB], s10[HB], s01[HB];
+        float gx[HB], gy[HB];
+#pragma unroll
+        for (int k = 0; k < HB; k++) {                // (1) the pattern's points: HB gathers from the configuration block, one wait
+          const bool live = p0 + 4 * k < np;          // (a dead slot of the last turn reads the cell of point 0 and is dropped)
+          gx[k] = cfg.height_points_x[live ? ix : 0];
+          gy[k] = cfg.height_points_y[live ? iy : 0];
+          iy += 4;
+          while (iy >= ny) { iy -= ny; ix++; }
+        }
+#pragma unroll
+        for (int k = 0; k < HB; k++) {                // (2) their cells: 2 loads per point (samples [0], [1] as one), one wait
+          V3 w = quat_rotate(0.f, 0.f, yz, yw, v3(gx[k], gy[k], 0.f));
+          long px = (long)((w.x + bx + border) / hscale);
+          long py = (long)((w.y + by + border) / hscale);
+          px = px < 0 ? 0 : (px > rmax ? rmax : px);
+          py = py < 0 ? 0 : (py > cmax ? cmax : py);
+          const int16_t* q = hs + px * cols + py;
+          s00[k] = q[0]; s10[k] = q[cols]; s01[k] = q[1];
+        }
+#pragma unroll
+        for (int k = 0; k < HB; k++) {
+          const int p = p0 + 4 * k;
+          if (p < np) {
+            int hm = s00[k] < s10[k] ? s00[k] : s10[k];
+            hm = hm < s01[k] ? hm : s01[k];
+            const float hgt = hm * vscale;
+            AT(B.measured_heights, p, e) = hgt;
+            sum += hgt;
+          }
+        }
       }
-      AT(B.measured_heights, p, e) = hgt;
-      sum += hgt;
+    } else {
+#pragma unroll 1
+      for (int p = leg; p < np; p += 4) AT(B.measured_heights, p, e) = 0.f;
     }
     mean_height = quad_sum(sum) / np;
   }
@@ -841,13 +877,13 @@ DEV void post_physics(CfgRef cfg, BufRef B, const int* plan_lds, float* obs_stag
 
   // ---- compute_observations (+ privileged observations, roll): post_observations() -------------------------------------------
   if (!helper_obs) {
-    post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, 3 PROF_PASS);
+    post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, 3, 0, 1 PROF_PASS);
     if (helper_flag != nullptr) BLOCK_SYNC(nw);       // S2 (the helper had nothing to do)
   } else {
-    if (__ballot(reset) == 0ull) post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, 2 PROF_PASS);
+    if (__ballot(reset) == 0ull) post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, 2, 0, 1 PROF_PASS);
     BLOCK_SYNC(nw);                                   // S2: the helper's observations are written
     if (__ballot(reset) != 0ull)                      // only through the failed-simulation guard above: this environment once more, re-initialised
-      post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, reset ? 3 : 2 PROF_PASS);
+      post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, reset ? 3 : 2, 0, 1 PROF_PASS);
   }
   PROF(14);
   PROF(15);

@@ -438,18 +438,30 @@ DEV void cand_init(Cand& c) { c.phi = 1e30f; c.x = c.y = c.z = c.un = 0.f; c.nx 
 // next to the point: unit horizontal normal (towards the low side), horizontal distance, height of its upper edge
 // (oracle terrain_sample(): the `trimesh` terrain's slope_treshold restated per cell of the height field).
 struct Wall { bool on; V3 n; float d, top; int cell; };
-template <bool WALLS, bool PLANE = false>
-DEV void terrain_sample(CfgRef cfg, const int16_t* __restrict__ hs, float x, float y, float& h, V3& n, Wall& wall) {
-  wall.on = false; wall.n = v3(1.f, 0.f, 0.f); wall.d = 0.f; wall.top = 0.f; wall.cell = 0;
-  if (PLANE || cfg.terrain_type == 0 || hs == nullptr) { h = 0.f; n = v3(0.f, 0.f, 1.f); return; }
+// The sample in two halves, so that a caller can have the loads of several points in flight before it evaluates the first (one point at a
+// time, a lane's 21 candidate points per substep were 21 dependent round trips to L2: profiles/r05_step_kernel_phases_rough.txt):
+// terrain_fetch() = cell, in-cell coordinates and the four int16 loads; terrain_eval() = everything computed from them.
+struct TerrFetch { float ax, ay; int cell, p00, p01, p10, p11; bool flat; };
+DEV void terrain_fetch(CfgRef cfg, const int16_t* __restrict__ hs, float x, float y, TerrFetch& f) {
+  f.flat = cfg.terrain_type == 0 || hs == nullptr;
+  f.ax = f.ay = 0.f; f.cell = 0; f.p00 = f.p01 = f.p10 = f.p11 = 0;
+  if (f.flat) return;
   float fx = (x + cfg.hf_border) / cfg.hf_hscale, fy = (y + cfg.hf_border) / cfg.hf_hscale;
   fx = fminf(fmaxf(fx, 0.f), (float)cfg.hf_rows - 1.000001f);
   fy = fminf(fmaxf(fy, 0.f), (float)cfg.hf_cols - 1.000001f);
   const int ix = (int)fx, iy = (int)fy;
-  const float ax = fx - ix, ay = fy - iy;
-  wall.cell = ix * cfg.hf_cols + iy;
+  f.ax = fx - ix; f.ay = fy - iy;
+  f.cell = ix * cfg.hf_cols + iy;
   const int16_t* p = hs + (size_t)ix * cfg.hf_cols + iy;
-  const int p00 = p[0], p01 = p[1], p10 = p[cfg.hf_cols], p11 = p[cfg.hf_cols + 1];
+  f.p00 = p[0]; f.p01 = p[1]; f.p10 = p[cfg.hf_cols]; f.p11 = p[cfg.hf_cols + 1];
+}
+template <bool WALLS>
+DEV void terrain_eval(CfgRef cfg, const TerrFetch& f, float& h, V3& n, Wall& wall) {
+  wall.on = false; wall.n = v3(1.f, 0.f, 0.f); wall.d = 0.f; wall.top = 0.f; wall.cell = 0;
+  if (f.flat) { h = 0.f; n = v3(0.f, 0.f, 1.f); return; }
+  const float ax = f.ax, ay = f.ay;
+  const int p00 = f.p00, p01 = f.p01, p10 = f.p10, p11 = f.p11;
+  wall.cell = f.cell;
   float h00 = p00 * cfg.hf_vscale, h01 = p01 * cfg.hf_vscale, h10 = p10 * cfg.hf_vscale, h11 = p11 * cfg.hf_vscale;
   if (WALLS) {
     const int T = cfg.hf_wall_units;
@@ -488,16 +500,19 @@ DEV void terrain_sample(CfgRef cfg, const int16_t* __restrict__ hs, float x, flo
   const float inv = rsqrtf(dhdx * dhdx + dhdy * dhdy + 1.f);
   n = v3(-dhdx * inv, -dhdy * inv, inv);
 }
+template <bool WALLS, bool PLANE = false>
+DEV void terrain_sample(CfgRef cfg, const int16_t* __restrict__ hs, float x, float y, float& h, V3& n, Wall& wall) {
+  if (PLANE) { wall.on = false; wall.n = v3(1.f, 0.f, 0.f); wall.d = 0.f; wall.top = 0.f; wall.cell = 0; h = 0.f; n = v3(0.f, 0.f, 1.f); return; }
+  TerrFetch f;
+  terrain_fetch(cfg, hs, x, y, f);
+  terrain_eval<WALLS>(cfg, f, h, n, wall);
+}
 
 // x: candidate point relative to the base origin (world axes); bpos: world position of the base origin.  c: deepest
 // top-surface candidate of the point's group, cw: closest wall candidate of its shape
 // WANTW: also keep the wall candidate (hip capsules do not: their points are too high up to meet a riser)
-template <bool WALLS, bool WANTW = WALLS, bool PLANE = false>
-DEV void cand_try(CfgRef cfg, const int16_t* __restrict__ hs, Cand& c, Cand& cw, V3 x, V3 bpos, float radius, SV vb, int m) {
-  float h;
-  V3 n;
-  Wall wl;
-  terrain_sample<WALLS, PLANE>(cfg, hs, bpos.x + x.x, bpos.y + x.y, h, n, wl);
+template <bool WALLS, bool WANTW>
+DEV void cand_take(Cand& c, Cand& cw, float h, V3 n, const Wall& wl, V3 x, V3 bpos, float radius, SV vb, int m) {
   const float phi = (bpos.z + x.z) - radius - h;
   if (phi < c.phi) {
     const V3 xs = x - radius * n;               // contact point on the shape surface
@@ -516,6 +531,23 @@ DEV void cand_try(CfgRef cfg, const int16_t* __restrict__ hs, Cand& c, Cand& cw,
       cw.tag = 16u * (uint32_t)wl.cell + (uint32_t)m;
     }
   }
+}
+template <bool WALLS, bool WANTW = WALLS, bool PLANE = false>
+DEV void cand_try(CfgRef cfg, const int16_t* __restrict__ hs, Cand& c, Cand& cw, V3 x, V3 bpos, float radius, SV vb, int m) {
+  float h;
+  V3 n;
+  Wall wl;
+  terrain_sample<WALLS, PLANE>(cfg, hs, bpos.x + x.x, bpos.y + x.y, h, n, wl);
+  cand_take<WALLS, WANTW>(c, cw, h, n, wl, x, bpos, radius, vb, m);
+}
+// the same from a sample fetched earlier (terrain_fetch at bpos + x)
+template <bool WALLS, bool WANTW = WALLS>
+DEV void cand_eval(CfgRef cfg, const TerrFetch& f, Cand& c, Cand& cw, V3 x, V3 bpos, float radius, SV vb, int m) {
+  float h;
+  V3 n;
+  Wall wl;
+  terrain_eval<WALLS>(cfg, f, h, n, wl);
+  cand_take<WALLS, WANTW>(c, cw, h, n, wl, x, bpos, radius, vb, m);
 }
 DEV void cand_min_dpp(Cand& c, int lane) {      // quad-wide deepest candidate (ties: lower leg index, as the serial scan)
 #pragma unroll
@@ -806,6 +838,17 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
   const M3 R0 = quat_to_mat(s.qx, s.qy, s.qz, s.qw);
   const SV v0 = sv(s.w, s.v);
   const float cd = cfg.contact_distance;
+  // (height field: the samples under the lane's two trunk corners are requested here and used after the base-body block)
+  TerrFetch fb[2];
+  V3 xb[2];
+  if (!PLANE) {
+#pragma unroll
+    for (int mm = 0; mm < 2; mm++) {
+      const int m = 2 * leg + mm;
+      xb[mm] = mul(R0, v3((m & 1 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[2]));
+      terrain_fetch(cfg, hs, s.pos.x + xb[mm].x, s.pos.y + xb[mm].y, fb[mm]);
+    }
+  }
   // ---- base body (replicated) ----------------------------------------------------------------------
   Sym6 IA0;
   SV pA0;
@@ -829,8 +872,10 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
   for (int mm = 0; mm < 2; mm++) {
     cand_init(cb[mm]);
     const int m = 2 * leg + mm;
-    V3 l = v3((m & 1 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[2]);
-    cand_try<WALLS, WALLS, PLANE>(cfg, hs, cb[mm], cwb, mul(R0, l), s.pos, 0.f, v0, m);
+    if (PLANE) {
+      V3 l = v3((m & 1 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[2]);
+      cand_try<WALLS, WALLS, PLANE>(cfg, hs, cb[mm], cwb, mul(R0, l), s.pos, 0.f, v0, m);
+    } else cand_eval<WALLS, WALLS>(cfg, fb[mm], cb[mm], cwb, xb[mm], s.pos, 0.f, v0, m);
   }
   if (WALLS) cand_min_dpp(cwb, lane);
 
@@ -881,15 +926,15 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
       Cand nowall;
       cand_init(nowall);
       V3 hc = model_v3(GO1_HIP_CAPSULE_CENTER, leg);
+      if (PLANE) {
 #pragma unroll
-      for (int m = 0; m < 2; m++) {
-        V3 l = v3(hc.x, hc.y + (m ? 1.f : -1.f) * (float)GO1_HIP_CAPSULE_HALF, hc.z);
-        cand_try<WALLS, false, PLANE>(cfg, hs, ch[m], nowall, p[0] + mul(R[0], l), s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0], m);      // (same top surface as every other shape)
-      }
+        for (int m = 0; m < 2; m++) {
+          V3 l = v3(hc.x, hc.y + (m ? 1.f : -1.f) * (float)GO1_HIP_CAPSULE_HALF, hc.z);
+          cand_try<WALLS, false, PLANE>(cfg, hs, ch[m], nowall, p[0] + mul(R[0], l), s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0], m);      // (same top surface as every other shape)
+        }
 #ifndef GO1_ABLATE_CAND
 #pragma unroll
-      for (int en = 0; en < 2; en++) {       // thigh / calf boxes: long axis z -> ends by the sign of z (corner bit 2)
-        if (PLANE) {
+        for (int en = 0; en < 2; en++) {       // thigh / calf boxes: long axis z -> ends by the sign of z (corner bit 2)
           // on the plane the deepest corner of an end minimises z = ... + sx hx R.c0.z + sy hy R.c1.z: sx = -sign(R.c0.z), sy likewise
           // (ties: the lower corner index, i.e. the negative sign — the order the scan over the corners resolves them in)
           const int mt = (R[1].c0.z < 0.f ? 1 : 0) | (R[1].c1.z < 0.f ? 2 : 0) | (4 * en);
@@ -902,25 +947,60 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
                            GO1_CALF_BOX_CENTER[2] + (mk & 4 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[2]);
           cand_try<false, false, true>(cfg, hs, ct[en], cwt, p[1] + mul(R[1], lt), s.pos, 0.f, v[1], mt);
           cand_try<false, false, true>(cfg, hs, ck[en], cwk, p[2] + mul(R[2], lk), s.pos, 0.f, v[2], mk);
-        } else {
+        }
+#endif
+        cand_try<WALLS, WALLS, PLANE>(cfg, hs, cf, cwf, p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2], 0);
+      } else {
+        // Height field: 19 points per lane (2 hip capsule ends, 8 + 8 box corners, the foot), each a cell look-up.  The look-ups run one
+        // AHEAD of the evaluations: the hip ends', the foot's and the first thigh corner's loads are requested together, and every turn of the
+        // corner loops requests the next corner's sample before it evaluates its own (the candidates of a group are still tried in corner
+        // order, which is what decides ties)
+        auto thigh_corner = [&](int m) {
+          return p[1] + mul(R[1], v3(GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[0],
+                                     GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[1],
+                                     GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[2]));
+        };
+        auto calf_corner = [&](int m) {
+          return p[2] + mul(R[2], v3(GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[0],
+                                     GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[1],
+                                     GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[2]));
+        };
+        TerrFetch fh[2], ff, cur, nxt;
+        V3 xh[2], xc, xn;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+          xh[m] = p[0] + mul(R[0], v3(hc.x, hc.y + (m ? 1.f : -1.f) * (float)GO1_HIP_CAPSULE_HALF, hc.z));
+          terrain_fetch(cfg, hs, s.pos.x + xh[m].x, s.pos.y + xh[m].y, fh[m]);
+        }
+        const V3 xf = p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg));
+        terrain_fetch(cfg, hs, s.pos.x + xf.x, s.pos.y + xf.y, ff);
+#ifndef GO1_ABLATE_CAND
+        xc = thigh_corner(0);
+        terrain_fetch(cfg, hs, s.pos.x + xc.x, s.pos.y + xc.y, cur);
+#endif
+#pragma unroll
+        for (int m = 0; m < 2; m++) cand_eval<WALLS, false>(cfg, fh[m], ch[m], nowall, xh[m], s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0], m);
+        cand_eval<WALLS, WALLS>(cfg, ff, cf, cwf, xf, s.pos, (float)GO1_FOOT_RADIUS, v[2], 0);
+#ifndef GO1_ABLATE_CAND
+#pragma unroll
+        for (int en = 0; en < 2; en++) {       // thigh / calf boxes: long axis z -> ends by the sign of z (corner bit 2)
 #pragma unroll 1
           for (int m = 4 * en; m < 4 * en + 4; m++) {
-            V3 l = v3(GO1_THIGH_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[0],
-                      GO1_THIGH_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[1],
-                      GO1_THIGH_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_THIGH_BOX_HALF[2]);
-            cand_try<WALLS>(cfg, hs, ct[en], cwt, p[1] + mul(R[1], l), s.pos, 0.f, v[1], m);
+            xn = (m == 4 * en + 3) ? calf_corner(4 * en) : thigh_corner(m + 1);
+            terrain_fetch(cfg, hs, s.pos.x + xn.x, s.pos.y + xn.y, nxt);
+            cand_eval<WALLS>(cfg, cur, ct[en], cwt, xc, s.pos, 0.f, v[1], m);
+            cur = nxt; xc = xn;
           }
 #pragma unroll 1
           for (int m = 4 * en; m < 4 * en + 4; m++) {
-            V3 l = v3(GO1_CALF_BOX_CENTER[0] + (m & 1 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[0],
-                      GO1_CALF_BOX_CENTER[1] + (m & 2 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[1],
-                      GO1_CALF_BOX_CENTER[2] + (m & 4 ? 1.f : -1.f) * GO1_CALF_BOX_HALF[2]);
-            cand_try<WALLS>(cfg, hs, ck[en], cwk, p[2] + mul(R[2], l), s.pos, 0.f, v[2], m);
+            xn = (m == 4 * en + 3) ? thigh_corner((4 * en + 4) & 7) : calf_corner(m + 1);      // (after the last corner: a sample nobody uses)
+            terrain_fetch(cfg, hs, s.pos.x + xn.x, s.pos.y + xn.y, nxt);
+            cand_eval<WALLS>(cfg, cur, ck[en], cwk, xc, s.pos, 0.f, v[2], m);
+            cur = nxt; xc = xn;
           }
         }
-      }
 #endif
-      cand_try<WALLS, WALLS, PLANE>(cfg, hs, cf, cwf, p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg)), s.pos, (float)GO1_FOOT_RADIUS, v[2], 0);
+      }
       pthigh = p[1]; pknee = p[2]; pfoot = p[2] + mul(R[2], model_v3(GO1_FOOT_OFFSET, leg));
       vthigh = v[1]; vlow = v[2]; vhip = v[0];
       {
