@@ -620,6 +620,9 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
 // helper is through).  The helper does NOT go when an environment of the wavefront resets (the observations then read the re-initialised
 // state, which exists only after the rewards: master as before).  A reset that only the rewards bring about (a non-finite term: the
 // failed-simulation guard) is met after S2 by evaluating the observations of that environment again.
+// PLANE: the step kernel's plane instance (terrain_type 0 or no samples bound — go1sim.hip picks it on exactly that test): the height-field
+// branches are not compiled into it
+template <bool PLANE = false>
 DEV void post_physics(CfgRef cfg, BufRef B, const int* plan_lds, float* obs_stage, int lane, int e, int N, int64_t counter_post, V3 grav,
                       int history_slot, uint32_t& fault, bool is_eval, float* helper_flag, int nw PROF_PARAM) {
   const int leg = lane & 3;
@@ -717,7 +720,7 @@ DEV void post_physics(CfgRef cfg, BufRef B, const int* plan_lds, float* obs_stag
     float sum = 0.f;
     const int ny = cfg.num_height_y;
     int ix = leg / ny, iy = leg % ny;          // p = ix * ny + iy, advanced by 4 per point (a divide and a remainder per point otherwise)
-    if (cfg.terrain_type != 0 && B.height_samples) {
+    if (!PLANE && cfg.terrain_type != 0 && B.height_samples) {
       // HB points per turn: all their sample loads are issued before the first is used.  One point per turn was a chain of 47 dependent
       // round trips to L2 per lane — 49 k cycles of the rough-terrain step (profiles/r05_step_kernel_phases_rough.txt), none of it arithmetic.
       // The sample index is the reference's fp32 quotient truncated (legged_robot.py:1795-1797); the library is built with correctly rounded
@@ -771,8 +774,8 @@ DEV void post_physics(CfgRef cfg, BufRef B, const int* plan_lds, float* obs_stag
   F.hz = F.pos.z;
   d.base_hz = d.base_pos.z;
   if ((fm & F_ABOVE)) {
-    F.hz -= hf_sample_min3(cfg, B.height_samples, F.pos.x, F.pos.y);
-    d.base_hz -= ((fm & F_MEAS) && B.measured_heights) ? mean_height : hf_sample_min3(cfg, B.height_samples, d.base_pos.x, d.base_pos.y);
+    F.hz -= PLANE ? 0.f : hf_sample_min3(cfg, B.height_samples, F.pos.x, F.pos.y);
+    d.base_hz -= ((fm & F_MEAS) && B.measured_heights) ? mean_height : (PLANE ? 0.f : hf_sample_min3(cfg, B.height_samples, d.base_pos.x, d.base_pos.y));
   }
   // ---- check_termination ---------------------------------------------------------------------------
   PROF(10);

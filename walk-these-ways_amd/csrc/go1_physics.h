@@ -541,8 +541,17 @@ DEV void cand_try(CfgRef cfg, const int16_t* __restrict__ hs, Cand& c, Cand& cw,
   cand_take<WALLS, WANTW>(c, cw, h, n, wl, x, bpos, radius, vb, m);
 }
 // the same from a sample fetched earlier (terrain_fetch at bpos + x)
+// cd: the contact distance.  A point further than cd above the HIGHEST of its cell's four samples cannot become a contact — the bilinear
+// surface (and, with walls, the lowered one and the risers' upper edges) lies at or below that sample — and is dropped before the
+// evaluation: a group's candidate is only ever read where its depth is below cd (contact list below), so the list does not change.
+// (The margin covers the rounding of the interpolation weights' sum.)  A walking robot's trunk, hips and thighs take this exit.
 template <bool WALLS, bool WANTW = WALLS>
-DEV void cand_eval(CfgRef cfg, const TerrFetch& f, Cand& c, Cand& cw, V3 x, V3 bpos, float radius, SV vb, int m) {
+DEV void cand_eval(CfgRef cfg, const TerrFetch& f, Cand& c, Cand& cw, V3 x, V3 bpos, float radius, SV vb, int m, float cd) {
+  {
+    const float vs = cfg.hf_vscale;
+    const float top = fmaxf(fmaxf(f.p00 * vs, f.p01 * vs), fmaxf(f.p10 * vs, f.p11 * vs));
+    if ((bpos.z + x.z) - radius - (top + 1e-4f + 1e-5f * fabsf(top)) >= cd) return;
+  }
   float h;
   V3 n;
   Wall wl;
@@ -875,7 +884,7 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
     if (PLANE) {
       V3 l = v3((m & 1 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[0], (m & 2 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[1], (m & 4 ? 1.f : -1.f) * GO1_TRUNK_BOX_HALF[2]);
       cand_try<WALLS, WALLS, PLANE>(cfg, hs, cb[mm], cwb, mul(R0, l), s.pos, 0.f, v0, m);
-    } else cand_eval<WALLS, WALLS>(cfg, fb[mm], cb[mm], cwb, xb[mm], s.pos, 0.f, v0, m);
+    } else cand_eval<WALLS, WALLS>(cfg, fb[mm], cb[mm], cwb, xb[mm], s.pos, 0.f, v0, m, cd);
   }
   if (WALLS) cand_min_dpp(cwb, lane);
 
@@ -979,8 +988,8 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
         terrain_fetch(cfg, hs, s.pos.x + xc.x, s.pos.y + xc.y, cur);
 #endif
 #pragma unroll
-        for (int m = 0; m < 2; m++) cand_eval<WALLS, false>(cfg, fh[m], ch[m], nowall, xh[m], s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0], m);
-        cand_eval<WALLS, WALLS>(cfg, ff, cf, cwf, xf, s.pos, (float)GO1_FOOT_RADIUS, v[2], 0);
+        for (int m = 0; m < 2; m++) cand_eval<WALLS, false>(cfg, fh[m], ch[m], nowall, xh[m], s.pos, (float)GO1_HIP_CAPSULE_RADIUS, v[0], m, cd);
+        cand_eval<WALLS, WALLS>(cfg, ff, cf, cwf, xf, s.pos, (float)GO1_FOOT_RADIUS, v[2], 0, cd);
 #ifndef GO1_ABLATE_CAND
 #pragma unroll
         for (int en = 0; en < 2; en++) {       // thigh / calf boxes: long axis z -> ends by the sign of z (corner bit 2)
@@ -988,14 +997,14 @@ DEV void physics_substep(CfgRef cfg, BufRef B, const SolverLds& Z, int lane, int
           for (int m = 4 * en; m < 4 * en + 4; m++) {
             xn = (m == 4 * en + 3) ? calf_corner(4 * en) : thigh_corner(m + 1);
             terrain_fetch(cfg, hs, s.pos.x + xn.x, s.pos.y + xn.y, nxt);
-            cand_eval<WALLS>(cfg, cur, ct[en], cwt, xc, s.pos, 0.f, v[1], m);
+            cand_eval<WALLS>(cfg, cur, ct[en], cwt, xc, s.pos, 0.f, v[1], m, cd);
             cur = nxt; xc = xn;
           }
 #pragma unroll 1
           for (int m = 4 * en; m < 4 * en + 4; m++) {
             xn = (m == 4 * en + 3) ? thigh_corner((4 * en + 4) & 7) : calf_corner(m + 1);      // (after the last corner: a sample nobody uses)
             terrain_fetch(cfg, hs, s.pos.x + xn.x, s.pos.y + xn.y, nxt);
-            cand_eval<WALLS>(cfg, cur, ck[en], cwk, xc, s.pos, 0.f, v[2], m);
+            cand_eval<WALLS>(cfg, cur, ck[en], cwk, xc, s.pos, 0.f, v[2], m, cd);
             cur = nxt; xc = xn;
           }
         }

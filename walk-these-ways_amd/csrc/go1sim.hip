@@ -264,8 +264,8 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
   PROF(7);
 #ifndef GO1_ABLATE_POST
   if (!substep_only)
-    post_physics(cfg, B, plan_lds, lds, lane, e, N, A.counter + 1, grav, A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs,
-                 nw > 1 ? acth : nullptr, nw PROF_PASS);
+    post_physics<PLANE>(cfg, B, plan_lds, lds, lane, e, N, A.counter + 1, grav, A.history_slot, fault, (int)blockIdx.x * EPW >= csc->num_train_envs,
+                        nw > 1 ? acth : nullptr, nw PROF_PASS);
 #endif
   report_fault(B, e, fault);
   report_drops(B, drops);
