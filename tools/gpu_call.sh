@@ -20,6 +20,8 @@ case $step in
   gputests) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt TMO=1500 run gputests python -m pytest tests/ -x -q -m gpu --durations=30 ;;
   dropin) run dropin python -m pytest tests/test_gpu_env.py -q -x -s -k "unchanged_train_script" ;;
   ab) run ab python tools/probes/step_variant_ab.py $(ls walk-these-ways_amd/csrc/variants/*.so | grep -v prof) ;;
+  ab_resets) AB_RESETS=1 run ab_resets python tools/probes/step_variant_ab.py $(ls walk-these-ways_amd/csrc/variants/*.so | grep -v "prof\|r04") ;;
+  ab_rough_resets) AB_RESETS=1 AB_ROUGH=1 AB_REPS=3 run ab_rough_resets python tools/probes/step_variant_ab.py $(ls walk-these-ways_amd/csrc/variants/*.so | grep -v "prof\|r04") ;;
   ab_rough) AB_ROUGH=1 AB_REPS=3 run ab_rough python tools/probes/step_variant_ab.py $(ls walk-these-ways_amd/csrc/variants/*.so | grep -v "prof\|r04") ;;
   icache) run icache tools/probes/icache_probe ;;
   phases_rough) run phases_rough python tools/phase_profile.py --lib walk-these-ways_amd/csrc/variants/prof.so --steps 32 --rough ;;

@@ -21,6 +21,9 @@ def rate(lib_path, zero_actions, envs=4096, steps=480):
     from bench import build_env
     env, cfg = build_env(envs, 0, 0, rough=bool(os.environ.get("AB_ROUGH")))      # AB_ROUGH=1: BASELINE configs[2] (height field with walls, 257 observations)
     env.reset()
+    if os.environ.get("AB_RESETS"):      # AB_RESETS=1: episode lengths spread over the horizon as the runner leaves them (ppo_cse/__init__.py:113) — about
+        buf = env.episode_length_buf     # envs / max_episode_length time-outs per step, so nearly every launch holds a workgroup that resets
+        buf.copy_(torch.randint_like(buf, high=int(env.max_episode_length)))
     acts = (torch.zeros if zero_actions else torch.randn)(24, envs, 12, device="cuda")
     for i in range(48):
         env.step(acts[i % 24])

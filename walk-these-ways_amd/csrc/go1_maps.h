@@ -45,10 +45,41 @@ DEV V3 gravity_at(CfgRef cfg, int64_t t) {
 // ================================================================================================
 DEV float fmod1(float x) { float r = fmodf(x, 1.0f); return r < 0.f ? r + 1.0f : r; }
 
+// Where the sampling functions below take their uniform draws from.  RngDirect: generated where they are used, one Philox call per draw
+// (rng_uniform).  RngTable: read from a table the environment's four lanes filled together (reset_rng_table) — the reset of an environment
+// draws 60 numbers from 17 generator blocks, and as 60 calls on one lane they were more than half of the ~80 k cycles a reset added to its
+// workgroup's step (and the step kernel's launch lasts as long as its slowest workgroup: with random episode lengths some environment of the
+// 4096 resets in nearly every step).  The same (environment, step, purpose, index) -> number map either way.
+struct RngDirect {
+  CfgRef cfg; uint32_t eg; int64_t step;
+  DEV float operator()(uint32_t purpose, uint32_t idx) const { return rng_uniform(cfg, eg, step, purpose, idx); }
+};
+enum { RT_CMD = 0, RT_DOF = 20, RT_RIGID = 36, RT_RESET = 44, RT_END = 68, RT_BLOCKS = RT_END / 4 };      // table layout: block-aligned runs per purpose
+static_assert(RT_END <= GO1_MAX_OBS, "the reset's table of draws lives in the environment's observation staging row");
+struct RngTable {
+  const float* t;
+  DEV float operator()(uint32_t purpose, uint32_t idx) const {
+    return t[(purpose == P_CMD_RESET ? RT_CMD : purpose == P_DOFPROPS_RESET ? RT_DOF : purpose == P_RIGID_RESET ? RT_RIGID : RT_RESET) + idx];
+  }
+};
+// the four lanes of an environment (leg = 0 .. 3) fill its table: block b by lane b & 3.  Indices used: P_CMD_RESET 0 .. 17, P_DOFPROPS_RESET
+// 0 .. 14, P_RIGID_RESET 0 .. 5, P_RESET 0 .. 20 (resample_commands / randomize_* / reset_env below)
+DEV void reset_rng_table(CfgRef cfg, uint32_t eg, int64_t step, float* t, int leg) {
+#pragma unroll 1
+  for (int b = leg; b < RT_BLOCKS; b += 4) {
+    const uint32_t purpose = 4 * b < RT_DOF ? P_CMD_RESET : 4 * b < RT_RIGID ? P_DOFPROPS_RESET : 4 * b < RT_RESET ? P_RIGID_RESET : P_RESET;
+    const uint32_t blk = 4 * b < RT_DOF ? b : 4 * b < RT_RIGID ? b - RT_DOF / 4 : 4 * b < RT_RESET ? b - RT_RIGID / 4 : b - RT_RESET / 4;
+    uint32_t out[4];
+    philox4x32_10(eg, (uint32_t)step, purpose, blk, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), out);
+#pragma unroll
+    for (int i = 0; i < 4; i++) t[4 * b + i] = u32_to_unit(out[i]);
+  }
+}
+
 // slot_step: the policy step the success bookkeeping belongs to (oracle resample_commands()): slot slot_step % curriculum_update_interval
-DEV void resample_commands(CfgRef cfg, BufRef B, int e, int N, int64_t step, uint32_t purpose, int64_t slot_step) {
+template <class Rng>
+DEV void resample_commands_t(CfgRef cfg, BufRef B, int e, int N, uint32_t purpose, int64_t slot_step, const Rng& rng) {
   if (cfg.device_curriculum) {
-    const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
     const int ep_len = cfg.max_episode_length < cfg.resample_interval ? cfg.max_episode_length : cfg.resample_interval;
     bool ok = cfg.curriculum_keys != 0;
 #pragma unroll 1
@@ -59,7 +90,7 @@ DEV void resample_commands(CfgRef cfg, BufRef B, int e, int N, int64_t step, uin
     }
     int cat_old = B.env_command_categories[e], bin_old = B.env_command_bins[e];
     if (ok) atomicAdd(&B.curriculum_success[((int)(slot_step % cfg.curriculum_update_interval) * cfg.num_categories + cat_old) * cfg.num_bins + bin_old], 1);
-    float u0 = rng_uniform(cfg, eg, step, purpose, 0), u1 = rng_uniform(cfg, eg, step, purpose, 1);
+    float u0 = rng(purpose, 0), u1 = rng(purpose, 1);
     int cat = (int)(u0 * cfg.num_categories);
     if (cat >= cfg.num_categories) cat = cfg.num_categories - 1;
     const float* cdf = B.curriculum_cdf + (size_t)cat * cfg.num_bins;
@@ -80,7 +111,7 @@ DEV void resample_commands(CfgRef cfg, BufRef B, int e, int N, int64_t step, uin
       rem /= nb;
       float bs = (cfg.grid_high[kx] - cfg.grid_low[kx]) / nb;
       float centroid = cfg.grid_low[kx] + bs * (idx + 0.5f);
-      float u = rng_uniform(cfg, eg, step, purpose, 2 + kx);
+      float u = rng(purpose, 2 + kx);
       cmd[kx] = centroid + (u - 0.5f) * bs;
     }
     if (cfg.num_commands > 5) {
@@ -90,13 +121,13 @@ DEV void resample_commands(CfgRef cfg, BufRef B, int e, int N, int64_t step, uin
         else if (cat == 2) { cmd[5] = 0.f; cmd[6] = cmd[6] / 2 + 0.25f; cmd[7] = 0.f; }
         else { cmd[5] = 0.f; cmd[6] = 0.f; cmd[7] = cmd[7] / 2 + 0.25f; }
       } else if (cfg.exclusive_phase_offset) {            // legged_robot.py:783-793: one of phase / offset / bound survives
-        const float r = rng_uniform(cfg, eg, step, purpose, 2 + GO1_MAX_COMMANDS);
+        const float r = rng(purpose, 2 + GO1_MAX_COMMANDS);
         const bool trot = r < 0.34f, pace = 0.34f <= r && r < 0.67f, bnd = 0.67f <= r;
         if (pace || bnd) cmd[5] = 0.f;
         if (trot || bnd) cmd[6] = 0.f;
         if (trot || pace) cmd[7] = 0.f;
       } else if (cfg.balance_gait_distribution) {         // :795-812, same statement order (the 0.25 boundary belongs to two sets)
-        const float r = rng_uniform(cfg, eg, step, purpose, 2 + GO1_MAX_COMMANDS);
+        const float r = rng(purpose, 2 + GO1_MAX_COMMANDS);
         const bool pronk = r <= 0.25f, trot = 0.25f <= r && r < 0.50f, pace = 0.50f <= r && r < 0.75f, bnd = 0.75f <= r;
         if (pronk) { cmd[5] = fmod1(cmd[5] / 2 - 0.25f); cmd[6] = fmod1(cmd[6] / 2 - 0.25f); cmd[7] = fmod1(cmd[7] / 2 - 0.25f); }
         if (trot) { cmd[6] = 0.f; cmd[7] = 0.f; }
@@ -121,94 +152,109 @@ DEV void resample_commands(CfgRef cfg, BufRef B, int e, int N, int64_t step, uin
 #pragma unroll 1
   for (int kx = 0; kx < cfg.num_rewards + 5; kx++) AT(B.command_sums, kx, e) = 0.f;
 }
+DEV void resample_commands(CfgRef cfg, BufRef B, int e, int N, int64_t step, uint32_t purpose, int64_t slot_step) {
+  resample_commands_t(cfg, B, e, N, purpose, slot_step, RngDirect{cfg, (uint32_t)(cfg.env_id_offset + e), step});
+}
 
-DEV void randomize_dof_props(CfgRef cfg, BufRef B, int e, int N, int64_t step, uint32_t purpose) {
-  const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
+// j0, js: the joints this lane writes (0, 1: all of them; leg, 4: one lane of the environment's four)
+template <class Rng>
+DEV void randomize_dof_props_t(CfgRef cfg, BufRef B, int e, int N, uint32_t purpose, const Rng& rng, int j0, int js) {
   if (cfg.randomize_motor_strength) {
-    float v = rng_uniform(cfg, eg, step, purpose, 0) * (cfg.motor_strength_range[1] - cfg.motor_strength_range[0]) + cfg.motor_strength_range[0];
+    float v = rng(purpose, 0) * (cfg.motor_strength_range[1] - cfg.motor_strength_range[0]) + cfg.motor_strength_range[0];
 #pragma unroll 1
-    for (int j = 0; j < 12; j++) AT(B.motor_strengths, j, e) = v;
+    for (int j = j0; j < 12; j += js) AT(B.motor_strengths, j, e) = v;
   }
   if (cfg.randomize_motor_offset) {
 #pragma unroll 1
-    for (int j = 0; j < 12; j++)
-      AT(B.motor_offsets, j, e) = rng_uniform(cfg, eg, step, purpose, 1 + j) * (cfg.motor_offset_range[1] - cfg.motor_offset_range[0]) + cfg.motor_offset_range[0];
+    for (int j = j0; j < 12; j += js)
+      AT(B.motor_offsets, j, e) = rng(purpose, 1 + j) * (cfg.motor_offset_range[1] - cfg.motor_offset_range[0]) + cfg.motor_offset_range[0];
   }
   if (cfg.randomize_Kp_factor) {
-    float v = rng_uniform(cfg, eg, step, purpose, 13) * (cfg.Kp_factor_range[1] - cfg.Kp_factor_range[0]) + cfg.Kp_factor_range[0];
+    float v = rng(purpose, 13) * (cfg.Kp_factor_range[1] - cfg.Kp_factor_range[0]) + cfg.Kp_factor_range[0];
 #pragma unroll 1
-    for (int j = 0; j < 12; j++) AT(B.Kp_factors, j, e) = v;
+    for (int j = j0; j < 12; j += js) AT(B.Kp_factors, j, e) = v;
   }
   if (cfg.randomize_Kd_factor) {
-    float v = rng_uniform(cfg, eg, step, purpose, 14) * (cfg.Kd_factor_range[1] - cfg.Kd_factor_range[0]) + cfg.Kd_factor_range[0];
+    float v = rng(purpose, 14) * (cfg.Kd_factor_range[1] - cfg.Kd_factor_range[0]) + cfg.Kd_factor_range[0];
 #pragma unroll 1
-    for (int j = 0; j < 12; j++) AT(B.Kd_factors, j, e) = v;
+    for (int j = j0; j < 12; j += js) AT(B.Kd_factors, j, e) = v;
   }
+}
+DEV void randomize_dof_props(CfgRef cfg, BufRef B, int e, int N, int64_t step, uint32_t purpose) {
+  randomize_dof_props_t(cfg, B, e, N, purpose, RngDirect{cfg, (uint32_t)(cfg.env_id_offset + e), step}, 0, 1);
 }
 
 // _randomize_rigid_body_props when called from the step callback (randomize_rigids_after_start, legged_robot.py:706-708).
 // Deviation, documented in DESIGN.md: the reference re-draws payload / COM into its tensors but never pushes them into
 // PhysX (only friction / restitution of the first 12 of 17 shapes are refreshed, App. D9), so there the privileged
 // observation stops describing the simulated body; here the re-drawn values ARE the simulated body, whole robot.
-DEV void randomize_rigid_props(CfgRef cfg, BufRef B, int e, int N, int64_t step, uint32_t purpose) {
-  const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
+template <class Rng>
+DEV void randomize_rigid_props_t(CfgRef cfg, BufRef B, int e, int N, uint32_t purpose, const Rng& rng) {
   if (cfg.randomize_base_mass)
-    B.payloads[e] = rng_uniform(cfg, eg, step, purpose, 0) * (cfg.added_mass_range[1] - cfg.added_mass_range[0]) + cfg.added_mass_range[0];
+    B.payloads[e] = rng(purpose, 0) * (cfg.added_mass_range[1] - cfg.added_mass_range[0]) + cfg.added_mass_range[0];
   if (cfg.randomize_com_displacement)
 #pragma unroll 1
     for (int i = 0; i < 3; i++)
-      AT(B.com_displacements, i, e) = rng_uniform(cfg, eg, step, purpose, 1 + i) * (cfg.com_displacement_range[1] - cfg.com_displacement_range[0]) + cfg.com_displacement_range[0];
+      AT(B.com_displacements, i, e) = rng(purpose, 1 + i) * (cfg.com_displacement_range[1] - cfg.com_displacement_range[0]) + cfg.com_displacement_range[0];
   if (cfg.randomize_friction)
-    B.friction_coeffs[e] = rng_uniform(cfg, eg, step, purpose, 4) * (cfg.friction_range[1] - cfg.friction_range[0]) + cfg.friction_range[0];
+    B.friction_coeffs[e] = rng(purpose, 4) * (cfg.friction_range[1] - cfg.friction_range[0]) + cfg.friction_range[0];
   if (cfg.randomize_restitution)
-    B.restitutions[e] = rng_uniform(cfg, eg, step, purpose, 5) * (cfg.restitution_range[1] - cfg.restitution_range[0]) + cfg.restitution_range[0];
+    B.restitutions[e] = rng(purpose, 5) * (cfg.restitution_range[1] - cfg.restitution_range[0]) + cfg.restitution_range[0];
+}
+DEV void randomize_rigid_props(CfgRef cfg, BufRef B, int e, int N, int64_t step, uint32_t purpose) {
+  randomize_rigid_props_t(cfg, B, e, N, purpose, RngDirect{cfg, (uint32_t)(cfg.env_id_offset + e), step});
 }
 
 // is_eval: an evaluation environment (legged_robot.py:188-195): its episode sums stay out of the training log; the first
 // finished episode after the caller armed episode_sums_eval with -1 is kept there
-DEV void reset_env(CfgRef cfg, BufRef B, int e, int N, int64_t step, bool is_eval, int64_t slot_step) {
-  const uint32_t eg = (uint32_t)(cfg.env_id_offset + e);
-  resample_commands(cfg, B, e, N, step, P_CMD_RESET, slot_step);
-  randomize_dof_props(cfg, B, e, N, step, P_DOFPROPS_RESET);
-  if (cfg.randomize_rigids_after_start) randomize_rigid_props(cfg, B, e, N, step, P_RIGID_RESET);      // legged_robot.py:166-168
+// k0, ks: this lane's share of the per-joint / per-term loops (0, 1: everything, one lane per environment — the reset kernel; leg, 4: the
+// step kernel, called by all four lanes of the environment: the scalar parts then run on the leg-0 lane, the loops on all four)
+template <class Rng>
+DEV void reset_env_t(CfgRef cfg, BufRef B, int e, int N, int64_t step, bool is_eval, int64_t slot_step, const Rng& rng, int k0, int ks) {
+  const bool lead = k0 == 0;
+  if (lead) resample_commands_t(cfg, B, e, N, P_CMD_RESET, slot_step, rng);
+  randomize_dof_props_t(cfg, B, e, N, P_DOFPROPS_RESET, rng, k0, ks);
+  if (lead && cfg.randomize_rigids_after_start) randomize_rigid_props_t(cfg, B, e, N, P_RIGID_RESET, rng);      // legged_robot.py:166-168
 #pragma unroll 1
-  for (int j = 0; j < 12; j++) {
-    AT(B.dof_pos, j, e) = cfg.default_dof_pos[j] * (0.5f + rng_uniform(cfg, eg, step, P_RESET, j));
+  for (int j = k0; j < 12; j += ks) {
+    AT(B.dof_pos, j, e) = cfg.default_dof_pos[j] * (0.5f + rng(P_RESET, j));
     AT(B.dof_vel, j, e) = 0.f;
+    AT(B.last_actions, j, e) = 0.f; AT(B.last_last_actions, j, e) = 0.f; AT(B.last_dof_vel, j, e) = 0.f;
   }
-  float root[13];
+  if (lead) {
+    float root[13];
 #pragma unroll
-  for (int i = 0; i < 13; i++) root[i] = cfg.base_init_state[i];
+    for (int i = 0; i < 13; i++) root[i] = cfg.base_init_state[i];
 #pragma unroll
-  for (int i = 0; i < 3; i++) root[i] += AT(B.env_origins, i, e);
-  if (cfg.custom_origins) {
-    root[0] += (2 * rng_uniform(cfg, eg, step, P_RESET, 12) - 1) * cfg.x_init_range + cfg.x_init_offset;
-    root[1] += (2 * rng_uniform(cfg, eg, step, P_RESET, 13) - 1) * cfg.y_init_range + cfg.y_init_offset;
+    for (int i = 0; i < 3; i++) root[i] += AT(B.env_origins, i, e);
+    if (cfg.custom_origins) {
+      root[0] += (2 * rng(P_RESET, 12) - 1) * cfg.x_init_range + cfg.x_init_offset;
+      root[1] += (2 * rng(P_RESET, 13) - 1) * cfg.y_init_range + cfg.y_init_offset;
+    }
+    float yaw = (2 * rng(P_RESET, 14) - 1) * cfg.yaw_init_range;
+    root[3] = 0.f; root[4] = 0.f; root[5] = sinf(0.5f * yaw); root[6] = cosf(0.5f * yaw);
+#pragma unroll
+    for (int i = 0; i < 6; i++) root[7 + i] = rng(P_RESET, 15 + i) - 0.5f;
+#pragma unroll
+    for (int i = 0; i < 13; i++) AT(B.root_states, i, e) = root[i];
+    B.episode_length_buf[e] = 0;
+    B.reset_buf[e] = 1;
+    if (!is_eval) atomicAdd(&B.episode_log[cfg.num_rewards + 1], 1.0f);
+    B.gait_indices[e] = 0.f;
   }
-  float yaw = (2 * rng_uniform(cfg, eg, step, P_RESET, 14) - 1) * cfg.yaw_init_range;
-  root[3] = 0.f; root[4] = 0.f; root[5] = sinf(0.5f * yaw); root[6] = cosf(0.5f * yaw);
-#pragma unroll
-  for (int i = 0; i < 6; i++) root[7 + i] = rng_uniform(cfg, eg, step, P_RESET, 15 + i) - 0.5f;
-#pragma unroll
-  for (int i = 0; i < 13; i++) AT(B.root_states, i, e) = root[i];
 #pragma unroll 1
-  for (int j = 0; j < 12; j++) { AT(B.last_actions, j, e) = 0.f; AT(B.last_last_actions, j, e) = 0.f; AT(B.last_dof_vel, j, e) = 0.f; }
-  B.episode_length_buf[e] = 0;
-  B.reset_buf[e] = 1;
-#pragma unroll 1
-  for (int kx = 0; kx <= cfg.num_rewards; kx++) {
+  for (int kx = k0; kx <= cfg.num_rewards; kx += ks) {
     const float sum = AT(B.episode_sums, kx, e);
     if (!is_eval) atomicAdd(&B.episode_log[kx], sum);
     else if (B.episode_sums_eval && AT(B.episode_sums_eval, kx, e) == -1.f) AT(B.episode_sums_eval, kx, e) = sum;
     AT(B.episode_sums, kx, e) = 0.f;
   }
-  if (!is_eval) atomicAdd(&B.episode_log[cfg.num_rewards + 1], 1.0f);
-  B.gait_indices[e] = 0.f;
-  const int nl = cfg.lag_timesteps + 1;
+  const int nlag = 12 * (cfg.lag_timesteps + 1);
 #pragma unroll 1
-  for (int sl = 0; sl < nl; sl++)
-#pragma unroll 1
-    for (int j = 0; j < 12; j++) B.lag_buffer[((size_t)sl * 12 + j) * N + e] = 0.f;
+  for (int i = k0; i < nlag; i += ks) B.lag_buffer[(size_t)i * N + e] = 0.f;        // ([slot][joint][env])
+}
+DEV void reset_env(CfgRef cfg, BufRef B, int e, int N, int64_t step, bool is_eval, int64_t slot_step) {
+  reset_env_t(cfg, B, e, N, step, is_eval, slot_step, RngDirect{cfg, (uint32_t)(cfg.env_id_offset + e), step}, 0, 1);
 }
 
 // ================================================================================================
@@ -873,20 +919,50 @@ DEV void post_physics(CfgRef cfg, BufRef B, const int* plan_lds, float* obs_stag
   }
   PROF(11);
   QUAD_SYNC();                // running sums complete before a reset logs / clears them
-  // ---- reset ----------------------------------------------------------------------------------------
-  if (GO1_RARE(reset && is0)) reset_env(cfg, B, e, N, counter_post, is_eval, counter_post - 1);
-  QUAD_SYNC();                // the observation sees the post-reset state, as in the reference
-  PROF(12);
-
-  // ---- compute_observations (+ privileged observations, roll): post_observations() -------------------------------------------
-  if (!helper_obs) {
+  // ---- reset, compute_observations (+ privileged observations, roll) --------------------------------------------------------------
+  const bool late = __ballot(reset) != 0ull;          // an environment of the wavefront is re-initialised
+  // the reset: all four lanes of the environment — the draws as a table they fill together (in the observation staging row, free until the
+  // observations are staged), then the scalar parts on the leg-0 lane and the per-joint / per-term loops on all four (reset_env_t)
+  auto do_reset = [&]() {
+    float* rt = obs_stage + (lane >> 2) * GO1_MAX_OBS;
+    if (GO1_RARE(reset)) reset_rng_table(cfg, (uint32_t)(cfg.env_id_offset + e), counter_post, rt, leg);
+    QUAD_SYNC();              // (wavefront-wide ordering points stay outside the divergent blocks)
+    if (GO1_RARE(reset)) reset_env_t(cfg, B, e, N, counter_post, is_eval, counter_post - 1, RngTable{rt}, leg, 4);
+    QUAD_SYNC();              // the observation sees the post-reset state, as in the reference
+  };
+  if (helper_flag == nullptr) {                       // one-wavefront workgroup: everything here
+    do_reset();
+    PROF(12);
     post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, 3, 0, 1 PROF_PASS);
-    if (helper_flag != nullptr) BLOCK_SYNC(nw);       // S2 (the helper had nothing to do)
-  } else {
-    if (__ballot(reset) == 0ull) post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, 2, 0, 1 PROF_PASS);
-    BLOCK_SYNC(nw);                                   // S2: the helper's observations are written
-    if (__ballot(reset) != 0ull)                      // only through the failed-simulation guard above: this environment once more, re-initialised
-      post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, reset ? 3 : 2, 0, 1 PROF_PASS);
+  } else if (helper_obs && !late) {                   // the usual step: the helpers are writing the observations, the privileged ones here
+    if (lane == 0) helper_flag[1] = 0.f;
+    PROF(12);
+    post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, 2, 0, 1 PROF_PASS);
+    BLOCK_SYNC(nw);                                   // S2: the helpers' observations are written
+  } else if (helper_obs) {                            // only through the failed-simulation guard above: the helpers wrote the observations of
+    if (lane == 0) helper_flag[1] = 0.f;              // the state before; once they are through (their staging rows are free then), this
+    BLOCK_SYNC(nw);                                   // S2   environment is re-initialised and observed once more
+    do_reset();
+    PROF(12);
+    post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, reset ? 3 : 2, 0, 1 PROF_PASS);
+  } else {                                            // a reset known at S1: the helpers are waiting at S2
+    do_reset();
+    PROF(12);
+    // LATE HAND-OVER: the helpers take the observations of the re-initialised wavefront as well (from the buffers: the reset leaves
+    // projected_gravity, clock_inputs and contact_forces as post_physics stored them — the reference's observation after reset_idx reads the
+    // same stale values) while the privileged ones are written here; S3 ends their round.  Not after a failed simulation (the guard above
+    // cleared buffers the observation would read differently from the registers passed here): that rare case stays on this wavefront.
+    const bool hand_over = __ballot(sim_failed) == 0ull;
+    if (lane == 0) helper_flag[1] = hand_over ? 1.f : 0.f;
+    __threadfence_block();
+    if (hand_over) {
+      BLOCK_SYNC(nw);                                 // S2: the helpers start
+      post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, 2, 0, 1 PROF_PASS);
+      BLOCK_SYNC(nw);                                 // S3: their observations are written
+    } else {
+      post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, 3, 0, 1 PROF_PASS);
+      BLOCK_SYNC(nw);                                 // S2 (the helpers had nothing to do)
+    }
   }
   PROF(14);
   PROF(15);

@@ -151,20 +151,26 @@ DEV void step_body(const StepArgs& A, float* lds, lf4* ldsx, float* act_lds, flo
 #ifndef GO1_ABLATE_POST
     if (!substep_only) {       // post_physics(): the observations on helper 1 while the master evaluates the rewards (go1_maps.h)
       BLOCK_SYNC(nw);          // S1
-      if (wv == 1 && acth[0] != 0.f) {
-        PROF_DECL
-        const int leg_ = lane & 3;
-        const V3 pg = v3(AT(B.projected_gravity, 0, e), AT(B.projected_gravity, 1, e), AT(B.projected_gravity, 2, e));
-        const float clock_own = AT(B.clock_inputs, leg_, e), force_z = AT(B.contact_forces, 3 * (4 + 4 * leg_) + 2, e);
-        uint32_t fault_h = 0;
-        post_observations(cfg, B, lds, lane, e, N, A.counter + 1, gravity_at(cfg, A.counter), A.history_slot, fault_h, pg, clock_own, force_z, 1, 0, nw - 1 PROF_PASS);
-        report_fault(B, e, fault_h);
-      } else if (wv > 1 && acth[0] != 0.f) {       // the other helpers: their share of the measured-heights columns (configurations that observe them)
-        PROF_DECL
-        uint32_t fault_h = 0;
-        post_observations(cfg, B, lds, lane, e, N, A.counter + 1, gravity_at(cfg, A.counter), A.history_slot, fault_h, v3(0.f, 0.f, 0.f), 0.f, 0.f, 4, wv - 1, nw - 1 PROF_PASS);
+      // round 0: the usual step (acth[0], written before S1).  round 1: the late hand-over — a reset kept the observations back until the
+      // environment was re-initialised; acth[1] (written before S2) says whether the helpers take them then, and S3 ends that round
+#pragma unroll 1
+      for (int round = 0; round < 2; round++) {
+        if (wv == 1 && acth[round] != 0.f) {
+          PROF_DECL
+          const int leg_ = lane & 3;
+          const V3 pg = v3(AT(B.projected_gravity, 0, e), AT(B.projected_gravity, 1, e), AT(B.projected_gravity, 2, e));
+          const float clock_own = AT(B.clock_inputs, leg_, e), force_z = AT(B.contact_forces, 3 * (4 + 4 * leg_) + 2, e);
+          uint32_t fault_h = 0;
+          post_observations(cfg, B, lds, lane, e, N, A.counter + 1, gravity_at(cfg, A.counter), A.history_slot, fault_h, pg, clock_own, force_z, 1, 0, nw - 1 PROF_PASS);
+          report_fault(B, e, fault_h);
+        } else if (wv > 1 && acth[round] != 0.f) {       // the other helpers: their share of the measured-heights columns (configurations that observe them)
+          PROF_DECL
+          uint32_t fault_h = 0;
+          post_observations(cfg, B, lds, lane, e, N, A.counter + 1, gravity_at(cfg, A.counter), A.history_slot, fault_h, v3(0.f, 0.f, 0.f), 0.f, 0.f, 4, wv - 1, nw - 1 PROF_PASS);
+        }
+        BLOCK_SYNC(nw);          // S2 (round 0), S3 (round 1)
+        if (acth[1] == 0.f) break;
       }
-      BLOCK_SYNC(nw);          // S2
     }
 #endif
     return;
