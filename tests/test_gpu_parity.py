@@ -134,8 +134,9 @@ def to_gpu(S, Bc, product=False):
 ROW_MAJOR = ("obs_buf", "privileged_obs_buf", "obs_history")
 
 
-def identical_envs(Ba, Bb, N, keys):
-    """(N,) bool: every listed output of the environment is bit-identical in the two buffer sets"""
+def identical_envs(Ba, Bb, N, keys, tally=None):
+    """(N,) bool: every listed output of the environment is bit-identical in the two buffer sets
+    (tally: dict key -> environment-steps in which THAT output differs, accumulated)"""
     same = torch.ones(N, dtype=torch.bool)
     for k in keys:
         a, b = Ba.tensors[k], Bb.tensors[k]
@@ -144,6 +145,8 @@ def identical_envs(Ba, Bb, N, keys):
             ne = ne & ~(a.isnan() & b.isnan())
         per_env = ne.reshape(N, -1).any(1) if k in ROW_MAJOR else ne.reshape(-1, N).any(0)
         same &= ~per_env.cpu()
+        if tally is not None and bool(per_env.any()):
+            tally[k] = tally.get(k, 0) + int(per_env.sum())
     return same
 
 
@@ -155,12 +158,13 @@ class ProductPair:
         self.Bg, self.sim = to_gpu(S, Bc, product=True)
         self.Bt, self.sim_t = to_gpu(S, Bc)
         self.env_steps = self.differ = 0
+        self.by_key = {}
 
     def step(self, a):
         self.sim.step(a)
         self.sim_t.step(a)
         torch.cuda.synchronize()
-        same = identical_envs(self.Bg, self.Bt, self.Bc.root_states.shape[1], self.keys)
+        same = identical_envs(self.Bg, self.Bt, self.Bc.root_states.shape[1], self.keys, self.by_key)
         self.env_steps += same.numel()
         self.differ += int((~same).sum())
         return (self.Bt, same)
@@ -170,7 +174,8 @@ class ProductPair:
         sync_from(self.Bc, self.Bt, self.sim_t, self.orc)
 
     def note(self):
-        return f"; product instance vs `_sig` twin: {self.differ} of {self.env_steps} env-steps not bit-identical"
+        by = (" (by output: " + ", ".join(f"{k} {v}" for k, v in self.by_key.items()) + ")") if self.by_key else ""
+        return f"; product instance vs `_sig` twin: {self.differ} of {self.env_steps} env-steps not bit-identical{by}"
 
 
 def sync_from(Bc, Bg, sim, orc):
