@@ -634,6 +634,16 @@ static void jac_row(const Kin* k, int dynb, const real* x, const real* d, real* 
 static int g_solver_legs_parallel = 3;
 void go1_oracle_set_solver_order(int legs_parallel) { g_solver_legs_parallel = legs_parallel; }
 
+/* STUDY option, never the contract (tools/solver_tgs_study.py): a TGS-like solve — what the reference's PhysX setting solver_type 1 with 4
+ * position iterations does differently from a plain PGS (legged_robot_config.py:410-414; Macklin et al. 2019, "Small steps in physics
+ * simulation", restated for this velocity-level solve with frozen Jacobians).  The substep h is cut into N = solver_iterations parts of
+ * hs = h / N; sweep k aims each contact's normal rate at the error that is left,  -(phi + sum_{j<k} hs un_j) / hs  (clamped like the plain
+ * target; a restitution target is kept), i.e. the constraint errors are re-evaluated between the sweeps and resolved over hs instead of h.
+ * 1: targets only, the pose is integrated with the final velocity over h as in the contract;  2: the pose is also advanced by hs with every
+ * sweep's velocity (the TGS "stepping").  0 = off. */
+static int g_tgs_like = 0;
+void go1_oracle_set_tgs_like(int mode) { g_tgs_like = mode; }
+
 /* ------------------------------------------------------------------ one physics substep (replaces gym.simulate) */
 typedef struct { real force[17][3]; int dropped[GO1_CC_COUNT]; uint32_t sig[GO1_SIG_WORDS]; } ContactOut;
 
@@ -755,7 +765,25 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
   }
   int slid[GO1_MAX_CONTACTS];
   for (int c = 0; c < nc; c++) slid[c] = 0;
+  /* (study) TGS-like: normal displacement accumulated over the sweeps, the plain target (kept where it is a restitution target), the pose */
+  real tgs_delta[GO1_MAX_CONTACTS], tgs_plain[GO1_MAX_CONTACTS], tgs_x[NV];
+  const real tgs_hs = h / (cfg->solver_iterations > 0 ? cfg->solver_iterations : 1);
+  for (int c = 0; c < nc; c++) {
+    real vs = -C[c].phi / h;
+    if (vs > cfg->max_depenetration_velocity) vs = cfg->max_depenetration_velocity;
+    tgs_plain[c] = vs;
+    tgs_delta[c] = 0;
+  }
+  for (int i = 0; i < NV; i++) tgs_x[i] = 0;
   for (int it = 0; it < cfg->solver_iterations; it++) {
+    if (g_tgs_like)
+      for (int c = 0; c < nc; c++) {
+        if (vstar[c] != tgs_plain[c] && it == 0) tgs_plain[c] = (real)-1e30;      /* marks a restitution target: left alone */
+        if (tgs_plain[c] == (real)-1e30) continue;
+        real vs = -(C[c].phi + tgs_delta[c]) / tgs_hs;
+        if (vs > cfg->max_depenetration_velocity) vs = cfg->max_depenetration_velocity;
+        vstar[c] = vs;
+      }
     /* one contact's update on the velocity vector vv (projected Gauss-Seidel step: normal row, then the two tangent rows on the cone) */
 #define CONTACT_UPDATE(c, vv) CONTACT_UPDATE_X(c, vv, T, A)
 #define CONTACT_UPDATE_X(c, vv, T, A) do { \
@@ -850,6 +878,14 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
       lamj[j] = ln;
       for (int i = 0; i < NV; i++) v[i] += TJ[j][i] * dl;
     }
+    if (g_tgs_like) {
+      for (int c = 0; c < nc; c++) {
+        real un = 0;
+        for (int i = 0; i < NV; i++) un += J[c][0][i] * v[i];
+        tgs_delta[c] += tgs_hs * un;
+      }
+      for (int i = 0; i < NV; i++) tgs_x[i] += tgs_hs * v[i];
+    }
     if (out) {
       /* signature: the active set after EVERY sweep (pressing contacts, contacts projected on the cone in this sweep, limit rows
        * carrying an impulse), weighted by the sweep: a projection that flips in an intermediate sweep sends the unconverged
@@ -886,18 +922,22 @@ static void physics_substep(const Go1SimConfig* cfg, const Terrain* ter, Phys* s
     if (wn2 > cfg->max_angular_velocity) for (int i = 0; i < 3; i++) v[i] *= cfg->max_angular_velocity / wn2;
     if (vn2 > cfg->max_linear_velocity) for (int i = 0; i < 3; i++) v[3 + i] *= cfg->max_linear_velocity / vn2;
   }
-  for (int i = 0; i < 3; i++) { s->vang[i] = v[i]; s->vlin[i] = v[3 + i]; s->pos[i] += h * v[3 + i]; }
-  real wn = v3norm(s->vang);
+  real xd[NV];          /* displacement of the substep: h v (the contract), or (study, TGS-like 2) the sum of the sweeps' hs v_k */
+  for (int i = 0; i < NV; i++) xd[i] = g_tgs_like == 2 ? tgs_x[i] : h * v[i];
+  for (int i = 0; i < 3; i++) { s->vang[i] = v[i]; s->vlin[i] = v[3 + i]; s->pos[i] += xd[3 + i]; }
+  real wrot[3] = {s->vang[0], s->vang[1], s->vang[2]};       /* mean angular rate of the substep */
+  if (g_tgs_like == 2) for (int i = 0; i < 3; i++) wrot[i] = xd[i] / h;
+  real wn = v3norm(wrot);
   if (wn > 1e-12) {
     real half = 0.5 * wn * h, sn = sin(half) / wn;
-    real dq[4] = {s->vang[0] * sn, s->vang[1] * sn, s->vang[2] * sn, cos(half)}, qn[4];
+    real dq[4] = {wrot[0] * sn, wrot[1] * sn, wrot[2] * sn, cos(half)}, qn[4];
     quat_mul(qn, dq, s->quat);
     real l = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
     for (int i = 0; i < 4; i++) s->quat[i] = qn[i] / l;
   }
   for (int j = 0; j < 12; j++) {
     s->qd[j] = v[6 + j];
-    s->q[j] += h * s->qd[j];
+    s->q[j] += g_tgs_like == 2 ? xd[6 + j] : h * s->qd[j];
     if (s->q[j] < GO1_JOINT_LOWER[j] - GO1_LIMIT_SLACK) { s->q[j] = GO1_JOINT_LOWER[j] - GO1_LIMIT_SLACK; if (s->qd[j] < 0) s->qd[j] = 0; }
     if (s->q[j] > GO1_JOINT_UPPER[j] + GO1_LIMIT_SLACK) { s->q[j] = GO1_JOINT_UPPER[j] + GO1_LIMIT_SLACK; if (s->qd[j] > 0) s->qd[j] = 0; }
   }

@@ -66,6 +66,7 @@ def _bind(L):
         L.go1_oracle_curriculum_update.argtypes = [cfgp, bufp]
         L.go1_oracle_set_eval.argtypes = [cfgp, ctypes.c_int]
         L.go1_oracle_set_solver_order.argtypes = [ctypes.c_int]
+        L.go1_oracle_set_tgs_like.argtypes = [ctypes.c_int]
         L.go1_oracle_dynamics.argtypes = [vp] * 5 + [ctypes.c_double] + [vp] * 4
         L.go1_oracle_actuator_net.argtypes = [vp, ctypes.c_int, vp]
         L.go1_oracle_philox.argtypes = [vp, vp, vp]

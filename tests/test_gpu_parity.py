@@ -537,6 +537,7 @@ def run_full_step_comparison(variant, N, steps, seed=11, prepare=None, watch=Non
             sp.sync()
     assert int(Bg.fault_counts[:10].sum()) == 0, Bg.fault_counts.tolist()
     att.note = pp.note() if product else ""
+    assert not product or pp.differ == 0, pp.note()        # (the twin relation: see test_product_instances_match_oracle)
     att.finish(f"{what} [{variant}, {N} envs x {steps} steps]")
     return att, resets, resamples, timeouts
 
@@ -846,6 +847,10 @@ def test_product_instances_match_oracle(instance):
         assert (resets > N // 64 and resamples > N // 64) or steps < 40
     else:
         att, pp = run_height_field_comparison(instance == "walls", N=N, steps=steps, product=True)
+        # the twin relation is asserted, not only reported, since round 5 met a build in which it did not hold (1 % of the `_hf` instance's
+        # environment-steps: fused multiply-adds formed differently in the two instances — csrc/go1_physics.h GO1_NO_CONTRACT,
+        # tests/twin_probe.py tells a compile difference from a race)
+        assert pp.differ == 0, pp.note()
     assert att.env_steps == N * steps
 
 

@@ -18,6 +18,8 @@ case $step in
   benchfull) TMO=900 run benchfull python bench.py ;;
   prof) (cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -- python $OLDPWD/bench.py --steps 3 --warmup 2 --headline-only --no-cpu-baseline) > $OUT/prof.log 2>&1; find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \; ; for t in $(find $OUT/prof -name "*kernel_trace.csv"); do python tools/timeline.py $t --which -3 > $OUT/timeline.txt 2>&1; python tools/timeline.py $t --anchor mse_kernel --which -3 >> $OUT/timeline.txt 2>&1; python tools/timeline.py $t --anchor go1_step_kernel --which -5 > $OUT/timeline_rollout.txt 2>&1; done; find $OUT/prof -type f ! -name "*stats*" -delete; echo "=== prof rc=$?" | tee -a $OUT/index.txt ;;
   changed) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt TMO=330 run changed python -m pytest tests/test_gpu_parity.py tests/test_gpu_env.py -x -q --durations=15 -k "not (learns or play_eval or teacher or unchanged_train or graph_replay or autograd_update or two_rank or rccl_one_rank or training_survives)" ;;
+  rough) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt TMO=200 run rough python -m pytest tests/test_gpu_parity.py tests/test_gpu_env.py -x -q --durations=8 -k "height_field or (product_instances and not plane) or rough_terrain_env_end_to_end or height_scan" ;;
+  twin) run twin python tests/twin_probe.py ;;
   gputests) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt TMO=1500 run gputests python -m pytest tests/ -x -q -m gpu --durations=30 ;;
   dropin) run dropin python -m pytest tests/test_gpu_env.py -q -x -s -k "unchanged_train_script" ;;
   ab) run ab python tools/probes/step_variant_ab.py $(ls walk-these-ways_amd/csrc/variants/*.so | grep -v prof) ;;

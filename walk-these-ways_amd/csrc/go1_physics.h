@@ -441,8 +441,22 @@ struct Wall { bool on; V3 n; float d, top; int cell; };
 // The sample in two halves, so that a caller can have the loads of several points in flight before it evaluates the first (one point at a
 // time, a lane's 21 candidate points per substep were 21 dependent round trips to L2: profiles/r05_step_kernel_phases_rough.txt):
 // terrain_fetch() = cell, in-cell coordinates and the four int16 loads; terrain_eval() = everything computed from them.
+// GO1_NO_CONTRACT (first statement of a function body): no fused multiply-adds formed ACROSS the source's operations in that function.
+// hipcc's default (-ffp-contract=fast) lets the backend fuse a product into a sum wherever the product has no other user — a property of the
+// surrounding code after inlining, so two template instances of the same source can round differently.  Round 5 met exactly that: once the
+// look-ups below ran ahead of their evaluation, go1_step_kernel_hf and its `_sig` twin (which keeps Cand::tag and the cell index alive)
+// disagreed in the last bit of the bilinear interpolation, and 1 % of the environment-steps of the product-instance parity test were no longer
+// bit-identical between the two (tests/twin_probe.py: deterministic, gone with -ffp-contract=on / off, gone with the pragma in these three
+// functions alone; the plane instance's results are untouched by it — same digest).  The terrain sample is 30 operations per point: what
+// the fusing saved is not measurable, the twin relation is what rule (a) of the parity tests stands on.
+#if defined(__clang__)
+#define GO1_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define GO1_NO_CONTRACT
+#endif
 struct TerrFetch { float ax, ay; int cell, p00, p01, p10, p11; bool flat; };
 DEV void terrain_fetch(CfgRef cfg, const int16_t* __restrict__ hs, float x, float y, TerrFetch& f) {
+  GO1_NO_CONTRACT
   f.flat = cfg.terrain_type == 0 || hs == nullptr;
   f.ax = f.ay = 0.f; f.cell = 0; f.p00 = f.p01 = f.p10 = f.p11 = 0;
   if (f.flat) return;
@@ -457,6 +471,7 @@ DEV void terrain_fetch(CfgRef cfg, const int16_t* __restrict__ hs, float x, floa
 }
 template <bool WALLS>
 DEV void terrain_eval(CfgRef cfg, const TerrFetch& f, float& h, V3& n, Wall& wall) {
+  GO1_NO_CONTRACT
   wall.on = false; wall.n = v3(1.f, 0.f, 0.f); wall.d = 0.f; wall.top = 0.f; wall.cell = 0;
   if (f.flat) { h = 0.f; n = v3(0.f, 0.f, 1.f); return; }
   const float ax = f.ax, ay = f.ay;
@@ -547,6 +562,7 @@ DEV void cand_try(CfgRef cfg, const int16_t* __restrict__ hs, Cand& c, Cand& cw,
 // (The margin covers the rounding of the interpolation weights' sum.)  A walking robot's trunk, hips and thighs take this exit.
 template <bool WALLS, bool WANTW = WALLS>
 DEV void cand_eval(CfgRef cfg, const TerrFetch& f, Cand& c, Cand& cw, V3 x, V3 bpos, float radius, SV vb, int m, float cd) {
+  GO1_NO_CONTRACT
   {
     const float vs = cfg.hf_vscale;
     const float top = fmaxf(fmaxf(f.p00 * vs, f.p01 * vs), fmaxf(f.p10 * vs, f.p11 * vs));
