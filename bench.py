@@ -313,6 +313,8 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="dry run: all ranks share GPU 0 (with --backend gloo)")
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="N > 1: dtype of the PPO-stage gradient exchange (PPO_Args.dp_grad_dtype)")
     ap.add_argument("--zero1", action="store_true", help="N > 1: reduce-scatter + sharded optimiser step + all-gather (PPO_Args.dp_zero1)")
+    ap.add_argument("--rough", action="store_true", help="diagnostic: BASELINE configs[2] (trimesh tile grid + height scan) instead of the flat headline "
+                    "configuration — with --sim-only for profiles of go1_step_kernel_walls; never the headline line")
     ap.add_argument("--breakdown", action="store_true", help="diagnostic: print rollout/update split to stderr (adds syncs)")
     ap.add_argument("--headline-only", action="store_true", help="skip the extra single-GPU records (rates, height field, 8192 envs)")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the step kernel's HBM traffic "
@@ -381,7 +383,7 @@ def main():
     # the command curriculum keeps the reference's per-step cadence at every rank count (sharded: one 7 KB int32 all-reduce of the
     # success counts per step); --curriculum-interval 24 exchanges them once per rollout instead — a different sampling cadence,
     # recorded in config.curriculum_update_interval
-    env, cfg = build_env(args.envs, rank, args.seed, curriculum_update_interval=args.curriculum_interval)
+    env, cfg = build_env(args.envs, rank, args.seed, rough=args.rough, curriculum_update_interval=args.curriculum_interval)
     device = f"cuda:{local_rank}"
     runner = Runner(env, device=device)
     sim = env.env.sim
@@ -496,7 +498,9 @@ def main():
             "value": total_env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Go1 flat terrain, 4096 envs/GPU, train.py config (actuator_net, lag 6, DR, gait "
+            "config": {"workload": ("DIAGNOSTIC (--rough), not the headline: BASELINE configs[2], trimesh tile grid + 187-point height scan, "
+                                    "train.py config otherwise") if args.rough else
+                                   "Go1 flat terrain, 4096 envs/GPU, train.py config (actuator_net, lag 6, DR, gait "
                                    "curriculum), HIP sim + ppo_cse, 24 steps/iter, 5 epochs x 4 minibatches",
                        "envs_per_gpu": args.envs, "curriculum_update_interval": int(args.curriculum_interval), "policy_dtype": "fp32" if args.fp32 else "bf16 autocast (fp32 master)",
                        "physics_dtype": "f32", "step": "one PPO iteration = 24 x envs env-steps + update",

@@ -21,6 +21,9 @@ case $step in
   rough) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt TMO=200 run rough python -m pytest tests/test_gpu_parity.py tests/test_gpu_env.py -x -q --durations=8 -k "height_field or (product_instances and not plane) or rough_terrain_env_end_to_end or height_scan" ;;
   twin) run twin python tests/twin_probe.py ;;
   traj) run traj python -m pytest tests/test_gpu_ppo_fused.py -q -s -k "tracks_autograd" ;;
+  rest) TMO=150 run rest_other python -m pytest tests -m gpu -q --durations=10 --ignore=tests/test_gpu_parity.py --ignore=tests/test_gpu_env.py
+        TMO=200 run rest_env python -m pytest tests/test_gpu_env.py -m gpu -q --durations=10 -k "learns or play_eval or teacher or unchanged_train or graph_replay or autograd_update or two_rank or rccl_one_rank or training_survives" ;;
+  pmc_walls) GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD} PMC_EXTRA=--rough run pmc_walls bash tools/pmc.sh ${TAG}_walls ;;
   gputests) GO1_PARITY_LOG=$PWD/$OUT/parity_rates.txt TMO=1500 run gputests python -m pytest tests/ -x -q -m gpu --durations=30 ;;
   dropin) run dropin python -m pytest tests/test_gpu_env.py -q -x -s -k "unchanged_train_script" ;;
   ab) run ab python tools/probes/step_variant_ab.py $(ls walk-these-ways_amd/csrc/variants/*.so | grep -v prof) ;;

@@ -5,7 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$1
 mkdir -p $OUT
 run() {
   name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$name -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sim-only > /tmp/pmc_$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$name -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sim-only $PMC_EXTRA > /tmp/pmc_$name.log 2>&1
   f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
   python - "$f" "$OUT/$name.txt" <<PY
 import csv, sys, collections
