@@ -604,3 +604,38 @@ def test_thigh_capsules_take_part_in_the_self_collision(oracle_lib):
         min_d = min(min_d, _seg_dist(*th[0], *th[1]))
     assert seen_pairs, "no pair with a thigh was ever listed"
     assert fmax > 1.0 and min_d > 2 * 0.017 - 0.012, (fmax, min_d)
+
+
+def test_tgs_like_study_option_is_off_by_default_and_rests_when_stepped(oracle_lib):
+    """`go1_oracle_set_tgs_like` (oracle/go1_oracle.c: constraint errors re-evaluated between the sweeps — what PhysX's TGS, the reference's
+    solver_type 1 of legged_robot_config.py:410-414, does differently from a PGS) is a STUDY option (tools/solver_tgs_study.py,
+    profiles/r05_tgs_like_study.txt), never the contract: (1) switched to 0 the oracle is bit for bit the oracle that never heard of it, whatever
+    was selected before; (2) with the stepping (mode 2) four limp robots rest like under the contract (the bound of the contract's own rest test,
+    doubled for the tangled pose)."""
+    def run(mode, substeps):
+        cfg, S, meta, B = make_sim("train", 4, extra={"domain_rand": dict(randomize_gravity=False)})
+        standing_state(S, B, 0.30)
+        B.root_states[2, 1] = 0.12; B.root_states[3, 1] = np.sin(np.pi / 4); B.root_states[6, 1] = np.cos(np.pi / 4)
+        B.root_states[2, 2] = 0.10; B.dof_pos[:, 2] = torch.tensor([0.0, 1.3, -2.6] * 4)
+        B.root_states[2, 3] = 0.15; B.root_states[3, 3] = 1.0; B.root_states[6, 3] = 0.0
+        orc = oracle_lib.Oracle(S, B)
+        B.torques.zero_()
+        orc.L.go1_oracle_set_tgs_like(mode)
+        try:
+            wmax = torch.zeros(4)
+            for it in range(substeps):
+                orc.physics_substep()
+                if it >= substeps - 40:
+                    wmax = torch.maximum(wmax, B.root_states[10:13].norm(dim=0))
+        finally:
+            orc.L.go1_oracle_set_tgs_like(0)
+        return B.root_states.clone(), B.dof_pos.clone(), wmax
+
+    r0, q0, _ = run(0, 60)
+    run(2, 5)                                            # (the switch leaves no state behind)
+    r1, q1, _ = run(0, 60)
+    assert torch.equal(r0, r1) and torch.equal(q0, q1)
+    _, _, w_contract = run(0, 840)
+    _, _, w_tgs = run(2, 840)
+    assert float(w_contract[[0, 2, 3]].max()) < 0.02 and float(w_contract[1]) < 0.05, w_contract
+    assert float(w_tgs[[0, 2, 3]].max()) < 0.02 and float(w_tgs[1]) < 0.1, w_tgs
