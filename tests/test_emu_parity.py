@@ -256,6 +256,8 @@ def test_emulated_reward_guard_with_the_observations_on_the_helper(oracle_lib, e
     sim.set_counters(orc.ctr.common_step_counter, orc.ctr.lag_head)
     victim = 5
     Be.last_dof_vel[4, victim] = float("nan")
+    for B in (Be, Br):            # the previous target differs from this step's: a second roll of the pair would show (advisor finding, round 5)
+        B.last_joint_pos_target[:, victim] += 0.37
     z = torch.zeros(N, 12)
     sim.step(z)
     ref.step(z)
@@ -269,6 +271,10 @@ def test_emulated_reward_guard_with_the_observations_on_the_helper(oracle_lib, e
         a, b = Be.tensors[k], Br.tensors[k]
         per_env_first = a.shape[0] == N and k in ("obs_buf", "privileged_obs_buf")
         assert torch.equal(a[others] if (per_env_first or a.dim() == 1) else a[..., others], b[others] if (per_env_first or b.dim() == 1) else b[..., others]), k
+    # the roll of the victim's joint position targets happened ONCE (the reset leaves the pair alone: the undisturbed run's values)
+    for k in ("last_joint_pos_target", "last_last_joint_pos_target"):
+        assert torch.equal(Be.tensors[k][:, victim], Br.tensors[k][:, victim]), k
+    assert not torch.equal(Be.last_joint_pos_target[:, victim], Be.last_last_joint_pos_target[:, victim])
     # the victim's observation is that of the re-initialised environment: its joint-velocity columns are those of the reset state
     assert torch.isfinite(Be.obs_buf[victim]).all() and not torch.equal(Be.obs_buf[victim], Br.obs_buf[victim])
 

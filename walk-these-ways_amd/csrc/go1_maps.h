@@ -466,7 +466,7 @@ DEV int reward_raw_sign(int id) {
 // (the own foot's vertical contact force) are the three values post_physics() holds in registers — a caller that does not have them
 // (the helper wavefront of the step kernel) loads them from projected_gravity / clock_inputs / contact_forces, where post_physics() stored
 // them.  parts: 1 = observations + roll, 2 = privileged observations (the step kernel gives 1 to the helper and keeps 2 on the master: the
-// helper's share then takes as long as the master's rewards).  Four lanes per environment, must be called by all four.
+// helper's share then takes as long as the master's rewards), 8 = with 1: leave the joint-position-target pair out of the roll.  Four lanes per environment, must be called by all four.
 DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int e, int N, int64_t counter_post, V3 grav, int history_slot,
                            uint32_t& fault, V3 pg, float clock_own, float force_z, int parts, int hpart, int hparts PROF_PARAM) {
   const int leg = lane & 3;
@@ -587,8 +587,10 @@ DEV void post_observations(CfgRef cfg, BufRef B, float* obs_stage, int lane, int
       const int j = 3 * leg + jj;
       AT(B.last_last_actions, j, e) = o_lact[jj];
       AT(B.last_actions, j, e) = o_act[jj];
-      AT(B.last_last_joint_pos_target, j, e) = o_ljpt[jj];
-      AT(B.last_joint_pos_target, j, e) = o_jpt[jj];
+      if (!(parts & 8)) {       // (8: this step's targets were rolled already — the second observation of an environment re-initialised late)
+        AT(B.last_last_joint_pos_target, j, e) = o_ljpt[jj];
+        AT(B.last_joint_pos_target, j, e) = o_jpt[jj];
+      }
       AT(B.last_dof_vel, j, e) = o_qd[jj];
     }
   }
@@ -944,7 +946,9 @@ DEV void post_physics(CfgRef cfg, BufRef B, const int* plan_lds, float* obs_stag
     BLOCK_SYNC(nw);                                   // S2   environment is re-initialised and observed once more
     do_reset();
     PROF(12);
-    post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, reset ? 3 : 2, 0, 1 PROF_PASS);
+    // (parts 8: the helpers rolled this step's joint position targets already and the reset leaves the pair alone — a second roll would put
+    //  THIS step's target into last_last_joint_pos_target; the action / joint-rate buffers are re-zeroed by the reset, so rolling them again is exact)
+    post_observations(cfg, B, obs_stage, lane, e, N, counter_post, grav, history_slot, fault, d.pg, clock_own, F.force.z, reset ? 3 | 8 : 2, 0, 1 PROF_PASS);
   } else {                                            // a reset known at S1: the helpers are waiting at S2
     do_reset();
     PROF(12);
