@@ -199,6 +199,43 @@ def time_iterations(runner, env, obs_dict, iters, rollout_only=False, warmup=2):
     return env.num_envs * T * iters / (time.perf_counter() - t0), obs_dict
 
 
+MFMA_PEAK_BF16_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 2:1-sparsity headline figure is never used)
+
+
+def update_roofline(runner, env, obs_dict, reps=3):
+    """`PPO.update()` alone (HIP events on the stream it runs on; the rollout that fills the storage is outside the events) against the MFMA
+    roofline.  Counted: the first-layer products only — per mini-batch step forward + weight gradient of the PPO pass (n1 rows of W1) and of
+    the adaptation pass (its nd rows), 2 M n K each, no input gradient (the history has none) —, which is > 97 % of the update's flops at
+    BASELINE configs[2]'s 7744-wide augmented history."""
+    from go1_gym_learn.ppo_cse.ppo import PPO_Args
+    alg, T, n = runner.alg, runner.num_steps_per_env, env.num_train_envs
+    pol = getattr(alg, "policy", None)
+    if pol is None or not getattr(alg, "fused", False):
+        return None
+    ms = []
+    for _ in range(reps):
+        with torch.inference_mode():
+            for _ in range(T):
+                obs_dict, _ = runner._rollout_step(obs_dict)
+            alg.compute_returns(obs_dict["obs_history"][:n], obs_dict["privileged_obs"][:n])
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        alg.update()
+        b.record()
+        torch.cuda.synchronize()
+        ms.append(a.elapsed_time(b))
+    upd_ms = sum(ms[1:]) / max(len(ms) - 1, 1)               # (the first repetition may re-capture graphs)
+    nd, na, nc = pol.first
+    mb = n * T // PPO_Args.num_mini_batches
+    steps = PPO_Args.num_learning_epochs * PPO_Args.num_mini_batches
+    flops = steps * 2.0 * mb * pol.Kp * (2 * (nd + na + nc) + 2 * nd)
+    ach = flops / (upd_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "first-layer GEMMs of the update (hipBLASLt forward + weight gradient, PPO and adaptation pass)",
+            "achieved": ach, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_BF16_TFLOPS, "traffic": None,
+            "update_ms": upd_ms, "flops_per_update": flops, "floor_ms_at_peak": flops / (MFMA_PEAK_BF16_TFLOPS * 1e12) * 1e3,
+            "note": "achieved = first-layer flops of one update / the WHOLE update's time (optimiser, tails, loss included): a lower bound of the GEMMs' own rate"}
+
+
 def dropin_default(args, device, iters=40):
     """What the UNCHANGED scripts/train.py gets (train.py:207-216: Runner with the default PPO_Args, `runner.learn`): the caller sets
     nothing on PPO_Args — the bf16 policy is selected by the environment variable GO1_POLICY_DTYPE=bf16 alone —
@@ -252,6 +289,10 @@ def extra_records(args, env, runner, obs_dict, device):
     except Exception as err:
         out["rates"] = {"error": f"{type(err).__name__}: {err}"}
     try:
+        out["update_roofline"] = update_roofline(runner, env, obs_dict)
+    except Exception as err:
+        out["update_roofline"] = {"error": f"{type(err).__name__}: {err}"}
+    try:
         out["dropin_default"] = dropin_default(args, device)
     except Exception as err:
         out["dropin_default"] = {"error": f"{type(err).__name__}: {err}"}
@@ -264,6 +305,7 @@ def extra_records(args, env, runner, obs_dict, device):
         env3.episode_length_buf.copy_(torch.randint_like(env3.episode_length_buf, high=int(env3.max_episode_length)))
         od3 = env3.get_observations()
         full, od3 = time_iterations(runner3, env3, od3, 5, warmup=2)
+        roof3 = update_roofline(runner3, env3, od3)
         so, ms = time_sim_only(env3, env3.env.sim, args.envs, 240, device)
         f3 = env3.env.extras["sim_faults"].consume()
         out["rough_trimesh"] = {"workload": "BASELINE configs[2]: terrain-curriculum tile grid (slopes, rough slopes, stairs up / down, discrete "
@@ -271,6 +313,7 @@ def extra_records(args, env, runner, obs_dict, device):
                                             "slope_treshold 0.75 —, 187-point height scan in the observation (257 wide, history 7710), 4096 envs",
                                 "sim_ppo_env_steps_s": full, "sim_only_env_steps_s": so, "step_kernel_launch_ms": ms,
                                 "wall_instance": bool(env3.env.sim_config.hf_wall_units > 0),
+                                "roofline": roof3,
                                 "guard_activations": {k: v for k, v in f3.items() if v},
                                 "note": "sim+PPO: 5 timed PPO iterations (live policy), first-layer GEMM selections for the 7744-wide history from the "
                                         "shipped TunableOp table (1.17 TFLOP of first-layer products per mini-batch step: the update is FLOP-bound, "

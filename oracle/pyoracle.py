@@ -22,12 +22,28 @@ LIB = os.path.join(_HERE, "_build", "libgo1oracle.so")
 LIB32 = os.path.join(_HERE, "_build", "libgo1oracle32.so")        # the same restatement with real = float (Makefile)
 
 
+def _content_hash():
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_PKG, "csrc")
+    for f in (os.path.join(_HERE, "go1_oracle.c"), os.path.join(_HERE, "Makefile"), os.path.join(_HERE, "..", "include", "go1sim.h"),
+              os.path.join(csrc, "go1_model_data.h"), os.path.join(csrc, "go1_actuator_data.h")):
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False):
-    src = os.path.join(_HERE, "go1_oracle.c")
-    stale = (not os.path.exists(LIB)) or (not os.path.exists(LIB32)) or min(os.path.getmtime(LIB), os.path.getmtime(LIB32) if os.path.exists(LIB32) else 0) < max(
-        os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "..", "include", "go1sim.h")))
-    if force or stale:
+    """make both libraries; rebuilt whenever the hash of the sources (content, not mtimes: as __graft_entry__.build_hip) differs from the one
+    recorded beside them"""
+    stamp = os.path.join(_HERE, "_build", "stamp")
+    want = _content_hash()
+    fresh = os.path.exists(LIB) and os.path.exists(LIB32) and os.path.exists(stamp) and open(stamp).read().strip() == want
+    if force or not fresh:
         subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+        with open(stamp, "w") as fh:
+            fh.write(want)
     return LIB
 
 

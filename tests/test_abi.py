@@ -36,17 +36,50 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_build_rebuilds_a_library_whose_stamp_does_not_match_the_sources(tmp_path, monkeypatch):
-    """a library built from other sources (here: a copy with its stamp overwritten) is not accepted by the up-to-date check"""
+    """build_ppo_hip() calls the compiler for a library built from other sources (here: a copy of the shipped one with its stamp overwritten)
+    and does not for one whose stamp matches; the stamp reader refuses an absent, an unstamped and an ambiguous file"""
+    import shutil
+    import subprocess
     import __graft_entry__ as g
     g.build_ppo_hip()
-    path = os.path.join(g.CSRC, "libgo1ppo.so")
+    good = os.path.join(g.CSRC, "libgo1ppo.so")
     want = g.source_hash(g.ppo_sources(), g.PPO_FLAGS)
-    assert g.library_stamp(path) == want
-    stale = tmp_path / "libstale.so"
-    blob = open(path, "rb").read()
-    stale.write_bytes(blob.replace(g.STAMP + want.encode(), g.STAMP + b"0" * 16))
-    assert g.library_stamp(str(stale)) == "0" * 16 != want
+    assert g.library_stamp(good) == want
+    # a scratch csrc directory: the sources as they are + the library under test
+    csrc = tmp_path / "csrc"
+    csrc.mkdir()
+    for f in g.ppo_sources():
+        if os.path.dirname(f) == g.CSRC:
+            shutil.copy(f, csrc / os.path.basename(f))
+    lib = csrc / "libgo1ppo.so"
+    blob = open(good, "rb").read()
+    lib.write_bytes(blob.replace(g.STAMP + want.encode(), g.STAMP + b"0" * 16))
+    assert g.library_stamp(str(lib)) == "0" * 16 != want
+    calls = []
+
+    def fake_compiler(cmd, cwd=None):
+        calls.append(cmd)
+        out = cmd[cmd.index("-o") + 1]
+        assert ('-DGO1_SOURCE_HASH="%s"' % want) in cmd
+        shutil.copy(good, out)                        # "compiles" the current sources
+
+    patched = [str(csrc / os.path.basename(f)) if os.path.dirname(f) == g.CSRC else f for f in g.ppo_sources()]
+    monkeypatch.setattr(g, "ppo_sources", lambda: patched)
+    monkeypatch.setattr(g, "CSRC", str(csrc))
+    monkeypatch.setattr(subprocess, "check_call", fake_compiler)
+    assert g.source_hash(g.ppo_sources(), g.PPO_FLAGS) == want          # same bytes, same names: same hash
+    g.build_ppo_hip()
+    assert len(calls) == 1 and g.library_stamp(str(lib)) == want         # the stale library was rebuilt ...
+    g.build_ppo_hip()
+    assert len(calls) == 1                                               # ... and an up-to-date one is left alone
+    # the reader: absent / unstamped / two different stamps in one file
     assert g.library_stamp(str(tmp_path / "absent.so")) is None
+    (tmp_path / "unstamped.so").write_bytes(b"xx" + g.STAMP + b"unstamped" + b"yy")
+    assert g.library_stamp(str(tmp_path / "unstamped.so")) is None
+    (tmp_path / "two.so").write_bytes(g.STAMP + b"0" * 16 + b" ... " + g.STAMP + want.encode())
+    assert g.library_stamp(str(tmp_path / "two.so")) is None
+    (tmp_path / "twice_the_same.so").write_bytes(g.STAMP + want.encode() + b" ... " + g.STAMP + want.encode())
+    assert g.library_stamp(str(tmp_path / "twice_the_same.so")) == want
 
 
 def test_struct_sizes_match_oracle_build(oracle_lib):

@@ -10,6 +10,9 @@ bench.time_sim_only (48 warm-up + 240 timed launches, HIP events of the library)
   bench-leg    what bench.py's `rough_trimesh` leg does: 7 live-policy PPO iterations (2 warm-up + 5 timed), THEN the sim-only window
   hot          fresh environment, but the device has just run 20 s of back-to-back bf16 GEMMs (the state bench.py's leg meets: it comes after the
                headline's 223 PPO iterations) — same workload, same contact load: what is left is the device's clock / power state
+  after-flat   the rough environment built in a process that already holds the headline's flat environment + Runner and ran 5 of its PPO
+               iterations (what bench.py's leg meets); `+empty_cache`: the same with torch.cuda.empty_cache() before the rough environment
+               is built (allocator state: are the environment's ~100 SoA arrays carved out of recycled segments?)
 Contact load: the `_sig` twin of the kernel stepped over a copy of the state right after the timed window, 24 steps; per environment and
 substep the listed top-surface points (signature word 0), wall + hip points (word 1; bits 0..12 = wall points), self contacts (word 2).
 """
@@ -70,6 +73,8 @@ def contact_load(env, steps=24):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--regimes", default="fresh,after-flat,after-flat+empty_cache,after-flat+bench-leg,fresh",
+                    help="comma-separated, in order: fresh, aged, bench-leg, hot, after-flat[+empty_cache][+bench-leg]")
     args = ap.parse_args()
     device = "cuda:0"
     from go1_gym_learn.ppo_cse import Runner, RunnerArgs
@@ -78,11 +83,20 @@ def main():
     RunnerArgs.save_video_interval = 0
     print(f"# go1_step_kernel_walls at {args.envs} envs, BASELINE configs[2]; launch ms = HIP events around the launch (go1sim_read_timings), 240 launches")
     print("# regime      launch_ms  sim_only_M/s  listed/env/substep (top + wall + hip + self)   max   resets/step")
-    for regime in ("fresh", "aged", "bench-leg", "fresh", "hot", "fresh"):
+    keep = None
+    for regime in args.regimes.split(","):
         torch.manual_seed(0)
+        if regime.startswith("after-flat") and keep is None:
+            envf, _ = bench.build_env(args.envs, 0, 0)
+            runf = Runner(envf, device=device)
+            envf.episode_length_buf.copy_(torch.randint_like(envf.episode_length_buf, high=int(envf.max_episode_length)))
+            _, odf = bench.time_iterations(runf, envf, envf.get_observations(), 5, warmup=2)
+            keep = (envf, runf, odf)
+        if "empty_cache" in regime:
+            torch.cuda.empty_cache()
         env, _ = bench.build_env(args.envs, 0, 0, rough=True)
         env.episode_length_buf.copy_(torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length)))       # as bench.py main() and its leg do
-        if regime == "bench-leg":
+        if regime.endswith("bench-leg"):
             runner = Runner(env, device=device)
             od = env.get_observations()
             _, od = bench.time_iterations(runner, env, od, 5, warmup=2)
@@ -103,7 +117,7 @@ def main():
         rate, ms = bench.time_sim_only(env, env.env.sim, args.envs, 240, device)
         c = contact_load(env)
         sys.stdout.flush()
-        print(f"  {regime:10s}  {ms:8.4f}  {rate / 1e6:10.2f}     {c['listed']:.2f} ({c['top']:.2f} + {c['wall']:.3f} + {c['hip']:.3f} + {c['self']:.3f})"
+        print(f"  {regime:24s}  {ms:8.4f}  {rate / 1e6:10.2f}     {c['listed']:.2f} ({c['top']:.2f} + {c['wall']:.3f} + {c['hip']:.3f} + {c['self']:.3f})"
               f"            {c['max_listed']:3d}   {c['resets_per_step']:.1f}")
         del env
         torch.cuda.empty_cache()

@@ -200,7 +200,11 @@ __device__ __forceinline__ void block_reduce_atomic(float (&v)[NV], float* const
   if (threadIdx.x < NV) {
     float t = 0.f;
     for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += lds[w * NV + threadIdx.x];
+#if defined(LOSS_ABLATE) && (LOSS_ABLATE & 8)
+    if (dst[threadIdx.x] && t == 12345.678f) *dst[threadIdx.x] = t;      // probe build: the reduction without its atomics
+#else
     if (dst[threadIdx.x]) atomicAdd(dst[threadIdx.x], t);
+#endif
   }
 }
 
@@ -212,21 +216,36 @@ __device__ __forceinline__ void block_reduce_atomic(float (&v)[NV], float* const
 //   branches coincide and torch.max splits the gradient half/half onto two identical paths), else 0
 //   value loss: max((v-R)^2, (v_old + clamp(v - v_old, -eps, eps) - R)^2), same tie rule
 //   entropy = sum log sigma + const (independent of the sample)
-__global__ __launch_bounds__(256) void loss_kernel(Go1PpoLossArgs a) {
-  __shared__ float lds[4 * (4 + 2 * GO1PPO_MAX_ACTIONS)];
+#if defined(LOSS_ABLATE) && (LOSS_ABLATE & 2)
+#define LOSS_LOG(x) __logf(x)
+#define LOSS_EXP(x) __expf(x)
+#else
+#define LOSS_LOG(x) logf(x)
+#define LOSS_EXP(x) expf(x)
+#endif
+#if defined(LOSS_ABLATE) && (LOSS_ABLATE & 4)
+#define LOSS_NO_STORES 1
+#else
+#define LOSS_NO_STORES 0
+#endif
+// one sample: losses and the analytic gradient w.r.t. its head outputs (written to d_mean / d_value); the sample's shares of the sums
+// come back in sur / vl / kl / dvb / dstd[] / dmb[] (zero for a thread past the last row)
+__device__ __forceinline__ void loss_sample(const Go1PpoLossArgs& a, int64_t r, float& sur, float& vl, float& kl, float& dvb,
+                                            float (&dstd)[GO1PPO_MAX_ACTIONS], float (&dmb)[GO1PPO_MAX_ACTIONS]) {
   const int A = a.num_actions;
   const bool vec4 = (A & 3) == 0 && (a.head_ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.actions) | reinterpret_cast<uintptr_t>(a.old_mu) |
                                                               reinterpret_cast<uintptr_t>(a.old_sigma)) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(a.mean) & 7) == 0;
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool on = r < a.rows;
   float invM = 1.f / (float)a.rows;
-  float sur = 0.f, vl = 0.f, kl = 0.f, dvb = 0.f;
-  float dstd[GO1PPO_MAX_ACTIONS], dmb[GO1PPO_MAX_ACTIONS];
+  sur = vl = kl = dvb = 0.f;
 #pragma unroll
   for (int j = 0; j < GO1PPO_MAX_ACTIONS; j++) dstd[j] = dmb[j] = 0.f;
   if (on) {
     int64_t s = a.idx[r];
+#if defined(LOSS_ABLATE) && (LOSS_ABLATE & 1)
+    s = r;                       // probe build (tools/probes/loss_ablate.py): storage rows in order instead of through the permutation
+#endif
     const bf16_t* mrow = reinterpret_cast<const bf16_t*>(a.mean) + r * a.head_ld;
     float mu[GO1PPO_MAX_ACTIONS], z[GO1PPO_MAX_ACTIONS], isg[GO1PPO_MAX_ACTIONS];
     float act[GO1PPO_MAX_ACTIONS], omu[GO1PPO_MAX_ACTIONS], osg[GO1PPO_MAX_ACTIONS];
@@ -260,13 +279,13 @@ __global__ __launch_bounds__(256) void loss_kernel(Go1PpoLossArgs a) {
         float sg = a.std[j];
         isg[j] = 1.f / sg;
         z[j] = (act[j] - mu[j]) * isg[j];
-        logp += -0.5f * z[j] * z[j] - logf(sg) - HALF_LOG_2PI;
+        logp += -0.5f * z[j] * z[j] - LOSS_LOG(sg) - HALF_LOG_2PI;
         float so = osg[j], dm = omu[j] - mu[j];
-        kl += logf(sg / so + 1.e-5f) + (so * so + dm * dm) / (2.f * sg * sg) - 0.5f;
+        kl += LOSS_LOG(sg / so + 1.e-5f) + (so * so + dm * dm) / (2.f * sg * sg) - 0.5f;
       }
     }
     float adv = a.advantages[s];
-    float ratio = expf(logp - a.old_logp[s]);
+    float ratio = LOSS_EXP(logp - a.old_logp[s]);
     float lo = 1.f - a.clip_param, hi = 1.f + a.clip_param;
     float rc = fminf(fmaxf(ratio, lo), hi);
     float s1 = -adv * ratio, s2 = -adv * rc;
@@ -274,13 +293,28 @@ __global__ __launch_bounds__(256) void loss_kernel(Go1PpoLossArgs a) {
     float dratio = (ratio >= lo && ratio <= hi) ? -adv : (s1 > s2 ? -adv : 0.f);
     float dlogp = dratio * ratio * invM;
     bf16_t* drow = reinterpret_cast<bf16_t*>(a.d_mean) + r * a.head_ld;
+    const bool st4 = vec4 && (reinterpret_cast<uintptr_t>(a.d_mean) & 7) == 0;      // four gradients per 8-byte store (12 two-byte stores per
+                                                                                    // sample were 2.6-4.9 us of the kernel: r06_loss_kernel_ablation.txt)
 #pragma unroll
-    for (int j = 0; j < GO1PPO_MAX_ACTIONS; j++) {
-      if (j < A) {
-        bf16_t g = f2bf(dlogp * z[j] * isg[j]);
-        drow[j] = g;
-        dmb[j] = bf2f(g);
-        dstd[j] = dlogp * (z[j] * z[j] - 1.f) * isg[j];
+    for (int j0 = 0; j0 < GO1PPO_MAX_ACTIONS; j0 += 4) {
+      if (j0 < A) {
+        bf16_t gq[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int j = j0 + q;
+          if (j < A) {
+            gq[q] = f2bf(dlogp * z[j] * isg[j]);
+            if (!LOSS_NO_STORES && !st4) drow[j] = gq[q];
+            dmb[j] = bf2f(gq[q]);
+            dstd[j] = dlogp * (z[j] * z[j] - 1.f) * isg[j];
+          }
+        }
+        if (!LOSS_NO_STORES && st4) {
+          uint2 o;
+          o.x = (uint32_t)gq[0] | ((uint32_t)gq[1] << 16);
+          o.y = (uint32_t)gq[2] | ((uint32_t)gq[3] << 16);
+          *reinterpret_cast<uint2*>(drow + j0) = o;
+        }
       }
     }
     float v = bf2f(reinterpret_cast<const bf16_t*>(a.value)[r * a.head_ld]);
@@ -298,10 +332,18 @@ __global__ __launch_bounds__(256) void loss_kernel(Go1PpoLossArgs a) {
       dv = 2.f * (v - R);
     }
     bf16_t g = f2bf(a.value_loss_coef * dv * invM);
-    reinterpret_cast<bf16_t*>(a.d_value)[r * a.head_ld] = g;
+    if (!LOSS_NO_STORES) reinterpret_cast<bf16_t*>(a.d_value)[r * a.head_ld] = g;
     dvb = bf2f(g);
     kl *= invM;
   }
+}
+
+__global__ __launch_bounds__(256) void loss_kernel(Go1PpoLossArgs a) {
+  __shared__ float lds[4 * (4 + 2 * GO1PPO_MAX_ACTIONS)];
+  const int A = a.num_actions;
+  float sur, vl, kl, dvb;
+  float dstd[GO1PPO_MAX_ACTIONS], dmb[GO1PPO_MAX_ACTIONS];
+  loss_sample(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, sur, vl, kl, dvb, dstd, dmb);
   // reductions: [sur, vl, kl, dvb] then dstd[A], dmb[A]
   {
     float v4[4] = {sur, vl, kl, dvb};
@@ -1023,10 +1065,11 @@ extern "C" int go1ppo_loss(const Go1PpoLossArgs* a, void* stream) {
   if (!a || a->rows <= 0 || a->num_actions <= 0 || a->num_actions > GO1PPO_MAX_ACTIONS || a->head_ld < a->num_actions) return -1;
   // (measured: 64-thread workgroups — 384 instead of 96 — are slower, 33 vs 26 us: four times the atomics on the same 28 words)
   // (one wavefront per workgroup — 384 workgroups instead of 96 — measured 32 us against 22: four times the same-address atomics of the reductions)
+  // (measured, round 6 — profiles/r06_loss_kernel_ablation.txt: the same-address atomics are 1 us of the kernel's 16-22; meeting the sums through
+  //  per-workgroup rows and a last-workgroup ticket instead took 45 us: the device-scope fences in front of the ticket write the XCD's L2 back)
   loss_kernel<<<dim3((unsigned)((a->rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(*a);
   return hipGetLastError() == hipSuccess ? 0 : -9;
 }
-
 extern "C" int go1ppo_mse(const void* pred, int pred_ld, const float* target, int npv, const int64_t* idx, int64_t rows,
                           int64_t num_train, int selective, void* d_pred, float* d_pred_bias, float* train_loss,
                           float* test_loss, void* stream) {

@@ -180,6 +180,7 @@ class PPO:
         # when it applies and libgo1ppo.so is missing, load_library() raises.
         self.fused = bool(self.bf16 and PPO_Args.use_fused_kernels and self.policy.act is torch.nn.ELU)
         self._roll_net = self._train_net = None
+        self._roll_noise = None           # (T, N, actions) sampling noise of the current rollout (fused path)
         self._opt = self._opt_ad = None
         if self.on_gpu and PPO_Args.use_tuned_gemms:
             _enable_tuned_gemms()
@@ -350,7 +351,13 @@ class PPO:
             raise AssertionError("Rollout buffer overflow")
         with torch.no_grad():
             mean, value, _ = self._roll_net.forward(slot)
-            noise = torch.randn(slot.shape[0], self.n_std, device=slot.device)
+            # the sampling noise of a whole rollout as ONE generator launch at its first step (24 launches of 5 us each sat on the
+            # rollout's critical path, profiles/r05b_rollout_step_timeline.txt): N(0, 1) draws either way; the fp32 / CPU path above keeps
+            # torch.randn_like per step, which is what the reference-fixture tests pin
+            T = st.num_transitions_per_env
+            if s == 0 or self._roll_noise is None or tuple(self._roll_noise.shape) != (T, slot.shape[0], self.n_std):
+                self._roll_noise = torch.randn(T, slot.shape[0], self.n_std, device=slot.device)
+            noise = self._roll_noise[s]
             fused.act(self._fused_lib, mean, value, self.std, noise, st, s)
         t.actions, t.values, t.actions_log_prob = st.actions[s], st.values[s], st.actions_log_prob[s]
         t.action_mean, t.action_sigma = st.mu[s], st.sigma[s]
@@ -610,23 +617,31 @@ class PPO:
         graphs = []
         if self.dp and PPO_Args.dp_graph_collectives and PPO_Args.num_adaptation_module_substeps == 1 and self._collectives_capturable is not False \
                 and dist.get_backend() == "nccl":          # (RCCL records into a capturing stream; gloo stages through the host and cannot)
-            # the whole mini-batch — stages AND collectives — as one graph.  Tried once: a backend that cannot record its
-            # collectives (gloo in the CPU dry runs; an RCCL build without capture support) raises here and the scheme below takes over
+            # the whole mini-batch — stages AND collectives — as one graph.  A backend that cannot record its collectives (an RCCL build
+            # without capture support) raises here and the scheme below takes over
+            g, err = None, None
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._minibatch_eager(idx)
+            except Exception as e:          # a failed plan-table copy or an out-of-memory during capture ends up here too: logged in full below
+                g, err = None, e
+            # every rank takes the SAME scheme: one rank replaying a graph with the collectives inside while another issues them eagerly
+            # between three graphs would pair different collectives.  The outcome is agreed on here, outside any capture (MIN over the
+            # ranks' success flags); a rank whose own capture succeeded discards it when another rank's did not.
+            ok = torch.tensor([0 if g is None else 1], device=self.device, dtype=torch.int64)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
                 self._collectives_capturable = True
                 return [g]
-            except Exception as err:
-                # every rank takes the SAME scheme: the outcome is agreed on below.  The full error is logged once per rank — a failed plan-table
-                # copy or an out-of-memory during capture ends up here too and must not hide behind "not capturable"
-                if self._collectives_capturable is None:
-                    print(f"[ppo] rank {dist.get_rank()}: one-graph capture of stages + collectives failed ({type(err).__name__}: {err}); "
-                          f"eager collectives between graphs", file=sys.stderr)
-                self._collectives_capturable = False
-                torch.cuda.synchronize()
-                self.master.grad.zero_()
+            if self._collectives_capturable is not False:
+                why = f"{type(err).__name__}: {err}" if err is not None else "another rank's capture failed"
+                print(f"[ppo] rank {dist.get_rank()}: one-graph capture of stages + collectives not taken ({why}); "
+                      f"eager collectives between graphs on every rank", file=sys.stderr)
+            self._collectives_capturable = False
+            del g
+            torch.cuda.synchronize()
+            self.master.grad.zero_()
 
         def rec(fn):
             nonlocal pool
