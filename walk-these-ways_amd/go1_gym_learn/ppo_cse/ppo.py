@@ -181,6 +181,7 @@ class PPO:
         self.fused = bool(self.bf16 and PPO_Args.use_fused_kernels and self.policy.act is torch.nn.ELU)
         self._roll_net = self._train_net = None
         self._roll_noise = None           # (T, N, actions) sampling noise of the current rollout (fused path)
+        self._update_graph_ok = True      # cleared when the whole-update graph could not be captured (update())
         self._opt = self._opt_ad = None
         if self.on_gpu and PPO_Args.use_tuned_gemms:
             _enable_tuned_gemms()
@@ -713,6 +714,31 @@ class PPO:
         if self._pregathered:
             for i in range(nmb):
                 self._gather_rows(self._idx_all[i], self._Xall[i])
+        # single process, fused update: ALL epochs x mini-batches of the update as ONE graph (round 6: every replay of a per-mini-batch graph
+        # cost 9 us of idle device in front of its first kernel — 20 replays per update, profiles/r05b_minibatch_timeline.txt).  The mini-batch
+        # index sets, their pre-gathered row blocks and every buffer the stages touch are static, so the 20 steps record back to back.
+        # GO1_UPDATE_GRAPH=slot: one graph per mini-batch slot, replayed once per epoch (the scheme data-parallel runs keep).
+        if graph_mode and self.fused and not self.dp and self._update_graph_ok and os.environ.get("GO1_UPDATE_GRAPH", "all") == "all":
+            key_all = ("all", int(A.num_learning_epochs))
+            g = self._graphs.get(key_all)
+            if g is None:
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        for epoch in range(A.num_learning_epochs):
+                            for i in range(nmb):
+                                self._train_net.X = self._Xall[i]
+                                self._minibatch_eager(self._idx_all[i])
+                    self._graphs[key_all] = g
+                except Exception as err:          # an optimisation: the per-slot graphs below take over
+                    print(f"[ppo] whole-update graph capture failed ({type(err).__name__}: {err}); one graph per mini-batch slot", file=sys.stderr)
+                    self._update_graph_ok, g = False, None
+                    torch.cuda.synchronize()
+                    self.master.grad.zero_()
+                    self._acc.zero_()
+            if g is not None:
+                g.replay()
+                return self._finish_update()
         for epoch in range(A.num_learning_epochs):
             for i in range(nmb):
                 idx = self._idx_all[i]
@@ -738,6 +764,10 @@ class PPO:
                     self._minibatch_replay(i)
                 else:
                     self._minibatch_eager(idx)
+        return self._finish_update()
+
+    def _finish_update(self):
+        A = PPO_Args
         self._updates_done += 1
         num_updates = A.num_learning_epochs * A.num_mini_batches
         v, s, a, at = (self._acc / num_updates).tolist()         # the only host read of the update
