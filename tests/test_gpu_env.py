@@ -257,7 +257,7 @@ def test_unchanged_train_script_configuration_clears_one_million_env_steps_per_s
 
 def test_rough_terrain_training_survives_once_the_flat_ground_assumptions_are_lifted():
     """BASELINE configs[2] (terrain-curriculum tile grid as a `trimesh` terrain + 187-point height scan) under scripts/train.py's reward
-    set does not learn — in the reference either, for three reasons that are the REFERENCE's, not the simulator's (DESIGN.md section 9,
+    set does not learn — in the reference either, for three reasons that are the REFERENCE's, not the simulator's (docs/DESIGN_round5.md section 9,
     profiles/r04_rough_train_sanity.txt): tiles spawn at their rim height (terrain.py:177), the foot-clearance / jump / contact-velocity
     terms read world z (corl_rewards.py:129 `# - reference_heights`), and reward = positive x exp(negative / 0.02) is identically 0
     while robots still fall.  With the three lifted by flagged, non-default switches (centre-patch spawn, heights above the terrain,
