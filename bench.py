@@ -199,6 +199,38 @@ def time_iterations(runner, env, obs_dict, iters, rollout_only=False, warmup=2):
     return env.num_envs * T * iters / (time.perf_counter() - t0), obs_dict
 
 
+def listed_contacts(env, steps=12):
+    """mean number of contacts the solver lists per environment and substep (top-surface / wall / hip points, self contacts): the `_sig` twin of
+    the step kernel stepped over a COPY of the environment's state under N(0, 1) actions (include/go1sim.h GO1_SIG_WORDS) — the contact load the
+    launch times of a leg were measured under.  The environment itself is not touched."""
+    import go1sim_abi as abi
+    import go1sim_host as H
+    inner = env.env
+    Bt = inner.buffers.clone_to(inner.buffers.device)
+    Bt.enable_contact_signature()
+    sim = H.Go1Sim(inner.sim_config, Bt, inner.sim_device_id)
+    if inner.sim_config_eval is not None:
+        sim.set_eval_config(inner.sim_config_eval, inner.num_train_envs)
+    sim.set_counters(*inner.sim.counters())
+    n = Bt.root_states.shape[1]
+
+    def pop(t):
+        t = t.to(torch.int64) & 0xFFFFFFFF
+        return sum(((t >> b) & 1) for b in range(32)).float().mean().item()
+    acc = {"top": 0.0, "wall": 0.0, "hip": 0.0, "self": 0.0}
+    for _ in range(steps):
+        sim.step(torch.randn(n, 12, device=Bt.device))
+        sig = Bt.contact_signature.view(abi.GO1_SIG_MAX_SUBSTEPS, abi.GO1_SIG_WORDS, n)
+        w2 = sig[:, 2].to(torch.int64) & 0xFFFFFFFF
+        acc["top"] += pop(sig[:, 0])
+        acc["wall"] += pop(sig[:, 1] & 0x1FFF)
+        acc["hip"] += pop(sig[:, 1] & ~0x1FFF)
+        acc["self"] += sum((((w2 >> (3 * p)) & 7) != 0).float().mean().item() for p in range(6)) + pop((w2 >> 18) & 0xF)
+    out = {k: v / steps for k, v in acc.items()}
+    out["listed"] = sum(out.values())
+    return out
+
+
 MFMA_PEAK_BF16_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 2:1-sparsity headline figure is never used)
 
 
@@ -308,11 +340,22 @@ def extra_records(args, env, runner, obs_dict, device):
         roof3 = update_roofline(runner3, env3, od3)
         so, ms = time_sim_only(env3, env3.env.sim, args.envs, 240, device)
         f3 = env3.env.extras["sim_faults"].consume()
+        load3 = listed_contacts(env3)
+        # the same kernel on a FRESH environment of the same configuration, in this process (reset distribution, no policy iterations before):
+        # the regime of `bench.py --sim-only --rough` (profiles/r06_walls_regimes.txt reconciles the two)
+        env3b, _ = build_env(args.envs, 0, args.seed, rough=True)
+        env3b.episode_length_buf.copy_(torch.randint_like(env3b.episode_length_buf, high=int(env3b.max_episode_length)))
+        so_fresh, ms_fresh = time_sim_only(env3b, env3b.env.sim, args.envs, 240, device)
+        load3b = listed_contacts(env3b)
+        del env3b
         out["rough_trimesh"] = {"workload": "BASELINE configs[2]: terrain-curriculum tile grid (slopes, rough slopes, stairs up / down, discrete "
                                             "obstacles) as a `trimesh` terrain — int16 height field with vertical faces where the slope exceeds "
                                             "slope_treshold 0.75 —, 187-point height scan in the observation (257 wide, history 7710), 4096 envs",
                                 "sim_ppo_env_steps_s": full, "sim_only_env_steps_s": so, "step_kernel_launch_ms": ms,
                                 "wall_instance": bool(env3.env.sim_config.hf_wall_units > 0),
+                                "listed_contacts_per_env_and_substep": load3,
+                                "fresh_env_same_process": {"sim_only_env_steps_s": so_fresh, "step_kernel_launch_ms": ms_fresh,
+                                                           "listed_contacts_per_env_and_substep": load3b},
                                 "roofline": roof3,
                                 "guard_activations": {k: v for k, v in f3.items() if v},
                                 "note": "sim+PPO: 5 timed PPO iterations (live policy), first-layer GEMM selections for the 7744-wide history from the "

@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--zero-actions", action="store_true", help="robots standing on four feet instead of N(0,1) actions")
     ap.add_argument("--rough", action="store_true", help="BASELINE configs[2]: the terrain-curriculum tile grid as a trimesh terrain + height scan "
                                                          "(go1_step_kernel_walls; the markers of workgroup 0 and the per-workgroup statistics)")
+    ap.add_argument("--aged", default=None, choices=["inphase", "dephased"],
+                    help="with --rough: first the 7 live-policy PPO iterations of bench.py's rough_trimesh leg — `dephased`: episode lengths spread over the "
+                         "horizon AFTER the Runner's reset, as bench.py has them; `inphase`: all episodes started together (profiles/r06_walls_regimes.txt)")
     args, extra = ap.parse_known_args()
     if args.lib is None:
         build(["-DGO1_PROFILE"] + extra)
@@ -59,6 +62,15 @@ def main():
             wrapped, cfg = build_env(args.envs, 0, 0, rough=True)
             env = wrapped.env if hasattr(wrapped, "env") else wrapped
             env.reset()
+            if args.aged:
+                import bench
+                from go1_gym_learn.ppo_cse import Runner, RunnerArgs
+                from go1_gym_learn.ppo_cse.ppo import PPO_Args
+                PPO_Args.autocast_bf16, RunnerArgs.save_video_interval = True, 0
+                runner = Runner(wrapped, device="cuda:0")
+                if args.aged == "dephased":
+                    wrapped.episode_length_buf.copy_(torch.randint_like(wrapped.episode_length_buf, high=int(wrapped.max_episode_length)))
+                bench.time_iterations(runner, wrapped, wrapped.get_observations(), 5, warmup=2)
         else:
             cfg = apply_train_config(make_cfg(), num_envs=args.envs)
             env = VelocityTrackingEasyEnv(sim_device="cuda:0", headless=True, cfg=cfg)

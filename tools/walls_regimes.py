@@ -10,6 +10,8 @@ bench.time_sim_only (48 warm-up + 240 timed launches, HIP events of the library)
   bench-leg    what bench.py's `rough_trimesh` leg does: 7 live-policy PPO iterations (2 warm-up + 5 timed), THEN the sim-only window
   hot          fresh environment, but the device has just run 20 s of back-to-back bf16 GEMMs (the state bench.py's leg meets: it comes after the
                headline's 223 PPO iterations) — same workload, same contact load: what is left is the device's clock / power state
+  +churn       (with after-flat) three more flat environments + Runners built, run for 3 iterations and dropped first: the allocator's free lists
+               as bench.py's rough_trimesh leg meets them (after `dropin_default`)
   after-flat   the rough environment built in a process that already holds the headline's flat environment + Runner and ran 5 of its PPO
                iterations (what bench.py's leg meets); `+empty_cache`: the same with torch.cuda.empty_cache() before the rough environment
                is built (allocator state: are the environment's ~100 SoA arrays carved out of recycled segments?)
@@ -92,12 +94,21 @@ def main():
             envf.episode_length_buf.copy_(torch.randint_like(envf.episode_length_buf, high=int(envf.max_episode_length)))
             _, odf = bench.time_iterations(runf, envf, envf.get_observations(), 5, warmup=2)
             keep = (envf, runf, odf)
+        if "churn" in regime:             # what bench.py's later legs meet: other environments + Runners were built, run and dropped before
+            for _ in range(3):
+                e2, _ = bench.build_env(args.envs, 0, 0)
+                r2 = Runner(e2, device=device)
+                e2.episode_length_buf.copy_(torch.randint_like(e2.episode_length_buf, high=int(e2.max_episode_length)))
+                bench.time_iterations(r2, e2, e2.get_observations(), 2, warmup=1)
+                del e2, r2
         if "empty_cache" in regime:
             torch.cuda.empty_cache()
         env, _ = bench.build_env(args.envs, 0, 0, rough=True)
         env.episode_length_buf.copy_(torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length)))       # as bench.py main() and its leg do
-        if regime.endswith("bench-leg"):
-            runner = Runner(env, device=device)
+        if regime.endswith("bench-leg") or regime.endswith("bench-leg-dephased"):
+            runner = Runner(env, device=device)          # (Runner.__init__ resets the environment: the episode lengths are back at 0 ...)
+            if regime.endswith("dephased"):              # (... unless they are spread again AFTER it, which is the order bench.py's leg has)
+                env.episode_length_buf.copy_(torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length)))
             od = env.get_observations()
             _, od = bench.time_iterations(runner, env, od, 5, warmup=2)
         elif regime == "hot":
