@@ -9,6 +9,6 @@ mkdir -p "$OUT" && cd "$OUT"
 S=go1sim-hip-amdgcn-amd-amdhsa-gfx950.s
 for k in go1_step_kernel go1_aux_kernel; do
   echo "== $k"
-  grep -A14 "name:           $k" $S | grep -E "vgpr_count|sgpr_count|spill_count|private_segment_fixed_size|group_segment_fixed_size" | sed 's/^ */  /'
+  grep -B8 -A14 "name:           $k" $S | grep -E "vgpr_count|sgpr_count|spill_count|private_segment_fixed_size|group_segment_fixed_size" | sed 's/^ */  /'
   awk "/^$k:/,/s_endpgm/" $S | grep -cE "^\s+(v_|s_|ds_|global_|scratch_|buffer_)" | sed 's/^/  static instructions: /'
 done
