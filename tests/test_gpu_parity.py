@@ -828,7 +828,7 @@ def test_full_step_on_height_field(walls):
 # configs[4]'s per-GPU size — 8192 environments = 512 workgroups on 256 CUs: the only regime in which a workgroup starts on a CU whose LDS the
 # previous one just left (step_body zero-fills `lds` / `ldsx`) — and the second seed / second relief that used to sit behind GO1_PARITY_ALT=1
 PRODUCT_CASES = [("plane", 4096, 40, False), ("hf", 4096, 40, False), ("walls", 4096, 40, False),
-                 ("plane", 8192, 10, False), ("walls", 8192, 10, False),
+                 ("plane", 8192, 10, False), ("hf", 8192, 10, False), ("walls", 8192, 10, False),
                  ("plane", 4096, 40, True), ("hf", 4096, 40, True), ("walls", 4096, 40, True)]
 
 
